@@ -1,0 +1,166 @@
+/*
+ * raglite_hip.h -- C ABI of libraglite_hip.so: the MI355X (gfx950) retrieval / rerank hot path
+ * of RAGLite.  Plain pointers and sizes only; no torch / C++ types cross this boundary.
+ *
+ * The reference (superlinear-ai/raglite v1.0.0) is pure Python and has no FFI of its own; each
+ * entry point below states the reference lines (relative to /root/reference) whose arithmetic
+ * it replaces.  INTEGRATION.md shows the ctypes binding a RAGLite maintainer would add.
+ *
+ * Conventions
+ *  - every function returns 0 (RL_OK) or a negative rl_status; rl_last_error() gives the
+ *    thread-local message of the last failure on the calling thread.
+ *  - `mem` says where the caller's data pointers live: RL_MEM_HOST (the library stages through
+ *    its own device scratch, synchronously) or RL_MEM_DEVICE (pointers are HIP device pointers,
+ *    work is enqueued on `stream` and NOT synchronised -- the caller owns ordering).
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *  - all matrices are row-major and dense; dim is the embedding dimension.
+ *  - thread safety: calls on distinct rl_index handles / distinct streams may run concurrently;
+ *    calls on one handle serialise on an internal mutex (the reference calls the path from up to
+ *    4 worker threads: src/raglite/_insert.py:159,208-237; src/raglite/_rag.py:317-318).
+ */
+#ifndef RAGLITE_HIP_H
+#define RAGLITE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    RL_OK = 0,
+    RL_ERR_INVALID = -1,     /* bad argument (maps to Python ValueError) */
+    RL_ERR_HIP = -2,         /* HIP runtime failure (RuntimeError) */
+    RL_ERR_UNSUPPORTED = -3, /* shape outside what the kernels implement (ValueError) */
+    RL_ERR_NOMEM = -4        /* device allocation failed (MemoryError) */
+} rl_status;
+
+typedef enum { RL_MEM_HOST = 0, RL_MEM_DEVICE = 1 } rl_mem;
+typedef enum { RL_F32 = 0, RL_F16 = 1 } rl_dtype;
+/* src/raglite/_config.py:69 `vector_search_distance_metric`; src/raglite/_typing.py:123-134 */
+typedef enum { RL_COSINE = 0, RL_DOT = 1, RL_L2 = 2 } rl_metric;
+typedef enum { RL_SYNTH_UNIFORM = 0, RL_SYNTH_SMALL_INT = 1 } rl_synth_kind;
+
+typedef struct rl_index rl_index; /* opaque device-resident index (corpus matrix + chunk CSR) */
+
+/* ---- runtime ------------------------------------------------------------------------------ */
+int rl_version(void);
+const char* rl_last_error(void);
+/* Select the HIP device for the calling thread; fails if it is not a gfx950 part. */
+int rl_init(int device);
+int rl_device_count(int* count);
+/* name[<=len], number of CUs, bytes of device memory */
+int rl_device_info(int device, char* name, int len, int* compute_units, int64_t* total_mem);
+
+/* Device memory helpers so that a pure-ctypes caller needs no other GPU library. */
+int rl_dev_alloc(void** ptr, size_t bytes);
+int rl_dev_free(void* ptr);
+int rl_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream);
+int rl_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream);
+int rl_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+int rl_stream_sync(void* stream);
+
+/* Counter-based synthetic data, bit-identical to oracle/oracle.py:synth_uniform / synth_small_int:
+ * element i (i in [start, start+count)) of stream `seed`.  dst is a DEVICE pointer. */
+int rl_synth_fill(float* dst, int64_t start, int64_t count, uint64_t seed, int kind, void* stream);
+
+/* ---- a1 + a2 + a3: late-chunking pool, L2 normalise, fp16 cast ------------------------------
+ * Replaces src/raglite/_embed.py:131-140 (per-sentence np.mean over contiguous token rows,
+ * rowwise X /= ||X||, astype(float16)) and :154,158-164 (whole-string mean, eps-guarded
+ * normalise).  The host computes the row spans (largest-remainder split, :122-129) and passes
+ * them in; span s pools token rows [span_begin[s], span_end[s]).
+ *   tokens      [T x dim] f32
+ *   normalize   0/1            (RAGLiteConfig.embedder_normalize)
+ *   eps         0  -> unguarded divide (:139);  >0 -> divide by max(norm, eps) (:160-163)
+ *   out_f32     [S x dim] f32 or NULL;  out_f16 [S x dim] IEEE half bits or NULL
+ * Accumulation is fp64 (the reference pools float64 arrays), the cast rounds to nearest even.
+ * An empty span produces NaN, as np.mean of zero rows does. */
+int rl_pool_norm(const float* tokens, int64_t n_token_rows, int32_t dim,
+                 const int64_t* span_begin, const int64_t* span_end, int64_t n_spans,
+                 int32_t normalize, double eps, float* out_f32, uint16_t* out_f16,
+                 int mem, void* stream);
+
+/* ---- a5: query adapter -----------------------------------------------------------------------
+ * Replaces src/raglite/_search.py:62  `(Q @ q).astype(q.dtype)`; out[b] = A @ q[b].
+ *   A [dim x dim] f32, queries [B x dim] f32, out_f32 [B x dim] or NULL, out_f16 or NULL. */
+int rl_adapter_apply(const float* A, const float* queries, int32_t n_queries, int32_t dim,
+                     float* out_f32, uint16_t* out_f16, int mem, void* stream);
+
+/* ---- index lifecycle -------------------------------------------------------------------------
+ * The device-resident equivalent of the `chunk_embedding` table (src/raglite/_database.py:403-430):
+ * one row per chunklet vector, rows of a chunk contiguous (a4: src/raglite/_split_chunks.py:116-122,
+ * src/raglite/_insert.py:114-123).
+ *   embeddings     [n_rows x dim] f32; with mem == RL_MEM_DEVICE the pointer is BORROWED (must
+ *                  outlive the index), with RL_MEM_HOST it is copied to the device.
+ *   chunk_offsets  [n_chunks + 1] int64 ascending CSR, chunk_offsets[0]==0, [n_chunks]==n_rows
+ *                  (always a HOST pointer); NULL -> every row is its own chunk.
+ *   metric         rl_metric used by rl_search_rows / rl_search_chunks.
+ * Precomputes 1/||e|| per row (cosine) or ||e||^2 (l2): 4 B/row extra. */
+int rl_index_create(rl_index** out, const float* embeddings, int64_t n_rows, int32_t dim,
+                    const int64_t* chunk_offsets, int64_t n_chunks, int metric, int mem, void* stream);
+int rl_index_destroy(rl_index* index);
+int rl_index_info(const rl_index* index, int64_t* n_rows, int32_t* dim, int64_t* n_chunks, int* metric);
+
+/* ---- a6 + a7: similarity + exact row top-k ----------------------------------------------------
+ * Replaces the SQL at src/raglite/_search.py:69-79 (`sim = 1 - dist`, ORDER BY dist LIMIT k) with
+ * dist per src/raglite/_typing.py:123-134, ranked EXACTLY (the reference's HNSW is approximate).
+ *   queries [B x dim] f32;  k <= 2048
+ *   out_scores [B x k] f32 (sim, descending), out_rows [B x k] int32 (row ordinals; ties ->
+ *   lowest row); when k > n_rows the tail is filled with score -inf / row -1. */
+int rl_search_rows(rl_index* index, const float* queries, int32_t n_queries, int32_t k,
+                   float* out_scores, int32_t* out_rows, int mem, void* stream);
+
+/* ---- a6 + a7 + a8: the reference's two-stage semantics ------------------------------------------
+ * top-`num_hits` rows -> max(sim) GROUP BY chunk -> top-`k` chunks (src/raglite/_search.py:66-67,
+ * 75-79,143-149).  out_counts[b] (<= k) chunks are valid per query; the rest is -inf / -1. */
+int rl_search_chunks(rl_index* index, const float* queries, int32_t n_queries, int32_t num_hits,
+                     int32_t k, float* out_scores, int32_t* out_chunks, int32_t* out_counts,
+                     int mem, void* stream);
+
+/* ---- a9: MaxSim late interaction ----------------------------------------------------------------
+ * score[c] = sum_{i<nq} max_{j in chunk c} Q[i].D[j]  -- the multi-query-vector generalisation of
+ * src/raglite/_search.py:143-149 / src/raglite/_query_adapter.py:174, offered behind the reranker
+ * plugin boundary (src/raglite/_search.py:394-396).  Dot-product similarity (ColBERT convention:
+ * rows are pre-normalised), independent of the index metric.
+ *
+ * rl_maxsim_topk: one query (nq vectors) against EVERY chunk of the index, exact top-k chunks.
+ *   out_scores [k] f32 descending, out_chunks [k] int32 (ties -> lowest chunk ordinal).
+ * rl_maxsim_scores: the same scores, all chunks, no selection: out_scores [n_chunks]. */
+int rl_maxsim_topk(rl_index* index, const float* query_vecs, int32_t nq, int32_t k,
+                   float* out_scores, int32_t* out_chunks, int mem, void* stream);
+int rl_maxsim_scores(rl_index* index, const float* query_vecs, int32_t nq, float* out_scores,
+                     int mem, void* stream);
+
+/* rl_maxsim_rerank: the rerank shape (SURVEY.md cfg 3).  `n_queries` independent queries in one
+ * launch, each with its own nq query vectors and its own list of n_cand candidate chunk ordinals.
+ *   query_vecs [n_queries x nq x dim] f32, candidates [n_queries x n_cand] int32
+ *   out_scores [n_queries x n_cand] f32 in candidate order (the caller sorts: the reference
+ *   reorders by `result.doc_id`, src/raglite/_search.py:396). */
+int rl_maxsim_rerank(rl_index* index, const float* query_vecs, int32_t n_queries, int32_t nq,
+                     const int32_t* candidates, int32_t n_cand, float* out_scores, int mem, void* stream);
+
+/* ---- section 8e: shard merge --------------------------------------------------------------------
+ * Merge `n_lists` per-shard top-k lists per query (as produced by an all-gather of each rank's
+ * rl_search_rows / rl_maxsim_topk output with GLOBAL ids) into the global top-k by
+ * (score desc, id asc).  in_* are [n_lists x n_queries x k_in]; out_* are [n_queries x k]. */
+int rl_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_lists, int32_t n_queries,
+                  int32_t k_in, int32_t k, float* out_scores, int32_t* out_ids, int mem, void* stream);
+
+/* Generic exact top-k over a dense score matrix [n_queries x n] (row stride ld), the selection
+ * stage used by every search above; exposed for tests and for callers that score elsewhere. */
+int rl_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32_t k,
+            float* out_scores, int32_t* out_ids, int mem, void* stream);
+
+/* Timing hook for bench.py: run `fn`-independent -- records the elapsed milliseconds between two
+ * events on `stream` bracketing `iters` back-to-back launches of the named kernel path with the
+ * given index / query.  kind: 0 = rl_maxsim_scores kernel only, 1 = rl_search_rows scan kernel
+ * only (no selection).  Used so that roofline.achieved is measured with HIP events on the stream
+ * the kernel runs on. */
+int rl_time_kernel(rl_index* index, int kind, const float* query_vecs_dev, int32_t nq, int32_t iters,
+                   float* out_ms_total, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RAGLITE_HIP_H */

@@ -1,0 +1,356 @@
+"""CPU oracle for the RAGLite retrieval/rerank hot path -- TEST INFRASTRUCTURE ONLY.
+
+This module is a NumPy restatement of the arithmetic the reference
+(superlinear-ai/raglite v1.0.0, mounted at /root/reference when authoring) performs on
+the path pool -> L2-normalise -> fp16 cast -> query-adapter matvec -> distance ->
+row top-k -> per-chunk max -> chunk top-k, plus the multi-query MaxSim generalisation and
+the shard merge.  Every function cites the reference file:line it follows.
+
+Who may import this: `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline`
+leg.  Nothing under `raglite_amd/` imports it; the product path has no CPU fallback.
+
+Parity pinning status
+---------------------
+* pool / normalise / cast (rows a1-a3 of SURVEY.md section 8): PINNED.  The reference's own
+  `_embed.py` is executed in the authoring container by `oracle/make_golden.py` (third-party
+  imports stubbed, a deterministic fake llama embedder supplying token embeddings) and its
+  outputs are committed under `tests/golden/`; `tests/test_oracle_golden.py` checks this
+  module against them bit-for-bit.
+* adapter / distance / two-stage selection (rows a5-a8): PARITY UNPINNED.  The reference
+  evaluates these inside DuckDB (`array_cosine_distance` + usearch HNSW, approximate) or
+  pgvector; neither engine nor any golden vector is available.  The
+  restatement follows the SQL the reference emits (`_search.py:66-79,143-149`) with exact
+  (brute-force) ranking; ties, which SQL leaves unspecified, resolve to the lowest row id /
+  lowest chunk ordinal.
+* MaxSim with several query vectors (row a9): new functionality behind the reference's
+  reranker plugin; defined here as the multi-query generalisation of `_search.py:143-149` /
+  `_query_adapter.py:174` and reduces to it for nq == 1 (tested).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+# ----------------------------------------------------------------------------------------
+# Deterministic synthetic data (shared bit-for-bit with raglite_amd/csrc/synth.hip)
+# ----------------------------------------------------------------------------------------
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    """SplitMix64 finaliser on uint64 arrays (wrapping arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        x = ((x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        x = ((x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        x = x ^ (x >> np.uint64(31))
+    return x
+
+
+def synth_bits(seed: int, start: int, count: int) -> np.ndarray:
+    """64 hash bits for elements [start, start+count) of stream `seed`."""
+    idx = np.arange(start, start + count, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        key = (np.uint64(seed) * np.uint64(0xD1342543DE82EF95)) & _M64
+        return _splitmix64(idx ^ _splitmix64(np.full(1, key, dtype=np.uint64))[0])
+
+
+def synth_uniform(seed: int, start: int, count: int) -> np.ndarray:
+    """float32 uniform in [-1, 1): the top 24 hash bits u -> u * 2^-23 - 1 (exact in fp32)."""
+    u = (synth_bits(seed, start, count) >> np.uint64(40)).astype(np.float32)
+    return u * np.float32(2.0**-23) - np.float32(1.0)
+
+
+def synth_small_int(seed: int, start: int, count: int) -> np.ndarray:
+    """float32 integers in {-3..3}: dot products / squared norms are exact in fp32 for d<=1024."""
+    u = (synth_bits(seed, start, count) >> np.uint64(40)) % np.uint64(7)
+    return u.astype(np.float32) - np.float32(3.0)
+
+
+def synth_matrix(seed: int, n_rows: int, dim: int, kind: str = "uniform", row0: int = 0) -> np.ndarray:
+    gen = {"uniform": synth_uniform, "small_int": synth_small_int}[kind]
+    return gen(seed, row0 * dim, n_rows * dim).reshape(n_rows, dim)
+
+
+# ----------------------------------------------------------------------------------------
+# a1: late-chunking pool   (reference: src/raglite/_embed.py:119-136)
+# ----------------------------------------------------------------------------------------
+
+
+def largest_remainder_sizes(n_token_rows: int, segment_tokens: np.ndarray) -> np.ndarray:
+    """Rows of a segment's token matrix apportioned to its sentences.
+
+    Follows `_embed.py:122-129` operation for operation (same `np.floor`, same `np.argsort`
+    on the fractional parts, same `[-remainder:]` slice), because the tie behaviour of the
+    largest-remainder method is defined by that argsort call.
+    """
+    segment_tokens = np.asarray(segment_tokens)
+    sentence_size_frac = n_token_rows * (segment_tokens / np.sum(segment_tokens))
+    sentence_size = np.floor(sentence_size_frac).astype(np.intp)
+    remainder = n_token_rows - np.sum(sentence_size)
+    if remainder > 0:
+        top_remainders = np.argsort(sentence_size_frac - sentence_size)[-remainder:]
+        sentence_size[top_remainders] += 1
+    return sentence_size
+
+
+def create_segment(
+    content_start_index: int, max_tokens_preamble: int, max_tokens_content: int, num_tokens: np.ndarray
+) -> tuple[int, int]:
+    """Segment bounds with a <=38.2 % preamble.  Follows `_embed.py:38-58`."""
+    cumsum_backwards = np.cumsum(num_tokens[:content_start_index][::-1])
+    offset_preamble = np.searchsorted(cumsum_backwards, max_tokens_preamble, side="right")
+    segment_start_index = content_start_index - int(offset_preamble)
+    max_tokens_content = max_tokens_content + (
+        max_tokens_preamble - np.sum(num_tokens[segment_start_index:content_start_index])
+    )
+    cumsum_forwards = np.cumsum(num_tokens[content_start_index:])
+    offset_segment = np.searchsorted(cumsum_forwards, max_tokens_content, side="right")
+    segment_end_index = content_start_index + int(offset_segment)
+    return segment_start_index, segment_end_index
+
+
+def create_segments(num_tokens: np.ndarray, n_ctx: int, n_batch: int) -> list[tuple[int, int, int]]:
+    """All (segment_start, content_start, segment_end) triples.  Follows `_embed.py:99-110`."""
+    max_tokens = min(n_ctx, n_batch) - 16
+    max_tokens_preamble = round(0.382 * max_tokens)
+    max_tokens_content = max_tokens - max_tokens_preamble
+    segments = []
+    content_start_index = 0
+    while content_start_index < len(num_tokens):
+        s, e = create_segment(content_start_index, max_tokens_preamble, max_tokens_content, num_tokens)
+        segments.append((s, content_start_index, e))
+        content_start_index = e
+    return segments
+
+
+def pool_segment(
+    segment_embedding: np.ndarray, segment_tokens: np.ndarray, n_preamble_sentences: int
+) -> np.ndarray:
+    """Mean-pool the token rows of each *content* sentence.  Follows `_embed.py:122-135`.
+
+    `segment_embedding` is float64 in the reference (llama-cpp returns Python floats,
+    `np.asarray` at `_embed.py:119`); the mean is `np.mean(axis=0)` in float64.
+    """
+    segment_embedding = np.asarray(segment_embedding, dtype=np.float64)
+    sizes = largest_remainder_sizes(len(segment_embedding), segment_tokens)
+    mats = np.split(segment_embedding, np.cumsum(sizes)[:-1])
+    content = [np.mean(m, axis=0, keepdims=True) for m in mats[n_preamble_sentences:]]
+    return np.vstack(content)
+
+
+def pool_spans(tokens: np.ndarray, span_begin: np.ndarray, span_end: np.ndarray) -> np.ndarray:
+    """Span form of a1 (what the HIP kernel receives): mean of rows [b, e) per span, float64.
+
+    An empty span yields NaN exactly as `np.mean` of a (0, d) matrix does in the reference
+    (`_embed.py:132`, reachable when a sentence is apportioned zero rows).
+    """
+    tokens = np.asarray(tokens, dtype=np.float64)
+    out = np.empty((len(span_begin), tokens.shape[1]), dtype=np.float64)
+    for i, (b, e) in enumerate(zip(span_begin, span_end)):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                out[i] = np.mean(tokens[b:e], axis=0)
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# a2: L2 normalise + fp16 cast   (reference: _embed.py:138-140 and :158-164)
+# ----------------------------------------------------------------------------------------
+
+
+def l2_normalize(x: np.ndarray, eps: float | None = None) -> np.ndarray:
+    """`X /= ||X||` rowwise.  eps=None: unguarded divide (`_embed.py:139`);
+    eps given: `X /= max(norm, eps)` (`_embed.py:160-163`, eps = finfo(dtype).eps there)."""
+    x = np.array(x, copy=True)
+    norm = np.linalg.norm(x, axis=1, keepdims=True)
+    if eps is not None:
+        norm = np.maximum(norm, eps)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        x /= norm
+    return x
+
+
+def to_fp16(x: np.ndarray) -> np.ndarray:
+    """`astype(np.float16)` (round-to-nearest-even).  `_embed.py:140,164`."""
+    with np.errstate(over="ignore"):
+        return np.asarray(x).astype(np.float16)
+
+
+def pool_norm_cast(
+    tokens: np.ndarray, span_begin: np.ndarray, span_end: np.ndarray, normalize: bool = True,
+    eps: float | None = None,
+) -> tuple[np.ndarray, np.ndarray]:
+    """a1+a2 on spans: returns (float64 pooled[/normalised], fp16 cast)."""
+    x = pool_spans(tokens, span_begin, span_end)
+    if normalize:
+        x = l2_normalize(x, eps)
+    return x, to_fp16(x)
+
+
+def embed_string_batch_pool(token_matrices: list[np.ndarray], normalize: bool = True) -> np.ndarray:
+    """a3: mean over all tokens of each string, eps-guarded normalise, fp16.  `_embed.py:154-164`."""
+    embeddings = np.asarray([np.mean(np.asarray(row, dtype=np.float64), axis=0) for row in token_matrices])
+    if normalize:
+        eps = np.finfo(embeddings.dtype).eps
+        norm = np.linalg.norm(embeddings, axis=1, keepdims=True)
+        embeddings /= np.maximum(norm, eps)
+    return embeddings.astype(np.float16)
+
+
+# ----------------------------------------------------------------------------------------
+# a5: query adapter   (reference: src/raglite/_search.py:58-62)
+# ----------------------------------------------------------------------------------------
+
+
+def adapter_apply(A: np.ndarray, q: np.ndarray) -> np.ndarray:
+    """`(Q @ q).astype(q.dtype)`; batched form applies it to every row of q."""
+    q = np.asarray(q)
+    if q.ndim == 1:
+        return (A @ q).astype(q.dtype)
+    return (q @ A.T).astype(q.dtype)
+
+
+# ----------------------------------------------------------------------------------------
+# a6: distance / similarity   (reference: _search.py:69-72, _typing.py:123-134)
+# ----------------------------------------------------------------------------------------
+
+
+def distance(E: np.ndarray, q: np.ndarray, metric: str = "cosine", dtype=np.float64) -> np.ndarray:
+    """DuckDB semantics: cosine -> 1 - e.q/(|e||q|); dot -> -(e.q); l2 -> |e-q|_2.
+
+    `dtype=np.float64` is the "truth" variant, `np.float32` the as-computed variant (DuckDB
+    evaluates FLOAT[d] arrays in fp32; its exact rounding is unverifiable here)."""
+    E = np.asarray(E, dtype=dtype)
+    q = np.asarray(q, dtype=dtype)
+    if metric == "cosine":
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return 1.0 - (E @ q) / (np.linalg.norm(E, axis=1) * np.linalg.norm(q))
+    if metric == "dot":
+        return -(E @ q)
+    if metric == "l2":
+        return np.linalg.norm(E - q[None, :], axis=1)
+    raise ValueError(f"Unsupported metric: {metric}")
+
+
+def similarity(E: np.ndarray, q: np.ndarray, metric: str = "cosine", dtype=np.float64) -> np.ndarray:
+    """`sim = 1.0 - dist` (`_search.py:72`)."""
+    return 1.0 - distance(E, q, metric, dtype)
+
+
+# ----------------------------------------------------------------------------------------
+# a7 + a8: two-stage selection   (reference: _search.py:66-67, 75-79, 143-149)
+# ----------------------------------------------------------------------------------------
+
+
+def num_hits(num_results: int, oversample: int = 4, chunk_max_size: int = 2048) -> int:
+    """`round(oversample * chunk_max_size / 2048) * max(num_results, 10)` (`_search.py:66-67`)."""
+    corrected_oversample = oversample * chunk_max_size / 2048
+    return round(corrected_oversample) * max(num_results, 10)
+
+
+def topk_desc(scores: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
+    """Exact top-k by (score descending, index ascending).  NaNs rank last.
+
+    `ORDER BY dist LIMIT k` (`_search.py:77-79`) with the tie order SQL leaves unspecified
+    fixed to the lowest index."""
+    scores = np.asarray(scores)
+    k = min(k, len(scores))
+    key = np.where(np.isnan(scores), -np.inf, scores)
+    order = np.lexsort((np.arange(len(scores)), -key))[:k]
+    return scores[order], order.astype(np.int64)
+
+
+def search_rows(E, q, k, metric="cosine", dtype=np.float64):
+    """a6+a7: top-k rows by similarity."""
+    return topk_desc(similarity(E, q, metric, dtype), k)
+
+
+def group_chunk_max(row_scores: np.ndarray, row_chunks: np.ndarray, num_results: int):
+    """a8: `SELECT chunk_id, max(sim) GROUP BY chunk_id ORDER BY max DESC LIMIT n`
+    (`_search.py:143-149`) over the a7 rows.  Ties -> lowest chunk ordinal."""
+    best: dict[int, float] = {}
+    for s, c in zip(row_scores.tolist(), row_chunks.tolist()):
+        if c not in best or s > best[c]:
+            best[c] = s
+    items = sorted(best.items(), key=lambda kv: (-kv[1], kv[0]))[:num_results]
+    return (
+        np.asarray([s for _, s in items], dtype=row_scores.dtype),
+        np.asarray([c for c, _ in items], dtype=np.int64),
+    )
+
+
+def search_chunks(E, row_to_chunk, q, n_hits, num_results, metric="cosine", dtype=np.float64):
+    """a6+a7+a8: the reference's two-stage semantics (rows -> per-chunk max -> chunks).
+    Fewer than `num_results` chunks come back when the `n_hits` best rows span fewer chunks."""
+    s, rows = search_rows(E, q, n_hits, metric, dtype)
+    return group_chunk_max(s, np.asarray(row_to_chunk)[rows], num_results)
+
+
+# ----------------------------------------------------------------------------------------
+# a9: MaxSim (multi-query generalisation of _search.py:143-149 / _query_adapter.py:174)
+# ----------------------------------------------------------------------------------------
+
+
+def maxsim_scores(D: np.ndarray, chunk_offsets: np.ndarray, Q: np.ndarray, dtype=np.float64) -> np.ndarray:
+    """score[c] = sum_i max_{j in chunk c} Q[i] . D[j]; empty chunks score -inf."""
+    D = np.asarray(D, dtype=dtype)
+    Q = np.atleast_2d(np.asarray(Q, dtype=dtype))
+    off = np.asarray(chunk_offsets, dtype=np.int64)
+    n_chunks = len(off) - 1
+    out = np.full(n_chunks, -np.inf, dtype=dtype)
+    nonempty = np.nonzero(off[1:] > off[:-1])[0]
+    if len(nonempty) == 0 or len(D) == 0:
+        return out
+    S = D @ Q.T  # (N, nq)
+    seg_max = np.maximum.reduceat(S, off[nonempty], axis=0)  # valid because nonempty starts ascend
+    out[nonempty] = seg_max.sum(axis=1)
+    return out
+
+
+def maxsim_topk(D, chunk_offsets, Q, k, dtype=np.float64):
+    return topk_desc(maxsim_scores(D, chunk_offsets, Q, dtype), k)
+
+
+def maxsim_candidates(D, chunk_offsets, Q, cand, dtype=np.float64) -> np.ndarray:
+    """MaxSim restricted to candidate chunk ordinals (rerank shape, SURVEY cfg 3)."""
+    D = np.asarray(D, dtype=dtype)
+    Q = np.atleast_2d(np.asarray(Q, dtype=dtype))
+    off = np.asarray(chunk_offsets, dtype=np.int64)
+    out = np.empty(len(cand), dtype=dtype)
+    for i, c in enumerate(cand):
+        b, e = off[c], off[c + 1]
+        out[i] = (D[b:e] @ Q.T).max(axis=0).sum() if e > b else -np.inf
+    return out
+
+
+# ----------------------------------------------------------------------------------------
+# section 8e: shard merge
+# ----------------------------------------------------------------------------------------
+
+
+def merge_topk(scores_list: list[np.ndarray], ids_list: list[np.ndarray], k: int):
+    """Concatenate per-shard top-k lists (global ids) and take the global top-k by
+    (score desc, id asc): identical to the single-shard result."""
+    s = np.concatenate(scores_list)
+    i = np.concatenate(ids_list).astype(np.int64)
+    key = np.where(np.isnan(s), -np.inf, s)
+    order = np.lexsort((i, -key))[:k]
+    return s[order], i[order]
+
+
+def shard_bounds_by_chunk(chunk_offsets: np.ndarray, world: int) -> list[tuple[int, int]]:
+    """Contiguous chunk ranges per rank, balanced by row count, chunks never split."""
+    off = np.asarray(chunk_offsets, dtype=np.int64)
+    n_rows, n_chunks = int(off[-1]), len(off) - 1
+    cuts = [0]
+    for r in range(1, world):
+        target = (n_rows * r) // world
+        c = int(np.searchsorted(off, target, side="left"))
+        cuts.append(min(max(c, cuts[-1]), n_chunks))
+    cuts.append(n_chunks)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]

@@ -1,0 +1,38 @@
+"""raglite_amd -- MI355X-native retrieval / rerank hot path for RAGLite.
+
+Hand-written HIP (gfx950) kernels behind a C ABI (`include/raglite_hip.h`, `libraglite_hip.so`)
+and a Python host layer that mirrors the reference's own entry points for this path:
+`embed_strings()`, `vector_search()`, `rerank_chunks()` and the `RAGLiteConfig.search_method` /
+`.reranker` plugin objects.  There is no CPU fallback: without the shared library (or a gfx950
+GPU) the calls raise.
+"""
+
+from raglite_amd._config import HotPathConfig
+from raglite_amd._embed import (
+    embed_strings,
+    embed_strings_with_late_chunking,
+    embed_strings_without_late_chunking,
+    embedding_type,
+    set_embedder_factory,
+)
+from raglite_amd._ops import DeviceIndex, adapter_apply, merge_topk, pool_norm, set_device, synth_fill, topk
+from raglite_amd._search import (
+    GpuIndex,
+    GpuVectorSearch,
+    MaxSimRanker,
+    attach_index,
+    detach_index,
+    rerank_chunks,
+    search_and_rerank_chunks,
+    vector_search,
+)
+from raglite_amd._sharded import ShardedIndex, merge_topk_host, shard_bounds_by_chunk
+
+__all__ = [
+    "DeviceIndex", "GpuIndex", "GpuVectorSearch", "HotPathConfig", "MaxSimRanker", "ShardedIndex",
+    "adapter_apply", "attach_index", "detach_index", "embed_strings", "embed_strings_with_late_chunking",
+    "embed_strings_without_late_chunking", "embedding_type", "merge_topk", "merge_topk_host", "pool_norm",
+    "rerank_chunks", "search_and_rerank_chunks", "set_device", "set_embedder_factory", "shard_bounds_by_chunk",
+    "synth_fill", "topk", "vector_search",
+]
+__version__ = "0.1.0"

@@ -1,0 +1,114 @@
+"""ctypes binding of libraglite_hip.so (the C ABI declared in include/raglite_hip.h).
+
+There is no CPU fallback: if the shared library is missing or a call fails, an exception is
+raised.  Status codes map to the reference's error conventions:
+RL_ERR_INVALID / RL_ERR_UNSUPPORTED -> ValueError, RL_ERR_NOMEM -> MemoryError, RL_ERR_HIP ->
+RuntimeError.  ctypes releases the GIL for the duration of every call, which is what the
+reference's threaded callers need (`src/raglite/_insert.py:208-237`, `src/raglite/_rag.py:317`).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import functools
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libraglite_hip.so"
+
+RL_OK, RL_ERR_INVALID, RL_ERR_HIP, RL_ERR_UNSUPPORTED, RL_ERR_NOMEM = 0, -1, -2, -3, -4
+MEM_HOST, MEM_DEVICE = 0, 1
+METRICS = {"cosine": 0, "dot": 1, "l2": 2}
+SYNTH_KINDS = {"uniform": 0, "small_int": 1}
+
+c_void_p, c_int, c_i32, c_i64, c_u64, c_size_t = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
+c_double, c_char_p = C.c_double, C.c_char_p
+
+# name -> argtypes (every function returns int status unless listed in _RESTYPES)
+_SIGNATURES = {
+    "rl_version": [],
+    "rl_last_error": [],
+    "rl_init": [c_int],
+    "rl_device_count": [C.POINTER(c_int)],
+    "rl_device_info": [c_int, c_char_p, c_int, C.POINTER(c_int), C.POINTER(c_i64)],
+    "rl_dev_alloc": [C.POINTER(c_void_p), c_size_t],
+    "rl_dev_free": [c_void_p],
+    "rl_memcpy_h2d": [c_void_p, c_void_p, c_size_t, c_void_p],
+    "rl_memcpy_d2h": [c_void_p, c_void_p, c_size_t, c_void_p],
+    "rl_memcpy_d2d": [c_void_p, c_void_p, c_size_t, c_void_p],
+    "rl_stream_sync": [c_void_p],
+    "rl_synth_fill": [c_void_p, c_i64, c_i64, c_u64, c_int, c_void_p],
+    "rl_pool_norm": [c_void_p, c_i64, c_i32, c_void_p, c_void_p, c_i64, c_i32, c_double, c_void_p, c_void_p,
+                     c_int, c_void_p],
+    "rl_adapter_apply": [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_int, c_void_p],
+    "rl_index_create": [C.POINTER(c_void_p), c_void_p, c_i64, c_i32, c_void_p, c_i64, c_int, c_int, c_void_p],
+    "rl_index_destroy": [c_void_p],
+    "rl_index_info": [c_void_p, C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i64), C.POINTER(c_int)],
+    "rl_search_rows": [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_int, c_void_p],
+    "rl_search_chunks": [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "rl_maxsim_topk": [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_int, c_void_p],
+    "rl_maxsim_scores": [c_void_p, c_void_p, c_i32, c_void_p, c_int, c_void_p],
+    "rl_maxsim_rerank": [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_i32, c_void_p, c_int, c_void_p],
+    "rl_merge_topk": [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_int, c_void_p],
+    "rl_topk": [c_void_p, c_i32, c_i64, c_i64, c_i32, c_void_p, c_void_p, c_int, c_void_p],
+    "rl_time_kernel": [c_void_p, c_int, c_void_p, c_i32, c_i32, C.POINTER(C.c_float), c_void_p],
+}
+_RESTYPES = {"rl_last_error": c_char_p}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class RagliteHipError(RuntimeError):
+    """HIP runtime failure inside libraglite_hip.so."""
+
+
+@functools.lru_cache(maxsize=1)
+def lib() -> C.CDLL:
+    """Load the library (once).  Fails loudly: the product path has no CPU fallback."""
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m raglite_amd._build` (needs hipcc; "
+            "cross-compiles for gfx950 without a GPU). raglite_amd has no CPU fallback."
+        )
+    handle = C.CDLL(str(LIB_PATH))
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if the library does not export the declared symbol
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, c_int)
+    return handle
+
+
+def last_error() -> str:
+    msg = lib().rl_last_error()
+    return msg.decode() if msg else ""
+
+
+def check(status: int) -> None:
+    if status == RL_OK:
+        return
+    msg = last_error() or f"libraglite_hip status {status}"
+    if status in (RL_ERR_INVALID, RL_ERR_UNSUPPORTED):
+        raise ValueError(msg)
+    if status == RL_ERR_NOMEM:
+        raise MemoryError(msg)
+    raise RagliteHipError(msg)
+
+
+_initialised: set[int] = set()
+
+
+def init(device: int = 0) -> None:
+    """`hipSetDevice` for the calling thread + gfx950 check (idempotent per device)."""
+    check(lib().rl_init(device))
+    _initialised.add(device)
+
+
+def device_count() -> int:
+    n = c_int(0)
+    check(lib().rl_device_count(C.byref(n)))
+    return n.value
+
+
+def device_info(device: int = 0) -> dict:
+    name = C.create_string_buffer(64)
+    cus, mem = c_int(0), c_i64(0)
+    check(lib().rl_device_info(device, name, 64, C.byref(cus), C.byref(mem)))
+    return {"arch": name.value.decode(), "compute_units": cus.value, "total_mem": mem.value}

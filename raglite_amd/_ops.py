@@ -1,0 +1,319 @@
+"""Thin array-level wrappers over the C ABI.
+
+Every function accepts either NumPy arrays (host pointers: the library stages them through HBM
+and the call is synchronous) or `torch` CUDA tensors (device pointers: work is enqueued on torch's
+current stream and results come back as CUDA tensors, no synchronisation).  PyTorch is only the
+owner of device memory and streams here; no torch kernel runs on the hot path.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import threading
+from typing import Any
+
+import numpy as np
+
+from raglite_amd import _abi
+from raglite_amd._abi import MEM_DEVICE, MEM_HOST, METRICS, SYNTH_KINDS, check, lib
+
+K_MAX = 2048
+
+
+def _is_torch(x: Any) -> bool:
+    return type(x).__module__.split(".")[0] == "torch"
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+class _Args:
+    """Collects the pointers of one call and enforces that they all live on the same side."""
+
+    def __init__(self) -> None:
+        self.mem: int | None = None
+        self.device = None
+        self.keep: list[Any] = []
+
+    def _side(self, mem: int, device=None) -> None:
+        if self.mem is None:
+            self.mem, self.device = mem, device
+        elif self.mem != mem:
+            raise ValueError("all array arguments of one call must be NumPy arrays or all CUDA tensors")
+
+    def inp(self, x: Any, dtype: np.dtype) -> int:
+        if _is_torch(x):
+            torch = _torch()
+            if not x.is_cuda:
+                raise ValueError("torch tensors passed to raglite_amd must live on a CUDA (HIP) device")
+            t = x.to(getattr(torch, np.dtype(dtype).name)).contiguous()
+            self._side(MEM_DEVICE, t.device)
+            self.keep.append(t)
+            return t.data_ptr()
+        a = np.ascontiguousarray(x, dtype=dtype)
+        self._side(MEM_HOST)
+        self.keep.append(a)
+        return a.ctypes.data
+
+    def out(self, shape: tuple[int, ...], dtype: np.dtype) -> tuple[Any, int]:
+        if self.mem == MEM_DEVICE:
+            torch = _torch()
+            t = torch.empty(shape, dtype=getattr(torch, np.dtype(dtype).name), device=self.device)
+            self.keep.append(t)
+            return t, t.data_ptr()
+        a = np.empty(shape, dtype=dtype)
+        self.keep.append(a)
+        return a, a.ctypes.data
+
+    @property
+    def stream(self) -> int:
+        if self.mem == MEM_DEVICE:
+            return _torch().cuda.current_stream(self.device).cuda_stream
+        return 0
+
+    def ensure_device(self) -> None:
+        """Make the HIP device current for this thread (ctypes calls run on the caller's thread)."""
+        dev = self.device.index if (self.mem == MEM_DEVICE and self.device.index is not None) else _current_device()
+        _ensure_init(dev)
+
+
+_tls = threading.local()
+
+
+def _current_device() -> int:
+    return getattr(_tls, "device", 0)
+
+
+def _ensure_init(device: int) -> None:
+    if getattr(_tls, "initialised", None) != device:
+        _abi.init(device)
+        _tls.initialised = device
+        _tls.device = device
+
+
+def set_device(device: int) -> None:
+    """Select the GPU used by host-array calls made from this thread."""
+    _tls.device = device
+    _ensure_init(device)
+
+
+# ----------------------------------------------------------------------------------------------
+def synth_fill(out, seed: int, start: int = 0, kind: str = "uniform"):
+    """Fill a float32 CUDA tensor with the counter-based synthetic stream (oracle-identical bits)."""
+    a = _Args()
+    ptr = a.inp(out, np.float32)
+    if a.mem != MEM_DEVICE or a.keep[0].data_ptr() != out.data_ptr():
+        raise ValueError("synth_fill needs a contiguous float32 CUDA tensor")
+    a.ensure_device()
+    check(lib().rl_synth_fill(ptr, start, out.numel(), seed, SYNTH_KINDS[kind], a.stream))
+    return out
+
+
+def pool_norm(tokens, span_begin, span_end, *, normalize: bool = True, eps: float = 0.0,
+              want_f32: bool = False, want_f16: bool = True):
+    """a1+a2(+a3): mean-pool token rows [b, e) per span, L2-normalise, cast.  Returns (f32|None, f16|None).
+
+    Mirrors `src/raglite/_embed.py:131-140` (eps == 0) and `:154-164` (eps > 0)."""
+    a = _Args()
+    p_tok = a.inp(tokens, np.float32)
+    p_b = a.inp(span_begin, np.int64)
+    p_e = a.inp(span_end, np.int64)
+    tok = a.keep[0]
+    if tok.ndim != 2:
+        raise ValueError("tokens must be a (T, dim) matrix")
+    n_rows, dim = int(tok.shape[0]), int(tok.shape[1])
+    n_spans = int(a.keep[1].shape[0])
+    if int(a.keep[2].shape[0]) != n_spans:
+        raise ValueError("span_begin and span_end must have the same length")
+    o32, p32 = a.out((n_spans, dim), np.float32) if want_f32 else (None, None)
+    o16, p16 = a.out((n_spans, dim), np.float16) if want_f16 else (None, None)
+    a.ensure_device()
+    check(lib().rl_pool_norm(p_tok, n_rows, dim, p_b, p_e, n_spans, int(normalize), float(eps), p32, p16,
+                             a.mem, a.stream))
+    return o32, o16
+
+
+def adapter_apply(A, queries, *, want_f16: bool = False):
+    """a5: out[b] = A @ q[b] (`src/raglite/_search.py:62`).  Accepts a vector or a (B, dim) batch."""
+    a = _Args()
+    p_a = a.inp(A, np.float32)
+    q = queries
+    single = q.ndim == 1
+    if single:
+        q = q.reshape(1, -1)
+    p_q = a.inp(q, np.float32)
+    dim = int(a.keep[0].shape[0])
+    if tuple(a.keep[0].shape) != (dim, dim) or int(a.keep[1].shape[1]) != dim:
+        raise ValueError("adapter must be (dim, dim) and queries (B, dim)")
+    B = int(a.keep[1].shape[0])
+    out, p_o = a.out((B, dim), np.float16 if want_f16 else np.float32)
+    a.ensure_device()
+    check(lib().rl_adapter_apply(p_a, p_q, B, dim, None if want_f16 else p_o, p_o if want_f16 else None,
+                                 a.mem, a.stream))
+    return out[0] if single else out
+
+
+def topk(scores, k: int):
+    """Exact top-k per row of a (B, n) score matrix by (score desc, index asc)."""
+    a = _Args()
+    s2 = scores if scores.ndim == 2 else scores.reshape(1, -1)
+    p_s = a.inp(s2, np.float32)
+    B, n = int(s2.shape[0]), int(s2.shape[1])
+    o_s, p_os = a.out((B, k), np.float32)
+    o_i, p_oi = a.out((B, k), np.int32)
+    a.ensure_device()
+    check(lib().rl_topk(p_s, B, n, n, k, p_os, p_oi, a.mem, a.stream))
+    return (o_s, o_i) if scores.ndim == 2 else (o_s[0], o_i[0])
+
+
+def merge_topk(scores, ids, k: int):
+    """Merge per-shard lists: scores/ids are (n_lists, B, k_in) -> (B, k)."""
+    a = _Args()
+    p_s = a.inp(scores, np.float32)
+    p_i = a.inp(ids, np.int32)
+    n_lists, B, k_in = (int(v) for v in a.keep[0].shape)
+    o_s, p_os = a.out((B, k), np.float32)
+    o_i, p_oi = a.out((B, k), np.int32)
+    a.ensure_device()
+    check(lib().rl_merge_topk(p_s, p_i, n_lists, B, k_in, k, p_os, p_oi, a.mem, a.stream))
+    return o_s, o_i
+
+
+class DeviceIndex:
+    """Device-resident chunk-embedding matrix + chunk CSR: the GPU image of the reference's
+    `chunk_embedding` table (`src/raglite/_database.py:403-430`).
+
+    `embeddings`: (n_rows, dim) float32 NumPy array (copied to HBM) or CUDA tensor (borrowed, kept
+    alive by this object).  `chunk_offsets`: ascending int64 CSR of length n_chunks+1 (rows of a chunk
+    contiguous, `src/raglite/_split_chunks.py:116-122`); None = one row per chunk."""
+
+    def __init__(self, embeddings, chunk_offsets=None, *, metric: str = "cosine") -> None:
+        if metric not in METRICS:
+            raise ValueError(f"Unsupported metric: {metric}")  # wording of src/raglite/_query_adapter.py:207
+        a = _Args()
+        p_e = a.inp(embeddings, np.float32)
+        emb = a.keep[0]
+        if emb.ndim != 2:
+            raise ValueError("embeddings must be a (n_rows, dim) matrix")
+        self.n_rows, self.dim = int(emb.shape[0]), int(emb.shape[1])
+        self.metric = metric
+        self.mem = a.mem
+        self.device = a.device
+        self._keep = emb if a.mem == MEM_DEVICE else None
+        if chunk_offsets is None:
+            off_ptr, n_chunks = None, self.n_rows
+            self.chunk_offsets = None
+        else:
+            off = np.ascontiguousarray(np.asarray(chunk_offsets.cpu() if _is_torch(chunk_offsets) else chunk_offsets),
+                                       dtype=np.int64)
+            if off.ndim != 1 or off.size < 1:
+                raise ValueError("chunk_offsets must be a 1-D array of length n_chunks + 1")
+            off_ptr, n_chunks = off.ctypes.data, int(off.size - 1)
+            self.chunk_offsets = off
+        self.n_chunks = n_chunks
+        a.ensure_device()
+        handle = C.c_void_p()
+        check(lib().rl_index_create(C.byref(handle), p_e, self.n_rows, self.dim, off_ptr, n_chunks,
+                                    METRICS[metric], a.mem, a.stream))
+        self._handle = handle
+
+    def close(self) -> None:
+        h, self._handle = getattr(self, "_handle", None), None
+        if h:
+            lib().rl_index_destroy(h)
+        self._keep = None
+
+    def __del__(self) -> None:  # noqa: D105
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001,S110 - interpreter shutdown
+            pass
+
+    # -- helpers -------------------------------------------------------------------------------
+    def _queries(self, a: _Args, q) -> tuple[int, int, bool]:
+        single = q.ndim == 1
+        q2 = q.reshape(1, -1) if single else q
+        ptr = a.inp(q2, np.float32)
+        if int(a.keep[-1].shape[1]) != self.dim:
+            raise ValueError(f"query dimension {int(a.keep[-1].shape[1])} != index dimension {self.dim}")
+        return ptr, int(a.keep[-1].shape[0]), single
+
+    def _prep(self, a: _Args) -> None:
+        if a.mem == MEM_HOST and self.mem == MEM_DEVICE:
+            _ensure_init(self.device.index or 0)
+        else:
+            a.ensure_device()
+
+    # -- a6 + a7 -------------------------------------------------------------------------------
+    def search_rows(self, queries, k: int):
+        """Exact top-k rows: (scores (B,k) desc, rows (B,k) int32); padding = (-inf, -1)."""
+        a = _Args()
+        p_q, B, single = self._queries(a, queries)
+        o_s, p_s = a.out((B, k), np.float32)
+        o_r, p_r = a.out((B, k), np.int32)
+        self._prep(a)
+        check(lib().rl_search_rows(self._handle, p_q, B, k, p_s, p_r, a.mem, a.stream))
+        return (o_s[0], o_r[0]) if single else (o_s, o_r)
+
+    # -- a6 + a7 + a8 ----------------------------------------------------------------------------
+    def search_chunks(self, queries, num_hits: int, k: int):
+        """Reference two-stage semantics (`src/raglite/_search.py:66-79,143-149`):
+        returns (scores (B,k), chunk ordinals (B,k), counts (B,))."""
+        a = _Args()
+        p_q, B, single = self._queries(a, queries)
+        o_s, p_s = a.out((B, k), np.float32)
+        o_c, p_c = a.out((B, k), np.int32)
+        o_n, p_n = a.out((B,), np.int32)
+        self._prep(a)
+        check(lib().rl_search_chunks(self._handle, p_q, B, num_hits, k, p_s, p_c, p_n, a.mem, a.stream))
+        return (o_s[0], o_c[0], o_n[0]) if single else (o_s, o_c, o_n)
+
+    # -- a9 ----------------------------------------------------------------------------------------
+    def maxsim_scores(self, query_vecs):
+        a = _Args()
+        p_q, nq, _ = self._queries(a, query_vecs)
+        o_s, p_s = a.out((self.n_chunks,), np.float32)
+        self._prep(a)
+        check(lib().rl_maxsim_scores(self._handle, p_q, nq, p_s, a.mem, a.stream))
+        return o_s
+
+    def maxsim_topk(self, query_vecs, k: int):
+        a = _Args()
+        p_q, nq, _ = self._queries(a, query_vecs)
+        o_s, p_s = a.out((k,), np.float32)
+        o_c, p_c = a.out((k,), np.int32)
+        self._prep(a)
+        check(lib().rl_maxsim_topk(self._handle, p_q, nq, k, p_s, p_c, a.mem, a.stream))
+        return o_s, o_c
+
+    def maxsim_rerank(self, query_vecs, candidates):
+        """query_vecs (n_queries, nq, dim), candidates (n_queries, n_cand) int32 -> scores (n_queries, n_cand)."""
+        a = _Args()
+        p_q = a.inp(query_vecs, np.float32)
+        qv = a.keep[-1]
+        if qv.ndim != 3 or int(qv.shape[2]) != self.dim:
+            raise ValueError("query_vecs must be (n_queries, nq, dim)")
+        p_c = a.inp(candidates, np.int32)
+        cv = a.keep[-1]
+        n_queries, nq = int(qv.shape[0]), int(qv.shape[1])
+        if cv.ndim != 2 or int(cv.shape[0]) != n_queries:
+            raise ValueError("candidates must be (n_queries, n_cand)")
+        n_cand = int(cv.shape[1])
+        o_s, p_s = a.out((n_queries, n_cand), np.float32)
+        self._prep(a)
+        check(lib().rl_maxsim_rerank(self._handle, p_q, n_queries, nq, p_c, n_cand, p_s, a.mem, a.stream))
+        return o_s
+
+    def time_kernel(self, kind: int, query_vecs_cuda, iters: int) -> float:
+        """Milliseconds (HIP events on the launch stream) for `iters` launches of the dominant kernel."""
+        a = _Args()
+        p_q, nq, _ = self._queries(a, query_vecs_cuda)
+        if a.mem != MEM_DEVICE:
+            raise ValueError("time_kernel needs CUDA tensors")
+        ms = C.c_float(0.0)
+        self._prep(a)
+        check(lib().rl_time_kernel(self._handle, kind, p_q, nq, iters, C.byref(ms), a.stream))
+        return float(ms.value)

@@ -1,0 +1,272 @@
+"""Host mirror of the retrieval half of `src/raglite/_search.py` over a device-resident index.
+
+    vector_search(query, *, num_results=3, oversample=4, metadata_filter=None, config=None)
+        -> (list[ChunkId], list[float])                                   (`_search.py:36-153`)
+    rerank_chunks(query, chunk_ids, *, config=None) -> list[chunk]        (`_search.py:364-397`)
+    search_and_rerank_chunks(...)                                         (`_search.py:400-414`)
+    GpuVectorSearch   -- a `BasicSearchMethod` (`_typing.py:35-43`) for `RAGLiteConfig.search_method`
+    MaxSimRanker      -- a duck-typed `rerankers.BaseRanker` for `RAGLiteConfig.reranker`
+                         (`.rank(query=, docs=)` -> `.results[*].doc_id`, `_search.py:394-396`)
+
+The reference evaluates distance + ORDER BY/LIMIT + GROUP BY inside DuckDB/pgvector; here the
+`chunk_embedding` table lives in HBM (`GpuIndex`) and the same three steps run as HIP kernels.  The
+store, ORM and HNSW index are out of scope.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Callable, Sequence
+
+import numpy as np
+
+from raglite_amd import _ops
+from raglite_amd._config import DEFAULT_CHUNK_MAX_SIZE, HotPathConfig
+from raglite_amd._embed import embed_strings
+
+ChunkId = str
+
+
+class GpuIndex:
+    """Device image of the `chunk` / `chunk_embedding` tables for one database.
+
+    chunk_ids        list[str] -- `Chunk.id` per chunk ordinal (`_database.py:233`)
+    chunk_embeddings list of (n_i, dim) matrices -- `Chunk.embedding_matrix` (`_database.py:279-283`),
+                     or a single (N, dim) matrix together with `chunk_offsets`
+    query_adapter    optional (dim, dim) matrix -- `IndexMetadata.get("default")["query_adapter"]`
+                     (`_search.py:58-62`, fitted by `_query_adapter.py:141-219`, out of scope)
+    docs             optional list[str] -- `str(chunk)` per chunk, lets `MaxSimRanker` map the strings the
+                     reranker plugin receives back to chunk ordinals
+    metadata         optional list[dict] per chunk for `metadata_filter`
+    """
+
+    def __init__(self, chunk_ids: Sequence[ChunkId], chunk_embeddings, *, chunk_offsets=None,
+                 metric: str = "cosine", query_adapter=None, docs: Sequence[str] | None = None,
+                 metadata: Sequence[dict] | None = None) -> None:
+        if chunk_offsets is None:
+            mats = [np.asarray(m, dtype=np.float32).reshape(len(m), -1) for m in chunk_embeddings]
+            sizes = np.asarray([len(m) for m in mats], dtype=np.int64)
+            chunk_offsets = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+            dim = mats[0].shape[1] if mats else 0
+            matrix = np.vstack(mats) if mats else np.zeros((0, max(dim, 1)), dtype=np.float32)
+        else:
+            matrix = chunk_embeddings
+        if len(chunk_ids) != len(chunk_offsets) - 1:
+            raise ValueError("one chunk id per chunk is required")
+        self.chunk_ids = list(chunk_ids)
+        self._matrix = matrix  # kept for metadata-filtered searches (row gather)
+        self.index = _ops.DeviceIndex(matrix, chunk_offsets, metric=metric)
+        self.metric = metric
+        self.query_adapter = None if query_adapter is None else np.asarray(query_adapter, dtype=np.float32)
+        self.docs = None if docs is None else list(docs)
+        self._doc_to_ordinal = None if docs is None else {d: i for i, d in enumerate(self.docs)}
+        self.metadata = None if metadata is None else list(metadata)
+        self._id_to_ordinal = {cid: i for i, cid in enumerate(self.chunk_ids)}
+
+    def ordinal_of(self, chunk_id: ChunkId) -> int:
+        return self._id_to_ordinal[chunk_id]
+
+    def ordinal_of_doc(self, doc: str) -> int:
+        if self._doc_to_ordinal is None:
+            raise ValueError("GpuIndex was built without `docs`; MaxSimRanker cannot map strings to chunks")
+        return self._doc_to_ordinal[doc]
+
+    def close(self) -> None:
+        self.index.close()
+
+
+# config (hashable, like the reference's lru_cache keys) -> GpuIndex
+_attached: dict[Any, GpuIndex] = {}
+_DEFAULT_KEY = "default"
+
+
+def attach_index(index: GpuIndex, config: Any | None = None) -> None:
+    """Make `index` the one `vector_search(..., config=config)` searches."""
+    _attached[_DEFAULT_KEY if config is None else config] = index
+
+
+def detach_index(config: Any | None = None) -> None:
+    _attached.pop(_DEFAULT_KEY if config is None else config, None)
+
+
+def _index_for(config: Any | None) -> GpuIndex:
+    idx = _attached.get(_DEFAULT_KEY if config is None else config) or _attached.get(_DEFAULT_KEY)
+    if idx is None:
+        raise ValueError("No GpuIndex attached: call raglite_amd.attach_index(index, config) first.")
+    return idx
+
+
+def _adapt_metadata(metadata_filter: dict | None) -> dict | None:
+    """Normalise filter values to lists (`src/raglite/_database.py` `_adapt_metadata`)."""
+    if not metadata_filter:
+        return None
+    return {k: (list(v) if isinstance(v, (list, tuple, set)) else [v]) for k, v in metadata_filter.items()}
+
+
+def _matches(meta: dict, flt: dict) -> bool:
+    """JSON containment `metadata @> filter` (`_search.py:84-97`): every filter value must occur."""
+    for key, wanted in flt.items():
+        have = meta.get(key)
+        have = list(have) if isinstance(have, (list, tuple, set)) else [have]
+        if any(w not in have for w in wanted):
+            return False
+    return True
+
+
+def vector_search(query: str | np.ndarray, *, num_results: int = 3, oversample: int = 4,
+                  metadata_filter: dict | None = None, config: Any | None = None,
+                  index: GpuIndex | None = None) -> tuple[list[ChunkId], list[float]]:
+    """Search chunks with an exact GPU scan (the reference's HNSW search is approximate)."""
+    cfg = config or HotPathConfig()
+    gi = index or _index_for(config)
+    metadata_filter = _adapt_metadata(metadata_filter)
+    if getattr(cfg, "self_query", False) and isinstance(query, str):
+        raise NotImplementedError("self_query needs the LLM stack, which is outside this package")
+    # Embed the query (`_search.py:54-56`).
+    q = embed_strings([query], config=cfg)[0, :] if isinstance(query, str) else np.ravel(query)
+    # Apply the query adapter (`_search.py:58-62`): result is cast back to the query dtype.
+    if cfg.vector_search_query_adapter and gi.query_adapter is not None:
+        q = _ops.adapter_apply(gi.query_adapter, np.asarray(q, dtype=np.float32)).astype(q.dtype)
+    if gi.index.n_rows == 0:
+        return [], []  # empty database (`tests/test_search.py:76-85`)
+    # `_search.py:66-67`
+    corrected_oversample = oversample * cfg.chunk_max_size / DEFAULT_CHUNK_MAX_SIZE
+    num_hits = round(corrected_oversample) * max(num_results, 10)
+    if num_hits < 1 or num_results < 1:
+        return [], []
+    if metadata_filter:
+        return _filtered_search(gi, q, num_hits, num_results, metadata_filter)
+    k = min(num_results, _ops.K_MAX)
+    scores, chunks, count = gi.index.search_chunks(np.asarray(q, dtype=np.float32), min(num_hits, _ops.K_MAX), k)
+    n = int(count)
+    return [gi.chunk_ids[c] for c in chunks[:n].tolist()], [float(s) for s in scores[:n]]
+
+
+def _filtered_search(gi: GpuIndex, q, num_hits: int, num_results: int, flt: dict):
+    """Filter-first branch of the reference (`_search.py:105-119`): restrict to the chunks whose metadata
+    contains the filter, then rank exactly.  The restricted rows are gathered into a temporary index."""
+    if gi.metadata is None:
+        raise ValueError("GpuIndex was built without `metadata`; metadata_filter cannot be applied")
+    allowed = [i for i, m in enumerate(gi.metadata) if _matches(m, flt)]
+    if not allowed:
+        return [], []
+    rows_of = gi.index.chunk_offsets
+    sel = np.concatenate([np.arange(rows_of[c], rows_of[c + 1]) for c in allowed])
+    if _ops._is_torch(gi._matrix):  # noqa: SLF001 - device gather, rows never leave HBM
+        import torch
+
+        sub = gi._matrix.index_select(0, torch.as_tensor(sel, device=gi._matrix.device))  # noqa: SLF001
+    else:
+        sub = np.asarray(gi._matrix)[sel]  # noqa: SLF001
+    sizes = np.asarray([rows_of[c + 1] - rows_of[c] for c in allowed], dtype=np.int64)
+    off = np.concatenate(([0], np.cumsum(sizes)))
+    tmp = _ops.DeviceIndex(sub, off, metric=gi.metric)
+    try:
+        k = min(num_results, _ops.K_MAX)
+        scores, chunks, count = tmp.search_chunks(np.asarray(q, dtype=np.float32), min(num_hits, _ops.K_MAX), k)
+    finally:
+        tmp.close()
+    n = int(count)
+    return [gi.chunk_ids[allowed[c]] for c in chunks[:n].tolist()], [float(s) for s in scores[:n]]
+
+
+class GpuVectorSearch:
+    """`BasicSearchMethod` for `RAGLiteConfig.search_method` (`src/raglite/_typing.py:35-43`,
+    consumed at `src/raglite/_rag.py:53-63`)."""
+
+    def __init__(self, index: GpuIndex, *, oversample: int = 4) -> None:
+        self.index = index
+        self.oversample = oversample
+
+    def __call__(self, query: str | np.ndarray, *, num_results: int = 8, metadata_filter: dict | None = None,
+                 config: Any | None = None) -> tuple[list[ChunkId], list[float]]:
+        return vector_search(query, num_results=num_results, oversample=self.oversample,
+                             metadata_filter=metadata_filter, config=config, index=self.index)
+
+
+# ---- reranking -------------------------------------------------------------------------------------------
+@dataclass
+class Result:
+    """Shape of `rerankers.results.Result` that `_search.py:396` reads (`.doc_id`), plus score and rank."""
+
+    doc_id: int
+    score: float
+    rank: int
+    text: str = ""
+
+
+@dataclass
+class RankedResults:
+    results: list[Result] = field(default_factory=list)
+    query: str = ""
+
+    def top_k(self, k: int) -> list[Result]:
+        return self.results[:k]
+
+
+class MaxSimRanker:
+    """ColBERT-style late-interaction reranker behind the reference's reranker plugin boundary.
+
+    `rank(query=, docs=)` scores every doc as  sum_i max_j q_i . d_j  over the query's token vectors
+    q_i and the doc's chunklet vectors d_j (GPU: `rl_maxsim_rerank`) and returns them best-first.
+    `query_encoder(query: str) -> (nq, dim)` supplies the query's multi-vector representation.
+    """
+
+    def __init__(self, index: GpuIndex, query_encoder: Callable[[str], np.ndarray]) -> None:
+        self.index = index
+        self.query_encoder = query_encoder
+
+    def score(self, query: str, ordinals: Sequence[int]) -> np.ndarray:
+        qv = np.asarray(self.query_encoder(query), dtype=np.float32)
+        qv = qv.reshape(1, *qv.shape) if qv.ndim == 2 else qv.reshape(1, 1, -1)
+        cand = np.asarray(ordinals, dtype=np.int32).reshape(1, -1)
+        return np.asarray(self.index.index.maxsim_rerank(qv, cand))[0]
+
+    def rank(self, query: str, docs: Sequence[Any], doc_ids: Sequence[int] | None = None, **_: Any) -> RankedResults:
+        docs = list(docs)
+        if not docs:
+            return RankedResults([], query)
+        ordinals = [self.index.ordinal_of_doc(d if isinstance(d, str) else str(d)) for d in docs]
+        scores = self.score(query, ordinals)
+        # best first; equal scores keep input order (stable), NaN last
+        key = np.where(np.isnan(scores), -np.inf, scores)
+        order = np.lexsort((np.arange(len(docs)), -key))
+        ids = list(doc_ids) if doc_ids is not None else list(range(len(docs)))
+        return RankedResults(
+            [Result(doc_id=ids[i], score=float(scores[i]), rank=r + 1, text=str(docs[i])) for r, i in enumerate(order)],
+            query,
+        )
+
+
+def rerank_chunks(query: str, chunk_ids: Sequence[Any], *, config: Any | None = None,
+                  chunk_lookup: Callable[[Sequence[ChunkId]], list[Any]] | None = None) -> list[Any]:
+    """Rerank chunks according to their relevance to a query (`src/raglite/_search.py:364-397`).
+
+    `chunk_ids` may be chunk ids or chunk objects (anything whose `str()` is the chunk text).  Ids are
+    resolved through `chunk_lookup` (the reference uses `retrieve_chunks`, a SQL query, out of scope)."""
+    cfg = config or HotPathConfig()
+    chunks = list(chunk_ids)
+    if chunks and all(isinstance(c, ChunkId) for c in chunks):
+        if chunk_lookup is None:
+            raise ValueError("chunk ids need a chunk_lookup callable (the reference's retrieve_chunks)")
+        chunks = chunk_lookup(chunks)
+    reranker = getattr(cfg, "reranker", None)
+    if not reranker or not chunks:
+        return chunks
+    if isinstance(reranker, dict):
+        # The reference picks a language-specific ranker with langdetect (`_search.py:379-392`), which is
+        # not installed here; a MaxSim ranker is language-agnostic, so the "other" entry is used.
+        reranker = reranker.get("other")
+    if reranker:
+        results = reranker.rank(query=query, docs=[str(chunk) for chunk in chunks])
+        chunks = [chunks[result.doc_id] for result in results.results]
+    return chunks
+
+
+def search_and_rerank_chunks(query: str, *, num_results: int = 8, oversample: int = 4,
+                             search: Callable[..., tuple[list[ChunkId], list[float]]] = vector_search,
+                             config: Any | None = None, metadata_filter: dict | None = None,
+                             chunk_lookup: Callable[[Sequence[ChunkId]], list[Any]] | None = None) -> list[Any]:
+    """`src/raglite/_search.py:400-414` (default `search` there is hybrid_search, whose keyword half is SQL)."""
+    chunk_ids, _ = search(query, num_results=oversample * num_results, metadata_filter=metadata_filter, config=config)
+    return rerank_chunks(query, chunk_ids, config=config, chunk_lookup=chunk_lookup)[:num_results]

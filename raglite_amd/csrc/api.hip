@@ -1,0 +1,591 @@
+// C ABI of libraglite_hip.so (see include/raglite_hip.h for the contract of every entry point).
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+
+namespace rl {
+
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+namespace {
+
+hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Device scratch that frees itself; used for RL_MEM_HOST staging and per-call temporaries.
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        if (bytes == 0) bytes = 16;
+        RL_HIP(hipMalloc(&p, bytes));
+        return RL_OK;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Growable device buffer owned by an index (never shrinks; no allocation in steady state).
+struct Pool {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return RL_OK;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        RL_HIP(hipMalloc(&p, bytes));
+        cap = bytes;
+        return RL_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// Input staging: returns a device pointer for `src` (copying when it is a host pointer).
+template <class T>
+int stage_in(const T* src, size_t count, int mem, hipStream_t s, DevBuf& tmp, const T** out) {
+    if (mem == RL_MEM_DEVICE) { *out = src; return RL_OK; }
+    RL_TRY(tmp.alloc(count * sizeof(T)));
+    if (count) RL_HIP(hipMemcpyAsync(tmp.p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    *out = tmp.as<T>();
+    return RL_OK;
+}
+// Output staging: a device pointer to write to; stage_out copies back for host callers.
+template <class T>
+int stage_out_begin(T* dst, size_t count, int mem, DevBuf& tmp, T** out) {
+    if (mem == RL_MEM_DEVICE || dst == nullptr) { *out = dst; return RL_OK; }
+    RL_TRY(tmp.alloc(count * sizeof(T)));
+    *out = tmp.as<T>();
+    return RL_OK;
+}
+template <class T>
+int stage_out_end(T* dst, size_t count, int mem, hipStream_t s, const DevBuf& tmp) {
+    if (mem == RL_MEM_DEVICE || dst == nullptr || count == 0) return RL_OK;
+    RL_HIP(hipMemcpyAsync(dst, tmp.p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+    return RL_OK;
+}
+int finish(int mem, hipStream_t s) {
+    if (mem == RL_MEM_HOST) RL_HIP(hipStreamSynchronize(s));
+    return RL_OK;
+}
+
+int scan_mode(int metric) {
+    switch (metric) {
+        case RL_COSINE: return SCAN_COSINE;
+        case RL_DOT: return SCAN_DOT;
+        case RL_L2: return SCAN_L2;
+        default: return -1;
+    }
+}
+
+constexpr size_t SCORE_BATCH_BYTES = size_t(8) << 30;  // cap of the [B x N] score scratch per sub-batch
+
+}  // namespace
+}  // namespace rl
+
+struct rl_index {
+    const float* E = nullptr;
+    bool owns_E = false;
+    int64_t n_rows = 0;
+    int32_t dim = 0;
+    int64_t n_chunks = 0;
+    int metric = RL_COSINE;
+    bool has_empty_chunk = false;
+    int64_t* offsets = nullptr;       // device [n_chunks + 1]
+    int32_t* row_to_chunk = nullptr;  // device [n_rows + 1]
+    float* norm = nullptr;            // device [n_rows]  (cosine)
+    float* sumsq = nullptr;           // device [n_rows]  (l2)
+    int n_cu = 256;
+    std::mutex mu;
+    rl::SelectWorkspace ws;
+    rl::Pool scores;                  // [B x ld] similarity scratch / chunk scores
+    rl::Pool hits;                    // search_chunks: [B x num_hits] (score, row)
+    rl::Pool misc;
+};
+
+using namespace rl;
+
+extern "C" {
+
+int rl_version(void) { return 100; }
+const char* rl_last_error(void) { return g_last_error.c_str(); }
+
+int rl_init(int device) {
+    int n = 0;
+    RL_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(RL_ERR_INVALID, "rl_init: no such device");
+    RL_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RL_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(RL_ERR_UNSUPPORTED, std::string("rl_init: libraglite_hip is built for gfx950 only, found ") +
+                                            prop.gcnArchName);
+    return RL_OK;
+}
+
+int rl_device_count(int* count) {
+    if (!count) return fail(RL_ERR_INVALID, "rl_device_count: null argument");
+    RL_HIP(hipGetDeviceCount(count));
+    return RL_OK;
+}
+
+int rl_device_info(int device, char* name, int len, int* compute_units, int64_t* total_mem) {
+    hipDeviceProp_t prop;
+    RL_HIP(hipGetDeviceProperties(&prop, device));
+    if (name && len > 0) {
+        std::strncpy(name, prop.gcnArchName, (size_t)len - 1);
+        name[len - 1] = 0;
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (total_mem) *total_mem = (int64_t)prop.totalGlobalMem;
+    return RL_OK;
+}
+
+int rl_dev_alloc(void** ptr, size_t bytes) {
+    if (!ptr) return fail(RL_ERR_INVALID, "rl_dev_alloc: null argument");
+    RL_HIP(hipMalloc(ptr, bytes ? bytes : 16));
+    return RL_OK;
+}
+int rl_dev_free(void* ptr) {
+    if (ptr) RL_HIP(hipFree(ptr));
+    return RL_OK;
+}
+int rl_memcpy_h2d(void* dst, const void* src, size_t bytes, void* stream) {
+    if (bytes) RL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    return RL_OK;
+}
+int rl_memcpy_d2h(void* dst, const void* src, size_t bytes, void* stream) {
+    if (bytes) RL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    RL_HIP(hipStreamSynchronize(as_stream(stream)));
+    return RL_OK;
+}
+int rl_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+    if (bytes) RL_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return RL_OK;
+}
+int rl_stream_sync(void* stream) {
+    RL_HIP(hipStreamSynchronize(as_stream(stream)));
+    return RL_OK;
+}
+
+int rl_synth_fill(float* dst, int64_t start, int64_t count, uint64_t seed, int kind, void* stream) {
+    if (count < 0 || (count > 0 && !dst)) return fail(RL_ERR_INVALID, "rl_synth_fill: bad arguments");
+    if (kind != RL_SYNTH_UNIFORM && kind != RL_SYNTH_SMALL_INT) return fail(RL_ERR_INVALID, "rl_synth_fill: bad kind");
+    return launch_synth(dst, start, count, seed, kind, as_stream(stream));
+}
+
+// ---- a1 + a2 + a3 ----------------------------------------------------------------------------------
+int rl_pool_norm(const float* tokens, int64_t n_token_rows, int32_t dim, const int64_t* span_begin,
+                 const int64_t* span_end, int64_t n_spans, int32_t normalize, double eps, float* out_f32,
+                 uint16_t* out_f16, int mem, void* stream) {
+    if (dim <= 0 || n_token_rows < 0 || n_spans < 0) return fail(RL_ERR_INVALID, "rl_pool_norm: negative size");
+    if (n_spans > 0 && (!span_begin || !span_end)) return fail(RL_ERR_INVALID, "rl_pool_norm: null spans");
+    if (!out_f32 && !out_f16) return fail(RL_ERR_INVALID, "rl_pool_norm: no output requested");
+    if (!(eps >= 0.0)) return fail(RL_ERR_INVALID, "rl_pool_norm: eps must be >= 0");
+    if (n_spans == 0) return RL_OK;
+    hipStream_t s = as_stream(stream);
+    if (mem == RL_MEM_HOST) {  // validate the spans the host handed over (device callers own their spans)
+        for (int64_t i = 0; i < n_spans; ++i)
+            if (span_begin[i] < 0 || span_end[i] < span_begin[i] || span_end[i] > n_token_rows)
+                return fail(RL_ERR_INVALID, "rl_pool_norm: span outside the token matrix");
+    }
+    DevBuf t_tok, t_b, t_e, t_o32, t_o16;
+    const float* d_tok; const int64_t* d_b; const int64_t* d_e;
+    RL_TRY(stage_in(tokens, (size_t)n_token_rows * dim, mem, s, t_tok, &d_tok));
+    RL_TRY(stage_in(span_begin, (size_t)n_spans, mem, s, t_b, &d_b));
+    RL_TRY(stage_in(span_end, (size_t)n_spans, mem, s, t_e, &d_e));
+    float* d_o32; uint16_t* d_o16;
+    RL_TRY(stage_out_begin(out_f32, (size_t)n_spans * dim, mem, t_o32, &d_o32));
+    RL_TRY(stage_out_begin(out_f16, (size_t)n_spans * dim, mem, t_o16, &d_o16));
+    RL_TRY(launch_pool_norm(d_tok, dim, d_b, d_e, n_spans, normalize, eps, d_o32, d_o16, s));
+    RL_TRY(stage_out_end(out_f32, (size_t)n_spans * dim, mem, s, t_o32));
+    RL_TRY(stage_out_end(out_f16, (size_t)n_spans * dim, mem, s, t_o16));
+    return finish(mem, s);
+}
+
+// ---- a5 ----------------------------------------------------------------------------------------------
+int rl_adapter_apply(const float* A, const float* queries, int32_t n_queries, int32_t dim, float* out_f32,
+                     uint16_t* out_f16, int mem, void* stream) {
+    if (dim <= 0 || n_queries < 0) return fail(RL_ERR_INVALID, "rl_adapter_apply: bad size");
+    if (!A || (n_queries > 0 && !queries)) return fail(RL_ERR_INVALID, "rl_adapter_apply: null input");
+    if (!out_f32 && !out_f16) return fail(RL_ERR_INVALID, "rl_adapter_apply: no output requested");
+    if (n_queries == 0) return RL_OK;
+    hipStream_t s = as_stream(stream);
+    DevBuf t_a, t_q, t_o32, t_o16, t_tmp;
+    const float* d_a; const float* d_q;
+    RL_TRY(stage_in(A, (size_t)dim * dim, mem, s, t_a, &d_a));
+    RL_TRY(stage_in(queries, (size_t)n_queries * dim, mem, s, t_q, &d_q));
+    float* d_o32; uint16_t* d_o16;
+    RL_TRY(stage_out_begin(out_f32, (size_t)n_queries * dim, mem, t_o32, &d_o32));
+    RL_TRY(stage_out_begin(out_f16, (size_t)n_queries * dim, mem, t_o16, &d_o16));
+    float* d_res = d_o32;
+    if (!d_res) {  // fp16-only output still needs the fp32 result first
+        RL_TRY(t_tmp.alloc((size_t)n_queries * dim * sizeof(float)));
+        d_res = t_tmp.as<float>();
+    }
+    // out[b][r] = sum_c A[r][c] q[b][c]: the similarity scan over the rows of A in raw-dot mode.
+    RL_TRY(launch_scan_rows(d_a, dim, dim, d_q, n_queries, nullptr, SCAN_RAW_DOT, d_res, dim, s));
+    if (d_o16) RL_TRY(launch_cast_f16(d_res, d_o16, (int64_t)n_queries * dim, s));
+    RL_TRY(stage_out_end(out_f32, (size_t)n_queries * dim, mem, s, t_o32));
+    RL_TRY(stage_out_end(out_f16, (size_t)n_queries * dim, mem, s, t_o16));
+    if (mem == RL_MEM_DEVICE && !out_f32) RL_HIP(hipStreamSynchronize(s));  // t_tmp dies with this frame
+    return finish(mem, s);
+}
+
+// ---- index ---------------------------------------------------------------------------------------------
+int rl_index_destroy(rl_index* idx) {
+    if (!idx) return RL_OK;
+    if (idx->owns_E && idx->E) (void)hipFree(const_cast<float*>(idx->E));
+    if (idx->offsets) (void)hipFree(idx->offsets);
+    if (idx->row_to_chunk) (void)hipFree(idx->row_to_chunk);
+    if (idx->norm) (void)hipFree(idx->norm);
+    if (idx->sumsq) (void)hipFree(idx->sumsq);
+    select_workspace_free(idx->ws);
+    idx->scores.release();
+    idx->hits.release();
+    idx->misc.release();
+    delete idx;
+    return RL_OK;
+}
+
+int rl_index_create(rl_index** out, const float* embeddings, int64_t n_rows, int32_t dim,
+                    const int64_t* chunk_offsets, int64_t n_chunks, int metric, int mem, void* stream) {
+    if (!out) return fail(RL_ERR_INVALID, "rl_index_create: null output handle");
+    *out = nullptr;
+    if (n_rows < 0 || dim <= 0) return fail(RL_ERR_INVALID, "rl_index_create: bad shape");
+    if (n_rows > 0 && !embeddings) return fail(RL_ERR_INVALID, "rl_index_create: null embeddings");
+    if (n_rows >= (int64_t)0x7fffffff - 1) return fail(RL_ERR_UNSUPPORTED, "rl_index_create: more than 2^31-2 rows");
+    if (scan_mode(metric) < 0) return fail(RL_ERR_INVALID, "rl_index_create: unknown metric");
+    if (dim > 4096) return fail(RL_ERR_UNSUPPORTED, "rl_index_create: dim must be <= 4096");
+    std::vector<int64_t> host_offsets;
+    bool has_empty = false;
+    if (chunk_offsets) {
+        if (n_chunks < 0) return fail(RL_ERR_INVALID, "rl_index_create: negative n_chunks");
+        if (chunk_offsets[0] != 0 || chunk_offsets[n_chunks] != n_rows)
+            return fail(RL_ERR_INVALID, "rl_index_create: chunk_offsets must start at 0 and end at n_rows");
+        for (int64_t c = 0; c < n_chunks; ++c) {
+            if (chunk_offsets[c + 1] < chunk_offsets[c])
+                return fail(RL_ERR_INVALID, "rl_index_create: chunk_offsets must be ascending");
+            has_empty |= chunk_offsets[c + 1] == chunk_offsets[c];
+        }
+    } else {
+        n_chunks = n_rows;
+        host_offsets.resize((size_t)n_rows + 1);
+        for (int64_t i = 0; i <= n_rows; ++i) host_offsets[(size_t)i] = i;
+        chunk_offsets = host_offsets.data();
+    }
+    hipStream_t s = as_stream(stream);
+    rl_index* idx = new rl_index();
+    idx->n_rows = n_rows;
+    idx->dim = dim;
+    idx->n_chunks = n_chunks;
+    idx->metric = metric;
+    idx->has_empty_chunk = has_empty;
+    auto bail = [&](int code) { rl_index_destroy(idx); return code; };
+#define RL_IDX(expr) do { int _s = (expr); if (_s != RL_OK) return bail(_s); } while (0)
+#define RL_IDX_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(fail(_e == hipErrorOutOfMemory ? RL_ERR_NOMEM : RL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
+    int dev = 0;
+    RL_IDX_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    RL_IDX_HIP(hipGetDeviceProperties(&prop, dev));
+    idx->n_cu = prop.multiProcessorCount;
+    if (mem == RL_MEM_HOST) {
+        float* d = nullptr;
+        RL_IDX_HIP(hipMalloc(&d, std::max<size_t>((size_t)n_rows * dim * sizeof(float), 16)));
+        idx->E = d;
+        idx->owns_E = true;
+        if (n_rows) RL_IDX_HIP(hipMemcpyAsync(d, embeddings, (size_t)n_rows * dim * sizeof(float), hipMemcpyHostToDevice, s));
+    } else {
+        idx->E = embeddings;
+    }
+    RL_IDX_HIP(hipMalloc(&idx->offsets, (size_t)(n_chunks + 1) * sizeof(int64_t)));
+    RL_IDX_HIP(hipMemcpyAsync(idx->offsets, chunk_offsets, (size_t)(n_chunks + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    RL_IDX_HIP(hipMalloc(&idx->row_to_chunk, (size_t)(n_rows + 1) * sizeof(int32_t)));
+    RL_IDX(launch_row_to_chunk(idx->offsets, n_chunks, n_rows, idx->row_to_chunk, s));
+    if (metric == RL_COSINE) RL_IDX_HIP(hipMalloc(&idx->norm, std::max<size_t>((size_t)n_rows * sizeof(float), 16)));
+    if (metric == RL_L2) RL_IDX_HIP(hipMalloc(&idx->sumsq, std::max<size_t>((size_t)n_rows * sizeof(float), 16)));
+    if (idx->norm || idx->sumsq) RL_IDX(launch_row_norms(idx->E, n_rows, dim, idx->norm, idx->sumsq, s));
+    RL_IDX_HIP(hipStreamSynchronize(s));  // host_offsets / caller buffers may go away after return
+#undef RL_IDX
+#undef RL_IDX_HIP
+    *out = idx;
+    return RL_OK;
+}
+
+int rl_index_info(const rl_index* idx, int64_t* n_rows, int32_t* dim, int64_t* n_chunks, int* metric) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_index_info: null index");
+    if (n_rows) *n_rows = idx->n_rows;
+    if (dim) *dim = idx->dim;
+    if (n_chunks) *n_chunks = idx->n_chunks;
+    if (metric) *metric = idx->metric;
+    return RL_OK;
+}
+
+// ---- a6 + a7 -----------------------------------------------------------------------------------------
+namespace {
+
+// Similarity of `nb` device queries against every row -> idx->scores [nb x ld] (device).
+int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStream_t s) {
+    const int mode = scan_mode(idx->metric);
+    float* sc = idx->scores.as<float>();
+    if (nb > 4 && idx->dim == 1024) {
+        // MFMA tile kernel, 32 queries per corpus pass, raw dots; then the metric transform.
+        bool ok = true;
+        for (int32_t b0 = 0; b0 < nb && ok; b0 += 32) {
+            const int32_t nq = std::min<int32_t>(32, nb - b0);
+            const int st = launch_maxsim_stream(idx->E, idx->n_rows, idx->dim, d_q + (int64_t)b0 * idx->dim, nq,
+                                                idx->row_to_chunk, idx->offsets, idx->n_chunks, 1,
+                                                sc + (int64_t)b0 * ld, ld, idx->n_cu, s);
+            if (st == RL_ERR_UNSUPPORTED) ok = false; else RL_TRY(st);
+        }
+        if (ok) return launch_transform(sc, nb, idx->n_rows, ld, idx->norm, idx->sumsq, d_q, idx->dim, mode, s);
+    }
+    return launch_scan_rows(idx->E, idx->n_rows, idx->dim, d_q, nb, idx->norm, mode, sc, ld, s);
+}
+
+int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, float* d_scores, int32_t* d_rows,
+                       hipStream_t s) {
+    const int64_t n = idx->n_rows;
+    const int64_t ld = (n + 3) & ~int64_t(3);
+    if (n == 0) {  // empty index: every slot is padding (the reference returns ([], []), tests/test_search.py:76-85)
+        RL_TRY(launch_fill_f32(d_scores, -std::numeric_limits<float>::infinity(), (int64_t)B * k, s));
+        RL_HIP(hipMemsetAsync(d_rows, 0xff, (size_t)B * k * sizeof(int32_t), s));
+        return RL_OK;
+    }
+    const int64_t per_query = std::max<int64_t>(ld * 4, 1);
+    const int32_t batch = (int32_t)std::max<int64_t>(1, std::min<int64_t>(B, (int64_t)(SCORE_BATCH_BYTES / per_query)));
+    RL_TRY(idx->scores.reserve((size_t)batch * ld * sizeof(float)));
+    for (int32_t b0 = 0; b0 < B; b0 += batch) {
+        const int32_t nb = std::min<int32_t>(batch, B - b0);
+        RL_TRY(score_rows(idx, d_q + (int64_t)b0 * idx->dim, nb, ld, s));
+        RL_TRY(launch_topk(idx->scores.as<float>(), nb, n, ld, k, idx->ws, d_scores + (int64_t)b0 * k,
+                           d_rows + (int64_t)b0 * k, s));
+    }
+    return RL_OK;
+}
+
+int check_search_args(const rl_index* idx, const float* q, int32_t B, int32_t k, const char* who) {
+    if (!idx) return fail(RL_ERR_INVALID, std::string(who) + ": null index");
+    if (B < 0 || k < 1) return fail(RL_ERR_INVALID, std::string(who) + ": n_queries must be >= 0 and k >= 1");
+    if (k > K_MAX) return fail(RL_ERR_UNSUPPORTED, std::string(who) + ": k must be <= 2048");
+    if (B > 0 && !q) return fail(RL_ERR_INVALID, std::string(who) + ": null queries");
+    return RL_OK;
+}
+
+}  // namespace
+
+int rl_search_rows(rl_index* idx, const float* queries, int32_t B, int32_t k, float* out_scores, int32_t* out_rows,
+                   int mem, void* stream) {
+    RL_TRY(check_search_args(idx, queries, B, k, "rl_search_rows"));
+    if (B == 0) return RL_OK;
+    if (!out_scores || !out_rows) return fail(RL_ERR_INVALID, "rl_search_rows: null output");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    DevBuf t_q, t_s, t_r;
+    const float* d_q; float* d_s; int32_t* d_r;
+    RL_TRY(stage_in(queries, (size_t)B * idx->dim, mem, s, t_q, &d_q));
+    RL_TRY(stage_out_begin(out_scores, (size_t)B * k, mem, t_s, &d_s));
+    RL_TRY(stage_out_begin(out_rows, (size_t)B * k, mem, t_r, &d_r));
+    RL_TRY(search_rows_device(idx, d_q, B, k, d_s, d_r, s));
+    RL_TRY(stage_out_end(out_scores, (size_t)B * k, mem, s, t_s));
+    RL_TRY(stage_out_end(out_rows, (size_t)B * k, mem, s, t_r));
+    return finish(mem, s);
+}
+
+// ---- a6 + a7 + a8 --------------------------------------------------------------------------------------
+int rl_search_chunks(rl_index* idx, const float* queries, int32_t B, int32_t num_hits, int32_t k, float* out_scores,
+                     int32_t* out_chunks, int32_t* out_counts, int mem, void* stream) {
+    RL_TRY(check_search_args(idx, queries, B, k, "rl_search_chunks"));
+    if (num_hits < 1 || num_hits > K_MAX) return fail(RL_ERR_INVALID, "rl_search_chunks: num_hits must be in [1, 2048]");
+    if (B == 0) return RL_OK;
+    if (!out_scores || !out_chunks || !out_counts) return fail(RL_ERR_INVALID, "rl_search_chunks: null output");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    DevBuf t_q, t_s, t_c, t_n;
+    const float* d_q; float* d_s; int32_t* d_c; int32_t* d_n;
+    RL_TRY(stage_in(queries, (size_t)B * idx->dim, mem, s, t_q, &d_q));
+    RL_TRY(stage_out_begin(out_scores, (size_t)B * k, mem, t_s, &d_s));
+    RL_TRY(stage_out_begin(out_chunks, (size_t)B * k, mem, t_c, &d_c));
+    RL_TRY(stage_out_begin(out_counts, (size_t)B, mem, t_n, &d_n));
+    RL_TRY(idx->hits.reserve((size_t)B * num_hits * 8));
+    float* h_s = idx->hits.as<float>();
+    int32_t* h_r = reinterpret_cast<int32_t*>(h_s + (size_t)B * num_hits);
+    RL_TRY(search_rows_device(idx, d_q, B, num_hits, h_s, h_r, s));
+    RL_TRY(launch_group_chunk_max(h_s, h_r, B, num_hits, idx->offsets, idx->n_chunks, k, d_s, d_c, d_n, s));
+    RL_TRY(stage_out_end(out_scores, (size_t)B * k, mem, s, t_s));
+    RL_TRY(stage_out_end(out_chunks, (size_t)B * k, mem, s, t_c));
+    RL_TRY(stage_out_end(out_counts, (size_t)B, mem, s, t_n));
+    return finish(mem, s);
+}
+
+// ---- a9 --------------------------------------------------------------------------------------------------
+namespace {
+
+int maxsim_scores_device(rl_index* idx, const float* d_q, int32_t nq, float* d_out, hipStream_t s) {
+    if (idx->n_chunks == 0) return RL_OK;
+    int st = RL_ERR_UNSUPPORTED;
+    if (idx->n_rows > 0) {
+        if (idx->has_empty_chunk)
+            RL_TRY(launch_fill_f32(d_out, -std::numeric_limits<float>::infinity(), idx->n_chunks, s));
+        st = launch_maxsim_stream(idx->E, idx->n_rows, idx->dim, d_q, nq, idx->row_to_chunk, idx->offsets,
+                                  idx->n_chunks, 0, d_out, 0, idx->n_cu, s);
+    }
+    if (st == RL_ERR_UNSUPPORTED)
+        st = launch_maxsim_generic(idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, nullptr,
+                                   idx->n_chunks, 1, d_out, s);
+    return st;
+}
+
+}  // namespace
+
+int rl_maxsim_scores(rl_index* idx, const float* query_vecs, int32_t nq, float* out_scores, int mem, void* stream) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_maxsim_scores: null index");
+    if (nq < 1 || !query_vecs) return fail(RL_ERR_INVALID, "rl_maxsim_scores: need at least one query vector");
+    if (!out_scores) return fail(RL_ERR_INVALID, "rl_maxsim_scores: null output");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    DevBuf t_q, t_o;
+    const float* d_q; float* d_o;
+    RL_TRY(stage_in(query_vecs, (size_t)nq * idx->dim, mem, s, t_q, &d_q));
+    RL_TRY(stage_out_begin(out_scores, (size_t)idx->n_chunks, mem, t_o, &d_o));
+    RL_TRY(maxsim_scores_device(idx, d_q, nq, d_o, s));
+    RL_TRY(stage_out_end(out_scores, (size_t)idx->n_chunks, mem, s, t_o));
+    return finish(mem, s);
+}
+
+int rl_maxsim_topk(rl_index* idx, const float* query_vecs, int32_t nq, int32_t k, float* out_scores,
+                   int32_t* out_chunks, int mem, void* stream) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_maxsim_topk: null index");
+    if (nq < 1 || !query_vecs) return fail(RL_ERR_INVALID, "rl_maxsim_topk: need at least one query vector");
+    if (k < 1) return fail(RL_ERR_INVALID, "rl_maxsim_topk: k must be >= 1");
+    if (k > K_MAX) return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_topk: k must be <= 2048");
+    if (!out_scores || !out_chunks) return fail(RL_ERR_INVALID, "rl_maxsim_topk: null output");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    DevBuf t_q, t_s, t_c;
+    const float* d_q; float* d_s; int32_t* d_c;
+    RL_TRY(stage_in(query_vecs, (size_t)nq * idx->dim, mem, s, t_q, &d_q));
+    RL_TRY(stage_out_begin(out_scores, (size_t)k, mem, t_s, &d_s));
+    RL_TRY(stage_out_begin(out_chunks, (size_t)k, mem, t_c, &d_c));
+    RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));
+    RL_TRY(maxsim_scores_device(idx, d_q, nq, idx->scores.as<float>(), s));
+    RL_TRY(launch_topk(idx->scores.as<float>(), 1, idx->n_chunks, idx->n_chunks, k, idx->ws, d_s, d_c, s));
+    RL_TRY(stage_out_end(out_scores, (size_t)k, mem, s, t_s));
+    RL_TRY(stage_out_end(out_chunks, (size_t)k, mem, s, t_c));
+    return finish(mem, s);
+}
+
+int rl_maxsim_rerank(rl_index* idx, const float* query_vecs, int32_t n_queries, int32_t nq, const int32_t* candidates,
+                     int32_t n_cand, float* out_scores, int mem, void* stream) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_maxsim_rerank: null index");
+    if (n_queries < 0 || n_cand < 0 || nq < 1) return fail(RL_ERR_INVALID, "rl_maxsim_rerank: bad sizes");
+    if (n_queries == 0 || n_cand == 0) return RL_OK;
+    if (!query_vecs || !candidates || !out_scores) return fail(RL_ERR_INVALID, "rl_maxsim_rerank: null argument");
+    if (mem == RL_MEM_HOST) {
+        for (int64_t i = 0; i < (int64_t)n_queries * n_cand; ++i)
+            if (candidates[i] < 0 || candidates[i] >= idx->n_chunks)
+                return fail(RL_ERR_INVALID, "rl_maxsim_rerank: candidate chunk ordinal out of range");
+    }
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    DevBuf t_q, t_c, t_o;
+    const float* d_q; const int32_t* d_c; float* d_o;
+    RL_TRY(stage_in(query_vecs, (size_t)n_queries * nq * idx->dim, mem, s, t_q, &d_q));
+    RL_TRY(stage_in(candidates, (size_t)n_queries * n_cand, mem, s, t_c, &d_c));
+    RL_TRY(stage_out_begin(out_scores, (size_t)n_queries * n_cand, mem, t_o, &d_o));
+    int st = launch_maxsim_cand(idx->E, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s);
+    if (st == RL_ERR_UNSUPPORTED)
+        st = launch_maxsim_generic(idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, d_c, n_cand,
+                                   n_queries, d_o, s);
+    RL_TRY(st);
+    RL_TRY(stage_out_end(out_scores, (size_t)n_queries * n_cand, mem, s, t_o));
+    return finish(mem, s);
+}
+
+// ---- section 8e + generic selection ----------------------------------------------------------------------
+int rl_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_lists, int32_t n_queries, int32_t k_in,
+                  int32_t k, float* out_scores, int32_t* out_ids, int mem, void* stream) {
+    if (n_lists < 1 || n_queries < 0 || k_in < 1 || k < 1) return fail(RL_ERR_INVALID, "rl_merge_topk: bad sizes");
+    if (k > K_MAX) return fail(RL_ERR_UNSUPPORTED, "rl_merge_topk: k must be <= 2048");
+    if (n_queries == 0) return RL_OK;
+    if (!in_scores || !in_ids || !out_scores || !out_ids) return fail(RL_ERR_INVALID, "rl_merge_topk: null argument");
+    hipStream_t s = as_stream(stream);
+    const size_t n_in = (size_t)n_lists * n_queries * k_in, n_out = (size_t)n_queries * k;
+    DevBuf t_is, t_ii, t_os, t_oi;
+    const float* d_is; const int32_t* d_ii; float* d_os; int32_t* d_oi;
+    RL_TRY(stage_in(in_scores, n_in, mem, s, t_is, &d_is));
+    RL_TRY(stage_in(in_ids, n_in, mem, s, t_ii, &d_ii));
+    RL_TRY(stage_out_begin(out_scores, n_out, mem, t_os, &d_os));
+    RL_TRY(stage_out_begin(out_ids, n_out, mem, t_oi, &d_oi));
+    RL_TRY(launch_merge_topk(d_is, d_ii, n_lists, n_queries, k_in, k, d_os, d_oi, s));
+    RL_TRY(stage_out_end(out_scores, n_out, mem, s, t_os));
+    RL_TRY(stage_out_end(out_ids, n_out, mem, s, t_oi));
+    return finish(mem, s);
+}
+
+int rl_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32_t k, float* out_scores,
+            int32_t* out_ids, int mem, void* stream) {
+    if (n_queries < 0 || n < 0 || ld < n || k < 1) return fail(RL_ERR_INVALID, "rl_topk: bad sizes");
+    if (k > K_MAX) return fail(RL_ERR_UNSUPPORTED, "rl_topk: k must be <= 2048");
+    if (n_queries == 0) return RL_OK;
+    if ((n > 0 && !scores) || !out_scores || !out_ids) return fail(RL_ERR_INVALID, "rl_topk: null argument");
+    hipStream_t s = as_stream(stream);
+    const size_t n_in = (size_t)n_queries * ld, n_out = (size_t)n_queries * k;
+    DevBuf t_in, t_os, t_oi;
+    const float* d_in; float* d_os; int32_t* d_oi;
+    RL_TRY(stage_in(scores, n_in, mem, s, t_in, &d_in));
+    RL_TRY(stage_out_begin(out_scores, n_out, mem, t_os, &d_os));
+    RL_TRY(stage_out_begin(out_ids, n_out, mem, t_oi, &d_oi));
+    SelectWorkspace ws;  // one-off workspace: this entry point is for tests / external scorers
+    int st = launch_topk(d_in, n_queries, n, ld, k, ws, d_os, d_oi, s);
+    if (st == RL_OK) st = stage_out_end(out_scores, n_out, mem, s, t_os);
+    if (st == RL_OK) st = stage_out_end(out_ids, n_out, mem, s, t_oi);
+    (void)hipStreamSynchronize(s);  // the workspace is freed below
+    select_workspace_free(ws);
+    return st;
+}
+
+// ---- timing hook for bench.py ------------------------------------------------------------------------------
+int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int32_t iters, float* out_ms_total,
+                   void* stream) {
+    if (!idx || !q_dev || !out_ms_total || iters < 1 || nq < 1) return fail(RL_ERR_INVALID, "rl_time_kernel: bad arguments");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    const int64_t ld = (idx->n_rows + 3) & ~int64_t(3);
+    if (kind == 0) RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));
+    else RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)nq * ld * sizeof(float), 16)));
+    hipEvent_t e0, e1;
+    RL_HIP(hipEventCreate(&e0));
+    RL_HIP(hipEventCreate(&e1));
+    int st = RL_OK;
+    RL_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters && st == RL_OK; ++i) {
+        if (kind == 0) st = maxsim_scores_device(idx, q_dev, nq, idx->scores.as<float>(), s);
+        else st = score_rows(idx, q_dev, nq, ld, s);
+    }
+    RL_HIP(hipEventRecord(e1, s));
+    RL_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    RL_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *out_ms_total = ms;
+    return st;
+}
+
+}  // extern "C"

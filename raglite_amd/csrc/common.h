@@ -1,0 +1,123 @@
+// Shared declarations for libraglite_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <string>
+
+#include "raglite_hip.h"
+
+namespace rl {
+
+// ---- host-side error plumbing ---------------------------------------------------------------
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define RL_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return ::rl::fail(_e == hipErrorOutOfMemory ? RL_ERR_NOMEM : RL_ERR_HIP,         \
+                              std::string(#expr) + ": " + hipGetErrorString(_e));            \
+    } while (0)
+
+#define RL_TRY(expr)              \
+    do {                          \
+        int _s = (expr);          \
+        if (_s != RL_OK) return _s; \
+    } while (0)
+
+constexpr int WAVE = 64;
+constexpr int K_MAX = 2048;       // largest top-k the selection stage supports
+constexpr int HIST_BINS = 2048;   // top 11 bits of the orderable score key
+constexpr int CAND_CAP = 4096;    // threshold-bin candidates kept per query before the slow path
+constexpr int MERGE_CAP = 8192;   // n_lists * k_in accepted by rl_merge_topk
+
+// ---- device helpers ----------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+// Monotone map float -> uint32: larger float <=> larger key; every NaN -> 0 (ranks last).
+__device__ __forceinline__ uint32_t score_key(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return 0u;
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_score(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+// 64-bit total order: (score desc, id asc)  <=>  key64 desc.  key64 == 0 is the padding value.
+__device__ __forceinline__ uint64_t make_key64(float score, uint32_t id) {
+    return ((uint64_t)score_key(score) << 32) | (uint64_t)(0xffffffffu - id);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Wave-uniform id of the calling wave inside its block (provably uniform for the compiler).
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+#endif  // __HIPCC__
+
+// ---- kernel launchers (one per .hip file) -------------------------------------------------------
+int launch_synth(float* dst, int64_t start, int64_t count, uint64_t seed, int kind, hipStream_t s);
+
+int launch_pool_norm(const float* tokens, int32_t dim, const int64_t* span_begin, const int64_t* span_end,
+                     int64_t n_spans, int normalize, double eps, float* out_f32, uint16_t* out_f16,
+                     hipStream_t s);
+
+// scan.hip
+enum ScanMode { SCAN_RAW_DOT = 0, SCAN_COSINE = 1, SCAN_DOT = 2, SCAN_L2 = 3 };
+// scores[b * ld + row] for b < nb (nb <= 4 per launch handled inside), rows < n.
+int launch_scan_rows(const float* E, int64_t n, int32_t dim, const float* queries, int32_t nb,
+                     const float* row_norm, int mode, float* scores, int64_t ld, hipStream_t s);
+int launch_row_norms(const float* E, int64_t n, int32_t dim, float* norm, float* sumsq, hipStream_t s);
+int launch_cast_f16(const float* src, uint16_t* dst, int64_t count, hipStream_t s);
+int launch_fill_f32(float* dst, float value, int64_t count, hipStream_t s);
+// in-place metric transform of raw dots: scores[b*ld+i] (i<n), per-row norm / sumsq, per-query norm.
+int launch_transform(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm,
+                     const float* row_sumsq, const float* queries, int32_t dim, int mode, hipStream_t s);
+
+// select.hip
+struct SelectWorkspace {      // device buffers sized for `capacity_queries`
+    uint32_t* hist = nullptr; // [B][HIST_BINS + 8]  (bins, then counters)
+    uint64_t* sel = nullptr;  // [B][K_MAX]
+    uint64_t* cand = nullptr; // [B][CAND_CAP]
+    int32_t capacity_queries = 0;
+};
+int select_workspace_reserve(SelectWorkspace& ws, int32_t n_queries);
+void select_workspace_free(SelectWorkspace& ws);
+int launch_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32_t k,
+                SelectWorkspace& ws, float* out_scores, int32_t* out_ids, hipStream_t s);
+int launch_group_chunk_max(const float* hit_scores, const int32_t* hit_rows, int32_t n_queries,
+                           int32_t num_hits, const int64_t* chunk_offsets, int64_t n_chunks, int32_t k,
+                           float* out_scores, int32_t* out_chunks, int32_t* out_counts, hipStream_t s);
+int launch_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_lists, int32_t n_queries,
+                      int32_t k_in, int32_t k, float* out_scores, int32_t* out_ids, hipStream_t s);
+
+// maxsim*.hip
+int launch_row_to_chunk(const int64_t* chunk_offsets, int64_t n_chunks, int64_t n_rows, int32_t* row_to_chunk,
+                        hipStream_t s);
+// Fast path: dim == 1024, nq <= 32.  mode 0: chunk MaxSim scores out[n_chunks]; mode 1: raw row dots
+// out[q * ld + row].  Returns RL_ERR_UNSUPPORTED when the shape is outside the fast path.
+int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
+                         const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
+                         float* out, int64_t ld, int n_cu, hipStream_t s);
+// Any dim / nq: one wave per chunk (or per candidate), VALU dot products.
+int launch_maxsim_generic(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride_queries,
+                          const int64_t* chunk_offsets, const int32_t* candidates, int64_t n_items,
+                          int32_t n_queries, float* out, hipStream_t s);
+// Rerank fast path: dim == 128, nq <= 32 (MFMA, direct fragment loads).
+int launch_maxsim_cand(const float* D, int32_t dim, const float* Q, int32_t nq, const int64_t* chunk_offsets,
+                       const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s);
+
+}  // namespace rl

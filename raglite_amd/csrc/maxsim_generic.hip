@@ -1,0 +1,225 @@
+// a9: MaxSim for shapes outside the dim == 1024 streaming fast path.
+//
+//   maxsim_generic_kernel : any dim <= 4096, any nq <= 1024; one wave per (query, chunk) item; VALU dots
+//                           with a wave butterfly per (row, query vector).  Correctness backstop.
+//   maxsim_cand_kernel    : the rerank shape (SURVEY.md cfg 3): dim == 128, nq <= 32, many independent
+//                           queries x candidate lists per launch.  v_mfma_f32_16x16x4_f32 with the query's
+//                           32 x 128 matrix resident in 64 VGPRs as B fragments; candidate rows are loaded
+//                           straight into A-fragment layout (16 rows x 64 B per instruction = whole 64-B
+//                           sectors, every byte fetched exactly once), no LDS: a chunk is only 16 rows x
+//                           512 B per tile, and each wave handles 8 candidates of one query back to back.
+//                           Algorithmic bytes/query = n_cand * rows * 512 B (8.39 MB at 256 x 64);
+//                           algorithmic flops/query = 2 * nq * n_cand * rows * 128 (134 MFLOP).
+//
+// score[item] = sum_{i<nq} max_{j in chunk} Q[i].D[j]   (src/raglite/_search.py:143-149 generalised to
+// several query vectors; plugged in behind the reranker call at src/raglite/_search.py:394-396).
+#include "common.h"
+
+namespace rl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GEN_NQ_MAX = 1024;
+
+template <int NV, int VEC>
+__global__ __launch_bounds__(256) void maxsim_generic_kernel(const float* __restrict__ D, int dim,
+                                                              const float* __restrict__ Q, int nq,
+                                                              const int64_t* __restrict__ offsets,
+                                                              const int32_t* __restrict__ candidates,
+                                                              int64_t n_items, float* __restrict__ out) {
+    __shared__ float msh[4][GEN_NQ_MAX];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    float* m = msh[w];
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + w;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t item = wave0; item < n_items; item += n_waves) {
+        // one query per launch: item = chunk ordinal, or an index into this query's candidate list
+        const int64_t chunk = candidates ? (int64_t)candidates[item] : item;
+        const int64_t b = offsets[chunk], e = offsets[chunk + 1];
+        for (int i = lane; i < nq; i += 64) m[i] = -INFINITY;
+        for (int64_t r = b; r < e; ++r) {
+            float x[NV][VEC];
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int c = (v * 64 + lane) * VEC;
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) x[v][j] = 0.f;
+                if (c < dim) {
+                    if constexpr (VEC == 4) {
+                        const float4 t = *reinterpret_cast<const float4*>(D + r * (int64_t)dim + c);
+                        x[v][0] = t.x; x[v][1] = t.y; x[v][2] = t.z; x[v][3] = t.w;
+                    } else {
+                        x[v][0] = D[r * (int64_t)dim + c];
+                    }
+                }
+            }
+            for (int i = 0; i < nq; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const int c = (v * 64 + lane) * VEC;
+                    if (c < dim) {
+                        if constexpr (VEC == 4) {
+                            const float4 t = *reinterpret_cast<const float4*>(Q + (int64_t)i * dim + c);
+                            s = fmaf(x[v][0], t.x, s); s = fmaf(x[v][1], t.y, s);
+                            s = fmaf(x[v][2], t.z, s); s = fmaf(x[v][3], t.w, s);
+                        } else {
+                            s = fmaf(x[v][0], Q[(int64_t)i * dim + c], s);
+                        }
+                    }
+                }
+                s = wave_sum(s);
+                if (lane == 0) m[i] = fmaxf(m[i], s);
+            }
+        }
+        // fixed-order sum over the query vectors: lane-strided partial sums, then a butterfly
+        float t = 0.f;
+        for (int i = lane; i < nq; i += 64) t += m[i];
+        t = wave_sum(t);
+        if (lane == 0) out[item] = (e > b) ? t : -INFINITY;
+    }
+}
+
+template <int NV, int VEC>
+static int generic_t(const float* D, int32_t dim, const float* Q, int32_t nq, const int64_t* offsets,
+                     const int32_t* cand, int64_t n_items, float* out, hipStream_t s) {
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_items + 3) / 4, 256 * 8));
+    hipLaunchKernelGGL((maxsim_generic_kernel<NV, VEC>), dim3(blocks), dim3(256), 0, s, D, (int)dim, Q, (int)nq,
+                       offsets, cand, n_items, out);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// One launch per query (the generic path is a correctness backstop, not a throughput path).
+int launch_maxsim_generic(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride,
+                          const int64_t* offsets, const int32_t* candidates, int64_t n_items_per_query,
+                          int32_t n_queries, float* out, hipStream_t s) {
+    if (nq < 1 || nq > GEN_NQ_MAX) return fail(RL_ERR_UNSUPPORTED, "MaxSim: nq must be in [1, 1024]");
+    if (n_items_per_query <= 0 || n_queries <= 0) return RL_OK;
+    const bool vec4 = (dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(D) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(Q) & 15) == 0) && ((q_stride * 4) % 16 == 0);
+    for (int32_t qi = 0; qi < n_queries; ++qi) {
+        const float* Qq = Q + (int64_t)qi * q_stride;
+        const int32_t* cq = candidates ? candidates + (int64_t)qi * n_items_per_query : nullptr;
+        float* oq = out + (int64_t)qi * n_items_per_query;
+        int st = RL_ERR_UNSUPPORTED;
+        if (vec4) {
+            const int nv = (dim + 255) / 256;
+            if (nv <= 1) st = generic_t<1, 4>(D, dim, Qq, nq, offsets, cq, n_items_per_query, oq, s);
+            else if (nv <= 2) st = generic_t<2, 4>(D, dim, Qq, nq, offsets, cq, n_items_per_query, oq, s);
+            else if (nv <= 4) st = generic_t<4, 4>(D, dim, Qq, nq, offsets, cq, n_items_per_query, oq, s);
+            else if (nv <= 8) st = generic_t<8, 4>(D, dim, Qq, nq, offsets, cq, n_items_per_query, oq, s);
+            else if (nv <= 16) st = generic_t<16, 4>(D, dim, Qq, nq, offsets, cq, n_items_per_query, oq, s);
+        } else {
+            const int nv = (dim + 63) / 64;
+            if (nv <= 2) st = generic_t<2, 1>(D, dim, Qq, nq, offsets, cq, n_items_per_query, oq, s);
+            else if (nv <= 8) st = generic_t<8, 1>(D, dim, Qq, nq, offsets, cq, n_items_per_query, oq, s);
+            else if (nv <= 32) st = generic_t<32, 1>(D, dim, Qq, nq, offsets, cq, n_items_per_query, oq, s);
+        }
+        if (st == RL_ERR_UNSUPPORTED) return fail(RL_ERR_UNSUPPORTED, "MaxSim: dim too large for the generic kernel");
+        RL_TRY(st);
+    }
+    return RL_OK;
+}
+
+// ---- rerank fast path: dim == 128 ----------------------------------------------------------------------
+constexpr int CD = 128;   // embedding dimension of the rerank fast path
+constexpr int CPW = 8;    // candidates per wave
+
+template <int NQT>
+__global__ __launch_bounds__(256) void maxsim_cand_kernel(const float* __restrict__ D, const float* __restrict__ Q,
+                                                           int nq, const int64_t* __restrict__ offsets,
+                                                           const int32_t* __restrict__ candidates, int n_cand,
+                                                           int n_queries, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int fj = lane & 15, kq = lane >> 4;
+    const int groups = (n_cand + CPW - 1) / CPW;            // waves per query
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wave >= (int64_t)n_queries * groups) return;
+    const int qi = (int)(wave / groups);
+    const int c0 = (int)(wave % groups) * CPW;
+
+    // B fragments: lane (j, kq), MFMA 4*mm + tt uses Q[16h + j][16*mm + 4*kq + tt]
+    float qreg[NQT][32];
+    const float* Qq = Q + (int64_t)qi * nq * CD;
+#pragma unroll
+    for (int h = 0; h < NQT; ++h) {
+        const int qv = 16 * h + fj;
+        const int qc_ = qv < nq ? qv : nq - 1;
+#pragma unroll
+        for (int mm = 0; mm < 8; ++mm) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(Qq + (int64_t)qc_ * CD + 16 * mm + 4 * kq);
+            if (qv >= nq) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            qreg[h][4 * mm + 0] = v[0]; qreg[h][4 * mm + 1] = v[1];
+            qreg[h][4 * mm + 2] = v[2]; qreg[h][4 * mm + 3] = v[3];
+        }
+    }
+
+    for (int ci = c0; ci < c0 + CPW && ci < n_cand; ++ci) {
+        const int64_t chunk = candidates[(int64_t)qi * n_cand + ci];
+        const int64_t b = offsets[chunk], e = offsets[chunk + 1];
+        f32x4 mx[NQT];
+#pragma unroll
+        for (int h = 0; h < NQT; ++h) mx[h] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        for (int64_t r0 = b; r0 < e; r0 += 16) {
+            int64_t row = r0 + fj;            // A fragment: lane (i = fj, k = kq) supplies row i
+            if (row > e - 1) row = e - 1;     // clamp; masked below
+            const float* p = D + row * CD + 4 * kq;
+            f32x4 a[8];
+#pragma unroll
+            for (int mm = 0; mm < 8; ++mm) a[mm] = *reinterpret_cast<const f32x4*>(p + 16 * mm);
+            f32x4 acc[NQT];
+#pragma unroll
+            for (int h = 0; h < NQT; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int mm = 0; mm < 8; ++mm)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int h = 0; h < NQT; ++h)
+                        acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mm][tt], qreg[h][4 * mm + tt], acc[h], 0, 0, 0);
+            // C/D: column fj = query, row 4*kq + reg = corpus row r0 + 4*kq + reg
+#pragma unroll
+            for (int h = 0; h < NQT; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool valid = (r0 + 4 * kq + r) < e;
+                    mx[h][r] = fmaxf(mx[h][r], valid ? acc[h][r] : -INFINITY);
+                }
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int h = 0; h < NQT; ++h) {
+            float v = fmaxf(fmaxf(mx[h][0], mx[h][1]), fmaxf(mx[h][2], mx[h][3]));
+            v = fmaxf(v, __shfl_xor(v, 16, 64));
+            v = fmaxf(v, __shfl_xor(v, 32, 64));
+            s += (16 * h + fj < nq) ? v : 0.f;
+        }
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 8, 64);
+        if (lane == 0) out[(int64_t)qi * n_cand + ci] = (e > b) ? s : -INFINITY;
+    }
+}
+
+int launch_maxsim_cand(const float* D, int32_t dim, const float* Q, int32_t nq, const int64_t* offsets,
+                       const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s) {
+    if (dim != CD || nq < 1 || nq > 32) return RL_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
+    if (n_cand <= 0 || n_queries <= 0) return RL_OK;
+    const int64_t waves = (int64_t)n_queries * ((n_cand + CPW - 1) / CPW);
+    const int64_t blocks = (waves + 3) / 4;
+    if (blocks > 0x7fffffff) return fail(RL_ERR_UNSUPPORTED, "MaxSim rerank: too many (query, candidate) pairs per launch");
+    if (nq <= 16)
+        hipLaunchKernelGGL((maxsim_cand_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, D, Q, (int)nq, offsets,
+                           candidates, (int)n_cand, (int)n_queries, out);
+    else
+        hipLaunchKernelGGL((maxsim_cand_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, D, Q, (int)nq, offsets,
+                           candidates, (int)n_cand, (int)n_queries, out);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+}  // namespace rl

@@ -1,0 +1,411 @@
+// a7 / a8 / section 8e: exact top-k selection, per-chunk max grouping, shard merge.
+//
+// a7 replaces `ORDER BY dist LIMIT num_hits` (src/raglite/_search.py:75-79) with an EXACT selection
+// (the reference's HNSW index is approximate).  Order: (score descending, id ascending) -- SQL leaves
+// ties unspecified; the oracle and this file fix them to the lowest id.  NaN scores rank last.
+//
+// Every element is mapped to a unique 64-bit key (orderable score bits << 32 | ~id); top-k = the k
+// largest keys.  Three launches per batch of queries, no host round trip:
+//   1. hist    : 2048-bin histogram of the key's top 11 bits (LDS-privatised, nonzero bins flushed).
+//   2. filter  : every block locates the threshold bin from the histogram; elements in higher bins go
+//                straight to the `sel` list, elements in the threshold bin to the `cand` list.
+//   3. final   : one block per query bitonic-sorts the (few hundred) candidates, takes what is still
+//                needed, sorts the k survivors and writes (score, id).  If the threshold bin overflows
+//                CAND_CAP (massive ties, e.g. the reference's all-ones test corpus,
+//                tests/test_split_chunks.py:28) the block refines the threshold itself with two more
+//                radix passes over the scores and an index-ordered tie pass -- slow but exact.
+// Traffic: scores are read twice (4*N B each; 0.2 % of the 4*N*dim B scan that produced them).
+#include "common.h"
+
+namespace rl {
+
+constexpr int CNT_SEL = HIST_BINS + 0;   // counters live right after the bins
+constexpr int CNT_CAND = HIST_BINS + 1;
+constexpr int HIST_STRIDE = HIST_BINS + 8;
+
+// ---- block-wide helpers (256 or 1024 threads) -----------------------------------------------------
+
+// Inclusive prefix sum over the block; `scratch` holds >= blockDim/64 + 1 uint32.  Returns the inclusive
+// value for the caller and the block total through `total`.
+__device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t* scratch, uint32_t& total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) scratch[w] = x;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int i = 0; i < w; ++i) base += scratch[i];
+    uint32_t t = 0;
+    for (int i = 0; i < nw; ++i) t += scratch[i];
+    total = t;
+    return x + base;
+}
+
+// Given `hist[0..nbins)` in LDS (nbins <= 8 * blockDim), find the bin b* such that the number of
+// elements in bins > b* is < need <= that number + hist[b*].  Results in sh_out[0] = b*, sh_out[1] =
+// count above.  Every thread must call; ends with a barrier.  If the histogram holds fewer than `need`
+// elements, b* = 0 and above = total - hist[0].
+__device__ __forceinline__ void find_threshold_bin(const uint32_t* hist, int nbins, uint32_t need, uint32_t* scratch,
+                                                    uint32_t* sh_out) {
+    const int per = (nbins + (int)blockDim.x - 1) / (int)blockDim.x;  // bins per thread, walked from the top
+    const int hi = nbins - 1 - (int)threadIdx.x * per;
+    uint32_t s = 0;
+    for (int j = 0; j < per; ++j) {
+        const int b = hi - j;
+        if (b >= 0) s += hist[b];
+    }
+    uint32_t total;
+    const uint32_t incl = block_inclusive_scan(s, scratch, total);
+    const uint32_t excl = incl - s;
+    if (threadIdx.x == 0) { sh_out[0] = 0; sh_out[1] = total - hist[0]; }
+    __syncthreads();
+    if (excl < need && need <= incl) {
+        uint32_t cum = excl;
+        for (int j = 0; j < per; ++j) {
+            const int b = hi - j;
+            if (b < 0) break;
+            const uint32_t c = hist[b];
+            if (cum + c >= need) { sh_out[0] = (uint32_t)b; sh_out[1] = cum; break; }
+            cum += c;
+        }
+    }
+    __syncthreads();
+}
+
+// In-LDS bitonic sort, descending, n a power of two.
+__device__ __forceinline__ void bitonic_sort_desc(uint64_t* a, int n) {
+    for (int k = 2; k <= n; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint64_t x = a[i], y = a[ixj];
+                    const bool desc = ((i & k) == 0);
+                    if (desc ? (x < y) : (x > y)) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---- 1. histogram -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict__ scores, int64_t n, int64_t ld,
+                                                         uint32_t* __restrict__ ws_hist) {
+    __shared__ uint32_t h[HIST_BINS];
+    const int q = blockIdx.y;
+    for (int i = threadIdx.x; i < HIST_BINS; i += 256) h[i] = 0;
+    __syncthreads();
+    const float* s = scores + (int64_t)q * ld;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+        atomicAdd(&h[score_key(s[i]) >> 21], 1u);
+    __syncthreads();
+    uint32_t* g = ws_hist + (int64_t)q * HIST_STRIDE;
+    for (int i = threadIdx.x; i < HIST_BINS; i += 256)
+        if (h[i]) atomicAdd(&g[i], h[i]);
+}
+
+// ---- 2. filter ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topk_filter_kernel(const float* __restrict__ scores, int64_t n, int64_t ld,
+                                                           int32_t k, uint32_t* __restrict__ ws_hist,
+                                                           uint64_t* __restrict__ ws_sel,
+                                                           uint64_t* __restrict__ ws_cand) {
+    __shared__ uint32_t h[HIST_BINS];
+    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t thr[2];
+    const int q = blockIdx.y;
+    uint32_t* g = ws_hist + (int64_t)q * HIST_STRIDE;
+    for (int i = threadIdx.x; i < HIST_BINS; i += 256) h[i] = g[i];
+    __syncthreads();
+    const uint32_t need = (uint32_t)std::min<int64_t>(k, n);
+    find_threshold_bin(h, HIST_BINS, need, scratch, thr);
+    const uint32_t bstar = thr[0];
+    const float* s = scores + (int64_t)q * ld;
+    uint64_t* sel = ws_sel + (int64_t)q * K_MAX;
+    uint64_t* cand = ws_cand + (int64_t)q * CAND_CAP;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const float v = s[i];
+        const uint32_t bin = score_key(v) >> 21;
+        if (bin > bstar) {
+            const uint32_t p = atomicAdd(&g[CNT_SEL], 1u);
+            if (p < (uint32_t)K_MAX) sel[p] = make_key64(v, (uint32_t)i);
+        } else if (bin == bstar) {
+            const uint32_t p = atomicAdd(&g[CNT_CAND], 1u);
+            if (p < (uint32_t)CAND_CAP) cand[p] = make_key64(v, (uint32_t)i);
+        }
+    }
+}
+
+// ---- 3. final ----------------------------------------------------------------------------------------
+__device__ __forceinline__ void write_results(const uint64_t* sorted, int n_valid, int32_t k,
+                                              float* __restrict__ out_scores, int32_t* __restrict__ out_ids) {
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const uint64_t key = (i < n_valid) ? sorted[i] : 0ull;
+        if (key == 0ull) {
+            out_scores[i] = -INFINITY;
+            out_ids[i] = -1;
+        } else {
+            const uint32_t k32 = (uint32_t)(key >> 32);
+            out_scores[i] = k32 ? key_score(k32) : __uint_as_float(0x7fc00000u);
+            out_ids[i] = (int32_t)(0xffffffffu - (uint32_t)key);
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restrict__ scores, int64_t n, int64_t ld,
+                                                           int32_t k, const uint32_t* __restrict__ ws_hist,
+                                                           const uint64_t* __restrict__ ws_sel,
+                                                           const uint64_t* __restrict__ ws_cand,
+                                                           float* __restrict__ out_scores,
+                                                           int32_t* __restrict__ out_ids) {
+    __shared__ uint64_t buf[CAND_CAP];   // 32 KiB: candidate sort, then reused as the result sort buffer
+    __shared__ uint64_t fin[K_MAX];      // 16 KiB
+    __shared__ uint32_t h[HIST_BINS];    // 8 KiB
+    __shared__ uint32_t scratch[20];
+    __shared__ uint32_t thr[2];
+    __shared__ uint32_t sh_cnt[2];
+    const int q = blockIdx.x;
+    const uint32_t* g = ws_hist + (int64_t)q * HIST_STRIDE;
+    const uint64_t* sel = ws_sel + (int64_t)q * K_MAX;
+    const uint64_t* cand = ws_cand + (int64_t)q * CAND_CAP;
+    float* os = out_scores + (int64_t)q * k;
+    int32_t* oi = out_ids + (int64_t)q * k;
+    const uint32_t kk = (uint32_t)std::min<int64_t>(k, n);
+    const uint32_t n_sel = g[CNT_SEL];
+    const uint32_t n_cand = g[CNT_CAND];
+    const uint32_t need = kk - n_sel;  // >= 1 whenever kk >= 1 (the threshold bin is never empty)
+    for (int i = threadIdx.x; i < K_MAX; i += blockDim.x) fin[i] = (i < (int)n_sel) ? sel[i] : 0ull;
+    __syncthreads();
+    if (kk == 0) { write_results(fin, 0, k, os, oi); return; }
+
+    if (n_cand <= (uint32_t)CAND_CAP) {
+        int p2 = 64;
+        while (p2 < (int)n_cand) p2 <<= 1;
+        for (int i = threadIdx.x; i < p2; i += blockDim.x) buf[i] = (i < (int)n_cand) ? cand[i] : 0ull;
+        __syncthreads();
+        bitonic_sort_desc(buf, p2);
+        for (int i = threadIdx.x; i < (int)need; i += blockDim.x) fin[n_sel + i] = buf[i];
+        __syncthreads();
+    } else {
+        // Slow exact path: refine the 32-bit threshold inside bin b*, then take ties in index order.
+        // (Recompute b* from the histogram exactly as the filter kernel did.)
+        for (int i = threadIdx.x; i < HIST_BINS; i += blockDim.x) h[i] = g[i];
+        __syncthreads();
+        find_threshold_bin(h, HIST_BINS, kk, scratch, thr);
+        const uint32_t bstar = thr[0];
+        const float* s = scores + (int64_t)q * ld;
+        // pass A: bits [20:10] among keys in bin b*
+        for (int i = threadIdx.x; i < HIST_BINS; i += blockDim.x) h[i] = 0;
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint32_t key = score_key(s[i]);
+            if ((key >> 21) == bstar) atomicAdd(&h[(key >> 10) & 2047u], 1u);
+        }
+        __syncthreads();
+        find_threshold_bin(h, HIST_BINS, need, scratch, thr);
+        const uint32_t b1 = thr[0];
+        const uint32_t need1 = need - thr[1];
+        __syncthreads();
+        // pass B: bits [9:0] among keys matching (b*, b1)
+        for (int i = threadIdx.x; i < HIST_BINS; i += blockDim.x) h[i] = 0;
+        __syncthreads();
+        const uint32_t prefix22 = (bstar << 11) | b1;
+        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint32_t key = score_key(s[i]);
+            if ((key >> 10) == prefix22) atomicAdd(&h[key & 1023u], 1u);
+        }
+        __syncthreads();
+        find_threshold_bin(h, 1024, need1, scratch, thr);
+        const uint32_t t32 = (prefix22 << 10) | thr[0];
+        const uint32_t need_eq = need1 - thr[1];  // ties on the exact threshold value still to take
+        __syncthreads();
+        // pass C: keys in bin b* above t32 (any order) + the first `need_eq` keys == t32 by index.
+        if (threadIdx.x == 0) { sh_cnt[0] = 0; sh_cnt[1] = 0; }
+        __syncthreads();
+        for (int64_t base = 0; base < n; base += blockDim.x) {
+            const int64_t i = base + threadIdx.x;
+            uint32_t key = 0;
+            float v = 0.f;
+            if (i < n) { v = s[i]; key = score_key(v); }
+            const bool gt = (i < n) && ((key >> 21) == bstar) && (key > t32);
+            const bool eq = (i < n) && (key == t32);
+            if (gt) {
+                const uint32_t p = atomicAdd(&sh_cnt[0], 1u);
+                fin[n_sel + p] = make_key64(v, (uint32_t)i);
+            }
+            uint32_t tot;
+            const uint32_t incl = block_inclusive_scan(eq ? 1u : 0u, scratch, tot);
+            const uint32_t rank = sh_cnt[1] + incl - 1;  // 0-based rank of this tie in index order
+            __syncthreads();
+            if (eq && rank < need_eq) fin[n_sel + (need - need_eq) + rank] = make_key64(v, (uint32_t)i);
+            if (threadIdx.x == 0) sh_cnt[1] += tot;
+            __syncthreads();
+            if (sh_cnt[1] >= need_eq && sh_cnt[0] >= need - need_eq) break;  // uniform: both in LDS
+        }
+        __syncthreads();
+    }
+    // Sort the kk survivors (all distinct keys) and write them out.
+    int p2 = 64;
+    while (p2 < (int)kk) p2 <<= 1;
+    for (int i = threadIdx.x; i < p2; i += blockDim.x) buf[i] = (i < (int)kk) ? fin[i] : 0ull;
+    __syncthreads();
+    bitonic_sort_desc(buf, p2);
+    write_results(buf, (int)kk, k, os, oi);
+}
+
+int select_workspace_reserve(SelectWorkspace& ws, int32_t nq) {
+    if (nq <= ws.capacity_queries) return RL_OK;
+    select_workspace_free(ws);
+    RL_HIP(hipMalloc(&ws.hist, (size_t)nq * HIST_STRIDE * sizeof(uint32_t)));
+    RL_HIP(hipMalloc(&ws.sel, (size_t)nq * K_MAX * sizeof(uint64_t)));
+    RL_HIP(hipMalloc(&ws.cand, (size_t)nq * CAND_CAP * sizeof(uint64_t)));
+    ws.capacity_queries = nq;
+    return RL_OK;
+}
+
+void select_workspace_free(SelectWorkspace& ws) {
+    if (ws.hist) (void)hipFree(ws.hist);
+    if (ws.sel) (void)hipFree(ws.sel);
+    if (ws.cand) (void)hipFree(ws.cand);
+    ws = SelectWorkspace{};
+}
+
+int launch_topk(const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t k, SelectWorkspace& ws,
+                float* out_scores, int32_t* out_ids, hipStream_t s) {
+    if (nq <= 0 || k <= 0) return RL_OK;
+    if (k > K_MAX) return fail(RL_ERR_UNSUPPORTED, "top-k: k must be <= 2048");
+    if (n >= (int64_t)0x7fffffff) return fail(RL_ERR_UNSUPPORTED, "top-k: more than 2^31-2 elements per query");
+    RL_TRY(select_workspace_reserve(ws, nq));
+    RL_HIP(hipMemsetAsync(ws.hist, 0, (size_t)nq * HIST_STRIDE * sizeof(uint32_t), s));
+    if (n > 0) {
+        const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((n + 4095) / 4096, nq >= 64 ? 64 : 512));
+        hipLaunchKernelGGL(topk_hist_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, ws.hist);
+        hipLaunchKernelGGL(topk_filter_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, k, ws.hist, ws.sel,
+                           ws.cand);
+    }
+    hipLaunchKernelGGL(topk_final_kernel, dim3(nq), dim3(1024), 0, s, scores, n, ld, k, ws.hist, ws.sel, ws.cand,
+                       out_scores, out_ids);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// ---- a8: max(sim) GROUP BY chunk ORDER BY max DESC LIMIT k  (src/raglite/_search.py:143-149) -----------
+// Input: the a7 hits of each query, already sorted by (score desc, row asc).  A hit is kept iff no
+// earlier hit belongs to the same chunk -- the first hit of a chunk carries the chunk's max, and the
+// kept hits stay in (max desc, chunk ordinal asc) order because rows of a lower chunk ordinal are lower.
+__global__ __launch_bounds__(256) void group_chunk_max_kernel(const float* __restrict__ hit_scores,
+                                                               const int32_t* __restrict__ hit_rows,
+                                                               int32_t num_hits,
+                                                               const int64_t* __restrict__ chunk_offsets,
+                                                               int64_t n_chunks, int32_t k,
+                                                               float* __restrict__ out_scores,
+                                                               int32_t* __restrict__ out_chunks,
+                                                               int32_t* __restrict__ out_counts) {
+    __shared__ int32_t chunk[K_MAX];
+    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t running;
+    const int q = blockIdx.x;
+    const float* hs = hit_scores + (int64_t)q * num_hits;
+    const int32_t* hr = hit_rows + (int64_t)q * num_hits;
+    for (int i = threadIdx.x; i < num_hits; i += 256) {
+        const int32_t r = hr[i];
+        int32_t c = -1;
+        if (r >= 0) {
+            if (chunk_offsets) {  // largest c with offsets[c] <= r
+                int64_t lo = 0, hi = n_chunks;  // invariant: offsets[lo] <= r < offsets[hi]
+                while (hi - lo > 1) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (chunk_offsets[mid] <= (int64_t)r) lo = mid; else hi = mid;
+                }
+                c = (int32_t)lo;
+            } else {
+                c = r;
+            }
+        }
+        chunk[i] = c;
+    }
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    for (int base = 0; base < num_hits; base += 256) {
+        const int i = base + threadIdx.x;
+        bool keep = false;
+        int32_t c = -1;
+        if (i < num_hits) {
+            c = chunk[i];
+            keep = c >= 0;
+            for (int j = 0; keep && j < i; ++j) keep = chunk[j] != c;
+        }
+        uint32_t tot;
+        const uint32_t incl = block_inclusive_scan(keep ? 1u : 0u, scratch, tot);
+        const uint32_t pos = running + incl - 1;
+        __syncthreads();
+        if (keep && pos < (uint32_t)k) {
+            out_scores[(int64_t)q * k + pos] = hs[i];
+            out_chunks[(int64_t)q * k + pos] = c;
+        }
+        if (threadIdx.x == 0) running += tot;
+        __syncthreads();
+    }
+    const uint32_t count = running < (uint32_t)k ? running : (uint32_t)k;
+    for (int i = count + threadIdx.x; i < k; i += 256) {
+        out_scores[(int64_t)q * k + i] = -INFINITY;
+        out_chunks[(int64_t)q * k + i] = -1;
+    }
+    if (threadIdx.x == 0) out_counts[q] = (int32_t)count;
+}
+
+int launch_group_chunk_max(const float* hit_scores, const int32_t* hit_rows, int32_t nq, int32_t num_hits,
+                           const int64_t* chunk_offsets, int64_t n_chunks, int32_t k, float* out_scores,
+                           int32_t* out_chunks, int32_t* out_counts, hipStream_t s) {
+    if (nq <= 0) return RL_OK;
+    if (num_hits > K_MAX) return fail(RL_ERR_UNSUPPORTED, "group-by-chunk: num_hits must be <= 2048");
+    hipLaunchKernelGGL(group_chunk_max_kernel, dim3(nq), dim3(256), 0, s, hit_scores, hit_rows, num_hits,
+                       chunk_offsets, n_chunks, k, out_scores, out_chunks, out_counts);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// ---- section 8e: merge of per-shard top-k lists ---------------------------------------------------------
+__global__ __launch_bounds__(1024) void merge_topk_kernel(const float* __restrict__ in_scores,
+                                                           const int32_t* __restrict__ in_ids, int32_t n_lists,
+                                                           int32_t n_queries, int32_t k_in, int32_t k,
+                                                           float* __restrict__ out_scores,
+                                                           int32_t* __restrict__ out_ids) {
+    __shared__ uint64_t buf[MERGE_CAP];
+    const int q = blockIdx.x;
+    const int total = n_lists * k_in;
+    int p2 = 64;
+    while (p2 < total) p2 <<= 1;
+    for (int i = threadIdx.x; i < p2; i += blockDim.x) {
+        uint64_t key = 0ull;
+        if (i < total) {
+            const int l = i / k_in, j = i % k_in;
+            const int64_t src = ((int64_t)l * n_queries + q) * k_in + j;
+            const int32_t id = in_ids[src];
+            if (id >= 0) key = make_key64(in_scores[src], (uint32_t)id);
+        }
+        buf[i] = key;
+    }
+    __syncthreads();
+    bitonic_sort_desc(buf, p2);
+    write_results(buf, total < k ? total : k, k, out_scores + (int64_t)q * k, out_ids + (int64_t)q * k);
+}
+
+int launch_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_lists, int32_t nq, int32_t k_in,
+                      int32_t k, float* out_scores, int32_t* out_ids, hipStream_t s) {
+    if (nq <= 0 || k <= 0) return RL_OK;
+    if ((int64_t)n_lists * k_in > MERGE_CAP) return fail(RL_ERR_UNSUPPORTED, "merge: n_lists * k_in must be <= 8192");
+    hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(1024), 0, s, in_scores, in_ids, n_lists, nq, k_in, k,
+                       out_scores, out_ids);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+}  // namespace rl

@@ -1,0 +1,129 @@
+"""The oracle and the host mirror against the golden vectors produced by the REFERENCE's own
+`_embed.py` (oracle/make_golden.py).  CPU only: pooling arithmetic here is the oracle's NumPy;
+the GPU run of the same fixtures is tests/test_gpu_parity.py::test_embed_golden_*.
+"""
+
+import json
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from oracle.fake_embedder import FakeLlama, make_sentences
+from raglite_amd import _embed as mirror
+
+
+def _manifest(golden_dir):
+    return json.loads((golden_dir / "manifest.json").read_text())
+
+
+def _cases(kind):
+    from pathlib import Path
+
+    man = json.loads((Path(__file__).parent / "golden" / "manifest.json").read_text())
+    return [k for k, v in man.items() if v["kind"] == kind]
+
+
+def _oracle_late_chunking(sentences, emb, normalize):
+    """The oracle's end-to-end restatement of `_embed.py:16-141` (token counting via the mirror's
+    sentinel logic is checked separately below; here it is restated in the reference's own shape)."""
+    sentinel_tokens = [t for t in emb.tokenize(f"A⊕B ⊕ C.\n⊕D".encode(), add_bos=False)
+                       if "⊕" in emb.detokenize([t]).decode()]
+    num_tokens_list, batch, batch_len = [], [], 0
+    for i, s in enumerate(sentences):
+        batch.append(s)
+        batch_len += len(s)
+        if i == len(sentences) - 1 or batch_len > (emb.n_ctx() // 2):
+            toks = np.asarray(emb.tokenize("⊕".join(batch).encode(), add_bos=False), dtype=np.intp)
+            for st in sentinel_tokens[1:]:
+                toks[toks == st] = sentinel_tokens[0]
+            idx = np.where(toks == sentinel_tokens[0])[0]
+            num_tokens_list.extend(np.diff(idx, prepend=0, append=len(toks)).tolist())
+            batch, batch_len = [], 0
+    num_tokens = np.asarray(num_tokens_list, dtype=np.intp)
+    rows = []
+    for s0, c0, e0 in oracle.create_segments(num_tokens, emb.n_ctx(), emb.n_batch):
+        seg = np.asarray(emb.embed("".join(sentences[s0:e0])))
+        rows.append(oracle.pool_segment(seg, num_tokens[s0:e0], c0 - s0))
+    x = np.vstack(rows)
+    if normalize:
+        x = oracle.l2_normalize(x)
+    return oracle.to_fp16(x), num_tokens
+
+
+@pytest.mark.parametrize("name", _cases("late_chunking"))
+def test_oracle_reproduces_reference_late_chunking(golden_dir, name):
+    meta = _manifest(golden_dir)[name]
+    golden = np.load(golden_dir / f"{name}.npz")["output"]
+    emb = FakeLlama(dim=meta["dim"], n_ctx=meta["n_ctx"], n_batch=meta["n_batch"], seed=meta["embedder_seed"])
+    sentences = make_sentences(meta["sentence_seed"], meta["n_sentences"])
+    out, _ = _oracle_late_chunking(sentences, emb, meta["normalize"])
+    assert out.dtype == np.float16 and out.shape == golden.shape
+    assert np.array_equal(out.view(np.uint16), golden.view(np.uint16)), "oracle differs from the reference bit-wise"
+
+
+@pytest.mark.parametrize("name", _cases("late_chunking"))
+def test_host_mirror_spans_reproduce_reference(golden_dir, name):
+    """The mirror's own bookkeeping (token counts, segment plan, row split) + oracle pooling on its spans
+    must give the reference's bits: pins everything in raglite_amd/_embed.py except the kernel."""
+    meta = _manifest(golden_dir)[name]
+    golden = np.load(golden_dir / f"{name}.npz")["output"]
+    emb = FakeLlama(dim=meta["dim"], n_ctx=meta["n_ctx"], n_batch=meta["n_batch"], seed=meta["embedder_seed"])
+    sentences = make_sentences(meta["sentence_seed"], meta["n_sentences"])
+    tokens, b, e = mirror.plan_document(sentences, emb)
+    assert tokens.dtype == np.float32 and len(b) == len(e) == len(sentences)
+    assert emb.embed_calls == meta["embed_calls"]  # same number of segments as the reference made
+    _, out = oracle.pool_norm_cast(tokens, b, e, normalize=meta["normalize"])
+    assert np.array_equal(out.view(np.uint16), golden.view(np.uint16))
+
+
+@pytest.mark.parametrize("name", _cases("batch"))
+def test_oracle_reproduces_reference_batch_pool(golden_dir, name):
+    meta = _manifest(golden_dir)[name]
+    golden = np.load(golden_dir / f"{name}.npz")["output"]
+    emb = FakeLlama(dim=meta["dim"], n_ctx=meta["n_ctx"], seed=meta["embedder_seed"])
+    strings = make_sentences(meta["sentence_seed"], meta["n_sentences"])
+    out = oracle.embed_string_batch_pool([emb.token_matrix(s) for s in strings], normalize=meta["normalize"])
+    assert np.array_equal(out.view(np.uint16), golden.view(np.uint16))
+    # span form with the eps guard (what the kernel computes for this path)
+    mats = [emb.token_matrix(s) for s in strings]
+    ends = np.cumsum([len(m) for m in mats])
+    begins = ends - np.asarray([len(m) for m in mats])
+    _, out2 = oracle.pool_norm_cast(np.vstack(mats), begins, ends, normalize=meta["normalize"],
+                                    eps=float(np.finfo(np.float64).eps))
+    assert np.array_equal(out2.view(np.uint16), golden.view(np.uint16))
+
+
+def test_reference_behavioural_contract(golden_dir):
+    """`tests/test_embed.py:19-26` of the reference: fp16, finite, unit norm (rtol 1e-3)."""
+    for name, meta in _manifest(golden_dir).items():
+        g = np.load(golden_dir / f"{name}.npz")["output"]
+        assert g.dtype == np.float16 and np.all(np.isfinite(g)) and len(g) == meta["n_sentences"]
+        if meta["normalize"]:
+            assert np.allclose(np.linalg.norm(g.astype(np.float64), axis=1), 1.0, rtol=1e-3)
+
+
+def test_plan_segments_matches_oracle_random():
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        n = int(rng.integers(1, 80))
+        toks = rng.integers(0, 60, size=n).astype(np.intp)
+        n_ctx = int(rng.integers(80, 600))
+        if toks.max() > min(n_ctx, n_ctx) - 16 - round(0.382 * (n_ctx - 16)):
+            continue  # the reference loops forever on an over-long sentence; the mirror documents its deviation
+        assert mirror.plan_segments(toks, n_ctx, n_ctx) == oracle.create_segments(toks, n_ctx, n_ctx)
+
+
+def test_split_rows_matches_oracle_random():
+    rng = np.random.default_rng(1)
+    for _ in range(300):
+        n = int(rng.integers(1, 40))
+        toks = rng.integers(1, 50, size=n).astype(np.intp)
+        rows = int(toks.sum() + rng.integers(0, 5))
+        a, b = mirror.split_rows(rows, toks), oracle.largest_remainder_sizes(rows, toks)
+        assert np.array_equal(a, b) and a.sum() == rows
+
+
+def test_plan_segments_oversized_sentence_terminates():
+    plan = mirror.plan_segments(np.asarray([5, 900, 7], dtype=np.intp), 128, 128)
+    assert [p[1:] for p in plan] == [(0, 1), (1, 2), (2, 3)]
