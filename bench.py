@@ -1,0 +1,195 @@
+"""bench.py -- the headline metric of BASELINE.json on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): MaxSim late-interaction retrieval, 32 query vectors x 1,000,000 chunk
+vectors, d = 1024, fp32, exact top-100 chunks -- the shape `metric` is quoted on.  The corpus is
+synthetic U(-1,1) (counter-based generator, identical bits on CPU and GPU) grouped into ragged chunks
+of 1..15 rows (mean 8, RAGLite's multi-vector chunks), resident in HBM before the timed region.
+
+A step = one batch of QUERIES_PER_STEP queries pushed through the hot path: per query one
+`rl_maxsim_topk` (MFMA streaming kernel + exact selection) on device pointers, then per batch the
+exchange step (N > 1: ONE RCCL all-gather of every rank's local top-k, (QB, k, 2) int32) and the host
+merge.  value = queries / second over the whole job.
+
+N > 1: the 1 M-row corpus is sharded by chunk across the ranks (strong scaling on the metric's own
+shape); every rank receives the same queries.
+
+Extra objects in the JSON line: `roofline` (dominant kernel, HIP-event timed on its launch stream),
+`cpu_baseline` (the NumPy oracle on the host cores, rank 0, N = 1 only), `recall_at_100`.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+N_ROWS, DIM, NQ, TOPK = 1_000_000, 1024, 32, 100
+QUERIES_PER_STEP = 16
+SEED_CORPUS, SEED_QUERY, SEED_CHUNKS = 6, 60, 600
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def chunk_offsets(n_rows: int) -> np.ndarray:
+    """Ragged chunk sizes U{1..15} from the shared counter-based generator (deterministic everywhere)."""
+    from oracle.oracle import synth_bits
+
+    sizes = (synth_bits(SEED_CHUNKS, 0, n_rows // 4) >> np.uint64(40)) % np.uint64(15) + np.uint64(1)
+    off = np.concatenate(([0], np.cumsum(sizes.astype(np.int64))))
+    off = off[off < n_rows]
+    return np.concatenate((off, [n_rows])).astype(np.int64)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=N_ROWS, help=argparse.SUPPRESS)  # debugging only
+    ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import raglite_amd
+    from raglite_amd._sharded import ShardedIndex, shard_bounds_by_chunk
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    raglite_amd.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n_rows = args.rows
+    off = chunk_offsets(n_rows)
+    c_lo, c_hi = shard_bounds_by_chunk(off, world)[rank]
+    r_lo, r_hi = int(off[c_lo]), int(off[c_hi])
+    local_off = off[c_lo : c_hi + 1] - off[c_lo]
+    # ---- synthetic corpus shard, generated in HBM (element (r, c) is stream element r*DIM + c) ----------
+    E = torch.empty((r_hi - r_lo, DIM), dtype=torch.float32, device=dev)
+    raglite_amd.synth_fill(E, seed=SEED_CORPUS, start=r_lo * DIM)
+    index = raglite_amd.DeviceIndex(E, local_off, metric="dot")
+    sharded = ShardedIndex(index, row_base=r_lo, chunk_base=c_lo, local_chunk_offsets=local_off)
+    n_batches = 4  # distinct query batches, cycled
+    queries = torch.empty((n_batches, QUERIES_PER_STEP, NQ, DIM), dtype=torch.float32, device=dev)
+    raglite_amd.synth_fill(queries, seed=SEED_QUERY)
+    torch.cuda.synchronize()
+
+    def step(i: int):
+        return sharded.maxsim_topk_batch(queries[i % n_batches], TOPK)
+
+    def fence() -> None:
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_queries = args.steps * QUERIES_PER_STEP
+    result = {
+        "metric": "queries/sec, MaxSim 32x1M d=1024 exact top-100",
+        "value": total_queries / elapsed,
+        "unit": "queries/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"maxsim_{NQ}x{n_rows}_d{DIM}_top{TOPK}_ragged_chunks_1to15",
+            "queries_per_step": QUERIES_PER_STEP,
+            "n_chunks": int(len(off) - 1),
+            "parallelism": f"corpus sharded by chunk over {world} GPU(s); one all-gather of local top-k per step",
+        },
+    }
+
+    # ---- roofline of the dominant kernel: HIP events on the launch stream, kernel only -----------------
+    iters = 20
+    index.time_kernel(0, queries[0, 0], 3)  # warm
+    ms = index.time_kernel(0, queries[0, 0], iters) / iters
+    algo_bytes = 4.0 * (r_hi - r_lo) * DIM  # 4*N*d bytes per corpus pass
+    achieved = algo_bytes / (ms * 1e-3) / 1e9
+    traffic = None
+    tf = ROOT / "profiles" / "traffic.json"  # filled from a separate rocprofv3 --pmc pass
+    if tf.exists():
+        traffic = json.loads(tf.read_text()).get("maxsim_stream_bytes_per_launch")
+    result["roofline"] = {
+        "bound": "hbm", "kernel": "maxsim_stream_kernel<2,0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+        "kernel_ms": ms, "algorithmic_bytes_per_launch": algo_bytes,
+        "mfma_fp32_tflops": 2.0 * NQ * (r_hi - r_lo) * DIM / (ms * 1e-3) / 1e12,
+    }
+
+    # ---- recall@100 and CPU baseline: NumPy oracle on the host cores (rank 0, N = 1) --------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+
+        E_host = E.cpu().numpy()
+        q_host = queries[(args.steps - 1) % n_batches].cpu().numpy()
+        try:
+            from threadpoolctl import threadpool_info
+
+            cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        except Exception:  # noqa: BLE001
+            cores = os.cpu_count() or 1
+        oracle.maxsim_topk(E_host[:1000], np.arange(0, 1001, 8), q_host[0], 10, np.float32)  # warm BLAS
+        n_cpu = 2
+        t0 = time.perf_counter()
+        refs = [oracle.maxsim_topk(E_host, off, q_host[b], TOPK, np.float32) for b in range(n_cpu)]
+        cpu_s = (time.perf_counter() - t0) / n_cpu
+        gpu_scores, gpu_ids = last
+        recalls, errs = [], []
+        for b in range(n_cpu):
+            rs, rc = refs[b]
+            recalls.append(len(set(rc.tolist()) & set(gpu_ids[b].tolist())) / TOPK)
+            errs.append(float(np.max(np.abs(np.sort(rs)[::-1] - np.sort(gpu_scores[b])[::-1]))))
+        result["recall_at_100"] = float(np.mean(recalls))
+        result["score_max_abs_err"] = float(np.max(errs))
+        result["cpu_baseline"] = {
+            "value": 1.0 / cpu_s, "unit": "queries/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n_cpu} queries of the full workload ({NQ}x{n_rows}x{DIM} fp32, ragged chunks, top-{TOPK}) "
+                      f"through oracle/oracle.py (NumPy sgemm + maximum.reduceat + lexsort), host cpu_count={os.cpu_count()}",
+        }
+    if rank == 0:
+        print(json.dumps(result))
+    index.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

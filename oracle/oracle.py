@@ -257,11 +257,12 @@ def topk_desc(scores: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
     """Exact top-k by (score descending, index ascending).  NaNs rank last.
 
     `ORDER BY dist LIMIT k` (`_search.py:77-79`) with the tie order SQL leaves unspecified
-    fixed to the lowest index."""
+    fixed to the lowest index; NaN ranks after -inf."""
     scores = np.asarray(scores)
     k = min(k, len(scores))
-    key = np.where(np.isnan(scores), -np.inf, scores)
-    order = np.lexsort((np.arange(len(scores)), -key))[:k]
+    nan = np.isnan(scores)
+    key = np.where(nan, -np.inf, scores)
+    order = np.lexsort((np.arange(len(scores)), -key, nan))[:k]  # NaN strictly after -inf
     return scores[order], order.astype(np.int64)
 
 
@@ -338,8 +339,9 @@ def merge_topk(scores_list: list[np.ndarray], ids_list: list[np.ndarray], k: int
     (score desc, id asc): identical to the single-shard result."""
     s = np.concatenate(scores_list)
     i = np.concatenate(ids_list).astype(np.int64)
-    key = np.where(np.isnan(s), -np.inf, s)
-    order = np.lexsort((i, -key))[:k]
+    nan = np.isnan(s)
+    key = np.where(nan, -np.inf, s)
+    order = np.lexsort((i, -key, nan))[:k]
     return s[order], i[order]
 
 

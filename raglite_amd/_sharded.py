@@ -118,6 +118,8 @@ class ShardedIndex:
                          for c in cols], axis=-1)
 
     def _exchange(self, scores, ids_local, base: int, extra=None):
+        if hasattr(scores, "is_cuda") and scores.is_cuda:
+            return self._exchange_device(scores, ids_local, base)
         s = _to_numpy(scores).astype(np.float32, copy=False)
         i = _to_numpy(ids_local).astype(np.int64)
         s2 = s.reshape(1, -1) if s.ndim == 1 else s
@@ -127,6 +129,26 @@ class ShardedIndex:
         g = self._all_gather(self._pack(*cols))  # (world, B, k, ncols)
         gs = np.ascontiguousarray(g[..., 0]).view(np.float32)
         return gs, g[..., 1], (g[..., 2] if extra is not None else None), s.ndim == 1
+
+    def _exchange_device(self, scores, ids_local, base: int):
+        """CUDA tensors in: pack (score bits, global id) on the device, ONE all-gather (RCCL), one D2H."""
+        import torch
+        import torch.distributed as dist
+
+        single = scores.dim() == 1
+        s2 = scores.reshape(1, -1) if single else scores
+        i2 = ids_local.reshape(1, -1) if single else ids_local
+        gid = torch.where(i2 >= 0, i2 + base, torch.full_like(i2, -1))
+        packed = torch.stack([s2.contiguous().view(torch.int32), gid.to(torch.int32)], dim=-1).contiguous()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            world = dist.get_world_size(self.group)
+            out = torch.empty((world, *packed.shape), dtype=packed.dtype, device=packed.device)
+            dist.all_gather_into_tensor(out, packed, group=self.group)
+        else:
+            out = packed[None]
+        g = out.cpu().numpy()
+        gs = np.ascontiguousarray(g[..., 0]).view(np.float32)
+        return gs, g[..., 1], None, single
 
     # -- searches ----------------------------------------------------------------------------------------
     def search_rows(self, queries, k: int):
@@ -142,6 +164,19 @@ class ShardedIndex:
         gs, gi, _, _ = self._exchange(s, c, self.chunk_base)
         ms, mi = merge_topk_host(gs, gi, k)
         return ms[0], mi[0]
+
+    def maxsim_topk_batch(self, query_batch, k: int):
+        """A batch of queries (QB, nq, dim): QB local launches, ONE all-gather of (QB, k, 2) int32, one
+        host merge.  Returns (scores (QB,k), global chunk ordinals (QB,k))."""
+        outs = [self.local.maxsim_topk(query_batch[b], k) for b in range(len(query_batch))]
+        if hasattr(outs[0][0], "is_cuda"):
+            import torch
+
+            s, c = torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs])
+        else:
+            s, c = np.stack([o[0] for o in outs]), np.stack([o[1] for o in outs])
+        gs, gi, _, _ = self._exchange(s, c, self.chunk_base)
+        return merge_topk_host(gs, gi, k)
 
     def search_chunks(self, queries, num_hits: int, k: int):
         """Reference two-stage semantics across shards: gather each rank's top-`num_hits` rows with their

@@ -1,0 +1,82 @@
+"""The C-ABI library loads on a CPU-only box and exports exactly what include/raglite_hip.h declares.
+Only argument validation that returns before the first HIP call is exercised here."""
+
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from raglite_amd import _abi
+
+HEADER = Path(__file__).resolve().parent.parent / "include" / "raglite_hip.h"
+
+
+def _declared():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    return sorted(set(re.findall(r"\b(rl_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    declared = _declared()
+    assert len(declared) >= 20
+    handle = C.CDLL(str(_abi.LIB_PATH))
+    for name in declared:
+        assert hasattr(handle, name), f"{name} declared in raglite_hip.h but not exported"
+    assert sorted(_abi.EXPORTED_SYMBOLS) == declared, "ctypes signatures out of sync with the header"
+
+
+def test_version_and_error_channel():
+    lib = _abi.lib()
+    assert lib.rl_version() == 100
+    # dim <= 0 is rejected before any HIP call
+    st = lib.rl_pool_norm(None, 0, 0, None, None, 0, 1, 0.0, None, None, _abi.MEM_HOST, None)
+    assert st == _abi.RL_ERR_INVALID
+    assert "rl_pool_norm" in _abi.last_error()
+    with pytest.raises(ValueError, match="rl_pool_norm"):
+        _abi.check(st)
+
+
+def test_argument_validation_without_gpu():
+    lib = _abi.lib()
+    tok = np.zeros((4, 8), dtype=np.float32)
+    b = np.array([0, 3], dtype=np.int64)
+    e = np.array([2, 9], dtype=np.int64)  # 9 > 4 rows
+    out = np.zeros((2, 8), dtype=np.float32)
+    st = lib.rl_pool_norm(tok.ctypes.data, 4, 8, b.ctypes.data, e.ctypes.data, 2, 1, 0.0, out.ctypes.data, None,
+                          _abi.MEM_HOST, None)
+    assert st == _abi.RL_ERR_INVALID and "span" in _abi.last_error()
+    st = lib.rl_pool_norm(tok.ctypes.data, 4, 8, b.ctypes.data, e.ctypes.data, 2, 1, 0.0, None, None,
+                          _abi.MEM_HOST, None)
+    assert st == _abi.RL_ERR_INVALID and "no output" in _abi.last_error()
+    h = C.c_void_p()
+    off = np.array([0, 2, 1, 4], dtype=np.int64)  # not ascending
+    st = lib.rl_index_create(C.byref(h), tok.ctypes.data, 4, 8, off.ctypes.data, 3, 0, _abi.MEM_HOST, None)
+    assert st == _abi.RL_ERR_INVALID and "ascending" in _abi.last_error() and not h.value
+    st = lib.rl_index_create(C.byref(h), tok.ctypes.data, 4, 8, None, 0, 7, _abi.MEM_HOST, None)
+    assert st == _abi.RL_ERR_INVALID and "metric" in _abi.last_error()
+    assert lib.rl_search_rows(None, None, 1, 10, None, None, 0, None) == _abi.RL_ERR_INVALID
+    assert lib.rl_topk(None, 1, 10, 10, 4096, None, None, 0, None) == _abi.RL_ERR_UNSUPPORTED
+    assert lib.rl_merge_topk(None, None, 0, 1, 1, 1, None, None, 0, None) == _abi.RL_ERR_INVALID
+
+
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU fallback: on a box without a GPU the ops raise instead of computing elsewhere."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import raglite_amd
+
+    with pytest.raises(RuntimeError):
+        raglite_amd.pool_norm(np.zeros((4, 8), np.float32), np.array([0]), np.array([4]))
+    with pytest.raises(RuntimeError):
+        raglite_amd.DeviceIndex(np.zeros((4, 8), np.float32))
+
+
+def test_no_oracle_import_in_product():
+    """Parity rule: nothing under raglite_amd/ may import oracle/."""
+    root = Path(__file__).resolve().parent.parent / "raglite_amd"
+    for path in root.rglob("*.py"):
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", path.read_text(), flags=re.M), path

@@ -1,0 +1,424 @@
+"""Parity of the HIP path (through the C ABI) against the oracle and the golden fixtures.
+
+Bars (BASELINE.json north_star): bit-exact indices on integer tie-free... in fact on ALL integer data
+(ties resolve to the lowest id on both sides); cosine / MaxSim scores within 1e-4 in fp32; fp16
+pooling outputs bit-exact against the reference's golden vectors.
+"""
+
+import json
+
+import numpy as np
+import pytest
+
+import raglite_amd
+from oracle import oracle
+from oracle.fake_embedder import FakeLlama, make_sentences
+from tests.util import assert_topk_close, ragged_offsets, sim_fp32_exact
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    assert torch.cuda.is_available()
+    raglite_amd.set_device(0)
+    return torch
+
+
+# ---------------------------------------------------------------------------------------------------
+# synthetic generator
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["uniform", "small_int"])
+def test_synth_bit_identical(torch_cuda, kind):
+    t = torch_cuda.empty(100_003, dtype=torch_cuda.float32, device="cuda")
+    raglite_amd.synth_fill(t, seed=17, start=12345, kind=kind)
+    gen = oracle.synth_uniform if kind == "uniform" else oracle.synth_small_int
+    assert np.array_equal(t.cpu().numpy().view(np.uint32), gen(17, 12345, 100_003).view(np.uint32))
+
+
+# ---------------------------------------------------------------------------------------------------
+# a1 + a2 + a3: pooling
+# ---------------------------------------------------------------------------------------------------
+def _golden_cases(kind):
+    from pathlib import Path
+
+    man = json.loads((Path(__file__).parent / "golden" / "manifest.json").read_text())
+    return [(k, v) for k, v in man.items() if v["kind"] == kind]
+
+
+@pytest.mark.parametrize("name,meta", _golden_cases("late_chunking"))
+def test_embed_golden_late_chunking(golden_dir, name, meta):
+    """`embed_strings()` of the mirror (HIP pooling) == the reference's own output, bit for bit."""
+    golden = np.load(golden_dir / f"{name}.npz")["output"]
+    emb = FakeLlama(dim=meta["dim"], n_ctx=meta["n_ctx"], n_batch=meta["n_batch"], seed=meta["embedder_seed"])
+    cfg = raglite_amd.HotPathConfig(embedder=f"llama-cpp-python/fake/{name}", embedder_normalize=meta["normalize"])
+    out = raglite_amd.embed_strings(make_sentences(meta["sentence_seed"], meta["n_sentences"]), config=cfg, embedder=emb)
+    assert out.dtype == np.float16 and out.shape == golden.shape and np.all(np.isfinite(out))
+    assert np.array_equal(out.view(np.uint16), golden.view(np.uint16))
+    if meta["normalize"]:  # tests/test_embed.py:26 of the reference
+        assert np.allclose(np.linalg.norm(out.astype(np.float64), axis=1), 1.0, rtol=1e-3)
+
+
+@pytest.mark.parametrize("name,meta", _golden_cases("batch"))
+def test_embed_golden_batch(golden_dir, name, meta):
+    golden = np.load(golden_dir / f"{name}.npz")["output"]
+    emb = FakeLlama(dim=meta["dim"], n_ctx=meta["n_ctx"], seed=meta["embedder_seed"])
+    cfg = raglite_amd.HotPathConfig(embedder=f"llama-cpp-python/fake/{name}", embedder_normalize=meta["normalize"])
+    out = raglite_amd.embed_strings_without_late_chunking(
+        make_sentences(meta["sentence_seed"], meta["n_sentences"]), config=cfg, embedder=emb)
+    assert np.array_equal(out.view(np.uint16), golden.view(np.uint16))
+
+
+@pytest.mark.parametrize("dim", [4, 48, 64, 100, 257, 768, 1024, 2048, 4096])
+@pytest.mark.parametrize("normalize,eps", [(True, 0.0), (True, 2.2e-16), (False, 0.0)])
+def test_pool_norm_vs_oracle(dim, normalize, eps):
+    rng = np.random.default_rng(dim)
+    T = 600
+    tokens = oracle.synth_matrix(dim, T, dim)
+    cuts = np.sort(rng.choice(np.arange(1, T), size=60, replace=False))
+    begins = np.concatenate(([0], cuts)).astype(np.int64)
+    ends = np.concatenate((cuts, [T])).astype(np.int64)
+    begins = np.concatenate((begins, [5, 10, 0]))  # overlapping spans, an EMPTY span, the whole matrix
+    ends = np.concatenate((ends, [300, 10, T]))
+    f32, f16 = raglite_amd.pool_norm(tokens, begins, ends, normalize=normalize, eps=eps, want_f32=True, want_f16=True)
+    ref64, ref16 = oracle.pool_norm_cast(tokens, begins, ends, normalize=normalize, eps=eps or None)
+    empty = ends == begins
+    assert np.all(np.isnan(f32[empty])) and np.all(np.isnan(f16[empty]))  # np.mean of zero rows
+    np.testing.assert_allclose(f32[~empty], ref64[~empty], rtol=0, atol=1e-6)
+    ulp = np.abs(f16[~empty].view(np.int16).astype(np.int32) - ref16[~empty].view(np.int16).astype(np.int32))
+    assert ulp.max() <= 1 and (ulp > 0).mean() < 1e-3, "fp16 cast differs from astype(float16)"
+
+
+def test_pool_norm_zero_vector_eps_guard():
+    tokens = np.zeros((8, 64), dtype=np.float32)
+    _, guarded = raglite_amd.pool_norm(tokens, np.array([0]), np.array([8]), normalize=True, eps=2.2e-16)
+    assert np.all(guarded == 0)  # `_embed.py:160-163`: 0 / max(0, eps) = 0
+    _, raw = raglite_amd.pool_norm(tokens, np.array([0]), np.array([8]), normalize=True, eps=0.0)
+    assert np.all(np.isnan(raw))  # `_embed.py:139`: 0 / 0
+
+
+def test_pool_norm_device_pointers(torch_cuda):
+    tokens = oracle.synth_matrix(3, 300, 1024)
+    b = np.arange(0, 300, 10, dtype=np.int64)
+    e = b + 10
+    _, host = raglite_amd.pool_norm(tokens, b, e)
+    t = torch_cuda.as_tensor(tokens, device="cuda")
+    _, dev = raglite_amd.pool_norm(t, torch_cuda.as_tensor(b, device="cuda"), torch_cuda.as_tensor(e, device="cuda"))
+    assert dev.is_cuda and np.array_equal(dev.cpu().numpy().view(np.uint16), host.view(np.uint16))
+
+
+# ---------------------------------------------------------------------------------------------------
+# a5: adapter
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dim,B", [(64, 1), (1024, 1), (1024, 5), (768, 3), (100, 2)])
+def test_adapter_apply(dim, B):
+    A = oracle.synth_matrix(21, dim, dim)
+    Q = oracle.synth_matrix(22, B, dim)
+    out = raglite_amd.adapter_apply(A, Q if B > 1 else Q[0])
+    ref = oracle.adapter_apply(A.astype(np.float64), (Q if B > 1 else Q[0]).astype(np.float64))
+    np.testing.assert_allclose(out, ref, rtol=0, atol=TOL)
+    Ai, Qi = oracle.synth_matrix(23, dim, dim, "small_int"), oracle.synth_matrix(24, B, dim, "small_int")
+    outi = raglite_amd.adapter_apply(Ai, Qi)
+    assert np.array_equal(outi, (Qi.astype(np.float64) @ Ai.astype(np.float64).T).astype(np.float32))  # exact
+    h = raglite_amd.adapter_apply(A, Q, want_f16=True)  # `.astype(q.dtype)` with an fp16 query, `_search.py:62`
+    assert h.dtype == np.float16
+    np.testing.assert_allclose(h.astype(np.float64), ref.reshape(B, dim), rtol=2e-3, atol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------------
+# a6 + a7: similarity + exact top-k
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+@pytest.mark.parametrize("n,dim", [(3000, 1024), (1500, 128), (700, 100), (5000, 384)])
+def test_search_rows_integer_data_bit_exact(metric, n, dim):
+    """Integer-valued embeddings: scores and indices bit-identical to the fp32 as-computed oracle."""
+    E = oracle.synth_matrix(31, n, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    for b in range(2):
+        q = oracle.synth_matrix(32 + b, 1, dim, "small_int")[0]
+        s, r = idx.search_rows(q, 100)
+        ref = sim_fp32_exact(E, q, metric)
+        es, ei = oracle.topk_desc(ref, 100)
+        assert np.array_equal(r, ei), "indices differ (ties must resolve to the lowest row)"
+        assert np.array_equal(s.view(np.uint32), es.astype(np.float32).view(np.uint32)), "scores not bit-exact"
+    idx.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+@pytest.mark.parametrize("B", [1, 2, 3, 4, 5, 7, 33])
+def test_search_rows_uniform_data_batched(metric, B):
+    """U(-1,1) data, every batch size class: VALU scan (B <= 4) and MFMA tile path (B > 4, dim 1024)."""
+    n, dim = 4100, 1024
+    E = oracle.synth_matrix(41, n, dim)
+    Q = oracle.synth_matrix(42, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    S, R = idx.search_rows(Q, 50)
+    for b in range(B):
+        assert_topk_close(S[b], R[b], oracle.similarity(E, Q[b], metric), 50, TOL)
+    idx.close()
+
+
+def test_search_rows_edge_cases(torch_cuda):
+    dim = 64
+    E = oracle.synth_matrix(51, 37, dim)
+    q = oracle.synth_matrix(52, 1, dim)[0]
+    idx = raglite_amd.DeviceIndex(E, metric="cosine")
+    s, r = idx.search_rows(q, 100)  # k > n: padding
+    assert_topk_close(s, r, oracle.similarity(E, q, "cosine"), 100, TOL)
+    assert np.all(r[37:] == -1) and np.all(np.isneginf(s[37:]))
+    s1, r1 = idx.search_rows(q, 1)
+    assert r1[0] == r[0]
+    with pytest.raises(ValueError):
+        idx.search_rows(q, 4096)
+    with pytest.raises(ValueError):
+        idx.search_rows(np.zeros(dim + 1, np.float32), 5)
+    idx.close()
+    empty = raglite_amd.DeviceIndex(np.zeros((0, dim), np.float32))  # empty DB, tests/test_search.py:76-85
+    s, r = empty.search_rows(q, 5)
+    assert np.all(r == -1) and np.all(np.isneginf(s))
+    empty.close()
+    # identical rows (the reference's np.ones fixture, tests/test_split_chunks.py:28): N-way tie -> slow path
+    ones = np.ones((6000, 768), dtype=np.float16).astype(np.float32)
+    idx = raglite_amd.DeviceIndex(ones, metric="cosine")
+    s, r = idx.search_rows(np.ones(768, np.float32), 300)
+    assert r.tolist() == list(range(300)) and np.allclose(s, 1.0, atol=1e-6)
+    idx.close()
+    # device-pointer call path returns CUDA tensors with the same bits
+    Ed = torch_cuda.as_tensor(E, device="cuda")
+    idx = raglite_amd.DeviceIndex(Ed, metric="dot")
+    sd, rd = idx.search_rows(torch_cuda.as_tensor(q, device="cuda"), 10)
+    sh, rh = idx.search_rows(q, 10)
+    assert sd.is_cuda and np.array_equal(sd.cpu().numpy(), sh) and np.array_equal(rd.cpu().numpy(), rh)
+    idx.close()
+
+
+def test_topk_kernel_properties():
+    rng = np.random.default_rng(61)
+    for n, k in [(1, 1), (63, 64), (5000, 100), (100_000, 2048), (300_000, 10)]:
+        x = rng.standard_normal(n).astype(np.float32)
+        s, i = raglite_amd.topk(x, k)
+        es, ei = oracle.topk_desc(x, k)
+        kk = min(n, k)
+        assert np.array_equal(i[:kk], ei) and np.array_equal(s[:kk], es)
+    # specials: NaN last, -inf before NaN, +inf first, signed zeros tie -> lowest index
+    x = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 1.0, np.nan, -1.0, 1.0], dtype=np.float32)
+    s, i = raglite_amd.topk(x, 9)
+    assert i.tolist()[:3] == [3, 5, 8] and i.tolist()[-3:] == [4, 2, 6]
+    assert np.isnan(s[-1]) and np.isnan(s[-2]) and np.isneginf(s[-3])
+    # heavy ties straddling the candidate capacity: few distinct values
+    x = rng.integers(0, 3, size=50_000).astype(np.float32)
+    s, i = raglite_amd.topk(x, 1000)
+    es, ei = oracle.topk_desc(x, 1000)
+    assert np.array_equal(i, ei)
+    # batched
+    X = rng.standard_normal((7, 9000)).astype(np.float32)
+    S, I = raglite_amd.topk(X, 33)
+    for b in range(7):
+        es, ei = oracle.topk_desc(X[b], 33)
+        assert np.array_equal(I[b], ei) and np.array_equal(S[b], es)
+
+
+# ---------------------------------------------------------------------------------------------------
+# a6 + a7 + a8: two-stage semantics
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+def test_search_chunks_two_stage(metric):
+    rng = np.random.default_rng(71)
+    n, dim = 2500, 1024
+    E = oracle.synth_matrix(72, n, dim, "small_int")
+    off = ragged_offsets(rng, n, 1, 9)
+    r2c = np.repeat(np.arange(len(off) - 1), np.diff(off))
+    idx = raglite_amd.DeviceIndex(E, off, metric=metric)
+    for seed, (hits, k) in enumerate([(40, 3), (40, 10), (160, 40), (12, 12)]):
+        q = oracle.synth_matrix(80 + seed, 1, dim, "small_int")[0]
+        s, c, cnt = idx.search_chunks(q, hits, k)
+        rs, rr = oracle.topk_desc(sim_fp32_exact(E, q, metric), hits)
+        es, ec = oracle.group_chunk_max(rs, r2c[rr], k)
+        assert cnt == len(ec) and c[:cnt].tolist() == ec.tolist()
+        assert np.array_equal(s[:cnt], es.astype(np.float32))
+        assert np.all(c[cnt:] == -1)
+    # all hits inside one chunk -> a single result even though k = 5 (reference semantics)
+    one = raglite_amd.DeviceIndex(E[:50], np.array([0, 50]), metric=metric)
+    s, c, cnt = one.search_chunks(E[3], 40, 5)
+    assert cnt == 1 and c[0] == 0
+    one.close()
+    idx.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# a9: MaxSim
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nq", [1, 7, 16, 17, 32])
+@pytest.mark.parametrize("layout", ["fixed8", "ragged", "rows", "ragged_with_empty", "one_big"])
+def test_maxsim_stream_d1024_integer_exact(nq, layout):
+    """dim 1024 MFMA streaming kernel; integer data -> exact scores, exact top-k incl. tie order."""
+    rng = np.random.default_rng(91)
+    n, dim = 4133, 1024  # not a multiple of 16 nor of the grid
+    E = oracle.synth_matrix(92, n, dim, "small_int")
+    if layout == "fixed8":
+        n = 4128
+        E = E[:n]
+        off = np.arange(0, n + 1, 8, dtype=np.int64)
+    elif layout == "ragged":
+        off = ragged_offsets(rng, n, 1, 15)
+    elif layout == "rows":
+        off = None
+    elif layout == "ragged_with_empty":
+        off = ragged_offsets(rng, n, 1, 40, empty_every=4)
+    else:
+        off = np.array([0, 5, n - 3, n], dtype=np.int64)  # one chunk spanning many workgroups' shares
+    Q = oracle.synth_matrix(93, nq, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    off_ref = np.arange(n + 1) if off is None else off
+    ref = oracle.maxsim_scores(E, off_ref, Q).astype(np.float32)
+    got = idx.maxsim_scores(Q)
+    assert np.array_equal(got, ref), f"max abs err {np.nanmax(np.abs(got - ref))}"
+    s, c = idx.maxsim_topk(Q, 100)
+    es, ec = oracle.topk_desc(ref, 100)
+    kk = len(ec)
+    assert np.array_equal(c[:kk], ec) and np.array_equal(s[:kk], es)
+    idx.close()
+
+
+def test_maxsim_stream_uniform_tolerance_and_linearity():
+    n, dim, nq = 20_000, 1024, 32
+    E = oracle.synth_matrix(94, n, dim)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)  # ColBERT convention: unit rows
+    Q = oracle.synth_matrix(95, nq, dim)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    off = ragged_offsets(np.random.default_rng(96), n, 1, 15)
+    idx = raglite_amd.DeviceIndex(E.astype(np.float32), off, metric="dot")
+    got = idx.maxsim_scores(Q.astype(np.float32))
+    ref = oracle.maxsim_scores(E.astype(np.float32), off, Q.astype(np.float32))
+    np.testing.assert_allclose(got, ref, rtol=0, atol=TOL)
+    s, c = idx.maxsim_topk(Q.astype(np.float32), 100)
+    assert_topk_close(s, c, ref, 100, TOL)
+    # scaling Q by a power of two scales every score exactly (size-independent property)
+    got2 = idx.maxsim_scores((2.0 * Q).astype(np.float32))
+    assert np.array_equal(got2, 2.0 * got)
+    # nq = 1 reduces to the reference's single-vector per-chunk max (`_search.py:143-149`)
+    one = idx.maxsim_scores(Q[:1].astype(np.float32))
+    dots = E.astype(np.float64) @ Q[0].astype(np.float64)
+    np.testing.assert_allclose(one, np.maximum.reduceat(dots, off[:-1]), rtol=0, atol=TOL)
+    idx.close()
+
+
+@pytest.mark.parametrize("dim,nq", [(64, 5), (128, 40), (100, 3), (2048, 9)])
+def test_maxsim_generic_path(dim, nq):
+    rng = np.random.default_rng(dim)
+    n = 900
+    E = oracle.synth_matrix(97, n, dim, "small_int")
+    off = ragged_offsets(rng, n, 1, 12, empty_every=7)
+    Q = oracle.synth_matrix(98, nq, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    ref = oracle.maxsim_scores(E, off, Q).astype(np.float32)
+    assert np.array_equal(idx.maxsim_scores(Q), ref)
+    s, c = idx.maxsim_topk(Q, 20)
+    es, ec = oracle.topk_desc(ref, 20)
+    assert np.array_equal(c, ec) and np.array_equal(s, es)
+    idx.close()
+
+
+@pytest.mark.parametrize("dim,nq,rows", [(128, 32, 64), (128, 7, 64), (128, 20, "ragged"), (96, 6, "ragged"), (1024, 4, 8)])
+def test_maxsim_rerank(dim, nq, rows):
+    """SURVEY cfg 3: per-query candidate lists; dim 128 takes the MFMA fast path, others the generic one."""
+    rng = np.random.default_rng(101)
+    n_chunks, n_queries, n_cand = 300, 9, 37
+    if rows == "ragged":
+        off = ragged_offsets(rng, 4000, 1, 40, empty_every=11)
+        n_chunks = len(off) - 1
+    else:
+        off = np.arange(0, n_chunks * rows + 1, rows, dtype=np.int64)
+    n = int(off[-1])
+    E = oracle.synth_matrix(102, n, dim, "small_int")
+    Q = oracle.synth_matrix(103, n_queries * nq, dim, "small_int").reshape(n_queries, nq, dim)
+    cand = rng.integers(0, n_chunks, size=(n_queries, n_cand)).astype(np.int32)
+    cand[:, 1] = cand[:, 0]  # duplicates are legal
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    got = idx.maxsim_rerank(Q, cand)
+    for i in range(n_queries):
+        ref = oracle.maxsim_candidates(E, off, Q[i], cand[i]).astype(np.float32)
+        assert np.array_equal(got[i], ref), f"query {i}"
+    with pytest.raises(ValueError):
+        idx.maxsim_rerank(Q, np.full((n_queries, 2), n_chunks, np.int32))
+    # uniform data tolerance
+    Eu = oracle.synth_matrix(104, n, dim) / np.sqrt(dim)
+    Qu = oracle.synth_matrix(105, n_queries * nq, dim).reshape(n_queries, nq, dim) / np.sqrt(dim)
+    iu = raglite_amd.DeviceIndex(Eu.astype(np.float32), off, metric="dot")
+    gu = iu.maxsim_rerank(Qu.astype(np.float32), cand)
+    for i in range(n_queries):
+        np.testing.assert_allclose(gu[i], oracle.maxsim_candidates(Eu.astype(np.float32), off, Qu[i].astype(np.float32), cand[i]),
+                                   rtol=0, atol=TOL)
+    iu.close()
+    idx.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# section 8e: merge
+# ---------------------------------------------------------------------------------------------------
+def test_merge_topk_kernel_and_shard_equivalence():
+    n, dim, k = 6000, 1024, 100
+    E = oracle.synth_matrix(111, n, dim, "small_int")
+    Q = oracle.synth_matrix(112, 3, dim, "small_int")
+    full = raglite_amd.DeviceIndex(E, metric="cosine")
+    fs, fi = full.search_rows(Q, k)
+    bounds = [(0, 1000), (1000, 1007), (1007, 4000), (4000, 6000)]
+    ss, ii = [], []
+    for lo, hi in bounds:
+        sh = raglite_amd.DeviceIndex(E[lo:hi], metric="cosine")
+        s, i = sh.search_rows(Q, k)
+        ss.append(s)
+        ii.append(np.where(i >= 0, i + lo, -1))
+        sh.close()
+    ms, mi = raglite_amd.merge_topk(np.stack(ss), np.stack(ii).astype(np.int32), k)
+    assert np.array_equal(mi, fi) and np.array_equal(ms, fs)
+    from raglite_amd import merge_topk_host
+
+    hs, hi_ = merge_topk_host(np.stack(ss), np.stack(ii), k)
+    assert np.array_equal(hi_, fi) and np.array_equal(hs, fs)
+    full.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# end-to-end drop-ins
+# ---------------------------------------------------------------------------------------------------
+def test_vector_search_and_rerank_dropins():
+    rng = np.random.default_rng(121)
+    dim, n_chunks = 128, 60
+    mats = [oracle.synth_matrix(122 + i, int(rng.integers(1, 7)), dim) for i in range(n_chunks)]
+    mats = [(m / np.linalg.norm(m, axis=1, keepdims=True)).astype(np.float16) for m in mats]  # as stored by RAGLite
+    ids = [f"{i:016x}" for i in range(n_chunks)]
+    docs = [f"chunk body {i}" for i in range(n_chunks)]
+    A = np.linalg.qr(rng.standard_normal((dim, dim)))[0]  # orthogonal adapter, `_query_adapter.py:202-205`
+    meta = [{"topic": ["Physics"] if i % 2 == 0 else ["Biology"], "author": "Albert"} for i in range(n_chunks)]
+    gi = raglite_amd.GpuIndex(ids, mats, query_adapter=A, docs=docs, metadata=meta)
+    cfg = raglite_amd.HotPathConfig()
+    q = mats[17][0]
+    got_ids, got_scores = raglite_amd.vector_search(q, num_results=5, config=cfg, index=gi)
+    assert len(got_ids) == len(got_scores) == 5 and all(isinstance(s, float) for s in got_scores)
+    E = np.vstack(mats).astype(np.float32)
+    r2c = np.repeat(np.arange(n_chunks), [len(m) for m in mats])
+    qa = oracle.adapter_apply(A, q)  # fp64 matvec, cast back to fp16 (`_search.py:62`)
+    es, ec = oracle.search_chunks(E, r2c, qa.astype(np.float32), oracle.num_hits(5), 5, "cosine")
+    assert got_ids == [ids[c] for c in ec]
+    np.testing.assert_allclose(got_scores, es, rtol=0, atol=2e-3)  # adapter output rounds through fp16
+    cfg_na = raglite_amd.HotPathConfig(vector_search_query_adapter=False)
+    ids_na, sc_na = raglite_amd.vector_search(q, num_results=3, config=cfg_na, index=gi)
+    assert ids_na[0] == ids[17] and abs(sc_na[0] - 1.0) < 1e-3  # the query is a stored row
+    # metadata filter (filter-first semantics, `_search.py:105-119`)
+    f_ids, _ = raglite_amd.vector_search(q, num_results=4, metadata_filter={"topic": "Biology"}, config=cfg_na, index=gi)
+    assert len(f_ids) == 4 and all(int(i, 16) % 2 == 1 for i in f_ids)
+    assert raglite_amd.vector_search(q, num_results=4, metadata_filter={"topic": "Chemistry"}, config=cfg_na, index=gi) == ([], [])
+    # reranker plugin: Kendall-tau style contract of tests/test_rerank.py:64-70 (best-first ordering)
+    qv = np.vstack([mats[5].astype(np.float32), mats[9].astype(np.float32)])
+    ranker = raglite_amd.MaxSimRanker(gi, lambda _q: qv)
+    cfg_r = raglite_amd.HotPathConfig(reranker=ranker)
+    cand = [docs[i] for i in (30, 9, 2, 5, 41)]
+    out = raglite_amd.rerank_chunks("q", cand, config=cfg_r)
+    ref = oracle.maxsim_candidates(E, np.concatenate(([0], np.cumsum([len(m) for m in mats]))), qv, [30, 9, 2, 5, 41])
+    assert out == [cand[i] for i in np.argsort(-ref, kind="stable")]
+    assert set(out[:2]) == {docs[5], docs[9]}
+    gi.close()

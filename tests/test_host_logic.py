@@ -1,0 +1,151 @@
+"""Host-side logic of the mirror that needs no GPU (fake device index)."""
+
+import numpy as np
+import pytest
+
+import raglite_amd
+from raglite_amd import _search
+from raglite_amd._sharded import group_chunk_max_host, merge_topk_host, shard_bounds_by_chunk
+from oracle import oracle
+
+
+class _FakeDeviceIndex:
+    """Stands in for raglite_amd.DeviceIndex: records the call, answers with the oracle."""
+
+    def __init__(self, E, off, metric):
+        self.E, self.off, self.metric = E, off, metric
+        self.n_rows, self.n_chunks = len(E), len(off) - 1
+        self.calls = []
+
+    def search_chunks(self, q, num_hits, k):
+        self.calls.append((num_hits, k))
+        r2c = np.repeat(np.arange(self.n_chunks), np.diff(self.off))
+        s, c = oracle.search_chunks(self.E, r2c, q, num_hits, k, self.metric, np.float32)
+        out_s = np.full(k, -np.inf, np.float32); out_c = np.full(k, -1, np.int32)
+        out_s[: len(s)] = s; out_c[: len(c)] = c
+        return out_s, out_c, np.int32(len(c))
+
+    def maxsim_rerank(self, qv, cand):
+        return np.stack([oracle.maxsim_candidates(self.E, self.off, qv[i], cand[i], np.float32)
+                         for i in range(len(qv))]).astype(np.float32)
+
+
+def _gpu_index(n_chunks=30, dim=16, seed=0, **kw):
+    rng = np.random.default_rng(seed)
+    sizes = rng.integers(1, 6, size=n_chunks)
+    off = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+    E = rng.standard_normal((off[-1], dim)).astype(np.float32)
+    gi = _search.GpuIndex.__new__(_search.GpuIndex)
+    gi.chunk_ids = [f"chunk{i:04d}" for i in range(n_chunks)]
+    gi.index = _FakeDeviceIndex(E, off, kw.get("metric", "cosine"))
+    gi.metric = kw.get("metric", "cosine")
+    gi.query_adapter = kw.get("query_adapter")
+    gi.docs = [f"doc text {i}" for i in range(n_chunks)]
+    gi._doc_to_ordinal = {d: i for i, d in enumerate(gi.docs)}
+    gi.metadata = None
+    gi._id_to_ordinal = {c: i for i, c in enumerate(gi.chunk_ids)}
+    return gi
+
+
+def test_vector_search_contract_and_num_hits():
+    """`tests/test_search.py:36-60` of the reference: list[str] ids, list[float] scores, same length."""
+    gi = _gpu_index()
+    cfg = raglite_amd.HotPathConfig(vector_search_query_adapter=False)
+    q = np.random.default_rng(1).standard_normal(16).astype(np.float16)
+    ids, scores = raglite_amd.vector_search(q, num_results=5, config=cfg, index=gi)
+    assert len(ids) == len(scores) == 5
+    assert all(isinstance(i, str) for i in ids) and all(isinstance(s, float) for s in scores)
+    assert gi.index.calls[-1] == (40, 5)  # round(4 * 2048 / 2048) * max(5, 10)
+    ids, _ = raglite_amd.vector_search(q, num_results=40, oversample=4, config=cfg, index=gi)
+    assert gi.index.calls[-1] == (160, 40)
+    cfg2 = raglite_amd.HotPathConfig(chunk_max_size=1024, vector_search_query_adapter=False)
+    raglite_amd.vector_search(q, num_results=8, config=cfg2, index=gi)
+    assert gi.index.calls[-1] == (20, 8)
+    assert scores == sorted(scores, reverse=True)
+
+
+def test_vector_search_empty_index_returns_empty_lists():
+    gi = _gpu_index()
+    gi.index.n_rows = 0
+    assert raglite_amd.vector_search(np.zeros(16, np.float16), num_results=5, index=gi) == ([], [])
+
+
+def test_search_method_plugin_signature():
+    gi = _gpu_index()
+    method = raglite_amd.GpuVectorSearch(gi)
+    cfg = raglite_amd.HotPathConfig(search_method=method, vector_search_query_adapter=False)
+    ids, scores = cfg.search_method(np.ones(16, np.float16), num_results=3, metadata_filter=None, config=cfg)
+    assert len(ids) == 3 and len(scores) == 3
+
+
+def test_rerank_chunks_identity_without_reranker():
+    """`src/raglite/_search.py:376-377` / `tests/test_rerank.py:64-70`: identity when reranker is None."""
+    cfg = raglite_amd.HotPathConfig(reranker=None)
+    chunks = ["c", "a", "b"]
+    assert raglite_amd.rerank_chunks("q", chunks, config=cfg, chunk_lookup=lambda ids: list(ids)) == chunks
+    assert raglite_amd.rerank_chunks("q", [], config=cfg) == []
+
+
+def test_maxsim_ranker_orders_by_score_and_plugs_into_rerank_chunks():
+    gi = _gpu_index(n_chunks=12, dim=8, seed=3)
+    rng = np.random.default_rng(5)
+    qv = rng.standard_normal((4, 8)).astype(np.float32)
+    ranker = raglite_amd.MaxSimRanker(gi, lambda query: qv)
+    docs = [gi.docs[i] for i in (7, 2, 9, 0, 5)]
+    res = ranker.rank(query="anything", docs=docs)
+    exp = oracle.maxsim_candidates(gi.index.E, gi.index.off, qv, [7, 2, 9, 0, 5], np.float32)
+    order = np.argsort(-exp, kind="stable")
+    assert [r.doc_id for r in res.results] == order.tolist()
+    assert [r.rank for r in res.results] == [1, 2, 3, 4, 5]
+
+    class _Chunk:  # what the reference hands over: objects whose str() is the chunk text
+        def __init__(self, text): self.text = text
+        def __str__(self): return self.text
+
+    cfg = raglite_amd.HotPathConfig(reranker=ranker)
+    chunks = [_Chunk(d) for d in docs]
+    out = raglite_amd.rerank_chunks("anything", chunks, config=cfg)
+    assert [c.text for c in out] == [docs[i] for i in order]
+    cfg_dict = raglite_amd.HotPathConfig(reranker={"en": None, "other": ranker})
+    out2 = raglite_amd.rerank_chunks("anything", chunks, config=cfg_dict)
+    assert [c.text for c in out2] == [c.text for c in out]
+
+
+def test_merge_topk_host_matches_oracle():
+    rng = np.random.default_rng(7)
+    world, B, k = 4, 5, 10
+    scores = rng.integers(-5, 6, size=(world, B, k)).astype(np.float32)
+    scores = -np.sort(-scores, axis=2)
+    ids = np.stack([rng.permutation(1000)[: B * k].reshape(B, k) + w * 1000 for w in range(world)]).astype(np.int64)
+    ids[3, :, -2:] = -1; scores[3, :, -2:] = -np.inf  # padding from a short shard
+    ms, mi = merge_topk_host(scores, ids, k)
+    for b in range(B):
+        valid = [ids[w, b][ids[w, b] >= 0] for w in range(world)]
+        vs = [scores[w, b][ids[w, b] >= 0] for w in range(world)]
+        es, ei = oracle.merge_topk(vs, valid, k)
+        assert np.array_equal(mi[b], ei) and np.array_equal(ms[b], es)
+
+
+def test_shard_bounds_match_oracle():
+    rng = np.random.default_rng(9)
+    for _ in range(50):
+        sizes = rng.integers(0, 20, size=int(rng.integers(1, 60)))
+        off = np.concatenate(([0], np.cumsum(sizes)))
+        for w in (1, 2, 3, 8):
+            assert shard_bounds_by_chunk(off, w) == oracle.shard_bounds_by_chunk(off, w)
+
+
+def test_group_chunk_max_host_matches_oracle():
+    """Hits arrive sorted by (score desc, row asc) and chunk ordinals grow with row ids, as on the GPU."""
+    rng = np.random.default_rng(11)
+    for _ in range(20):
+        n_rows = 200
+        r2c = np.sort(rng.integers(0, 30, size=n_rows))
+        rows = rng.permutation(n_rows)[:40]
+        sc = rng.integers(0, 9, size=40).astype(np.float32)  # many ties
+        order = np.lexsort((rows, -sc))
+        rows, sc = rows[order], sc[order]
+        out_s, out_c, n = group_chunk_max_host(sc[None], r2c[rows][None], 5)
+        es, ec = oracle.group_chunk_max(sc, r2c[rows], 5)
+        assert out_c[0, : n[0]].tolist() == ec.tolist()
+        np.testing.assert_array_equal(out_s[0, : n[0]], es)
