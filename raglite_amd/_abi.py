@@ -68,6 +68,13 @@ def lib() -> C.CDLL:
             f"{LIB_PATH} not found: build it with `python -m raglite_amd._build` (needs hipcc; "
             "cross-compiles for gfx950 without a GPU). raglite_amd has no CPU fallback."
         )
+    try:
+        # PyTorch-ROCm bundles its own libamdhip64; loading it FIRST makes this library bind to the same HIP
+        # runtime (same soname), which is what lets device pointers and streams cross between the two.  With the
+        # opposite order two runtimes end up in the process and the second one finds no device.
+        import torch  # noqa: F401
+    except ImportError:  # pure-ctypes use without PyTorch: the system ROCm runtime is loaded instead
+        pass
     handle = C.CDLL(str(LIB_PATH))
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(handle, name)  # AttributeError if the library does not export the declared symbol

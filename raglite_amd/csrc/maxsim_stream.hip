@@ -32,6 +32,7 @@
 namespace rl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int32_t i32x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 constexpr int SD = 1024;                      // embedding dimension of the fast path
@@ -137,12 +138,29 @@ __global__ __launch_bounds__(256, 1) void maxsim_stream_kernel(const float* __re
     int32_t* const CID = reinterpret_cast<int32_t*>(smem + OFF_CID);
     constexpr int NQC = 16 * NQT;  // query columns carried through the epilogue
 
+    // Chunk ordinals of a tile's 16 rows + the row after it (17 dwords) are fetched with hand-issued scalar
+    // loads ONE TILE AHEAD: hipcc would otherwise either wait for them in front of the LDS reads (SMEM and LDS
+    // share lgkmcnt) or, for a vector load, drain the DMA pipeline with vmcnt(0).  Issued right after the
+    // A-fragment wait, their latency hides behind the 128 MFMAs; the barrier's lgkmcnt(0) retires them.
+    // row_to_chunk is padded by 32 entries so that the look-ahead never leaves the array.
+    [[maybe_unused]] i32x8 rc_lo, rc_hi, rn_lo, rn_hi;
+    [[maybe_unused]] int32_t rc_last = 0, rn_last = 0;
+    auto load_rc = [&](int64_t row, i32x8& lo, i32x8& hi, int32_t& last) {
+        const int32_t* rc = row_to_chunk + row;
+        asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x20\n\ts_load_dword %2, %3, 0x40"
+                     : "=&s"(lo), "=&s"(hi), "=&s"(last)
+                     : "s"(rc)
+                     : "memory");
+    };
+    if constexpr (MODE == 0) load_rc(r_lo, rc_lo, rc_hi, rc_last);
+
     for (int t = 0; t < nt; ++t) {
         const int s = t & 1;
         // Tile t has landed once at most the 16 DMAs of tile t+1 are still outstanding.
         if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+        const int64_t row0 = r_lo + (int64_t)t * TR;
         f32x4 acc[NQT];
 #pragma unroll
         for (int h = 0; h < NQT; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -152,6 +170,11 @@ __global__ __launch_bounds__(256, 1) void maxsim_stream_kernel(const float* __re
         f32x4 a[16];
 #pragma unroll
         for (int mm = 0; mm < 16; ++mm) a[mm] = *reinterpret_cast<const f32x4*>(ap + mm * 64);
+        if constexpr (MODE == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(rc_lo), "+s"(rc_hi), "+s"(rc_last)::"memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_sched_barrier(0);  // keep hipcc from sinking the reads back next to their MFMAs
 #pragma unroll
         for (int mm = 0; mm < 16; ++mm) {
@@ -160,6 +183,15 @@ __global__ __launch_bounds__(256, 1) void maxsim_stream_kernel(const float* __re
 #pragma unroll
                 for (int h = 0; h < NQT; ++h)
                     acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mm][tt], qreg[h][4 * mm + tt], acc[h], 0, 0, 0);
+            if constexpr (MODE == 0) {
+                if (mm == 0) {
+                    // Next tile's chunk ordinals: issued behind the first MFMAs (i.e. behind hipcc's own wait
+                    // for the A fragments), pinned so the wait cannot end up after it.
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_rc(row0 + TR, rn_lo, rn_hi, rn_last);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
         // Stage s is consumed: refill it with tile t+2 before anything else.
         if (t + 2 < nt) issue(t + 2, s);
@@ -168,7 +200,15 @@ __global__ __launch_bounds__(256, 1) void maxsim_stream_kernel(const float* __re
         char* red = smem + OFF_RED + (t & 1) * RED_BYTES;
 #pragma unroll
         for (int h = 0; h < NQT; ++h) *reinterpret_cast<f32x4*>(red + ((w * 2 + h) * 64 + lane) * 16) = acc[h];
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (MODE == 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+s"(rn_lo), "+s"(rn_hi), "+s"(rn_last)::"memory");
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        // this tile's ordinals for the epilogue; the look-ahead becomes current for the next iteration
+        [[maybe_unused]] const i32x8 ec_lo = rc_lo, ec_hi = rc_hi;
+        [[maybe_unused]] const int32_t ec_last = rc_last;
+        if constexpr (MODE == 0) { rc_lo = rn_lo; rc_hi = rn_hi; rc_last = rn_last; }
 
         if (w != (t & 3)) continue;  // epilogue duty rotates over the four waves
         // C/D layout of 16x16x4: column (lane & 15) = query, row = 4*(lane >> 4) + reg = corpus row in tile.
@@ -181,7 +221,6 @@ __global__ __launch_bounds__(256, 1) void maxsim_stream_kernel(const float* __re
             const f32x4 p3 = *reinterpret_cast<const f32x4*>(red + ((3 * 2 + h) * 64 + lane) * 16);
             v[h] = (p0 + p1) + (p2 + p3);
         }
-        const int64_t row0 = r_lo + (int64_t)t * TR;
         const int nvalid = (int)((r_hi - row0) < TR ? (r_hi - row0) : TR);
 
         if constexpr (MODE == 1) {
@@ -199,22 +238,33 @@ __global__ __launch_bounds__(256, 1) void maxsim_stream_kernel(const float* __re
                 }
             }
         } else {
+            int32_t rcv[TR + 1];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { rcv[i] = ec_lo[i]; rcv[8 + i] = ec_hi[i]; }
+            rcv[TR] = ec_last;
+            uint32_t ends = 0;  // bit i: row0+i is the last row of its chunk (wave-uniform)
+#pragma unroll
+            for (int i = 0; i < TR; ++i) ends |= (uint32_t)(rcv[i] != rcv[i + 1]) << i;
 #pragma unroll
             for (int h = 0; h < NQT; ++h)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) S[(4 * kq + r) * S_PITCH + 16 * h + fj] = v[h][r];
             const int qc = lane & (NQC - 1);
             float m = (t == 0) ? -INFINITY : STATE[qc];
+            float sv[TR];
+#pragma unroll
+            for (int i = 0; i < TR; ++i) sv[i] = S[i * S_PITCH + qc];  // one batch of LDS reads, one wait
             int ncl = 0;
-            const int32_t* rc = row_to_chunk + row0;  // wave-uniform address: scalar loads
-            for (int i = 0; i < nvalid; ++i) {
-                m = fmaxf(m, S[i * S_PITCH + qc]);
-                const int32_t c = rc[i], cn = rc[i + 1];
-                if (c != cn) {  // row0+i closes chunk c
-                    CM[ncl * 32 + qc] = m;
-                    if (lane == 0) CID[ncl] = c;
-                    ++ncl;
-                    m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < TR; ++i) {
+                if (i < nvalid) {  // wave-uniform
+                    m = fmaxf(m, sv[i]);
+                    if ((ends >> i) & 1u) {  // row0+i closes chunk rcv[i] (wave-uniform)
+                        CM[ncl * 32 + qc] = m;
+                        if (lane == 0) CID[ncl] = rcv[i];
+                        ++ncl;
+                        m = -INFINITY;
+                    }
                 }
             }
             STATE[qc] = m;
@@ -239,13 +289,14 @@ __global__ __launch_bounds__(256, 1) void maxsim_stream_kernel(const float* __re
 __global__ __launch_bounds__(256) void row_to_chunk_kernel(const int64_t* __restrict__ chunk_offsets,
                                                             int64_t n_chunks, int64_t n_rows,
                                                             int32_t* __restrict__ row_to_chunk) {
-    // One thread per chunk writes its rows' ordinals; rc[n_rows] = -1 terminates the last chunk.
+    // One thread per chunk writes its rows' ordinals; rc[n_rows .. n_rows+32] = -1 terminates the last chunk
+    // and pads the array so that a tile's 17-entry scalar read never leaves it.
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += stride) {
         const int64_t b = chunk_offsets[c], e = chunk_offsets[c + 1];
         for (int64_t r = b; r < e; ++r) row_to_chunk[r] = (int32_t)c;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) row_to_chunk[n_rows] = -1;
+    if (blockIdx.x == 0 && threadIdx.x < 33) row_to_chunk[n_rows + threadIdx.x] = -1;  // terminator + padding
 }
 
 int launch_row_to_chunk(const int64_t* chunk_offsets, int64_t n_chunks, int64_t n_rows, int32_t* row_to_chunk,

@@ -416,9 +416,18 @@ def test_vector_search_and_rerank_dropins():
     qv = np.vstack([mats[5].astype(np.float32), mats[9].astype(np.float32)])
     ranker = raglite_amd.MaxSimRanker(gi, lambda _q: qv)
     cfg_r = raglite_amd.HotPathConfig(reranker=ranker)
-    cand = [docs[i] for i in (30, 9, 2, 5, 41)]
+    class _Chunk:  # the reference passes Chunk objects whose str() is the chunk text (`_search.py:395`)
+        def __init__(self, text): self.text = text
+        def __str__(self): return self.text
+
+    cand = [_Chunk(docs[i]) for i in (30, 9, 2, 5, 41)]
     out = raglite_amd.rerank_chunks("q", cand, config=cfg_r)
     ref = oracle.maxsim_candidates(E, np.concatenate(([0], np.cumsum([len(m) for m in mats]))), qv, [30, 9, 2, 5, 41])
-    assert out == [cand[i] for i in np.argsort(-ref, kind="stable")]
-    assert set(out[:2]) == {docs[5], docs[9]}
+    assert [c.text for c in out] == [cand[i].text for i in np.argsort(-ref, kind="stable")]
+    assert {c.text for c in out[:2]} == {docs[5], docs[9]}
+    # chunk ids resolve through chunk_lookup (the reference's retrieve_chunks)
+    by_id = {ids[i]: _Chunk(docs[i]) for i in range(n_chunks)}
+    out_ids = raglite_amd.rerank_chunks("q", [ids[i] for i in (30, 9, 2, 5, 41)], config=cfg_r,
+                                        chunk_lookup=lambda cids: [by_id[c] for c in cids])
+    assert [c.text for c in out_ids] == [c.text for c in out]
     gi.close()
