@@ -131,6 +131,11 @@ int rl_maxsim_topk(rl_index* index, const float* query_vecs, int32_t nq, int32_t
                    float* out_scores, int32_t* out_chunks, int mem, void* stream);
 int rl_maxsim_scores(rl_index* index, const float* query_vecs, int32_t nq, float* out_scores,
                      int mem, void* stream);
+/* rl_maxsim_topk_batch: `n_queries` independent queries (each nq vectors) against every chunk: one corpus pass
+ * per query, then ONE batched selection launch for all of them (amortises the three selection kernels).
+ *   query_vecs [n_queries x nq x dim] f32; out_scores / out_chunks [n_queries x k]. */
+int rl_maxsim_topk_batch(rl_index* index, const float* query_vecs, int32_t n_queries, int32_t nq, int32_t k,
+                         float* out_scores, int32_t* out_chunks, int mem, void* stream);
 
 /* rl_maxsim_rerank: the rerank shape (SURVEY.md cfg 3).  `n_queries` independent queries in one
  * launch, each with its own nq query vectors and its own list of n_cand candidate chunk ordinals.

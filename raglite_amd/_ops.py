@@ -289,6 +289,21 @@ class DeviceIndex:
         check(lib().rl_maxsim_topk(self._handle, p_q, nq, k, p_s, p_c, a.mem, a.stream))
         return o_s, o_c
 
+    def maxsim_topk_batch(self, query_batch, k: int):
+        """query_batch (n_queries, nq, dim) -> (scores (n_queries, k), chunk ordinals (n_queries, k)); one corpus
+        pass per query and one batched selection launch."""
+        a = _Args()
+        p_q = a.inp(query_batch, np.float32)
+        qv = a.keep[-1]
+        if qv.ndim != 3 or int(qv.shape[2]) != self.dim:
+            raise ValueError("query_batch must be (n_queries, nq, dim)")
+        n_queries, nq = int(qv.shape[0]), int(qv.shape[1])
+        o_s, p_s = a.out((n_queries, k), np.float32)
+        o_c, p_c = a.out((n_queries, k), np.int32)
+        self._prep(a)
+        check(lib().rl_maxsim_topk_batch(self._handle, p_q, n_queries, nq, k, p_s, p_c, a.mem, a.stream))
+        return o_s, o_c
+
     def maxsim_rerank(self, query_vecs, candidates):
         """query_vecs (n_queries, nq, dim), candidates (n_queries, n_cand) int32 -> scores (n_queries, n_cand)."""
         a = _Args()

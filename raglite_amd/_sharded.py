@@ -168,13 +168,11 @@ class ShardedIndex:
     def maxsim_topk_batch(self, query_batch, k: int):
         """A batch of queries (QB, nq, dim): QB local launches, ONE all-gather of (QB, k, 2) int32, one
         host merge.  Returns (scores (QB,k), global chunk ordinals (QB,k))."""
-        outs = [self.local.maxsim_topk(query_batch[b], k) for b in range(len(query_batch))]
-        if hasattr(outs[0][0], "is_cuda"):
-            import torch
-
-            s, c = torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs])
+        if hasattr(self.local, "maxsim_topk_batch"):
+            s, c = self.local.maxsim_topk_batch(query_batch, k)
         else:
-            s, c = np.stack([o[0] for o in outs]), np.stack([o[1] for o in outs])
+            outs = [self.local.maxsim_topk(query_batch[b], k) for b in range(len(query_batch))]
+            s, c = np.stack([_to_numpy(o[0]) for o in outs]), np.stack([_to_numpy(o[1]) for o in outs])
         gs, gi, _, _ = self._exchange(s, c, self.chunk_base)
         return merge_topk_host(gs, gi, k)
 

@@ -1,5 +1,6 @@
 // C ABI of libraglite_hip.so (see include/raglite_hip.h for the contract of every entry point).
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -487,6 +488,33 @@ int rl_maxsim_topk(rl_index* idx, const float* query_vecs, int32_t nq, int32_t k
     RL_TRY(launch_topk(idx->scores.as<float>(), 1, idx->n_chunks, idx->n_chunks, k, idx->ws, d_s, d_c, s));
     RL_TRY(stage_out_end(out_scores, (size_t)k, mem, s, t_s));
     RL_TRY(stage_out_end(out_chunks, (size_t)k, mem, s, t_c));
+    return finish(mem, s);
+}
+
+int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queries, int32_t nq, int32_t k,
+                         float* out_scores, int32_t* out_chunks, int mem, void* stream) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: null index");
+    if (n_queries < 0 || nq < 1) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: bad sizes");
+    if (k < 1) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: k must be >= 1");
+    if (k > K_MAX) return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_topk_batch: k must be <= 2048");
+    if (n_queries == 0) return RL_OK;
+    if (!query_vecs || !out_scores || !out_chunks) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: null argument");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    DevBuf t_q, t_s, t_c;
+    const float* d_q; float* d_s; int32_t* d_c;
+    const size_t q_elems = (size_t)nq * idx->dim;
+    RL_TRY(stage_in(query_vecs, (size_t)n_queries * q_elems, mem, s, t_q, &d_q));
+    RL_TRY(stage_out_begin(out_scores, (size_t)n_queries * k, mem, t_s, &d_s));
+    RL_TRY(stage_out_begin(out_chunks, (size_t)n_queries * k, mem, t_c, &d_c));
+    const int64_t ld = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
+    RL_TRY(idx->scores.reserve((size_t)n_queries * ld * sizeof(float)));
+    float* sc = idx->scores.as<float>();
+    for (int32_t b = 0; b < n_queries; ++b)
+        RL_TRY(maxsim_scores_device(idx, d_q + (size_t)b * q_elems, nq, sc + (int64_t)b * ld, s));
+    RL_TRY(launch_topk(sc, n_queries, idx->n_chunks, ld, k, idx->ws, d_s, d_c, s));
+    RL_TRY(stage_out_end(out_scores, (size_t)n_queries * k, mem, s, t_s));
+    RL_TRY(stage_out_end(out_chunks, (size_t)n_queries * k, mem, s, t_c));
     return finish(mem, s);
 }
 

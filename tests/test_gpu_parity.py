@@ -296,6 +296,12 @@ def test_maxsim_stream_uniform_tolerance_and_linearity():
     np.testing.assert_allclose(got, ref, rtol=0, atol=TOL)
     s, c = idx.maxsim_topk(Q.astype(np.float32), 100)
     assert_topk_close(s, c, ref, 100, TOL)
+    # batched entry point: same bits as query-by-query calls
+    Qb = np.stack([Q, Q[::-1].copy(), 0.5 * Q]).astype(np.float32)
+    bs, bc = idx.maxsim_topk_batch(Qb, 100)
+    for b in range(3):
+        ss, cc = idx.maxsim_topk(Qb[b], 100)
+        assert np.array_equal(bs[b], ss) and np.array_equal(bc[b], cc)
     # scaling Q by a power of two scales every score exactly (size-independent property)
     got2 = idx.maxsim_scores((2.0 * Q).astype(np.float32))
     assert np.array_equal(got2, 2.0 * got)
