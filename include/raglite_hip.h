@@ -96,7 +96,7 @@ int rl_adapter_apply(const float* A, const float* queries, int32_t n_queries, in
  *   chunk_offsets  [n_chunks + 1] int64 ascending CSR, chunk_offsets[0]==0, [n_chunks]==n_rows
  *                  (always a HOST pointer); NULL -> every row is its own chunk.
  *   metric         rl_metric used by rl_search_rows / rl_search_chunks.
- * Precomputes 1/||e|| per row (cosine) or ||e||^2 (l2): 4 B/row extra. */
+ * Precomputes ||e|| per row (cosine) or ||e||^2 (l2): 4 B/row extra. */
 int rl_index_create(rl_index** out, const float* embeddings, int64_t n_rows, int32_t dim,
                     const int64_t* chunk_offsets, int64_t n_chunks, int metric, int mem, void* stream);
 int rl_index_destroy(rl_index* index);

@@ -239,8 +239,23 @@ int rl_adapter_apply(const float* A, const float* queries, int32_t n_queries, in
         RL_TRY(t_tmp.alloc((size_t)n_queries * dim * sizeof(float)));
         d_res = t_tmp.as<float>();
     }
-    // out[b][r] = sum_c A[r][c] q[b][c]: the similarity scan over the rows of A in raw-dot mode.
-    RL_TRY(launch_scan_rows(d_a, dim, dim, d_q, n_queries, nullptr, SCAN_RAW_DOT, d_res, dim, s));
+    // out[b][r] = sum_c A[r][c] q[b][c]: a similarity scan over the rows of A in raw-dot mode.  Batches go
+    // through the MFMA tile kernel (32 queries per pass over A, which stays L2-resident), single queries and
+    // other dims through the VALU scan.
+    bool done = false;
+    if (n_queries > 4 && dim == 1024) {
+        int dev = 0, n_cu = 256;
+        RL_HIP(hipGetDevice(&dev));
+        RL_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        done = true;
+        for (int32_t b0 = 0; b0 < n_queries && done; b0 += 32) {
+            const int32_t nq = std::min<int32_t>(32, n_queries - b0);
+            const int st = launch_maxsim_stream(d_a, dim, dim, d_q + (int64_t)b0 * dim, nq, nullptr, nullptr, 0, 1,
+                                                d_res + (int64_t)b0 * dim, dim, n_cu, s);
+            if (st == RL_ERR_UNSUPPORTED) done = false; else RL_TRY(st);
+        }
+    }
+    if (!done) RL_TRY(launch_scan_rows(d_a, dim, dim, d_q, n_queries, nullptr, SCAN_RAW_DOT, d_res, dim, s));
     if (d_o16) RL_TRY(launch_cast_f16(d_res, d_o16, (int64_t)n_queries * dim, s));
     RL_TRY(stage_out_end(out_f32, (size_t)n_queries * dim, mem, s, t_o32));
     RL_TRY(stage_out_end(out_f16, (size_t)n_queries * dim, mem, s, t_o16));
