@@ -127,7 +127,10 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict_
 template <int NV, int VEC>
 static int launch_t(const float* tokens, int32_t dim, const int64_t* sb, const int64_t* se, int64_t n_spans,
                     int normalize, double eps, float* o32, uint16_t* o16, hipStream_t s) {
-    const int blocks = (int)std::min<int64_t>((n_spans + 3) / 4, 256 * 32);
+    // Spans are ragged (4..60 token rows at cfg 4), so a few generations of workgroups balance better than one
+    // persistent generation: 8x measured 2.34 ms vs 2.44 ms on 3.2 M token rows.
+    const int blocks = (int)std::min<int64_t>((int64_t)persistent_grid(pool_norm_kernel<NV, VEC>, 256, (n_spans + 3) / 4) * 8,
+                                              (n_spans + 3) / 4);
     hipLaunchKernelGGL((pool_norm_kernel<NV, VEC>), dim3(blocks), dim3(256), 0, s, tokens, (int)dim, sb, se, n_spans,
                        normalize, eps, o32, o16);
     RL_HIP(hipGetLastError());

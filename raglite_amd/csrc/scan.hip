@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void transform_kernel(float* __restrict__ scor
 template <int NV, int VEC, int BQ>
 static int scan_t(const float* E, int64_t n, int32_t dim, const float* q, const float* rn, int mode, float* sc,
                   int64_t ld, hipStream_t s) {
-    const int blocks = (int)std::min<int64_t>((n + 7) / 8, 256 * 8);
+    const int blocks = persistent_grid(scan_rows_kernel<NV, VEC, BQ>, 256, (n + 7) / 8);
     hipLaunchKernelGGL((scan_rows_kernel<NV, VEC, BQ>), dim3(blocks), dim3(256), 0, s, E, n, (int)dim, q, rn, mode, sc,
                        ld);
     RL_HIP(hipGetLastError());
@@ -252,7 +252,7 @@ int launch_scan_rows(const float* E, int64_t n, int32_t dim, const float* querie
 
 template <int NV, int VEC>
 static int norms_t(const float* E, int64_t n, int32_t dim, float* norm, float* sumsq, hipStream_t s) {
-    const int blocks = (int)std::min<int64_t>((n + 3) / 4, 256 * 8);
+    const int blocks = persistent_grid(row_norms_kernel<NV, VEC>, 256, (n + 3) / 4);
     hipLaunchKernelGGL((row_norms_kernel<NV, VEC>), dim3(blocks), dim3(256), 0, s, E, n, (int)dim, norm, sumsq);
     RL_HIP(hipGetLastError());
     return RL_OK;

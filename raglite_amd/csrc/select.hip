@@ -22,6 +22,7 @@ namespace rl {
 constexpr int CNT_SEL = HIST_BINS + 0;   // counters live right after the bins
 constexpr int CNT_CAND = HIST_BINS + 1;
 constexpr int HIST_STRIDE = HIST_BINS + 8;
+constexpr int RANK_MAX = 1024;        // up to this many keys are ordered by counting instead of a bitonic network
 
 // ---- block-wide helpers (256 or 1024 threads) -----------------------------------------------------
 
@@ -185,7 +186,19 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restric
     __syncthreads();
     if (kk == 0) { write_results(fin, 0, k, os, oi); return; }
 
-    if (n_cand <= (uint32_t)CAND_CAP) {
+    if (n_cand <= (uint32_t)RANK_MAX) {
+        // Few candidates (the common case: a few hundred): every thread ranks one key by counting the larger ones
+        // (all keys are distinct; the LDS reads are wave-wide broadcasts) -- two barriers instead of a sorting network.
+        for (int i = threadIdx.x; i < (int)n_cand; i += blockDim.x) buf[i] = cand[i];
+        __syncthreads();
+        if (threadIdx.x < n_cand) {
+            const uint64_t mine = buf[threadIdx.x];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n_cand; ++j) rank += buf[j] > mine;
+            if (rank < need) fin[n_sel + rank] = mine;
+        }
+        __syncthreads();
+    } else if (n_cand <= (uint32_t)CAND_CAP) {
         int p2 = 64;
         while (p2 < (int)n_cand) p2 <<= 1;
         for (int i = threadIdx.x; i < p2; i += blockDim.x) buf[i] = (i < (int)n_cand) ? cand[i] : 0ull;
@@ -251,7 +264,18 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restric
         }
         __syncthreads();
     }
-    // Sort the kk survivors (all distinct keys) and write them out.
+    // Order the kk survivors (all distinct keys) and write them out.
+    if (kk <= (uint32_t)RANK_MAX) {
+        if (threadIdx.x < kk) {
+            const uint64_t mine = fin[threadIdx.x];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < kk; ++j) rank += fin[j] > mine;
+            buf[rank] = mine;
+        }
+        __syncthreads();
+        write_results(buf, (int)kk, k, os, oi);
+        return;
+    }
     int p2 = 64;
     while (p2 < (int)kk) p2 <<= 1;
     for (int i = threadIdx.x; i < p2; i += blockDim.x) buf[i] = (i < (int)kk) ? fin[i] : 0ull;
