@@ -243,7 +243,7 @@ int rl_adapter_apply(const float* A, const float* queries, int32_t n_queries, in
     // through the MFMA tile kernel (32 queries per pass over A, which stays L2-resident), single queries and
     // other dims through the VALU scan.
     bool done = false;
-    if (n_queries > 4 && dim == 1024) {
+    if (n_queries > 4) {
         int dev = 0, n_cu = 256;
         RL_HIP(hipGetDevice(&dev));
         RL_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
@@ -359,7 +359,7 @@ namespace {
 int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStream_t s) {
     const int mode = scan_mode(idx->metric);
     float* sc = idx->scores.as<float>();
-    if (nb > 4 && idx->dim == 1024) {
+    if (nb > 4) {  // launch_maxsim_stream reports RL_ERR_UNSUPPORTED for dims outside its fast path
         // MFMA tile kernel, 32 queries per corpus pass, raw dots; then the metric transform.
         bool ok = true;
         for (int32_t b0 = 0; b0 < nb && ok; b0 += 32) {

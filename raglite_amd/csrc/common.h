@@ -126,7 +126,7 @@ int launch_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_l
 // maxsim*.hip
 int launch_row_to_chunk(const int64_t* chunk_offsets, int64_t n_chunks, int64_t n_rows, int32_t* row_to_chunk,
                         hipStream_t s);
-// Fast path: dim == 1024, nq <= 32 (wave-specialised MFMA streaming kernel).  mode 0: chunk MaxSim scores
+// Fast path: dim in {128,256,384,512,768,1024}, nq <= 32 (wave-specialised MFMA streaming kernel).  mode 0: chunk MaxSim scores
 // out[n_chunks]; mode 1: raw row dots out[q * ld + row].  Returns RL_ERR_UNSUPPORTED outside the fast path.
 int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
                          const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,

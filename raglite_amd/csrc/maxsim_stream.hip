@@ -1,4 +1,5 @@
-// a9 (metric shape) and batched a6: the MFMA streaming tile kernel, dim == 1024.
+// a9 (metric shape) and batched a6: the MFMA streaming tile kernel, dim in {128, 256, 384, 512, 768, 1024}
+// (the numbers below are for dim = 1024, bge-m3, the reference's default embedder).
 //
 //   mode 0 (MaxSim):  out[c]          = sum_{i<nq} max_{j in chunk c} Q[i].D[j]      (nq <= 32)
 //   mode 1 (rows):    out[i*ld + row] = Q[i].D[row]   (raw dots; scan.hip:transform_kernel applies the metric of
@@ -47,16 +48,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int32_t i32x8 __attribute__((ext_vector_type(8)));
 
 namespace {
-constexpr int SD = 1024;
-constexpr int TR = 16;
-constexpr int PITCH = 1040;                     // 1024 B of a quarter row + 16 B: 16 rows hit 16 different bank slots
-constexpr int STAGE = TR * PITCH;               // 16640 B per compute wave per stage
+constexpr int TR = 16;      // rows per tile (one 16x16x4 MFMA row block)
 constexpr int NSTAGE = 2;
-constexpr int OFF_RED = 4 * NSTAGE * STAGE;     // 133120
-constexpr int RED_BYTES = 4 * 2 * 64 * 16;      // 8192 per exchange buffer (double-buffered by tile parity)
-constexpr int OFF_CM = OFF_RED + 2 * RED_BYTES; // 149504: closed-chunk maxima [16][32] fp32
-constexpr int OFF_STATE = OFF_CM + TR * 32 * 4; // 151552: running max of the open chunk [32]
-constexpr int LDS_TOTAL = OFF_STATE + 32 * 4;   // 151680 B
+// Compile-time geometry for dim = 4 * KW (KW = columns per compute wave, a multiple of 16).
+template <int KW>
+struct Geo {
+    static constexpr int DIM = 4 * KW;
+    static constexpr int QBYTES = KW * 4;                  // one quarter row: KW/4 lanes x 16 B per DMA instruction
+    static constexpr int PITCH = QBYTES + 16;              // +16 B: (KW/4 + 1) is odd -> 16 rows hit 16 different bank slots
+    static constexpr int STAGE = TR * PITCH;               // per compute wave per stage
+    static constexpr int KSTEPS = KW / 16;                 // ds_read_b128 per lane per tile; 4 MFMA k-steps each
+    static constexpr int OFF_RED = 4 * NSTAGE * STAGE;
+    static constexpr int RED_BYTES = 4 * 2 * 64 * 16;      // 8192 per exchange buffer (double-buffered by tile parity)
+    static constexpr int OFF_CM = OFF_RED + 2 * RED_BYTES; // closed-chunk maxima [16][32] fp32
+    static constexpr int OFF_STATE = OFF_CM + TR * 32 * 4; // running max of the open chunk [32]
+    static constexpr int LDS_TOTAL = OFF_STATE + 32 * 4;   // 151680 B at KW = 256
+};
 
 __device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ a, int64_t n, int64_t target) {
     int64_t lo = 0, hi = n;
@@ -75,14 +82,17 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 }  // namespace
 
-template <int NQT, int MODE, bool TRACE = false>
+template <int KW, int NQT, int MODE, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __restrict__ D, int64_t n_rows,
                                                                  const float* __restrict__ Q, int nq,
                                                                  const int32_t* __restrict__ row_to_chunk,
                                                                  const int64_t* __restrict__ chunk_offsets,
                                                                  int64_t n_chunks, float* __restrict__ out,
                                                                  int64_t ld, unsigned long long* trace) {
-    __shared__ __attribute__((aligned(16))) char smem[LDS_TOTAL];
+    using G_ = Geo<KW>;
+    constexpr int SD = G_::DIM, PITCH = G_::PITCH, STAGE = G_::STAGE, KSTEPS = G_::KSTEPS;
+    constexpr int OFF_RED = G_::OFF_RED, RED_BYTES = G_::RED_BYTES, OFF_CM = G_::OFF_CM, OFF_STATE = G_::OFF_STATE;
+    __shared__ __attribute__((aligned(16))) char smem[G_::LDS_TOTAL];
     const int lane = threadIdx.x & 63;
     const int wv = wave_id();          // 0..7
     // Optional tile timeline (diagnostic build only, RAGLITE_HIP_TRACE=1): workgroup 7, tiles 100..107, 8
@@ -123,14 +133,14 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
         // Q slice as MFMA B fragments: lane (j = lane & 15, kq = lane >> 4) holds, for MFMA 4*mm + tt,
         // Q[16*h + j][256*w + 16*mm + 4*kq + tt]  (a fixed permutation of K inside the wave).
         const int fj = lane & 15, kq = lane >> 4;
-        float qreg[NQT][64];
+        float qreg[NQT][KW / 4];
 #pragma unroll
         for (int h = 0; h < NQT; ++h) {
             const int qi = 16 * h + fj;
             const int qc_ = qi < nq ? qi : nq - 1;  // clamped load, zeroed below: padded query vectors add 0
 #pragma unroll
-            for (int mm = 0; mm < 16; ++mm) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(Q + (int64_t)qc_ * SD + 256 * w + 16 * mm + 4 * kq);
+            for (int mm = 0; mm < KSTEPS; ++mm) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(Q + (int64_t)qc_ * SD + KW * w + 16 * mm + 4 * kq);
                 if (qi >= nq) v = (f32x4){0.f, 0.f, 0.f, 0.f};
                 qreg[h][4 * mm + 0] = v[0]; qreg[h][4 * mm + 1] = v[1];
                 qreg[h][4 * mm + 2] = v[2]; qreg[h][4 * mm + 3] = v[3];
@@ -141,10 +151,10 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
             stamp(t, 0);
             wg_barrier();  // B1(t): tile t is in stage t&1
             stamp(t, 1);
-            f32x4 a[16];
+            f32x4 a[KSTEPS];
             const char* ap = a_base + (t & 1) * STAGE;
 #pragma unroll
-            for (int mm = 0; mm < 16; ++mm) a[mm] = *reinterpret_cast<const f32x4*>(ap + mm * 64);
+            for (int mm = 0; mm < KSTEPS; ++mm) a[mm] = *reinterpret_cast<const f32x4*>(ap + mm * 64);
             stamp(t, 2);
             wg_barrier();  // B2(t): (after lgkmcnt(0)) the stage may be refilled
             stamp(t, 3);
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
 #pragma unroll
             for (int h = 0; h < NQT; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int mm = 0; mm < 16; ++mm)
+            for (int mm = 0; mm < KSTEPS; ++mm)
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
@@ -174,8 +184,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
         // queues are full), so two of the four extra waves stream and never do anything else: loader l feeds the
         // K quarters 2l and 2l+1 (adjacent 1-KiB pieces of each row).
         const int lq = wv - 4;
-        const char* const src0 = reinterpret_cast<const char*>(D + 256 * (2 * lq));
+        const char* const src0 = reinterpret_cast<const char*>(D + KW * (2 * lq));
         const uint32_t lane_off = 16u * lane;
+        const bool lane_on = lane < KW / 4;  // a quarter row is KW/4 lanes x 16 B (all 64 lanes at dim 1024)
         auto dma_tile = [&](int t) {  // 2 x 16 quarter rows of tile t -> stage t&1; rows clamped to the corpus
             char* dst0 = smem + ((2 * lq) * NSTAGE + (t & 1)) * STAGE;
             char* dst1 = smem + ((2 * lq + 1) * NSTAGE + (t & 1)) * STAGE;
@@ -185,10 +196,12 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
                 int32_t row = row0 + i;
                 row = row < last_row ? row : last_row;
                 const char* p = src0 + (int64_t)row * (SD * 4) + lane_off;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                                 (__attribute__((address_space(3))) void*)(dst0 + i * PITCH), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 1024),
-                                                 (__attribute__((address_space(3))) void*)(dst1 + i * PITCH), 16, 0, 0);
+                if (lane_on) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
+                                                     (__attribute__((address_space(3))) void*)(dst0 + i * PITCH), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + KW * 4),
+                                                     (__attribute__((address_space(3))) void*)(dst1 + i * PITCH), 16, 0, 0);
+                }
             }
         };
         dma_tile(0);
@@ -362,23 +375,40 @@ int launch_row_to_chunk(const int64_t* chunk_offsets, int64_t n_chunks, int64_t 
     return RL_OK;
 }
 
+namespace {
+struct StreamArgs {
+    const float* D; int64_t n_rows; const float* Q; int nq; const int32_t* r2c; const int64_t* off; int64_t n_chunks;
+    int mode; float* out; int64_t ld; dim3 grid; hipStream_t s; unsigned long long* trace;
+};
+template <int KW>
+void launch_kw(const StreamArgs& a) {
+    const dim3 blk(512);
+#define RL_STREAM(NQT, MODE) hipLaunchKernelGGL((maxsim_stream_kernel<KW, NQT, MODE>), a.grid, blk, 0, a.s, a.D, a.n_rows, \
+                                                a.Q, a.nq, a.r2c, a.off, a.n_chunks, a.out, a.ld, a.trace)
+    if (a.mode == 0) { if (a.nq <= 16) RL_STREAM(1, 0); else RL_STREAM(2, 0); }
+    else             { if (a.nq <= 16) RL_STREAM(1, 1); else RL_STREAM(2, 1); }
+#undef RL_STREAM
+}
+}  // namespace
+
+// Fast path for dim in {128, 256, 384, 512, 768, 1024} (dim = 4 * KW, KW a multiple of 32) and nq <= 32.
 int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
-                          const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
-                          float* out, int64_t ld, int n_cu, hipStream_t s) {
-    if (dim != SD || nq < 1 || nq > 32 || n_rows < 1) return RL_ERR_UNSUPPORTED;
+                         const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
+                         float* out, int64_t ld, int n_cu, hipStream_t s) {
+    if (nq < 1 || nq > 32 || n_rows < 1) return RL_ERR_UNSUPPORTED;
+    if (dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
     const int64_t tiles = (n_rows + TR - 1) / TR;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles));
-    const dim3 g(grid), blk(512);
     static unsigned long long* trace = [] {
         unsigned long long* p = nullptr;
         if (std::getenv("RAGLITE_HIP_TRACE")) { (void)hipMalloc(&p, 8 * 8 * 8 * 8); (void)hipMemset(p, 0, 8 * 8 * 8 * 8); }
         return p;
     }();
-    if (trace && mode == 0 && nq > 16) {  // diagnostic build: dump the 30th launch's timeline to stderr
+    if (trace && mode == 0 && nq > 16 && dim == 1024) {  // diagnostic build: dump the 30th launch's timeline to stderr
         static int calls = 0;
-        hipLaunchKernelGGL((maxsim_stream_kernel<2, 0, true>), g, blk, 0, s, D, n_rows, Q, nq, row_to_chunk,
-                           chunk_offsets, n_chunks, out, ld, trace);
+        hipLaunchKernelGGL((maxsim_stream_kernel<256, 2, 0, true>), dim3(grid), dim3(512), 0, s, D, n_rows, Q, nq,
+                           row_to_chunk, chunk_offsets, n_chunks, out, ld, trace);
         if (++calls == 30) {
             unsigned long long h[8 * 8 * 8];
             (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
@@ -399,20 +429,14 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
         }
         return RL_OK;
     }
-    if (mode == 0) {
-        if (nq <= 16)
-            hipLaunchKernelGGL((maxsim_stream_kernel<1, 0>), g, blk, 0, s, D, n_rows, Q, nq, row_to_chunk, chunk_offsets,
-                               n_chunks, out, ld, trace);
-        else
-            hipLaunchKernelGGL((maxsim_stream_kernel<2, 0>), g, blk, 0, s, D, n_rows, Q, nq, row_to_chunk, chunk_offsets,
-                               n_chunks, out, ld, trace);
-    } else {
-        if (nq <= 16)
-            hipLaunchKernelGGL((maxsim_stream_kernel<1, 1>), g, blk, 0, s, D, n_rows, Q, nq, row_to_chunk, chunk_offsets,
-                               n_chunks, out, ld, trace);
-        else
-            hipLaunchKernelGGL((maxsim_stream_kernel<2, 1>), g, blk, 0, s, D, n_rows, Q, nq, row_to_chunk, chunk_offsets,
-                               n_chunks, out, ld, trace);
+    const StreamArgs a{D, n_rows, Q, (int)nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, dim3(grid), s, nullptr};
+    switch (dim) {
+        case 128: launch_kw<32>(a); break;
+        case 256: launch_kw<64>(a); break;
+        case 384: launch_kw<96>(a); break;
+        case 512: launch_kw<128>(a); break;
+        case 768: launch_kw<192>(a); break;
+        default: launch_kw<256>(a); break;
     }
     RL_HIP(hipGetLastError());
     return RL_OK;

@@ -312,6 +312,34 @@ def test_maxsim_stream_uniform_tolerance_and_linearity():
     idx.close()
 
 
+@pytest.mark.parametrize("dim", [128, 256, 384, 512, 768])
+@pytest.mark.parametrize("nq", [3, 16, 32])
+def test_maxsim_stream_other_dims(dim, nq):
+    """The MFMA streaming kernel is templated on dim/4 columns per compute wave: every supported dim, both
+    query-tile counts, ragged chunks with empties, exact on integer data; plus the batched row-score mode."""
+    rng = np.random.default_rng(dim + nq)
+    n = 3000 + dim // 64
+    E = oracle.synth_matrix(130 + dim, n, dim, "small_int")
+    off = ragged_offsets(rng, n, 1, 12, empty_every=9)
+    Q = oracle.synth_matrix(131 + dim, nq, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    ref = oracle.maxsim_scores(E, off, Q).astype(np.float32)
+    assert np.array_equal(idx.maxsim_scores(Q), ref)
+    s, c = idx.maxsim_topk(Q, 50)
+    es, ec = oracle.topk_desc(ref, 50)
+    assert np.array_equal(c, ec) and np.array_equal(s, es)
+    idx.close()
+    cos = raglite_amd.DeviceIndex(E, metric="cosine")
+    S, R = cos.search_rows(Q, 20)  # nq > 4 -> MFMA row-score mode + metric transform
+    for b in range(0, nq, max(1, nq // 3)):
+        es, ei = oracle.topk_desc(sim_fp32_exact(E, Q[b], "cosine"), 20)
+        if nq > 4:
+            assert_topk_close(S[b], R[b], oracle.similarity(E, Q[b], "cosine"), 20, TOL)
+        else:
+            assert np.array_equal(R[b], ei) and np.array_equal(S[b], es.astype(np.float32))
+    cos.close()
+
+
 @pytest.mark.parametrize("dim,nq", [(64, 5), (128, 40), (100, 3), (2048, 9)])
 def test_maxsim_generic_path(dim, nq):
     rng = np.random.default_rng(dim)
