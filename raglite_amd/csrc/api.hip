@@ -108,7 +108,7 @@ struct rl_index {
     int metric = RL_COSINE;
     bool has_empty_chunk = false;
     int64_t* offsets = nullptr;       // device [n_chunks + 1]
-    int32_t* row_to_chunk = nullptr;  // device [n_rows + 33]
+    int32_t* row_to_chunk = nullptr;  // device [n_rows + 65]
     float* norm = nullptr;            // device [n_rows]  (cosine)
     float* sumsq = nullptr;           // device [n_rows]  (l2)
     int n_cu = 256;
@@ -331,7 +331,7 @@ int rl_index_create(rl_index** out, const float* embeddings, int64_t n_rows, int
     }
     RL_IDX_HIP(hipMalloc(&idx->offsets, (size_t)(n_chunks + 1) * sizeof(int64_t)));
     RL_IDX_HIP(hipMemcpyAsync(idx->offsets, chunk_offsets, (size_t)(n_chunks + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    RL_IDX_HIP(hipMalloc(&idx->row_to_chunk, (size_t)(n_rows + 33) * sizeof(int32_t)));  // +1 terminator, +32 pad
+    RL_IDX_HIP(hipMalloc(&idx->row_to_chunk, (size_t)(n_rows + 65) * sizeof(int32_t)));  // +1 terminator, +64 pad
     RL_IDX(launch_row_to_chunk(idx->offsets, n_chunks, n_rows, idx->row_to_chunk, s));
     if (metric == RL_COSINE) RL_IDX_HIP(hipMalloc(&idx->norm, std::max<size_t>((size_t)n_rows * sizeof(float), 16)));
     if (metric == RL_L2) RL_IDX_HIP(hipMalloc(&idx->sumsq, std::max<size_t>((size_t)n_rows * sizeof(float), 16)));

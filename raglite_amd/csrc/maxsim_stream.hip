@@ -54,15 +54,19 @@ constexpr int NSTAGE = 2;
 template <int KW>
 struct Geo {
     static constexpr int DIM = 4 * KW;
-    static constexpr int QBYTES = KW * 4;                  // one quarter row: KW/4 lanes x 16 B per DMA instruction
-    static constexpr int PITCH = QBYTES + 16;              // +16 B: (KW/4 + 1) is odd -> 16 rows hit 16 different bank slots
-    static constexpr int STAGE = TR * PITCH;               // per compute wave per stage
+    static constexpr int QBYTES = KW * 4;                  // one K quarter of a row (what one compute wave consumes)
+    static constexpr int ROWB = DIM * 4;                   // one corpus row
+    static constexpr int PITCH = ROWB + 16;                // +16 B: row stride = 4 banks (mod 64) -> the 16 rows of one
+                                                           // ds_read_b128 pass hit 16 different 16-B bank groups
+    static constexpr int STAGE = TR * PITCH;               // one tile, row-major: [16 rows][DIM fp32 + pad]
+    static constexpr int NCH = (ROWB + 1023) / 1024;       // 1-KiB DMA instructions per row (the last may be half)
     static constexpr int KSTEPS = KW / 16;                 // ds_read_b128 per lane per tile; 4 MFMA k-steps each
-    static constexpr int OFF_RED = 4 * NSTAGE * STAGE;
-    static constexpr int RED_BYTES = 4 * 2 * 64 * 16;      // 8192 per exchange buffer (double-buffered by tile parity)
-    static constexpr int OFF_CM = OFF_RED + 2 * RED_BYTES; // closed-chunk maxima [16][32] fp32
-    static constexpr int OFF_STATE = OFF_CM + TR * 32 * 4; // running max of the open chunk [32]
-    static constexpr int LDS_TOTAL = OFF_STATE + 32 * 4;   // 151680 B at KW = 256
+    static constexpr int OFF_RED = NSTAGE * STAGE;
+    static constexpr int RED_BYTES = 4 * 2 * 64 * 16;      // 8192: K-partial exchange buffer (4 waves x 2 query halves)
+    static constexpr int OFF_ST = OFF_RED + RED_BYTES;     // K-reduced tile, transposed: [32 query columns][20] fp32
+    static constexpr int ST_PITCH = 20;                    // 16 rows + 4 pad floats: 80-B columns, b128-aligned
+    static constexpr int OFF_ORD = OFF_ST + 32 * ST_PITCH * 4;    // chunk ordinals of the tiles' rows: ring of 4 x 64 int32
+    static constexpr int LDS_TOTAL = OFF_ORD + 4 * 256;           // 143360 B at KW = 256
 };
 
 __device__ __forceinline__ int64_t lower_bound_i64(const int64_t* __restrict__ a, int64_t n, int64_t target) {
@@ -82,7 +86,7 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 }  // namespace
 
-template <int KW, int NQT, int MODE, bool TRACE = false>
+template <int KW, int NQT, int MODE, bool TRACE = false, int SPLR = 6>
 __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __restrict__ D, int64_t n_rows,
                                                                  const float* __restrict__ Q, int nq,
                                                                  const int32_t* __restrict__ row_to_chunk,
@@ -90,19 +94,36 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
                                                                  int64_t n_chunks, float* __restrict__ out,
                                                                  int64_t ld, unsigned long long* trace) {
     using G_ = Geo<KW>;
-    constexpr int SD = G_::DIM, PITCH = G_::PITCH, STAGE = G_::STAGE, KSTEPS = G_::KSTEPS;
-    constexpr int OFF_RED = G_::OFF_RED, RED_BYTES = G_::RED_BYTES, OFF_CM = G_::OFF_CM, OFF_STATE = G_::OFF_STATE;
-    __shared__ __attribute__((aligned(16))) char smem[G_::LDS_TOTAL];
+    constexpr int SD = G_::DIM, PITCH = G_::PITCH, STAGE = G_::STAGE, KSTEPS = G_::KSTEPS, NCH = G_::NCH, ROWB = G_::ROWB;
+    constexpr int OFF_RED = G_::OFF_RED, OFF_ST = G_::OFF_ST, ST_PITCH = G_::ST_PITCH, OFF_ORD = G_::OFF_ORD;
+    __shared__ __attribute__((aligned(16))) char smem[G_::LDS_TOTAL + (TRACE ? 4096 : 0)];
     const int lane = threadIdx.x & 63;
     const int wv = wave_id();          // 0..7
     // Optional tile timeline (diagnostic build only, RAGLITE_HIP_TRACE=1): workgroup 7, tiles 100..107, 8
-    // s_memtime stamps per wave per tile.  Compiled out of the production instantiation.
+    // s_memtime stamps per wave per tile, kept in LDS (a global store per stamp would queue behind the loaders' DMAs
+    // and distort the timeline) and copied out by each wave before it exits.  Compiled out of the production kernel.
+    int nt_trace = 0;
     auto stamp = [&](int t, int k) {
         if constexpr (TRACE) {
-            if (blockIdx.x == 7 && t >= 100 && t < 108 && lane == 0)
-                trace[((t - 100) * 8 + wv) * 8 + k] = __builtin_amdgcn_s_memtime();
+            // rows of the dump: tiles 100..105, then the workgroup's first and last tile (whole-kernel span)
+            const int slot = (t >= 100 && t < 106) ? t - 100 : (t == 0 ? 6 : (t == nt_trace - 1 ? 7 : -1));
+            if (blockIdx.x == 7 && slot >= 0 && lane == 0)
+                reinterpret_cast<unsigned long long*>(smem + G_::LDS_TOTAL)[(slot * 8 + wv) * 8 + k] =
+                    __builtin_amdgcn_s_memtime();
         }
     };
+    auto dump_trace = [&]() {
+        if constexpr (TRACE) {
+            if (blockIdx.x == 7) {
+                const int i = ((lane >> 3) * 8 + wv) * 8 + (lane & 7);
+                trace[i] = reinterpret_cast<unsigned long long*>(smem + G_::LDS_TOTAL)[i];
+            }
+        }
+    };
+    if constexpr (TRACE) {
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) reinterpret_cast<unsigned long long*>(smem + G_::LDS_TOTAL)[i] = 0;
+        __syncthreads();
+    }
     const int w = wv & 3;              // K quarter this wave computes (waves 0-3) or feeds (waves 4-7)
     const bool is_loader = wv >= 4;    // wave-uniform
     const int64_t G = gridDim.x, b = blockIdx.x;
@@ -122,10 +143,12 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
     r_lo = uniform_i64(r_lo);
     r_hi = uniform_i64(r_hi);
     const int nt = (int)((r_hi - r_lo + TR - 1) / TR);
+    nt_trace = nt;
     if (nt <= 0) return;  // whole workgroup: no barrier is skipped by a subset of its waves
     const int32_t last_row = (int32_t)(n_rows - 1);  // n_rows < 2^31 (checked by rl_index_create)
     const int32_t r_lo32 = (int32_t)r_lo;
-    char* const red_base = smem + OFF_RED;
+    char* const red = smem + OFF_RED;
+    float* const ST = reinterpret_cast<float*>(smem + OFF_ST);
     constexpr int NQC = 16 * NQT;
 
     if (!is_loader) {
@@ -146,7 +169,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
                 qreg[h][4 * mm + 2] = v[2]; qreg[h][4 * mm + 3] = v[3];
             }
         }
-        const char* const a_base = smem + w * NSTAGE * STAGE + fj * PITCH + kq * 16;
+        const char* const a_base = smem + fj * PITCH + w * G_::QBYTES + kq * 16;
         for (int t = 0; t < nt; ++t) {
             stamp(t, 0);
             wg_barrier();  // B1(t): tile t is in stage t&1
@@ -169,201 +192,250 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
 #pragma unroll
                     for (int h = 0; h < NQT; ++h)
                         acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mm][tt], qreg[h][4 * mm + tt], acc[h], 0, 0, 0);
-            char* red = red_base + (t & 1) * RED_BYTES;
             stamp(t, 4);
 #pragma unroll
             for (int h = 0; h < NQT; ++h) *reinterpret_cast<f32x4*>(red + ((w * 2 + h) * 64 + lane) * 16) = acc[h];
         }
         wg_barrier();  // B1(nt): publishes the K-partials of the last tile
+        wg_barrier();  // B2(nt): (the loaders reduce them in between)
+        dump_trace();
         return;
     }
 
     if (wv < 6) {
         // ==================================== LOADER WAVE (4, 5) ==================================================
-        // One loader already saturates a CU's share of HBM (VMEM issue blocks at memory rate once the CU's request
-        // queues are full), so two of the four extra waves stream and never do anything else: loader l feeds the
-        // K quarters 2l and 2l+1 (adjacent 1-KiB pieces of each row).
+        // Two of the four extra waves stream and never do anything else: loader l feeds rows 8l..8l+7 of every tile,
+        // NCH 1-KiB LDS-DMA instructions per row.  What bounds them is INSTRUCTION ISSUE, not memory: a wave that shares a
+        // SIMD with a compute wave gets about one issue slot per 32-cycle MFMA while that wave is in its MFMA phase
+        // (measured: the compiler's 6 instructions per DMA -- 64-bit address arithmetic, row clamp, M0 -- took ~5.8 k
+        // cycles per tile even with 7/8 of the chip idle).  So the steady-state path is hand-issued and costs
+        // 1.5 instructions per DMA: per row one SALU write of M0 (+ the hazard nop) and NCH DMAs that share one
+        // precomputed 32-bit lane offset, a wave-uniform 64-bit tile base, and the instruction's immediate offset,
+        // which the hardware adds to BOTH the global and the LDS address (hence the row-major stage layout).
         const int lq = wv - 4;
-        const char* const src0 = reinterpret_cast<const char*>(D + KW * (2 * lq));
+        const char* const src = reinterpret_cast<const char*>(D);
         const uint32_t lane_off = 16u * lane;
-        const bool lane_on = lane < KW / 4;  // a quarter row is KW/4 lanes x 16 B (all 64 lanes at dim 1024)
-        auto dma_tile = [&](int t) {  // 2 x 16 quarter rows of tile t -> stage t&1; rows clamped to the corpus
-            char* dst0 = smem + ((2 * lq) * NSTAGE + (t & 1)) * STAGE;
-            char* dst1 = smem + ((2 * lq + 1) * NSTAGE + (t & 1)) * STAGE;
-            const int32_t row0 = r_lo32 + t * TR;
+        uint32_t voff[8];  // byte offset of (row 8l + i, lane) inside a tile
 #pragma unroll
-            for (int i = 0; i < TR; ++i) {
-                int32_t row = row0 + i;
-                row = row < last_row ? row : last_row;
-                const char* p = src0 + (int64_t)row * (SD * 4) + lane_off;
-                if (lane_on) {
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)p,
-                                                     (__attribute__((address_space(3))) void*)(dst0 + i * PITCH), 16, 0, 0);
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + KW * 4),
-                                                     (__attribute__((address_space(3))) void*)(dst1 + i * PITCH), 16, 0, 0);
+        for (int i = 0; i < 8; ++i) voff[i] = (uint32_t)((8 * lq + i) * ROWB) + lane_off;
+        const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem) +
+                              (uint32_t)(8 * lq * PITCH);
+        constexpr bool HALF_TAIL = (ROWB % 1024) != 0;  // dims 128 / 384: the last DMA of a row is 32 lanes wide
+        // Rows i0..i1-1 (of this loader's 8) of tile t -> stage t&1.
+        const uint32_t lds_ord = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem) + OFF_ORD;
+        const uint32_t voff_ord = 4u * lane;
+        constexpr bool ORD = MODE == 0;  // MaxSim: loader 0 also brings the tile's chunk ordinals (64 int32 from its first row)
+        auto dma_rows = [&](int t, auto I0_, auto I1_) {
+            constexpr int i0 = decltype(I0_)::value, i1 = decltype(I1_)::value;
+            const int32_t row0 = r_lo32 + t * TR;
+            if constexpr (ORD && i0 == 0) {
+                if (lq == 0) {  // wave-uniform
+                    const int32_t rowc = row0 < last_row ? row0 : last_row;
+                    const int32_t* rc = row_to_chunk + rowc;
+                    const uint32_t dst = lds_ord + (uint32_t)((t & 3) * 256);
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(dst), "v"(voff_ord), "s"(rc)
+                                 : "memory", "m0");
+                }
+            }
+            if (row0 + TR - 1 <= last_row) {  // wave-uniform: the whole tile is inside the corpus
+                const char* base = src + (int64_t)row0 * ROWB;
+                const uint32_t lds = lds0 + (uint32_t)((t & 1) * STAGE);
+#pragma unroll
+                for (int i = i0; i < i1; ++i) {
+                    asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0" ::"s"(lds), "n"(i * PITCH) : "memory", "m0", "scc");
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        if (HALF_TAIL && c == NCH - 1) {
+                            if (lane < 32)
+                                asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff[i]), "s"(base), "n"(c * 1024) : "memory");
+                        } else {
+                            asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff[i]), "s"(base), "n"(c * 1024) : "memory");
+                        }
+                    }
+                }
+            } else {  // tail of the corpus (and look-ahead past it): clamp the rows; harmless re-reads keep vmcnt uniform
+                char* dst0 = smem + (t & 1) * STAGE + 8 * lq * PITCH;
+#pragma unroll
+                for (int i = i0; i < i1; ++i) {
+                    int32_t row = row0 + 8 * lq + i;
+                    row = row < last_row ? row : last_row;
+                    const char* p = src + (int64_t)row * ROWB + lane_off;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c)
+                        if (!(HALF_TAIL && c == NCH - 1) || lane < 32)
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + c * 1024),
+                                                             (__attribute__((address_space(3))) void*)(dst0 + i * PITCH + c * 1024), 16, 0, 0);
                 }
             }
         };
-        dma_tile(0);
-        dma_tile(1);  // rows past the range are clamped: harmless re-reads that keep the vmcnt bookkeeping uniform
+        using I0 = std::integral_constant<int, 0>;
+        using IS = std::integral_constant<int, SPLR>;
+        using I8 = std::integral_constant<int, 8>;
+        // K-reduction of the previous tile's partials, done HERE because the loaders have to pause between B1 and B2
+        // anyway (stage t&1 is still being read) and because in that window the compute waves issue LDS reads, not
+        // MFMAs, so a wave sharing their SIMD is not starved of issue slots (measured: the same 60 instructions took
+        // ~4.5 k cycles on an epilogue wave during the MFMA phase).  Loader l reduces row groups 2l and 2l+1 (one per
+        // half wave) for every query column; C/D layout: lane (16g + j) of half h holds rows 4g..4g+3 of query 16h + j.
+        auto kreduce = [&](int te) {
+            const int qcL = lane & (NQC - 1), g = 2 * lq + ((lane >> 5) & 1);
+            const int idx = 16 * g + (qcL & 15), qhL = qcL >> 4;
+            const f32x4 p0 = *reinterpret_cast<const f32x4*>(red + ((0 * 2 + qhL) * 64 + idx) * 16);
+            const f32x4 p1 = *reinterpret_cast<const f32x4*>(red + ((1 * 2 + qhL) * 64 + idx) * 16);
+            const f32x4 p2 = *reinterpret_cast<const f32x4*>(red + ((2 * 2 + qhL) * 64 + idx) * 16);
+            const f32x4 p3 = *reinterpret_cast<const f32x4*>(red + ((3 * 2 + qhL) * 64 + idx) * 16);
+            const f32x4 v = (p0 + p1) + (p2 + p3);  // fixed order: deterministic
+            if constexpr (MODE == 0) {
+                *reinterpret_cast<f32x4*>(ST + qcL * ST_PITCH + 4 * g) = v;  // transposed: one 16-B store per lane
+            } else {
+                const int32_t row0 = r_lo32 + te * TR;
+                const int nvalid = ((int32_t)r_hi - row0) < TR ? ((int32_t)r_hi - row0) : TR;
+                if ((lane & 31) < NQC && qcL < nq) {
+                    float* o = out + (int64_t)qcL * ld + row0 + 4 * g;
+                    if (4 * g + 3 < nvalid && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+                        *reinterpret_cast<f32x4*>(o) = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (4 * g + r < nvalid) o[r] = v[r];
+                    }
+                }
+            }
+        };
+        // The DMA stream runs SPLR of a tile's 8 rows ahead of the barrier pair: when the loader stops for B1(t)/B2(t), the
+        // first SPLR rows of tile t+1 are in flight and the rest follow right after B2(t).
+        dma_rows(0, I0{}, I8{});
+        dma_rows(1, I0{}, IS{});
         for (int t = 0; t < nt; ++t) {
             stamp(t, 0);
-            // Tile t has landed once at most the 32 DMAs of tile t+1 are still outstanding.
-            asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            // Loads retire in order: at most SPLR * NCH outstanding <=> tile t has landed (stores issued by kreduce in
+            // between only make the wait stricter).
+            if (ORD && lq == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPLR * NCH + 1) : "memory");  // + the ordinals of tile t+1
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPLR * NCH) : "memory");
             stamp(t, 1);
             wg_barrier();  // B1(t)
             stamp(t, 2);
-            wg_barrier();  // B2(t): stage t&1 is free
+            if (t > 0) kreduce(t - 1);
+            wg_barrier();  // B2(t): stage t&1 is free, the reduced tile t-1 is in ST
             stamp(t, 3);
-            dma_tile(t + 2);
+            dma_rows(t + 1, IS{}, I8{});  // stage (t+1)&1, free since B2(t-1)
+            dma_rows(t + 2, I0{}, IS{});  // stage t&1, free since B2(t)
             stamp(t, 4);
         }
         wg_barrier();  // B1(nt)
+        kreduce(nt - 1);
+        wg_barrier();  // B2(nt)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
+        dump_trace();
         return;
     }
 
-    // ==================================== EPILOGUE WAVE (6, 7) ======================================================
+    // ==================================== EPILOGUE WAVES (6, 7) =====================================================
+    // MODE 1 is finished by the loaders' K-reduction; in MODE 0 wave 6 turns each reduced tile into per-chunk scores and
+    // wave 7 only keeps the barrier count.  This wave shares a SIMD with a compute wave and gets an issue slot only
+    // every ~60 cycles while that wave multiplies (measured), so whatever it does between B2 and the next B1 must be
+    // SHORT or it delays every B1 (the first version's ~280 instructions did, by ~2 k cycles).  Hence:
+    //   * the chunk ordinals of a tile's rows arrive in LDS with the tile (ring OFF_ORD); lane i compares the ordinals
+    //     of rows i and i+1 and one v_cmp yields the chunk-end mask as a scalar;
+    //   * every lane owns one query column and walks the 16 rows with ONE v_max per row (inline asm: fmaxf() would add
+    //     two canonicalising v_max) and a wave-uniform branch where a chunk ends;
+    //   * a chunk's sum over the query columns is a 4-step DPP butterfly (+ one row broadcast for 32 columns) done on
+    //     the spot -- fixed order, deterministic -- and stored by one lane; the running maximum of the open chunk stays
+    //     in a register across tiles;
+    //   * the walk of tile t-1 runs in the NEXT B1..B2 window, where the compute waves read LDS instead of multiplying
+    //     and nobody is starved (after B2(t) this wave only copies its ST column into registers);
+    //   * finished chunks are collected lane-indexed (lane s = s-th chunk closed in the tile) and leave with ONE store
+    //     per tile, issued after B2 where waiting behind the loaders' DMA backlog costs nothing.
     const int ew = wv - 6;
-    float* const CM = reinterpret_cast<float*>(smem + OFF_CM);
-    float* const STATE = reinterpret_cast<float*>(smem + OFF_STATE);
     const int qc = lane & (NQC - 1);
-    const int qh = qc >> 4, qf = qc & 15;
-
-    // MaxSim epilogue of tile te (MODE 0).  C/D layout of 16x16x4: lane (16g + j) of half h holds rows 4g..4g+3 of
-    // query 16h + j.  Every lane takes one query column qc and walks the 16 rows with wave-uniform selects.
-    // Chunk ordinals of a tile's 16 rows + the row after it (row_to_chunk is padded by 32 entries): scalar loads
-    // issued by hand BEFORE the wave parks at B1, retired by that barrier's lgkmcnt(0).
-    [[maybe_unused]] i32x8 e_lo, e_hi;
-    [[maybe_unused]] int32_t e_last = 0;
-    auto load_ordinals = [&](int te) {
-        const int32_t* rc = row_to_chunk + (r_lo + (int64_t)te * TR);
-        asm volatile("s_load_dwordx8 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x20\n\ts_load_dword %2, %3, 0x40"
-                     : "=&s"(e_lo), "=&s"(e_hi), "=&s"(e_last)
-                     : "s"(rc)
-                     : "memory");
+    const bool col_on = qc < nq;
+    const bool store_lane = lane == 16 * (NQT - 1);
+    auto dpp_add = [](float x, auto CTRL) {
+        return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(CTRL)::value, 0xf, 0xf, false));
     };
-    auto epilogue_maxsim = [&](int te) {
-        const int32_t row0 = r_lo32 + te * TR;
-        stamp(te + 1, 3);
-        int32_t rcv[TR + 1];
+    float m = -INFINITY;  // running maximum of the chunk that is still open (per query column)
+    float sv[TR];         // this lane's query column of the tile being walked
+    float xacc = 0.f;     // lane s: score of the s-th chunk closed in the tile ...
+    int32_t cacc = 0;     // ... and its ordinal
+    int nclosed = 0;      // wave-uniform
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { rcv[i] = e_lo[i]; rcv[8 + i] = e_hi[i]; }
-        rcv[TR] = e_last;
-        const int nvalid = ((int32_t)r_hi - row0) < TR ? ((int32_t)r_hi - row0) : TR;
-        const char* red = red_base + (te & 1) * RED_BYTES;
-        float sv[TR];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int idx = 16 * g + qf;
-            const f32x4 p0 = *reinterpret_cast<const f32x4*>(red + ((0 * 2 + qh) * 64 + idx) * 16);
-            const f32x4 p1 = *reinterpret_cast<const f32x4*>(red + ((1 * 2 + qh) * 64 + idx) * 16);
-            const f32x4 p2 = *reinterpret_cast<const f32x4*>(red + ((2 * 2 + qh) * 64 + idx) * 16);
-            const f32x4 p3 = *reinterpret_cast<const f32x4*>(red + ((3 * 2 + qh) * 64 + idx) * 16);
-            const f32x4 v = (p0 + p1) + (p2 + p3);  // fixed order: deterministic
-            sv[4 * g + 0] = v[0]; sv[4 * g + 1] = v[1]; sv[4 * g + 2] = v[2]; sv[4 * g + 3] = v[3];
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stamp(te + 1, 4);
-        float m = (te == 0) ? -INFINITY : STATE[qc];
-        int slot = 0;       // chunks closed so far in this tile (wave-uniform)
-        int32_t cidv = -1;  // lane s: ordinal of the s-th chunk closed in this tile
-        uint32_t ends = 0;  // bit i: row0+i is the last row of its chunk (wave-uniform, scalar registers)
-#pragma unroll
-        for (int i = 0; i < TR; ++i) ends |= (uint32_t)(rcv[i] != rcv[i + 1]) << i;
-        if (nvalid < TR) ends &= (1u << nvalid) - 1u;  // rows past this workgroup's range belong to its neighbour
+    for (int i = 0; i < TR; ++i) sv[i] = -INFINITY;
+    int32_t rcl = 0;    // lane i: chunk ordinal of row i of the tile being walked
+    uint32_t ends = 0;  // bit i: row i is the last row of its chunk (wave-uniform)
+    // Chunk-end mask of tile te (its ordinals landed with the tile, before B1(te)): lane i compares rows i and i+1.
+    auto fetch_ordinals = [&](int te) {
+        const int32_t* ord = reinterpret_cast<const int32_t*>(smem + OFF_ORD + (te & 3) * 256);
+        rcl = ord[lane];
+        const int32_t rcn = ord[lane + 1 < 64 ? lane + 1 : 63];
+        ends = (uint32_t)__builtin_amdgcn_ballot_w64(rcl != rcn) & 0xffffu;
+        const int32_t left = (int32_t)r_hi - (r_lo32 + te * TR);
+        if (left < TR) ends &= (1u << left) - 1u;  // rows past this workgroup's range belong to its neighbour
+    };
+    // Rows of the fetched tile: segmented running max; a closed chunk is summed over the query columns at once.
+    auto walk = [&]() {
+        nclosed = 0;
 #pragma unroll
         for (int i = 0; i < TR; ++i) {
-            // one v_max per row; the closing work only runs (wave-uniform branch) where a chunk really ends
-            m = fmaxf(m, (i < nvalid) ? sv[i] : -INFINITY);
-            if ((ends >> i) & 1u) {
-                CM[slot * 32 + qc] = m;
-                cidv = (lane == slot) ? rcv[i] : cidv;
+            asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(sv[i]));
+            if (__builtin_expect((ends >> i) & 1u, 0)) {
+                float x = col_on ? m : 0.f;  // padded query columns add 0
+                x = dpp_add(x, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+                x = dpp_add(x, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+                x = dpp_add(x, std::integral_constant<int, 0x141>{});  // row_half_mirror
+                x = dpp_add(x, std::integral_constant<int, 0x140>{});  // row_mirror: every lane = sum of its 16
+                if constexpr (NQT == 2)  // lanes 16..31 += lane 15 (columns 0..15)
+                    x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xa, 0xf, false));
+                const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16 * (NQT - 1)));
+                const int32_t cid = __builtin_amdgcn_readlane(rcl, i);
+                xacc = lane == nclosed ? total : xacc;
+                cacc = lane == nclosed ? cid : cacc;
+                ++nclosed;
                 m = -INFINITY;
-                ++slot;
-            }
-        }
-        STATE[qc] = m;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        stamp(te + 1, 5);
-        // per-chunk sum over the query vectors: 4 lanes per closed chunk, PER maxima each, then a 2-step butterfly
-        const int cs = lane >> 2, part = lane & 3;
-        constexpr int PER = NQC / 4;
-        const int32_t cid = __shfl(cidv, cs, 64);
-        float x = 0.f;
-#pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int qq = part * PER + u;
-            const float cmv = CM[cs * 32 + qq];
-            x += (qq < nq) ? cmv : 0.f;
-        }
-        stamp(te + 1, 6);
-        x += __shfl_xor(x, 1, 64);
-        x += __shfl_xor(x, 2, 64);
-        if (part == 0 && cs < slot) out[cid] = x;
-        stamp(te + 1, 7);
-    };
-    // Row-score epilogue (MODE 1): finish row group grp (rows 4grp..4grp+3) of tile te for every query column.
-    auto epilogue_rows = [&](int te, int grp) {
-        if (lane >= NQC) return;
-        const int32_t row0 = r_lo32 + te * TR;
-        const int nvalid = ((int32_t)r_hi - row0) < TR ? ((int32_t)r_hi - row0) : TR;
-        const char* red = red_base + (te & 1) * RED_BYTES;
-        const int idx = 16 * grp + qf;
-        const f32x4 p0 = *reinterpret_cast<const f32x4*>(red + ((0 * 2 + qh) * 64 + idx) * 16);
-        const f32x4 p1 = *reinterpret_cast<const f32x4*>(red + ((1 * 2 + qh) * 64 + idx) * 16);
-        const f32x4 p2 = *reinterpret_cast<const f32x4*>(red + ((2 * 2 + qh) * 64 + idx) * 16);
-        const f32x4 p3 = *reinterpret_cast<const f32x4*>(red + ((3 * 2 + qh) * 64 + idx) * 16);
-        const f32x4 v = (p0 + p1) + (p2 + p3);
-        if (qc < nq) {
-            float* o = out + (int64_t)qc * ld + row0 + 4 * grp;
-            if (4 * grp + 3 < nvalid && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
-                *reinterpret_cast<f32x4*>(o) = v;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * grp + r < nvalid) o[r] = v[r];
             }
         }
     };
-    auto epilogue = [&](int te) {
-        if constexpr (MODE == 0) {
-            if ((te & 1) == ew) epilogue_maxsim(te);  // the two epilogue waves alternate tiles
-        } else {
-            epilogue_rows(te, 2 * ew);
-            epilogue_rows(te, 2 * ew + 1);
-        }
-    };
-    auto barrier_with_ordinals = [&]() {
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : "+s"(e_lo), "+s"(e_hi), "+s"(e_last)::"memory");
-    };
-    for (int t = 0; t < nt; ++t) {
+    const bool worker = MODE == 0 && ew == 0;  // wave-uniform
+    for (int t = 0; t <= nt; ++t) {  // iteration t: walk tile t-2 in the window, fetch tile t-1 after it; t = nt drains
         stamp(t, 0);
-        const bool mine = MODE == 0 && t > 0 && ((t - 1) & 1) == ew;  // wave-uniform
-        if (mine) load_ordinals(t - 1);
-        barrier_with_ordinals();  // B1(t): K-partials of tile t-1 are published
+        wg_barrier();  // B1(t)
         stamp(t, 1);
-        wg_barrier();  // B2(t)
+        if (worker && t > 1) walk();  // tile t-2: pure VALU/SALU work, nothing that queues behind the A-fragment reads
         stamp(t, 2);
-        if (t > 0) epilogue(t - 1);
+        wg_barrier();  // B2(t): the loaders have put the reduced tile t-1 into ST
+        stamp(t, 3);
+        if (worker && t > 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(ST + qc * ST_PITCH + 4 * g);
+                sv[4 * g + 0] = v[0]; sv[4 * g + 1] = v[1]; sv[4 * g + 2] = v[2]; sv[4 * g + 3] = v[3];
+            }
+            const int32_t left = (int32_t)r_hi - (r_lo32 + (t - 1) * TR);
+            if (left < TR) {  // last tile of the range only
+#pragma unroll
+                for (int i = 0; i < TR; ++i) sv[i] = i < left ? sv[i] : -INFINITY;
+            }
+            if (t > 1 && lane < nclosed) out[cacc] = xacc;  // tile t-2's chunks
+            fetch_ordinals(t - 1);
+            stamp(t, 4);
+        }
     }
-    const bool mine_last = MODE == 0 && ((nt - 1) & 1) == ew;
-    if (mine_last) load_ordinals(nt - 1);
-    barrier_with_ordinals();  // B1(nt)
-    epilogue(nt - 1);
+    if (worker) {
+        walk();
+        if (lane < nclosed) out[cacc] = xacc;
+    }
+    dump_trace();
 }
 
 __global__ __launch_bounds__(256) void row_to_chunk_kernel(const int64_t* __restrict__ chunk_offsets,
                                                             int64_t n_chunks, int64_t n_rows,
                                                             int32_t* __restrict__ row_to_chunk) {
-    // One thread per chunk writes its rows' ordinals; rc[n_rows .. n_rows+32] = -1 terminates the last chunk and
-    // pads the array so that a tile's 17-entry scalar read never leaves it.
+    // One thread per chunk writes its rows' ordinals; rc[n_rows .. n_rows+64] = -1 terminates the last chunk and
+    // pads the array so that a tile's 64-entry ordinal DMA (first row clamped to the corpus) never leaves it.
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += stride) {
         const int64_t b = chunk_offsets[c], e = chunk_offsets[c + 1];
         for (int64_t r = b; r < e; ++r) row_to_chunk[r] = (int32_t)c;
     }
-    if (blockIdx.x == 0 && threadIdx.x < 33) row_to_chunk[n_rows + threadIdx.x] = -1;
+    if (blockIdx.x == 0 && threadIdx.x < 65) row_to_chunk[n_rows + threadIdx.x] = -1;
 }
 
 int launch_row_to_chunk(const int64_t* chunk_offsets, int64_t n_chunks, int64_t n_rows, int32_t* row_to_chunk,
@@ -399,7 +471,8 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
     if (dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
     const int64_t tiles = (n_rows + TR - 1) / TR;
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles));
+    int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles));
+    if (const char* e = std::getenv("RAGLITE_HIP_GRID")) grid = std::max(8, std::min(grid, atoi(e)));  // diagnostic
     static unsigned long long* trace = [] {
         unsigned long long* p = nullptr;
         if (std::getenv("RAGLITE_HIP_TRACE")) { (void)hipMalloc(&p, 8 * 8 * 8 * 8); (void)hipMemset(p, 0, 8 * 8 * 8 * 8); }
@@ -412,11 +485,11 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
         if (++calls == 30) {
             unsigned long long h[8 * 8 * 8];
             (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
-            const unsigned long long t0 = h[0];
+            const unsigned long long t0 = h[6 * 64];  // first stamp of the workgroup's first tile
             fprintf(stderr, "TRACE columns: compute 0-3: arrive-B1 after-B1 after-A-reads after-B2 after-MFMA | "
                             "loader 4-5: before-vmcnt after-vmcnt after-B1 after-B2 after-DMA-issue | epilogue 6-7: "
-                            "arrive-B1 after-B1 after-B2 [epilogue of the previous tile:] start after-K-reduce "
-                            "after-row-walk after-chunk-sums done   (shader cycles)\n");
+                            "arrive-B1 after-B1 after-walk(t-2) after-B2 after-ST-copy/store/ordinals(t-1)   (s_memtime ticks "
+                            "since the first stamp; rows 'tile 106/107' are the workgroup's FIRST and LAST tile)\n");
             for (int t = 0; t < 8; ++t)
                 for (int wv = 0; wv < 8; ++wv) {
                     fprintf(stderr, "TRACE tile %d wave %d:", t + 100, wv);

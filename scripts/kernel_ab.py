@@ -1,0 +1,48 @@
+"""Box-normalised timing of the headline kernel: the MaxSim stream kernel next to the single-query scan kernel.
+
+    python scripts/kernel_ab.py [reps]
+
+GPU boxes differ by a few percent (clocks under load), so kernel variants measured on different boxes are compared
+through the ratio stream/scan: both kernels stream the same 4.096 GB corpus, and the scan kernel does not change
+between variants.
+"""
+
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+import torch  # noqa: E402
+
+import raglite_amd  # noqa: E402
+from bench import chunk_offsets  # noqa: E402
+
+
+def main() -> None:
+    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    n, d = 1_000_000, 1024
+    raglite_amd.set_device(0)
+    E = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=1)
+    Q = torch.empty((32, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=2)
+    idx = raglite_amd.DeviceIndex(E, chunk_offsets(n), metric="dot")
+    idx.time_kernel(0, Q, 5)
+    idx.time_kernel(1, Q[:1], 5)
+    stream, scan = [], []
+    for _ in range(reps):
+        stream.append(idx.time_kernel(0, Q, 20) / 20)
+        scan.append(idx.time_kernel(1, Q[:1], 20) / 20)
+    gb = 4.0 * n * d / 1e9
+    s, c = min(stream), min(scan)
+    print(json.dumps({"stream_ms": round(s, 4), "scan_ms": round(c, 4), "ratio": round(s / c, 4),
+                      "stream_GBps": round(gb / s * 1e3, 1), "scan_GBps": round(gb / c * 1e3, 1),
+                      "stream_all": [round(x, 4) for x in stream], "scan_all": [round(x, 4) for x in scan]}))
+
+
+if __name__ == "__main__":
+    main()
