@@ -11,32 +11,38 @@
 // 128 x 32 = 4.1 k cycles of v_mfma_f32_16x16x4_f32 per SIMD at nq = 32: HBM-bound, but only if the matrix pipe
 // and the memory pipeline really run side by side.
 //
-// Design (what the measurements forced -- see DESIGN.md section 5 and profiles/r01_*):
+// Design (what the measurements forced -- see DESIGN.md section 4.1 and profiles/r01_*):
 //  * one 512-thread workgroup per CU (LDS-limited), persistent over a contiguous, chunk-aligned row range, so
 //    per-chunk maxima never cross workgroups and there is no inter-workgroup hand-off;
-//  * WAVE SPECIALISATION.  A wave that issues MFMAs and `global_load_lds` itself stalls on every DMA once the
-//    CU's memory queues are full (VMEM issue blocks at memory rate: ~180-370 cycles per 1-KiB DMA measured), and
-//    an in-order wave cannot issue MFMAs while it is blocked.  So:
+//  * WAVE SPECIALISATION, shaped by one hardware fact: while a wave issues back-to-back v_mfma_f32_16x16x4_f32, every
+//    other wave on that SIMD gets an issue slot only every ~30-60 cycles (s_setprio does not help; s_nop between the
+//    MFMAs only slows them).  All four SIMDs carry a compute wave, so everything else must be FEW instructions, or
+//    must run while the compute waves are not multiplying:
 //      waves 0-3  COMPUTE, one per SIMD: K-split (wave w owns columns [256w, 256w+256); its 32 x 256 slice of Q
 //                 lives in 128 VGPRs as the MFMA B operand for the whole kernel, so Q costs no LDS traffic).
 //                 Per tile: 16 ds_read_b128 (A fragments), 128 MFMAs, one 2-KiB K-partial write.  Nothing else.
-//      waves 4-5  LOAD: stream D HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip; one instruction =
-//                 one fully coalesced 1-KiB quarter row) into two 16-row stages, always two tiles ahead.  Rows sit
-//                 at a 1040-B pitch so the A-operand read (16 lanes = 16 rows, same column) hits 16 different
-//                 16-B bank slots.  One loader already saturates a CU's share of HBM; two share the work.
-//      waves 6-7  EPILOGUE, alternating tiles: K-reduction of the four partials in a fixed order, segmented
-//                 running max over the tile's rows driven by wave-uniform chunk boundaries (hand-issued scalar
-//                 loads of row_to_chunk, retired while the wave is parked at a barrier), per-chunk sum over the
-//                 query vectors, store.
+//      waves 4-5  LOAD: stream D HBM -> LDS with `global_load_lds_dwordx4 ... nt` (no VGPR round trip; one instruction
+//                 = 1 KiB of a row) into two row-major 16-row stages, 1.75 tiles ahead.  Hand-issued: 1.5 instructions
+//                 per DMA (the compiler's 6 per DMA made the loaders the bottleneck at ~5.8 k cycles per tile).  Rows
+//                 sit at a (row + 16 B) pitch so the A-operand read (16 lanes = 16 rows, same column) hits 16
+//                 different 16-B bank groups.  Loader 0 also brings the tile's chunk ordinals into a small LDS ring.
+//                 In the B1..B2 window (below) the loaders do the K-reduction of the previous tile's partials.
+//      wave 6     EPILOGUE: segmented running max over the tile's rows (one v_max per row, wave-uniform branch at
+//                 chunk ends), DPP-butterfly sum over the query columns per finished chunk, one store per tile.  The
+//                 walk runs in the B1..B2 window; in the MFMA phase the wave only parks.  Wave 7 is idle (barriers).
 //  * two workgroup barriers per tile hand the stages back and forth:
 //      B1(t): tile t has landed (loaders waited on their own vmcnt) and the K-partials of tile t-1 are in LDS;
-//      B2(t): every compute wave holds tile t in registers -> stage t&1 may be refilled with tile t+2.
-//    The barriers retire LDS/SMEM operations only (`s_waitcnt lgkmcnt(0); s_barrier`), never VMEM: the DMAs stay
-//    in flight across them, counted with `s_waitcnt vmcnt(32)`.
+//      B2(t): every compute wave holds tile t in registers -> stage t&1 may be refilled with tile t+2; the reduced
+//             tile t-1 is in ST.
+//    The B1..B2 window is the only time the compute waves are not issuing MFMAs (they read A fragments, ~0.5 k
+//    cycles of LDS bandwidth), so it hosts the K-reduction (loaders) and the row walk of tile t-2 (wave 6).
+//    The barriers retire LDS operations only (`s_waitcnt lgkmcnt(0); s_barrier`), never VMEM: the DMAs stay in
+//    flight across them, counted with `s_waitcnt vmcnt(N)`.
 //  * deterministic: fixed K order inside a wave (fp32 MFMA is bitwise an ordered fmaf chain), fixed
-//    ((p0+p1)+(p2+p3)) across waves, fixed order of the per-chunk sum.
-// Measured on MI355X (32 x 1M x 1024, ragged chunks): 0.805 ms per corpus pass = 5.1 TB/s = 64 % of the 8 TB/s
-// peak, matrix pipe ~52 % busy; tile timeline in profiles/r01_tile_timeline.txt.
+//    ((p0+p1)+(p2+p3)) across waves, fixed butterfly order of the per-chunk sum.
+// Measured on MI355X (32 x 1M x 1024, ragged chunks): 0.66 ms per corpus pass = 6.2 TB/s = 78 % of the 8 TB/s peak --
+// the rate of the MFMA-free single-query scan kernel on the same box (scripts/kernel_ab.py); history 0.98 -> 0.81 ->
+// 0.66 ms and tile timelines in DESIGN.md section 4.1 / profiles/r01_tile_timeline*.txt.
 #include <cstdio>
 #include <cstdlib>
 
@@ -247,9 +253,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
                     for (int c = 0; c < NCH; ++c) {
                         if (HALF_TAIL && c == NCH - 1) {
                             if (lane < 32)
-                                asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff[i]), "s"(base), "n"(c * 1024) : "memory");
+                                asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2 nt" ::"v"(voff[i]), "s"(base), "n"(c * 1024) : "memory");
                         } else {
-                            asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2" ::"v"(voff[i]), "s"(base), "n"(c * 1024) : "memory");
+                            asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2 nt" ::"v"(voff[i]), "s"(base), "n"(c * 1024) : "memory");
                         }
                     }
                 }
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
                     for (int c = 0; c < NCH; ++c)
                         if (!(HALF_TAIL && c == NCH - 1) || lane < 32)
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + c * 1024),
-                                                             (__attribute__((address_space(3))) void*)(dst0 + i * PITCH + c * 1024), 16, 0, 0);
+                                                             (__attribute__((address_space(3))) void*)(dst0 + i * PITCH + c * 1024), 16, 0, /*nt*/ 2);
                 }
             }
         };
@@ -471,8 +477,7 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
     if (dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
     const int64_t tiles = (n_rows + TR - 1) / TR;
-    int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles));
-    if (const char* e = std::getenv("RAGLITE_HIP_GRID")) grid = std::max(8, std::min(grid, atoi(e)));  // diagnostic
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles));
     static unsigned long long* trace = [] {
         unsigned long long* p = nullptr;
         if (std::getenv("RAGLITE_HIP_TRACE")) { (void)hipMalloc(&p, 8 * 8 * 8 * 8); (void)hipMemset(p, 0, 8 * 8 * 8 * 8); }

@@ -15,13 +15,15 @@ struct VecLoad;
 template <>
 struct VecLoad<4> {
     static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        // token rows are read exactly once: non-temporal (no L1 allocation)
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
     }
 };
 template <>
 struct VecLoad<1> {
-    static __device__ __forceinline__ void load(const float* p, float (&v)[1]) { v[0] = *p; }
+    static __device__ __forceinline__ void load(const float* p, float (&v)[1]) { v[0] = __builtin_nontemporal_load(p); }
 };
 
 __device__ __forceinline__ uint16_t f64_to_f16_bits(double x) {

