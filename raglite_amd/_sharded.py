@@ -150,6 +150,26 @@ class ShardedIndex:
         gs = np.ascontiguousarray(g[..., 0]).view(np.float32)
         return gs, g[..., 1], None, single
 
+    def _exchange_merge_device(self, scores, ids_local, base: int, k: int):
+        """CUDA tensors in, CUDA tensors out, no host synchronisation: pack (score bits, global id) on the device,
+        ONE all-gather (RCCL), unpack, merge with `rl_merge_topk`.  Lets consecutive query batches queue
+        back to back on the stream (the host only enqueues)."""
+        import torch
+        import torch.distributed as dist
+
+        from . import _ops
+
+        gid = torch.where(ids_local >= 0, ids_local + base, torch.full_like(ids_local, -1)).to(torch.int32)
+        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+        if world == 1:
+            return scores, gid
+        packed = torch.stack([scores.contiguous().view(torch.int32), gid], dim=-1).contiguous()  # (B, k, 2)
+        out = torch.empty((world, *packed.shape), dtype=packed.dtype, device=packed.device)
+        dist.all_gather_into_tensor(out, packed, group=self.group)
+        gs = out[..., 0].contiguous().view(torch.float32)  # (world, B, k)
+        gi = out[..., 1].contiguous()
+        return _ops.merge_topk(gs, gi, k)
+
     # -- searches ----------------------------------------------------------------------------------------
     def search_rows(self, queries, k: int):
         """Global exact top-k rows: (scores (B,k), global row ordinals (B,k))."""
@@ -166,10 +186,13 @@ class ShardedIndex:
         return ms[0], mi[0]
 
     def maxsim_topk_batch(self, query_batch, k: int):
-        """A batch of queries (QB, nq, dim): QB local launches, ONE all-gather of (QB, k, 2) int32, one
-        host merge.  Returns (scores (QB,k), global chunk ordinals (QB,k))."""
+        """A batch of queries (QB, nq, dim): QB local launches, ONE all-gather of (QB, k, 2) int32, one merge
+        (on the device without any host synchronisation when the queries are CUDA tensors, else on the host).
+        Returns (scores (QB,k), global chunk ordinals (QB,k))."""
         if hasattr(self.local, "maxsim_topk_batch"):
             s, c = self.local.maxsim_topk_batch(query_batch, k)
+            if hasattr(s, "is_cuda") and s.is_cuda:  # device-resident queries: results stay on the device
+                return self._exchange_merge_device(s, c, self.chunk_base, k)
         else:
             outs = [self.local.maxsim_topk(query_batch[b], k) for b in range(len(query_batch))]
             s, c = np.stack([_to_numpy(o[0]) for o in outs]), np.stack([_to_numpy(o[1]) for o in outs])

@@ -1,0 +1,70 @@
+"""The N > 1 exchange on the device (pack -> all-gather -> unpack -> rl_merge_topk), exercised on ONE GPU by
+standing in for the collective: two half-corpus shards live on the same device and a patched
+`all_gather_into_tensor` hands each "rank" the other's packed list.  The result must equal the single-index search
+bit for bit (merge of per-shard top-k == global top-k)."""
+
+import numpy as np
+import pytest
+
+import raglite_amd
+from raglite_amd._sharded import ShardedIndex, shard_bounds_by_chunk
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_exchange_merge_two_shards(monkeypatch):
+    import torch
+    import torch.distributed as dist
+
+    raglite_amd.set_device(0)
+    n, d, k, nq, qb = 40_000, 1024, 100, 32, 3
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(1, 16, size=n)
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    off = off[off <= n]
+    if off[-1] != n:
+        off = np.append(off, n)
+    E = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=11)
+    Q = torch.empty((qb, nq, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=12)
+    full = raglite_amd.DeviceIndex(E, off, metric="dot")
+    ref_s, ref_c = full.maxsim_topk_batch(Q, k)
+
+    bounds = shard_bounds_by_chunk(off, 2)
+    shards = []
+    for c_lo, c_hi in bounds:
+        r_lo, r_hi = int(off[c_lo]), int(off[c_hi])
+        loc = off[c_lo : c_hi + 1] - off[c_lo]
+        idx = raglite_amd.DeviceIndex(E[r_lo:r_hi], loc, metric="dot")
+        shards.append(ShardedIndex(idx, row_base=r_lo, chunk_base=c_lo, local_chunk_offsets=loc))
+
+    # what each rank would contribute to the all-gather
+    packed = []
+    for sh in shards:
+        s, c = sh.local.maxsim_topk_batch(Q, k)
+        gid = torch.where(c >= 0, c + sh.chunk_base, torch.full_like(c, -1)).to(torch.int32)
+        packed.append(torch.stack([s.contiguous().view(torch.int32), gid], dim=-1).contiguous())
+
+    def fake_all_gather(out, inp, group=None):
+        # the calling rank's own slot must carry what it passed in; the peer's slot the peer's list
+        me = 0 if torch.equal(inp, packed[0]) else 1
+        assert torch.equal(inp, packed[me])
+        out[0].copy_(packed[0])
+        out[1].copy_(packed[1])
+
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake_all_gather)
+    for sh in shards:
+        s, c = sh.maxsim_topk_batch(Q, k)
+        assert s.is_cuda and c.is_cuda  # stayed on the device
+        assert torch.equal(s, ref_s) and torch.equal(c.to(ref_c.dtype), ref_c)
+    monkeypatch.undo()
+    # world = 1: global ids only, still on the device
+    one = ShardedIndex(full, row_base=0, chunk_base=7, local_chunk_offsets=off)
+    s, c = one.maxsim_topk_batch(Q, k)
+    assert s.is_cuda and torch.equal(s, ref_s) and torch.equal(c.to(ref_c.dtype), ref_c + 7)
+    for sh in shards:
+        sh.local.close()
+    full.close()
