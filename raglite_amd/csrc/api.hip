@@ -356,9 +356,18 @@ int rl_index_info(const rl_index* idx, int64_t* n_rows, int32_t* dim, int64_t* n
 namespace {
 
 // Similarity of `nb` device queries against every row -> idx->scores [nb x ld] (device).
+// Below this many queries the stream kernel's per-32-query corpus passes (HBM-bound) beat a 128-query GEMM tile.
+constexpr int32_t GEMM_MIN_QUERIES = 96;
+
 int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStream_t s) {
     const int mode = scan_mode(idx->metric);
     float* sc = idx->scores.as<float>();
+    if (nb >= GEMM_MIN_QUERIES) {  // MFMA-bound regime: one 128 x 128-tiled GEMM instead of a corpus pass per 32 queries
+        RL_TRY(idx->misc.reserve((size_t)nb * sizeof(float)));
+        const int st = launch_score_gemm(idx->E, idx->n_rows, idx->dim, d_q, nb, sc, ld, idx->norm, idx->sumsq,
+                                         idx->misc.as<float>(), mode, idx->n_cu, s);
+        if (st != RL_ERR_UNSUPPORTED) return st;
+    }
     if (nb > 4) {  // launch_maxsim_stream reports RL_ERR_UNSUPPORTED for dims outside its fast path
         // MFMA tile kernel, 32 queries per corpus pass, raw dots; then the metric transform.
         bool ok = true;

@@ -132,6 +132,10 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
                          const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
                          float* out, int64_t ld, int n_cu, hipStream_t s);
 // Any dim / nq: one wave per chunk (or per candidate), VALU dot products.
+// score_gemm.hip: similarity of many queries at once (fp32 MFMA GEMM, 128 x 128 tiles, fused metric); dim % 32 == 0.
+int launch_score_gemm(const float* E, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores,
+                      int64_t ld, const float* row_norm, const float* row_sumsq, float* q_sumsq_scratch, int mode,
+                      int n_cu, hipStream_t s);
 int launch_maxsim_generic(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride_queries,
                           const int64_t* chunk_offsets, const int32_t* candidates, int64_t n_items,
                           int32_t n_queries, float* out, hipStream_t s);

@@ -1,0 +1,238 @@
+// a6 for MANY queries at once (BASELINE cfg 5: B = 1000 against a 1.25 M-row shard): raw dots
+//     S[b * ld + r] = Q[b] . E[r]
+// as an exact-fp32 MFMA GEMM with the metric of src/raglite/_typing.py:123-134 applied in the epilogue (same
+// formulas as scan.hip:transform_kernel); select.hip takes the top-k.  Batched generalisation of src/raglite/_search.py:69-72.
+//
+// Why a second kernel next to maxsim_stream.hip (mode 1): that one re-streams the corpus once per 32 queries, which is
+// right up to ~64 queries (HBM-bound, AI = nq/2 flop/B) but at B = 1000 moves 164 GB for 2.56 TFLOP.  Here a
+// 128-query x 128-row tile keeps AI at 32 flop/B against L2 and the corpus leaves HBM about once: the bound is the
+// fp32 matrix pipe (157.3 TF peak; v_mfma_f32_16x16x4_f32 = 256 flop/clk/CU).
+//
+// Structure (same lessons as the stream kernel -- a wave that issues MFMAs must do nothing else):
+//   * one persistent 384-thread workgroup per CU: waves 0-3 compute a 64 x 64 quadrant each (16 accumulator tiles = 64
+//     VGPRs), waves 4-5 only issue LDS-DMA: wave 4 the E rows, wave 5 the Q rows of every K slab;
+//   * K slabs of 32 (128 B per row): one slab = 128 E rows + 128 Q rows = 32 KiB, ring of 4 slabs in LDS, loaders 3
+//     slabs ahead, ONE workgroup barrier per slab (slab g+3 overwrites the slot of slab g-1, which every compute wave
+//     has provably consumed before it reaches the barrier of slab g);
+//   * `global_load_lds_dwordx4` writes 64 lanes x 16 B contiguously, so rows sit unpadded at a 128-B pitch; bank
+//     conflicts are avoided by swizzling on the GLOBAL side instead: 16-B chunk c of row r is stored at chunk position
+//     c ^ ((r >> 1) & 7), and a fragment read (16 lanes = 16 rows, same chunk) then hits 16 different 16-B bank groups;
+//   * per slab and wave: 16 ds_read_b128 (8 E + 8 Q fragments, each good for 4 k-steps) feed 128 MFMAs; the second half
+//     of the reads lands while the first 64 MFMAs run;
+//   * tiles are enumerated so that the 8 query tiles of one row tile run back to back on ONE XCD (blockIdx % 8 is the
+//     XCD): E comes from HBM once and then from that XCD's L2;
+//   * deterministic and position-independent: every (row, query) sums K in the same fixed order.
+#include "common.h"
+
+namespace rl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int GM = 128;                 // queries per tile
+constexpr int GN = 128;                 // corpus rows per tile
+constexpr int GK = 32;                  // K per slab
+constexpr int NSLOT = 4;                // LDS ring
+constexpr int OP_BYTES = 128 * GK * 4;  // one operand of one slab: 128 rows x 128 B = 16 KiB
+constexpr int SLAB_BYTES = 2 * OP_BYTES;
+
+__global__ __launch_bounds__(384) void score_gemm_kernel(const float* __restrict__ E, int64_t n_rows, int32_t dim,
+                                                         const float* __restrict__ Q, int32_t B,
+                                                         float* __restrict__ S, int64_t ld, int64_t n_tiles,
+                                                         int32_t QT, const float* __restrict__ row_norm,
+                                                         const float* __restrict__ row_sumsq,
+                                                         const float* __restrict__ q_sumsq, int mode) {
+    __shared__ __attribute__((aligned(16))) char smem[NSLOT * SLAB_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wv = wave_id();
+    const int nslab = dim / GK;
+    const int64_t G = gridDim.x, b = blockIdx.x;
+    if (n_tiles <= b) return;
+    const int my_tiles = (int)((n_tiles - b + G - 1) / G);
+    const int total = my_tiles * nslab;  // K slabs this workgroup consumes, tile after tile
+    // Tile it of this workgroup -> first corpus row, first query.  Linear id L = it * G + b; L % 8 is the XCD the
+    // workgroup runs on; each XCD walks its own row tiles and takes all QT query tiles of one before the next.
+    auto decode = [&](int it, int64_t& row0, int32_t& q0) {
+        const int64_t L = (int64_t)it * G + b;
+        const int64_t x = L & 7, j = L >> 3;
+        q0 = (int32_t)(j % QT) * GM;
+        row0 = ((j / QT) * 8 + x) * GN;
+    };
+
+    if (wv < 4) {
+        // ================================ COMPUTE WAVE ==============================================================
+        const int wy = wv >> 1, wx = wv & 1;  // quadrant: queries [64 wy, +64), rows [64 wx, +64)
+        const int fj = lane & 15, kq = lane >> 4;
+        // fragment (16 rows x 4 k-steps): lane (fj, kq) reads chunk kk * 4 + kq of row fj, stored at chunk ^ (fj >> 1)
+        const uint32_t sw0 = (uint32_t)((kq ^ (fj >> 1)) * 16), sw1 = (uint32_t)(((4 + kq) ^ (fj >> 1)) * 16);
+        const uint32_t e_off = (uint32_t)((64 * wx + fj) * 128), q_off = (uint32_t)(OP_BYTES + (64 * wy + fj) * 128);
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int it = 0, sl = 0;
+        for (int g = 0; g < total; ++g) {
+            asm volatile("s_barrier" ::: "memory");  // slab g has landed (the loaders waited on their vmcnt)
+            const char* base = smem + (g & (NSLOT - 1)) * SLAB_BYTES;
+            f32x4 ea[2][4], qa[2][4];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const uint32_t sw = kk ? sw1 : sw0;
+#pragma unroll
+                for (int a = 0; a < 4; ++a) ea[kk][a] = *reinterpret_cast<const f32x4*>(base + e_off + a * 2048 + sw);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) qa[kk][c] = *reinterpret_cast<const f32x4*>(base + q_off + c * 2048 + sw);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[kk][a][tt], qa[kk][c][tt], acc[a][c], 0, 0, 0);
+            if (++sl == nslab) {
+                // tile done: C/D layout of 16x16x4 -- lane (16 gq + j) holds rows 4 gq .. 4 gq + 3 of column (query) j
+                int64_t row0;
+                int32_t q0;
+                decode(it, row0, q0);
+                const int gq = lane >> 4, j = lane & 15;
+                // Metric epilogue: the formulas (and operation order) of scan.hip:transform_kernel, so fused and
+                // unfused paths give the same bits.
+                f32x4 rn[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int64_t r = row0 + 64 * wx + 16 * a + 4 * gq;
+                    const float* src = mode == SCAN_COSINE ? row_norm : row_sumsq;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        rn[a][u] = (mode == SCAN_COSINE || mode == SCAN_L2) ? src[r + u < n_rows ? r + u : n_rows - 1] : 0.f;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int32_t q = q0 + 64 * wy + 16 * c + j;
+                    const float qss = q_sumsq[q < B ? q : B - 1];
+                    const float qn = sqrtf(qss);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int64_t r = row0 + 64 * wx + 16 * a + 4 * gq;
+                        f32x4 v = acc[a][c];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float d = v[u];
+                            if (mode == SCAN_COSINE) v[u] = 1.0f - (1.0f - d / (rn[a][u] * qn));
+                            else if (mode == SCAN_DOT) v[u] = 1.0f + d;
+                            else if (mode == SCAN_L2) v[u] = 1.0f - sqrtf(fmaxf(rn[a][u] + qss - 2.0f * d, 0.f));
+                        }
+                        if (q < B && r < n_rows) {
+                            float* o = S + (int64_t)q * ld + r;
+                            if (r + 3 < n_rows && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+                                *reinterpret_cast<f32x4*>(o) = v;
+                            } else {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
+                                    if (r + u < n_rows) o[u] = v[u];
+                            }
+                        }
+                        acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                sl = 0;
+                ++it;
+            }
+        }
+        return;
+    }
+
+    // ==================================== LOADER WAVE (4: E rows, 5: Q rows) ========================================
+    // 16 DMAs per slab: DMA i fills rows 8i .. 8i+7 (1 KiB of LDS); lane l -> row 8i + (l >> 3), chunk position l & 7,
+    // which holds source chunk (l & 7) ^ ((row >> 1) & 7).  Rows past the matrix are clamped (their results are never
+    // stored).  2 instructions per DMA: M0 and the load (per-lane offsets are per-tile constants).
+    const int op = wv - 4;
+    const char* const src = reinterpret_cast<const char*>(op == 0 ? E : Q);
+    const int64_t lim = (op == 0 ? n_rows : (int64_t)B) - 1;
+    const int64_t pitch = (int64_t)dim * 4;
+    const uint32_t lds_op = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem) +
+                            (uint32_t)(op * OP_BYTES);
+    uint32_t voff[16];
+    const char* tile_base = src;
+    int cur_it = -1;
+    auto issue = [&](int gi) {
+        int gg = gi < total ? gi : total - 1;  // past the end: harmless re-read that keeps the vmcnt bookkeeping uniform
+        const int it = gg / nslab, sl = gg - it * nslab;
+        if (it != cur_it) {  // wave-uniform: new tile -> per-lane row offsets relative to the tile's first row
+            cur_it = it;
+            int64_t row0;
+            int32_t q0;
+            decode(it, row0, q0);
+            int64_t first = op == 0 ? row0 : (int64_t)q0;
+            first = first < lim ? first : lim;
+            tile_base = src + first * pitch;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = 8 * i + (lane >> 3);
+                int64_t rr = first + r;
+                rr = rr < lim ? rr : lim;
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                voff[i] = (uint32_t)((rr - first) * pitch) + (uint32_t)(c * 16);
+            }
+        }
+        const char* base = tile_base + sl * (GK * 4);
+        const uint32_t lds = lds_op + (uint32_t)((gi & (NSLOT - 1)) * SLAB_BYTES);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" ::"s"(lds), "n"(i * 1024),
+                         "v"(voff[i]), "s"(base)
+                         : "memory", "m0", "scc");
+    };
+    issue(0);
+    issue(1);
+    issue(2);
+    for (int g = 0; g < total; ++g) {
+        asm volatile("s_waitcnt vmcnt(32)" ::: "memory");  // in-order: at most slabs g+1, g+2 outstanding => slab g landed
+        asm volatile("s_barrier" ::: "memory");
+        issue(g + 3);  // into the slot of slab g-1: every compute wave consumed it before reaching this barrier
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
+}
+
+// Sum of squares of every query, in transform_kernel's summation order (256 strided partial sums, wave butterflies,
+// ((p0+p1)+(p2+p3))), so the fused epilogue reproduces the unfused path bit for bit.
+__global__ __launch_bounds__(256) void query_sumsq_kernel(const float* __restrict__ queries, int dim,
+                                                           float* __restrict__ q_sumsq) {
+    __shared__ float part[4];
+    const int b = blockIdx.x;
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < dim; c += 256) {
+        const float v = queries[(int64_t)b * dim + c];
+        ss = fmaf(v, v, ss);
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) q_sumsq[b] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+}  // namespace
+
+// Similarity (metric `mode`, scan.hip conventions) of nb queries against every row; dim % 32 == 0, 16-B aligned
+// operands.  q_sumsq_scratch: device float[nb].
+int launch_score_gemm(const float* E, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores,
+                      int64_t ld, const float* row_norm, const float* row_sumsq, float* q_sumsq_scratch, int mode,
+                      int n_cu, hipStream_t s) {
+    if (nb < 1 || n_rows < 1 || dim < GK || dim % GK != 0) return RL_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(E) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
+    if ((mode == SCAN_COSINE && !row_norm) || (mode == SCAN_L2 && !row_sumsq)) return RL_ERR_INVALID;
+    const int64_t RT = (n_rows + GN - 1) / GN;
+    const int32_t QT = (nb + GM - 1) / GM;
+    const int64_t n_tiles = ((RT + 7) / 8) * 8 * QT;  // row tiles padded to a multiple of 8 (one residue class per XCD)
+    const int grid = (int)std::min<int64_t>(n_cu > 0 ? n_cu : 256, n_tiles);
+    hipLaunchKernelGGL(query_sumsq_kernel, dim3(nb), dim3(256), 0, s, Q, (int)dim, q_sumsq_scratch);
+    hipLaunchKernelGGL(score_gemm_kernel, dim3(grid), dim3(384), 0, s, E, n_rows, dim, Q, nb, scores, ld, n_tiles, QT,
+                       row_norm, row_sumsq, q_sumsq_scratch, mode);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+}  // namespace rl

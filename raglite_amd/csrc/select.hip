@@ -104,8 +104,20 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict_
     __syncthreads();
     const float* s = scores + (int64_t)q * ld;
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
-        atomicAdd(&h[score_key(s[i]) >> 21], 1u);
+    if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0) {  // 16-B loads: 4 elements per lane in flight
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4* s4 = reinterpret_cast<const f4*>(s);
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            const f4 v = s4[i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) atomicAdd(&h[score_key(v[u]) >> 21], 1u);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) atomicAdd(&h[score_key(s[(n4 << 2) + threadIdx.x]) >> 21], 1u);
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
+            atomicAdd(&h[score_key(s[i]) >> 21], 1u);
+    }
     __syncthreads();
     uint32_t* g = ws_hist + (int64_t)q * HIST_STRIDE;
     for (int i = threadIdx.x; i < HIST_BINS; i += 256)
@@ -131,8 +143,7 @@ __global__ __launch_bounds__(256) void topk_filter_kernel(const float* __restric
     uint64_t* sel = ws_sel + (int64_t)q * K_MAX;
     uint64_t* cand = ws_cand + (int64_t)q * CAND_CAP;
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        const float v = s[i];
+    auto visit = [&](float v, int64_t i) {
         const uint32_t bin = score_key(v) >> 21;
         if (bin > bstar) {
             const uint32_t p = atomicAdd(&g[CNT_SEL], 1u);
@@ -141,6 +152,19 @@ __global__ __launch_bounds__(256) void topk_filter_kernel(const float* __restric
             const uint32_t p = atomicAdd(&g[CNT_CAND], 1u);
             if (p < (uint32_t)CAND_CAP) cand[p] = make_key64(v, (uint32_t)i);
         }
+    };
+    if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0) {  // 16-B loads, streamed once more: nt
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4* s4 = reinterpret_cast<const f4*>(s);
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            const f4 v = __builtin_nontemporal_load(s4 + i);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) visit(v[u], (i << 2) + u);
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) visit(s[(n4 << 2) + threadIdx.x], (n4 << 2) + threadIdx.x);
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) visit(s[i], i);
     }
 }
 

@@ -87,6 +87,30 @@ def test_fullsize_batched_cosine_mfma_path(corpus):
     idx.close()
 
 
+def test_fullsize_gemm_path_cfg5_shape(corpus):
+    """cfg 5's per-GPU shape class: hundreds of queries against the full 1 M x 1024 corpus through score_gemm.hip."""
+    torch, E = corpus
+    B = 300
+    Q = torch.empty((B, D), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=64)
+    idx = raglite_amd.DeviceIndex(E, metric="cosine")
+    S, R = idx.search_rows(Q, 100)
+    norms = E.norm(dim=1)
+    for b in (0, 127, 128, 299):
+        cos = (E @ Q[b]) / (norms * Q[b].norm())
+        _check_topk_against(torch, S[b], R[b], cos, 100, 1e-4)
+    # the merge of two half-corpus searches equals the full search, bit for bit (scores are position-independent)
+    half = N // 2 + 77
+    lo = raglite_amd.DeviceIndex(E[:half], metric="cosine")
+    hi = raglite_amd.DeviceIndex(E[half:], metric="cosine")
+    s0, r0 = lo.search_rows(Q, 100)
+    s1, r1 = hi.search_rows(Q, 100)
+    ms, mr = raglite_amd.merge_topk(torch.stack([s0, s1]), torch.stack([r0, r1 + half]).int(), 100)
+    assert torch.equal(ms, S) and torch.equal(mr, R)
+    for i in (idx, lo, hi):
+        i.close()
+
+
 def test_fullsize_maxsim_32x1m(corpus):
     """The metric shape: 32 query vectors x 1 M chunk vectors, ragged chunks, exact top-100."""
     torch, E = corpus

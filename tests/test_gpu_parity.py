@@ -161,6 +161,48 @@ def test_search_rows_uniform_data_batched(metric, B):
     idx.close()
 
 
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+@pytest.mark.parametrize("n,dim,B", [(1000, 1024, 96), (4100, 1024, 130), (777, 128, 257), (2049, 384, 128), (130, 64, 100)])
+def test_search_rows_gemm_path_integer_bit_exact(metric, n, dim, B):
+    """B >= 96 takes the 128 x 128-tiled fp32 MFMA GEMM (score_gemm.hip): ragged tile edges in both directions,
+    every fast-path dim class; integer data => scores and indices bit-identical to the fp32 as-computed oracle,
+    and identical to what the single-query VALU path returns (position- and batch-independence)."""
+    E = oracle.synth_matrix(51, n, dim, "small_int")
+    Q = oracle.synth_matrix(52, B, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    k = 40
+    S, R = idx.search_rows(Q, k)
+    for b in (0, 1, 63, 64, B // 2, B - 2, B - 1):
+        ref = sim_fp32_exact(E, Q[b], metric)
+        es, ei = oracle.topk_desc(ref, k)
+        assert np.array_equal(R[b], ei), f"query {b}: indices differ"
+        assert np.array_equal(S[b].view(np.uint32), es.astype(np.float32).view(np.uint32)), f"query {b}: scores"
+        s1, r1 = idx.search_rows(Q[b], k)
+        assert np.array_equal(r1, R[b]) and np.array_equal(s1, S[b])
+    idx.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+def test_search_rows_gemm_path_uniform_tolerance(metric):
+    n, dim, B = 3001, 1024, 200
+    E = oracle.synth_matrix(53, n, dim)
+    Q = oracle.synth_matrix(54, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    S, R = idx.search_rows(Q, 50)
+    for b in (0, 17, 127, 128, 199):
+        assert_topk_close(S[b], R[b], oracle.similarity(E, Q[b], metric), 50, TOL)
+    S2, R2 = idx.search_rows(Q, 50)
+    assert np.array_equal(S, S2) and np.array_equal(R, R2)  # deterministic
+    # a row's score does not depend on where the row sits: shift the corpus by 37 rows
+    idx2 = raglite_amd.DeviceIndex(np.ascontiguousarray(E[37:]), metric=metric)
+    S3, R3 = idx2.search_rows(Q, 50)
+    for b in (0, 199):
+        keep = R[b] >= 37
+        assert np.array_equal(R[b][keep] - 37, R3[b][: keep.sum()]) and np.array_equal(S[b][keep], S3[b][: keep.sum()])
+    idx.close()
+    idx2.close()
+
+
 def test_search_rows_edge_cases(torch_cuda):
     dim = 64
     E = oracle.synth_matrix(51, 37, dim)
