@@ -219,6 +219,9 @@ int rl_pool_norm(const float* tokens, int64_t n_token_rows, int32_t dim, const i
     return finish(mem, s);
 }
 
+// Below this many queries the stream kernel's per-32-query corpus passes (HBM-bound) beat a 128-query GEMM tile.
+constexpr int32_t GEMM_MIN_QUERIES = 96;
+
 // ---- a5 ----------------------------------------------------------------------------------------------
 int rl_adapter_apply(const float* A, const float* queries, int32_t n_queries, int32_t dim, float* out_f32,
                      uint16_t* out_f16, int mem, void* stream) {
@@ -243,10 +246,15 @@ int rl_adapter_apply(const float* A, const float* queries, int32_t n_queries, in
     // through the MFMA tile kernel (32 queries per pass over A, which stays L2-resident), single queries and
     // other dims through the VALU scan.
     bool done = false;
-    if (n_queries > 4) {
-        int dev = 0, n_cu = 256;
-        RL_HIP(hipGetDevice(&dev));
-        RL_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    int dev = 0, n_cu = 256;
+    RL_HIP(hipGetDevice(&dev));
+    RL_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (n_queries >= GEMM_MIN_QUERIES) {  // cfg 5's B = 1000: one fp32 MFMA GEMM (score_gemm.hip)
+        const int st = launch_score_gemm(d_a, dim, dim, d_q, n_queries, d_res, dim, nullptr, nullptr, nullptr,
+                                         SCAN_RAW_DOT, n_cu, s);
+        if (st == RL_OK) done = true; else if (st != RL_ERR_UNSUPPORTED) return st;
+    }
+    if (!done && n_queries > 4) {
         done = true;
         for (int32_t b0 = 0; b0 < n_queries && done; b0 += 32) {
             const int32_t nq = std::min<int32_t>(32, n_queries - b0);
@@ -356,9 +364,6 @@ int rl_index_info(const rl_index* idx, int64_t* n_rows, int32_t* dim, int64_t* n
 namespace {
 
 // Similarity of `nb` device queries against every row -> idx->scores [nb x ld] (device).
-// Below this many queries the stream kernel's per-32-query corpus passes (HBM-bound) beat a 128-query GEMM tile.
-constexpr int32_t GEMM_MIN_QUERIES = 96;
-
 int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStream_t s) {
     const int mode = scan_mode(idx->metric);
     float* sc = idx->scores.as<float>();

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(384) void score_gemm_kernel(const float* __restrict
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int32_t q = q0 + 64 * wy + 16 * c + j;
-                    const float qss = q_sumsq[q < B ? q : B - 1];
+                    const float qss = (mode == SCAN_COSINE || mode == SCAN_L2) ? q_sumsq[q < B ? q : B - 1] : 0.f;
                     const float qn = sqrtf(qss);
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void query_sumsq_kernel(const float* __restric
 }  // namespace
 
 // Similarity (metric `mode`, scan.hip conventions) of nb queries against every row; dim % 32 == 0, 16-B aligned
-// operands.  q_sumsq_scratch: device float[nb].
+// operands.  q_sumsq_scratch: device float[nb] (cosine / l2 only).
 int launch_score_gemm(const float* E, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores,
                       int64_t ld, const float* row_norm, const float* row_sumsq, float* q_sumsq_scratch, int mode,
                       int n_cu, hipStream_t s) {
@@ -228,7 +228,10 @@ int launch_score_gemm(const float* E, int64_t n_rows, int32_t dim, const float* 
     const int32_t QT = (nb + GM - 1) / GM;
     const int64_t n_tiles = ((RT + 7) / 8) * 8 * QT;  // row tiles padded to a multiple of 8 (one residue class per XCD)
     const int grid = (int)std::min<int64_t>(n_cu > 0 ? n_cu : 256, n_tiles);
-    hipLaunchKernelGGL(query_sumsq_kernel, dim3(nb), dim3(256), 0, s, Q, (int)dim, q_sumsq_scratch);
+    if (mode == SCAN_COSINE || mode == SCAN_L2) {
+        if (!q_sumsq_scratch) return RL_ERR_INVALID;
+        hipLaunchKernelGGL(query_sumsq_kernel, dim3(nb), dim3(256), 0, s, Q, (int)dim, q_sumsq_scratch);
+    }
     hipLaunchKernelGGL(score_gemm_kernel, dim3(grid), dim3(384), 0, s, E, n_rows, dim, Q, nb, scores, ld, n_tiles, QT,
                        row_norm, row_sumsq, q_sumsq_scratch, mode);
     RL_HIP(hipGetLastError());

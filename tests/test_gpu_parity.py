@@ -113,8 +113,9 @@ def test_pool_norm_device_pointers(torch_cuda):
 # ---------------------------------------------------------------------------------------------------
 # a5: adapter
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("dim,B", [(64, 1), (1024, 1), (1024, 5), (768, 3), (100, 2)])
+@pytest.mark.parametrize("dim,B", [(64, 1), (1024, 1), (1024, 5), (768, 3), (100, 2), (1024, 40), (1024, 1000), (384, 97), (64, 130)])
 def test_adapter_apply(dim, B):
+    """Every batch class: VALU scan (B <= 4), MFMA stream kernel (5..95), fp32 MFMA GEMM (B >= 96; cfg 5 uses 1000)."""
     A = oracle.synth_matrix(21, dim, dim)
     Q = oracle.synth_matrix(22, B, dim)
     out = raglite_amd.adapter_apply(A, Q if B > 1 else Q[0])
