@@ -102,6 +102,23 @@ int rl_index_create(rl_index** out, const float* embeddings, int64_t n_rows, int
 int rl_index_destroy(rl_index* index);
 int rl_index_info(const rl_index* index, int64_t* n_rows, int32_t* dim, int64_t* n_chunks, int* metric);
 
+/* ---- index lifecycle beyond create/destroy -----------------------------
+ * rl_index_append: the device image of `insert_documents` appending `chunk_embedding` rows
+ * (src/raglite/_insert.py:247-272, rows ordered by chunk, src/raglite/_database.py:403-430).
+ *   rows             [n_new_rows x dim] f32 (host or device per `mem`)
+ *   new_chunk_sizes  HOST int64[n_new_chunks], sum == n_new_rows; NULL -> one chunk per new row.
+ * New rows / chunks get the next ordinals; existing ordinals never change.  The index takes
+ * ownership of its storage on the first append (a borrowed device matrix is copied once) and grows
+ * geometrically afterwards.
+ * rl_index_delete_chunks: the device image of `delete_documents` (src/raglite/_delete.py:148-176).
+ * The chunks' rows stay in place as tombstones (ordinals stay stable) and never match again in any
+ * search of this index; deleting twice is a no-op.  chunk_ordinals is a HOST array.
+ * rl_index_live: rows / chunks that are not tombstoned. */
+int rl_index_append(rl_index* index, const float* rows, int64_t n_new_rows, const int64_t* new_chunk_sizes,
+                    int64_t n_new_chunks, int mem, void* stream);
+int rl_index_delete_chunks(rl_index* index, const int64_t* chunk_ordinals, int64_t n, void* stream);
+int rl_index_live(rl_index* index, int64_t* live_rows, int64_t* live_chunks, void* stream);
+
 /* ---- a6 + a7: similarity + exact row top-k ----------------------------------------------------
  * Replaces the SQL at src/raglite/_search.py:69-79 (`sim = 1 - dist`, ORDER BY dist LIMIT k) with
  * dist per src/raglite/_typing.py:123-134, ranked EXACTLY (the reference's HNSW is approximate).
@@ -156,6 +173,24 @@ int rl_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_lists
  * stage used by every search above; exposed for tests and for callers that score elsewhere. */
 int rl_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32_t k,
             float* out_scores, int32_t* out_ids, int mem, void* stream);
+
+/* ---- metadata filter pushed down ---------------------------------------
+ * The filter-first branch of the reference's vector search (src/raglite/_search.py:96-119): only
+ * rows of chunks that match the metadata filter are ranked.  The caller evaluates the filter on its
+ * metadata (host) and passes the result as a bitset over chunk ordinals:
+ *   chunk_filter  uint32[(n_chunks + 31) / 32], bit (c % 32) of word (c / 32) set <=> chunk c may
+ *                 match (host or device per `mem`); NULL = no filter.
+ * Semantics otherwise identical to the unfiltered calls; slots that cannot be filled are reported
+ * as (-inf, -1) and excluded from out_counts.  Tombstoned chunks never match, filter or not. */
+int rl_search_rows_filtered(rl_index* index, const float* queries, int32_t n_queries, int32_t k,
+                            const uint32_t* chunk_filter, float* out_scores, int32_t* out_rows, int mem,
+                            void* stream);
+int rl_search_chunks_filtered(rl_index* index, const float* queries, int32_t n_queries, int32_t num_hits,
+                              int32_t k, const uint32_t* chunk_filter, float* out_scores, int32_t* out_chunks,
+                              int32_t* out_counts, int mem, void* stream);
+int rl_maxsim_topk_filtered(rl_index* index, const float* query_vecs, int32_t nq, int32_t k,
+                            const uint32_t* chunk_filter, float* out_scores, int32_t* out_chunks, int mem,
+                            void* stream);
 
 /* Timing hook for bench.py: run `fn`-independent -- records the elapsed milliseconds between two
  * events on `stream` bracketing `iters` back-to-back launches of the named kernel path with the

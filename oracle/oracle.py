@@ -293,6 +293,50 @@ def search_chunks(E, row_to_chunk, q, n_hits, num_results, metric="cosine", dtyp
 
 
 # ----------------------------------------------------------------------------------------
+# 8f-1: metadata filter (filter-first branch) and deleted chunks
+# ----------------------------------------------------------------------------------------
+
+
+def search_chunks_filtered(E, row_to_chunk, q, n_hits, num_results, chunk_ok, metric="cosine", dtype=np.float64):
+    """The reference's filtered vector search (`_search.py:96-149`) for an exact engine.
+
+    `chunk_ok[c]` = chunk c matches the metadata filter (`json_contains`, `:88-94`) and still exists
+    (deleted documents' chunks are gone from the table, `_delete.py:148-176`).  Filter-first branch
+    (`:105-119`): `WHERE chunk_id IN (matching) ORDER BY dist LIMIT n_hits`, then the per-chunk max
+    (`:143-149`).  The other branch (`:120-141`, more than 100 000 matching rows) first cuts the table
+    to its 1 000 000 nearest rows -- an artefact of serving it from the ANN index; on tables of up to
+    1 000 000 rows (every BASELINE config's single-GPU shard) both branches return the same rows, and
+    the restatement ranks exactly over all matching rows.
+    Returns (scores, chunk ordinals) like `group_chunk_max`."""
+    r2c = np.asarray(row_to_chunk)
+    ok_rows = np.asarray(chunk_ok, dtype=bool)[r2c]
+    sims = np.where(ok_rows, similarity(E, q, metric, dtype), -np.inf)
+    s, rows = topk_desc(sims, n_hits)
+    keep = rows >= 0
+    keep[keep] &= ok_rows[rows[keep]]  # non-matching rows only surface when fewer than n_hits rows match
+    return group_chunk_max(s[keep], r2c[rows[keep]], num_results)
+
+
+def search_rows_filtered(E, row_to_chunk, q, k, chunk_ok, metric="cosine", dtype=np.float64):
+    """Top-k rows among the rows of matching chunks; unfilled slots are (-inf, -1)."""
+    r2c = np.asarray(row_to_chunk)
+    ok_rows = np.asarray(chunk_ok, dtype=bool)[r2c]
+    sims = np.where(ok_rows, similarity(E, q, metric, dtype), -np.inf)
+    s, rows = topk_desc(sims, k)
+    dead = (rows >= 0) & ~ok_rows[np.clip(rows, 0, max(len(ok_rows) - 1, 0))] if len(ok_rows) else rows >= 0
+    return np.where(dead, -np.inf, s), np.where(dead, -1, rows)
+
+
+def maxsim_topk_filtered(D, chunk_offsets, Q, k, chunk_ok, dtype=np.float64):
+    """MaxSim top-k among matching chunks; unfilled slots are (-inf, -1)."""
+    sc = maxsim_scores(D, chunk_offsets, Q, dtype)
+    ok = np.asarray(chunk_ok, dtype=bool)
+    s, c = topk_desc(np.where(ok, sc, -np.inf), k)
+    dead = (c >= 0) & (~ok[np.clip(c, 0, max(len(ok) - 1, 0))] | np.isneginf(s))
+    return np.where(dead, -np.inf, s), np.where(dead, -1, c)
+
+
+# ----------------------------------------------------------------------------------------
 # a9: MaxSim (multi-query generalisation of _search.py:143-149 / _query_adapter.py:174)
 # ----------------------------------------------------------------------------------------
 

@@ -15,7 +15,16 @@ from raglite_amd._embed import (
     embedding_type,
     set_embedder_factory,
 )
-from raglite_amd._ops import DeviceIndex, adapter_apply, merge_topk, pool_norm, set_device, synth_fill, topk
+from raglite_amd._ops import (
+    DeviceIndex,
+    adapter_apply,
+    merge_topk,
+    pack_bits,
+    pool_norm,
+    set_device,
+    synth_fill,
+    topk,
+)
 from raglite_amd._search import (
     GpuIndex,
     GpuVectorSearch,
@@ -29,6 +38,7 @@ from raglite_amd._search import (
 from raglite_amd._sharded import ShardedIndex, merge_topk_host, shard_bounds_by_chunk
 
 __all__ = [
+    "pack_bits",
     "DeviceIndex", "GpuIndex", "GpuVectorSearch", "HotPathConfig", "MaxSimRanker", "ShardedIndex",
     "adapter_apply", "attach_index", "detach_index", "embed_strings", "embed_strings_with_late_chunking",
     "embed_strings_without_late_chunking", "embedding_type", "merge_topk", "merge_topk_host", "pool_norm",

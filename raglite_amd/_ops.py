@@ -182,6 +182,20 @@ def merge_topk(scores, ids, k: int):
     return o_s, o_i
 
 
+def pack_bits(mask) -> np.ndarray:
+    """Boolean mask (NumPy / torch, any device) -> little-endian uint32 bitset (bit i of word i // 32)."""
+    if _is_torch(mask):
+        mask = mask.detach().cpu().numpy()
+    m = np.asarray(mask)
+    if m.dtype == np.uint32 and m.ndim == 1:
+        return np.ascontiguousarray(m)
+    b = np.packbits(m.astype(bool).ravel(), bitorder="little")
+    pad = (-b.size) % 4
+    if pad:
+        b = np.concatenate([b, np.zeros(pad, np.uint8)])
+    return np.ascontiguousarray(b).view(np.uint32)
+
+
 class DeviceIndex:
     """Device-resident chunk-embedding matrix + chunk CSR: the GPU image of the reference's
     `chunk_embedding` table (`src/raglite/_database.py:403-430`).
@@ -247,28 +261,82 @@ class DeviceIndex:
         else:
             a.ensure_device()
 
+    def _filter(self, a: _Args, chunk_filter):
+        """chunk_filter (bool mask over chunks, or a packed uint32 bitset) -> pointer on the call's side, or None."""
+        if chunk_filter is None:
+            return None
+        bits = pack_bits(chunk_filter)
+        if bits.size != (self.n_chunks + 31) // 32:
+            raise ValueError("chunk_filter must have one entry per chunk")
+        if a.mem == MEM_DEVICE:
+            t = _torch().from_numpy(bits.view(np.int32)).to(a.device)
+            a.keep.append(t)
+            return t.data_ptr()
+        a.keep.append(bits)
+        return bits.ctypes.data
+
+    # -- lifecycle (SURVEY.md 8f-1) ---------------------------------------------------------------
+    def append(self, rows, chunk_sizes=None) -> None:
+        """Append embedding rows as new chunks (`insert_documents`, `src/raglite/_insert.py:247-272`): existing
+        row / chunk ordinals never change.  chunk_sizes: rows per new chunk (None = one chunk per row)."""
+        a = _Args()
+        p_r = a.inp(rows, np.float32)
+        r = a.keep[0]
+        if r.ndim != 2 or int(r.shape[1]) != self.dim:
+            raise ValueError("rows must be (n_new_rows, dim)")
+        n_new = int(r.shape[0])
+        if chunk_sizes is None:
+            sizes, p_sz, n_new_chunks = None, None, n_new
+        else:
+            sizes = np.ascontiguousarray(np.asarray(chunk_sizes), dtype=np.int64)
+            p_sz, n_new_chunks = sizes.ctypes.data, int(sizes.size)
+        self._prep(a)
+        check(lib().rl_index_append(self._handle, p_r, n_new, p_sz, n_new_chunks, a.mem, a.stream))
+        if self.chunk_offsets is not None or sizes is not None:
+            old = self.chunk_offsets if self.chunk_offsets is not None else np.arange(self.n_rows + 1, dtype=np.int64)
+            add = sizes if sizes is not None else np.ones(n_new, np.int64)
+            self.chunk_offsets = np.concatenate([old, old[-1] + np.cumsum(add)]).astype(np.int64)
+        self.n_rows += n_new
+        self.n_chunks += n_new_chunks
+        self._keep = None  # the index owns its storage after the first append
+
+    def delete_chunks(self, chunk_ordinals) -> None:
+        """Tombstone chunks (`delete_documents`, `src/raglite/_delete.py:148-176`): they never match again."""
+        c = np.ascontiguousarray(np.asarray(chunk_ordinals), dtype=np.int64).ravel()
+        _ensure_init(self.device.index or 0) if self.mem == MEM_DEVICE else _ensure_init(_current_device())
+        check(lib().rl_index_delete_chunks(self._handle, c.ctypes.data, int(c.size), None))
+
+    def live(self) -> tuple[int, int]:
+        """(live rows, live chunks)."""
+        r, c = C.c_int64(0), C.c_int64(0)
+        check(lib().rl_index_live(self._handle, C.byref(r), C.byref(c), None))
+        return int(r.value), int(c.value)
+
     # -- a6 + a7 -------------------------------------------------------------------------------
-    def search_rows(self, queries, k: int):
-        """Exact top-k rows: (scores (B,k) desc, rows (B,k) int32); padding = (-inf, -1)."""
+    def search_rows(self, queries, k: int, chunk_filter=None):
+        """Exact top-k rows: (scores (B,k) desc, rows (B,k) int32); padding = (-inf, -1).
+        chunk_filter: optional bool mask over chunks (the reference's filter-first branch, `_search.py:105-119`)."""
         a = _Args()
         p_q, B, single = self._queries(a, queries)
         o_s, p_s = a.out((B, k), np.float32)
         o_r, p_r = a.out((B, k), np.int32)
+        p_f = self._filter(a, chunk_filter)
         self._prep(a)
-        check(lib().rl_search_rows(self._handle, p_q, B, k, p_s, p_r, a.mem, a.stream))
+        check(lib().rl_search_rows_filtered(self._handle, p_q, B, k, p_f, p_s, p_r, a.mem, a.stream))
         return (o_s[0], o_r[0]) if single else (o_s, o_r)
 
     # -- a6 + a7 + a8 ----------------------------------------------------------------------------
-    def search_chunks(self, queries, num_hits: int, k: int):
-        """Reference two-stage semantics (`src/raglite/_search.py:66-79,143-149`):
-        returns (scores (B,k), chunk ordinals (B,k), counts (B,))."""
+    def search_chunks(self, queries, num_hits: int, k: int, chunk_filter=None):
+        """Reference two-stage semantics (`src/raglite/_search.py:66-79,143-149`; with chunk_filter the
+        filter-first branch `:105-119`): returns (scores (B,k), chunk ordinals (B,k), counts (B,))."""
         a = _Args()
         p_q, B, single = self._queries(a, queries)
         o_s, p_s = a.out((B, k), np.float32)
         o_c, p_c = a.out((B, k), np.int32)
         o_n, p_n = a.out((B,), np.int32)
+        p_f = self._filter(a, chunk_filter)
         self._prep(a)
-        check(lib().rl_search_chunks(self._handle, p_q, B, num_hits, k, p_s, p_c, p_n, a.mem, a.stream))
+        check(lib().rl_search_chunks_filtered(self._handle, p_q, B, num_hits, k, p_f, p_s, p_c, p_n, a.mem, a.stream))
         return (o_s[0], o_c[0], o_n[0]) if single else (o_s, o_c, o_n)
 
     # -- a9 ----------------------------------------------------------------------------------------
@@ -280,13 +348,14 @@ class DeviceIndex:
         check(lib().rl_maxsim_scores(self._handle, p_q, nq, p_s, a.mem, a.stream))
         return o_s
 
-    def maxsim_topk(self, query_vecs, k: int):
+    def maxsim_topk(self, query_vecs, k: int, chunk_filter=None):
         a = _Args()
         p_q, nq, _ = self._queries(a, query_vecs)
         o_s, p_s = a.out((k,), np.float32)
         o_c, p_c = a.out((k,), np.int32)
+        p_f = self._filter(a, chunk_filter)
         self._prep(a)
-        check(lib().rl_maxsim_topk(self._handle, p_q, nq, k, p_s, p_c, a.mem, a.stream))
+        check(lib().rl_maxsim_topk_filtered(self._handle, p_q, nq, k, p_f, p_s, p_c, a.mem, a.stream))
         return o_s, o_c
 
     def maxsim_topk_batch(self, query_batch, k: int):

@@ -54,7 +54,6 @@ class GpuIndex:
         if len(chunk_ids) != len(chunk_offsets) - 1:
             raise ValueError("one chunk id per chunk is required")
         self.chunk_ids = list(chunk_ids)
-        self._matrix = matrix  # kept for metadata-filtered searches (row gather)
         self.index = _ops.DeviceIndex(matrix, chunk_offsets, metric=metric)
         self.metric = metric
         self.query_adapter = None if query_adapter is None else np.asarray(query_adapter, dtype=np.float32)
@@ -70,6 +69,38 @@ class GpuIndex:
         if self._doc_to_ordinal is None:
             raise ValueError("GpuIndex was built without `docs`; MaxSimRanker cannot map strings to chunks")
         return self._doc_to_ordinal[doc]
+
+    # -- lifecycle -------------------------------------------------------------------------
+    def insert_chunks(self, chunk_ids: Sequence[ChunkId], chunk_embeddings, *, docs: Sequence[str] | None = None,
+                      metadata: Sequence[dict] | None = None) -> None:
+        """`insert_documents` on the device image (`src/raglite/_insert.py:247-272`): append the chunks'
+        embedding matrices; existing ordinals keep their meaning."""
+        mats = [np.asarray(m, dtype=np.float32).reshape(len(m), -1) for m in chunk_embeddings]
+        if len(mats) != len(chunk_ids):
+            raise ValueError("one embedding matrix per chunk id is required")
+        if any(cid in self._id_to_ordinal for cid in chunk_ids):
+            raise ValueError("chunk id already present")  # the reference skips existing documents (`_insert.py:184-186`)
+        if (self.docs is None) != (docs is None) or (self.metadata is None) != (metadata is None):
+            raise ValueError("docs / metadata must be given iff the index was built with them")
+        if not mats:
+            return
+        self.index.append(np.vstack(mats), np.asarray([len(m) for m in mats], dtype=np.int64))
+        base = len(self.chunk_ids)
+        self.chunk_ids.extend(chunk_ids)
+        self._id_to_ordinal.update({cid: base + i for i, cid in enumerate(chunk_ids)})
+        if docs is not None:
+            self.docs.extend(docs)
+            self._doc_to_ordinal.update({d: base + i for i, d in enumerate(docs)})
+        if metadata is not None:
+            self.metadata.extend(metadata)
+
+    def delete_chunks(self, chunk_ids: Sequence[ChunkId]) -> int:
+        """`delete_documents` on the device image (`src/raglite/_delete.py:148-176`): the chunks never match
+        again; unknown ids are ignored like the reference's `WHERE id IN (...)`.  Returns the number deleted."""
+        ords = [self._id_to_ordinal.pop(cid) for cid in chunk_ids if cid in self._id_to_ordinal]
+        if ords:
+            self.index.delete_chunks(np.asarray(ords, dtype=np.int64))
+        return len(ords)
 
     def close(self) -> None:
         self.index.close()
@@ -143,31 +174,18 @@ def vector_search(query: str | np.ndarray, *, num_results: int = 3, oversample: 
 
 
 def _filtered_search(gi: GpuIndex, q, num_hits: int, num_results: int, flt: dict):
-    """Filter-first branch of the reference (`_search.py:105-119`): restrict to the chunks whose metadata
-    contains the filter, then rank exactly.  The restricted rows are gathered into a temporary index."""
+    """Filter-first branch of the reference (`_search.py:96-119`): evaluate the JSON containment on the host
+    metadata, push the result down as a bitset over chunk ordinals, rank exactly among the matching rows."""
     if gi.metadata is None:
         raise ValueError("GpuIndex was built without `metadata`; metadata_filter cannot be applied")
-    allowed = [i for i, m in enumerate(gi.metadata) if _matches(m, flt)]
-    if not allowed:
+    allowed = np.fromiter((_matches(m, flt) for m in gi.metadata), dtype=bool, count=len(gi.metadata))
+    if not allowed.any():
         return [], []
-    rows_of = gi.index.chunk_offsets
-    sel = np.concatenate([np.arange(rows_of[c], rows_of[c + 1]) for c in allowed])
-    if _ops._is_torch(gi._matrix):  # noqa: SLF001 - device gather, rows never leave HBM
-        import torch
-
-        sub = gi._matrix.index_select(0, torch.as_tensor(sel, device=gi._matrix.device))  # noqa: SLF001
-    else:
-        sub = np.asarray(gi._matrix)[sel]  # noqa: SLF001
-    sizes = np.asarray([rows_of[c + 1] - rows_of[c] for c in allowed], dtype=np.int64)
-    off = np.concatenate(([0], np.cumsum(sizes)))
-    tmp = _ops.DeviceIndex(sub, off, metric=gi.metric)
-    try:
-        k = min(num_results, _ops.K_MAX)
-        scores, chunks, count = tmp.search_chunks(np.asarray(q, dtype=np.float32), min(num_hits, _ops.K_MAX), k)
-    finally:
-        tmp.close()
+    k = min(num_results, _ops.K_MAX)
+    scores, chunks, count = gi.index.search_chunks(np.asarray(q, dtype=np.float32), min(num_hits, _ops.K_MAX), k,
+                                                   chunk_filter=allowed)
     n = int(count)
-    return [gi.chunk_ids[allowed[c]] for c in chunks[:n].tolist()], [float(s) for s in scores[:n]]
+    return [gi.chunk_ids[c] for c in chunks[:n].tolist()], [float(s) for s in scores[:n]]
 
 
 class GpuVectorSearch:

@@ -117,6 +117,15 @@ struct rl_index {
     rl::Pool scores;                  // [B x ld] similarity scratch / chunk scores
     rl::Pool hits;                    // search_chunks: [B x num_hits] (score, row)
     rl::Pool misc;
+    // lifecycle (append / delete / filter)
+    int64_t cap_rows = 0;                 // rows the owned buffers (E, norm, sumsq, row_to_chunk) can hold
+    int64_t cap_chunks = 0;               // chunks the device CSR can hold
+    std::vector<int64_t> h_offsets;       // host copy of the CSR
+    std::vector<uint32_t> h_live;         // host bitset over chunks: 1 = live (empty until the first delete)
+    uint32_t* live_chunk_bits = nullptr;  // device copy of h_live (nullptr: every chunk is live)
+    uint32_t* live_row_bits = nullptr;    // the same expanded to rows
+    int64_t n_dead_chunks = 0, n_dead_rows = 0;
+    rl::Pool maskbuf;                     // per-call effective row mask
 };
 
 using namespace rl;
@@ -279,6 +288,9 @@ int rl_index_destroy(rl_index* idx) {
     if (idx->row_to_chunk) (void)hipFree(idx->row_to_chunk);
     if (idx->norm) (void)hipFree(idx->norm);
     if (idx->sumsq) (void)hipFree(idx->sumsq);
+    if (idx->live_chunk_bits) (void)hipFree(idx->live_chunk_bits);
+    if (idx->live_row_bits) (void)hipFree(idx->live_row_bits);
+    idx->maskbuf.release();
     select_workspace_free(idx->ws);
     idx->scores.release();
     idx->hits.release();
@@ -320,6 +332,9 @@ int rl_index_create(rl_index** out, const float* embeddings, int64_t n_rows, int
     idx->n_chunks = n_chunks;
     idx->metric = metric;
     idx->has_empty_chunk = has_empty;
+    idx->h_offsets.assign(chunk_offsets, chunk_offsets + n_chunks + 1);
+    idx->cap_rows = n_rows;
+    idx->cap_chunks = n_chunks;
     auto bail = [&](int code) { rl_index_destroy(idx); return code; };
 #define RL_IDX(expr) do { int _s = (expr); if (_s != RL_OK) return bail(_s); } while (0)
 #define RL_IDX_HIP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return bail(fail(_e == hipErrorOutOfMemory ? RL_ERR_NOMEM : RL_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e))); } while (0)
@@ -348,6 +363,141 @@ int rl_index_create(rl_index** out, const float* embeddings, int64_t n_rows, int
 #undef RL_IDX
 #undef RL_IDX_HIP
     *out = idx;
+    return RL_OK;
+}
+
+// ---- lifecycle: append / delete -------------------------------------------------
+namespace {
+// (Re)build the device live bitsets from idx->h_live.
+int upload_live_bits(rl_index* idx, hipStream_t s) {
+    if (idx->h_live.empty()) return RL_OK;
+    const size_t cw = (size_t)(idx->n_chunks + 31) / 32, rw = (size_t)(idx->n_rows + 31) / 32;
+    if (idx->live_chunk_bits) (void)hipFree(idx->live_chunk_bits);
+    if (idx->live_row_bits) (void)hipFree(idx->live_row_bits);
+    idx->live_chunk_bits = idx->live_row_bits = nullptr;
+    RL_HIP(hipMalloc(&idx->live_chunk_bits, std::max<size_t>(cw * 4, 16)));
+    RL_HIP(hipMalloc(&idx->live_row_bits, std::max<size_t>(rw * 4, 16)));
+    RL_HIP(hipMemcpyAsync(idx->live_chunk_bits, idx->h_live.data(), cw * 4, hipMemcpyHostToDevice, s));
+    RL_TRY(launch_expand_chunk_bits(idx->live_chunk_bits, idx->row_to_chunk, idx->n_rows, nullptr, idx->live_row_bits, s));
+    RL_HIP(hipStreamSynchronize(s));
+    return RL_OK;
+}
+}  // namespace
+
+int rl_index_delete_chunks(rl_index* idx, const int64_t* chunk_ordinals, int64_t n, void* stream) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_index_delete_chunks: null index");
+    if (n < 0 || (n > 0 && !chunk_ordinals)) return fail(RL_ERR_INVALID, "rl_index_delete_chunks: bad arguments");
+    for (int64_t i = 0; i < n; ++i)
+        if (chunk_ordinals[i] < 0 || chunk_ordinals[i] >= idx->n_chunks)
+            return fail(RL_ERR_INVALID, "rl_index_delete_chunks: chunk ordinal out of range");
+    if (n == 0) return RL_OK;
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    const size_t cw = (size_t)(idx->n_chunks + 31) / 32;
+    if (idx->h_live.empty()) idx->h_live.assign(cw, 0xffffffffu);
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t c = chunk_ordinals[i];
+        uint32_t& w = idx->h_live[(size_t)(c >> 5)];
+        const uint32_t bit = 1u << (c & 31);
+        if (w & bit) {
+            w &= ~bit;
+            ++idx->n_dead_chunks;
+            idx->n_dead_rows += idx->h_offsets[(size_t)c + 1] - idx->h_offsets[(size_t)c];
+        }
+    }
+    return upload_live_bits(idx, s);
+}
+
+int rl_index_live(rl_index* idx, int64_t* live_rows, int64_t* live_chunks, void* stream) {
+    (void)stream;
+    if (!idx) return fail(RL_ERR_INVALID, "rl_index_live: null index");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (live_rows) *live_rows = idx->n_rows - idx->n_dead_rows;
+    if (live_chunks) *live_chunks = idx->n_chunks - idx->n_dead_chunks;
+    return RL_OK;
+}
+
+int rl_index_append(rl_index* idx, const float* rows, int64_t n_new_rows, const int64_t* new_chunk_sizes,
+                    int64_t n_new_chunks, int mem, void* stream) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_index_append: null index");
+    if (n_new_rows < 0 || n_new_chunks < 0) return fail(RL_ERR_INVALID, "rl_index_append: negative size");
+    if (!new_chunk_sizes) n_new_chunks = n_new_rows;
+    if (n_new_rows == 0 && n_new_chunks == 0) return RL_OK;
+    if (n_new_rows > 0 && !rows) return fail(RL_ERR_INVALID, "rl_index_append: null rows");
+    if (new_chunk_sizes) {
+        int64_t tot = 0;
+        for (int64_t c = 0; c < n_new_chunks; ++c) {
+            if (new_chunk_sizes[c] < 0) return fail(RL_ERR_INVALID, "rl_index_append: negative chunk size");
+            tot += new_chunk_sizes[c];
+        }
+        if (tot != n_new_rows) return fail(RL_ERR_INVALID, "rl_index_append: chunk sizes must sum to n_new_rows");
+    }
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    const int64_t old_n = idx->n_rows, new_n = old_n + n_new_rows;
+    const int64_t old_c = idx->n_chunks, new_c = old_c + n_new_chunks;
+    if (new_n >= (int64_t)0x7fffffff - 1) return fail(RL_ERR_UNSUPPORTED, "rl_index_append: more than 2^31-2 rows");
+    const size_t row_bytes = (size_t)idx->dim * sizeof(float);
+    // ---- storage: own it, grow geometrically -----------------------------------------------------------
+    if (!idx->owns_E || new_n > idx->cap_rows) {
+        const int64_t cap = std::max<int64_t>(new_n, idx->cap_rows + idx->cap_rows / 2);  // geometric growth
+        float* e = nullptr;
+        RL_HIP(hipMalloc(&e, std::max<size_t>((size_t)cap * row_bytes, 16)));
+        if (old_n) RL_HIP(hipMemcpyAsync(e, idx->E, (size_t)old_n * row_bytes, hipMemcpyDeviceToDevice, s));
+        auto regrow = [&](float*& p) -> int {
+            if (!p) return RL_OK;
+            float* q = nullptr;
+            RL_HIP(hipMalloc(&q, std::max<size_t>((size_t)cap * sizeof(float), 16)));
+            if (old_n) RL_HIP(hipMemcpyAsync(q, p, (size_t)old_n * sizeof(float), hipMemcpyDeviceToDevice, s));
+            RL_HIP(hipStreamSynchronize(s));
+            (void)hipFree(p);
+            p = q;
+            return RL_OK;
+        };
+        RL_TRY(regrow(idx->norm));
+        RL_TRY(regrow(idx->sumsq));
+        int32_t* r2c = nullptr;
+        RL_HIP(hipMalloc(&r2c, (size_t)(cap + 65) * sizeof(int32_t)));
+        RL_HIP(hipStreamSynchronize(s));
+        if (idx->owns_E && idx->E) (void)hipFree(const_cast<float*>(idx->E));
+        (void)hipFree(idx->row_to_chunk);
+        idx->E = e;
+        idx->owns_E = true;
+        idx->row_to_chunk = r2c;
+        idx->cap_rows = cap;
+    }
+    if (new_c > idx->cap_chunks) {
+        const int64_t cap = std::max<int64_t>(new_c, idx->cap_chunks + idx->cap_chunks / 2);
+        int64_t* o = nullptr;
+        RL_HIP(hipMalloc(&o, (size_t)(cap + 1) * sizeof(int64_t)));
+        (void)hipFree(idx->offsets);
+        idx->offsets = o;
+        idx->cap_chunks = cap;
+    }
+    // ---- new rows, CSR, ordinals, norms ------------------------------------------------------------------
+    if (n_new_rows)
+        RL_HIP(hipMemcpyAsync(const_cast<float*>(idx->E) + (size_t)old_n * idx->dim, rows, (size_t)n_new_rows * row_bytes,
+                              mem == RL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+    idx->h_offsets.reserve((size_t)new_c + 1);
+    for (int64_t c = 0; c < n_new_chunks; ++c) {
+        const int64_t sz = new_chunk_sizes ? new_chunk_sizes[c] : 1;
+        idx->has_empty_chunk |= sz == 0;
+        idx->h_offsets.push_back(idx->h_offsets.back() + sz);
+    }
+    idx->n_rows = new_n;
+    idx->n_chunks = new_c;
+    RL_HIP(hipMemcpyAsync(idx->offsets, idx->h_offsets.data(), (size_t)(new_c + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    RL_TRY(launch_row_to_chunk(idx->offsets, new_c, new_n, idx->row_to_chunk, s));
+    if ((idx->norm || idx->sumsq) && n_new_rows)
+        RL_TRY(launch_row_norms(idx->E + (size_t)old_n * idx->dim, n_new_rows, idx->dim,
+                                idx->norm ? idx->norm + old_n : nullptr, idx->sumsq ? idx->sumsq + old_n : nullptr, s));
+    if (!idx->h_live.empty()) {  // new chunks are live
+        const size_t cw = (size_t)(new_c + 31) / 32;
+        idx->h_live.resize(cw, 0u);
+        for (int64_t c = old_c; c < new_c; ++c) idx->h_live[(size_t)(c >> 5)] |= 1u << (c & 31);
+        RL_TRY(upload_live_bits(idx, s));
+    }
+    RL_HIP(hipStreamSynchronize(s));  // the caller's buffers may go away after return
     return RL_OK;
 }
 
@@ -388,8 +538,19 @@ int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStrea
     return launch_scan_rows(idx->E, idx->n_rows, idx->dim, d_q, nb, idx->norm, mode, sc, ld, s);
 }
 
+// Effective row mask of a call: tombstones and-ed with the expanded chunk filter (nullptr = every row takes part).
+int effective_row_mask(rl_index* idx, const uint32_t* d_chunk_filter, hipStream_t s, const uint32_t** out) {
+    *out = idx->live_row_bits;
+    if (!d_chunk_filter || idx->n_rows == 0) return RL_OK;
+    RL_TRY(idx->maskbuf.reserve((size_t)((idx->n_rows + 31) / 32) * sizeof(uint32_t)));
+    RL_TRY(launch_expand_chunk_bits(d_chunk_filter, idx->row_to_chunk, idx->n_rows, idx->live_row_bits,
+                                    idx->maskbuf.as<uint32_t>(), s));
+    *out = idx->maskbuf.as<uint32_t>();
+    return RL_OK;
+}
+
 int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, float* d_scores, int32_t* d_rows,
-                       hipStream_t s) {
+                       hipStream_t s, const uint32_t* d_row_bits = nullptr) {
     const int64_t n = idx->n_rows;
     const int64_t ld = (n + 3) & ~int64_t(3);
     if (n == 0) {  // empty index: every slot is padding (the reference returns ([], []), tests/test_search.py:76-85)
@@ -403,9 +564,11 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
     for (int32_t b0 = 0; b0 < B; b0 += batch) {
         const int32_t nb = std::min<int32_t>(batch, B - b0);
         RL_TRY(score_rows(idx, d_q + (int64_t)b0 * idx->dim, nb, ld, s));
+        if (d_row_bits) RL_TRY(launch_mask_scores(idx->scores.as<float>(), nb, n, ld, d_row_bits, s));
         RL_TRY(launch_topk(idx->scores.as<float>(), nb, n, ld, k, idx->ws, d_scores + (int64_t)b0 * k,
                            d_rows + (int64_t)b0 * k, s));
     }
+    if (d_row_bits) RL_TRY(launch_fix_masked(d_scores, d_rows, (int64_t)B * k, s));  // masked rows are "no hit"
     return RL_OK;
 }
 
@@ -419,35 +582,49 @@ int check_search_args(const rl_index* idx, const float* q, int32_t B, int32_t k,
 
 }  // namespace
 
-int rl_search_rows(rl_index* idx, const float* queries, int32_t B, int32_t k, float* out_scores, int32_t* out_rows,
-                   int mem, void* stream) {
+int rl_search_rows_filtered(rl_index* idx, const float* queries, int32_t B, int32_t k, const uint32_t* chunk_filter,
+                            float* out_scores, int32_t* out_rows, int mem, void* stream) {
     RL_TRY(check_search_args(idx, queries, B, k, "rl_search_rows"));
     if (B == 0) return RL_OK;
     if (!out_scores || !out_rows) return fail(RL_ERR_INVALID, "rl_search_rows: null output");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
-    DevBuf t_q, t_s, t_r;
+    DevBuf t_q, t_s, t_r, t_f;
     const float* d_q; float* d_s; int32_t* d_r;
+    const uint32_t* d_f = nullptr;
+    const uint32_t* d_bits = nullptr;
+    if (chunk_filter) RL_TRY(stage_in(chunk_filter, (size_t)((idx->n_chunks + 31) / 32), mem, s, t_f, &d_f));
+    RL_TRY(effective_row_mask(idx, d_f, s, &d_bits));
     RL_TRY(stage_in(queries, (size_t)B * idx->dim, mem, s, t_q, &d_q));
     RL_TRY(stage_out_begin(out_scores, (size_t)B * k, mem, t_s, &d_s));
     RL_TRY(stage_out_begin(out_rows, (size_t)B * k, mem, t_r, &d_r));
-    RL_TRY(search_rows_device(idx, d_q, B, k, d_s, d_r, s));
+    RL_TRY(search_rows_device(idx, d_q, B, k, d_s, d_r, s, d_bits));
     RL_TRY(stage_out_end(out_scores, (size_t)B * k, mem, s, t_s));
     RL_TRY(stage_out_end(out_rows, (size_t)B * k, mem, s, t_r));
     return finish(mem, s);
 }
 
+int rl_search_rows(rl_index* idx, const float* queries, int32_t B, int32_t k, float* out_scores, int32_t* out_rows,
+                   int mem, void* stream) {
+    return rl_search_rows_filtered(idx, queries, B, k, nullptr, out_scores, out_rows, mem, stream);
+}
+
 // ---- a6 + a7 + a8 --------------------------------------------------------------------------------------
-int rl_search_chunks(rl_index* idx, const float* queries, int32_t B, int32_t num_hits, int32_t k, float* out_scores,
-                     int32_t* out_chunks, int32_t* out_counts, int mem, void* stream) {
+int rl_search_chunks_filtered(rl_index* idx, const float* queries, int32_t B, int32_t num_hits, int32_t k,
+                              const uint32_t* chunk_filter, float* out_scores, int32_t* out_chunks, int32_t* out_counts,
+                              int mem, void* stream) {
     RL_TRY(check_search_args(idx, queries, B, k, "rl_search_chunks"));
     if (num_hits < 1 || num_hits > K_MAX) return fail(RL_ERR_INVALID, "rl_search_chunks: num_hits must be in [1, 2048]");
     if (B == 0) return RL_OK;
     if (!out_scores || !out_chunks || !out_counts) return fail(RL_ERR_INVALID, "rl_search_chunks: null output");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
-    DevBuf t_q, t_s, t_c, t_n;
+    DevBuf t_q, t_s, t_c, t_n, t_f;
     const float* d_q; float* d_s; int32_t* d_c; int32_t* d_n;
+    const uint32_t* d_f = nullptr;
+    const uint32_t* d_bits = nullptr;
+    if (chunk_filter) RL_TRY(stage_in(chunk_filter, (size_t)((idx->n_chunks + 31) / 32), mem, s, t_f, &d_f));
+    RL_TRY(effective_row_mask(idx, d_f, s, &d_bits));
     RL_TRY(stage_in(queries, (size_t)B * idx->dim, mem, s, t_q, &d_q));
     RL_TRY(stage_out_begin(out_scores, (size_t)B * k, mem, t_s, &d_s));
     RL_TRY(stage_out_begin(out_chunks, (size_t)B * k, mem, t_c, &d_c));
@@ -455,7 +632,7 @@ int rl_search_chunks(rl_index* idx, const float* queries, int32_t B, int32_t num
     RL_TRY(idx->hits.reserve((size_t)B * num_hits * 8));
     float* h_s = idx->hits.as<float>();
     int32_t* h_r = reinterpret_cast<int32_t*>(h_s + (size_t)B * num_hits);
-    RL_TRY(search_rows_device(idx, d_q, B, num_hits, h_s, h_r, s));
+    RL_TRY(search_rows_device(idx, d_q, B, num_hits, h_s, h_r, s, d_bits));
     RL_TRY(launch_group_chunk_max(h_s, h_r, B, num_hits, idx->offsets, idx->n_chunks, k, d_s, d_c, d_n, s));
     RL_TRY(stage_out_end(out_scores, (size_t)B * k, mem, s, t_s));
     RL_TRY(stage_out_end(out_chunks, (size_t)B * k, mem, s, t_c));
@@ -463,8 +640,22 @@ int rl_search_chunks(rl_index* idx, const float* queries, int32_t B, int32_t num
     return finish(mem, s);
 }
 
+int rl_search_chunks(rl_index* idx, const float* queries, int32_t B, int32_t num_hits, int32_t k, float* out_scores,
+                     int32_t* out_chunks, int32_t* out_counts, int mem, void* stream) {
+    return rl_search_chunks_filtered(idx, queries, B, num_hits, k, nullptr, out_scores, out_chunks, out_counts, mem,
+                                     stream);
+}
+
 // ---- a9 --------------------------------------------------------------------------------------------------
 namespace {
+
+// Chunk-level masking of MaxSim scores: the caller's filter, then the tombstones.
+int mask_chunk_scores(rl_index* idx, float* d_scores, int32_t nb, int64_t ld, const uint32_t* d_chunk_filter,
+                      hipStream_t s) {
+    if (d_chunk_filter) RL_TRY(launch_mask_scores(d_scores, nb, idx->n_chunks, ld, d_chunk_filter, s));
+    if (idx->live_chunk_bits) RL_TRY(launch_mask_scores(d_scores, nb, idx->n_chunks, ld, idx->live_chunk_bits, s));
+    return RL_OK;
+}
 
 int maxsim_scores_device(rl_index* idx, const float* d_q, int32_t nq, float* d_out, hipStream_t s) {
     if (idx->n_chunks == 0) return RL_OK;
@@ -494,12 +685,13 @@ int rl_maxsim_scores(rl_index* idx, const float* query_vecs, int32_t nq, float* 
     RL_TRY(stage_in(query_vecs, (size_t)nq * idx->dim, mem, s, t_q, &d_q));
     RL_TRY(stage_out_begin(out_scores, (size_t)idx->n_chunks, mem, t_o, &d_o));
     RL_TRY(maxsim_scores_device(idx, d_q, nq, d_o, s));
+    RL_TRY(mask_chunk_scores(idx, d_o, 1, idx->n_chunks, nullptr, s));  // deleted chunks score -inf
     RL_TRY(stage_out_end(out_scores, (size_t)idx->n_chunks, mem, s, t_o));
     return finish(mem, s);
 }
 
-int rl_maxsim_topk(rl_index* idx, const float* query_vecs, int32_t nq, int32_t k, float* out_scores,
-                   int32_t* out_chunks, int mem, void* stream) {
+int rl_maxsim_topk_filtered(rl_index* idx, const float* query_vecs, int32_t nq, int32_t k, const uint32_t* chunk_filter,
+                            float* out_scores, int32_t* out_chunks, int mem, void* stream) {
     if (!idx) return fail(RL_ERR_INVALID, "rl_maxsim_topk: null index");
     if (nq < 1 || !query_vecs) return fail(RL_ERR_INVALID, "rl_maxsim_topk: need at least one query vector");
     if (k < 1) return fail(RL_ERR_INVALID, "rl_maxsim_topk: k must be >= 1");
@@ -507,17 +699,27 @@ int rl_maxsim_topk(rl_index* idx, const float* query_vecs, int32_t nq, int32_t k
     if (!out_scores || !out_chunks) return fail(RL_ERR_INVALID, "rl_maxsim_topk: null output");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
-    DevBuf t_q, t_s, t_c;
+    DevBuf t_q, t_s, t_c, t_f;
     const float* d_q; float* d_s; int32_t* d_c;
+    const uint32_t* d_f = nullptr;
+    if (chunk_filter) RL_TRY(stage_in(chunk_filter, (size_t)((idx->n_chunks + 31) / 32), mem, s, t_f, &d_f));
     RL_TRY(stage_in(query_vecs, (size_t)nq * idx->dim, mem, s, t_q, &d_q));
     RL_TRY(stage_out_begin(out_scores, (size_t)k, mem, t_s, &d_s));
     RL_TRY(stage_out_begin(out_chunks, (size_t)k, mem, t_c, &d_c));
     RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));
     RL_TRY(maxsim_scores_device(idx, d_q, nq, idx->scores.as<float>(), s));
+    const bool masked = d_f || idx->live_chunk_bits;
+    RL_TRY(mask_chunk_scores(idx, idx->scores.as<float>(), 1, idx->n_chunks, d_f, s));
     RL_TRY(launch_topk(idx->scores.as<float>(), 1, idx->n_chunks, idx->n_chunks, k, idx->ws, d_s, d_c, s));
+    if (masked) RL_TRY(launch_fix_masked(d_s, d_c, k, s));
     RL_TRY(stage_out_end(out_scores, (size_t)k, mem, s, t_s));
     RL_TRY(stage_out_end(out_chunks, (size_t)k, mem, s, t_c));
     return finish(mem, s);
+}
+
+int rl_maxsim_topk(rl_index* idx, const float* query_vecs, int32_t nq, int32_t k, float* out_scores,
+                   int32_t* out_chunks, int mem, void* stream) {
+    return rl_maxsim_topk_filtered(idx, query_vecs, nq, k, nullptr, out_scores, out_chunks, mem, stream);
 }
 
 int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queries, int32_t nq, int32_t k,
@@ -541,7 +743,9 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
     float* sc = idx->scores.as<float>();
     for (int32_t b = 0; b < n_queries; ++b)
         RL_TRY(maxsim_scores_device(idx, d_q + (size_t)b * q_elems, nq, sc + (int64_t)b * ld, s));
+    RL_TRY(mask_chunk_scores(idx, sc, n_queries, ld, nullptr, s));  // tombstones (no-op without deletions)
     RL_TRY(launch_topk(sc, n_queries, idx->n_chunks, ld, k, idx->ws, d_s, d_c, s));
+    if (idx->live_chunk_bits) RL_TRY(launch_fix_masked(d_s, d_c, (int64_t)n_queries * k, s));
     RL_TRY(stage_out_end(out_scores, (size_t)n_queries * k, mem, s, t_s));
     RL_TRY(stage_out_end(out_chunks, (size_t)n_queries * k, mem, s, t_c));
     return finish(mem, s);

@@ -123,6 +123,13 @@ int launch_group_chunk_max(const float* hit_scores, const int32_t* hit_rows, int
 int launch_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_lists, int32_t n_queries,
                       int32_t k_in, int32_t k, float* out_scores, int32_t* out_ids, hipStream_t s);
 
+// mask.hip: validity bitsets (metadata filter pushed down to the device, tombstones of deleted chunks)
+int launch_expand_chunk_bits(const uint32_t* chunk_bits, const int32_t* row_to_chunk, int64_t n_rows,
+                             const uint32_t* and_rows, uint32_t* row_bits, hipStream_t s);
+int launch_mask_scores(float* scores, int32_t nb, int64_t n, int64_t ld, const uint32_t* bits, hipStream_t s);
+int launch_fix_masked(const float* scores, int32_t* ids, int64_t count, hipStream_t s);
+int launch_popcount(const uint32_t* bits, int64_t n, unsigned long long* out_dev, hipStream_t s);
+
 // maxsim*.hip
 int launch_row_to_chunk(const int64_t* chunk_offsets, int64_t n_chunks, int64_t n_rows, int32_t* row_to_chunk,
                         hipStream_t s);

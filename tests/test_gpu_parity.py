@@ -507,4 +507,151 @@ def test_vector_search_and_rerank_dropins():
     out_ids = raglite_amd.rerank_chunks("q", [ids[i] for i in (30, 9, 2, 5, 41)], config=cfg_r,
                                         chunk_lookup=lambda cids: [by_id[c] for c in cids])
     assert [c.text for c in out_ids] == [c.text for c in out]
+    # lifecycle through the host mirror: inserted chunks are found, deleted chunks never come back
+    extra = [(m / np.linalg.norm(m, axis=1, keepdims=True)).astype(np.float16)
+             for m in (oracle.synth_matrix(300 + i, 2, dim) for i in range(3))]
+    gi.insert_chunks([f"new{i}" for i in range(3)], extra, docs=[f"new body {i}" for i in range(3)],
+                     metadata=[{"topic": ["Chemistry"]}] * 3)
+    top, sc = raglite_amd.vector_search(extra[1][0], num_results=3, config=cfg_na, index=gi)
+    assert top[0] == "new1" and abs(sc[0] - 1.0) < 1e-3
+    chem, _ = raglite_amd.vector_search(q, num_results=5, metadata_filter={"topic": "Chemistry"}, config=cfg_na, index=gi)
+    assert sorted(chem) == ["new0", "new1", "new2"]
+    assert gi.delete_chunks(["new1", ids[17]]) == 2
+    top2, _ = raglite_amd.vector_search(extra[1][0], num_results=8, config=cfg_na, index=gi)
+    assert "new1" not in top2 and len(top2) == 8
+    top3, _ = raglite_amd.vector_search(q, num_results=3, config=cfg_na, index=gi)
+    assert ids[17] not in top3
     gi.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# 8f-1: metadata filter pushed down, deleted chunks, appended rows
+# ---------------------------------------------------------------------------------------------------
+def _r2c(off):
+    return np.repeat(np.arange(len(off) - 1), np.diff(off))
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+@pytest.mark.parametrize("density", [0.5, 0.02, 0.0])
+def test_filtered_search_matches_oracle(metric, density):
+    """Filter-first branch (`_search.py:105-119`) as a device bitset: integer data => bit-exact against the oracle,
+    including filters that leave fewer rows than num_hits (padding) and filters that match nothing."""
+    rng = np.random.default_rng(7)
+    n, dim = 6000, 256
+    off = ragged_offsets(rng, n, 1, 9)
+    n_chunks = len(off) - 1
+    E = oracle.synth_matrix(61, n, dim, "small_int")
+    q = oracle.synth_matrix(62, 2, dim, "small_int")
+    ok = rng.random(n_chunks) < density
+    idx = raglite_amd.DeviceIndex(E, off, metric=metric)
+    r2c = _r2c(off)
+    for b in range(2):
+        ref = sim_fp32_exact(E, q[b], metric)
+        es, er = oracle.topk_desc(np.where(ok[r2c], ref, -np.inf), 80)
+        dead = (er >= 0) & ~ok[r2c][np.clip(er, 0, n - 1)]
+        es, er = np.where(dead, -np.inf, es), np.where(dead, -1, er)
+        s, r = idx.search_rows(q[b], 80, chunk_filter=ok)
+        assert np.array_equal(r, er) and np.array_equal(s, es.astype(np.float32))
+        # two-stage semantics with the filter
+        ws, wc = oracle.search_chunks_filtered(E, r2c, q[b], 80, 10, ok, metric)
+        gs, gc, cnt = idx.search_chunks(q[b], 80, 10, chunk_filter=ok)
+        assert int(cnt) == len(wc) and np.array_equal(gc[: len(wc)], wc)
+        np.testing.assert_allclose(gs[: len(wc)], ws, atol=TOL)
+    # MaxSim with the filter
+    Q = oracle.synth_matrix(63, 7, dim, "small_int")
+    ws, wc = oracle.maxsim_topk_filtered(E, off, Q, 50, ok)
+    gs, gc = idx.maxsim_topk(Q, 50, chunk_filter=ok)
+    assert np.array_equal(gc, wc) and np.array_equal(gs, ws.astype(np.float32))
+    idx.close()
+
+
+def test_filter_device_pointers_and_unfiltered_equivalence(torch_cuda):
+    torch = torch_cuda
+    n, dim = 5000, 1024
+    rng = np.random.default_rng(8)
+    off = ragged_offsets(rng, n, 1, 15)
+    E = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=64)
+    q = torch.empty((3, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(q, seed=65)
+    idx = raglite_amd.DeviceIndex(E, off, metric="cosine")
+    all_ok = np.ones(len(off) - 1, bool)
+    s0, r0 = idx.search_rows(q, 64)
+    s1, r1 = idx.search_rows(q, 64, chunk_filter=all_ok)
+    assert torch.equal(s0, s1) and torch.equal(r0, r1)
+    ok = rng.random(len(off) - 1) < 0.3
+    s2, r2 = idx.search_rows(q, 64, chunk_filter=torch.as_tensor(ok, device="cuda"))
+    r2c = _r2c(off)
+    assert ok[r2c[r2.cpu().numpy()]].all()
+    Eh = E.cpu().numpy()
+    for b in range(3):
+        assert_topk_close(s2[b].cpu().numpy(), r2[b].cpu().numpy(),
+                          np.where(ok[r2c], oracle.similarity(Eh, q[b].cpu().numpy(), "cosine"), -np.inf), 64, TOL)
+    idx.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_index_append_and_delete_lifecycle(metric):
+    """insert_documents / delete_documents on the device image: an index grown by appends and thinned by deletes
+    answers exactly like a fresh index over the surviving rows (ordinals mapped back), bit for bit."""
+    rng = np.random.default_rng(9)
+    dim = 384
+    parts = [(1500, 61), (700, 62), (1, 63), (2200, 64)]
+    Es, offs = [], []
+    for n, seed in parts:
+        Es.append(oracle.synth_matrix(seed, n, dim, "small_int"))
+        offs.append(ragged_offsets(rng, n, 1, 7))
+    idx = raglite_amd.DeviceIndex(Es[0], offs[0], metric=metric)
+    for E, off in zip(Es[1:], offs[1:]):
+        idx.append(E, np.diff(off))
+    E_all = np.concatenate(Es)
+    off_all = np.concatenate([[0]] + [o[1:] + sum(len(e) for e in Es[:i]) for i, o in enumerate(offs)]).astype(np.int64)
+    assert idx.n_rows == len(E_all) and idx.n_chunks == len(off_all) - 1
+    assert np.array_equal(idx.chunk_offsets, off_all)
+    fresh = raglite_amd.DeviceIndex(E_all, off_all, metric=metric)
+    q = oracle.synth_matrix(66, 3, dim, "small_int")
+    Q = oracle.synth_matrix(67, 5, dim, "small_int")
+    for b in range(3):
+        a, f = idx.search_rows(q[b], 100), fresh.search_rows(q[b], 100)
+        assert np.array_equal(a[0], f[0]) and np.array_equal(a[1], f[1])
+    a, f = idx.maxsim_topk(Q, 60), fresh.maxsim_topk(Q, 60)
+    assert np.array_equal(a[0], f[0]) and np.array_equal(a[1], f[1])
+    # delete a third of the chunks (some twice), including the very first and the very last
+    n_chunks = len(off_all) - 1
+    dead = np.unique(np.concatenate([rng.choice(n_chunks, n_chunks // 3, replace=False), [0, n_chunks - 1]]))
+    idx.delete_chunks(dead)
+    idx.delete_chunks(dead[:5])
+    alive = np.ones(n_chunks, bool)
+    alive[dead] = False
+    r2c = _r2c(off_all)
+    assert idx.live() == (int(alive[r2c].sum()), int(alive.sum()))
+    for b in range(3):
+        ws, wr = oracle.search_rows_filtered(E_all, r2c, q[b], 100, alive, metric, np.float64)
+        s, r = idx.search_rows(q[b], 100)
+        assert np.array_equal(r, wr)
+        ref = sim_fp32_exact(E_all, q[b], metric)
+        assert np.array_equal(s, ref[wr].astype(np.float32))
+        gs, gc, cnt = idx.search_chunks(q[b], 40, 8)
+        os_, oc = oracle.search_chunks_filtered(E_all, r2c, q[b], 40, 8, alive, metric)
+        assert int(cnt) == len(oc) and np.array_equal(gc[: len(oc)], oc)
+    ws, wc = oracle.maxsim_topk_filtered(E_all, off_all, Q, 60, alive)
+    gs, gc = idx.maxsim_topk(Q, 60)
+    assert np.array_equal(gc, wc) and np.array_equal(gs, ws.astype(np.float32))
+    sb, cb = idx.maxsim_topk_batch(np.stack([Q, Q]), 60)
+    assert np.array_equal(cb[0], wc) and np.array_equal(cb[1], wc)
+    assert np.isneginf(idx.maxsim_scores(Q)[dead]).all()
+    # deletes combine with a filter, and appends after deletes are live
+    flt = rng.random(n_chunks) < 0.5
+    ws, wr = oracle.search_rows_filtered(E_all, r2c, q[0], 50, alive & flt, metric)
+    s, r = idx.search_rows(q[0], 50, chunk_filter=flt)
+    assert np.array_equal(r, wr)
+    extra = oracle.synth_matrix(68, 40, dim, "small_int")
+    idx.append(extra)  # one chunk per row
+    E2 = np.concatenate([E_all, extra])
+    off2 = np.concatenate([off_all, off_all[-1] + 1 + np.arange(40)])
+    alive2 = np.concatenate([alive, np.ones(40, bool)])
+    ws, wr = oracle.search_rows_filtered(E2, _r2c(off2), q[1], 100, alive2, metric)
+    s, r = idx.search_rows(q[1], 100)
+    assert np.array_equal(r, wr)
+    idx.close()
+    fresh.close()

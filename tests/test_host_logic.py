@@ -16,11 +16,23 @@ class _FakeDeviceIndex:
         self.E, self.off, self.metric = E, off, metric
         self.n_rows, self.n_chunks = len(E), len(off) - 1
         self.calls = []
+        self.alive = np.ones(self.n_chunks, bool)
 
-    def search_chunks(self, q, num_hits, k):
+    def append(self, rows, sizes):
+        self.E = np.concatenate([self.E, rows])
+        self.off = np.concatenate([self.off, self.off[-1] + np.cumsum(sizes)])
+        self.alive = np.concatenate([self.alive, np.ones(len(sizes), bool)])
+        self.n_rows, self.n_chunks = len(self.E), len(self.off) - 1
+
+    def delete_chunks(self, ords):
+        self.alive[np.asarray(ords)] = False
+
+    def search_chunks(self, q, num_hits, k, chunk_filter=None):
         self.calls.append((num_hits, k))
         r2c = np.repeat(np.arange(self.n_chunks), np.diff(self.off))
-        s, c = oracle.search_chunks(self.E, r2c, q, num_hits, k, self.metric, np.float32)
+        ok = np.ones(self.n_chunks, bool) if chunk_filter is None else np.asarray(chunk_filter, bool)
+        ok = ok & self.alive
+        s, c = oracle.search_chunks_filtered(self.E, r2c, q, num_hits, k, ok, self.metric, np.float32)
         out_s = np.full(k, -np.inf, np.float32); out_c = np.full(k, -1, np.int32)
         out_s[: len(s)] = s; out_c[: len(c)] = c
         return out_s, out_c, np.int32(len(c))
@@ -62,6 +74,41 @@ def test_vector_search_contract_and_num_hits():
     raglite_amd.vector_search(q, num_results=8, config=cfg2, index=gi)
     assert gi.index.calls[-1] == (20, 8)
     assert scores == sorted(scores, reverse=True)
+
+
+def test_metadata_filter_is_pushed_down_as_chunk_mask():
+    """`_search.py:84-119`: JSON containment evaluated on the host metadata, ranking restricted to matching chunks."""
+    gi = _gpu_index(n_chunks=40)
+    gi.metadata = [{"topic": ["a", "b"] if i % 3 == 0 else ["c"], "year": 2020 + i % 2} for i in range(40)]
+    cfg = raglite_amd.HotPathConfig(vector_search_query_adapter=False)
+    q = np.random.default_rng(3).standard_normal(16).astype(np.float32)
+    ids, scores = raglite_amd.vector_search(q, num_results=6, metadata_filter={"topic": "a", "year": 2020},
+                                            config=cfg, index=gi)
+    want = {f"chunk{i:04d}" for i in range(40) if i % 3 == 0 and i % 2 == 0}
+    assert ids and set(ids) <= want and scores == sorted(scores, reverse=True)
+    assert raglite_amd.vector_search(q, num_results=6, metadata_filter={"topic": "zzz"}, config=cfg, index=gi) == ([], [])
+    gi.metadata = None
+    with pytest.raises(ValueError):
+        raglite_amd.vector_search(q, num_results=6, metadata_filter={"topic": "a"}, config=cfg, index=gi)
+
+
+def test_insert_and_delete_chunks_keep_ordinals_stable():
+    """`insert_documents` / `delete_documents` on the host mirror (`_insert.py:247-272`, `_delete.py:148-176`)."""
+    gi = _gpu_index(n_chunks=12)
+    gi.metadata = [{"k": i} for i in range(12)]
+    cfg = raglite_amd.HotPathConfig(vector_search_query_adapter=False)
+    rng = np.random.default_rng(5)
+    new = [rng.standard_normal((3, 16)).astype(np.float32), rng.standard_normal((1, 16)).astype(np.float32)]
+    gi.insert_chunks(["new-a", "new-b"], new, docs=["doc a", "doc b"], metadata=[{"k": 100}, {"k": 101}])
+    assert gi.ordinal_of("new-b") == 13 and gi.ordinal_of_doc("doc a") == 12 and len(gi.metadata) == 14
+    ids, _ = raglite_amd.vector_search(new[1][0], num_results=1, config=cfg, index=gi)
+    assert ids == ["new-b"]
+    with pytest.raises(ValueError):
+        gi.insert_chunks(["new-a"], [new[0]], docs=["x"], metadata=[{}])
+    assert gi.delete_chunks(["new-b", "chunk0003", "not-there"]) == 2
+    ids, _ = raglite_amd.vector_search(new[1][0], num_results=14, config=cfg, index=gi)
+    assert "new-b" not in ids and "chunk0003" not in ids and len(ids) == 12
+    assert gi.delete_chunks(["new-b"]) == 0
 
 
 def test_vector_search_empty_index_returns_empty_lists():
