@@ -99,6 +99,15 @@ int rl_adapter_apply(const float* A, const float* queries, int32_t n_queries, in
  * Precomputes ||e|| per row (cosine) or ||e||^2 (l2): 4 B/row extra. */
 int rl_index_create(rl_index** out, const float* embeddings, int64_t n_rows, int32_t dim,
                     const int64_t* chunk_offsets, int64_t n_chunks, int metric, int mem, void* stream);
+/* fp16-STORED index.  The reference stores its embeddings as float16
+ * (src/raglite/_embed.py:140, src/raglite/_database.py:279-283), so this storage is lossless for real
+ * RAGLite data and halves the bytes of every HBM-bound pass.  embeddings_f16: [n_rows x dim] IEEE
+ * binary16 bit patterns; dim must be one of 128, 256, 384, 512, 768, 1024.  Queries, scores and every
+ * other argument stay fp32; arithmetic is fp32 (VALU) or fp16 x fp16 -> fp32 MFMA (exact products).
+ * rl_index_append on such an index takes fp32 rows and rounds them to nearest-even fp16;
+ * rl_maxsim_rerank is not available on it yet (RL_ERR_UNSUPPORTED). */
+int rl_index_create_f16(rl_index** out, const uint16_t* embeddings_f16, int64_t n_rows, int32_t dim,
+                        const int64_t* chunk_offsets, int64_t n_chunks, int metric, int mem, void* stream);
 int rl_index_destroy(rl_index* index);
 int rl_index_info(const rl_index* index, int64_t* n_rows, int32_t* dim, int64_t* n_chunks, int* metric);
 

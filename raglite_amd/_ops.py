@@ -204,11 +204,30 @@ class DeviceIndex:
     alive by this object).  `chunk_offsets`: ascending int64 CSR of length n_chunks+1 (rows of a chunk
     contiguous, `src/raglite/_split_chunks.py:116-122`); None = one row per chunk."""
 
-    def __init__(self, embeddings, chunk_offsets=None, *, metric: str = "cosine") -> None:
+    def __init__(self, embeddings, chunk_offsets=None, *, metric: str = "cosine", storage: str = "f32") -> None:
+        """storage="f16": keep the corpus as IEEE fp16 in HBM (lossless for the reference's data,
+        `src/raglite/_embed.py:140`).  float16 input is taken as is, float32 input is rounded to nearest even."""
         if metric not in METRICS:
             raise ValueError(f"Unsupported metric: {metric}")  # wording of src/raglite/_query_adapter.py:207
+        if storage not in ("f32", "f16"):
+            raise ValueError("storage must be 'f32' or 'f16'")
+        self.storage = storage
         a = _Args()
-        p_e = a.inp(embeddings, np.float32)
+        if storage == "f16":
+            if _is_torch(embeddings):
+                t = embeddings.to(_torch().float16).contiguous()
+                if not t.is_cuda:
+                    raise ValueError("torch tensors passed to raglite_amd must live on a CUDA (HIP) device")
+                a._side(MEM_DEVICE, t.device)  # noqa: SLF001
+                a.keep.append(t)
+                p_e = t.data_ptr()
+            else:
+                h = np.ascontiguousarray(np.asarray(embeddings).astype(np.float16, copy=False))
+                a._side(MEM_HOST)  # noqa: SLF001
+                a.keep.append(h)
+                p_e = h.ctypes.data
+        else:
+            p_e = a.inp(embeddings, np.float32)
         emb = a.keep[0]
         if emb.ndim != 2:
             raise ValueError("embeddings must be a (n_rows, dim) matrix")
@@ -230,8 +249,8 @@ class DeviceIndex:
         self.n_chunks = n_chunks
         a.ensure_device()
         handle = C.c_void_p()
-        check(lib().rl_index_create(C.byref(handle), p_e, self.n_rows, self.dim, off_ptr, n_chunks,
-                                    METRICS[metric], a.mem, a.stream))
+        create = lib().rl_index_create_f16 if storage == "f16" else lib().rl_index_create
+        check(create(C.byref(handle), p_e, self.n_rows, self.dim, off_ptr, n_chunks, METRICS[metric], a.mem, a.stream))
         self._handle = handle
 
     def close(self) -> None:

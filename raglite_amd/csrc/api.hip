@@ -100,7 +100,8 @@ constexpr size_t SCORE_BATCH_BYTES = size_t(8) << 30;  // cap of the [B x N] sco
 }  // namespace rl
 
 struct rl_index {
-    const float* E = nullptr;
+    const float* E = nullptr;       // fp32 storage ...
+    const uint16_t* E16 = nullptr;  // ... or IEEE fp16 storage (rl_index_create_f16); exactly one is set
     bool owns_E = false;
     int64_t n_rows = 0;
     int32_t dim = 0;
@@ -284,6 +285,7 @@ int rl_adapter_apply(const float* A, const float* queries, int32_t n_queries, in
 int rl_index_destroy(rl_index* idx) {
     if (!idx) return RL_OK;
     if (idx->owns_E && idx->E) (void)hipFree(const_cast<float*>(idx->E));
+    if (idx->owns_E && idx->E16) (void)hipFree(const_cast<uint16_t*>(idx->E16));
     if (idx->offsets) (void)hipFree(idx->offsets);
     if (idx->row_to_chunk) (void)hipFree(idx->row_to_chunk);
     if (idx->norm) (void)hipFree(idx->norm);
@@ -299,8 +301,8 @@ int rl_index_destroy(rl_index* idx) {
     return RL_OK;
 }
 
-int rl_index_create(rl_index** out, const float* embeddings, int64_t n_rows, int32_t dim,
-                    const int64_t* chunk_offsets, int64_t n_chunks, int metric, int mem, void* stream) {
+static int index_create_any(rl_index** out, const void* embeddings, bool f16, int64_t n_rows, int32_t dim,
+                            const int64_t* chunk_offsets, int64_t n_chunks, int metric, int mem, void* stream) {
     if (!out) return fail(RL_ERR_INVALID, "rl_index_create: null output handle");
     *out = nullptr;
     if (n_rows < 0 || dim <= 0) return fail(RL_ERR_INVALID, "rl_index_create: bad shape");
@@ -308,6 +310,10 @@ int rl_index_create(rl_index** out, const float* embeddings, int64_t n_rows, int
     if (n_rows >= (int64_t)0x7fffffff - 1) return fail(RL_ERR_UNSUPPORTED, "rl_index_create: more than 2^31-2 rows");
     if (scan_mode(metric) < 0) return fail(RL_ERR_INVALID, "rl_index_create: unknown metric");
     if (dim > 4096) return fail(RL_ERR_UNSUPPORTED, "rl_index_create: dim must be <= 4096");
+    if (f16 && dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024)
+        return fail(RL_ERR_UNSUPPORTED, "rl_index_create_f16: dim must be one of 128, 256, 384, 512, 768, 1024");
+    if (f16 && mem == RL_MEM_DEVICE && (reinterpret_cast<uintptr_t>(embeddings) & 15))
+        return fail(RL_ERR_INVALID, "rl_index_create_f16: device embeddings must be 16-byte aligned");
     std::vector<int64_t> host_offsets;
     bool has_empty = false;
     if (chunk_offsets) {
@@ -343,27 +349,41 @@ int rl_index_create(rl_index** out, const float* embeddings, int64_t n_rows, int
     hipDeviceProp_t prop;
     RL_IDX_HIP(hipGetDeviceProperties(&prop, dev));
     idx->n_cu = prop.multiProcessorCount;
+    const size_t elt = f16 ? sizeof(uint16_t) : sizeof(float);
+    const void* dev_rows = embeddings;
     if (mem == RL_MEM_HOST) {
-        float* d = nullptr;
-        RL_IDX_HIP(hipMalloc(&d, std::max<size_t>((size_t)n_rows * dim * sizeof(float), 16)));
-        idx->E = d;
+        void* d = nullptr;
+        RL_IDX_HIP(hipMalloc(&d, std::max<size_t>((size_t)n_rows * dim * elt, 16)));
         idx->owns_E = true;
-        if (n_rows) RL_IDX_HIP(hipMemcpyAsync(d, embeddings, (size_t)n_rows * dim * sizeof(float), hipMemcpyHostToDevice, s));
-    } else {
-        idx->E = embeddings;
+        dev_rows = d;
+        (f16 ? (const void*&)idx->E16 : (const void*&)idx->E) = d;  // owned from here on (bail() frees it)
+        if (n_rows) RL_IDX_HIP(hipMemcpyAsync(d, embeddings, (size_t)n_rows * dim * elt, hipMemcpyHostToDevice, s));
     }
+    if (f16) idx->E16 = static_cast<const uint16_t*>(dev_rows); else idx->E = static_cast<const float*>(dev_rows);
     RL_IDX_HIP(hipMalloc(&idx->offsets, (size_t)(n_chunks + 1) * sizeof(int64_t)));
     RL_IDX_HIP(hipMemcpyAsync(idx->offsets, chunk_offsets, (size_t)(n_chunks + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
     RL_IDX_HIP(hipMalloc(&idx->row_to_chunk, (size_t)(n_rows + 65) * sizeof(int32_t)));  // +1 terminator, +64 pad
     RL_IDX(launch_row_to_chunk(idx->offsets, n_chunks, n_rows, idx->row_to_chunk, s));
     if (metric == RL_COSINE) RL_IDX_HIP(hipMalloc(&idx->norm, std::max<size_t>((size_t)n_rows * sizeof(float), 16)));
     if (metric == RL_L2) RL_IDX_HIP(hipMalloc(&idx->sumsq, std::max<size_t>((size_t)n_rows * sizeof(float), 16)));
-    if (idx->norm || idx->sumsq) RL_IDX(launch_row_norms(idx->E, n_rows, dim, idx->norm, idx->sumsq, s));
+    if (idx->norm || idx->sumsq)
+        RL_IDX(f16 ? launch_row_norms16(idx->E16, n_rows, dim, idx->norm, idx->sumsq, s)
+                   : launch_row_norms(idx->E, n_rows, dim, idx->norm, idx->sumsq, s));
     RL_IDX_HIP(hipStreamSynchronize(s));  // host_offsets / caller buffers may go away after return
 #undef RL_IDX
 #undef RL_IDX_HIP
     *out = idx;
     return RL_OK;
+}
+
+int rl_index_create(rl_index** out, const float* embeddings, int64_t n_rows, int32_t dim,
+                    const int64_t* chunk_offsets, int64_t n_chunks, int metric, int mem, void* stream) {
+    return index_create_any(out, embeddings, false, n_rows, dim, chunk_offsets, n_chunks, metric, mem, stream);
+}
+
+int rl_index_create_f16(rl_index** out, const uint16_t* embeddings_f16, int64_t n_rows, int32_t dim,
+                        const int64_t* chunk_offsets, int64_t n_chunks, int metric, int mem, void* stream) {
+    return index_create_any(out, embeddings_f16, true, n_rows, dim, chunk_offsets, n_chunks, metric, mem, stream);
 }
 
 // ---- lifecycle: append / delete -------------------------------------------------
@@ -437,13 +457,15 @@ int rl_index_append(rl_index* idx, const float* rows, int64_t n_new_rows, const 
     const int64_t old_n = idx->n_rows, new_n = old_n + n_new_rows;
     const int64_t old_c = idx->n_chunks, new_c = old_c + n_new_chunks;
     if (new_n >= (int64_t)0x7fffffff - 1) return fail(RL_ERR_UNSUPPORTED, "rl_index_append: more than 2^31-2 rows");
-    const size_t row_bytes = (size_t)idx->dim * sizeof(float);
+    const bool f16 = idx->E16 != nullptr;
+    const size_t row_bytes = (size_t)idx->dim * (f16 ? sizeof(uint16_t) : sizeof(float));
+    const void* old_rows = f16 ? (const void*)idx->E16 : (const void*)idx->E;
     // ---- storage: own it, grow geometrically -----------------------------------------------------------
     if (!idx->owns_E || new_n > idx->cap_rows) {
         const int64_t cap = std::max<int64_t>(new_n, idx->cap_rows + idx->cap_rows / 2);  // geometric growth
-        float* e = nullptr;
+        void* e = nullptr;
         RL_HIP(hipMalloc(&e, std::max<size_t>((size_t)cap * row_bytes, 16)));
-        if (old_n) RL_HIP(hipMemcpyAsync(e, idx->E, (size_t)old_n * row_bytes, hipMemcpyDeviceToDevice, s));
+        if (old_n) RL_HIP(hipMemcpyAsync(e, old_rows, (size_t)old_n * row_bytes, hipMemcpyDeviceToDevice, s));
         auto regrow = [&](float*& p) -> int {
             if (!p) return RL_OK;
             float* q = nullptr;
@@ -459,9 +481,9 @@ int rl_index_append(rl_index* idx, const float* rows, int64_t n_new_rows, const 
         int32_t* r2c = nullptr;
         RL_HIP(hipMalloc(&r2c, (size_t)(cap + 65) * sizeof(int32_t)));
         RL_HIP(hipStreamSynchronize(s));
-        if (idx->owns_E && idx->E) (void)hipFree(const_cast<float*>(idx->E));
+        if (idx->owns_E && old_rows) (void)hipFree(const_cast<void*>(old_rows));
         (void)hipFree(idx->row_to_chunk);
-        idx->E = e;
+        if (f16) idx->E16 = static_cast<const uint16_t*>(e); else idx->E = static_cast<const float*>(e);
         idx->owns_E = true;
         idx->row_to_chunk = r2c;
         idx->cap_rows = cap;
@@ -475,9 +497,16 @@ int rl_index_append(rl_index* idx, const float* rows, int64_t n_new_rows, const 
         idx->cap_chunks = cap;
     }
     // ---- new rows, CSR, ordinals, norms ------------------------------------------------------------------
-    if (n_new_rows)
+    DevBuf t_rows;
+    if (n_new_rows && !f16)
         RL_HIP(hipMemcpyAsync(const_cast<float*>(idx->E) + (size_t)old_n * idx->dim, rows, (size_t)n_new_rows * row_bytes,
                               mem == RL_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, s));
+    if (n_new_rows && f16) {  // fp32 rows in, rounded to nearest even into the fp16 store (the reference's astype(float16))
+        const float* d_rows;
+        RL_TRY(stage_in(rows, (size_t)n_new_rows * idx->dim, mem, s, t_rows, &d_rows));
+        RL_TRY(launch_cast_f16(d_rows, const_cast<uint16_t*>(idx->E16) + (size_t)old_n * idx->dim,
+                               n_new_rows * (int64_t)idx->dim, s));
+    }
     idx->h_offsets.reserve((size_t)new_c + 1);
     for (int64_t c = 0; c < n_new_chunks; ++c) {
         const int64_t sz = new_chunk_sizes ? new_chunk_sizes[c] : 1;
@@ -488,9 +517,12 @@ int rl_index_append(rl_index* idx, const float* rows, int64_t n_new_rows, const 
     idx->n_chunks = new_c;
     RL_HIP(hipMemcpyAsync(idx->offsets, idx->h_offsets.data(), (size_t)(new_c + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
     RL_TRY(launch_row_to_chunk(idx->offsets, new_c, new_n, idx->row_to_chunk, s));
-    if ((idx->norm || idx->sumsq) && n_new_rows)
-        RL_TRY(launch_row_norms(idx->E + (size_t)old_n * idx->dim, n_new_rows, idx->dim,
-                                idx->norm ? idx->norm + old_n : nullptr, idx->sumsq ? idx->sumsq + old_n : nullptr, s));
+    if ((idx->norm || idx->sumsq) && n_new_rows) {
+        float* nn = idx->norm ? idx->norm + old_n : nullptr;
+        float* ns = idx->sumsq ? idx->sumsq + old_n : nullptr;
+        RL_TRY(f16 ? launch_row_norms16(idx->E16 + (size_t)old_n * idx->dim, n_new_rows, idx->dim, nn, ns, s)
+                   : launch_row_norms(idx->E + (size_t)old_n * idx->dim, n_new_rows, idx->dim, nn, ns, s));
+    }
     if (!idx->h_live.empty()) {  // new chunks are live
         const size_t cw = (size_t)(new_c + 31) / 32;
         idx->h_live.resize(cw, 0u);
@@ -517,6 +549,16 @@ namespace {
 int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStream_t s) {
     const int mode = scan_mode(idx->metric);
     float* sc = idx->scores.as<float>();
+    if (idx->E16) {  // fp16 storage: VALU scan up to 4 queries, else f16-MFMA stream passes of 32 (half the bytes each)
+        if (nb <= 4) return launch_scan_rows16(idx->E16, idx->n_rows, idx->dim, d_q, nb, idx->norm, mode, sc, ld, s);
+        for (int32_t b0 = 0; b0 < nb; b0 += 32) {
+            const int32_t nq = std::min<int32_t>(32, nb - b0);
+            RL_TRY(launch_maxsim_stream16(idx->E16, idx->n_rows, idx->dim, d_q + (int64_t)b0 * idx->dim, nq,
+                                          idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, sc + (int64_t)b0 * ld, ld,
+                                          idx->n_cu, s));
+        }
+        return launch_transform(sc, nb, idx->n_rows, ld, idx->norm, idx->sumsq, d_q, idx->dim, mode, s);
+    }
     if (nb >= GEMM_MIN_QUERIES) {  // MFMA-bound regime: one 128 x 128-tiled GEMM instead of a corpus pass per 32 queries
         RL_TRY(idx->misc.reserve((size_t)nb * sizeof(float)));
         const int st = launch_score_gemm(idx->E, idx->n_rows, idx->dim, d_q, nb, sc, ld, idx->norm, idx->sumsq,
@@ -660,6 +702,14 @@ int mask_chunk_scores(rl_index* idx, float* d_scores, int32_t nb, int64_t ld, co
 int maxsim_scores_device(rl_index* idx, const float* d_q, int32_t nq, float* d_out, hipStream_t s) {
     if (idx->n_chunks == 0) return RL_OK;
     int st = RL_ERR_UNSUPPORTED;
+    if (idx->E16) {
+        if (nq > 32) return fail(RL_ERR_UNSUPPORTED, "MaxSim over an fp16-stored index takes at most 32 query vectors");
+        if (idx->has_empty_chunk || idx->n_rows == 0)
+            RL_TRY(launch_fill_f32(d_out, -std::numeric_limits<float>::infinity(), idx->n_chunks, s));
+        if (idx->n_rows == 0) return RL_OK;
+        return launch_maxsim_stream16(idx->E16, idx->n_rows, idx->dim, d_q, nq, idx->row_to_chunk, idx->offsets,
+                                      idx->n_chunks, 0, d_out, 0, idx->n_cu, s);
+    }
     if (idx->n_rows > 0) {
         if (idx->has_empty_chunk)
             RL_TRY(launch_fill_f32(d_out, -std::numeric_limits<float>::infinity(), idx->n_chunks, s));
@@ -757,6 +807,7 @@ int rl_maxsim_rerank(rl_index* idx, const float* query_vecs, int32_t n_queries, 
     if (n_queries < 0 || n_cand < 0 || nq < 1) return fail(RL_ERR_INVALID, "rl_maxsim_rerank: bad sizes");
     if (n_queries == 0 || n_cand == 0) return RL_OK;
     if (!query_vecs || !candidates || !out_scores) return fail(RL_ERR_INVALID, "rl_maxsim_rerank: null argument");
+    if (idx->E16) return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_rerank: not available on an fp16-stored index yet");
     if (mem == RL_MEM_HOST) {
         for (int64_t i = 0; i < (int64_t)n_queries * n_cand; ++i)
             if (candidates[i] < 0 || candidates[i] >= idx->n_chunks)

@@ -99,6 +99,10 @@ enum ScanMode { SCAN_RAW_DOT = 0, SCAN_COSINE = 1, SCAN_DOT = 2, SCAN_L2 = 3 };
 // scores[b * ld + row] for b < nb (nb <= 4 per launch handled inside), rows < n.
 int launch_scan_rows(const float* E, int64_t n, int32_t dim, const float* queries, int32_t nb,
                      const float* row_norm, int mode, float* scores, int64_t ld, hipStream_t s);
+// scan16.hip: the same over an fp16-stored corpus
+int launch_scan_rows16(const uint16_t* E, int64_t n, int32_t dim, const float* queries, int32_t nb,
+                       const float* row_norm, int mode, float* scores, int64_t ld, hipStream_t s);
+int launch_row_norms16(const uint16_t* E, int64_t n, int32_t dim, float* norm, float* sumsq, hipStream_t s);
 int launch_row_norms(const float* E, int64_t n, int32_t dim, float* norm, float* sumsq, hipStream_t s);
 int launch_cast_f16(const float* src, uint16_t* dst, int64_t count, hipStream_t s);
 int launch_fill_f32(float* dst, float value, int64_t count, hipStream_t s);
@@ -143,6 +147,10 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
 int launch_score_gemm(const float* E, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores,
                       int64_t ld, const float* row_norm, const float* row_sumsq, float* q_sumsq_scratch, int mode,
                       int n_cu, hipStream_t s);
+// the same over an fp16-stored corpus
+int launch_maxsim_stream16(const uint16_t* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
+                           const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
+                           float* out, int64_t ld, int n_cu, hipStream_t s);
 int launch_maxsim_generic(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride_queries,
                           const int64_t* chunk_offsets, const int32_t* candidates, int64_t n_items,
                           int32_t n_queries, float* out, hipStream_t s);

@@ -52,21 +52,24 @@ namespace rl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int32_t i32x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 constexpr int TR = 16;      // rows per tile (one 16x16x4 MFMA row block)
 constexpr int NSTAGE = 2;
 // Compile-time geometry for dim = 4 * KW (KW = columns per compute wave, a multiple of 16).
-template <int KW>
+template <int KW, bool F16 = false>
 struct Geo {
     static constexpr int DIM = 4 * KW;
-    static constexpr int QBYTES = KW * 4;                  // one K quarter of a row (what one compute wave consumes)
-    static constexpr int ROWB = DIM * 4;                   // one corpus row
+    static constexpr int ELT = F16 ? 2 : 4;                // corpus element: fp32, or fp16 storage
+    static constexpr int QBYTES = KW * ELT;                // one K quarter of a row (what one compute wave consumes)
+    static constexpr int ROWB = DIM * ELT;                 // one corpus row
     static constexpr int PITCH = ROWB + 16;                // +16 B: row stride = 4 banks (mod 64) -> the 16 rows of one
                                                            // ds_read_b128 pass hit 16 different 16-B bank groups
     static constexpr int STAGE = TR * PITCH;               // one tile, row-major: [16 rows][DIM fp32 + pad]
     static constexpr int NCH = (ROWB + 1023) / 1024;       // 1-KiB DMA instructions per row (the last may be half)
-    static constexpr int KSTEPS = KW / 16;                 // ds_read_b128 per lane per tile; 4 MFMA k-steps each
+    static constexpr int KSTEPS = F16 ? KW / 32 : KW / 16; // ds_read_b128 per lane per tile: 4 fp32 k-steps of 4, or one
+                                                           // 16x16x32 f16 MFMA, each
     static constexpr int OFF_RED = NSTAGE * STAGE;
     static constexpr int RED_BYTES = 4 * 2 * 64 * 16;      // 8192: K-partial exchange buffer (4 waves x 2 query halves)
     static constexpr int OFF_ST = OFF_RED + RED_BYTES;     // K-reduced tile, transposed: [32 query columns][20] fp32
@@ -92,14 +95,14 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 }  // namespace
 
-template <int KW, int NQT, int MODE, bool TRACE = false, int SPLR = 6>
+template <int KW, int NQT, int MODE, bool TRACE = false, int SPLR = 6, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __restrict__ D, int64_t n_rows,
                                                                  const float* __restrict__ Q, int nq,
                                                                  const int32_t* __restrict__ row_to_chunk,
                                                                  const int64_t* __restrict__ chunk_offsets,
                                                                  int64_t n_chunks, float* __restrict__ out,
                                                                  int64_t ld, unsigned long long* trace) {
-    using G_ = Geo<KW>;
+    using G_ = Geo<KW, F16>;
     constexpr int SD = G_::DIM, PITCH = G_::PITCH, STAGE = G_::STAGE, KSTEPS = G_::KSTEPS, NCH = G_::NCH, ROWB = G_::ROWB;
     constexpr int OFF_RED = G_::OFF_RED, OFF_ST = G_::OFF_ST, ST_PITCH = G_::ST_PITCH, OFF_ORD = G_::OFF_ORD;
     __shared__ __attribute__((aligned(16))) char smem[G_::LDS_TOTAL + (TRACE ? 4096 : 0)];
@@ -162,25 +165,45 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
         // Q slice as MFMA B fragments: lane (j = lane & 15, kq = lane >> 4) holds, for MFMA 4*mm + tt,
         // Q[16*h + j][256*w + 16*mm + 4*kq + tt]  (a fixed permutation of K inside the wave).
         const int fj = lane & 15, kq = lane >> 4;
-        float qreg[NQT][KW / 4];
+        // fp32 corpus: qreg[h][4 mm + tt] feeds v_mfma_f32_16x16x4_f32.  fp16 corpus: the query slice is split into
+        // fp16 hi + lo halves (q = hi + lo to ~2^-22 relative; lo == 0 for the reference's fp16-valued queries) that feed
+        // v_mfma_f32_16x16x32_f16 -- fp16 x fp16 products are exact in fp32, so nothing is lost against the stored data.
+        [[maybe_unused]] float qreg[F16 ? 1 : NQT][F16 ? 1 : KW / 4];
+        [[maybe_unused]] h16x8 qhi[F16 ? NQT : 1][F16 ? KSTEPS : 1], qlo[F16 ? NQT : 1][F16 ? KSTEPS : 1];
+        [[maybe_unused]] bool any_lo = false;
 #pragma unroll
         for (int h = 0; h < NQT; ++h) {
             const int qi = 16 * h + fj;
             const int qc_ = qi < nq ? qi : nq - 1;  // clamped load, zeroed below: padded query vectors add 0
 #pragma unroll
             for (int mm = 0; mm < KSTEPS; ++mm) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(Q + (int64_t)qc_ * SD + KW * w + 16 * mm + 4 * kq);
-                if (qi >= nq) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                qreg[h][4 * mm + 0] = v[0]; qreg[h][4 * mm + 1] = v[1];
-                qreg[h][4 * mm + 2] = v[2]; qreg[h][4 * mm + 3] = v[3];
+                if constexpr (!F16) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(Q + (int64_t)qc_ * SD + KW * w + 16 * mm + 4 * kq);
+                    if (qi >= nq) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    qreg[h][4 * mm + 0] = v[0]; qreg[h][4 * mm + 1] = v[1];
+                    qreg[h][4 * mm + 2] = v[2]; qreg[h][4 * mm + 3] = v[3];
+                } else {
+                    const float* qp = Q + (int64_t)qc_ * SD + KW * w + 32 * mm + 8 * kq;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp), v1 = *reinterpret_cast<const f32x4*>(qp + 4);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float x = qi < nq ? (u < 4 ? v0[u] : v1[u - 4]) : 0.f;
+                        const _Float16 hi = (_Float16)x;                // round to nearest even
+                        const _Float16 lo = (_Float16)(x - (float)hi);  // exact difference, then rounded
+                        qhi[h][mm][u] = hi;
+                        qlo[h][mm][u] = lo;
+                        any_lo |= lo != (_Float16)0.0f;
+                    }
+                }
             }
         }
+        if constexpr (F16) any_lo = __builtin_amdgcn_ballot_w64(any_lo) != 0;  // wave-uniform
         const char* const a_base = smem + fj * PITCH + w * G_::QBYTES + kq * 16;
         for (int t = 0; t < nt; ++t) {
             stamp(t, 0);
             wg_barrier();  // B1(t): tile t is in stage t&1
             stamp(t, 1);
-            f32x4 a[KSTEPS];
+            f32x4 a[KSTEPS];  // 16 B per lane and step: 4 fp32 (k = 16 mm + 4 kq ..) or 8 fp16 (k = 32 mm + 8 kq ..)
             const char* ap = a_base + (t & 1) * STAGE;
 #pragma unroll
             for (int mm = 0; mm < KSTEPS; ++mm) a[mm] = *reinterpret_cast<const f32x4*>(ap + mm * 64);
@@ -191,13 +214,34 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
             f32x4 acc[NQT];
 #pragma unroll
             for (int h = 0; h < NQT; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (!F16) {
 #pragma unroll
-            for (int mm = 0; mm < KSTEPS; ++mm)
+                for (int mm = 0; mm < KSTEPS; ++mm)
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
+                    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                        for (int h = 0; h < NQT; ++h)
+                            acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mm][tt], qreg[h][4 * mm + tt], acc[h], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int mm = 0; mm < KSTEPS; ++mm) {
+                    h16x8 af;
+                    __builtin_memcpy(&af, &a[mm], 16);
 #pragma unroll
                     for (int h = 0; h < NQT; ++h)
-                        acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mm][tt], qreg[h][4 * mm + tt], acc[h], 0, 0, 0);
+                        acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qhi[h][mm], acc[h], 0, 0, 0);
+                }
+                if (any_lo) {
+#pragma unroll
+                    for (int mm = 0; mm < KSTEPS; ++mm) {
+                        h16x8 af;
+                        __builtin_memcpy(&af, &a[mm], 16);
+#pragma unroll
+                        for (int h = 0; h < NQT; ++h)
+                            acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qlo[h][mm], acc[h], 0, 0, 0);
+                    }
+                }
+            }
             stamp(t, 4);
 #pragma unroll
             for (int h = 0; h < NQT; ++h) *reinterpret_cast<f32x4*>(red + ((w * 2 + h) * 64 + lane) * 16) = acc[h];
@@ -226,7 +270,8 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
         for (int i = 0; i < 8; ++i) voff[i] = (uint32_t)((8 * lq + i) * ROWB) + lane_off;
         const uint32_t lds0 = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem) +
                               (uint32_t)(8 * lq * PITCH);
-        constexpr bool HALF_TAIL = (ROWB % 1024) != 0;  // dims 128 / 384: the last DMA of a row is 32 lanes wide
+        constexpr int TAIL_LANES = (ROWB % 1024) / 16;  // lanes of a row's last DMA when the row is not a multiple of 1 KiB
+        constexpr bool HALF_TAIL = TAIL_LANES != 0;
         // Rows i0..i1-1 (of this loader's 8) of tile t -> stage t&1.
         const uint32_t lds_ord = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem) + OFF_ORD;
         const uint32_t voff_ord = 4u * lane;
@@ -252,7 +297,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
 #pragma unroll
                     for (int c = 0; c < NCH; ++c) {
                         if (HALF_TAIL && c == NCH - 1) {
-                            if (lane < 32)
+                            if (lane < TAIL_LANES)
                                 asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2 nt" ::"v"(voff[i]), "s"(base), "n"(c * 1024) : "memory");
                         } else {
                             asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2 nt" ::"v"(voff[i]), "s"(base), "n"(c * 1024) : "memory");
@@ -268,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
                     const char* p = src + (int64_t)row * ROWB + lane_off;
 #pragma unroll
                     for (int c = 0; c < NCH; ++c)
-                        if (!(HALF_TAIL && c == NCH - 1) || lane < 32)
+                        if (!(HALF_TAIL && c == NCH - 1) || lane < TAIL_LANES)
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + c * 1024),
                                                              (__attribute__((address_space(3))) void*)(dst0 + i * PITCH + c * 1024), 16, 0, /*nt*/ 2);
                 }
@@ -458,11 +503,11 @@ struct StreamArgs {
     const float* D; int64_t n_rows; const float* Q; int nq; const int32_t* r2c; const int64_t* off; int64_t n_chunks;
     int mode; float* out; int64_t ld; dim3 grid; hipStream_t s; unsigned long long* trace;
 };
-template <int KW>
+template <int KW, bool F16>
 void launch_kw(const StreamArgs& a) {
     const dim3 blk(512);
-#define RL_STREAM(NQT, MODE) hipLaunchKernelGGL((maxsim_stream_kernel<KW, NQT, MODE>), a.grid, blk, 0, a.s, a.D, a.n_rows, \
-                                                a.Q, a.nq, a.r2c, a.off, a.n_chunks, a.out, a.ld, a.trace)
+#define RL_STREAM(NQT, MODE) hipLaunchKernelGGL((maxsim_stream_kernel<KW, NQT, MODE, false, 6, F16>), a.grid, blk, 0, a.s, a.D, \
+                                                a.n_rows, a.Q, a.nq, a.r2c, a.off, a.n_chunks, a.out, a.ld, a.trace)
     if (a.mode == 0) { if (a.nq <= 16) RL_STREAM(1, 0); else RL_STREAM(2, 0); }
     else             { if (a.nq <= 16) RL_STREAM(1, 1); else RL_STREAM(2, 1); }
 #undef RL_STREAM
@@ -470,9 +515,10 @@ void launch_kw(const StreamArgs& a) {
 }  // namespace
 
 // Fast path for dim in {128, 256, 384, 512, 768, 1024} (dim = 4 * KW, KW a multiple of 32) and nq <= 32.
-int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
-                         const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
-                         float* out, int64_t ld, int n_cu, hipStream_t s) {
+// f16 = the corpus is stored as IEEE fp16 (D then points at uint16_t data); queries and scores stay fp32.
+static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
+                             const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
+                             float* out, int64_t ld, int n_cu, hipStream_t s) {
     if (nq < 1 || nq > 32 || n_rows < 1) return RL_ERR_UNSUPPORTED;
     if (dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
@@ -483,7 +529,7 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
         if (std::getenv("RAGLITE_HIP_TRACE")) { (void)hipMalloc(&p, 8 * 8 * 8 * 8); (void)hipMemset(p, 0, 8 * 8 * 8 * 8); }
         return p;
     }();
-    if (trace && mode == 0 && nq > 16 && dim == 1024) {  // diagnostic build: dump the 30th launch's timeline to stderr
+    if (trace && !f16 && mode == 0 && nq > 16 && dim == 1024) {  // diagnostic build: dump the 30th launch's timeline to stderr
         static int calls = 0;
         hipLaunchKernelGGL((maxsim_stream_kernel<256, 2, 0, true>), dim3(grid), dim3(512), 0, s, D, n_rows, Q, nq,
                            row_to_chunk, chunk_offsets, n_chunks, out, ld, trace);
@@ -508,16 +554,26 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
         return RL_OK;
     }
     const StreamArgs a{D, n_rows, Q, (int)nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, dim3(grid), s, nullptr};
-    switch (dim) {
-        case 128: launch_kw<32>(a); break;
-        case 256: launch_kw<64>(a); break;
-        case 384: launch_kw<96>(a); break;
-        case 512: launch_kw<128>(a); break;
-        case 768: launch_kw<192>(a); break;
-        default: launch_kw<256>(a); break;
-    }
+#define RL_DIMS(F) switch (dim) { \
+        case 128: launch_kw<32, F>(a); break; case 256: launch_kw<64, F>(a); break; case 384: launch_kw<96, F>(a); break; \
+        case 512: launch_kw<128, F>(a); break; case 768: launch_kw<192, F>(a); break; default: launch_kw<256, F>(a); break; }
+    if (f16) { RL_DIMS(true) } else { RL_DIMS(false) }
+#undef RL_DIMS
     RL_HIP(hipGetLastError());
     return RL_OK;
+}
+
+int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
+                         const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
+                         float* out, int64_t ld, int n_cu, hipStream_t s) {
+    return launch_stream_any(D, false, n_rows, dim, Q, nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, n_cu, s);
+}
+
+int launch_maxsim_stream16(const uint16_t* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
+                           const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
+                           float* out, int64_t ld, int n_cu, hipStream_t s) {
+    return launch_stream_any(reinterpret_cast<const float*>(D), true, n_rows, dim, Q, nq, row_to_chunk, chunk_offsets,
+                             n_chunks, mode, out, ld, n_cu, s);
 }
 
 }  // namespace rl

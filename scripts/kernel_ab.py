@@ -23,23 +23,27 @@ from bench import chunk_offsets  # noqa: E402
 
 
 def main() -> None:
-    reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    f16 = "--f16" in sys.argv  # fp16-stored corpus: half the bytes per pass
+    reps = int(args[0]) if args else 5
     n, d = 1_000_000, 1024
     raglite_amd.set_device(0)
     E = torch.empty((n, d), dtype=torch.float32, device="cuda")
     raglite_amd.synth_fill(E, seed=1)
     Q = torch.empty((32, d), dtype=torch.float32, device="cuda")
     raglite_amd.synth_fill(Q, seed=2)
-    idx = raglite_amd.DeviceIndex(E, chunk_offsets(n), metric="dot")
+    if f16:
+        E = E.half()
+    idx = raglite_amd.DeviceIndex(E, chunk_offsets(n), metric="dot", storage="f16" if f16 else "f32")
     idx.time_kernel(0, Q, 5)
     idx.time_kernel(1, Q[:1], 5)
     stream, scan = [], []
     for _ in range(reps):
         stream.append(idx.time_kernel(0, Q, 20) / 20)
         scan.append(idx.time_kernel(1, Q[:1], 20) / 20)
-    gb = 4.0 * n * d / 1e9
+    gb = (2.0 if f16 else 4.0) * n * d / 1e9
     s, c = min(stream), min(scan)
-    print(json.dumps({"stream_ms": round(s, 4), "scan_ms": round(c, 4), "ratio": round(s / c, 4),
+    print(json.dumps({"storage": "f16" if f16 else "f32", "stream_ms": round(s, 4), "scan_ms": round(c, 4), "ratio": round(s / c, 4),
                       "stream_GBps": round(gb / s * 1e3, 1), "scan_GBps": round(gb / c * 1e3, 1),
                       "stream_all": [round(x, 4) for x in stream], "scan_all": [round(x, 4) for x in scan]}))
 

@@ -655,3 +655,97 @@ def test_index_append_and_delete_lifecycle(metric):
     assert np.array_equal(r, wr)
     idx.close()
     fresh.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# 8f-1: fp16-stored corpus (the reference's own storage precision, `_embed.py:140`)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+@pytest.mark.parametrize("n,dim", [(3000, 1024), (1501, 128), (2050, 384), (777, 768)])
+def test_f16_storage_search_rows_integer_bit_exact(metric, n, dim):
+    """Integer data is exact in fp16: every batch class of an fp16-stored index (VALU scan16 for B <= 4, f16-MFMA
+    stream passes beyond) returns the oracle's scores and indices bit for bit -- and so equals the fp32-stored index."""
+    E = oracle.synth_matrix(71, n, dim, "small_int")
+    idx16 = raglite_amd.DeviceIndex(E, metric=metric, storage="f16")
+    idx32 = raglite_amd.DeviceIndex(E, metric=metric)
+    for B in (1, 3, 7, 33):
+        Q = oracle.synth_matrix(72 + B, B, dim, "small_int")
+        S, R = idx16.search_rows(Q if B > 1 else Q[0], 60)
+        S, R = np.atleast_2d(S), np.atleast_2d(R)
+        S32, R32 = idx32.search_rows(Q if B > 1 else Q[0], 60)
+        assert np.array_equal(S, np.atleast_2d(S32)) and np.array_equal(R, np.atleast_2d(R32))
+        for b in (0, B - 1):
+            es, ei = oracle.topk_desc(sim_fp32_exact(E, Q[b], metric), 60)
+            assert np.array_equal(R[b], ei) and np.array_equal(S[b], es.astype(np.float32))
+    idx16.close()
+    idx32.close()
+
+
+@pytest.mark.parametrize("dim,nq", [(1024, 32), (1024, 5), (128, 17), (512, 16), (768, 1)])
+def test_f16_storage_maxsim(dim, nq):
+    rng = np.random.default_rng(10)
+    n = 5003
+    off = ragged_offsets(rng, n, 1, 15)
+    # integer data: exact
+    Ei = oracle.synth_matrix(81, n, dim, "small_int")
+    Qi = oracle.synth_matrix(82, nq, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(Ei, off, metric="dot", storage="f16")
+    ref = oracle.maxsim_scores(Ei, off, Qi)
+    assert np.array_equal(idx.maxsim_scores(Qi), ref.astype(np.float32))
+    s, c = idx.maxsim_topk(Qi, 50)
+    es, ec = oracle.topk_desc(ref.astype(np.float32), 50)
+    assert np.array_equal(c, ec) and np.array_equal(s, es)
+    idx.close()
+    # unit-norm rows rounded through fp16 (what RAGLite stores); fp32 queries that are NOT fp16-valued (hi + lo path)
+    # and fp16-valued queries (lo == 0 path): within 1e-4 of the fp64 MaxSim over the stored values
+    E = oracle.synth_matrix(83, n, dim)
+    E16 = (E / np.linalg.norm(E, axis=1, keepdims=True)).astype(np.float16)
+    Q = oracle.synth_matrix(84, nq, dim)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    idx = raglite_amd.DeviceIndex(E16, off, metric="dot", storage="f16")
+    for qq in (Q, Q.astype(np.float16).astype(np.float32)):
+        ref = oracle.maxsim_scores(E16.astype(np.float64), off, qq.astype(np.float64))
+        got = idx.maxsim_scores(qq)
+        np.testing.assert_allclose(got, ref, rtol=0, atol=TOL)
+        s, c = idx.maxsim_topk(qq, 40)
+        assert_topk_close(s, c, ref, 40, TOL)
+    assert np.array_equal(idx.maxsim_scores(Q), idx.maxsim_scores(Q))  # deterministic
+    idx.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "l2"])
+def test_f16_storage_uniform_tolerance_and_lifecycle(metric):
+    n, dim = 4100, 1024
+    rng = np.random.default_rng(11)
+    off = ragged_offsets(rng, n, 1, 9)
+    E16 = oracle.synth_matrix(85, n, dim).astype(np.float16)
+    Ev = E16.astype(np.float32)  # the stored values
+    idx = raglite_amd.DeviceIndex(E16, off, metric=metric, storage="f16")
+    for B in (1, 4, 9):
+        Q = oracle.synth_matrix(86 + B, B, dim)
+        S, R = idx.search_rows(Q, 50)
+        for b in range(B):
+            assert_topk_close(S[b], R[b], oracle.similarity(Ev, Q[b], metric), 50, TOL)
+    # filter + delete + append (fp32 rows are rounded into the fp16 store)
+    n_chunks = len(off) - 1
+    r2c = _r2c(off)
+    q = oracle.synth_matrix(90, 1, dim)[0]
+    flt = rng.random(n_chunks) < 0.4
+    s, r = idx.search_rows(q, 30, chunk_filter=flt)
+    assert flt[r2c[r]].all()
+    assert_topk_close(s, r, np.where(flt[r2c], oracle.similarity(Ev, q, metric), -np.inf), 30, TOL)
+    idx.delete_chunks(np.nonzero(~flt)[0])
+    s2, r2 = idx.search_rows(q, 30)
+    assert np.array_equal(r2, r) and np.array_equal(s2, s)
+    extra = oracle.synth_matrix(91, 33, dim)
+    idx.append(extra)
+    Ev2 = np.concatenate([Ev, extra.astype(np.float16).astype(np.float32)])
+    alive = np.concatenate([flt[r2c], np.ones(33, bool)])
+    s3, r3 = idx.search_rows(extra[7], 5)
+    assert r3[0] == n + 7
+    assert_topk_close(s3, r3, np.where(alive, oracle.similarity(Ev2, extra[7], metric), -np.inf), 5, TOL)
+    with pytest.raises(Exception):
+        idx.maxsim_rerank(np.zeros((1, 2, dim), np.float32), np.zeros((1, 2), np.int32))
+    idx.close()
+    with pytest.raises(Exception):
+        raglite_amd.DeviceIndex(np.zeros((4, 100), np.float16), storage="f16")  # dim outside the fast path
