@@ -42,7 +42,7 @@ class GpuIndex:
 
     def __init__(self, chunk_ids: Sequence[ChunkId], chunk_embeddings, *, chunk_offsets=None,
                  metric: str = "cosine", query_adapter=None, docs: Sequence[str] | None = None,
-                 metadata: Sequence[dict] | None = None) -> None:
+                 metadata: Sequence[dict] | None = None, storage: str = "f32") -> None:
         if chunk_offsets is None:
             mats = [np.asarray(m, dtype=np.float32).reshape(len(m), -1) for m in chunk_embeddings]
             sizes = np.asarray([len(m) for m in mats], dtype=np.int64)
@@ -54,7 +54,7 @@ class GpuIndex:
         if len(chunk_ids) != len(chunk_offsets) - 1:
             raise ValueError("one chunk id per chunk is required")
         self.chunk_ids = list(chunk_ids)
-        self.index = _ops.DeviceIndex(matrix, chunk_offsets, metric=metric)
+        self.index = _ops.DeviceIndex(matrix, chunk_offsets, metric=metric, storage=storage)
         self.metric = metric
         self.query_adapter = None if query_adapter is None else np.asarray(query_adapter, dtype=np.float32)
         self.docs = None if docs is None else list(docs)
