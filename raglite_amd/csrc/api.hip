@@ -842,7 +842,8 @@ int rl_maxsim_rerank(rl_index* idx, const float* query_vecs, int32_t n_queries, 
     if (n_queries < 0 || n_cand < 0 || nq < 1) return fail(RL_ERR_INVALID, "rl_maxsim_rerank: bad sizes");
     if (n_queries == 0 || n_cand == 0) return RL_OK;
     if (!query_vecs || !candidates || !out_scores) return fail(RL_ERR_INVALID, "rl_maxsim_rerank: null argument");
-    if (idx->E16) return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_rerank: not available on an fp16-stored index yet");
+    if (idx->E16 && (idx->dim != 128 || nq > 32))
+        return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_rerank on an fp16-stored index needs dim == 128 and nq <= 32");
     if (mem == RL_MEM_HOST) {
         for (int64_t i = 0; i < (int64_t)n_queries * n_cand; ++i)
             if (candidates[i] < 0 || candidates[i] >= idx->n_chunks)
@@ -855,8 +856,9 @@ int rl_maxsim_rerank(rl_index* idx, const float* query_vecs, int32_t n_queries, 
     RL_TRY(stage_in(query_vecs, (size_t)n_queries * nq * idx->dim, mem, s, t_q, &d_q));
     RL_TRY(stage_in(candidates, (size_t)n_queries * n_cand, mem, s, t_c, &d_c));
     RL_TRY(stage_out_begin(out_scores, (size_t)n_queries * n_cand, mem, t_o, &d_o));
-    int st = launch_maxsim_cand(idx->E, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s);
-    if (st == RL_ERR_UNSUPPORTED)
+    int st = idx->E16 ? launch_maxsim_cand16(idx->E16, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s)
+                      : launch_maxsim_cand(idx->E, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s);
+    if (st == RL_ERR_UNSUPPORTED && !idx->E16)
         st = launch_maxsim_generic(idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, d_c, n_cand,
                                    n_queries, d_o, s);
     RL_TRY(st);

@@ -157,5 +157,7 @@ int launch_maxsim_generic(const float* D, int32_t dim, const float* Q, int32_t n
 // Rerank fast path: dim == 128, nq <= 32 (MFMA, direct fragment loads).
 int launch_maxsim_cand(const float* D, int32_t dim, const float* Q, int32_t nq, const int64_t* chunk_offsets,
                        const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s);
+int launch_maxsim_cand16(const uint16_t* D, int32_t dim, const float* Q, int32_t nq, const int64_t* chunk_offsets,
+                         const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s);
 
 }  // namespace rl

@@ -18,6 +18,7 @@
 namespace rl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int GEN_NQ_MAX = 1024;
 
@@ -127,7 +128,9 @@ int launch_maxsim_generic(const float* D, int32_t dim, const float* Q, int32_t n
 constexpr int CD = 128;   // embedding dimension of the rerank fast path
 constexpr int CPW = 8;    // candidates per wave
 
-template <int NQT>
+// F16: D holds IEEE fp16 rows (fp16-stored index); the query is split into fp16 hi + lo halves for
+// v_mfma_f32_16x16x32_f16 exactly as in maxsim_stream.hip.
+template <int NQT, bool F16>
 __global__ __launch_bounds__(256) void maxsim_cand_kernel(const float* __restrict__ D, const float* __restrict__ Q,
                                                            int nq, const int64_t* __restrict__ offsets,
                                                            const int32_t* __restrict__ candidates, int n_cand,
@@ -140,21 +143,42 @@ __global__ __launch_bounds__(256) void maxsim_cand_kernel(const float* __restric
     const int qi = (int)(wave / groups);
     const int c0 = (int)(wave % groups) * CPW;
 
-    // B fragments: lane (j, kq), MFMA 4*mm + tt uses Q[16h + j][16*mm + 4*kq + tt]
-    float qreg[NQT][32];
+    // B fragments: lane (j, kq), MFMA 4*mm + tt uses Q[16h + j][16*mm + 4*kq + tt]  (fp16 storage: MFMA mm uses
+    // Q[16h + j][32*mm + 8*kq .. +7] as hi / lo halves)
+    [[maybe_unused]] float qreg[F16 ? 1 : NQT][F16 ? 1 : 32];
+    [[maybe_unused]] h16x8 qhi[F16 ? NQT : 1][F16 ? 4 : 1], qlo[F16 ? NQT : 1][F16 ? 4 : 1];
+    [[maybe_unused]] bool any_lo = false;
     const float* Qq = Q + (int64_t)qi * nq * CD;
 #pragma unroll
     for (int h = 0; h < NQT; ++h) {
         const int qv = 16 * h + fj;
         const int qc_ = qv < nq ? qv : nq - 1;
+        if constexpr (!F16) {
 #pragma unroll
-        for (int mm = 0; mm < 8; ++mm) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(Qq + (int64_t)qc_ * CD + 16 * mm + 4 * kq);
-            if (qv >= nq) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            qreg[h][4 * mm + 0] = v[0]; qreg[h][4 * mm + 1] = v[1];
-            qreg[h][4 * mm + 2] = v[2]; qreg[h][4 * mm + 3] = v[3];
+            for (int mm = 0; mm < 8; ++mm) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(Qq + (int64_t)qc_ * CD + 16 * mm + 4 * kq);
+                if (qv >= nq) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                qreg[h][4 * mm + 0] = v[0]; qreg[h][4 * mm + 1] = v[1];
+                qreg[h][4 * mm + 2] = v[2]; qreg[h][4 * mm + 3] = v[3];
+            }
+        } else {
+#pragma unroll
+            for (int mm = 0; mm < 4; ++mm) {
+                const float* qp = Qq + (int64_t)qc_ * CD + 32 * mm + 8 * kq;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp), v1 = *reinterpret_cast<const f32x4*>(qp + 4);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float x = qv < nq ? (u < 4 ? v0[u] : v1[u - 4]) : 0.f;
+                    const _Float16 hi = (_Float16)x;
+                    const _Float16 lo = (_Float16)(x - (float)hi);
+                    qhi[h][mm][u] = hi;
+                    qlo[h][mm][u] = lo;
+                    any_lo |= lo != (_Float16)0.0f;
+                }
+            }
         }
     }
+    if constexpr (F16) any_lo = __builtin_amdgcn_ballot_w64(any_lo) != 0;
 
     for (int ci = c0; ci < c0 + CPW && ci < n_cand; ++ci) {
         const int64_t chunk = candidates[(int64_t)qi * n_cand + ci];
@@ -165,20 +189,39 @@ __global__ __launch_bounds__(256) void maxsim_cand_kernel(const float* __restric
         for (int64_t r0 = b; r0 < e; r0 += 16) {
             int64_t row = r0 + fj;            // A fragment: lane (i = fj, k = kq) supplies row i
             if (row > e - 1) row = e - 1;     // clamp; masked below
-            const float* p = D + row * CD + 4 * kq;
-            f32x4 a[8];
-#pragma unroll
-            for (int mm = 0; mm < 8; ++mm) a[mm] = *reinterpret_cast<const f32x4*>(p + 16 * mm);
             f32x4 acc[NQT];
 #pragma unroll
             for (int h = 0; h < NQT; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (!F16) {
+                const float* p = D + row * CD + 4 * kq;
+                f32x4 a[8];
 #pragma unroll
-            for (int mm = 0; mm < 8; ++mm)
+                for (int mm = 0; mm < 8; ++mm) a[mm] = *reinterpret_cast<const f32x4*>(p + 16 * mm);
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
+                for (int mm = 0; mm < 8; ++mm)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                        for (int h = 0; h < NQT; ++h)
+                            acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mm][tt], qreg[h][4 * mm + tt], acc[h], 0, 0, 0);
+            } else {
+                const uint16_t* p = reinterpret_cast<const uint16_t*>(D) + row * CD + 8 * kq;
+                h16x8 a[4];
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm) a[mm] = *reinterpret_cast<const h16x8*>(p + 32 * mm);
+#pragma unroll
+                for (int mm = 0; mm < 4; ++mm)
 #pragma unroll
                     for (int h = 0; h < NQT; ++h)
-                        acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mm][tt], qreg[h][4 * mm + tt], acc[h], 0, 0, 0);
+                        acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mm], qhi[h][mm], acc[h], 0, 0, 0);
+                if (any_lo) {
+#pragma unroll
+                    for (int mm = 0; mm < 4; ++mm)
+#pragma unroll
+                        for (int h = 0; h < NQT; ++h)
+                            acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mm], qlo[h][mm], acc[h], 0, 0, 0);
+                }
+            }
             // C/D: column fj = query, row 4*kq + reg = corpus row r0 + 4*kq + reg
 #pragma unroll
             for (int h = 0; h < NQT; ++h)
@@ -204,22 +247,32 @@ __global__ __launch_bounds__(256) void maxsim_cand_kernel(const float* __restric
     }
 }
 
-int launch_maxsim_cand(const float* D, int32_t dim, const float* Q, int32_t nq, const int64_t* offsets,
-                       const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s) {
+static int launch_cand_any(const float* D, bool f16, int32_t dim, const float* Q, int32_t nq, const int64_t* offsets,
+                           const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s) {
     if (dim != CD || nq < 1 || nq > 32) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
     if (n_cand <= 0 || n_queries <= 0) return RL_OK;
     const int64_t waves = (int64_t)n_queries * ((n_cand + CPW - 1) / CPW);
     const int64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7fffffff) return fail(RL_ERR_UNSUPPORTED, "MaxSim rerank: too many (query, candidate) pairs per launch");
-    if (nq <= 16)
-        hipLaunchKernelGGL((maxsim_cand_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, D, Q, (int)nq, offsets,
-                           candidates, (int)n_cand, (int)n_queries, out);
-    else
-        hipLaunchKernelGGL((maxsim_cand_kernel<2>), dim3((unsigned)blocks), dim3(256), 0, s, D, Q, (int)nq, offsets,
-                           candidates, (int)n_cand, (int)n_queries, out);
+#define RL_CAND(NQT, F) hipLaunchKernelGGL((maxsim_cand_kernel<NQT, F>), dim3((unsigned)blocks), dim3(256), 0, s, D, Q, \
+                                           (int)nq, offsets, candidates, (int)n_cand, (int)n_queries, out)
+    if (f16) { if (nq <= 16) RL_CAND(1, true); else RL_CAND(2, true); }
+    else     { if (nq <= 16) RL_CAND(1, false); else RL_CAND(2, false); }
+#undef RL_CAND
     RL_HIP(hipGetLastError());
     return RL_OK;
+}
+
+int launch_maxsim_cand(const float* D, int32_t dim, const float* Q, int32_t nq, const int64_t* offsets,
+                       const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s) {
+    return launch_cand_any(D, false, dim, Q, nq, offsets, candidates, n_cand, n_queries, out, s);
+}
+
+int launch_maxsim_cand16(const uint16_t* D, int32_t dim, const float* Q, int32_t nq, const int64_t* offsets,
+                         const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s) {
+    return launch_cand_any(reinterpret_cast<const float*>(D), true, dim, Q, nq, offsets, candidates, n_cand, n_queries,
+                           out, s);
 }
 
 }  // namespace rl

@@ -75,26 +75,30 @@ def cfg2():
     }
 
 
-def cfg3():
+def cfg3(storage="f32"):
     """ColBERT rerank: 32 query vectors x 256 candidate chunks x 64 vectors/chunk, d = 128."""
     d, nq, n_cand, rows, n_chunks = 128, 32, 256, 64, 16384  # 1 M candidate vectors in the pool
     E = torch.empty((n_chunks * rows, d), dtype=torch.float32, device="cuda")
     raglite_amd.synth_fill(E, seed=3)
     off = np.arange(0, n_chunks * rows + 1, rows, dtype=np.int64)
-    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    idx = raglite_amd.DeviceIndex(E.half() if storage == "f16" else E, off, metric="dot", storage=storage)
     nb = 4096
     Q = torch.empty((nb, nq, d), dtype=torch.float32, device="cuda")
     raglite_amd.synth_fill(Q, seed=30)
     cand = torch.randint(0, n_chunks, (nb, n_cand), device="cuda", dtype=torch.int32)
     ms = timed(lambda: idx.maxsim_rerank(Q, cand), 10)
     qps = nb / (ms * 1e-3)
-    bytes_q, flops_q = n_cand * rows * d * 4.0, 2.0 * nq * n_cand * rows * d
+    bytes_q, flops_q = n_cand * rows * d * (2.0 if storage == "f16" else 4.0), 2.0 * nq * n_cand * rows * d
     return {
-        "config": "cfg3: MaxSim rerank 32 x (256 x 64) x 128, 4096 queries per launch", "queries_per_s": qps,
+        "config": f"cfg3: MaxSim rerank 32 x (256 x 64) x 128, 4096 queries per launch, {storage}-stored corpus", "queries_per_s": qps,
         "ms_per_launch": ms, "GBps_algorithmic": qps * bytes_q / 1e9, "frac_of_hbm_peak": qps * bytes_q / 1e9 / HBM_PEAK,
         "TFLOPs_fp32": qps * flops_q / 1e12, "frac_of_mfma_f32_peak": qps * flops_q / 1e12 / MFMA_F32_PEAK,
         "note": "candidates are drawn from a 1M-vector pool (512 MB): partly L2/MALL-resident",
     }
+
+
+def cfg3_f16():
+    return cfg3("f16")
 
 
 def cfg4():

@@ -744,8 +744,35 @@ def test_f16_storage_uniform_tolerance_and_lifecycle(metric):
     s3, r3 = idx.search_rows(extra[7], 5)
     assert r3[0] == n + 7
     assert_topk_close(s3, r3, np.where(alive, oracle.similarity(Ev2, extra[7], metric), -np.inf), 5, TOL)
-    with pytest.raises(Exception):
+    with pytest.raises(Exception):  # the rerank fast path is dim 128 only on an fp16-stored index
         idx.maxsim_rerank(np.zeros((1, 2, dim), np.float32), np.zeros((1, 2), np.int32))
     idx.close()
     with pytest.raises(Exception):
         raglite_amd.DeviceIndex(np.zeros((4, 100), np.float16), storage="f16")  # dim outside the fast path
+
+
+@pytest.mark.parametrize("nq", [32, 9])
+def test_f16_storage_rerank(nq):
+    """cfg 3's shape class on an fp16-stored index: integer data exact, fp16 unit rows within 1e-4."""
+    rng = np.random.default_rng(12)
+    dim, n_queries, n_cand = 128, 5, 37
+    off = ragged_offsets(rng, 6000, 1, 40)
+    n, n_chunks = int(off[-1]), len(off) - 1
+    cand = rng.integers(0, n_chunks, size=(n_queries, n_cand)).astype(np.int32)
+    Ei = oracle.synth_matrix(95, n, dim, "small_int")
+    Qi = oracle.synth_matrix(96, n_queries * nq, dim, "small_int").reshape(n_queries, nq, dim)
+    idx = raglite_amd.DeviceIndex(Ei, off, metric="dot", storage="f16")
+    got = idx.maxsim_rerank(Qi, cand)
+    for b in range(n_queries):
+        assert np.array_equal(got[b], oracle.maxsim_candidates(Ei, off, Qi[b], cand[b]).astype(np.float32))
+    idx.close()
+    E = oracle.synth_matrix(97, n, dim)
+    E16 = (E / np.linalg.norm(E, axis=1, keepdims=True)).astype(np.float16)
+    Q = oracle.synth_matrix(98, n_queries * nq, dim).reshape(n_queries, nq, dim)
+    Q /= np.linalg.norm(Q, axis=2, keepdims=True)
+    idx = raglite_amd.DeviceIndex(E16, off, metric="dot", storage="f16")
+    got = idx.maxsim_rerank(Q, cand)
+    for b in range(n_queries):
+        np.testing.assert_allclose(got[b], oracle.maxsim_candidates(E16.astype(np.float64), off, Q[b], cand[b]),
+                                   rtol=0, atol=TOL)
+    idx.close()
