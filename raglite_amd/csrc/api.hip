@@ -717,20 +717,21 @@ int mask_chunk_scores(rl_index* idx, float* d_scores, int32_t nb, int64_t ld, co
 int maxsim_scores_device(rl_index* idx, const float* d_q, int32_t nq, float* d_out, hipStream_t s) {
     if (idx->n_chunks == 0) return RL_OK;
     int st = RL_ERR_UNSUPPORTED;
-    if (idx->E16) {
-        if (nq > 32) return fail(RL_ERR_UNSUPPORTED, "MaxSim over an fp16-stored index takes at most 32 query vectors");
-        if (idx->has_empty_chunk || idx->n_rows == 0)
-            RL_TRY(launch_fill_f32(d_out, -std::numeric_limits<float>::infinity(), idx->n_chunks, s));
-        if (idx->n_rows == 0) return RL_OK;
-        return launch_maxsim_stream16(idx->E16, idx->n_rows, idx->dim, d_q, nq, idx->row_to_chunk, idx->offsets,
-                                      idx->n_chunks, 0, d_out, 0, idx->n_cu, s);
+    if (idx->has_empty_chunk || idx->n_rows == 0)
+        RL_TRY(launch_fill_f32(d_out, -std::numeric_limits<float>::infinity(), idx->n_chunks, s));
+    if (idx->n_rows == 0) return RL_OK;
+    // More than 32 query vectors: passes of 32, each adding its chunk scores to the previous ones (fixed pass order).
+    for (int32_t v0 = 0; v0 < nq; v0 += 32) {
+        const int32_t nv = std::min<int32_t>(32, nq - v0);
+        const float* qv = d_q + (int64_t)v0 * idx->dim;
+        const int64_t accumulate = v0 > 0 ? 1 : 0;
+        st = idx->E16 ? launch_maxsim_stream16(idx->E16, idx->n_rows, idx->dim, qv, nv, idx->row_to_chunk, idx->offsets,
+                                               idx->n_chunks, 0, d_out, accumulate, idx->n_cu, s)
+                      : launch_maxsim_stream(idx->E, idx->n_rows, idx->dim, qv, nv, idx->row_to_chunk, idx->offsets,
+                                             idx->n_chunks, 0, d_out, accumulate, idx->n_cu, s);
+        if (st != RL_OK) break;
     }
-    if (idx->n_rows > 0) {
-        if (idx->has_empty_chunk)
-            RL_TRY(launch_fill_f32(d_out, -std::numeric_limits<float>::infinity(), idx->n_chunks, s));
-        st = launch_maxsim_stream(idx->E, idx->n_rows, idx->dim, d_q, nq, idx->row_to_chunk, idx->offsets,
-                                  idx->n_chunks, 0, d_out, 0, idx->n_cu, s);
-    }
+    if (idx->E16 && st == RL_ERR_UNSUPPORTED) return fail(st, "MaxSim: unsupported shape for an fp16-stored index");
     if (st == RL_ERR_UNSUPPORTED)
         st = launch_maxsim_generic(idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, nullptr,
                                    idx->n_chunks, 1, d_out, s);

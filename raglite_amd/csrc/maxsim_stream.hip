@@ -444,6 +444,10 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
         }
     };
     const bool worker = MODE == 0 && ew == 0;  // wave-uniform
+    // MODE 0 reuses `ld` (meaningless without a score matrix) as a flag: add this pass's chunk scores to `out` instead
+    // of overwriting them.  That is how more than 32 query vectors are handled: 32 at a time, summed in pass order
+    // (every chunk is owned by exactly one lane of one workgroup, so the read-modify-write needs no atomics).
+    const bool accumulate = MODE == 0 && ld != 0;
     for (int t = 0; t <= nt; ++t) {  // iteration t: walk tile t-2 in the window, fetch tile t-1 after it; t = nt drains
         stamp(t, 0);
         wg_barrier();  // B1(t)
@@ -463,14 +467,14 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
 #pragma unroll
                 for (int i = 0; i < TR; ++i) sv[i] = i < left ? sv[i] : -INFINITY;
             }
-            if (t > 1 && lane < nclosed) out[cacc] = xacc;  // tile t-2's chunks
+            if (t > 1 && lane < nclosed) out[cacc] = accumulate ? out[cacc] + xacc : xacc;  // tile t-2's chunks
             fetch_ordinals(t - 1);
             stamp(t, 4);
         }
     }
     if (worker) {
         walk();
-        if (lane < nclosed) out[cacc] = xacc;
+        if (lane < nclosed) out[cacc] = accumulate ? out[cacc] + xacc : xacc;
     }
     dump_trace();
 }

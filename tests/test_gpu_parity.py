@@ -776,3 +776,28 @@ def test_f16_storage_rerank(nq):
         np.testing.assert_allclose(got[b], oracle.maxsim_candidates(E16.astype(np.float64), off, Q[b], cand[b]),
                                    rtol=0, atol=TOL)
     idx.close()
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("nq", [33, 64, 70])
+def test_maxsim_more_than_32_query_vectors(storage, nq):
+    """Passes of 32 query vectors accumulate into the chunk scores (fixed pass order): exact on integer data, and
+    equal to the sum of the separately computed 32-vector blocks."""
+    rng = np.random.default_rng(13)
+    n, dim = 4001, 1024
+    off = ragged_offsets(rng, n, 1, 15, empty_every=37)
+    E = oracle.synth_matrix(101, n, dim, "small_int")
+    Q = oracle.synth_matrix(102, nq, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot", storage=storage)
+    got = idx.maxsim_scores(Q)
+    assert np.array_equal(got, oracle.maxsim_scores(E, off, Q).astype(np.float32))
+    s, c = idx.maxsim_topk(Q, 30)
+    es, ec = oracle.topk_desc(oracle.maxsim_scores(E, off, Q).astype(np.float32), 30)
+    assert np.array_equal(c, ec) and np.array_equal(s, es)
+    Qu = oracle.synth_matrix(103, nq, dim)
+    blocks = [idx.maxsim_scores(Qu[i : i + 32]).astype(np.float32) for i in range(0, nq, 32)]
+    want = blocks[0]
+    for b in blocks[1:]:
+        want = want + b  # fp32, pass order
+    assert np.array_equal(idx.maxsim_scores(Qu), want)
+    idx.close()
