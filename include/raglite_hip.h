@@ -105,7 +105,7 @@ int rl_index_create(rl_index** out, const float* embeddings, int64_t n_rows, int
  * binary16 bit patterns; dim must be one of 128, 256, 384, 512, 768, 1024.  Queries, scores and every
  * other argument stay fp32; arithmetic is fp32 (VALU) or fp16 x fp16 -> fp32 MFMA (exact products).
  * rl_index_append on such an index takes fp32 rows and rounds them to nearest-even fp16;
- * rl_maxsim_rerank needs dim == 128 and nq <= 32 on it (the cfg 3 shape), MaxSim nq <= 32. */
+ * rl_maxsim_rerank needs dim == 128 and nq <= 32 on it (the cfg 3 shape). */
 int rl_index_create_f16(rl_index** out, const uint16_t* embeddings_f16, int64_t n_rows, int32_t dim,
                         const int64_t* chunk_offsets, int64_t n_chunks, int metric, int mem, void* stream);
 int rl_index_destroy(rl_index* index);
