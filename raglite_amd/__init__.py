@@ -35,9 +35,13 @@ from raglite_amd._search import (
     search_and_rerank_chunks,
     vector_search,
 )
+from raglite_amd._torch_embedder import EncoderShape, HashTokenizer, TorchTokenEmbedder
 from raglite_amd._sharded import ShardedIndex, merge_topk_host, shard_bounds_by_chunk
 
 __all__ = [
+    "EncoderShape",
+    "HashTokenizer",
+    "TorchTokenEmbedder",
     "pack_bits",
     "DeviceIndex", "GpuIndex", "GpuVectorSearch", "HotPathConfig", "MaxSimRanker", "ShardedIndex",
     "adapter_apply", "attach_index", "detach_index", "embed_strings", "embed_strings_with_late_chunking",

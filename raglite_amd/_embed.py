@@ -129,16 +129,49 @@ def split_rows(n_rows: int, sentence_tokens: np.ndarray) -> np.ndarray:
 
 
 # ---- the three embed entry points ---------------------------------------------------------------------
-def plan_document(sentences: list[str], embedder: Any) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+def _is_device_tensor(x: Any) -> bool:
+    return type(x).__module__.split(".")[0] == "torch" and bool(getattr(x, "is_cuda", False))
+
+
+def _token_matrix(x: Any) -> Any:
+    """llama.cpp returns fp32 values as Python floats (`_embed.py:119`); a GPU embedder (`_torch_embedder.py`)
+    returns CUDA tensors, which stay where they are."""
+    return x.float() if _is_device_tensor(x) else np.asarray(x, dtype=np.float32)
+
+
+def _stack(blocks: list) -> Any:
+    if len(blocks) == 1:
+        return blocks[0]
+    if _is_device_tensor(blocks[0]):
+        import torch
+
+        return torch.cat(blocks)
+    return np.vstack(blocks)
+
+
+def _pool(tokens: Any, begins: np.ndarray, ends: np.ndarray, *, normalize: bool, eps: float) -> np.ndarray:
+    """`rl_pool_norm` on whichever side the token matrix lives; always returns the fp16 NumPy matrix of the contract."""
+    if _is_device_tensor(tokens):
+        import torch
+
+        b = torch.as_tensor(begins, device=tokens.device)
+        e = torch.as_tensor(ends, device=tokens.device)
+        _, out = _ops.pool_norm(tokens, b, e, normalize=normalize, eps=eps)
+        return out.cpu().numpy()
+    _, out = _ops.pool_norm(tokens, begins, ends, normalize=normalize, eps=eps)
+    return out
+
+
+def plan_document(sentences: list[str], embedder: Any) -> tuple[Any, np.ndarray, np.ndarray]:
     """Everything the pooling kernel needs for one document: the concatenated token matrix of all
-    segments (T, dim) float32 and, per content sentence, its row span [begin, end) in that matrix."""
+    segments (T, dim) float32 (NumPy, or a CUDA tensor when the embedder runs on the GPU) and, per content
+    sentence, its row span [begin, end) in that matrix."""
     num_tokens = count_sentence_tokens(sentences, embedder)
     plan = plan_segments(num_tokens, embedder.n_ctx(), embedder.n_batch)
     token_blocks, begins, ends = [], [], []
     base = 0
     for seg_start, content_start, seg_end in plan:
-        # llama.cpp returns fp32 values as Python floats (`_embed.py:119`); fp32 storage is lossless.
-        tokens = np.asarray(embedder.embed("".join(sentences[seg_start:seg_end])), dtype=np.float32)
+        tokens = _token_matrix(embedder.embed("".join(sentences[seg_start:seg_end])))
         sizes = split_rows(len(tokens), num_tokens[seg_start:seg_end])
         bounds = base + np.concatenate(([0], np.cumsum(sizes)))
         first = content_start - seg_start
@@ -146,8 +179,7 @@ def plan_document(sentences: list[str], embedder: Any) -> tuple[np.ndarray, np.n
         ends.append(bounds[first + 1 :])
         token_blocks.append(tokens)
         base += len(tokens)
-    all_tokens = token_blocks[0] if len(token_blocks) == 1 else np.vstack(token_blocks)
-    return all_tokens, np.concatenate(begins).astype(np.int64), np.concatenate(ends).astype(np.int64)
+    return _stack(token_blocks), np.concatenate(begins).astype(np.int64), np.concatenate(ends).astype(np.int64)
 
 
 def embed_strings_with_late_chunking(sentences: list[str], *, config: Any | None = None,
@@ -159,26 +191,24 @@ def embed_strings_with_late_chunking(sentences: list[str], *, config: Any | None
     if len(sentences) == 0:
         raise ValueError("need at least one sentence")
     tokens, begins, ends = plan_document(sentences, embedder)
-    _, out = _ops.pool_norm(tokens, begins, ends, normalize=bool(config.embedder_normalize), eps=0.0)
-    return out
+    return _pool(tokens, begins, ends, normalize=bool(config.embedder_normalize), eps=0.0)
 
 
 def _embed_string_batch(strings: list[str], *, config: Any, embedder: Any | None = None) -> np.ndarray:
     """`_embed.py:144-165`: one pooled vector per string; eps-guarded normalisation."""
     if config.embedder.startswith("llama-cpp-python"):
         embedder = embedder or embedder_for(config)
-        mats = [np.asarray(m, dtype=np.float32) for m in embedder.embed(strings)]
+        mats = [_token_matrix(m) for m in embedder.embed(strings)]
         lengths = np.asarray([len(m) for m in mats], dtype=np.int64)
-        tokens = np.vstack(mats)
+        tokens = _stack(mats)
     else:
         # API embedders return one vector per string (`_embed.py:156-158`): spans of a single row.
         embedder = embedder or embedder_for(config)
         tokens = np.asarray(embedder(strings), dtype=np.float32)
         lengths = np.ones(len(strings), dtype=np.int64)
     ends = np.cumsum(lengths)
-    _, out = _ops.pool_norm(tokens, ends - lengths, ends, normalize=bool(config.embedder_normalize),
-                            eps=float(np.finfo(np.float64).eps))
-    return out
+    return _pool(tokens, ends - lengths, ends, normalize=bool(config.embedder_normalize),
+                 eps=float(np.finfo(np.float64).eps))
 
 
 def embed_strings_without_late_chunking(strings: list[str], *, config: Any | None = None,

@@ -1,0 +1,188 @@
+"""Token-level embedding forward in PyTorch-ROCm.
+
+The reference gets one embedding per TOKEN from llama.cpp -- `Llama(embedding=True, pooling_type=NONE)`,
+`src/raglite/_embed.py:64-66,119,151-154` -- for its default embedder bge-m3, an XLM-RoBERTa-large encoder
+(24 layers, d = 1024, 16 heads, FFN 4096).  This module is that forward pass on the GPU behind the same duck-typed
+surface `_embed.py` touches (`n_ctx()`, `n_batch`, `tokenize`, `detokenize`, `embed`), so that
+
+    raglite_amd.set_embedder_factory(lambda cfg: TorchTokenEmbedder.bge_m3_shaped(device="cuda"))
+
+makes `embed_strings()` run tokenise -> encoder -> late-chunking pool (`rl_pool_norm`) without the token matrix ever
+leaving HBM.  PyTorch is plumbing here (GEMMs through hipBLASLt, attention through SDPA); the kernels this package
+owns start at the pooling seam.
+
+No checkpoint can be fetched in this environment: weights are random-initialised in the architecture's shape unless a
+state dict is supplied (`load_state_dict`), and the default tokenizer is a deterministic hashing word-piece splitter;
+pass `tokenizer=` (anything with `encode(str) -> list[int]` / `decode(list[int]) -> str`, e.g. a `tokenizers`
+SentencePiece model of bge-m3) for real text.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Any
+
+SENTINEL = "⊕"  # `_embed.py:70`
+
+
+@dataclass(frozen=True)
+class EncoderShape:
+    vocab_size: int = 250_002
+    hidden: int = 1024
+    layers: int = 24
+    heads: int = 16
+    ffn: int = 4096
+    max_positions: int = 8194
+    n_ctx: int = 8192
+    layer_norm_eps: float = 1e-5
+    pad_id: int = 1  # XLM-R: <s>=0, <pad>=1, </s>=2; positions start at pad_id + 1
+    bos_id: int = 0
+    eos_id: int = 2
+
+
+class HashTokenizer:
+    """Deterministic stand-in for a SentencePiece vocabulary: pieces of up to 4 alphanumerics, single other
+    characters, the sentinel as its own token; ids by FNV-1a into the vocabulary, remembered for `decode`."""
+
+    def __init__(self, vocab_size: int, reserved: int = 8) -> None:
+        self.vocab_size, self.reserved = vocab_size, reserved
+        self._piece_of: dict[int, str] = {}
+
+    @staticmethod
+    def _pieces(text: str) -> list[str]:
+        out, i = [], 0
+        while i < len(text):
+            if text[i].isalnum():
+                j = i
+                while j < len(text) and j - i < 4 and text[j].isalnum():
+                    j += 1
+                out.append(text[i:j])
+                i = j
+            else:
+                out.append(text[i])
+                i += 1
+        return out
+
+    def encode(self, text: str) -> list[int]:
+        ids = []
+        for p in self._pieces(text):
+            h = 2166136261
+            for b in p.encode():
+                h = ((h ^ b) * 16777619) & 0xFFFFFFFF
+            tid = self.reserved + h % (self.vocab_size - self.reserved)
+            while self._piece_of.get(tid, p) != p:  # keep decode a function under hash collisions
+                tid = self.reserved + (tid + 1 - self.reserved) % (self.vocab_size - self.reserved)
+            self._piece_of[tid] = p
+            ids.append(tid)
+        return ids
+
+    def decode(self, ids: list[int]) -> str:
+        return "".join(self._piece_of.get(t, "") for t in ids)
+
+
+def _build_encoder(shape: EncoderShape):
+    import torch
+    from torch import nn
+    from torch.nn import functional as F  # noqa: N812
+
+    class Layer(nn.Module):
+        def __init__(self) -> None:
+            super().__init__()
+            d = shape.hidden
+            self.qkv = nn.Linear(d, 3 * d)
+            self.out = nn.Linear(d, d)
+            self.ln1 = nn.LayerNorm(d, eps=shape.layer_norm_eps)
+            self.up = nn.Linear(d, shape.ffn)
+            self.down = nn.Linear(shape.ffn, d)
+            self.ln2 = nn.LayerNorm(d, eps=shape.layer_norm_eps)
+
+        def forward(self, x, mask):  # x: (B, T, d); mask: (B, 1, 1, T) additive or None
+            B, T, d = x.shape  # noqa: N806
+            h = shape.heads
+            q, k, v = self.qkv(x).view(B, T, 3, h, d // h).permute(2, 0, 3, 1, 4)  # each (B, h, T, d/h)
+            a = F.scaled_dot_product_attention(q, k, v, attn_mask=mask)
+            x = self.ln1(x + self.out(a.transpose(1, 2).reshape(B, T, d)))  # post-LN, like BERT / XLM-R
+            return self.ln2(x + self.down(F.gelu(self.up(x))))
+
+    class Encoder(nn.Module):
+        def __init__(self) -> None:
+            super().__init__()
+            self.tok = nn.Embedding(shape.vocab_size, shape.hidden, padding_idx=shape.pad_id)
+            self.pos = nn.Embedding(shape.max_positions, shape.hidden, padding_idx=shape.pad_id)
+            self.ln = nn.LayerNorm(shape.hidden, eps=shape.layer_norm_eps)
+            self.layers = nn.ModuleList(Layer() for _ in range(shape.layers))
+
+        def forward(self, ids, lengths):  # ids: (B, T) padded with pad_id; lengths: (B,)
+            B, T = ids.shape  # noqa: N806
+            ar = torch.arange(T, device=ids.device)
+            valid = ar[None, :] < lengths[:, None]
+            pos = torch.where(valid, ar[None, :] + shape.pad_id + 1, torch.full_like(ids, shape.pad_id))
+            x = self.ln(self.tok(ids) + self.pos(pos))
+            mask = None
+            if not bool(valid.all()):
+                mask = torch.zeros((B, 1, 1, T), dtype=x.dtype, device=x.device).masked_fill(~valid[:, None, None, :],
+                                                                                           float("-inf"))
+            for layer in self.layers:
+                x = layer(x, mask)
+            return x  # (B, T, hidden): one embedding per token, pooling NONE
+
+    return Encoder()
+
+
+class TorchTokenEmbedder:
+    """llama-like facade over the encoder: the object `embedder_for(config)` is expected to return."""
+
+    def __init__(self, shape: EncoderShape | None = None, *, tokenizer: Any | None = None, device: str = "cuda",
+                 dtype: Any | None = None, seed: int = 0, n_batch: int | None = None) -> None:
+        import torch
+
+        self.shape = shape or EncoderShape()
+        self.tokenizer = tokenizer or HashTokenizer(self.shape.vocab_size)
+        self.device = torch.device(device)
+        self.dtype = dtype or (torch.bfloat16 if self.device.type == "cuda" else torch.float32)
+        self.n_batch = n_batch or self.shape.n_ctx
+        gen_state = torch.random.get_rng_state()
+        torch.manual_seed(seed)  # random-initialised weights of the architecture's shape (no checkpoint here)
+        self.encoder = _build_encoder(self.shape).to(device=self.device, dtype=self.dtype).eval()
+        torch.random.set_rng_state(gen_state)
+        self.embed_calls = 0
+
+    @classmethod
+    def bge_m3_shaped(cls, **kw: Any) -> "TorchTokenEmbedder":
+        return cls(EncoderShape(), **kw)
+
+    def load_state_dict(self, state: dict) -> None:
+        self.encoder.load_state_dict(state)
+
+    # -- the surface `_embed.py` touches ---------------------------------------------------------------------
+    def n_ctx(self) -> int:
+        return self.shape.n_ctx
+
+    def tokenize(self, data: bytes, add_bos: bool = True, special: bool = False) -> list[int]:  # noqa: ARG002,FBT001,FBT002
+        ids = self.tokenizer.encode(data.decode())
+        return ([self.shape.bos_id] if add_bos else []) + ids
+
+    def detokenize(self, tokens: list[int]) -> bytes:
+        return self.tokenizer.decode([t for t in tokens if t not in (self.shape.bos_id, self.shape.eos_id)]).encode()
+
+    def embed(self, text):  # noqa: ANN001,ANN201 - mirrors llama_cpp.Llama.embed(str | list[str])
+        """One (T_i, hidden) float32 CUDA tensor per input string (T_i = tokens + <s> + </s>, truncated to n_ctx);
+        a single tensor for a single string.  Strings of one call are padded into one batch."""
+        import torch
+
+        self.embed_calls += 1
+        single = isinstance(text, str)
+        texts = [text] if single else list(text)
+        rows = []
+        for t in texts:
+            ids = self.tokenizer.encode(t)[: self.shape.n_ctx - 2]
+            rows.append([self.shape.bos_id, *ids, self.shape.eos_id])
+        lengths = torch.tensor([len(r) for r in rows], device=self.device)
+        T = int(lengths.max())  # noqa: N806
+        ids = torch.full((len(rows), T), self.shape.pad_id, dtype=torch.long)
+        for i, r in enumerate(rows):
+            ids[i, : len(r)] = torch.tensor(r, dtype=torch.long)
+        with torch.inference_mode():
+            out = self.encoder(ids.to(self.device), lengths).float()
+        mats = [out[i, : int(lengths[i])] for i in range(len(rows))]
+        return mats[0] if single else mats

@@ -801,3 +801,47 @@ def test_maxsim_more_than_32_query_vectors(storage, nq):
         want = want + b  # fp32, pass order
     assert np.array_equal(idx.maxsim_scores(Qu), want)
     idx.close()
+
+
+def test_cfg1_shape_10k_chunks_top10():
+    """BASELINE configs[0]: 10 k chunk embeddings, d = 1024, cosine top-10 -- the reference's CPU-runnable case, rows
+    L2-normalised and rounded through fp16 like `_embed.py:139-140`; through the two-stage semantics with 5 rows/chunk."""
+    n, dim = 10_000, 1024
+    E = oracle.synth_matrix(1, n, dim)
+    E = (E / np.linalg.norm(E, axis=1, keepdims=True)).astype(np.float16).astype(np.float32)
+    off = np.arange(0, n + 1, 5, dtype=np.int64)
+    r2c = np.repeat(np.arange(n // 5), 5)
+    idx = raglite_amd.DeviceIndex(E, off, metric="cosine")
+    for seed in (2, 3):
+        q = oracle.synth_matrix(seed, 1, dim)[0]
+        s, r = idx.search_rows(q, 10)
+        assert_topk_close(s, r, oracle.similarity(E, q, "cosine"), 10, TOL)
+        gs, gc, cnt = idx.search_chunks(q, oracle.num_hits(10), 10)
+        ws, wc = oracle.search_chunks(E, r2c, q, oracle.num_hits(10), 10, "cosine")
+        assert int(cnt) == len(wc) and np.array_equal(gc[: len(wc)], wc)
+        np.testing.assert_allclose(gs[: len(wc)], ws, rtol=0, atol=TOL)
+    idx.close()
+
+
+def test_torch_embedder_feeds_pooling_on_device(torch_cuda):
+    """tokenise -> PyTorch-ROCm encoder -> `rl_pool_norm`, the token matrix never leaving HBM.  The
+    pooled fp16 rows must equal the oracle's late-chunking pool of the very token matrices the encoder produced."""
+    from raglite_amd import _embed
+    from raglite_amd._torch_embedder import EncoderShape, TorchTokenEmbedder
+
+    shape = EncoderShape(vocab_size=30000, hidden=256, layers=3, heads=8, ffn=512, max_positions=600, n_ctx=512)
+    emb = TorchTokenEmbedder(shape, device="cuda", seed=5, n_batch=512)
+    cfg = raglite_amd.HotPathConfig()
+    sents = make_sentences(77, 60)  # ~1000 tokens: several segments with preambles
+    out = raglite_amd.embed_strings(sents, config=cfg, embedder=emb)
+    assert out.dtype == np.float16 and out.shape == (60, 256) and np.isfinite(out.astype(np.float32)).all()
+    np.testing.assert_allclose(np.linalg.norm(out.astype(np.float64), axis=1), 1.0, rtol=1e-3)  # tests/test_embed.py:24-26
+    tokens, begins, ends = _embed.plan_document(sents, emb)
+    assert tokens.is_cuda
+    _, want = oracle.pool_norm_cast(tokens.cpu().numpy().astype(np.float64), begins, ends, normalize=True, eps=None)
+    assert np.array_equal(out.view(np.uint16), want.view(np.uint16))
+    # the whole-string path (`_embed.py:144-165`)
+    out2 = raglite_amd.embed_strings_without_late_chunking(sents[:7], config=cfg, embedder=emb)
+    mats = [m.cpu().numpy() for m in emb.embed(sents[:7])]
+    want2 = oracle.embed_string_batch_pool(mats, normalize=True)
+    assert np.array_equal(out2.view(np.uint16), want2.view(np.uint16))

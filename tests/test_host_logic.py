@@ -196,3 +196,33 @@ def test_group_chunk_max_host_matches_oracle():
         es, ec = oracle.group_chunk_max(sc, r2c[rows], 5)
         assert out_c[0, : n[0]].tolist() == ec.tolist()
         np.testing.assert_array_equal(out_s[0, : n[0]], es)
+
+
+def test_torch_token_embedder_surface_on_cpu():
+    """the PyTorch token-level embedder exposes exactly what `_embed.py` touches; a tiny shape runs
+    on the CPU here (the encoder is plain PyTorch), the pooling seam is exercised on the GPU in test_gpu_parity."""
+    import torch
+
+    from raglite_amd import _embed
+    from raglite_amd._torch_embedder import EncoderShape, HashTokenizer, TorchTokenEmbedder
+
+    shape = EncoderShape(vocab_size=5000, hidden=32, layers=2, heads=4, ffn=64, max_positions=300, n_ctx=256)
+    emb = TorchTokenEmbedder(shape, device="cpu", seed=3)
+    tok = HashTokenizer(5000)
+    text = "Some text, with punctuation; and numbers 12345678."
+    assert tok.decode(tok.encode(text)) == text
+    assert emb.detokenize(emb.tokenize(text.encode(), add_bos=True)) == text.encode()
+    assert _embed._sentinel_token_ids(emb)  # the sentinel character is a token of its own
+    sents = ["Hello world this is one sentence. ", "And another, shorter one. ", "Third! "]
+    counts = _embed.count_sentence_tokens(sents, emb)
+    assert len(counts) == 3 and counts.sum() > 0
+    whole = emb.embed("".join(sents))
+    assert whole.shape == (len(tok.encode("".join(sents))) + 2, 32) and whole.dtype == torch.float32
+    batch = emb.embed(sents)
+    for s, m in zip(sents, batch):  # padding + attention mask: a string's rows do not depend on its batch mates
+        torch.testing.assert_close(m, emb.embed(s), atol=1e-5, rtol=0)
+    again = TorchTokenEmbedder(shape, device="cpu", seed=3).embed(sents[0])
+    torch.testing.assert_close(again, batch[0], atol=1e-5, rtol=0)  # seeded init
+    plan = _embed.plan_segments(counts, emb.n_ctx(), emb.n_batch)
+    assert plan == [(0, 0, 3)]
+    assert _embed.split_rows(len(whole), counts).sum() == len(whole)
