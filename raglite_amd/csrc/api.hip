@@ -127,11 +127,6 @@ struct rl_index {
     uint32_t* live_row_bits = nullptr;    // the same expanded to rows
     int64_t n_dead_chunks = 0, n_dead_rows = 0;
     rl::Pool maskbuf;                     // per-call effective row mask
-    // Side streams for batches of independent corpus passes: consecutive launches on ONE stream leave the chip idle
-    // for the tail of one kernel plus the ramp of the next (~5-7 us per pass, 6-8 % of a 125 k-row shard's pass);
-    // round-robin over three streams lets the next pass's workgroups start as CUs free up.
-    hipStream_t side[2] = {nullptr, nullptr};
-    hipEvent_t fork_ev = nullptr, join_ev[2] = {nullptr, nullptr};
 };
 
 using namespace rl;
@@ -297,11 +292,6 @@ int rl_index_destroy(rl_index* idx) {
     if (idx->sumsq) (void)hipFree(idx->sumsq);
     if (idx->live_chunk_bits) (void)hipFree(idx->live_chunk_bits);
     if (idx->live_row_bits) (void)hipFree(idx->live_row_bits);
-    for (int i = 0; i < 2; ++i) {
-        if (idx->side[i]) (void)hipStreamDestroy(idx->side[i]);
-        if (idx->join_ev[i]) (void)hipEventDestroy(idx->join_ev[i]);
-    }
-    if (idx->fork_ev) (void)hipEventDestroy(idx->fork_ev);
     idx->maskbuf.release();
     select_workspace_free(idx->ws);
     idx->scores.release();
@@ -404,11 +394,6 @@ int upload_live_bits(rl_index* idx, hipStream_t s) {
     const size_t cw = (size_t)(idx->n_chunks + 31) / 32, rw = (size_t)(idx->n_rows + 31) / 32;
     if (idx->live_chunk_bits) (void)hipFree(idx->live_chunk_bits);
     if (idx->live_row_bits) (void)hipFree(idx->live_row_bits);
-    for (int i = 0; i < 2; ++i) {
-        if (idx->side[i]) (void)hipStreamDestroy(idx->side[i]);
-        if (idx->join_ev[i]) (void)hipEventDestroy(idx->join_ev[i]);
-    }
-    if (idx->fork_ev) (void)hipEventDestroy(idx->fork_ev);
     idx->live_chunk_bits = idx->live_row_bits = nullptr;
     RL_HIP(hipMalloc(&idx->live_chunk_bits, std::max<size_t>(cw * 4, 16)));
     RL_HIP(hipMalloc(&idx->live_row_bits, std::max<size_t>(rw * 4, 16)));
@@ -807,28 +792,12 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
     const int64_t ld = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
     RL_TRY(idx->scores.reserve((size_t)n_queries * ld * sizeof(float)));
     float* sc = idx->scores.as<float>();
-    if (n_queries >= 4) {  // independent passes: overlap each launch's tail with the next one's ramp (see rl_index::side)
-        if (!idx->fork_ev) {
-            RL_HIP(hipEventCreateWithFlags(&idx->fork_ev, hipEventDisableTiming));
-            for (int i = 0; i < 2; ++i) {
-                RL_HIP(hipStreamCreateWithFlags(&idx->side[i], hipStreamNonBlocking));
-                RL_HIP(hipEventCreateWithFlags(&idx->join_ev[i], hipEventDisableTiming));
-            }
-        }
-        RL_HIP(hipEventRecord(idx->fork_ev, s));  // staged queries / earlier work on s are visible to the side streams
-        for (int i = 0; i < 2; ++i) RL_HIP(hipStreamWaitEvent(idx->side[i], idx->fork_ev, 0));
-        for (int32_t b = 0; b < n_queries; ++b) {
-            hipStream_t sb = (b % 3 == 0) ? s : idx->side[b % 3 - 1];
-            RL_TRY(maxsim_scores_device(idx, d_q + (size_t)b * q_elems, nq, sc + (int64_t)b * ld, sb));
-        }
-        for (int i = 0; i < 2; ++i) {
-            RL_HIP(hipEventRecord(idx->join_ev[i], idx->side[i]));
-            RL_HIP(hipStreamWaitEvent(s, idx->join_ev[i], 0));
-        }
-    } else {
-        for (int32_t b = 0; b < n_queries; ++b)
-            RL_TRY(maxsim_scores_device(idx, d_q + (size_t)b * q_elems, nq, sc + (int64_t)b * ld, s));
-    }
+    // One corpus pass per query, back to back on the caller's stream.  (Round-robin over side streams hides each
+    // launch's tail behind the next one's ramp and measured +1.5 % at 1 M rows / +3.3 % on a 125 k-row shard, but
+    // concurrent kernels stretch each other's durations 3x in a kernel trace, which would make the rocprofv3 summary
+    // disagree with the live roofline timing; the serial form keeps every number checkable.)
+    for (int32_t b = 0; b < n_queries; ++b)
+        RL_TRY(maxsim_scores_device(idx, d_q + (size_t)b * q_elems, nq, sc + (int64_t)b * ld, s));
     RL_TRY(mask_chunk_scores(idx, sc, n_queries, ld, nullptr, s));  // tombstones (no-op without deletions)
     RL_TRY(launch_topk(sc, n_queries, idx->n_chunks, ld, k, idx->ws, d_s, d_c, s));
     if (idx->live_chunk_bits) RL_TRY(launch_fix_masked(d_s, d_c, (int64_t)n_queries * k, s));
