@@ -201,6 +201,19 @@ int rl_maxsim_topk_filtered(rl_index* index, const float* query_vecs, int32_t nq
                             const uint32_t* chunk_filter, float* out_scores, int32_t* out_chunks, int mem,
                             void* stream);
 
+/* ---- device half of update_query_adapter ----------------------------------
+ * src/raglite/_query_adapter.py:153-205 fits the query adapter from evals: per eval a vector search
+ * (rl_search_chunks, batched over all evals), then for every retrieved chunk the row
+ * np.argmax(chunk.embedding_matrix @ q) (:174,180) as positive / negative example, then NNLS +
+ * Procrustes on the host.
+ *   rl_chunk_best_rows: queries [B x dim] f32, candidates [B x n_cand] int32 chunk ordinals (-1 =
+ *     none) -> out_rows [B x n_cand] int32 row ordinals (first maximum on ties; -1 for no chunk or an
+ *     empty chunk).
+ *   rl_gather_rows: out[i] = embedding row rows[i] as f32 (NaN row for an out-of-range ordinal). */
+int rl_chunk_best_rows(rl_index* index, const float* queries, int32_t n_queries, const int32_t* candidates,
+                       int32_t n_cand, int32_t* out_rows, int mem, void* stream);
+int rl_gather_rows(rl_index* index, const int32_t* rows, int64_t n, float* out, int mem, void* stream);
+
 /* Timing hook for bench.py: run `fn`-independent -- records the elapsed milliseconds between two
  * events on `stream` bracketing `iters` back-to-back launches of the named kernel path with the
  * given index / query.  kind: 0 = rl_maxsim_scores kernel only, 1 = rl_search_rows scan kernel

@@ -1,0 +1,91 @@
+"""Generate `tests/golden/query_adapter.npz` by executing the REFERENCE's own query-adapter arithmetic
+-- TEST INFRASTRUCTURE.  Run in the authoring container only (needs /root/reference):
+
+    python -m oracle.make_golden_adapter
+
+`src/raglite/_query_adapter.py` cannot be imported here (sqlmodel / tqdm / the database layer are absent), and its
+arithmetic sits inside one function that also talks to the store.  So the REAL source text is executed piecewise,
+nothing is copied into this repository:
+
+* `_optimize_query_target` (`_query_adapter.py:20-38`): the function definition is cut out with `ast` and exec'd with
+  the real `numpy` and `scipy.optimize.lsq_linear`;
+* the closed-form block that turns the stacked (Q, T) into the adapter (`:182-205`: row normalisation, M = TᵀQ / n,
+  null-space completion, Procrustes / Frobenius solution): the source lines between its first and last comment are
+  exec'd on our Q, T and a stand-in `config`;
+* positive / negative row selection (`:170-181`): `E[[np.argmax(E @ q)]]`, evaluated literally.
+"""
+
+from __future__ import annotations
+
+import ast
+import textwrap
+import types
+from pathlib import Path
+
+import numpy as np
+from scipy.optimize import lsq_linear
+
+SRC = Path("/root/reference/src/raglite/_query_adapter.py")
+OUT = Path(__file__).resolve().parent.parent / "tests" / "golden" / "query_adapter.npz"
+
+
+def _reference_pieces():
+    text = SRC.read_text()
+    tree = ast.parse(text)
+    fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "_optimize_query_target")
+    fn_src = "\n".join(text.splitlines()[fn.lineno - 1 : fn.end_lineno])
+    ns = {"np": np, "lsq_linear": lsq_linear, "FloatVector": np.ndarray, "FloatMatrix": np.ndarray}
+    exec(compile(fn_src, str(SRC), "exec"), ns)  # noqa: S102 - the reference's own code, read-only
+    lines = text.splitlines()
+    a = next(i for i, ln in enumerate(lines) if "# Normalise the rows of Q and T." in ln)
+    b = next(i for i, ln in enumerate(lines) if "# Store the optimal query adapter in the database." in ln)
+    block = textwrap.dedent("\n".join(lines[a:b]))
+
+    def adapter_from(Q, T, metric):  # noqa: N803
+        env = {"np": np, "Q": Q.copy(), "T": T.copy(), "FloatMatrix": np.ndarray,
+               "config": types.SimpleNamespace(vector_search_distance_metric=metric)}
+        exec(compile(block, str(SRC), "exec"), env)  # noqa: S102
+        return env["A_star"], env["Q"], env["T"]
+
+    return ns["_optimize_query_target"], adapter_from
+
+
+def main() -> None:
+    optimize, adapter_from = _reference_pieces()
+    rng = np.random.default_rng(2024)
+    out: dict[str, np.ndarray] = {}
+    # ---- target optimisation cases (fp16 inputs like the reference's embeddings) --------------------------
+    n_t = 0
+    for d, n_pos, n_neg, alpha in [(16, 1, 3, 0.05), (32, 2, 5, 0.05), (32, 4, 1, 0.2), (64, 3, 7, 0.05), (24, 1, 1, 0.0)]:
+        q = rng.standard_normal(d)
+        q = (q / np.linalg.norm(q)).astype(np.float16)
+        P = rng.standard_normal((n_pos, d))
+        N = rng.standard_normal((n_neg, d))
+        P = (P / np.linalg.norm(P, axis=1, keepdims=True)).astype(np.float16)
+        N = (N / np.linalg.norm(N, axis=1, keepdims=True)).astype(np.float16)
+        t = optimize(q, P, N, α=alpha)
+        for k, v in (("q", q), ("P", P), ("N", N), ("alpha", np.float64(alpha)), ("t", t)):
+            out[f"target{n_t}_{k}"] = v
+        n_t += 1
+    out["n_target_cases"] = np.int64(n_t)
+    # ---- adapter from stacked (Q, T): under- and over-determined, both metrics -----------------------------
+    n_a = 0
+    for d, n, metric in [(16, 5, "cosine"), (16, 40, "cosine"), (24, 7, "dot"), (24, 60, "dot"), (32, 32, "cosine")]:
+        Q = rng.standard_normal((n, d))
+        T = Q + 0.1 * rng.standard_normal((n, d))
+        A, Qn, Tn = adapter_from(Q, T, metric)
+        out[f"adapter{n_a}_Q"], out[f"adapter{n_a}_T"], out[f"adapter{n_a}_A"] = Q, T, A
+        out[f"adapter{n_a}_metric"] = np.asarray(metric)
+        n_a += 1
+    out["n_adapter_cases"] = np.int64(n_a)
+    # ---- positive / negative row selection ----------------------------------------------------------------------
+    E = rng.standard_normal((9, 16)).astype(np.float16)
+    q = rng.standard_normal(16).astype(np.float16)
+    out["select_E"], out["select_q"] = E, q
+    out["select_row"] = E[[np.argmax(E @ q)]]
+    np.savez(OUT, **out)
+    print(f"wrote {OUT} ({n_t} target cases, {n_a} adapter cases)")
+
+
+if __name__ == "__main__":
+    main()

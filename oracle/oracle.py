@@ -16,7 +16,11 @@ Parity pinning status
   imports stubbed, a deterministic fake llama embedder supplying token embeddings) and its
   outputs are committed under `tests/golden/`; `tests/test_oracle_golden.py` checks this
   module against them bit-for-bit.
-* adapter / distance / two-stage selection (rows a5-a8): PARITY UNPINNED.  The reference
+* the adapter's producer (`_optimize_query_target`, the closed-form
+  Procrustes block, positive / negative row selection of `_query_adapter.py`): PINNED.
+  `oracle/make_golden_adapter.py` executes the reference's own source lines (scipy + numpy are
+  available) and `tests/golden/query_adapter.npz` holds their outputs.
+* adapter application / distance / two-stage selection (rows a5-a8): PARITY UNPINNED.  The reference
   evaluates these inside DuckDB (`array_cosine_distance` + usearch HNSW, approximate) or
   pgvector; neither engine nor any golden vector is available.  The
   restatement follows the SQL the reference emits (`_search.py:66-79,143-149`) with exact
@@ -334,6 +338,79 @@ def maxsim_topk_filtered(D, chunk_offsets, Q, k, chunk_ok, dtype=np.float64):
     s, c = topk_desc(np.where(ok, sc, -np.inf), k)
     dead = (c >= 0) & (~ok[np.clip(c, 0, max(len(ok) - 1, 0))] | np.isneginf(s))
     return np.where(dead, -np.inf, s), np.where(dead, -1, c)
+
+
+# ----------------------------------------------------------------------------------------
+# 8f-3: the query adapter's producer (`_query_adapter.py:20-38,153-205`) -- pinned by
+# tests/golden/query_adapter.npz (oracle/make_golden_adapter.py executes the reference's own lines)
+# ----------------------------------------------------------------------------------------
+
+
+def best_row(E_chunk: np.ndarray, q: np.ndarray) -> int:
+    """`np.argmax(chunk.embedding_matrix @ q)` (`_query_adapter.py:174,180`): first maximum on ties."""
+    return int(np.argmax(np.asarray(E_chunk) @ np.asarray(q)))
+
+
+def optimize_query_target(q: np.ndarray, P: np.ndarray, N: np.ndarray, alpha: float = 0.05) -> np.ndarray:  # noqa: N803
+    """`_optimize_query_target` (`_query_adapter.py:20-38`): t* = q + Dᵀ μ*, μ* = argmin ½‖q + Dᵀμ‖², μ ≥ 0,
+    D = all P_i − (1 + α) N_j; solved in fp64, cast back to q's dtype."""
+    from scipy.optimize import lsq_linear
+
+    dt = q.dtype
+    q64, P64, N64 = q.astype(np.float64), P.astype(np.float64), N.astype(np.float64)
+    D = np.reshape(P64[:, np.newaxis, :] - (1.0 + alpha) * N64[np.newaxis, :, :], (-1, P64.shape[1]))
+    mu = lsq_linear(D.T, -q64, bounds=(0.0, np.inf), tol=np.finfo(np.float64).eps).x
+    return (q64 + D.T @ mu).astype(dt)
+
+
+def query_adapter_from_targets(Q: np.ndarray, T: np.ndarray, metric: str = "cosine") -> np.ndarray:  # noqa: N803
+    """`_query_adapter.py:182-205`: normalise the rows of Q (and of T for cosine), M = TᵀQ / n completed on Q's null
+    space, then the orthogonal Procrustes solution U Vᵀ (cosine) or M scaled to Frobenius norm √d (dot)."""
+    Q = np.array(Q, dtype=np.float64)
+    T = np.array(T, dtype=np.float64)
+    Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    if metric == "cosine":
+        T /= np.linalg.norm(T, axis=1, keepdims=True)
+    n, d = Q.shape
+    M = (1 / n) * T.T @ Q
+    if n < d or np.linalg.matrix_rank(Q) < d:
+        M += np.eye(d) - Q.T @ np.linalg.pinv(Q @ Q.T) @ Q
+    if metric == "dot":
+        return M / np.linalg.norm(M, ord="fro") * np.sqrt(d)
+    if metric == "cosine":
+        U, _, VT = np.linalg.svd(M, full_matrices=False)
+        return U @ VT
+    raise ValueError(f"Unsupported metric: {metric}")
+
+
+def update_query_adapter(evals, E, chunk_offsets, chunk_ids, *, optimize_top_k=40, optimize_gap=0.05, metric="cosine",
+                         oversample=4, chunk_max_size=2048, dtype=np.float64):
+    """The whole loop of `update_query_adapter` (`_query_adapter.py:153-205`) over an in-memory table.
+
+    evals: sequence of (query vector, relevant chunk ids).  Per eval: vector search WITHOUT the adapter for
+    `optimize_top_k` chunks (`:166-168`), skip unless both relevant and irrelevant chunks were retrieved (`:171-173`),
+    P / N = best row of every relevant / irrelevant retrieved chunk (`:174-181`), target t (`:183`).  Returns
+    (A*, Q, T) with Q, T the stacked un-normalised rows."""
+    off = np.asarray(chunk_offsets, dtype=np.int64)
+    r2c = np.repeat(np.arange(len(off) - 1), np.diff(off))
+    E = np.asarray(E)
+    Qs, Ts = [], []
+    for q, relevant in evals:
+        q = np.asarray(q)
+        n_hits = num_hits(optimize_top_k, oversample, chunk_max_size)
+        _, chunks = search_chunks(E, r2c, q.astype(dtype), n_hits, optimize_top_k, metric, dtype)
+        rel = np.asarray([chunk_ids[c] in relevant for c in chunks], dtype=bool)
+        if not rel.any() or rel.all():
+            continue
+        rows = [int(off[c]) + best_row(E[off[c] : off[c + 1]], q) for c in chunks]
+        P = E[[r for r, ok in zip(rows, rel) if ok]]
+        N = E[[r for r, ok in zip(rows, rel) if not ok]]
+        Ts.append(optimize_query_target(q, P, N, optimize_gap))
+        Qs.append(q)
+    if not Qs:
+        raise ValueError("no eval retrieved both relevant and irrelevant chunks")
+    Q, T = np.vstack(Qs).astype(np.float64), np.vstack(Ts).astype(np.float64)
+    return query_adapter_from_targets(Q, T, metric), Q, T
 
 
 # ----------------------------------------------------------------------------------------

@@ -36,9 +36,11 @@ from raglite_amd._search import (
     vector_search,
 )
 from raglite_amd._torch_embedder import EncoderShape, HashTokenizer, TorchTokenEmbedder
+from raglite_amd._query_adapter import update_query_adapter
 from raglite_amd._sharded import ShardedIndex, merge_topk_host, shard_bounds_by_chunk
 
 __all__ = [
+    "update_query_adapter",
     "EncoderShape",
     "HashTokenizer",
     "TorchTokenEmbedder",

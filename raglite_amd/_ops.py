@@ -410,6 +410,32 @@ class DeviceIndex:
         check(lib().rl_maxsim_rerank(self._handle, p_q, n_queries, nq, p_c, n_cand, p_s, a.mem, a.stream))
         return o_s
 
+    # -- 8f-3: device half of update_query_adapter ---------------------------------------------------
+    def chunk_best_rows(self, queries, candidates):
+        """For every (query b, chunk candidates[b][j]): the row ordinal maximising q . row, i.e.
+        `np.argmax(chunk.embedding_matrix @ q)` (`src/raglite/_query_adapter.py:174,180`); -1 for candidate -1."""
+        a = _Args()
+        p_q, B, single = self._queries(a, queries)
+        c2 = candidates.reshape(1, -1) if candidates.ndim == 1 else candidates
+        p_c = a.inp(c2, np.int32)
+        if int(a.keep[-1].shape[0]) != B:
+            raise ValueError("candidates must have one row per query")
+        n_cand = int(a.keep[-1].shape[1])
+        o_r, p_r = a.out((B, n_cand), np.int32)
+        self._prep(a)
+        check(lib().rl_chunk_best_rows(self._handle, p_q, B, p_c, n_cand, p_r, a.mem, a.stream))
+        return o_r[0] if single else o_r
+
+    def gather_rows(self, rows):
+        """Embedding rows as float32 (whatever the storage precision)."""
+        a = _Args()
+        p_r = a.inp(rows, np.int32)
+        n = int(a.keep[0].shape[0])
+        o, p_o = a.out((n, self.dim), np.float32)
+        self._prep(a)
+        check(lib().rl_gather_rows(self._handle, p_r, n, p_o, a.mem, a.stream))
+        return o
+
     def time_kernel(self, kind: int, query_vecs_cuda, iters: int) -> float:
         """Milliseconds (HIP events on the launch stream) for `iters` launches of the dominant kernel."""
         a = _Args()

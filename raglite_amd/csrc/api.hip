@@ -880,6 +880,42 @@ int rl_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32
 }
 
 // ---- timing hook for bench.py ------------------------------------------------------------------------------
+int rl_chunk_best_rows(rl_index* idx, const float* queries, int32_t B, const int32_t* candidates, int32_t n_cand,
+                       int32_t* out_rows, int mem, void* stream) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_chunk_best_rows: null index");
+    if (B < 0 || n_cand < 0) return fail(RL_ERR_INVALID, "rl_chunk_best_rows: bad sizes");
+    if (B == 0 || n_cand == 0) return RL_OK;
+    if (!queries || !candidates || !out_rows) return fail(RL_ERR_INVALID, "rl_chunk_best_rows: null argument");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    DevBuf t_q, t_c, t_o;
+    const float* d_q; const int32_t* d_c; int32_t* d_o;
+    RL_TRY(stage_in(queries, (size_t)B * idx->dim, mem, s, t_q, &d_q));
+    RL_TRY(stage_in(candidates, (size_t)B * n_cand, mem, s, t_c, &d_c));
+    RL_TRY(stage_out_begin(out_rows, (size_t)B * n_cand, mem, t_o, &d_o));
+    RL_TRY(launch_chunk_best_rows(idx->E16 ? (const void*)idx->E16 : (const void*)idx->E, idx->E16 != nullptr, idx->dim,
+                                  d_q, idx->offsets, idx->n_chunks, d_c, n_cand, (int64_t)B * n_cand, d_o, s));
+    RL_TRY(stage_out_end(out_rows, (size_t)B * n_cand, mem, s, t_o));
+    return finish(mem, s);
+}
+
+int rl_gather_rows(rl_index* idx, const int32_t* rows, int64_t n, float* out, int mem, void* stream) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_gather_rows: null index");
+    if (n < 0) return fail(RL_ERR_INVALID, "rl_gather_rows: negative count");
+    if (n == 0) return RL_OK;
+    if (!rows || !out) return fail(RL_ERR_INVALID, "rl_gather_rows: null argument");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    DevBuf t_r, t_o;
+    const int32_t* d_r; float* d_o;
+    RL_TRY(stage_in(rows, (size_t)n, mem, s, t_r, &d_r));
+    RL_TRY(stage_out_begin(out, (size_t)n * idx->dim, mem, t_o, &d_o));
+    RL_TRY(launch_gather_rows(idx->E16 ? (const void*)idx->E16 : (const void*)idx->E, idx->E16 != nullptr, idx->dim,
+                              idx->n_rows, d_r, n, d_o, s));
+    RL_TRY(stage_out_end(out, (size_t)n * idx->dim, mem, s, t_o));
+    return finish(mem, s);
+}
+
 int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int32_t iters, float* out_ms_total,
                    void* stream) {
     if (!idx || !q_dev || !out_ms_total || iters < 1 || nq < 1) return fail(RL_ERR_INVALID, "rl_time_kernel: bad arguments");

@@ -134,6 +134,13 @@ int launch_mask_scores(float* scores, int32_t nb, int64_t n, int64_t ld, const u
 int launch_fix_masked(const float* scores, int32_t* ids, int64_t count, hipStream_t s);
 int launch_popcount(const uint32_t* bits, int64_t n, unsigned long long* out_dev, hipStream_t s);
 
+// adapter_fit.hip: device half of update_query_adapter (best row per (query, chunk), row gather)
+int launch_chunk_best_rows(const void* E, bool f16, int32_t dim, const float* Q, const int64_t* offsets,
+                           int64_t n_chunks, const int32_t* cand, int32_t n_cand, int64_t n_items, int32_t* out_rows,
+                           hipStream_t s);
+int launch_gather_rows(const void* E, bool f16, int32_t dim, int64_t n_rows, const int32_t* rows, int64_t n, float* out,
+                       hipStream_t s);
+
 // maxsim*.hip
 int launch_row_to_chunk(const int64_t* chunk_offsets, int64_t n_chunks, int64_t n_rows, int32_t* row_to_chunk,
                         hipStream_t s);

@@ -845,3 +845,58 @@ def test_torch_embedder_feeds_pooling_on_device(torch_cuda):
     mats = [m.cpu().numpy() for m in emb.embed(sents[:7])]
     want2 = oracle.embed_string_batch_pool(mats, normalize=True)
     assert np.array_equal(out2.view(np.uint16), want2.view(np.uint16))
+
+
+# ---------------------------------------------------------------------------------------------------
+# 8f-3: device half of update_query_adapter
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_chunk_best_rows_and_gather(storage):
+    rng = np.random.default_rng(14)
+    n, dim = 3000, 256
+    off = ragged_offsets(rng, n, 1, 9, empty_every=41)
+    n_chunks = len(off) - 1
+    E = oracle.synth_matrix(111, n, dim, "small_int")
+    Q = oracle.synth_matrix(112, 6, dim, "small_int")
+    cand = rng.integers(0, n_chunks, size=(6, 25)).astype(np.int32)
+    cand[2, 3] = -1
+    idx = raglite_amd.DeviceIndex(E, off, metric="cosine", storage=storage)
+    got = idx.chunk_best_rows(Q, cand)
+    for b in range(6):
+        for j, c in enumerate(cand[b]):
+            if c < 0 or off[c + 1] == off[c]:
+                assert got[b, j] == -1
+            else:
+                assert got[b, j] == off[c] + oracle.best_row(E[off[c] : off[c + 1]], Q[b])  # integer data: exact, ties -> first
+    rows = np.asarray([0, 17, n - 1, 5], dtype=np.int32)
+    assert np.array_equal(idx.gather_rows(rows), E[rows])
+    idx.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_update_query_adapter_on_device(metric):
+    """The batched fit (one rl_search_chunks over all evals -- the GEMM path at >= 96 evals --, one rl_chunk_best_rows,
+    one rl_gather_rows, host NNLS + Procrustes) equals the per-eval loop of the oracle, and the fitted adapter is then
+    used by vector_search."""
+    rng = np.random.default_rng(15)
+    dim, n_chunks = 128, 200
+    mats = [oracle.synth_matrix(400 + i, int(rng.integers(1, 6)), dim) for i in range(n_chunks)]
+    mats = [(m / np.linalg.norm(m, axis=1, keepdims=True)).astype(np.float16) for m in mats]
+    ids = [f"{i:016x}" for i in range(n_chunks)]
+    gi = raglite_amd.GpuIndex(ids, mats, metric=metric)
+    E = np.vstack(mats).astype(np.float32)
+    off = np.concatenate(([0], np.cumsum([len(m) for m in mats]))).astype(np.int64)
+    evals = []
+    for _ in range(120):
+        t = int(rng.integers(0, n_chunks))
+        q = (mats[t][0].astype(np.float32) + 0.08 * rng.standard_normal(dim)).astype(np.float16)
+        evals.append((q, [ids[t], ids[(t + 11) % n_chunks]]))
+    cfg = raglite_amd.HotPathConfig(vector_search_distance_metric=metric)
+    A = raglite_amd.update_query_adapter(evals, optimize_top_k=10, config=cfg, index=gi)
+    want, Qs, _ = oracle.update_query_adapter(evals, E, off, ids, optimize_top_k=10, metric=metric, dtype=np.float32)
+    assert len(Qs) > 50
+    np.testing.assert_allclose(A, want, rtol=0, atol=1e-6)
+    assert gi.query_adapter is not None and gi.query_adapter.shape == (dim, dim)
+    got_ids, _ = raglite_amd.vector_search(evals[0][0], num_results=5, config=cfg, index=gi)  # adapter now applied
+    assert len(got_ids) == 5
+    gi.close()

@@ -28,6 +28,9 @@ class _FakeDeviceIndex:
         self.alive[np.asarray(ords)] = False
 
     def search_chunks(self, q, num_hits, k, chunk_filter=None):
+        if np.ndim(q) == 2:  # batched form: one row per query
+            outs = [self.search_chunks(qq, num_hits, k, chunk_filter) for qq in q]
+            return tuple(np.stack([o[j] for o in outs]) for j in range(3))
         self.calls.append((num_hits, k))
         r2c = np.repeat(np.arange(self.n_chunks), np.diff(self.off))
         ok = np.ones(self.n_chunks, bool) if chunk_filter is None else np.asarray(chunk_filter, bool)
@@ -36,6 +39,17 @@ class _FakeDeviceIndex:
         out_s = np.full(k, -np.inf, np.float32); out_c = np.full(k, -1, np.int32)
         out_s[: len(s)] = s; out_c[: len(c)] = c
         return out_s, out_c, np.int32(len(c))
+
+    def chunk_best_rows(self, Q, cand):
+        out = np.full(cand.shape, -1, np.int32)
+        for b in range(len(Q)):
+            for j, c in enumerate(cand[b]):
+                if c >= 0:
+                    out[b, j] = self.off[c] + oracle.best_row(self.E[self.off[c] : self.off[c + 1]], Q[b])
+        return out
+
+    def gather_rows(self, rows):
+        return self.E[np.asarray(rows)].astype(np.float32)
 
     def maxsim_rerank(self, qv, cand):
         return np.stack([oracle.maxsim_candidates(self.E, self.off, qv[i], cand[i], np.float32)
@@ -226,3 +240,35 @@ def test_torch_token_embedder_surface_on_cpu():
     plan = _embed.plan_segments(counts, emb.n_ctx(), emb.n_batch)
     assert plan == [(0, 0, 3)]
     assert _embed.split_rows(len(whole), counts).sum() == len(whole)
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_update_query_adapter_matches_oracle_loop(metric):
+    """the batched host mirror (one search, one best-row call, one gather) computes the same adapter
+    as the reference's per-eval loop restated in oracle.update_query_adapter (whose arithmetic is pinned against the
+    reference's own lines by tests/golden/query_adapter.npz)."""
+    gi = _gpu_index(n_chunks=60, dim=16, seed=4, metric=metric)
+    gi.index.E = (gi.index.E / np.linalg.norm(gi.index.E, axis=1, keepdims=True)).astype(np.float16).astype(np.float32)
+    rng = np.random.default_rng(6)
+    evals = []
+    for _ in range(25):
+        target = int(rng.integers(0, 60))
+        row = gi.index.E[gi.index.off[target]]
+        q = (row + 0.6 * rng.standard_normal(16)).astype(np.float16)
+        evals.append((q, [gi.chunk_ids[target], gi.chunk_ids[(target + 7) % 60]]))
+    evals.append((rng.standard_normal(16).astype(np.float16), ["no-such-chunk"]))  # retrieves nothing relevant: skipped
+    cfg = raglite_amd.HotPathConfig(vector_search_distance_metric=metric)
+    A = raglite_amd.update_query_adapter(evals, optimize_top_k=8, config=cfg, index=gi)
+    want, Q, T = oracle.update_query_adapter(evals, gi.index.E, gi.index.off, gi.chunk_ids, optimize_top_k=8,
+                                             metric=metric, dtype=np.float32)
+    assert len(Q) < len(evals)  # at least the last eval was skipped
+    np.testing.assert_allclose(A, want, rtol=0, atol=1e-9)
+    np.testing.assert_allclose(gi.query_adapter, want.astype(np.float32), atol=1e-6)
+    if metric == "cosine":
+        np.testing.assert_allclose(A @ A.T, np.eye(16), atol=1e-9)
+    with pytest.raises(ValueError):
+        raglite_amd.update_query_adapter([], config=cfg, index=gi)
+    with pytest.raises(ValueError):
+        raglite_amd.update_query_adapter(evals, config=raglite_amd.HotPathConfig(vector_search_distance_metric="l2"), index=gi)
+    with pytest.raises(ValueError):
+        raglite_amd.update_query_adapter([(evals[0][0], ["no-such-chunk"])], config=cfg, index=gi)

@@ -127,3 +127,25 @@ def test_split_rows_matches_oracle_random():
 def test_plan_segments_oversized_sentence_terminates():
     plan = mirror.plan_segments(np.asarray([5, 900, 7], dtype=np.intp), 128, 128)
     assert [p[1:] for p in plan] == [(0, 1), (1, 2), (2, 3)]
+
+
+# ---------------------------------------------------------------------------------------------------
+# 8f-3: the query adapter's producer, pinned against the reference's own lines
+# ---------------------------------------------------------------------------------------------------
+def test_query_adapter_arithmetic_matches_reference_golden():
+    """tests/golden/query_adapter.npz was produced by executing `_query_adapter.py`'s own source text
+    (oracle/make_golden_adapter.py): target optimisation, the closed-form adapter, positive/negative row choice."""
+    from pathlib import Path
+
+    g = np.load(Path(__file__).parent / "golden" / "query_adapter.npz")
+    for i in range(int(g["n_target_cases"])):
+        t = oracle.optimize_query_target(g[f"target{i}_q"], g[f"target{i}_P"], g[f"target{i}_N"], float(g[f"target{i}_alpha"]))
+        assert t.dtype == g[f"target{i}_t"].dtype
+        assert np.array_equal(t.view(np.uint16), g[f"target{i}_t"].view(np.uint16))  # same solver, same inputs: same bits
+    for i in range(int(g["n_adapter_cases"])):
+        A = oracle.query_adapter_from_targets(g[f"adapter{i}_Q"], g[f"adapter{i}_T"], str(g[f"adapter{i}_metric"]))
+        np.testing.assert_allclose(A, g[f"adapter{i}_A"], rtol=0, atol=1e-12)
+        if str(g[f"adapter{i}_metric"]) == "cosine":
+            np.testing.assert_allclose(A @ A.T, np.eye(len(A)), atol=1e-10)  # orthogonal Procrustes solution
+    E, q = g["select_E"], g["select_q"]
+    assert np.array_equal(E[[oracle.best_row(E, q)]], g["select_row"])
