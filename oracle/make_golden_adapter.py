@@ -83,6 +83,30 @@ def main() -> None:
     q = rng.standard_normal(16).astype(np.float16)
     out["select_E"], out["select_q"] = E, q
     out["select_row"] = E[[np.argmax(E @ q)]]
+    # ---- reciprocal rank fusion (`src/raglite/_search.py:233-252`): the function text, exec'd ----------------------
+    stext = (SRC.parent / "_search.py").read_text()
+    stree = ast.parse(stext)
+    rrf = next(n for n in stree.body if isinstance(n, ast.FunctionDef) and n.name == "reciprocal_rank_fusion")
+    rrf_src = "\n".join(stext.splitlines()[rrf.lineno - 1 : rrf.end_lineno])
+    from collections import defaultdict
+
+    ns2 = {"defaultdict": defaultdict, "ChunkId": str}
+    exec(compile(rrf_src, str(SRC.parent / "_search.py"), "exec"), ns2)  # noqa: S102
+    cases = [
+        ([["a", "b", "c", "d"], ["c", "a", "e"]], None, 60),
+        ([["a", "b", "c", "d"], ["c", "a", "e"]], [0.75, 0.25], 60),
+        ([["x1", "x2"], []], [0.75, 0.25], 60),
+        ([[], []], None, 60),
+        ([[f"id{i}" for i in range(20)], [f"id{(i * 7) % 23}" for i in range(20)], [f"id{i}" for i in range(19, -1, -1)]],
+         [1.0, 0.5, 0.25], 10),
+    ]
+    import json as _json
+
+    rrf_out = []
+    for rankings, weights, kk in cases:
+        ids, sc = ns2["reciprocal_rank_fusion"](rankings, k=kk, weights=weights)
+        rrf_out.append({"rankings": rankings, "weights": weights, "k": kk, "ids": ids, "scores": sc})
+    out["rrf_json"] = np.asarray(_json.dumps(rrf_out))
     np.savez(OUT, **out)
     print(f"wrote {OUT} ({n_t} target cases, {n_a} adapter cases)")
 

@@ -27,6 +27,8 @@ from raglite_amd._ops import (
 )
 from raglite_amd._search import (
     GpuIndex,
+    hybrid_search,
+    reciprocal_rank_fusion,
     GpuVectorSearch,
     MaxSimRanker,
     attach_index,
@@ -40,6 +42,8 @@ from raglite_amd._query_adapter import update_query_adapter
 from raglite_amd._sharded import ShardedIndex, merge_topk_host, shard_bounds_by_chunk
 
 __all__ = [
+    "hybrid_search",
+    "reciprocal_rank_fusion",
     "update_query_adapter",
     "EncoderShape",
     "HashTokenizer",

@@ -202,6 +202,43 @@ class GpuVectorSearch:
                              metadata_filter=metadata_filter, config=config, index=self.index)
 
 
+# ---- hybrid search ------------------------------------------------------------------------
+def reciprocal_rank_fusion(rankings: Sequence[Sequence[ChunkId]], *, k: int = 60,
+                           weights: Sequence[float] | None = None) -> tuple[list[ChunkId], list[float]]:
+    """Reciprocal Rank Fusion (`src/raglite/_search.py:233-252`): score(id) = sum_r w_r / (k + rank_r(id)), ranked by
+    descending score; ids with equal scores keep the order in which they were first seen (stable sort)."""
+    if weights is None:
+        weights = [1.0] * len(rankings)
+    if len(weights) != len(rankings):
+        raise ValueError("The number of weights must match the number of rankings.")
+    score: dict[ChunkId, float] = {}
+    for ranking, weight in zip(rankings, weights):
+        for i, cid in enumerate(ranking):
+            score[cid] = score.get(cid, 0.0) + weight / (k + i)
+    if not score:
+        return [], []
+    ordered = sorted(score.items(), key=lambda kv: kv[1], reverse=True)
+    return [cid for cid, _ in ordered], [s for _, s in ordered]
+
+
+def hybrid_search(query: str | np.ndarray, *, num_results: int = 3, oversample: int = 2,
+                  vector_search_weight: float = 0.75, keyword_search_weight: float = 0.25,
+                  metadata_filter: dict | None = None, config: Any | None = None, index: GpuIndex | None = None,
+                  keyword_search: Callable[..., tuple[list[ChunkId], list[float]]] | None = None,
+                  ) -> tuple[list[ChunkId], list[float]]:
+    """`src/raglite/_search.py:255-279`: GPU vector search fused with a keyword ranking by RRF.  The BM25 keyword
+    search lives in the store (`_search.py:156-230`, out of scope): pass the reference's own `keyword_search` (or any
+    callable with its signature) as `keyword_search=`; without one the fusion degenerates to the vector ranking."""
+    vs_ids, _ = vector_search(query, num_results=oversample * num_results, metadata_filter=metadata_filter,
+                              config=config, index=index)
+    ks_ids: list[ChunkId] = []
+    if keyword_search is not None:
+        ks_ids, _ = keyword_search(query, num_results=oversample * num_results, metadata_filter=metadata_filter,
+                                   config=config)
+    ids, scores = reciprocal_rank_fusion([vs_ids, ks_ids], weights=[vector_search_weight, keyword_search_weight])
+    return ids[:num_results], scores[:num_results]
+
+
 # ---- reranking -------------------------------------------------------------------------------------------
 @dataclass
 class Result:

@@ -272,3 +272,22 @@ def test_update_query_adapter_matches_oracle_loop(metric):
         raglite_amd.update_query_adapter(evals, config=raglite_amd.HotPathConfig(vector_search_distance_metric="l2"), index=gi)
     with pytest.raises(ValueError):
         raglite_amd.update_query_adapter([(evals[0][0], ["no-such-chunk"])], config=cfg, index=gi)
+
+
+def test_hybrid_search_fuses_vector_and_keyword_rankings():
+    """`_search.py:255-279`: oversampled vector + keyword rankings fused by RRF with weights 0.75 / 0.25."""
+    gi = _gpu_index(n_chunks=30)
+    cfg = raglite_amd.HotPathConfig(vector_search_query_adapter=False)
+    q = np.random.default_rng(8).standard_normal(16).astype(np.float32)
+    vs, _ = raglite_amd.vector_search(q, num_results=6, config=cfg, index=gi)
+    calls = []
+
+    def keyword_search(query, *, num_results, metadata_filter=None, config=None):
+        calls.append(num_results)
+        return [vs[3], "chunk0029", vs[0]], [3.0, 2.0, 1.0]
+
+    ids, scores = raglite_amd.hybrid_search(q, num_results=3, config=cfg, index=gi, keyword_search=keyword_search)
+    want_ids, want_scores = raglite_amd.reciprocal_rank_fusion([vs, [vs[3], "chunk0029", vs[0]]], weights=[0.75, 0.25])
+    assert calls == [6] and ids == want_ids[:3] and scores == want_scores[:3]
+    only_vs, _ = raglite_amd.hybrid_search(q, num_results=3, config=cfg, index=gi)
+    assert only_vs == vs[:3]

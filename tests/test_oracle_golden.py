@@ -149,3 +149,18 @@ def test_query_adapter_arithmetic_matches_reference_golden():
             np.testing.assert_allclose(A @ A.T, np.eye(len(A)), atol=1e-10)  # orthogonal Procrustes solution
     E, q = g["select_E"], g["select_q"]
     assert np.array_equal(E[[oracle.best_row(E, q)]], g["select_row"])
+
+
+def test_reciprocal_rank_fusion_matches_reference_golden():
+    """`_search.py:233-252` executed from its own source text (oracle/make_golden_adapter.py) vs the host mirror."""
+    import json
+    from pathlib import Path
+
+    import raglite_amd
+
+    g = np.load(Path(__file__).parent / "golden" / "query_adapter.npz")
+    for case in json.loads(str(g["rrf_json"])):
+        ids, scores = raglite_amd.reciprocal_rank_fusion(case["rankings"], k=case["k"], weights=case["weights"])
+        assert ids == case["ids"] and scores == case["scores"]  # same float operations in the same order
+    with pytest.raises(ValueError):
+        raglite_amd.reciprocal_rank_fusion([["a"]], weights=[1.0, 2.0])
