@@ -214,6 +214,18 @@ int rl_chunk_best_rows(rl_index* index, const float* queries, int32_t n_queries,
                        int32_t n_cand, int32_t* out_rows, int mem, void* stream);
 int rl_gather_rows(rl_index* index, const int32_t* rows, int64_t n, float* out, int mem, void* stream);
 
+/* ---- semantic-chunking similarities ---------------------------------------
+ * src/raglite/_split_chunks.py:54-72, the consumer of the pooled chunklet embeddings and the cost
+ * vector of the chunk-partition MILP (which stays on the host), batched over documents:
+ *   X            [n x dim] f32 chunklet embeddings of all documents, concatenated (nonzero rows)
+ *   doc_offsets  int64[n_docs + 1] CSR over those rows (same side as X); NULL = one document
+ *   nonoutlying  uint8[n], nonzero = chunklet size within the document's 15 %..85 % quantiles
+ *                (:57-58, computed on the host from string lengths); NULL = no discourse removal
+ *   out          f32[n]: out[i] = max((x_i . x_{i+1} + 1) / 2, sqrt(eps)) on the normalised,
+ *                discourse-free rows (:59-72); 0 for the last row of a document. */
+int rl_partition_similarity(const float* X, int64_t n, int32_t dim, const int64_t* doc_offsets, int64_t n_docs,
+                            const uint8_t* nonoutlying, float* out, int mem, void* stream);
+
 /* Timing hook for bench.py: run `fn`-independent -- records the elapsed milliseconds between two
  * events on `stream` bracketing `iters` back-to-back launches of the named kernel path with the
  * given index / query.  kind: 0 = rl_maxsim_scores kernel only, 1 = rl_search_rows scan kernel

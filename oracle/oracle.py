@@ -20,6 +20,9 @@ Parity pinning status
   Procrustes block, positive / negative row selection of `_query_adapter.py`): PINNED.
   `oracle/make_golden_adapter.py` executes the reference's own source lines (scipy + numpy are
   available) and `tests/golden/query_adapter.npz` holds their outputs.
+* semantic-chunking similarities and reciprocal rank fusion (section 8f-4): PINNED.  The REAL
+  `_split_chunks.split_chunks` runs in `oracle/make_golden_chunks.py` (cost vector captured at its
+  `linprog` call); `reciprocal_rank_fusion` is exec'd from its source text.
 * adapter application / distance / two-stage selection (rows a5-a8): PARITY UNPINNED.  The reference
   evaluates these inside DuckDB (`array_cosine_distance` + usearch HNSW, approximate) or
   pgvector; neither engine nor any golden vector is available.  The
@@ -411,6 +414,50 @@ def update_query_adapter(evals, E, chunk_offsets, chunk_ids, *, optimize_top_k=4
         raise ValueError("no eval retrieved both relevant and irrelevant chunks")
     Q, T = np.vstack(Qs).astype(np.float64), np.vstack(Ts).astype(np.float64)
     return query_adapter_from_targets(Q, T, metric), Q, T
+
+
+# ----------------------------------------------------------------------------------------
+# 8f-4: semantic-chunking similarities (`_split_chunks.py:54-86`) -- pinned by
+# tests/golden/split_chunks.npz (oracle/make_golden_chunks.py runs the reference's own function)
+# ----------------------------------------------------------------------------------------
+
+
+def nonoutlying_mask(chunklet_size: np.ndarray) -> np.ndarray:
+    """`_split_chunks.py:57-58`: chunklets whose size lies within the 15 %..85 % quantiles."""
+    q15, q85 = np.quantile(chunklet_size, [0.15, 0.85])
+    return (q15 <= chunklet_size) & (chunklet_size <= q85)
+
+
+def partition_similarity(chunklet_embeddings: np.ndarray, chunklet_size: np.ndarray) -> np.ndarray:
+    """`_split_chunks.py:54-72` in float32 like the reference: unit rows, discourse vector removed unless that
+    would zero a row, similarity of consecutive rows mapped to ((s + 1) / 2) and floored at sqrt(eps)."""
+    X = chunklet_embeddings.astype(np.float32)
+    X = X / np.linalg.norm(X, axis=1, keepdims=True)
+    sel = nonoutlying_mask(np.asarray(chunklet_size))
+    if np.any(sel):
+        discourse = np.mean(X[sel, :], axis=0)
+        discourse = discourse / np.linalg.norm(discourse)
+        X_mod = X - np.outer(X @ discourse, discourse)
+        if not np.any(np.linalg.norm(X_mod, axis=1) <= np.finfo(X.dtype).eps):
+            X = X_mod / np.linalg.norm(X_mod, axis=1, keepdims=True)
+    sim = np.sum(X[:-1] * X[1:], axis=1)
+    return np.maximum((sim + 1) / 2, np.sqrt(np.finfo(X.dtype).eps))
+
+
+def heading_adjusted(sim: np.ndarray, chunklets: list[str]) -> np.ndarray:
+    """`_split_chunks.py:73-86`: splitting before a Markdown heading is encouraged (/4), right after one forbidden (1.0)."""
+    import re
+
+    sim = np.array(sim, copy=True)
+    prev_is_heading = True
+    for i, c in enumerate(chunklets[:-1]):
+        is_heading = bool(re.match(r"^#+\s", c.replace("\n", "").strip()))
+        if is_heading:
+            if not prev_is_heading:
+                sim[i - 1] = sim[i - 1] / 4
+            sim[i] = 1.0
+        prev_is_heading = is_heading
+    return sim
 
 
 # ----------------------------------------------------------------------------------------

@@ -7,6 +7,7 @@ and a Python host layer that mirrors the reference's own entry points for this p
 GPU) the calls raise.
 """
 
+from raglite_amd._chunking import partition_cost, partition_similarities, split_chunks
 from raglite_amd._config import HotPathConfig
 from raglite_amd._embed import (
     embed_strings,
@@ -42,6 +43,9 @@ from raglite_amd._query_adapter import update_query_adapter
 from raglite_amd._sharded import ShardedIndex, merge_topk_host, shard_bounds_by_chunk
 
 __all__ = [
+    "partition_cost",
+    "partition_similarities",
+    "split_chunks",
     "hybrid_search",
     "reciprocal_rank_fusion",
     "update_query_adapter",

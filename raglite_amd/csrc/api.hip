@@ -880,6 +880,36 @@ int rl_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32
 }
 
 // ---- timing hook for bench.py ------------------------------------------------------------------------------
+int rl_partition_similarity(const float* X, int64_t n, int32_t dim, const int64_t* doc_offsets, int64_t n_docs,
+                            const uint8_t* nonoutlying, float* out, int mem, void* stream) {
+    if (n < 0 || dim <= 0) return fail(RL_ERR_INVALID, "rl_partition_similarity: bad shape");
+    if (n == 0) return RL_OK;
+    if (!X || !out) return fail(RL_ERR_INVALID, "rl_partition_similarity: null argument");
+    if (dim > 4096) return fail(RL_ERR_UNSUPPORTED, "rl_partition_similarity: dim must be <= 4096");
+    if (!doc_offsets) n_docs = 1;
+    if (n_docs < 1) return fail(RL_ERR_INVALID, "rl_partition_similarity: need at least one document");
+    hipStream_t s = as_stream(stream);
+    DevBuf t_x, t_off, t_sel, t_out, t_scr, t_one;
+    const float* d_x; const int64_t* d_off; const uint8_t* d_sel = nullptr; float* d_out;
+    RL_TRY(stage_in(X, (size_t)n * dim, mem, s, t_x, &d_x));
+    if (doc_offsets) {
+        RL_TRY(stage_in(doc_offsets, (size_t)n_docs + 1, mem, s, t_off, &d_off));
+    } else {
+        const int64_t one[2] = {0, n};
+        RL_TRY(t_one.alloc(sizeof(one)));
+        RL_HIP(hipMemcpyAsync(t_one.p, one, sizeof(one), hipMemcpyHostToDevice, s));
+        RL_HIP(hipStreamSynchronize(s));  // `one` lives on this stack frame
+        d_off = t_one.as<int64_t>();
+    }
+    if (nonoutlying) RL_TRY(stage_in(nonoutlying, (size_t)n, mem, s, t_sel, &d_sel));
+    RL_TRY(stage_out_begin(out, (size_t)n, mem, t_out, &d_out));
+    RL_TRY(t_scr.alloc(partition_sim_scratch_bytes(n, n_docs, dim)));
+    RL_TRY(launch_partition_similarity(d_x, n, dim, d_off, n_docs, d_sel, d_out, t_scr.p, s));
+    RL_TRY(stage_out_end(out, (size_t)n, mem, s, t_out));
+    RL_HIP(hipStreamSynchronize(s));  // the scratch dies with this frame
+    return RL_OK;
+}
+
 int rl_chunk_best_rows(rl_index* idx, const float* queries, int32_t B, const int32_t* candidates, int32_t n_cand,
                        int32_t* out_rows, int mem, void* stream) {
     if (!idx) return fail(RL_ERR_INVALID, "rl_chunk_best_rows: null index");

@@ -141,6 +141,11 @@ int launch_chunk_best_rows(const void* E, bool f16, int32_t dim, const float* Q,
 int launch_gather_rows(const void* E, bool f16, int32_t dim, int64_t n_rows, const int32_t* rows, int64_t n, float* out,
                        hipStream_t s);
 
+// partition_sim.hip: semantic-chunking similarities (src/raglite/_split_chunks.py:54-72), batched over documents
+size_t partition_sim_scratch_bytes(int64_t n, int64_t n_docs, int32_t dim);
+int launch_partition_similarity(const float* X, int64_t n, int32_t dim, const int64_t* doc_off, int64_t n_docs,
+                                const uint8_t* sel, float* out, void* scratch, hipStream_t s);
+
 // maxsim*.hip
 int launch_row_to_chunk(const int64_t* chunk_offsets, int64_t n_chunks, int64_t n_rows, int32_t* row_to_chunk,
                         hipStream_t s);

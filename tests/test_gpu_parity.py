@@ -900,3 +900,43 @@ def test_update_query_adapter_on_device(metric):
     got_ids, _ = raglite_amd.vector_search(evals[0][0], num_results=5, config=cfg, index=gi)  # adapter now applied
     assert len(got_ids) == 5
     gi.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# 8f-4: semantic-chunking similarities on the device
+# ---------------------------------------------------------------------------------------------------
+def test_split_chunks_matches_reference_golden(torch_cuda):
+    """`rl_partition_similarity` + host MILP vs the REAL reference `split_chunks` (tests/golden/split_chunks.npz):
+    same cost vector within fp32 tolerance, identical chunks; batched documents == one at a time; CUDA tensors too."""
+    from tests.test_oracle_golden import _split_cases
+
+    torch = torch_cuda
+    cases = _split_cases()
+    for chunklets, X, max_size, cost, sizes, chunks in cases:
+        got_chunks, got_embs = raglite_amd.split_chunks(chunklets, X, max_size=max_size)
+        assert got_chunks == chunks and [len(m) for m in got_embs] == sizes.tolist()
+        assert np.array_equal(np.vstack(got_embs), X)
+        if len(cost):
+            np.testing.assert_allclose(raglite_amd.partition_cost(chunklets, X), cost, rtol=0, atol=2e-6)
+            t_chunks, t_embs = raglite_amd.split_chunks(chunklets, torch.as_tensor(X, device="cuda"), max_size=max_size)
+            assert t_chunks == chunks and t_embs[0].is_cuda
+    # all documents of equal dim in one launch
+    same = [c for c in cases if c[1].shape[1] == 256 or c[1].shape[1] == 128]
+    for dim in (128, 256):
+        docs = [c for c in cases if c[1].shape[1] == dim]
+        if not docs:
+            continue
+        docs = docs * 3
+        Xall = np.vstack([c[1] for c in docs]).astype(np.float32)
+        off = np.concatenate(([0], np.cumsum([len(c[1]) for c in docs])))
+        lens = np.concatenate([[len(s) for s in c[0]] for c in docs])
+        sim = raglite_amd.partition_similarities(Xall, off, lens)
+        for d, c in enumerate(docs):
+            one = raglite_amd.partition_similarities(c[1].astype(np.float32), np.asarray([0, len(c[1])]), [len(s) for s in c[0]])
+            assert np.array_equal(sim[off[d] : off[d + 1]], one)
+            assert sim[off[d + 1] - 1] == 0.0
+    with pytest.raises(ValueError):
+        raglite_amd.split_chunks(["x" * 50, "y"], np.ones((2, 8), np.float16), max_size=10)
+    with pytest.raises(ValueError):
+        raglite_amd.split_chunks(["x" * 9, "y" * 9], np.zeros((2, 8), np.float16), max_size=10)
+    assert raglite_amd.split_chunks([], np.zeros((0, 8), np.float16))[0] == []

@@ -164,3 +164,42 @@ def test_reciprocal_rank_fusion_matches_reference_golden():
         assert ids == case["ids"] and scores == case["scores"]  # same float operations in the same order
     with pytest.raises(ValueError):
         raglite_amd.reciprocal_rank_fusion([["a"]], weights=[1.0, 2.0])
+
+
+# ---------------------------------------------------------------------------------------------------
+# 8f-4: semantic chunking, pinned against the reference's own split_chunks
+# ---------------------------------------------------------------------------------------------------
+def _split_cases():
+    import json
+    from pathlib import Path
+
+    g = np.load(Path(__file__).parent / "golden" / "split_chunks.npz")
+    meta = json.loads(str(g["meta_json"]))
+    return [(m["chunklets"], g[f"case{i}_X"], m["max_size"], g[f"case{i}_cost"], g[f"case{i}_sizes"], m["chunks"])
+            for i, m in enumerate(meta)]
+
+
+def test_partition_similarity_oracle_matches_reference_cost_vector():
+    """The MILP cost vector the REAL `split_chunks` handed to linprog (captured by oracle/make_golden_chunks.py)."""
+    for chunklets, X, _max_size, cost, sizes, _chunks in _split_cases():
+        if len(cost) == 0:  # single-chunk early exit: the reference never computes similarities
+            assert len(sizes) == 1
+            continue
+        lens = np.asarray([len(c) for c in chunklets])
+        got = oracle.heading_adjusted(oracle.partition_similarity(X, lens), chunklets)
+        assert got.dtype == np.float32
+        np.testing.assert_allclose(got, cost, rtol=0, atol=1e-6)
+
+
+def test_partition_milp_mirror_reproduces_reference_chunks():
+    """Host half of the mirror: given the reference's cost vector, the same partition comes out."""
+    from raglite_amd._chunking import _solve_partition
+
+    for chunklets, _X, max_size, cost, sizes, chunks in _split_cases():
+        if len(cost) == 0:
+            continue
+        lens = np.asarray([len(c) for c in chunklets])
+        cuts = _solve_partition(cost.astype(np.float32), lens, max_size)
+        bounds = [0, *cuts, len(chunklets)]
+        assert [j - i for i, j in zip(bounds[:-1], bounds[1:])] == sizes.tolist()
+        assert ["".join(chunklets[i:j]) for i, j in zip(bounds[:-1], bounds[1:])] == chunks
