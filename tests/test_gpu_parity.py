@@ -940,3 +940,39 @@ def test_split_chunks_matches_reference_golden(torch_cuda):
     with pytest.raises(ValueError):
         raglite_amd.split_chunks(["x" * 9, "y" * 9], np.zeros((2, 8), np.float16), max_size=10)
     assert raglite_amd.split_chunks([], np.zeros((0, 8), np.float16))[0] == []
+
+
+def test_end_to_end_indexing_pipeline_on_device(torch_cuda):
+    """sentences -> embed_strings (PyTorch-ROCm encoder + rl_pool_norm) -> split_chunks (rl_partition_similarity + host
+    MILP) -> GpuIndex.insert_chunks (rl_index_append) -> vector_search / MaxSim rerank: the reference's insert and
+    search flow (`_insert.py:96-123`, `_search.py`) with every embedding-sized array produced and consumed in HBM."""
+    from raglite_amd._torch_embedder import EncoderShape, TorchTokenEmbedder
+
+    shape = EncoderShape(vocab_size=30000, hidden=128, layers=2, heads=4, ffn=256, max_positions=600, n_ctx=512)
+    emb = TorchTokenEmbedder(shape, device="cuda", seed=9, n_batch=512)
+    cfg = raglite_amd.HotPathConfig(vector_search_query_adapter=False)
+    gi = None
+    all_chunks = []
+    for doc in range(3):
+        sents = make_sentences(500 + doc, 40)
+        X = raglite_amd.embed_strings(sents, config=cfg, embedder=emb)  # (40, 128) fp16, unit rows
+        chunks, chunk_embs = raglite_amd.split_chunks(sents, X, max_size=600)
+        assert "".join(chunks) == "".join(sents) and sum(len(m) for m in chunk_embs) == 40
+        assert all(len(c) <= 600 for c in chunks)
+        ids = [f"doc{doc}-chunk{i}" for i in range(len(chunks))]
+        if gi is None:
+            gi = raglite_amd.GpuIndex(ids, chunk_embs, docs=chunks, metadata=[{"doc": doc}] * len(chunks), storage="f16")
+        else:
+            gi.insert_chunks(ids, chunk_embs, docs=chunks, metadata=[{"doc": doc}] * len(chunks))
+        all_chunks += list(zip(ids, chunk_embs))
+    # every chunk is found by one of its own chunklet embeddings, with similarity ~1
+    for cid, m in all_chunks[::5]:
+        got, sc = raglite_amd.vector_search(np.asarray(m[0]), num_results=1, config=cfg, index=gi)
+        assert got == [cid] and abs(sc[0] - 1.0) < 2e-3
+    only1, _ = raglite_amd.vector_search(np.asarray(all_chunks[0][1][0]), num_results=50, metadata_filter={"doc": 1},
+                                         config=cfg, index=gi)
+    assert only1 and all(c.startswith("doc1-") for c in only1)
+    assert gi.delete_chunks([all_chunks[0][0]]) == 1
+    got, _ = raglite_amd.vector_search(np.asarray(all_chunks[0][1][0]), num_results=3, config=cfg, index=gi)
+    assert all_chunks[0][0] not in got
+    gi.close()
