@@ -976,3 +976,50 @@ def test_end_to_end_indexing_pipeline_on_device(torch_cuda):
     got, _ = raglite_amd.vector_search(np.asarray(all_chunks[0][1][0]), num_results=3, config=cfg, index=gi)
     assert all_chunks[0][0] not in got
     gi.close()
+
+
+# ---------------------------------------------------------------------------------------------------
+# hypothesis-generated ragged shapes (KAT class iv)
+# ---------------------------------------------------------------------------------------------------
+def test_fuzz_ragged_shapes_integer_exact():
+    """Random CSR layouts (empty chunks, single-row chunks, long chunks), row counts around the 16-row tile and the
+    workgroup-range boundaries, every dim class (stream fast path and generic fallback), 1..40 query vectors, both
+    storages: MaxSim scores, exact top-k and the two-stage search are bit-identical to the oracle on integer data."""
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    @given(
+        sizes=st.lists(st.one_of(st.just(0), st.integers(1, 3), st.integers(1, 40)), min_size=1, max_size=400),
+        dim=st.sampled_from([128, 256, 384, 512, 768, 1024, 64, 100]),
+        nq=st.integers(1, 40),
+        storage=st.sampled_from(["f32", "f16"]),
+        seed=st.integers(0, 10_000),
+    )
+    def run(sizes, dim, nq, storage, seed):
+        if storage == "f16" and dim not in (128, 256, 384, 512, 768, 1024):
+            storage = "f32"
+        off = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+        n = int(off[-1])
+        if n == 0:
+            return
+        E = oracle.synth_matrix(seed, n, dim, "small_int")
+        Q = oracle.synth_matrix(seed + 1, nq, dim, "small_int")
+        idx = raglite_amd.DeviceIndex(E, off, metric="dot", storage=storage)
+        try:
+            ref = oracle.maxsim_scores(E, off, Q).astype(np.float32)
+            assert np.array_equal(idx.maxsim_scores(Q), ref)
+            k = min(17, len(sizes))
+            s, c = idx.maxsim_topk(Q, k)
+            es, ec = oracle.topk_desc(ref, k)
+            es, ec = np.where(np.isneginf(es), es, es), ec
+            assert np.array_equal(s, es)
+            assert np.array_equal(c[np.isfinite(s)], ec[np.isfinite(es)])
+            r2c = np.repeat(np.arange(len(sizes)), sizes)
+            gs, gc, cnt = idx.search_chunks(Q[0], 20, 5)
+            ws, wc = oracle.search_chunks(E, r2c, Q[0], 20, 5, "dot", np.float32)
+            assert int(cnt) == len(wc) and np.array_equal(gc[: len(wc)], wc) and np.array_equal(gs[: len(wc)], ws)
+        finally:
+            idx.close()
+
+    run()
