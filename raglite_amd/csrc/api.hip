@@ -21,16 +21,57 @@ namespace {
 
 hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Device scratch that frees itself; used for RL_MEM_HOST staging and per-call temporaries.
+// Per-thread cache of small device blocks: RL_MEM_HOST calls stage a query in and a handful of results out, and a
+// hipMalloc + hipFree pair per staging buffer costs more than a 10 k-row search (measured: 121 us per host-argument
+// search_chunks against 39 us with device arguments).  Blocks up to 4 MiB are recycled, larger ones are not kept.
+struct BlockCache {
+    struct Block { void* p; size_t bytes; int device; };
+    std::vector<Block> free_blocks;
+    static constexpr size_t MAX_BLOCK = size_t(4) << 20;
+    static constexpr size_t MAX_BLOCKS = 32;
+    void* take(size_t bytes, int device, size_t* got) {
+        for (size_t i = 0; i < free_blocks.size(); ++i) {
+            Block b = free_blocks[i];
+            if (b.device == device && b.bytes >= bytes && b.bytes <= 4 * bytes + 4096) {
+                free_blocks.erase(free_blocks.begin() + (long)i);
+                *got = b.bytes;
+                return b.p;
+            }
+        }
+        return nullptr;
+    }
+    void give(void* p, size_t bytes, int device) {
+        if (bytes > MAX_BLOCK || free_blocks.size() >= MAX_BLOCKS) { (void)hipFree(p); return; }
+        free_blocks.push_back({p, bytes, device});
+    }
+    ~BlockCache() {
+        for (const Block& b : free_blocks) (void)hipFree(b.p);  // at thread exit; errors during runtime teardown are moot
+    }
+};
+thread_local BlockCache g_blocks;
+
+// Device scratch that returns itself to the thread's block cache; used for RL_MEM_HOST staging and per-call
+// temporaries.  Callers synchronise the stream before the buffer goes out of scope whenever the device may still
+// be using it (finish() for host calls), so a recycled block is never in flight.
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() {
-        if (p) (void)hipFree(p);
+    size_t bytes = 0;
+    int device = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) g_blocks.give(p, bytes, device);
+        p = nullptr;
     }
-    int alloc(size_t bytes) {
-        if (p) { (void)hipFree(p); p = nullptr; }
-        if (bytes == 0) bytes = 16;
-        RL_HIP(hipMalloc(&p, bytes));
+    int alloc(size_t want) {
+        release();
+        if (want == 0) want = 16;
+        RL_HIP(hipGetDevice(&device));
+        size_t got = 0;
+        p = g_blocks.take(want, device, &got);
+        if (p) { bytes = got; return RL_OK; }
+        const size_t rounded = (want + 255) & ~size_t(255);
+        RL_HIP(hipMalloc(&p, rounded));
+        bytes = rounded;
         return RL_OK;
     }
     template <class T>
