@@ -80,3 +80,11 @@ def test_no_oracle_import_in_product():
     root = Path(__file__).resolve().parent.parent / "raglite_amd"
     for path in root.rglob("*.py"):
         assert not re.search(r"^\s*(from|import)\s+oracle\b", path.read_text(), flags=re.M), path
+
+
+def test_graft_entry_build_runs():
+    """The driver's per-round build check: compiles (incrementally) every HIP source, binds the ABI and, where the
+    reference is mounted, regenerates every golden fixture from the reference's own code and checks nothing drifted."""
+    import __graft_entry__
+
+    __graft_entry__.build()
