@@ -110,11 +110,17 @@ def main() -> None:
     for i in range(args.warmup):
         step(i)
     fence()
+    # HIP events on the launch stream (torch's current stream IS the stream every kernel of a step is launched on)
+    # bracket the timed region as well: (event time) / (passes) cross-checks the per-launch figure of `roofline`.
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()
     for i in range(args.steps):
         last = step(i)
+    ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
+    region_ms_per_pass = ev0.elapsed_time(ev1) / (args.steps * QUERIES_PER_STEP)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -158,6 +164,8 @@ def main() -> None:
         "bound": "hbm", "kernel": "maxsim_stream_kernel<2,0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "kernel_ms": ms, "algorithmic_bytes_per_launch": algo_bytes,
+        # HIP events around the whole timed region / corpus passes in it: kernel + its share of selection and exchange
+        "timed_region_ms_per_pass": region_ms_per_pass,
         "mfma_fp32_tflops": 2.0 * NQ * (r_hi - r_lo) * DIM / (ms * 1e-3) / 1e12,
     }
 

@@ -174,6 +174,11 @@ class ShardedIndex:
     def search_rows(self, queries, k: int):
         """Global exact top-k rows: (scores (B,k), global row ordinals (B,k))."""
         s, r = self.local.search_rows(queries, k)
+        if hasattr(s, "is_cuda") and s.is_cuda:  # device-resident queries (cfg 5: B = 1000): merge on the device too
+            single = s.dim() == 1
+            ms, mi = self._exchange_merge_device(s.reshape(1, -1) if single else s, r.reshape(1, -1) if single else r,
+                                                 self.row_base, k)
+            return (ms[0], mi[0]) if single else (ms, mi)
         gs, gi, _, single = self._exchange(s, r, self.row_base)
         ms, mi = merge_topk_host(gs, gi, k)
         return (ms[0], mi[0]) if single else (ms, mi)
@@ -181,6 +186,9 @@ class ShardedIndex:
     def maxsim_topk(self, query_vecs, k: int):
         """Global exact top-k chunks by MaxSim: (scores (k,), global chunk ordinals (k,))."""
         s, c = self.local.maxsim_topk(query_vecs, k)
+        if hasattr(s, "is_cuda") and s.is_cuda:
+            ms, mi = self._exchange_merge_device(s.reshape(1, -1), c.reshape(1, -1), self.chunk_base, k)
+            return ms[0], mi[0]
         gs, gi, _, _ = self._exchange(s, c, self.chunk_base)
         ms, mi = merge_topk_host(gs, gi, k)
         return ms[0], mi[0]

@@ -61,6 +61,34 @@ def test_device_exchange_merge_two_shards(monkeypatch):
         assert s.is_cuda and c.is_cuda  # stayed on the device
         assert torch.equal(s, ref_s) and torch.equal(c.to(ref_c.dtype), ref_c)
     monkeypatch.undo()
+    # the batched row search (cfg 5's 8-GPU shape) takes the same device exchange
+    Qr = torch.empty((130, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Qr, seed=13)
+    full_c = raglite_amd.DeviceIndex(E, off, metric="cosine")
+    ref_rs, ref_rr = full_c.search_rows(Qr, k)
+    row_shards, packed_r = [], []
+    for c_lo, c_hi in bounds:
+        r_lo, r_hi = int(off[c_lo]), int(off[c_hi])
+        idx = raglite_amd.DeviceIndex(E[r_lo:r_hi], metric="cosine")
+        row_shards.append(ShardedIndex(idx, row_base=r_lo, chunk_base=c_lo))
+        s, r = idx.search_rows(Qr, k)
+        gid = torch.where(r >= 0, r + r_lo, torch.full_like(r, -1)).to(torch.int32)
+        packed_r.append(torch.stack([s.contiguous().view(torch.int32), gid], dim=-1).contiguous())
+
+    def fake_rows(out, inp, group=None):
+        out[0].copy_(packed_r[0])
+        out[1].copy_(packed_r[1])
+
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake_rows)
+    for sh in row_shards:
+        s, r = sh.search_rows(Qr, k)
+        assert s.is_cuda and torch.equal(s, ref_rs) and torch.equal(r.to(ref_rr.dtype), ref_rr)
+    monkeypatch.undo()
+    for sh in row_shards:
+        sh.local.close()
+    full_c.close()
     # world = 1: global ids only, still on the device
     one = ShardedIndex(full, row_base=0, chunk_base=7, local_chunk_offsets=off)
     s, c = one.maxsim_topk_batch(Q, k)
