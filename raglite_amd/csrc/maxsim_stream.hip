@@ -51,7 +51,6 @@
 namespace rl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef int32_t i32x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
@@ -398,7 +397,6 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
     const int ew = wv - 6;
     const int qc = lane & (NQC - 1);
     const bool col_on = qc < nq;
-    const bool store_lane = lane == 16 * (NQT - 1);
     auto dpp_add = [](float x, auto CTRL) {
         return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(CTRL)::value, 0xf, 0xf, false));
     };
