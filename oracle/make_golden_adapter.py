@@ -107,6 +107,38 @@ def main() -> None:
         ids, sc = ns2["reciprocal_rank_fusion"](rankings, k=kk, weights=weights)
         rrf_out.append({"rankings": rankings, "weights": weights, "k": kk, "ids": ids, "scores": sc})
     out["rrf_json"] = np.asarray(_json.dumps(rrf_out))
+    # ---- a5 + the num_hits rule, straight from vector_search's body (`src/raglite/_search.py:57-67`) ----------------
+    slines = stext.splitlines()
+    a5_a = next(i for i, ln in enumerate(slines) if "# Apply the query adapter to the query embedding." in ln)
+    a5_b = next(i for i, ln in enumerate(slines) if "# Rank the chunks by relevance according to the L" in ln)
+    a5_src = textwrap.dedent("\n".join(slines[a5_a:a5_b]))
+    nh_a = next(i for i, ln in enumerate(slines) if "corrected_oversample = oversample * config.chunk_max_size" in ln)
+    nh_src = textwrap.dedent("\n".join(slines[nh_a : nh_a + 2]))
+    n_a5 = 0
+    for d, dtype in [(16, np.float16), (64, np.float16), (256, np.float16), (32, np.float32)]:
+        A = np.linalg.qr(rng.standard_normal((d, d)))[0]  # an orthogonal adapter, fp64 as stored (`_query_adapter.py:203-205`)
+        q = rng.standard_normal(d)
+        q = (q / np.linalg.norm(q)).astype(dtype)
+
+        class _IndexMetadata:
+            @staticmethod
+            def get(id_="default", *, config=None):  # noqa: ANN001,ANN205
+                return {"query_adapter": A}
+
+        env = {"np": np, "IndexMetadata": _IndexMetadata, "query_embedding": q.copy(),
+               "config": types.SimpleNamespace(vector_search_query_adapter=True)}
+        exec(compile(a5_src, "_search.py", "exec"), env)  # noqa: S102
+        out[f"a5_{n_a5}_A"], out[f"a5_{n_a5}_q"], out[f"a5_{n_a5}_out"] = A, q, env["query_embedding"]
+        n_a5 += 1
+    out["n_a5_cases"] = np.int64(n_a5)
+    nh = []
+    for oversample, chunk_max_size, num_results in [(4, 2048, 3), (4, 2048, 40), (4, 1024, 8), (2, 2048, 10), (4, 4096, 5), (3, 1536, 7)]:
+        env = {"oversample": oversample, "num_results": num_results,
+               "config": types.SimpleNamespace(chunk_max_size=chunk_max_size),
+               "RAGLiteConfig": types.SimpleNamespace(chunk_max_size=2048)}  # the class default, `_config.py`
+        exec(compile(nh_src, "_search.py", "exec"), env)  # noqa: S102
+        nh.append([oversample, chunk_max_size, num_results, int(env["num_hits"])])
+    out["num_hits_cases"] = np.asarray(nh, dtype=np.int64)
     np.savez(OUT, **out)
     print(f"wrote {OUT} ({n_t} target cases, {n_a} adapter cases)")
 

@@ -1023,3 +1023,21 @@ def test_fuzz_ragged_shapes_integer_exact():
             idx.close()
 
     run()
+
+
+def test_adapter_apply_against_reference_lines():
+    """a5 pinned: `(Q @ q).astype(q.dtype)` exec'd from vector_search's body (tests/golden/query_adapter.npz).  The
+    device multiplies in fp32 (the reference in fp64): after the cast back to the query's fp16 the results agree to
+    within one fp16 ulp, and exactly in the overwhelming majority of elements."""
+    from pathlib import Path
+
+    g = np.load(Path(__file__).parent / "golden" / "query_adapter.npz")
+    for i in range(int(g["n_a5_cases"])):
+        A, q, want = g[f"a5_{i}_A"], g[f"a5_{i}_q"], g[f"a5_{i}_out"]
+        if want.dtype == np.float16:
+            got = raglite_amd.adapter_apply(A.astype(np.float32), q.astype(np.float32), want_f16=True)
+            ulps = np.abs(got.view(np.int16).astype(np.int32) - want.view(np.int16).astype(np.int32))
+            assert ulps.max() <= 1 and (ulps == 0).mean() > 0.97
+        else:
+            got = raglite_amd.adapter_apply(A.astype(np.float32), q.astype(np.float32))
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)

@@ -203,3 +203,19 @@ def test_partition_milp_mirror_reproduces_reference_chunks():
         bounds = [0, *cuts, len(chunklets)]
         assert [j - i for i, j in zip(bounds[:-1], bounds[1:])] == sizes.tolist()
         assert ["".join(chunklets[i:j]) for i, j in zip(bounds[:-1], bounds[1:])] == chunks
+
+
+def test_adapter_application_and_num_hits_match_reference_lines():
+    """a5 (`_search.py:57-62`) and the num_hits rule (`:66-67`), exec'd from vector_search's own body: the oracle and
+    the host mirror's arithmetic reproduce them exactly."""
+    from pathlib import Path
+
+    from raglite_amd import _search
+
+    g = np.load(Path(__file__).parent / "golden" / "query_adapter.npz")
+    for i in range(int(g["n_a5_cases"])):
+        A, q, want = g[f"a5_{i}_A"], g[f"a5_{i}_q"], g[f"a5_{i}_out"]
+        got = oracle.adapter_apply(A, q)
+        assert got.dtype == want.dtype and np.array_equal(got, want)
+    for oversample, chunk_max_size, num_results, want in g["num_hits_cases"].tolist():
+        assert oracle.num_hits(num_results, oversample, chunk_max_size) == want
