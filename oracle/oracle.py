@@ -23,7 +23,9 @@ Parity pinning status
 * semantic-chunking similarities and reciprocal rank fusion (section 8f-4): PINNED.  The REAL
   `_split_chunks.split_chunks` runs in `oracle/make_golden_chunks.py` (cost vector captured at its
   `linprog` call); `reciprocal_rank_fusion` is exec'd from its source text.
-* adapter application / distance / two-stage selection (rows a5-a8): PARITY UNPINNED.  The reference
+* adapter application (a5, `_search.py:57-62`) and the num_hits rule (`:66-67`): PINNED -- the statements
+  are exec'd from vector_search's body by `oracle/make_golden_adapter.py`.
+* distance / two-stage selection (rows a6-a8): PARITY UNPINNED.  The reference
   evaluates these inside DuckDB (`array_cosine_distance` + usearch HNSW, approximate) or
   pgvector; neither engine nor any golden vector is available.  The
   restatement follows the SQL the reference emits (`_search.py:66-79,143-149`) with exact
