@@ -24,8 +24,9 @@
 //      waves 4-5  LOAD: stream D HBM -> LDS with `global_load_lds_dwordx4 ... nt` (no VGPR round trip; one instruction
 //                 = 1 KiB of a row) into two row-major 16-row stages, 1.75 tiles ahead.  Hand-issued: 1.5 instructions
 //                 per DMA (the compiler's 6 per DMA made the loaders the bottleneck at ~5.8 k cycles per tile).  Rows
-//                 sit at a (row + 16 B) pitch so the A-operand read (16 lanes = 16 rows, same column) hits 16
-//                 different 16-B bank groups.  Loader 0 also brings the tile's chunk ordinals into a small LDS ring.
+//                 sit at a (row + 32 B) pitch: ds_read_b128 serves 8 rows x 2 k-groups per cycle, which this pitch
+//                 spreads over all 64 banks (measured 236 B/clk/CU; +16 B gives 128, scripts/micro/lds_b128.hip).
+//                 Loader 0 also brings the tile's chunk ordinals into a small LDS ring.
 //                 In the B1..B2 window (below) the loaders do the K-reduction of the previous tile's partials.
 //      wave 6     EPILOGUE: segmented running max over the tile's rows (one v_max per row, wave-uniform branch at
 //                 chunk ends), DPP-butterfly sum over the query columns per finished chunk, one store per tile.  The
@@ -63,8 +64,9 @@ struct Geo {
     static constexpr int ELT = F16 ? 2 : 4;                // corpus element: fp32, or fp16 storage
     static constexpr int QBYTES = KW * ELT;                // one K quarter of a row (what one compute wave consumes)
     static constexpr int ROWB = DIM * ELT;                 // one corpus row
-    static constexpr int PITCH = ROWB + 16;                // +16 B: row stride = 4 banks (mod 64) -> the 16 rows of one
-                                                           // ds_read_b128 pass hit 16 different 16-B bank groups
+    static constexpr int PITCH = ROWB + 32;                // +32 B, MEASURED (scripts/micro/lds_b128.hip): ds_read_b128 serves 8 rows x
+                                                           // 2 k-groups per cycle, so the row stride must be 8 banks (mod 64):
+                                                           // +32 B -> 236 B/clk/CU, +16 B -> 128 (2-way conflicts), +0 -> 32
     static constexpr int STAGE = TR * PITCH;               // one tile, row-major: [16 rows][DIM fp32 + pad]
     static constexpr int NCH = (ROWB + 1023) / 1024;       // 1-KiB DMA instructions per row (the last may be half)
     static constexpr int KSTEPS = F16 ? KW / 32 : KW / 16; // ds_read_b128 per lane per tile: 4 fp32 k-steps of 4, or one
