@@ -47,6 +47,41 @@ __global__ __launch_bounds__(256) void chunk_best_rows_kernel(const ET* __restri
     }
 }
 
+// Exact l2 similarity 1 - sqrt(sum (e - q)^2) of every selected (query, row) pair, and the pair's position after a
+// re-sort by it.  The batched paths rank by |e|^2 + |q|^2 - 2 e.q, which is accurate except for near-duplicates
+// (distance below ~1e-3, where the expansion cancels); those are exactly the hits whose reported similarity matters.
+template <typename ET>
+__global__ __launch_bounds__(256) void rescore_l2_kernel(const ET* __restrict__ E, int dim, const float* __restrict__ Q,
+                                                          const int32_t* __restrict__ rows,
+                                                          const float* __restrict__ ranked, int k, int64_t n_items,
+                                                          float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    for (int64_t item = wave0; item < n_items; item += n_waves) {
+        int32_t r = rows[item];
+        if (ranked[item] == -INFINITY) r = -1;  // padding, or a row masked out by a filter / tombstone: stays "no hit"
+        float s = 0.f;
+        if (r >= 0) {
+            const float* q = Q + (item / k) * (int64_t)dim;
+            const ET* row = E + (int64_t)r * dim;
+            for (int c = lane; c < dim; c += 64) { const float t = elt<ET>(row + c) - q[c]; s = fmaf(t, t, s); }
+            s = wave_sum(s);
+        }
+        if (lane == 0) out[item] = r >= 0 ? 1.0f - sqrtf(s) : -INFINITY;
+    }
+}
+
+// rows_out[b][j] = rows_in[b][pos[b][j]]
+__global__ __launch_bounds__(256) void permute_rows_kernel(const int32_t* __restrict__ rows_in,
+                                                            const int32_t* __restrict__ pos, int k, int64_t n_items,
+                                                            int32_t* __restrict__ rows_out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_items) return;
+    const int32_t p = pos[i];
+    rows_out[i] = p >= 0 ? rows_in[(i / k) * k + p] : -1;
+}
+
 template <typename ET>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const ET* __restrict__ E, int dim, int64_t n_rows,
                                                            const int32_t* __restrict__ rows, int64_t n,
@@ -73,6 +108,29 @@ int launch_chunk_best_rows(const void* E, bool f16, int32_t dim, const float* Q,
     else
         hipLaunchKernelGGL((chunk_best_rows_kernel<float>), dim3(blocks), dim3(256), 0, s, static_cast<const float*>(E),
                            (int)dim, Q, offsets, n_chunks, cand, (int)n_cand, n_items, out_rows);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+int launch_rescore_l2(const void* E, bool f16, int32_t dim, const float* Q, const int32_t* rows, const float* ranked,
+                      int32_t k, int64_t n_items, float* out, hipStream_t s) {
+    if (n_items <= 0) return RL_OK;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_items + 3) / 4, 256 * 16));
+    if (f16)
+        hipLaunchKernelGGL((rescore_l2_kernel<uint16_t>), dim3(blocks), dim3(256), 0, s, static_cast<const uint16_t*>(E),
+                           (int)dim, Q, rows, ranked, (int)k, n_items, out);
+    else
+        hipLaunchKernelGGL((rescore_l2_kernel<float>), dim3(blocks), dim3(256), 0, s, static_cast<const float*>(E),
+                           (int)dim, Q, rows, ranked, (int)k, n_items, out);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+int launch_permute_rows(const int32_t* rows_in, const int32_t* pos, int32_t k, int64_t n_items, int32_t* rows_out,
+                        hipStream_t s) {
+    if (n_items <= 0) return RL_OK;
+    hipLaunchKernelGGL(permute_rows_kernel, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, rows_in, pos, (int)k,
+                       n_items, rows_out);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -590,8 +590,13 @@ namespace {
 int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStream_t s) {
     const int mode = scan_mode(idx->metric);
     float* sc = idx->scores.as<float>();
-    if (idx->E16) {  // fp16 storage: VALU scan up to 4 queries, else f16-MFMA stream passes of 32 (half the bytes each)
-        if (nb <= 4) return launch_scan_rows16(idx->E16, idx->n_rows, idx->dim, d_q, nb, idx->norm, mode, sc, ld, s);
+    if (idx->E16) {  // fp16 storage: f16-MFMA stream passes of up to 32 queries, whatever the batch size: the VALU scan
+        // (scan16.hip) was measured at 0.37 ms per 1 M x 1024 pass against 0.31 ms for one stream pass + transform -- with
+        // half the bytes per row the LDS-DMA stream is the faster reader even for a single query.  Exception: l2 with up
+        // to 4 queries keeps the scan, which sums (e - q)^2 directly; the stream path's |e|^2 + |q|^2 - 2 e.q loses a
+        // near-duplicate's small distance to cancellation (the reference's nearest neighbour IS often a near-duplicate).
+        if (nb <= 4 && mode == SCAN_L2)
+            return launch_scan_rows16(idx->E16, idx->n_rows, idx->dim, d_q, nb, idx->norm, mode, sc, ld, s);
         for (int32_t b0 = 0; b0 < nb; b0 += 32) {
             const int32_t nq = std::min<int32_t>(32, nb - b0);
             RL_TRY(launch_maxsim_stream16(idx->E16, idx->n_rows, idx->dim, d_q + (int64_t)b0 * idx->dim, nq,
@@ -648,8 +653,23 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
         const int32_t nb = std::min<int32_t>(batch, B - b0);
         RL_TRY(score_rows(idx, d_q + (int64_t)b0 * idx->dim, nb, ld, s));
         if (d_row_bits) RL_TRY(launch_mask_scores(idx->scores.as<float>(), nb, n, ld, d_row_bits, s));
-        RL_TRY(launch_topk(idx->scores.as<float>(), nb, n, ld, k, idx->ws, d_scores + (int64_t)b0 * k,
-                           d_rows + (int64_t)b0 * k, s));
+        float* o_s = d_scores + (int64_t)b0 * k;
+        int32_t* o_r = d_rows + (int64_t)b0 * k;
+        RL_TRY(launch_topk(idx->scores.as<float>(), nb, n, ld, k, idx->ws, o_s, o_r, s));
+        if (idx->metric == RL_L2 && (nb > 4)) {
+            // The batched paths rank by |e|^2 + |q|^2 - 2 e.q; re-score the k hits of every query with the exact
+            // sum (e - q)^2 and re-sort them (near-duplicates would otherwise report a cancelled distance).
+            const int64_t items = (int64_t)nb * k;
+            RL_TRY(idx->misc.reserve((size_t)items * (sizeof(float) + 2 * sizeof(int32_t))));
+            float* re = idx->misc.as<float>();
+            int32_t* pos = reinterpret_cast<int32_t*>(re + items);
+            int32_t* tmp_rows = pos + items;
+            RL_TRY(launch_rescore_l2(idx->E16 ? (const void*)idx->E16 : (const void*)idx->E, idx->E16 != nullptr, idx->dim,
+                                     d_q + (int64_t)b0 * idx->dim, o_r, o_s, k, items, re, s));
+            RL_HIP(hipMemcpyAsync(tmp_rows, o_r, (size_t)items * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+            RL_TRY(launch_topk(re, nb, k, k, k, idx->ws, o_s, pos, s));
+            RL_TRY(launch_permute_rows(tmp_rows, pos, k, items, o_r, s));
+        }
     }
     if (d_row_bits) RL_TRY(launch_fix_masked(d_scores, d_rows, (int64_t)B * k, s));  // masked rows are "no hit"
     return RL_OK;

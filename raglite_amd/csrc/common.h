@@ -138,6 +138,10 @@ int launch_popcount(const uint32_t* bits, int64_t n, unsigned long long* out_dev
 int launch_chunk_best_rows(const void* E, bool f16, int32_t dim, const float* Q, const int64_t* offsets,
                            int64_t n_chunks, const int32_t* cand, int32_t n_cand, int64_t n_items, int32_t* out_rows,
                            hipStream_t s);
+int launch_rescore_l2(const void* E, bool f16, int32_t dim, const float* Q, const int32_t* rows, const float* ranked,
+                      int32_t k, int64_t n_items, float* out, hipStream_t s);
+int launch_permute_rows(const int32_t* rows_in, const int32_t* pos, int32_t k, int64_t n_items, int32_t* rows_out,
+                        hipStream_t s);
 int launch_gather_rows(const void* E, bool f16, int32_t dim, int64_t n_rows, const int32_t* rows, int64_t n, float* out,
                        hipStream_t s);
 

@@ -1041,3 +1041,28 @@ def test_adapter_apply_against_reference_lines():
         else:
             got = raglite_amd.adapter_apply(A.astype(np.float32), q.astype(np.float32))
             np.testing.assert_allclose(got, want, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("B", [7, 40, 130])
+def test_l2_batched_near_duplicates_are_rescored(storage, B):
+    """The batched paths rank l2 by |e|^2 + |q|^2 - 2 e.q, which cancels for near-duplicates of large norm; the k hits
+    are re-scored with the exact sum (e - q)^2, so even a query that IS a stored row (plus fp16 rounding noise) reports
+    its true similarity within 1e-4 -- for every batch class, also under a filter."""
+    n, dim = 3000, 1024
+    E = (3.0 * oracle.synth_matrix(121, n, dim)).astype(np.float16).astype(np.float32)  # |e|^2 ~ 3000: worst case
+    rng = np.random.default_rng(16)
+    picks = rng.choice(n, B, replace=False)
+    Q = E[picks] + (1e-3 * oracle.synth_matrix(122, B, dim)).astype(np.float32)  # near-duplicates, true distance ~0.02
+    idx = raglite_amd.DeviceIndex(E, metric="l2", storage=storage)
+    S, R = idx.search_rows(Q, 20)
+    for b in (0, B // 2, B - 1):
+        ref = oracle.similarity(E, Q[b], "l2")
+        assert R[b, 0] == picks[b]
+        assert_topk_close(S[b], R[b], ref, 20, TOL)
+    flt = np.ones(n, bool)
+    flt[picks[0]] = False  # one row per chunk: the best hit of query 0 is filtered away
+    S2, R2 = idx.search_rows(Q, 20, chunk_filter=flt)
+    assert picks[0] not in R2[0]
+    assert_topk_close(S2[0], R2[0], np.where(flt, oracle.similarity(E, Q[0], "l2"), -np.inf), 20, TOL)
+    idx.close()
