@@ -614,8 +614,10 @@ int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStrea
     // Small batches too: one LDS-DMA stream pass (16-query variant: half the MFMAs) + the 4-MB transform reads the
     // corpus at 6.9 TB/s, the VALU scan's global loads at 6.4 (measured, 1 M x 1024: 0.594 vs 0.639 ms).  l2 keeps the
     // scan, which sums (e - q)^2 directly.  launch_maxsim_stream reports RL_ERR_UNSUPPORTED for dims outside its fast
-    // path; those fall through to the scan as well.
-    if (nb > 4 || mode != SCAN_L2) {
+    // path; those fall through to the scan as well.  Below ~256 MB of corpus the scan's lower fixed cost wins
+    // (10 k rows: 28 vs 44 us per query).
+    const bool big = (int64_t)idx->n_rows * idx->dim >= (int64_t(64) << 20);
+    if (nb > 4 || (mode != SCAN_L2 && big)) {
         // MFMA tile kernel, 32 queries per corpus pass, raw dots; then the metric transform.
         bool ok = true;
         for (int32_t b0 = 0; b0 < nb && ok; b0 += 32) {
