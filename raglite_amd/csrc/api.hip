@@ -501,41 +501,52 @@ int rl_index_append(rl_index* idx, const float* rows, int64_t n_new_rows, const 
     const bool f16 = idx->E16 != nullptr;
     const size_t row_bytes = (size_t)idx->dim * (f16 ? sizeof(uint16_t) : sizeof(float));
     const void* old_rows = f16 ? (const void*)idx->E16 : (const void*)idx->E;
-    // ---- storage: own it, grow geometrically -----------------------------------------------------------
-    if (!idx->owns_E || new_n > idx->cap_rows) {
-        const int64_t cap = std::max<int64_t>(new_n, idx->cap_rows + idx->cap_rows / 2);  // geometric growth
+    // ---- storage: own it, grow geometrically.  All-or-nothing: every new buffer is allocated (and filled) before the
+    // index is touched, so a failed allocation leaves the index exactly as it was. -----------------------------------
+    if (!idx->owns_E || new_n > idx->cap_rows || new_c > idx->cap_chunks) {
+        const bool grow_rows = !idx->owns_E || new_n > idx->cap_rows;
+        const bool grow_chunks = new_c > idx->cap_chunks;
+        const int64_t cap = grow_rows ? std::max<int64_t>(new_n, idx->cap_rows + idx->cap_rows / 2) : idx->cap_rows;
+        const int64_t ccap = grow_chunks ? std::max<int64_t>(new_c, idx->cap_chunks + idx->cap_chunks / 2) : idx->cap_chunks;
         void* e = nullptr;
-        RL_HIP(hipMalloc(&e, std::max<size_t>((size_t)cap * row_bytes, 16)));
-        if (old_n) RL_HIP(hipMemcpyAsync(e, old_rows, (size_t)old_n * row_bytes, hipMemcpyDeviceToDevice, s));
-        auto regrow = [&](float*& p) -> int {
-            if (!p) return RL_OK;
-            float* q = nullptr;
-            RL_HIP(hipMalloc(&q, std::max<size_t>((size_t)cap * sizeof(float), 16)));
-            if (old_n) RL_HIP(hipMemcpyAsync(q, p, (size_t)old_n * sizeof(float), hipMemcpyDeviceToDevice, s));
-            RL_HIP(hipStreamSynchronize(s));
-            (void)hipFree(p);
-            p = q;
-            return RL_OK;
-        };
-        RL_TRY(regrow(idx->norm));
-        RL_TRY(regrow(idx->sumsq));
+        float *nn = nullptr, *ns = nullptr;
         int32_t* r2c = nullptr;
-        RL_HIP(hipMalloc(&r2c, (size_t)(cap + 65) * sizeof(int32_t)));
-        RL_HIP(hipStreamSynchronize(s));
-        if (idx->owns_E && old_rows) (void)hipFree(const_cast<void*>(old_rows));
-        (void)hipFree(idx->row_to_chunk);
-        if (f16) idx->E16 = static_cast<const uint16_t*>(e); else idx->E = static_cast<const float*>(e);
-        idx->owns_E = true;
-        idx->row_to_chunk = r2c;
-        idx->cap_rows = cap;
-    }
-    if (new_c > idx->cap_chunks) {
-        const int64_t cap = std::max<int64_t>(new_c, idx->cap_chunks + idx->cap_chunks / 2);
         int64_t* o = nullptr;
-        RL_HIP(hipMalloc(&o, (size_t)(cap + 1) * sizeof(int64_t)));
-        (void)hipFree(idx->offsets);
-        idx->offsets = o;
-        idx->cap_chunks = cap;
+        auto undo = [&](int code) {
+            for (void* p : {e, (void*)nn, (void*)ns, (void*)r2c, (void*)o}) if (p) (void)hipFree(p);
+            return code;
+        };
+#define RL_GROW(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return undo(fail(_e == hipErrorOutOfMemory ? RL_ERR_NOMEM : RL_ERR_HIP, std::string("rl_index_append: ") + hipGetErrorString(_e))); } while (0)
+        if (grow_rows) {
+            RL_GROW(hipMalloc(&e, std::max<size_t>((size_t)cap * row_bytes, 16)));
+            if (idx->norm) RL_GROW(hipMalloc(&nn, std::max<size_t>((size_t)cap * sizeof(float), 16)));
+            if (idx->sumsq) RL_GROW(hipMalloc(&ns, std::max<size_t>((size_t)cap * sizeof(float), 16)));
+            RL_GROW(hipMalloc(&r2c, (size_t)(cap + 65) * sizeof(int32_t)));
+        }
+        if (grow_chunks) RL_GROW(hipMalloc(&o, (size_t)(ccap + 1) * sizeof(int64_t)));
+        if (grow_rows && old_n) {
+            RL_GROW(hipMemcpyAsync(e, old_rows, (size_t)old_n * row_bytes, hipMemcpyDeviceToDevice, s));
+            if (nn) RL_GROW(hipMemcpyAsync(nn, idx->norm, (size_t)old_n * sizeof(float), hipMemcpyDeviceToDevice, s));
+            if (ns) RL_GROW(hipMemcpyAsync(ns, idx->sumsq, (size_t)old_n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        }
+        RL_GROW(hipStreamSynchronize(s));
+#undef RL_GROW
+        // commit
+        if (grow_rows) {
+            if (idx->owns_E && old_rows) (void)hipFree(const_cast<void*>(old_rows));
+            if (idx->norm) { (void)hipFree(idx->norm); idx->norm = nn; }
+            if (idx->sumsq) { (void)hipFree(idx->sumsq); idx->sumsq = ns; }
+            (void)hipFree(idx->row_to_chunk);
+            if (f16) idx->E16 = static_cast<const uint16_t*>(e); else idx->E = static_cast<const float*>(e);
+            idx->owns_E = true;
+            idx->row_to_chunk = r2c;
+            idx->cap_rows = cap;
+        }
+        if (grow_chunks) {
+            (void)hipFree(idx->offsets);
+            idx->offsets = o;
+            idx->cap_chunks = ccap;
+        }
     }
     // ---- new rows, CSR, ordinals, norms ------------------------------------------------------------------
     DevBuf t_rows;
