@@ -50,6 +50,42 @@ struct BlockCache {
 };
 thread_local BlockCache g_blocks;
 
+// Per-thread pinned bounce buffer for the small host <-> device copies of RL_MEM_HOST calls (a query in, k results
+// out).  A hipMemcpyAsync from / to pageable memory is synchronous and goes through the driver's own staging; through
+// pinned memory the copies are truly asynchronous and the call needs ONE synchronisation: results are copied out of
+// the pinned buffer after it (drain()).  Entries are keyed by the DevBuf they belong to, so that an early error
+// return, which destroys its DevBufs without draining, can never copy stale data into a caller's buffer later.
+struct PinnedBounce {
+    static constexpr size_t CAP = size_t(1) << 20, SMALL = size_t(256) << 10;
+    char* base = nullptr;
+    size_t used = 0;
+    struct Pending { const void* owner; const void* src; void* dst; size_t bytes; };
+    std::vector<Pending> pending;
+    void* take(size_t bytes) {
+        if (bytes == 0 || bytes > SMALL) return nullptr;
+        if (!base && hipHostMalloc(reinterpret_cast<void**>(&base), CAP, hipHostMallocDefault) != hipSuccess) {
+            base = nullptr;
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        const size_t at = (used + 63) & ~size_t(63);
+        if (at + bytes > CAP) return nullptr;
+        used = at + bytes;
+        return base + at;
+    }
+    void drain() {  // after the stream has been synchronised
+        for (const Pending& p : pending) std::memcpy(p.dst, p.src, p.bytes);
+        pending.clear();
+        used = 0;
+    }
+    void drop(const void* owner) {
+        for (size_t i = pending.size(); i-- > 0;)
+            if (pending[i].owner == owner) pending.erase(pending.begin() + (long)i);
+    }
+    ~PinnedBounce() { if (base) (void)hipHostFree(base); }
+};
+thread_local PinnedBounce g_pinned;
+
 // Device scratch that returns itself to the thread's block cache; used for RL_MEM_HOST staging and per-call
 // temporaries.  Callers synchronise the stream before the buffer goes out of scope whenever the device may still
 // be using it (finish() for host calls), so a recycled block is never in flight.
@@ -59,6 +95,7 @@ struct DevBuf {
     int device = 0;
     ~DevBuf() { release(); }
     void release() {
+        g_pinned.drop(this);
         if (p) g_blocks.give(p, bytes, device);
         p = nullptr;
     }
@@ -103,7 +140,14 @@ template <class T>
 int stage_in(const T* src, size_t count, int mem, hipStream_t s, DevBuf& tmp, const T** out) {
     if (mem == RL_MEM_DEVICE) { *out = src; return RL_OK; }
     RL_TRY(tmp.alloc(count * sizeof(T)));
-    if (count) RL_HIP(hipMemcpyAsync(tmp.p, src, count * sizeof(T), hipMemcpyHostToDevice, s));
+    if (count) {
+        const void* from = src;
+        if (void* pin = g_pinned.take(count * sizeof(T))) {
+            std::memcpy(pin, src, count * sizeof(T));
+            from = pin;
+        }
+        RL_HIP(hipMemcpyAsync(tmp.p, from, count * sizeof(T), hipMemcpyHostToDevice, s));
+    }
     *out = tmp.as<T>();
     return RL_OK;
 }
@@ -118,11 +162,22 @@ int stage_out_begin(T* dst, size_t count, int mem, DevBuf& tmp, T** out) {
 template <class T>
 int stage_out_end(T* dst, size_t count, int mem, hipStream_t s, const DevBuf& tmp) {
     if (mem == RL_MEM_DEVICE || dst == nullptr || count == 0) return RL_OK;
+    if (void* pin = g_pinned.take(count * sizeof(T))) {
+        RL_HIP(hipMemcpyAsync(pin, tmp.p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+        g_pinned.pending.push_back({&tmp, pin, dst, count * sizeof(T)});
+        return RL_OK;
+    }
     RL_HIP(hipMemcpyAsync(dst, tmp.p, count * sizeof(T), hipMemcpyDeviceToHost, s));
     return RL_OK;
 }
+// Synchronise and hand the bounced results to the caller's buffers.
+int sync_and_drain(hipStream_t s) {
+    RL_HIP(hipStreamSynchronize(s));
+    g_pinned.drain();
+    return RL_OK;
+}
 int finish(int mem, hipStream_t s) {
-    if (mem == RL_MEM_HOST) RL_HIP(hipStreamSynchronize(s));
+    if (mem == RL_MEM_HOST) return sync_and_drain(s);
     return RL_OK;
 }
 
@@ -581,8 +636,7 @@ int rl_index_append(rl_index* idx, const float* rows, int64_t n_new_rows, const 
         for (int64_t c = old_c; c < new_c; ++c) idx->h_live[(size_t)(c >> 5)] |= 1u << (c & 31);
         RL_TRY(upload_live_bits(idx, s));
     }
-    RL_HIP(hipStreamSynchronize(s));  // the caller's buffers may go away after return
-    return RL_OK;
+    return sync_and_drain(s);  // the caller's buffers may go away after return
 }
 
 int rl_index_info(const rl_index* idx, int64_t* n_rows, int32_t* dim, int64_t* n_chunks, int* metric) {
@@ -952,9 +1006,9 @@ int rl_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32
     int st = launch_topk(d_in, n_queries, n, ld, k, ws, d_os, d_oi, s);
     if (st == RL_OK) st = stage_out_end(out_scores, n_out, mem, s, t_os);
     if (st == RL_OK) st = stage_out_end(out_ids, n_out, mem, s, t_oi);
-    (void)hipStreamSynchronize(s);  // the workspace is freed below
+    const int sy = sync_and_drain(s);  // the workspace is freed below; bounced results reach the caller here
     select_workspace_free(ws);
-    return st;
+    return st == RL_OK ? sy : st;
 }
 
 // ---- timing hook for bench.py ------------------------------------------------------------------------------
@@ -984,8 +1038,7 @@ int rl_partition_similarity(const float* X, int64_t n, int32_t dim, const int64_
     RL_TRY(t_scr.alloc(partition_sim_scratch_bytes(n, n_docs, dim)));
     RL_TRY(launch_partition_similarity(d_x, n, dim, d_off, n_docs, d_sel, d_out, t_scr.p, s));
     RL_TRY(stage_out_end(out, (size_t)n, mem, s, t_out));
-    RL_HIP(hipStreamSynchronize(s));  // the scratch dies with this frame
-    return RL_OK;
+    return sync_and_drain(s);  // the scratch dies with this frame
 }
 
 int rl_chunk_best_rows(rl_index* idx, const float* queries, int32_t B, const int32_t* candidates, int32_t n_cand,
