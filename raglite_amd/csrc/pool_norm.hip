@@ -57,6 +57,26 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < VEC; ++j) acc[v][j] = 0.0;
         int64_t r = b;
+        for (; r + 4 <= e; r += 4) {  // four rows (4*NV loads) in flight per lane
+            float x0[NV][VEC], x1[NV][VEC], x2[NV][VEC], x3[NV][VEC];
+            const float* p0 = tokens + r * (int64_t)dim;
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                if (ok[v]) {
+                    VecLoad<VEC>::load(p0 + col[v], x0[v]);
+                    VecLoad<VEC>::load(p0 + dim + col[v], x1[v]);
+                    VecLoad<VEC>::load(p0 + 2 * (int64_t)dim + col[v], x2[v]);
+                    VecLoad<VEC>::load(p0 + 3 * (int64_t)dim + col[v], x3[v]);
+                }
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                if (ok[v])
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {  // same row order as the two-row loop: bit-identical sums
+                        acc[v][j] += (double)x0[v][j]; acc[v][j] += (double)x1[v][j];
+                        acc[v][j] += (double)x2[v][j]; acc[v][j] += (double)x3[v][j];
+                    }
+        }
         for (; r + 2 <= e; r += 2) {  // two rows (2*NV loads) in flight per lane
             float x0[NV][VEC], x1[NV][VEC];
             const float* p0 = tokens + r * (int64_t)dim;
