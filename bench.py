@@ -61,6 +61,10 @@ def main() -> None:
     # NOT the BASELINE.json configuration (that one is fp32, the default): the fp16-stored index of SURVEY.md 8f-1,
     # reported under its own workload name so it can never be mistaken for the headline number.
     ap.add_argument("--storage", choices=("f32", "f16"), default="f32", help=argparse.SUPPRESS)
+    # Test hooks for the N > 1 code path on a ONE-GPU box (scripts/test_multirank_one_gpu.sh): every rank uses cuda:0
+    # and the collective runs over gloo.  Never used by the driver.
+    ap.add_argument("--same-gpu", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     import torch
@@ -74,12 +78,17 @@ def main() -> None:
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.same_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     raglite_amd.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     n_rows = args.rows
     off = chunk_offsets(n_rows)

@@ -69,6 +69,20 @@ def group_chunk_max_host(row_scores: np.ndarray, row_chunks: np.ndarray, k: int)
     return out_s, out_c, counts
 
 
+def _all_gather_stacked(t, group):
+    """(world, *t.shape) tensor of every rank's `t`.  The output is allocated in the CONCATENATED form
+    `(world * t.shape[0], ...)` -- the one every backend's `all_gather_into_tensor` accepts (gloo rejects the stacked
+    form) -- and viewed as a stack afterwards."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    t = t.contiguous()
+    flat = torch.empty((world * t.shape[0], *t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(flat, t, group=group)
+    return flat.view(world, *t.shape)
+
+
 def _to_numpy(x: Any) -> np.ndarray:
     return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
@@ -103,10 +117,9 @@ class ShardedIndex:
         t = torch.from_numpy(np.ascontiguousarray(packed))
         if backend == "nccl":  # RCCL moves device memory
             t = t.cuda()
-        out = torch.empty((world, *t.shape), dtype=t.dtype, device=t.device)
         try:
-            dist.all_gather_into_tensor(out, t, group=self.group)
-        except (RuntimeError, NotImplementedError):  # backends without the flat form
+            out = _all_gather_stacked(t, self.group)
+        except (RuntimeError, NotImplementedError):  # backends without all_gather_into_tensor
             parts = [torch.empty_like(t) for _ in range(world)]
             dist.all_gather(parts, t, group=self.group)
             out = torch.stack(parts)
@@ -141,9 +154,7 @@ class ShardedIndex:
         gid = torch.where(i2 >= 0, i2 + base, torch.full_like(i2, -1))
         packed = torch.stack([s2.contiguous().view(torch.int32), gid.to(torch.int32)], dim=-1).contiguous()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            world = dist.get_world_size(self.group)
-            out = torch.empty((world, *packed.shape), dtype=packed.dtype, device=packed.device)
-            dist.all_gather_into_tensor(out, packed, group=self.group)
+            out = _all_gather_stacked(packed, self.group)
         else:
             out = packed[None]
         g = out.cpu().numpy()
@@ -164,8 +175,7 @@ class ShardedIndex:
         if world == 1:
             return scores, gid
         packed = torch.stack([scores.contiguous().view(torch.int32), gid], dim=-1).contiguous()  # (B, k, 2)
-        out = torch.empty((world, *packed.shape), dtype=packed.dtype, device=packed.device)
-        dist.all_gather_into_tensor(out, packed, group=self.group)
+        out = _all_gather_stacked(packed, self.group)
         gs = out[..., 0].contiguous().view(torch.float32)  # (world, B, k)
         gi = out[..., 1].contiguous()
         return _ops.merge_topk(gs, gi, k)

@@ -50,8 +50,9 @@ def test_device_exchange_merge_two_shards(monkeypatch):
         # the calling rank's own slot must carry what it passed in; the peer's slot the peer's list
         me = 0 if torch.equal(inp, packed[0]) else 1
         assert torch.equal(inp, packed[me])
-        out[0].copy_(packed[0])
-        out[1].copy_(packed[1])
+        stacked = out.view(2, *inp.shape)  # the library allocates the concatenated form every backend accepts
+        stacked[0].copy_(packed[0])
+        stacked[1].copy_(packed[1])
 
     monkeypatch.setattr(dist, "is_initialized", lambda: True)
     monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
@@ -76,8 +77,9 @@ def test_device_exchange_merge_two_shards(monkeypatch):
         packed_r.append(torch.stack([s.contiguous().view(torch.int32), gid], dim=-1).contiguous())
 
     def fake_rows(out, inp, group=None):
-        out[0].copy_(packed_r[0])
-        out[1].copy_(packed_r[1])
+        stacked = out.view(2, *inp.shape)
+        stacked[0].copy_(packed_r[0])
+        stacked[1].copy_(packed_r[1])
 
     monkeypatch.setattr(dist, "is_initialized", lambda: True)
     monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
