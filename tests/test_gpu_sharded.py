@@ -98,3 +98,26 @@ def test_device_exchange_merge_two_shards(monkeypatch):
     for sh in shards:
         sh.local.close()
     full.close()
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """bench.py's N > 1 path end to end (what the driver launches, minus RCCL): two ranks share cuda:0, the all-gather
+    runs over gloo, rank 0 prints ONE JSON line for n_gpus = 2."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29617", str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "100000",
+           "--same-gpu", "--backend", "gloo"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "strong"
+    assert out["roofline"]["algorithmic_bytes_per_launch"] < 4.0 * 100000 * 1024  # a shard, not the whole corpus
