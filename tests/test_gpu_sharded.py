@@ -109,10 +109,15 @@ def test_bench_two_ranks_on_one_gpu():
     import sys
     from pathlib import Path
 
+    import socket
+
     root = Path(__file__).resolve().parent.parent
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as sock:  # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29617", str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "100000",
+           "--master-port", str(port), str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "100000",
            "--same-gpu", "--backend", "gloo"]
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
