@@ -271,6 +271,22 @@ class MaxSimRanker:
         self.index = index
         self.query_encoder = query_encoder
 
+    @classmethod
+    def from_embedder(cls, index: GpuIndex, embedder: Any, *, normalize: bool = True, max_vectors: int = 32) -> "MaxSimRanker":
+        """Query side from a token-level embedder (`raglite_amd.TorchTokenEmbedder`, or llama.cpp with pooling NONE):
+        the query's token embeddings, L2-normalised like the stored chunklet vectors, at most `max_vectors` of them
+        (ColBERT's fixed query length; the first tokens are kept)."""
+
+        def encode(query: str) -> np.ndarray:
+            m = embedder.embed(query)
+            m = m.float().cpu().numpy() if hasattr(m, "cpu") else np.asarray(m, dtype=np.float32)
+            m = m[:max_vectors]
+            if normalize:
+                m = m / np.maximum(np.linalg.norm(m, axis=1, keepdims=True), np.finfo(np.float32).eps)
+            return m.astype(np.float32)
+
+        return cls(index, encode)
+
     def score(self, query: str, ordinals: Sequence[int]) -> np.ndarray:
         qv = np.asarray(self.query_encoder(query), dtype=np.float32)
         qv = qv.reshape(1, *qv.shape) if qv.ndim == 2 else qv.reshape(1, 1, -1)
