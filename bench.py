@@ -170,7 +170,7 @@ def main() -> None:
     if tf.exists() and args.storage == "f32" and n_rows == N_ROWS and world == 1:
         traffic = json.loads(tf.read_text()).get("maxsim_stream_bytes_per_launch")
     result["roofline"] = {
-        "bound": "hbm", "kernel": "maxsim_stream_kernel<2,0>", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "bound": "hbm", "kernel": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false> (as rocprofv3 names it; F16 = true with --storage f16)", "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "kernel_ms": ms, "algorithmic_bytes_per_launch": algo_bytes,
         # HIP events around the whole timed region / corpus passes in it: kernel + its share of selection and exchange
