@@ -1005,7 +1005,11 @@ def test_fuzz_ragged_shapes_integer_exact():
     from hypothesis import HealthCheck, given, settings
     from hypothesis import strategies as st
 
-    @settings(max_examples=150, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+    import os
+
+    n_examples = int(os.environ.get("RAGLITE_FUZZ_EXAMPLES", "150"))  # crank up for a soak run
+
+    @settings(max_examples=n_examples, deadline=None, derandomize=n_examples <= 150, suppress_health_check=list(HealthCheck))
     @given(
         sizes=st.lists(st.one_of(st.just(0), st.integers(1, 3), st.integers(1, 40)), min_size=1, max_size=400),
         dim=st.sampled_from([128, 256, 384, 512, 768, 1024, 64, 100]),
@@ -1082,4 +1086,58 @@ def test_l2_batched_near_duplicates_are_rescored(storage, B):
     S2, R2 = idx.search_rows(Q, 20, chunk_filter=flt)
     assert picks[0] not in R2[0]
     assert_topk_close(S2[0], R2[0], np.where(flt, oracle.similarity(E, Q[0], "l2"), -np.inf), 20, TOL)
+    idx.close()
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_lifecycle_random_operation_sequences(storage):
+    """Random interleavings of append / delete / filtered and unfiltered searches against a NumPy mirror of the table
+    (integer data: bit-exact).  Exercises capacity growth (several reallocations), tombstones that are extended by
+    appends, deletes of already deleted chunks, filters over deleted chunks and k larger than what is left."""
+    rng = np.random.default_rng(20 if storage == "f32" else 21)
+    dim = 256
+    E = oracle.synth_matrix(200, 40, dim, "small_int")
+    sizes = [int(x) for x in rng.integers(1, 6, size=12)]
+    sizes[-1] += 40 - sum(sizes) if sum(sizes) < 40 else 0
+    while sum(sizes) > 40:
+        sizes.pop()
+    sizes.append(40 - sum(sizes)) if sum(sizes) < 40 else None
+    off = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot", storage=storage)
+    alive = np.ones(len(off) - 1, bool)
+    seed = 300
+    for step in range(40):
+        op = rng.choice(["append", "delete", "search", "filter", "maxsim"], p=[0.25, 0.2, 0.2, 0.2, 0.15])
+        n_chunks = len(off) - 1
+        r2c = np.repeat(np.arange(n_chunks), np.diff(off))
+        if op == "append":
+            n_new_chunks = int(rng.integers(1, 8))
+            new_sizes = rng.integers(0 if step % 7 == 0 else 1, 9, size=n_new_chunks)
+            rows = oracle.synth_matrix(seed, int(new_sizes.sum()), dim, "small_int")
+            seed += 1
+            idx.append(rows, new_sizes)
+            E = np.concatenate([E, rows])
+            off = np.concatenate([off, off[-1] + np.cumsum(new_sizes)]).astype(np.int64)
+            alive = np.concatenate([alive, np.ones(n_new_chunks, bool)])
+            assert idx.n_rows == len(E) and idx.n_chunks == len(off) - 1
+        elif op == "delete":
+            dead = rng.choice(n_chunks, size=int(rng.integers(1, max(2, n_chunks // 6))), replace=False)
+            idx.delete_chunks(dead)
+            alive[dead] = False
+            assert idx.live() == (int(alive[r2c].sum()), int(alive.sum()))
+        else:
+            q = oracle.synth_matrix(seed, 3, dim, "small_int")
+            seed += 1
+            flt = (rng.random(n_chunks) < 0.6) if op == "filter" else None
+            ok = alive if flt is None else alive & flt
+            if op == "maxsim":
+                ws, wc = oracle.maxsim_topk_filtered(E, off, q, 12, ok)
+                gs, gc = idx.maxsim_topk(q, 12, chunk_filter=flt)
+                assert np.array_equal(gc, wc) and np.array_equal(gs, ws.astype(np.float32))
+            else:
+                for b in range(3):
+                    ws, wr = oracle.search_rows_filtered(E, r2c, q[b], 25, ok, "dot", np.float64)
+                    gs, gr = idx.search_rows(q[b], 25, chunk_filter=flt)
+                    assert np.array_equal(gr, wr), (step, op)
+                    assert np.array_equal(gs, np.where(wr >= 0, ws, -np.inf).astype(np.float32))
     idx.close()
