@@ -1141,3 +1141,25 @@ def test_lifecycle_random_operation_sequences(storage):
                     assert np.array_equal(gr, wr), (step, op)
                     assert np.array_equal(gs, np.where(wr >= 0, ws, -np.inf).astype(np.float32))
     idx.close()
+
+
+def test_pure_c_consumer(tmp_path):
+    """The drop-in boundary is a C ABI: tests/c/abi_smoke.c includes only include/raglite_hip.h, is compiled with gcc
+    and linked against libraglite_hip.so -- no Python, torch or HIP headers -- and checks known answers."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    from raglite_amd import _build
+
+    root = Path(__file__).resolve().parent.parent
+    lib = _build.LIB_PATH
+    assert lib.exists(), "build the library first (python -m raglite_amd._build)"
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    exe = tmp_path / "abi_smoke"
+    subprocess.run([gcc, "-std=c11", "-Wall", "-Wextra", "-Werror", f"-I{root / 'include'}", str(root / "tests" / "c" / "abi_smoke.c"),
+                    "-o", str(exe), f"-L{lib.parent}", "-lraglite_hip", "-lm", f"-Wl,-rpath,{lib.parent}"], check=True)
+    res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    assert "abi_smoke OK" in res.stdout
