@@ -38,6 +38,7 @@ from raglite_amd._search import (
     search_and_rerank_chunks,
     vector_search,
 )
+from raglite_amd._cross_encoder import CrossEncoderShape, TorchCrossEncoderRanker
 from raglite_amd._torch_embedder import EncoderShape, HashTokenizer, TorchTokenEmbedder
 from raglite_amd._query_adapter import update_query_adapter
 from raglite_amd._sharded import ShardedIndex, merge_topk_host, shard_bounds_by_chunk
@@ -52,6 +53,8 @@ __all__ = [
     "EncoderShape",
     "HashTokenizer",
     "TorchTokenEmbedder",
+    "TorchCrossEncoderRanker",
+    "CrossEncoderShape",
     "pack_bits",
     "DeviceIndex", "GpuIndex", "GpuVectorSearch", "HotPathConfig", "MaxSimRanker", "ShardedIndex",
     "adapter_apply", "attach_index", "detach_index", "embed_strings", "embed_strings_with_late_chunking",

@@ -38,6 +38,9 @@ class EncoderShape:
     pad_id: int = 1  # XLM-R: <s>=0, <pad>=1, </s>=2; positions start at pad_id + 1
     bos_id: int = 0
     eos_id: int = 2
+    type_vocab: int = 1  # XLM-R has one segment type whose embedding is added to every token; BERT has two
+    position_offset: int = 2  # XLM-R / RoBERTa: position of token t is t + pad_id + 1; BERT: t
+    classifier: bool = False  # BERT pooler (dense + tanh on the first token) + a one-logit head (`_cross_encoder.py`)
 
 
 class HashTokenizer:
@@ -108,25 +111,62 @@ def _build_encoder(shape: EncoderShape):
         def __init__(self) -> None:
             super().__init__()
             self.tok = nn.Embedding(shape.vocab_size, shape.hidden, padding_idx=shape.pad_id)
-            self.pos = nn.Embedding(shape.max_positions, shape.hidden, padding_idx=shape.pad_id)
+            self.pos = nn.Embedding(shape.max_positions, shape.hidden)
+            self.typ = nn.Embedding(shape.type_vocab, shape.hidden)
             self.ln = nn.LayerNorm(shape.hidden, eps=shape.layer_norm_eps)
             self.layers = nn.ModuleList(Layer() for _ in range(shape.layers))
+            if shape.classifier:
+                self.pooler = nn.Linear(shape.hidden, shape.hidden)
+                self.head = nn.Linear(shape.hidden, 1)
 
-        def forward(self, ids, lengths):  # ids: (B, T) padded with pad_id; lengths: (B,)
+        def forward(self, ids, lengths, type_ids=None):  # ids: (B, T) padded with pad_id; lengths: (B,)
             B, T = ids.shape  # noqa: N806
             ar = torch.arange(T, device=ids.device)
             valid = ar[None, :] < lengths[:, None]
-            pos = torch.where(valid, ar[None, :] + shape.pad_id + 1, torch.full_like(ids, shape.pad_id))
-            x = self.ln(self.tok(ids) + self.pos(pos))
+            pos = torch.where(valid, ar[None, :] + shape.position_offset, torch.zeros_like(ids))
+            typ = self.typ.weight[0] if type_ids is None else self.typ(type_ids)
+            x = self.ln(self.tok(ids) + self.pos(pos) + typ)
             mask = None
             if not bool(valid.all()):
                 mask = torch.zeros((B, 1, 1, T), dtype=x.dtype, device=x.device).masked_fill(~valid[:, None, None, :],
                                                                                            float("-inf"))
             for layer in self.layers:
                 x = layer(x, mask)
+            if shape.classifier:
+                return self.head(torch.tanh(self.pooler(x[:, 0])))[:, 0]  # (B,): one relevance logit per pair
             return x  # (B, T, hidden): one embedding per token, pooling NONE
 
     return Encoder()
+
+
+def native_state_from_hf(state: dict, shape: EncoderShape) -> dict:
+    """Rename a Hugging Face `XLMRobertaModel` / `BertModel` / `BertForSequenceClassification` state dict (the layout
+    bge-m3 and the ms-marco MiniLM cross-encoders are published in) to this module's parameters; q/k/v are fused into
+    one (3d, d) projection.  Unknown keys (`position_ids` buffers, an unused pooler) are ignored."""
+    import torch
+
+    def strip(k: str) -> str:
+        for pre in ("roberta.", "bert.", "model."):
+            if k.startswith(pre):
+                return k[len(pre):]
+        return k
+
+    src = {strip(k): v for k, v in state.items()}
+    out = {"tok.weight": src["embeddings.word_embeddings.weight"], "pos.weight": src["embeddings.position_embeddings.weight"],
+           "typ.weight": src["embeddings.token_type_embeddings.weight"], "ln.weight": src["embeddings.LayerNorm.weight"],
+           "ln.bias": src["embeddings.LayerNorm.bias"]}
+    names = {"attention.output.dense": "out", "attention.output.LayerNorm": "ln1", "intermediate.dense": "up",
+             "output.dense": "down", "output.LayerNorm": "ln2"}
+    for i in range(shape.layers):
+        pre = f"encoder.layer.{i}."
+        for part in ("weight", "bias"):
+            out[f"layers.{i}.qkv.{part}"] = torch.cat([src[f"{pre}attention.self.{n}.{part}"] for n in ("query", "key", "value")])
+            for hf, mine in names.items():
+                out[f"layers.{i}.{mine}.{part}"] = src[f"{pre}{hf}.{part}"]
+    if shape.classifier:
+        out.update({"pooler.weight": src["pooler.dense.weight"], "pooler.bias": src["pooler.dense.bias"],
+                    "head.weight": src["classifier.weight"], "head.bias": src["classifier.bias"]})
+    return out
 
 
 class TorchTokenEmbedder:
@@ -153,6 +193,10 @@ class TorchTokenEmbedder:
 
     def load_state_dict(self, state: dict) -> None:
         self.encoder.load_state_dict(state)
+
+    def load_hf_state_dict(self, state: dict) -> None:
+        """Weights in the Hugging Face layout bge-m3 is published in (`XLMRobertaModel.state_dict()`)."""
+        self.encoder.load_state_dict({k: v.to(self.dtype) for k, v in native_state_from_hf(state, self.shape).items()})
 
     # -- the surface `_embed.py` touches ---------------------------------------------------------------------
     def n_ctx(self) -> int:

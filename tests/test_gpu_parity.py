@@ -1163,3 +1163,80 @@ def test_pure_c_consumer(tmp_path):
     res = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     assert "abi_smoke OK" in res.stdout
+
+
+def test_encoders_match_huggingface_on_device(torch_cuda):
+    """8f-2 / 8f-4 on the GPU: the token encoder and the cross-encoder, in fp32 on cuda:0, against Hugging Face's CPU
+    fp32 `XLMRobertaModel` / `BertForSequenceClassification` with the same weights (tolerance 2e-4: hipBLASLt and the
+    SDPA kernel accumulate in another order); bf16, the serving dtype, must reproduce the fp32 ranking up to pairs
+    whose scores differ by less than bf16 noise."""
+    import torch
+    from transformers import BertConfig, BertForSequenceClassification, XLMRobertaConfig, XLMRobertaModel
+
+    from raglite_amd._cross_encoder import CrossEncoderShape, TorchCrossEncoderRanker
+    from raglite_amd._torch_embedder import EncoderShape, TorchTokenEmbedder
+
+    torch.manual_seed(21)
+    xcfg = XLMRobertaConfig(vocab_size=2000, hidden_size=128, num_hidden_layers=3, num_attention_heads=8, intermediate_size=256,
+                            max_position_embeddings=260, type_vocab_size=1, layer_norm_eps=1e-5, hidden_dropout_prob=0.0,
+                            attention_probs_dropout_prob=0.0, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+    hf = XLMRobertaModel(xcfg, add_pooling_layer=False).eval()
+    with torch.no_grad():
+        for p in hf.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    shape = EncoderShape(vocab_size=2000, hidden=128, layers=3, heads=8, ffn=256, max_positions=260, n_ctx=256)
+    emb = TorchTokenEmbedder(shape, device="cuda", dtype=torch.float32)
+    emb.load_hf_state_dict(hf.state_dict())
+    g = torch.Generator().manual_seed(6)
+    rows = [[0, *torch.randint(3, 2000, (n,), generator=g).tolist(), 2] for n in (200, 31, 254, 1, 77)]
+    T = max(len(r) for r in rows)  # noqa: N806
+    ids = torch.full((len(rows), T), 1, dtype=torch.long)
+    for i, r in enumerate(rows):
+        ids[i, : len(r)] = torch.tensor(r)
+    lengths = torch.tensor([len(r) for r in rows])
+    with torch.no_grad():
+        want = hf(input_ids=ids, attention_mask=(torch.arange(T)[None, :] < lengths[:, None]).long()).last_hidden_state
+        got = emb.encoder(ids.cuda(), lengths.cuda()).cpu()
+    for i, r in enumerate(rows):
+        torch.testing.assert_close(got[i, : len(r)], want[i, : len(r)], atol=2e-4, rtol=1e-4)
+
+    bcfg = BertConfig(vocab_size=3000, hidden_size=128, num_hidden_layers=3, num_attention_heads=8, intermediate_size=256,
+                      max_position_embeddings=128, type_vocab_size=2, num_labels=1, hidden_dropout_prob=0.0,
+                      attention_probs_dropout_prob=0.0, layer_norm_eps=1e-12)
+    hb = BertForSequenceClassification(bcfg).eval()
+    with torch.no_grad():
+        for p in hb.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    cshape = CrossEncoderShape(vocab_size=3000, hidden=128, layers=3, heads=8, ffn=256, max_positions=128, n_ctx=128)
+    rk = TorchCrossEncoderRanker(cshape, device="cuda", dtype=torch.float32, pairs_per_batch=16)
+    rk.load_hf_state_dict(hb.state_dict())
+    query = "how does the reranker order passages"
+    docs = make_sentences(91, 50)
+    docs[7] = ""
+    docs[9] = docs[9] * 30  # truncated
+    pairs = rk.encode_pairs(query, docs)
+    T = max(len(p[0]) for p in pairs)  # noqa: N806
+    ids = torch.zeros((len(pairs), T), dtype=torch.long)
+    for i, p in enumerate(pairs):
+        ids[i, : len(p[0])] = torch.tensor(p[0])
+    lengths = torch.tensor([len(p[0]) for p in pairs])
+    first = torch.tensor([p[1] for p in pairs])
+    ar = torch.arange(T)
+    with torch.no_grad():
+        want = hb(input_ids=ids, attention_mask=(ar[None, :] < lengths[:, None]).long(),
+                  token_type_ids=((ar[None, :] >= first[:, None]) & (ar[None, :] < lengths[:, None])).long()).logits[:, 0]
+    got = rk.logits(query, docs)
+    assert got.is_cuda
+    torch.testing.assert_close(got.cpu(), want, atol=2e-4, rtol=1e-4)
+    res = rk.rank(query=query, docs=docs)
+    sig = torch.sigmoid(want).numpy()
+    got_order = [r.doc_id for r in res.results]
+    for a, b in zip(got_order, got_order[1:]):  # best first w.r.t. the HF scores, up to fp32 noise
+        assert sig[a] >= sig[b] - 1e-5
+    # bf16 serving dtype: same weights, ranking agrees wherever the fp32 scores are separated by more than bf16 noise
+    rk16 = TorchCrossEncoderRanker(cshape, device="cuda", dtype=torch.bfloat16)
+    rk16.load_hf_state_dict(hb.state_dict())
+    z16 = rk16.logits(query, docs).cpu()
+    assert torch.isfinite(z16).all()
+    scale = float(want.abs().max()) + 1.0
+    assert float((z16 - want).abs().max()) < 0.08 * scale

@@ -291,3 +291,106 @@ def test_hybrid_search_fuses_vector_and_keyword_rankings():
     assert calls == [6] and ids == want_ids[:3] and scores == want_scores[:3]
     only_vs, _ = raglite_amd.hybrid_search(q, num_results=3, config=cfg, index=gi)
     assert only_vs == vs[:3]
+
+
+def _hf_pad(rows, pad):
+    import torch
+
+    T = max(len(r) for r in rows)  # noqa: N806
+    ids = torch.full((len(rows), T), pad, dtype=torch.long)
+    for i, r in enumerate(rows):
+        ids[i, : len(r)] = torch.tensor(r)
+    lengths = torch.tensor([len(r) for r in rows])
+    return ids, lengths, (torch.arange(T)[None, :] < lengths[:, None]).long()
+
+
+def test_token_encoder_matches_huggingface_xlm_roberta():
+    """SURVEY.md 8f-2 pin: bge-m3 is an XLM-RoBERTa encoder; with the same (random) weights, loaded through
+    `load_hf_state_dict`, the token-level outputs equal Hugging Face's `XLMRobertaModel` -- embeddings incl. the
+    segment-type vector and the pad-offset positions, post-LN layers, padding mask."""
+    import torch
+    from transformers import XLMRobertaConfig, XLMRobertaModel
+
+    from raglite_amd._torch_embedder import EncoderShape, TorchTokenEmbedder
+
+    torch.manual_seed(11)
+    cfg = XLMRobertaConfig(vocab_size=900, hidden_size=48, num_hidden_layers=3, num_attention_heads=4, intermediate_size=96,
+                           max_position_embeddings=70, type_vocab_size=1, layer_norm_eps=1e-5, hidden_dropout_prob=0.0,
+                           attention_probs_dropout_prob=0.0, pad_token_id=1, bos_token_id=0, eos_token_id=2)
+    hf = XLMRobertaModel(cfg, add_pooling_layer=False).eval()
+    with torch.no_grad():
+        for p in hf.parameters():  # HF initialises biases / LayerNorm to 0 / 1: make every parameter count
+            p.add_(0.05 * torch.randn_like(p))
+    shape = EncoderShape(vocab_size=900, hidden=48, layers=3, heads=4, ffn=96, max_positions=70, n_ctx=64)
+    emb = TorchTokenEmbedder(shape, device="cpu", dtype=torch.float32)
+    emb.load_hf_state_dict(hf.state_dict())
+    g = torch.Generator().manual_seed(5)
+    rows = [[0, *torch.randint(3, 900, (n,), generator=g).tolist(), 2] for n in (17, 5, 62, 1)]
+    ids, lengths, mask = _hf_pad(rows, 1)
+    with torch.no_grad():
+        want = hf(input_ids=ids, attention_mask=mask).last_hidden_state
+        got = emb.encoder(ids, lengths)
+    for i, r in enumerate(rows):
+        torch.testing.assert_close(got[i, : len(r)], want[i, : len(r)], atol=2e-5, rtol=1e-5)
+
+
+def test_cross_encoder_matches_huggingface_bert_classifier():
+    """the cross-encoder `BaseRanker` (FlashRank's ms-marco MiniLM is a BERT sequence classifier).
+    With the same weights the pair logits equal Hugging Face's `BertForSequenceClassification`; scores are the
+    sigmoid; `rank` orders best-first with the reference's `doc_id` plumbing (`_search.py:394-396`)."""
+    import torch
+    from transformers import BertConfig, BertForSequenceClassification
+
+    import raglite_amd
+    from raglite_amd._cross_encoder import CrossEncoderShape, TorchCrossEncoderRanker, truncate_pair
+
+    torch.manual_seed(12)
+    cfg = BertConfig(vocab_size=1200, hidden_size=48, num_hidden_layers=2, num_attention_heads=4, intermediate_size=96,
+                     max_position_embeddings=64, type_vocab_size=2, num_labels=1, hidden_dropout_prob=0.0,
+                     attention_probs_dropout_prob=0.0, layer_norm_eps=1e-12)
+    hf = BertForSequenceClassification(cfg).eval()
+    with torch.no_grad():
+        for p in hf.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    shape = CrossEncoderShape(vocab_size=1200, hidden=48, layers=2, heads=4, ffn=96, max_positions=64, n_ctx=64)
+    rk = TorchCrossEncoderRanker(shape, device="cpu", dtype=torch.float32, pairs_per_batch=3)
+    rk.load_hf_state_dict(hf.state_dict())
+    query = "what is late chunking"
+    docs = ["late chunking pools token embeddings per sentence. " * 4, "short", "", "an unrelated passage about ducks, geese and swans " * 2,
+            "late chunking", "x y z " * 40]
+    pairs = rk.encode_pairs(query, docs)
+    assert max(len(p[0]) for p in pairs) == 64 and pairs[2][0][-2:] == [102, 102]  # truncated to max_length; empty passage
+    ids, lengths, mask = _hf_pad([p[0] for p in pairs], 0)
+    first = torch.tensor([p[1] for p in pairs])
+    ar = torch.arange(ids.shape[1])
+    types = ((ar[None, :] >= first[:, None]) & (ar[None, :] < lengths[:, None])).long()
+    with torch.no_grad():
+        want = hf(input_ids=ids, attention_mask=mask, token_type_ids=types).logits[:, 0]
+    got = rk.logits(query, docs)
+    torch.testing.assert_close(got, want, atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(rk.score(query, docs), torch.sigmoid(want).numpy(), atol=1e-6)
+    res = rk.rank(query=query, docs=docs)
+    order = np.lexsort((np.arange(len(docs)), -torch.sigmoid(want).numpy()))
+    assert [r.doc_id for r in res.results] == order.tolist() and res.results[0].rank == 1
+    assert rk.rank(query=query, docs=[]).results == []
+
+    # the reranker plugs into rerank_chunks exactly like the reference's (`_search.py:364-397`)
+    class _Chunk:
+        def __init__(self, t): self.t = t
+        def __str__(self): return self.t
+
+    chunks = [_Chunk(d) for d in docs]
+    out = raglite_amd.rerank_chunks(query, chunks, config=raglite_amd.HotPathConfig(reranker=rk))
+    assert [c.t for c in out] == [docs[i] for i in order]
+
+    # longest_first truncation in closed form == the one-token-at-a-time definition
+    for nq in range(0, 40, 3):
+        for nd in range(0, 40, 3):
+            for budget in (0, 1, 7, 20, 61):
+                a, b = nq, nd
+                while a + b > budget:
+                    if a > b:
+                        a -= 1
+                    else:
+                        b -= 1
+                assert truncate_pair(nq, nd, budget) == (a, b), (nq, nd, budget)
