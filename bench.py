@@ -61,6 +61,8 @@ def main() -> None:
     # NOT the BASELINE.json configuration (that one is fp32, the default): the fp16-stored index of SURVEY.md 8f-1,
     # reported under its own workload name so it can never be mistaken for the headline number.
     ap.add_argument("--storage", choices=("f32", "f16"), default="f32", help=argparse.SUPPRESS)
+    # A/B: the exact fp32 MFMA chain instead of the default fp16 (hi, lo) split of the fp32 operands
+    ap.add_argument("--exact-fp32", action="store_true", help=argparse.SUPPRESS)
     # Test hooks for the N > 1 code path on a ONE-GPU box (scripts/test_multirank_one_gpu.sh): every rank uses cuda:0
     # and the collective runs over gloo.  Never used by the driver.
     ap.add_argument("--same-gpu", action="store_true", help=argparse.SUPPRESS)
@@ -101,6 +103,9 @@ def main() -> None:
     if args.storage == "f16":
         E = E.half()  # the corpus IS these fp16 values (what RAGLite stores, `_embed.py:140`)
     index = raglite_amd.DeviceIndex(E, local_off, metric="dot", storage=args.storage)
+    if args.exact_fp32:
+        index.set_exact_fp32()
+    arithmetic = index.arithmetic
     sharded = ShardedIndex(index, row_base=r_lo, chunk_base=c_lo, local_chunk_offsets=local_off)
     n_batches = 4  # distinct query batches, cycled
     queries = torch.empty((n_batches, QUERIES_PER_STEP, NQ, DIM), dtype=torch.float32, device=dev)
@@ -147,7 +152,10 @@ def main() -> None:
         "higher_is_better": True,
         "scaling": "strong",
         "vs_baseline": None,
-        "dtype": "f32" if args.storage == "f32" else "f16 storage, f16 x f16 -> f32 MFMA",
+        # fp32 data in, fp32 scores out, fp32 accumulation; how the products are formed is `arithmetic`
+        "dtype": {"fp32_exact": "f32 (v_mfma_f32_16x16x4_f32)",
+                  "f16_split": "f32 operands as exact fp16 hi+lo pairs (22 bits), 3 x v_mfma_f32_16x16x32_f16, f32 accumulate",
+                  "f16_stored": "f16 storage, f16 x f16 -> f32 MFMA"}[arithmetic],
         "data": "synthetic",
         "config": {
             "workload": f"maxsim_{NQ}x{n_rows}_d{DIM}_top{TOPK}_ragged_chunks_1to15"
@@ -170,12 +178,16 @@ def main() -> None:
     if tf.exists() and args.storage == "f32" and n_rows == N_ROWS and world == 1:
         traffic = json.loads(tf.read_text()).get("maxsim_stream_bytes_per_launch")
     result["roofline"] = {
-        "bound": "hbm", "kernel": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false> (as rocprofv3 names it; F16 = true with --storage f16)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "bound": "hbm",
+        "kernel": {"fp32_exact": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, false>",
+                   "f16_split": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, true>",
+                   "f16_stored": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, true, false>"}[arithmetic] + " (as rocprofv3 names it)",
+        "arithmetic": arithmetic, "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "kernel_ms": ms, "algorithmic_bytes_per_launch": algo_bytes,
         # HIP events around the whole timed region / corpus passes in it: kernel + its share of selection and exchange
         "timed_region_ms_per_pass": region_ms_per_pass,
-        "mfma_fp32_tflops": 2.0 * NQ * (r_hi - r_lo) * DIM / (ms * 1e-3) / 1e12,
+        "useful_tflops": 2.0 * NQ * (r_hi - r_lo) * DIM / (ms * 1e-3) / 1e12,
     }
 
     # ---- recall@100 and CPU baseline: NumPy oracle on the host cores (rank 0, N = 1) --------------------

@@ -37,6 +37,13 @@ typedef enum {
 } rl_status;
 
 typedef enum { RL_MEM_HOST = 0, RL_MEM_DEVICE = 1 } rl_mem;
+/* How an index multiplies queries with its corpus in the MFMA streaming kernel (rl_index_set_arithmetic). */
+typedef enum {
+    RL_ARITH_AUTO = 0,       /* request: RL_ARITH_F16_SPLIT where the corpus allows it, else RL_ARITH_FP32_EXACT */
+    RL_ARITH_FP32_EXACT = 1, /* v_mfma_f32_16x16x4_f32: bitwise an ordered fp32 fmaf chain */
+    RL_ARITH_F16_SPLIT = 2,  /* in effect only: fp32 operands as fp16 (hi, lo) pairs, see below */
+    RL_ARITH_F16_STORED = 3  /* in effect only: an rl_index_create_f16 index */
+} rl_arith;
 typedef enum { RL_F32 = 0, RL_F16 = 1 } rl_dtype;
 /* src/raglite/_config.py:69 `vector_search_distance_metric`; src/raglite/_typing.py:123-134 */
 typedef enum { RL_COSINE = 0, RL_DOT = 1, RL_L2 = 2 } rl_metric;
@@ -127,6 +134,24 @@ int rl_index_append(rl_index* index, const float* rows, int64_t n_new_rows, cons
                     int64_t n_new_chunks, int mem, void* stream);
 int rl_index_delete_chunks(rl_index* index, const int64_t* chunk_ordinals, int64_t n, void* stream);
 int rl_index_live(rl_index* index, int64_t* live_rows, int64_t* live_chunks, void* stream);
+
+/* ---- arithmetic of the MFMA streaming kernel over an fp32-stored corpus --------------------------
+ * The reference multiplies in fp32 (DuckDB FLOAT[d], src/raglite/_typing.py:99-134) or fp64 (NumPy,
+ * src/raglite/_query_adapter.py:174); BASELINE.json asks for scores within 1e-4.  Two ways to get there:
+ *   RL_ARITH_FP32_EXACT  fp32 MFMAs, bitwise an ordered fmaf chain; matrix-pipe-bound at 32 query vectors.
+ *   RL_ARITH_F16_SPLIT   every fp32 operand x is scaled by a power of two and written as hi + lo with hi, lo
+ *                        fp16 (22 significant bits); e.q = eh.qh + (el.qh + eh.ql) on the fp16 matrix pipe,
+ *                        whose fp16 x fp16 products are exact and accumulate in fp32.  Measured error against
+ *                        float64 is that of the fp32 chain; the kernel becomes
+ *                        HBM-bound (10 % faster at 32 x 1M x 1024).
+ * Default RL_ARITH_AUTO: F16_SPLIT when every element is finite and the largest elements of all non-zero rows
+ * lie within a factor 2^10 of each other (any normalised corpus), FP32_EXACT otherwise; the environment variable
+ * RAGLITE_EXACT_FP32=1 forces FP32_EXACT for the whole process.  The single-query VALU scan, the batched
+ * GEMM (>= 96 queries) and rl_maxsim_rerank always compute in fp32.
+ * rl_index_set_arithmetic: mode = RL_ARITH_AUTO | RL_ARITH_FP32_EXACT.
+ * rl_index_arithmetic: what is in effect (FP32_EXACT, F16_SPLIT or F16_STORED). */
+int rl_index_set_arithmetic(rl_index* index, int mode);
+int rl_index_arithmetic(rl_index* index, int* in_effect);
 
 /* ---- a6 + a7: similarity + exact row top-k ----------------------------------------------------
  * Replaces the SQL at src/raglite/_search.py:69-79 (`sim = 1 - dist`, ORDER BY dist LIMIT k) with

@@ -325,6 +325,18 @@ class DeviceIndex:
         _ensure_init(self.device.index or 0) if self.mem == MEM_DEVICE else _ensure_init(_current_device())
         check(lib().rl_index_delete_chunks(self._handle, c.ctypes.data, int(c.size), None))
 
+    def set_exact_fp32(self, exact: bool = True) -> None:
+        """Make the MFMA streaming kernel use exact fp32 MFMAs (an ordered fmaf chain) instead of the default fp16
+        (hi, lo) split of its fp32 operands (`rl_index_set_arithmetic`, include/raglite_hip.h)."""
+        check(lib().rl_index_set_arithmetic(self._handle, 1 if exact else 0))
+
+    @property
+    def arithmetic(self) -> str:
+        """What the streaming kernel multiplies with: 'fp32_exact', 'f16_split' or 'f16_stored'."""
+        m = C.c_int(0)
+        check(lib().rl_index_arithmetic(self._handle, C.byref(m)))
+        return {1: "fp32_exact", 2: "f16_split", 3: "f16_stored"}[int(m.value)]
+
     def live(self) -> tuple[int, int]:
         """(live rows, live chunks)."""
         r, c = C.c_int64(0), C.c_int64(0)

@@ -223,7 +223,51 @@ struct rl_index {
     uint32_t* live_row_bits = nullptr;    // the same expanded to rows
     int64_t n_dead_chunks = 0, n_dead_rows = 0;
     rl::Pool maskbuf;                     // per-call effective row mask
+    // SPLIT arithmetic of the stream kernel (fp32 storage only): range of the row norms, and what follows from it
+    uint32_t* d_range = nullptr;          // device scratch of launch_row_range
+    float max_abs = 0.f, min_row_max = std::numeric_limits<float>::infinity();  // over rows that are not all zero
+    bool nonfinite = false;
+    int arithmetic = RL_ARITH_AUTO;
+    float split_scale = 0.f;              // > 0: power of two applied to the corpus inside the kernel; 0: exact fp32 MFMAs
 };
+
+namespace {
+// The stream kernel multiplies an fp32 corpus either with the exact fp32 MFMA chain or -- 10 % faster, HBM-bound instead
+// of matrix-pipe-bound -- as fp16 (hi, lo) pairs (maxsim_stream.hip, SPLIT).  After scaling the largest element to
+// [2^13, 2^14) a pair keeps 22 significant bits of every element down to 2^-3, fewer below (lo goes subnormal), which
+// is harmless inside a row (the loss is < 2^-38 of the row's largest element) but not for a whole row far below the
+// rest.  So SPLIT is used only when the largest elements of all non-zero rows lie within a factor 2^10 of each other
+// (every normalised corpus does), everything is finite, and the caller has not asked for the exact chain.
+void update_split_scale(rl_index* idx) {
+    static const bool env_exact = std::getenv("RAGLITE_EXACT_FP32") != nullptr;
+    idx->split_scale = 0.f;
+    if (idx->E16 || !idx->E || env_exact || idx->arithmetic == RL_ARITH_FP32_EXACT || idx->nonfinite) return;
+    if (idx->dim % 4) return;
+    if (idx->max_abs == 0.f) { idx->split_scale = 1.f; return; }  // all-zero (or empty) corpus: nothing to lose
+    if (!(idx->max_abs / idx->min_row_max <= 1024.f)) return;      // row magnitudes spread over more than 2^10
+    int ex = 0;
+    (void)std::frexp(idx->max_abs, &ex);                           // largest |e| = f * 2^ex, f in [0.5, 1)
+    idx->split_scale = std::ldexp(1.f, 14 - std::max(-100, ex));   // |e| * scale < 2^14
+}
+
+// Folds the magnitude range of rows [first, first + n) into the index (synchronises the stream: build / append only).
+int scan_row_range(rl_index* idx, int64_t first, int64_t n, hipStream_t s) {
+    if (idx->E16 || !idx->E || idx->dim % 4) return RL_OK;
+    if (!idx->d_range) RL_HIP(hipMalloc(&idx->d_range, 16));
+    RL_TRY(rl::launch_row_range(idx->E + (size_t)first * idx->dim, n, idx->dim, idx->d_range, s));
+    uint32_t h[3];
+    RL_HIP(hipMemcpyAsync(h, idx->d_range, sizeof(h), hipMemcpyDeviceToHost, s));
+    RL_HIP(hipStreamSynchronize(s));
+    float mx, mn;
+    std::memcpy(&mx, &h[0], 4);
+    std::memcpy(&mn, &h[1], 4);
+    idx->max_abs = std::max(idx->max_abs, mx);
+    idx->min_row_max = std::min(idx->min_row_max, mn);
+    idx->nonfinite |= h[2] != 0;
+    update_split_scale(idx);
+    return RL_OK;
+}
+}  // namespace
 
 using namespace rl;
 
@@ -386,6 +430,7 @@ int rl_index_destroy(rl_index* idx) {
     if (idx->row_to_chunk) (void)hipFree(idx->row_to_chunk);
     if (idx->norm) (void)hipFree(idx->norm);
     if (idx->sumsq) (void)hipFree(idx->sumsq);
+    if (idx->d_range) (void)hipFree(idx->d_range);
     if (idx->live_chunk_bits) (void)hipFree(idx->live_chunk_bits);
     if (idx->live_row_bits) (void)hipFree(idx->live_row_bits);
     idx->maskbuf.release();
@@ -465,6 +510,7 @@ static int index_create_any(rl_index** out, const void* embeddings, bool f16, in
     if (idx->norm || idx->sumsq)
         RL_IDX(f16 ? launch_row_norms16(idx->E16, n_rows, dim, idx->norm, idx->sumsq, s)
                    : launch_row_norms(idx->E, n_rows, dim, idx->norm, idx->sumsq, s));
+    RL_IDX(scan_row_range(idx, 0, n_rows, s));
     RL_IDX_HIP(hipStreamSynchronize(s));  // host_offsets / caller buffers may go away after return
 #undef RL_IDX
 #undef RL_IDX_HIP
@@ -530,6 +576,22 @@ int rl_index_live(rl_index* idx, int64_t* live_rows, int64_t* live_chunks, void*
     std::lock_guard<std::mutex> lock(idx->mu);
     if (live_rows) *live_rows = idx->n_rows - idx->n_dead_rows;
     if (live_chunks) *live_chunks = idx->n_chunks - idx->n_dead_chunks;
+    return RL_OK;
+}
+
+int rl_index_set_arithmetic(rl_index* idx, int mode) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_index_set_arithmetic: null index");
+    if (mode != RL_ARITH_AUTO && mode != RL_ARITH_FP32_EXACT) return fail(RL_ERR_INVALID, "rl_index_set_arithmetic: unknown mode");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    idx->arithmetic = mode;
+    update_split_scale(idx);
+    return RL_OK;
+}
+
+int rl_index_arithmetic(rl_index* idx, int* in_effect) {
+    if (!idx || !in_effect) return fail(RL_ERR_INVALID, "rl_index_arithmetic: null argument");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    *in_effect = idx->E16 ? RL_ARITH_F16_STORED : (idx->split_scale > 0.f ? RL_ARITH_F16_SPLIT : RL_ARITH_FP32_EXACT);
     return RL_OK;
 }
 
@@ -630,6 +692,7 @@ int rl_index_append(rl_index* idx, const float* rows, int64_t n_new_rows, const 
         RL_TRY(f16 ? launch_row_norms16(idx->E16 + (size_t)old_n * idx->dim, n_new_rows, idx->dim, nn, ns, s)
                    : launch_row_norms(idx->E + (size_t)old_n * idx->dim, n_new_rows, idx->dim, nn, ns, s));
     }
+    RL_TRY(scan_row_range(idx, old_n, n_new_rows, s));
     if (!idx->h_live.empty()) {  // new chunks are live
         const size_t cw = (size_t)(new_c + 31) / 32;
         idx->h_live.resize(cw, 0u);
@@ -689,7 +752,7 @@ int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStrea
             const int32_t nq = std::min<int32_t>(32, nb - b0);
             const int st = launch_maxsim_stream(idx->E, idx->n_rows, idx->dim, d_q + (int64_t)b0 * idx->dim, nq,
                                                 idx->row_to_chunk, idx->offsets, idx->n_chunks, 1,
-                                                sc + (int64_t)b0 * ld, ld, idx->n_cu, s);
+                                                sc + (int64_t)b0 * ld, ld, idx->n_cu, s, idx->split_scale);
             if (st == RL_ERR_UNSUPPORTED) ok = false; else RL_TRY(st);
         }
         if (ok) return launch_transform(sc, nb, idx->n_rows, ld, idx->norm, idx->sumsq, d_q, idx->dim, mode, s);
@@ -845,7 +908,7 @@ int maxsim_scores_device(rl_index* idx, const float* d_q, int32_t nq, float* d_o
         st = idx->E16 ? launch_maxsim_stream16(idx->E16, idx->n_rows, idx->dim, qv, nv, idx->row_to_chunk, idx->offsets,
                                                idx->n_chunks, 0, d_out, accumulate, idx->n_cu, s)
                       : launch_maxsim_stream(idx->E, idx->n_rows, idx->dim, qv, nv, idx->row_to_chunk, idx->offsets,
-                                             idx->n_chunks, 0, d_out, accumulate, idx->n_cu, s);
+                                             idx->n_chunks, 0, d_out, accumulate, idx->n_cu, s, idx->split_scale);
         if (st != RL_OK) break;
     }
     if (idx->E16 && st == RL_ERR_UNSUPPORTED) return fail(st, "MaxSim: unsupported shape for an fp16-stored index");

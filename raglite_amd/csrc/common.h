@@ -155,9 +155,13 @@ int launch_row_to_chunk(const int64_t* chunk_offsets, int64_t n_chunks, int64_t 
                         hipStream_t s);
 // Fast path: dim in {128,256,384,512,768,1024}, nq <= 32 (wave-specialised MFMA streaming kernel).  mode 0: chunk MaxSim scores
 // out[n_chunks]; mode 1: raw row dots out[q * ld + row].  Returns RL_ERR_UNSUPPORTED outside the fast path.
+// split_scale > 0: SPLIT arithmetic (fp32 operands as fp16 hi + lo pairs, three fp16 MFMAs, fp32 accumulation) with the
+// corpus scaled by that power of two; 0: the exact fp32 MFMA chain.
 int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
                          const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
-                         float* out, int64_t ld, int n_cu, hipStream_t s);
+                         float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale = 0.f);
+// [max row sumsq, min non-zero row sumsq, non-finite flag] of an fp32 corpus, as uint32 bit patterns (device, 3 words)
+int launch_row_range(const float* E, int64_t n_rows, int32_t dim, uint32_t* range, hipStream_t s);
 // Any dim / nq: one wave per chunk (or per candidate), VALU dot products.
 // score_gemm.hip: similarity of many queries at once (fp32 MFMA GEMM, 128 x 128 tiles, fused metric); dim % 32 == 0.
 int launch_score_gemm(const float* E, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores,

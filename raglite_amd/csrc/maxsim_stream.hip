@@ -52,6 +52,7 @@
 namespace rl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
@@ -88,13 +89,14 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
 __device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 }  // namespace
 
-template <int KW, int NQT, int MODE, bool TRACE = false, int SPLR = 6, bool F16 = false>
+template <int KW, int NQT, int MODE, bool TRACE = false, int SPLR = 6, bool F16 = false, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __restrict__ D, int64_t n_rows,
                                                                  const float* __restrict__ Q, int nq,
                                                                  const int32_t* __restrict__ row_to_chunk,
                                                                  const int64_t* __restrict__ chunk_offsets,
                                                                  int64_t n_chunks, float* __restrict__ out,
-                                                                 int64_t ld, unsigned long long* trace) {
+                                                                 int64_t ld, unsigned long long* trace, float e_scale) {
+    static_assert(!(F16 && SPLIT), "SPLIT is a way to multiply an fp32-stored corpus");
     using G_ = Geo<KW, F16>;
     constexpr int SD = G_::DIM, PITCH = G_::PITCH, STAGE = G_::STAGE, KSTEPS = G_::KSTEPS, NCH = G_::NCH, ROWB = G_::ROWB;
     constexpr int OFF_RED = G_::OFF_RED, OFF_ST = G_::OFF_ST, ST_PITCH = G_::ST_PITCH, OFF_ORD = G_::OFF_ORD;
@@ -168,11 +170,57 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
         // fp32 corpus: qreg[h][4 mm + tt] feeds v_mfma_f32_16x16x4_f32.  fp16 corpus: the query slice is split into
         // fp16 hi + lo halves (q = hi + lo to ~2^-22 relative; lo == 0 for the reference's fp16-valued queries) that feed
         // v_mfma_f32_16x16x32_f16 -- fp16 x fp16 products are exact in fp32, so nothing is lost against the stored data.
-        [[maybe_unused]] float qreg[F16 ? 1 : NQT][F16 ? 1 : KW / 4];
-        [[maybe_unused]] h16x8 qhi[F16 ? NQT : 1][F16 ? KSTEPS : 1], qlo[F16 ? NQT : 1][F16 ? KSTEPS : 1];
+        constexpr bool H = F16 || SPLIT;      // the MFMAs are v_mfma_f32_16x16x32_f16
+        constexpr int MS = KW / 32;           // ... MS of them per query tile and operand pair
+        [[maybe_unused]] float qreg[H ? 1 : NQT][H ? 1 : KW / 4];
+        [[maybe_unused]] h16x8 qhi[H ? NQT : 1][H ? MS : 1], qlo[H ? NQT : 1][H ? MS : 1];
         [[maybe_unused]] bool any_lo = false;
+        [[maybe_unused]] float q_unscale = 1.f;
+        if constexpr (SPLIT) {
+            // SPLIT: x = hi + lo with hi, lo fp16 (22 significant bits; fp16 x fp16 products are exact in the MFMA's fp32
+            // accumulators), so  e.q ~= eh.qh + (el.qh + eh.ql)  costs 3 fp16 MFMAs of 16 cycles where the exact path
+            // issues 8 fp32 MFMAs of 32.  Both operands are first brought to the top of fp16's range by powers of two
+            // (exact, undone on the K-partials) so that lo keeps its 11 bits instead of going subnormal: the slice of Q by
+            // a scale of its own, the corpus by `e_scale` (chosen from the largest row norm when the index is built).
+            float mx = 0.f;
 #pragma unroll
-        for (int h = 0; h < NQT; ++h) {
+            for (int h = 0; h < NQT; ++h) {
+                const int qi = 16 * h + fj;
+                if (qi < nq)
+                    for (int c = 0; c < KW / 4; c += 4) {
+                        const f32x4 v = *reinterpret_cast<const f32x4*>(Q + (int64_t)qi * SD + KW * w + KW / 4 * kq + c);
+                        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                    }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            int ex = 0;
+            if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &ex);  // mx = f * 2^ex, f in [0.5, 1)
+            const float q_scale = ldexpf(1.f, 14 - ex);           // |q| * q_scale < 2^14
+            q_unscale = ldexpf(1.f, ex - 14) / e_scale;
+#pragma unroll
+            for (int h = 0; h < NQT; ++h) {
+                const int qi = 16 * h + fj;
+                const int qc_ = qi < nq ? qi : nq - 1;
+#pragma unroll
+                for (int m = 0; m < MS; ++m) {
+                    const float* qp = Q + (int64_t)qc_ * SD + KW * w + 32 * m + 4 * kq;  // k = 16 (2m + (u >> 2)) + 4 kq + (u & 3)
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp), v1 = *reinterpret_cast<const f32x4*>(qp + 16);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const float x = qi < nq ? (u < 4 ? v0[u] : v1[u - 4]) * q_scale : 0.f;
+                        const _Float16 hi = (_Float16)x;
+                        const _Float16 lo = (_Float16)(x - (float)hi);
+                        qhi[h][m][u] = hi;
+                        qlo[h][m][u] = lo;
+                        any_lo |= lo != (_Float16)0.0f;
+                    }
+                }
+            }
+            any_lo = __builtin_amdgcn_ballot_w64(any_lo) != 0;
+        }
+#pragma unroll
+        for (int h = 0; h < (SPLIT ? 0 : NQT); ++h) {
             const int qi = 16 * h + fj;
             const int qc_ = qi < nq ? qi : nq - 1;  // clamped load, zeroed below: padded query vectors add 0
 #pragma unroll
@@ -214,7 +262,33 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
             f32x4 acc[NQT];
 #pragma unroll
             for (int h = 0; h < NQT; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if constexpr (!F16) {
+            if constexpr (SPLIT) {
+                f32x4 acl[NQT];  // the two cross terms (2^-11 of the main one), summed apart
+#pragma unroll
+                for (int h = 0; h < NQT; ++h) acl[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < MS; ++m) {
+                    h16x8 eh, el;
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) {
+                        const f32x2 x = (f32x2){a[2 * m + (u >> 2)][u & 3], a[2 * m + (u >> 2)][(u & 3) + 1]} * e_scale;
+                        const auto ph = __builtin_amdgcn_cvt_pkrtz(x[0], x[1]);  // truncation: the residual is exact in fp32
+                        const auto pl = __builtin_amdgcn_cvt_pkrtz(x[0] - (float)ph[0], x[1] - (float)ph[1]);
+                        eh[u] = ph[0]; eh[u + 1] = ph[1];
+                        el[u] = pl[0]; el[u + 1] = pl[1];
+                    }
+#pragma unroll
+                    for (int h = 0; h < NQT; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, qhi[h][m], acc[h], 0, 0, 0);
+#pragma unroll
+                    for (int h = 0; h < NQT; ++h) acl[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(el, qhi[h][m], acl[h], 0, 0, 0);
+                    if (any_lo) {
+#pragma unroll
+                        for (int h = 0; h < NQT; ++h) acl[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, qlo[h][m], acl[h], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < NQT; ++h) acc[h] = (acc[h] + acl[h]) * q_unscale;
+            } else if constexpr (!F16) {
 #pragma unroll
                 for (int mm = 0; mm < KSTEPS; ++mm)
 #pragma unroll
@@ -501,16 +575,63 @@ int launch_row_to_chunk(const int64_t* chunk_offsets, int64_t n_chunks, int64_t 
     return RL_OK;
 }
 
+// Range of the corpus' row magnitudes, for the SPLIT arithmetic of the stream kernel: range[0] = largest |element|,
+// range[1] = smallest row maximum over the rows that are not all zero, range[2] != 0 if an element is not finite.
+// Magnitudes travel as uint32 bit patterns: non-negative floats order like their bits, and inf / NaN sort above every
+// finite value.  (Maxima, not norms: a sum of squares underflows for corpora scaled far down.)  One wave per row.
+__global__ __launch_bounds__(256) void row_range_kernel(const float* __restrict__ E, int64_t n_rows, int32_t dim,
+                                                         uint32_t* __restrict__ range) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    uint32_t mx = 0u, mn = 0x7f800000u;
+    for (int64_t r = wave; r < n_rows; r += nw) {
+        const float* row = E + r * dim;
+        uint32_t m = 0u;
+        for (int c = 4 * lane; c < dim; c += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + c);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t bits = __float_as_uint(v[u]) & 0x7fffffffu;
+                m = bits > m ? bits : m;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)m, o);
+            m = other > m ? other : m;
+        }
+        mx = m > mx ? m : mx;
+        if (m != 0u) mn = m < mn ? m : mn;
+    }
+    if (lane == 0) {
+        atomicMax(range + 0, mx);
+        atomicMin(range + 1, mn);
+        if (mx >= 0x7f800000u) atomicOr(range + 2, 1u);
+    }
+}
+
+int launch_row_range(const float* E, int64_t n_rows, int32_t dim, uint32_t* range, hipStream_t s) {
+    if (dim % 4) return RL_ERR_UNSUPPORTED;
+    const uint32_t init[3] = {0u, 0x7f800000u, 0u};
+    RL_HIP(hipMemcpyAsync(range, init, sizeof(init), hipMemcpyHostToDevice, s));
+    if (n_rows > 0) {
+        const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_rows + 3) / 4, 256 * 8));
+        hipLaunchKernelGGL(row_range_kernel, dim3(blocks), dim3(256), 0, s, E, n_rows, dim, range);
+        RL_HIP(hipGetLastError());
+    }
+    return RL_OK;
+}
+
 namespace {
 struct StreamArgs {
     const float* D; int64_t n_rows; const float* Q; int nq; const int32_t* r2c; const int64_t* off; int64_t n_chunks;
-    int mode; float* out; int64_t ld; dim3 grid; hipStream_t s; unsigned long long* trace;
+    int mode; float* out; int64_t ld; dim3 grid; hipStream_t s; unsigned long long* trace; float e_scale;
 };
-template <int KW, bool F16>
+template <int KW, bool F16, bool SPLIT = false>
 void launch_kw(const StreamArgs& a) {
     const dim3 blk(512);
-#define RL_STREAM(NQT, MODE) hipLaunchKernelGGL((maxsim_stream_kernel<KW, NQT, MODE, false, 6, F16>), a.grid, blk, 0, a.s, a.D, \
-                                                a.n_rows, a.Q, a.nq, a.r2c, a.off, a.n_chunks, a.out, a.ld, a.trace)
+#define RL_STREAM(NQT, MODE) hipLaunchKernelGGL((maxsim_stream_kernel<KW, NQT, MODE, false, 6, F16, SPLIT>), a.grid, blk, 0, a.s, a.D, \
+                                                a.n_rows, a.Q, a.nq, a.r2c, a.off, a.n_chunks, a.out, a.ld, a.trace, a.e_scale)
     if (a.mode == 0) { if (a.nq <= 16) RL_STREAM(1, 0); else RL_STREAM(2, 0); }
     else             { if (a.nq <= 16) RL_STREAM(1, 1); else RL_STREAM(2, 1); }
 #undef RL_STREAM
@@ -521,7 +642,7 @@ void launch_kw(const StreamArgs& a) {
 // f16 = the corpus is stored as IEEE fp16 (D then points at uint16_t data); queries and scores stay fp32.
 static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
                              const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
-                             float* out, int64_t ld, int n_cu, hipStream_t s) {
+                             float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale = 0.f) {
     if (nq < 1 || nq > 32 || n_rows < 1) return RL_ERR_UNSUPPORTED;
     if (dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
@@ -535,7 +656,7 @@ static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t d
     if (trace && !f16 && mode == 0 && nq > 16 && dim == 1024) {  // diagnostic build: dump the 30th launch's timeline to stderr
         static int calls = 0;
         hipLaunchKernelGGL((maxsim_stream_kernel<256, 2, 0, true>), dim3(grid), dim3(512), 0, s, D, n_rows, Q, nq,
-                           row_to_chunk, chunk_offsets, n_chunks, out, ld, trace);
+                           row_to_chunk, chunk_offsets, n_chunks, out, ld, trace, 1.f);
         if (++calls == 30) {
             unsigned long long h[8 * 8 * 8];
             (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
@@ -556,11 +677,12 @@ static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t d
         }
         return RL_OK;
     }
-    const StreamArgs a{D, n_rows, Q, (int)nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, dim3(grid), s, nullptr};
-#define RL_DIMS(F) switch (dim) { \
-        case 128: launch_kw<32, F>(a); break; case 256: launch_kw<64, F>(a); break; case 384: launch_kw<96, F>(a); break; \
-        case 512: launch_kw<128, F>(a); break; case 768: launch_kw<192, F>(a); break; default: launch_kw<256, F>(a); break; }
-    if (f16) { RL_DIMS(true) } else { RL_DIMS(false) }
+    const StreamArgs a{D, n_rows, Q, (int)nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, dim3(grid), s, nullptr, split_scale};
+    const bool split = !f16 && split_scale > 0.f;  // 0: the exact fp32 MFMA chain
+#define RL_DIMS(...) switch (dim) { \
+        case 128: launch_kw<32, __VA_ARGS__>(a); break; case 256: launch_kw<64, __VA_ARGS__>(a); break; case 384: launch_kw<96, __VA_ARGS__>(a); break; \
+        case 512: launch_kw<128, __VA_ARGS__>(a); break; case 768: launch_kw<192, __VA_ARGS__>(a); break; default: launch_kw<256, __VA_ARGS__>(a); break; }
+    if (f16) { RL_DIMS(true) } else if (split) { RL_DIMS(false, true) } else { RL_DIMS(false) }
 #undef RL_DIMS
     RL_HIP(hipGetLastError());
     return RL_OK;
@@ -568,8 +690,9 @@ static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t d
 
 int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
                          const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
-                         float* out, int64_t ld, int n_cu, hipStream_t s) {
-    return launch_stream_any(D, false, n_rows, dim, Q, nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, n_cu, s);
+                         float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale) {
+    return launch_stream_any(D, false, n_rows, dim, Q, nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, n_cu, s,
+                             split_scale);
 }
 
 int launch_maxsim_stream16(const uint16_t* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,

@@ -1,6 +1,6 @@
 """Box-normalised timing of the headline kernel: the MaxSim stream kernel next to the single-query scan kernel.
 
-    python scripts/kernel_ab.py [reps]
+    python scripts/kernel_ab.py [reps] [--f16] [--exact]
 
 GPU boxes differ by a few percent (clocks under load), so kernel variants measured on different boxes are compared
 through the ratio stream/scan: both kernels stream the same 4.096 GB corpus, and the scan kernel does not change
@@ -35,6 +35,8 @@ def main() -> None:
     if f16:
         E = E.half()
     idx = raglite_amd.DeviceIndex(E, chunk_offsets(n), metric="dot", storage="f16" if f16 else "f32")
+    if "--exact" in sys.argv:  # exact fp32 MFMA chain instead of the fp16 (hi, lo) split (include/raglite_hip.h)
+        idx.set_exact_fp32()
     idx.time_kernel(0, Q, 5)
     idx.time_kernel(1, Q[:1], 5)
     stream, scan = [], []
@@ -43,7 +45,7 @@ def main() -> None:
         scan.append(idx.time_kernel(1, Q[:1], 20) / 20)
     gb = (2.0 if f16 else 4.0) * n * d / 1e9
     s, c = min(stream), min(scan)
-    print(json.dumps({"storage": "f16" if f16 else "f32", "stream_ms": round(s, 4), "scan_ms": round(c, 4), "ratio": round(s / c, 4),
+    print(json.dumps({"storage": "f16" if f16 else "f32", "arithmetic": idx.arithmetic, "stream_ms": round(s, 4), "scan_ms": round(c, 4), "ratio": round(s / c, 4),
                       "stream_GBps": round(gb / s * 1e3, 1), "scan_GBps": round(gb / c * 1e3, 1),
                       "stream_all": [round(x, 4) for x in stream], "scan_all": [round(x, 4) for x in scan]}))
 

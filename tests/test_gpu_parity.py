@@ -1240,3 +1240,99 @@ def test_encoders_match_huggingface_on_device(torch_cuda):
     assert torch.isfinite(z16).all()
     scale = float(want.abs().max()) + 1.0
     assert float((z16 - want).abs().max()) < 0.08 * scale
+
+
+# ---------------------------------------------------------------------------------------------------
+# Arithmetic of the MFMA streaming kernel: fp16 (hi, lo) split of fp32 operands vs the exact fp32 chain
+# ---------------------------------------------------------------------------------------------------
+def _maxsim_truth(E32, Q32, off):
+    S = E32.astype(np.float64) @ Q32.astype(np.float64).T  # noqa: N806
+    out = np.full(len(off) - 1, -np.inf)
+    for c in range(len(off) - 1):
+        if off[c + 1] > off[c]:
+            out[c] = S[off[c] : off[c + 1]].max(axis=0).sum()
+    return out, (np.abs(E32.astype(np.float64)) @ np.abs(Q32.astype(np.float64)).T).sum(axis=1).max()
+
+
+@pytest.mark.parametrize("kind", ["normalized", "uniform", "scaled_down", "scaled_up", "sparse_tiny"])
+def test_split_arithmetic_is_as_accurate_as_fp32(kind):
+    """The default arithmetic of the streaming kernel writes every fp32 operand as an fp16 (hi, lo) pair (22 bits) and
+    multiplies on the fp16 matrix pipe with fp32 accumulation (include/raglite_hip.h, rl_index_set_arithmetic).  Against
+    float64 truth its error must stay within 2x that of the exact fp32 MFMA chain (+ one fp32 ulp of the largest
+    |e||q| sum), for corpora and queries at any power-of-two-ish scale -- both are rescaled inside the kernel."""
+    rng = np.random.default_rng(31)
+    n, dim, nq = 6000, 1024, 32
+    E = rng.standard_normal((n, dim))
+    Q = rng.standard_normal((nq, dim))
+    if kind == "normalized":
+        E /= np.linalg.norm(E, axis=1, keepdims=True)
+        Q /= np.linalg.norm(Q, axis=1, keepdims=True)
+    elif kind == "uniform":
+        E, Q = rng.uniform(-1, 1, (n, dim)), rng.uniform(-1, 1, (nq, dim))
+    elif kind == "scaled_down":
+        E *= 3e-21
+        Q *= 7e-12
+    elif kind == "scaled_up":
+        E *= 5e17
+        Q *= 9e9
+    elif kind == "sparse_tiny":  # elements spanning many orders of magnitude inside every row
+        E *= 10.0 ** rng.uniform(-8, 0, (n, dim))
+        Q *= 10.0 ** rng.uniform(-5, 0, (nq, dim))
+    E32, Q32 = E.astype(np.float32), Q.astype(np.float32)
+    off = ragged_offsets(rng, n, 1, 9)
+    truth, unit = _maxsim_truth(E32, Q32, off)
+    idx = raglite_amd.DeviceIndex(E32, off, metric="dot")
+    assert idx.arithmetic == "f16_split"
+    split = np.asarray(idx.maxsim_scores(Q32), dtype=np.float64)
+    rows_split = np.asarray(idx.search_rows(Q32[:7], 5)[0], dtype=np.float64)  # mode 1 (row scores) of the same kernel
+    idx.set_exact_fp32()
+    assert idx.arithmetic == "fp32_exact"
+    exact = np.asarray(idx.maxsim_scores(Q32), dtype=np.float64)
+    rows_exact = np.asarray(idx.search_rows(Q32[:7], 5)[0], dtype=np.float64)
+    idx.set_exact_fp32(False)
+    assert idx.arithmetic == "f16_split"
+    live = np.isfinite(truth)
+    err_split, err_exact = np.abs(split - truth)[live].max(), np.abs(exact - truth)[live].max()
+    assert err_split <= 2.0 * err_exact + 32 * 2.0 ** -24 * unit, (err_split, err_exact, unit)
+    assert err_exact <= 32 * 1e-6 * unit
+    np.testing.assert_allclose(rows_split, rows_exact, rtol=2e-5, atol=1e-6 * unit / 32)
+    idx.close()
+
+
+def test_split_arithmetic_eligibility(torch_cuda):
+    """AUTO picks the split only where it cannot lose precision: all rows finite and all non-zero row norms within 2^10
+    of each other; an append that breaks this switches the index to the exact chain; integer data stays bit-exact."""
+    rng = np.random.default_rng(32)
+    n, dim = 2048, 256
+    E = rng.standard_normal((n, dim)).astype(np.float32)
+    off = np.arange(0, n + 1, 4, dtype=np.int64)
+    idx = raglite_amd.DeviceIndex(E, off, metric="cosine")
+    assert idx.arithmetic == "f16_split"
+    idx.append(np.zeros((4, dim), np.float32), [4])  # all-zero rows do not count
+    assert idx.arithmetic == "f16_split"
+    idx.append((E[:4] * 3000.0).astype(np.float32), [4])  # norm ratio 3000 > 2^10
+    assert idx.arithmetic == "fp32_exact"
+    idx.close()
+    wide = E.copy()
+    wide[5] *= 1e-5
+    idx = raglite_amd.DeviceIndex(wide, off, metric="cosine")
+    assert idx.arithmetic == "fp32_exact"
+    idx.close()
+    bad = E.copy()
+    bad[9, 3] = np.inf
+    idx = raglite_amd.DeviceIndex(bad, off, metric="dot")
+    assert idx.arithmetic == "fp32_exact"
+    idx.close()
+    idx = raglite_amd.DeviceIndex(E.astype(np.float16), off, metric="dot", storage="f16")
+    assert idx.arithmetic == "f16_stored"
+    idx.close()
+    # integers up to 2^21 are exact in a (hi, lo) pair: scores are bit-identical to integer arithmetic
+    Ei = rng.integers(-1500, 1500, size=(n, dim)).astype(np.float32)
+    Qi = rng.integers(-3, 4, size=(9, dim)).astype(np.float32)
+    idx = raglite_amd.DeviceIndex(torch_cuda.from_numpy(Ei).cuda(), off, metric="dot")
+    assert idx.arithmetic == "f16_split"
+    got = idx.maxsim_scores(torch_cuda.from_numpy(Qi).cuda()).cpu().numpy()
+    S = Ei.astype(np.int64) @ Qi.astype(np.int64).T  # noqa: N806
+    want = S.reshape(n // 4, 4, 9).max(axis=1).sum(axis=1)
+    assert np.array_equal(got.astype(np.int64), want) and np.array_equal(got, want.astype(np.float32))
+    idx.close()
