@@ -167,28 +167,45 @@ def main() -> None:
     }
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, kernel only -----------------
+    # In fp16-split arithmetic `rl_maxsim_topk_batch` scores TWO queries per corpus pass (maxsim_stream2_kernel); the
+    # other arithmetics make one pass per query (maxsim_stream_kernel).  Either way one launch = one corpus pass.
     iters = 20
-    index.time_kernel(0, queries[0, 0], 3)  # warm
-    ms = index.time_kernel(0, queries[0, 0], iters) / iters
+    queries_per_launch, kind, qv = 1, 0, queries[0, 0]
+    if arithmetic == "f16_split":
+        try:
+            index.time_kernel(2, queries[0, :2].reshape(2 * NQ, DIM), 3)
+            queries_per_launch, kind, qv = 2, 2, queries[0, :2].reshape(2 * NQ, DIM)
+        except Exception:  # noqa: BLE001 - shape outside the pair kernel: one query per pass
+            pass
+    index.time_kernel(kind, qv, 3)  # warm
+    ms = index.time_kernel(kind, qv, iters) / iters
+    region_ms_per_pass *= queries_per_launch
     elt = 4.0 if args.storage == "f32" else 2.0
     algo_bytes = elt * (r_hi - r_lo) * DIM  # 4*N*d bytes per corpus pass (2*N*d when fp16-stored)
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     traffic = None
     tf = ROOT / "profiles" / "traffic.json"  # filled from a separate rocprofv3 --pmc pass
     if tf.exists() and args.storage == "f32" and n_rows == N_ROWS and world == 1:
-        traffic = json.loads(tf.read_text()).get("maxsim_stream_bytes_per_launch")
+        traffic = json.loads(tf.read_text()).get("maxsim_stream2_bytes_per_launch" if queries_per_launch == 2
+                                                 else "maxsim_stream_bytes_per_launch")
+    useful_tflops = 2.0 * queries_per_launch * NQ * (r_hi - r_lo) * DIM / (ms * 1e-3) / 1e12
     result["roofline"] = {
         "bound": "hbm",
-        "kernel": {"fp32_exact": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, false>",
-                   "f16_split": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, true>",
-                   "f16_stored": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, true, false>"}[arithmetic] + " (as rocprofv3 names it)",
-        "arithmetic": arithmetic, "achieved": achieved, "peak": HBM_PEAK_GBS,
+        "kernel": ("rl::maxsim_stream2_kernel<256, false>" if queries_per_launch == 2 else
+                   {"fp32_exact": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, false>",
+                    "f16_split": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, true>",
+                    "f16_stored": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, true, false>"}[arithmetic]) + " (as rocprofv3 names it)",
+        "arithmetic": arithmetic, "queries_per_launch": queries_per_launch,
+        "achieved": achieved, "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
         "kernel_ms": ms, "algorithmic_bytes_per_launch": algo_bytes,
         # HIP events around the whole timed region / corpus passes in it: kernel + its share of selection and exchange
         "timed_region_ms_per_pass": region_ms_per_pass,
-        "useful_tflops": 2.0 * NQ * (r_hi - r_lo) * DIM / (ms * 1e-3) / 1e12,
+        # the second roof: 2*nq*N*d flop per query; SURVEY.md 8d prices it against the 157.3 TF fp32 MFMA peak, which the
+        # split arithmetic is not bound by (its products run on the fp16 matrix pipe, 3 MFMAs per exact-fp32-equivalent)
+        "useful_tflops": useful_tflops, "useful_tflops_over_fp32_mfma_peak": useful_tflops / 157.3,
     }
+    result["config"]["corpus_passes_per_step"] = QUERIES_PER_STEP // queries_per_launch
 
     # ---- recall@100 and CPU baseline: NumPy oracle on the host cores (rank 0, N = 1) --------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -254,7 +254,8 @@ int rl_partition_similarity(const float* X, int64_t n, int32_t dim, const int64_
 /* Timing hook for bench.py: run `fn`-independent -- records the elapsed milliseconds between two
  * events on `stream` bracketing `iters` back-to-back launches of the named kernel path with the
  * given index / query.  kind: 0 = rl_maxsim_scores kernel only, 1 = rl_search_rows scan kernel
- * only (no selection).  Used so that roofline.achieved is measured with HIP events on the stream
+ * only (no selection), 2 = the two-queries-per-pass MaxSim kernel of rl_maxsim_topk_batch (query_vecs_dev
+ * then holds two queries of nq / 2 vectors each; RL_ERR_UNSUPPORTED where that kernel does not apply).  Used so that roofline.achieved is measured with HIP events on the stream
  * the kernel runs on. */
 int rl_time_kernel(rl_index* index, int kind, const float* query_vecs_dev, int32_t nq, int32_t iters,
                    float* out_ms_total, void* stream);

@@ -894,6 +894,22 @@ int mask_chunk_scores(rl_index* idx, float* d_scores, int32_t nb, int64_t ld, co
     return RL_OK;
 }
 
+// Two queries of the same length in ONE corpus pass (maxsim_stream2_kernel); RL_ERR_UNSUPPORTED when the shape or the
+// index' arithmetic does not allow it -- the caller then makes one pass per query.
+int maxsim_scores_pair_device(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, float* d_out,
+                              int64_t out_stride, hipStream_t s) {
+    static const bool no_pairs = std::getenv("RAGLITE_NO_QUERY_PAIRS") != nullptr;  // A/B switch
+    if (no_pairs || idx->E16 || !idx->E || idx->n_rows == 0 || idx->n_chunks == 0 || !(idx->split_scale > 0.f))
+        return RL_ERR_UNSUPPORTED;
+    if (nq <= 16 || nq > 32) return RL_ERR_UNSUPPORTED;
+    if (idx->has_empty_chunk) {
+        RL_TRY(launch_fill_f32(d_out, -std::numeric_limits<float>::infinity(), idx->n_chunks, s));
+        RL_TRY(launch_fill_f32(d_out + out_stride, -std::numeric_limits<float>::infinity(), idx->n_chunks, s));
+    }
+    return launch_maxsim_stream2(idx->E, idx->n_rows, idx->dim, d_q, nq, q_stride, idx->row_to_chunk, idx->offsets,
+                                 idx->n_chunks, d_out, out_stride, idx->n_cu, s, idx->split_scale);
+}
+
 int maxsim_scores_device(rl_index* idx, const float* d_q, int32_t nq, float* d_out, hipStream_t s) {
     if (idx->n_chunks == 0) return RL_OK;
     int st = RL_ERR_UNSUPPORTED;
@@ -991,8 +1007,16 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
     // launch's tail behind the next one's ramp and measured +1.5 % at 1 M rows / +3.3 % on a 125 k-row shard, but
     // concurrent kernels stretch each other's durations 3x in a kernel trace, which would make the rocprofv3 summary
     // disagree with the live roofline timing; the serial form keeps every number checkable.)
-    for (int32_t b = 0; b < n_queries; ++b)
+    // Two queries share a pass where the arithmetic allows it (fp16-split, 17..32 vectors per query).
+    for (int32_t b = 0; b < n_queries;) {
+        if (b + 1 < n_queries) {
+            const int st = maxsim_scores_pair_device(idx, d_q + (size_t)b * q_elems, nq, (int64_t)q_elems, sc + (int64_t)b * ld, ld, s);
+            if (st == RL_OK) { b += 2; continue; }
+            if (st != RL_ERR_UNSUPPORTED) return st;
+        }
         RL_TRY(maxsim_scores_device(idx, d_q + (size_t)b * q_elems, nq, sc + (int64_t)b * ld, s));
+        ++b;
+    }
     RL_TRY(mask_chunk_scores(idx, sc, n_queries, ld, nullptr, s));  // tombstones (no-op without deletions)
     RL_TRY(launch_topk(sc, n_queries, idx->n_chunks, ld, k, idx->ws, d_s, d_c, s));
     if (idx->live_chunk_bits) RL_TRY(launch_fix_masked(d_s, d_c, (int64_t)n_queries * k, s));
@@ -1146,7 +1170,9 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
     const int64_t ld = (idx->n_rows + 3) & ~int64_t(3);
+    const int64_t ldc = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
     if (kind == 0) RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));
+    else if (kind == 2) RL_TRY(idx->scores.reserve((size_t)2 * ldc * sizeof(float)));
     else RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)nq * ld * sizeof(float), 16)));
     hipEvent_t e0, e1;
     RL_HIP(hipEventCreate(&e0));
@@ -1155,6 +1181,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     RL_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < iters && st == RL_OK; ++i) {
         if (kind == 0) st = maxsim_scores_device(idx, q_dev, nq, idx->scores.as<float>(), s);
+        else if (kind == 2) st = maxsim_scores_pair_device(idx, q_dev, nq / 2, (int64_t)(nq / 2) * idx->dim, idx->scores.as<float>(), ldc, s);
         else st = score_rows(idx, q_dev, nq, ld, s);
     }
     RL_HIP(hipEventRecord(e1, s));

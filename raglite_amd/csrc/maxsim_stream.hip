@@ -575,6 +575,333 @@ int launch_row_to_chunk(const int64_t* chunk_offsets, int64_t n_chunks, int64_t 
     return RL_OK;
 }
 
+// =====================================================================================================================
+// TWO QUERIES PER CORPUS PASS (batched MaxSim, SPLIT arithmetic only).
+//
+// With the fp16 (hi, lo) split a tile costs a compute wave 48 MFMAs of 16 cycles + ~160 conversion VALU ops -- a third
+// of the ~4.7 k cycles the tile's 64 KiB take to arrive -- so the kernel above is HBM-bound and the matrix pipe idles.
+// What stops it from scoring more query vectors per pass is the register file: a K-quarter of 32 query vectors as
+// (hi, lo) pairs is 128 VGPRs of a wave's 256.  This variant therefore makes all eight waves symmetric: wave
+// (g, w) = (wv >> 2, wv & 3) multiplies K-quarter w of the tile with query g's 32 vectors (both groups read the same
+// A fragments from LDS), and the loader / K-reduce / epilogue duties of the kernel above are spread over them:
+//   * every wave brings 2 rows of each tile (LDS-DMA, hand-issued as above; tile t+2 right after B2(t)); wave 0 also
+//     brings the tile's chunk ordinals;
+//   * waves w = 0, 1 of a group K-reduce that group's partials, wave w = 3 walks its 32 query columns (segmented max,
+//     DPP column sum) exactly as wave 6 does above;
+//   * same two barriers per tile, same data flow between them (partials -> ST -> walker registers -> one store).
+// One launch = one corpus pass = two queries' chunk scores: out[g * out_stride + chunk].
+template <int KW>
+struct Geo2 {
+    using G1 = Geo<KW, false>;
+    static constexpr int OFF_RED = NSTAGE * G1::STAGE;              // 2 groups x 8 KiB of K-partials
+    static constexpr int OFF_ST = OFF_RED + 2 * G1::RED_BYTES;
+    static constexpr int ST_BYTES = 32 * G1::ST_PITCH * 4;          // per group and tile parity: [32 query columns][20] fp32
+    static constexpr int OFF_ORD = OFF_ST + 4 * ST_BYTES;           // (two tiles deep: the walker reads tile t-2 while
+    static constexpr int LDS_TOTAL = OFF_ORD + 4 * 256;             //  tile t-1 is being reduced)  159 744 B at KW = 256
+};
+
+template <int KW, bool TRACE = false>
+__global__ __launch_bounds__(512, 2) void maxsim_stream2_kernel(const float* __restrict__ D, int64_t n_rows,
+                                                                  const float* __restrict__ Q, int nq, int64_t q_stride,
+                                                                  const int32_t* __restrict__ row_to_chunk,
+                                                                  const int64_t* __restrict__ chunk_offsets,
+                                                                  int64_t n_chunks, float* __restrict__ out,
+                                                                  int64_t out_stride, float e_scale,
+                                                                  unsigned long long* trace) {
+    using G1 = Geo<KW, false>;
+    using G2 = Geo2<KW>;
+    constexpr int SD = G1::DIM, PITCH = G1::PITCH, STAGE = G1::STAGE, NCH = G1::NCH, ROWB = G1::ROWB, ST_PITCH = G1::ST_PITCH;
+    constexpr int KSTEPS = KW / 16, MS = KW / 32, NQT = 2, NQC = 32;
+    __shared__ __attribute__((aligned(16))) char smem[G2::LDS_TOTAL + (TRACE ? 4096 : 0)];
+    const int lane = threadIdx.x & 63;
+    const int wv = wave_id();  // 0..7
+    // Tile timeline of workgroup 7, tiles 100..107 (diagnostic build, RAGLITE_HIP_TRACE2=1): s_memtime stamps kept in LDS.
+    auto stamp = [&](int t, int k) {
+        if constexpr (TRACE) {
+            if (blockIdx.x == 7 && t >= 100 && t < 108 && lane == 0)
+                reinterpret_cast<unsigned long long*>(smem + G2::LDS_TOTAL)[((t - 100) * 8 + wv) * 8 + k] = __builtin_amdgcn_s_memtime();
+        }
+    };
+    if constexpr (TRACE) {
+        for (int i = threadIdx.x; i < 512; i += blockDim.x) reinterpret_cast<unsigned long long*>(smem + G2::LDS_TOTAL)[i] = 0;
+        __syncthreads();
+    }
+    const int w = wv & 3, g = wv >> 2;
+    const int64_t G = gridDim.x, b = blockIdx.x;
+    auto boundary = [&](int64_t t) -> int64_t {
+        if (t <= 0) return 0;
+        if (t >= n_rows) return n_rows;
+        const int32_t c = row_to_chunk[t];
+        const int64_t c0 = chunk_offsets[c], c1 = chunk_offsets[c + 1];
+        return c0 == t ? t : c1;
+    };
+    const int64_t r_lo = uniform_i64(boundary((n_rows * b) / G));
+    const int64_t r_hi = uniform_i64((b + 1 == G) ? n_rows : boundary((n_rows * (b + 1)) / G));
+    const int nt = (int)((r_hi - r_lo + TR - 1) / TR);
+    if (nt <= 0) return;
+    const int32_t last_row = (int32_t)(n_rows - 1);
+    const int32_t r_lo32 = (int32_t)r_lo;
+    char* const red = smem + G2::OFF_RED + g * G1::RED_BYTES;
+    float* const ST0 = reinterpret_cast<float*>(smem + G2::OFF_ST + 2 * g * G2::ST_BYTES);  // [tile parity][32][20]
+    const float* const Qg = Q + (int64_t)g * q_stride;
+
+    // ---- this wave's slice of its query as (hi, lo) fp16 MFMA B fragments (see SPLIT above) ----------------------------
+    const int fj = lane & 15, kq = lane >> 4;
+    h16x8 qhi[NQT][MS], qlo[NQT][MS];
+    bool any_lo = false;
+    float q_unscale;
+    {
+        float mx = 0.f;
+#pragma unroll
+        for (int h = 0; h < NQT; ++h) {
+            const int qi = 16 * h + fj;
+            if (qi < nq)
+                for (int c = 0; c < KW / 4; c += 4) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(Qg + (int64_t)qi * SD + KW * w + KW / 4 * kq + c);
+                    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        int ex = 0;
+        if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &ex);
+        const float q_scale = ldexpf(1.f, 14 - ex);
+        q_unscale = ldexpf(1.f, ex - 14) / e_scale;
+#pragma unroll
+        for (int h = 0; h < NQT; ++h) {
+            const int qi = 16 * h + fj;
+            const int qc_ = qi < nq ? qi : nq - 1;
+#pragma unroll
+            for (int m = 0; m < MS; ++m) {
+                const float* qp = Qg + (int64_t)qc_ * SD + KW * w + 32 * m + 4 * kq;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp), v1 = *reinterpret_cast<const f32x4*>(qp + 16);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float x = qi < nq ? (u < 4 ? v0[u] : v1[u - 4]) * q_scale : 0.f;
+                    const _Float16 hi = (_Float16)x;
+                    const _Float16 lo = (_Float16)(x - (float)hi);
+                    qhi[h][m][u] = hi;
+                    qlo[h][m][u] = lo;
+                    any_lo |= lo != (_Float16)0.0f;
+                }
+            }
+        }
+        any_lo = __builtin_amdgcn_ballot_w64(any_lo) != 0;
+    }
+    const char* const a_base = smem + fj * PITCH + w * G1::QBYTES + kq * 16;
+
+    // ---- this wave's share of the DMA stream: rows 2 wv, 2 wv + 1 of every tile ------------------------------------------
+    const char* const src = reinterpret_cast<const char*>(D);
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+    const uint32_t lds0 = lds_base + (uint32_t)(2 * wv * PITCH);
+    const uint32_t lds_ord = lds_base + G2::OFF_ORD;
+    const uint32_t voff_ord = 4u * lane;
+    constexpr int TAIL_LANES = (ROWB % 1024) / 16;
+    constexpr bool HALF_TAIL = TAIL_LANES != 0;
+    constexpr int DMA_PER_TILE = 2 * NCH;
+    // One tile = 2 * NCH DMA instructions per wave (+ the ordinals, wave 0).  They are issued ONE AT A TIME from inside the
+    // MFMA loop of the tile two behind: all eight waves firing their DMAs at once right after B2 costs each of them
+    // 0.3-1.6 k cycles of issue stall on the critical path (measured, profiles/r01_i_pair_timeline.txt).
+    struct TileSrc { const char* row[2]; uint32_t lds; };
+    auto tile_src = [&](int t) {
+        TileSrc ts;
+        const int32_t row0 = r_lo32 + t * TR + 2 * wv;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int32_t row = row0 + i;
+            row = row < last_row ? row : last_row;  // past the corpus: harmless re-reads of the last row, never used
+            ts.row[i] = src + (int64_t)row * ROWB;
+        }
+        ts.lds = lds0 + (uint32_t)((t & 1) * STAGE);
+        return ts;
+    };
+    auto dma_ordinals = [&](int t) {
+        if (wv == 0) {  // wave-uniform: the tile's 64 chunk ordinals, from its first row on
+            const int32_t row0 = r_lo32 + t * TR;
+            const int32_t rowc = row0 < last_row ? row0 : last_row;
+            const int32_t* rc = row_to_chunk + rowc;
+            const uint32_t dst = lds_ord + (uint32_t)((t & 3) * 256);
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(dst), "v"(voff_ord), "s"(rc)
+                         : "memory", "m0");
+        }
+    };
+    auto dma_one = [&](const TileSrc& ts, auto J_) {  // DMA j = NCH * i + c of the tile: 1 KiB (or the half tail) of row i
+        constexpr int j = decltype(J_)::value, i = j / NCH, c = j % NCH;
+        const uint32_t lane_off = 16u * lane;  // (asm operands alone do not capture an enclosing local in a generic lambda)
+        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0" ::"s"(ts.lds), "n"(i * PITCH) : "memory", "m0", "scc");
+        if (HALF_TAIL && c == NCH - 1) {
+            if (lane < TAIL_LANES)
+                asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2 nt" ::"v"(lane_off), "s"(ts.row[i]), "n"(c * 1024) : "memory");
+        } else {
+            asm volatile("global_load_lds_dwordx4 %0, %1 offset:%2 nt" ::"v"(lane_off), "s"(ts.row[i]), "n"(c * 1024) : "memory");
+        }
+    };
+    auto dma_tile = [&](int t) {  // the whole tile at once (prologue only)
+        dma_ordinals(t);
+        const TileSrc ts = tile_src(t);
+        [&]<int... J>(std::integer_sequence<int, J...>) { (dma_one(ts, std::integral_constant<int, J>{}), ...); }
+        (std::make_integer_sequence<int, DMA_PER_TILE>{});
+    };
+
+    // ---- K-reduction of a tile's partials (waves w = 0, 1 of the group), as the loaders do above ----------------------
+    auto kreduce = [&](int te) {
+        float* const ST = ST0 + (te & 1) * (G2::ST_BYTES / 4);
+        const int qcL = lane & (NQC - 1), gg = 2 * w + ((lane >> 5) & 1);
+        const int idx = 16 * gg + (qcL & 15), qhL = qcL >> 4;
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(red + ((0 * 2 + qhL) * 64 + idx) * 16);
+        const f32x4 p1 = *reinterpret_cast<const f32x4*>(red + ((1 * 2 + qhL) * 64 + idx) * 16);
+        const f32x4 p2 = *reinterpret_cast<const f32x4*>(red + ((2 * 2 + qhL) * 64 + idx) * 16);
+        const f32x4 p3 = *reinterpret_cast<const f32x4*>(red + ((3 * 2 + qhL) * 64 + idx) * 16);
+        *reinterpret_cast<f32x4*>(ST + qcL * ST_PITCH + 4 * gg) = (p0 + p1) + (p2 + p3);
+    };
+
+    // ---- the walkers: the epilogue wave of the kernel above, one per query group ------------------------------------------
+    // The walk of a tile takes ~1.3 k cycles of dependent code.  The older waves of each SIMD (0-3, group 0) get through
+    // their MFMA phase ~0.8 k cycles before the younger ones (measured), so the two walkers are waves 3 (group 0's
+    // columns) and 2 (group 1's), and they walk tile t-1 AFTER their MFMA phase of tile t, in time they would otherwise
+    // spend waiting at the next barrier -- not in the B1..B2 window, where every other wave would wait for them.
+    const bool walker = wv == 3 || wv == 2;   // wave-uniform
+    const int wg_ = wv == 3 ? 0 : 1;          // whose columns this walker owns
+    const bool reducer = w < 2;
+    const float* const STw = reinterpret_cast<const float*>(smem + G2::OFF_ST + 2 * wg_ * G2::ST_BYTES);
+    float* const outw = out + (int64_t)wg_ * out_stride;
+
+    const int qc = lane & (NQC - 1);
+    const bool col_on = qc < nq;
+    auto dpp_add = [](float x, auto CTRL) {
+        return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(CTRL)::value, 0xf, 0xf, false));
+    };
+    float m = -INFINITY;
+    float xacc = 0.f;
+    int32_t cacc = 0;
+    int nclosed = 0;
+    int32_t rcl = 0;
+    uint32_t ends = 0;
+    auto fetch_ordinals = [&](int te) {
+        const int32_t* ord = reinterpret_cast<const int32_t*>(smem + G2::OFF_ORD + (te & 3) * 256);
+        rcl = ord[lane];
+        const int32_t rcn = ord[lane + 1 < 64 ? lane + 1 : 63];
+        ends = (uint32_t)__builtin_amdgcn_ballot_w64(rcl != rcn) & 0xffffu;
+        const int32_t left = (int32_t)r_hi - (r_lo32 + te * TR);
+        if (left < TR) ends &= (1u << left) - 1u;
+    };
+    auto walk = [&](int te) {  // this lane's query column of the reduced tile te, straight from LDS
+        const float* const ST = STw + (te & 1) * (G2::ST_BYTES / 4);
+        float sv[TR];
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(ST + qc * ST_PITCH + 4 * q4);
+            sv[4 * q4 + 0] = v[0]; sv[4 * q4 + 1] = v[1]; sv[4 * q4 + 2] = v[2]; sv[4 * q4 + 3] = v[3];
+        }
+        const int32_t left = (int32_t)r_hi - (r_lo32 + te * TR);
+        if (left < TR) {  // last tile of the range only
+#pragma unroll
+            for (int i = 0; i < TR; ++i) sv[i] = i < left ? sv[i] : -INFINITY;
+        }
+        nclosed = 0;
+#pragma unroll
+        for (int i = 0; i < TR; ++i) {
+            asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(sv[i]));
+            if (__builtin_expect((ends >> i) & 1u, 0)) {
+                float x = col_on ? m : 0.f;
+                x = dpp_add(x, std::integral_constant<int, 0xB1>{});
+                x = dpp_add(x, std::integral_constant<int, 0x4E>{});
+                x = dpp_add(x, std::integral_constant<int, 0x141>{});
+                x = dpp_add(x, std::integral_constant<int, 0x140>{});
+                x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x142, 0xa, 0xf, false));
+                const float total = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 16));
+                const int32_t cid = __builtin_amdgcn_readlane(rcl, i);
+                xacc = lane == nclosed ? total : xacc;
+                cacc = lane == nclosed ? cid : cacc;
+                ++nclosed;
+                m = -INFINITY;
+            }
+        }
+    };
+    dma_tile(0);
+    if (nt > 1) dma_tile(1);
+    for (int t = 0; t <= nt; ++t) {
+        const bool live = t < nt;  // iteration nt only drains the epilogue pipeline
+        stamp(t, 0);
+        if (live) {
+            // Loads retire in order: when at most one tile's worth of this wave's DMAs is outstanding, tile t has landed
+            // (the walker's stores in between only make the wait stricter).
+            if (t + 1 < nt) {
+                if (wv == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_TILE + 1) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DMA_PER_TILE) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        stamp(t, 1);
+        wg_barrier();  // B1(t): tile t is in stage t&1; the K-partials of tile t-1 are in LDS
+        stamp(t, 2);
+        f32x4 a[KSTEPS];
+        if (live) {
+            const char* ap = a_base + (t & 1) * STAGE;
+#pragma unroll
+            for (int mm = 0; mm < KSTEPS; ++mm) a[mm] = *reinterpret_cast<const f32x4*>(ap + mm * 64);
+        }
+        if (reducer && t > 0) kreduce(t - 1);
+        stamp(t, 3);
+        wg_barrier();  // B2(t): every wave holds tile t in registers; the reduced tile t-1 is in ST
+        stamp(t, 4);
+        const bool feed = t + 2 < nt;                    // tile t+2 goes into stage t&1, free since this barrier
+        TileSrc ts{};
+        if (feed) { ts = tile_src(t + 2); dma_ordinals(t + 2); }
+        stamp(t, 5);
+        if (live) {
+            __builtin_amdgcn_sched_barrier(0);
+            f32x4 acc[NQT], acl[NQT];
+#pragma unroll
+            for (int h = 0; h < NQT; ++h) { acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[h] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int mi = 0; mi < MS; ++mi) {
+                h16x8 eh, el;
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) {
+                    // (two scalar multiplies, not one v_pk_mul_f32: packed fp32 VALU beside MFMAs costs ~+25 cycles each)
+                    const float x0 = a[2 * mi + (u >> 2)][u & 3] * e_scale, x1 = a[2 * mi + (u >> 2)][(u & 3) + 1] * e_scale;
+                    const auto ph = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+                    const auto pl = __builtin_amdgcn_cvt_pkrtz(x0 - (float)ph[0], x1 - (float)ph[1]);
+                    eh[u] = ph[0]; eh[u + 1] = ph[1];
+                    el[u] = pl[0]; el[u + 1] = pl[1];
+                }
+#pragma unroll
+                for (int h = 0; h < NQT; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, qhi[h][mi], acc[h], 0, 0, 0);
+#pragma unroll
+                for (int h = 0; h < NQT; ++h) acl[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(el, qhi[h][mi], acl[h], 0, 0, 0);
+                if (any_lo) {
+#pragma unroll
+                    for (int h = 0; h < NQT; ++h) acl[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, qlo[h][mi], acl[h], 0, 0, 0);
+                }
+                if (feed) {  // this step's share of the DMA stream
+                    [&]<int... J>(std::integer_sequence<int, J...>) {
+                        ((J * MS / DMA_PER_TILE == mi ? dma_one(ts, std::integral_constant<int, J>{}) : (void)0), ...);
+                    }(std::make_integer_sequence<int, DMA_PER_TILE>{});
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int h = 0; h < NQT; ++h)
+                *reinterpret_cast<f32x4*>(red + ((w * 2 + h) * 64 + lane) * 16) = (acc[h] + acl[h]) * q_unscale;
+        }
+        stamp(t, 6);
+        if (walker && t > 0) {  // tile t-1: reduced in this iteration's window, complete since B2(t)
+            fetch_ordinals(t - 1);
+            walk(t - 1);
+            if (lane < nclosed) outw[cacc] = xacc;
+        }
+        stamp(t, 7);
+    }
+    if constexpr (TRACE) {
+        if (blockIdx.x == 7) {
+            const int i = ((lane >> 3) * 8 + wv) * 8 + (lane & 7);
+            trace[i] = reinterpret_cast<unsigned long long*>(smem + G2::LDS_TOTAL)[i];
+        }
+    }
+}
+
 // Range of the corpus' row magnitudes, for the SPLIT arithmetic of the stream kernel: range[0] = largest |element|,
 // range[1] = smallest row maximum over the rows that are not all zero, range[2] != 0 if an element is not finite.
 // Magnitudes travel as uint32 bit patterns: non-negative floats order like their bits, and inf / NaN sort above every
@@ -693,6 +1020,50 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
                          float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale) {
     return launch_stream_any(D, false, n_rows, dim, Q, nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, n_cu, s,
                              split_scale);
+}
+
+// Two queries (17..32 vectors each, q_stride floats apart) per corpus pass over an fp32 corpus in SPLIT arithmetic:
+// out[g * out_stride + chunk], g = 0, 1.  RL_ERR_UNSUPPORTED outside that shape (the caller then makes two passes).
+int launch_maxsim_stream2(const float* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq, int64_t q_stride,
+                          const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, float* out,
+                          int64_t out_stride, int n_cu, hipStream_t s, float split_scale) {
+    if (nq <= 16 || nq > 32 || n_rows < 1 || !(split_scale > 0.f)) return RL_ERR_UNSUPPORTED;
+    if (dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024) return RL_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
+    const int64_t tiles = (n_rows + TR - 1) / TR;
+    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
+    static unsigned long long* trace = [] {
+        unsigned long long* p = nullptr;
+        if (std::getenv("RAGLITE_HIP_TRACE2")) { (void)hipMalloc(&p, 4096); (void)hipMemset(p, 0, 4096); }
+        return p;
+    }();
+    if (trace && dim == 1024) {  // diagnostic build: dump the 30th launch's tile timeline to stderr
+        static int calls = 0;
+        hipLaunchKernelGGL((maxsim_stream2_kernel<256, true>), grid, blk, 0, s, D, n_rows, Q, (int)nq, q_stride, row_to_chunk,
+                           chunk_offsets, n_chunks, out, out_stride, split_scale, trace);
+        if (++calls == 30) {
+            unsigned long long h[512];
+            (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
+            const unsigned long long t0 = h[0];
+            fprintf(stderr, "TRACE2 columns: before-vmcnt after-vmcnt after-B1 after-reads/kreduce after-B2 after-ordinal-DMA after-compute after-walk\n");
+            for (int t = 0; t < 8; ++t)
+                for (int wv = 0; wv < 8; ++wv) {
+                    fprintf(stderr, "TRACE2 tile %d wave %d:", t + 100, wv);
+                    for (int k = 0; k < 8; ++k) fprintf(stderr, " %8lld", (long long)(h[(t * 8 + wv) * 8 + k] - t0));
+                    fprintf(stderr, "\n");
+                }
+        }
+        return RL_OK;
+    }
+#define RL_STREAM2(KW) hipLaunchKernelGGL((maxsim_stream2_kernel<KW>), grid, blk, 0, s, D, n_rows, Q, (int)nq, q_stride, \
+                                          row_to_chunk, chunk_offsets, n_chunks, out, out_stride, split_scale, nullptr)
+    switch (dim) {
+        case 128: RL_STREAM2(32); break; case 256: RL_STREAM2(64); break; case 384: RL_STREAM2(96); break;
+        case 512: RL_STREAM2(128); break; case 768: RL_STREAM2(192); break; default: RL_STREAM2(256); break;
+    }
+#undef RL_STREAM2
+    RL_HIP(hipGetLastError());
+    return RL_OK;
 }
 
 int launch_maxsim_stream16(const uint16_t* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,

@@ -39,15 +39,26 @@ def main() -> None:
         idx.set_exact_fp32()
     idx.time_kernel(0, Q, 5)
     idx.time_kernel(1, Q[:1], 5)
-    stream, scan = [], []
+    Q2 = torch.empty((64, d), dtype=torch.float32, device="cuda")  # two queries of 32 vectors: the pair kernel
+    raglite_amd.synth_fill(Q2, seed=3)
+    stream, scan, pair = [], [], []
+    try:
+        idx.time_kernel(2, Q2, 3)
+        has_pair = True
+    except Exception:  # noqa: BLE001 - fp16-stored / exact-fp32 indexes have no pair kernel
+        has_pair = False
     for _ in range(reps):
         stream.append(idx.time_kernel(0, Q, 20) / 20)
         scan.append(idx.time_kernel(1, Q[:1], 20) / 20)
+        if has_pair:
+            pair.append(idx.time_kernel(2, Q2, 20) / 20)
     gb = (2.0 if f16 else 4.0) * n * d / 1e9
     s, c = min(stream), min(scan)
     print(json.dumps({"storage": "f16" if f16 else "f32", "arithmetic": idx.arithmetic, "stream_ms": round(s, 4), "scan_ms": round(c, 4), "ratio": round(s / c, 4),
                       "stream_GBps": round(gb / s * 1e3, 1), "scan_GBps": round(gb / c * 1e3, 1),
-                      "stream_all": [round(x, 4) for x in stream], "scan_all": [round(x, 4) for x in scan]}))
+                      "pair_ms": round(min(pair), 4) if pair else None, "pair_GBps": round(gb / min(pair) * 1e3, 1) if pair else None,
+                      "stream_all": [round(x, 4) for x in stream], "scan_all": [round(x, 4) for x in scan],
+                      "pair_all": [round(x, 4) for x in pair]}))
 
 
 if __name__ == "__main__":

@@ -1336,3 +1336,58 @@ def test_split_arithmetic_eligibility(torch_cuda):
     want = S.reshape(n // 4, 4, 9).max(axis=1).sum(axis=1)
     assert np.array_equal(got.astype(np.int64), want) and np.array_equal(got, want.astype(np.float32))
     idx.close()
+
+
+@pytest.mark.parametrize("dim", [128, 256, 384, 512, 768, 1024])
+@pytest.mark.parametrize("n_rows,nq", [(20, 32), (700, 17), (9000, 32), (40_000, 25)])
+def test_maxsim_batch_two_queries_per_pass(dim, n_rows, nq):
+    """`rl_maxsim_topk_batch` scores two queries per corpus pass (maxsim_stream2_kernel: eight symmetric waves, query
+    group x K-quarter) wherever the fp16-split arithmetic is in effect and a query has 17..32 vectors.  Integer data:
+    scores are exact, so batch == one-query-at-a-time == oracle, bit for bit, incl. the odd query left over, empty
+    chunks, tombstones and workgroups with 1, 2, 3 or many tiles."""
+    rng = np.random.default_rng(dim + n_rows)
+    off = ragged_offsets(rng, n_rows, 1, 15, empty_every=23)
+    n_chunks = len(off) - 1
+    E = oracle.synth_matrix(900 + dim, n_rows, dim, "small_int")
+    Qb = np.stack([oracle.synth_matrix(950 + i, nq, dim, "small_int") for i in range(5)])
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    assert idx.arithmetic == "f16_split"
+    k = min(50, n_chunks)
+    bs, bc = idx.maxsim_topk_batch(Qb, k)
+    for i in range(5):
+        ws, wc = oracle.maxsim_topk(E, off, Qb[i], k, np.float32)
+        ss, sc = idx.maxsim_topk(Qb[i], k)
+        assert np.array_equal(bc[i][: len(wc)], wc) and np.array_equal(bs[i][: len(wc)], ws)
+        assert np.array_equal(bc[i], sc) and np.array_equal(bs[i], ss)
+    if n_chunks > 8:
+        dead = rng.choice(n_chunks, size=n_chunks // 4, replace=False)
+        idx.delete_chunks(dead)
+        bs, bc = idx.maxsim_topk_batch(Qb[:4], k)
+        for i in range(4):
+            ss, sc = idx.maxsim_topk(Qb[i], k)
+            assert np.array_equal(bc[i], sc) and np.array_equal(bs[i], ss)
+            assert not np.isin(bc[i][bc[i] >= 0], dead).any()
+    idx.close()
+
+
+def test_maxsim_batch_pairs_float_data_device_pointers(torch_cuda):
+    """Float data, CUDA tensors: the pair kernel's scores equal the single-query kernel's bit for bit (same arithmetic,
+    same K order), and the oracle's within tolerance."""
+    torch = torch_cuda
+    n, dim, nq = 30_000, 1024, 32
+    rng = np.random.default_rng(77)
+    off = ragged_offsets(rng, n, 1, 15)
+    E = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=31)
+    Qb = torch.empty((6, nq, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Qb, seed=32)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    bs, bc = idx.maxsim_topk_batch(Qb, 100)
+    Eh = E.cpu().numpy()
+    for i in range(6):
+        ss, sc = idx.maxsim_topk(Qb[i], 100)
+        assert torch.equal(bc[i], sc) and torch.equal(bs[i], ss)
+    ws, wc = oracle.maxsim_topk(Eh, off, Qb[0].cpu().numpy(), 100, np.float64)
+    assert set(wc.tolist()) == set(bc[0].cpu().numpy().tolist())
+    np.testing.assert_allclose(np.sort(bs[0].cpu().numpy())[::-1], np.sort(ws)[::-1], rtol=0, atol=2e-4)
+    idx.close()
