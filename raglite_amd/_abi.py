@@ -11,9 +11,11 @@ from __future__ import annotations
 
 import ctypes as C
 import functools
+import os
 from pathlib import Path
 
-LIB_PATH = Path(__file__).resolve().parent / "_lib" / "libraglite_hip.so"
+# RAGLITE_HIP_LIB: developer hook for same-box A/B timing of kernel variants (scripts/ab_variant.sh); unset in normal use.
+LIB_PATH = Path(os.environ.get("RAGLITE_HIP_LIB") or Path(__file__).resolve().parent / "_lib" / "libraglite_hip.so")
 
 RL_OK, RL_ERR_INVALID, RL_ERR_HIP, RL_ERR_UNSUPPORTED, RL_ERR_NOMEM = 0, -1, -2, -3, -4
 MEM_HOST, MEM_DEVICE = 0, 1
