@@ -223,6 +223,7 @@ struct rl_index {
     uint32_t* live_row_bits = nullptr;    // the same expanded to rows
     int64_t n_dead_chunks = 0, n_dead_rows = 0;
     rl::Pool maskbuf;                     // per-call effective row mask
+    rl::Pool qsplit;                      // fp16 (hi, lo) query fragments of a MaxSim batch (maxsim_stream.hip)
     // SPLIT arithmetic of the stream kernel (fp32 storage only): range of the row norms, and what follows from it
     uint32_t* d_range = nullptr;          // device scratch of launch_row_range
     float max_abs = 0.f, min_row_max = std::numeric_limits<float>::infinity();  // over rows that are not all zero
@@ -434,6 +435,7 @@ int rl_index_destroy(rl_index* idx) {
     if (idx->live_chunk_bits) (void)hipFree(idx->live_chunk_bits);
     if (idx->live_row_bits) (void)hipFree(idx->live_row_bits);
     idx->maskbuf.release();
+    idx->qsplit.release();
     select_workspace_free(idx->ws);
     idx->scores.release();
     idx->hits.release();
@@ -894,20 +896,28 @@ int mask_chunk_scores(rl_index* idx, float* d_scores, int32_t nb, int64_t ld, co
     return RL_OK;
 }
 
-// Two queries of the same length in ONE corpus pass (maxsim_stream2_kernel); RL_ERR_UNSUPPORTED when the shape or the
-// index' arithmetic does not allow it -- the caller then makes one pass per query.
-int maxsim_scores_pair_device(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, float* d_out,
-                              int64_t out_stride, hipStream_t s) {
+// Batched MaxSim in fp16-split arithmetic scores two queries per corpus pass (maxsim_stream2_kernel).  pairs_prepare
+// splits `n_queries` queries into fp16 (hi, lo) MFMA fragments once (idx->qsplit); pairs_pass scores queries `first` and
+// `first + 1` of them.  RL_ERR_UNSUPPORTED when the shape or the index' arithmetic does not allow it -- the caller then
+// makes one pass per query.
+int pairs_prepare(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, int32_t n_queries, hipStream_t s) {
     static const bool no_pairs = std::getenv("RAGLITE_NO_QUERY_PAIRS") != nullptr;  // A/B switch
     if (no_pairs || idx->E16 || !idx->E || idx->n_rows == 0 || idx->n_chunks == 0 || !(idx->split_scale > 0.f))
         return RL_ERR_UNSUPPORTED;
-    if (nq <= 16 || nq > 32) return RL_ERR_UNSUPPORTED;
+    if (nq <= 16 || nq > 32 || n_queries < 2) return RL_ERR_UNSUPPORTED;
+    const int32_t d = idx->dim;
+    if (d != 128 && d != 256 && d != 384 && d != 512 && d != 768 && d != 1024) return RL_ERR_UNSUPPORTED;
+    RL_TRY(idx->qsplit.reserve(query_split_bytes(d, n_queries)));
+    return launch_query_split(d_q, d, nq, q_stride, n_queries, idx->qsplit.as<char>(), s);
+}
+
+int pairs_pass(rl_index* idx, int32_t nq, int32_t n_queries, int32_t first, float* d_out, int64_t out_stride, hipStream_t s) {
     if (idx->has_empty_chunk) {
         RL_TRY(launch_fill_f32(d_out, -std::numeric_limits<float>::infinity(), idx->n_chunks, s));
         RL_TRY(launch_fill_f32(d_out + out_stride, -std::numeric_limits<float>::infinity(), idx->n_chunks, s));
     }
-    return launch_maxsim_stream2(idx->E, idx->n_rows, idx->dim, d_q, nq, q_stride, idx->row_to_chunk, idx->offsets,
-                                 idx->n_chunks, d_out, out_stride, idx->n_cu, s, idx->split_scale);
+    return launch_maxsim_stream2(idx->E, idx->n_rows, idx->dim, idx->qsplit.as<char>(), n_queries, first, nq, idx->row_to_chunk,
+                                 idx->offsets, idx->n_chunks, d_out, out_stride, idx->n_cu, s, idx->split_scale);
 }
 
 int maxsim_scores_device(rl_index* idx, const float* d_q, int32_t nq, float* d_out, hipStream_t s) {
@@ -1007,16 +1017,17 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
     // launch's tail behind the next one's ramp and measured +1.5 % at 1 M rows / +3.3 % on a 125 k-row shard, but
     // concurrent kernels stretch each other's durations 3x in a kernel trace, which would make the rocprofv3 summary
     // disagree with the live roofline timing; the serial form keeps every number checkable.)
-    // Two queries share a pass where the arithmetic allows it (fp16-split, 17..32 vectors per query).
-    for (int32_t b = 0; b < n_queries;) {
-        if (b + 1 < n_queries) {
-            const int st = maxsim_scores_pair_device(idx, d_q + (size_t)b * q_elems, nq, (int64_t)q_elems, sc + (int64_t)b * ld, ld, s);
-            if (st == RL_OK) { b += 2; continue; }
-            if (st != RL_ERR_UNSUPPORTED) return st;
-        }
-        RL_TRY(maxsim_scores_device(idx, d_q + (size_t)b * q_elems, nq, sc + (int64_t)b * ld, s));
-        ++b;
+    // Two queries share a pass where the arithmetic allows it (fp16-split, 17..32 vectors per query); an odd query out,
+    // and every query otherwise, takes a pass of its own.
+    int32_t paired = 0;
+    {
+        const int st = pairs_prepare(idx, d_q, nq, (int64_t)q_elems, n_queries & ~1, s);
+        if (st == RL_OK) paired = n_queries & ~1;
+        else if (st != RL_ERR_UNSUPPORTED) return st;
     }
+    for (int32_t b = 0; b < paired; b += 2) RL_TRY(pairs_pass(idx, nq, paired, b, sc + (int64_t)b * ld, ld, s));
+    for (int32_t b = paired; b < n_queries; ++b)
+        RL_TRY(maxsim_scores_device(idx, d_q + (size_t)b * q_elems, nq, sc + (int64_t)b * ld, s));
     RL_TRY(mask_chunk_scores(idx, sc, n_queries, ld, nullptr, s));  // tombstones (no-op without deletions)
     RL_TRY(launch_topk(sc, n_queries, idx->n_chunks, ld, k, idx->ws, d_s, d_c, s));
     if (idx->live_chunk_bits) RL_TRY(launch_fix_masked(d_s, d_c, (int64_t)n_queries * k, s));
@@ -1178,10 +1189,14 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     RL_HIP(hipEventCreate(&e0));
     RL_HIP(hipEventCreate(&e1));
     int st = RL_OK;
+    if (kind == 2) {  // the query fragments are prepared once per batch, outside the pass
+        st = pairs_prepare(idx, q_dev, nq / 2, (int64_t)(nq / 2) * idx->dim, 2, s);
+        if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the pair kernel does not apply to this index / shape") : st; }
+    }
     RL_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < iters && st == RL_OK; ++i) {
         if (kind == 0) st = maxsim_scores_device(idx, q_dev, nq, idx->scores.as<float>(), s);
-        else if (kind == 2) st = maxsim_scores_pair_device(idx, q_dev, nq / 2, (int64_t)(nq / 2) * idx->dim, idx->scores.as<float>(), ldc, s);
+        else if (kind == 2) st = pairs_pass(idx, nq / 2, 2, 0, idx->scores.as<float>(), ldc, s);
         else st = score_rows(idx, q_dev, nq, ld, s);
     }
     RL_HIP(hipEventRecord(e1, s));

@@ -600,9 +600,73 @@ struct Geo2 {
     static constexpr int LDS_TOTAL = OFF_ORD + 4 * 256;             //  tile t-1 is being reduced)  159 744 B at KW = 256
 };
 
+// Query side of the SPLIT arithmetic, done ONCE per query instead of in every corpus pass's prologue (where its ~1.5 k
+// instructions per wave cost ~12 us -- 13 % of a pass over a 125 k-row shard): wave (query, w) scales its K-quarter of the
+// query's vectors to [2^13, 2^14), splits every element into fp16 (hi, lo) and writes the MFMA B fragments in exactly
+// the register layout the pass kernels hold them in:
+//   frag[((((query * 4 + w) * 2 + h) * MS + m) * 2 + part) * 64 + lane]   (16 B: 8 fp16; part 0 = hi, 1 = lo)
+//   meta[(query * 4 + w) * 2 + {0, 1}] = {2^(ex - 14) (undoes the scale), any lo != 0}
+template <int KW>
+__global__ __launch_bounds__(64) void query_split_kernel(const float* __restrict__ Q, int nq, int64_t q_stride,
+                                                          uint4* __restrict__ frag, float* __restrict__ meta) {
+    constexpr int SD = 4 * KW, MS = KW / 32, NQT = 2;
+    const int lane = threadIdx.x, w = blockIdx.x;
+    const int64_t query = blockIdx.y;
+    const float* const Qg = Q + query * q_stride;
+    const int fj = lane & 15, kq = lane >> 4;
+    float mx = 0.f;
+#pragma unroll
+    for (int h = 0; h < NQT; ++h) {
+        const int qi = 16 * h + fj;
+        if (qi < nq)
+            for (int c = 0; c < KW / 4; c += 4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Qg + (int64_t)qi * SD + KW * w + KW / 4 * kq + c);
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    int ex = 0;
+    if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &ex);  // mx = f * 2^ex, f in [0.5, 1)
+    const float q_scale = ldexpf(1.f, 14 - ex);
+    bool any_lo = false;
+    uint4* const out = frag + (query * 4 + w) * (NQT * MS * 2 * 64) + lane;
+#pragma unroll
+    for (int h = 0; h < NQT; ++h) {
+        const int qi = 16 * h + fj;
+        const int qc_ = qi < nq ? qi : nq - 1;  // clamped load, zeroed below: padded query vectors add 0
+#pragma unroll
+        for (int m = 0; m < MS; ++m) {
+            const float* qp = Qg + (int64_t)qc_ * SD + KW * w + 32 * m + 4 * kq;  // k = 16 (2m + (u >> 2)) + 4 kq + (u & 3)
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp), v1 = *reinterpret_cast<const f32x4*>(qp + 16);
+            h16x8 hi8, lo8;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float x = qi < nq ? (u < 4 ? v0[u] : v1[u - 4]) * q_scale : 0.f;
+                const _Float16 hi = (_Float16)x;
+                const _Float16 lo = (_Float16)(x - (float)hi);
+                hi8[u] = hi;
+                lo8[u] = lo;
+                any_lo |= lo != (_Float16)0.0f;
+            }
+            uint4 a, b;
+            __builtin_memcpy(&a, &hi8, 16);
+            __builtin_memcpy(&b, &lo8, 16);
+            out[((h * MS + m) * 2 + 0) * 64] = a;
+            out[((h * MS + m) * 2 + 1) * 64] = b;
+        }
+    }
+    any_lo = __builtin_amdgcn_ballot_w64(any_lo) != 0;
+    if (lane == 0) {
+        meta[(query * 4 + w) * 2 + 0] = ldexpf(1.f, ex - 14);
+        meta[(query * 4 + w) * 2 + 1] = any_lo ? 1.f : 0.f;
+    }
+}
+
 template <int KW, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void maxsim_stream2_kernel(const float* __restrict__ D, int64_t n_rows,
-                                                                  const float* __restrict__ Q, int nq, int64_t q_stride,
+                                                                  const uint4* __restrict__ qfrag,
+                                                                  const float* __restrict__ qmeta, int nq,
                                                                   const int32_t* __restrict__ row_to_chunk,
                                                                   const int64_t* __restrict__ chunk_offsets,
                                                                   int64_t n_chunks, float* __restrict__ out,
@@ -643,51 +707,23 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream2_kernel(const float* __r
     const int32_t r_lo32 = (int32_t)r_lo;
     char* const red = smem + G2::OFF_RED + g * G1::RED_BYTES;
     float* const ST0 = reinterpret_cast<float*>(smem + G2::OFF_ST + 2 * g * G2::ST_BYTES);  // [tile parity][32][20]
-    const float* const Qg = Q + (int64_t)g * q_stride;
 
-    // ---- this wave's slice of its query as (hi, lo) fp16 MFMA B fragments (see SPLIT above) ----------------------------
+    // ---- this wave's slice of its query as (hi, lo) fp16 MFMA B fragments, prepared by query_split_kernel ------------------
     const int fj = lane & 15, kq = lane >> 4;
     h16x8 qhi[NQT][MS], qlo[NQT][MS];
-    bool any_lo = false;
-    float q_unscale;
     {
-        float mx = 0.f;
+        const uint4* const fr = qfrag + (int64_t)(g * 4 + w) * (NQT * MS * 2 * 64) + lane;
 #pragma unroll
-        for (int h = 0; h < NQT; ++h) {
-            const int qi = 16 * h + fj;
-            if (qi < nq)
-                for (int c = 0; c < KW / 4; c += 4) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(Qg + (int64_t)qi * SD + KW * w + KW / 4 * kq + c);
-                    mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-                }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        int ex = 0;
-        if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &ex);
-        const float q_scale = ldexpf(1.f, 14 - ex);
-        q_unscale = ldexpf(1.f, ex - 14) / e_scale;
-#pragma unroll
-        for (int h = 0; h < NQT; ++h) {
-            const int qi = 16 * h + fj;
-            const int qc_ = qi < nq ? qi : nq - 1;
+        for (int h = 0; h < NQT; ++h)
 #pragma unroll
             for (int m = 0; m < MS; ++m) {
-                const float* qp = Qg + (int64_t)qc_ * SD + KW * w + 32 * m + 4 * kq;
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp), v1 = *reinterpret_cast<const f32x4*>(qp + 16);
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float x = qi < nq ? (u < 4 ? v0[u] : v1[u - 4]) * q_scale : 0.f;
-                    const _Float16 hi = (_Float16)x;
-                    const _Float16 lo = (_Float16)(x - (float)hi);
-                    qhi[h][m][u] = hi;
-                    qlo[h][m][u] = lo;
-                    any_lo |= lo != (_Float16)0.0f;
-                }
+                const uint4 x = fr[((h * MS + m) * 2 + 0) * 64], y = fr[((h * MS + m) * 2 + 1) * 64];
+                __builtin_memcpy(&qhi[h][m], &x, 16);
+                __builtin_memcpy(&qlo[h][m], &y, 16);
             }
-        }
-        any_lo = __builtin_amdgcn_ballot_w64(any_lo) != 0;
     }
+    const float q_unscale = qmeta[(g * 4 + w) * 2 + 0] / e_scale;
+    const bool any_lo = __builtin_amdgcn_readfirstlane(__float_as_int(qmeta[(g * 4 + w) * 2 + 1])) != 0;
     const char* const a_base = smem + fj * PITCH + w * G1::QBYTES + kq * 16;
 
     // ---- this wave's share of the DMA stream: rows 2 wv, 2 wv + 1 of every tile ------------------------------------------
@@ -1024,12 +1060,37 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
 
 // Two queries (17..32 vectors each, q_stride floats apart) per corpus pass over an fp32 corpus in SPLIT arithmetic:
 // out[g * out_stride + chunk], g = 0, 1.  RL_ERR_UNSUPPORTED outside that shape (the caller then makes two passes).
-int launch_maxsim_stream2(const float* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq, int64_t q_stride,
-                          const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, float* out,
-                          int64_t out_stride, int n_cu, hipStream_t s, float split_scale) {
-    if (nq <= 16 || nq > 32 || n_rows < 1 || !(split_scale > 0.f)) return RL_ERR_UNSUPPORTED;
+// SPLIT query fragments for `n_queries` queries of nq (17..32) vectors, q_stride floats apart (see query_split_kernel).
+size_t query_split_bytes(int32_t dim, int32_t n_queries) { return (size_t)n_queries * (4 * 2 * (dim / 128) * 2 * 64 * 16 + 64); }
+int launch_query_split(const float* Q, int32_t dim, int32_t nq, int64_t q_stride, int32_t n_queries, void* buf, hipStream_t s) {
+    if (nq <= 16 || nq > 32 || n_queries < 1) return RL_ERR_UNSUPPORTED;
     if (dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024) return RL_ERR_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
+    uint4* frag = static_cast<uint4*>(buf);
+    float* meta = reinterpret_cast<float*>(static_cast<char*>(buf) + (size_t)n_queries * (4 * 2 * (dim / 128) * 2 * 64 * 16));
+    const dim3 grid(4, (unsigned)n_queries), blk(64);
+#define RL_QS(KW) hipLaunchKernelGGL((query_split_kernel<KW>), grid, blk, 0, s, Q, (int)nq, q_stride, frag, meta)
+    switch (dim) {
+        case 128: RL_QS(32); break; case 256: RL_QS(64); break; case 384: RL_QS(96); break;
+        case 512: RL_QS(128); break; case 768: RL_QS(192); break; default: RL_QS(256); break;
+    }
+#undef RL_QS
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// Two queries (17..32 vectors each; queries `first`, `first + 1` of a launch_query_split buffer over `n_queries`) per corpus
+// pass over an fp32 corpus in SPLIT arithmetic: out[g * out_stride + chunk], g = 0, 1.  RL_ERR_UNSUPPORTED outside that
+// shape (the caller then makes one pass per query).
+int launch_maxsim_stream2(const float* D, int64_t n_rows, int32_t dim, const void* split_buf, int32_t n_queries, int32_t first,
+                          int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, float* out,
+                          int64_t out_stride, int n_cu, hipStream_t s, float split_scale) {
+    if (nq <= 16 || nq > 32 || n_rows < 1 || !(split_scale > 0.f) || first < 0 || first + 2 > n_queries) return RL_ERR_UNSUPPORTED;
+    if (dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024) return RL_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(D) & 15) return RL_ERR_UNSUPPORTED;
+    const size_t per_query = (size_t)4 * 2 * (dim / 128) * 2 * 64;  // uint4 per query
+    const uint4* qfrag = static_cast<const uint4*>(split_buf) + (size_t)first * per_query;
+    const float* qmeta = reinterpret_cast<const float*>(static_cast<const char*>(split_buf) + (size_t)n_queries * per_query * 16) + (size_t)first * 8;
     const int64_t tiles = (n_rows + TR - 1) / TR;
     const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
     static unsigned long long* trace = [] {
@@ -1039,7 +1100,7 @@ int launch_maxsim_stream2(const float* D, int64_t n_rows, int32_t dim, const flo
     }();
     if (trace && dim == 1024) {  // diagnostic build: dump the 30th launch's tile timeline to stderr
         static int calls = 0;
-        hipLaunchKernelGGL((maxsim_stream2_kernel<256, true>), grid, blk, 0, s, D, n_rows, Q, (int)nq, q_stride, row_to_chunk,
+        hipLaunchKernelGGL((maxsim_stream2_kernel<256, true>), grid, blk, 0, s, D, n_rows, qfrag, qmeta, (int)nq, row_to_chunk,
                            chunk_offsets, n_chunks, out, out_stride, split_scale, trace);
         if (++calls == 30) {
             unsigned long long h[512];
@@ -1055,7 +1116,7 @@ int launch_maxsim_stream2(const float* D, int64_t n_rows, int32_t dim, const flo
         }
         return RL_OK;
     }
-#define RL_STREAM2(KW) hipLaunchKernelGGL((maxsim_stream2_kernel<KW>), grid, blk, 0, s, D, n_rows, Q, (int)nq, q_stride, \
+#define RL_STREAM2(KW) hipLaunchKernelGGL((maxsim_stream2_kernel<KW>), grid, blk, 0, s, D, n_rows, qfrag, qmeta, (int)nq, \
                                           row_to_chunk, chunk_offsets, n_chunks, out, out_stride, split_scale, nullptr)
     switch (dim) {
         case 128: RL_STREAM2(32); break; case 256: RL_STREAM2(64); break; case 384: RL_STREAM2(96); break;
