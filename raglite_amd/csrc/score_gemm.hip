@@ -27,6 +27,7 @@
 namespace rl {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 constexpr int GM = 128;                 // queries per tile
@@ -36,12 +37,31 @@ constexpr int NSLOT = 4;                // LDS ring
 constexpr int OP_BYTES = 128 * GK * 4;  // one operand of one slab: 128 rows x 128 B = 16 KiB
 constexpr int SLAB_BYTES = 2 * OP_BYTES;
 
+// 8 fp32 values (two fragment reads) scaled by a power of two -> exact fp16 (hi, lo) pairs, as in maxsim_stream.hip:
+// x*s = hi + lo, hi = fp16_rtz(x*s), lo = fp16_rtz(x*s - hi).
+__device__ __forceinline__ void split8(const f32x4& A0, const f32x4& A1, float s, h16x8& hi, h16x8& lo) {
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+        const float x0 = (u < 4 ? A0[u] : A1[u - 4]) * s, x1 = (u < 4 ? A0[u + 1] : A1[u - 3]) * s;
+        const auto ph = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+        const auto pl = __builtin_amdgcn_cvt_pkrtz(x0 - (float)ph[0], x1 - (float)ph[1]);
+        hi[u] = ph[0]; hi[u + 1] = ph[1];
+        lo[u] = pl[0]; lo[u + 1] = pl[1];
+    }
+}
+
+// SPLIT = the fp16 (hi, lo) arithmetic of include/raglite_hip.h (RL_ARITH_F16_SPLIT): per K slab and 16 x 16 tile three
+// v_mfma_f32_16x16x32_f16 (16 cycles each) replace eight v_mfma_f32_16x16x4_f32 (32 cycles each); the corpus is scaled by
+// the index' power of two `e_scale`, every query by one of its own (`q_scale[b]`, from query_scale_kernel), both undone on
+// the accumulators before the metric is applied.
+template <bool SPLIT>
 __global__ __launch_bounds__(384) void score_gemm_kernel(const float* __restrict__ E, int64_t n_rows, int32_t dim,
                                                          const float* __restrict__ Q, int32_t B,
                                                          float* __restrict__ S, int64_t ld, int64_t n_tiles,
                                                          int32_t QT, const float* __restrict__ row_norm,
                                                          const float* __restrict__ row_sumsq,
-                                                         const float* __restrict__ q_sumsq, int mode) {
+                                                         const float* __restrict__ q_sumsq, int mode,
+                                                         float e_scale, const float* __restrict__ q_scale) {
     __shared__ __attribute__((aligned(16))) char smem[NSLOT * SLAB_BYTES];
     const int lane = threadIdx.x & 63;
     const int wv = wave_id();
@@ -72,7 +92,20 @@ __global__ __launch_bounds__(384) void score_gemm_kernel(const float* __restrict
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int it = 0, sl = 0;
+        [[maybe_unused]] float qs[4] = {1.f, 1.f, 1.f, 1.f};  // SPLIT: scale of the query this lane holds in Q fragment c
         for (int g = 0; g < total; ++g) {
+            if constexpr (SPLIT) {
+                if (sl == 0) {  // new tile
+                    int64_t row0;
+                    int32_t q0;
+                    decode(it, row0, q0);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int32_t q = q0 + 64 * wy + 16 * c + fj;
+                        qs[c] = q_scale[q < B ? q : B - 1];
+                    }
+                }
+            }
             asm volatile("s_barrier" ::: "memory");  // slab g has landed (the loaders waited on their vmcnt)
             const char* base = smem + (g & (NSLOT - 1)) * SLAB_BYTES;
             f32x4 ea[2][4], qa[2][4];
@@ -84,15 +117,36 @@ __global__ __launch_bounds__(384) void score_gemm_kernel(const float* __restrict
 #pragma unroll
                 for (int c = 0; c < 4; ++c) qa[kk][c] = *reinterpret_cast<const f32x4*>(base + q_off + c * 2048 + sw);
             }
+            if constexpr (SPLIT) {
+                // lane (fj, kq) holds k = 4 kq .. 4 kq + 3 and 16 + 4 kq .. of its row: the same 8 positions in both operands
+                h16x8 eh[4], el[4], qh[4], ql[4];
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+                for (int a = 0; a < 4; ++a) split8(ea[0][a], ea[1][a], e_scale, eh[a], el[a]);
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt)
+                for (int c = 0; c < 4; ++c) split8(qa[0][c], qa[1][c], qs[c], qh[c], ql[c]);
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < 4; ++a)
 #pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[kk][a][tt], qa[kk][c][tt], acc[a][c], 0, 0, 0);
+                    for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh[a], qh[c], acc[a][c], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(el[a], qh[c], acc[a][c], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh[a], ql[c], acc[a][c], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[kk][a][tt], qa[kk][c][tt], acc[a][c], 0, 0, 0);
+            }
             if (++sl == nslab) {
                 // tile done: C/D layout of 16x16x4 -- lane (16 gq + j) holds rows 4 gq .. 4 gq + 3 of column (query) j
                 int64_t row0;
@@ -115,13 +169,15 @@ __global__ __launch_bounds__(384) void score_gemm_kernel(const float* __restrict
                     const int32_t q = q0 + 64 * wy + 16 * c + j;
                     const float qss = (mode == SCAN_COSINE || mode == SCAN_L2) ? q_sumsq[q < B ? q : B - 1] : 0.f;
                     const float qn = sqrtf(qss);
+                    [[maybe_unused]] float unscale = 1.f;
+                    if constexpr (SPLIT) unscale = 1.0f / (e_scale * q_scale[q < B ? q : B - 1]);  // powers of two: exact
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         const int64_t r = row0 + 64 * wx + 16 * a + 4 * gq;
                         f32x4 v = acc[a][c];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            const float d = v[u];
+                            const float d = SPLIT ? v[u] * unscale : v[u];
                             if (mode == SCAN_COSINE) v[u] = 1.0f - (1.0f - d / (rn[a][u] * qn));
                             else if (mode == SCAN_DOT) v[u] = 1.0f + d;
                             else if (mode == SCAN_L2) v[u] = 1.0f - sqrtf(fmaxf(rn[a][u] + qss - 2.0f * d, 0.f));
@@ -214,13 +270,31 @@ __global__ __launch_bounds__(256) void query_sumsq_kernel(const float* __restric
     __syncthreads();
     if (threadIdx.x == 0) q_sumsq[b] = (part[0] + part[1]) + (part[2] + part[3]);
 }
+// SPLIT arithmetic: q_scale[b] = the power of two that brings query b's largest |element| into [2^13, 2^14).
+__global__ __launch_bounds__(256) void query_scale_kernel(const float* __restrict__ queries, int dim, float* __restrict__ q_scale) {
+    __shared__ float part[4];
+    const int b = blockIdx.x;
+    float mx = 0.f;
+    for (int c = threadIdx.x; c < dim; c += 256) mx = fmaxf(mx, fabsf(queries[(int64_t)b * dim + c]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+        int ex = 0;
+        if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &ex);
+        q_scale[b] = ldexpf(1.f, 14 - (ex > -100 ? ex : -100));
+    }
+}
 }  // namespace
 
 // Similarity (metric `mode`, scan.hip conventions) of nb queries against every row; dim % 32 == 0, 16-B aligned
 // operands.  q_sumsq_scratch: device float[nb] (cosine / l2 only).
+// split_scale > 0: fp16-split arithmetic with the corpus scaled by that power of two (q_sumsq_scratch then holds 2 nb floats).
 int launch_score_gemm(const float* E, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores,
                       int64_t ld, const float* row_norm, const float* row_sumsq, float* q_sumsq_scratch, int mode,
-                      int n_cu, hipStream_t s) {
+                      int n_cu, hipStream_t s, float split_scale) {
     if (nb < 1 || n_rows < 1 || dim < GK || dim % GK != 0) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(E) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
     if ((mode == SCAN_COSINE && !row_norm) || (mode == SCAN_L2 && !row_sumsq)) return RL_ERR_INVALID;
@@ -228,12 +302,18 @@ int launch_score_gemm(const float* E, int64_t n_rows, int32_t dim, const float* 
     const int32_t QT = (nb + GM - 1) / GM;
     const int64_t n_tiles = ((RT + 7) / 8) * 8 * QT;  // row tiles padded to a multiple of 8 (one residue class per XCD)
     const int grid = (int)std::min<int64_t>(n_cu > 0 ? n_cu : 256, n_tiles);
-    if (mode == SCAN_COSINE || mode == SCAN_L2) {
-        if (!q_sumsq_scratch) return RL_ERR_INVALID;
+    if (!q_sumsq_scratch && (mode == SCAN_COSINE || mode == SCAN_L2 || split_scale > 0.f)) return RL_ERR_INVALID;
+    if (mode == SCAN_COSINE || mode == SCAN_L2)
         hipLaunchKernelGGL(query_sumsq_kernel, dim3(nb), dim3(256), 0, s, Q, (int)dim, q_sumsq_scratch);
+    if (split_scale > 0.f) {
+        float* q_scale = q_sumsq_scratch + nb;
+        hipLaunchKernelGGL(query_scale_kernel, dim3(nb), dim3(256), 0, s, Q, (int)dim, q_scale);
+        hipLaunchKernelGGL(score_gemm_kernel<true>, dim3(grid), dim3(384), 0, s, E, n_rows, dim, Q, nb, scores, ld, n_tiles, QT,
+                           row_norm, row_sumsq, q_sumsq_scratch, mode, split_scale, q_scale);
+    } else {
+        hipLaunchKernelGGL(score_gemm_kernel<false>, dim3(grid), dim3(384), 0, s, E, n_rows, dim, Q, nb, scores, ld, n_tiles, QT,
+                           row_norm, row_sumsq, q_sumsq_scratch, mode, 0.f, nullptr);
     }
-    hipLaunchKernelGGL(score_gemm_kernel, dim3(grid), dim3(384), 0, s, E, n_rows, dim, Q, nb, scores, ld, n_tiles, QT,
-                       row_norm, row_sumsq, q_sumsq_scratch, mode);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -84,6 +84,16 @@ int main(void) {
     CHECK(rl_search_rows(idx, q, 1, K, s, r, RL_MEM_HOST, NULL));
     EXPECT(r[0] == 7 && r[1] == 263 && r[4] == N); /* 135 is gone, the appended row N ties with the others */
 
+    /* arithmetic of the MFMA streaming kernels: this corpus (row maxima 1..5, all finite) gets the fp16 split by default */
+    int arith = -1;
+    CHECK(rl_index_arithmetic(idx, &arith));
+    EXPECT(arith == RL_ARITH_F16_SPLIT);
+    CHECK(rl_index_set_arithmetic(idx, RL_ARITH_FP32_EXACT));
+    CHECK(rl_index_arithmetic(idx, &arith));
+    EXPECT(arith == RL_ARITH_FP32_EXACT);
+    EXPECT(rl_index_set_arithmetic(idx, 77) != RL_OK);
+    CHECK(rl_index_set_arithmetic(idx, RL_ARITH_AUTO));
+
     /* MaxSim: two query vectors e_7 and e_9 -> chunk 1 (rows 4..7) scores 1*1 + 0, chunk 2 (rows 8..11) 0 + 1 ... */
     float Q2[2 * D];
     memset(Q2, 0, sizeof(Q2));
