@@ -8,10 +8,13 @@ vectors, d = 1024, fp32, exact top-100 chunks -- the shape `metric` is quoted on
 synthetic U(-1,1) (counter-based generator, identical bits on CPU and GPU) grouped into ragged chunks
 of 1..15 rows (mean 8, RAGLite's multi-vector chunks), resident in HBM before the timed region.
 
-A step = one batch of QUERIES_PER_STEP queries pushed through the hot path: per query one
-`rl_maxsim_topk` (MFMA streaming kernel + exact selection) on device pointers, then per batch the
-exchange step (N > 1: ONE RCCL all-gather of every rank's local top-k, (QB, k, 2) int32) and the host
-merge.  value = queries / second over the whole job.
+A step = one batch of QUERIES_PER_STEP queries pushed through the hot path (`rl_maxsim_topk_batch` on
+device pointers): the queries' fp16 (hi, lo) fragments once, one corpus pass of the MFMA streaming kernel
+per TWO queries (per query with the exact-fp32 arithmetic), one batched exact selection, then the
+exchange step (N > 1: ONE RCCL all-gather of every rank's local top-k, (QB, k, 2) int32) and the device
+merge.  value = queries / second over the whole job.  (128 queries per step: selection and exchange
+are per-step costs, 8 % of a step on a 125 k-row shard at 32 queries per step, 2 % at 128; at N = 1
+the rate does not depend on it.)
 
 N > 1: the 1 M-row corpus is sharded by chunk across the ranks (strong scaling on the metric's own
 shape); every rank receives the same queries.
@@ -36,7 +39,7 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 N_ROWS, DIM, NQ, TOPK = 1_000_000, 1024, 32, 100
-QUERIES_PER_STEP = 32
+QUERIES_PER_STEP = 128
 SEED_CORPUS, SEED_QUERY, SEED_CHUNKS = 6, 60, 600
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -61,6 +64,7 @@ def main() -> None:
     # NOT the BASELINE.json configuration (that one is fp32, the default): the fp16-stored index of SURVEY.md 8f-1,
     # reported under its own workload name so it can never be mistaken for the headline number.
     ap.add_argument("--storage", choices=("f32", "f16"), default="f32", help=argparse.SUPPRESS)
+    ap.add_argument("--queries-per-step", type=int, default=QUERIES_PER_STEP, help=argparse.SUPPRESS)
     # A/B: the exact fp32 MFMA chain instead of the default fp16 (hi, lo) split of the fp32 operands
     ap.add_argument("--exact-fp32", action="store_true", help=argparse.SUPPRESS)
     # Test hooks for the N > 1 code path on a ONE-GPU box (scripts/test_multirank_one_gpu.sh): every rank uses cuda:0
@@ -71,6 +75,8 @@ def main() -> None:
 
     import torch
     import torch.distributed as dist
+
+    qps = args.queries_per_step
 
     import raglite_amd
     from raglite_amd._sharded import ShardedIndex, shard_bounds_by_chunk
@@ -108,7 +114,7 @@ def main() -> None:
     arithmetic = index.arithmetic
     sharded = ShardedIndex(index, row_base=r_lo, chunk_base=c_lo, local_chunk_offsets=local_off)
     n_batches = 4  # distinct query batches, cycled
-    queries = torch.empty((n_batches, QUERIES_PER_STEP, NQ, DIM), dtype=torch.float32, device=dev)
+    queries = torch.empty((n_batches, qps, NQ, DIM), dtype=torch.float32, device=dev)
     raglite_amd.synth_fill(queries, seed=SEED_QUERY)
     torch.cuda.synchronize()
 
@@ -134,13 +140,13 @@ def main() -> None:
     ev1.record()
     fence()
     elapsed = time.perf_counter() - t0
-    region_ms_per_pass = ev0.elapsed_time(ev1) / (args.steps * QUERIES_PER_STEP)
+    region_ms_per_pass = ev0.elapsed_time(ev1) / (args.steps * qps)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    total_queries = args.steps * QUERIES_PER_STEP
+    total_queries = args.steps * qps
     result = {
         "metric": "queries/sec, MaxSim 32x1M d=1024 exact top-100",
         "value": total_queries / elapsed,
@@ -160,7 +166,7 @@ def main() -> None:
         "config": {
             "workload": f"maxsim_{NQ}x{n_rows}_d{DIM}_top{TOPK}_ragged_chunks_1to15"
                         + ("" if args.storage == "f32" else "_F16_STORED_CORPUS_not_the_baseline_config"),
-            "queries_per_step": QUERIES_PER_STEP,
+            "queries_per_step": qps,
             "n_chunks": int(len(off) - 1),
             "parallelism": f"corpus sharded by chunk over {world} GPU(s); per step one all-gather of local top-k + device merge, no host sync",
         },
@@ -205,7 +211,7 @@ def main() -> None:
         # split arithmetic is not bound by (its products run on the fp16 matrix pipe, 3 MFMAs per exact-fp32-equivalent)
         "useful_tflops": useful_tflops, "useful_tflops_over_fp32_mfma_peak": useful_tflops / 157.3,
     }
-    result["config"]["corpus_passes_per_step"] = QUERIES_PER_STEP // queries_per_launch
+    result["config"]["corpus_passes_per_step"] = qps // queries_per_launch
 
     # ---- recall@100 and CPU baseline: NumPy oracle on the host cores (rank 0, N = 1) --------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
