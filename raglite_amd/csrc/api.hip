@@ -736,7 +736,7 @@ int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStrea
         return launch_transform(sc, nb, idx->n_rows, ld, idx->norm, idx->sumsq, d_q, idx->dim, mode, s);
     }
     if (nb >= GEMM_MIN_QUERIES) {  // MFMA-bound regime: one 128 x 128-tiled GEMM instead of a corpus pass per 32 queries
-        RL_TRY(idx->misc.reserve((size_t)2 * nb * sizeof(float)));
+        RL_TRY(idx->misc.reserve(score_gemm_scratch_floats(nb, idx->dim, idx->split_scale > 0.f) * sizeof(float)));
         const int st = launch_score_gemm(idx->E, idx->n_rows, idx->dim, d_q, nb, sc, ld, idx->norm, idx->sumsq,
                                          idx->misc.as<float>(), mode, idx->n_cu, s, idx->split_scale);
         if (st != RL_ERR_UNSUPPORTED) return st;

@@ -171,7 +171,8 @@ int launch_row_range(const float* E, int64_t n_rows, int32_t dim, uint32_t* rang
 // score_gemm.hip: similarity of many queries at once (fp32 MFMA GEMM, 128 x 128 tiles, fused metric); dim % 32 == 0.
 int launch_score_gemm(const float* E, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores,
                       int64_t ld, const float* row_norm, const float* row_sumsq, float* q_sumsq_scratch, int mode,
-                      int n_cu, hipStream_t s, float split_scale = 0.f);  // scratch: 2 * nb floats
+                      int n_cu, hipStream_t s, float split_scale = 0.f);
+size_t score_gemm_scratch_floats(int32_t nb, int32_t dim, bool split);
 // the same over an fp16-stored corpus
 int launch_maxsim_stream16(const uint16_t* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
                            const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,

@@ -92,23 +92,9 @@ __global__ __launch_bounds__(384) void score_gemm_kernel(const float* __restrict
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int it = 0, sl = 0;
-        [[maybe_unused]] float qs[4] = {1.f, 1.f, 1.f, 1.f};  // SPLIT: scale of the query this lane holds in Q fragment c
-        for (int g = 0; g < total; ++g) {
-            if constexpr (SPLIT) {
-                if (sl == 0) {  // new tile
-                    int64_t row0;
-                    int32_t q0;
-                    decode(it, row0, q0);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const int32_t q = q0 + 64 * wy + 16 * c + fj;
-                        qs[c] = q_scale[q < B ? q : B - 1];
-                    }
-                }
-            }
-            asm volatile("s_barrier" ::: "memory");  // slab g has landed (the loaders waited on their vmcnt)
+        // Slab g's fragments: 16 ds_read_b128 (8 E + 8 Q; each E read is good for 4 fp32 k-steps / half an fp16 MFMA operand).
+        auto read_slab = [&](int g, f32x4 (&ea)[2][4], f32x4 (&qa)[2][4]) {
             const char* base = smem + (g & (NSLOT - 1)) * SLAB_BYTES;
-            f32x4 ea[2][4], qa[2][4];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
                 const uint32_t sw = kk ? sw1 : sw0;
@@ -117,37 +103,8 @@ __global__ __launch_bounds__(384) void score_gemm_kernel(const float* __restrict
 #pragma unroll
                 for (int c = 0; c < 4; ++c) qa[kk][c] = *reinterpret_cast<const f32x4*>(base + q_off + c * 2048 + sw);
             }
-            if constexpr (SPLIT) {
-                // lane (fj, kq) holds k = 4 kq .. 4 kq + 3 and 16 + 4 kq .. of its row: the same 8 positions in both operands
-                h16x8 eh[4], el[4], qh[4], ql[4];
-#pragma unroll
-                for (int a = 0; a < 4; ++a) split8(ea[0][a], ea[1][a], e_scale, eh[a], el[a]);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) split8(qa[0][c], qa[1][c], qs[c], qh[c], ql[c]);
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh[a], qh[c], acc[a][c], 0, 0, 0);
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(el[a], qh[c], acc[a][c], 0, 0, 0);
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh[a], ql[c], acc[a][c], 0, 0, 0);
-            } else {
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                    for (int tt = 0; tt < 4; ++tt)
-#pragma unroll
-                        for (int a = 0; a < 4; ++a)
-#pragma unroll
-                            for (int c = 0; c < 4; ++c)
-                                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[kk][a][tt], qa[kk][c][tt], acc[a][c], 0, 0, 0);
-            }
-            if (++sl == nslab) {
+        };
+        auto tile_done = [&]() {
                 // tile done: C/D layout of 16x16x4 -- lane (16 gq + j) holds rows 4 gq .. 4 gq + 3 of column (query) j
                 int64_t row0;
                 int32_t q0;
@@ -195,8 +152,78 @@ __global__ __launch_bounds__(384) void score_gemm_kernel(const float* __restrict
                         acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
                     }
                 }
+        };
+        auto mma_slab = [&](const f32x4 (&ea)[2][4], const f32x4 (&qa)[2][4]) {
+            if constexpr (SPLIT) {
+                // lane (fj, kq) holds k = 4 kq .. 4 kq + 3 and 16 + 4 kq .. of its row: the same 8 positions in both operands.
+                // The query operand arrives pre-split (query_presplit_kernel): chunk kq of a row's 128-B slab piece holds the 8 hi
+                // halves of exactly those positions, chunk 4 + kq the 8 lo halves.
+                h16x8 eh[4], el[4], qh[4], ql[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    __builtin_memcpy(&qh[c], &qa[0][c], 16);
+                    __builtin_memcpy(&ql[c], &qa[1][c], 16);
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) split8(ea[0][a], ea[1][a], e_scale, eh[a], el[a]);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh[a], qh[c], acc[a][c], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(el[a], qh[c], acc[a][c], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh[a], ql[c], acc[a][c], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c)
+                                acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(ea[kk][a][tt], qa[kk][c][tt], acc[a][c], 0, 0, 0);
+            }
+            if (++sl == nslab) {
+                tile_done();
                 sl = 0;
                 ++it;
+            }
+        };
+        if constexpr (SPLIT) {
+            // Software pipeline over two register sets: slab g's fragments are read (16 ds_read_b128, ~0.6-0.9 k cycles of LDS
+            // time) while slab g-1 is converted and multiplied -- with the fp16 MFMAs a slab's arithmetic is only ~1.2 k cycles,
+            // so the reads no longer hide behind it as they do behind 4.1 k cycles of fp32 MFMAs.  Every read of slab g-1 has
+            // completed (lgkmcnt(0)) before this wave reaches barrier g, which is what lets the loaders refill its slot.
+            f32x4 eaA[2][4], qaA[2][4], eaB[2][4], qaB[2][4];
+            int g = 0;
+            for (; g + 1 < total; g += 2) {
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                read_slab(g, eaA, qaA);
+                if (g > 0) mma_slab(eaB, qaB);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                read_slab(g + 1, eaB, qaB);
+                mma_slab(eaA, qaA);
+            }
+            if (g < total) {  // odd number of slabs: one more read into A
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                read_slab(g, eaA, qaA);
+                if (g > 0) mma_slab(eaB, qaB);
+                mma_slab(eaA, qaA);
+            } else if (total > 0) {
+                mma_slab(eaB, qaB);
+            }
+        } else {
+            for (int g = 0; g < total; ++g) {
+                asm volatile("s_barrier" ::: "memory");  // slab g has landed (the loaders waited on their vmcnt)
+                f32x4 ea[2][4], qa[2][4];
+                read_slab(g, ea, qa);
+                mma_slab(ea, qa);
             }
         }
         return;
@@ -270,28 +297,54 @@ __global__ __launch_bounds__(256) void query_sumsq_kernel(const float* __restric
     __syncthreads();
     if (threadIdx.x == 0) q_sumsq[b] = (part[0] + part[1]) + (part[2] + part[3]);
 }
-// SPLIT arithmetic: q_scale[b] = the power of two that brings query b's largest |element| into [2^13, 2^14).
-__global__ __launch_bounds__(256) void query_scale_kernel(const float* __restrict__ queries, int dim, float* __restrict__ q_scale) {
+// SPLIT arithmetic, query side, once per batch: q_scale[b] = the power of two that brings query b's largest |element|
+// into [2^13, 2^14), and Qs = the scaled query as fp16 (hi, lo) pairs in the GEMM's slab layout -- the 128 B that hold
+// k = 32 s .. 32 s + 31 of a row become 8 chunks of 16 B: chunk kq (0..3) = hi of k = 32 s + {4 kq .. 4 kq + 3, 16 + 4 kq ..
+// 16 + 4 kq + 3}, chunk 4 + kq = the lo halves of the same positions: exactly what lane (., kq) of a compute wave holds of E.
+// Same bytes per row as the fp32 query, so the loaders move it unchanged.
+__global__ __launch_bounds__(256) void query_presplit_kernel(const float* __restrict__ queries, int dim, float* __restrict__ q_scale,
+                                                             uint4* __restrict__ Qs) {
     __shared__ float part[4];
     const int b = blockIdx.x;
+    const float* q = queries + (int64_t)b * dim;
     float mx = 0.f;
-    for (int c = threadIdx.x; c < dim; c += 256) mx = fmaxf(mx, fabsf(queries[(int64_t)b * dim + c]));
+    for (int c = threadIdx.x; c < dim; c += 256) mx = fmaxf(mx, fabsf(q[c]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        mx = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-        int ex = 0;
-        if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &ex);
-        q_scale[b] = ldexpf(1.f, 14 - (ex > -100 ? ex : -100));
+    mx = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    int ex = 0;
+    if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &ex);
+    const float sc = ldexpf(1.f, 14 - (ex > -100 ? ex : -100));
+    if (threadIdx.x == 0) q_scale[b] = sc;
+    // one thread per (slab, kq): 8 elements -> one hi chunk and one lo chunk
+    for (int t = threadIdx.x; t < dim / 8; t += 256) {
+        const int sl = t >> 2, kq = t & 3;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(q + 32 * sl + 4 * kq), v1 = *reinterpret_cast<const f32x4*>(q + 32 * sl + 16 + 4 * kq);
+        h16x8 hi, lo;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float x = (u < 4 ? v0[u] : v1[u - 4]) * sc;
+            const _Float16 h = (_Float16)x;
+            hi[u] = h;
+            lo[u] = (_Float16)(x - (float)h);
+        }
+        uint4 a, c;
+        __builtin_memcpy(&a, &hi, 16);
+        __builtin_memcpy(&c, &lo, 16);
+        uint4* row = Qs + (int64_t)b * (dim / 4) + sl * 8;
+        row[kq] = a;
+        row[4 + kq] = c;
     }
 }
 }  // namespace
 
 // Similarity (metric `mode`, scan.hip conventions) of nb queries against every row; dim % 32 == 0, 16-B aligned
 // operands.  q_sumsq_scratch: device float[nb] (cosine / l2 only).
-// split_scale > 0: fp16-split arithmetic with the corpus scaled by that power of two (q_sumsq_scratch then holds 2 nb floats).
+// split_scale > 0: fp16-split arithmetic with the corpus scaled by that power of two; q_sumsq_scratch then holds
+// score_gemm_scratch_floats(nb, dim) floats: q_sumsq, q_scale and the pre-split queries.
+size_t score_gemm_scratch_floats(int32_t nb, int32_t dim, bool split) { return split ? (size_t)nb * (dim + 8) + 8 : (size_t)nb; }
 int launch_score_gemm(const float* E, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores,
                       int64_t ld, const float* row_norm, const float* row_sumsq, float* q_sumsq_scratch, int mode,
                       int n_cu, hipStream_t s, float split_scale) {
@@ -307,8 +360,10 @@ int launch_score_gemm(const float* E, int64_t n_rows, int32_t dim, const float* 
         hipLaunchKernelGGL(query_sumsq_kernel, dim3(nb), dim3(256), 0, s, Q, (int)dim, q_sumsq_scratch);
     if (split_scale > 0.f) {
         float* q_scale = q_sumsq_scratch + nb;
-        hipLaunchKernelGGL(query_scale_kernel, dim3(nb), dim3(256), 0, s, Q, (int)dim, q_scale);
-        hipLaunchKernelGGL(score_gemm_kernel<true>, dim3(grid), dim3(384), 0, s, E, n_rows, dim, Q, nb, scores, ld, n_tiles, QT,
+        float* Qs = q_sumsq_scratch + (((size_t)2 * nb + 7) & ~(size_t)7);  // 32-B aligned behind q_sumsq and q_scale
+        if (reinterpret_cast<uintptr_t>(Qs) & 15) return RL_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(query_presplit_kernel, dim3(nb), dim3(256), 0, s, Q, (int)dim, q_scale, reinterpret_cast<uint4*>(Qs));
+        hipLaunchKernelGGL(score_gemm_kernel<true>, dim3(grid), dim3(384), 0, s, E, n_rows, dim, Qs, nb, scores, ld, n_tiles, QT,
                            row_norm, row_sumsq, q_sumsq_scratch, mode, split_scale, q_scale);
     } else {
         hipLaunchKernelGGL(score_gemm_kernel<false>, dim3(grid), dim3(384), 0, s, E, n_rows, dim, Q, nb, scores, ld, n_tiles, QT,
