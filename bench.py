@@ -177,7 +177,7 @@ def main() -> None:
     # other arithmetics make one pass per query (maxsim_stream_kernel).  Either way one launch = one corpus pass.
     iters = 20
     queries_per_launch, kind, qv = 1, 0, queries[0, 0]
-    if arithmetic == "f16_split":
+    if arithmetic in ("f16_split", "f16_stored"):
         try:
             index.time_kernel(2, queries[0, :2].reshape(2 * NQ, DIM), 3)
             queries_per_launch, kind, qv = 2, 2, queries[0, :2].reshape(2 * NQ, DIM)
@@ -197,7 +197,8 @@ def main() -> None:
     useful_tflops = 2.0 * queries_per_launch * NQ * (r_hi - r_lo) * DIM / (ms * 1e-3) / 1e12
     result["roofline"] = {
         "bound": "hbm",
-        "kernel": ("rl::maxsim_stream2_kernel<256, false>" if queries_per_launch == 2 else
+        "kernel": (("rl::maxsim_stream2_kernel<256, false, true>" if arithmetic == "f16_stored" else "rl::maxsim_stream2_kernel<256, false, false>")
+                   if queries_per_launch == 2 else
                    {"fp32_exact": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, false>",
                     "f16_split": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, true>",
                     "f16_stored": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, true, false>"}[arithmetic]) + " (as rocprofv3 names it)",

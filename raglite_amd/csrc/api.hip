@@ -902,13 +902,13 @@ int mask_chunk_scores(rl_index* idx, float* d_scores, int32_t nb, int64_t ld, co
 // makes one pass per query.
 int pairs_prepare(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, int32_t n_queries, hipStream_t s) {
     static const bool no_pairs = std::getenv("RAGLITE_NO_QUERY_PAIRS") != nullptr;  // A/B switch
-    if (no_pairs || idx->E16 || !idx->E || idx->n_rows == 0 || idx->n_chunks == 0 || !(idx->split_scale > 0.f))
-        return RL_ERR_UNSUPPORTED;
+    if (no_pairs || idx->n_rows == 0 || idx->n_chunks == 0) return RL_ERR_UNSUPPORTED;
+    if (!idx->E16 && !(idx->E && idx->split_scale > 0.f)) return RL_ERR_UNSUPPORTED;  // fp16-stored, or fp32 in split arithmetic
     if (nq <= 16 || nq > 32 || n_queries < 2) return RL_ERR_UNSUPPORTED;
     const int32_t d = idx->dim;
     if (d != 128 && d != 256 && d != 384 && d != 512 && d != 768 && d != 1024) return RL_ERR_UNSUPPORTED;
     RL_TRY(idx->qsplit.reserve(query_split_bytes(d, n_queries)));
-    return launch_query_split(d_q, d, nq, q_stride, n_queries, idx->qsplit.as<char>(), s);
+    return launch_query_split(d_q, d, nq, q_stride, n_queries, idx->qsplit.as<char>(), idx->E16 != nullptr, s);
 }
 
 int pairs_pass(rl_index* idx, int32_t nq, int32_t n_queries, int32_t first, float* d_out, int64_t out_stride, hipStream_t s) {
@@ -916,8 +916,9 @@ int pairs_pass(rl_index* idx, int32_t nq, int32_t n_queries, int32_t first, floa
         RL_TRY(launch_fill_f32(d_out, -std::numeric_limits<float>::infinity(), idx->n_chunks, s));
         RL_TRY(launch_fill_f32(d_out + out_stride, -std::numeric_limits<float>::infinity(), idx->n_chunks, s));
     }
-    return launch_maxsim_stream2(idx->E, idx->n_rows, idx->dim, idx->qsplit.as<char>(), n_queries, first, nq, idx->row_to_chunk,
-                                 idx->offsets, idx->n_chunks, d_out, out_stride, idx->n_cu, s, idx->split_scale);
+    return launch_maxsim_stream2(idx->E16 ? (const void*)idx->E16 : (const void*)idx->E, idx->E16 != nullptr, idx->n_rows, idx->dim,
+                                 idx->qsplit.as<char>(), n_queries, first, nq, idx->row_to_chunk, idx->offsets, idx->n_chunks, d_out,
+                                 out_stride, idx->n_cu, s, idx->split_scale);
 }
 
 int maxsim_scores_device(rl_index* idx, const float* d_q, int32_t nq, float* d_out, hipStream_t s) {

@@ -161,10 +161,11 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
                          const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
                          float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale = 0.f);
 size_t query_split_bytes(int32_t dim, int32_t n_queries);
-int launch_query_split(const float* Q, int32_t dim, int32_t nq, int64_t q_stride, int32_t n_queries, void* buf, hipStream_t s);
-int launch_maxsim_stream2(const float* D, int64_t n_rows, int32_t dim, const void* split_buf, int32_t n_queries, int32_t first,
-                          int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, float* out,
-                          int64_t out_stride, int n_cu, hipStream_t s, float split_scale);
+int launch_query_split(const float* Q, int32_t dim, int32_t nq, int64_t q_stride, int32_t n_queries, void* buf, bool f16_corpus,
+                       hipStream_t s);
+int launch_maxsim_stream2(const void* D, bool f16, int64_t n_rows, int32_t dim, const void* split_buf, int32_t n_queries,
+                          int32_t first, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks,
+                          float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale);
 // [largest |element|, smallest non-zero row maximum, non-finite flag] of an fp32 corpus, as uint32 bit patterns (device, 3 words)
 int launch_row_range(const float* E, int64_t n_rows, int32_t dim, uint32_t* range, hipStream_t s);
 // Any dim / nq: one wave per chunk (or per candidate), VALU dot products.

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
         [[maybe_unused]] h16x8 qhi[H ? NQT : 1][H ? MS : 1], qlo[H ? NQT : 1][H ? MS : 1];
         [[maybe_unused]] bool any_lo = false;
         [[maybe_unused]] float q_unscale = 1.f;
-        if constexpr (SPLIT) {
+        if constexpr (SPLIT || F16) {
             // SPLIT: x = hi + lo with hi, lo fp16 (22 significant bits; fp16 x fp16 products are exact in the MFMA's fp32
             // accumulators), so  e.q ~= eh.qh + (el.qh + eh.ql)  costs 3 fp16 MFMAs of 16 cycles where the exact path
             // issues 8 fp32 MFMAs of 32.  Both operands are first brought to the top of fp16's range by powers of two
@@ -197,15 +197,17 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
             int ex = 0;
             if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &ex);  // mx = f * 2^ex, f in [0.5, 1)
             const float q_scale = ldexpf(1.f, 14 - ex);           // |q| * q_scale < 2^14
-            q_unscale = ldexpf(1.f, ex - 14) / e_scale;
+            q_unscale = F16 ? ldexpf(1.f, ex - 14) : ldexpf(1.f, ex - 14) / e_scale;  // stored halves are not rescaled
 #pragma unroll
             for (int h = 0; h < NQT; ++h) {
                 const int qi = 16 * h + fj;
                 const int qc_ = qi < nq ? qi : nq - 1;
 #pragma unroll
                 for (int m = 0; m < MS; ++m) {
-                    const float* qp = Q + (int64_t)qc_ * SD + KW * w + 32 * m + 4 * kq;  // k = 16 (2m + (u >> 2)) + 4 kq + (u & 3)
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp), v1 = *reinterpret_cast<const f32x4*>(qp + 16);
+                    // fp32 corpus: k = 16 (2m + (u >> 2)) + 4 kq + (u & 3) (two fp32 fragment reads); fp16-stored corpus:
+                    // k = 32 m + 8 kq + u (one read of 8 stored halves)
+                    const float* qp = Q + (int64_t)qc_ * SD + KW * w + 32 * m + (F16 ? 8 : 4) * kq;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp), v1 = *reinterpret_cast<const f32x4*>(qp + (F16 ? 4 : 16));
 #pragma unroll
                     for (int u = 0; u < 8; ++u) {
                         const float x = qi < nq ? (u < 4 ? v0[u] : v1[u - 4]) * q_scale : 0.f;
@@ -220,32 +222,17 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
             any_lo = __builtin_amdgcn_ballot_w64(any_lo) != 0;
         }
 #pragma unroll
-        for (int h = 0; h < (SPLIT ? 0 : NQT); ++h) {
+        for (int h = 0; h < ((SPLIT || F16) ? 0 : NQT); ++h) {
             const int qi = 16 * h + fj;
             const int qc_ = qi < nq ? qi : nq - 1;  // clamped load, zeroed below: padded query vectors add 0
 #pragma unroll
             for (int mm = 0; mm < KSTEPS; ++mm) {
-                if constexpr (!F16) {
-                    f32x4 v = *reinterpret_cast<const f32x4*>(Q + (int64_t)qc_ * SD + KW * w + 16 * mm + 4 * kq);
-                    if (qi >= nq) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    qreg[h][4 * mm + 0] = v[0]; qreg[h][4 * mm + 1] = v[1];
-                    qreg[h][4 * mm + 2] = v[2]; qreg[h][4 * mm + 3] = v[3];
-                } else {
-                    const float* qp = Q + (int64_t)qc_ * SD + KW * w + 32 * mm + 8 * kq;
-                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp), v1 = *reinterpret_cast<const f32x4*>(qp + 4);
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const float x = qi < nq ? (u < 4 ? v0[u] : v1[u - 4]) : 0.f;
-                        const _Float16 hi = (_Float16)x;                // round to nearest even
-                        const _Float16 lo = (_Float16)(x - (float)hi);  // exact difference, then rounded
-                        qhi[h][mm][u] = hi;
-                        qlo[h][mm][u] = lo;
-                        any_lo |= lo != (_Float16)0.0f;
-                    }
-                }
+                f32x4 v = *reinterpret_cast<const f32x4*>(Q + (int64_t)qc_ * SD + KW * w + 16 * mm + 4 * kq);
+                if (qi >= nq) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                qreg[h][4 * mm + 0] = v[0]; qreg[h][4 * mm + 1] = v[1];
+                qreg[h][4 * mm + 2] = v[2]; qreg[h][4 * mm + 3] = v[3];
             }
         }
-        if constexpr (F16) any_lo = __builtin_amdgcn_ballot_w64(any_lo) != 0;  // wave-uniform
         const char* const a_base = smem + fj * PITCH + w * G_::QBYTES + kq * 16;
         for (int t = 0; t < nt; ++t) {
             stamp(t, 0);
@@ -297,6 +284,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
                         for (int h = 0; h < NQT; ++h)
                             acc[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mm][tt], qreg[h][4 * mm + tt], acc[h], 0, 0, 0);
             } else {
+                f32x4 acl[NQT];  // the lo term, summed apart (as in the SPLIT path and in maxsim_stream2_kernel: same bits)
+#pragma unroll
+                for (int h = 0; h < NQT; ++h) acl[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int mm = 0; mm < KSTEPS; ++mm) {
                     h16x8 af;
@@ -304,17 +294,14 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
 #pragma unroll
                     for (int h = 0; h < NQT; ++h)
                         acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qhi[h][mm], acc[h], 0, 0, 0);
-                }
-                if (any_lo) {
-#pragma unroll
-                    for (int mm = 0; mm < KSTEPS; ++mm) {
-                        h16x8 af;
-                        __builtin_memcpy(&af, &a[mm], 16);
+                    if (any_lo) {
 #pragma unroll
                         for (int h = 0; h < NQT; ++h)
-                            acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qlo[h][mm], acc[h], 0, 0, 0);
+                            acl[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qlo[h][mm], acl[h], 0, 0, 0);
                     }
                 }
+#pragma unroll
+                for (int h = 0; h < NQT; ++h) acc[h] = (acc[h] + acl[h]) * q_unscale;
             }
             stamp(t, 4);
 #pragma unroll
@@ -590,9 +577,9 @@ int launch_row_to_chunk(const int64_t* chunk_offsets, int64_t n_chunks, int64_t 
 //     DPP column sum) exactly as wave 6 does above;
 //   * same two barriers per tile, same data flow between them (partials -> ST -> walker registers -> one store).
 // One launch = one corpus pass = two queries' chunk scores: out[g * out_stride + chunk].
-template <int KW>
+template <int KW, bool F16 = false>
 struct Geo2 {
-    using G1 = Geo<KW, false>;
+    using G1 = Geo<KW, F16>;
     static constexpr int OFF_RED = NSTAGE * G1::STAGE;              // 2 groups x 8 KiB of K-partials
     static constexpr int OFF_ST = OFF_RED + 2 * G1::RED_BYTES;
     static constexpr int ST_BYTES = 32 * G1::ST_PITCH * 4;          // per group and tile parity: [32 query columns][20] fp32
@@ -606,7 +593,7 @@ struct Geo2 {
 // the register layout the pass kernels hold them in:
 //   frag[((((query * 4 + w) * 2 + h) * MS + m) * 2 + part) * 64 + lane]   (16 B: 8 fp16; part 0 = hi, 1 = lo)
 //   meta[(query * 4 + w) * 2 + {0, 1}] = {2^(ex - 14) (undoes the scale), any lo != 0}
-template <int KW>
+template <int KW, bool F16>
 __global__ __launch_bounds__(64) void query_split_kernel(const float* __restrict__ Q, int nq, int64_t q_stride,
                                                           uint4* __restrict__ frag, float* __restrict__ meta) {
     constexpr int SD = 4 * KW, MS = KW / 32, NQT = 2;
@@ -637,8 +624,9 @@ __global__ __launch_bounds__(64) void query_split_kernel(const float* __restrict
         const int qc_ = qi < nq ? qi : nq - 1;  // clamped load, zeroed below: padded query vectors add 0
 #pragma unroll
         for (int m = 0; m < MS; ++m) {
-            const float* qp = Qg + (int64_t)qc_ * SD + KW * w + 32 * m + 4 * kq;  // k = 16 (2m + (u >> 2)) + 4 kq + (u & 3)
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp), v1 = *reinterpret_cast<const f32x4*>(qp + 16);
+            // fp32 corpus: k = 16 (2m + (u >> 2)) + 4 kq + (u & 3); fp16-stored corpus: k = 32 m + 8 kq + u
+            const float* qp = Qg + (int64_t)qc_ * SD + KW * w + 32 * m + (F16 ? 8 : 4) * kq;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp), v1 = *reinterpret_cast<const f32x4*>(qp + (F16 ? 4 : 16));
             h16x8 hi8, lo8;
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
@@ -663,7 +651,7 @@ __global__ __launch_bounds__(64) void query_split_kernel(const float* __restrict
     }
 }
 
-template <int KW, bool TRACE = false>
+template <int KW, bool TRACE = false, bool F16 = false>
 __global__ __launch_bounds__(512, 2) void maxsim_stream2_kernel(const float* __restrict__ D, int64_t n_rows,
                                                                   const uint4* __restrict__ qfrag,
                                                                   const float* __restrict__ qmeta, int nq,
@@ -672,10 +660,10 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream2_kernel(const float* __r
                                                                   int64_t n_chunks, float* __restrict__ out,
                                                                   int64_t out_stride, float e_scale,
                                                                   unsigned long long* trace) {
-    using G1 = Geo<KW, false>;
-    using G2 = Geo2<KW>;
-    constexpr int SD = G1::DIM, PITCH = G1::PITCH, STAGE = G1::STAGE, NCH = G1::NCH, ROWB = G1::ROWB, ST_PITCH = G1::ST_PITCH;
-    constexpr int KSTEPS = KW / 16, MS = KW / 32, NQT = 2, NQC = 32;
+    using G1 = Geo<KW, F16>;
+    using G2 = Geo2<KW, F16>;
+    constexpr int PITCH = G1::PITCH, STAGE = G1::STAGE, NCH = G1::NCH, ROWB = G1::ROWB, ST_PITCH = G1::ST_PITCH;
+    constexpr int KSTEPS = G1::KSTEPS, MS = KW / 32, NQT = 2, NQC = 32;  // fragment reads per tile; fp16 MFMA steps
     __shared__ __attribute__((aligned(16))) char smem[G2::LDS_TOTAL + (TRACE ? 4096 : 0)];
     const int lane = threadIdx.x & 63;
     const int wv = wave_id();  // 0..7
@@ -722,7 +710,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream2_kernel(const float* __r
                 __builtin_memcpy(&qlo[h][m], &y, 16);
             }
     }
-    const float q_unscale = qmeta[(g * 4 + w) * 2 + 0] / e_scale;
+    const float q_unscale = F16 ? qmeta[(g * 4 + w) * 2 + 0] : qmeta[(g * 4 + w) * 2 + 0] / e_scale;  // stored halves are not rescaled
     const bool any_lo = __builtin_amdgcn_readfirstlane(__float_as_int(qmeta[(g * 4 + w) * 2 + 1])) != 0;
     const char* const a_base = smem + fj * PITCH + w * G1::QBYTES + kq * 16;
 
@@ -893,23 +881,34 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream2_kernel(const float* __r
             for (int h = 0; h < NQT; ++h) { acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f}; acl[h] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int mi = 0; mi < MS; ++mi) {
-                h16x8 eh, el;
+                if constexpr (F16) {  // the stored halves ARE the operand: two MFMAs per query tile, no conversion
+                    h16x8 af;
+                    __builtin_memcpy(&af, &a[mi], 16);
 #pragma unroll
-                for (int u = 0; u < 8; u += 2) {
-                    // (two scalar multiplies, not one v_pk_mul_f32: packed fp32 VALU beside MFMAs costs ~+25 cycles each)
-                    const float x0 = a[2 * mi + (u >> 2)][u & 3] * e_scale, x1 = a[2 * mi + (u >> 2)][(u & 3) + 1] * e_scale;
-                    const auto ph = __builtin_amdgcn_cvt_pkrtz(x0, x1);
-                    const auto pl = __builtin_amdgcn_cvt_pkrtz(x0 - (float)ph[0], x1 - (float)ph[1]);
-                    eh[u] = ph[0]; eh[u + 1] = ph[1];
-                    el[u] = pl[0]; el[u + 1] = pl[1];
-                }
+                    for (int h = 0; h < NQT; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qhi[h][mi], acc[h], 0, 0, 0);
+                    if (any_lo) {
 #pragma unroll
-                for (int h = 0; h < NQT; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, qhi[h][mi], acc[h], 0, 0, 0);
+                        for (int h = 0; h < NQT; ++h) acl[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, qlo[h][mi], acl[h], 0, 0, 0);
+                    }
+                } else {
+                    h16x8 eh, el;
 #pragma unroll
-                for (int h = 0; h < NQT; ++h) acl[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(el, qhi[h][mi], acl[h], 0, 0, 0);
-                if (any_lo) {
+                    for (int u = 0; u < 8; u += 2) {
+                        // (two scalar multiplies, not one v_pk_mul_f32: packed fp32 VALU beside MFMAs costs ~+25 cycles each)
+                        const float x0 = a[2 * mi + (u >> 2)][u & 3] * e_scale, x1 = a[2 * mi + (u >> 2)][(u & 3) + 1] * e_scale;
+                        const auto ph = __builtin_amdgcn_cvt_pkrtz(x0, x1);
+                        const auto pl = __builtin_amdgcn_cvt_pkrtz(x0 - (float)ph[0], x1 - (float)ph[1]);
+                        eh[u] = ph[0]; eh[u + 1] = ph[1];
+                        el[u] = pl[0]; el[u + 1] = pl[1];
+                    }
 #pragma unroll
-                    for (int h = 0; h < NQT; ++h) acl[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, qlo[h][mi], acl[h], 0, 0, 0);
+                    for (int h = 0; h < NQT; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, qhi[h][mi], acc[h], 0, 0, 0);
+#pragma unroll
+                    for (int h = 0; h < NQT; ++h) acl[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(el, qhi[h][mi], acl[h], 0, 0, 0);
+                    if (any_lo) {
+#pragma unroll
+                        for (int h = 0; h < NQT; ++h) acl[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, qlo[h][mi], acl[h], 0, 0, 0);
+                    }
                 }
                 if (feed) {  // this step's share of the DMA stream
                     [&]<int... J>(std::integer_sequence<int, J...>) {
@@ -1062,14 +1061,16 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
 // out[g * out_stride + chunk], g = 0, 1.  RL_ERR_UNSUPPORTED outside that shape (the caller then makes two passes).
 // SPLIT query fragments for `n_queries` queries of nq (17..32) vectors, q_stride floats apart (see query_split_kernel).
 size_t query_split_bytes(int32_t dim, int32_t n_queries) { return (size_t)n_queries * (4 * 2 * (dim / 128) * 2 * 64 * 16 + 64); }
-int launch_query_split(const float* Q, int32_t dim, int32_t nq, int64_t q_stride, int32_t n_queries, void* buf, hipStream_t s) {
+int launch_query_split(const float* Q, int32_t dim, int32_t nq, int64_t q_stride, int32_t n_queries, void* buf, bool f16_corpus,
+                       hipStream_t s) {
     if (nq <= 16 || nq > 32 || n_queries < 1) return RL_ERR_UNSUPPORTED;
     if (dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
     uint4* frag = static_cast<uint4*>(buf);
     float* meta = reinterpret_cast<float*>(static_cast<char*>(buf) + (size_t)n_queries * (4 * 2 * (dim / 128) * 2 * 64 * 16));
     const dim3 grid(4, (unsigned)n_queries), blk(64);
-#define RL_QS(KW) hipLaunchKernelGGL((query_split_kernel<KW>), grid, blk, 0, s, Q, (int)nq, q_stride, frag, meta)
+#define RL_QS(KW) do { if (f16_corpus) hipLaunchKernelGGL((query_split_kernel<KW, true>), grid, blk, 0, s, Q, (int)nq, q_stride, frag, meta); \
+                       else hipLaunchKernelGGL((query_split_kernel<KW, false>), grid, blk, 0, s, Q, (int)nq, q_stride, frag, meta); } while (0)
     switch (dim) {
         case 128: RL_QS(32); break; case 256: RL_QS(64); break; case 384: RL_QS(96); break;
         case 512: RL_QS(128); break; case 768: RL_QS(192); break; default: RL_QS(256); break;
@@ -1082,10 +1083,11 @@ int launch_query_split(const float* Q, int32_t dim, int32_t nq, int64_t q_stride
 // Two queries (17..32 vectors each; queries `first`, `first + 1` of a launch_query_split buffer over `n_queries`) per corpus
 // pass over an fp32 corpus in SPLIT arithmetic: out[g * out_stride + chunk], g = 0, 1.  RL_ERR_UNSUPPORTED outside that
 // shape (the caller then makes one pass per query).
-int launch_maxsim_stream2(const float* D, int64_t n_rows, int32_t dim, const void* split_buf, int32_t n_queries, int32_t first,
-                          int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, float* out,
-                          int64_t out_stride, int n_cu, hipStream_t s, float split_scale) {
-    if (nq <= 16 || nq > 32 || n_rows < 1 || !(split_scale > 0.f) || first < 0 || first + 2 > n_queries) return RL_ERR_UNSUPPORTED;
+int launch_maxsim_stream2(const void* Dv, bool f16, int64_t n_rows, int32_t dim, const void* split_buf, int32_t n_queries,
+                          int32_t first, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks,
+                          float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale) {
+    const float* D = static_cast<const float*>(Dv);  // fp32 rows, or (f16) IEEE halves
+    if (nq <= 16 || nq > 32 || n_rows < 1 || (!f16 && !(split_scale > 0.f)) || first < 0 || first + 2 > n_queries) return RL_ERR_UNSUPPORTED;
     if (dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024) return RL_ERR_UNSUPPORTED;
     if (reinterpret_cast<uintptr_t>(D) & 15) return RL_ERR_UNSUPPORTED;
     const size_t per_query = (size_t)4 * 2 * (dim / 128) * 2 * 64;  // uint4 per query
@@ -1098,7 +1100,7 @@ int launch_maxsim_stream2(const float* D, int64_t n_rows, int32_t dim, const voi
         if (std::getenv("RAGLITE_HIP_TRACE2")) { (void)hipMalloc(&p, 4096); (void)hipMemset(p, 0, 4096); }
         return p;
     }();
-    if (trace && dim == 1024) {  // diagnostic build: dump the 30th launch's tile timeline to stderr
+    if (trace && dim == 1024 && !f16) {  // diagnostic build: dump the 30th launch's tile timeline to stderr
         static int calls = 0;
         hipLaunchKernelGGL((maxsim_stream2_kernel<256, true>), grid, blk, 0, s, D, n_rows, qfrag, qmeta, (int)nq, row_to_chunk,
                            chunk_offsets, n_chunks, out, out_stride, split_scale, trace);
@@ -1116,8 +1118,10 @@ int launch_maxsim_stream2(const float* D, int64_t n_rows, int32_t dim, const voi
         }
         return RL_OK;
     }
-#define RL_STREAM2(KW) hipLaunchKernelGGL((maxsim_stream2_kernel<KW>), grid, blk, 0, s, D, n_rows, qfrag, qmeta, (int)nq, \
-                                          row_to_chunk, chunk_offsets, n_chunks, out, out_stride, split_scale, nullptr)
+#define RL_STREAM2(KW) do { if (f16) hipLaunchKernelGGL((maxsim_stream2_kernel<KW, false, true>), grid, blk, 0, s, D, n_rows, qfrag, qmeta, \
+                                                        (int)nq, row_to_chunk, chunk_offsets, n_chunks, out, out_stride, 1.f, nullptr); \
+                            else hipLaunchKernelGGL((maxsim_stream2_kernel<KW, false, false>), grid, blk, 0, s, D, n_rows, qfrag, qmeta, \
+                                                    (int)nq, row_to_chunk, chunk_offsets, n_chunks, out, out_stride, split_scale, nullptr); } while (0)
     switch (dim) {
         case 128: RL_STREAM2(32); break; case 256: RL_STREAM2(64); break; case 384: RL_STREAM2(96); break;
         case 512: RL_STREAM2(128); break; case 768: RL_STREAM2(192); break; default: RL_STREAM2(256); break;

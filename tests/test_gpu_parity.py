@@ -1338,9 +1338,10 @@ def test_split_arithmetic_eligibility(torch_cuda):
     idx.close()
 
 
+@pytest.mark.parametrize("storage", ["f32", "f16"])
 @pytest.mark.parametrize("dim", [128, 256, 384, 512, 768, 1024])
 @pytest.mark.parametrize("n_rows,nq", [(20, 32), (700, 17), (9000, 32), (40_000, 25)])
-def test_maxsim_batch_two_queries_per_pass(dim, n_rows, nq):
+def test_maxsim_batch_two_queries_per_pass(dim, n_rows, nq, storage):
     """`rl_maxsim_topk_batch` scores two queries per corpus pass (maxsim_stream2_kernel: eight symmetric waves, query
     group x K-quarter) wherever the fp16-split arithmetic is in effect and a query has 17..32 vectors.  Integer data:
     scores are exact, so batch == one-query-at-a-time == oracle, bit for bit, incl. the odd query left over, empty
@@ -1350,8 +1351,8 @@ def test_maxsim_batch_two_queries_per_pass(dim, n_rows, nq):
     n_chunks = len(off) - 1
     E = oracle.synth_matrix(900 + dim, n_rows, dim, "small_int")
     Qb = np.stack([oracle.synth_matrix(950 + i, nq, dim, "small_int") for i in range(5)])
-    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
-    assert idx.arithmetic == "f16_split"
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot", storage=storage)  # small integers are exact in fp16 storage too
+    assert idx.arithmetic == ("f16_split" if storage == "f32" else "f16_stored")
     k = min(50, n_chunks)
     bs, bc = idx.maxsim_topk_batch(Qb, k)
     for i in range(5):
@@ -1370,9 +1371,10 @@ def test_maxsim_batch_two_queries_per_pass(dim, n_rows, nq):
     idx.close()
 
 
-def test_maxsim_batch_pairs_float_data_device_pointers(torch_cuda):
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_maxsim_batch_pairs_float_data_device_pointers(torch_cuda, storage):
     """Float data, CUDA tensors: the pair kernel's scores equal the single-query kernel's bit for bit (same arithmetic,
-    same K order), and the oracle's within tolerance."""
+    same K order), and the oracle's within tolerance; fp32- and fp16-stored corpus."""
     torch = torch_cuda
     n, dim, nq = 30_000, 1024, 32
     rng = np.random.default_rng(77)
@@ -1381,9 +1383,11 @@ def test_maxsim_batch_pairs_float_data_device_pointers(torch_cuda):
     raglite_amd.synth_fill(E, seed=31)
     Qb = torch.empty((6, nq, dim), dtype=torch.float32, device="cuda")
     raglite_amd.synth_fill(Qb, seed=32)
-    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    if storage == "f16":
+        E = E.half()
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot", storage=storage)
     bs, bc = idx.maxsim_topk_batch(Qb, 100)
-    Eh = E.cpu().numpy()
+    Eh = E.float().cpu().numpy()
     for i in range(6):
         ss, sc = idx.maxsim_topk(Qb[i], 100)
         assert torch.equal(bc[i], sc) and torch.equal(bs[i], ss)
