@@ -1058,7 +1058,7 @@ int rl_maxsim_rerank(rl_index* idx, const float* query_vecs, int32_t n_queries, 
     RL_TRY(stage_in(candidates, (size_t)n_queries * n_cand, mem, s, t_c, &d_c));
     RL_TRY(stage_out_begin(out_scores, (size_t)n_queries * n_cand, mem, t_o, &d_o));
     int st = idx->E16 ? launch_maxsim_cand16(idx->E16, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s)
-                      : launch_maxsim_cand(idx->E, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s);
+                      : launch_maxsim_cand(idx->E, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s, idx->split_scale);
     if (st == RL_ERR_UNSUPPORTED && !idx->E16)
         st = launch_maxsim_generic(idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, d_c, n_cand,
                                    n_queries, d_o, s);

@@ -183,7 +183,8 @@ int launch_maxsim_generic(const float* D, int32_t dim, const float* Q, int32_t n
                           int32_t n_queries, float* out, hipStream_t s);
 // Rerank fast path: dim == 128, nq <= 32 (MFMA, direct fragment loads).
 int launch_maxsim_cand(const float* D, int32_t dim, const float* Q, int32_t nq, const int64_t* chunk_offsets,
-                       const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s);
+                       const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s,
+                       float split_scale = 0.f);  // > 0: fp16-split arithmetic, corpus scaled by that power of two
 int launch_maxsim_cand16(const uint16_t* D, int32_t dim, const float* Q, int32_t nq, const int64_t* chunk_offsets,
                          const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s);
 

@@ -130,11 +130,14 @@ constexpr int CPW = 8;    // candidates per wave
 
 // F16: D holds IEEE fp16 rows (fp16-stored index); the query is split into fp16 hi + lo halves for
 // v_mfma_f32_16x16x32_f16 exactly as in maxsim_stream.hip.
-template <int NQT, bool F16>
+// SPLIT: the fp16 (hi, lo) arithmetic of maxsim_stream.hip for an fp32-stored corpus (include/raglite_hip.h,
+// RL_ARITH_F16_SPLIT): with exact fp32 MFMAs this shape sits right on the ridge (matrix pipe 62 %, HBM 76 %).
+template <int NQT, bool F16, bool SPLIT = false>
 __global__ __launch_bounds__(256) void maxsim_cand_kernel(const float* __restrict__ D, const float* __restrict__ Q,
                                                            int nq, const int64_t* __restrict__ offsets,
                                                            const int32_t* __restrict__ candidates, int n_cand,
-                                                           int n_queries, float* __restrict__ out) {
+                                                           int n_queries, float* __restrict__ out, float e_scale) {
+    static_assert(!(F16 && SPLIT), "SPLIT is a way to multiply an fp32-stored corpus");
     const int lane = threadIdx.x & 63;
     const int fj = lane & 15, kq = lane >> 4;
     const int groups = (n_cand + CPW - 1) / CPW;            // waves per query
@@ -145,12 +148,55 @@ __global__ __launch_bounds__(256) void maxsim_cand_kernel(const float* __restric
 
     // B fragments: lane (j, kq), MFMA 4*mm + tt uses Q[16h + j][16*mm + 4*kq + tt]  (fp16 storage: MFMA mm uses
     // Q[16h + j][32*mm + 8*kq .. +7] as hi / lo halves)
-    [[maybe_unused]] float qreg[F16 ? 1 : NQT][F16 ? 1 : 32];
-    [[maybe_unused]] h16x8 qhi[F16 ? NQT : 1][F16 ? 4 : 1], qlo[F16 ? NQT : 1][F16 ? 4 : 1];
+    constexpr bool H = F16 || SPLIT;
+    [[maybe_unused]] float qreg[H ? 1 : NQT][H ? 1 : 32];
+    [[maybe_unused]] h16x8 qhi[H ? NQT : 1][H ? 4 : 1], qlo[H ? NQT : 1][H ? 4 : 1];
     [[maybe_unused]] bool any_lo = false;
+    [[maybe_unused]] float q_unscale = 1.f;
     const float* Qq = Q + (int64_t)qi * nq * CD;
+    if constexpr (SPLIT) {
+        // the whole query (nq x 128) scaled to [2^13, 2^14) by one power of two, split into fp16 (hi, lo); MFMA m uses
+        // k = 16 (2m + (u >> 2)) + 4 kq + (u & 3), the positions of A fragments 2m and 2m + 1
+        float mxq = 0.f;
 #pragma unroll
-    for (int h = 0; h < NQT; ++h) {
+        for (int h = 0; h < NQT; ++h) {
+            const int qv = 16 * h + fj;
+            if (qv < nq)
+#pragma unroll
+                for (int mm = 0; mm < 8; ++mm) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(Qq + (int64_t)qv * CD + 16 * mm + 4 * kq);
+                    mxq = fmaxf(mxq, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mxq = fmaxf(mxq, __shfl_xor(mxq, o));
+        int ex = 0;
+        if (mxq > 0.f && mxq < INFINITY) (void)frexpf(mxq, &ex);
+        const float q_scale = ldexpf(1.f, 14 - ex);
+        q_unscale = ldexpf(1.f, ex - 14) / e_scale;
+#pragma unroll
+        for (int h = 0; h < NQT; ++h) {
+            const int qv = 16 * h + fj;
+            const int qc_ = qv < nq ? qv : nq - 1;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float* qp = Qq + (int64_t)qc_ * CD + 32 * m + 4 * kq;
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(qp), v1 = *reinterpret_cast<const f32x4*>(qp + 16);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float x = qv < nq ? (u < 4 ? v0[u] : v1[u - 4]) * q_scale : 0.f;
+                    const _Float16 hi = (_Float16)x;
+                    const _Float16 lo = (_Float16)(x - (float)hi);
+                    qhi[h][m][u] = hi;
+                    qlo[h][m][u] = lo;
+                    any_lo |= lo != (_Float16)0.0f;
+                }
+            }
+        }
+        any_lo = __builtin_amdgcn_ballot_w64(any_lo) != 0;
+    }
+#pragma unroll
+    for (int h = 0; h < (SPLIT ? 0 : NQT); ++h) {
         const int qv = 16 * h + fj;
         const int qc_ = qv < nq ? qv : nq - 1;
         if constexpr (!F16) {
@@ -192,7 +238,37 @@ __global__ __launch_bounds__(256) void maxsim_cand_kernel(const float* __restric
             f32x4 acc[NQT];
 #pragma unroll
             for (int h = 0; h < NQT; ++h) acc[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if constexpr (!F16) {
+            if constexpr (SPLIT) {
+                const float* p = D + row * CD + 4 * kq;
+                f32x4 a[8];
+#pragma unroll
+                for (int mm = 0; mm < 8; ++mm) a[mm] = *reinterpret_cast<const f32x4*>(p + 16 * mm);
+                f32x4 acl[NQT];
+#pragma unroll
+                for (int h = 0; h < NQT; ++h) acl[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    h16x8 eh, el;
+#pragma unroll
+                    for (int u = 0; u < 8; u += 2) {
+                        const float x0 = a[2 * m + (u >> 2)][u & 3] * e_scale, x1 = a[2 * m + (u >> 2)][(u & 3) + 1] * e_scale;
+                        const auto ph = __builtin_amdgcn_cvt_pkrtz(x0, x1);  // truncation: the residual is exact in fp32
+                        const auto pl = __builtin_amdgcn_cvt_pkrtz(x0 - (float)ph[0], x1 - (float)ph[1]);
+                        eh[u] = ph[0]; eh[u + 1] = ph[1];
+                        el[u] = pl[0]; el[u + 1] = pl[1];
+                    }
+#pragma unroll
+                    for (int h = 0; h < NQT; ++h) acc[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, qhi[h][m], acc[h], 0, 0, 0);
+#pragma unroll
+                    for (int h = 0; h < NQT; ++h) acl[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(el, qhi[h][m], acl[h], 0, 0, 0);
+                    if (any_lo) {
+#pragma unroll
+                        for (int h = 0; h < NQT; ++h) acl[h] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, qlo[h][m], acl[h], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int h = 0; h < NQT; ++h) acc[h] = (acc[h] + acl[h]) * q_unscale;
+            } else if constexpr (!F16) {
                 const float* p = D + row * CD + 4 * kq;
                 f32x4 a[8];
 #pragma unroll
@@ -248,16 +324,18 @@ __global__ __launch_bounds__(256) void maxsim_cand_kernel(const float* __restric
 }
 
 static int launch_cand_any(const float* D, bool f16, int32_t dim, const float* Q, int32_t nq, const int64_t* offsets,
-                           const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s) {
+                           const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s,
+                           float split_scale = 0.f) {
     if (dim != CD || nq < 1 || nq > 32) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
     if (n_cand <= 0 || n_queries <= 0) return RL_OK;
     const int64_t waves = (int64_t)n_queries * ((n_cand + CPW - 1) / CPW);
     const int64_t blocks = (waves + 3) / 4;
     if (blocks > 0x7fffffff) return fail(RL_ERR_UNSUPPORTED, "MaxSim rerank: too many (query, candidate) pairs per launch");
-#define RL_CAND(NQT, F) hipLaunchKernelGGL((maxsim_cand_kernel<NQT, F>), dim3((unsigned)blocks), dim3(256), 0, s, D, Q, \
-                                           (int)nq, offsets, candidates, (int)n_cand, (int)n_queries, out)
+#define RL_CAND(NQT, ...) hipLaunchKernelGGL((maxsim_cand_kernel<NQT, __VA_ARGS__>), dim3((unsigned)blocks), dim3(256), 0, s, D, Q, \
+                                             (int)nq, offsets, candidates, (int)n_cand, (int)n_queries, out, split_scale)
     if (f16) { if (nq <= 16) RL_CAND(1, true); else RL_CAND(2, true); }
+    else if (split_scale > 0.f) { if (nq <= 16) RL_CAND(1, false, true); else RL_CAND(2, false, true); }
     else     { if (nq <= 16) RL_CAND(1, false); else RL_CAND(2, false); }
 #undef RL_CAND
     RL_HIP(hipGetLastError());
@@ -265,8 +343,9 @@ static int launch_cand_any(const float* D, bool f16, int32_t dim, const float* Q
 }
 
 int launch_maxsim_cand(const float* D, int32_t dim, const float* Q, int32_t nq, const int64_t* offsets,
-                       const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s) {
-    return launch_cand_any(D, false, dim, Q, nq, offsets, candidates, n_cand, n_queries, out, s);
+                       const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s,
+                       float split_scale) {
+    return launch_cand_any(D, false, dim, Q, nq, offsets, candidates, n_cand, n_queries, out, s, split_scale);
 }
 
 int launch_maxsim_cand16(const uint16_t* D, int32_t dim, const float* Q, int32_t nq, const int64_t* offsets,
