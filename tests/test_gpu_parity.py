@@ -1395,3 +1395,38 @@ def test_maxsim_batch_pairs_float_data_device_pointers(torch_cuda, storage):
     assert set(wc.tolist()) == set(bc[0].cpu().numpy().tolist())
     np.testing.assert_allclose(np.sort(bs[0].cpu().numpy())[::-1], np.sort(ws)[::-1], rtol=0, atol=2e-4)
     idx.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_split_arithmetic_gemm_and_rerank_query_scales(metric):
+    """Every query gets a power-of-two scale of its own in the fp16-split GEMM (query_presplit_kernel) and in the rerank
+    kernel: a batch whose queries span 20 orders of magnitude must score each query as accurately as it would alone --
+    cosine is scale-free (compare with float64 directly), dot scores are compared relative to |q|."""
+    rng = np.random.default_rng(41)
+    n, dim, B = 3000, 128, 130  # dim 128: the rerank MFMA kernel applies; B >= 96: the GEMM path
+    E = rng.standard_normal((n, dim)).astype(np.float32)
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    mag = 10.0 ** rng.uniform(-10, 10, size=B)
+    Q = (rng.standard_normal((B, dim)) * mag[:, None]).astype(np.float32)
+    off = np.arange(0, n + 1, 4, dtype=np.int64)
+    idx = raglite_amd.DeviceIndex(E, off, metric=metric)
+    assert idx.arithmetic == "f16_split"
+    s, r = idx.search_rows(Q, 10)
+    E64, Q64 = E.astype(np.float64), Q.astype(np.float64)
+    dots = Q64 @ E64.T
+    ref = dots / (np.linalg.norm(Q64, axis=1)[:, None] * np.linalg.norm(E64, axis=1)[None, :]) if metric == "cosine" else 1.0 + dots
+    unit = np.ones(B) if metric == "cosine" else np.maximum(np.linalg.norm(Q64, axis=1), 1.0)
+    for b in range(B):
+        want = np.sort(ref[b])[::-1][:10]
+        np.testing.assert_allclose(np.asarray(s[b], dtype=np.float64) / unit[b], want / unit[b], rtol=0, atol=2e-5)
+    # rerank kernel: 32 query vectors per query, each query at its own magnitude
+    nq = 32
+    Qv = (rng.standard_normal((6, nq, dim)) * (10.0 ** rng.uniform(-8, 8, size=6))[:, None, None]).astype(np.float32)
+    cand = rng.integers(0, n // 4, size=(6, 40)).astype(np.int32)
+    got = np.asarray(idx.maxsim_rerank(Qv, cand), dtype=np.float64)
+    for qi in range(6):
+        S = Qv[qi].astype(np.float64) @ E64.T  # noqa: N806
+        want = np.array([S[:, 4 * c : 4 * c + 4].max(axis=1).sum() for c in cand[qi]])
+        scale = np.abs(Qv[qi].astype(np.float64)).max() * nq
+        np.testing.assert_allclose(got[qi] / scale, want / scale, rtol=0, atol=2e-6)
+    idx.close()
