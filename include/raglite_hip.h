@@ -147,7 +147,7 @@ int rl_index_live(rl_index* index, int64_t* live_rows, int64_t* live_chunks, voi
  * Default RL_ARITH_AUTO: F16_SPLIT when every element is finite and the largest elements of all non-zero rows
  * lie within a factor 2^10 of each other (any normalised corpus), FP32_EXACT otherwise; the environment variable
  * RAGLITE_EXACT_FP32=1 forces FP32_EXACT for the whole process.  The batched GEMM (>= 96 queries) follows the
- * same setting (22 -> 12 ms at 1000 x 1.25 M x 1024) and so does rl_maxsim_rerank's dim-128 MFMA kernel (718 k -> 875 k
+ * same setting (22 -> 11 ms at 1000 x 1.25 M x 1024) and so does rl_maxsim_rerank's dim-128 MFMA kernel (718 k -> 875 k
  * queries/s at 32 x (256 x 64) x 128); the single-query VALU scan always computes in fp32.
  * rl_index_set_arithmetic: mode = RL_ARITH_AUTO | RL_ARITH_FP32_EXACT.
  * rl_index_arithmetic: what is in effect (FP32_EXACT, F16_SPLIT or F16_STORED). */

@@ -22,6 +22,8 @@
 //   * tiles are enumerated so that the 8 query tiles of one row tile run back to back on ONE XCD (blockIdx % 8 is the
 //     XCD): E comes from HBM once and then from that XCD's L2;
 //   * deterministic and position-independent: every (row, query) sums K in the same fixed order.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace rl {
@@ -281,6 +283,170 @@ __global__ __launch_bounds__(384) void score_gemm_kernel(const float* __restrict
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 128 rows x 256 queries per tile, fp16-split arithmetic only.  With the fp16 MFMAs the 128 x 128 kernel above is bound by
+// the bytes a K slab brings into the CU (32 KiB per 2.0 k cycles), not by the matrix pipe: a
+// 128 x 256 tile moves 48 KiB for twice the flops.  704 threads: waves 0-7 compute a 64 x 64 quadrant each
+// (wx = wv & 1 rows, wy = wv >> 1 queries), wave 8 streams the E rows, waves 9 and 10 the pre-split query rows (128 each);
+// ring of 3 slabs of 48 KiB, loaders 2 slabs ahead, one barrier per slab.  Three waves share a SIMD, so a compute wave
+// must stay under 168 VGPRs (it needs ~150: 64 accumulators, 64 of fragments, one converted pair at a time).
+constexpr int GM2 = 256;
+constexpr int NSLOT2 = 3;
+constexpr int OPQ2_BYTES = GM2 * GK * 4;                 // 32 KiB
+constexpr int SLAB2_BYTES = OP_BYTES + OPQ2_BYTES;       // 48 KiB
+
+__global__ __launch_bounds__(704) void score_gemm256_kernel(const float* __restrict__ E, int64_t n_rows, int32_t dim,
+                                                            const float* __restrict__ Qs, int32_t B,
+                                                            float* __restrict__ S, int64_t ld, int64_t n_tiles,
+                                                            int32_t QT, const float* __restrict__ row_norm,
+                                                            const float* __restrict__ row_sumsq,
+                                                            const float* __restrict__ q_sumsq, int mode,
+                                                            float e_scale, const float* __restrict__ q_scale) {
+    __shared__ __attribute__((aligned(16))) char smem[NSLOT2 * SLAB2_BYTES];
+    const int lane = threadIdx.x & 63;
+    const int wv = wave_id();
+    const int nslab = dim / GK;
+    const int64_t G = gridDim.x, b = blockIdx.x;
+    if (n_tiles <= b) return;
+    const int my_tiles = (int)((n_tiles - b + G - 1) / G);
+    const int total = my_tiles * nslab;
+    auto decode = [&](int it, int64_t& row0, int32_t& q0) {
+        const int64_t L = (int64_t)it * G + b;
+        const int64_t x = L & 7, j = L >> 3;
+        q0 = (int32_t)(j % QT) * GM2;
+        row0 = ((j / QT) * 8 + x) * GN;
+    };
+
+    if (wv < 8) {
+        // ================================ COMPUTE WAVE ==============================================================
+        const int wx = wv & 1, wy = wv >> 1;  // rows [64 wx, +64), queries [64 wy, +64)
+        const int fj = lane & 15, kq = lane >> 4;
+        const uint32_t sw0 = (uint32_t)((kq ^ (fj >> 1)) * 16), sw1 = (uint32_t)(((4 + kq) ^ (fj >> 1)) * 16);
+        const uint32_t e_off = (uint32_t)((64 * wx + fj) * 128), q_off = (uint32_t)(OP_BYTES + (64 * wy + fj) * 128);
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int it = 0, sl = 0;
+        for (int g = 0; g < total; ++g) {
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slab g has landed
+            const char* base = smem + (g % NSLOT2) * SLAB2_BYTES;
+            h16x8 qh[4], ql[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                qh[c] = *reinterpret_cast<const h16x8*>(base + q_off + c * 2048 + sw0);
+                ql[c] = *reinterpret_cast<const h16x8*>(base + q_off + c * 2048 + sw1);
+            }
+            f32x4 e0[4], e1[4];  // all 16 reads of the slab are in flight before the first conversion
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                e0[a] = *reinterpret_cast<const f32x4*>(base + e_off + a * 2048 + sw0);
+                e1[a] = *reinterpret_cast<const f32x4*>(base + e_off + a * 2048 + sw1);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                h16x8 eh, el;
+                split8(e0[a], e1[a], e_scale, eh, el);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, qh[c], acc[a][c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(el, qh[c], acc[a][c], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(eh, ql[c], acc[a][c], 0, 0, 0);
+            }
+            if (++sl == nslab) {
+                int64_t row0;
+                int32_t q0;
+                decode(it, row0, q0);
+                const int gq = lane >> 4, j = lane & 15;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int32_t q = q0 + 64 * wy + 16 * c + j;
+                    const float qss = (mode == SCAN_COSINE || mode == SCAN_L2) ? q_sumsq[q < B ? q : B - 1] : 0.f;
+                    const float qn = sqrtf(qss);
+                    const float unscale = 1.0f / (e_scale * q_scale[q < B ? q : B - 1]);  // powers of two: exact
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int64_t r = row0 + 64 * wx + 16 * a + 4 * gq;
+                        const float* src = mode == SCAN_COSINE ? row_norm : row_sumsq;
+                        f32x4 v = acc[a][c];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            const float rn = (mode == SCAN_COSINE || mode == SCAN_L2) ? src[r + u < n_rows ? r + u : n_rows - 1] : 0.f;
+                            const float d = v[u] * unscale;
+                            if (mode == SCAN_COSINE) v[u] = 1.0f - (1.0f - d / (rn * qn));
+                            else if (mode == SCAN_DOT) v[u] = 1.0f + d;
+                            else if (mode == SCAN_L2) v[u] = 1.0f - sqrtf(fmaxf(rn + qss - 2.0f * d, 0.f));
+                        }
+                        if (q < B && r < n_rows) {
+                            float* o = S + (int64_t)q * ld + r;
+                            if (r + 3 < n_rows && ((reinterpret_cast<uintptr_t>(o) & 15) == 0)) {
+                                *reinterpret_cast<f32x4*>(o) = v;
+                            } else {
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
+                                    if (r + u < n_rows) o[u] = v[u];
+                            }
+                        }
+                        acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+                sl = 0;
+                ++it;
+            }
+        }
+        return;
+    }
+
+    // ==================================== LOADER WAVES (8: E rows; 9, 10: query rows 0-127, 128-255) ================
+    const int op = wv == 8 ? 0 : 1, half = wv == 10 ? 1 : 0;
+    const char* const src = reinterpret_cast<const char*>(op == 0 ? E : Qs);
+    const int64_t lim = (op == 0 ? n_rows : (int64_t)B) - 1;
+    const int64_t pitch = (int64_t)dim * 4;
+    const uint32_t lds_op = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem) +
+                            (uint32_t)(op * OP_BYTES + half * 16 * 1024);
+    uint32_t voff[16];
+    const char* tile_base = src;
+    int cur_it = -1;
+    auto issue = [&](int gi) {
+        int gg = gi < total ? gi : total - 1;
+        const int it = gg / nslab, sl = gg - it * nslab;
+        if (it != cur_it) {
+            cur_it = it;
+            int64_t row0;
+            int32_t q0;
+            decode(it, row0, q0);
+            int64_t first = op == 0 ? row0 : (int64_t)q0;
+            first = first < lim ? first : lim;
+            tile_base = src + first * pitch;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int r = 128 * half + 8 * i + (lane >> 3);
+                int64_t rr = first + r;
+                rr = rr < lim ? rr : lim;
+                const int c = (lane & 7) ^ ((r >> 1) & 7);
+                voff[i] = (uint32_t)((rr - first) * pitch) + (uint32_t)(c * 16);
+            }
+        }
+        const char* base = tile_base + sl * (GK * 4);
+        const uint32_t lds = lds_op + (uint32_t)((gi % NSLOT2) * SLAB2_BYTES);
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" ::"s"(lds), "n"(i * 1024),
+                         "v"(voff[i]), "s"(base)
+                         : "memory", "m0", "scc");
+    };
+    issue(0);
+    issue(1);
+    for (int g = 0; g < total; ++g) {
+        asm volatile("s_waitcnt vmcnt(16)" ::: "memory");  // in-order: at most slab g+1 outstanding => slab g landed
+        asm volatile("s_barrier" ::: "memory");
+        issue(g + 2);  // into the slot of slab g-1: every compute wave consumed it before reaching this barrier
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // Sum of squares of every query, in transform_kernel's summation order (256 strided partial sums, wave butterflies,
 // ((p0+p1)+(p2+p3))), so the fused epilogue reproduces the unfused path bit for bit.
 __global__ __launch_bounds__(256) void query_sumsq_kernel(const float* __restrict__ queries, int dim,
@@ -363,6 +529,16 @@ int launch_score_gemm(const float* E, int64_t n_rows, int32_t dim, const float* 
         float* Qs = q_sumsq_scratch + (((size_t)2 * nb + 7) & ~(size_t)7);  // 32-B aligned behind q_sumsq and q_scale
         if (reinterpret_cast<uintptr_t>(Qs) & 15) return RL_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(query_presplit_kernel, dim3(nb), dim3(256), 0, s, Q, (int)dim, q_scale, reinterpret_cast<uint4*>(Qs));
+        static const bool tile128 = std::getenv("RAGLITE_GEMM_TILE128") != nullptr;  // A/B switch
+        if (!tile128 && nb > GM) {  // 128 x 256 tiles: 25 % fewer bytes into the CU per flop
+            const int32_t QT2 = (nb + GM2 - 1) / GM2;
+            const int64_t n_tiles2 = ((RT + 7) / 8) * 8 * QT2;
+            const int grid2 = (int)std::min<int64_t>(n_cu > 0 ? n_cu : 256, n_tiles2);
+            hipLaunchKernelGGL(score_gemm256_kernel, dim3(grid2), dim3(704), 0, s, E, n_rows, dim, Qs, nb, scores, ld, n_tiles2, QT2,
+                               row_norm, row_sumsq, q_sumsq_scratch, mode, split_scale, q_scale);
+            RL_HIP(hipGetLastError());
+            return RL_OK;
+        }
         hipLaunchKernelGGL(score_gemm_kernel<true>, dim3(grid), dim3(384), 0, s, E, n_rows, dim, Qs, nb, scores, ld, n_tiles, QT,
                            row_norm, row_sumsq, q_sumsq_scratch, mode, split_scale, q_scale);
     } else {
