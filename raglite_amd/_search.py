@@ -38,11 +38,13 @@ class GpuIndex:
     docs             optional list[str] -- `str(chunk)` per chunk, lets `MaxSimRanker` map the strings the
                      reranker plugin receives back to chunk ordinals
     metadata         optional list[dict] per chunk for `metadata_filter`
+    storage          "f32", or "f16" (the reference's own storage precision)
+    exact_fp32       multiply with exact fp32 MFMAs instead of the default fp16 (hi, lo) split of fp32 operands
     """
 
     def __init__(self, chunk_ids: Sequence[ChunkId], chunk_embeddings, *, chunk_offsets=None,
                  metric: str = "cosine", query_adapter=None, docs: Sequence[str] | None = None,
-                 metadata: Sequence[dict] | None = None, storage: str = "f32") -> None:
+                 metadata: Sequence[dict] | None = None, storage: str = "f32", exact_fp32: bool = False) -> None:
         if chunk_offsets is None:
             mats = [np.asarray(m, dtype=np.float32).reshape(len(m), -1) for m in chunk_embeddings]
             sizes = np.asarray([len(m) for m in mats], dtype=np.int64)
@@ -55,6 +57,8 @@ class GpuIndex:
             raise ValueError("one chunk id per chunk is required")
         self.chunk_ids = list(chunk_ids)
         self.index = _ops.DeviceIndex(matrix, chunk_offsets, metric=metric, storage=storage)
+        if exact_fp32:  # ordered fp32 MFMA chain instead of the fp16 (hi, lo) split (include/raglite_hip.h, rl_index_set_arithmetic)
+            self.index.set_exact_fp32()
         self.metric = metric
         self.query_adapter = None if query_adapter is None else np.asarray(query_adapter, dtype=np.float32)
         self.docs = None if docs is None else list(docs)
