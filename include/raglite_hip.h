@@ -183,8 +183,11 @@ int rl_maxsim_topk(rl_index* index, const float* query_vecs, int32_t nq, int32_t
                    float* out_scores, int32_t* out_chunks, int mem, void* stream);
 int rl_maxsim_scores(rl_index* index, const float* query_vecs, int32_t nq, float* out_scores,
                      int mem, void* stream);
-/* rl_maxsim_topk_batch: `n_queries` independent queries (each nq vectors) against every chunk: one corpus pass
- * per query, then ONE batched selection launch for all of them (amortises the three selection kernels).
+/* rl_maxsim_topk_batch: `n_queries` independent queries (each nq vectors) against every chunk, then ONE batched
+ * selection launch for all of them.  In RL_ARITH_F16_SPLIT arithmetic eight queries (nq <= 32) share one pass over
+ * the index' pre-split corpus image (fp16 hi | lo planes written when the index is built: 4 more bytes per element
+ * of device memory; RAGLITE_NO_PLANES=1 in the environment disables it), otherwise two queries or one query
+ * take a pass over the fp32 / fp16 rows.
  *   query_vecs [n_queries x nq x dim] f32; out_scores / out_chunks [n_queries x k]. */
 int rl_maxsim_topk_batch(rl_index* index, const float* query_vecs, int32_t n_queries, int32_t nq, int32_t k,
                          float* out_scores, int32_t* out_chunks, int mem, void* stream);
@@ -256,7 +259,8 @@ int rl_partition_similarity(const float* X, int64_t n, int32_t dim, const int64_
  * events on `stream` bracketing `iters` back-to-back launches of the named kernel path with the
  * given index / query.  kind: 0 = rl_maxsim_scores kernel only, 1 = rl_search_rows scan kernel
  * only (no selection), 2 = the two-queries-per-pass MaxSim kernel of rl_maxsim_topk_batch (query_vecs_dev
- * then holds two queries of nq / 2 vectors each; RL_ERR_UNSUPPORTED where that kernel does not apply).  Used so that roofline.achieved is measured with HIP events on the stream
+ * then holds two queries of nq / 2 vectors each; RL_ERR_UNSUPPORTED where that kernel does not apply), 3 = the
+ * eight-queries-per-pass kernel over the pre-split corpus image (eight queries of nq / 8 vectors each).  Used so that roofline.achieved is measured with HIP events on the stream
  * the kernel runs on. */
 int rl_time_kernel(rl_index* index, int kind, const float* query_vecs_dev, int32_t nq, int32_t iters,
                    float* out_ms_total, void* stream);

@@ -230,6 +230,11 @@ struct rl_index {
     bool nonfinite = false;
     int arithmetic = RL_ARITH_AUTO;
     float split_scale = 0.f;              // > 0: power of two applied to the corpus inside the kernel; 0: exact fp32 MFMAs
+    // Pre-split corpus image of maxsim_gemm.hip (fp16 hi | lo planes in the kernel's LDS layout, 4 B per element) and
+    // the "last row of its chunk" bitmap; built with the index, extended on append, rebuilt when split_scale changes.
+    rl::Pool planes, ends, qplanes;
+    float planes_scale = 0.f;             // the scale the image was built with; 0 = no image
+    int64_t planes_rows = 0;              // rows the image covers
 };
 
 namespace {
@@ -266,6 +271,38 @@ int scan_row_range(rl_index* idx, int64_t first, int64_t n, hipStream_t s) {
     idx->min_row_max = std::min(idx->min_row_max, mn);
     idx->nonfinite |= h[2] != 0;
     update_split_scale(idx);
+    return RL_OK;
+}
+
+// Builds / extends the pre-split corpus image so that it covers rows [0, idx->n_rows) at idx->split_scale.  Not having
+// the image is never an error (the streaming kernels read the fp32 rows): an allocation failure just leaves it absent.
+int refresh_planes(rl_index* idx, hipStream_t s) {
+    static const bool no_planes = std::getenv("RAGLITE_NO_PLANES") != nullptr;  // A/B switch
+    const bool want = !no_planes && !idx->E16 && idx->E && idx->split_scale > 0.f && idx->dim % 32 == 0 && idx->dim >= 32 &&
+                      idx->n_rows > 0;
+    if (!want) {
+        idx->planes.release();
+        idx->ends.release();
+        idx->planes_scale = 0.f;
+        idx->planes_rows = 0;
+        return RL_OK;
+    }
+    const int64_t cap = std::max<int64_t>(idx->n_rows, idx->owns_E ? idx->cap_rows : idx->n_rows);
+    const size_t need = rl::planes_bytes(cap, idx->dim), need_e = rl::chunk_ends_words(cap) * sizeof(uint32_t);
+    int64_t first = idx->planes_scale == idx->split_scale ? (idx->planes_rows & ~int64_t(15)) : 0;
+    if (idx->planes.cap < need) first = 0;  // Pool::reserve does not keep the contents
+    if (idx->planes.reserve(need) != RL_OK || idx->ends.reserve(need_e) != RL_OK) {
+        (void)hipGetLastError();
+        idx->planes.release();
+        idx->ends.release();
+        idx->planes_scale = 0.f;
+        idx->planes_rows = 0;
+        return RL_OK;
+    }
+    RL_TRY(rl::launch_presplit_rows(idx->E, first, idx->n_rows, idx->dim, idx->split_scale, idx->planes.p, s));
+    RL_TRY(rl::launch_chunk_ends(idx->row_to_chunk, idx->n_rows, idx->ends.as<uint32_t>(), s));
+    idx->planes_scale = idx->split_scale;
+    idx->planes_rows = idx->n_rows;
     return RL_OK;
 }
 }  // namespace
@@ -436,6 +473,9 @@ int rl_index_destroy(rl_index* idx) {
     if (idx->live_row_bits) (void)hipFree(idx->live_row_bits);
     idx->maskbuf.release();
     idx->qsplit.release();
+    idx->planes.release();
+    idx->ends.release();
+    idx->qplanes.release();
     select_workspace_free(idx->ws);
     idx->scores.release();
     idx->hits.release();
@@ -513,6 +553,7 @@ static int index_create_any(rl_index** out, const void* embeddings, bool f16, in
         RL_IDX(f16 ? launch_row_norms16(idx->E16, n_rows, dim, idx->norm, idx->sumsq, s)
                    : launch_row_norms(idx->E, n_rows, dim, idx->norm, idx->sumsq, s));
     RL_IDX(scan_row_range(idx, 0, n_rows, s));
+    RL_IDX(refresh_planes(idx, s));
     RL_IDX_HIP(hipStreamSynchronize(s));  // host_offsets / caller buffers may go away after return
 #undef RL_IDX
 #undef RL_IDX_HIP
@@ -587,6 +628,8 @@ int rl_index_set_arithmetic(rl_index* idx, int mode) {
     std::lock_guard<std::mutex> lock(idx->mu);
     idx->arithmetic = mode;
     update_split_scale(idx);
+    RL_TRY(refresh_planes(idx, nullptr));
+    RL_HIP(hipStreamSynchronize(nullptr));
     return RL_OK;
 }
 
@@ -695,6 +738,7 @@ int rl_index_append(rl_index* idx, const float* rows, int64_t n_new_rows, const 
                    : launch_row_norms(idx->E + (size_t)old_n * idx->dim, n_new_rows, idx->dim, nn, ns, s));
     }
     RL_TRY(scan_row_range(idx, old_n, n_new_rows, s));
+    RL_TRY(refresh_planes(idx, s));
     if (!idx->h_live.empty()) {  // new chunks are live
         const size_t cw = (size_t)(new_c + 31) / 32;
         idx->h_live.resize(cw, 0u);
@@ -921,6 +965,23 @@ int pairs_pass(rl_index* idx, int32_t nq, int32_t n_queries, int32_t first, floa
                                  out_stride, idx->n_cu, s, idx->split_scale);
 }
 
+// Batched MaxSim over the pre-split corpus image scores EIGHT queries per corpus pass (maxsim_gemm.hip).  gemm_prepare lays
+// the queries' fp16 (hi, lo) MFMA fragments out once per batch (idx->qplanes); gemm_pass scores queries first .. first +
+// n_q - 1 of them.  RL_ERR_UNSUPPORTED when the index has no image, has an empty chunk (the kernel finds a chunk by
+// counting chunk ends) or the shape is outside the kernel -- the caller then uses the streaming kernels.
+constexpr int32_t GEMM_PASS_QUERIES = 8, GEMM_PASS_MIN_QUERIES = 3;
+int gemm_prepare(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, int32_t n_queries, hipStream_t s) {
+    static const bool off = std::getenv("RAGLITE_NO_GEMM_PASS") != nullptr;  // A/B switch
+    if (off || idx->planes_scale <= 0.f || idx->planes_scale != idx->split_scale || idx->planes_rows != idx->n_rows) return RL_ERR_UNSUPPORTED;
+    if (idx->has_empty_chunk || idx->n_chunks == 0 || nq < 1 || nq > 32 || n_queries < GEMM_PASS_MIN_QUERIES) return RL_ERR_UNSUPPORTED;
+    RL_TRY(idx->qplanes.reserve(query_planes_bytes(idx->dim, n_queries)));
+    return launch_query_planes(d_q, idx->dim, nq, q_stride, n_queries, idx->qplanes.p, s);
+}
+int gemm_pass(rl_index* idx, int32_t nq, int32_t n_queries, int32_t first, int32_t n_q, float* d_out, int64_t out_stride, hipStream_t s) {
+    return launch_maxsim_gemm(idx->planes.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, first, n_q, nq, idx->row_to_chunk,
+                              idx->offsets, idx->ends.as<uint32_t>(), d_out, out_stride, idx->n_cu, s, idx->split_scale);
+}
+
 int maxsim_scores_device(rl_index* idx, const float* d_q, int32_t nq, float* d_out, hipStream_t s) {
     if (idx->n_chunks == 0) return RL_OK;
     int st = RL_ERR_UNSUPPORTED;
@@ -1020,14 +1081,30 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
     // disagree with the live roofline timing; the serial form keeps every number checkable.)
     // Two queries share a pass where the arithmetic allows it (fp16-split, 17..32 vectors per query); an odd query out,
     // and every query otherwise, takes a pass of its own.
-    int32_t paired = 0;
+    // Eight queries share a pass over the pre-split corpus image where the index has one (maxsim_gemm.hip); what is left
+    // of the batch (fewer than three queries) goes through the streaming kernels as before.
+    int32_t base = 0;
     {
-        const int st = pairs_prepare(idx, d_q, nq, (int64_t)q_elems, n_queries & ~1, s);
-        if (st == RL_OK) paired = n_queries & ~1;
+        const int st = gemm_prepare(idx, d_q, nq, (int64_t)q_elems, n_queries, s);
+        if (st == RL_OK) {
+            while (n_queries - base >= GEMM_PASS_MIN_QUERIES) {
+                const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_queries - base);
+                RL_TRY(gemm_pass(idx, nq, n_queries, base, n_q, sc + (int64_t)base * ld, ld, s));
+                base += n_q;
+            }
+        } else if (st != RL_ERR_UNSUPPORTED) {
+            return st;
+        }
+    }
+    const int32_t rest = n_queries - base;
+    int32_t paired = 0;
+    if (rest >= 2) {
+        const int st = pairs_prepare(idx, d_q + (size_t)base * q_elems, nq, (int64_t)q_elems, rest & ~1, s);
+        if (st == RL_OK) paired = rest & ~1;
         else if (st != RL_ERR_UNSUPPORTED) return st;
     }
-    for (int32_t b = 0; b < paired; b += 2) RL_TRY(pairs_pass(idx, nq, paired, b, sc + (int64_t)b * ld, ld, s));
-    for (int32_t b = paired; b < n_queries; ++b)
+    for (int32_t b = 0; b < paired; b += 2) RL_TRY(pairs_pass(idx, nq, paired, b, sc + (int64_t)(base + b) * ld, ld, s));
+    for (int32_t b = base + paired; b < n_queries; ++b)
         RL_TRY(maxsim_scores_device(idx, d_q + (size_t)b * q_elems, nq, sc + (int64_t)b * ld, s));
     RL_TRY(mask_chunk_scores(idx, sc, n_queries, ld, nullptr, s));  // tombstones (no-op without deletions)
     RL_TRY(launch_topk(sc, n_queries, idx->n_chunks, ld, k, idx->ws, d_s, d_c, s));
@@ -1185,6 +1262,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     const int64_t ldc = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
     if (kind == 0) RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));
     else if (kind == 2) RL_TRY(idx->scores.reserve((size_t)2 * ldc * sizeof(float)));
+    else if (kind == 3) RL_TRY(idx->scores.reserve((size_t)GEMM_PASS_QUERIES * ldc * sizeof(float)));
     else RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)nq * ld * sizeof(float), 16)));
     hipEvent_t e0, e1;
     RL_HIP(hipEventCreate(&e0));
@@ -1194,9 +1272,14 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
         st = pairs_prepare(idx, q_dev, nq / 2, (int64_t)(nq / 2) * idx->dim, 2, s);
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the pair kernel does not apply to this index / shape") : st; }
     }
+    if (kind == 3) {  // eight queries of nq / 8 vectors each
+        st = gemm_prepare(idx, q_dev, nq / GEMM_PASS_QUERIES, (int64_t)(nq / GEMM_PASS_QUERIES) * idx->dim, GEMM_PASS_QUERIES, s);
+        if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the eight-query kernel does not apply to this index / shape") : st; }
+    }
     RL_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < iters && st == RL_OK; ++i) {
-        if (kind == 0) st = maxsim_scores_device(idx, q_dev, nq, idx->scores.as<float>(), s);
+        if (kind == 3) st = gemm_pass(idx, nq / GEMM_PASS_QUERIES, GEMM_PASS_QUERIES, 0, GEMM_PASS_QUERIES, idx->scores.as<float>(), ldc, s);
+        else if (kind == 0) st = maxsim_scores_device(idx, q_dev, nq, idx->scores.as<float>(), s);
         else if (kind == 2) st = pairs_pass(idx, nq / 2, 2, 0, idx->scores.as<float>(), ldc, s);
         else st = score_rows(idx, q_dev, nq, ld, s);
     }

@@ -1,0 +1,503 @@
+// a9 at batch scale: MaxSim of EIGHT queries (up to 32 vectors each) per corpus pass over the PRE-SPLIT corpus image.
+//
+//   out[q * out_stride + c] = sum_{i < nq} max_{j in chunk c} Q_q[i] . D[j]      q = 0 .. n_q - 1  (n_q <= 8)
+//
+// Multi-query generalisation of src/raglite/_search.py:143-149 / src/raglite/_query_adapter.py:174, behind the reranker
+// plugin call src/raglite/_search.py:394-396 (rl_maxsim_topk_batch).
+//
+// Why a third MaxSim kernel.  The streaming kernels of maxsim_stream.hip keep the query in registers and the corpus
+// tile in LDS: one (or two) queries per corpus pass, HBM-bound at 0.58-0.68 ms per pass while the fp16 matrix pipe idles
+// (27 % busy, profiles/r01_m_pmc.txt) and every fp32 corpus element is re-split into its fp16 (hi, lo) pair on every
+// pass.  Per query the split arithmetic needs 3 x 2 x 32 x N x 1024 flop = 0.079 ms of the 2.5 PFLOP/s fp16 pipe at
+// N = 1 M, so the matrix roof is 4x away.  This kernel is the GEMM formulation of the same sum:
+//   * the corpus is split ONCE, when the index is built (presplit_rows_kernel): x * e_scale = hi + lo, hi = fp16_rtz, lo =
+//     fp16_rtz(x * e_scale - hi), stored as the kernel's own LDS image -- blocks of 16 rows, per block and 32-wide K slab
+//     2 KiB holding the rows' 4 hi chunks and 4 lo chunks of 16 B, already swizzled (chunk c of row j at position
+//     c ^ ((j >> 1) & 7)) so that every LDS-DMA instruction copies 1 KiB of contiguous HBM and every ds_read_b128
+//     fragment read is bank-conflict-free.  4 B per element: the same HBM bytes per pass as the fp32 matrix;
+//   * tile = 256 corpus rows x 256 query vectors (8 queries x 32), K slabs of 32: one persistent 512-thread workgroup
+//     per CU walks a contiguous, chunk-aligned row range; wave w owns query w: its accumulators are the 32 x 256 score
+//     tile S^T[query vector][corpus row] (2 x 16 MFMA tiles = 128 VGPRs), summed over all of K, so there is no K-split
+//     reduction and no partial exchange;
+//   * the corpus slab (32 KiB) goes HBM -> LDS by `global_load_lds_dwordx4 ... nt`, every wave issuing 4 of the 32 DMAs
+//     from inside its MFMA loop, ring of 3 slabs, ONE workgroup barrier per slab; the query fragments (4 KiB per wave
+//     and slab, L2-resident: the whole batch's image is 1 MiB) go straight from L2 into registers, one slab ahead;
+//   * per slab and wave 96 v_mfma_f32_16x16x32_f16 (q_hi.e_hi, q_hi.e_lo, q_lo.e_hi -- the third skipped when the
+//     query's lo halves are all zero) on 36 ds_read_b128: zero conversion VALU in the loop;
+//   * the MFMA operands are swapped against maxsim_stream.hip (A = query fragment, B = corpus fragment), so a lane of
+//     the C/D layout holds 4 query vectors x ONE corpus row and the 16 corpus rows of a block lie along a DPP row: the
+//     per-chunk maximum is a branch-free segmented max-scan over 16 lanes (row_shr 1, 2, 4, 8 under scalar lane masks
+//     derived from a per-row "last row of its chunk" bitmap), the open chunk's running maxima move to the next block by
+//     row_ror, the sum over the 32 query vectors is 7 adds + 2 cross-row shuffles, and a finished chunk is stored by
+//     its end row's lane.  No LDS round trip, no per-row branch.
+// Deterministic: fixed MFMA order per (query vector, row), fixed scan and sum order; results do not depend on the grid.
+// Integer-valued data is exact (products of fp16 halves are exact in fp32): bit-identical to the oracle.
+#include <cstdlib>
+
+#include "common.h"
+
+namespace rl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int MG_TM = 256;               // corpus rows per tile
+constexpr int MG_NBLK = MG_TM / 16;      // 16-row blocks per tile
+constexpr int MG_SLAB = MG_TM * 128;     // bytes of one K slab (32 k) of a tile in LDS: 16 blocks x 2 KiB
+constexpr int MG_NSLOT = 3;              // LDS ring
+constexpr int MG_WAVES = 8;              // waves per workgroup = queries per pass
+
+__device__ __forceinline__ int64_t mg_uniform_i64(int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+}  // namespace
+
+// ---- corpus image ----------------------------------------------------------------------------------------------------
+// Bytes of the image of `rows` rows (rounded up to whole 16-row blocks).
+size_t planes_bytes(int64_t rows, int32_t dim) { return (size_t)((rows + 15) / 16) * 16 * (size_t)dim * 4; }
+
+// One thread per (row, slab, k-quarter): 8 consecutive fp32 -> one hi chunk and one lo chunk.  Rows in
+// [n_rows, 16 * ceil(n_rows / 16)) are written as zeros.  `first_row` must be a multiple of 16 unless the rows before
+// it in its block are already in place (append).
+__global__ __launch_bounds__(256) void presplit_rows_kernel(const float* __restrict__ E, int64_t first_row, int64_t end_row,
+                                                             int64_t n_rows, int32_t dim, float scale, char* __restrict__ planes) {
+    const int32_t nslab = dim >> 5;
+    const int64_t per_row = (int64_t)nslab * 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = first_row + i / per_row;
+    if (row >= end_row) return;
+    const int32_t rem = (int32_t)(i % per_row), s = rem >> 2, kq = rem & 3;
+    f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (row < n_rows) {
+        const float* p = E + row * dim + 32 * s + 8 * kq;
+        v0 = *reinterpret_cast<const f32x4*>(p);
+        v1 = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    h16x8 hi, lo;
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+        const float x0 = (u < 4 ? v0[u] : v1[u - 4]) * scale, x1 = (u < 4 ? v0[u + 1] : v1[u - 3]) * scale;
+        const auto ph = __builtin_amdgcn_cvt_pkrtz(x0, x1);  // truncation: the residual is exact in fp32
+        const auto pl = __builtin_amdgcn_cvt_pkrtz(x0 - (float)ph[0], x1 - (float)ph[1]);
+        hi[u] = ph[0]; hi[u + 1] = ph[1];
+        lo[u] = pl[0]; lo[u + 1] = pl[1];
+    }
+    const int j = (int)(row & 15), sw = (j >> 1) & 7;
+    char* blk = planes + (((row >> 4) * nslab + s) * 16 + j) * 128;
+    *reinterpret_cast<h16x8*>(blk + ((kq ^ sw) << 4)) = hi;
+    *reinterpret_cast<h16x8*>(blk + (((4 + kq) ^ sw) << 4)) = lo;
+}
+
+int launch_presplit_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s) {
+    if (dim % 32 || dim < 32) return RL_ERR_UNSUPPORTED;
+    const int64_t end_row = (n_rows + 15) / 16 * 16;
+    if (end_row <= first_row) return RL_OK;
+    const int64_t threads = (end_row - first_row) * (dim / 8);
+    hipLaunchKernelGGL(presplit_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, E, first_row, end_row, n_rows, dim,
+                       scale, static_cast<char*>(planes));
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// ends[w] bit i <=> row 32 w + i is the last row of its chunk (row_to_chunk[n_rows] = -1 terminates the last chunk).
+// `words` words are written; rows >= n_rows give 0.
+__global__ __launch_bounds__(256) void chunk_ends_kernel(const int32_t* __restrict__ row_to_chunk, int64_t n_rows, int64_t words,
+                                                          uint32_t* __restrict__ ends) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= words) return;
+    uint32_t m = 0;
+    const int64_t r0 = w * 32;
+    if (r0 < n_rows) {
+        int32_t c = row_to_chunk[r0];
+        for (int i = 0; i < 32 && r0 + i < n_rows; ++i) {
+            const int32_t nx = row_to_chunk[r0 + i + 1];
+            m |= (uint32_t)(nx != c) << i;
+            c = nx;
+        }
+    }
+    ends[w] = m;
+}
+
+size_t chunk_ends_words(int64_t rows) { return (size_t)((rows + 31) / 32) + 16; }  // + window over-read of the last tile
+
+int launch_chunk_ends(const int32_t* row_to_chunk, int64_t n_rows, uint32_t* ends, hipStream_t s) {
+    const int64_t words = (int64_t)chunk_ends_words(n_rows);
+    hipLaunchKernelGGL(chunk_ends_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, row_to_chunk, n_rows, words, ends);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// ---- query image -----------------------------------------------------------------------------------------------------
+// One block per query: scale (one power of two per query, the largest |element| to [2^13, 2^14)), split into fp16
+// (hi, lo) and lay the MFMA A fragments out exactly as a wave loads them:
+//   frag[((query * nslab + s) * 4 + 2 * qb + part) * 64 + lane]   16 B = 8 halves, part 0 = hi, 1 = lo;
+//   lane (j = lane & 15, kq = lane >> 4) holds k = 32 s + 8 kq .. + 7 of query vector 16 qb + j (zeros past nq)
+//   meta[2 * query + {0, 1}] = {2^(ex - 14) (undoes the scale), any lo != 0}
+__global__ __launch_bounds__(256) void query_planes_kernel(const float* __restrict__ Q, int nq, int dim, int64_t q_stride,
+                                                            uint4* __restrict__ frag, float* __restrict__ meta) {
+    __shared__ float part[4];
+    __shared__ int any_lo_sh;
+    const int64_t query = blockIdx.x;
+    const float* const Qg = Q + query * q_stride;
+    const int nslab = dim >> 5;
+    float mx = 0.f;
+    for (int i = threadIdx.x * 4; i < nq * dim; i += 1024) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(Qg + i);
+        mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
+    if (threadIdx.x == 0) any_lo_sh = 0;
+    __syncthreads();
+    mx = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    int ex = 0;
+    if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &ex);  // mx = f * 2^ex, f in [0.5, 1)
+    ex = ex > -100 ? ex : -100;
+    const float q_scale = ldexpf(1.f, 14 - ex);
+    bool any_lo = false;
+    uint4* const out = frag + query * nslab * 4 * 64;
+    for (int t = threadIdx.x; t < nslab * 2 * 64; t += 256) {
+        const int lane = t & 63, qb = (t >> 6) & 1, s = t >> 7;
+        const int qi = 16 * qb + (lane & 15), kq = lane >> 4;
+        h16x8 hi8, lo8;
+        f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (qi < nq) {
+            const float* p = Qg + (int64_t)qi * dim + 32 * s + 8 * kq;
+            v0 = *reinterpret_cast<const f32x4*>(p);
+            v1 = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float x = (u < 4 ? v0[u] : v1[u - 4]) * q_scale;
+            const _Float16 hi = (_Float16)x;
+            const _Float16 lo = (_Float16)(x - (float)hi);
+            hi8[u] = hi;
+            lo8[u] = lo;
+            any_lo |= lo != (_Float16)0.0f;
+        }
+        uint4 a, b;
+        __builtin_memcpy(&a, &hi8, 16);
+        __builtin_memcpy(&b, &lo8, 16);
+        out[(s * 4 + 2 * qb + 0) * 64 + lane] = a;
+        out[(s * 4 + 2 * qb + 1) * 64 + lane] = b;
+    }
+    if (any_lo) any_lo_sh = 1;  // benign race: every writer stores 1
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        meta[2 * query + 0] = ldexpf(1.f, ex - 14);
+        meta[2 * query + 1] = any_lo_sh ? 1.f : 0.f;
+    }
+}
+
+size_t query_planes_bytes(int32_t dim, int32_t n_queries) { return (size_t)n_queries * ((size_t)dim * 128 + 8) + 64; }
+
+int launch_query_planes(const float* Q, int32_t dim, int32_t nq, int64_t q_stride, int32_t n_queries, void* buf, hipStream_t s) {
+    if (nq < 1 || nq > 32 || n_queries < 1 || dim % 32 || dim < 32) return RL_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
+    uint4* frag = static_cast<uint4*>(buf);
+    float* meta = reinterpret_cast<float*>(static_cast<char*>(buf) + (size_t)n_queries * dim * 128);
+    hipLaunchKernelGGL(query_planes_kernel, dim3((unsigned)n_queries), dim3(256), 0, s, Q, (int)nq, (int)dim, q_stride, frag, meta);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// ---- the pass --------------------------------------------------------------------------------------------------------
+namespace {
+// One query fragment load (64 lanes x 16 B, L2-resident) into 4 VGPRs, invisible to the compiler's vmcnt bookkeeping:
+// the value is only valid after the matching `s_waitcnt vmcnt` + mg_pin() below.
+__device__ __forceinline__ void mg_load_frag(f32x4& dst, uint32_t voff, const char* base) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(base) : "memory");
+}
+__device__ __forceinline__ void mg_pin(f32x4& a, f32x4& b, f32x4& c, f32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+
+}  // namespace
+
+// dst = max(src shifted along its DPP row, x); lanes without a source lane keep an undefined dst (never selected below).
+// `volatile`: the epilogue issues these in source order -- all DPP reads of a step, then all selects -- so that a VGPR
+// written by a select is read through DPP at least 8 instructions later (the VALU-write -> DPP-read hazard needs 2 wait
+// states and the compiler's hazard recogniser does not look inside inline asm).
+#define MG_MAX_DPP(dst, src, x, CTRLSTR) asm volatile("v_max_f32_dpp %0, %1, %2 " CTRLSTR " row_mask:0xf bank_mask:0xf" : "=&v"(dst) : "v"(src), "v"(x))
+#define MG_SELECT(x, t, mask) asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(x) : "v"(x), "v"(t), "s"(mask))
+
+template <int NQB>
+__global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restrict__ planes, int64_t n_rows, int32_t nslab,
+                                                               const char* __restrict__ qfrag, const float* __restrict__ qmeta,
+                                                               int32_t n_q, const int32_t* __restrict__ row_to_chunk,
+                                                               const int64_t* __restrict__ chunk_offsets,
+                                                               const uint32_t* __restrict__ ends_bits, float* __restrict__ out,
+                                                               int64_t out_stride, float inv_e_scale) {
+    __shared__ __attribute__((aligned(16))) char smem[MG_NSLOT * MG_SLAB];
+    const int lane = threadIdx.x & 63;
+    const int wv = wave_id();  // 0..7 = the query this wave scores
+    const int64_t G = gridDim.x, b = blockIdx.x;
+    // Chunk-aligned row range of this workgroup (as in maxsim_stream.hip): first chunk boundary at or after n_rows * b / G.
+    auto boundary = [&](int64_t t) -> int64_t {
+        if (t <= 0) return 0;
+        if (t >= n_rows) return n_rows;
+        const int32_t c = row_to_chunk[t];
+        const int64_t c0 = chunk_offsets[c], c1 = chunk_offsets[c + 1];
+        return c0 == t ? t : c1;
+    };
+    const int32_t r_lo = (int32_t)mg_uniform_i64(boundary((n_rows * b) / G));
+    const int32_t r_hi = (int32_t)mg_uniform_i64((b + 1 == G) ? n_rows : boundary((n_rows * (b + 1)) / G));
+    if (r_hi <= r_lo) return;  // whole workgroup
+    const int32_t org = r_lo & ~15;                       // tiles start on a 16-row block of the image
+    const int nt = (r_hi - org + MG_TM - 1) / MG_TM;
+    const int total = nt * nslab;                         // K slabs this workgroup consumes, tile after tile
+    const int32_t last_blk = (int32_t)((n_rows + 15) >> 4) - 1;
+    const bool has_q = wv < n_q;                          // wave-uniform
+    const int fj = lane & 15, kq = lane >> 4;
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+    const uint32_t lane16 = 16u * lane;
+
+    // ---- this wave's share of the corpus stream: blocks 2 wv, 2 wv + 1 of every slab (4 DMAs of 1 KiB) ---------------
+    struct Feed { const char* src[2]; uint32_t lds; };
+    int f_tile = 0, f_s = 0, f_slot = 0;   // position of the NEXT slab to fetch
+    auto next_feed = [&]() {
+        Feed f;
+        const int32_t b0 = (org >> 4) + f_tile * MG_NBLK + 2 * wv;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int32_t blk = b0 + i;
+            blk = blk < last_blk ? blk : last_blk;  // past the image: harmless re-read of the last block, never used
+            f.src[i] = planes + mg_uniform_i64(((int64_t)blk * nslab + f_s) * 2048);
+        }
+        f.lds = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(f_slot * MG_SLAB + 2 * wv * 2048));
+        if (++f_s == nslab) { f_s = 0; if (f_tile + 1 < nt) ++f_tile; }  // past the end: re-fetch the last tile (keeps vmcnt uniform)
+        f_slot = f_slot + 1 == MG_NSLOT ? 0 : f_slot + 1;
+        return f;
+    };
+    auto dma_piece = [&](const Feed& f, auto P_) {  // piece p = 2 * block + half
+        constexpr int p = decltype(P_)::value, i = p >> 1, h = p & 1;
+        const uint32_t lane16 = 16u * lane;  // (asm operands alone do not capture an enclosing local in a generic lambda)
+        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 offset:%4 nt" ::"s"(f.lds), "n"(i * 2048),
+                     "v"(lane16), "s"(f.src[i]), "n"(h * 1024)
+                     : "memory", "m0", "scc");
+    };
+    auto dma_all = [&](const Feed& f) {
+        dma_piece(f, std::integral_constant<int, 0>{});
+        dma_piece(f, std::integral_constant<int, 1>{});
+        dma_piece(f, std::integral_constant<int, 2>{});
+        dma_piece(f, std::integral_constant<int, 3>{});
+    };
+
+    // ---- this wave's query fragments: slab s -> 4 x 16 B per lane (qb0 hi, qb0 lo, qb1 hi, qb1 lo) -------------------
+    const char* const qbase = qfrag + (int64_t)(has_q ? wv : 0) * nslab * 4096;
+    int q_s = 0;  // slab of the NEXT fragment load
+    auto load_q = [&](f32x4 (&q)[4]) {
+        const char* p = qbase + (int64_t)q_s * 4096;
+        mg_load_frag(q[0], lane16, p);
+        mg_load_frag(q[1], lane16, p + 1024);
+        mg_load_frag(q[2], lane16, p + 2048);
+        mg_load_frag(q[3], lane16, p + 3072);
+        q_s = q_s + 1 == nslab ? 0 : q_s + 1;
+    };
+    const float unscale = has_q ? qmeta[2 * wv] * inv_e_scale : 0.f;
+    const bool any_lo = has_q && __builtin_amdgcn_readfirstlane(__float_as_int(qmeta[2 * (has_q ? wv : 0) + 1])) != 0;
+
+    // ---- accumulators: S^T[query vector 16 qb + 4 g + u][corpus row 16 a + j], lane = 16 g + j ------------------------
+    f32x4 acc[NQB][MG_NBLK];
+#pragma unroll
+    for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+        for (int a = 0; a < MG_NBLK; ++a) acc[qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float carry[NQB * 4];  // scanned maxima of the previous block (lane 15 of each DPP row = the chunk still open)
+#pragma unroll
+    for (int r = 0; r < NQB * 4; ++r) carry[r] = -INFINITY;
+    uint32_t prev_last_end = 1;  // is the row before the tile's first row the last row of its chunk?
+
+    const uint32_t sw = (uint32_t)((fj >> 1) & 7);
+    const uint32_t a_hi = (uint32_t)(fj * 128) + ((kq ^ sw) << 4), a_lo = (uint32_t)(fj * 128) + (((4 + kq) ^ sw) << 4);
+    float* const outq = out + (int64_t)(has_q ? wv : 0) * out_stride;
+
+    // ---- one K slab: fragments of slot `slot`, query fragments q, feeding the slab two ahead -------------------------
+    int c_tile = 0, c_s = 0, c_slot = 0;
+    auto slab = [&](f32x4 (&q)[4], int nb) {
+        const Feed f = next_feed();
+        if (has_q) {
+            h16x8 qh[2], ql[2];
+            __builtin_memcpy(&qh[0], &q[0], 16);
+            __builtin_memcpy(&ql[0], &q[1], 16);
+            __builtin_memcpy(&qh[1], &q[2], 16);
+            __builtin_memcpy(&ql[1], &q[3], 16);
+            const char* const base = smem + c_slot * MG_SLAB;
+            h16x8 eh[2][2], el[2][2];  // [pair parity][block of the pair]
+            auto read_pair = [&](int p, h16x8 (&h)[2], h16x8 (&l)[2]) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    h[i] = *reinterpret_cast<const h16x8*>(base + (2 * p + i) * 2048 + a_hi);
+                    l[i] = *reinterpret_cast<const h16x8*>(base + (2 * p + i) * 2048 + a_lo);
+                }
+            };
+            read_pair(0, eh[0], el[0]);
+#pragma unroll
+            for (int p = 0; p < MG_NBLK / 2; ++p) {
+                if (p + 1 < MG_NBLK / 2) read_pair(p + 1, eh[(p + 1) & 1], el[(p + 1) & 1]);
+                if (2 * p < nb) {  // wave-uniform: blocks past the workgroup's range are not multiplied
+                    const h16x8(&h)[2] = eh[p & 1];
+                    const h16x8(&l)[2] = el[p & 1];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int qb = 0; qb < NQB; ++qb)
+                            acc[qb][2 * p + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[qb], h[i], acc[qb][2 * p + i], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int qb = 0; qb < NQB; ++qb)
+                            acc[qb][2 * p + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[qb], l[i], acc[qb][2 * p + i], 0, 0, 0);
+                    if (any_lo) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int qb = 0; qb < NQB; ++qb)
+                                acc[qb][2 * p + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql[qb], h[i], acc[qb][2 * p + i], 0, 0, 0);
+                    }
+                }
+                if (p == 0) dma_piece(f, std::integral_constant<int, 0>{});
+                if (p == 2) dma_piece(f, std::integral_constant<int, 1>{});
+                if (p == 4) dma_piece(f, std::integral_constant<int, 2>{});
+                if (p == 6) dma_piece(f, std::integral_constant<int, 3>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            dma_all(f);
+        }
+        c_slot = c_slot + 1 == MG_NSLOT ? 0 : c_slot + 1;
+    };
+
+    // ---- tile epilogue: per-chunk maxima along the DPP rows, sum over the query vectors, store ---------------------------
+    auto epilogue = [&](int t) {
+        const int32_t row0 = org + t * MG_TM;
+        // "last row of its chunk" bits of the tile's 256 rows: 9 words from row0 / 32, shifted by 16 when row0 is odd in blocks
+        uint32_t m[9];
+        const uint32_t* const eb = ends_bits + (row0 >> 5);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) m[i] = eb[i];
+        const bool odd = (row0 & 16) != 0;
+        uint32_t mm[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) mm[i] = odd ? (m[i] >> 16) | (m[i + 1] << 16) : m[i];
+        if (has_q) {
+#pragma unroll
+            for (int a = 0; a < MG_NBLK; ++a) {
+                const uint32_t E = (mm[a >> 1] >> (16 * (a & 1))) & 0xffffu;
+                const int32_t base = row0 + 16 * a;
+                const int32_t ord0 = row_to_chunk[base < (int32_t)n_rows ? base : (int32_t)n_rows];
+                // lanes whose shifted neighbour belongs to the same chunk: no chunk end in rows [j - d, j - 1]
+                const uint32_t O1 = E << 1, O2 = O1 | (O1 << 1), O4 = O2 | (O2 << 2), O8 = O4 | (O4 << 4);
+                const uint64_t rep = 0x0001000100010001ull;
+                const uint64_t F1 = (uint64_t)(~O1 & 0xfffeu) * rep, F2 = (uint64_t)(~O2 & 0xfffcu) * rep;
+                const uint64_t F4 = (uint64_t)(~O4 & 0xfff0u) * rep, F8 = (uint64_t)(~O8 & 0xff00u) * rep;
+                const uint64_t C0 = prev_last_end ? 0ull : rep;  // row 0 continues the chunk open at the end of the previous block
+                float x[NQB * 4];
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[4 * qb + u] = acc[qb][a][u];
+                float tmp[NQB * 4];
+#define MG_STEP(SRC, CTRLSTR, MASK)                                                        \
+    _Pragma("unroll") for (int r = 0; r < NQB * 4; ++r) MG_MAX_DPP(tmp[r], SRC, x[r], CTRLSTR); \
+    _Pragma("unroll") for (int r = 0; r < NQB * 4; ++r) MG_SELECT(x[r], tmp[r], MASK);
+                MG_STEP(carry[r], "row_ror:1", C0)  // lane 0 <- lane 15 of the previous block's scan
+                MG_STEP(x[r], "row_shr:1", F1)
+                MG_STEP(x[r], "row_shr:2", F2)
+                MG_STEP(x[r], "row_shr:4", F4)
+                MG_STEP(x[r], "row_shr:8", F8)
+#undef MG_STEP
+#pragma unroll
+                for (int r = 0; r < NQB * 4; ++r) carry[r] = x[r];
+                float tsum;
+                if constexpr (NQB == 2) tsum = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                else tsum = (x[0] + x[1]) + (x[2] + x[3]);
+                tsum += __shfl_xor(tsum, 16);
+                tsum += __shfl_xor(tsum, 32);
+                // rows of this block inside the workgroup's range
+                int32_t lo = r_lo - base, hi = r_hi - base;
+                lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
+                hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
+                const uint32_t EM = E & ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                if (EM != 0u) {  // wave-uniform
+                    const uint32_t below = E & ((1u << fj) - 1u);
+                    if (lane < 16 && ((EM >> lane) & 1u)) outq[ord0 + __builtin_popcount(below)] = tsum * unscale;
+                }
+                prev_last_end = (E >> 15) & 1u;
+#pragma unroll
+                for (int qb = 0; qb < NQB; ++qb) acc[qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+            prev_last_end = (mm[7] >> 31) & 1u;
+        }
+    };
+
+    // ---- main loop: two slabs per iteration (two static sets of query fragment registers) ---------------------------------
+    f32x4 qa[4], qb_[4];
+    {   // prologue: DMA(0), Q(0), DMA(1) -- the order the waits below count on
+        const Feed f0 = next_feed();
+        dma_all(f0);
+        if (has_q) load_q(qa);
+        const Feed f1 = next_feed();
+        dma_all(f1);
+    }
+    auto tile_nb = [&](int t) {
+        const int32_t left = r_hi - (org + t * MG_TM);
+        const int nb = (left + 15) >> 4;
+        return nb < MG_NBLK ? nb : MG_NBLK;
+    };
+    int nb = tile_nb(0);
+    auto advance = [&]() {
+        if (++c_s == nslab) {
+            epilogue(c_tile);
+            c_s = 0;
+            ++c_tile;
+            nb = tile_nb(c_tile);
+        }
+    };
+    for (int g = 0; g < total; g += 2) {
+        // slab g: its DMAs (issued two slabs ago) and its query fragments (one slab ago) have landed when at most the 4 DMAs
+        // of slab g + 1 are outstanding; VMEM retires in order.
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        mg_pin(qa[0], qa[1], qa[2], qa[3]);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (has_q) load_q(qb_);
+        slab(qa, nb);
+        advance();
+        if (g + 1 < total) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            mg_pin(qb_[0], qb_[1], qb_[2], qb_[3]);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if (has_q) load_q(qa);
+            slab(qb_, nb);
+            advance();
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
+}
+
+// n_q (1..8) queries `first .. first + n_q - 1` of a launch_query_planes buffer over `n_queries`, each nq (<= 32) vectors:
+// out[q * out_stride + chunk].  Needs an index without empty chunks (the chunk of an end row is found by counting ends).
+int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first,
+                       int32_t n_q, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits,
+                       float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale) {
+    if (nq < 1 || nq > 32 || n_q < 1 || n_q > MG_WAVES || n_rows < 1 || first < 0 || first + n_q > n_queries) return RL_ERR_UNSUPPORTED;
+    if (dim % 32 || dim < 32 || !(split_scale > 0.f) || !planes || !ends_bits) return RL_ERR_UNSUPPORTED;
+    const int32_t nslab = dim / 32;
+    const char* qfrag = static_cast<const char*>(qbuf) + (size_t)first * nslab * 4096;
+    const float* qmeta = reinterpret_cast<const float*>(static_cast<const char*>(qbuf) + (size_t)n_queries * dim * 128) + 2 * (size_t)first;
+    const int64_t tiles = (n_rows + MG_TM - 1) / MG_TM;
+    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
+    if (nq <= 16)
+        hipLaunchKernelGGL((maxsim_gemm_kernel<1>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, qmeta, n_q,
+                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale);
+    else
+        hipLaunchKernelGGL((maxsim_gemm_kernel<2>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, qmeta, n_q,
+                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+}  // namespace rl

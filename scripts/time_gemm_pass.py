@@ -1,0 +1,31 @@
+"""Kernel-only timing (HIP events on the launch stream) of the MaxSim pass kernels at the metric shape:
+kind 2 = two queries per pass (maxsim_stream2_kernel), kind 3 = eight queries per pass over the pre-split
+corpus image (maxsim_gemm_kernel).  python scripts/time_gemm_pass.py [rows] [iters]"""
+import json
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import raglite_amd  # noqa: E402
+from bench import DIM, NQ, SEED_CORPUS, SEED_QUERY, chunk_offsets  # noqa: E402
+
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+raglite_amd.set_device(0)
+off = chunk_offsets(rows)
+E = torch.empty((rows, DIM), dtype=torch.float32, device="cuda")
+raglite_amd.synth_fill(E, seed=SEED_CORPUS)
+idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+Q = torch.empty((8, NQ, DIM), dtype=torch.float32, device="cuda")
+raglite_amd.synth_fill(Q, seed=SEED_QUERY)
+out = {"rows": rows, "arithmetic": idx.arithmetic}
+for kind, nqueries in ((2, 2), (3, 8)):
+    qv = Q[:nqueries].reshape(nqueries * NQ, DIM)
+    idx.time_kernel(kind, qv, 3)
+    ms = idx.time_kernel(kind, qv, iters) / iters
+    flops = 3 * 2.0 * nqueries * NQ * rows * DIM
+    out[f"kind{kind}"] = {"ms_per_pass": ms, "queries_per_pass": nqueries, "queries_per_s": nqueries / ms * 1e3,
+                          "hbm_GBs": 4.0 * rows * DIM / ms / 1e6, "f16_mfma_TFs": flops / ms / 1e9}
+print(json.dumps(out))

@@ -35,3 +35,14 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir() -> Path:
     return ROOT / "tests" / "golden"
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+
+    import raglite_amd
+
+    assert torch.cuda.is_available()
+    raglite_amd.set_device(0)
+    return torch
