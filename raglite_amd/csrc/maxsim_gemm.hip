@@ -32,6 +32,7 @@
 //     its end row's lane.  No LDS round trip, no per-row branch.
 // Deterministic: fixed MFMA order per (query vector, row), fixed scan and sum order; results do not depend on the grid.
 // Integer-valued data is exact (products of fp16 halves are exact in fp32): bit-identical to the oracle.
+#include <cstdio>
 #include <cstdlib>
 
 #include "common.h"
@@ -45,7 +46,7 @@ namespace {
 constexpr int MG_TM = 256;               // corpus rows per tile
 constexpr int MG_NBLK = MG_TM / 16;      // 16-row blocks per tile
 constexpr int MG_SLAB = MG_TM * 128;     // bytes of one K slab (32 k) of a tile in LDS: 16 blocks x 2 KiB
-constexpr int MG_NSLOT = 3;              // LDS ring
+constexpr int MG_NSLOT = 4;              // LDS ring: slab g being multiplied, g + 1 landed, g + 2 and g + 3 in flight
 constexpr int MG_WAVES = 8;              // waves per workgroup = queries per pass
 
 __device__ __forceinline__ int64_t mg_uniform_i64(int64_t v) {
@@ -223,14 +224,26 @@ __device__ __forceinline__ void mg_pin(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
 #define MG_MAX_DPP(dst, src, x, CTRLSTR) asm volatile("v_max_f32_dpp %0, %1, %2 " CTRLSTR " row_mask:0xf bank_mask:0xf" : "=&v"(dst) : "v"(src), "v"(x))
 #define MG_SELECT(x, t, mask) asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(x) : "v"(x), "v"(t), "s"(mask))
 
-template <int NQB>
+template <int NQB, bool TRACE = false>
 __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restrict__ planes, int64_t n_rows, int32_t nslab,
                                                                const char* __restrict__ qfrag, const float* __restrict__ qmeta,
                                                                int32_t n_q, const int32_t* __restrict__ row_to_chunk,
                                                                const int64_t* __restrict__ chunk_offsets,
                                                                const uint32_t* __restrict__ ends_bits, float* __restrict__ out,
-                                                               int64_t out_stride, float inv_e_scale) {
-    __shared__ __attribute__((aligned(16))) char smem[MG_NSLOT * MG_SLAB];
+                                                               int64_t out_stride, float inv_e_scale, int dbg, unsigned long long* trace) {
+    // TRACE (diagnostic build, RAGLITE_GEMM_TRACE=1): s_memtime stamps of workgroup 7, slabs 128..143, kept in
+    // LDS and copied out at the end: [slab - 128][wave][stamp 0..15] (3 + p = after pair p of the slab).
+    __shared__ __attribute__((aligned(16))) char smem[MG_NSLOT * MG_SLAB + (TRACE ? 16 * 8 * 16 * 8 : 0)];
+    auto stamp = [&](int g, int k) {
+        if constexpr (TRACE) {
+            if (blockIdx.x == 7 && g >= 128 && g < 144 && (threadIdx.x & 63) == 0)
+                reinterpret_cast<unsigned long long*>(smem + MG_NSLOT * MG_SLAB)[((g - 128) * 8 + (threadIdx.x >> 6)) * 16 + k] = __builtin_amdgcn_s_memtime();
+        }
+    };
+    if constexpr (TRACE) {
+        for (int i = threadIdx.x; i < 16 * 8 * 16; i += blockDim.x) reinterpret_cast<unsigned long long*>(smem + MG_NSLOT * MG_SLAB)[i] = 0;
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63;
     const int wv = wave_id();  // 0..7 = the query this wave scores
     const int64_t G = gridDim.x, b = blockIdx.x;
@@ -254,41 +267,55 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
     const uint32_t lane16 = 16u * lane;
 
-    // ---- this wave's share of the corpus stream: blocks 2 wv, 2 wv + 1 of every slab (4 DMAs of 1 KiB) ---------------
-    struct Feed { const char* src[2]; uint32_t lds; };
+    // ---- the corpus stream: waves 0-3 bring blocks 4 wv .. 4 wv + 3 of every slab (8 DMAs of 1 KiB each) ----------------
+    // Measured (profiles/r02_c_trace.txt): of the two waves of a SIMD the first-dispatched one (waves 0-3) wins the
+    // arbitration for the matrix pipe and finishes its 96 MFMAs of a slab ~1.5 k cycles before its partner, then waits at
+    // the barrier.  So the older waves carry the whole DMA duty (an LDS-DMA instruction stalls its wave for 60-185
+    // cycles): it costs them slack, not the critical path.
+    const bool feeder = (dbg & 16) ? wv >= 4 : wv < 4;  // wave-uniform
+    struct Feed { const char* src[4]; uint32_t lds; };
     int f_tile = 0, f_s = 0, f_slot = 0;   // position of the NEXT slab to fetch
-    auto next_feed = [&]() {
-        Feed f;
-        const int32_t b0 = (org >> 4) + f_tile * MG_NBLK + 2 * wv;
+    const char* f_base[4];                 // block bases of the tile being fetched
+    auto feed_tile = [&](int t) __attribute__((always_inline)) {
+        const int32_t b0 = (org >> 4) + t * MG_NBLK + 4 * (wv & 3);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
             int32_t blk = b0 + i;
             blk = blk < last_blk ? blk : last_blk;  // past the image: harmless re-read of the last block, never used
-            f.src[i] = planes + mg_uniform_i64(((int64_t)blk * nslab + f_s) * 2048);
+            f_base[i] = planes + mg_uniform_i64((int64_t)blk * nslab * 2048);
         }
-        f.lds = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(f_slot * MG_SLAB + 2 * wv * 2048));
-        if (++f_s == nslab) { f_s = 0; if (f_tile + 1 < nt) ++f_tile; }  // past the end: re-fetch the last tile (keeps vmcnt uniform)
+    };
+    feed_tile(0);
+    auto next_feed = [&]() __attribute__((always_inline)) {
+        Feed f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.src[i] = f_base[i] + f_s * 2048;
+        f.lds = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(f_slot * MG_SLAB + 4 * (wv & 3) * 2048));
+        if (++f_s == nslab) {  // past the end: re-fetch the last tile (keeps the vmcnt bookkeeping uniform)
+            f_s = 0;
+            if (f_tile + 1 < nt) { ++f_tile; feed_tile(f_tile); }
+        }
         f_slot = f_slot + 1 == MG_NSLOT ? 0 : f_slot + 1;
         return f;
     };
     auto dma_piece = [&](const Feed& f, auto P_) {  // piece p = 2 * block + half
         constexpr int p = decltype(P_)::value, i = p >> 1, h = p & 1;
         const uint32_t lane16 = 16u * lane;  // (asm operands alone do not capture an enclosing local in a generic lambda)
-        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 offset:%4 nt" ::"s"(f.lds), "n"(i * 2048),
-                     "v"(lane16), "s"(f.src[i]), "n"(h * 1024)
+        const char* const src = reinterpret_cast<const char*>(mg_uniform_i64(reinterpret_cast<int64_t>(f.src[i])));
+        const uint32_t lds = __builtin_amdgcn_readfirstlane(f.lds);
+        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 offset:%4 nt" ::"s"(lds), "n"(i * 2048),
+                     "v"(lane16), "s"(src), "n"(h * 1024)
                      : "memory", "m0", "scc");
     };
-    auto dma_all = [&](const Feed& f) {
-        dma_piece(f, std::integral_constant<int, 0>{});
-        dma_piece(f, std::integral_constant<int, 1>{});
-        dma_piece(f, std::integral_constant<int, 2>{});
-        dma_piece(f, std::integral_constant<int, 3>{});
+    auto dma_all = [&](const Feed& f) __attribute__((always_inline)) {
+        [&]<int... P>(std::integer_sequence<int, P...>) { (dma_piece(f, std::integral_constant<int, P>{}), ...); }
+        (std::make_integer_sequence<int, 8>{});
     };
 
     // ---- this wave's query fragments: slab s -> 4 x 16 B per lane (qb0 hi, qb0 lo, qb1 hi, qb1 lo) -------------------
     const char* const qbase = qfrag + (int64_t)(has_q ? wv : 0) * nslab * 4096;
     int q_s = 0;  // slab of the NEXT fragment load
-    auto load_q = [&](f32x4 (&q)[4]) {
+    auto load_q = [&](f32x4 (&q)[4]) __attribute__((always_inline)) {
         const char* p = qbase + (int64_t)q_s * 4096;
         mg_load_frag(q[0], lane16, p);
         mg_load_frag(q[1], lane16, p + 1024);
@@ -314,30 +341,41 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     const uint32_t a_hi = (uint32_t)(fj * 128) + ((kq ^ sw) << 4), a_lo = (uint32_t)(fj * 128) + (((4 + kq) ^ sw) << 4);
     float* const outq = out + (int64_t)(has_q ? wv : 0) * out_stride;
 
-    // ---- one K slab: fragments of slot `slot`, query fragments q, feeding the slab two ahead -------------------------
+    // ---- one K slab.  Fragments of 16-row blocks are read a PAIR ahead; the first pair of a slab is read at the end of the
+    // previous slab (the barrier at the top of slab g certifies slab g + 1 as landed), so the MFMAs start right after the
+    // barrier instead of after an LDS round trip that both waves of a SIMD would sit out together. -------------------------
     int c_tile = 0, c_s = 0, c_slot = 0;
-    auto slab = [&](f32x4 (&q)[4], int nb) {
-        const Feed f = next_feed();
+    h16x8 eh[2][2], el[2][2];  // [pair parity][block of the pair]
+    auto read_pair = [&](int slot, int p, h16x8 (&h)[2], h16x8 (&l)[2]) __attribute__((always_inline)) {
+        const char* const base = smem + slot * MG_SLAB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            h[i] = *reinterpret_cast<const h16x8*>(base + (2 * p + i) * 2048 + a_hi);
+            l[i] = *reinterpret_cast<const h16x8*>(base + (2 * p + i) * 2048 + a_lo);
+        }
+    };
+    auto slab = [&](f32x4 (&q)[4], f32x4 (&qn)[4], int nb, int g_trace) __attribute__((always_inline)) {
+        Feed f{};
+        if (feeder) f = next_feed();
+        const int next_slot = c_slot + 1 == MG_NSLOT ? 0 : c_slot + 1;
         if (has_q) {
+            // The next slab's query fragments: ONE load after each of the first four pairs.  (All four at the top of the slab
+            // stalled both waves of every SIMD for ~500 cycles while the matrix pipe idled: a VMEM instruction costs its wave
+            // 60-185 cycles of issue, profiles/r02_e_trace.txt.)
+            const char* const qp = qbase + (int64_t)q_s * 4096;
+            q_s = q_s + 1 == nslab ? 0 : q_s + 1;
             h16x8 qh[2], ql[2];
             __builtin_memcpy(&qh[0], &q[0], 16);
             __builtin_memcpy(&ql[0], &q[1], 16);
             __builtin_memcpy(&qh[1], &q[2], 16);
             __builtin_memcpy(&ql[1], &q[3], 16);
-            const char* const base = smem + c_slot * MG_SLAB;
-            h16x8 eh[2][2], el[2][2];  // [pair parity][block of the pair]
-            auto read_pair = [&](int p, h16x8 (&h)[2], h16x8 (&l)[2]) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    h[i] = *reinterpret_cast<const h16x8*>(base + (2 * p + i) * 2048 + a_hi);
-                    l[i] = *reinterpret_cast<const h16x8*>(base + (2 * p + i) * 2048 + a_lo);
-                }
-            };
-            read_pair(0, eh[0], el[0]);
 #pragma unroll
             for (int p = 0; p < MG_NBLK / 2; ++p) {
-                if (p + 1 < MG_NBLK / 2) read_pair(p + 1, eh[(p + 1) & 1], el[(p + 1) & 1]);
-                if (2 * p < nb) {  // wave-uniform: blocks past the workgroup's range are not multiplied
+                if (!(dbg & 8)) {
+                    if (p + 1 < MG_NBLK / 2) read_pair(c_slot, p + 1, eh[(p + 1) & 1], el[(p + 1) & 1]);
+                    else read_pair(next_slot, 0, eh[0], el[0]);
+                }
+                if (2 * p < nb && !(dbg & 2)) {  // wave-uniform: blocks past the workgroup's range are not multiplied
                     const h16x8(&h)[2] = eh[p & 1];
                     const h16x8(&l)[2] = el[p & 1];
 #pragma unroll
@@ -358,20 +396,23 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
                                 acc[qb][2 * p + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ql[qb], h[i], acc[qb][2 * p + i], 0, 0, 0);
                     }
                 }
-                if (p == 0) dma_piece(f, std::integral_constant<int, 0>{});
-                if (p == 2) dma_piece(f, std::integral_constant<int, 1>{});
-                if (p == 4) dma_piece(f, std::integral_constant<int, 2>{});
-                if (p == 6) dma_piece(f, std::integral_constant<int, 3>{});
+                if (p < 4) mg_load_frag(qn[p], lane16, qp + p * 1024);
+                if (feeder && p >= 4 && !(dbg & (4 | 32))) {  // two DMAs after each of the last four pairs (p is a constant after unrolling)
+                    [&]<int... P>(std::integer_sequence<int, P...>) { ((P / 2 == p - 4 ? dma_piece(f, std::integral_constant<int, P>{}) : (void)0), ...); }
+                    (std::make_integer_sequence<int, 8>{});
+                }
+                stamp(g_trace, 3 + p);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        } else {
+            if (feeder && (dbg & 32)) dma_all(f);
+        } else if (feeder) {
             dma_all(f);
         }
-        c_slot = c_slot + 1 == MG_NSLOT ? 0 : c_slot + 1;
+        c_slot = next_slot;
     };
 
     // ---- tile epilogue: per-chunk maxima along the DPP rows, sum over the query vectors, store ---------------------------
-    auto epilogue = [&](int t) {
+    auto epilogue = [&](int t) __attribute__((always_inline)) {
         const int32_t row0 = org + t * MG_TM;
         // "last row of its chunk" bits of the tile's 256 rows: 9 words from row0 / 32, shifted by 16 when row0 is odd in blocks
         uint32_t m[9];
@@ -382,7 +423,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
         uint32_t mm[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) mm[i] = odd ? (m[i] >> 16) | (m[i + 1] << 16) : m[i];
-        if (has_q) {
+        if (has_q && !(dbg & 1)) {
 #pragma unroll
             for (int a = 0; a < MG_NBLK; ++a) {
                 const uint32_t E = (mm[a >> 1] >> (16 * (a & 1))) & 0xffffu;
@@ -403,6 +444,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
 #define MG_STEP(SRC, CTRLSTR, MASK)                                                        \
     _Pragma("unroll") for (int r = 0; r < NQB * 4; ++r) MG_MAX_DPP(tmp[r], SRC, x[r], CTRLSTR); \
     _Pragma("unroll") for (int r = 0; r < NQB * 4; ++r) MG_SELECT(x[r], tmp[r], MASK);
+                // (skipping a step wave-uniformly when no lane takes it measured SLOWER: 17-20 k cycles per tile against 15.5-18 k)
                 MG_STEP(carry[r], "row_ror:1", C0)  // lane 0 <- lane 15 of the previous block's scan
                 MG_STEP(x[r], "row_shr:1", F1)
                 MG_STEP(x[r], "row_shr:2", F2)
@@ -411,17 +453,17 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
 #undef MG_STEP
 #pragma unroll
                 for (int r = 0; r < NQB * 4; ++r) carry[r] = x[r];
-                float tsum;
-                if constexpr (NQB == 2) tsum = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-                else tsum = (x[0] + x[1]) + (x[2] + x[3]);
-                tsum += __shfl_xor(tsum, 16);
-                tsum += __shfl_xor(tsum, 32);
                 // rows of this block inside the workgroup's range
                 int32_t lo = r_lo - base, hi = r_hi - base;
                 lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
                 hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
                 const uint32_t EM = E & ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-                if (EM != 0u) {  // wave-uniform
+                if (EM != 0u) {  // wave-uniform: some chunk of this workgroup ends in this block
+                    float tsum;
+                    if constexpr (NQB == 2) tsum = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                    else tsum = (x[0] + x[1]) + (x[2] + x[3]);
+                    tsum += __shfl_xor(tsum, 16);
+                    tsum += __shfl_xor(tsum, 32);
                     const uint32_t below = E & ((1u << fj) - 1u);
                     if (lane < 16 && ((EM >> lane) & 1u)) outq[ord0 + __builtin_popcount(below)] = tsum * unscale;
                 }
@@ -435,13 +477,15 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     };
 
     // ---- main loop: two slabs per iteration (two static sets of query fragment registers) ---------------------------------
+    // VMEM retires in order.  Per slab g a feeder issues Q(g + 1) (first half of the slab), then its 8 DMAs of slab g + 3; at the top of slab g it
+    // needs DMA(g + 1) and Q(g), i.e. at most the 8 DMAs of slab g + 2 outstanding.  The other waves only have Q in flight.
     f32x4 qa[4], qb_[4];
-    {   // prologue: DMA(0), Q(0), DMA(1) -- the order the waits below count on
-        const Feed f0 = next_feed();
-        dma_all(f0);
+    {   // prologue: DMA(0), DMA(1), Q(0), DMA(2); slab 0 must have landed for everybody before its first pair is read
+        if (feeder) { const Feed f0 = next_feed(); dma_all(f0); const Feed f1 = next_feed(); dma_all(f1); }
         if (has_q) load_q(qa);
-        const Feed f1 = next_feed();
-        dma_all(f1);
+        if (feeder) { const Feed f2 = next_feed(); dma_all(f2); asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (has_q) read_pair(0, 0, eh[0], el[0]);
     }
     auto tile_nb = [&](int t) {
         const int32_t left = r_hi - (org + t * MG_TM);
@@ -449,7 +493,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
         return nb < MG_NBLK ? nb : MG_NBLK;
     };
     int nb = tile_nb(0);
-    auto advance = [&]() {
+    auto advance = [&]() __attribute__((always_inline)) {
         if (++c_s == nslab) {
             epilogue(c_tile);
             c_s = 0;
@@ -457,25 +501,39 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
             nb = tile_nb(c_tile);
         }
     };
+    auto wait_top = [&]() __attribute__((always_inline)) {
+        if (feeder) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    auto run_slab = [&](f32x4 (&q)[4], f32x4 (&qn)[4], int g_trace) __attribute__((always_inline)) { slab(q, qn, nb, g_trace); };
     for (int g = 0; g < total; g += 2) {
-        // slab g: its DMAs (issued two slabs ago) and its query fragments (one slab ago) have landed when at most the 4 DMAs
-        // of slab g + 1 are outstanding; VMEM retires in order.
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        stamp(g, 0);
+        wait_top();
         mg_pin(qa[0], qa[1], qa[2], qa[3]);
+        stamp(g, 1);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (has_q) load_q(qb_);
-        slab(qa, nb);
+        stamp(g, 2);
+        run_slab(qa, qb_, g);
         advance();
+        stamp(g, 11);
         if (g + 1 < total) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            stamp(g + 1, 0);
+            wait_top();
             mg_pin(qb_[0], qb_[1], qb_[2], qb_[3]);
+            stamp(g + 1, 1);
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (has_q) load_q(qa);
-            slab(qb_, nb);
+            stamp(g + 1, 2);
+            run_slab(qb_, qa, g + 1);
             advance();
+            stamp(g + 1, 11);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
+    if constexpr (TRACE) {
+        __syncthreads();
+        if (blockIdx.x == 7)
+            for (int i = threadIdx.x; i < 16 * 8 * 16; i += blockDim.x) trace[i] = reinterpret_cast<unsigned long long*>(smem + MG_NSLOT * MG_SLAB)[i];
+    }
 }
 
 // n_q (1..8) queries `first .. first + n_q - 1` of a launch_query_planes buffer over `n_queries`, each nq (<= 32) vectors:
@@ -490,12 +548,35 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
     const float* qmeta = reinterpret_cast<const float*>(static_cast<const char*>(qbuf) + (size_t)n_queries * dim * 128) + 2 * (size_t)first;
     const int64_t tiles = (n_rows + MG_TM - 1) / MG_TM;
     const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
+    static const int dbg = std::getenv("RAGLITE_GEMM_DBG") ? std::atoi(std::getenv("RAGLITE_GEMM_DBG")) : 0;  // timing experiments only
+    static unsigned long long* trace = [] {
+        unsigned long long* p = nullptr;
+        if (std::getenv("RAGLITE_GEMM_TRACE")) { (void)hipMalloc(&p, 16 * 8 * 16 * 8); (void)hipMemset(p, 0, 16 * 8 * 16 * 8); }
+        return p;
+    }();
+    if (trace && nq > 16) {  // diagnostic build: dump the 10th launch's slab timeline to stderr
+        static int calls = 0;
+        hipLaunchKernelGGL((maxsim_gemm_kernel<2, true>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, qmeta, n_q,
+                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, trace);
+        if (++calls == 10) {
+            static unsigned long long h[16 * 8 * 16];
+            (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
+            fprintf(stderr, "GEMMTRACE columns: before-vmcnt after-vmcnt after-barrier after-pair0..7 after-advance(epilogue)\n");
+            for (int g = 0; g < 16; ++g)
+                for (int wv = 0; wv < 8; ++wv) {
+                    fprintf(stderr, "GEMMTRACE slab %d wave %d:", g + 128, wv);
+                    for (int k = 0; k < 12; ++k) fprintf(stderr, " %7lld", (long long)(h[(g * 8 + wv) * 16 + k] - h[0]));
+                    fprintf(stderr, "\n");
+                }
+        }
+        return RL_OK;
+    }
     if (nq <= 16)
         hipLaunchKernelGGL((maxsim_gemm_kernel<1>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, qmeta, n_q,
-                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale);
+                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr);
     else
         hipLaunchKernelGGL((maxsim_gemm_kernel<2>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, qmeta, n_q,
-                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale);
+                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -21,7 +21,11 @@ idx = raglite_amd.DeviceIndex(E, off, metric="dot")
 Q = torch.empty((8, NQ, DIM), dtype=torch.float32, device="cuda")
 raglite_amd.synth_fill(Q, seed=SEED_QUERY)
 out = {"rows": rows, "arithmetic": idx.arithmetic}
+kinds = [int(k) for k in sys.argv[3].split(",")] if len(sys.argv) > 3 else [2, 3]
+NQ8 = int(sys.argv[4]) if len(sys.argv) > 4 else 8  # queries given to the eight-query kernel (fewer: idle waves)
 for kind, nqueries in ((2, 2), (3, 8)):
+    if kind not in kinds:
+        continue
     qv = Q[:nqueries].reshape(nqueries * NQ, DIM)
     idx.time_kernel(kind, qv, 3)
     ms = idx.time_kernel(kind, qv, iters) / iters
