@@ -15,7 +15,8 @@
  *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).
  *  - all matrices are row-major and dense; dim is the embedding dimension.
  *  - thread safety: calls on distinct rl_index handles / distinct streams may run concurrently;
- *    calls on one handle serialise on an internal mutex (the reference calls the path from up to
+ *    calls on one handle share its device scratch: they serialise on an internal mutex, and a call on
+ *    another stream than the handle's previous call first waits for that stream (the reference calls the path from up to
  *    4 worker threads: src/raglite/_insert.py:159,208-237; src/raglite/_rag.py:317-318).
  */
 #ifndef RAGLITE_HIP_H
@@ -196,7 +197,9 @@ int rl_maxsim_topk_batch(rl_index* index, const float* query_vecs, int32_t n_que
  * launch, each with its own nq query vectors and its own list of n_cand candidate chunk ordinals.
  *   query_vecs [n_queries x nq x dim] f32, candidates [n_queries x n_cand] int32
  *   out_scores [n_queries x n_cand] f32 in candidate order (the caller sorts: the reference
- *   reorders by `result.doc_id`, src/raglite/_search.py:396). */
+ *   reorders by `result.doc_id`, src/raglite/_search.py:396).
+ * A candidate of -1 (the padding of rl_search_chunks results), a tombstoned chunk, and -- for RL_MEM_DEVICE
+ * callers, whose lists are not validated on the host -- any ordinal outside [0, n_chunks) scores -inf. */
 int rl_maxsim_rerank(rl_index* index, const float* query_vecs, int32_t n_queries, int32_t nq,
                      const int32_t* candidates, int32_t n_cand, float* out_scores, int mem, void* stream);
 

@@ -233,7 +233,17 @@ def distance(E: np.ndarray, q: np.ndarray, metric: str = "cosine", dtype=np.floa
     """DuckDB semantics: cosine -> 1 - e.q/(|e||q|); dot -> -(e.q); l2 -> |e-q|_2.
 
     `dtype=np.float64` is the "truth" variant, `np.float32` the as-computed variant (DuckDB
-    evaluates FLOAT[d] arrays in fp32; its exact rounding is unverifiable here)."""
+    evaluates FLOAT[d] arrays in fp32; its exact rounding is unverifiable here).
+
+    Cosine, the two published forms.  DuckDB (>= 1.1, the reference's pin `duckdb>=1.1.3`, absent from /root/reference
+    and from this image) documents `array_cosine_distance(a, b)` as `1 - array_cosine_similarity(a, b)` with
+    `array_cosine_similarity = sum(a_i b_i) / sqrt(sum(a_i^2) * sum(b_i^2))`: ONE square root of the product of the two
+    squared norms.  pgvector's `<=>` computes `1 - dot / sqrt(norm_a * norm_b)` the same way.  This restatement and
+    the device (scan.hip:finish_score, transform_kernel, the GEMM epilogue) divide by `sqrt(sum a^2) * sqrt(sum b^2)`:
+    TWO roots and a product, because ||e|| is precomputed per row when the index is built.  In IEEE arithmetic the two
+    forms differ by the roundings of one extra sqrt and one multiply: at most 1.5 ulp of the denominator, i.e. <= 2 ulp
+    (2.4e-7 relative) of the similarity -- three orders of magnitude inside the 1e-4 bar, and it cannot change a ranking
+    of scores that differ by more than that.  On integer-valued data with perfect-square norms both forms are exact."""
     E = np.asarray(E, dtype=dtype)
     q = np.asarray(q, dtype=dtype)
     if metric == "cosine":
@@ -485,6 +495,32 @@ def maxsim_scores(D: np.ndarray, chunk_offsets: np.ndarray, Q: np.ndarray, dtype
 
 def maxsim_topk(D, chunk_offsets, Q, k, dtype=np.float64):
     return topk_desc(maxsim_scores(D, chunk_offsets, Q, dtype), k)
+
+
+def maxsim_scores_batch(D: np.ndarray, chunk_offsets: np.ndarray, Qb: np.ndarray, dtype=np.float64,
+                        slab_rows: int = 65536) -> np.ndarray:
+    """`maxsim_scores` for a batch of queries Qb (n_queries, nq, dim) -> (n_queries, n_chunks), same arithmetic per
+    (row, query vector) product: the corpus goes through in chunk-aligned row slabs with ONE matrix product per slab
+    for all queries' vectors (what makes the CPU baseline use its BLAS threads well), then the per-chunk maximum
+    (`np.maximum.reduceat`, the NumPy analogue of `max(sim) GROUP BY chunk_id`, `_search.py:143-149`) and the sum over
+    each query's vectors.  No empty chunks (callers with empty chunks use `maxsim_scores`)."""
+    off = np.asarray(chunk_offsets, dtype=np.int64)
+    n_chunks = len(off) - 1
+    Qb = np.asarray(Qb, dtype=dtype)
+    n_queries, nq, dim = Qb.shape
+    assert np.all(off[1:] > off[:-1]), "maxsim_scores_batch: empty chunk"
+    Qall = np.ascontiguousarray(Qb.reshape(n_queries * nq, dim).T)  # (dim, n_queries * nq)
+    out = np.empty((n_queries, n_chunks), dtype=dtype)
+    c0 = 0
+    while c0 < n_chunks:
+        c1 = int(np.searchsorted(off, off[c0] + slab_rows, side="right")) - 1
+        c1 = min(max(c1, c0 + 1), n_chunks)
+        r0, r1 = int(off[c0]), int(off[c1])
+        S = np.asarray(D[r0:r1], dtype=dtype) @ Qall  # (rows, n_queries * nq)
+        seg = np.maximum.reduceat(S, off[c0:c1] - r0, axis=0)  # (chunks, n_queries * nq)
+        out[:, c0:c1] = seg.reshape(c1 - c0, n_queries, nq).sum(axis=2).T
+        c0 = c1
+    return out
 
 
 def maxsim_candidates(D, chunk_offsets, Q, cand, dtype=np.float64) -> np.ndarray:

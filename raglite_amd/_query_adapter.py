@@ -21,7 +21,7 @@ import numpy as np
 
 from raglite_amd import _ops
 from raglite_amd._config import DEFAULT_CHUNK_MAX_SIZE, HotPathConfig
-from raglite_amd._embed import embed_strings
+from raglite_amd._embed import embed_strings, embedding_type
 from raglite_amd._search import GpuIndex, _index_for
 
 
@@ -80,7 +80,13 @@ def update_query_adapter(evals: Sequence[Any], *, max_evals: int = 4096, optimiz
     # ---- embed the questions (`:160`) -----------------------------------------------------------------------
     fields = [_eval_fields(ev) for ev in evals]
     texts = [q for q, _ in fields if isinstance(q, str)]
-    embedded = iter(embed_strings(texts, config=no_adapter)) if texts else iter(())
+    # A late-chunking embedder treats a LIST of strings as the sentences of one document (they are joined and pooled
+    # with each other's context); the reference embeds each question alone (`embed_strings([eval_.question])[0]`,
+    # `_query_adapter.py:160`) and so does `vector_search` at query time.  Only the standard embedder is batched.
+    if texts and embedding_type(config=no_adapter) == "late_chunking":
+        embedded = iter([embed_strings([t], config=no_adapter)[0] for t in texts])
+    else:
+        embedded = iter(embed_strings(texts, config=no_adapter)) if texts else iter(())
     qs = [next(embedded) if isinstance(q, str) else np.ravel(np.asarray(q)) for q, _ in fields]
     Q_all = np.vstack([np.asarray(q, dtype=np.float32) for q in qs])  # noqa: N806
     # ---- ONE batched search without the adapter (`:162-165`, num_hits as in `_search.py:66-67`) --------------

@@ -171,10 +171,18 @@ def vector_search(query: str | np.ndarray, *, num_results: int = 3, oversample: 
         return [], []
     if metadata_filter:
         return _filtered_search(gi, q, num_hits, num_results, metadata_filter)
-    k = min(num_results, _ops.K_MAX)
-    scores, chunks, count = gi.index.search_chunks(np.asarray(q, dtype=np.float32), min(num_hits, _ops.K_MAX), k)
+    _check_limits(num_hits, num_results)
+    scores, chunks, count = gi.index.search_chunks(np.asarray(q, dtype=np.float32), num_hits, num_results)
     n = int(count)
     return [gi.chunk_ids[c] for c in chunks[:n].tolist()], [float(s) for s in scores[:n]]
+
+
+def _check_limits(num_hits: int, num_results: int) -> None:
+    """The exact selection ranks at most K_MAX rows per query; asking for more is an error, not a silent truncation
+    (the reference's `LIMIT num_hits` has no such bound: a documented limit of this implementation)."""
+    if num_hits > _ops.K_MAX or num_results > _ops.K_MAX:
+        raise ValueError(f"vector_search: num_results={num_results} needs the top {num_hits} rows, more than the "
+                         f"{_ops.K_MAX} the exact top-k kernel ranks; lower num_results or oversample")
 
 
 def _filtered_search(gi: GpuIndex, q, num_hits: int, num_results: int, flt: dict):
@@ -185,8 +193,8 @@ def _filtered_search(gi: GpuIndex, q, num_hits: int, num_results: int, flt: dict
     allowed = np.fromiter((_matches(m, flt) for m in gi.metadata), dtype=bool, count=len(gi.metadata))
     if not allowed.any():
         return [], []
-    k = min(num_results, _ops.K_MAX)
-    scores, chunks, count = gi.index.search_chunks(np.asarray(q, dtype=np.float32), min(num_hits, _ops.K_MAX), k,
+    _check_limits(num_hits, num_results)
+    scores, chunks, count = gi.index.search_chunks(np.asarray(q, dtype=np.float32), num_hits, num_results,
                                                    chunk_filter=allowed)
     n = int(count)
     return [gi.chunk_ids[c] for c in chunks[:n].tolist()], [float(s) for s in scores[:n]]

@@ -233,11 +233,25 @@ struct rl_index {
     // Pre-split corpus image of maxsim_gemm.hip (fp16 hi | lo planes in the kernel's LDS layout, 4 B per element) and
     // the "last row of its chunk" bitmap; built with the index, extended on append, rebuilt when split_scale changes.
     rl::Pool planes, ends, qplanes;
+    rl::Pool cand;                        // rl_maxsim_rerank: sanitised candidate ordinals
+    // The scratch above is shared by all calls on this handle; `mu` serialises only their host side.  Device-mode calls are
+    // asynchronous, so a call arriving on a DIFFERENT stream than the previous one first waits for that stream.
+    hipStream_t last_stream = nullptr;
+    bool last_stream_set = false;
     float planes_scale = 0.f;             // the scale the image was built with; 0 = no image
     int64_t planes_rows = 0;              // rows the image covers
 };
 
 namespace {
+// Called (under idx->mu) by every entry point that uses the index' shared scratch: a call on another stream than the
+// previous one waits for the previous stream's work on this handle (host-side; the rare case).
+int use_scratch(rl_index* idx, hipStream_t s) {
+    if (idx->last_stream_set && idx->last_stream != s) RL_HIP(hipStreamSynchronize(idx->last_stream));
+    idx->last_stream = s;
+    idx->last_stream_set = true;
+    return RL_OK;
+}
+
 // The stream kernel multiplies an fp32 corpus either with the exact fp32 MFMA chain or -- 10 % faster, HBM-bound instead
 // of matrix-pipe-bound -- as fp16 (hi, lo) pairs (maxsim_stream.hip, SPLIT).  After scaling the largest element to
 // [2^13, 2^14) a pair keeps 22 significant bits of every element down to 2^-3, fewer below (lo goes subnormal), which
@@ -476,6 +490,7 @@ int rl_index_destroy(rl_index* idx) {
     idx->planes.release();
     idx->ends.release();
     idx->qplanes.release();
+    idx->cand.release();
     select_workspace_free(idx->ws);
     idx->scores.release();
     idx->hits.release();
@@ -872,6 +887,7 @@ int rl_search_rows_filtered(rl_index* idx, const float* queries, int32_t B, int3
     if (!out_scores || !out_rows) return fail(RL_ERR_INVALID, "rl_search_rows: null output");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
     DevBuf t_q, t_s, t_r, t_f;
     const float* d_q; float* d_s; int32_t* d_r;
     const uint32_t* d_f = nullptr;
@@ -902,6 +918,7 @@ int rl_search_chunks_filtered(rl_index* idx, const float* queries, int32_t B, in
     if (!out_scores || !out_chunks || !out_counts) return fail(RL_ERR_INVALID, "rl_search_chunks: null output");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
     DevBuf t_q, t_s, t_c, t_n, t_f;
     const float* d_q; float* d_s; int32_t* d_c; int32_t* d_n;
     const uint32_t* d_f = nullptr;
@@ -1014,6 +1031,7 @@ int rl_maxsim_scores(rl_index* idx, const float* query_vecs, int32_t nq, float* 
     if (!out_scores) return fail(RL_ERR_INVALID, "rl_maxsim_scores: null output");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
     DevBuf t_q, t_o;
     const float* d_q; float* d_o;
     RL_TRY(stage_in(query_vecs, (size_t)nq * idx->dim, mem, s, t_q, &d_q));
@@ -1033,6 +1051,7 @@ int rl_maxsim_topk_filtered(rl_index* idx, const float* query_vecs, int32_t nq, 
     if (!out_scores || !out_chunks) return fail(RL_ERR_INVALID, "rl_maxsim_topk: null output");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
     DevBuf t_q, t_s, t_c, t_f;
     const float* d_q; float* d_s; int32_t* d_c;
     const uint32_t* d_f = nullptr;
@@ -1066,6 +1085,7 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
     if (!query_vecs || !out_scores || !out_chunks) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: null argument");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
     DevBuf t_q, t_s, t_c;
     const float* d_q; float* d_s; int32_t* d_c;
     const size_t q_elems = (size_t)nq * idx->dim;
@@ -1122,18 +1142,25 @@ int rl_maxsim_rerank(rl_index* idx, const float* query_vecs, int32_t n_queries, 
     if (!query_vecs || !candidates || !out_scores) return fail(RL_ERR_INVALID, "rl_maxsim_rerank: null argument");
     if (idx->E16 && (idx->dim != 128 || nq > 32))
         return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_rerank on an fp16-stored index needs dim == 128 and nq <= 32");
-    if (mem == RL_MEM_HOST) {
+    if (mem == RL_MEM_HOST) {  // -1 = "no chunk" (the padding of rl_search_chunks results) is allowed and scores -inf
         for (int64_t i = 0; i < (int64_t)n_queries * n_cand; ++i)
-            if (candidates[i] < 0 || candidates[i] >= idx->n_chunks)
+            if (candidates[i] < -1 || candidates[i] >= idx->n_chunks)
                 return fail(RL_ERR_INVALID, "rl_maxsim_rerank: candidate chunk ordinal out of range");
     }
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
     DevBuf t_q, t_c, t_o;
     const float* d_q; const int32_t* d_c; float* d_o;
     RL_TRY(stage_in(query_vecs, (size_t)n_queries * nq * idx->dim, mem, s, t_q, &d_q));
     RL_TRY(stage_in(candidates, (size_t)n_queries * n_cand, mem, s, t_c, &d_c));
     RL_TRY(stage_out_begin(out_scores, (size_t)n_queries * n_cand, mem, t_o, &d_o));
+    {   // ordinals that cannot be scored (device callers are not validated above; -1 pads of a search result; tombstones) -> -inf
+        const int64_t n_items = (int64_t)n_queries * n_cand;
+        RL_TRY(idx->cand.reserve((size_t)n_items * sizeof(int32_t)));
+        RL_TRY(launch_sanitize_candidates(d_c, n_items, idx->n_chunks, idx->live_chunk_bits, idx->cand.as<int32_t>(), s));
+        d_c = idx->cand.as<int32_t>();
+    }
     int st = idx->E16 ? launch_maxsim_cand16(idx->E16, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s)
                       : launch_maxsim_cand(idx->E, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s, idx->split_scale);
     if (st == RL_ERR_UNSUPPORTED && !idx->E16)
@@ -1258,6 +1285,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     if (!idx || !q_dev || !out_ms_total || iters < 1 || nq < 1) return fail(RL_ERR_INVALID, "rl_time_kernel: bad arguments");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
     const int64_t ld = (idx->n_rows + 3) & ~int64_t(3);
     const int64_t ldc = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
     if (kind == 0) RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));

@@ -191,6 +191,8 @@ int launch_maxsim_stream16(const uint16_t* D, int64_t n_rows, int32_t dim, const
 int launch_maxsim_generic(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride_queries,
                           const int64_t* chunk_offsets, const int32_t* candidates, int64_t n_items,
                           int32_t n_queries, float* out, hipStream_t s);
+int launch_sanitize_candidates(const int32_t* in, int64_t n, int64_t n_chunks, const uint32_t* live_chunk_bits, int32_t* out,
+                               hipStream_t s);
 // Rerank fast path: dim == 128, nq <= 32 (MFMA, direct fragment loads).
 int launch_maxsim_cand(const float* D, int32_t dim, const float* Q, int32_t nq, const int64_t* chunk_offsets,
                        const int32_t* candidates, int32_t n_cand, int32_t n_queries, float* out, hipStream_t s,

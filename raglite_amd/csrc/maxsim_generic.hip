@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void maxsim_generic_kernel(const float* __rest
     for (int64_t item = wave0; item < n_items; item += n_waves) {
         // one query per launch: item = chunk ordinal, or an index into this query's candidate list
         const int64_t chunk = candidates ? (int64_t)candidates[item] : item;
-        const int64_t b = offsets[chunk], e = offsets[chunk + 1];
+        // a negative ordinal = "no chunk" (padding of a search result, or sanitised by rl_maxsim_rerank): score -inf
+        const int64_t b = chunk >= 0 ? offsets[chunk] : 0, e = chunk >= 0 ? offsets[chunk + 1] : 0;
         for (int i = lane; i < nq; i += 64) m[i] = -INFINITY;
         for (int64_t r = b; r < e; ++r) {
             float x[NV][VEC];
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(256) void maxsim_cand_kernel(const float* __restric
 
     for (int ci = c0; ci < c0 + CPW && ci < n_cand; ++ci) {
         const int64_t chunk = candidates[(int64_t)qi * n_cand + ci];
-        const int64_t b = offsets[chunk], e = offsets[chunk + 1];
+        // a negative ordinal = "no chunk" (padding of a search result, or sanitised by rl_maxsim_rerank): score -inf
+        const int64_t b = chunk >= 0 ? offsets[chunk] : 0, e = chunk >= 0 ? offsets[chunk + 1] : 0;
         f32x4 mx[NQT];
 #pragma unroll
         for (int h = 0; h < NQT; ++h) mx[h] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -338,6 +340,26 @@ static int launch_cand_any(const float* D, bool f16, int32_t dim, const float* Q
     else if (split_scale > 0.f) { if (nq <= 16) RL_CAND(1, false, true); else RL_CAND(2, false, true); }
     else     { if (nq <= 16) RL_CAND(1, false); else RL_CAND(2, false); }
 #undef RL_CAND
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// Candidate ordinals that cannot be scored -- outside [0, n_chunks), or tombstoned -- become -1, which the kernels above
+// score as -inf (rl_chunk_best_rows treats -1 the same way).
+__global__ __launch_bounds__(256) void sanitize_candidates_kernel(const int32_t* __restrict__ in, int64_t n, int64_t n_chunks,
+                                                                   const uint32_t* __restrict__ live_chunk_bits,
+                                                                   int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int32_t c = in[i];
+    bool ok = c >= 0 && c < n_chunks;
+    if (ok && live_chunk_bits) ok = (live_chunk_bits[c >> 5] >> (c & 31)) & 1u;
+    out[i] = ok ? c : -1;
+}
+int launch_sanitize_candidates(const int32_t* in, int64_t n, int64_t n_chunks, const uint32_t* live_chunk_bits, int32_t* out,
+                               hipStream_t s) {
+    if (n <= 0) return RL_OK;
+    hipLaunchKernelGGL(sanitize_candidates_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, in, n, n_chunks, live_chunk_bits, out);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restric
     __shared__ uint32_t h[HIST_BINS];    // 8 KiB
     __shared__ uint32_t scratch[20];
     __shared__ uint32_t thr[2];
-    __shared__ uint32_t sh_cnt[2];
+    __shared__ uint32_t sh_cnt[3];
     const int q = blockIdx.x;
     const uint32_t* g = ws_hist + (int64_t)q * HIST_STRIDE;
     const uint64_t* sel = ws_sel + (int64_t)q * K_MAX;
@@ -282,9 +282,17 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restric
             const uint32_t rank = sh_cnt[1] + incl - 1;  // 0-based rank of this tie in index order
             __syncthreads();
             if (eq && rank < need_eq) fin[n_sel + (need - need_eq) + rank] = make_key64(v, (uint32_t)i);
-            if (threadIdx.x == 0) sh_cnt[1] += tot;
+            // The exit decision is taken by ONE thread and published in LDS: every thread reading the counters itself would
+            // race with a faster wave already counting the next iteration's `gt` hits (a non-uniform break leaves waves
+            // behind at the scan's barriers).
+            if (threadIdx.x == 0) {
+                sh_cnt[1] += tot;
+                sh_cnt[2] = (sh_cnt[1] >= need_eq && sh_cnt[0] >= need - need_eq) ? 1u : 0u;
+            }
             __syncthreads();
-            if (sh_cnt[1] >= need_eq && sh_cnt[0] >= need - need_eq) break;  // uniform: both in LDS
+            const bool done = sh_cnt[2] != 0;
+            __syncthreads();  // nobody writes sh_cnt again before everybody has read the flag
+            if (done) break;
         }
         __syncthreads();
     }

@@ -1,9 +1,12 @@
-"""Throughput of the other BASELINE.json configs on one MI355X (parity-test cases, not the bench line).
+"""Throughput of BASELINE.json configs 2-5 on one MI355X, each with a spot check against the oracle.
 
-    python scripts/bench_configs.py [cfg2 cfg3 cfg4 cfg5]   -> one JSON object per config on stdout
+    python scripts/bench_configs.py [cfg2 cfg3 cfg3_f16 cfg4 cfg5]   -> one JSON object per config on stdout
+    bench.py imports `run(name)` and prints the results in its `configs` block (outside the headline's timed region).
 
 Everything is resident in HBM before timing; kernels are launched on torch's current stream and timed with
-torch.cuda events (that stream IS the launch stream here).  Algorithmic bytes/flops follow SURVEY.md section 8d.
+torch.cuda events (that stream IS the launch stream here).  Algorithmic bytes / flops follow SURVEY.md section 8d.
+The full-scale parity tests of these shapes are tests/test_gpu_fullsize.py; the checks here only make sure a timed
+number belongs to a correct result.
 """
 
 from __future__ import annotations
@@ -16,13 +19,14 @@ from pathlib import Path
 import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
-sys.path.insert(0, str(ROOT))
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
 
 import torch  # noqa: E402
 
 import raglite_amd  # noqa: E402
 
-HBM_PEAK, MFMA_F32_PEAK = 8000.0, 157.3  # GB/s, TFLOP/s (MI355X_MICROARCH.md)
+HBM_PEAK, MFMA_F32_PEAK, MFMA_F16_PEAK = 8000.0, 157.3, 2500.0  # GB/s, TFLOP/s, TFLOP/s (MI355X_MICROARCH.md)
 
 
 def timed(fn, iters: int, warmup: int = 3) -> float:
@@ -38,8 +42,14 @@ def timed(fn, iters: int, warmup: int = 3) -> float:
     return e0.elapsed_time(e1) / iters  # ms
 
 
+def _recall(ref_ids, got_ids) -> float:
+    return len(set(np.asarray(ref_ids).tolist()) & set(np.asarray(got_ids).tolist())) / max(1, len(ref_ids))
+
+
 def cfg2():
-    """1 M x 1024 fp32, single-query cosine top-100."""
+    """BASELINE cfg 2: 1 M x 1024 fp32, single-query cosine top-100 (src/raglite/_search.py:69-79)."""
+    from oracle import oracle
+
     n, d, k = 1_000_000, 1024, 100
     E = torch.empty((n, d), dtype=torch.float32, device="cuda")
     raglite_amd.synth_fill(E, seed=2)
@@ -54,46 +64,64 @@ def cfg2():
 
     ms = timed(one, 50)
     ms_scan = idx.time_kernel(1, q[:1], 20) / 20
-    # CPU reference on a sample: NumPy sgemv + argpartition over 100k rows, scaled
-    Eh = E[:100_000].cpu().numpy()
-    qh = q[0].cpu().numpy()
-    from oracle import oracle
-
-    t0 = time.perf_counter()
-    for _ in range(5):
-        oracle.search_rows(Eh, qh, k, "cosine", np.float32)
-    cpu = (time.perf_counter() - t0) / 5 * (n / 100_000)
-    s, r = idx.search_rows(q[0], k)
-    ref = oracle.similarity(Eh, qh, "cosine")
+    # spot check + CPU reference: the fp32 NumPy oracle over the FULL corpus for 2 queries
+    Eh = E.cpu().numpy()
+    rec, err, cpu = [], [], []
+    for b in range(2):
+        qh = q[b].cpu().numpy()
+        t0 = time.perf_counter()
+        rs, rr = oracle.search_rows(Eh, qh, k, "cosine", np.float32)
+        cpu.append(time.perf_counter() - t0)
+        s, r = idx.search_rows(q[b], k)
+        rec.append(_recall(rr, r.cpu().numpy()))
+        err.append(float(np.abs(np.asarray(rs) - s.cpu().numpy()).max()))
+    idx.close()
     return {
-        "config": "cfg2: 1M x 1024 fp32, B=1 cosine top-100", "queries_per_s": 1e3 / ms, "ms_per_query": ms,
-        "scan_kernel_ms": ms_scan, "scan_GBps": 4.0 * n * d / (ms_scan * 1e-3) / 1e9,
-        "scan_frac_of_hbm_peak": 4.0 * n * d / (ms_scan * 1e-3) / 1e9 / HBM_PEAK,
-        "cpu_numpy_queries_per_s_scaled_from_100k_rows": 1.0 / cpu,
-        "sample_score_abs_err": float(np.abs(ref[r.cpu().numpy()[r.cpu().numpy() < 100_000]] -
-                                             s.cpu().numpy()[r.cpu().numpy() < 100_000]).max(initial=0.0)),
+        "workload": "cfg2: 1M x 1024 fp32, B=1 cosine exact top-100", "value": 1e3 / ms, "unit": "queries/s", "ms_per_query": ms,
+        "roofline": {"bound": "hbm", "kernel_ms": ms_scan, "achieved": 4.0 * n * d / (ms_scan * 1e-3) / 1e9, "peak": HBM_PEAK,
+                     "unit": "GB/s", "frac": 4.0 * n * d / (ms_scan * 1e-3) / 1e9 / HBM_PEAK},
+        "check": {"recall_at_100": float(np.mean(rec)), "score_max_abs_err": float(np.max(err)), "queries": 2,
+                  "against": "fp32 NumPy oracle, full corpus"},
+        "cpu_numpy_queries_per_s": 1.0 / float(np.mean(cpu)),
     }
 
 
 def cfg3(storage="f32"):
-    """ColBERT rerank: 32 query vectors x 256 candidate chunks x 64 vectors/chunk, d = 128."""
+    """BASELINE cfg 3: ColBERT rerank, 32 query vectors x 256 candidate chunks x 64 vectors/chunk, d = 128, 4096
+    independent queries per launch (the reranker plugin call, src/raglite/_search.py:394-396)."""
+    from oracle import oracle
+
     d, nq, n_cand, rows, n_chunks = 128, 32, 256, 64, 16384  # 1 M candidate vectors in the pool
     E = torch.empty((n_chunks * rows, d), dtype=torch.float32, device="cuda")
     raglite_amd.synth_fill(E, seed=3)
+    E /= E.norm(dim=1, keepdim=True)  # ColBERT convention: unit rows
+    if storage == "f16":
+        E = E.half()
     off = np.arange(0, n_chunks * rows + 1, rows, dtype=np.int64)
-    idx = raglite_amd.DeviceIndex(E.half() if storage == "f16" else E, off, metric="dot", storage=storage)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot", storage=storage)
     nb = 4096
     Q = torch.empty((nb, nq, d), dtype=torch.float32, device="cuda")
     raglite_amd.synth_fill(Q, seed=30)
+    Q /= Q.norm(dim=2, keepdim=True)
     cand = torch.randint(0, n_chunks, (nb, n_cand), device="cuda", dtype=torch.int32)
     ms = timed(lambda: idx.maxsim_rerank(Q, cand), 10)
+    got = idx.maxsim_rerank(Q, cand).cpu().numpy()
+    Eh = E.float().cpu().numpy()
+    err = 0.0
+    for b in (0, 1777, 4095):
+        want = oracle.maxsim_candidates(Eh, off, Q[b].cpu().numpy(), cand[b].cpu().numpy(), np.float64)
+        err = max(err, float(np.abs(want - got[b]).max()))
+    arith = idx.arithmetic
+    idx.close()
     qps = nb / (ms * 1e-3)
     bytes_q, flops_q = n_cand * rows * d * (2.0 if storage == "f16" else 4.0), 2.0 * nq * n_cand * rows * d
     return {
-        "config": f"cfg3: MaxSim rerank 32 x (256 x 64) x 128, 4096 queries per launch, {storage}-stored corpus", "queries_per_s": qps,
-        "ms_per_launch": ms, "GBps_algorithmic": qps * bytes_q / 1e9, "frac_of_hbm_peak": qps * bytes_q / 1e9 / HBM_PEAK,
-        "TFLOPs_fp32": qps * flops_q / 1e12, "frac_of_mfma_f32_peak": qps * flops_q / 1e12 / MFMA_F32_PEAK,
-        "note": "candidates are drawn from a 1M-vector pool (512 MB): partly L2/MALL-resident",
+        "workload": f"cfg3: MaxSim rerank 32 x (256 x 64) x 128, 4096 queries per launch, unit rows, {storage}-stored corpus",
+        "value": qps, "unit": "queries/s", "ms_per_launch": ms, "arithmetic": arith,
+        "roofline": {"bound": "hbm", "achieved": qps * bytes_q / 1e9, "peak": HBM_PEAK, "unit": "GB/s", "frac": qps * bytes_q / 1e9 / HBM_PEAK,
+                     "fp32_equivalent_tflops": qps * flops_q / 1e12,
+                     "note": "candidates are drawn from a 1M-vector pool (512 MB): partly L2 / Infinity-Cache resident"},
+        "check": {"score_max_abs_err": err, "queries": 3, "against": "float64 oracle (unit rows: scores <= 32)"},
     }
 
 
@@ -102,7 +130,10 @@ def cfg3_f16():
 
 
 def cfg4():
-    """Late-chunking pool + L2-norm + fp16 over 100 k sentences (U{4..60} tokens), d = 1024; adapter matvec."""
+    """BASELINE cfg 4: late-chunking pool + L2-norm + fp16 over 100 k sentences (U{4..60} tokens), d = 1024
+    (src/raglite/_embed.py:119-140); query-adapter matvec at B = 1 and B = 1000 (src/raglite/_search.py:58-62)."""
+    from oracle import oracle
+
     d, S = 1024, 100_000
     rng = np.random.default_rng(4)
     lens = rng.integers(4, 61, size=S)
@@ -114,6 +145,14 @@ def cfg4():
     b = torch.as_tensor(begins, device="cuda")
     e = torch.as_tensor(ends, device="cuda")
     ms = timed(lambda: raglite_amd.pool_norm(tokens, b, e), 10)
+    _, out16 = raglite_amd.pool_norm(tokens, b, e)
+    out16 = out16.cpu().numpy()
+    sample = rng.choice(S, size=400, replace=False)
+    worst = 0
+    for sidx in sample:
+        rows_h = tokens[int(begins[sidx]) : int(ends[sidx])].cpu().numpy()
+        _, ref16 = oracle.pool_norm_cast(rows_h, np.array([0]), np.array([len(rows_h)]))
+        worst = max(worst, int(np.abs(ref16.view(np.int16).astype(np.int32) - out16[sidx].view(np.int16).astype(np.int32)).max()))
     bytes_alg = 4.0 * T * d + 2.0 * S * d
     A = torch.empty((d, d), dtype=torch.float32, device="cuda")
     raglite_amd.synth_fill(A, seed=40)
@@ -123,16 +162,24 @@ def cfg4():
     raglite_amd.synth_fill(q1000, seed=42)
     ms_a1 = timed(lambda: raglite_amd.adapter_apply(A, q1), 50)
     ms_a1000 = timed(lambda: raglite_amd.adapter_apply(A, q1000), 5)
+    got = raglite_amd.adapter_apply(A, q1000).cpu().numpy()
+    want = q1000.cpu().numpy().astype(np.float64) @ A.cpu().numpy().astype(np.float64).T
     return {
-        "config": f"cfg4: pool+norm+fp16, {S} sentences, {T} token rows x 1024", "ms": ms,
-        "sentences_per_s": S / (ms * 1e-3), "GBps_algorithmic": bytes_alg / (ms * 1e-3) / 1e9,
-        "frac_of_hbm_peak": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK,
+        "workload": f"cfg4: late-chunking pool + L2-norm + fp16, {S} sentences, {T} token rows x 1024; adapter 1024 x 1024",
+        "value": S / (ms * 1e-3), "unit": "sentences/s", "ms": ms,
+        "roofline": {"bound": "hbm", "achieved": bytes_alg / (ms * 1e-3) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
+                     "frac": bytes_alg / (ms * 1e-3) / 1e9 / HBM_PEAK, "algorithmic_bytes": bytes_alg},
         "adapter_B1_ms": ms_a1, "adapter_B1000_ms": ms_a1000,
+        "check": {"pool_fp16_max_ulp_diff": worst, "sentences": 400, "against": "oracle.pool_norm_cast (reference arithmetic, float64)",
+                  "adapter_B1000_max_abs_err": float(np.abs(got - want).max()), "adapter_scale": float(np.abs(want).max())},
     }
 
 
 def cfg5():
-    """Per-GPU part of the 8-GPU config: 1.25 M x 1024 shard, 1000 queries, cosine top-100."""
+    """BASELINE cfg 5, the per-GPU part: a 1.25 M x 1024 shard of the 10 M-row corpus, 1000 queries, cosine exact
+    top-100 (the all-gather merge of the 8 shards is tests/test_sharded_gloo.py / bench.py --gpus N)."""
+    from oracle import oracle
+
     n, d, B, k = 1_250_000, 1024, 1000, 100
     E = torch.empty((n, d), dtype=torch.float32, device="cuda")
     raglite_amd.synth_fill(E, seed=5)
@@ -140,16 +187,39 @@ def cfg5():
     raglite_amd.synth_fill(Q, seed=50)
     idx = raglite_amd.DeviceIndex(E, metric="cosine")
     ms = timed(lambda: idx.search_rows(Q, k), 3, warmup=1)
+    s, r = idx.search_rows(Q, k)
+    s, r = s.cpu().numpy(), r.cpu().numpy()
+    Eh = E.cpu().numpy()
+    rec, err = [], []
+    for b in (0, 499, 999):
+        rs, rr = oracle.search_rows(Eh, Q[b].cpu().numpy(), k, "cosine", np.float32)
+        rec.append(_recall(rr, r[b]))
+        err.append(float(np.abs(np.asarray(rs) - s[b]).max()))
+    arith = idx.arithmetic
+    idx.close()
+    fp32_flops = 2.0 * B * n * d
+    split = arith == "f16_split"
+    achieved = (3.0 if split else 1.0) * fp32_flops / (ms * 1e-3) / 1e12
     return {
-        "config": "cfg5 (one of 8 shards): 1.25M x 1024 fp32, B=1000 cosine top-100", "ms_per_batch": ms,
-        "queries_per_s_per_shard_scan": B / (ms * 1e-3), "TFLOPs_fp32": 2.0 * B * n * d / (ms * 1e-3) / 1e12,
-        "frac_of_mfma_f32_peak": 2.0 * B * n * d / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK,
+        "workload": "cfg5 (one of 8 shards): 1.25M x 1024 fp32, B=1000 cosine exact top-100", "value": B / (ms * 1e-3),
+        "unit": "queries/s over this shard", "ms_per_batch": ms, "arithmetic": arith,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK if split else MFMA_F32_PEAK, "unit": "TFLOP/s",
+                     "frac": achieved / (MFMA_F16_PEAK if split else MFMA_F32_PEAK),
+                     "note": "whole batch incl. exact selection; 3 fp16 MFMA products per fp32-equivalent multiply in split arithmetic",
+                     "fp32_equivalent_tflops": fp32_flops / (ms * 1e-3) / 1e12},
+        "check": {"recall_at_100": float(np.mean(rec)), "score_max_abs_err": float(np.max(err)), "queries": 3,
+                  "against": "fp32 NumPy oracle, full shard"},
     }
+
+
+def run(name: str) -> dict:
+    out = globals()[name]()
+    torch.cuda.empty_cache()
+    return {k: (round(v, 6) if isinstance(v, float) else v) for k, v in out.items()}
 
 
 if __name__ == "__main__":
     raglite_amd.set_device(0)
     which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4", "cfg5"]
     for name in which:
-        print(json.dumps({k: (round(v, 6) if isinstance(v, float) else v) for k, v in globals()[name]().items()}), flush=True)
-        torch.cuda.empty_cache()
+        print(json.dumps(run(name)), flush=True)

@@ -1430,3 +1430,74 @@ def test_split_arithmetic_gemm_and_rerank_query_scales(metric):
         scale = np.abs(Qv[qi].astype(np.float64)).max() * nq
         np.testing.assert_allclose(got[qi] / scale, want / scale, rtol=0, atol=2e-6)
     idx.close()
+
+
+@pytest.mark.parametrize("dim", [128, 96])  # 128: the MFMA candidate kernel; 96: the generic one-wave-per-item kernel
+def test_maxsim_rerank_unscorable_candidates_are_minus_inf(torch_cuda, dim):
+    """`search_chunks` pads its chunk ordinals with -1 and device callers are not validated on the host: a candidate of
+    -1, an ordinal outside [0, n_chunks) and a tombstoned chunk all score -inf (no out-of-bounds read), everything else
+    is unchanged -- host and device arguments alike."""
+    torch = torch_cuda
+    rng = np.random.default_rng(dim)
+    n, nq = 900, 20
+    off = ragged_offsets(rng, n, 1, 9)
+    n_chunks = len(off) - 1
+    E = oracle.synth_matrix(70, n, dim, "small_int")
+    Q = np.stack([oracle.synth_matrix(71 + i, nq, dim, "small_int") for i in range(3)])
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    cand = rng.integers(0, n_chunks, size=(3, 24)).astype(np.int32)
+    want = np.asarray(idx.maxsim_rerank(Q, cand)).copy()
+    dead = np.unique(cand[:, 5])
+    idx.delete_chunks(dead)
+    bad = cand.copy()
+    bad[:, 0] = -1
+    got_host = np.asarray(idx.maxsim_rerank(Q, bad))
+    bad_dev = bad.copy()
+    bad_dev[:, 1] = n_chunks + 12345  # only a device caller can hand this over
+    bad_dev[:, 2] = -7
+    got_dev = idx.maxsim_rerank(torch.as_tensor(Q, device="cuda"), torch.as_tensor(bad_dev, device="cuda")).cpu().numpy()
+    gone = np.isin(cand, dead)
+    for got, mask in ((got_host, gone | (np.arange(24) == 0)[None, :]), (got_dev, gone | (np.arange(24) < 3)[None, :])):
+        assert np.all(np.isneginf(got[mask]))
+        assert np.array_equal(got[~mask], want[~mask])
+    with pytest.raises(ValueError):
+        idx.maxsim_rerank(Q, np.full((3, 4), n_chunks, dtype=np.int32))  # host callers are still validated
+    idx.close()
+
+
+def test_one_handle_on_two_streams_is_serialised(torch_cuda):
+    """The index' score / selection scratch is shared by all calls on a handle: calls arriving on different streams
+    must not overlap on the device (the second one waits for the first stream).  Alternating two streams with
+    different queries has to give each query its own result."""
+    torch = torch_cuda
+    n, dim = 200_000, 256
+    E = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=91, kind="small_int")
+    idx = raglite_amd.DeviceIndex(E, None, metric="dot")
+    Q = torch.empty((8, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=92, kind="small_int")
+    torch.cuda.synchronize()
+    want = [tuple(t.clone() for t in idx.search_rows(Q[i], 50)) for i in range(8)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    got = []
+    for i in range(8):
+        with torch.cuda.stream(streams[i % 2]):
+            got.append(idx.search_rows(Q[i], 50))
+    torch.cuda.synchronize()
+    for i in range(8):
+        assert torch.equal(got[i][1], want[i][1]) and torch.equal(got[i][0], want[i][0])
+    idx.close()
+
+
+def test_vector_search_raises_beyond_the_exact_topk_limit():
+    """`num_hits` / `num_results` beyond the 2048 rows the exact selection ranks raise instead of being clamped."""
+    rng = np.random.default_rng(3)
+    mats = [rng.standard_normal((2, 32)).astype(np.float16) for _ in range(50)]
+    gi = raglite_amd.GpuIndex([f"c{i}" for i in range(50)], mats, metric="cosine")
+    q = rng.standard_normal(32).astype(np.float16)
+    ids, scores = raglite_amd.vector_search(q, num_results=512, index=gi)  # 4 * 512 = 2048 rows: the limit itself
+    assert len(ids) == 50
+    with pytest.raises(ValueError, match="exact top-k"):
+        raglite_amd.vector_search(q, num_results=513, index=gi)
+    gi.close()

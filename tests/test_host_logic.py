@@ -394,3 +394,32 @@ def test_cross_encoder_matches_huggingface_bert_classifier():
                     else:
                         b -= 1
                 assert truncate_pair(nq, nd, budget) == (a, b), (nq, nd, budget)
+
+
+def test_update_query_adapter_embeds_questions_one_by_one_under_late_chunking(monkeypatch):
+    """A late-chunking embedder pools a LIST of strings as the sentences of one document, so the questions of the
+    evals must be embedded one call each, as the reference does (`/root/reference/src/raglite/_query_adapter.py:160`:
+    `embed_strings([eval_.question])[0]`) and as `vector_search` does at query time; a standard embedder is batched."""
+    from raglite_amd import _query_adapter
+
+    gi = _gpu_index(n_chunks=40, dim=16, seed=9, metric="cosine")
+    gi.index.E = (gi.index.E / np.linalg.norm(gi.index.E, axis=1, keepdims=True)).astype(np.float16).astype(np.float32)
+    rng = np.random.default_rng(3)
+    targets = [int(rng.integers(0, 40)) for _ in range(12)]
+    vec_of = {f"question {i}": (gi.index.E[gi.index.off[t]] + 0.5 * rng.standard_normal(16)).astype(np.float16)
+              for i, t in enumerate(targets)}
+    evals = [(text, [gi.chunk_ids[t], gi.chunk_ids[(t + 5) % 40]]) for text, t in zip(vec_of, targets)]
+    calls = []
+
+    def fake_embed_strings(strings, *, config=None, embedder=None):
+        calls.append(list(strings))
+        return np.stack([vec_of[s] for s in strings])
+
+    monkeypatch.setattr(_query_adapter, "embed_strings", fake_embed_strings)
+    late = raglite_amd.HotPathConfig(embedder="llama-cpp-python/some/model.gguf@512")
+    raglite_amd.update_query_adapter(evals, optimize_top_k=8, config=late, index=gi)
+    assert calls == [[text] for text in vec_of]  # one call per question
+    calls.clear()
+    standard = raglite_amd.HotPathConfig(embedder="text-embedding-3-large")
+    raglite_amd.update_query_adapter(evals, optimize_top_k=8, config=standard, index=gi)
+    assert calls == [list(vec_of)]  # one batched call
