@@ -127,7 +127,10 @@ def main() -> None:
     if args.exact_fp32:
         index.set_exact_fp32()
     arithmetic = index.arithmetic
-    sharded = ShardedIndex(index, row_base=r_lo, chunk_base=c_lo, local_chunk_offsets=local_off)
+    # N > 1: the exchange step runs behind the C ABI (rl_allgather_merge_topk over librccl); torch.distributed only hands
+    # the communicator id around, synchronises the ranks around the timed region and takes the max of their clocks.
+    comm = raglite_amd.Communicator.from_torch_distributed() if (world > 1 and args.backend == "nccl") else None
+    sharded = ShardedIndex(index, row_base=r_lo, chunk_base=c_lo, local_chunk_offsets=local_off, comm=comm)
     n_batches = 4  # distinct query batches, cycled
     queries = torch.empty((n_batches, qps, NQ, DIM), dtype=torch.float32, device=dev)
     raglite_amd.synth_fill(queries, seed=SEED_QUERY)
@@ -168,7 +171,8 @@ def main() -> None:
 
     total_queries = args.steps * qps
     exchange = ("no exchange step at N = 1" if world == 1 else
-                f"corpus sharded by chunk over {world} GPUs; per step ONE all-gather of every rank's local top-k + device merge, no host sync")
+                f"corpus sharded by chunk over {world} GPUs; per step ONE all-gather of every rank's local top-k + device merge, no host sync"
+                + (" (rl_allgather_merge_topk: librccl through the C ABI)" if comm is not None else " (torch.distributed)"))
     result = {
         "metric": "queries/sec, MaxSim 32x1M d=1024 exact top-100",
         "value": total_queries / elapsed,

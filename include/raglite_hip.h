@@ -210,6 +210,26 @@ int rl_maxsim_rerank(rl_index* index, const float* query_vecs, int32_t n_queries
 int rl_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_lists, int32_t n_queries,
                   int32_t k_in, int32_t k, float* out_scores, int32_t* out_ids, int mem, void* stream);
 
+/* The exchange step behind the C ABI: a communicator over RCCL (librccl, loaded on first use) for one process per
+ * GPU.  Rank 0 calls rl_comm_unique_id and hands the 128 bytes to every rank by whatever side channel the host
+ * program has (a file, an environment variable, MPI, torch.distributed's store); then EVERY rank calls rl_comm_init
+ * (collective).  rl_allgather_topk: each rank's local top-k lists (device pointers, [n_queries x k]; ids LOCAL, made
+ * global by adding id_offset, -1 stays -1) -> ONE ncclAllGather of (score bits, global id) records on `stream` ->
+ * out_* [world x n_queries x k] on every rank.  rl_allgather_merge_topk: the same followed by rl_merge_topk's kernel:
+ * out_* [n_queries x k] = the global top-k by (score desc, id asc), identical on every rank and identical to what one
+ * GPU holding the whole corpus returns.  Nothing synchronises with the host.  A communicator is used by one
+ * thread at a time (calls serialise on an internal mutex).  RL_ERR_UNSUPPORTED when librccl cannot be loaded. */
+#define RL_COMM_ID_BYTES 128
+typedef struct rl_comm rl_comm;
+int rl_comm_unique_id(void* out_id /* RL_COMM_ID_BYTES */);
+int rl_comm_init(rl_comm** out, int rank, int world, const void* unique_id);
+int rl_comm_info(const rl_comm* comm, int* rank, int* world);
+int rl_comm_destroy(rl_comm* comm);
+int rl_allgather_topk(rl_comm* comm, const float* local_scores, const int32_t* local_ids, int32_t n_queries, int32_t k,
+                      int32_t id_offset, float* out_scores, int32_t* out_ids, void* stream);
+int rl_allgather_merge_topk(rl_comm* comm, const float* local_scores, const int32_t* local_ids, int32_t n_queries,
+                            int32_t k_in, int32_t id_offset, int32_t k, float* out_scores, int32_t* out_ids, void* stream);
+
 /* Generic exact top-k over a dense score matrix [n_queries x n] (row stride ld), the selection
  * stage used by every search above; exposed for tests and for callers that score elsewhere. */
 int rl_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32_t k,

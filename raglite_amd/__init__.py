@@ -41,6 +41,7 @@ from raglite_amd._search import (
 from raglite_amd._cross_encoder import CrossEncoderShape, TorchCrossEncoderRanker
 from raglite_amd._torch_embedder import EncoderShape, HashTokenizer, TorchTokenEmbedder
 from raglite_amd._query_adapter import update_query_adapter
+from raglite_amd._comm import Communicator
 from raglite_amd._sharded import ShardedIndex, merge_topk_host, shard_bounds_by_chunk
 
 __all__ = [
@@ -56,7 +57,7 @@ __all__ = [
     "TorchCrossEncoderRanker",
     "CrossEncoderShape",
     "pack_bits",
-    "DeviceIndex", "GpuIndex", "GpuVectorSearch", "HotPathConfig", "MaxSimRanker", "ShardedIndex",
+    "Communicator", "DeviceIndex", "GpuIndex", "GpuVectorSearch", "HotPathConfig", "MaxSimRanker", "ShardedIndex",
     "adapter_apply", "attach_index", "detach_index", "embed_strings", "embed_strings_with_late_chunking",
     "embed_strings_without_late_chunking", "embedding_type", "merge_topk", "merge_topk_host", "pool_norm",
     "rerank_chunks", "search_and_rerank_chunks", "set_device", "set_embedder_factory", "shard_bounds_by_chunk",

@@ -67,7 +67,14 @@ _SIGNATURES = {
     "rl_merge_topk": [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_int, c_void_p],
     "rl_topk": [c_void_p, c_i32, c_i64, c_i64, c_i32, c_void_p, c_void_p, c_int, c_void_p],
     "rl_time_kernel": [c_void_p, c_int, c_void_p, c_i32, c_i32, C.POINTER(C.c_float), c_void_p],
+    "rl_comm_unique_id": [c_void_p],
+    "rl_comm_init": [C.POINTER(c_void_p), c_int, c_int, c_void_p],
+    "rl_comm_info": [c_void_p, C.POINTER(c_int), C.POINTER(c_int)],
+    "rl_comm_destroy": [c_void_p],
+    "rl_allgather_topk": [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p],
+    "rl_allgather_merge_topk": [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p],
 }
+COMM_ID_BYTES = 128
 _RESTYPES = {"rl_last_error": c_char_p}
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 

@@ -1,0 +1,87 @@
+"""The exchange step of SURVEY.md section 8e through the C ABI: an RCCL communicator (one process per GPU) and the
+all-gather + merge of every rank's local top-k, with no torch.distributed on the data path.
+
+    id_bytes = Communicator.unique_id()            # rank 0; hand the 128 bytes to every rank (any side channel)
+    comm = Communicator(rank, world, id_bytes)     # every rank (collective)
+    scores, ids = comm.allgather_merge_topk(local_scores, local_ids, id_offset, k)   # CUDA tensors in and out
+
+`Communicator.from_torch_distributed()` uses an initialised torch.distributed group only as that side channel (one
+broadcast of the id at start-up); the collectives of a search step then run through librccl directly.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+from typing import Any
+
+import numpy as np
+
+from raglite_amd import _ops
+from raglite_amd._abi import COMM_ID_BYTES, check, lib
+
+
+class Communicator:
+    def __init__(self, rank: int, world: int, unique_id: bytes) -> None:
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {COMM_ID_BYTES} bytes")
+        _ops._ensure_init(_ops._current_device())
+        handle = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), COMM_ID_BYTES)
+        check(lib().rl_comm_init(C.byref(handle), int(rank), int(world), buf))
+        self._handle: C.c_void_p | None = handle
+        self.rank, self.world = int(rank), int(world)
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        check(lib().rl_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    @classmethod
+    def from_torch_distributed(cls, group: Any = None) -> "Communicator":
+        """An RCCL communicator over the ranks of an initialised torch.distributed group; torch only broadcasts the id."""
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return cls(rank, world, box[0])
+
+    def close(self) -> None:
+        if self._handle is not None:
+            check(lib().rl_comm_destroy(self._handle))
+            self._handle = None
+
+    def __del__(self) -> None:  # noqa: D105
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001 - interpreter teardown
+            pass
+
+    def _args(self, scores, ids):
+        a = _ops._Args()
+        p_s = a.inp(scores, np.float32)
+        p_i = a.inp(ids, np.int32)
+        if a.mem != _ops.MEM_DEVICE:
+            raise ValueError("the RCCL exchange moves device memory: pass CUDA tensors")
+        s = a.keep[0]
+        if s.dim() != 2 or tuple(a.keep[1].shape) != tuple(s.shape):
+            raise ValueError("scores and ids must both be (n_queries, k)")
+        a.ensure_device()
+        return a, p_s, p_i, int(s.shape[0]), int(s.shape[1])
+
+    def allgather_topk(self, scores, ids, id_offset: int):
+        """(n_queries, k) local lists -> (world, n_queries, k) of every rank's, ids made global by `id_offset`."""
+        a, p_s, p_i, nq, k = self._args(scores, ids)
+        o_s, q_s = a.out((self.world, nq, k), np.float32)
+        o_i, q_i = a.out((self.world, nq, k), np.int32)
+        check(lib().rl_allgather_topk(self._handle, p_s, p_i, nq, k, int(id_offset), q_s, q_i, a.stream))
+        return o_s, o_i
+
+    def allgather_merge_topk(self, scores, ids, id_offset: int, k: int):
+        """(n_queries, k_in) local lists -> the global top-k (n_queries, k), identical on every rank."""
+        a, p_s, p_i, nq, k_in = self._args(scores, ids)
+        o_s, q_s = a.out((nq, k), np.float32)
+        o_i, q_i = a.out((nq, k), np.int32)
+        check(lib().rl_allgather_merge_topk(self._handle, p_s, p_i, nq, k_in, int(id_offset), int(k), q_s, q_i, a.stream))
+        return o_s, o_i

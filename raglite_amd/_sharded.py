@@ -1,13 +1,18 @@
-"""Multi-GPU retrieval: corpus sharded by chunk, one RCCL all-gather of the local top-k, host merge.
+"""Multi-GPU retrieval: corpus sharded by chunk, ONE all-gather of the local top-k over RCCL, merge.
 
 SURVEY.md section 8e.  The reference is single-process; this is the only place a collective exists.
-One process per GPU (`torch.distributed`, backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU for
-tests).  Each rank owns a contiguous range of chunks (all rows of a chunk on one rank, so the
-per-chunk max of `src/raglite/_search.py:143-149` and MaxSim stay local), runs the single-GPU
-kernels over its shard, and contributes `B x k x 8 B` (score bits, global id) to ONE
-`all_gather_into_tensor`; every rank then merges `world x k` candidates per query on the host.
-At B = 1000, k = 100 that is 0.8 MB per rank -- microseconds over a 153 GB/s xGMI link next to a
-~20 ms scan, so no bucketing / overlap machinery is warranted.
+One process per GPU.  Each rank owns a contiguous range of chunks (all rows of a chunk on one rank, so the
+per-chunk max of `src/raglite/_search.py:143-149` and MaxSim stay local), runs the single-GPU kernels over
+its shard, and contributes `B x k x 8 B` (score bits, global id) to ONE all-gather; every rank then merges
+`world x k` candidates per query.  At B = 1000, k = 100 that is 0.8 MB per rank -- microseconds over a
+153 GB/s xGMI link next to a ~10 ms scan, so no bucketing / overlap machinery is warranted.
+
+Two transports for that one step:
+  * `comm=` a `raglite_amd.Communicator`: the exchange and the merge run behind the C ABI (`rl_allgather_merge_topk`:
+    pack -> `ncclAllGather` through librccl -> `rl_merge_topk`'s kernel), CUDA tensors in and out, nothing
+    synchronises with the host.  This is the production path; torch.distributed is not on it.
+  * otherwise `torch.distributed` (`group=`): backend "nccl" (= RCCL) for CUDA tensors, "gloo" for the CPU
+    tests; NumPy callers get the host merge below.
 """
 
 from __future__ import annotations
@@ -29,44 +34,56 @@ def shard_bounds_by_chunk(chunk_offsets, world: int) -> list[tuple[int, int]]:
     return list(zip(cuts[:-1], cuts[1:]))
 
 
+def _merge_order(s: np.ndarray, i: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
+    """Positions of the k best entries of every row of s / i (shape (B, M); id -1 = padding) by (score desc, id asc),
+    NaN after -inf, padding last; and how many of them are real.  One lexsort over the whole batch."""
+    pad = i < 0
+    nan = np.isnan(s)
+    key = np.where(nan | pad, -np.inf, s)
+    order = np.lexsort((i, -key, nan, pad), axis=-1)[:, :k]
+    n_valid = np.minimum((~pad).sum(axis=1), k)
+    return order, n_valid
+
+
 def merge_topk_host(scores: np.ndarray, ids: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
     """Global top-k of per-shard lists.  scores/ids: (world, B, k_in); ids are GLOBAL, -1 = padding.
     Order (score desc, id asc), NaN last -- identical to what one GPU holding everything returns."""
     world, B, k_in = scores.shape
-    s = np.transpose(scores, (1, 0, 2)).reshape(B, world * k_in)
-    i = np.transpose(ids, (1, 0, 2)).reshape(B, world * k_in).astype(np.int64)
+    s = np.ascontiguousarray(np.transpose(scores, (1, 0, 2))).reshape(B, world * k_in)
+    i = np.ascontiguousarray(np.transpose(ids, (1, 0, 2))).reshape(B, world * k_in).astype(np.int64)
+    order, n_valid = _merge_order(s, i, k)
     out_s = np.full((B, k), -np.inf, dtype=np.float32)
     out_i = np.full((B, k), -1, dtype=np.int64)
-    for b in range(B):
-        valid = i[b] >= 0
-        sb, ib = s[b][valid], i[b][valid]
-        nan = np.isnan(sb)
-        order = np.lexsort((ib, -np.where(nan, -np.inf, sb), nan))[:k]
-        out_s[b, : len(order)] = sb[order]
-        out_i[b, : len(order)] = ib[order]
+    kk = order.shape[1]
+    real = np.arange(kk)[None, :] < n_valid[:, None]
+    out_s[:, :kk] = np.where(real, np.take_along_axis(s, order, axis=1), -np.inf)
+    out_i[:, :kk] = np.where(real, np.take_along_axis(i, order, axis=1), -1)
     return out_s, out_i
 
 
 def group_chunk_max_host(row_scores: np.ndarray, row_chunks: np.ndarray, k: int):
     """a8 on the host for the sharded two-stage search: hits are sorted (score desc, row asc), a hit is
-    kept iff it is the first of its chunk (`src/raglite/_search.py:143-149`)."""
-    B = row_scores.shape[0]
+    kept iff it is the first of its chunk (`src/raglite/_search.py:143-149`).  Array code over the whole batch."""
+    row_scores = np.asarray(row_scores)
+    row_chunks = np.asarray(row_chunks).astype(np.int64)
+    B, H = row_chunks.shape
     out_s = np.full((B, k), -np.inf, dtype=np.float32)
     out_c = np.full((B, k), -1, dtype=np.int64)
-    counts = np.zeros(B, dtype=np.int32)
-    for b in range(B):
-        seen: set[int] = set()
-        n = 0
-        for s, c in zip(row_scores[b], row_chunks[b]):
-            c = int(c)
-            if c < 0 or c in seen:
-                continue
-            seen.add(c)
-            if n < k:
-                out_s[b, n], out_c[b, n] = s, c
-                n += 1
-        counts[b] = n
-    return out_s, out_c, counts
+    if H == 0:
+        return out_s, out_c, np.zeros(B, dtype=np.int32)
+    by_chunk = np.argsort(row_chunks, axis=1, kind="stable")  # within a chunk the hits keep their rank order
+    sorted_chunks = np.take_along_axis(row_chunks, by_chunk, axis=1)
+    first_sorted = np.ones((B, H), dtype=bool)
+    first_sorted[:, 1:] = sorted_chunks[:, 1:] != sorted_chunks[:, :-1]
+    first = np.zeros((B, H), dtype=bool)
+    np.put_along_axis(first, by_chunk, first_sorted, axis=1)
+    first &= row_chunks >= 0
+    rank = np.cumsum(first, axis=1) - 1  # position of a kept hit among the kept hits of its query
+    keep = first & (rank < k)
+    b_idx, h_idx = np.nonzero(keep)
+    out_s[b_idx, rank[b_idx, h_idx]] = row_scores[b_idx, h_idx]
+    out_c[b_idx, rank[b_idx, h_idx]] = row_chunks[b_idx, h_idx]
+    return out_s, out_c, keep.sum(axis=1).astype(np.int32)
 
 
 def _all_gather_stacked(t, group):
@@ -87,26 +104,39 @@ def _to_numpy(x: Any) -> np.ndarray:
     return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
 
+def _is_cuda(x: Any) -> bool:
+    return bool(getattr(x, "is_cuda", False))
+
+
 class ShardedIndex:
     """This rank's shard plus the exchange step.
 
-    local       object with `search_rows(q, k)`, `maxsim_topk(Q, k)` returning LOCAL ordinals
-                (a `raglite_amd.DeviceIndex` over the shard's rows)
-    row_base    global ordinal of the shard's first row;  chunk_base likewise for chunks
-    row_chunks  optional callable local_rows -> local chunk ordinals (needed by `search_chunks`)
-    group       torch.distributed process group (None = default group)
+    local                 object with `search_rows(q, k)`, `maxsim_topk(Q, k)` returning LOCAL ordinals
+                          (a `raglite_amd.DeviceIndex` over the shard's rows)
+    row_base, chunk_base  global ordinal of the shard's first row / chunk
+    local_chunk_offsets   the shard's CSR (needed by `search_chunks`)
+    group                 torch.distributed process group (None = default group) for the torch transport
+    comm                  a `raglite_amd.Communicator`: the exchange goes through the C ABI / librccl instead
     """
 
-    def __init__(self, local: Any, *, row_base: int, chunk_base: int, local_chunk_offsets=None, group=None) -> None:
+    def __init__(self, local: Any, *, row_base: int, chunk_base: int, local_chunk_offsets=None, group=None, comm=None) -> None:
         self.local = local
         self.row_base = int(row_base)
         self.chunk_base = int(chunk_base)
         self.local_chunk_offsets = None if local_chunk_offsets is None else np.asarray(local_chunk_offsets, np.int64)
         self.group = group
+        self.comm = comm
 
     # -- the one collective ------------------------------------------------------------------------
+    def _world(self) -> int:
+        if self.comm is not None:
+            return self.comm.world
+        import torch.distributed as dist
+
+        return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
+
     def _all_gather(self, packed: np.ndarray) -> np.ndarray:
-        """packed: int32 array (identical shape on every rank) -> (world, *shape)."""
+        """packed: int32 array (identical shape on every rank) -> (world, *shape), torch transport, host arrays."""
         import torch
         import torch.distributed as dist
 
@@ -130,9 +160,8 @@ class ShardedIndex:
         return np.stack([np.ascontiguousarray(c).view(np.int32) if c.dtype == np.float32 else c.astype(np.int32)
                          for c in cols], axis=-1)
 
-    def _exchange(self, scores, ids_local, base: int, extra=None):
-        if hasattr(scores, "is_cuda") and scores.is_cuda:
-            return self._exchange_device(scores, ids_local, base)
+    def _exchange_host(self, scores, ids_local, base: int, extra=None):
+        """Host arrays: pack (score bits, global id[, extra]) -> ONE all-gather -> (world, B, k) arrays."""
         s = _to_numpy(scores).astype(np.float32, copy=False)
         i = _to_numpy(ids_local).astype(np.int64)
         s2 = s.reshape(1, -1) if s.ndim == 1 else s
@@ -143,36 +172,18 @@ class ShardedIndex:
         gs = np.ascontiguousarray(g[..., 0]).view(np.float32)
         return gs, g[..., 1], (g[..., 2] if extra is not None else None), s.ndim == 1
 
-    def _exchange_device(self, scores, ids_local, base: int):
-        """CUDA tensors in: pack (score bits, global id) on the device, ONE all-gather (RCCL), one D2H."""
-        import torch
-        import torch.distributed as dist
-
-        single = scores.dim() == 1
-        s2 = scores.reshape(1, -1) if single else scores
-        i2 = ids_local.reshape(1, -1) if single else ids_local
-        gid = torch.where(i2 >= 0, i2 + base, torch.full_like(i2, -1))
-        packed = torch.stack([s2.contiguous().view(torch.int32), gid.to(torch.int32)], dim=-1).contiguous()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            out = _all_gather_stacked(packed, self.group)
-        else:
-            out = packed[None]
-        g = out.cpu().numpy()
-        gs = np.ascontiguousarray(g[..., 0]).view(np.float32)
-        return gs, g[..., 1], None, single
-
     def _exchange_merge_device(self, scores, ids_local, base: int, k: int):
-        """CUDA tensors in, CUDA tensors out, no host synchronisation: pack (score bits, global id) on the device,
-        ONE all-gather (RCCL), unpack, merge with `rl_merge_topk`.  Lets consecutive query batches queue
-        back to back on the stream (the host only enqueues)."""
+        """CUDA tensors in, CUDA tensors out, no host synchronisation: (score bits, global id) records, ONE all-gather
+        (RCCL), merge with `rl_merge_topk`'s kernel.  Lets consecutive query batches queue back to back on the stream
+        (the host only enqueues).  Through the C ABI when a Communicator is attached."""
         import torch
-        import torch.distributed as dist
 
+        if self.comm is not None:
+            return self.comm.allgather_merge_topk(scores, ids_local.to(torch.int32), base, k)
         from . import _ops
 
         gid = torch.where(ids_local >= 0, ids_local + base, torch.full_like(ids_local, -1)).to(torch.int32)
-        world = dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
-        if world == 1:
+        if self._world() == 1:
             return scores, gid
         packed = torch.stack([scores.contiguous().view(torch.int32), gid], dim=-1).contiguous()  # (B, k, 2)
         out = _all_gather_stacked(packed, self.group)
@@ -180,62 +191,94 @@ class ShardedIndex:
         gi = out[..., 1].contiguous()
         return _ops.merge_topk(gs, gi, k)
 
+    def _gather_device(self, scores, ids, offset: int):
+        """(B, k) CUDA lists -> (world, B, k) of every rank's, ids + offset (-1 stays -1)."""
+        import torch
+
+        if self.comm is not None:
+            return self.comm.allgather_topk(scores, ids.to(torch.int32), offset)
+        gid = torch.where(ids >= 0, ids + offset, torch.full_like(ids, -1)).to(torch.int32)
+        if self._world() == 1:
+            return scores[None], gid[None]
+        packed = torch.stack([scores.contiguous().view(torch.int32), gid], dim=-1).contiguous()
+        out = _all_gather_stacked(packed, self.group)
+        return out[..., 0].contiguous().view(torch.float32), out[..., 1].contiguous()
+
     # -- searches ----------------------------------------------------------------------------------------
     def search_rows(self, queries, k: int):
         """Global exact top-k rows: (scores (B,k), global row ordinals (B,k))."""
         s, r = self.local.search_rows(queries, k)
-        if hasattr(s, "is_cuda") and s.is_cuda:  # device-resident queries (cfg 5: B = 1000): merge on the device too
+        if _is_cuda(s):  # device-resident queries (cfg 5: B = 1000): merge on the device too
             single = s.dim() == 1
             ms, mi = self._exchange_merge_device(s.reshape(1, -1) if single else s, r.reshape(1, -1) if single else r,
                                                  self.row_base, k)
             return (ms[0], mi[0]) if single else (ms, mi)
-        gs, gi, _, single = self._exchange(s, r, self.row_base)
+        gs, gi, _, single = self._exchange_host(s, r, self.row_base)
         ms, mi = merge_topk_host(gs, gi, k)
         return (ms[0], mi[0]) if single else (ms, mi)
 
     def maxsim_topk(self, query_vecs, k: int):
         """Global exact top-k chunks by MaxSim: (scores (k,), global chunk ordinals (k,))."""
         s, c = self.local.maxsim_topk(query_vecs, k)
-        if hasattr(s, "is_cuda") and s.is_cuda:
+        if _is_cuda(s):
             ms, mi = self._exchange_merge_device(s.reshape(1, -1), c.reshape(1, -1), self.chunk_base, k)
             return ms[0], mi[0]
-        gs, gi, _, _ = self._exchange(s, c, self.chunk_base)
+        gs, gi, _, _ = self._exchange_host(s, c, self.chunk_base)
         ms, mi = merge_topk_host(gs, gi, k)
         return ms[0], mi[0]
 
     def maxsim_topk_batch(self, query_batch, k: int):
-        """A batch of queries (QB, nq, dim): QB local launches, ONE all-gather of (QB, k, 2) int32, one merge
+        """A batch of queries (QB, nq, dim): the local batched search, ONE all-gather of (QB, k, 2) int32, one merge
         (on the device without any host synchronisation when the queries are CUDA tensors, else on the host).
         Returns (scores (QB,k), global chunk ordinals (QB,k))."""
         if hasattr(self.local, "maxsim_topk_batch"):
             s, c = self.local.maxsim_topk_batch(query_batch, k)
-            if hasattr(s, "is_cuda") and s.is_cuda:  # device-resident queries: results stay on the device
+            if _is_cuda(s):  # device-resident queries: results stay on the device
                 return self._exchange_merge_device(s, c, self.chunk_base, k)
         else:
             outs = [self.local.maxsim_topk(query_batch[b], k) for b in range(len(query_batch))]
             s, c = np.stack([_to_numpy(o[0]) for o in outs]), np.stack([_to_numpy(o[1]) for o in outs])
-        gs, gi, _, _ = self._exchange(s, c, self.chunk_base)
+        gs, gi, _, _ = self._exchange_host(s, c, self.chunk_base)
         return merge_topk_host(gs, gi, k)
 
     def search_chunks(self, queries, num_hits: int, k: int):
-        """Reference two-stage semantics across shards: gather each rank's top-`num_hits` rows with their
-        global chunk ordinals, merge to the global top-`num_hits` rows, then group on the host."""
+        """Reference two-stage semantics across shards (`src/raglite/_search.py:66-79,143-149`): every rank's
+        top-`num_hits` rows travel with their global chunk ordinals, are merged to the global top-`num_hits` rows
+        (score desc, row asc), then grouped by chunk.  CUDA queries: two tiny all-gathers on the device (rows, chunks),
+        one copy of the (world, B, num_hits) lists to the host for the merge + group-by, CUDA tensors back."""
         if self.local_chunk_offsets is None:
             raise ValueError("search_chunks needs local_chunk_offsets")
         s, r = self.local.search_rows(queries, num_hits)
-        r_np = _to_numpy(r).astype(np.int64)
-        r2 = r_np.reshape(1, -1) if r_np.ndim == 1 else r_np
-        chunk_local = np.searchsorted(self.local_chunk_offsets, r2, side="right") - 1
-        chunk_global = np.where(r2 >= 0, chunk_local + self.chunk_base, -1)
-        gs, gi, gc, single = self._exchange(s, r, self.row_base, extra=chunk_global)
+        device = s.device if _is_cuda(s) else None
+        if device is not None:
+            import torch
+
+            single = s.dim() == 1
+            s2, r2 = (s.reshape(1, -1), r.reshape(1, -1)) if single else (s, r)
+            loc = torch.as_tensor(self.local_chunk_offsets, device=device)
+            chunk_local = torch.searchsorted(loc, r2.to(torch.int64).clamp(min=0), right=True) - 1
+            chunk_local = torch.where(r2 >= 0, chunk_local, torch.full_like(chunk_local, -1)).to(torch.int32)
+            gs_t, gi_t = self._gather_device(s2, r2, self.row_base)
+            _, gc_t = self._gather_device(s2, chunk_local, self.chunk_base)
+            gs, gi, gc = gs_t.cpu().numpy(), gi_t.cpu().numpy(), gc_t.cpu().numpy()
+        else:
+            r_np = _to_numpy(r).astype(np.int64)
+            r2n = r_np.reshape(1, -1) if r_np.ndim == 1 else r_np
+            chunk_local = np.searchsorted(self.local_chunk_offsets, r2n, side="right") - 1
+            chunk_global = np.where(r2n >= 0, chunk_local + self.chunk_base, -1)
+            gs, gi, gc, single = self._exchange_host(s, r, self.row_base, extra=chunk_global)
         world, B, kin = gs.shape
-        ms, mi = merge_topk_host(gs, gi, num_hits)
-        # chunk ordinal of every merged row: look it up among the gathered (row, chunk) pairs
-        flat_rows = np.transpose(gi, (1, 0, 2)).reshape(B, world * kin)
-        flat_chunks = np.transpose(gc, (1, 0, 2)).reshape(B, world * kin)
-        mc = np.full_like(mi, -1)
-        for b in range(B):
-            lut = {int(rr): int(cc) for rr, cc in zip(flat_rows[b], flat_chunks[b]) if rr >= 0}
-            mc[b] = [lut.get(int(rr), -1) for rr in mi[b]]
+        fs = np.ascontiguousarray(np.transpose(gs, (1, 0, 2))).reshape(B, world * kin)
+        fr = np.ascontiguousarray(np.transpose(gi, (1, 0, 2))).reshape(B, world * kin).astype(np.int64)
+        fc = np.ascontiguousarray(np.transpose(gc, (1, 0, 2))).reshape(B, world * kin).astype(np.int64)
+        order, n_valid = _merge_order(fs, fr, num_hits)  # the global top-num_hits rows of every query
+        real = np.arange(order.shape[1])[None, :] < n_valid[:, None]
+        ms = np.where(real, np.take_along_axis(fs, order, axis=1), -np.inf).astype(np.float32)
+        mc = np.where(real, np.take_along_axis(fc, order, axis=1), -1)
         out = group_chunk_max_host(ms, mc, k)
+        if device is not None:
+            import torch
+
+            out = (torch.as_tensor(out[0], device=device), torch.as_tensor(out[1].astype(np.int32), device=device),
+                   torch.as_tensor(out[2], device=device))
         return tuple(o[0] for o in out) if single else out

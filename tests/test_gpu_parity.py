@@ -339,12 +339,17 @@ def test_maxsim_stream_uniform_tolerance_and_linearity():
     np.testing.assert_allclose(got, ref, rtol=0, atol=TOL)
     s, c = idx.maxsim_topk(Q.astype(np.float32), 100)
     assert_topk_close(s, c, ref, 100, TOL)
-    # batched entry point: same bits as query-by-query calls
+    # batched entry point.  Two queries share a pass of the streaming kernel: same bits as query-by-query calls.  Three or
+    # more go through the eight-query kernel over the pre-split corpus image, which sums K in one chain instead of four
+    # quarters: same bar against the oracle, not the same bits.
     Qb = np.stack([Q, Q[::-1].copy(), 0.5 * Q]).astype(np.float32)
-    bs, bc = idx.maxsim_topk_batch(Qb, 100)
-    for b in range(3):
+    bs, bc = idx.maxsim_topk_batch(Qb[:2], 100)
+    for b in range(2):
         ss, cc = idx.maxsim_topk(Qb[b], 100)
         assert np.array_equal(bs[b], ss) and np.array_equal(bc[b], cc)
+    bs, bc = idx.maxsim_topk_batch(Qb, 100)
+    for b in range(3):
+        assert_topk_close(bs[b], bc[b], oracle.maxsim_scores(E.astype(np.float32), off, Qb[b]), 100, TOL)
     # scaling Q by a power of two scales every score exactly (size-independent property)
     got2 = idx.maxsim_scores((2.0 * Q).astype(np.float32))
     assert np.array_equal(got2, 2.0 * got)
@@ -1386,8 +1391,12 @@ def test_maxsim_batch_pairs_float_data_device_pointers(torch_cuda, storage):
     if storage == "f16":
         E = E.half()
     idx = raglite_amd.DeviceIndex(E, off, metric="dot", storage=storage)
-    bs, bc = idx.maxsim_topk_batch(Qb, 100)
     Eh = E.float().cpu().numpy()
+    if storage == "f16":  # every batch size goes through the pair kernel
+        bs, bc = idx.maxsim_topk_batch(Qb, 100)
+    else:  # fp32-stored: batches of three or more take the eight-query kernel (tests/test_gpu_gemm_pass.py); pairs here
+        parts = [idx.maxsim_topk_batch(Qb[i : i + 2], 100) for i in (0, 2, 4)]
+        bs, bc = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
     for i in range(6):
         ss, sc = idx.maxsim_topk(Qb[i], 100)
         assert torch.equal(bc[i], sc) and torch.equal(bs[i], ss)

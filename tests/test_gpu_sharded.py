@@ -126,3 +126,111 @@ def test_bench_two_ranks_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and out["scaling"] == "strong"
     assert out["roofline"]["algorithmic_bytes_per_launch"] < 4.0 * 100000 * 1024  # a shard, not the whole corpus
+
+
+def test_rccl_communicator_world_of_one():
+    """The exchange step behind the C ABI (rl_comm_* / rl_allgather_topk / rl_allgather_merge_topk over librccl) on the one
+    GPU a test box has: communicator init, the all-gather and the merge with a single rank.  (Two ranks cannot share a
+    device under RCCL; the two-rank logic is covered over gloo in tests/test_sharded_gloo.py.)"""
+    import torch
+
+    raglite_amd.set_device(0)
+    comm = raglite_amd.Communicator(0, 1, raglite_amd.Communicator.unique_id())
+    assert (comm.rank, comm.world) == (0, 1)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    scores = torch.randn((7, 50), device="cuda", generator=g).sort(dim=1, descending=True).values
+    ids = torch.stack([torch.randperm(1000, device="cuda", generator=g)[:50] for _ in range(7)]).to(torch.int32)
+    ids[3, 40:] = -1  # padding of a short list
+    scores[3, 40:] = float("-inf")
+    gs, gi = comm.allgather_topk(scores, ids, 5000)
+    assert gs.shape == (1, 7, 50) and torch.equal(gs[0], scores)
+    assert torch.equal(gi[0], torch.where(ids >= 0, ids + 5000, torch.full_like(ids, -1)))
+    ms, mi = comm.allgather_merge_topk(scores, ids, 5000, 20)
+    # one list per query: the merge is its (score desc, id asc) top-20
+    want_s, want_i = raglite_amd.merge_topk(gs, gi, 20)
+    assert torch.equal(ms, want_s) and torch.equal(mi, want_i)
+    assert torch.equal(ms, scores[:, :20]) or bool((scores[:, :-1] == scores[:, 1:]).any())
+    # the sharded index on top of it: global ids, results stay on the device
+    n, d = 30_000, 256
+    rng = np.random.default_rng(8)
+    off = np.concatenate(([0], np.cumsum(rng.integers(1, 10, size=n))))
+    off = np.concatenate((off[off < n], [n])).astype(np.int64)
+    E = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=21, kind="small_int")
+    Q = torch.empty((5, 32, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=22, kind="small_int")
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    sh = ShardedIndex(idx, row_base=1000, chunk_base=77, local_chunk_offsets=off, comm=comm)
+    ref_s, ref_c = idx.maxsim_topk_batch(Q, 64)
+    s, c = sh.maxsim_topk_batch(Q, 64)
+    assert s.is_cuda and torch.equal(s, ref_s) and torch.equal(c, ref_c + 77)
+    qs = Q[:, 0, :].contiguous()
+    rs, rr = idx.search_rows(qs, 30)
+    s2, r2 = sh.search_rows(qs, 30)
+    assert torch.equal(s2, rs) and torch.equal(r2, rr + 1000)
+    cs, cc, cn = idx.search_chunks(qs, 40, 10)
+    s3, c3, n3 = sh.search_chunks(qs, 40, 10)  # CUDA queries through the two-stage search
+    assert s3.is_cuda and torch.equal(n3, cn) and torch.equal(s3, cs)
+    assert torch.equal(c3, torch.where(cc >= 0, cc + 77, torch.full_like(cc, -1)))
+    s4, c4, n4 = sh.search_chunks(qs[0], 40, 10)
+    assert torch.equal(s4, cs[0]) and int(n4) == int(cn[0])
+    idx.close()
+    comm.close()
+
+
+def test_device_search_chunks_two_shards(monkeypatch):
+    """`ShardedIndex.search_chunks` with CUDA queries across two shards on one device (the collective stood in for as
+    above): the merged top-`num_hits` rows grouped by chunk equal the single-index two-stage search, bit for bit."""
+    import torch
+    import torch.distributed as dist
+
+    raglite_amd.set_device(0)
+    n, d, num_hits, k = 20_000, 128, 60, 12
+    rng = np.random.default_rng(15)
+    off = np.concatenate(([0], np.cumsum(rng.integers(1, 8, size=n))))
+    off = np.concatenate((off[off < n], [n])).astype(np.int64)
+    E = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=31, kind="small_int")  # integer data: heavy ties across the shard boundary
+    Q = torch.empty((9, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=32, kind="small_int")
+    full = raglite_amd.DeviceIndex(E, off, metric="dot")
+    ref_s, ref_c, ref_n = full.search_chunks(Q, num_hits, k)
+    shards, contrib = [], {}
+    for c_lo, c_hi in shard_bounds_by_chunk(off, 2):
+        r_lo, r_hi = int(off[c_lo]), int(off[c_hi])
+        loc = off[c_lo : c_hi + 1] - off[c_lo]
+        shards.append(ShardedIndex(raglite_amd.DeviceIndex(E[r_lo:r_hi], loc, metric="dot"), row_base=r_lo, chunk_base=c_lo,
+                                   local_chunk_offsets=loc))
+    # every rank's contributions to the two gathers (rows, chunks), keyed by what the rank passes in
+    for kind in ("rows", "chunks"):
+        packs = []
+        for sh in shards:
+            s, r = sh.local.search_rows(Q, num_hits)
+            if kind == "rows":
+                ids = torch.where(r >= 0, r + sh.row_base, torch.full_like(r, -1))
+            else:
+                loc = torch.as_tensor(sh.local_chunk_offsets, device="cuda")
+                cl = torch.searchsorted(loc, r.to(torch.int64).clamp(min=0), right=True) - 1
+                ids = torch.where(r >= 0, cl + sh.chunk_base, torch.full_like(cl, -1))
+            packs.append(torch.stack([s.contiguous().view(torch.int32), ids.to(torch.int32)], dim=-1).contiguous())
+        contrib[kind] = packs
+
+    def fake_all_gather(out, inp, group=None):
+        for packs in contrib.values():
+            if any(torch.equal(inp, p) for p in packs):
+                stacked = out.view(2, *inp.shape)
+                stacked[0].copy_(packs[0])
+                stacked[1].copy_(packs[1])
+                return
+        raise AssertionError("unexpected all-gather input")
+
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake_all_gather)
+    for sh in shards:
+        s, c, cnt = sh.search_chunks(Q, num_hits, k)
+        assert s.is_cuda and torch.equal(cnt, ref_n) and torch.equal(s, ref_s) and torch.equal(c, ref_c)
+    monkeypatch.undo()
+    for sh in shards:
+        sh.local.close()
+    full.close()
