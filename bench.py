@@ -244,7 +244,7 @@ def main() -> None:
         result["roofline"] = {"bound": "hbm", **hbm, "traffic": traffic}
     result["roofline"].update({
         "kernel": kernel_name, "arithmetic": arithmetic, "queries_per_launch": per_launch, "kernel_ms": ms,
-        "traffic_source": traffic_source,
+        "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes,
         # HIP events around the whole timed region / corpus passes in it: the kernel + its share of query split and selection
         "timed_region_ms_per_pass": region_ms / (args.steps * qps) * per_launch,
         "fp32_equivalent_tflops": fp32_equiv_flops / (ms * 1e-3) / 1e12,
