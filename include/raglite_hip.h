@@ -135,6 +135,13 @@ int rl_index_append(rl_index* index, const float* rows, int64_t n_new_rows, cons
                     int64_t n_new_chunks, int mem, void* stream);
 int rl_index_delete_chunks(rl_index* index, const int64_t* chunk_ordinals, int64_t n, void* stream);
 int rl_index_live(rl_index* index, int64_t* live_rows, int64_t* live_chunks, void* stream);
+/* rl_index_compact: reclaim the tombstones.  The surviving chunks keep their relative order and get the ordinals
+ * 0 .. live_chunks - 1, their rows move together (one gather pass over the matrix, the per-row norms travel with
+ * them), every derived structure is rebuilt; afterwards the index equals one created from the surviving rows.
+ *   out_remap   HOST int64[old n_chunks] or NULL: new ordinal of every old chunk, -1 for a deleted one
+ * A long-lived index under delete_documents traffic (src/raglite/_delete.py:148-176) would otherwise keep streaming
+ * its dead rows in every scan.  No-op (identity remap) without tombstones.  Synchronous. */
+int rl_index_compact(rl_index* index, int64_t* out_remap, int64_t* new_n_rows, int64_t* new_n_chunks, void* stream);
 
 /* ---- arithmetic of the MFMA streaming kernel over an fp32-stored corpus --------------------------
  * The reference multiplies in fp32 (DuckDB FLOAT[d], src/raglite/_typing.py:99-134) or fp64 (NumPy,

@@ -325,6 +325,21 @@ class DeviceIndex:
         _ensure_init(self.device.index or 0) if self.mem == MEM_DEVICE else _ensure_init(_current_device())
         check(lib().rl_index_delete_chunks(self._handle, c.ctypes.data, int(c.size), None))
 
+    def compact(self) -> np.ndarray:
+        """Reclaim tombstoned chunks (`rl_index_compact`): survivors keep their order and are renumbered 0..live-1.
+        Returns remap (old n_chunks,) int64: new ordinal of every old chunk, -1 for a deleted one."""
+        _ensure_init(self.device.index or 0) if self.mem == MEM_DEVICE else _ensure_init(_current_device())
+        remap = np.empty(self.n_chunks, dtype=np.int64)
+        n_rows, n_chunks = C.c_int64(0), C.c_int64(0)
+        check(lib().rl_index_compact(self._handle, remap.ctypes.data, C.byref(n_rows), C.byref(n_chunks), None))
+        if int(n_chunks.value) != self.n_chunks:
+            if self.chunk_offsets is not None:
+                sizes = np.diff(self.chunk_offsets)[remap >= 0]
+                self.chunk_offsets = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+            self.n_rows, self.n_chunks = int(n_rows.value), int(n_chunks.value)
+            self._keep = None  # the index owns its (rewritten) storage
+        return remap
+
     def set_exact_fp32(self, exact: bool = True) -> None:
         """Make the MFMA streaming kernel use exact fp32 MFMAs (an ordered fmaf chain) instead of the default fp16
         (hi, lo) split of its fp32 operands (`rl_index_set_arithmetic`, include/raglite_hip.h)."""

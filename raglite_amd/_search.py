@@ -106,6 +106,77 @@ class GpuIndex:
             self.index.delete_chunks(np.asarray(ords, dtype=np.int64))
         return len(ords)
 
+    # -- the real store ----------------------------------------------------------------------
+    @classmethod
+    def from_store(cls, bind: Any, *, metric: str = "cosine", storage: str = "f32", exact_fp32: bool = False) -> "GpuIndex":
+        """Build the device index from a RAGLite database: `chunk_embedding` rows ordered by (chunk_id, id)
+        (`src/raglite/_database.py:403-430`), the chunks' `str(chunk)` text and metadata, and the stored query adapter
+        (`:450-462`).  `bind`: SQLAlchemy Engine / Connection / Session or a database URL.  `metric` is the store's
+        `vector_search_distance_metric` (`_config.py:69`).  The index remembers `bind` for `sync()`."""
+        from raglite_amd import _store
+
+        conn, owned = _store._connection(bind)  # noqa: SLF001
+        try:
+            img = _store.read_chunks(conn)
+            adapter = _store.read_query_adapter(conn)
+        finally:
+            if owned:
+                conn.close()
+        if not img.rows:
+            raise ValueError("First run `insert_documents()` to insert documents.")  # the reference's wording for an empty store
+        off = np.concatenate(([0], np.cumsum(np.asarray(img.sizes, dtype=np.int64)))).astype(np.int64)
+        gi = cls(img.chunk_ids, img.matrix(), chunk_offsets=off, metric=metric, query_adapter=adapter, docs=img.docs,
+                 metadata=img.metadata, storage=storage, exact_fp32=exact_fp32)
+        gi._bind = bind  # noqa: SLF001
+        return gi
+
+    def sync(self, bind: Any = None, *, compact_above: float = 0.25) -> tuple[int, int]:
+        """Bring the device image up to date with the store after `insert_documents` / `delete_documents`
+        (`src/raglite/_insert.py:247-272`, `src/raglite/_delete.py:148-176`): chunk ids that appeared are appended
+        (rows ordered by `id` within a chunk), ids that vanished are tombstoned, the query adapter is re-read; when
+        more than `compact_above` of the rows are dead the index is compacted.  Returns (appended, deleted)."""
+        from raglite_amd import _store
+
+        bind = bind if bind is not None else getattr(self, "_bind", None)
+        if bind is None:
+            raise ValueError("sync() needs the store: build the index with GpuIndex.from_store() or pass `bind`")
+        conn, owned = _store._connection(bind)  # noqa: SLF001
+        try:
+            in_store = set(_store.list_embedded_chunk_ids(conn))
+            gone = [cid for cid in self._id_to_ordinal if cid not in in_store]
+            new = sorted(in_store.difference(self._id_to_ordinal))
+            img = _store.read_chunks(conn, new) if new else None
+            self.query_adapter = _store.read_query_adapter(conn)
+        finally:
+            if owned:
+                conn.close()
+        n_deleted = self.delete_chunks(gone)
+        if img is not None and img.rows:
+            mats, at = [], 0
+            for size in img.sizes:
+                mats.append(np.vstack(img.rows[at : at + size]))
+                at += size
+            self.insert_chunks(img.chunk_ids, mats, docs=img.docs if self.docs is not None else None,
+                               metadata=img.metadata if self.metadata is not None else None)
+        live_rows, _ = self.index.live()
+        if self.index.n_rows and 1.0 - live_rows / self.index.n_rows > compact_above:
+            self.compact()
+        return (len(img.chunk_ids) if img is not None else 0), n_deleted
+
+    def compact(self) -> None:
+        """Drop the tombstoned chunks for good (`rl_index_compact`) and renumber the host-side tables accordingly."""
+        remap = self.index.compact()
+        keep = np.nonzero(remap >= 0)[0]
+        if len(keep) == len(remap):
+            return
+        self.chunk_ids = [self.chunk_ids[i] for i in keep]
+        self._id_to_ordinal = {cid: i for i, cid in enumerate(self.chunk_ids)}
+        if self.docs is not None:
+            self.docs = [self.docs[i] for i in keep]
+            self._doc_to_ordinal = {d: i for i, d in enumerate(self.docs)}
+        if self.metadata is not None:
+            self.metadata = [self.metadata[i] for i in keep]
+
     def close(self) -> None:
         self.index.close()
 

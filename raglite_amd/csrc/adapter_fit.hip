@@ -135,6 +135,28 @@ int launch_permute_rows(const int32_t* rows_in, const int32_t* pos, int32_t k, i
     return RL_OK;
 }
 
+// rl_index_compact: dst row i = src row old_row[i], `row_bytes` bytes each (a multiple of 4); one wave per row.
+__global__ __launch_bounds__(256) void compact_rows_kernel(const uint32_t* __restrict__ src, int64_t row_words,
+                                                            const int64_t* __restrict__ old_row, int64_t n,
+                                                            uint32_t* __restrict__ dst) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), nw = (int64_t)gridDim.x * 4;
+    for (int64_t i = wave; i < n; i += nw) {
+        const uint32_t* a = src + old_row[i] * row_words;
+        uint32_t* b = dst + i * row_words;
+        for (int64_t c = lane; c < row_words; c += 64) b[c] = a[c];
+    }
+}
+int launch_compact_rows(const void* src, int64_t row_bytes, const int64_t* old_row, int64_t n, void* dst, hipStream_t s) {
+    if (n <= 0) return RL_OK;
+    if (row_bytes % 4) return RL_ERR_UNSUPPORTED;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, 256 * 16));
+    hipLaunchKernelGGL(compact_rows_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const uint32_t*>(src), row_bytes / 4, old_row, n,
+                       static_cast<uint32_t*>(dst));
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 int launch_gather_rows(const void* E, bool f16, int32_t dim, int64_t n_rows, const int32_t* rows, int64_t n, float* out,
                        hipStream_t s) {
     if (n <= 0) return RL_OK;

@@ -637,6 +637,98 @@ int rl_index_live(rl_index* idx, int64_t* live_rows, int64_t* live_chunks, void*
     return RL_OK;
 }
 
+int rl_index_compact(rl_index* idx, int64_t* out_remap, int64_t* new_n_rows, int64_t* new_n_chunks, void* stream) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_index_compact: null index");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
+    const int64_t old_c = idx->n_chunks;
+    auto identity = [&]() {
+        if (out_remap) for (int64_t c = 0; c < old_c; ++c) out_remap[c] = c;
+        if (new_n_rows) *new_n_rows = idx->n_rows;
+        if (new_n_chunks) *new_n_chunks = idx->n_chunks;
+        return RL_OK;
+    };
+    if (idx->n_dead_chunks == 0) return identity();
+    // ---- the surviving chunks, in their old order: new CSR, old ordinal -> new ordinal, new row -> old row ---------------
+    std::vector<int64_t> new_off, remap((size_t)old_c, -1), old_row;
+    new_off.reserve((size_t)(old_c - idx->n_dead_chunks) + 1);
+    old_row.reserve((size_t)(idx->n_rows - idx->n_dead_rows));
+    new_off.push_back(0);
+    bool has_empty = false;
+    for (int64_t c = 0; c < old_c; ++c) {
+        if (!((idx->h_live[(size_t)(c >> 5)] >> (c & 31)) & 1u)) continue;
+        remap[(size_t)c] = (int64_t)new_off.size() - 1;
+        for (int64_t r = idx->h_offsets[(size_t)c]; r < idx->h_offsets[(size_t)c + 1]; ++r) old_row.push_back(r);
+        has_empty |= idx->h_offsets[(size_t)c + 1] == idx->h_offsets[(size_t)c];
+        new_off.push_back((int64_t)old_row.size());
+    }
+    const int64_t new_n = (int64_t)old_row.size(), new_c = (int64_t)new_off.size() - 1;
+    const bool f16 = idx->E16 != nullptr;
+    const size_t row_bytes = (size_t)idx->dim * (f16 ? sizeof(uint16_t) : sizeof(float));
+    if (row_bytes % 4) return fail(RL_ERR_UNSUPPORTED, "rl_index_compact: an odd dim of fp16 rows is not supported");
+    // ---- all-or-nothing: every new buffer exists before the index is touched ------------------------------------------------
+    void *e = nullptr, *map = nullptr;
+    float *nn = nullptr, *ns = nullptr;
+    int32_t* r2c = nullptr;
+    int64_t* o = nullptr;
+    auto undo = [&](int code) {
+        for (void* p : {e, map, (void*)nn, (void*)ns, (void*)r2c, (void*)o}) if (p) (void)hipFree(p);
+        return code;
+    };
+#define RL_CMP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return undo(fail(_e == hipErrorOutOfMemory ? RL_ERR_NOMEM : RL_ERR_HIP, std::string("rl_index_compact: ") + hipGetErrorString(_e))); } while (0)
+    RL_CMP(hipMalloc(&e, std::max<size_t>((size_t)new_n * row_bytes, 16)));
+    RL_CMP(hipMalloc(&map, std::max<size_t>((size_t)new_n * sizeof(int64_t), 16)));
+    if (idx->norm) RL_CMP(hipMalloc(&nn, std::max<size_t>((size_t)new_n * sizeof(float), 16)));
+    if (idx->sumsq) RL_CMP(hipMalloc(&ns, std::max<size_t>((size_t)new_n * sizeof(float), 16)));
+    RL_CMP(hipMalloc(&r2c, (size_t)(new_n + 65) * sizeof(int32_t)));
+    RL_CMP(hipMalloc(&o, (size_t)(new_c + 1) * sizeof(int64_t)));
+    if (new_n) RL_CMP(hipMemcpyAsync(map, old_row.data(), (size_t)new_n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    RL_CMP(hipMemcpyAsync(o, new_off.data(), (size_t)(new_c + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    {
+        const void* src = f16 ? (const void*)idx->E16 : (const void*)idx->E;
+        const int st = launch_compact_rows(src, (int64_t)row_bytes, static_cast<const int64_t*>(map), new_n, e, s);
+        if (st != RL_OK) return undo(st);
+        if (nn) { const int st2 = launch_compact_rows(idx->norm, 4, static_cast<const int64_t*>(map), new_n, nn, s); if (st2 != RL_OK) return undo(st2); }
+        if (ns) { const int st2 = launch_compact_rows(idx->sumsq, 4, static_cast<const int64_t*>(map), new_n, ns, s); if (st2 != RL_OK) return undo(st2); }
+    }
+    RL_CMP(hipStreamSynchronize(s));
+#undef RL_CMP
+    // ---- commit -----------------------------------------------------------------------------------------------------------------
+    if (idx->owns_E) (void)hipFree(const_cast<void*>(f16 ? (const void*)idx->E16 : (const void*)idx->E));
+    if (f16) idx->E16 = static_cast<const uint16_t*>(e); else idx->E = static_cast<const float*>(e);
+    idx->owns_E = true;
+    (void)hipFree(map);
+    if (idx->norm) { (void)hipFree(idx->norm); idx->norm = nn; }
+    if (idx->sumsq) { (void)hipFree(idx->sumsq); idx->sumsq = ns; }
+    (void)hipFree(idx->row_to_chunk);
+    idx->row_to_chunk = r2c;
+    (void)hipFree(idx->offsets);
+    idx->offsets = o;
+    idx->n_rows = idx->cap_rows = new_n;
+    idx->n_chunks = idx->cap_chunks = new_c;
+    idx->h_offsets = std::move(new_off);
+    idx->has_empty_chunk = has_empty;
+    idx->h_live.clear();
+    if (idx->live_chunk_bits) { (void)hipFree(idx->live_chunk_bits); idx->live_chunk_bits = nullptr; }
+    if (idx->live_row_bits) { (void)hipFree(idx->live_row_bits); idx->live_row_bits = nullptr; }
+    idx->n_dead_chunks = idx->n_dead_rows = 0;
+    RL_TRY(launch_row_to_chunk(idx->offsets, new_c, new_n, idx->row_to_chunk, s));
+    // the magnitude range may only have shrunk: recompute it over the survivors, then the corpus image from scratch
+    idx->max_abs = 0.f;
+    idx->min_row_max = std::numeric_limits<float>::infinity();
+    idx->nonfinite = false;
+    idx->planes_rows = 0;
+    idx->planes_scale = 0.f;
+    RL_TRY(scan_row_range(idx, 0, new_n, s));
+    RL_TRY(refresh_planes(idx, s));
+    RL_HIP(hipStreamSynchronize(s));
+    if (out_remap) std::memcpy(out_remap, remap.data(), (size_t)old_c * sizeof(int64_t));
+    if (new_n_rows) *new_n_rows = new_n;
+    if (new_n_chunks) *new_n_chunks = new_c;
+    return RL_OK;
+}
+
 int rl_index_set_arithmetic(rl_index* idx, int mode) {
     if (!idx) return fail(RL_ERR_INVALID, "rl_index_set_arithmetic: null index");
     if (mode != RL_ARITH_AUTO && mode != RL_ARITH_FP32_EXACT) return fail(RL_ERR_INVALID, "rl_index_set_arithmetic: unknown mode");

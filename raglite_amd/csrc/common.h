@@ -144,6 +144,7 @@ int launch_permute_rows(const int32_t* rows_in, const int32_t* pos, int32_t k, i
                         hipStream_t s);
 int launch_gather_rows(const void* E, bool f16, int32_t dim, int64_t n_rows, const int32_t* rows, int64_t n, float* out,
                        hipStream_t s);
+int launch_compact_rows(const void* src, int64_t row_bytes, const int64_t* old_row, int64_t n, void* dst, hipStream_t s);
 
 // partition_sim.hip: semantic-chunking similarities (src/raglite/_split_chunks.py:54-72), batched over documents
 size_t partition_sim_scratch_bytes(int64_t n, int64_t n_docs, int32_t dim);

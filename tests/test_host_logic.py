@@ -423,3 +423,42 @@ def test_update_query_adapter_embeds_questions_one_by_one_under_late_chunking(mo
     standard = raglite_amd.HotPathConfig(embedder="text-embedding-3-large")
     raglite_amd.update_query_adapter(evals, optimize_top_k=8, config=standard, index=gi)
     assert calls == [list(vec_of)]  # one batched call
+
+
+def test_store_reader_orders_rows_by_chunk_then_id_and_decodes_every_dialect():
+    """the reader's contract, no GPU -- rows come back ordered by (chunk_id, id) whatever the insertion
+    order, `str(chunk)` is rebuilt like /root/reference/src/raglite/_database.py:300-324, metadata is the JSON dict,
+    the query adapter is un-pickled, and the three embedding encodings of /root/reference/src/raglite/_typing.py decode."""
+    from raglite_amd import _store
+    from tests import store_fixture as sf
+
+    rng = np.random.default_rng(0)
+    engine = sf.create_store()
+    docs = sf.synthetic_documents(rng, 6, 8)
+    for doc_id, chunks in docs:
+        sf.insert_document(engine, doc_id, chunks, filename=f"{doc_id}.md")
+    A = rng.standard_normal((8, 8)).astype(np.float32)
+    sf.set_query_adapter(engine, A)
+    with engine.connect() as conn:
+        img = _store.read_chunks(conn)
+        adapter = _store.read_query_adapter(conn)
+        ids = _store.list_embedded_chunk_ids(conn)
+    by_id = {cid: (h, b, m) for _, chunks in docs for cid, h, b, m in chunks}
+    assert img.chunk_ids == sorted(by_id) and set(ids) == set(by_id)
+    at = 0
+    for cid, size, doc, md in zip(img.chunk_ids, img.sizes, img.docs, img.metadata):
+        h, b, m = by_id[cid]
+        assert size == len(m)
+        np.testing.assert_array_equal(np.vstack(img.rows[at : at + size]), m.astype(np.float32))  # insertion (= id) order
+        at += size
+        assert doc.startswith("---\nfilename: ") and doc.endswith(f"{h}\n\n{b}") and md["topic"][0].startswith("t")
+    np.testing.assert_array_equal(adapter, A)
+    only = img.chunk_ids[1:3]
+    with engine.connect() as conn:
+        part = _store.read_chunks(conn, only)
+    assert part.chunk_ids == only and part.docs == img.docs[1:3]
+    v = rng.standard_normal(5).astype(np.float16)
+    np.testing.assert_array_equal(_store.decode_embedding(v.astype(np.float32).tolist()), v.astype(np.float32))  # DuckDB FLOAT[d]
+    np.testing.assert_array_equal(_store.decode_embedding("[" + ",".join(str(x) for x in v) + "]"), v.astype(np.float32))  # halfvec text
+    np.testing.assert_array_equal(_store.decode_embedding(sf._npy(v)), v.astype(np.float32))  # NumpyArray bytes
+    assert _store._connection(engine)[1] and not _store._connection(engine.connect())[1]
