@@ -36,6 +36,8 @@ from raglite_amd._search import (
     detach_index,
     rerank_chunks,
     search_and_rerank_chunks,
+    select_reranker,
+    set_language_detector,
     vector_search,
 )
 from raglite_amd._cross_encoder import CrossEncoderShape, TorchCrossEncoderRanker
@@ -60,7 +62,7 @@ __all__ = [
     "Communicator", "DeviceIndex", "GpuIndex", "GpuVectorSearch", "HotPathConfig", "MaxSimRanker", "ShardedIndex",
     "adapter_apply", "attach_index", "detach_index", "embed_strings", "embed_strings_with_late_chunking",
     "embed_strings_without_late_chunking", "embedding_type", "merge_topk", "merge_topk_host", "pool_norm",
-    "rerank_chunks", "search_and_rerank_chunks", "set_device", "set_embedder_factory", "shard_bounds_by_chunk",
+    "rerank_chunks", "search_and_rerank_chunks", "select_reranker", "set_language_detector", "set_device", "set_embedder_factory", "shard_bounds_by_chunk",
     "synth_fill", "topk", "vector_search",
 ]
 __version__ = "0.1.0"

@@ -392,12 +392,57 @@ class MaxSimRanker:
         )
 
 
+_language_detector: Callable[[str], str] | None = None
+_language_detector_set = False
+
+
+def set_language_detector(detect: Callable[[str], str] | None) -> None:
+    """Install the callable `rerank_chunks` uses to pick a language-specific reranker from a `dict` of rerankers
+    (`src/raglite/_search.py:379-392`).  The reference imports `langdetect.detect`; any `str -> language code` callable
+    works (fastText, lingua, a customer's own).  None restores the default (langdetect if installed, else no detection)."""
+    global _language_detector, _language_detector_set
+    _language_detector, _language_detector_set = detect, detect is not None
+
+
+def _default_language_detector() -> Callable[[str], str] | None:
+    if _language_detector_set:
+        return _language_detector
+    try:
+        from langdetect import detect  # the reference's dependency (`_search.py:13`); not in this image
+
+        return detect
+    except ImportError:
+        return None
+
+
+def select_reranker(reranker: Any, query: str, chunks: Sequence[Any], detect: Callable[[str], str] | None = None) -> Any:
+    """The reference's reranker selection (`src/raglite/_search.py:378-392`): a `dict` maps language codes (and "other")
+    to rankers; when every chunk and the query are detected as ONE language that has an entry, that ranker is used,
+    otherwise the "other" entry.  A failing detector (the reference suppresses `LangDetectException`) or no detector at
+    all falls back to "other"."""
+    if not isinstance(reranker, dict):
+        return reranker
+    detect = detect or _default_language_detector()
+    langs: set[str] = set()
+    if detect is not None:
+        try:
+            langs = {detect(str(chunk)) for chunk in chunks}
+            langs.add(detect(query))
+        except Exception:  # noqa: BLE001 - e.g. langdetect's LangDetectException on text without letters
+            langs = set()
+    if len(langs) == 1 and (lang := next(iter(langs))) in reranker:
+        return reranker[lang]
+    return reranker.get("other")
+
+
 def rerank_chunks(query: str, chunk_ids: Sequence[Any], *, config: Any | None = None,
-                  chunk_lookup: Callable[[Sequence[ChunkId]], list[Any]] | None = None) -> list[Any]:
+                  chunk_lookup: Callable[[Sequence[ChunkId]], list[Any]] | None = None,
+                  detect: Callable[[str], str] | None = None) -> list[Any]:
     """Rerank chunks according to their relevance to a query (`src/raglite/_search.py:364-397`).
 
     `chunk_ids` may be chunk ids or chunk objects (anything whose `str()` is the chunk text).  Ids are
-    resolved through `chunk_lookup` (the reference uses `retrieve_chunks`, a SQL query, out of scope)."""
+    resolved through `chunk_lookup` (the reference uses `retrieve_chunks`, a SQL query, out of scope).
+    `detect`: language detector for a `dict` of rerankers (default: `set_language_detector` / langdetect)."""
     cfg = config or HotPathConfig()
     chunks = list(chunk_ids)
     if chunks and all(isinstance(c, ChunkId) for c in chunks):
@@ -407,10 +452,7 @@ def rerank_chunks(query: str, chunk_ids: Sequence[Any], *, config: Any | None = 
     reranker = getattr(cfg, "reranker", None)
     if not reranker or not chunks:
         return chunks
-    if isinstance(reranker, dict):
-        # The reference picks a language-specific ranker with langdetect (`_search.py:379-392`), which is
-        # not installed here; a MaxSim ranker is language-agnostic, so the "other" entry is used.
-        reranker = reranker.get("other")
+    reranker = select_reranker(reranker, query, chunks, detect)
     if reranker:
         results = reranker.rank(query=query, docs=[str(chunk) for chunk in chunks])
         chunks = [chunks[result.doc_id] for result in results.results]

@@ -886,6 +886,16 @@ int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStrea
         }
         return launch_transform(sc, nb, idx->n_rows, ld, idx->norm, idx->sumsq, d_q, idx->dim, mode, s);
     }
+    if (nb >= GEMM_MIN_QUERIES && idx->planes_scale > 0.f && idx->planes_scale == idx->split_scale && idx->planes_rows == idx->n_rows) {
+        // the same GEMM over the pre-split corpus image (maxsim_gemm.hip, row-score mode): no conversion in the loop
+        static const bool off = std::getenv("RAGLITE_NO_PLANES_GEMM") != nullptr;  // A/B switch
+        if (!off) {
+            RL_TRY(idx->misc.reserve(score_planes_scratch_floats(nb, idx->dim) * sizeof(float)));
+            const int st = launch_score_planes(idx->planes.p, idx->n_rows, idx->dim, d_q, nb, sc, ld, idx->norm, idx->sumsq,
+                                               idx->misc.as<float>(), mode, idx->n_cu, s, idx->split_scale);
+            if (st != RL_ERR_UNSUPPORTED) return st;
+        }
+    }
     if (nb >= GEMM_MIN_QUERIES) {  // MFMA-bound regime: one 128 x 128-tiled GEMM instead of a corpus pass per 32 queries
         RL_TRY(idx->misc.reserve(score_gemm_scratch_floats(nb, idx->dim, idx->split_scale > 0.f) * sizeof(float)));
         const int st = launch_score_gemm(idx->E, idx->n_rows, idx->dim, d_q, nb, sc, ld, idx->norm, idx->sumsq,

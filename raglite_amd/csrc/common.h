@@ -177,6 +177,9 @@ int launch_query_planes(const float* Q, int32_t dim, int32_t nq, int64_t q_strid
 int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first,
                        int32_t n_q, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits,
                        float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale);
+size_t score_planes_scratch_floats(int32_t nb, int32_t dim);
+int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores, int64_t ld,
+                        const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale);
 // [largest |element|, smallest non-zero row maximum, non-finite flag] of an fp32 corpus, as uint32 bit patterns (device, 3 words)
 int launch_row_range(const float* E, int64_t n_rows, int32_t dim, uint32_t* range, hipStream_t s);
 // Any dim / nq: one wave per chunk (or per candidate), VALU dot products.

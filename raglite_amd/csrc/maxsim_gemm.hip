@@ -224,13 +224,26 @@ __device__ __forceinline__ void mg_pin(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
 #define MG_MAX_DPP(dst, src, x, CTRLSTR) asm volatile("v_max_f32_dpp %0, %1, %2 " CTRLSTR " row_mask:0xf bank_mask:0xf" : "=&v"(dst) : "v"(src), "v"(x))
 #define MG_SELECT(x, t, mask) asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(x) : "v"(x), "v"(t), "s"(mask))
 
-template <int NQB, bool TRACE = false>
+// MODE 1: the same main loop as a row-score GEMM (a6 for many queries, BASELINE cfg 5): the 8 waves of a tile score 8 groups
+// of 32 independent queries, the metric of src/raglite/_typing.py:123-134 is applied in the epilogue and S[q * ld + row] is
+// stored; a workgroup walks (row tile, query tile) pairs, all query tiles of a row tile back to back.
+struct RowScoreArgs {
+    float* S; int64_t ld;                 // [B x ld] similarities
+    const float* row_norm;                // cosine: |e| per row;  l2: |e|^2 per row
+    const float* q_sumsq;                 // |q|^2 per query (cosine / l2)
+    const float* q_unscale;               // per query: 2^(ex - 14), undoes its scale
+    const float* q_anylo;                 // per group of 32 queries: any lo half != 0
+    int32_t B, QT, metric;                // queries, query tiles of 256 per row tile, SCAN_* mode
+};
+
+template <int NQB, bool TRACE = false, int MODE = 0>
 __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restrict__ planes, int64_t n_rows, int32_t nslab,
                                                                const char* __restrict__ qfrag, const float* __restrict__ qmeta,
                                                                int32_t n_q, const int32_t* __restrict__ row_to_chunk,
                                                                const int64_t* __restrict__ chunk_offsets,
                                                                const uint32_t* __restrict__ ends_bits, float* __restrict__ out,
-                                                               int64_t out_stride, float inv_e_scale, int dbg, unsigned long long* trace) {
+                                                               int64_t out_stride, float inv_e_scale, int dbg, unsigned long long* trace,
+                                                               RowScoreArgs rs) {
     // TRACE (diagnostic build, RAGLITE_GEMM_TRACE=1): s_memtime stamps of workgroup 7, slabs 128..143, kept in
     // LDS and copied out at the end: [slab - 128][wave][stamp 0..15] (3 + p = after pair p of the slab).
     __shared__ __attribute__((aligned(16))) char smem[MG_NSLOT * MG_SLAB + (TRACE ? 16 * 8 * 16 * 8 : 0)];
@@ -255,14 +268,24 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
         const int64_t c0 = chunk_offsets[c], c1 = chunk_offsets[c + 1];
         return c0 == t ? t : c1;
     };
-    const int32_t r_lo = (int32_t)mg_uniform_i64(boundary((n_rows * b) / G));
-    const int32_t r_hi = (int32_t)mg_uniform_i64((b + 1 == G) ? n_rows : boundary((n_rows * (b + 1)) / G));
+    int32_t r_lo, r_hi;
+    if constexpr (MODE == 0) {
+        r_lo = (int32_t)mg_uniform_i64(boundary((n_rows * b) / G));
+        r_hi = (int32_t)mg_uniform_i64((b + 1 == G) ? n_rows : boundary((n_rows * (b + 1)) / G));
+    } else {  // whole 256-row tiles, no chunk structure
+        const int64_t T = (n_rows + MG_TM - 1) / MG_TM;
+        r_lo = (int32_t)(((T * b) / G) * MG_TM);
+        r_hi = (int32_t)std::min<int64_t>(((T * (b + 1)) / G) * MG_TM, n_rows);
+    }
     if (r_hi <= r_lo) return;  // whole workgroup
     const int32_t org = r_lo & ~15;                       // tiles start on a 16-row block of the image
-    const int nt = (r_hi - org + MG_TM - 1) / MG_TM;
+    const int QT = MODE == 0 ? 1 : rs.QT;                 // query tiles per row tile
+    const int nt = ((r_hi - org + MG_TM - 1) / MG_TM) * QT;   // (row tile, query tile) pairs, query tile fastest
     const int total = nt * nslab;                         // K slabs this workgroup consumes, tile after tile
     const int32_t last_blk = (int32_t)((n_rows + 15) >> 4) - 1;
-    const bool has_q = wv < n_q;                          // wave-uniform
+    // MODE 0: wave = query wv of the pass.  MODE 1: wave = group (tile % QT) * 8 + wv of 32 queries; n_q counts the groups.
+    auto group_of = [&](int t) { return MODE == 0 ? wv : (t % QT) * MG_WAVES + wv; };
+    bool has_q = group_of(0) < n_q;                       // wave-uniform; per tile in MODE 1
     const int fj = lane & 15, kq = lane >> 4;
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
     const uint32_t lane16 = 16u * lane;
@@ -277,7 +300,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     int f_tile = 0, f_s = 0, f_slot = 0;   // position of the NEXT slab to fetch
     const char* f_base[4];                 // block bases of the tile being fetched
     auto feed_tile = [&](int t) __attribute__((always_inline)) {
-        const int32_t b0 = (org >> 4) + t * MG_NBLK + 4 * (wv & 3);
+        const int32_t b0 = (org >> 4) + (t / QT) * MG_NBLK + 4 * (wv & 3);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int32_t blk = b0 + i;
@@ -313,18 +336,32 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     };
 
     // ---- this wave's query fragments: slab s -> 4 x 16 B per lane (qb0 hi, qb0 lo, qb1 hi, qb1 lo) -------------------
-    const char* const qbase = qfrag + (int64_t)(has_q ? wv : 0) * nslab * 4096;
-    int q_s = 0;  // slab of the NEXT fragment load
+    auto qbase_of = [&](int t) {  // (clamped: a wave without a group loads some valid fragments and ignores them)
+        const int grp = group_of(t) < n_q ? group_of(t) : n_q - 1;
+        return qfrag + (int64_t)grp * nslab * 4096;
+    };
+    const char* qbase = qbase_of(0);
+    int q_s = 0, q_tile = 0;  // slab and tile of the NEXT fragment load
+    auto q_advance = [&]() __attribute__((always_inline)) {
+        if (++q_s == nslab) {
+            q_s = 0;
+            if constexpr (MODE == 1) { q_tile = q_tile + 1 < nt ? q_tile + 1 : q_tile; qbase = qbase_of(q_tile); }
+        }
+    };
     auto load_q = [&](f32x4 (&q)[4]) __attribute__((always_inline)) {
         const char* p = qbase + (int64_t)q_s * 4096;
         mg_load_frag(q[0], lane16, p);
         mg_load_frag(q[1], lane16, p + 1024);
         mg_load_frag(q[2], lane16, p + 2048);
         mg_load_frag(q[3], lane16, p + 3072);
-        q_s = q_s + 1 == nslab ? 0 : q_s + 1;
+        q_advance();
     };
-    const float unscale = has_q ? qmeta[2 * wv] * inv_e_scale : 0.f;
-    const bool any_lo = has_q && __builtin_amdgcn_readfirstlane(__float_as_int(qmeta[2 * (has_q ? wv : 0) + 1])) != 0;
+    const float unscale = (MODE == 0 && has_q) ? qmeta[2 * wv] * inv_e_scale : 0.f;
+    auto any_lo_of = [&](int t) {
+        if constexpr (MODE == 0) return has_q && __builtin_amdgcn_readfirstlane(__float_as_int(qmeta[2 * (has_q ? wv : 0) + 1])) != 0;
+        else return group_of(t) < n_q && __builtin_amdgcn_readfirstlane(__float_as_int(rs.q_anylo[group_of(t) < n_q ? group_of(t) : 0])) != 0;
+    };
+    bool any_lo = any_lo_of(0);
 
     // ---- accumulators: S^T[query vector 16 qb + 4 g + u][corpus row 16 a + j], lane = 16 g + j ------------------------
     f32x4 acc[NQB][MG_NBLK];
@@ -339,7 +376,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
 
     const uint32_t sw = (uint32_t)((fj >> 1) & 7);
     const uint32_t a_hi = (uint32_t)(fj * 128) + ((kq ^ sw) << 4), a_lo = (uint32_t)(fj * 128) + (((4 + kq) ^ sw) << 4);
-    float* const outq = out + (int64_t)(has_q ? wv : 0) * out_stride;
+    float* const outq = out + (int64_t)((MODE == 0 && has_q) ? wv : 0) * out_stride;
 
     // ---- one K slab.  Fragments of 16-row blocks are read a PAIR ahead; the first pair of a slab is read at the end of the
     // previous slab (the barrier at the top of slab g certifies slab g + 1 as landed), so the MFMAs start right after the
@@ -358,12 +395,12 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
         Feed f{};
         if (feeder) f = next_feed();
         const int next_slot = c_slot + 1 == MG_NSLOT ? 0 : c_slot + 1;
-        if (has_q) {
+        if (has_q || MODE == 1) {
             // The next slab's query fragments: ONE load after each of the first four pairs.  (All four at the top of the slab
             // stalled both waves of every SIMD for ~500 cycles while the matrix pipe idled: a VMEM instruction costs its wave
             // 60-185 cycles of issue, profiles/r02_e_trace.txt.)
             const char* const qp = qbase + (int64_t)q_s * 4096;
-            q_s = q_s + 1 == nslab ? 0 : q_s + 1;
+            q_advance();
             h16x8 qh[2], ql[2];
             __builtin_memcpy(&qh[0], &q[0], 16);
             __builtin_memcpy(&ql[0], &q[1], 16);
@@ -375,7 +412,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
                     if (p + 1 < MG_NBLK / 2) read_pair(c_slot, p + 1, eh[(p + 1) & 1], el[(p + 1) & 1]);
                     else read_pair(next_slot, 0, eh[0], el[0]);
                 }
-                if (2 * p < nb && !(dbg & 2)) {  // wave-uniform: blocks past the workgroup's range are not multiplied
+                if (2 * p < nb && has_q && !(dbg & 2)) {  // wave-uniform: blocks past the workgroup's range are not multiplied
                     const h16x8(&h)[2] = eh[p & 1];
                     const h16x8(&l)[2] = el[p & 1];
 #pragma unroll
@@ -412,6 +449,44 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     };
 
     // ---- tile epilogue: per-chunk maxima along the DPP rows, sum over the query vectors, store ---------------------------
+    auto epilogue_rows = [&](int t) __attribute__((always_inline)) {  // MODE 1: metric + store of the tile's 32 x 256 scores
+        const int32_t row0 = org + (t / QT) * MG_TM;
+        if (!has_q) return;
+        const int g = lane >> 4;
+        const int32_t q0 = group_of(t) * 32 + 4 * g;
+        const int mode = rs.metric;
+        const bool norms = mode == SCAN_COSINE || mode == SCAN_L2;
+        float us[NQB * 4], qss[NQB * 4], qn[NQB * 4];
+#pragma unroll
+        for (int r = 0; r < NQB * 4; ++r) {
+            const int32_t q = q0 + 16 * (r >> 2) + (r & 3);
+            const int32_t qc = q < rs.B ? q : rs.B - 1;
+            us[r] = rs.q_unscale[qc] * inv_e_scale;  // powers of two: exact
+            qss[r] = norms ? rs.q_sumsq[qc] : 0.f;
+            qn[r] = sqrtf(qss[r]);
+        }
+#pragma unroll
+        for (int a = 0; a < MG_NBLK; ++a) {
+            const int32_t row = row0 + 16 * a + fj;
+            const float rn = norms ? rs.row_norm[row < (int32_t)n_rows ? row : (int32_t)n_rows - 1] : 0.f;
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = 4 * qb + u;
+                    const int32_t q = q0 + 16 * qb + u;
+                    const float d = acc[qb][a][u] * us[r];
+                    float v = d;  // SCAN_RAW_DOT
+                    // the formulas (and operation order) of scan.hip:transform_kernel / score_gemm.hip: same bits
+                    if (mode == SCAN_COSINE) v = 1.0f - (1.0f - d / (rn * qn[r]));
+                    else if (mode == SCAN_DOT) v = 1.0f + d;
+                    else if (mode == SCAN_L2) v = 1.0f - sqrtf(fmaxf(rn + qss[r] - 2.0f * d, 0.f));
+                    if (q < rs.B && row < (int32_t)n_rows) rs.S[(int64_t)q * rs.ld + row] = v;
+                }
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) acc[qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    };
     auto epilogue = [&](int t) __attribute__((always_inline)) {
         const int32_t row0 = org + t * MG_TM;
         // "last row of its chunk" bits of the tile's 256 rows: 9 words from row0 / 32, shifted by 16 when row0 is odd in blocks
@@ -482,23 +557,28 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     f32x4 qa[4], qb_[4];
     {   // prologue: DMA(0), DMA(1), Q(0), DMA(2); slab 0 must have landed for everybody before its first pair is read
         if (feeder) { const Feed f0 = next_feed(); dma_all(f0); const Feed f1 = next_feed(); dma_all(f1); }
-        if (has_q) load_q(qa);
+        if (has_q || MODE == 1) load_q(qa);
         if (feeder) { const Feed f2 = next_feed(); dma_all(f2); asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (has_q) read_pair(0, 0, eh[0], el[0]);
+        if (has_q || MODE == 1) read_pair(0, 0, eh[0], el[0]);
     }
     auto tile_nb = [&](int t) {
-        const int32_t left = r_hi - (org + t * MG_TM);
+        const int32_t left = r_hi - (org + (t / QT) * MG_TM);
         const int nb = (left + 15) >> 4;
         return nb < MG_NBLK ? nb : MG_NBLK;
     };
     int nb = tile_nb(0);
     auto advance = [&]() __attribute__((always_inline)) {
         if (++c_s == nslab) {
-            epilogue(c_tile);
+            if constexpr (MODE == 0) epilogue(c_tile);
+            else epilogue_rows(c_tile);
             c_s = 0;
             ++c_tile;
             nb = tile_nb(c_tile);
+            if constexpr (MODE == 1) {  // the next tile's group of queries
+                has_q = group_of(c_tile) < n_q;
+                any_lo = any_lo_of(c_tile);
+            }
         }
     };
     auto wait_top = [&]() __attribute__((always_inline)) {
@@ -557,7 +637,7 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
     if (trace && nq > 16) {  // diagnostic build: dump the 10th launch's slab timeline to stderr
         static int calls = 0;
         hipLaunchKernelGGL((maxsim_gemm_kernel<2, true>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, qmeta, n_q,
-                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, trace);
+                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, trace, RowScoreArgs{});
         if (++calls == 10) {
             static unsigned long long h[16 * 8 * 16];
             (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
@@ -573,10 +653,105 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
     }
     if (nq <= 16)
         hipLaunchKernelGGL((maxsim_gemm_kernel<1>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, qmeta, n_q,
-                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr);
+                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr, RowScoreArgs{});
     else
         hipLaunchKernelGGL((maxsim_gemm_kernel<2>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, qmeta, n_q,
-                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr);
+                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr, RowScoreArgs{});
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// ---- MODE 1: many independent queries (a6 batched, BASELINE cfg 5) -------------------------------------------------------
+// Query image: groups of 32 queries in the fragment layout of query_planes_kernel, but every query scaled by a power of two
+// of its OWN (a batch may span many orders of magnitude): unscale[q] = 2^(ex_q - 14), anylo[group].
+__global__ __launch_bounds__(256) void query_rows_planes_kernel(const float* __restrict__ Q, int B, int dim, uint4* __restrict__ frag,
+                                                                 float* __restrict__ unscale, float* __restrict__ anylo) {
+    __shared__ float scale_sh[32];
+    __shared__ int any_lo_sh;
+    const int grp = blockIdx.x, nslab = dim >> 5;
+    const int v = threadIdx.x >> 3, sub = threadIdx.x & 7;  // 8 threads per query for the magnitude
+    const int q = grp * 32 + v;
+    float mx = 0.f;
+    if (q < B)
+        for (int c = 4 * sub; c < dim; c += 32) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(Q + (int64_t)q * dim + c);
+            mx = fmaxf(mx, fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))));
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 1));
+    mx = fmaxf(mx, __shfl_xor(mx, 2));
+    mx = fmaxf(mx, __shfl_xor(mx, 4));
+    int ex = 0;
+    if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &ex);
+    ex = ex > -100 ? ex : -100;
+    if (sub == 0) {
+        scale_sh[v] = ldexpf(1.f, 14 - ex);
+        if (q < B) unscale[q] = ldexpf(1.f, ex - 14);
+    }
+    if (threadIdx.x == 0) any_lo_sh = 0;
+    __syncthreads();
+    bool any_lo = false;
+    uint4* const out = frag + (int64_t)grp * nslab * 4 * 64;
+    for (int t = threadIdx.x; t < nslab * 2 * 64; t += 256) {
+        const int lane = t & 63, qb = (t >> 6) & 1, s = t >> 7;
+        const int vi = 16 * qb + (lane & 15), kq = lane >> 4;
+        const int qi = grp * 32 + vi;
+        h16x8 hi8, lo8;
+        f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+        if (qi < B) {
+            const float* p = Q + (int64_t)qi * dim + 32 * s + 8 * kq;
+            v0 = *reinterpret_cast<const f32x4*>(p);
+            v1 = *reinterpret_cast<const f32x4*>(p + 4);
+        }
+        const float sc = scale_sh[vi];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float x = (u < 4 ? v0[u] : v1[u - 4]) * sc;
+            const _Float16 hi = (_Float16)x;
+            const _Float16 lo = (_Float16)(x - (float)hi);
+            hi8[u] = hi;
+            lo8[u] = lo;
+            any_lo |= lo != (_Float16)0.0f;
+        }
+        uint4 a, b;
+        __builtin_memcpy(&a, &hi8, 16);
+        __builtin_memcpy(&b, &lo8, 16);
+        out[(s * 4 + 2 * qb + 0) * 64 + lane] = a;
+        out[(s * 4 + 2 * qb + 1) * 64 + lane] = b;
+    }
+    if (any_lo) any_lo_sh = 1;  // benign race: every writer stores 1
+    __syncthreads();
+    if (threadIdx.x == 0) anylo[grp] = any_lo_sh ? 1.f : 0.f;
+}
+
+// floats of scratch for `nb` queries: fragments (dim * 32 per group of 32), unscale[nb], anylo[groups], q_sumsq[nb]
+size_t score_planes_scratch_floats(int32_t nb, int32_t dim) {
+    const size_t groups = ((size_t)nb + 31) / 32;
+    return groups * 32 * (size_t)dim + 2 * (size_t)nb + groups + 64;
+}
+
+int launch_query_sumsq(const float* Q, int32_t nb, int32_t dim, float* out, hipStream_t s);  // score_gemm.hip
+
+// Similarity (metric `mode`, scan.hip conventions) of nb queries against every row over the pre-split corpus image:
+// scores[q * ld + row].  Same results as launch_score_gemm in split arithmetic up to the summation order over K.
+int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores, int64_t ld,
+                        const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale) {
+    if (nb < 1 || n_rows < 1 || dim % 32 || dim < 32 || !(split_scale > 0.f) || !planes) return RL_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(Q) & 15) || (reinterpret_cast<uintptr_t>(scratch) & 15)) return RL_ERR_UNSUPPORTED;
+    if ((mode == SCAN_COSINE && !row_norm) || (mode == SCAN_L2 && !row_sumsq)) return RL_ERR_INVALID;
+    const int32_t nslab = dim / 32, groups = (nb + 31) / 32;
+    float* frag = scratch;
+    float* unscale = frag + (size_t)groups * 32 * dim;
+    float* anylo = unscale + nb;
+    float* qss = anylo + groups;
+    hipLaunchKernelGGL(query_rows_planes_kernel, dim3((unsigned)groups), dim3(256), 0, s, Q, (int)nb, (int)dim, reinterpret_cast<uint4*>(frag), unscale,
+                       anylo);
+    if (mode == SCAN_COSINE || mode == SCAN_L2) RL_TRY(launch_query_sumsq(Q, nb, dim, qss, s));
+    RowScoreArgs rs{scores, ld, mode == SCAN_COSINE ? row_norm : row_sumsq, qss, unscale, anylo, nb, (groups + MG_WAVES - 1) / MG_WAVES, mode};
+    const int64_t tiles = (n_rows + MG_TM - 1) / MG_TM;
+    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
+    hipLaunchKernelGGL((maxsim_gemm_kernel<2, false, 1>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab,
+                       reinterpret_cast<const char*>(frag), nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, 0,
+                       nullptr, rs);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

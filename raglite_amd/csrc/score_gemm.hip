@@ -506,6 +506,13 @@ __global__ __launch_bounds__(256) void query_presplit_kernel(const float* __rest
 }
 }  // namespace
 
+// |q|^2 per query in transform_kernel's summation order (shared with maxsim_gemm.hip's row-score mode)
+int launch_query_sumsq(const float* Q, int32_t nb, int32_t dim, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(query_sumsq_kernel, dim3(nb), dim3(256), 0, s, Q, (int)dim, out);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 // Similarity (metric `mode`, scan.hip conventions) of nb queries against every row; dim % 32 == 0, 16-B aligned
 // operands.  q_sumsq_scratch: device float[nb] (cosine / l2 only).
 // split_scale > 0: fp16-split arithmetic with the corpus scaled by that power of two; q_sumsq_scratch then holds

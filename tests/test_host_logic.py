@@ -462,3 +462,40 @@ def test_store_reader_orders_rows_by_chunk_then_id_and_decodes_every_dialect():
     np.testing.assert_array_equal(_store.decode_embedding("[" + ",".join(str(x) for x in v) + "]"), v.astype(np.float32))  # halfvec text
     np.testing.assert_array_equal(_store.decode_embedding(sf._npy(v)), v.astype(np.float32))  # NumpyArray bytes
     assert _store._connection(engine)[1] and not _store._connection(engine.connect())[1]
+
+
+def test_language_aware_reranker_selection():
+    """`/root/reference/src/raglite/_search.py:378-392`: a dict of rerankers is resolved by language -- one detected language
+    with an entry -> that ranker; mixed languages, an unknown language, a failing detector or no detector -> "other"."""
+
+    class _R:
+        def __init__(self, name):
+            self.name, self.calls = name, 0
+
+        def rank(self, query, docs):
+            self.calls += 1
+            return type("Res", (), {"results": [type("X", (), {"doc_id": i})() for i in reversed(range(len(docs)))]})()
+
+    en, nl, other = _R("en"), _R("nl"), _R("other")
+    rer = {"en": en, "nl": nl, "other": other}
+    lang_of = {"hello world": "en", "good morning": "en", "hallo wereld": "nl", "bonjour": "fr"}
+    detect = lang_of.__getitem__
+    assert raglite_amd.select_reranker(rer, "hello world", ["good morning"], detect) is en
+    assert raglite_amd.select_reranker(rer, "hallo wereld", ["hallo wereld"], detect) is nl
+    assert raglite_amd.select_reranker(rer, "hello world", ["hallo wereld"], detect) is other       # mixed
+    assert raglite_amd.select_reranker(rer, "bonjour", ["bonjour"], detect) is other                # no entry for fr
+    assert raglite_amd.select_reranker(rer, "???", ["hello world"], detect) is other                # detector raised (KeyError)
+    assert raglite_amd.select_reranker(en, "x", ["y"], detect) is en                                 # not a dict: as configured
+    assert raglite_amd.select_reranker({"en": en}, "bonjour", ["bonjour"], detect) is None           # no "other": no reranking
+    cfg = raglite_amd.HotPathConfig(reranker=rer)
+    out = raglite_amd.rerank_chunks("hello world", ["good morning", "hello world"], config=cfg, detect=detect,
+                                    chunk_lookup=lambda ids: list(ids))
+    assert out == ["hello world", "good morning"] and en.calls == 1 and other.calls == 0
+    raglite_amd.set_language_detector(detect)  # process-wide default (the reference's module-level langdetect import)
+    try:
+        raglite_amd.rerank_chunks("hallo wereld", ["hallo wereld"], config=cfg, chunk_lookup=lambda ids: list(ids))
+        assert nl.calls == 1
+    finally:
+        raglite_amd.set_language_detector(None)
+    raglite_amd.rerank_chunks("hallo wereld", ["hallo wereld"], config=cfg, chunk_lookup=lambda ids: list(ids))
+    assert other.calls == 1  # no langdetect in this image: "other"
