@@ -6,6 +6,8 @@
 // (the reference pools float64 arrays) -- at ~10 B/clk/CU of HBM the fp64 adds are <5 % of VALU time
 // -- so the fp16 result is bit-identical to the reference except where the mean sits within 1e-16
 // of a rounding boundary.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace rl {
@@ -159,9 +161,175 @@ static int launch_t(const float* tokens, int32_t dim, const int64_t* sb, const i
     return RL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant for dim = 256 * NV (bge-m3's 1024 = NV 4): the token rows stream HBM -> LDS by `global_load_lds_dwordx4`
+// into a wave-private ring, so the bytes in flight do not live in VGPRs (the register-staged kernel above keeps 64 of its
+// 188 VGPRs for them, runs two waves per SIMD and stops streaming at every 4-row group and at every span boundary:
+// 5.7 TB/s at BASELINE cfg 4).  Here every wave owns 16 KiB of LDS (ring of 16 / NV rows), refills a slot the moment it
+// has read it, and keeps streaming through span boundaries while the previous span is normalised and stored.  No
+// workgroup barrier: a wave only ever waits on its own DMA counter.  Spans are claimed from a device counter, eight at a
+// time at first and fewer towards the end (ragged spans: a static split leaves a ~20 % tail), results do not depend on who takes which span: rows are
+// summed in order in fp64 exactly as above, the mean / norm / cast are the same statements.
+template <int NV>
+__global__ __launch_bounds__(512) void pool_norm_dma_kernel(const float* __restrict__ tokens, const int64_t* __restrict__ span_begin,
+                                                             const int64_t* __restrict__ span_end, int64_t n_spans, int normalize,
+                                                             double eps, float* __restrict__ out_f32, uint16_t* __restrict__ out_f16,
+                                                             unsigned int* __restrict__ counter, int tune) {
+    constexpr int DIM = 256 * NV, ROWB = DIM * 4, RING = 16 / NV >= 8 ? 8 : 16 / NV, BATCH = 8;
+    __shared__ __attribute__((aligned(16))) char smem[8 * RING * ROWB];
+    const int lane = threadIdx.x & 63;
+    const int wv = wave_id();
+    char* const ring = smem + wv * RING * ROWB;
+    const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)ring);
+    const uint32_t lane16 = 16u * lane;
+    const char* const src0 = reinterpret_cast<const char*>(tokens);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int n_queues = gridDim.x < 8 ? (int)gridDim.x : 8;  // one span queue per XCD (fewer on a tiny grid)
+    const int xcd = blockIdx.x % n_queues;
+    const int64_t x_first = (n_spans * xcd) / n_queues, x_count = (n_spans * (xcd + 1)) / n_queues - x_first;  // this queue's spans
+    const int x_waves = (((int)gridDim.x - xcd + n_queues - 1) / n_queues) * 8;                               // waves pulling from it
+    int64_t x_left = x_count;
+    for (;;) {
+        // ---- claim up to BATCH spans; lane i keeps span i's bounds ---------------------------------------------------------
+        // Guided claiming from one counter per XCD (blockIdx % 8 is the XCD; a single word saturates at a few dozen
+        // dequeues per microsecond with 2048 waves pulling): every XCD owns an eighth of the spans; a wave takes BATCH
+        // spans while plenty are left and fewer towards the end (a batch of 8 spans is ~250 rows = 15 % of a wave's
+        // share: the last batches decide the tail).
+        unsigned int base = 0, want = BATCH;
+        if (lane == 0) {
+            const int64_t share = x_left / (int64_t)(x_waves);
+            want = (unsigned int)(share < 1 ? 1 : (share > BATCH ? BATCH : share));
+            if (tune > 0) want = (unsigned int)tune;  // experiment: fixed batch size
+            base = atomicAdd(counter + xcd, want);
+        }
+        base = __builtin_amdgcn_readfirstlane(base);
+        want = __builtin_amdgcn_readfirstlane(want);
+        if ((int64_t)base >= x_count) break;
+        x_left = x_count - (int64_t)base - want;  // what was left after this claim (as far as this wave knows)
+        const int count = (int)std::min<int64_t>(want, x_count - base);
+        base += (unsigned int)x_first;
+        int64_t vb = 0, ve = 0;
+        if (lane < count) { vb = span_begin[base + lane]; ve = span_end[base + lane]; }
+        auto bound = [&](int64_t v, int i) -> int64_t {
+            const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)(uint64_t)v, i), hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)v >> 32), i);
+            return (int64_t)(((uint64_t)hi << 32) | lo);
+        };
+        // ---- fetch cursor: the next row to bring in (skipping empty spans) --------------------------------------------------
+        int fs = 0;
+        int64_t fr = bound(vb, 0), fe = bound(ve, 0);
+        int fetched = 0, consumed = 0;
+        auto fetch_skip = [&]() {
+            while (fr >= fe && fs + 1 < count) { ++fs; fr = bound(vb, fs); fe = bound(ve, fs); }
+        };
+        fetch_skip();
+        auto fetch_row = [&]() {  // one row (NV pieces of 1 KiB) into slot fetched % RING, if any is left in the batch
+            if (fr >= fe) return;
+            const char* src = src0 + fr * (int64_t)ROWB;
+            const uint32_t lds = ring_lds + (uint32_t)((fetched % RING) * ROWB);
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                // (the instruction's immediate offset is added to BOTH the global and the LDS address)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3 nt" ::"s"(lds), "v"(lane16), "s"(src),
+                             "n"(v * 1024)
+                             : "memory", "m0");
+            ++fetched;
+            ++fr;
+            fetch_skip();
+        };
+        for (int i = 0; i < RING; ++i) fetch_row();
+        // ---- consume span after span ----------------------------------------------------------------------------------------------
+        for (int cs = 0; cs < count; ++cs) {
+            const int64_t b = bound(vb, cs), e = bound(ve, cs), sidx = (int64_t)base + cs;
+            double acc[NV][4];
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[v][j] = 0.0;
+            for (int64_t r = b; r < e; ++r) {
+                // VMEM retires in order: row `consumed` has landed when at most the rows fetched after it are outstanding
+                if (fetched - consumed - 1 == RING - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RING - 1) * NV) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const char* slot = ring + (consumed % RING) * ROWB;
+                f4 x[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) x[v] = *reinterpret_cast<const f4*>(slot + v * 1024 + 16 * lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]) : : "memory");  // the slot is read: it may be refilled
+                ++consumed;
+                fetch_row();
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[v][j] += (double)x[v][j];
+            }
+            // ---- mean, L2 norm, cast, store: the statements of pool_norm_kernel (same bits) -----------------------------------------
+            const double n = (double)(e - b);  // n == 0 -> 0/0 = NaN like np.mean of zero rows
+            double ss = 0.0;
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[v][j] = acc[v][j] / n;
+                    ss += acc[v][j] * acc[v][j];
+                }
+            if (normalize) {
+                double norm = sqrt(wave_sum(ss));
+                if (eps > 0.0) norm = fmax(norm, eps);
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[v][j] = acc[v][j] / norm;
+            }
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const int col = (v * 64 + lane) * 4;
+                if (out_f32)
+                    *reinterpret_cast<float4*>(out_f32 + sidx * (int64_t)DIM + col) =
+                        make_float4((float)acc[v][0], (float)acc[v][1], (float)acc[v][2], (float)acc[v][3]);
+                if (out_f16) {
+                    ushort4 h;
+                    h.x = f64_to_f16_bits(acc[v][0]); h.y = f64_to_f16_bits(acc[v][1]);
+                    h.z = f64_to_f16_bits(acc[v][2]); h.w = f64_to_f16_bits(acc[v][3]);
+                    *reinterpret_cast<ushort4*>(out_f16 + sidx * (int64_t)DIM + col) = h;
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of this batch is in flight when the next one starts
+    }
+}
+
+namespace {
+// One zeroed 4-byte span counter per launch, from a small per-thread pool of device words (a launch may still be running
+// when the same host thread enqueues the next one on another stream).
+unsigned int* next_span_counter(hipStream_t s) {
+    constexpr int SLOTS = 64 * 8;  // 8 words (one per XCD) per launch
+    static thread_local unsigned int* pool = nullptr;
+    static thread_local int at = 0;
+    if (!pool && hipMalloc(&pool, SLOTS * sizeof(unsigned int)) != hipSuccess) { pool = nullptr; (void)hipGetLastError(); return nullptr; }
+    unsigned int* c = pool + 8 * (at++ % (SLOTS / 8));
+    if (hipMemsetAsync(c, 0, 8 * sizeof(unsigned int), s) != hipSuccess) return nullptr;
+    return c;
+}
+}  // namespace
+
 int launch_pool_norm(const float* tokens, int32_t dim, const int64_t* sb, const int64_t* se, int64_t n_spans,
                      int normalize, double eps, float* o32, uint16_t* o16, hipStream_t s) {
     if (n_spans <= 0) return RL_OK;
+    // dim = 256 * NV with fp32-vector-aligned buffers: the LDS-DMA stream (RAGLITE_POOL_VGPR=1 keeps the register-staged kernel)
+    static const bool vgpr_only = std::getenv("RAGLITE_POOL_VGPR") != nullptr;
+    if (!vgpr_only && (dim == 256 || dim == 512 || dim == 1024) && n_spans >= 64 && (reinterpret_cast<uintptr_t>(tokens) & 15) == 0 &&
+        (!o32 || (reinterpret_cast<uintptr_t>(o32) & 15) == 0) && (!o16 || (reinterpret_cast<uintptr_t>(o16) & 7) == 0)) {
+        if (unsigned int* counter = next_span_counter(s)) {
+            int n_cu = 256, dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
+            const int blocks = (int)std::min<int64_t>(n_cu, (n_spans + 63) / 64);
+            static const int tune = std::getenv("RAGLITE_POOL_BATCH") ? std::atoi(std::getenv("RAGLITE_POOL_BATCH")) : 0;
+#define RL_POOL_DMA(NV) hipLaunchKernelGGL((pool_norm_dma_kernel<NV>), dim3(blocks), dim3(512), 0, s, tokens, sb, se, n_spans, normalize, eps, o32, o16, counter, tune)
+            if (dim == 256) RL_POOL_DMA(1); else if (dim == 512) RL_POOL_DMA(2); else RL_POOL_DMA(4);
+#undef RL_POOL_DMA
+            RL_HIP(hipGetLastError());
+            return RL_OK;
+        }
+    }
     const bool vec4 = (dim % 4 == 0) && ((reinterpret_cast<uintptr_t>(tokens) & 15) == 0) &&
                       (!o32 || (reinterpret_cast<uintptr_t>(o32) & 15) == 0) &&
                       (!o16 || (reinterpret_cast<uintptr_t>(o16) & 7) == 0);
