@@ -170,13 +170,17 @@ static int launch_t(const float* tokens, int32_t dim, const int64_t* sb, const i
 // workgroup barrier: a wave only ever waits on its own DMA counter.  Spans are claimed from a device counter, eight at a
 // time at first and fewer towards the end (ragged spans: a static split leaves a ~20 % tail), results do not depend on who takes which span: rows are
 // summed in order in fp64 exactly as above, the mean / norm / cast are the same statements.
-template <int NV>
-__global__ __launch_bounds__(512) void pool_norm_dma_kernel(const float* __restrict__ tokens, const int64_t* __restrict__ span_begin,
+// Measured at BASELINE cfg 4 (3.2 M x 1024 rows, same box A/B): 2.24 ms against 2.36 ms for the register-staged kernel.
+// What did NOT matter (profiles/r02_pool_experiments.txt): ring depth 3 / 4 / 5 rows per wave, 8 / 4 / 2 waves per CU at equal
+// bytes in flight, dropping the fp64 accumulation altogether (same time: the kernel is bound by what the memory system
+// delivers to 4-KiB-granular streams, ~6.0 TB/s, not by the waves); dropping `nt` costs 10 %.
+template <int NV, int RING_ = 0, bool NT = true, int WAVES = 8>
+__global__ __launch_bounds__(64 * WAVES) void pool_norm_dma_kernel(const float* __restrict__ tokens, const int64_t* __restrict__ span_begin,
                                                              const int64_t* __restrict__ span_end, int64_t n_spans, int normalize,
                                                              double eps, float* __restrict__ out_f32, uint16_t* __restrict__ out_f16,
                                                              unsigned int* __restrict__ counter, int tune) {
-    constexpr int DIM = 256 * NV, ROWB = DIM * 4, RING = 16 / NV >= 8 ? 8 : 16 / NV, BATCH = 8;
-    __shared__ __attribute__((aligned(16))) char smem[8 * RING * ROWB];
+    constexpr int DIM = 256 * NV, ROWB = DIM * 4, RING = RING_ > 0 ? RING_ : (16 / NV >= 8 ? 8 : 16 / NV), BATCH = 8;
+    __shared__ __attribute__((aligned(16))) char smem[WAVES * RING * ROWB];
     const int lane = threadIdx.x & 63;
     const int wv = wave_id();
     char* const ring = smem + wv * RING * ROWB;
@@ -187,7 +191,7 @@ __global__ __launch_bounds__(512) void pool_norm_dma_kernel(const float* __restr
     const int n_queues = gridDim.x < 8 ? (int)gridDim.x : 8;  // one span queue per XCD (fewer on a tiny grid)
     const int xcd = blockIdx.x % n_queues;
     const int64_t x_first = (n_spans * xcd) / n_queues, x_count = (n_spans * (xcd + 1)) / n_queues - x_first;  // this queue's spans
-    const int x_waves = (((int)gridDim.x - xcd + n_queues - 1) / n_queues) * 8;                               // waves pulling from it
+    const int x_waves = (((int)gridDim.x - xcd + n_queues - 1) / n_queues) * WAVES;                               // waves pulling from it
     int64_t x_left = x_count;
     for (;;) {
         // ---- claim up to BATCH spans; lane i keeps span i's bounds ---------------------------------------------------------
@@ -229,9 +233,14 @@ __global__ __launch_bounds__(512) void pool_norm_dma_kernel(const float* __restr
 #pragma unroll
             for (int v = 0; v < NV; ++v)
                 // (the instruction's immediate offset is added to BOTH the global and the LDS address)
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3 nt" ::"s"(lds), "v"(lane16), "s"(src),
-                             "n"(v * 1024)
-                             : "memory", "m0");
+                if constexpr (NT)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3 nt" ::"s"(lds), "v"(lane16), "s"(src),
+                                 "n"(v * 1024)
+                                 : "memory", "m0");
+                else
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3" ::"s"(lds), "v"(lane16), "s"(src),
+                                 "n"(v * 1024)
+                                 : "memory", "m0");
             ++fetched;
             ++fr;
             fetch_skip();
@@ -256,6 +265,11 @@ __global__ __launch_bounds__(512) void pool_norm_dma_kernel(const float* __restr
                 asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]) : : "memory");  // the slot is read: it may be refilled
                 ++consumed;
                 fetch_row();
+                if (tune == -1) {  // experiment: the memory side alone (one add per piece keeps the reads alive)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) acc[v][0] += (double)x[v][0];
+                    continue;
+                }
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
