@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 run() { # name, counters...
   local name=$1; shift
-  ( cd /tmp && env $ENVV timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -o bench -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$OUT/pmc_$name.err" )
+  ( cd /tmp && env $ENVV timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$OUT/pmc_$name" -o bench -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-configs > /dev/null 2> "$OUT/pmc_$name.err" )
   echo "pmc $name exit $?"
 }
 run sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
