@@ -234,6 +234,7 @@ struct rl_index {
     // the "last row of its chunk" bitmap; built with the index, extended on append, rebuilt when split_scale changes.
     rl::Pool planes, ends, qplanes;
     rl::Pool cand;                        // rl_maxsim_rerank: sanitised candidate ordinals
+    rl::Pool fused;                       // fused batched top-k: sample scores, thresholds, candidate lists, counters
     // The scratch above is shared by all calls on this handle; `mu` serialises only their host side.  Device-mode calls are
     // asynchronous, so a call arriving on a DIFFERENT stream than the previous one first waits for that stream.
     hipStream_t last_stream = nullptr;
@@ -491,6 +492,7 @@ int rl_index_destroy(rl_index* idx) {
     idx->ends.release();
     idx->qplanes.release();
     idx->cand.release();
+    idx->fused.release();
     select_workspace_free(idx->ws);
     idx->scores.release();
     idx->hits.release();
@@ -934,6 +936,64 @@ int effective_row_mask(rl_index* idx, const uint32_t* d_chunk_filter, hipStream_
     return RL_OK;
 }
 
+// Exact row top-k of a big batch WITHOUT the [B x N] score matrix (BASELINE cfg 5: 1000 queries x 1.25 M rows would write and
+// re-read 5 GB twice).  (1) the row-score GEMM over every stride-th 256-row tile of the pre-split image -> a small score
+// matrix -> its exact top-k: the k-th best of a subset is a LOWER bound of the k-th best overall, so (2) a second GEMM pass
+// over all rows only has to keep the scores that reach their query's bound -- ~k * stride per query, appended to
+// per-query candidate lists from the epilogue (maxsim_gemm.hip MODE 2) -- and (3) rl_merge_topk's kernel ranks each list
+// exactly, ties to the lowest row.  Same results as the dense path bit for bit (the kept scores are computed by the same
+// statements).  A list that overflows (massive ties, an unlucky sample) or an unusable bound sets a device flag, on which
+// (4) the dense GEMM + selection run as a guarded fallback -- launched always, returning at once when the flag is clear, so
+// nothing here synchronises with the host.  cosine / dot, k <= 512, no row mask; RL_ERR_UNSUPPORTED otherwise.
+int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, float* d_scores, int32_t* d_rows, int64_t ld,
+                      hipStream_t s) {
+    // read per call (two getenv's against a multi-millisecond batch) so that a test can flip them inside one process
+    const char* off_env = std::getenv("RAGLITE_NO_FUSED_TOPK");                        // A/B switch
+    const bool off = off_env && off_env[0] && off_env[0] != '0';
+    const char* cap_str = std::getenv("RAGLITE_FUSED_TOPK_CAP");                       // tests: force list overflows
+    const int cap_env = cap_str ? std::atoi(cap_str) : 0;
+    const int mode = scan_mode(idx->metric);
+    if (off || B < GEMM_MIN_QUERIES || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT)) return RL_ERR_UNSUPPORTED;
+    if (!(idx->planes_scale > 0.f) || idx->planes_scale != idx->split_scale || idx->planes_rows != idx->n_rows) return RL_ERR_UNSUPPORTED;
+    const int64_t n = idx->n_rows, T = (n + 255) / 256;
+    const int32_t cap = cap_env > 0 ? std::min(cap_env, MERGE_CAP) : MERGE_CAP;
+    const int32_t stride = (int32_t)std::min<int64_t>(MERGE_CAP / (3 * (int64_t)k), T / 8);  // ~k * stride candidates per query, a third of the list
+    if (stride < 2) return RL_ERR_UNSUPPORTED;
+    const int64_t Tv = (T + stride - 1) / stride, ld_s = Tv * 256;
+    if (ld_s < k) return RL_ERR_UNSUPPORTED;
+    // ---- scratch ------------------------------------------------------------------------------------------------------------
+    RL_TRY(idx->misc.reserve(score_planes_scratch_floats(B, idx->dim) * sizeof(float)));
+    const size_t n_sample = (size_t)B * ld_s, n_top = (size_t)B * k, n_cand = (size_t)B * cap;
+    RL_TRY(idx->fused.reserve((n_sample + 2 * n_top + 2 * n_cand + (size_t)B + 16) * 4));
+    float* S_s = idx->fused.as<float>();
+    float* top_s = S_s + n_sample;
+    int32_t* top_i = reinterpret_cast<int32_t*>(top_s + n_top);
+    float* c_s = reinterpret_cast<float*>(top_i + n_top);
+    int32_t* c_i = reinterpret_cast<int32_t*>(c_s + n_cand);
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(c_i + n_cand);
+    uint32_t* flag = cnt + B;
+    float* qs = idx->misc.as<float>();
+    float* sc = idx->scores.as<float>();  // [B x ld], reserved by the caller: only the fallback touches it
+    // ---- (1) sample pass + its exact top-k --------------------------------------------------------------------------------------
+    RL_TRY(launch_score_planes_queries(d_q, B, idx->dim, qs, mode, s));
+    RL_TRY(launch_fill_f32(S_s, -std::numeric_limits<float>::infinity(), (int64_t)n_sample, s));  // rows past the corpus in the last tile
+    RL_TRY(launch_score_planes_pass(idx->planes.p, n, idx->dim, B, qs, S_s, ld_s, idx->norm, idx->sumsq, mode, stride, nullptr, nullptr,
+                                    idx->n_cu, s, idx->split_scale));
+    RL_TRY(launch_topk(S_s, B, ld_s, ld_s, k, idx->ws, top_s, top_i, s));
+    // ---- (2) full pass keeping what reaches the bound ---------------------------------------------------------------------------
+    RL_HIP(hipMemsetAsync(cnt, 0, ((size_t)B + 1) * sizeof(uint32_t), s));  // list lengths + the overflow flag; the lists need no fill
+    const CandArgs ca{top_s + (k - 1), k, c_s, c_i, cnt, flag, cap};
+    RL_TRY(launch_score_planes_pass(idx->planes.p, n, idx->dim, B, qs, nullptr, 0, idx->norm, idx->sumsq, mode, 1, nullptr, &ca, idx->n_cu, s,
+                                    idx->split_scale));
+    // ---- (3) exact ranking of every list ------------------------------------------------------------------------------------------
+    RL_TRY(launch_merge_topk(c_s, c_i, 1, B, cap, k, d_scores, d_rows, s, cnt));
+    // ---- (4) guarded dense fallback -----------------------------------------------------------------------------------------------
+    RL_TRY(launch_score_planes_pass(idx->planes.p, n, idx->dim, B, qs, sc, ld, idx->norm, idx->sumsq, mode, 1, flag, nullptr, idx->n_cu, s,
+                                    idx->split_scale));
+    RL_TRY(launch_topk(sc, B, n, ld, k, idx->ws, d_scores, d_rows, s, flag));
+    return RL_OK;
+}
+
 int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, float* d_scores, int32_t* d_rows,
                        hipStream_t s, const uint32_t* d_row_bits = nullptr) {
     const int64_t n = idx->n_rows;
@@ -948,6 +1008,11 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
     RL_TRY(idx->scores.reserve((size_t)batch * ld * sizeof(float)));
     for (int32_t b0 = 0; b0 < B; b0 += batch) {
         const int32_t nb = std::min<int32_t>(batch, B - b0);
+        if (!d_row_bits) {  // big batches over the pre-split image: no score matrix at all
+            const int st = search_rows_fused(idx, d_q + (int64_t)b0 * idx->dim, nb, k, d_scores + (int64_t)b0 * k, d_rows + (int64_t)b0 * k, ld, s);
+            if (st == RL_OK) continue;
+            if (st != RL_ERR_UNSUPPORTED) return st;
+        }
         RL_TRY(score_rows(idx, d_q + (int64_t)b0 * idx->dim, nb, ld, s));
         if (d_row_bits) RL_TRY(launch_mask_scores(idx->scores.as<float>(), nb, n, ld, d_row_bits, s));
         float* o_s = d_scores + (int64_t)b0 * k;

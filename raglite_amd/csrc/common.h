@@ -119,13 +119,15 @@ struct SelectWorkspace {      // device buffers sized for `capacity_queries`
 };
 int select_workspace_reserve(SelectWorkspace& ws, int32_t n_queries);
 void select_workspace_free(SelectWorkspace& ws);
+// run_if != nullptr: the three kernels return at once unless *run_if != 0 (the guarded dense fallback of the fused top-k)
 int launch_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32_t k,
-                SelectWorkspace& ws, float* out_scores, int32_t* out_ids, hipStream_t s);
+                SelectWorkspace& ws, float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* run_if = nullptr);
 int launch_group_chunk_max(const float* hit_scores, const int32_t* hit_rows, int32_t n_queries,
                            int32_t num_hits, const int64_t* chunk_offsets, int64_t n_chunks, int32_t k,
                            float* out_scores, int32_t* out_chunks, int32_t* out_counts, hipStream_t s);
 int launch_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_lists, int32_t n_queries,
-                      int32_t k_in, int32_t k, float* out_scores, int32_t* out_ids, hipStream_t s);
+                      int32_t k_in, int32_t k, float* out_scores, int32_t* out_ids, hipStream_t s,
+                      const uint32_t* counts = nullptr);  // counts (n_lists == 1): records list q really holds
 
 // mask.hip: validity bitsets (metadata filter pushed down to the device, tombstones of deleted chunks)
 int launch_expand_chunk_bits(const uint32_t* chunk_bits, const int32_t* row_to_chunk, int64_t n_rows,
@@ -180,6 +182,11 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
 size_t score_planes_scratch_floats(int32_t nb, int32_t dim);
 int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores, int64_t ld,
                         const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale);
+struct CandArgs { const float* tau; int32_t tau_stride; float* scores; int32_t* ids; uint32_t* cnt; uint32_t* overflow; int32_t cap; };
+int launch_score_planes_queries(const float* Q, int32_t nb, int32_t dim, float* scratch, int mode, hipStream_t s);
+int launch_score_planes_pass(const void* planes, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, float* scores, int64_t ld,
+                             const float* row_norm, const float* row_sumsq, int mode, int32_t tile_stride, const uint32_t* run_if,
+                             const CandArgs* cand, int n_cu, hipStream_t s, float split_scale);
 // [largest |element|, smallest non-zero row maximum, non-finite flag] of an fp32 corpus, as uint32 bit patterns (device, 3 words)
 int launch_row_range(const float* E, int64_t n_rows, int32_t dim, uint32_t* range, hipStream_t s);
 // Any dim / nq: one wave per chunk (or per candidate), VALU dot products.

@@ -234,6 +234,15 @@ struct RowScoreArgs {
     const float* q_unscale;               // per query: 2^(ex - 14), undoes its scale
     const float* q_anylo;                 // per group of 32 queries: any lo half != 0
     int32_t B, QT, metric;                // queries, query tiles of 256 per row tile, SCAN_* mode
+    int32_t tile_stride;                  // only every tile_stride-th 256-row tile is scored (1 = all; > 1: the sample pass)
+    int32_t compact;                      // MODE 1 with a stride: column of S = sampled tile ordinal * 256 + row in tile
+    const uint32_t* run_if;               // the kernel returns at once unless *run_if != 0 (nullptr: always runs)
+    // MODE 2 (fused exact top-k, no score matrix): rows whose similarity reaches tau[q] are appended to per-query lists
+    const float* tau; int32_t tau_stride; // threshold of query q: tau[q * tau_stride]
+    float* cand_scores; int32_t* cand_ids;  // [B x cap], pre-filled with (-inf, -1)
+    uint32_t* cand_cnt;                   // [B] zeroed
+    uint32_t* overflow;                   // set when a list overflows or a threshold is unusable: the caller's dense path then runs
+    int32_t cap;
 };
 
 template <int NQB, bool TRACE = false, int MODE = 0>
@@ -246,7 +255,10 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
                                                                RowScoreArgs rs) {
     // TRACE (diagnostic build, RAGLITE_GEMM_TRACE=1): s_memtime stamps of workgroup 7, slabs 128..143, kept in
     // LDS and copied out at the end: [slab - 128][wave][stamp 0..15] (3 + p = after pair p of the slab).
-    __shared__ __attribute__((aligned(16))) char smem[MG_NSLOT * MG_SLAB + (TRACE ? 16 * 8 * 16 * 8 : 0)];
+    __shared__ __attribute__((aligned(16))) char smem[MG_NSLOT * MG_SLAB + (TRACE ? 16 * 8 * 16 * 8 : 0) + (MODE == 2 ? MG_WAVES * 4096 : 0)];
+    if constexpr (MODE != 0) {
+        if (rs.run_if && __builtin_amdgcn_readfirstlane((int)*rs.run_if) == 0) return;  // whole grid: the guarded fallback is not needed
+    }
     auto stamp = [&](int g, int k) {
         if constexpr (TRACE) {
             if (blockIdx.x == 7 && g >= 128 && g < 144 && (threadIdx.x & 63) == 0)
@@ -268,19 +280,23 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
         const int64_t c0 = chunk_offsets[c], c1 = chunk_offsets[c + 1];
         return c0 == t ? t : c1;
     };
-    int32_t r_lo, r_hi;
+    int32_t r_lo = 0, r_hi = 0, vt0 = 0, vt1 = 0;
+    const int32_t stride = MODE == 0 ? 1 : rs.tile_stride;
     if constexpr (MODE == 0) {
         r_lo = (int32_t)mg_uniform_i64(boundary((n_rows * b) / G));
         r_hi = (int32_t)mg_uniform_i64((b + 1 == G) ? n_rows : boundary((n_rows * (b + 1)) / G));
-    } else {  // whole 256-row tiles, no chunk structure
-        const int64_t T = (n_rows + MG_TM - 1) / MG_TM;
-        r_lo = (int32_t)(((T * b) / G) * MG_TM);
-        r_hi = (int32_t)std::min<int64_t>(((T * (b + 1)) / G) * MG_TM, n_rows);
+        if (r_hi <= r_lo) return;  // whole workgroup
+    } else {  // whole 256-row tiles, no chunk structure; with a stride only the tiles 0, stride, 2 stride, ...
+        const int64_t T = (n_rows + MG_TM - 1) / MG_TM, Tv = (T + stride - 1) / stride;
+        vt0 = (int32_t)((Tv * b) / G);
+        vt1 = (int32_t)((Tv * (b + 1)) / G);
+        if (vt1 <= vt0) return;  // whole workgroup
+        r_hi = (int32_t)n_rows;
     }
-    if (r_hi <= r_lo) return;  // whole workgroup
-    const int32_t org = r_lo & ~15;                       // tiles start on a 16-row block of the image
+    const int32_t org = r_lo & ~15;                       // MODE 0: tiles start on a 16-row block of the image
     const int QT = MODE == 0 ? 1 : rs.QT;                 // query tiles per row tile
-    const int nt = ((r_hi - org + MG_TM - 1) / MG_TM) * QT;   // (row tile, query tile) pairs, query tile fastest
+    const int nt = MODE == 0 ? (r_hi - org + MG_TM - 1) / MG_TM : (vt1 - vt0) * QT;  // (row tile, query tile) pairs, query tile fastest
+    auto tile_row0 = [&](int t) -> int32_t { return MODE == 0 ? org + t * MG_TM : (vt0 + t / QT) * stride * MG_TM; };
     const int total = nt * nslab;                         // K slabs this workgroup consumes, tile after tile
     const int32_t last_blk = (int32_t)((n_rows + 15) >> 4) - 1;
     // MODE 0: wave = query wv of the pass.  MODE 1: wave = group (tile % QT) * 8 + wv of 32 queries; n_q counts the groups.
@@ -300,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     int f_tile = 0, f_s = 0, f_slot = 0;   // position of the NEXT slab to fetch
     const char* f_base[4];                 // block bases of the tile being fetched
     auto feed_tile = [&](int t) __attribute__((always_inline)) {
-        const int32_t b0 = (org >> 4) + (t / QT) * MG_NBLK + 4 * (wv & 3);
+        const int32_t b0 = (tile_row0(t) >> 4) + 4 * (wv & 3);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int32_t blk = b0 + i;
@@ -345,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     auto q_advance = [&]() __attribute__((always_inline)) {
         if (++q_s == nslab) {
             q_s = 0;
-            if constexpr (MODE == 1) { q_tile = q_tile + 1 < nt ? q_tile + 1 : q_tile; qbase = qbase_of(q_tile); }
+            if constexpr (MODE != 0) { q_tile = q_tile + 1 < nt ? q_tile + 1 : q_tile; qbase = qbase_of(q_tile); }
         }
     };
     auto load_q = [&](f32x4 (&q)[4]) __attribute__((always_inline)) {
@@ -395,7 +411,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
         Feed f{};
         if (feeder) f = next_feed();
         const int next_slot = c_slot + 1 == MG_NSLOT ? 0 : c_slot + 1;
-        if (has_q || MODE == 1) {
+        if (has_q || MODE != 0) {
             // The next slab's query fragments: ONE load after each of the first four pairs.  (All four at the top of the slab
             // stalled both waves of every SIMD for ~500 cycles while the matrix pipe idled: a VMEM instruction costs its wave
             // 60-185 cycles of issue, profiles/r02_e_trace.txt.)
@@ -450,7 +466,8 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
 
     // ---- tile epilogue: per-chunk maxima along the DPP rows, sum over the query vectors, store ---------------------------
     auto epilogue_rows = [&](int t) __attribute__((always_inline)) {  // MODE 1: metric + store of the tile's 32 x 256 scores
-        const int32_t row0 = org + (t / QT) * MG_TM;
+        const int32_t row0 = tile_row0(t);
+        const int64_t col0 = rs.compact ? (int64_t)(vt0 + t / QT) * MG_TM - row0 : 0;  // column of S = col0 + row
         if (!has_q) return;
         const int g = lane >> 4;
         const int32_t q0 = group_of(t) * 32 + 4 * g;
@@ -481,11 +498,98 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
                     if (mode == SCAN_COSINE) v = 1.0f - (1.0f - d / (rn * qn[r]));
                     else if (mode == SCAN_DOT) v = 1.0f + d;
                     else if (mode == SCAN_L2) v = 1.0f - sqrtf(fmaxf(rn + qss[r] - 2.0f * d, 0.f));
-                    if (q < rs.B && row < (int32_t)n_rows) rs.S[(int64_t)q * rs.ld + row] = v;
+                    if (q < rs.B && row < (int32_t)n_rows) rs.S[(int64_t)q * rs.ld + col0 + row] = v;
                 }
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb) acc[qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+    };
+    // MODE 2: no score matrix.  A score that reaches its query's threshold (the k-th best of a row sample: a lower bound of
+    // the k-th best overall, so every row of the exact top-k passes) is kept as a record in a wave-private LDS list and
+    // appended to the query's candidate list when the tile is done; everything else is dropped after one compare.  The cosine
+    // test uses reciprocals (2 VALU instead of an IEEE divide) against a threshold lowered by 1e-5; the exact similarity --
+    // the formulas of MODE 1, same bits -- is computed for the few records only.
+    [[maybe_unused]] int ncand = 0;  // wave-uniform
+    [[maybe_unused]] float* const rec_d = reinterpret_cast<float*>(smem + MG_NSLOT * MG_SLAB + (TRACE ? 16 * 8 * 16 * 8 : 0) + wv * 4096);
+    [[maybe_unused]] uint32_t* const rec_m = reinterpret_cast<uint32_t*>(rec_d + 512);
+    constexpr int REC_CAP = 512;  // records a wave keeps per tile (expected: a few dozen); more -> the guarded dense fallback
+    auto flush_candidates = [&](int t) __attribute__((always_inline)) {
+        const int32_t row0 = tile_row0(t);
+        const int mode = rs.metric;
+        for (int i = lane; i < ncand; i += 64) {
+            const uint32_t m = rec_m[i];
+            const int32_t q = group_of(t) * 32 + (int32_t)(m >> 8), row = row0 + (int32_t)(m & 255u);
+            const float d = rec_d[i] * (rs.q_unscale[q] * inv_e_scale);  // the dot product, as MODE 1 forms it
+            float v = d;
+            if (mode == SCAN_COSINE) v = 1.0f - (1.0f - d / (rs.row_norm[row] * sqrtf(rs.q_sumsq[q])));
+            else if (mode == SCAN_DOT) v = 1.0f + d;
+            const uint32_t slot = atomicAdd(rs.cand_cnt + q, 1u);
+            if (slot < (uint32_t)rs.cap) {
+                rs.cand_scores[(int64_t)q * rs.cap + slot] = v;
+                rs.cand_ids[(int64_t)q * rs.cap + slot] = row;
+            } else {
+                *rs.overflow = 1u;
+            }
+        }
+        ncand = 0;
+    };
+    auto epilogue_cand = [&](int t) __attribute__((always_inline)) {
+        if (!has_q) return;
+        const int32_t row0 = tile_row0(t);
+        // Opaque copies of the lane coordinates: with the plain values every record word below (128 of them) is loop-invariant,
+        // the compiler hoists all of them out of the K loop and spills them -- and a scratch reload anywhere in the loop makes
+        // its waitcnt pass put s_waitcnt vmcnt(0) into the slab code, which drains the look-ahead DMAs three times per two slabs.
+        int g = lane >> 4, fj = lane & 15;
+        asm volatile("" : "+v"(g), "+v"(fj));
+        const int32_t q0 = group_of(t) * 32 + 4 * g;
+        const bool cosine = rs.metric == SCAN_COSINE;
+        // One threshold per accumulator register, on the RAW accumulator (times 1 / |e| for cosine): a lower bound of what
+        // the exact formula needs -- 1e-5 of slack covers the reciprocals and the two roundings of 1 - (1 - c) -- so the test
+        // costs one multiply and one compare, and a record that passes is re-evaluated exactly at the flush.
+        float thr[NQB * 4];
+        bool bad = false;
+#pragma unroll
+        for (int r = 0; r < NQB * 4; ++r) {
+            const int32_t q = q0 + 16 * (r >> 2) + (r & 3);
+            const int32_t qc = q < rs.B ? q : rs.B - 1;
+            const float us = rs.q_unscale[qc] * inv_e_scale;  // > 0
+            const float tq = rs.tau[(int64_t)qc * rs.tau_stride];
+            bad |= !(tq > -INFINITY);  // NaN or -inf: fewer than k usable sample scores
+            const float slack = 1e-5f * fmaxf(1.0f, fabsf(tq));
+            const float t_dot = cosine ? (tq - slack) * sqrtf(rs.q_sumsq[qc]) : (tq - 1.0f) - slack;  // bound on d (cosine: on d / |e|)
+            thr[r] = q < rs.B ? (t_dot - fabsf(t_dot) * 1e-6f) / us : INFINITY;
+        }
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *rs.overflow = 1u;
+#pragma unroll
+        for (int a = 0; a < MG_NBLK; ++a) {
+            const int32_t row = row0 + 16 * a + fj;
+            const bool row_ok = row < (int32_t)n_rows;
+            const float rscale = cosine ? __builtin_amdgcn_rcpf(rs.row_norm[row_ok ? row : (int32_t)n_rows - 1]) : 1.0f;
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = 4 * qb + u;
+                    const bool pass = row_ok && acc[qb][a][u] * rscale >= thr[r];
+                    const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
+                    if (mask != 0ull) {  // wave-uniform, rare
+                        const int pos = ncand + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                        if (pass && pos < REC_CAP) {
+                            rec_d[pos] = acc[qb][a][u];
+                            rec_m[pos] = ((uint32_t)(16 * qb + 4 * g + u) << 8) | (uint32_t)(16 * a + fj);
+                        }
+                        ncand += __builtin_popcountll(mask);
+                    }
+                }
+#pragma unroll
+            for (int qb = 0; qb < NQB; ++qb) acc[qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_sched_barrier(0);  // one block at a time: hoisting the 16 norm loads costs registers this kernel does not have
+        }
+        if (ncand > REC_CAP) {  // (wave-uniform) more than the wave can hold: let the dense path decide
+            if (lane == 0) *rs.overflow = 1u;
+            ncand = REC_CAP;
+        }
+        if (ncand > 0) flush_candidates(t);
     };
     auto epilogue = [&](int t) __attribute__((always_inline)) {
         const int32_t row0 = org + t * MG_TM;
@@ -557,13 +661,13 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     f32x4 qa[4], qb_[4];
     {   // prologue: DMA(0), DMA(1), Q(0), DMA(2); slab 0 must have landed for everybody before its first pair is read
         if (feeder) { const Feed f0 = next_feed(); dma_all(f0); const Feed f1 = next_feed(); dma_all(f1); }
-        if (has_q || MODE == 1) load_q(qa);
+        if (has_q || MODE != 0) load_q(qa);
         if (feeder) { const Feed f2 = next_feed(); dma_all(f2); asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (has_q || MODE == 1) read_pair(0, 0, eh[0], el[0]);
+        if (has_q || MODE != 0) read_pair(0, 0, eh[0], el[0]);
     }
     auto tile_nb = [&](int t) {
-        const int32_t left = r_hi - (org + (t / QT) * MG_TM);
+        const int32_t left = r_hi - tile_row0(t);
         const int nb = (left + 15) >> 4;
         return nb < MG_NBLK ? nb : MG_NBLK;
     };
@@ -571,11 +675,12 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     auto advance = [&]() __attribute__((always_inline)) {
         if (++c_s == nslab) {
             if constexpr (MODE == 0) epilogue(c_tile);
-            else epilogue_rows(c_tile);
+            else if constexpr (MODE == 1) epilogue_rows(c_tile);
+            else epilogue_cand(c_tile);
             c_s = 0;
             ++c_tile;
             nb = tile_nb(c_tile);
-            if constexpr (MODE == 1) {  // the next tile's group of queries
+            if constexpr (MODE != 0) {  // the next tile's group of queries
                 has_q = group_of(c_tile) < n_q;
                 any_lo = any_lo_of(c_tile);
             }
@@ -731,29 +836,64 @@ size_t score_planes_scratch_floats(int32_t nb, int32_t dim) {
 
 int launch_query_sumsq(const float* Q, int32_t nb, int32_t dim, float* out, hipStream_t s);  // score_gemm.hip
 
-// Similarity (metric `mode`, scan.hip conventions) of nb queries against every row over the pre-split corpus image:
-// scores[q * ld + row].  Same results as launch_score_gemm in split arithmetic up to the summation order over K.
-int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores, int64_t ld,
-                        const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale) {
-    if (nb < 1 || n_rows < 1 || dim % 32 || dim < 32 || !(split_scale > 0.f) || !planes) return RL_ERR_UNSUPPORTED;
+// Query side of the row-score modes: fragments, per-query unscale, per-group lo flags, |q|^2 -> `scratch`
+// (score_planes_scratch_floats floats, 16-B aligned).
+int launch_score_planes_queries(const float* Q, int32_t nb, int32_t dim, float* scratch, int mode, hipStream_t s) {
+    if (nb < 1 || dim % 32 || dim < 32) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(Q) & 15) || (reinterpret_cast<uintptr_t>(scratch) & 15)) return RL_ERR_UNSUPPORTED;
-    if ((mode == SCAN_COSINE && !row_norm) || (mode == SCAN_L2 && !row_sumsq)) return RL_ERR_INVALID;
-    const int32_t nslab = dim / 32, groups = (nb + 31) / 32;
+    const int32_t groups = (nb + 31) / 32;
     float* frag = scratch;
     float* unscale = frag + (size_t)groups * 32 * dim;
     float* anylo = unscale + nb;
     float* qss = anylo + groups;
     hipLaunchKernelGGL(query_rows_planes_kernel, dim3((unsigned)groups), dim3(256), 0, s, Q, (int)nb, (int)dim, reinterpret_cast<uint4*>(frag), unscale,
                        anylo);
+    RL_HIP(hipGetLastError());
     if (mode == SCAN_COSINE || mode == SCAN_L2) RL_TRY(launch_query_sumsq(Q, nb, dim, qss, s));
-    RowScoreArgs rs{scores, ld, mode == SCAN_COSINE ? row_norm : row_sumsq, qss, unscale, anylo, nb, (groups + MG_WAVES - 1) / MG_WAVES, mode};
-    const int64_t tiles = (n_rows + MG_TM - 1) / MG_TM;
+    return RL_OK;
+}
+
+// One pass of the row-score GEMM over the pre-split corpus image with the query side prepared by
+// launch_score_planes_queries.  Dense (cand == nullptr): scores[q * ld + row] (or + sampled-tile column with
+// tile_stride > 1).  Fused top-k (cand != nullptr): candidate lists, see RowScoreArgs.
+int launch_score_planes_pass(const void* planes, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, float* scores, int64_t ld,
+                             const float* row_norm, const float* row_sumsq, int mode, int32_t tile_stride, const uint32_t* run_if,
+                             const CandArgs* cand, int n_cu, hipStream_t s, float split_scale) {
+    if (nb < 1 || n_rows < 1 || dim % 32 || dim < 32 || !(split_scale > 0.f) || !planes || tile_stride < 1) return RL_ERR_UNSUPPORTED;
+    if ((mode == SCAN_COSINE && !row_norm) || (mode == SCAN_L2 && !row_sumsq)) return RL_ERR_INVALID;
+    const int32_t nslab = dim / 32, groups = (nb + 31) / 32;
+    float* frag = scratch;
+    float* unscale = frag + (size_t)groups * 32 * dim;
+    float* anylo = unscale + nb;
+    float* qss = anylo + groups;
+    RowScoreArgs rs{};
+    rs.S = scores; rs.ld = ld; rs.row_norm = mode == SCAN_COSINE ? row_norm : row_sumsq; rs.q_sumsq = qss; rs.q_unscale = unscale;
+    rs.q_anylo = anylo; rs.B = nb; rs.QT = (groups + MG_WAVES - 1) / MG_WAVES; rs.metric = mode; rs.tile_stride = tile_stride;
+    rs.compact = tile_stride > 1 ? 1 : 0; rs.run_if = run_if;
+    if (cand) { rs.tau = cand->tau; rs.tau_stride = cand->tau_stride; rs.cand_scores = cand->scores; rs.cand_ids = cand->ids; rs.cand_cnt = cand->cnt;
+                rs.overflow = cand->overflow; rs.cap = cand->cap; }
+    const int64_t tiles = ((n_rows + MG_TM - 1) / MG_TM + tile_stride - 1) / tile_stride;
     const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
-    hipLaunchKernelGGL((maxsim_gemm_kernel<2, false, 1>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab,
-                       reinterpret_cast<const char*>(frag), nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, 0,
-                       nullptr, rs);
+    if (cand)
+        hipLaunchKernelGGL((maxsim_gemm_kernel<2, false, 2>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab,
+                           reinterpret_cast<const char*>(frag), nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, 0,
+                           nullptr, rs);
+    else
+        hipLaunchKernelGGL((maxsim_gemm_kernel<2, false, 1>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab,
+                           reinterpret_cast<const char*>(frag), nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, 0,
+                           nullptr, rs);
     RL_HIP(hipGetLastError());
     return RL_OK;
+}
+
+// Similarity (metric `mode`, scan.hip conventions) of nb queries against every row over the pre-split corpus image:
+// scores[q * ld + row].  Same results as launch_score_gemm in split arithmetic up to the summation order over K.
+int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores, int64_t ld,
+                        const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale) {
+    if (!(split_scale > 0.f) || !planes) return RL_ERR_UNSUPPORTED;
+    RL_TRY(launch_score_planes_queries(Q, nb, dim, scratch, mode, s));
+    return launch_score_planes_pass(planes, n_rows, dim, nb, scratch, scores, ld, row_norm, row_sumsq, mode, 1, nullptr, nullptr, n_cu, s,
+                                    split_scale);
 }
 
 }  // namespace rl

@@ -97,8 +97,9 @@ __device__ __forceinline__ void bitonic_sort_desc(uint64_t* a, int n) {
 
 // ---- 1. histogram -----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict__ scores, int64_t n, int64_t ld,
-                                                         uint32_t* __restrict__ ws_hist) {
+                                                         uint32_t* __restrict__ ws_hist, const uint32_t* __restrict__ run_if) {
     __shared__ uint32_t h[HIST_BINS];
+    if (run_if && *run_if == 0u) return;  // guarded fallback of the fused top-k: not needed
     const int q = blockIdx.y;
     for (int i = threadIdx.x; i < HIST_BINS; i += 256) h[i] = 0;
     __syncthreads();
@@ -128,10 +129,11 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void topk_filter_kernel(const float* __restrict__ scores, int64_t n, int64_t ld,
                                                            int32_t k, uint32_t* __restrict__ ws_hist,
                                                            uint64_t* __restrict__ ws_sel,
-                                                           uint64_t* __restrict__ ws_cand) {
+                                                           uint64_t* __restrict__ ws_cand, const uint32_t* __restrict__ run_if) {
     __shared__ uint32_t h[HIST_BINS];
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t thr[2];
+    if (run_if && *run_if == 0u) return;
     const int q = blockIdx.y;
     uint32_t* g = ws_hist + (int64_t)q * HIST_STRIDE;
     for (int i = threadIdx.x; i < HIST_BINS; i += 256) h[i] = g[i];
@@ -189,8 +191,9 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restric
                                                            const uint64_t* __restrict__ ws_sel,
                                                            const uint64_t* __restrict__ ws_cand,
                                                            float* __restrict__ out_scores,
-                                                           int32_t* __restrict__ out_ids) {
+                                                           int32_t* __restrict__ out_ids, const uint32_t* __restrict__ run_if) {
     __shared__ uint64_t buf[CAND_CAP];   // 32 KiB: candidate sort, then reused as the result sort buffer
+    if (run_if && *run_if == 0u) return;
     __shared__ uint64_t fin[K_MAX];      // 16 KiB
     __shared__ uint32_t h[HIST_BINS];    // 8 KiB
     __shared__ uint32_t scratch[20];
@@ -334,7 +337,7 @@ void select_workspace_free(SelectWorkspace& ws) {
 }
 
 int launch_topk(const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t k, SelectWorkspace& ws,
-                float* out_scores, int32_t* out_ids, hipStream_t s) {
+                float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* run_if) {
     if (nq <= 0 || k <= 0) return RL_OK;
     if (k > K_MAX) return fail(RL_ERR_UNSUPPORTED, "top-k: k must be <= 2048");
     if (n >= (int64_t)0x7fffffff) return fail(RL_ERR_UNSUPPORTED, "top-k: more than 2^31-2 elements per query");
@@ -342,12 +345,12 @@ int launch_topk(const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t 
     RL_HIP(hipMemsetAsync(ws.hist, 0, (size_t)nq * HIST_STRIDE * sizeof(uint32_t), s));
     if (n > 0) {
         const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((n + 4095) / 4096, nq >= 64 ? 64 : 512));
-        hipLaunchKernelGGL(topk_hist_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, ws.hist);
+        hipLaunchKernelGGL(topk_hist_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, ws.hist, run_if);
         hipLaunchKernelGGL(topk_filter_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, k, ws.hist, ws.sel,
-                           ws.cand);
+                           ws.cand, run_if);
     }
     hipLaunchKernelGGL(topk_final_kernel, dim3(nq), dim3(1024), 0, s, scores, n, ld, k, ws.hist, ws.sel, ws.cand,
-                       out_scores, out_ids);
+                       out_scores, out_ids, run_if);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -433,10 +436,13 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float* __restric
                                                            const int32_t* __restrict__ in_ids, int32_t n_lists,
                                                            int32_t n_queries, int32_t k_in, int32_t k,
                                                            float* __restrict__ out_scores,
-                                                           int32_t* __restrict__ out_ids) {
+                                                           int32_t* __restrict__ out_ids,
+                                                           const uint32_t* __restrict__ counts) {
     __shared__ uint64_t buf[MERGE_CAP];
     const int q = blockIdx.x;
-    const int total = n_lists * k_in;
+    // counts (one list per query only): the list of query q holds min(counts[q], k_in) records, the rest of its k_in slots
+    // was never written -- the sort then runs over the next power of two of THAT (the fused top-k's lists are a third full)
+    const int total = counts ? (int)min(counts[q], (uint32_t)k_in) : n_lists * k_in;
     int p2 = 64;
     while (p2 < total) p2 <<= 1;
     for (int i = threadIdx.x; i < p2; i += blockDim.x) {
@@ -455,11 +461,12 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float* __restric
 }
 
 int launch_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_lists, int32_t nq, int32_t k_in,
-                      int32_t k, float* out_scores, int32_t* out_ids, hipStream_t s) {
+                      int32_t k, float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* counts) {
     if (nq <= 0 || k <= 0) return RL_OK;
     if ((int64_t)n_lists * k_in > MERGE_CAP) return fail(RL_ERR_UNSUPPORTED, "merge: n_lists * k_in must be <= 8192");
+    if (counts && n_lists != 1) return fail(RL_ERR_INVALID, "merge: per-query counts need n_lists == 1");
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(1024), 0, s, in_scores, in_ids, n_lists, nq, k_in, k,
-                       out_scores, out_ids);
+                       out_scores, out_ids, counts);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

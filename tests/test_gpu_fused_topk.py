@@ -1,0 +1,139 @@
+"""GPU parity of the fused exact batched row top-k (api.hip `search_rows_fused`, maxsim_gemm.hip MODE 2): batches of
+>= 96 queries over >= 4096 rows rank WITHOUT the [B x N] score matrix -- a sampled GEMM pass gives every query a lower
+bound of its k-th best score, a second pass keeps only the rows that reach it, and the merge kernel ranks those lists.
+
+The contract is "same bits as the dense GEMM + selection path" (the reference ranks every row,
+/root/reference/src/raglite/_search.py:75-79 `ORDER BY ... LIMIT`): checked against the oracle on integer data, against
+the dense path (RAGLITE_NO_FUSED_TOPK=1) on float data, and with the candidate lists forced to overflow
+(RAGLITE_FUSED_TOPK_CAP) so that the guarded dense fallback is the one that answers.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+import raglite_amd
+from oracle import oracle
+from tests.util import assert_topk_close, sim_fp32_exact
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-6  # relative to the score scale (|e| |q| for dot products), against float64
+
+
+def _tol(E, q, metric):
+    if metric == "cosine":
+        return TOL
+    return TOL * max(1.0, float(np.linalg.norm(E, axis=1).max() * np.linalg.norm(q)))
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+@pytest.mark.parametrize("n,dim,B,k", [(4096, 64, 96, 10), (5000, 128, 128, 100), (20_001, 384, 200, 7), (70_000, 1024, 97, 512),
+                                        (33_333, 256, 1000, 1)])
+def test_fused_equals_dense_path_bitwise(metric, n, dim, B, k):
+    E = oracle.synth_matrix(7000 + n, n, dim)
+    Q = oracle.synth_matrix(7100 + B, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    S, R = idx.search_rows(Q, k)
+    with _env(RAGLITE_NO_FUSED_TOPK="1"):
+        S0, R0 = idx.search_rows(Q, k)
+    assert np.array_equal(R, R0)
+    assert np.array_equal(S.view(np.uint32), S0.view(np.uint32))
+    for b in (0, B // 2, B - 1):
+        assert_topk_close(S[b], R[b], oracle.similarity(E, Q[b], metric), k, _tol(E, Q[b], metric))
+    idx.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_fused_integer_ties_bit_exact(metric):
+    """Small-integer data: thousands of rows share every score, the bound itself is a tie value -- ties resolve to the lowest
+    row exactly as the oracle's stable sort does, whether the lists hold them or the fallback answers."""
+    n, dim, B, k = 30_000, 64, 130, 64
+    E = oracle.synth_matrix(7200, n, dim, "small_int")
+    Q = oracle.synth_matrix(7201, B, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    S, R = idx.search_rows(Q, k)
+    for b in (0, 1, 64, 129):
+        es, ei = oracle.topk_desc(sim_fp32_exact(E, Q[b], metric), k)
+        assert np.array_equal(R[b], ei)
+        assert np.array_equal(S[b].view(np.uint32), es.astype(np.float32).view(np.uint32))
+    with _env(RAGLITE_NO_FUSED_TOPK="1"):
+        S0, R0 = idx.search_rows(Q, k)
+    assert np.array_equal(R, R0) and np.array_equal(S.view(np.uint32), S0.view(np.uint32))
+    idx.close()
+
+
+def test_fused_constant_corpus_overflows_into_fallback():
+    """Every row identical: each query's list would need all N rows -> overflow flag -> the guarded dense pass; the answer is
+    rows 0..k-1 with one score."""
+    n, dim, B, k = 10_000, 128, 100, 20
+    E = np.tile(oracle.synth_matrix(7300, 1, dim), (n, 1))
+    Q = oracle.synth_matrix(7301, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric="dot")
+    S, R = idx.search_rows(Q, k)
+    assert np.array_equal(R, np.tile(np.arange(k, dtype=R.dtype), (B, 1)))
+    assert (S == S[:, :1]).all()
+    idx.close()
+
+
+@pytest.mark.parametrize("cap", ["16", "64", "700"])
+def test_forced_list_overflow_falls_back_exactly(cap):
+    n, dim, B, k = 50_000, 128, 128, 10
+    E = oracle.synth_matrix(7400, n, dim)
+    Q = oracle.synth_matrix(7401, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric="cosine")
+    with _env(RAGLITE_NO_FUSED_TOPK="1"):
+        S0, R0 = idx.search_rows(Q, k)
+    with _env(RAGLITE_FUSED_TOPK_CAP=cap):
+        S, R = idx.search_rows(Q, k)
+    assert np.array_equal(R, R0) and np.array_equal(S.view(np.uint32), S0.view(np.uint32))
+    S, R = idx.search_rows(Q, k)  # and the flag is re-armed per call: the next batch takes the lists again
+    assert np.array_equal(R, R0) and np.array_equal(S.view(np.uint32), S0.view(np.uint32))
+    idx.close()
+
+
+def test_fused_after_append_and_delete():
+    """The image follows appends; deletions put a row mask on the search, which routes to the dense path -- both agree with
+    a fresh index over the same rows."""
+    n, dim, B, k = 12_000, 128, 100, 25
+    E = oracle.synth_matrix(7500, n, dim)
+    Q = oracle.synth_matrix(7501, B, dim)
+    idx = raglite_amd.DeviceIndex(E[:8000], metric="cosine")
+    idx.append(E[8000:])
+    S, R = idx.search_rows(Q, k)
+    ref = raglite_amd.DeviceIndex(E, metric="cosine")
+    with _env(RAGLITE_NO_FUSED_TOPK="1"):
+        S0, R0 = ref.search_rows(Q, k)
+    assert np.array_equal(R, R0) and np.array_equal(S.view(np.uint32), S0.view(np.uint32))
+    for b in (0, 50, 99):
+        assert_topk_close(S[b], R[b], oracle.similarity(E, Q[b], "cosine"), k, TOL)
+    dead = np.unique(R[:, 0])[:40]
+    idx.delete_chunks(dead)
+    S1, R1 = idx.search_rows(Q, k)
+    assert not np.isin(R1, dead).any()
+    for b in (0, 99):
+        sim = oracle.similarity(E, Q[b], "cosine").copy()
+        sim[dead] = -np.inf
+        assert_topk_close(S1[b], R1[b], sim, k, TOL)
+    idx.compact()  # tombstones squeezed out: no mask any more, the lists answer again
+    live = np.setdiff1d(np.arange(n), dead)
+    S2, R2 = idx.search_rows(Q, k)
+    assert np.array_equal(live[R2], R1) and np.array_equal(S2.view(np.uint32), S1.view(np.uint32))
+    idx.close()
+    ref.close()
