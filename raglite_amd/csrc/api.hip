@@ -870,7 +870,16 @@ int rl_index_info(const rl_index* idx, int64_t* n_rows, int32_t* dim, int64_t* n
 namespace {
 
 // Similarity of `nb` device queries against every row -> idx->scores [nb x ld] (device).
-int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStream_t s) {
+// hist_done != nullptr: the caller ranks the scores next and there is no row mask in between -- where the path ends in the
+// metric transform of raw dots, the selection's histogram is taken in the same launch and *hist_done says so.
+int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStream_t s, bool* hist_done = nullptr) {
+    auto transform = [&](float* sc_, int mode_) {
+        if (hist_done) {
+            *hist_done = true;
+            return launch_transform_hist(sc_, nb, idx->n_rows, ld, idx->norm, idx->sumsq, d_q, idx->dim, mode_, idx->ws, s);
+        }
+        return launch_transform(sc_, nb, idx->n_rows, ld, idx->norm, idx->sumsq, d_q, idx->dim, mode_, s);
+    };
     const int mode = scan_mode(idx->metric);
     float* sc = idx->scores.as<float>();
     if (idx->E16) {  // fp16 storage: f16-MFMA stream passes of up to 32 queries, whatever the batch size: the VALU scan
@@ -886,7 +895,7 @@ int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStrea
                                           idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, sc + (int64_t)b0 * ld, ld,
                                           idx->n_cu, s));
         }
-        return launch_transform(sc, nb, idx->n_rows, ld, idx->norm, idx->sumsq, d_q, idx->dim, mode, s);
+        return transform(sc, mode);
     }
     if (nb >= GEMM_MIN_QUERIES && idx->planes_scale > 0.f && idx->planes_scale == idx->split_scale && idx->planes_rows == idx->n_rows) {
         // the same GEMM over the pre-split corpus image (maxsim_gemm.hip, row-score mode): no conversion in the loop
@@ -920,7 +929,7 @@ int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStrea
                                                 sc + (int64_t)b0 * ld, ld, idx->n_cu, s, idx->split_scale);
             if (st == RL_ERR_UNSUPPORTED) ok = false; else RL_TRY(st);
         }
-        if (ok) return launch_transform(sc, nb, idx->n_rows, ld, idx->norm, idx->sumsq, d_q, idx->dim, mode, s);
+        if (ok) return transform(sc, mode);
     }
     return launch_scan_rows(idx->E, idx->n_rows, idx->dim, d_q, nb, idx->norm, mode, sc, ld, s);
 }
@@ -1013,11 +1022,12 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
             if (st == RL_OK) continue;
             if (st != RL_ERR_UNSUPPORTED) return st;
         }
-        RL_TRY(score_rows(idx, d_q + (int64_t)b0 * idx->dim, nb, ld, s));
+        bool hist_done = false;
+        RL_TRY(score_rows(idx, d_q + (int64_t)b0 * idx->dim, nb, ld, s, d_row_bits ? nullptr : &hist_done));
         if (d_row_bits) RL_TRY(launch_mask_scores(idx->scores.as<float>(), nb, n, ld, d_row_bits, s));
         float* o_s = d_scores + (int64_t)b0 * k;
         int32_t* o_r = d_rows + (int64_t)b0 * k;
-        RL_TRY(launch_topk(idx->scores.as<float>(), nb, n, ld, k, idx->ws, o_s, o_r, s));
+        RL_TRY(launch_topk(idx->scores.as<float>(), nb, n, ld, k, idx->ws, o_s, o_r, s, nullptr, hist_done));
         if (idx->metric == RL_L2 && (nb > 4)) {
             // The batched paths rank by |e|^2 + |q|^2 - 2 e.q; re-score the k hits of every query with the exact
             // sum (e - q)^2 and re-sort them (near-duplicates would otherwise report a cancelled distance).

@@ -63,6 +63,7 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
+
 // Wave-uniform id of the calling wave inside its block (provably uniform for the compiler).
 __device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
@@ -96,6 +97,15 @@ int launch_pool_norm(const float* tokens, int32_t dim, const int64_t* span_begin
 
 // scan.hip
 enum ScanMode { SCAN_RAW_DOT = 0, SCAN_COSINE = 1, SCAN_DOT = 2, SCAN_L2 = 3 };
+
+// The metric transform of a raw dot product (transform_kernel in scan.hip and transform_hist_kernel in select.hip share
+// these statements, so both give the same bits): qss = |q|^2 summed as block_query_sumsq does, qn = sqrtf(qss).
+__device__ __forceinline__ float transform_score(float d, int mode, float row_norm, float row_sumsq, float qn, float qss) {
+    if (mode == SCAN_COSINE) return 1.0f - (1.0f - d / (row_norm * qn));
+    if (mode == SCAN_DOT) return 1.0f + d;
+    if (mode == SCAN_L2) return 1.0f - sqrtf(fmaxf(row_sumsq + qss - 2.0f * d, 0.f));
+    return d;
+}
 // scores[b * ld + row] for b < nb (nb <= 4 per launch handled inside), rows < n.
 int launch_scan_rows(const float* E, int64_t n, int32_t dim, const float* queries, int32_t nb,
                      const float* row_norm, int mode, float* scores, int64_t ld, hipStream_t s);
@@ -112,16 +122,25 @@ int launch_transform(float* scores, int32_t nb, int64_t n, int64_t ld, const flo
 
 // select.hip
 struct SelectWorkspace {      // device buffers sized for `capacity_queries`
-    uint32_t* hist = nullptr; // [B][HIST_BINS + 8]  (bins, then counters)
+    uint32_t* hist = nullptr; // [B][HIST_BINS + 8]  (bins, then counters).  ALL ZERO between selections: zeroed when
+                              // allocated, and the final kernel of every selection zeroes its query's row again once it
+                              // has read it -- no memset launch in front of every top-k
     uint64_t* sel = nullptr;  // [B][K_MAX]
     uint64_t* cand = nullptr; // [B][CAND_CAP]
     int32_t capacity_queries = 0;
+    bool dirty = false;       // a launch sequence was cut short by an error: re-zero `hist` before the next use
 };
-int select_workspace_reserve(SelectWorkspace& ws, int32_t n_queries);
+int select_workspace_reserve(SelectWorkspace& ws, int32_t n_queries, hipStream_t s);
 void select_workspace_free(SelectWorkspace& ws);
-// run_if != nullptr: the three kernels return at once unless *run_if != 0 (the guarded dense fallback of the fused top-k)
+// run_if != nullptr: the three kernels return at once unless *run_if != 0 (the guarded dense fallback of the fused top-k).
+// have_hist: the histogram of `scores` is already in ws.hist (launch_transform_hist) -- skip that pass.
 int launch_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32_t k,
-                SelectWorkspace& ws, float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* run_if = nullptr);
+                SelectWorkspace& ws, float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* run_if = nullptr,
+                bool have_hist = false);
+// launch_transform (scan.hip) + the selection's histogram pass in ONE launch: raw dots -> similarities in place, and their
+// 2048-bin key histogram into ws.hist (same statements as transform_kernel: same bits).  Follow with launch_topk(have_hist).
+int launch_transform_hist(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm, const float* row_sumsq,
+                          const float* queries, int32_t dim, int mode, SelectWorkspace& ws, hipStream_t s);
 int launch_group_chunk_max(const float* hit_scores, const int32_t* hit_rows, int32_t n_queries,
                            int32_t num_hits, const int64_t* chunk_offsets, int64_t n_chunks, int32_t k,
                            float* out_scores, int32_t* out_chunks, int32_t* out_counts, hipStream_t s);

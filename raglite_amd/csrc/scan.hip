@@ -191,16 +191,7 @@ __global__ __launch_bounds__(256) void transform_kernel(float* __restrict__ scor
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float d = scores[(int64_t)b * ld + i];
-        float out;
-        if (mode == SCAN_COSINE) {
-            out = 1.0f - (1.0f - d / (row_norm[i] * qn));
-        } else if (mode == SCAN_DOT) {
-            out = 1.0f + d;
-        } else if (mode == SCAN_L2) {
-            out = 1.0f - sqrtf(fmaxf(row_sumsq[i] + qss - 2.0f * d, 0.f));
-        } else {
-            out = d;
-        }
+        const float out = transform_score(d, mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
         scores[(int64_t)b * ld + i] = out;
     }
 }

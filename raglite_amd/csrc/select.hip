@@ -5,8 +5,11 @@
 // ties unspecified; the oracle and this file fix them to the lowest id.  NaN scores rank last.
 //
 // Every element is mapped to a unique 64-bit key (orderable score bits << 32 | ~id); top-k = the k
-// largest keys.  Three launches per batch of queries, no host round trip:
-//   1. hist    : 2048-bin histogram of the key's top 11 bits (LDS-privatised, nonzero bins flushed).
+// largest keys.  Three launches per batch of queries, no host round trip, no memset (the histogram rows are zero between
+// selections: the final kernel zeroes the row it has just read):
+//   1. hist    : 2048-bin histogram of the key's top 11 bits (LDS-privatised, four lane-interleaved copies, nonzero bins
+//                flushed).  For raw dots that still need their metric transform (small batches over the MFMA stream)
+//                transform_hist_kernel does both in one launch.
 //   2. filter  : every block locates the threshold bin from the histogram; elements in higher bins go
 //                straight to the `sel` list, elements in the threshold bin to the `cand` list.
 //   3. final   : one block per query bitonic-sorts the (few hundred) candidates, takes what is still
@@ -96,12 +99,32 @@ __device__ __forceinline__ void bitonic_sort_desc(uint64_t* a, int n) {
 }
 
 // ---- 1. histogram -----------------------------------------------------------------------------------
+// Similarities of one query crowd into a few dozen bins (cosines around 0: ~30 bins hold 95 % of a corpus), and LDS atomics of
+// one instruction that hit the same address serialise: round 1 measured 85 % of this kernel's LDS cycles as conflicts
+// (profiles/r01_m_pmc.txt).  Four copies of the histogram, copy = lane & 3, 16 banks apart: a quarter of the collisions.
+constexpr int HIST_COPIES = 4;
+constexpr int HIST_COPY_STRIDE = HIST_BINS + 16;
+__device__ __forceinline__ void hist_zero(uint32_t* h) {
+    for (int i = threadIdx.x; i < HIST_COPIES * HIST_COPY_STRIDE; i += blockDim.x) h[i] = 0;
+}
+__device__ __forceinline__ void hist_add(uint32_t* h, float v) {
+    atomicAdd(&h[(threadIdx.x & (HIST_COPIES - 1)) * HIST_COPY_STRIDE + (score_key(v) >> 21)], 1u);
+}
+__device__ __forceinline__ void hist_flush(const uint32_t* h, uint32_t* g) {
+    for (int i = threadIdx.x; i < HIST_BINS; i += blockDim.x) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < HIST_COPIES; ++j) c += h[j * HIST_COPY_STRIDE + i];
+        if (c) atomicAdd(&g[i], c);
+    }
+}
+
 __global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict__ scores, int64_t n, int64_t ld,
                                                          uint32_t* __restrict__ ws_hist, const uint32_t* __restrict__ run_if) {
-    __shared__ uint32_t h[HIST_BINS];
+    __shared__ uint32_t h[HIST_COPIES * HIST_COPY_STRIDE];
     if (run_if && *run_if == 0u) return;  // guarded fallback of the fused top-k: not needed
     const int q = blockIdx.y;
-    for (int i = threadIdx.x; i < HIST_BINS; i += 256) h[i] = 0;
+    hist_zero(h);
     __syncthreads();
     const float* s = scores + (int64_t)q * ld;
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -112,17 +135,71 @@ __global__ __launch_bounds__(256) void topk_hist_kernel(const float* __restrict_
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
             const f4 v = s4[i];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) atomicAdd(&h[score_key(v[u]) >> 21], 1u);
+            for (int u = 0; u < 4; ++u) hist_add(h, v[u]);
         }
-        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) atomicAdd(&h[score_key(s[(n4 << 2) + threadIdx.x]) >> 21], 1u);
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) hist_add(h, s[(n4 << 2) + threadIdx.x]);
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride)
-            atomicAdd(&h[score_key(s[i]) >> 21], 1u);
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) hist_add(h, s[i]);
     }
     __syncthreads();
-    uint32_t* g = ws_hist + (int64_t)q * HIST_STRIDE;
-    for (int i = threadIdx.x; i < HIST_BINS; i += 256)
-        if (h[i]) atomicAdd(&g[i], h[i]);
+    hist_flush(h, ws_hist + (int64_t)q * HIST_STRIDE);
+}
+
+// Raw dots -> similarities in place (the statements of scan.hip:transform_kernel) AND their histogram: one launch and one
+// pass over the scores instead of transform + memset + hist (B = 1 over 1 M rows: 5.3 + 4.7 + 6.5 us of kernels and two
+// launch gaps, profiles/r02_m_cfg2_kernel_stats.csv).
+__global__ __launch_bounds__(256) void transform_hist_kernel(float* __restrict__ scores, int64_t n, int64_t ld,
+                                                              const float* __restrict__ row_norm,
+                                                              const float* __restrict__ row_sumsq,
+                                                              const float* __restrict__ queries, int dim, int mode,
+                                                              uint32_t* __restrict__ ws_hist) {
+    __shared__ uint32_t h[HIST_COPIES * HIST_COPY_STRIDE];
+    __shared__ float part[4];
+    const int b = blockIdx.y;
+    hist_zero(h);
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < dim; c += 256) {
+        const float v = queries[(int64_t)b * dim + c];
+        ss = fmaf(v, v, ss);
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float qss = (part[0] + part[1]) + (part[2] + part[3]);
+    const float qn = sqrtf(qss);
+    float* const sb = scores + (int64_t)b * ld;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0) {  // 16-B accesses
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+            const f4 d = reinterpret_cast<const f4*>(sb)[i];
+            f4 rn = {1.f, 1.f, 1.f, 1.f}, rss = {0.f, 0.f, 0.f, 0.f};
+            if (mode == SCAN_COSINE) rn = reinterpret_cast<const f4*>(row_norm)[i];   // hipMalloc'd: 16-B aligned
+            if (mode == SCAN_L2) rss = reinterpret_cast<const f4*>(row_sumsq)[i];
+            f4 o;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                o[u] = transform_score(d[u], mode, rn[u], rss[u], qn, qss);
+                hist_add(h, o[u]);
+            }
+            reinterpret_cast<f4*>(sb)[i] = o;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+            const int64_t i = (n4 << 2) + threadIdx.x;
+            const float o = transform_score(sb[i], mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
+            hist_add(h, o);
+            sb[i] = o;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+            const float o = transform_score(sb[i], mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
+            hist_add(h, o);
+            sb[i] = o;
+        }
+    }
+    __syncthreads();
+    hist_flush(h, ws_hist + (int64_t)b * HIST_STRIDE);
 }
 
 // ---- 2. filter ---------------------------------------------------------------------------------------
@@ -187,7 +264,7 @@ __device__ __forceinline__ void write_results(const uint64_t* sorted, int n_vali
 }
 
 __global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restrict__ scores, int64_t n, int64_t ld,
-                                                           int32_t k, const uint32_t* __restrict__ ws_hist,
+                                                           int32_t k, uint32_t* __restrict__ ws_hist,
                                                            const uint64_t* __restrict__ ws_sel,
                                                            const uint64_t* __restrict__ ws_cand,
                                                            float* __restrict__ out_scores,
@@ -200,7 +277,7 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restric
     __shared__ uint32_t thr[2];
     __shared__ uint32_t sh_cnt[3];
     const int q = blockIdx.x;
-    const uint32_t* g = ws_hist + (int64_t)q * HIST_STRIDE;
+    uint32_t* g = ws_hist + (int64_t)q * HIST_STRIDE;
     const uint64_t* sel = ws_sel + (int64_t)q * K_MAX;
     const uint64_t* cand = ws_cand + (int64_t)q * CAND_CAP;
     float* os = out_scores + (int64_t)q * k;
@@ -209,8 +286,12 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restric
     const uint32_t n_sel = g[CNT_SEL];
     const uint32_t n_cand = g[CNT_CAND];
     const uint32_t need = kk - n_sel;  // >= 1 whenever kk >= 1 (the threshold bin is never empty)
+    // This block is the last reader of the query's histogram row: keep the bins (the slow path wants them) and hand the row
+    // back all zero, which is what the next selection's histogram pass expects (no memset launch per top-k).
+    for (int i = threadIdx.x; i < HIST_BINS; i += blockDim.x) h[i] = g[i];
     for (int i = threadIdx.x; i < K_MAX; i += blockDim.x) fin[i] = (i < (int)n_sel) ? sel[i] : 0ull;
     __syncthreads();
+    for (int i = threadIdx.x; i < HIST_STRIDE; i += blockDim.x) g[i] = 0u;
     if (kk == 0) { write_results(fin, 0, k, os, oi); return; }
 
     if (n_cand <= (uint32_t)RANK_MAX) {
@@ -235,9 +316,7 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restric
         __syncthreads();
     } else {
         // Slow exact path: refine the 32-bit threshold inside bin b*, then take ties in index order.
-        // (Recompute b* from the histogram exactly as the filter kernel did.)
-        for (int i = threadIdx.x; i < HIST_BINS; i += blockDim.x) h[i] = g[i];
-        __syncthreads();
+        // (Recompute b* from the histogram -- copied to LDS above -- exactly as the filter kernel did.)
         find_threshold_bin(h, HIST_BINS, kk, scratch, thr);
         const uint32_t bstar = thr[0];
         const float* s = scores + (int64_t)q * ld;
@@ -319,13 +398,19 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restric
     write_results(buf, (int)kk, k, os, oi);
 }
 
-int select_workspace_reserve(SelectWorkspace& ws, int32_t nq) {
-    if (nq <= ws.capacity_queries) return RL_OK;
-    select_workspace_free(ws);
-    RL_HIP(hipMalloc(&ws.hist, (size_t)nq * HIST_STRIDE * sizeof(uint32_t)));
-    RL_HIP(hipMalloc(&ws.sel, (size_t)nq * K_MAX * sizeof(uint64_t)));
-    RL_HIP(hipMalloc(&ws.cand, (size_t)nq * CAND_CAP * sizeof(uint64_t)));
-    ws.capacity_queries = nq;
+int select_workspace_reserve(SelectWorkspace& ws, int32_t nq, hipStream_t s) {
+    if (nq > ws.capacity_queries) {
+        select_workspace_free(ws);
+        RL_HIP(hipMalloc(&ws.hist, (size_t)nq * HIST_STRIDE * sizeof(uint32_t)));
+        RL_HIP(hipMalloc(&ws.sel, (size_t)nq * K_MAX * sizeof(uint64_t)));
+        RL_HIP(hipMalloc(&ws.cand, (size_t)nq * CAND_CAP * sizeof(uint64_t)));
+        ws.capacity_queries = nq;
+        ws.dirty = true;
+    }
+    if (ws.dirty) {  // fresh allocation, or an earlier launch sequence did not get to its final kernel
+        RL_HIP(hipMemsetAsync(ws.hist, 0, (size_t)ws.capacity_queries * HIST_STRIDE * sizeof(uint32_t), s));
+        ws.dirty = false;
+    }
     return RL_OK;
 }
 
@@ -336,22 +421,42 @@ void select_workspace_free(SelectWorkspace& ws) {
     ws = SelectWorkspace{};
 }
 
+static int hist_grid(int64_t n, int32_t nq) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>((n + 4095) / 4096, nq >= 64 ? 64 : 512));
+}
+
+int launch_transform_hist(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm, const float* row_sumsq,
+                          const float* queries, int32_t dim, int mode, SelectWorkspace& ws, hipStream_t s) {
+    if (n <= 0 || nb <= 0) return RL_OK;
+    RL_TRY(select_workspace_reserve(ws, nb, s));
+    ws.dirty = true;  // the histogram rows stay non-zero until launch_topk(have_hist) has run its final kernel
+    hipLaunchKernelGGL(transform_hist_kernel, dim3(hist_grid(n, nb), nb), dim3(256), 0, s, scores, n, ld, row_norm, row_sumsq,
+                       queries, (int)dim, mode, ws.hist);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 int launch_topk(const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t k, SelectWorkspace& ws,
-                float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* run_if) {
+                float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* run_if, bool have_hist) {
     if (nq <= 0 || k <= 0) return RL_OK;
     if (k > K_MAX) return fail(RL_ERR_UNSUPPORTED, "top-k: k must be <= 2048");
     if (n >= (int64_t)0x7fffffff) return fail(RL_ERR_UNSUPPORTED, "top-k: more than 2^31-2 elements per query");
-    RL_TRY(select_workspace_reserve(ws, nq));
-    RL_HIP(hipMemsetAsync(ws.hist, 0, (size_t)nq * HIST_STRIDE * sizeof(uint32_t), s));
+    if (have_hist) {
+        if (nq > ws.capacity_queries || !ws.dirty) return fail(RL_ERR_INVALID, "top-k: no histogram in the workspace");
+    } else {
+        RL_TRY(select_workspace_reserve(ws, nq, s));
+    }
+    ws.dirty = true;
     if (n > 0) {
-        const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((n + 4095) / 4096, nq >= 64 ? 64 : 512));
-        hipLaunchKernelGGL(topk_hist_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, ws.hist, run_if);
+        const int bx = hist_grid(n, nq);
+        if (!have_hist) hipLaunchKernelGGL(topk_hist_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, ws.hist, run_if);
         hipLaunchKernelGGL(topk_filter_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, k, ws.hist, ws.sel,
                            ws.cand, run_if);
     }
     hipLaunchKernelGGL(topk_final_kernel, dim3(nq), dim3(1024), 0, s, scores, n, ld, k, ws.hist, ws.sel, ws.cand,
                        out_scores, out_ids, run_if);
     RL_HIP(hipGetLastError());
+    ws.dirty = false;  // every row this selection touched is zero again once the final kernel has run
     return RL_OK;
 }
 
