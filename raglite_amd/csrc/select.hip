@@ -156,6 +156,29 @@ __global__ __launch_bounds__(256) void transform_hist_kernel(float* __restrict__
     __shared__ uint32_t h[HIST_COPIES * HIST_COPY_STRIDE];
     __shared__ float part[4];
     const int b = blockIdx.y;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    float* const sb = scores + (int64_t)b * ld;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0;  // 16-B accesses (row_norm / row_sumsq are hipMalloc'd)
+    const int64_t n4 = vec ? n >> 2 : 0;
+    // The kernel is latency-bound (4 MB at B = 1): two 16-B groups per lane and trip, and the first trip's loads are issued
+    // BEFORE the query-norm reduction and the histogram reset so that their latency hides behind both.
+    struct Trip { f4 d0, d1, a0, a1; int64_t i0, i1; bool has0, has1; };
+    auto fetch = [&](int64_t i) {
+        Trip t;
+        t.i0 = i; t.i1 = i + stride;
+        t.has0 = t.i0 < n4; t.has1 = t.i1 < n4;
+        const int64_t j0 = t.has0 ? t.i0 : 0, j1 = t.has1 ? t.i1 : j0;
+        t.d0 = t.d1 = t.a0 = t.a1 = (f4){0.f, 0.f, 0.f, 0.f};
+        if (n4 > 0) {
+            t.d0 = reinterpret_cast<const f4*>(sb)[j0];
+            t.d1 = reinterpret_cast<const f4*>(sb)[j1];
+            const float* aux = mode == SCAN_COSINE ? row_norm : mode == SCAN_L2 ? row_sumsq : nullptr;
+            if (aux) { t.a0 = reinterpret_cast<const f4*>(aux)[j0]; t.a1 = reinterpret_cast<const f4*>(aux)[j1]; }
+        }
+        return t;
+    };
+    Trip cur = fetch((int64_t)blockIdx.x * 256 + threadIdx.x);
     hist_zero(h);
     float ss = 0.f;
     for (int c = threadIdx.x; c < dim; c += 256) {
@@ -167,36 +190,30 @@ __global__ __launch_bounds__(256) void transform_hist_kernel(float* __restrict__
     __syncthreads();
     const float qss = (part[0] + part[1]) + (part[2] + part[3]);
     const float qn = sqrtf(qss);
-    float* const sb = scores + (int64_t)b * ld;
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0) {  // 16-B accesses
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        const int64_t n4 = n >> 2;
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-            const f4 d = reinterpret_cast<const f4*>(sb)[i];
-            f4 rn = {1.f, 1.f, 1.f, 1.f}, rss = {0.f, 0.f, 0.f, 0.f};
-            if (mode == SCAN_COSINE) rn = reinterpret_cast<const f4*>(row_norm)[i];   // hipMalloc'd: 16-B aligned
-            if (mode == SCAN_L2) rss = reinterpret_cast<const f4*>(row_sumsq)[i];
-            f4 o;
+    auto one = [&](int64_t i) {  // scalar tail / unaligned layout
+        const float o = transform_score(sb[i], mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
+        hist_add(h, o);
+        sb[i] = o;
+    };
+    auto finish = [&](int64_t i, const f4 d, const f4 a) {
+        f4 o;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                o[u] = transform_score(d[u], mode, rn[u], rss[u], qn, qss);
-                hist_add(h, o[u]);
-            }
-            reinterpret_cast<f4*>(sb)[i] = o;
+        for (int u = 0; u < 4; ++u) {
+            o[u] = transform_score(d[u], mode, a[u], a[u], qn, qss);  // a = the row norms (cosine) or squared norms (l2)
+            hist_add(h, o[u]);
         }
-        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
-            const int64_t i = (n4 << 2) + threadIdx.x;
-            const float o = transform_score(sb[i], mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
-            hist_add(h, o);
-            sb[i] = o;
+        reinterpret_cast<f4*>(sb)[i] = o;
+    };
+    if (vec) {
+        while (cur.has0) {
+            const Trip nxt = fetch(cur.i0 + 2 * stride);
+            finish(cur.i0, cur.d0, cur.a0);
+            if (cur.has1) finish(cur.i1, cur.d1, cur.a1);
+            cur = nxt;
         }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) one((n4 << 2) + threadIdx.x);
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-            const float o = transform_score(sb[i], mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
-            hist_add(h, o);
-            sb[i] = o;
-        }
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) one(i);
     }
     __syncthreads();
     hist_flush(h, ws_hist + (int64_t)b * HIST_STRIDE);
