@@ -227,18 +227,20 @@ def main() -> None:
         tj = json.loads(tf.read_text())
         traffic = tj.get({3: "maxsim_gemm_bytes_per_launch", 2: "maxsim_stream2_bytes_per_launch"}.get(kind, "maxsim_stream_bytes_per_launch"))
         traffic_source = "static: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 for the gfx950 half-count, separate run)"
-    kernel_name = {3: "rl::maxsim_gemm_kernel<2, false>",
+    kernel_name = {3: "rl::maxsim_gemm_kernel<2, false, 0, true>" if arithmetic == "f16_stored" else "rl::maxsim_gemm_kernel<2, false, 0, false>",
                    2: "rl::maxsim_stream2_kernel<256, false, true>" if arithmetic == "f16_stored" else "rl::maxsim_stream2_kernel<256, false, false>",
                    0: {"fp32_exact": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, false>",
                        "f16_split": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, true>",
                        "f16_stored": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, true, false>"}[arithmetic]}[kind] + " (as rocprofv3 names it)"
     if kind == 3:
-        mfma_flops = 3.0 * fp32_equiv_flops  # q_hi.e_hi + q_hi.e_lo + q_lo.e_hi: what the split arithmetic needs on the fp16 pipe
+        # q_hi.e_hi + q_hi.e_lo + q_lo.e_hi: what the split arithmetic needs on the fp16 pipe; an fp16-stored corpus has no e_lo
+        products = 2.0 if arithmetic == "f16_stored" else 3.0
+        mfma_flops = products * fp32_equiv_flops
         achieved = mfma_flops / (ms * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                               "frac": achieved / MFMA_F16_PEAK_TF, "traffic": traffic,
                               "algorithmic_flops_per_launch": mfma_flops,
-                              "flops_note": "3 fp16 MFMA products per fp32-equivalent multiply-add (SURVEY.md 8d: 2*32*N*d per query), 8 queries per launch",
+                              "flops_note": f"{products:.0f} fp16 MFMA products per fp32-equivalent multiply-add (SURVEY.md 8d: 2*32*N*d per query), 8 queries per launch",
                               "hbm": hbm}
     else:
         result["roofline"] = {"bound": "hbm", **hbm, "traffic": traffic}

@@ -289,11 +289,20 @@ int scan_row_range(rl_index* idx, int64_t first, int64_t n, hipStream_t s) {
     return RL_OK;
 }
 
-// Builds / extends the pre-split corpus image so that it covers rows [0, idx->n_rows) at idx->split_scale.  Not having
-// the image is never an error (the streaming kernels read the fp32 rows): an allocation failure just leaves it absent.
+// Scale of the corpus image the index should have: the split scale of an fp32 corpus, 1 for an fp16-stored one (its image is
+// the stored halves, permuted), 0 = no image.
+float image_scale(const rl_index* idx) { return idx->E16 ? 1.0f : idx->split_scale; }
+bool image_valid(const rl_index* idx) {
+    return idx->planes_scale > 0.f && idx->planes_scale == image_scale(idx) && idx->planes_rows == idx->n_rows && idx->n_rows > 0;
+}
+
+// Builds / extends the corpus image so that it covers rows [0, idx->n_rows) at image_scale(idx).  Not having the image is
+// never an error (the streaming kernels read the stored rows): an allocation failure just leaves it absent.
+
 int refresh_planes(rl_index* idx, hipStream_t s) {
     static const bool no_planes = std::getenv("RAGLITE_NO_PLANES") != nullptr;  // A/B switch
-    const bool want = !no_planes && !idx->E16 && idx->E && idx->split_scale > 0.f && idx->dim % 32 == 0 && idx->dim >= 32 &&
+    const bool half = idx->E16 != nullptr;
+    const bool want = !no_planes && (idx->E16 || idx->E) && image_scale(idx) > 0.f && idx->dim % 32 == 0 && idx->dim >= 32 &&
                       idx->n_rows > 0;
     if (!want) {
         idx->planes.release();
@@ -303,8 +312,8 @@ int refresh_planes(rl_index* idx, hipStream_t s) {
         return RL_OK;
     }
     const int64_t cap = std::max<int64_t>(idx->n_rows, idx->owns_E ? idx->cap_rows : idx->n_rows);
-    const size_t need = rl::planes_bytes(cap, idx->dim), need_e = rl::chunk_ends_words(cap) * sizeof(uint32_t);
-    int64_t first = idx->planes_scale == idx->split_scale ? (idx->planes_rows & ~int64_t(15)) : 0;
+    const size_t need = rl::planes_bytes(cap, idx->dim, half), need_e = rl::chunk_ends_words(cap) * sizeof(uint32_t);
+    int64_t first = idx->planes_scale == image_scale(idx) ? (idx->planes_rows & ~int64_t(15)) : 0;
     if (idx->planes.cap < need) first = 0;  // Pool::reserve does not keep the contents
     if (idx->planes.reserve(need) != RL_OK || idx->ends.reserve(need_e) != RL_OK) {
         (void)hipGetLastError();
@@ -314,9 +323,18 @@ int refresh_planes(rl_index* idx, hipStream_t s) {
         idx->planes_rows = 0;
         return RL_OK;
     }
-    RL_TRY(rl::launch_presplit_rows(idx->E, first, idx->n_rows, idx->dim, idx->split_scale, idx->planes.p, s));
+    const int st = half ? rl::launch_preformat_rows16(idx->E16, first, idx->n_rows, idx->dim, idx->planes.p, s)
+                        : rl::launch_presplit_rows(idx->E, first, idx->n_rows, idx->dim, idx->split_scale, idx->planes.p, s);
+    if (st == RL_ERR_UNSUPPORTED) {  // e.g. caller-owned rows that are not 16-byte aligned: no image, the streaming kernels serve
+        idx->planes.release();
+        idx->ends.release();
+        idx->planes_scale = 0.f;
+        idx->planes_rows = 0;
+        return RL_OK;
+    }
+    RL_TRY(st);
     RL_TRY(rl::launch_chunk_ends(idx->row_to_chunk, idx->n_rows, idx->ends.as<uint32_t>(), s));
-    idx->planes_scale = idx->split_scale;
+    idx->planes_scale = image_scale(idx);
     idx->planes_rows = idx->n_rows;
     return RL_OK;
 }
@@ -882,6 +900,17 @@ int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStrea
     };
     const int mode = scan_mode(idx->metric);
     float* sc = idx->scores.as<float>();
+    if (nb >= GEMM_MIN_QUERIES && image_valid(idx)) {
+        // the row-score GEMM over the corpus image (maxsim_gemm.hip MODE 1; fp32 corpus: pre-split planes, fp16-stored corpus:
+        // its one-plane image): no conversion in the loop
+        static const bool off = std::getenv("RAGLITE_NO_PLANES_GEMM") != nullptr;  // A/B switch
+        if (!off) {
+            RL_TRY(idx->misc.reserve(score_planes_scratch_floats(nb, idx->dim) * sizeof(float)));
+            const int st = launch_score_planes(idx->planes.p, idx->n_rows, idx->dim, d_q, nb, sc, ld, idx->norm, idx->sumsq,
+                                               idx->misc.as<float>(), mode, idx->n_cu, s, image_scale(idx), idx->E16 != nullptr);
+            if (st != RL_ERR_UNSUPPORTED) return st;
+        }
+    }
     if (idx->E16) {  // fp16 storage: f16-MFMA stream passes of up to 32 queries, whatever the batch size: the VALU scan
         // (scan16.hip) was measured at 0.37 ms per 1 M x 1024 pass against 0.31 ms for one stream pass + transform -- with
         // half the bytes per row the LDS-DMA stream is the faster reader even for a single query.  Exception: l2 with up
@@ -896,16 +925,6 @@ int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStrea
                                           idx->n_cu, s));
         }
         return transform(sc, mode);
-    }
-    if (nb >= GEMM_MIN_QUERIES && idx->planes_scale > 0.f && idx->planes_scale == idx->split_scale && idx->planes_rows == idx->n_rows) {
-        // the same GEMM over the pre-split corpus image (maxsim_gemm.hip, row-score mode): no conversion in the loop
-        static const bool off = std::getenv("RAGLITE_NO_PLANES_GEMM") != nullptr;  // A/B switch
-        if (!off) {
-            RL_TRY(idx->misc.reserve(score_planes_scratch_floats(nb, idx->dim) * sizeof(float)));
-            const int st = launch_score_planes(idx->planes.p, idx->n_rows, idx->dim, d_q, nb, sc, ld, idx->norm, idx->sumsq,
-                                               idx->misc.as<float>(), mode, idx->n_cu, s, idx->split_scale);
-            if (st != RL_ERR_UNSUPPORTED) return st;
-        }
     }
     if (nb >= GEMM_MIN_QUERIES) {  // MFMA-bound regime: one 128 x 128-tiled GEMM instead of a corpus pass per 32 queries
         RL_TRY(idx->misc.reserve(score_gemm_scratch_floats(nb, idx->dim, idx->split_scale > 0.f) * sizeof(float)));
@@ -963,7 +982,9 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
     const int cap_env = cap_str ? std::atoi(cap_str) : 0;
     const int mode = scan_mode(idx->metric);
     if (off || B < GEMM_MIN_QUERIES || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT)) return RL_ERR_UNSUPPORTED;
-    if (!(idx->planes_scale > 0.f) || idx->planes_scale != idx->split_scale || idx->planes_rows != idx->n_rows) return RL_ERR_UNSUPPORTED;
+    if (!image_valid(idx)) return RL_ERR_UNSUPPORTED;
+    const bool half = idx->E16 != nullptr;
+    const float img_scale = image_scale(idx);
     const int64_t n = idx->n_rows, T = (n + 255) / 256;
     const int32_t cap = cap_env > 0 ? std::min(cap_env, MERGE_CAP) : MERGE_CAP;
     const int32_t stride = (int32_t)std::min<int64_t>(MERGE_CAP / (3 * (int64_t)k), T / 8);  // ~k * stride candidates per query, a third of the list
@@ -987,18 +1008,18 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
     RL_TRY(launch_score_planes_queries(d_q, B, idx->dim, qs, mode, s));
     RL_TRY(launch_fill_f32(S_s, -std::numeric_limits<float>::infinity(), (int64_t)n_sample, s));  // rows past the corpus in the last tile
     RL_TRY(launch_score_planes_pass(idx->planes.p, n, idx->dim, B, qs, S_s, ld_s, idx->norm, idx->sumsq, mode, stride, nullptr, nullptr,
-                                    idx->n_cu, s, idx->split_scale));
+                                    idx->n_cu, s, img_scale, half));
     RL_TRY(launch_topk(S_s, B, ld_s, ld_s, k, idx->ws, top_s, top_i, s));
     // ---- (2) full pass keeping what reaches the bound ---------------------------------------------------------------------------
     RL_HIP(hipMemsetAsync(cnt, 0, ((size_t)B + 1) * sizeof(uint32_t), s));  // list lengths + the overflow flag; the lists need no fill
     const CandArgs ca{top_s + (k - 1), k, c_s, c_i, cnt, flag, cap};
     RL_TRY(launch_score_planes_pass(idx->planes.p, n, idx->dim, B, qs, nullptr, 0, idx->norm, idx->sumsq, mode, 1, nullptr, &ca, idx->n_cu, s,
-                                    idx->split_scale));
+                                    img_scale, half));
     // ---- (3) exact ranking of every list ------------------------------------------------------------------------------------------
     RL_TRY(launch_merge_topk(c_s, c_i, 1, B, cap, k, d_scores, d_rows, s, cnt));
     // ---- (4) guarded dense fallback -----------------------------------------------------------------------------------------------
     RL_TRY(launch_score_planes_pass(idx->planes.p, n, idx->dim, B, qs, sc, ld, idx->norm, idx->sumsq, mode, 1, flag, nullptr, idx->n_cu, s,
-                                    idx->split_scale));
+                                    img_scale, half));
     RL_TRY(launch_topk(sc, B, n, ld, k, idx->ws, d_scores, d_rows, s, flag));
     return RL_OK;
 }
@@ -1166,14 +1187,14 @@ int pairs_pass(rl_index* idx, int32_t nq, int32_t n_queries, int32_t first, floa
 constexpr int32_t GEMM_PASS_QUERIES = 8, GEMM_PASS_MIN_QUERIES = 3;
 int gemm_prepare(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, int32_t n_queries, hipStream_t s) {
     static const bool off = std::getenv("RAGLITE_NO_GEMM_PASS") != nullptr;  // A/B switch
-    if (off || idx->planes_scale <= 0.f || idx->planes_scale != idx->split_scale || idx->planes_rows != idx->n_rows) return RL_ERR_UNSUPPORTED;
+    if (off || !image_valid(idx)) return RL_ERR_UNSUPPORTED;
     if (idx->has_empty_chunk || idx->n_chunks == 0 || nq < 1 || nq > 32 || n_queries < GEMM_PASS_MIN_QUERIES) return RL_ERR_UNSUPPORTED;
     RL_TRY(idx->qplanes.reserve(query_planes_bytes(idx->dim, n_queries)));
     return launch_query_planes(d_q, idx->dim, nq, q_stride, n_queries, idx->qplanes.p, s);
 }
 int gemm_pass(rl_index* idx, int32_t nq, int32_t n_queries, int32_t first, int32_t n_q, float* d_out, int64_t out_stride, hipStream_t s) {
     return launch_maxsim_gemm(idx->planes.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, first, n_q, nq, idx->row_to_chunk,
-                              idx->offsets, idx->ends.as<uint32_t>(), d_out, out_stride, idx->n_cu, s, idx->split_scale);
+                              idx->offsets, idx->ends.as<uint32_t>(), d_out, out_stride, idx->n_cu, s, image_scale(idx), idx->E16 != nullptr);
 }
 
 int maxsim_scores_device(rl_index* idx, const float* d_q, int32_t nq, float* d_out, hipStream_t s) {

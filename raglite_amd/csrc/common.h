@@ -188,24 +188,27 @@ int launch_query_split(const float* Q, int32_t dim, int32_t nq, int64_t q_stride
 int launch_maxsim_stream2(const void* D, bool f16, int64_t n_rows, int32_t dim, const void* split_buf, int32_t n_queries,
                           int32_t first, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks,
                           float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale);
-// maxsim_gemm.hip: eight queries per corpus pass over the pre-split (fp16 hi | lo) corpus image
-size_t planes_bytes(int64_t rows, int32_t dim);
+// maxsim_gemm.hip: eight queries per corpus pass over the pre-split (fp16 hi | lo) corpus image; `half`: the one-plane image of
+// an fp16-stored corpus (split_scale = 1)
+size_t planes_bytes(int64_t rows, int32_t dim, bool half = false);
 int launch_presplit_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s);
+int launch_preformat_rows16(const uint16_t* E, int64_t first_row, int64_t n_rows, int32_t dim, void* planes, hipStream_t s);
 size_t chunk_ends_words(int64_t rows);
 int launch_chunk_ends(const int32_t* row_to_chunk, int64_t n_rows, uint32_t* ends, hipStream_t s);
 size_t query_planes_bytes(int32_t dim, int32_t n_queries);
 int launch_query_planes(const float* Q, int32_t dim, int32_t nq, int64_t q_stride, int32_t n_queries, void* buf, hipStream_t s);
 int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first,
                        int32_t n_q, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits,
-                       float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale);
+                       float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale, bool half = false);
 size_t score_planes_scratch_floats(int32_t nb, int32_t dim);
 int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores, int64_t ld,
-                        const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale);
+                        const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale,
+                        bool half = false);
 struct CandArgs { const float* tau; int32_t tau_stride; float* scores; int32_t* ids; uint32_t* cnt; uint32_t* overflow; int32_t cap; };
 int launch_score_planes_queries(const float* Q, int32_t nb, int32_t dim, float* scratch, int mode, hipStream_t s);
 int launch_score_planes_pass(const void* planes, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, float* scores, int64_t ld,
                              const float* row_norm, const float* row_sumsq, int mode, int32_t tile_stride, const uint32_t* run_if,
-                             const CandArgs* cand, int n_cu, hipStream_t s, float split_scale);
+                             const CandArgs* cand, int n_cu, hipStream_t s, float split_scale, bool half = false);
 // [largest |element|, smallest non-zero row maximum, non-finite flag] of an fp32 corpus, as uint32 bit patterns (device, 3 words)
 int launch_row_range(const float* E, int64_t n_rows, int32_t dim, uint32_t* range, hipStream_t s);
 // Any dim / nq: one wave per chunk (or per candidate), VALU dot products.

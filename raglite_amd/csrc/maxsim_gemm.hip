@@ -58,7 +58,7 @@ __device__ __forceinline__ int64_t mg_uniform_i64(int64_t v) {
 
 // ---- corpus image ----------------------------------------------------------------------------------------------------
 // Bytes of the image of `rows` rows (rounded up to whole 16-row blocks).
-size_t planes_bytes(int64_t rows, int32_t dim) { return (size_t)((rows + 15) / 16) * 16 * (size_t)dim * 4; }
+size_t planes_bytes(int64_t rows, int32_t dim, bool half) { return (size_t)((rows + 15) / 16) * 16 * (size_t)dim * (half ? 2 : 4); }
 
 // One thread per (row, slab, k-quarter): 8 consecutive fp32 -> one hi chunk and one lo chunk.  Rows in
 // [n_rows, 16 * ceil(n_rows / 16)) are written as zeros.  `first_row` must be a multiple of 16 unless the rows before
@@ -99,6 +99,32 @@ int launch_presplit_rows(const float* E, int64_t first_row, int64_t n_rows, int3
     const int64_t threads = (end_row - first_row) * (dim / 8);
     hipLaunchKernelGGL(presplit_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, E, first_row, end_row, n_rows, dim,
                        scale, static_cast<char*>(planes));
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// fp16-stored corpus -> its one-plane image (a pure permutation, 2 B per element): the 1 KiB of a (16-row block, slab) holds
+// k-chunk kq of row j at 256 kq + 16 j, i.e. in the order the 64 lanes of a wave read it (and a 1-KiB LDS-DMA writes it).
+__global__ __launch_bounds__(256) void preformat_rows16_kernel(const uint16_t* __restrict__ E, int64_t first_row, int64_t end_row,
+                                                                int64_t n_rows, int32_t dim, char* __restrict__ planes) {
+    const int32_t nslab = dim >> 5;
+    const int64_t per_row = (int64_t)nslab * 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = first_row + i / per_row;
+    if (row >= end_row) return;
+    const int32_t rem = (int32_t)(i % per_row), s = rem >> 2, kq = rem & 3;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row < n_rows) v = *reinterpret_cast<const uint4*>(E + row * dim + 32 * s + 8 * kq);
+    *reinterpret_cast<uint4*>(planes + ((row >> 4) * nslab + s) * 1024 + kq * 256 + (row & 15) * 16) = v;
+}
+
+int launch_preformat_rows16(const uint16_t* E, int64_t first_row, int64_t n_rows, int32_t dim, void* planes, hipStream_t s) {
+    if (dim % 32 || dim < 32 || (reinterpret_cast<uintptr_t>(E) & 15)) return RL_ERR_UNSUPPORTED;
+    const int64_t end_row = (n_rows + 15) / 16 * 16;
+    if (end_row <= first_row) return RL_OK;
+    const int64_t threads = (end_row - first_row) * (dim / 8);
+    hipLaunchKernelGGL(preformat_rows16_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, E, first_row, end_row, n_rows, dim,
+                       static_cast<char*>(planes));
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -246,7 +272,11 @@ struct RowScoreArgs {
     int32_t cap;
 };
 
-template <int NQB, bool TRACE = false, int MODE = 0>
+// HALF: the image of an fp16-STORED corpus (rl_index_create_f16; the reference's pgvector halfvec column,
+// src/raglite/_typing.py:211-232): one fp16 plane, 2 B per element -- a (block, slab) is 1 KiB laid out exactly as a wave
+// reads it (lane 16 kq + j <- k-chunk kq of row j), the slab 16 KiB, and each product is 2 MFMAs (q_hi.e + q_lo.e), exact
+// for the stored values.
+template <int NQB, bool TRACE = false, int MODE = 0, bool HALF = false>
 __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restrict__ planes, int64_t n_rows, int32_t nslab,
                                                                const char* __restrict__ qfrag, const float* __restrict__ qmeta,
                                                                int32_t n_q, const int32_t* __restrict__ row_to_chunk,
@@ -256,18 +286,20 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
                                                                RowScoreArgs rs) {
     // TRACE (diagnostic build, RAGLITE_GEMM_TRACE=1): s_memtime stamps of workgroup 7, slabs 128..143, kept in
     // LDS and copied out at the end: [slab - 128][wave][stamp 0..15] (3 + p = after pair p of the slab).
-    __shared__ __attribute__((aligned(16))) char smem[MG_NSLOT * MG_SLAB + (TRACE ? 16 * 8 * 16 * 8 : 0) + (MODE == 2 ? MG_WAVES * 4096 : 0)];
+    constexpr int BLKB = HALF ? 1024 : 2048;   // bytes of one (16-row block, K slab) of the image
+    constexpr int SLAB = MG_NBLK * BLKB;       // one K slab of a tile in LDS
+    __shared__ __attribute__((aligned(16))) char smem[MG_NSLOT * SLAB + (TRACE ? 16 * 8 * 16 * 8 : 0) + (MODE == 2 ? MG_WAVES * 4096 : 0)];
     if constexpr (MODE != 0) {
         if (rs.run_if && __builtin_amdgcn_readfirstlane((int)*rs.run_if) == 0) return;  // whole grid: the guarded fallback is not needed
     }
     auto stamp = [&](int g, int k) {
         if constexpr (TRACE) {
             if (blockIdx.x == 7 && g >= 128 && g < 144 && (threadIdx.x & 63) == 0)
-                reinterpret_cast<unsigned long long*>(smem + MG_NSLOT * MG_SLAB)[((g - 128) * 8 + (threadIdx.x >> 6)) * 16 + k] = __builtin_amdgcn_s_memtime();
+                reinterpret_cast<unsigned long long*>(smem + MG_NSLOT * SLAB)[((g - 128) * 8 + (threadIdx.x >> 6)) * 16 + k] = __builtin_amdgcn_s_memtime();
         }
     };
     if constexpr (TRACE) {
-        for (int i = threadIdx.x; i < 16 * 8 * 16; i += blockDim.x) reinterpret_cast<unsigned long long*>(smem + MG_NSLOT * MG_SLAB)[i] = 0;
+        for (int i = threadIdx.x; i < 16 * 8 * 16; i += blockDim.x) reinterpret_cast<unsigned long long*>(smem + MG_NSLOT * SLAB)[i] = 0;
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
@@ -330,15 +362,15 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
         for (int i = 0; i < 4; ++i) {
             int32_t blk = b0 + i;
             blk = blk < last_blk ? blk : last_blk;  // past the image: harmless re-read of the last block, never used
-            f_base[i] = planes + mg_uniform_i64((int64_t)blk * nslab * 2048);
+            f_base[i] = planes + mg_uniform_i64((int64_t)blk * nslab * BLKB);
         }
     };
     feed_tile(0);
     auto next_feed = [&]() __attribute__((always_inline)) {
         Feed f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f.src[i] = f_base[i] + f_s * 2048;
-        f.lds = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(f_slot * MG_SLAB + 4 * (wv & 3) * 2048));
+        for (int i = 0; i < 4; ++i) f.src[i] = f_base[i] + f_s * BLKB;
+        f.lds = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)(f_slot * SLAB + 4 * (wv & 3) * BLKB));
         if (++f_s == nslab) {  // past the end: re-fetch the last tile (keeps the vmcnt bookkeeping uniform)
             f_s = 0;
             if (f_tile + 1 < nt) { ++f_tile; feed_tile(f_tile); }
@@ -346,14 +378,16 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
         f_slot = f_slot + 1 == MG_NSLOT ? 0 : f_slot + 1;
         return f;
     };
-    auto dma_piece = [&](const Feed& f, auto P_) {  // piece p = 2 * block + half
+    auto dma_piece = [&](const Feed& f, auto P_) {  // piece p = 2 * block + half (HALF: a block is one piece)
         constexpr int p = decltype(P_)::value, i = p >> 1, h = p & 1;
-        const uint32_t lane16 = 16u * lane;  // (asm operands alone do not capture an enclosing local in a generic lambda)
-        const char* const src = reinterpret_cast<const char*>(mg_uniform_i64(reinterpret_cast<int64_t>(f.src[i])));
-        const uint32_t lds = __builtin_amdgcn_readfirstlane(f.lds);
-        asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 offset:%4 nt" ::"s"(lds), "n"(i * 2048),
-                     "v"(lane16), "s"(src), "n"(h * 1024)
-                     : "memory", "m0", "scc");
+        if constexpr (!(HALF && h == 1)) {
+            const uint32_t lane16 = 16u * lane;  // (asm operands alone do not capture an enclosing local in a generic lambda)
+            const char* const src = reinterpret_cast<const char*>(mg_uniform_i64(reinterpret_cast<int64_t>(f.src[i])));
+            const uint32_t lds = __builtin_amdgcn_readfirstlane(f.lds);
+            asm volatile("s_add_u32 m0, %0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 offset:%4 nt" ::"s"(lds), "n"(i * BLKB),
+                         "v"(lane16), "s"(src), "n"(h * 1024)
+                         : "memory", "m0", "scc");
+        }
     };
     auto dma_all = [&](const Feed& f) __attribute__((always_inline)) {
         [&]<int... P>(std::integer_sequence<int, P...>) { (dma_piece(f, std::integral_constant<int, P>{}), ...); }
@@ -409,11 +443,15 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     int c_tile = 0, c_s = 0, c_slot = 0;
     h16x8 eh[2][2], el[2][2];  // [pair parity][block of the pair]
     auto read_pair = [&](int slot, int p, h16x8 (&h)[2], h16x8 (&l)[2]) __attribute__((always_inline)) {
-        const char* const base = smem + slot * MG_SLAB;
+        const char* const base = smem + slot * SLAB;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            h[i] = *reinterpret_cast<const h16x8*>(base + (2 * p + i) * 2048 + a_hi);
-            l[i] = *reinterpret_cast<const h16x8*>(base + (2 * p + i) * 2048 + a_lo);
+            if constexpr (HALF) {
+                h[i] = *reinterpret_cast<const h16x8*>(base + (2 * p + i) * BLKB + lane16);
+            } else {
+                h[i] = *reinterpret_cast<const h16x8*>(base + (2 * p + i) * BLKB + a_hi);
+                l[i] = *reinterpret_cast<const h16x8*>(base + (2 * p + i) * BLKB + a_lo);
+            }
         }
     };
     auto slab = [&](f32x4 (&q)[4], f32x4 (&qn)[4], int nb, int g_trace) __attribute__((always_inline)) {
@@ -445,11 +483,13 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
 #pragma unroll
                         for (int qb = 0; qb < NQB; ++qb)
                             acc[qb][2 * p + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[qb], h[i], acc[qb][2 * p + i], 0, 0, 0);
+                    if constexpr (!HALF) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int qb = 0; qb < NQB; ++qb)
-                            acc[qb][2 * p + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[qb], l[i], acc[qb][2 * p + i], 0, 0, 0);
+                            for (int qb = 0; qb < NQB; ++qb)
+                                acc[qb][2 * p + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[qb], l[i], acc[qb][2 * p + i], 0, 0, 0);
+                    }
                     if (any_lo) {
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
@@ -519,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     // test uses reciprocals (2 VALU instead of an IEEE divide) against a threshold lowered by 1e-5; the exact similarity --
     // the formulas of MODE 1, same bits -- is computed for the few records only.
     [[maybe_unused]] int ncand = 0;  // wave-uniform
-    [[maybe_unused]] float* const rec_d = reinterpret_cast<float*>(smem + MG_NSLOT * MG_SLAB + (TRACE ? 16 * 8 * 16 * 8 : 0) + wv * 4096);
+    [[maybe_unused]] float* const rec_d = reinterpret_cast<float*>(smem + MG_NSLOT * SLAB + (TRACE ? 16 * 8 * 16 * 8 : 0) + wv * 4096);
     [[maybe_unused]] uint32_t* const rec_m = reinterpret_cast<uint32_t*>(rec_d + 512);
     constexpr int REC_CAP = 512;  // records a wave keeps per tile (expected: a few dozen); more -> the guarded dense fallback
     auto flush_candidates = [&](int t) __attribute__((always_inline)) {
@@ -671,7 +711,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     {   // prologue: DMA(0), DMA(1), Q(0), DMA(2); slab 0 must have landed for everybody before its first pair is read
         if (feeder) { const Feed f0 = next_feed(); dma_all(f0); const Feed f1 = next_feed(); dma_all(f1); }
         if (has_q || MODE != 0) load_q(qa);
-        if (feeder) { const Feed f2 = next_feed(); dma_all(f2); asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); }
+        if (feeder) { const Feed f2 = next_feed(); dma_all(f2); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HALF ? 12 : 20) : "memory"); }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (has_q || MODE != 0) read_pair(0, 0, eh[0], el[0]);
     }
@@ -696,7 +736,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
         }
     };
     auto wait_top = [&]() __attribute__((always_inline)) {
-        if (feeder) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (feeder) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HALF ? 4 : 8) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
     auto run_slab = [&](f32x4 (&q)[4], f32x4 (&qn)[4], int g_trace) __attribute__((always_inline)) { slab(q, qn, nb, g_trace); };
@@ -726,7 +766,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     if constexpr (TRACE) {
         __syncthreads();
         if (blockIdx.x == 7)
-            for (int i = threadIdx.x; i < 16 * 8 * 16; i += blockDim.x) trace[i] = reinterpret_cast<unsigned long long*>(smem + MG_NSLOT * MG_SLAB)[i];
+            for (int i = threadIdx.x; i < 16 * 8 * 16; i += blockDim.x) trace[i] = reinterpret_cast<unsigned long long*>(smem + MG_NSLOT * SLAB)[i];
     }
 }
 
@@ -734,7 +774,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
 // out[q * out_stride + chunk].  Needs an index without empty chunks (the chunk of an end row is found by counting ends).
 int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first,
                        int32_t n_q, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits,
-                       float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale) {
+                       float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale, bool half) {
     if (nq < 1 || nq > 32 || n_q < 1 || n_q > MG_WAVES || n_rows < 1 || first < 0 || first + n_q > n_queries) return RL_ERR_UNSUPPORTED;
     if (dim % 32 || dim < 32 || !(split_scale > 0.f) || !planes || !ends_bits) return RL_ERR_UNSUPPORTED;
     const int32_t nslab = dim / 32;
@@ -748,7 +788,7 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
         if (std::getenv("RAGLITE_GEMM_TRACE")) { (void)hipMalloc(&p, 16 * 8 * 16 * 8); (void)hipMemset(p, 0, 16 * 8 * 16 * 8); }
         return p;
     }();
-    if (trace && nq > 16) {  // diagnostic build: dump the 10th launch's slab timeline to stderr
+    if (trace && nq > 16 && !half) {  // diagnostic build: dump the 10th launch's slab timeline to stderr
         static int calls = 0;
         hipLaunchKernelGGL((maxsim_gemm_kernel<2, true>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, qmeta, n_q,
                            row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, trace, RowScoreArgs{});
@@ -765,12 +805,12 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
         }
         return RL_OK;
     }
-    if (nq <= 16)
-        hipLaunchKernelGGL((maxsim_gemm_kernel<1>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, qmeta, n_q,
-                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr, RowScoreArgs{});
-    else
-        hipLaunchKernelGGL((maxsim_gemm_kernel<2>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, qmeta, n_q,
-                           row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr, RowScoreArgs{});
+#define RL_MG_LAUNCH(NQB_, HALF_)                                                                                                     \
+    hipLaunchKernelGGL((maxsim_gemm_kernel<NQB_, false, 0, HALF_>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, \
+                       qmeta, n_q, row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr, RowScoreArgs{})
+    if (half) { if (nq <= 16) RL_MG_LAUNCH(1, true); else RL_MG_LAUNCH(2, true); }
+    else      { if (nq <= 16) RL_MG_LAUNCH(1, false); else RL_MG_LAUNCH(2, false); }
+#undef RL_MG_LAUNCH
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -867,7 +907,7 @@ int launch_score_planes_queries(const float* Q, int32_t nb, int32_t dim, float* 
 // tile_stride > 1).  Fused top-k (cand != nullptr): candidate lists, see RowScoreArgs.
 int launch_score_planes_pass(const void* planes, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, float* scores, int64_t ld,
                              const float* row_norm, const float* row_sumsq, int mode, int32_t tile_stride, const uint32_t* run_if,
-                             const CandArgs* cand, int n_cu, hipStream_t s, float split_scale) {
+                             const CandArgs* cand, int n_cu, hipStream_t s, float split_scale, bool half) {
     if (nb < 1 || n_rows < 1 || dim % 32 || dim < 32 || !(split_scale > 0.f) || !planes || tile_stride < 1) return RL_ERR_UNSUPPORTED;
     if ((mode == SCAN_COSINE && !row_norm) || (mode == SCAN_L2 && !row_sumsq)) return RL_ERR_INVALID;
     const int32_t nslab = dim / 32, groups = (nb + 31) / 32;
@@ -885,14 +925,13 @@ int launch_score_planes_pass(const void* planes, int64_t n_rows, int32_t dim, in
                 rs.overflow = cand->overflow; rs.cap = cand->cap; }
     const int64_t tiles = ((n_rows + MG_TM - 1) / MG_TM + tile_stride - 1) / tile_stride;
     const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles * rs.QT))), blk(512);
-    if (cand)
-        hipLaunchKernelGGL((maxsim_gemm_kernel<2, false, 2>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab,
-                           reinterpret_cast<const char*>(frag), nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, 0,
-                           nullptr, rs);
-    else
-        hipLaunchKernelGGL((maxsim_gemm_kernel<2, false, 1>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab,
-                           reinterpret_cast<const char*>(frag), nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, 0,
-                           nullptr, rs);
+#define RL_MG_LAUNCH(MODE_, HALF_)                                                                                                      \
+    hipLaunchKernelGGL((maxsim_gemm_kernel<2, false, MODE_, HALF_>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab,          \
+                       reinterpret_cast<const char*>(frag), nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, \
+                       0, nullptr, rs)
+    if (half) { if (cand) RL_MG_LAUNCH(2, true); else RL_MG_LAUNCH(1, true); }
+    else      { if (cand) RL_MG_LAUNCH(2, false); else RL_MG_LAUNCH(1, false); }
+#undef RL_MG_LAUNCH
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -900,11 +939,12 @@ int launch_score_planes_pass(const void* planes, int64_t n_rows, int32_t dim, in
 // Similarity (metric `mode`, scan.hip conventions) of nb queries against every row over the pre-split corpus image:
 // scores[q * ld + row].  Same results as launch_score_gemm in split arithmetic up to the summation order over K.
 int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores, int64_t ld,
-                        const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale) {
+                        const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale,
+                        bool half) {
     if (!(split_scale > 0.f) || !planes) return RL_ERR_UNSUPPORTED;
     RL_TRY(launch_score_planes_queries(Q, nb, dim, scratch, mode, s));
     return launch_score_planes_pass(planes, n_rows, dim, nb, scratch, scores, ld, row_norm, row_sumsq, mode, 1, nullptr, nullptr, n_cu, s,
-                                    split_scale);
+                                    split_scale, half);
 }
 
 }  // namespace rl

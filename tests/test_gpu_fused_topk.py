@@ -137,3 +137,31 @@ def test_fused_after_append_and_delete():
     assert np.array_equal(live[R2], R1) and np.array_equal(S2.view(np.uint32), S1.view(np.uint32))
     idx.close()
     ref.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+def test_f16_storage_big_batch_over_the_image(metric):
+    """fp16-stored index, B >= 96: the row-score GEMM (and, cosine / dot, the fused top-k) over the one-plane image.  Integer
+    data is exact in fp16 -> bit-identical to the fp32 oracle; unit-norm fp16 rows -> tolerance against float64."""
+    n, dim, B, k = 9000, 128, 130, 30
+    E = oracle.synth_matrix(7600, n, dim, "small_int")
+    Q = oracle.synth_matrix(7601, B, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E, metric=metric, storage="f16")
+    S, R = idx.search_rows(Q, k)
+    for b in (0, 64, B - 1):
+        es, ei = oracle.topk_desc(sim_fp32_exact(E, Q[b], metric), k)
+        assert np.array_equal(R[b], ei)
+        assert np.array_equal(S[b].view(np.uint32), es.astype(np.float32).view(np.uint32))
+    idx.close()
+    Ef = oracle.synth_matrix(7602, n, dim)
+    E16 = (Ef / np.linalg.norm(Ef, axis=1, keepdims=True)).astype(np.float16)
+    Qf = oracle.synth_matrix(7603, B, dim)
+    idx = raglite_amd.DeviceIndex(E16, metric=metric, storage="f16")
+    S, R = idx.search_rows(Qf, k)
+    Ev = E16.astype(np.float32)
+    for b in (0, B - 1):
+        assert_topk_close(S[b], R[b], oracle.similarity(Ev, Qf[b], metric), k, 1e-5 if metric == "l2" else _tol(Ev, Qf[b], metric))
+    with _env(RAGLITE_NO_FUSED_TOPK="1"):
+        S0, R0 = idx.search_rows(Qf, k)
+    assert np.array_equal(R, R0) and np.array_equal(S.view(np.uint32), S0.view(np.uint32))
+    idx.close()

@@ -160,3 +160,57 @@ def test_gemm_pass_follows_append_delete_and_arithmetic_switch():
     assert np.array_equal(g_c, d_c) and np.array_equal(g_s, d_s)
     idx.close()
     fresh.close()
+
+
+# ---- fp16-stored corpus (the reference's pgvector halfvec column, src/raglite/_typing.py:211-232): the same pass over the
+# one-plane image, two MFMA products per multiply ------------------------------------------------------------------------------
+@pytest.mark.parametrize("dim", [128, 384, 1024])  # (an fp16-stored index takes dims 128 ... 1024)
+@pytest.mark.parametrize("n_rows,nq,n_queries,kind", [
+    (20, 32, 3, "ragged"), (700, 17, 8, "ragged"), (9000, 32, 11, "ragged"), (5000, 1, 8, "rows"), (20_000, 32, 8, "long"),
+    (4097, 32, 16, "ragged"),
+])
+def test_gemm_pass_f16_storage_integer_bit_exact(dim, n_rows, nq, n_queries, kind):
+    rng = np.random.default_rng(dim * 11 + n_rows + nq)
+    off = _layout(kind, rng, n_rows)
+    n_chunks = len(off) - 1
+    E = oracle.synth_matrix(1400 + dim, n_rows, dim, "small_int")  # exact in fp16
+    Qb = np.stack([oracle.synth_matrix(1500 + i, nq, dim, "small_int") for i in range(n_queries)])
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot", storage="f16")
+    assert idx.arithmetic == "f16_stored"
+    k = min(50, n_chunks)
+    bs, bc = idx.maxsim_topk_batch(Qb, k)
+    for i in range(n_queries):
+        ws, wc = oracle.maxsim_topk(E, off, Qb[i], k, np.float32)
+        assert np.array_equal(bc[i][: len(wc)], wc), (i, bc[i][:8], wc[:8])
+        assert np.array_equal(bs[i][: len(wc)], ws), (i, bs[i][:8], ws[:8])
+    idx.close()
+
+
+def test_gemm_pass_f16_storage_float_data_and_lifecycle():
+    """Unit-norm rows rounded to fp16 (what RAGLite stores): scores within 1e-5 of the float64 oracle over the STORED values;
+    append extends the image, deleted chunks never appear."""
+    rng = np.random.default_rng(77)
+    n_rows, dim, nq, n_queries = 30_000, 128, 32, 9
+    off = ragged_offsets(rng, n_rows, 1, 12)
+    n_chunks = len(off) - 1
+    E = oracle.synth_matrix(1600, n_rows, dim)
+    E16 = (E / np.linalg.norm(E, axis=1, keepdims=True)).astype(np.float16)
+    Ev = E16.astype(np.float32)
+    Qb = np.stack([oracle.synth_matrix(1700 + i, nq, dim) for i in range(n_queries)])
+    split = int(off[n_chunks // 2])
+    idx = raglite_amd.DeviceIndex(E16[:split], off[: n_chunks // 2 + 1], metric="dot", storage="f16")
+    idx.append(E16[split:], np.diff(off[n_chunks // 2:]))
+    k = 40
+    bs, bc = idx.maxsim_topk_batch(Qb, k)
+    for i in range(n_queries):
+        ref = oracle.maxsim_scores(Ev, off, Qb[i], np.float64)
+        assert_topk_close(bs[i], bc[i], ref, k, 1e-5 * float(np.abs(ref).max()))
+    dead = np.unique(bc[:, 0])
+    idx.delete_chunks(dead)
+    bs2, bc2 = idx.maxsim_topk_batch(Qb, k)
+    assert not np.isin(bc2, dead).any()
+    for i in (0, n_queries - 1):
+        ref = oracle.maxsim_scores(Ev, off, Qb[i], np.float64).copy()
+        ref[dead] = -np.inf
+        assert_topk_close(bs2[i], bc2[i], ref, k, 1e-5 * float(np.abs(ref[np.isfinite(ref)]).max()))
+    idx.close()

@@ -1392,11 +1392,9 @@ def test_maxsim_batch_pairs_float_data_device_pointers(torch_cuda, storage):
         E = E.half()
     idx = raglite_amd.DeviceIndex(E, off, metric="dot", storage=storage)
     Eh = E.float().cpu().numpy()
-    if storage == "f16":  # every batch size goes through the pair kernel
-        bs, bc = idx.maxsim_topk_batch(Qb, 100)
-    else:  # fp32-stored: batches of three or more take the eight-query kernel (tests/test_gpu_gemm_pass.py); pairs here
-        parts = [idx.maxsim_topk_batch(Qb[i : i + 2], 100) for i in (0, 2, 4)]
-        bs, bc = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
+    # batches of three or more take the eight-query kernel over the corpus image (tests/test_gpu_gemm_pass.py); pairs here
+    parts = [idx.maxsim_topk_batch(Qb[i : i + 2], 100) for i in (0, 2, 4)]
+    bs, bc = torch.cat([p[0] for p in parts]), torch.cat([p[1] for p in parts])
     for i in range(6):
         ss, sc = idx.maxsim_topk(Qb[i], 100)
         assert torch.equal(bc[i], sc) and torch.equal(bs[i], ss)
