@@ -260,6 +260,21 @@ int rl_maxsim_topk_filtered(rl_index* index, const float* query_vecs, int32_t nq
                             const uint32_t* chunk_filter, float* out_scores, int32_t* out_chunks, int mem,
                             void* stream);
 
+/* The order-first-then-filter branch of the reference (src/raglite/_search.py:120-141, taken when the
+ * metadata filter matches more than 100 000 embedding rows): `ORDER BY dist LIMIT 1_000_000` over the
+ * UNFILTERED table, then the filter, then `ORDER BY dist LIMIT num_hits`.
+ *   rank_limit  > 0: per query only its rank_limit nearest live rows -- order (similarity descending,
+ *               row ascending), ties on the boundary resolved to the lowest rows (SQL leaves them
+ *               unspecified) -- are eligible; chunk_filter (may be NULL) is applied to those.
+ *               rank_limit >= live rows, or 0, gives exactly the *_filtered result.
+ * The cut is exact (three-level radix select over the score keys), not an ANN artefact. */
+int rl_search_rows_ranked(rl_index* index, const float* queries, int32_t n_queries, int32_t k,
+                          const uint32_t* chunk_filter, int64_t rank_limit, float* out_scores, int32_t* out_rows,
+                          int mem, void* stream);
+int rl_search_chunks_ranked(rl_index* index, const float* queries, int32_t n_queries, int32_t num_hits,
+                            int32_t k, const uint32_t* chunk_filter, int64_t rank_limit, float* out_scores,
+                            int32_t* out_chunks, int32_t* out_counts, int mem, void* stream);
+
 /* ---- device half of update_query_adapter ----------------------------------
  * src/raglite/_query_adapter.py:153-205 fits the query adapter from evals: per eval a vector search
  * (rl_search_chunks, batched over all evals), then for every retrieved chunk the row

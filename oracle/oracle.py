@@ -336,6 +336,35 @@ def search_chunks_filtered(E, row_to_chunk, q, n_hits, num_results, chunk_ok, me
     return group_chunk_max(s[keep], r2c[rows[keep]], num_results)
 
 
+def search_rows_ranked(E, row_to_chunk, q, k, chunk_ok, rank_limit, live_chunk=None, metric="cosine", dtype=np.float64):
+    """The order-first-then-filter branch of the reference (`_search.py:120-141`, taken when the filter matches more than
+    100 000 rows): `ORDER BY dist LIMIT rank_limit` over the unfiltered table (`:121-126`, rank_limit = 1 000 000 there), the
+    metadata filter on those rows (`:127-139`), `ORDER BY dist LIMIT k` (`:138-139`).  `live_chunk[c]` = chunk c is still in
+    the table (`_delete.py:148-176`); ties are resolved to the lowest row (SQL leaves them unspecified).
+    Unfilled slots are (-inf, -1)."""
+    r2c = np.asarray(row_to_chunk)
+    n = len(r2c)
+    live_rows = np.ones(n, dtype=bool) if live_chunk is None else np.asarray(live_chunk, dtype=bool)[r2c]
+    ok_rows = np.asarray(chunk_ok, dtype=bool)[r2c] & live_rows
+    sims = similarity(E, q, metric, dtype)
+    _, nearest = topk_desc(np.where(live_rows, sims, -np.inf), min(int(rank_limit), n))
+    eligible = np.zeros(n, dtype=bool)
+    eligible[nearest[nearest >= 0]] = True
+    eligible &= ok_rows
+    s, rows = topk_desc(np.where(eligible, sims, -np.inf), k)
+    dead = (rows >= 0) & ~eligible[np.clip(rows, 0, max(n - 1, 0))] if n else rows >= 0
+    return np.where(dead, -np.inf, s), np.where(dead, -1, rows)
+
+
+def search_chunks_ranked(E, row_to_chunk, q, n_hits, num_results, chunk_ok, rank_limit, live_chunk=None, metric="cosine",
+                         dtype=np.float64):
+    """`search_rows_ranked` followed by the per-chunk max of `_search.py:143-149`."""
+    r2c = np.asarray(row_to_chunk)
+    s, rows = search_rows_ranked(E, r2c, q, n_hits, chunk_ok, rank_limit, live_chunk, metric, dtype)
+    keep = rows >= 0
+    return group_chunk_max(s[keep], r2c[rows[keep]], num_results)
+
+
 def search_rows_filtered(E, row_to_chunk, q, k, chunk_ok, metric="cosine", dtype=np.float64):
     """Top-k rows among the rows of matching chunks; unfilled slots are (-inf, -1)."""
     r2c = np.asarray(row_to_chunk)

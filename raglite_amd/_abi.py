@@ -59,6 +59,9 @@ _SIGNATURES = {
     "rl_search_chunks_filtered": [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_void_p],
     "rl_maxsim_topk_filtered": [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
+    "rl_search_rows_ranked": [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_void_p],
+    "rl_search_chunks_ranked": [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_void_p,
+                                c_int, c_void_p],
     "rl_search_rows": [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_int, c_void_p],
     "rl_search_chunks": [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "rl_maxsim_topk": [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_int, c_void_p],

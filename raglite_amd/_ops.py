@@ -359,22 +359,25 @@ class DeviceIndex:
         return int(r.value), int(c.value)
 
     # -- a6 + a7 -------------------------------------------------------------------------------
-    def search_rows(self, queries, k: int, chunk_filter=None):
+    def search_rows(self, queries, k: int, chunk_filter=None, rank_limit: int | None = None):
         """Exact top-k rows: (scores (B,k) desc, rows (B,k) int32); padding = (-inf, -1).
-        chunk_filter: optional bool mask over chunks (the reference's filter-first branch, `_search.py:105-119`)."""
+        chunk_filter: optional bool mask over chunks (the reference's filter-first branch, `_search.py:105-119`).
+        rank_limit: the order-first-then-filter branch (`_search.py:120-141`): only the `rank_limit` nearest live rows of
+        each query are eligible, the filter applies to those (None / 0: no cut)."""
         a = _Args()
         p_q, B, single = self._queries(a, queries)
         o_s, p_s = a.out((B, k), np.float32)
         o_r, p_r = a.out((B, k), np.int32)
         p_f = self._filter(a, chunk_filter)
         self._prep(a)
-        check(lib().rl_search_rows_filtered(self._handle, p_q, B, k, p_f, p_s, p_r, a.mem, a.stream))
+        check(lib().rl_search_rows_ranked(self._handle, p_q, B, k, p_f, int(rank_limit or 0), p_s, p_r, a.mem, a.stream))
         return (o_s[0], o_r[0]) if single else (o_s, o_r)
 
     # -- a6 + a7 + a8 ----------------------------------------------------------------------------
-    def search_chunks(self, queries, num_hits: int, k: int, chunk_filter=None):
+    def search_chunks(self, queries, num_hits: int, k: int, chunk_filter=None, rank_limit: int | None = None):
         """Reference two-stage semantics (`src/raglite/_search.py:66-79,143-149`; with chunk_filter the
-        filter-first branch `:105-119`): returns (scores (B,k), chunk ordinals (B,k), counts (B,))."""
+        filter-first branch `:105-119`, with rank_limit the order-first-then-filter branch `:120-141`): returns
+        (scores (B,k), chunk ordinals (B,k), counts (B,))."""
         a = _Args()
         p_q, B, single = self._queries(a, queries)
         o_s, p_s = a.out((B, k), np.float32)
@@ -382,7 +385,8 @@ class DeviceIndex:
         o_n, p_n = a.out((B,), np.int32)
         p_f = self._filter(a, chunk_filter)
         self._prep(a)
-        check(lib().rl_search_chunks_filtered(self._handle, p_q, B, num_hits, k, p_f, p_s, p_c, p_n, a.mem, a.stream))
+        check(lib().rl_search_chunks_ranked(self._handle, p_q, B, num_hits, k, p_f, int(rank_limit or 0), p_s, p_c, p_n,
+                                            a.mem, a.stream))
         return (o_s[0], o_c[0], o_n[0]) if single else (o_s, o_c, o_n)
 
     # -- a9 ----------------------------------------------------------------------------------------

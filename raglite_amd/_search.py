@@ -256,17 +256,28 @@ def _check_limits(num_hits: int, num_results: int) -> None:
                          f"{_ops.K_MAX} the exact top-k kernel ranks; lower num_results or oversample")
 
 
+FILTER_FIRST_MAX_ROWS = 100_000  # `metadata_count <= 100_000` (`src/raglite/_search.py:105`)
+ORDER_FIRST_LIMIT = 1_000_000    # `.limit(1_000_000)` (`src/raglite/_search.py:124`)
+
+
 def _filtered_search(gi: GpuIndex, q, num_hits: int, num_results: int, flt: dict):
-    """Filter-first branch of the reference (`_search.py:96-119`): evaluate the JSON containment on the host
-    metadata, push the result down as a bitset over chunk ordinals, rank exactly among the matching rows."""
+    """The reference's filtered vector search (`_search.py:96-141`): evaluate the JSON containment on the host metadata and
+    push the result down as a bitset over chunk ordinals.  Like the reference, count the matching embedding rows first
+    (`:97-103`): up to 100 000 -> filter first, rank the matching rows (`:105-119`); more -> order first, i.e. only the
+    1 000 000 rows nearest to the query are eligible, then the filter (`:120-141`).  Both branches rank exactly; they
+    differ only on a corpus of more than 1 000 000 rows."""
     if gi.metadata is None:
         raise ValueError("GpuIndex was built without `metadata`; metadata_filter cannot be applied")
     allowed = np.fromiter((_matches(m, flt) for m in gi.metadata), dtype=bool, count=len(gi.metadata))
     if not allowed.any():
         return [], []
     _check_limits(num_hits, num_results)
+    offsets = gi.index.chunk_offsets
+    rows_per_chunk = np.diff(offsets) if offsets is not None else np.ones(len(allowed), dtype=np.int64)
+    matching_rows = int(rows_per_chunk[allowed].sum())
+    rank_limit = ORDER_FIRST_LIMIT if matching_rows > FILTER_FIRST_MAX_ROWS else None
     scores, chunks, count = gi.index.search_chunks(np.asarray(q, dtype=np.float32), num_hits, num_results,
-                                                   chunk_filter=allowed)
+                                                   chunk_filter=allowed, rank_limit=rank_limit)
     n = int(count)
     return [gi.chunk_ids[c] for c in chunks[:n].tolist()], [float(s) for s in scores[:n]]
 

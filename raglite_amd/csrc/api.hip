@@ -235,6 +235,7 @@ struct rl_index {
     rl::Pool planes, ends, qplanes;
     rl::Pool cand;                        // rl_maxsim_rerank: sanitised candidate ordinals
     rl::Pool fused;                       // fused batched top-k: sample scores, thresholds, candidate lists, counters
+    rl::Pool rankbuf;                     // rank cut (order-first-then-filter): histogram levels + tie counts
     // The scratch above is shared by all calls on this handle; `mu` serialises only their host side.  Device-mode calls are
     // asynchronous, so a call arriving on a DIFFERENT stream than the previous one first waits for that stream.
     hipStream_t last_stream = nullptr;
@@ -511,6 +512,7 @@ int rl_index_destroy(rl_index* idx) {
     idx->qplanes.release();
     idx->cand.release();
     idx->fused.release();
+    idx->rankbuf.release();
     select_workspace_free(idx->ws);
     idx->scores.release();
     idx->hits.release();
@@ -1024,8 +1026,10 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
     return RL_OK;
 }
 
+// rank_limit > 0: the order-first-then-filter branch (src/raglite/_search.py:120-141) -- only the rank_limit nearest LIVE
+// rows of a query are eligible, and among those the rows d_row_bits lets through are ranked.
 int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, float* d_scores, int32_t* d_rows,
-                       hipStream_t s, const uint32_t* d_row_bits = nullptr) {
+                       hipStream_t s, const uint32_t* d_row_bits = nullptr, int64_t rank_limit = 0) {
     const int64_t n = idx->n_rows;
     const int64_t ld = (n + 3) & ~int64_t(3);
     if (n == 0) {  // empty index: every slot is padding (the reference returns ([], []), tests/test_search.py:76-85)
@@ -1038,14 +1042,21 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
     RL_TRY(idx->scores.reserve((size_t)batch * ld * sizeof(float)));
     for (int32_t b0 = 0; b0 < B; b0 += batch) {
         const int32_t nb = std::min<int32_t>(batch, B - b0);
-        if (!d_row_bits) {  // big batches over the pre-split image: no score matrix at all
+        const bool cut = rank_limit > 0 && rank_limit < n;
+        if (!d_row_bits && !cut) {  // big batches over the pre-split image: no score matrix at all
             const int st = search_rows_fused(idx, d_q + (int64_t)b0 * idx->dim, nb, k, d_scores + (int64_t)b0 * k, d_rows + (int64_t)b0 * k, ld, s);
             if (st == RL_OK) continue;
             if (st != RL_ERR_UNSUPPORTED) return st;
         }
         bool hist_done = false;
-        RL_TRY(score_rows(idx, d_q + (int64_t)b0 * idx->dim, nb, ld, s, d_row_bits ? nullptr : &hist_done));
-        if (d_row_bits) RL_TRY(launch_mask_scores(idx->scores.as<float>(), nb, n, ld, d_row_bits, s));
+        RL_TRY(score_rows(idx, d_q + (int64_t)b0 * idx->dim, nb, ld, s, (d_row_bits || cut) ? nullptr : &hist_done));
+        if (cut) {  // tombstoned rows are not in the reference's table at all: out before the cut, then cut + filter
+            if (idx->live_row_bits) RL_TRY(launch_mask_scores(idx->scores.as<float>(), nb, n, ld, idx->live_row_bits, s));
+            RL_TRY(idx->rankbuf.reserve(rank_cut_scratch_bytes(nb, n)));
+            RL_TRY(launch_rank_cut(idx->scores.as<float>(), nb, n, ld, rank_limit, d_row_bits, idx->rankbuf.p, s));
+        } else if (d_row_bits) {
+            RL_TRY(launch_mask_scores(idx->scores.as<float>(), nb, n, ld, d_row_bits, s));
+        }
         float* o_s = d_scores + (int64_t)b0 * k;
         int32_t* o_r = d_rows + (int64_t)b0 * k;
         RL_TRY(launch_topk(idx->scores.as<float>(), nb, n, ld, k, idx->ws, o_s, o_r, s, nullptr, hist_done));
@@ -1064,7 +1075,7 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
             RL_TRY(launch_permute_rows(tmp_rows, pos, k, items, o_r, s));
         }
     }
-    if (d_row_bits) RL_TRY(launch_fix_masked(d_scores, d_rows, (int64_t)B * k, s));  // masked rows are "no hit"
+    if (d_row_bits || (rank_limit > 0 && rank_limit < n)) RL_TRY(launch_fix_masked(d_scores, d_rows, (int64_t)B * k, s));  // masked rows are "no hit"
     return RL_OK;
 }
 
@@ -1078,9 +1089,10 @@ int check_search_args(const rl_index* idx, const float* q, int32_t B, int32_t k,
 
 }  // namespace
 
-int rl_search_rows_filtered(rl_index* idx, const float* queries, int32_t B, int32_t k, const uint32_t* chunk_filter,
-                            float* out_scores, int32_t* out_rows, int mem, void* stream) {
+int rl_search_rows_ranked(rl_index* idx, const float* queries, int32_t B, int32_t k, const uint32_t* chunk_filter,
+                          int64_t rank_limit, float* out_scores, int32_t* out_rows, int mem, void* stream) {
     RL_TRY(check_search_args(idx, queries, B, k, "rl_search_rows"));
+    if (rank_limit < 0) return fail(RL_ERR_INVALID, "rl_search_rows: rank_limit must be >= 0 (0 = no cut)");
     if (B == 0) return RL_OK;
     if (!out_scores || !out_rows) return fail(RL_ERR_INVALID, "rl_search_rows: null output");
     hipStream_t s = as_stream(stream);
@@ -1095,10 +1107,15 @@ int rl_search_rows_filtered(rl_index* idx, const float* queries, int32_t B, int3
     RL_TRY(stage_in(queries, (size_t)B * idx->dim, mem, s, t_q, &d_q));
     RL_TRY(stage_out_begin(out_scores, (size_t)B * k, mem, t_s, &d_s));
     RL_TRY(stage_out_begin(out_rows, (size_t)B * k, mem, t_r, &d_r));
-    RL_TRY(search_rows_device(idx, d_q, B, k, d_s, d_r, s, d_bits));
+    RL_TRY(search_rows_device(idx, d_q, B, k, d_s, d_r, s, d_bits, rank_limit));
     RL_TRY(stage_out_end(out_scores, (size_t)B * k, mem, s, t_s));
     RL_TRY(stage_out_end(out_rows, (size_t)B * k, mem, s, t_r));
     return finish(mem, s);
+}
+
+int rl_search_rows_filtered(rl_index* idx, const float* queries, int32_t B, int32_t k, const uint32_t* chunk_filter,
+                            float* out_scores, int32_t* out_rows, int mem, void* stream) {
+    return rl_search_rows_ranked(idx, queries, B, k, chunk_filter, 0, out_scores, out_rows, mem, stream);
 }
 
 int rl_search_rows(rl_index* idx, const float* queries, int32_t B, int32_t k, float* out_scores, int32_t* out_rows,
@@ -1107,10 +1124,11 @@ int rl_search_rows(rl_index* idx, const float* queries, int32_t B, int32_t k, fl
 }
 
 // ---- a6 + a7 + a8 --------------------------------------------------------------------------------------
-int rl_search_chunks_filtered(rl_index* idx, const float* queries, int32_t B, int32_t num_hits, int32_t k,
-                              const uint32_t* chunk_filter, float* out_scores, int32_t* out_chunks, int32_t* out_counts,
-                              int mem, void* stream) {
+int rl_search_chunks_ranked(rl_index* idx, const float* queries, int32_t B, int32_t num_hits, int32_t k,
+                            const uint32_t* chunk_filter, int64_t rank_limit, float* out_scores, int32_t* out_chunks,
+                            int32_t* out_counts, int mem, void* stream) {
     RL_TRY(check_search_args(idx, queries, B, k, "rl_search_chunks"));
+    if (rank_limit < 0) return fail(RL_ERR_INVALID, "rl_search_chunks: rank_limit must be >= 0 (0 = no cut)");
     if (num_hits < 1 || num_hits > K_MAX) return fail(RL_ERR_INVALID, "rl_search_chunks: num_hits must be in [1, 2048]");
     if (B == 0) return RL_OK;
     if (!out_scores || !out_chunks || !out_counts) return fail(RL_ERR_INVALID, "rl_search_chunks: null output");
@@ -1130,12 +1148,18 @@ int rl_search_chunks_filtered(rl_index* idx, const float* queries, int32_t B, in
     RL_TRY(idx->hits.reserve((size_t)B * num_hits * 8));
     float* h_s = idx->hits.as<float>();
     int32_t* h_r = reinterpret_cast<int32_t*>(h_s + (size_t)B * num_hits);
-    RL_TRY(search_rows_device(idx, d_q, B, num_hits, h_s, h_r, s, d_bits));
+    RL_TRY(search_rows_device(idx, d_q, B, num_hits, h_s, h_r, s, d_bits, rank_limit));
     RL_TRY(launch_group_chunk_max(h_s, h_r, B, num_hits, idx->offsets, idx->n_chunks, k, d_s, d_c, d_n, s));
     RL_TRY(stage_out_end(out_scores, (size_t)B * k, mem, s, t_s));
     RL_TRY(stage_out_end(out_chunks, (size_t)B * k, mem, s, t_c));
     RL_TRY(stage_out_end(out_counts, (size_t)B, mem, s, t_n));
     return finish(mem, s);
+}
+
+int rl_search_chunks_filtered(rl_index* idx, const float* queries, int32_t B, int32_t num_hits, int32_t k,
+                              const uint32_t* chunk_filter, float* out_scores, int32_t* out_chunks, int32_t* out_counts,
+                              int mem, void* stream) {
+    return rl_search_chunks_ranked(idx, queries, B, num_hits, k, chunk_filter, 0, out_scores, out_chunks, out_counts, mem, stream);
 }
 
 int rl_search_chunks(rl_index* idx, const float* queries, int32_t B, int32_t num_hits, int32_t k, float* out_scores,

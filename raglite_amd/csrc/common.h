@@ -148,6 +148,12 @@ int launch_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_l
                       int32_t k_in, int32_t k, float* out_scores, int32_t* out_ids, hipStream_t s,
                       const uint32_t* counts = nullptr);  // counts (n_lists == 1): records list q really holds
 
+// select.hip, rank cut (order-first-then-filter, src/raglite/_search.py:120-141): rows outside the rank_limit best of their
+// query, and rows whose keep bit is clear, become -inf
+size_t rank_cut_scratch_bytes(int32_t n_queries, int64_t n);
+int launch_rank_cut(float* scores, int32_t n_queries, int64_t n, int64_t ld, int64_t rank_limit, const uint32_t* keep_bits,
+                    void* scratch, hipStream_t s);
+
 // mask.hip: validity bitsets (metadata filter pushed down to the device, tombstones of deleted chunks)
 int launch_expand_chunk_bits(const uint32_t* chunk_bits, const int32_t* row_to_chunk, int64_t n_rows,
                              const uint32_t* and_rows, uint32_t* row_bits, hipStream_t s);

@@ -477,6 +477,139 @@ int launch_topk(const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t 
     return RL_OK;
 }
 
+// ---- rank cut: the order-first-then-filter branch of the reference's vector search -----------------------------------------
+// src/raglite/_search.py:120-141: when the metadata filter matches more than 100 000 rows the reference first cuts the table to
+// its `LIMIT 1_000_000` nearest rows and filters THOSE.  Here: per query, the exact key T of the L-th best score by a
+// three-level radix select (11 + 11 + 10 bits, the histogram machinery of the top-k above), ties on T taken in row order
+// (SQL leaves them unspecified; the oracle and this file take the lowest rows) -- every row outside the L best, and every
+// row whose chunk fails the filter, is set to -inf before the ordinary top-k.  5 passes over the [B x N] scores; the corpus
+// scan that produced them read dim times as much.
+constexpr int RANK_CHUNK = 4096;  // rows per block of the ordered passes
+
+// Walks `levels` (1..3) histogram levels of query q (hq: [3][HIST_BINS], level 2 uses 1024 bins) from `need` = L: on
+// return prefix = the key's leading 11 / 22 / 32 bits, need = elements still to take inside that prefix.  Every thread must
+// call; h: HIST_BINS words of LDS.
+__device__ __forceinline__ void rank_prefix(const uint32_t* __restrict__ hq, int levels, uint32_t L, uint32_t* h, uint32_t* scratch,
+                                            uint32_t* thr, uint32_t& prefix, uint32_t& need) {
+    prefix = 0;
+    need = L;
+    for (int lv = 0; lv < levels; ++lv) {
+        const int nbins = lv == 2 ? 1024 : HIST_BINS;
+        for (int i = threadIdx.x; i < nbins; i += blockDim.x) h[i] = hq[lv * HIST_BINS + i];
+        __syncthreads();
+        find_threshold_bin(h, nbins, need, scratch, thr);
+        prefix = (prefix << (lv == 2 ? 10 : 11)) | thr[0];
+        need -= thr[1];
+        __syncthreads();
+    }
+}
+
+// LEVEL 0: histogram of the key's top 11 bits; LEVEL 1: of bits [20:10] among keys whose top 11 bits are the level-0
+// threshold bin; LEVEL 2: of bits [9:0] among keys matching the 22-bit prefix.
+template <int LEVEL>
+__global__ __launch_bounds__(256) void rank_level_kernel(const float* __restrict__ scores, int64_t n, int64_t ld, uint32_t L,
+                                                          uint32_t* __restrict__ hists) {
+    __shared__ uint32_t h[HIST_BINS];
+    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t thr[2];
+    const int q = blockIdx.y;
+    uint32_t* hq = hists + (int64_t)q * 3 * HIST_BINS;
+    uint32_t prefix, need;
+    rank_prefix(hq, LEVEL, L, h, scratch, thr, prefix, need);
+    for (int i = threadIdx.x; i < HIST_BINS; i += 256) h[i] = 0;
+    __syncthreads();
+    const float* s = scores + (int64_t)q * ld;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint32_t key = score_key(s[i]);
+        if (LEVEL == 0) atomicAdd(&h[key >> 21], 1u);
+        else if (LEVEL == 1) { if ((key >> 21) == prefix) atomicAdd(&h[(key >> 10) & 2047u], 1u); }
+        else { if ((key >> 10) == prefix) atomicAdd(&h[key & 1023u], 1u); }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HIST_BINS; i += 256)
+        if (h[i]) atomicAdd(&hq[LEVEL * HIST_BINS + i], h[i]);
+}
+
+// Keys equal to the threshold T in this block's RANK_CHUNK rows -> tie_counts[q][block].
+__global__ __launch_bounds__(256) void rank_tie_count_kernel(const float* __restrict__ scores, int64_t n, int64_t ld, uint32_t L,
+                                                              const uint32_t* __restrict__ hists, uint32_t* __restrict__ tie_counts) {
+    __shared__ uint32_t h[HIST_BINS];
+    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t thr[2];
+    const int q = blockIdx.y;
+    uint32_t T, need_eq;
+    rank_prefix(hists + (int64_t)q * 3 * HIST_BINS, 3, L, h, scratch, thr, T, need_eq);
+    const float* s = scores + (int64_t)q * ld;
+    const int64_t base = (int64_t)blockIdx.x * RANK_CHUNK;
+    uint32_t c = 0;
+    for (int it = 0; it < RANK_CHUNK / 256; ++it) {
+        const int64_t i = base + it * 256 + threadIdx.x;
+        if (i < n) c += score_key(s[i]) == T;
+    }
+    uint32_t total;
+    (void)block_inclusive_scan(c, scratch, total);
+    if (threadIdx.x == 0) tie_counts[(int64_t)q * gridDim.x + blockIdx.x] = total;
+}
+
+// scores[i] = -inf unless row i is among the L best of its query (ties on T: the need_eq lowest rows) AND, with keep_bits,
+// its bit is set (the metadata filter expanded to rows, tombstones included).
+__global__ __launch_bounds__(256) void rank_cut_kernel(float* __restrict__ scores, int64_t n, int64_t ld, uint32_t L,
+                                                        const uint32_t* __restrict__ hists, const uint32_t* __restrict__ tie_counts,
+                                                        const uint32_t* __restrict__ keep_bits) {
+    __shared__ uint32_t h[HIST_BINS];
+    __shared__ uint32_t scratch[8];
+    __shared__ uint32_t thr[2];
+    const int q = blockIdx.y;
+    uint32_t T, need_eq;
+    rank_prefix(hists + (int64_t)q * 3 * HIST_BINS, 3, L, h, scratch, thr, T, need_eq);
+    uint32_t before = 0;  // ties in the blocks before this one
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += tie_counts[(int64_t)q * gridDim.x + b];
+    uint32_t running;
+    (void)block_inclusive_scan(before, scratch, running);
+    __syncthreads();
+    float* s = scores + (int64_t)q * ld;
+    const int64_t base = (int64_t)blockIdx.x * RANK_CHUNK;
+    for (int it = 0; it < RANK_CHUNK / 256; ++it) {
+        const int64_t i = base + it * 256 + threadIdx.x;
+        const uint32_t key = i < n ? score_key(s[i]) : 0u;
+        const bool eq = i < n && key == T;
+        uint32_t tot;
+        const uint32_t incl = block_inclusive_scan(eq ? 1u : 0u, scratch, tot);
+        bool keep = key > T || (eq && running + incl - 1 < need_eq);
+        if (keep && keep_bits) keep = (keep_bits[i >> 5] >> (i & 31)) & 1u;
+        if (i < n && !keep) s[i] = -INFINITY;
+        running += tot;
+        __syncthreads();  // scratch is reused by the next scan
+    }
+}
+
+size_t rank_cut_scratch_bytes(int32_t nq, int64_t n) {
+    return (size_t)nq * (3 * HIST_BINS + (size_t)((n + RANK_CHUNK - 1) / RANK_CHUNK)) * sizeof(uint32_t);
+}
+
+// The cut + filter, in place on scores [nq x ld] (elements that do not take part already -inf).  rank_limit >= n: only the
+// filter.  scratch: rank_cut_scratch_bytes(nq, n).
+int launch_rank_cut(float* scores, int32_t nq, int64_t n, int64_t ld, int64_t rank_limit, const uint32_t* keep_bits, void* scratch,
+                    hipStream_t s) {
+    if (nq <= 0 || n <= 0) return RL_OK;
+    if (rank_limit < 1) return fail(RL_ERR_INVALID, "rank cut: rank_limit must be >= 1");
+    if (rank_limit >= n) return keep_bits ? launch_mask_scores(scores, nq, n, ld, keep_bits, s) : RL_OK;
+    if (n >= (int64_t)0x7fffffff) return fail(RL_ERR_UNSUPPORTED, "rank cut: more than 2^31-2 elements per query");
+    uint32_t* hists = static_cast<uint32_t*>(scratch);
+    uint32_t* ties = hists + (size_t)nq * 3 * HIST_BINS;
+    const int nblk = (int)((n + RANK_CHUNK - 1) / RANK_CHUNK);
+    const uint32_t L = (uint32_t)rank_limit;
+    RL_HIP(hipMemsetAsync(hists, 0, (size_t)nq * 3 * HIST_BINS * sizeof(uint32_t), s));
+    const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((n + 4095) / 4096, nq >= 64 ? 64 : 512));
+    hipLaunchKernelGGL(rank_level_kernel<0>, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, L, hists);
+    hipLaunchKernelGGL(rank_level_kernel<1>, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, L, hists);
+    hipLaunchKernelGGL(rank_level_kernel<2>, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, L, hists);
+    hipLaunchKernelGGL(rank_tie_count_kernel, dim3(nblk, nq), dim3(256), 0, s, scores, n, ld, L, hists, ties);
+    hipLaunchKernelGGL(rank_cut_kernel, dim3(nblk, nq), dim3(256), 0, s, scores, n, ld, L, hists, ties, keep_bits);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 // ---- a8: max(sim) GROUP BY chunk ORDER BY max DESC LIMIT k  (src/raglite/_search.py:143-149) -----------
 // Input: the a7 hits of each query, already sorted by (score desc, row asc).  A hit is kept iff no
 // earlier hit belongs to the same chunk -- the first hit of a chunk carries the chunk's max, and the

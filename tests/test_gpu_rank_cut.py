@@ -1,0 +1,137 @@
+"""GPU parity of the order-first-then-filter branch (`/root/reference/src/raglite/_search.py:120-141`): when the metadata
+filter matches more than 100 000 rows the reference cuts the table to the 1 000 000 rows nearest to the query and filters
+those.  `rl_search_rows_ranked` / `rl_search_chunks_ranked` make that cut exactly (three-level radix select over the score
+keys, ties on the boundary to the lowest rows); checked against `oracle.search_rows_ranked` with small limits so that the
+cut actually bites."""
+
+import numpy as np
+import pytest
+
+import raglite_amd
+from oracle import oracle
+from tests.util import ragged_offsets, sim_fp32_exact
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_ranked(S, R, sims, ok_rows, live_rows, limit, k, tol):
+    """Tolerance-aware check of a ranked search on float data (rounding may swap near-equal rows at the cut and inside
+    the list): every returned row is live, passes the filter, lies within `tol` of the cut, carries its oracle score; the
+    scores are non-increasing; and no eligible row that is clearly better than the last returned one is missing."""
+    sims = np.asarray(sims, np.float64)
+    live_sims = np.where(live_rows, sims, -np.inf)
+    cut = np.sort(live_sims)[::-1][min(limit, len(sims)) - 1]  # the limit-th best live score
+    got = R[R >= 0]
+    assert len(set(got.tolist())) == len(got) and (R[len(got):] == -1).all()
+    assert live_rows[got].all() and ok_rows[got].all()
+    assert (sims[got] >= cut - tol).all()
+    np.testing.assert_allclose(S[: len(got)], sims[got], rtol=0, atol=tol)
+    assert (np.diff(S[: len(got)]) <= 0).all()
+    sure = live_rows & ok_rows & (sims > cut + tol)  # certainly inside the cut and eligible
+    if len(got) == k:
+        missed = np.setdiff1d(np.nonzero(sure & (sims > S[k - 1] + 2 * tol))[0], got)
+    else:  # the list is not full: every surely-eligible row must be in it
+        missed = np.setdiff1d(np.nonzero(sure)[0], got)
+    assert missed.size == 0, missed[:5]
+
+
+def _pad(s, r, k):
+    s = np.concatenate([np.asarray(s, np.float64), np.full(k - len(s), -np.inf)])
+    r = np.concatenate([np.asarray(r, np.int64), np.full(k - len(r), -1)])
+    return s, r
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+@pytest.mark.parametrize("n,dim,B,limit", [(20_000, 64, 1, 1000), (20_000, 64, 3, 4097), (9000, 128, 130, 300), (5000, 32, 2, 1)])
+def test_rank_cut_integer_ties_bit_exact(metric, n, dim, B, limit):
+    """Small-integer data: hundreds of rows share the boundary score, so the cut runs through a tie group and the lowest
+    rows of the group must be the ones that stay eligible."""
+    rng = np.random.default_rng(n + B + limit)
+    off = ragged_offsets(rng, n, 1, 9)
+    n_chunks = len(off) - 1
+    r2c = np.repeat(np.arange(n_chunks), np.diff(off))
+    E = oracle.synth_matrix(8100 + dim, n, dim, "small_int")
+    Q = oracle.synth_matrix(8200 + B, B, dim, "small_int")
+    ok = rng.random(n_chunks) < 0.5
+    idx = raglite_amd.DeviceIndex(E, off, metric=metric)
+    k = 60
+    S, R = idx.search_rows(Q if B > 1 else Q[0], k, chunk_filter=ok, rank_limit=limit)
+    S, R = np.atleast_2d(S), np.atleast_2d(R)
+    for b in sorted({0, B // 2, B - 1}):
+        sims = sim_fp32_exact(E, Q[b], metric).astype(np.float64)
+        live = np.ones(n, bool)
+        _, nearest = oracle.topk_desc(sims, limit)
+        elig = np.zeros(n, bool)
+        elig[nearest] = True
+        elig &= ok[r2c] & live
+        es, er = oracle.topk_desc(np.where(elig, sims, -np.inf), k)
+        dead = ~elig[er]
+        es, er = _pad(np.where(dead, -np.inf, es), np.where(dead, -1, er), k)
+        assert np.array_equal(R[b], er), (b, R[b][:10], er[:10])
+        assert np.array_equal(S[b].astype(np.float64), es)
+    idx.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_rank_cut_float_data_tombstones_and_chunks(metric):
+    rng = np.random.default_rng(5)
+    n, dim, limit, num_hits, k = 30_000, 128, 2000, 80, 12
+    off = ragged_offsets(rng, n, 1, 12)
+    n_chunks = len(off) - 1
+    r2c = np.repeat(np.arange(n_chunks), np.diff(off))
+    E = oracle.synth_matrix(8300, n, dim)
+    Q = oracle.synth_matrix(8301, 4, dim)
+    ok = rng.random(n_chunks) < 0.6
+    idx = raglite_amd.DeviceIndex(E, off, metric=metric)
+    dead_chunks = rng.choice(n_chunks, 300, replace=False)
+    idx.delete_chunks(dead_chunks)
+    live = np.ones(n_chunks, bool)
+    live[dead_chunks] = False
+    S, R = idx.search_rows(Q, 50, chunk_filter=ok, rank_limit=limit)
+    CS, CC, CN = idx.search_chunks(Q, num_hits, k, chunk_filter=ok, rank_limit=limit)
+    for b in range(4):
+        sims = oracle.similarity(E, Q[b], metric)
+        tol = 3e-6 * max(1.0, float(np.abs(sims).max()))
+        _check_ranked(S[b].astype(np.float64), R[b], sims, ok[r2c], live[r2c], limit, 50, tol)
+        cs, cc = oracle.search_chunks_ranked(E, r2c, Q[b], num_hits, k, ok, limit, live, metric)
+        assert CN[b] == len(cc) and set(CC[b][: len(cc)].tolist()) == set(cc.tolist())  # (near-equal maxima may swap places)
+        np.testing.assert_allclose(np.sort(CS[b][: len(cc)]), np.sort(cs), rtol=0, atol=tol)
+    # a limit that covers every live row is the filter-first result, bit for bit
+    S1, R1 = idx.search_rows(Q, 50, chunk_filter=ok, rank_limit=n)
+    S2, R2 = idx.search_rows(Q, 50, chunk_filter=ok)
+    assert np.array_equal(R1, R2) and np.array_equal(S1.view(np.uint32), S2.view(np.uint32))
+    # no filter: just the rank_limit nearest rows (k > limit pads)
+    S3, R3 = idx.search_rows(Q[0], 50, rank_limit=7)
+    es, er = oracle.search_rows_ranked(E, r2c, Q[0], 50, np.ones(n_chunks, bool), 7, live, metric)
+    assert set(R3[:7].tolist()) == set(er[:7].tolist()) and (R3[7:] == -1).all() and np.isneginf(S3[7:]).all()
+    idx.close()
+
+
+def test_vector_search_takes_the_order_first_branch(monkeypatch):
+    """The host mirror counts the matching rows like `_search.py:97-105` and switches branch at the reference's thresholds
+    (shrunk here so that a small corpus exercises it)."""
+    from raglite_amd import _search
+
+    rng = np.random.default_rng(9)
+    n_chunks, dim = 400, 64
+    sizes = rng.integers(1, 6, n_chunks)
+    mats = [oracle.synth_matrix(8400 + i, int(sizes[i]), dim) for i in range(n_chunks)]
+    ids = [f"c{i:04d}" for i in range(n_chunks)]
+    meta = [{"topic": "a" if i % 3 else "b"} for i in range(n_chunks)]
+    gi = raglite_amd.GpuIndex(ids, mats, metric="cosine", metadata=meta)
+    E = np.concatenate(mats)
+    r2c = np.repeat(np.arange(n_chunks), sizes)
+    q = oracle.synth_matrix(8500, 1, dim)[0]
+    ok = np.array([m["topic"] == "a" for m in meta])
+    monkeypatch.setattr(_search, "FILTER_FIRST_MAX_ROWS", 10)
+    monkeypatch.setattr(_search, "ORDER_FIRST_LIMIT", 150)
+    got_ids, got_s = raglite_amd.vector_search(q, num_results=5, metadata_filter={"topic": "a"}, index=gi)
+    cs, cc = oracle.search_chunks_ranked(E, r2c, q, 4 * 10, 5, ok, 150, None, "cosine")
+    assert got_ids == [ids[c] for c in cc]
+    np.testing.assert_allclose(got_s, cs, rtol=0, atol=3e-6)
+    # and with the real thresholds (few matching rows) it is the filter-first result
+    monkeypatch.undo()
+    got_ids2, _ = raglite_amd.vector_search(q, num_results=5, metadata_filter={"topic": "a"}, index=gi)
+    cs2, cc2 = oracle.search_chunks_filtered(E, r2c, q, 4 * 10, 5, ok, "cosine")
+    assert got_ids2 == [ids[c] for c in cc2]
+    gi.close()

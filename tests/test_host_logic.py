@@ -15,6 +15,7 @@ class _FakeDeviceIndex:
     def __init__(self, E, off, metric):
         self.E, self.off, self.metric = E, off, metric
         self.n_rows, self.n_chunks = len(E), len(off) - 1
+        self.chunk_offsets = np.asarray(off, dtype=np.int64)
         self.calls = []
         self.alive = np.ones(self.n_chunks, bool)
 
@@ -23,19 +24,23 @@ class _FakeDeviceIndex:
         self.off = np.concatenate([self.off, self.off[-1] + np.cumsum(sizes)])
         self.alive = np.concatenate([self.alive, np.ones(len(sizes), bool)])
         self.n_rows, self.n_chunks = len(self.E), len(self.off) - 1
+        self.chunk_offsets = np.asarray(self.off, dtype=np.int64)
 
     def delete_chunks(self, ords):
         self.alive[np.asarray(ords)] = False
 
-    def search_chunks(self, q, num_hits, k, chunk_filter=None):
+    def search_chunks(self, q, num_hits, k, chunk_filter=None, rank_limit=None):
         if np.ndim(q) == 2:  # batched form: one row per query
-            outs = [self.search_chunks(qq, num_hits, k, chunk_filter) for qq in q]
+            outs = [self.search_chunks(qq, num_hits, k, chunk_filter, rank_limit) for qq in q]
             return tuple(np.stack([o[j] for o in outs]) for j in range(3))
         self.calls.append((num_hits, k))
+        self.rank_limits = getattr(self, "rank_limits", []) + [rank_limit]
         r2c = np.repeat(np.arange(self.n_chunks), np.diff(self.off))
         ok = np.ones(self.n_chunks, bool) if chunk_filter is None else np.asarray(chunk_filter, bool)
-        ok = ok & self.alive
-        s, c = oracle.search_chunks_filtered(self.E, r2c, q, num_hits, k, ok, self.metric, np.float32)
+        if rank_limit:
+            s, c = oracle.search_chunks_ranked(self.E, r2c, q, num_hits, k, ok, rank_limit, self.alive, self.metric, np.float32)
+        else:
+            s, c = oracle.search_chunks_filtered(self.E, r2c, q, num_hits, k, ok & self.alive, self.metric, np.float32)
         out_s = np.full(k, -np.inf, np.float32); out_c = np.full(k, -1, np.int32)
         out_s[: len(s)] = s; out_c[: len(c)] = c
         return out_s, out_c, np.int32(len(c))
@@ -499,3 +504,47 @@ def test_language_aware_reranker_selection():
         raglite_amd.set_language_detector(None)
     raglite_amd.rerank_chunks("hallo wereld", ["hallo wereld"], config=cfg, chunk_lookup=lambda ids: list(ids))
     assert other.calls == 1  # no langdetect in this image: "other"
+
+
+def test_vector_search_switches_branch_on_the_matching_row_count(monkeypatch):
+    """`_search.py:97-105`: more than 100 000 matching embedding rows -> order first (LIMIT 1 000 000), then filter."""
+    from raglite_amd import _search
+
+    rng = np.random.default_rng(3)
+    n_chunks, dim = 60, 16
+    sizes = rng.integers(1, 4, n_chunks)
+    off = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+    E = rng.standard_normal((int(off[-1]), dim)).astype(np.float32)
+    fake = _FakeDeviceIndex(E, off, "cosine")
+    gi = raglite_amd.GpuIndex.__new__(raglite_amd.GpuIndex)
+    gi.index, gi.chunk_ids, gi.query_adapter = fake, [f"c{i}" for i in range(n_chunks)], None
+    gi.metadata = [{"k": "x" if i % 2 else "y"} for i in range(n_chunks)]
+    q = rng.standard_normal(dim).astype(np.float32)
+    raglite_amd.vector_search(q, num_results=3, metadata_filter={"k": "x"}, index=gi)
+    assert fake.rank_limits[-1] is None  # a few dozen matching rows: filter first
+    monkeypatch.setattr(_search, "FILTER_FIRST_MAX_ROWS", 5)
+    ids, _ = raglite_amd.vector_search(q, num_results=3, metadata_filter={"k": "x"}, index=gi)
+    assert fake.rank_limits[-1] == 1_000_000 and len(ids) == 3
+
+
+def test_oracle_order_first_then_filter_branch():
+    """`oracle.search_rows_ranked` (`_search.py:120-141`): hand-checkable case -- the cut to the `rank_limit` nearest rows
+    happens BEFORE the filter, so a matching row outside the cut never surfaces, and a covering limit is the filter-first
+    result."""
+    from oracle import oracle
+
+    E = np.eye(6, dtype=np.float32)[:, :4].copy()
+    E[:, 0] = [0.9, 0.8, 0.7, 0.6, 0.5, 0.4]  # dot with q = e0 ranks the rows 0, 1, 2, 3, 4, 5
+    q = np.array([1, 0, 0, 0], np.float32)
+    r2c = np.array([0, 0, 1, 1, 2, 2])
+    ok = np.array([False, True, True])  # chunk 0 fails the filter
+    s, r = oracle.search_rows_ranked(E, r2c, q, 3, ok, 3, None, "dot")
+    assert r.tolist() == [2, -1, -1] and abs(s[0] - 1.7) < 1e-6 and np.isneginf(s[1:]).all()  # rows 0, 1 cut in, filtered out; 3.. cut out
+    s, r = oracle.search_rows_ranked(E, r2c, q, 3, ok, 6, None, "dot")
+    fs, fr = oracle.search_rows_filtered(E, r2c, q, 3, ok, "dot")
+    assert r.tolist() == fr.tolist() == [2, 3, 4]
+    live = np.array([True, False, True])  # chunk 1 deleted: rows 2, 3 are not in the table, the cut takes 0, 1, 4
+    s, r = oracle.search_rows_ranked(E, r2c, q, 3, ok, 3, live, "dot")
+    assert r.tolist() == [4, -1, -1]
+    cs, cc = oracle.search_chunks_ranked(E, r2c, q, 3, 2, ok, 3, live, "dot")
+    assert cc.tolist() == [2] and abs(cs[0] - 1.5) < 1e-6
