@@ -3,9 +3,12 @@
 // Replaces src/raglite/_embed.py:131-140 (and the whole-string variant :154,158-164).  HBM-bound:
 // algorithmic bytes = 4*T*dim read + (4 and/or 2)*S*dim written.  One wave per span; a token row of
 // dim = 1024 is 4 KiB = four coalesced 1-KiB `global_load_dwordx4` per wave.  Sums are kept in fp64
-// (the reference pools float64 arrays) -- at ~10 B/clk/CU of HBM the fp64 adds are <5 % of VALU time
-// -- so the fp16 result is bit-identical to the reference except where the mean sits within 1e-16
-// of a rounding boundary.
+// (the reference pools float64 arrays) -- at ~10 B/clk/CU of HBM the fp64 adds are <5 % of VALU time.
+// mean = sum * (1 / n) and out = mean * (1 / norm): one reciprocal per span instead of a 13-instruction IEEE fp64 divide per
+// element -- the 2 x 10^8 divides of a cfg 4 launch were 0.3 ms of its 2.3 (profiles/r02_pool_experiments.txt).  Against
+// sum / n / norm that is <= 2 ulp of fp64 (2e-16) more, on top of the summation-order difference to np.mean that was there
+// anyway: the fp16 result equals the reference's except where the value sits within ~1e-15 (relative) of an fp16 rounding
+// boundary -- 1 element in 10^12 (the golden fixtures, tests/golden/*, stay bit-identical).
 #include <cstdlib>
 
 #include "common.h"
@@ -104,22 +107,23 @@ __global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict_
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) acc[v][j] += (double)x0[v][j];
         }
-        const double n = (double)(e - b);  // n == 0 -> 0/0 = NaN like np.mean of zero rows
+        const double rn = 1.0 / (double)(e - b);  // zero rows: 0 * inf = NaN like np.mean of zero rows
         double ss = 0.0;
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                acc[v][j] = acc[v][j] / n;
+                acc[v][j] = acc[v][j] * rn;
                 if (ok[v]) ss += acc[v][j] * acc[v][j];
             }
         if (normalize) {
             double norm = sqrt(wave_sum(ss));
             if (eps > 0.0) norm = fmax(norm, eps);
+            const double rnorm = 1.0 / norm;
 #pragma unroll
             for (int v = 0; v < NV; ++v)
 #pragma unroll
-                for (int j = 0; j < VEC; ++j) acc[v][j] = acc[v][j] / norm;
+                for (int j = 0; j < VEC; ++j) acc[v][j] = acc[v][j] * rnorm;
         }
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
@@ -161,6 +165,14 @@ static int launch_t(const float* tokens, int32_t dim, const int64_t* sb, const i
     return RL_OK;
 }
 
+// Decision shared by the two DMA kernels (see pool_norm_coop_kernel): ordered spans that cover >= 3/4 of their row range.
+__device__ __forceinline__ bool pool_layout_cooperative(const unsigned int* __restrict__ layout, int64_t rows_all) {
+    const unsigned int bad = __builtin_amdgcn_readfirstlane(layout[0]);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(layout[2]), hi = __builtin_amdgcn_readfirstlane(layout[3]);
+    const unsigned long long covered = ((unsigned long long)hi << 32) | lo;
+    return bad == 0 && rows_all >= 0 && covered * 4ull >= (unsigned long long)rows_all * 3ull;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // LDS-DMA variant for dim = 256 * NV (bge-m3's 1024 = NV 4): the token rows stream HBM -> LDS by `global_load_lds_dwordx4`
 // into a wave-private ring, so the bytes in flight do not live in VGPRs (the register-staged kernel above keeps 64 of its
@@ -178,9 +190,11 @@ template <int NV, int RING_ = 0, bool NT = true, int WAVES = 8>
 __global__ __launch_bounds__(64 * WAVES) void pool_norm_dma_kernel(const float* __restrict__ tokens, const int64_t* __restrict__ span_begin,
                                                              const int64_t* __restrict__ span_end, int64_t n_spans, int normalize,
                                                              double eps, float* __restrict__ out_f32, uint16_t* __restrict__ out_f16,
-                                                             unsigned int* __restrict__ counter, int tune) {
+                                                             unsigned int* __restrict__ counter, int tune,
+                                                             const unsigned int* __restrict__ layout) {
     constexpr int DIM = 256 * NV, ROWB = DIM * 4, RING = RING_ > 0 ? RING_ : (16 / NV >= 8 ? 8 : 16 / NV), BATCH = 8;
     __shared__ __attribute__((aligned(16))) char smem[WAVES * RING * ROWB];
+    if (layout && pool_layout_cooperative(layout, span_end[n_spans - 1] - span_begin[0])) return;  // the cooperative kernel serves
     const int lane = threadIdx.x & 63;
     const int wv = wave_id();
     char* const ring = smem + wv * RING * ROWB;
@@ -276,22 +290,23 @@ __global__ __launch_bounds__(64 * WAVES) void pool_norm_dma_kernel(const float* 
                     for (int j = 0; j < 4; ++j) acc[v][j] += (double)x[v][j];
             }
             // ---- mean, L2 norm, cast, store: the statements of pool_norm_kernel (same bits) -----------------------------------------
-            const double n = (double)(e - b);  // n == 0 -> 0/0 = NaN like np.mean of zero rows
+            const double rn = 1.0 / (double)(e - b);  // zero rows: 0 * inf = NaN like np.mean of zero rows
             double ss = 0.0;
 #pragma unroll
             for (int v = 0; v < NV; ++v)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[v][j] = acc[v][j] / n;
+                    acc[v][j] = acc[v][j] * rn;
                     ss += acc[v][j] * acc[v][j];
                 }
             if (normalize) {
                 double norm = sqrt(wave_sum(ss));
                 if (eps > 0.0) norm = fmax(norm, eps);
+                const double rnorm = 1.0 / norm;
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[v][j] = acc[v][j] / norm;
+                    for (int j = 0; j < 4; ++j) acc[v][j] = acc[v][j] * rnorm;
             }
 #pragma unroll
             for (int v = 0; v < NV; ++v) {
@@ -311,16 +326,296 @@ __global__ __launch_bounds__(64 * WAVES) void pool_norm_dma_kernel(const float* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Workgroup-cooperative variant for ORDERED, (nearly) gap-free spans -- what late chunking produces (_embed.py:119-135:
+// consecutive sentences of a segment) and what one-span-per-string pooling is (:154).  The wave-private streams above stay at
+// ~6.0 TB/s whatever the ring depth, waves per CU or arithmetic (profiles/r02_pool_experiments.txt): 2 048 independent 4-KiB
+// granular streams.  Here a workgroup streams ONE contiguous row range, as the MaxSim stream kernel does at 7 TB/s:
+//   * LOADER waves 0-7: tiles of 8 rows (wave w brings row w), a ring of 4 tiles in LDS, one barrier per tile ("epoch");
+//     every loader sums a fixed 128-column slice of every row (fp64, rows in order -> the same sums as the kernels above) and,
+//     where a span ends, drops its two sums per lane into LDS -- nothing else: measured, every piece of arithmetic on the
+//     loaders' path between two barriers costs its full latency (the DMA issue alone stalls a wave ~0.5 k cycles per tile),
+//     finishing the spans there made 2.4 ms of 1.9;
+//   * FINISHER waves 8-15 (wave 8 + w finishes the columns of loader w; they share the SIMDs, whose VALUs the loaders leave
+//     idle) run the statements of pool_norm_kernel as a three-stage pipeline clocked by the same barriers:
+//       stage 1 (epoch after the span ended): mean = sum / n; per (virtual) lane L of pool_norm_kernel the 16 squares of
+//               columns (v * 64 + L) * 4 + j summed in (v, j) order -- lanes 0..7 of finisher w stand in for L = 8 w .. 8 w + 7,
+//               whose columns are the wave's own -- and dropped into LDS;
+//       stage 2 (next epoch): every finisher runs the 64-lane xor butterfly on the 64 partial sums, sqrt -> the norm;
+//       stage 3 (next epoch): mean / norm, cast, store.
+//     The same bits as pool_norm_kernel, including the order of the norm reduction.
+// Two span ends in one epoch insert an extra barrier.  Workgroup ranges are cut at span starts by rows (binary search in
+// span_begin), so the work is balanced to within one span without a queue; span bounds are staged through LDS, CAP at a time
+// (read from global memory where a span ends they are dependent scalar loads through a memory system busy streaming).
+// `layout` = {order violations, -, covered rows (u64)} from pool_layout_kernel: the kernel returns at once unless the spans are
+// ordered and cover >= 3/4 of the row range they span (the wave-private kernel then runs instead, guarded the other way).
+template <int NV>
+__global__ __launch_bounds__(1024) void pool_norm_coop_kernel(const float* __restrict__ tokens, const int64_t* __restrict__ span_begin,
+                                                               const int64_t* __restrict__ span_end, int64_t n_spans, int normalize,
+                                                               double eps, float* __restrict__ out_f32, uint16_t* __restrict__ out_f16,
+                                                               const unsigned int* __restrict__ layout, int dbg) {
+    // dbg (RAGLITE_POOL_DBG, timing experiments only): 1 = no LDS reads / adds, 2 = spans are not finished, 4 / 8 / 16 = the
+    // finishers skip stage 3 / 2 / 1, 32 = the loaders do not deposit
+    constexpr int DIM = 256 * NV, ROWB = DIM * 4, TILE = 8, RING = 4, CAP = 256, LOADERS = 8;
+    constexpr int OFF_DEP = RING * TILE * ROWB;       // [2][DIM] fp64: the loaders' sums of a finished span
+    constexpr int OFF_MEANS = OFF_DEP + 2 * DIM * 8;  // [DIM] fp64: the span's means (each finisher its own columns)
+    constexpr int OFF_SS = OFF_MEANS + DIM * 8;       // [2][64] fp64: per-virtual-lane sums of squares
+    constexpr int OFF_TAB = OFF_SS + 2 * 64 * 8;      // [2][CAP] int64: span bounds
+    __shared__ __attribute__((aligned(16))) char smem[OFF_TAB + 2 * CAP * 8];
+    auto uni = [](int64_t v) -> int64_t {
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    const int64_t R0 = uni(span_begin[0]), rows_all = uni(span_end[n_spans - 1]) - R0;
+    if (!pool_layout_cooperative(layout, rows_all)) return;  // whole grid
+    const int lane = threadIdx.x & 63, wv = wave_id();
+    const bool loader = wv < LOADERS;  // wave-uniform
+    const int cw = wv & (LOADERS - 1);  // the column slice this wave sums (loader) or finishes (finisher)
+    if (loader && !(dbg & 128)) __builtin_amdgcn_s_setprio(3);  // the stream comes first wherever a loader and a finisher compete for issue
+    const int64_t G = gridDim.x, b = blockIdx.x;
+    auto first_span_at = [&](int64_t row) -> int64_t {  // first span with begin >= row (spans are ordered)
+        int64_t lo = 0, hi = n_spans;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (uni(span_begin[mid]) >= row) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    };
+    const int64_t s_lo = b == 0 ? 0 : first_span_at(R0 + (rows_all * b) / G);
+    const int64_t s_hi = b + 1 == G ? n_spans : first_span_at(R0 + (rows_all * (b + 1)) / G);
+    if (s_lo >= s_hi) return;  // whole workgroup
+    const int64_t r_begin = uni(span_begin[s_lo]), r_end = uni(span_end[s_hi - 1]);
+    const int64_t n_tiles = (r_end - r_begin + TILE - 1) / TILE;
+    const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+    const uint32_t lane16 = 16u * lane;
+    double* const dep = reinterpret_cast<double*>(smem + OFF_DEP);
+    double* const means = reinterpret_cast<double*>(smem + OFF_MEANS);
+    double* const ssbuf = reinterpret_cast<double*>(smem + OFF_SS);
+    int64_t* const tb = reinterpret_cast<int64_t*>(smem + OFF_TAB);
+    int64_t* const te = tb + CAP;
+    // ---- the stream: loader w brings row w of every tile; exactly NV DMAs per loader and tile (rows past the range re-read the
+    // last row into a free slot) so that the in-order vmcnt bookkeeping is the same for every tile --------------------------------
+    auto fetch_tile = [&](int64_t t) __attribute__((always_inline)) {
+        int64_t row = r_begin + t * TILE + cw;
+        row = row < r_end ? row : r_end - 1;
+        const char* src = reinterpret_cast<const char*>(tokens) + uni(row) * (int64_t)ROWB;
+        const uint32_t lds = __builtin_amdgcn_readfirstlane(ring_lds + (uint32_t)((((int)(t % RING)) * TILE + cw) * ROWB));
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%3 nt" ::"s"(lds), "v"(lane16), "s"(src), "n"(v * 1024)
+                         : "memory", "m0");
+    };
+    // ---- this lane's two columns: slice cw = the columns that lanes 8 cw .. 8 cw + 7 of pool_norm_kernel own ---------------------
+    const int vq = lane >> 4, li = lane & 15;
+    const bool active = vq < NV;
+    const int c0 = (active ? vq : 0) * 256 + 32 * cw + 2 * li;
+    double acc0 = 0.0, acc1 = 0.0;
+    // ---- span bounds, CAP at a time in LDS ----------------------------------------------------------------------------------------
+    int64_t s = s_lo, s_base = s_lo;
+    auto load_table = [&]() __attribute__((always_inline)) {  // spans s_base .. s_base + CAP - 1 (workgroup-uniform call)
+        __syncthreads();  // nobody still reads the previous batch
+        for (int i = threadIdx.x; i < CAP; i += blockDim.x) {
+            const int64_t j = s_base + i;
+            tb[i] = j < s_hi ? span_begin[j] : 0;
+            te[i] = j < s_hi ? span_end[j] : 0;
+        }
+        __syncthreads();
+    };
+    load_table();
+    constexpr int64_t NO_SPAN = INT64_MAX;
+    auto fetch_bounds = [&](int64_t idx, int64_t& b_, int64_t& e_) __attribute__((always_inline)) {
+        if (idx >= s_hi) { b_ = NO_SPAN; e_ = NO_SPAN; return; }
+        if (idx - s_base >= CAP) { s_base = idx; load_table(); }
+        b_ = uni(tb[idx - s_base]);
+        e_ = uni(te[idx - s_base]);
+    };
+    int64_t cb, ce, nb, ne;  // the open span s and the one after it (read a whole span before it is needed)
+    fetch_bounds(s, cb, ce);
+    fetch_bounds(s + 1, nb, ne);
+    // ---- the finishing pipeline.  p0: deposited this epoch; p1: after stage 1; p2: after stage 2.  The flags, span ordinals and
+    // row counts are workgroup-uniform (every wave keeps them); the data lives in the finishers ------------------------------------
+    unsigned k0 = 0;  // spans deposited so far
+    bool p0 = false, p1 = false, p2 = false;
+    int64_t p0_s = 0, p1_s = 0, p2_s = 0, p0_n = 0;
+    unsigned p0_par = 0, p1_par = 0;
+    double f_m0 = 0.0, f_m1 = 0.0;   // finisher: means of the span in p1
+    double g_m0 = 0.0, g_m1 = 0.0, g_norm = 1.0;  // finisher: means and norm of the span in p2
+    auto store_span = [&](int64_t sp, double m0, double m1) __attribute__((always_inline)) {
+        if (active) {
+            if (out_f32) *reinterpret_cast<float2*>(out_f32 + sp * (int64_t)DIM + c0) = make_float2((float)m0, (float)m1);
+            if (out_f16) {
+                ushort2 h;
+                h.x = f64_to_f16_bits(m0); h.y = f64_to_f16_bits(m1);
+                if (dbg & 64) asm volatile("" ::"v"(h.x), "v"(h.y));  // experiment: everything but the store instruction
+                else *reinterpret_cast<ushort2*>(out_f16 + sp * (int64_t)DIM + c0) = h;
+            }
+        }
+    };
+    auto advance = [&]() __attribute__((always_inline)) {  // right after a workgroup barrier
+        if (p2) {  // stage 3
+            if (!loader && !(dbg & 4)) store_span(p2_s, g_m0 * g_norm, g_m1 * g_norm);  // (g_norm holds 1 / norm)
+            p2 = false;
+        }
+        if (p1) {  // stage 2
+            if (!loader && !(dbg & 8)) {
+                double norm = sqrt(wave_sum(ssbuf[p1_par * 64 + lane]));
+                if (eps > 0.0) norm = fmax(norm, eps);
+                g_m0 = f_m0; g_m1 = f_m1; g_norm = 1.0 / norm;
+            }
+            p2_s = p1_s;
+            p2 = true;
+            p1 = false;
+        }
+        if (p0) {  // stage 1
+            if (!loader && !(dbg & 16)) {
+                const double rn = 1.0 / (double)p0_n;  // zero rows: 0 * inf = NaN like np.mean of zero rows
+                double2 sums = {0.0, 0.0};
+                if (active) sums = *reinterpret_cast<const double2*>(dep + p0_par * DIM + c0);
+                const double m0 = sums.x * rn, m1 = sums.y * rn;
+                if (!normalize) {
+                    store_span(p0_s, m0, m1);
+                } else {
+                    if (active) {
+                        double2 m;
+                        m.x = m0; m.y = m1;
+                        *reinterpret_cast<double2*>(means + c0) = m;
+                    }
+                    if (lane < 8) {  // (the wave's own LDS writes above are visible to it: same wave, in order)
+                        const int L = 8 * cw + lane;
+                        double ss = 0.0;
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) {
+                            const double2 a = *reinterpret_cast<const double2*>(means + (v * 64 + L) * 4);
+                            const double2 c = *reinterpret_cast<const double2*>(means + (v * 64 + L) * 4 + 2);
+                            ss += a.x * a.x; ss += a.y * a.y; ss += c.x * c.x; ss += c.y * c.y;
+                        }
+                        ssbuf[p0_par * 64 + L] = ss;
+                    }
+                    f_m0 = m0; f_m1 = m1;
+                }
+            }
+            if (normalize) { p1_s = p0_s; p1_par = p0_par; p1 = true; }
+            p0 = false;
+        }
+    };
+    auto finish_span = [&]() __attribute__((always_inline)) {  // span s = [cb, ce) is complete (workgroup-uniform)
+        if (p0) {  // the previous span ended in this epoch too: an epoch of its own
+            __syncthreads();
+            advance();
+        }
+        if (loader && active && !(dbg & 32)) {
+            double2 sums;
+            sums.x = acc0; sums.y = acc1;
+            *reinterpret_cast<double2*>(dep + (k0 & 1u) * DIM + c0) = sums;
+        }
+        acc0 = 0.0;
+        acc1 = 0.0;
+        p0_s = s; p0_n = ce - cb; p0_par = k0 & 1u;
+        p0 = true;
+        ++k0;
+        ++s;
+        cb = nb;
+        ce = ne;
+        fetch_bounds(s + 1, nb, ne);
+    };
+    if (n_tiles > 0 && loader)  // (a range of empty spans only has no rows to stream)
+        for (int t = 0; t < RING - 1; ++t) fetch_tile(t);
+    for (int64_t t = 0; t < n_tiles; ++t) {
+        // VMEM retires in order: at most the NV DMAs of tiles t + 1 and t + 2 outstanding <=> this loader's row of tile t landed
+        if (loader) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NV) : "memory");
+        __syncthreads();  // every row of tile t is in LDS; everybody is done with tile t - 1
+        if (loader) fetch_tile(t + RING - 1);  // into the slot of tile t - 1
+        advance();
+        const char* const tile = smem + ((int)(t % RING)) * TILE * ROWB;
+        const int64_t row0 = r_begin + t * TILE;
+        const int64_t row1 = row0 + TILE < r_end ? row0 + TILE : r_end;
+        if (dbg & 1) continue;
+        if (!(dbg & 2))
+            while (row0 >= ce) finish_span();  // the open span ended with the previous tile (also: empty spans on the way)
+        const bool inside = row0 >= cb && row1 <= ce;
+        const bool one_cut = row0 >= cb && ce < row1 && nb == ce && ne >= row1;  // one span end inside, the next span adjoins
+        const bool sum = loader && active;
+        if (inside || one_cut || (dbg & 2)) {
+            // All LDS reads first, then the adds in row order (a read-then-add per row exposes the LDS latency eight times).  With
+            // one span end inside the tile: rows before it, the deposit, rows after it -- all under uniform branches (an add of a
+            // masked 0.0 would turn a sum of -0.0 into +0.0).
+            const int cut = (inside || (dbg & 2)) ? TILE : (int)(ce - row0);  // 1 .. TILE - 1 with one_cut
+            const int live = (int)(row1 - row0);                               // TILE except in the range's last tile
+            float2 x[TILE];
+            if (sum) {
+#pragma unroll
+                for (int i = 0; i < TILE; ++i) x[i] = *reinterpret_cast<const float2*>(tile + i * ROWB + c0 * 4);
+#pragma unroll
+                for (int i = 0; i < TILE; ++i)
+                    if (i < cut && i < live) {
+                        acc0 += (double)x[i].x;
+                        acc1 += (double)x[i].y;
+                    }
+            }
+            if (cut < TILE) {
+                finish_span();
+                if (sum) {
+#pragma unroll
+                    for (int i = 1; i < TILE; ++i)
+                        if (i >= cut && i < live) {
+                            acc0 += (double)x[i].x;
+                            acc1 += (double)x[i].y;
+                        }
+                }
+            }
+        } else {  // several span ends or a gap inside the tile: row by row
+            float2 x = make_float2(0.f, 0.f);
+            if (sum) x = *reinterpret_cast<const float2*>(tile + c0 * 4);  // one row ahead of the walk
+#pragma unroll 1
+            for (int i = 0; i < TILE; ++i) {
+                const int64_t row = row0 + i;
+                if (row >= r_end) break;
+                float2 xn = x;
+                if (sum) xn = *reinterpret_cast<const float2*>(tile + (i + 1 < TILE ? i + 1 : i) * ROWB + c0 * 4);
+                while (row >= ce) finish_span();
+                if (row >= cb && sum) {  // (rows in a gap between spans are skipped)
+                    acc0 += (double)x.x;
+                    acc1 += (double)x.y;
+                }
+                x = xn;
+            }
+        }
+    }
+    while (s < s_hi && !(dbg & 3)) finish_span();  // the last span of the range and empty spans after it
+    while (p0 || p1 || p2) {                       // drain the pipeline
+        __syncthreads();
+        advance();
+    }
+    if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
+}
+
+// {order violations, -, covered rows (u64)} of a span list, for the guards of the two DMA kernels.
+__global__ __launch_bounds__(256) void pool_layout_kernel(const int64_t* __restrict__ span_begin, const int64_t* __restrict__ span_end,
+                                                           int64_t n_spans, unsigned int* __restrict__ layout) {
+    unsigned int bad = 0;
+    unsigned long long covered = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_spans; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = span_begin[i], e = span_end[i];
+        bad += (e < b) || (i + 1 < n_spans && span_begin[i + 1] < e);
+        covered += (unsigned long long)(e > b ? e - b : 0);
+    }
+    for (int o = 32; o > 0; o >>= 1) { bad += __shfl_xor(bad, o, 64); covered += __shfl_xor(covered, o, 64); }
+    if ((threadIdx.x & 63) == 0 && (bad || covered)) {
+        if (bad) atomicAdd(layout, bad);
+        atomicAdd(reinterpret_cast<unsigned long long*>(layout + 2), covered);
+    }
+}
+
 namespace {
 // One zeroed 4-byte span counter per launch, from a small per-thread pool of device words (a launch may still be running
 // when the same host thread enqueues the next one on another stream).
 unsigned int* next_span_counter(hipStream_t s) {
-    constexpr int SLOTS = 64 * 8;  // 8 words (one per XCD) per launch
+    constexpr int WORDS = 16, SLOTS = 64;  // per launch: 8 span counters (one per XCD) + 4 words of span-layout summary
     static thread_local unsigned int* pool = nullptr;
     static thread_local int at = 0;
-    if (!pool && hipMalloc(&pool, SLOTS * sizeof(unsigned int)) != hipSuccess) { pool = nullptr; (void)hipGetLastError(); return nullptr; }
-    unsigned int* c = pool + 8 * (at++ % (SLOTS / 8));
-    if (hipMemsetAsync(c, 0, 8 * sizeof(unsigned int), s) != hipSuccess) return nullptr;
+    if (!pool && hipMalloc(&pool, SLOTS * WORDS * sizeof(unsigned int)) != hipSuccess) { pool = nullptr; (void)hipGetLastError(); return nullptr; }
+    unsigned int* c = pool + WORDS * (at++ % SLOTS);
+    if (hipMemsetAsync(c, 0, WORDS * sizeof(unsigned int), s) != hipSuccess) return nullptr;
     return c;
 }
 }  // namespace
@@ -337,7 +632,22 @@ int launch_pool_norm(const float* tokens, int32_t dim, const int64_t* sb, const 
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
             const int blocks = (int)std::min<int64_t>(n_cu, (n_spans + 63) / 64);
             static const int tune = std::getenv("RAGLITE_POOL_BATCH") ? std::atoi(std::getenv("RAGLITE_POOL_BATCH")) : 0;
-#define RL_POOL_DMA(NV) hipLaunchKernelGGL((pool_norm_dma_kernel<NV>), dim3(blocks), dim3(512), 0, s, tokens, sb, se, n_spans, normalize, eps, o32, o16, counter, tune)
+            // The workgroup-cooperative stream (pool_norm_coop_kernel) is opt-in: RAGLITE_POOL_COOP=1 (read per call: tests flip it).
+            // Measured on the cfg 4 shape it streams at 6.9 TB/s with the spans left unfinished but lands where the wave-private
+            // kernel is (2.38 vs 2.37 ms, same box) once they are finished -- wherever the finishing arithmetic runs
+            // (profiles/r02_pool_experiments.txt) -- so the simpler kernel stays the default.
+            const char* co = std::getenv("RAGLITE_POOL_COOP");
+            const bool no_coop = !(co && co[0] && co[0] != '0');
+            unsigned int* layout = no_coop ? nullptr : counter + 8;
+            const char* dbg_env = std::getenv("RAGLITE_POOL_DBG");
+            const int dbg = dbg_env ? std::atoi(dbg_env) : 0;
+            if (layout)
+                hipLaunchKernelGGL(pool_layout_kernel, dim3((unsigned)std::min<int64_t>(64, (n_spans + 1023) / 1024)), dim3(256), 0, s, sb, se, n_spans, layout);
+#define RL_POOL_DMA(NV)                                                                                                                     \
+    do {                                                                                                                                    \
+        if (layout) hipLaunchKernelGGL((pool_norm_coop_kernel<NV>), dim3(blocks), dim3(1024), 0, s, tokens, sb, se, n_spans, normalize, eps, o32, o16, layout, dbg); \
+        hipLaunchKernelGGL((pool_norm_dma_kernel<NV>), dim3(blocks), dim3(512), 0, s, tokens, sb, se, n_spans, normalize, eps, o32, o16, counter, tune, layout); \
+    } while (0)
             if (dim == 256) RL_POOL_DMA(1); else if (dim == 512) RL_POOL_DMA(2); else RL_POOL_DMA(4);
 #undef RL_POOL_DMA
             RL_HIP(hipGetLastError());
