@@ -31,8 +31,21 @@ struct VecLoad<1> {
     static __device__ __forceinline__ void load(const float* p, float (&v)[1]) { v[0] = __builtin_nontemporal_load(p); }
 };
 
+// fp64 -> fp16 with ONE rounding (RNE), as numpy's astype(float16) does (_embed.py:140).  There is no such instruction and the
+// compiler's lowering of (_Float16)double is ~40 integer instructions per element -- 10^8 of them per cfg 4 launch, more
+// VALU work than the sums.  Instead: fp64 -> fp32 rounded TO ODD (v_cvt_f32_f64 rounds to nearest; when that was inexact,
+// of the two floats around x take the one with the odd significand), then v_cvt_f16_f32: with 13 spare significand bits the
+// second rounding of a round-to-odd intermediate equals the direct rounding (Boldo & Melquiond 2008) -- bit-identical for
+// every input (checked against numpy on all fp16 midpoints and their fp64 neighbours), NaN stays NaN.
 __device__ __forceinline__ uint16_t f64_to_f16_bits(double x) {
-    const _Float16 h = (_Float16)x;  // single correctly-rounded (RNE) conversion
+    const float f = (float)x;
+    const double back = (double)f;  // exact
+    uint32_t u = __float_as_uint(f);
+    if (back != x && x == x) {      // inexact, not NaN
+        const uint32_t other = fabs(back) < fabs(x) ? u + 1u : u - 1u;  // the float on the other side of x
+        u = (u & 1u) ? u : other;
+    }
+    const _Float16 h = (_Float16)__uint_as_float(u);
     uint16_t b;
     __builtin_memcpy(&b, &h, 2);
     return b;
