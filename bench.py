@@ -79,6 +79,7 @@ def main() -> None:
     # NOT the BASELINE.json configuration (that one is fp32, the default): the fp16-stored index of SURVEY.md 8f-1,
     # reported under its own workload name so it can never be mistaken for the headline number.
     ap.add_argument("--storage", choices=("f32", "f16"), default="f32", help=argparse.SUPPRESS)
+    ap.add_argument("--no-f16", action="store_true", help="skip the fp16-stored block (the reference's storage dtype, own workload name)")
     ap.add_argument("--queries-per-step", type=int, default=QUERIES_PER_STEP, help=argparse.SUPPRESS)
     # A/B: the exact fp32 MFMA chain as the HEADLINE arithmetic (the default run reports it in `exact_fp32` anyway)
     ap.add_argument("--exact-fp32", action="store_true", help=argparse.SUPPRESS)
@@ -277,6 +278,42 @@ def main() -> None:
     else:
         exact_last = None
 
+    # ---- the reference's real storage dtype (pgvector halfvec, `_typing.py:211-232`; `_embed.py:140` casts to fp16): the same
+    # workload over the SAME corpus rounded to fp16, under its own workload name -- not the BASELINE config, driver-timed ----------
+    if single and args.storage == "f32" and not args.exact_fp32 and not args.no_f16:
+        E16 = E.half()
+        idx16 = raglite_amd.DeviceIndex(E16, local_off, metric="dot", storage="f16")
+
+        def step16(i: int):
+            return idx16.maxsim_topk_batch(queries[i % n_batches], TOPK)
+
+        for i in range(2):
+            step16(i)
+        fence()
+        f_steps = max(5, min(args.steps, 10))
+        t0 = time.perf_counter()
+        for i in range(f_steps):
+            last16 = step16(i)
+        fence()
+        f_elapsed = time.perf_counter() - t0
+        qv8 = queries[0, :8].reshape(8 * NQ, DIM)
+        idx16.time_kernel(3, qv8, 3)
+        f_ms = idx16.time_kernel(3, qv8, iters) / iters
+        f_flops = 2.0 * 2.0 * 8 * NQ * rows_local * DIM  # two fp16 MFMA products per multiply (q_hi.e + q_lo.e)
+        # spot check: query 0 of the last batch against the fp32 NumPy oracle over the stored (fp16) values, first 50 k rows
+        result["f16_stored"] = {
+            "workload": "maxsim_32x1000000_d1024_top100_F16_STORED_CORPUS_not_the_baseline_config",
+            "value": f_steps * qps / f_elapsed, "unit": "queries/s", "steps": f_steps, "ms_per_step": 1e3 * f_elapsed / f_steps,
+            "arithmetic": idx16.arithmetic, "kernel": "rl::maxsim_gemm_kernel<2, false, 0, true>", "kernel_ms": f_ms,
+            "queries_per_launch": 8, "bound": "mfma", "achieved_tflops": f_flops / (f_ms * 1e-3) / 1e12,
+            "frac": f_flops / (f_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TF,
+            "hbm_frac": 2.0 * rows_local * DIM / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        }
+        f16_last = tuple(x.clone() for x in last16)
+        f16_index, f16_matrix = idx16, E16
+    else:
+        f16_last = None
+
     # ---- recall@100, score error and CPU baseline: NumPy oracle on the host cores (rank 0, N = 1) -------------------
     if single and not args.no_cpu_baseline:
         from oracle import oracle
@@ -321,6 +358,20 @@ def main() -> None:
         result["score_max_abs_err_vs_f64_slab"] = float(np.max(np.abs(ss - got64)))
         result["score_check"] = (f"{qps} queries x top-{ks} of the first {c1} chunks ({r1} rows) against float64; "
                                  f"recall and score_max_abs_err: all {qps} queries of the last timed step, full corpus, fp32 NumPy oracle")
+        if f16_last is not None:  # the fp16-stored run: same slab check over the STORED (fp16) values
+            slab16 = raglite_amd.DeviceIndex(f16_matrix[:r1], off[: c1 + 1], metric="dot", storage="f16")
+            s16, c16 = (x.cpu().numpy() for x in slab16.maxsim_topk_batch(queries[(args.steps - 1) % n_batches], ks))
+            slab16.close()
+            ref16 = oracle.maxsim_scores_batch(f16_matrix[:r1].float().cpu().numpy(), off[: c1 + 1], q_host, np.float64)
+            got16 = np.take_along_axis(ref16, c16.astype(np.int64), axis=1)
+            top16 = np.argsort(-ref16, axis=1, kind="stable")[:, :TOPK]
+            result["f16_stored"].update({
+                "score_max_rel_err": float(np.max(np.abs(s16 - got16) / np.maximum(np.abs(got16), 1e-30))),
+                "recall_at_100_slab": float(np.mean([len(set(top16[b].tolist()) & set(c16[b][:TOPK].tolist())) / TOPK for b in range(qps)])),
+                "check": f"{qps} queries x top-{ks} of the first {c1} chunks against float64 over the stored fp16 values",
+            })
+            del ref16
+            f16_index.close()
         result["cpu_baseline"] = {
             "value": qps / cpu_s, "unit": "queries/s", "cores": int(cores), "blas_threads": int(cores), "kind": "port",
             "sample": f"{qps} queries (one step) of the full workload ({NQ}x{n_rows}x{DIM} fp32, ragged chunks, top-{TOPK}) through "
