@@ -26,14 +26,14 @@ if has bench; then
   cat "$OUT/bench.json"; tail -5 "$OUT/bench.err"
 fi
 if has prof; then
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-configs > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err" ); echo "prof exit $?" | tee -a "$OUT/summary.txt"
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-configs --no-f16 > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err" ); echo "prof exit $?" | tee -a "$OUT/summary.txt"
   find "$OUT/prof" -name "*kernel_stats*" | head -3 | while read f; do echo "--- $f"; head -15 "$f"; done
   # keep only the small summaries (the raw trace can be large)
   find "$OUT/prof" -name "*kernel_trace*" -size +8M -delete
 fi
 if has pmc; then
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OLDPWD/$OUT/pmc_fetch" -o bench -- python "$OLDPWD/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-configs > /dev/null 2> "$OLDPWD/$OUT/pmc_fetch.err" ); echo "pmc fetch exit $?" | tee -a "$OUT/summary.txt"
-  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OLDPWD/$OUT/pmc_mfma" -o bench -- python "$OLDPWD/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-configs > /dev/null 2> "$OLDPWD/$OUT/pmc_mfma.err" ); echo "pmc mfma exit $?" | tee -a "$OUT/summary.txt"
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OLDPWD/$OUT/pmc_fetch" -o bench -- python "$OLDPWD/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-configs --no-f16 > /dev/null 2> "$OLDPWD/$OUT/pmc_fetch.err" ); echo "pmc fetch exit $?" | tee -a "$OUT/summary.txt"
+  ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OLDPWD/$OUT/pmc_mfma" -o bench -- python "$OLDPWD/bench.py" --steps 4 --warmup 1 --no-cpu-baseline --no-configs --no-f16 > /dev/null 2> "$OLDPWD/$OUT/pmc_mfma.err" ); echo "pmc mfma exit $?" | tee -a "$OUT/summary.txt"
   python scripts/summarize_pmc.py "$OUT" > "$OUT/pmc_summary.txt" 2>&1; cat "$OUT/pmc_summary.txt"
   find "$OUT" -name "*.csv" -size +8M -delete
 fi
