@@ -989,13 +989,12 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
     const float img_scale = image_scale(idx);
     const int64_t n = idx->n_rows, T = (n + 255) / 256;
     const int32_t cap = cap_env > 0 ? std::min(cap_env, MERGE_CAP) : MERGE_CAP;
-    // Sample stride: ~k * stride rows per query reach the bound, so at most cap / (2 k) (lists half full on average, the
-    // fluctuation is ~sqrt(k) * stride) and at least 8 sample tiles; within that, the stride that makes the sample pass TWO
-    // (row tile, query tile) pairs per workgroup -- 724 pairs over 256 workgroups ran three rounds for 2.83 of work.
-    const int64_t QT = ((int64_t)B + 255) / 256;
-    const int64_t stride_max = std::min<int64_t>(MERGE_CAP / (2 * (int64_t)k), T / 8);  // (MERGE_CAP, not the test knob `cap`)
-    const int64_t tiles_bal = std::max<int64_t>(1, 2 * (int64_t)(idx->n_cu > 0 ? idx->n_cu : 256) / QT);
-    const int32_t stride = (int32_t)std::min<int64_t>(stride_max, std::max<int64_t>(2, (T + tiles_bal - 1) / tiles_bal));
+    // Sample stride: ~k * stride rows per query reach the bound -- a third of a list on average (the fluctuation is
+    // ~sqrt(k) * stride) -- and at least 8 sample tiles.  Measured at cfg 5 (same box): stride 27 (this rule) 7.50 ms, 20: 7.67
+    // (more sample work), 39 (two pairs per workgroup in the sample pass instead of 2.83): 8.0 -- the candidates' epilogue and
+    // list work grows faster than the sample pass shrinks.
+    int32_t stride = (int32_t)std::min<int64_t>(MERGE_CAP / (3 * (int64_t)k), T / 8);
+    if (const char* st_env = std::getenv("RAGLITE_FUSED_TOPK_STRIDE")) stride = std::min<int32_t>(std::atoi(st_env), (int32_t)(T / 8));  // A/B
     if (stride < 2) return RL_ERR_UNSUPPORTED;
     const int64_t Tv = (T + stride - 1) / stride, ld_s = Tv * 256;
     if (ld_s < k) return RL_ERR_UNSUPPORTED;
