@@ -130,7 +130,17 @@ def main() -> None:
     arithmetic = index.arithmetic
     # N > 1: the exchange step runs behind the C ABI (rl_allgather_merge_topk over librccl); torch.distributed only hands
     # the communicator id around, synchronises the ranks around the timed region and takes the max of their clocks.
-    comm = raglite_amd.Communicator.from_torch_distributed() if (world > 1 and args.backend == "nccl") else None
+    comm = None
+    if world > 1 and args.backend == "nccl":
+        try:
+            comm = raglite_amd.Communicator.from_torch_distributed()
+        except Exception as exc:  # noqa: BLE001 - e.g. librccl not loadable: the exchange then goes through torch.distributed
+            print(f"[rank {rank}] rl_comm_init failed ({exc}); exchange step falls back to torch.distributed", file=sys.stderr)
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # every rank must take the same path
+        if int(ok.item()) == 0 and comm is not None:
+            comm.close()
+            comm = None
     sharded = ShardedIndex(index, row_base=r_lo, chunk_base=c_lo, local_chunk_offsets=local_off, comm=comm)
     n_batches = 4  # distinct query batches, cycled
     queries = torch.empty((n_batches, qps, NQ, DIM), dtype=torch.float32, device=dev)

@@ -43,9 +43,16 @@ class Communicator:
         import torch.distributed as dist
 
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [cls.unique_id() if rank == 0 else None]
+        box: list[Any] = [None]
+        if rank == 0:
+            try:
+                box[0] = cls.unique_id()
+            except Exception as exc:  # noqa: BLE001 - still broadcast, or the other ranks wait for ever
+                box[0] = exc
         dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        return cls(rank, world, box[0])
+        if not isinstance(box[0], (bytes, bytearray)):
+            raise RuntimeError(f"rank 0 could not create an RCCL unique id: {box[0]}")
+        return cls(rank, world, bytes(box[0]))
 
     def close(self) -> None:
         if self._handle is not None:
