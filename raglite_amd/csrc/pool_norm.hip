@@ -349,31 +349,26 @@ __global__ __launch_bounds__(64 * WAVES) void pool_norm_dma_kernel(const float* 
 //     where a span ends, drops its two sums per lane into LDS -- nothing else: measured, every piece of arithmetic on the
 //     loaders' path between two barriers costs its full latency (the DMA issue alone stalls a wave ~0.5 k cycles per tile),
 //     finishing the spans there made 2.4 ms of 1.9;
-//   * FINISHER waves 8-15 (wave 8 + w finishes the columns of loader w; they share the SIMDs, whose VALUs the loaders leave
-//     idle) run the statements of pool_norm_kernel as a three-stage pipeline clocked by the same barriers:
-//       stage 1 (epoch after the span ended): mean = sum / n; per (virtual) lane L of pool_norm_kernel the 16 squares of
-//               columns (v * 64 + L) * 4 + j summed in (v, j) order -- lanes 0..7 of finisher w stand in for L = 8 w .. 8 w + 7,
-//               whose columns are the wave's own -- and dropped into LDS;
-//       stage 2 (next epoch): every finisher runs the 64-lane xor butterfly on the 64 partial sums, sqrt -> the norm;
-//       stage 3 (next epoch): mean / norm, cast, store.
-//     The same bits as pool_norm_kernel, including the order of the norm reduction.
+//   * FINISHER waves 8-11: finisher (k mod 4) takes span k -- all 1024 sums from LDS after the next barrier -- and runs the
+//     statements of pool_norm_dma_kernel on them with that kernel's lane <-> column mapping, alone and without further
+//     synchronisation, while the loaders stream on.  The same bits, including the order of the norm reduction.  (Earlier
+//     arrangements -- all waves finishing their own columns in one go, a three-stage pipeline over the tile barriers, finishers
+//     that each finish a column slice of EVERY span -- all cost the finishing arithmetic in full: profiles/r02_pool_experiments.txt.)
 // Two span ends in one epoch insert an extra barrier.  Workgroup ranges are cut at span starts by rows (binary search in
 // span_begin), so the work is balanced to within one span without a queue; span bounds are staged through LDS, CAP at a time
 // (read from global memory where a span ends they are dependent scalar loads through a memory system busy streaming).
 // `layout` = {order violations, -, covered rows (u64)} from pool_layout_kernel: the kernel returns at once unless the spans are
 // ordered and cover >= 3/4 of the row range they span (the wave-private kernel then runs instead, guarded the other way).
 template <int NV>
-__global__ __launch_bounds__(1024) void pool_norm_coop_kernel(const float* __restrict__ tokens, const int64_t* __restrict__ span_begin,
+__global__ __launch_bounds__(768) void pool_norm_coop_kernel(const float* __restrict__ tokens, const int64_t* __restrict__ span_begin,
                                                                const int64_t* __restrict__ span_end, int64_t n_spans, int normalize,
                                                                double eps, float* __restrict__ out_f32, uint16_t* __restrict__ out_f16,
                                                                const unsigned int* __restrict__ layout, int dbg) {
-    // dbg (RAGLITE_POOL_DBG, timing experiments only): 1 = no LDS reads / adds, 2 = spans are not finished, 4 / 8 / 16 = the
-    // finishers skip stage 3 / 2 / 1, 32 = the loaders do not deposit
-    constexpr int DIM = 256 * NV, ROWB = DIM * 4, TILE = 8, RING = 4, CAP = 256, LOADERS = 8;
+    // dbg (RAGLITE_POOL_DBG, timing experiments only): 1 = no LDS reads / adds, 2 = spans are not finished, 4 = the finishers
+    // skip their work, 32 = the loaders do not deposit
+    constexpr int DIM = 256 * NV, ROWB = DIM * 4, TILE = 8, RING = 4, CAP = 256, LOADERS = 8, FINISHERS = 4;
     constexpr int OFF_DEP = RING * TILE * ROWB;       // [2][DIM] fp64: the loaders' sums of a finished span
-    constexpr int OFF_MEANS = OFF_DEP + 2 * DIM * 8;  // [DIM] fp64: the span's means (each finisher its own columns)
-    constexpr int OFF_SS = OFF_MEANS + DIM * 8;       // [2][64] fp64: per-virtual-lane sums of squares
-    constexpr int OFF_TAB = OFF_SS + 2 * 64 * 8;      // [2][CAP] int64: span bounds
+    constexpr int OFF_TAB = OFF_DEP + 2 * DIM * 8;    // [2][CAP] int64: span bounds
     __shared__ __attribute__((aligned(16))) char smem[OFF_TAB + 2 * CAP * 8];
     auto uni = [](int64_t v) -> int64_t {
         const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
@@ -402,8 +397,6 @@ __global__ __launch_bounds__(1024) void pool_norm_coop_kernel(const float* __res
     const uint32_t ring_lds = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
     const uint32_t lane16 = 16u * lane;
     double* const dep = reinterpret_cast<double*>(smem + OFF_DEP);
-    double* const means = reinterpret_cast<double*>(smem + OFF_MEANS);
-    double* const ssbuf = reinterpret_cast<double*>(smem + OFF_SS);
     int64_t* const tb = reinterpret_cast<int64_t*>(smem + OFF_TAB);
     int64_t* const te = tb + CAP;
     // ---- the stream: loader w brings row w of every tile; exactly NV DMAs per loader and tile (rows past the range re-read the
@@ -445,85 +438,99 @@ __global__ __launch_bounds__(1024) void pool_norm_coop_kernel(const float* __res
     int64_t cb, ce, nb, ne;  // the open span s and the one after it (read a whole span before it is needed)
     fetch_bounds(s, cb, ce);
     fetch_bounds(s + 1, nb, ne);
-    // ---- the finishing pipeline.  p0: deposited this epoch; p1: after stage 1; p2: after stage 2.  The flags, span ordinals and
-    // row counts are workgroup-uniform (every wave keeps them); the data lives in the finishers ------------------------------------
-    unsigned k0 = 0;  // spans deposited so far
-    bool p0 = false, p1 = false, p2 = false;
-    int64_t p0_s = 0, p1_s = 0, p2_s = 0, p0_n = 0;
-    unsigned p0_par = 0, p1_par = 0;
-    double f_m0 = 0.0, f_m1 = 0.0;   // finisher: means of the span in p1
-    double g_m0 = 0.0, g_m1 = 0.0, g_norm = 1.0;  // finisher: means and norm of the span in p2
-    auto store_span = [&](int64_t sp, double m0, double m1) __attribute__((always_inline)) {
-        if (active) {
-            if (out_f32) *reinterpret_cast<float2*>(out_f32 + sp * (int64_t)DIM + c0) = make_float2((float)m0, (float)m1);
-            if (out_f16) {
-                ushort2 h;
-                h.x = f64_to_f16_bits(m0); h.y = f64_to_f16_bits(m1);
-                if (dbg & 64) asm volatile("" ::"v"(h.x), "v"(h.y));  // experiment: everything but the store instruction
-                else *reinterpret_cast<ushort2*>(out_f16 + sp * (int64_t)DIM + c0) = h;
+    // ---- finishing.  A span's sums are dropped into one of two LDS slots by the loaders (p0: dropped this epoch, visible after
+    // the next barrier); finisher (k mod 4) then takes span k ALONE, with the lane <-> column mapping and the statements of
+    // pool_norm_dma_kernel -- the same bits -- while everybody else streams on: one span in four per finisher. ------------------
+    unsigned k0 = 0;  // spans dropped so far
+    bool p0 = false;  // (workgroup-uniform)
+    int64_t p0_s = 0, p0_n = 0;
+    unsigned p0_par = 0, p0_k = 0;
+    // The finisher's job, in pieces of a few hundred cycles, ONE piece per epoch: it takes part in every tile barrier, and a
+    // job done in one go (~2.3 us) holds the next two barriers -- and with them the loaders' DMA issue -- up by what it
+    // exceeds the epoch (1.2 us) by: that is how finishing cost its full price on waves that do nothing else.
+    int f_stage = 0;  // 0 = idle (wave-uniform)
+    int64_t f_s = 0;
+    double f_acc[NV][4], f_ss = 0.0, f_rnorm = 1.0;
+    auto finisher_step = [&]() __attribute__((always_inline)) {
+        switch (f_stage) {
+            case 1: {  // the butterfly of the norm (the xor order of wave_sum: same bits)
+                f_ss = wave_sum(f_ss);
+                f_stage = 2;
+                break;
             }
+            case 2: {
+                double norm = sqrt(f_ss);
+                if (eps > 0.0) norm = fmax(norm, eps);
+                f_rnorm = 1.0 / norm;
+                f_stage = 3;
+                break;
+            }
+            case 3:
+            case 4: {  // scale, cast, store: half of the columns per epoch
+                const int v0 = f_stage == 3 ? 0 : (NV + 1) / 2, v1 = f_stage == 3 ? (NV + 1) / 2 : NV;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    if (v < v0 || v >= v1) continue;
+                    const int col = (v * 64 + lane) * 4;
+                    double o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = normalize ? f_acc[v][j] * f_rnorm : f_acc[v][j];
+                    if (out_f32)
+                        *reinterpret_cast<float4*>(out_f32 + f_s * (int64_t)DIM + col) = make_float4((float)o[0], (float)o[1], (float)o[2], (float)o[3]);
+                    if (out_f16) {
+                        ushort4 h;
+                        h.x = f64_to_f16_bits(o[0]); h.y = f64_to_f16_bits(o[1]);
+                        h.z = f64_to_f16_bits(o[2]); h.w = f64_to_f16_bits(o[3]);
+                        *reinterpret_cast<ushort4*>(out_f16 + f_s * (int64_t)DIM + col) = h;
+                    }
+                }
+                f_stage = f_stage == 3 && NV > 1 ? 4 : 0;
+                break;
+            }
+            default: break;
         }
     };
     auto advance = [&]() __attribute__((always_inline)) {  // right after a workgroup barrier
-        if (p2) {  // stage 3
-            if (!loader && !(dbg & 4)) store_span(p2_s, g_m0 * g_norm, g_m1 * g_norm);  // (g_norm holds 1 / norm)
-            p2 = false;
-        }
-        if (p1) {  // stage 2
-            if (!loader && !(dbg & 8)) {
-                double norm = sqrt(wave_sum(ssbuf[p1_par * 64 + lane]));
-                if (eps > 0.0) norm = fmax(norm, eps);
-                g_m0 = f_m0; g_m1 = f_m1; g_norm = 1.0 / norm;
-            }
-            p2_s = p1_s;
-            p2 = true;
-            p1 = false;
-        }
-        if (p0) {  // stage 1
-            if (!loader && !(dbg & 16)) {
-                const double rn = 1.0 / (double)p0_n;  // zero rows: 0 * inf = NaN like np.mean of zero rows
-                double2 sums = {0.0, 0.0};
-                if (active) sums = *reinterpret_cast<const double2*>(dep + p0_par * DIM + c0);
-                const double m0 = sums.x * rn, m1 = sums.y * rn;
-                if (!normalize) {
-                    store_span(p0_s, m0, m1);
-                } else {
-                    if (active) {
-                        double2 m;
-                        m.x = m0; m.y = m1;
-                        *reinterpret_cast<double2*>(means + c0) = m;
-                    }
-                    if (lane < 8) {  // (the wave's own LDS writes above are visible to it: same wave, in order)
-                        const int L = 8 * cw + lane;
-                        double ss = 0.0;
+        if (!loader && !(dbg & 4)) {
+            finisher_step();
+            if (p0 && wv - LOADERS == (int)(p0_k % FINISHERS)) {
+                while (f_stage != 0) finisher_step();  // still busy (spans shorter than a tile, four in a row): finish in one go
+                const double* const slot = dep + p0_par * DIM;
 #pragma unroll
-                        for (int v = 0; v < NV; ++v) {
-                            const double2 a = *reinterpret_cast<const double2*>(means + (v * 64 + L) * 4);
-                            const double2 c = *reinterpret_cast<const double2*>(means + (v * 64 + L) * 4 + 2);
-                            ss += a.x * a.x; ss += a.y * a.y; ss += c.x * c.x; ss += c.y * c.y;
-                        }
-                        ssbuf[p0_par * 64 + L] = ss;
-                    }
-                    f_m0 = m0; f_m1 = m1;
+                for (int v = 0; v < NV; ++v) {
+                    const double2 a = *reinterpret_cast<const double2*>(slot + (v * 64 + lane) * 4);
+                    const double2 c = *reinterpret_cast<const double2*>(slot + (v * 64 + lane) * 4 + 2);
+                    f_acc[v][0] = a.x; f_acc[v][1] = a.y; f_acc[v][2] = c.x; f_acc[v][3] = c.y;
                 }
+                const double rn = 1.0 / (double)p0_n;  // zero rows: 0 * inf = NaN like np.mean of zero rows
+                double ss = 0.0;
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        f_acc[v][j] = f_acc[v][j] * rn;
+                        ss += f_acc[v][j] * f_acc[v][j];
+                    }
+                f_ss = ss;
+                f_s = p0_s;
+                f_stage = normalize ? 1 : 3;
             }
-            if (normalize) { p1_s = p0_s; p1_par = p0_par; p1 = true; }
-            p0 = false;
         }
+        p0 = false;
     };
     auto finish_span = [&]() __attribute__((always_inline)) {  // span s = [cb, ce) is complete (workgroup-uniform)
         if (p0) {  // the previous span ended in this epoch too: an epoch of its own
             __syncthreads();
             advance();
         }
-        if (loader && active && !(dbg & 32)) {
+        if (loader && active) {
             double2 sums;
             sums.x = acc0; sums.y = acc1;
             *reinterpret_cast<double2*>(dep + (k0 & 1u) * DIM + c0) = sums;
         }
         acc0 = 0.0;
         acc1 = 0.0;
-        p0_s = s; p0_n = ce - cb; p0_par = k0 & 1u;
+        p0_s = s; p0_n = ce - cb; p0_par = k0 & 1u; p0_k = k0;
         p0 = true;
         ++k0;
         ++s;
@@ -595,10 +602,11 @@ __global__ __launch_bounds__(1024) void pool_norm_coop_kernel(const float* __res
         }
     }
     while (s < s_hi && !(dbg & 3)) finish_span();  // the last span of the range and empty spans after it
-    while (p0 || p1 || p2) {                       // drain the pipeline
+    if (p0) {  // the last span
         __syncthreads();
         advance();
     }
+    while (f_stage != 0) finisher_step();  // (per wave: no barrier involved)
     if (loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
 }
 
@@ -658,7 +666,7 @@ int launch_pool_norm(const float* tokens, int32_t dim, const int64_t* sb, const 
                 hipLaunchKernelGGL(pool_layout_kernel, dim3((unsigned)std::min<int64_t>(64, (n_spans + 1023) / 1024)), dim3(256), 0, s, sb, se, n_spans, layout);
 #define RL_POOL_DMA(NV)                                                                                                                     \
     do {                                                                                                                                    \
-        if (layout) hipLaunchKernelGGL((pool_norm_coop_kernel<NV>), dim3(blocks), dim3(1024), 0, s, tokens, sb, se, n_spans, normalize, eps, o32, o16, layout, dbg); \
+        if (layout) hipLaunchKernelGGL((pool_norm_coop_kernel<NV>), dim3(blocks), dim3(768), 0, s, tokens, sb, se, n_spans, normalize, eps, o32, o16, layout, dbg); \
         hipLaunchKernelGGL((pool_norm_dma_kernel<NV>), dim3(blocks), dim3(512), 0, s, tokens, sb, se, n_spans, normalize, eps, o32, o16, counter, tune, layout); \
     } while (0)
             if (dim == 256) RL_POOL_DMA(1); else if (dim == 512) RL_POOL_DMA(2); else RL_POOL_DMA(4);
