@@ -236,6 +236,11 @@ struct rl_index {
     rl::Pool cand;                        // rl_maxsim_rerank: sanitised candidate ordinals
     rl::Pool fused;                       // fused batched top-k: sample scores, thresholds, candidate lists, counters
     rl::Pool rankbuf;                     // rank cut (order-first-then-filter): histogram levels + tie counts
+    // HI plane (round 2): fp16(e * split_scale) rounded toward zero, row-major [n_rows x dim] -- the hi halves of the fp16
+    // split as a matrix of their own, 2 B per element: what the single-query search streams (search_rows_hi).
+    rl::Pool hiplane, hibuf;
+    float hi_scale = 0.f;                 // the scale the plane was built with; 0 = no plane
+    int64_t hi_rows = 0;                  // rows it covers
     // The scratch above is shared by all calls on this handle; `mu` serialises only their host side.  Device-mode calls are
     // asynchronous, so a call arriving on a DIFFERENT stream than the previous one first waits for that stream.
     hipStream_t last_stream = nullptr;
@@ -337,6 +342,48 @@ int refresh_planes(rl_index* idx, hipStream_t s) {
     RL_TRY(rl::launch_chunk_ends(idx->row_to_chunk, idx->n_rows, idx->ends.as<uint32_t>(), s));
     idx->planes_scale = image_scale(idx);
     idx->planes_rows = idx->n_rows;
+    return RL_OK;
+}
+
+// The HI plane follows the corpus like the image does: built for big fp32 corpora in split arithmetic whose dim the fp16
+// stream kernel takes; RAGLITE_NO_HI_PLANE=1 disables it (2 B per element of extra HBM).
+bool hi_valid(const rl_index* idx) {
+    return idx->hi_scale > 0.f && idx->hi_scale == idx->split_scale && idx->hi_rows == idx->n_rows && idx->n_rows > 0;
+}
+int refresh_hi_plane(rl_index* idx, hipStream_t s) {
+    static const bool off = std::getenv("RAGLITE_NO_HI_PLANE") != nullptr;  // A/B switch
+    const int32_t d = idx->dim;
+    const bool dim_ok = d == 128 || d == 256 || d == 384 || d == 512 || d == 768 || d == 1024;
+    const bool want = !off && !idx->E16 && idx->E && idx->split_scale > 0.f && dim_ok &&
+                      (int64_t)idx->n_rows * d >= (int64_t(64) << 20) && (idx->metric == RL_COSINE || idx->metric == RL_DOT);
+    if (!want) {
+        idx->hiplane.release();
+        idx->hi_scale = 0.f;
+        idx->hi_rows = 0;
+        return RL_OK;
+    }
+    const int64_t cap = std::max<int64_t>(idx->n_rows, idx->owns_E ? idx->cap_rows : idx->n_rows);
+    const size_t need = (size_t)cap * d * sizeof(uint16_t);
+    int64_t first = idx->hi_scale == idx->split_scale ? idx->hi_rows : 0;
+    if (idx->hiplane.cap < need) first = 0;  // Pool::reserve does not keep the contents
+    if (idx->hiplane.reserve(need) != RL_OK) {
+        (void)hipGetLastError();
+        idx->hiplane.release();
+        idx->hi_scale = 0.f;
+        idx->hi_rows = 0;
+        return RL_OK;
+    }
+    const int st = rl::launch_cast_f16_rtz(idx->E + (size_t)first * d, idx->hiplane.as<uint16_t>() + (size_t)first * d,
+                                           (idx->n_rows - first) * d, idx->split_scale, s);
+    if (st == RL_ERR_UNSUPPORTED) {  // caller-owned rows that are not 16-byte aligned
+        idx->hiplane.release();
+        idx->hi_scale = 0.f;
+        idx->hi_rows = 0;
+        return RL_OK;
+    }
+    RL_TRY(st);
+    idx->hi_scale = idx->split_scale;
+    idx->hi_rows = idx->n_rows;
     return RL_OK;
 }
 }  // namespace
@@ -513,6 +560,8 @@ int rl_index_destroy(rl_index* idx) {
     idx->cand.release();
     idx->fused.release();
     idx->rankbuf.release();
+    idx->hiplane.release();
+    idx->hibuf.release();
     select_workspace_free(idx->ws);
     idx->scores.release();
     idx->hits.release();
@@ -591,6 +640,7 @@ static int index_create_any(rl_index** out, const void* embeddings, bool f16, in
                    : launch_row_norms(idx->E, n_rows, dim, idx->norm, idx->sumsq, s));
     RL_IDX(scan_row_range(idx, 0, n_rows, s));
     RL_IDX(refresh_planes(idx, s));
+    RL_IDX(refresh_hi_plane(idx, s));
     RL_IDX_HIP(hipStreamSynchronize(s));  // host_offsets / caller buffers may go away after return
 #undef RL_IDX
 #undef RL_IDX_HIP
@@ -742,8 +792,11 @@ int rl_index_compact(rl_index* idx, int64_t* out_remap, int64_t* new_n_rows, int
     idx->nonfinite = false;
     idx->planes_rows = 0;
     idx->planes_scale = 0.f;
+    idx->hi_rows = 0;
+    idx->hi_scale = 0.f;
     RL_TRY(scan_row_range(idx, 0, new_n, s));
     RL_TRY(refresh_planes(idx, s));
+    RL_TRY(refresh_hi_plane(idx, s));
     RL_HIP(hipStreamSynchronize(s));
     if (out_remap) std::memcpy(out_remap, remap.data(), (size_t)old_c * sizeof(int64_t));
     if (new_n_rows) *new_n_rows = new_n;
@@ -758,6 +811,7 @@ int rl_index_set_arithmetic(rl_index* idx, int mode) {
     idx->arithmetic = mode;
     update_split_scale(idx);
     RL_TRY(refresh_planes(idx, nullptr));
+    RL_TRY(refresh_hi_plane(idx, nullptr));
     RL_HIP(hipStreamSynchronize(nullptr));
     return RL_OK;
 }
@@ -868,6 +922,7 @@ int rl_index_append(rl_index* idx, const float* rows, int64_t n_new_rows, const 
     }
     RL_TRY(scan_row_range(idx, old_n, n_new_rows, s));
     RL_TRY(refresh_planes(idx, s));
+    RL_TRY(refresh_hi_plane(idx, s));
     if (!idx->h_live.empty()) {  // new chunks are live
         const size_t cw = (size_t)(new_c + 31) / 32;
         idx->h_live.resize(cw, 0u);
@@ -1031,6 +1086,72 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
     return RL_OK;
 }
 
+// Exact row top-k of up to four queries at HALF the bytes of a corpus pass (BASELINE cfg 2, `ORDER BY dist LIMIT k` of
+// src/raglite/_search.py:69-79 for one query): the single-query search is HBM-bound on the 4 B per element of the fp32 corpus,
+// and the hi halves of the fp16 split carry 11 of every element's 24 significand bits in 2 B.
+//   (1) the f16 stream kernel over the HI plane -> approximate dots (query in full hi + lo precision), the metric, their exact
+//       top-k;
+//   (2) |approximate - exact| <= m for every row, rigorously: the dropped lo half is < 2^-10 of its element (truncation), so
+//       the dot product moves by <= 2^-10 |e| |q| (Cauchy-Schwarz) -- m = 2^-10 for a cosine, 2^-10 sqrt(dim) max|e| |q| for a
+//       dot product, plus 2^-12 for the fp32 roundings of both passes.  A row can belong to the exact top-k only if its
+//       approximate score reaches (k-th best approximate) - 2 m: one more pass over the 4 B per row of approximate scores
+//       collects exactly those rows (k + a few dozen on embedding-like data; a list holds 1024);
+//   (3) the candidates' fp32 rows are gathered and scored by the SAME kernels the full pass uses (a row's score does not
+//       depend on where the row sits: tests/test_gpu_parity.py), ranked by (score desc, row asc): the same bits as the
+//       full pass, ties included;
+//   (4) list overflow (more than 1024 rows within 2 m of the k-th: near-duplicate-heavy corpora): the full-precision pass,
+//       launched always, returning at once when the flag is clear -- nothing here synchronises with the host.
+// cosine / dot, B <= 4, k <= 512, no row mask; RL_ERR_UNSUPPORTED otherwise.
+int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float* d_scores, int32_t* d_rows, int64_t ld, hipStream_t s) {
+    const char* off_env = std::getenv("RAGLITE_NO_HI_SEARCH");  // A/B switch, read per call (tests flip it)
+    if (off_env && off_env[0] && off_env[0] != '0') return RL_ERR_UNSUPPORTED;
+    const int mode = scan_mode(idx->metric);
+    const int64_t n = idx->n_rows;
+    if (!hi_valid(idx) || nb > 4 || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT) || n < 65536) return RL_ERR_UNSUPPORTED;
+    const int32_t dim = idx->dim, cap = 1024;  // candidates per query (expected: k + a few dozen)
+    const int64_t nc = (int64_t)nb * cap, ldx = nc;
+    // ---- scratch: approximate top-k scores (+ unused ids), thresholds, counters + flag, candidate rows, their norms, the
+    // gathered rows, the exact score block and its diagonal -------------------------------------------------------------------------
+    const size_t words = (size_t)nb * k * 2 + 16 + 32 + (size_t)nc * 2 + (size_t)nc * dim + (size_t)nb * ldx + (size_t)nc;
+    RL_TRY(idx->hibuf.reserve(words * 4));
+    float* ts = idx->hibuf.as<float>();                        // [nb x k]
+    int32_t* ti = reinterpret_cast<int32_t*>(ts + (size_t)nb * k);
+    float* thr = reinterpret_cast<float*>(ti + (size_t)nb * k);  // [nb] (16 words)
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(thr + 16);       // [nb] counters, then the flag at cnt[16]
+    uint32_t* flag = cnt + 16;
+    int32_t* ci = reinterpret_cast<int32_t*>(cnt + 32);        // [nb x cap]
+    float* gn = reinterpret_cast<float*>(ci + nc);             // [nb x cap]
+    float* G = gn + nc;                                        // [nb * cap x dim]
+    float* xs = G + (size_t)nc * dim;                          // [nb x nb * cap]
+    float* es = xs + (size_t)nb * ldx;                         // [nb x cap]
+    float* sc = idx->scores.as<float>();
+    // ---- (1) approximate pass over the HI plane, its exact top-k -----------------------------------------------------------------------
+    int st = launch_maxsim_stream16(idx->hiplane.as<uint16_t>(), n, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, sc, ld,
+                                    idx->n_cu, s);
+    if (st != RL_OK) return st;
+    RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f / idx->hi_scale));
+    RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s, nullptr, true));
+    // ---- (2) every row that could be in the exact top-k ------------------------------------------------------------------------------------
+    const float m_rel = 0x1p-10f + 0x1p-12f;
+    RL_TRY(launch_approx_threshold(ts, nb, k, d_q, dim, mode, m_rel, std::sqrt((float)dim) * idx->max_abs, thr, cnt, flag, s));
+    RL_TRY(launch_collect_above(sc, nb, n, ld, thr, mode == SCAN_COSINE ? idx->norm : nullptr, cap, ci, gn, cnt, flag, s));
+    // ---- (3) exact scores of the candidates, by the kernels of the full pass (slots past a list's length hold stale row numbers:
+    // gathered and scored, never ranked) ---------------------------------------------------------------------------------------------------------
+    RL_TRY(launch_gather_rows(idx->E, false, dim, n, ci, nc, G, s));
+    st = launch_maxsim_stream(G, nc, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, xs, ldx, idx->n_cu, s, idx->split_scale);
+    if (st != RL_OK) return st;
+    RL_TRY(launch_transform(xs, nb, nc, ldx, gn, nullptr, d_q, dim, mode, s));
+    if (nb > 1) RL_TRY(launch_diag_blocks(xs, ldx, cap, nc, es, s));  // (one query: the block IS its diagonal)
+    RL_TRY(launch_merge_topk(nb > 1 ? es : xs, ci, 1, nb, cap, k, d_scores, d_rows, s, cnt));
+    // ---- (4) guarded full-precision pass ------------------------------------------------------------------------------------------
+    st = launch_maxsim_stream(idx->E, n, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, sc, ld, idx->n_cu, s, idx->split_scale,
+                              flag);
+    if (st != RL_OK) return st;
+    RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f, flag));
+    RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, d_scores, d_rows, s, flag, true));
+    return RL_OK;
+}
+
 // rank_limit > 0: the order-first-then-filter branch (src/raglite/_search.py:120-141) -- only the rank_limit nearest LIVE
 // rows of a query are eligible, and among those the rows d_row_bits lets through are ranked.
 int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, float* d_scores, int32_t* d_rows,
@@ -1050,6 +1171,11 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
         const bool cut = rank_limit > 0 && rank_limit < n;
         if (!d_row_bits && !cut) {  // big batches over the pre-split image: no score matrix at all
             const int st = search_rows_fused(idx, d_q + (int64_t)b0 * idx->dim, nb, k, d_scores + (int64_t)b0 * k, d_rows + (int64_t)b0 * k, ld, s);
+            if (st == RL_OK) continue;
+            if (st != RL_ERR_UNSUPPORTED) return st;
+        }
+        if (!d_row_bits && !cut && nb <= 4) {  // few queries over a big fp32 corpus: half the bytes through the HI plane
+            const int st = search_rows_hi(idx, d_q + (int64_t)b0 * idx->dim, nb, k, d_scores + (int64_t)b0 * k, d_rows + (int64_t)b0 * k, ld, s);
             if (st == RL_OK) continue;
             if (st != RL_ERR_UNSUPPORTED) return st;
         }

@@ -115,6 +115,8 @@ int launch_scan_rows16(const uint16_t* E, int64_t n, int32_t dim, const float* q
 int launch_row_norms16(const uint16_t* E, int64_t n, int32_t dim, float* norm, float* sumsq, hipStream_t s);
 int launch_row_norms(const float* E, int64_t n, int32_t dim, float* norm, float* sumsq, hipStream_t s);
 int launch_cast_f16(const float* src, uint16_t* dst, int64_t count, hipStream_t s);
+// dst = fp16(src * scale) rounded TOWARD ZERO (the hi half of the fp16 split); count % 8 == 0, 16-byte aligned pointers
+int launch_cast_f16_rtz(const float* src, uint16_t* dst, int64_t count, float scale, hipStream_t s);
 int launch_fill_f32(float* dst, float value, int64_t count, hipStream_t s);
 // in-place metric transform of raw dots: scores[b*ld+i] (i<n), per-row norm / sumsq, per-query norm.
 int launch_transform(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm,
@@ -139,8 +141,10 @@ int launch_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, i
                 bool have_hist = false);
 // launch_transform (scan.hip) + the selection's histogram pass in ONE launch: raw dots -> similarities in place, and their
 // 2048-bin key histogram into ws.hist (same statements as transform_kernel: same bits).  Follow with launch_topk(have_hist).
+// pre_scale: the raw dots are multiplied by it first (a power of two: exact; 1 = the plain transform); run_if as in launch_topk.
 int launch_transform_hist(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm, const float* row_sumsq,
-                          const float* queries, int32_t dim, int mode, SelectWorkspace& ws, hipStream_t s);
+                          const float* queries, int32_t dim, int mode, SelectWorkspace& ws, hipStream_t s, float pre_scale = 1.0f,
+                          const uint32_t* run_if = nullptr);
 int launch_group_chunk_max(const float* hit_scores, const int32_t* hit_rows, int32_t n_queries,
                            int32_t num_hits, const int64_t* chunk_offsets, int64_t n_chunks, int32_t k,
                            float* out_scores, int32_t* out_chunks, int32_t* out_counts, hipStream_t s);
@@ -153,6 +157,14 @@ int launch_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_l
 size_t rank_cut_scratch_bytes(int32_t n_queries, int64_t n);
 int launch_rank_cut(float* scores, int32_t n_queries, int64_t n, int64_t ld, int64_t rank_limit, const uint32_t* keep_bits,
                     void* scratch, hipStream_t s);
+
+// hi_filter.hip: helpers of the half-bytes single-query search (api.hip: search_rows_hi)
+int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const float* queries, int32_t dim, int mode, float m_rel,
+                            float e_norm_bound, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s);  // also zeroes cnt[0..nb) and *flag
+int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld, const float* thr, const float* row_norm, int32_t cap,
+                         int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s);
+int launch_gather_f32(const float* src, const int32_t* idx, int64_t count, float* dst, hipStream_t s);
+int launch_diag_blocks(const float* src, int64_t ld, int32_t k2, int64_t count, float* dst, hipStream_t s);
 
 // mask.hip: validity bitsets (metadata filter pushed down to the device, tombstones of deleted chunks)
 int launch_expand_chunk_bits(const uint32_t* chunk_bits, const int32_t* row_to_chunk, int64_t n_rows,
@@ -187,7 +199,8 @@ int launch_row_to_chunk(const int64_t* chunk_offsets, int64_t n_chunks, int64_t 
 // corpus scaled by that power of two; 0: the exact fp32 MFMA chain.
 int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
                          const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
-                         float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale = 0.f);
+                         float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale = 0.f,
+                         const uint32_t* run_if = nullptr);  // run_if: the kernel returns at once unless *run_if != 0
 size_t query_split_bytes(int32_t dim, int32_t n_queries);
 int launch_query_split(const float* Q, int32_t dim, int32_t nq, int64_t q_stride, int32_t n_queries, void* buf, bool f16_corpus,
                        hipStream_t s);

@@ -97,6 +97,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
                                                                  int64_t n_chunks, float* __restrict__ out,
                                                                  int64_t ld, unsigned long long* trace, float e_scale) {
     static_assert(!(F16 && SPLIT), "SPLIT is a way to multiply an fp32-stored corpus");
+    if constexpr (!TRACE) {  // production build: `trace` carries an optional run-if flag (a guarded fallback launch returns at once)
+        if (trace && __builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const uint32_t*>(trace)) == 0) return;  // whole grid
+    }
     using G_ = Geo<KW, F16>;
     constexpr int SD = G_::DIM, PITCH = G_::PITCH, STAGE = G_::STAGE, KSTEPS = G_::KSTEPS, NCH = G_::NCH, ROWB = G_::ROWB;
     constexpr int OFF_RED = G_::OFF_RED, OFF_ST = G_::OFF_ST, ST_PITCH = G_::ST_PITCH, OFF_ORD = G_::OFF_ORD;
@@ -1004,7 +1007,7 @@ void launch_kw(const StreamArgs& a) {
 // f16 = the corpus is stored as IEEE fp16 (D then points at uint16_t data); queries and scores stay fp32.
 static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
                              const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
-                             float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale = 0.f) {
+                             float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale = 0.f, const uint32_t* run_if = nullptr) {
     if (nq < 1 || nq > 32 || n_rows < 1) return RL_ERR_UNSUPPORTED;
     if (dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
@@ -1039,7 +1042,8 @@ static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t d
         }
         return RL_OK;
     }
-    const StreamArgs a{D, n_rows, Q, (int)nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, dim3(grid), s, nullptr, split_scale};
+    const StreamArgs a{D, n_rows, Q, (int)nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, dim3(grid), s,
+                       reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(run_if)), split_scale};
     const bool split = !f16 && split_scale > 0.f;  // 0: the exact fp32 MFMA chain
 #define RL_DIMS(...) switch (dim) { \
         case 128: launch_kw<32, __VA_ARGS__>(a); break; case 256: launch_kw<64, __VA_ARGS__>(a); break; case 384: launch_kw<96, __VA_ARGS__>(a); break; \
@@ -1052,9 +1056,9 @@ static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t d
 
 int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
                          const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
-                         float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale) {
+                         float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if) {
     return launch_stream_any(D, false, n_rows, dim, Q, nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, n_cu, s,
-                             split_scale);
+                             split_scale, run_if);
 }
 
 // Two queries (17..32 vectors each, q_stride floats apart) per corpus pass over an fp32 corpus in SPLIT arithmetic:

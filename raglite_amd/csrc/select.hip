@@ -153,9 +153,11 @@ __global__ __launch_bounds__(256) void transform_hist_kernel(float* __restrict__
                                                               const float* __restrict__ row_norm,
                                                               const float* __restrict__ row_sumsq,
                                                               const float* __restrict__ queries, int dim, int mode,
-                                                              uint32_t* __restrict__ ws_hist) {
+                                                              uint32_t* __restrict__ ws_hist, float pre_scale,
+                                                              const uint32_t* __restrict__ run_if) {
     __shared__ uint32_t h[HIST_COPIES * HIST_COPY_STRIDE];
     __shared__ float part[4];
+    if (run_if && *run_if == 0u) return;
     const int b = blockIdx.y;
     typedef float f4 __attribute__((ext_vector_type(4)));
     float* const sb = scores + (int64_t)b * ld;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void transform_hist_kernel(float* __restrict__
     const float qss = (part[0] + part[1]) + (part[2] + part[3]);
     const float qn = sqrtf(qss);
     auto one = [&](int64_t i) {  // scalar tail / unaligned layout
-        const float o = transform_score(sb[i], mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
+        const float o = transform_score(sb[i] * pre_scale, mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
         hist_add(h, o);
         sb[i] = o;
     };
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(256) void transform_hist_kernel(float* __restrict__
         f4 o;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            o[u] = transform_score(d[u], mode, a[u], a[u], qn, qss);  // a = the row norms (cosine) or squared norms (l2)
+            o[u] = transform_score(d[u] * pre_scale, mode, a[u], a[u], qn, qss);  // a = the row norms (cosine) or squared norms (l2)
             hist_add(h, o[u]);
         }
         reinterpret_cast<f4*>(sb)[i] = o;
@@ -517,12 +519,13 @@ static int hist_grid(int64_t n, int32_t nq) {
 }
 
 int launch_transform_hist(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm, const float* row_sumsq,
-                          const float* queries, int32_t dim, int mode, SelectWorkspace& ws, hipStream_t s) {
+                          const float* queries, int32_t dim, int mode, SelectWorkspace& ws, hipStream_t s, float pre_scale,
+                          const uint32_t* run_if) {
     if (n <= 0 || nb <= 0) return RL_OK;
     RL_TRY(select_workspace_reserve(ws, nb, s));
     ws.dirty = true;  // the histogram rows stay non-zero until launch_topk(have_hist) has run its final kernel
     hipLaunchKernelGGL(transform_hist_kernel, dim3(hist_grid(n, nb), nb), dim3(256), 0, s, scores, n, ld, row_norm, row_sumsq,
-                       queries, (int)dim, mode, ws.hist);
+                       queries, (int)dim, mode, ws.hist, pre_scale, run_if);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -1,0 +1,106 @@
+"""GPU parity of the half-bytes single-query search (api.hip `search_rows_hi`): for up to four queries over a big fp32 corpus
+the ranking pass streams only the HI halves of the fp16 split (2 B per element), a rigorous error bound turns its top-2048
+into a candidate set that contains the exact top-k, and the candidates are re-scored by the exact kernels.
+
+Contract: the same bits as the full-precision pass (`ORDER BY dist LIMIT k`, `/root/reference/src/raglite/_search.py:69-79`,
+ranked exactly) -- checked against RAGLITE_NO_HI_SEARCH=1 bit for bit, against the oracle, and on corpora built to defeat the
+bound (thousands of near-duplicates of the best row), where the guarded full-precision pass has to answer."""
+
+import os
+
+import numpy as np
+import pytest
+
+import raglite_amd
+from oracle import oracle
+from tests.util import assert_topk_close, sim_fp32_exact
+
+pytestmark = pytest.mark.gpu
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _same(a, b):
+    return np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+@pytest.mark.parametrize("n,dim,B,k", [(70_000, 1024, 1, 100), (66_000, 1024, 4, 512), (140_000, 512, 2, 10), (530_000, 128, 3, 100)])
+def test_hi_search_equals_full_pass_bitwise(metric, n, dim, B, k):
+    E = oracle.synth_matrix(9500 + dim, n, dim)
+    Q = oracle.synth_matrix(9600 + B, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    S, R = idx.search_rows(Q if B > 1 else Q[0], k)
+    with _env(RAGLITE_NO_HI_SEARCH="1"):
+        S0, R0 = idx.search_rows(Q if B > 1 else Q[0], k)
+    assert np.array_equal(R, R0) and _same(S, S0)
+    S, R = np.atleast_2d(S), np.atleast_2d(R)
+    for b in (0, B - 1):
+        sims = oracle.similarity(E, Q[b], metric)
+        assert_topk_close(S[b], R[b], sims, k, 2e-6 * max(1.0, float(np.abs(sims).max())))
+    idx.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_hi_search_integer_data_bit_exact(metric):
+    n, dim, k = 80_000, 1024, 64
+    E = oracle.synth_matrix(9700, n, dim, "small_int")
+    Q = oracle.synth_matrix(9701, 3, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    S, R = idx.search_rows(Q, k)
+    for b in range(3):
+        es, ei = oracle.topk_desc(sim_fp32_exact(E, Q[b], metric), k)
+        assert np.array_equal(R[b], ei)
+        assert _same(S[b], es.astype(np.float32))
+    idx.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_near_duplicates_defeat_the_bound_and_the_full_pass_answers(metric):
+    """5000 rows within 1e-4 of the query's best match: more than 2048 rows sit inside twice the error bound of the k-th score,
+    the guard flags it, the full-precision pass ranks them -- same bits as without the HI plane."""
+    rng = np.random.default_rng(11)
+    n, dim, k = 70_000, 1024, 100
+    E = oracle.synth_matrix(9800, n, dim)
+    q = oracle.synth_matrix(9801, 1, dim)[0]
+    dup = rng.choice(n, 5000, replace=False)
+    E[dup] = (q[None, :] * 0.9 + 1e-4 * rng.standard_normal((5000, dim))).astype(np.float32)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    S, R = idx.search_rows(q, k)
+    with _env(RAGLITE_NO_HI_SEARCH="1"):
+        S0, R0 = idx.search_rows(q, k)
+    assert np.array_equal(R, R0) and _same(S, S0)
+    assert np.isin(R, dup).all()
+    idx.close()
+
+
+def test_hi_plane_follows_append_and_two_stage_search():
+    n, dim = 70_000, 1024
+    E = oracle.synth_matrix(9900, n + 3000, dim)
+    q = oracle.synth_matrix(9901, 1, dim)[0]
+    idx = raglite_amd.DeviceIndex(E[:n], metric="cosine")
+    idx.append(E[n:])
+    S, R = idx.search_rows(q, 50)
+    ref = raglite_amd.DeviceIndex(E, metric="cosine")
+    with _env(RAGLITE_NO_HI_SEARCH="1"):
+        S0, R0 = ref.search_rows(q, 50)
+    assert np.array_equal(R, R0) and _same(S, S0)
+    cs, cc, cn = idx.search_chunks(q, 40, 5)  # every row its own chunk here: the two-stage search rides on the same path
+    cs0, cc0, cn0 = ref.search_chunks(q, 40, 5)
+    assert cn == cn0 and np.array_equal(cc, cc0) and _same(cs, cs0)
+    idx.close()
+    ref.close()
