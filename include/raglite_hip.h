@@ -167,7 +167,12 @@ int rl_index_arithmetic(rl_index* index, int* in_effect);
  * dist per src/raglite/_typing.py:123-134, ranked EXACTLY (the reference's HNSW is approximate).
  *   queries [B x dim] f32;  k <= 2048
  *   out_scores [B x k] f32 (sim, descending), out_rows [B x k] int32 (row ordinals; ties ->
- *   lowest row); when k > n_rows the tail is filled with score -inf / row -1. */
+ *   lowest row); when k > n_rows the tail is filled with score -inf / row -1.
+ * How the rows are found does not change what is returned: up to four queries over a big fp32 corpus
+ * rank on an fp16 "HI plane" of the corpus (2 B per element, kept by the index), bound the error
+ * rigorously and re-score the candidates with the exact kernels; 96 or more queries rank through a
+ * GEMM with fused candidate lists instead of a score matrix.  Both are bit-identical to the plain
+ * pass + selection and fall back to it on the device where their bounds do not hold. */
 int rl_search_rows(rl_index* index, const float* queries, int32_t n_queries, int32_t k,
                    float* out_scores, int32_t* out_rows, int mem, void* stream);
 
@@ -305,8 +310,10 @@ int rl_partition_similarity(const float* X, int64_t n, int32_t dim, const int64_
  * given index / query.  kind: 0 = rl_maxsim_scores kernel only, 1 = rl_search_rows scan kernel
  * only (no selection), 2 = the two-queries-per-pass MaxSim kernel of rl_maxsim_topk_batch (query_vecs_dev
  * then holds two queries of nq / 2 vectors each; RL_ERR_UNSUPPORTED where that kernel does not apply), 3 = the
- * eight-queries-per-pass kernel over the pre-split corpus image (eight queries of nq / 8 vectors each).  Used so that roofline.achieved is measured with HIP events on the stream
- * the kernel runs on. */
+ * eight-queries-per-pass kernel over the pre-split corpus image (eight queries of nq / 8 vectors each), 4 = the
+ * ranking pass of the half-bytes search of rl_search_rows (nq <= 4 queries over the fp16 HI plane;
+ * RL_ERR_UNSUPPORTED when the index has none).  Used so that roofline.achieved is measured with HIP
+ * events on the stream the kernel runs on. */
 int rl_time_kernel(rl_index* index, int kind, const float* query_vecs_dev, int32_t nq, int32_t iters,
                    float* out_ms_total, void* stream);
 

@@ -1662,6 +1662,11 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
         if (kind == 3) st = gemm_pass(idx, nq / GEMM_PASS_QUERIES, GEMM_PASS_QUERIES, 0, GEMM_PASS_QUERIES, idx->scores.as<float>(), ldc, s);
         else if (kind == 0) st = maxsim_scores_device(idx, q_dev, nq, idx->scores.as<float>(), s);
         else if (kind == 2) st = pairs_pass(idx, nq / 2, 2, 0, idx->scores.as<float>(), ldc, s);
+        else if (kind == 4) {  // the ranking pass of the half-bytes search: the f16 stream kernel over the HI plane
+            st = hi_valid(idx) ? launch_maxsim_stream16(idx->hiplane.as<uint16_t>(), idx->n_rows, idx->dim, q_dev, nq, idx->row_to_chunk, idx->offsets,
+                                                        idx->n_chunks, 1, idx->scores.as<float>(), ld, idx->n_cu, s)
+                               : fail(RL_ERR_UNSUPPORTED, "rl_time_kernel: the index has no HI plane");
+        }
         else st = score_rows(idx, q_dev, nq, ld, s);
     }
     RL_HIP(hipEventRecord(e1, s));
