@@ -1101,8 +1101,10 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
 //       full pass, ties included;
 //   (4) list overflow (more than 1024 rows within 2 m of the k-th: near-duplicate-heavy corpora): the full-precision pass,
 //       launched always, returning at once when the flag is clear -- nothing here synchronises with the host.
-// cosine / dot, B <= 4, k <= 512, no row mask; RL_ERR_UNSUPPORTED otherwise.
-int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float* d_scores, int32_t* d_rows, int64_t ld, hipStream_t s) {
+// cosine / dot, B <= 4, k <= 512, with or without a row mask (masked rows rank -inf in the approximate pass: they are never
+// candidates); RL_ERR_UNSUPPORTED otherwise.
+int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float* d_scores, int32_t* d_rows, int64_t ld, hipStream_t s,
+                   const uint32_t* d_row_bits) {
     const char* off_env = std::getenv("RAGLITE_NO_HI_SEARCH");  // A/B switch, read per call (tests flip it)
     if (off_env && off_env[0] && off_env[0] != '0') return RL_ERR_UNSUPPORTED;
     const int mode = scan_mode(idx->metric);
@@ -1129,8 +1131,14 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     int st = launch_maxsim_stream16(idx->hiplane.as<uint16_t>(), n, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, sc, ld,
                                     idx->n_cu, s);
     if (st != RL_OK) return st;
-    RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f / idx->hi_scale));
-    RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s, nullptr, true));
+    if (d_row_bits) {  // tombstones / metadata filter: masked rows rank -inf, so they reach neither the top-k nor the candidates
+        RL_TRY(launch_transform(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, s, 1.0f / idx->hi_scale));
+        RL_TRY(launch_mask_scores(sc, nb, n, ld, d_row_bits, s));
+        RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s));
+    } else {
+        RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f / idx->hi_scale));
+        RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s, nullptr, true));
+    }
     // ---- (2) every row that could be in the exact top-k ------------------------------------------------------------------------------------
     const float m_rel = 0x1p-10f + 0x1p-12f;
     RL_TRY(launch_approx_threshold(ts, nb, k, d_q, dim, mode, m_rel, std::sqrt((float)dim) * idx->max_abs, thr, cnt, flag, s));
@@ -1147,8 +1155,14 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     st = launch_maxsim_stream(idx->E, n, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, sc, ld, idx->n_cu, s, idx->split_scale,
                               flag);
     if (st != RL_OK) return st;
-    RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f, flag));
-    RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, d_scores, d_rows, s, flag, true));
+    if (d_row_bits) {  // (the mask needs no guard: applied to scores nobody reads it changes nothing)
+        RL_TRY(launch_transform(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, s, 1.0f, flag));
+        RL_TRY(launch_mask_scores(sc, nb, n, ld, d_row_bits, s));
+        RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, d_scores, d_rows, s, flag));
+    } else {
+        RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f, flag));
+        RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, d_scores, d_rows, s, flag, true));
+    }
     return RL_OK;
 }
 
@@ -1174,8 +1188,9 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
             if (st == RL_OK) continue;
             if (st != RL_ERR_UNSUPPORTED) return st;
         }
-        if (!d_row_bits && !cut && nb <= 4) {  // few queries over a big fp32 corpus: half the bytes through the HI plane
-            const int st = search_rows_hi(idx, d_q + (int64_t)b0 * idx->dim, nb, k, d_scores + (int64_t)b0 * k, d_rows + (int64_t)b0 * k, ld, s);
+        if (!cut && nb <= 4) {  // few queries over a big fp32 corpus: half the bytes through the HI plane
+            const int st = search_rows_hi(idx, d_q + (int64_t)b0 * idx->dim, nb, k, d_scores + (int64_t)b0 * k, d_rows + (int64_t)b0 * k, ld, s,
+                                          d_row_bits);
             if (st == RL_OK) continue;
             if (st != RL_ERR_UNSUPPORTED) return st;
         }

@@ -119,8 +119,10 @@ int launch_cast_f16(const float* src, uint16_t* dst, int64_t count, hipStream_t 
 int launch_cast_f16_rtz(const float* src, uint16_t* dst, int64_t count, float scale, hipStream_t s);
 int launch_fill_f32(float* dst, float value, int64_t count, hipStream_t s);
 // in-place metric transform of raw dots: scores[b*ld+i] (i<n), per-row norm / sumsq, per-query norm.
+// (pre_scale: the raw dots are multiplied by it first -- a power of two, exact; run_if as in launch_topk)
 int launch_transform(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm,
-                     const float* row_sumsq, const float* queries, int32_t dim, int mode, hipStream_t s);
+                     const float* row_sumsq, const float* queries, int32_t dim, int mode, hipStream_t s, float pre_scale = 1.0f,
+                     const uint32_t* run_if = nullptr);
 
 // select.hip
 struct SelectWorkspace {      // device buffers sized for `capacity_queries`

@@ -175,8 +175,10 @@ __global__ __launch_bounds__(256) void fill_f32_kernel(float* __restrict__ dst, 
 __global__ __launch_bounds__(256) void transform_kernel(float* __restrict__ scores, int64_t n, int64_t ld,
                                                          const float* __restrict__ row_norm,
                                                          const float* __restrict__ row_sumsq,
-                                                         const float* __restrict__ queries, int dim, int mode) {
+                                                         const float* __restrict__ queries, int dim, int mode, float pre_scale,
+                                                         const uint32_t* __restrict__ run_if) {
     __shared__ float part[4];
+    if (run_if && *run_if == 0u) return;
     const int b = blockIdx.y;
     float ss = 0.f;
     for (int c = threadIdx.x; c < dim; c += 256) {
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void transform_kernel(float* __restrict__ scor
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const float d = scores[(int64_t)b * ld + i];
-        const float out = transform_score(d, mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
+        const float out = transform_score(d * pre_scale, mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
         scores[(int64_t)b * ld + i] = out;
     }
 }
@@ -322,11 +324,11 @@ int launch_fill_f32(float* dst, float value, int64_t count, hipStream_t s) {
 }
 
 int launch_transform(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm, const float* row_sumsq,
-                     const float* queries, int32_t dim, int mode, hipStream_t s) {
+                     const float* queries, int32_t dim, int mode, hipStream_t s, float pre_scale, const uint32_t* run_if) {
     if (n <= 0 || nb <= 0) return RL_OK;
     const int bx = (int)std::min<int64_t>((n + 255) / 256, 1024);
     hipLaunchKernelGGL(transform_kernel, dim3(bx, nb), dim3(256), 0, s, scores, n, ld, row_norm, row_sumsq, queries,
-                       (int)dim, mode);
+                       (int)dim, mode, pre_scale, run_if);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -104,3 +104,32 @@ def test_hi_plane_follows_append_and_two_stage_search():
     assert cn == cn0 and np.array_equal(cc, cc0) and _same(cs, cs0)
     idx.close()
     ref.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_hi_search_with_filter_and_tombstones(metric):
+    """Metadata filter / deleted chunks: masked rows rank -inf in the approximate pass, so they are neither in its top-k nor
+    among the candidates; a filter that leaves fewer than k rows makes the bound unusable and the full pass answers."""
+    rng = np.random.default_rng(21)
+    n, dim, k = 70_000, 1024, 100
+    E = oracle.synth_matrix(9950, n, dim)
+    Q = oracle.synth_matrix(9951, 2, dim)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    ok = rng.random(n) < 0.4
+    S, R = idx.search_rows(Q, k, chunk_filter=ok)
+    with _env(RAGLITE_NO_HI_SEARCH="1"):
+        S0, R0 = idx.search_rows(Q, k, chunk_filter=ok)
+    assert np.array_equal(R, R0) and _same(S, S0) and ok[R].all()
+    dead = np.unique(R[:, :30])
+    idx.delete_chunks(dead)
+    S1, R1 = idx.search_rows(Q, k)
+    with _env(RAGLITE_NO_HI_SEARCH="1"):
+        S2, R2 = idx.search_rows(Q, k)
+    assert np.array_equal(R1, R2) and _same(S1, S2) and not np.isin(R1, dead).any()
+    few = np.zeros(n, bool)
+    few[rng.choice(n, 37, replace=False)] = True
+    S3, R3 = idx.search_rows(Q[0], k, chunk_filter=few)
+    with _env(RAGLITE_NO_HI_SEARCH="1"):
+        S4, R4 = idx.search_rows(Q[0], k, chunk_filter=few)
+    assert np.array_equal(R3, R4) and _same(S3, S4) and (R3 >= 0).sum() <= 37
+    idx.close()
