@@ -1093,7 +1093,7 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
 //       top-k;
 //   (2) |approximate - exact| <= m for every row, rigorously: the dropped lo half is < 2^-10 of its element (truncation), so
 //       the dot product moves by <= 2^-10 |e| |q| (Cauchy-Schwarz) -- m = 2^-10 for a cosine, 2^-10 sqrt(dim) max|e| |q| for a
-//       dot product, plus 2^-12 for the fp32 roundings of both passes.  A row can belong to the exact top-k only if its
+//       dot product, plus 2^-11 for the fp32 roundings of both passes.  A row can belong to the exact top-k only if its
 //       approximate score reaches (k-th best approximate) - 2 m: one more pass over the 4 B per row of approximate scores
 //       collects exactly those rows (k + a few dozen on embedding-like data; a list holds 1024);
 //   (3) the candidates' fp32 rows are gathered and scored by the SAME kernels the full pass uses (a row's score does not
@@ -1140,7 +1140,9 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
         RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s, nullptr, true));
     }
     // ---- (2) every row that could be in the exact top-k ------------------------------------------------------------------------------------
-    const float m_rel = 0x1p-10f + 0x1p-12f;
+    // 2^-10 for the dropped lo halves + 2^-11 for everything fp32 does to both passes (worst case of a 1024-term fp32 sum:
+    // 6e-5 each; the query's own 2^-22 split; the metric's two roundings)
+    const float m_rel = 0x1p-10f + 0x1p-11f;
     RL_TRY(launch_approx_threshold(ts, nb, k, d_q, dim, mode, m_rel, std::sqrt((float)dim) * idx->max_abs, thr, cnt, flag, s));
     RL_TRY(launch_collect_above(sc, nb, n, ld, thr, mode == SCAN_COSINE ? idx->norm : nullptr, cap, ci, gn, cnt, flag, s));
     // ---- (3) exact scores of the candidates, by the kernels of the full pass (slots past a list's length hold stale row numbers:
