@@ -168,7 +168,7 @@ int rl_index_arithmetic(rl_index* index, int* in_effect);
  *   queries [B x dim] f32;  k <= 2048
  *   out_scores [B x k] f32 (sim, descending), out_rows [B x k] int32 (row ordinals; ties ->
  *   lowest row); when k > n_rows the tail is filled with score -inf / row -1.
- * How the rows are found does not change what is returned: up to four queries over a big fp32 corpus
+ * How the rows are found does not change what is returned: up to 16 queries over a big fp32 corpus
  * rank on an fp16 "HI plane" of the corpus (2 B per element, kept by the index), bound the error
  * rigorously and re-score the candidates with the exact kernels; 96 or more queries rank through a
  * GEMM with fused candidate lists instead of a score matrix.  Both are bit-identical to the plain

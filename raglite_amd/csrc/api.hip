@@ -1086,7 +1086,7 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
     return RL_OK;
 }
 
-// Exact row top-k of up to four queries at HALF the bytes of a corpus pass (BASELINE cfg 2, `ORDER BY dist LIMIT k` of
+// Exact row top-k of up to 16 queries at HALF the bytes of a corpus pass (BASELINE cfg 2, `ORDER BY dist LIMIT k` of
 // src/raglite/_search.py:69-79 for one query): the single-query search is HBM-bound on the 4 B per element of the fp32 corpus,
 // and the hi halves of the fp16 split carry 11 of every element's 24 significand bits in 2 B.
 //   (1) the f16 stream kernel over the HI plane -> approximate dots (query in full hi + lo precision), the metric, their exact
@@ -1101,7 +1101,8 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
 //       full pass, ties included;
 //   (4) list overflow (more than 1024 rows within 2 m of the k-th: near-duplicate-heavy corpora): the full-precision pass,
 //       launched always, returning at once when the flag is clear -- nothing here synchronises with the host.
-// cosine / dot, B <= 4, k <= 512, with or without a row mask (masked rows rank -inf in the approximate pass: they are never
+// cosine / dot, B <= 16 (measured at 1 M x 1024: 1.6x at B = 1, 1.3x at B = 16, slower at B = 32 where the gather and the
+// re-scoring of 32 x 1024 candidate rows cost more than the half pass saves), k <= 512, with or without a row mask (masked rows rank -inf in the approximate pass: they are never
 // candidates); RL_ERR_UNSUPPORTED otherwise.
 int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float* d_scores, int32_t* d_rows, int64_t ld, hipStream_t s,
                    const uint32_t* d_row_bits) {
@@ -1109,7 +1110,7 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     if (off_env && off_env[0] && off_env[0] != '0') return RL_ERR_UNSUPPORTED;
     const int mode = scan_mode(idx->metric);
     const int64_t n = idx->n_rows;
-    if (!hi_valid(idx) || nb > 4 || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT) || n < 65536) return RL_ERR_UNSUPPORTED;
+    if (!hi_valid(idx) || nb > 16 || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT) || n < 65536) return RL_ERR_UNSUPPORTED;
     const int32_t dim = idx->dim, cap = 1024;  // candidates per query (expected: k + a few dozen)
     const int64_t nc = (int64_t)nb * cap, ldx = nc;
     // ---- scratch: approximate top-k scores (+ unused ids), thresholds, counters + flag, candidate rows, their norms, the
@@ -1190,7 +1191,7 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
             if (st == RL_OK) continue;
             if (st != RL_ERR_UNSUPPORTED) return st;
         }
-        if (!cut && nb <= 4) {  // few queries over a big fp32 corpus: half the bytes through the HI plane
+        if (!cut && nb <= 16) {  // a few queries over a big fp32 corpus: half the bytes through the HI plane
             const int st = search_rows_hi(idx, d_q + (int64_t)b0 * idx->dim, nb, k, d_scores + (int64_t)b0 * k, d_rows + (int64_t)b0 * k, ld, s,
                                           d_row_bits);
             if (st == RL_OK) continue;

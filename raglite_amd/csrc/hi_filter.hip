@@ -2,7 +2,7 @@
 // (2 B per element) ranks approximately, a rigorous error bound turns the approximate top of the list into a candidate set
 // that provably contains the exact top-k, and the candidates are re-scored with the exact kernels.
 //
-// a6 + a7 of SURVEY.md section 8a (src/raglite/_search.py:69-79) for B <= 4 queries: results identical to the full-precision
+// a6 + a7 of SURVEY.md section 8a (src/raglite/_search.py:69-79) for B <= 16 queries: results identical to the full-precision
 // pass, bit for bit.
 #include "common.h"
 
@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void approx_threshold_kernel(const float* __re
                                                                 const float* __restrict__ queries, int dim, int mode, float m_rel,
                                                                 float e_norm_bound, float* __restrict__ thr, uint32_t* __restrict__ cnt,
                                                                 uint32_t* __restrict__ flag) {
-    // ONE block for all (<= 4) queries: it also zeroes the candidate counters and the flag of this call (no memset launch).
+    // ONE block for all (<= 16) queries: it also zeroes the candidate counters and the flag of this call (no memset launch).
     __shared__ float part[4];
     bool bad = false;
     for (int b = 0; b < nb; ++b) {

@@ -39,7 +39,8 @@ def _same(a, b):
 
 
 @pytest.mark.parametrize("metric", ["cosine", "dot"])
-@pytest.mark.parametrize("n,dim,B,k", [(70_000, 1024, 1, 100), (66_000, 1024, 4, 512), (140_000, 512, 2, 10), (530_000, 128, 3, 100)])
+@pytest.mark.parametrize("n,dim,B,k", [(70_000, 1024, 1, 100), (66_000, 1024, 4, 512), (140_000, 512, 2, 10), (530_000, 128, 3, 100),
+                                        (70_000, 1024, 16, 100), (68_000, 1024, 9, 40)])
 def test_hi_search_equals_full_pass_bitwise(metric, n, dim, B, k):
     E = oracle.synth_matrix(9500 + dim, n, dim)
     Q = oracle.synth_matrix(9600 + B, B, dim)
