@@ -1534,7 +1534,9 @@ int rl_maxsim_rerank(rl_index* idx, const float* query_vecs, int32_t n_queries, 
     }
     int st = idx->E16 ? launch_maxsim_cand16(idx->E16, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s)
                       : launch_maxsim_cand(idx->E, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s, idx->split_scale);
-    if (st == RL_ERR_UNSUPPORTED && !idx->E16)
+    if (st == RL_ERR_UNSUPPORTED && !idx->E16)  // other dims: the fp32-MFMA pairs kernel (dim % 16 == 0, <= 1024, nq <= 32) ...
+        st = launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, d_c, n_cand, n_queries, d_o, s);
+    if (st == RL_ERR_UNSUPPORTED && !idx->E16)  // ... and the VALU backstop for everything else
         st = launch_maxsim_generic(idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, d_c, n_cand,
                                    n_queries, d_o, s);
     RL_TRY(st);
