@@ -241,6 +241,13 @@ struct rl_index {
     rl::Pool hiplane, hibuf;
     float hi_scale = 0.f;                 // the scale the plane was built with; 0 = no plane
     int64_t hi_rows = 0;                  // rows it covers
+    // ... and the same halves in the one-plane IMAGE layout (maxsim_gemm.hip HALF): what the approximate MaxSim pass of a
+    // batch multiplies (maxsim_batch_hi); max_row_norm = max |e| over the rows, for its error bound
+    rl::Pool hi_image;
+    float hi_image_scale = 0.f;
+    int64_t hi_image_rows = 0;
+    float max_row_norm = 0.f;
+    int64_t max_row_norm_rows = 0;        // rows folded into max_row_norm
     // The scratch above is shared by all calls on this handle; `mu` serialises only their host side.  Device-mode calls are
     // asynchronous, so a call arriving on a DIFFERENT stream than the previous one first waits for that stream.
     hipStream_t last_stream = nullptr;
@@ -350,7 +357,58 @@ int refresh_planes(rl_index* idx, hipStream_t s) {
 bool hi_valid(const rl_index* idx) {
     return idx->hi_scale > 0.f && idx->hi_scale == idx->split_scale && idx->hi_rows == idx->n_rows && idx->n_rows > 0;
 }
+bool hi_image_valid(const rl_index* idx) {
+    return idx->hi_image_scale > 0.f && idx->hi_image_scale == idx->split_scale && idx->hi_image_rows == idx->n_rows && idx->n_rows > 0 &&
+           idx->max_row_norm_rows == idx->n_rows && idx->max_row_norm > 0.f;
+}
+// The HI halves in image layout + the largest row norm (synchronises the stream: build / append / compact only).
+int refresh_hi_image(rl_index* idx, hipStream_t s) {
+    static const bool off = std::getenv("RAGLITE_NO_HI_PLANE") != nullptr;  // A/B switch (shared with the row-major plane)
+    const bool want = !off && !idx->E16 && idx->E && idx->split_scale > 0.f && idx->dim % 32 == 0 && idx->dim >= 32 && idx->dim <= 1024 &&
+                      (int64_t)idx->n_rows * idx->dim >= (int64_t(64) << 20) && image_valid(idx);
+    if (!want) {
+        idx->hi_image.release();
+        idx->hi_image_scale = 0.f;
+        idx->hi_image_rows = 0;
+        return RL_OK;
+    }
+    const int64_t cap = std::max<int64_t>(idx->n_rows, idx->owns_E ? idx->cap_rows : idx->n_rows);
+    const size_t need = rl::planes_bytes(cap, idx->dim, true);
+    int64_t first = idx->hi_image_scale == idx->split_scale ? (idx->hi_image_rows & ~int64_t(15)) : 0;
+    if (idx->hi_image.cap < need) first = 0;
+    if (idx->hi_image.reserve(need) != RL_OK) {
+        (void)hipGetLastError();
+        idx->hi_image.release();
+        idx->hi_image_scale = 0.f;
+        idx->hi_image_rows = 0;
+        return RL_OK;
+    }
+    const int st = rl::launch_presplit_hi_rows(idx->E, first, idx->n_rows, idx->dim, idx->split_scale, idx->hi_image.p, s);
+    if (st == RL_ERR_UNSUPPORTED) {
+        idx->hi_image.release();
+        idx->hi_image_scale = 0.f;
+        idx->hi_image_rows = 0;
+        return RL_OK;
+    }
+    RL_TRY(st);
+    idx->hi_image_scale = idx->split_scale;
+    idx->hi_image_rows = idx->n_rows;
+    if (idx->max_row_norm_rows != idx->n_rows) {  // fold the new rows' norms in
+        const int64_t from = std::min<int64_t>(idx->max_row_norm_rows, idx->n_rows);
+        if (!idx->d_range) RL_HIP(hipMalloc(&idx->d_range, 16));
+        uint32_t bits = 0;
+        std::memcpy(&bits, &idx->max_row_norm, 4);
+        RL_HIP(hipMemcpyAsync(idx->d_range + 3, &bits, 4, hipMemcpyHostToDevice, s));
+        RL_TRY(rl::launch_max_row_norm(idx->E + (size_t)from * idx->dim, idx->n_rows - from, idx->dim, idx->d_range + 3, s));
+        RL_HIP(hipMemcpyAsync(&bits, idx->d_range + 3, 4, hipMemcpyDeviceToHost, s));
+        RL_HIP(hipStreamSynchronize(s));
+        std::memcpy(&idx->max_row_norm, &bits, 4);
+        idx->max_row_norm_rows = idx->n_rows;
+    }
+    return RL_OK;
+}
 int refresh_hi_plane(rl_index* idx, hipStream_t s) {
+    RL_TRY(refresh_hi_image(idx, s));
     static const bool off = std::getenv("RAGLITE_NO_HI_PLANE") != nullptr;  // A/B switch
     const int32_t d = idx->dim;
     const bool dim_ok = d == 128 || d == 256 || d == 384 || d == 512 || d == 768 || d == 1024;
@@ -562,6 +620,7 @@ int rl_index_destroy(rl_index* idx) {
     idx->rankbuf.release();
     idx->hiplane.release();
     idx->hibuf.release();
+    idx->hi_image.release();
     select_workspace_free(idx->ws);
     idx->scores.release();
     idx->hits.release();
@@ -794,6 +853,10 @@ int rl_index_compact(rl_index* idx, int64_t* out_remap, int64_t* new_n_rows, int
     idx->planes_scale = 0.f;
     idx->hi_rows = 0;
     idx->hi_scale = 0.f;
+    idx->hi_image_rows = 0;
+    idx->hi_image_scale = 0.f;
+    idx->max_row_norm = 0.f;
+    idx->max_row_norm_rows = 0;
     RL_TRY(scan_row_range(idx, 0, new_n, s));
     RL_TRY(refresh_planes(idx, s));
     RL_TRY(refresh_hi_plane(idx, s));
@@ -1475,13 +1538,79 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
     // Eight queries share a pass over the pre-split corpus image where the index has one (maxsim_gemm.hip); what is left
     // of the batch (fewer than three queries) goes through the streaming kernels as before.
     int32_t base = 0;
+    bool hi_done = false;  // queries [0, base) were ranked by the half-bytes pipeline below (results already in d_s / d_c)
     {
         const int st = gemm_prepare(idx, d_q, nq, (int64_t)q_elems, n_queries, s);
         if (st == RL_OK) {
-            while (n_queries - base >= GEMM_PASS_MIN_QUERIES) {
-                const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_queries - base);
-                RL_TRY(gemm_pass(idx, nq, n_queries, base, n_q, sc + (int64_t)base * ld, ld, s));
-                base += n_q;
+            const int32_t n_gemm = n_queries - base >= GEMM_PASS_MIN_QUERIES
+                                       ? (n_queries / GEMM_PASS_QUERIES) * GEMM_PASS_QUERIES +
+                                             ((n_queries % GEMM_PASS_QUERIES) >= GEMM_PASS_MIN_QUERIES ? n_queries % GEMM_PASS_QUERIES : 0)
+                                       : 0;
+            const char* off_env = std::getenv("RAGLITE_NO_HI_MAXSIM");  // A/B switch, read per call (tests flip it)
+            const bool hi_off = off_env && off_env[0] && off_env[0] != '0';
+            if (n_gemm > 0 && !hi_off && hi_image_valid(idx) && k <= 512) {
+                // ---- MaxSim of a batch at two MFMA products per multiply instead of three (the headline path) -------------------------
+                // (1) approximate chunk scores: the eight-query pass over the HI image (q_hi.e_hi + q_lo.e_hi);
+                // (2) |approximate - exact| <= m = (2^-10 + 2^-11) max|e| sum_i |q_i| for every chunk (the per-pair bound of
+                //     search_rows_hi under the max over a chunk's rows and the sum over the query vectors), so the chunks with
+                //     approximate score >= (k-th best approximate) - 2 m contain the exact top-k: collected per query;
+                // (3) their exact scores by maxsim_pairs_kernel (fp32 matrix pipe), ranked by (score desc, chunk asc);
+                // (4) list overflow / unusable bound -> device flag -> the full-precision passes + selection, launched always,
+                //     returning at once when the flag is clear.
+                const int32_t cap = 2048;  // (the benchmark corpus needs ~1 150: score spread sigma ~ 34, window 2 m = 34)
+                const size_t words = (size_t)n_gemm * k * 2 + (size_t)n_gemm * 2 + 16 + (size_t)n_gemm * cap * 2;
+                RL_TRY(idx->hibuf.reserve(words * 4));
+                float* ts = idx->hibuf.as<float>();                            // [n x k] approximate top-k scores
+                int32_t* ti = reinterpret_cast<int32_t*>(ts + (size_t)n_gemm * k);
+                float* thr = reinterpret_cast<float*>(ti + (size_t)n_gemm * k);  // [n]
+                uint32_t* cnt = reinterpret_cast<uint32_t*>(thr + n_gemm);       // [n]
+                uint32_t* flag = cnt + n_gemm;                                   // (16 words)
+                int32_t* ci = reinterpret_cast<int32_t*>(flag + 16);             // [n x cap] candidate chunks
+                float* es = reinterpret_cast<float*>(ci + (size_t)n_gemm * cap); // [n x cap] their exact scores
+                RL_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), s));
+                RL_HIP(hipMemsetAsync(ci, 0xff, (size_t)n_gemm * cap * sizeof(int32_t), s));  // unused slots: -1 = "no chunk"
+                for (int32_t b = 0; b < n_gemm; b += GEMM_PASS_QUERIES) {
+                    const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_gemm - b);
+                    RL_TRY(launch_maxsim_gemm(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
+                                              idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale, true));
+                }
+                RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // tombstones never become candidates
+                RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, ts, ti, s));
+                const float m_rel = 0x1p-10f + 0x1p-11f;
+                RL_TRY(launch_maxsim_threshold(ts, n_gemm, k, d_q, nq, idx->dim, (int64_t)q_elems, m_rel, idx->max_row_norm, thr, cnt, flag, s));
+                RL_TRY(launch_collect_above(sc, n_gemm, idx->n_chunks, ld, thr, nullptr, cap, ci, nullptr, cnt, flag, s));
+                if (std::getenv("RAGLITE_HI_DEBUG")) {  // diagnostic: synchronises; list lengths, threshold and flag of this batch to stderr
+                    std::vector<uint32_t> h_cnt(n_gemm);
+                    std::vector<float> h_thr(n_gemm), h_ts((size_t)n_gemm * k);
+                    uint32_t h_flag = 0;
+                    RL_HIP(hipStreamSynchronize(s));
+                    RL_HIP(hipMemcpy(h_cnt.data(), cnt, (size_t)n_gemm * 4, hipMemcpyDeviceToHost));
+                    RL_HIP(hipMemcpy(h_thr.data(), thr, (size_t)n_gemm * 4, hipMemcpyDeviceToHost));
+                    RL_HIP(hipMemcpy(h_ts.data(), ts, (size_t)n_gemm * k * 4, hipMemcpyDeviceToHost));
+                    RL_HIP(hipMemcpy(&h_flag, flag, 4, hipMemcpyDeviceToHost));
+                    uint32_t mx = 0; double mean = 0;
+                    for (int32_t b = 0; b < n_gemm; ++b) { mx = std::max(mx, h_cnt[b]); mean += h_cnt[b]; }
+                    fprintf(stderr, "HIDEBUG n=%d k=%d flag=%u max_row_norm=%g cnt mean=%.1f max=%u  q0: best=%g kth=%g thr=%g\n", n_gemm, k, h_flag,
+                            idx->max_row_norm, mean / n_gemm, mx, h_ts[0], h_ts[k - 1], h_thr[0]);
+                }
+                RL_TRY(launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, ci, cap, n_gemm, es, s));
+                RL_TRY(launch_merge_topk(es, ci, 1, n_gemm, cap, k, d_s, d_c, s, cnt));
+                for (int32_t b = 0; b < n_gemm; b += GEMM_PASS_QUERIES) {  // (4)
+                    const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_gemm - b);
+                    RL_TRY(launch_maxsim_gemm(idx->planes.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
+                                              idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, image_scale(idx),
+                                              idx->E16 != nullptr, flag));
+                }
+                RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // (harmless on scores nobody reads)
+                RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, d_s, d_c, s, flag));
+                base = n_gemm;
+                hi_done = true;
+            } else {
+                while (n_queries - base >= GEMM_PASS_MIN_QUERIES) {
+                    const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_queries - base);
+                    RL_TRY(gemm_pass(idx, nq, n_queries, base, n_q, sc + (int64_t)base * ld, ld, s));
+                    base += n_q;
+                }
             }
         } else if (st != RL_ERR_UNSUPPORTED) {
             return st;
@@ -1497,8 +1626,14 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
     for (int32_t b = 0; b < paired; b += 2) RL_TRY(pairs_pass(idx, nq, paired, b, sc + (int64_t)(base + b) * ld, ld, s));
     for (int32_t b = base + paired; b < n_queries; ++b)
         RL_TRY(maxsim_scores_device(idx, d_q + (size_t)b * q_elems, nq, sc + (int64_t)b * ld, s));
-    RL_TRY(mask_chunk_scores(idx, sc, n_queries, ld, nullptr, s));  // tombstones (no-op without deletions)
-    RL_TRY(launch_topk(sc, n_queries, idx->n_chunks, ld, k, idx->ws, d_s, d_c, s));
+    {   // what the half-bytes pipeline did not rank: every query, or the one or two left over
+        const int32_t first = hi_done ? base : 0;
+        if (n_queries > first) {
+            RL_TRY(mask_chunk_scores(idx, sc + (int64_t)first * ld, n_queries - first, ld, nullptr, s));  // tombstones (no-op without deletions)
+            RL_TRY(launch_topk(sc + (int64_t)first * ld, n_queries - first, idx->n_chunks, ld, k, idx->ws, d_s + (int64_t)first * k,
+                               d_c + (int64_t)first * k, s));
+        }
+    }
     if (idx->live_chunk_bits) RL_TRY(launch_fix_masked(d_s, d_c, (int64_t)n_queries * k, s));
     RL_TRY(stage_out_end(out_scores, (size_t)n_queries * k, mem, s, t_s));
     RL_TRY(stage_out_end(out_chunks, (size_t)n_queries * k, mem, s, t_c));
@@ -1663,7 +1798,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     const int64_t ldc = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
     if (kind == 0) RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));
     else if (kind == 2) RL_TRY(idx->scores.reserve((size_t)2 * ldc * sizeof(float)));
-    else if (kind == 3) RL_TRY(idx->scores.reserve((size_t)GEMM_PASS_QUERIES * ldc * sizeof(float)));
+    else if (kind == 3 || kind == 5) RL_TRY(idx->scores.reserve((size_t)GEMM_PASS_QUERIES * ldc * sizeof(float)));
     else RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)nq * ld * sizeof(float), 16)));
     hipEvent_t e0, e1;
     RL_HIP(hipEventCreate(&e0));
@@ -1673,7 +1808,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
         st = pairs_prepare(idx, q_dev, nq / 2, (int64_t)(nq / 2) * idx->dim, 2, s);
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the pair kernel does not apply to this index / shape") : st; }
     }
-    if (kind == 3) {  // eight queries of nq / 8 vectors each
+    if (kind == 3 || kind == 5) {  // eight queries of nq / 8 vectors each
         st = gemm_prepare(idx, q_dev, nq / GEMM_PASS_QUERIES, (int64_t)(nq / GEMM_PASS_QUERIES) * idx->dim, GEMM_PASS_QUERIES, s);
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the eight-query kernel does not apply to this index / shape") : st; }
     }
@@ -1682,6 +1817,12 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
         if (kind == 3) st = gemm_pass(idx, nq / GEMM_PASS_QUERIES, GEMM_PASS_QUERIES, 0, GEMM_PASS_QUERIES, idx->scores.as<float>(), ldc, s);
         else if (kind == 0) st = maxsim_scores_device(idx, q_dev, nq, idx->scores.as<float>(), s);
         else if (kind == 2) st = pairs_pass(idx, nq / 2, 2, 0, idx->scores.as<float>(), ldc, s);
+        else if (kind == 5) {  // the approximate MaxSim pass of a batch: eight queries over the HI image (two MFMA products)
+            st = hi_image_valid(idx) ? launch_maxsim_gemm(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, GEMM_PASS_QUERIES, 0,
+                                                          GEMM_PASS_QUERIES, nq / GEMM_PASS_QUERIES, idx->row_to_chunk, idx->offsets,
+                                                          idx->ends.as<uint32_t>(), idx->scores.as<float>(), ldc, idx->n_cu, s, idx->split_scale, true)
+                                     : fail(RL_ERR_UNSUPPORTED, "rl_time_kernel: the index has no HI image");
+        }
         else if (kind == 4) {  // the ranking pass of the half-bytes search: the f16 stream kernel over the HI plane
             st = hi_valid(idx) ? launch_maxsim_stream16(idx->hiplane.as<uint16_t>(), idx->n_rows, idx->dim, q_dev, nq, idx->row_to_chunk, idx->offsets,
                                                         idx->n_chunks, 1, idx->scores.as<float>(), ld, idx->n_cu, s)

@@ -166,6 +166,12 @@ int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const floa
 int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld, const float* thr, const float* row_norm, int32_t cap,
                          int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s);
 int launch_gather_f32(const float* src, const int32_t* idx, int64_t count, float* dst, hipStream_t s);
+// MaxSim flavour of the threshold: thr[b] = topk[b * k + k - 1] - 2 * m_rel * e_max * sum_i |q_i|; zeroes cnt[b]; sets *flag when
+// the k-th score is unusable.  One block per query.
+int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, const float* Q, int32_t nq, int32_t dim, int64_t q_stride,
+                            float m_rel, float e_max, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s);
+// max over rows of |e| (fp32, nudged up by 1e-6), folded into *bits (a float's bit pattern; start it at 0)
+int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, uint32_t* bits, hipStream_t s);
 int launch_diag_blocks(const float* src, int64_t ld, int32_t k2, int64_t count, float* dst, hipStream_t s);
 
 // mask.hip: validity bitsets (metadata filter pushed down to the device, tombstones of deleted chunks)
@@ -214,13 +220,15 @@ int launch_maxsim_stream2(const void* D, bool f16, int64_t n_rows, int32_t dim, 
 size_t planes_bytes(int64_t rows, int32_t dim, bool half = false);
 int launch_presplit_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s);
 int launch_preformat_rows16(const uint16_t* E, int64_t first_row, int64_t n_rows, int32_t dim, void* planes, hipStream_t s);
+int launch_presplit_hi_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s);
 size_t chunk_ends_words(int64_t rows);
 int launch_chunk_ends(const int32_t* row_to_chunk, int64_t n_rows, uint32_t* ends, hipStream_t s);
 size_t query_planes_bytes(int32_t dim, int32_t n_queries);
 int launch_query_planes(const float* Q, int32_t dim, int32_t nq, int64_t q_stride, int32_t n_queries, void* buf, hipStream_t s);
 int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first,
                        int32_t n_q, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits,
-                       float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale, bool half = false);
+                       float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale, bool half = false,
+                       const uint32_t* run_if = nullptr);
 size_t score_planes_scratch_floats(int32_t nb, int32_t dim);
 int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores, int64_t ld,
                         const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale,

@@ -50,9 +50,17 @@ __global__ __launch_bounds__(256) void collect_above_kernel(const float* __restr
     const int b = blockIdx.y;
     const float t = thr[b];
     const float* s = scores + (int64_t)b * ld;
-    auto visit = [&](float v, int64_t i) {
-        if (v >= t) {
-            const uint32_t p = atomicAdd(cnt + b, 1u);
+    // one atomic per wave and call, not per row (a MaxSim batch collects ~1 000 chunks for each of 128 queries: 128 hot words)
+    auto visit = [&](float v, int64_t i, bool in_range) {
+        const bool hit = in_range && v >= t;
+        const uint64_t mask = __builtin_amdgcn_ballot_w64(hit);
+        if (mask == 0ull) return;  // (wave-uniform)
+        const int lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == __builtin_ctzll(mask)) base = atomicAdd(cnt + b, (uint32_t)__builtin_popcountll(mask));
+        base = __builtin_amdgcn_readlane(base, __builtin_ctzll(mask));
+        if (hit) {
+            const uint32_t p = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
             if (p < (uint32_t)cap) {
                 ids[(int64_t)b * cap + p] = (int32_t)i;
                 if (row_norm) norms[(int64_t)b * cap + p] = row_norm[i];
@@ -66,15 +74,67 @@ __global__ __launch_bounds__(256) void collect_above_kernel(const float* __restr
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4* s4 = reinterpret_cast<const f4*>(s);
         const int64_t n4 = n >> 2;
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
-            const f4 v = s4[i];
+        // (whole waves walk the loop together -- the ballot needs every lane -- so the trip count is rounded up per block)
+        for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n4; i0 += stride) {
+            const int64_t i = i0 + threadIdx.x;
+            const bool in = i < n4;
+            const f4 v = in ? s4[i] : (f4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int u = 0; u < 4; ++u) visit(v[u], (i << 2) + u);
+            for (int u = 0; u < 4; ++u) visit(v[u], (i << 2) + u, in);
         }
-        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) visit(s[(n4 << 2) + threadIdx.x], (n4 << 2) + threadIdx.x);
+        if (blockIdx.x == 0 && threadIdx.x < 64) {  // the n % 4 rows at the end: one wave
+            const bool in = threadIdx.x < (n & 3);
+            visit(in ? s[(n4 << 2) + threadIdx.x] : 0.f, (n4 << 2) + threadIdx.x, in);
+        }
     } else {
-        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) visit(s[i], i);
+        for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += stride) {
+            const int64_t i = i0 + threadIdx.x;
+            visit(i < n ? s[i] : 0.f, i, i < n);
+        }
     }
+}
+
+__global__ __launch_bounds__(256) void maxsim_threshold_kernel(const float* __restrict__ topk, int32_t k, const float* __restrict__ Q, int nq,
+                                                                int dim, int64_t q_stride, float m_rel, float e_max,
+                                                                float* __restrict__ thr, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag) {
+    // |approx - exact| of a chunk's MaxSim score <= sum_i max_j 2^-10 |q_i| |e_j| <= m_rel * e_max * sum_i |q_i|
+    __shared__ float part[4];
+    const int b = blockIdx.x;
+    const float* Qb = Q + (int64_t)b * q_stride;
+    float sum_norms = 0.f;  // (thread 0)
+    for (int i = 0; i < nq; ++i) {
+        float ss = 0.f;
+        for (int c = threadIdx.x; c < dim; c += 256) {
+            const float v = Qb[(int64_t)i * dim + c];
+            ss = fmaf(v, v, ss);
+        }
+        ss = wave_sum(ss);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) sum_norms += sqrtf((part[0] + part[1]) + (part[2] + part[3]));
+    }
+    if (threadIdx.x != 0) return;
+    const float t = topk[(int64_t)b * k + (k - 1)] - 2.0f * m_rel * e_max * sum_norms;
+    thr[b] = t;
+    cnt[b] = 0u;
+    if (!(t > -INFINITY)) atomicOr(flag, 1u);  // NaN or -inf: fewer than k scorable chunks
+}
+
+__global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restrict__ E, int64_t n_rows, int dim, uint32_t* __restrict__ bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    float mx = 0.f;
+    for (int64_t r = wave0; r < n_rows; r += n_waves) {
+        float ss = 0.f;
+        for (int c = lane; c < dim; c += 64) {
+            const float v = E[r * (int64_t)dim + c];
+            ss = fmaf(v, v, ss);
+        }
+        ss = wave_sum(ss);
+        mx = fmaxf(mx, sqrtf(ss));
+    }
+    if (lane == 0 && mx > 0.f) atomicMax(bits, __float_as_uint(mx * 1.000001f));  // (non-negative floats order like their bits)
 }
 
 __global__ __launch_bounds__(256) void gather_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int64_t count,
@@ -107,6 +167,23 @@ int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld,
     if (n <= 0 || nb <= 0) return RL_OK;
     const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((n + 4095) / 4096, 512));
     hipLaunchKernelGGL(collect_above_kernel, dim3(bx, nb), dim3(256), 0, s, scores, n, ld, thr, row_norm, cap, ids, norms, cnt, flag);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, const float* Q, int32_t nq, int32_t dim, int64_t q_stride,
+                            float m_rel, float e_max, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s) {
+    if (n_queries <= 0) return RL_OK;
+    hipLaunchKernelGGL(maxsim_threshold_kernel, dim3(n_queries), dim3(256), 0, s, topk, k, Q, (int)nq, (int)dim, q_stride, m_rel, e_max, thr, cnt,
+                       flag);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, uint32_t* bits, hipStream_t s) {
+    if (n_rows <= 0) return RL_OK;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_rows + 3) / 4, 256 * 8));
+    hipLaunchKernelGGL(max_row_norm_kernel, dim3(blocks), dim3(256), 0, s, E, n_rows, (int)dim, bits);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

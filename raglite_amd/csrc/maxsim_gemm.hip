@@ -118,6 +118,40 @@ __global__ __launch_bounds__(256) void preformat_rows16_kernel(const uint16_t* _
     *reinterpret_cast<uint4*>(planes + ((row >> 4) * nslab + s) * 1024 + kq * 256 + (row & 15) * 16) = v;
 }
 
+// The HI halves of the fp16 split of an fp32 corpus as a one-plane image (the layout of preformat_rows16_kernel): what the
+// approximate MaxSim pass of big batches multiplies (api.hip: maxsim_batch_hi) -- fp16(e * scale) rounded toward zero.
+__global__ __launch_bounds__(256) void presplit_hi_rows_kernel(const float* __restrict__ E, int64_t first_row, int64_t end_row,
+                                                                int64_t n_rows, int32_t dim, float scale, char* __restrict__ planes) {
+    const int32_t nslab = dim >> 5;
+    const int64_t per_row = (int64_t)nslab * 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t row = first_row + i / per_row;
+    if (row >= end_row) return;
+    const int32_t rem = (int32_t)(i % per_row), s = rem >> 2, kq = rem & 3;
+    f32x4 v0 = (f32x4){0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (row < n_rows) {
+        const float* p = E + row * dim + 32 * s + 8 * kq;
+        v0 = *reinterpret_cast<const f32x4*>(p);
+        v1 = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    const auto p0 = __builtin_amdgcn_cvt_pkrtz(v0[0] * scale, v0[1] * scale), p1 = __builtin_amdgcn_cvt_pkrtz(v0[2] * scale, v0[3] * scale);
+    const auto p2 = __builtin_amdgcn_cvt_pkrtz(v1[0] * scale, v1[1] * scale), p3 = __builtin_amdgcn_cvt_pkrtz(v1[2] * scale, v1[3] * scale);
+    uint4 o;
+    __builtin_memcpy(&o.x, &p0, 4); __builtin_memcpy(&o.y, &p1, 4); __builtin_memcpy(&o.z, &p2, 4); __builtin_memcpy(&o.w, &p3, 4);
+    *reinterpret_cast<uint4*>(planes + ((row >> 4) * nslab + s) * 1024 + kq * 256 + (row & 15) * 16) = o;
+}
+
+int launch_presplit_hi_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s) {
+    if (dim % 32 || dim < 32 || (reinterpret_cast<uintptr_t>(E) & 15)) return RL_ERR_UNSUPPORTED;
+    const int64_t end_row = (n_rows + 15) / 16 * 16;
+    if (end_row <= first_row) return RL_OK;
+    const int64_t threads = (end_row - first_row) * (dim / 8);
+    hipLaunchKernelGGL(presplit_hi_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, E, first_row, end_row, n_rows, dim,
+                       scale, static_cast<char*>(planes));
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 int launch_preformat_rows16(const uint16_t* E, int64_t first_row, int64_t n_rows, int32_t dim, void* planes, hipStream_t s) {
     if (dim % 32 || dim < 32 || (reinterpret_cast<uintptr_t>(E) & 15)) return RL_ERR_UNSUPPORTED;
     const int64_t end_row = (n_rows + 15) / 16 * 16;
@@ -289,9 +323,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     constexpr int BLKB = HALF ? 1024 : 2048;   // bytes of one (16-row block, K slab) of the image
     constexpr int SLAB = MG_NBLK * BLKB;       // one K slab of a tile in LDS
     __shared__ __attribute__((aligned(16))) char smem[MG_NSLOT * SLAB + (TRACE ? 16 * 8 * 16 * 8 : 0) + (MODE == 2 ? MG_WAVES * 4096 : 0)];
-    if constexpr (MODE != 0) {
-        if (rs.run_if && __builtin_amdgcn_readfirstlane((int)*rs.run_if) == 0) return;  // whole grid: the guarded fallback is not needed
-    }
+    if (rs.run_if && __builtin_amdgcn_readfirstlane((int)*rs.run_if) == 0) return;  // whole grid: the guarded fallback is not needed
     auto stamp = [&](int g, int k) {
         if constexpr (TRACE) {
             if (blockIdx.x == 7 && g >= 128 && g < 144 && (threadIdx.x & 63) == 0)
@@ -774,7 +806,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
 // out[q * out_stride + chunk].  Needs an index without empty chunks (the chunk of an end row is found by counting ends).
 int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first,
                        int32_t n_q, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits,
-                       float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale, bool half) {
+                       float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale, bool half, const uint32_t* run_if) {
     if (nq < 1 || nq > 32 || n_q < 1 || n_q > MG_WAVES || n_rows < 1 || first < 0 || first + n_q > n_queries) return RL_ERR_UNSUPPORTED;
     if (dim % 32 || dim < 32 || !(split_scale > 0.f) || !planes || !ends_bits) return RL_ERR_UNSUPPORTED;
     const int32_t nslab = dim / 32;
@@ -805,9 +837,11 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
         }
         return RL_OK;
     }
+    RowScoreArgs rs0{};
+    rs0.run_if = run_if;
 #define RL_MG_LAUNCH(NQB_, HALF_)                                                                                                     \
     hipLaunchKernelGGL((maxsim_gemm_kernel<NQB_, false, 0, HALF_>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, \
-                       qmeta, n_q, row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr, RowScoreArgs{})
+                       qmeta, n_q, row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr, rs0)
     if (half) { if (nq <= 16) RL_MG_LAUNCH(1, true); else RL_MG_LAUNCH(2, true); }
     else      { if (nq <= 16) RL_MG_LAUNCH(1, false); else RL_MG_LAUNCH(2, false); }
 #undef RL_MG_LAUNCH

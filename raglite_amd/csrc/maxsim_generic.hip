@@ -96,13 +96,13 @@ static int generic_t(const float* D, int32_t dim, const float* Q, int32_t nq, co
 // ---------------------------------------------------------------------------------------------------------------------
 // maxsim_pairs_kernel: exact MaxSim of arbitrary (query, chunk) pairs at any dim % 16 == 0, dim <= 1024, nq <= 32 -- the
 // rerank shape beyond dim 128 and the re-scoring step of the half-bytes MaxSim batch (api.hip: maxsim_batch_hi).
-// One workgroup serves ONE query (blockIdx.y; blockIdx.x splits its candidate list): the query's [32 x dim] fp32 matrix sits
+// One workgroup of eight waves serves ONE query (blockIdx.y; blockIdx.x splits its candidate list): the query's [32 x dim] fp32 matrix sits
 // in LDS (pitch dim + 4 floats: the 16 lanes of a fragment read hit 16 different bank quads), every wave takes candidates
 // round robin: per 16-row tile of the chunk and 16-wide k step one 16-B global load per lane (16 rows x 64 B: every byte
 // of a row fetched once) feeds four v_mfma_f32_16x16x4_f32 steps per 16-column half of the query -- exact fp32 products,
 // fp32 accumulation -- then max over the chunk's rows (rows past its end masked), sum over the query vectors in a fixed
 // order.  Candidates < 0 (padding, sanitised ordinals) and empty chunks score -inf.
-__global__ __launch_bounds__(256) void maxsim_pairs_kernel(const float* __restrict__ D, int dim, const float* __restrict__ Q, int nq,
+__global__ __launch_bounds__(512) void maxsim_pairs_kernel(const float* __restrict__ D, int dim, const float* __restrict__ Q, int nq,
                                                             int64_t q_stride, const int64_t* __restrict__ offsets,
                                                             const int32_t* __restrict__ candidates, int64_t n_items,
                                                             float* __restrict__ out) {
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void maxsim_pairs_kernel(const float* __restri
     const float* Qb = Q + (int64_t)blockIdx.y * q_stride;
     const int32_t* cb = candidates + (int64_t)blockIdx.y * n_items;
     float* ob = out + (int64_t)blockIdx.y * n_items;
-    for (int i = threadIdx.x * 4; i < 32 * dim; i += 256 * 4) {
+    for (int i = threadIdx.x * 4; i < 32 * dim; i += 512 * 4) {
         const int n = i / dim, c = i - n * dim;
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};  // query vectors past nq: zeros (their maxima are 0 and add nothing)
         if (n < nq) v = *reinterpret_cast<const f32x4*>(Qb + (int64_t)n * dim + c);
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void maxsim_pairs_kernel(const float* __restri
     const int m = lane & 15, g = lane >> 4;  // A: row m of the tile, k quad g;  B / C: query column m, k quad / row quad g
     const float* q0 = qs + m * pitch + 4 * g;
     const float* q1 = qs + (16 + m) * pitch + 4 * g;
-    for (int64_t item = (int64_t)blockIdx.x * 4 + w; item < n_items; item += (int64_t)gridDim.x * 4) {
+    for (int64_t item = (int64_t)blockIdx.x * 8 + w; item < n_items; item += (int64_t)gridDim.x * 8) {
         const int64_t chunk = cb[item];
         const int64_t b = chunk >= 0 ? offsets[chunk] : 0, e = chunk >= 0 ? offsets[chunk + 1] : 0;
         float best0 = -INFINITY, best1 = -INFINITY;  // running max over the chunk's rows of this lane's column (both halves)
@@ -130,15 +130,22 @@ __global__ __launch_bounds__(256) void maxsim_pairs_kernel(const float* __restri
             const int64_t row = r0 + m < e ? r0 + m : e - 1;  // rows past the chunk: re-read its last row, masked below
             const float* a = D + row * (int64_t)dim + 4 * g;
             f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-#pragma unroll 4
-            for (int t = 0; t < dim; t += 16) {
-                const f32x4 x = *reinterpret_cast<const f32x4*>(a + t);
-                const f32x4 y0 = *reinterpret_cast<const f32x4*>(q0 + t);
-                const f32x4 y1 = *reinterpret_cast<const f32x4*>(q1 + t);
+            // eight 16-B row loads in flight per lane ahead of their MFMAs (with the query in LDS a workgroup is alone on its
+            // CU: nothing else hides the rows' HBM latency)
+            for (int t0 = 0; t0 < dim; t0 += 128) {
+                f32x4 x[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u], y0[u], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[u], y1[u], acc1, 0, 0, 0);
+                for (int j = 0; j < 8; ++j) x[j] = t0 + 16 * j < dim ? *reinterpret_cast<const f32x4*>(a + t0 + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (t0 + 16 * j >= dim) break;  // (uniform)
+                    const f32x4 y0 = *reinterpret_cast<const f32x4*>(q0 + t0 + 16 * j);
+                    const f32x4 y1 = *reinterpret_cast<const f32x4*>(q1 + t0 + 16 * j);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][u], y0[u], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][u], y1[u], acc1, 0, 0, 0);
+                    }
                 }
             }
             // C layout: this lane holds rows 4 g + i (i = 0..3) of column m
@@ -171,8 +178,8 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
         attr_set = true;
     }
     // workgroups per query: enough to fill the chip when there are few queries, at most one wave per candidate
-    int per_query = (int)std::max<int64_t>(1, std::min<int64_t>((n_items_per_query + 3) / 4, std::max<int64_t>(1, 512 / n_queries)));
-    hipLaunchKernelGGL(maxsim_pairs_kernel, dim3(per_query, n_queries), dim3(256), lds, s, D, (int)dim, Q, (int)nq, q_stride, offsets,
+    int per_query = (int)std::max<int64_t>(1, std::min<int64_t>((n_items_per_query + 7) / 8, std::max<int64_t>(1, 512 / n_queries)));
+    hipLaunchKernelGGL(maxsim_pairs_kernel, dim3(per_query, n_queries), dim3(512), lds, s, D, (int)dim, Q, (int)nq, q_stride, offsets,
                        candidates, n_items_per_query, out);
     RL_HIP(hipGetLastError());
     return RL_OK;
