@@ -210,15 +210,19 @@ def main() -> None:
     }
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, kernel only -----------------------------
-    # One launch = one corpus pass.  f16_split with the pre-split corpus image: EIGHT queries per pass (maxsim_gemm_kernel,
-    # matrix-pipe-bound: 3 fp16 MFMA products per fp32-equivalent multiply).  Otherwise two queries (fp16-stored) or one
-    # query (exact fp32) per pass through the HBM-bound streaming kernels.
+    # One launch = one corpus pass of EIGHT queries through maxsim_gemm_kernel (matrix-pipe-bound).  Big fp32 corpora in split
+    # arithmetic: the approximate pass over the HI image (kind 5: 2 fp16 MFMA products per multiply; the candidates it leaves
+    # are re-scored exactly on the fp32 matrix pipe), else the full-precision pass over the pre-split image (kind 3: 3 products;
+    # fp16-stored corpus: 2).  Otherwise two queries or one query (exact fp32) per pass through the HBM-bound streaming kernels.
     iters = 20
     rows_local = r_hi - r_lo
     elt = 4.0 if args.storage == "f32" else 2.0
     algo_bytes = elt * rows_local * DIM  # 4*N*d bytes per corpus pass (2*N*d when fp16-stored)
+    streamed_bytes = algo_bytes
     kind, per_launch = 0, 1
-    for cand_kind, cand_q in ((3, 8), (2, 2)):
+    for cand_kind, cand_q in ((5, 8), (3, 8), (2, 2)):
+        if cand_kind == 5 and os.environ.get("RAGLITE_NO_HI_MAXSIM"):
+            continue
         if arithmetic in ("f16_split", "f16_stored"):
             try:
                 index.time_kernel(cand_kind, queries[0, :cand_q].reshape(cand_q * NQ, DIM), 2)
@@ -226,35 +230,44 @@ def main() -> None:
                 break
             except Exception:  # noqa: BLE001 - that kernel does not apply to this index / shape
                 continue
+    if kind == 5:
+        streamed_bytes = 2.0 * rows_local * DIM  # the HI image: 2 B per element
     qv = queries[0, :per_launch].reshape(per_launch * NQ, DIM)
     index.time_kernel(kind, qv, 3)  # warm
     ms = index.time_kernel(kind, qv, iters) / iters
     fp32_equiv_flops = 2.0 * per_launch * NQ * rows_local * DIM  # 2*nq*N*d per query
-    hbm = {"achieved": algo_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": algo_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes}
+    hbm = {"achieved": streamed_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": streamed_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
+           "streamed_bytes_per_launch": streamed_bytes}
     traffic, traffic_source = None, None
     tf = ROOT / "profiles" / "traffic.json"  # from separate rocprofv3 --pmc FETCH_SIZE passes
     if tf.exists() and args.storage == "f32" and n_rows == N_ROWS and world == 1:
         tj = json.loads(tf.read_text())
-        traffic = tj.get({3: "maxsim_gemm_bytes_per_launch", 2: "maxsim_stream2_bytes_per_launch"}.get(kind, "maxsim_stream_bytes_per_launch"))
+        traffic = tj.get({5: "maxsim_gemm_hi_bytes_per_launch", 3: "maxsim_gemm_bytes_per_launch", 2: "maxsim_stream2_bytes_per_launch"}.get(kind, "maxsim_stream_bytes_per_launch"))
         traffic_source = "static: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 for the gfx950 half-count, separate run)"
-    kernel_name = {3: "rl::maxsim_gemm_kernel<2, false, 0, true>" if arithmetic == "f16_stored" else "rl::maxsim_gemm_kernel<2, false, 0, false>",
+    kernel_name = {5: "rl::maxsim_gemm_kernel<2, false, 0, true>",
+                   3: "rl::maxsim_gemm_kernel<2, false, 0, true>" if arithmetic == "f16_stored" else "rl::maxsim_gemm_kernel<2, false, 0, false>",
                    2: "rl::maxsim_stream2_kernel<256, false, true>" if arithmetic == "f16_stored" else "rl::maxsim_stream2_kernel<256, false, false>",
                    0: {"fp32_exact": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, false>",
                        "f16_split": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, true>",
                        "f16_stored": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, true, false>"}[arithmetic]}[kind] + " (as rocprofv3 names it)"
-    if kind == 3:
-        # q_hi.e_hi + q_hi.e_lo + q_lo.e_hi: what the split arithmetic needs on the fp16 pipe; an fp16-stored corpus has no e_lo
-        products = 2.0 if arithmetic == "f16_stored" else 3.0
+    if kind in (3, 5):
+        # q_hi.e_hi + q_hi.e_lo + q_lo.e_hi: what the split arithmetic needs on the fp16 pipe; an fp16-stored corpus has no e_lo,
+        # and the approximate pass over the HI image (kind 5) leaves the e_lo product to the exact re-scoring of its candidates
+        products = 2.0 if (arithmetic == "f16_stored" or kind == 5) else 3.0
         mfma_flops = products * fp32_equiv_flops
         achieved = mfma_flops / (ms * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                               "frac": achieved / MFMA_F16_PEAK_TF, "traffic": traffic,
                               "algorithmic_flops_per_launch": mfma_flops,
-                              "flops_note": f"{products:.0f} fp16 MFMA products per fp32-equivalent multiply-add (SURVEY.md 8d: 2*32*N*d per query), 8 queries per launch",
+                              "flops_note": f"{products:.0f} fp16 MFMA products per fp32-equivalent multiply-add (SURVEY.md 8d: 2*32*N*d per query), 8 queries per launch"
+                                            + ("; approximate pass over the HI image, its candidates re-scored exactly by maxsim_pairs_kernel inside the timed step" if kind == 5 else ""),
                               "hbm": hbm}
     else:
         result["roofline"] = {"bound": "hbm", **hbm, "traffic": traffic}
+    if kind == 5:  # for reference: the full-precision pass the approximate one replaces (and falls back to)
+        index.time_kernel(3, qv, 2)
+        result["roofline"]["full_precision_pass_ms"] = index.time_kernel(3, qv, iters) / iters
     result["roofline"].update({
         "kernel": kernel_name, "arithmetic": arithmetic, "queries_per_launch": per_launch, "kernel_ms": ms,
         "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes,
