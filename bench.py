@@ -197,7 +197,9 @@ def main() -> None:
         "vs_baseline": None,
         # fp32 data in, fp32 scores out, fp32 accumulation; how the products are formed is `arithmetic`
         "dtype": {"fp32_exact": "f32 (v_mfma_f32_16x16x4_f32)",
-                  "f16_split": "f32 operands as exact fp16 hi+lo pairs (22 bits), 3 x v_mfma_f32_16x16x32_f16, f32 accumulate",
+                  "f16_split": "f32 in / f32 scores: candidate chunks found with the hi halves of the exact fp16 hi+lo split (2 x v_mfma_f32_16x16x32_f16 per "
+                               "multiply, f32 accumulate, rigorous error bound), their scores by v_mfma_f32_16x16x4_f32 (exact f32 products); "
+                               "full-precision fallback: 3 x v_mfma_f32_16x16x32_f16 on hi+lo pairs (22 bits)",
                   "f16_stored": "f16 storage, f16 x f16 -> f32 MFMA"}[arithmetic],
         "data": "synthetic",
         "config": {
