@@ -246,8 +246,10 @@ struct rl_index {
     rl::Pool hi_image;
     float hi_image_scale = 0.f;
     int64_t hi_image_rows = 0;
-    float max_row_norm = 0.f;
-    int64_t max_row_norm_rows = 0;        // rows folded into max_row_norm
+    float max_row_norm = 0.f, max_lo_norm = 0.f, max_lo_ratio = 0.f;  // max |e|, max |e_lo|, max |e_lo| / |e| (e_lo: what the HI halves drop)
+    float max_row_norm_scale = 0.f;       // the split scale they were computed at
+    uint32_t* d_norms = nullptr;          // device scratch of launch_max_row_norm (4 words)
+    int64_t max_row_norm_rows = 0;        // rows folded into them
     // The scratch above is shared by all calls on this handle; `mu` serialises only their host side.  Device-mode calls are
     // asynchronous, so a call arriving on a DIFFERENT stream than the previous one first waits for that stream.
     hipStream_t last_stream = nullptr;
@@ -393,17 +395,26 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
     RL_TRY(st);
     idx->hi_image_scale = idx->split_scale;
     idx->hi_image_rows = idx->n_rows;
-    if (idx->max_row_norm_rows != idx->n_rows) {  // fold the new rows' norms in
+    if (idx->max_row_norm_rows != idx->n_rows || idx->max_row_norm_scale != idx->split_scale) {  // fold the new rows' norms in
+        if (idx->max_row_norm_scale != idx->split_scale) {  // (the dropped halves depend on the scale: start over)
+            idx->max_row_norm = idx->max_lo_norm = idx->max_lo_ratio = 0.f;
+            idx->max_row_norm_rows = 0;
+        }
         const int64_t from = std::min<int64_t>(idx->max_row_norm_rows, idx->n_rows);
-        if (!idx->d_range) RL_HIP(hipMalloc(&idx->d_range, 16));
-        uint32_t bits = 0;
-        std::memcpy(&bits, &idx->max_row_norm, 4);
-        RL_HIP(hipMemcpyAsync(idx->d_range + 3, &bits, 4, hipMemcpyHostToDevice, s));
-        RL_TRY(rl::launch_max_row_norm(idx->E + (size_t)from * idx->dim, idx->n_rows - from, idx->dim, idx->d_range + 3, s));
-        RL_HIP(hipMemcpyAsync(&bits, idx->d_range + 3, 4, hipMemcpyDeviceToHost, s));
+        if (!idx->d_norms) RL_HIP(hipMalloc(&idx->d_norms, 16));
+        uint32_t bits[4] = {0, 0, 0, 0};
+        std::memcpy(&bits[0], &idx->max_row_norm, 4);
+        std::memcpy(&bits[1], &idx->max_lo_norm, 4);
+        std::memcpy(&bits[2], &idx->max_lo_ratio, 4);
+        RL_HIP(hipMemcpyAsync(idx->d_norms, bits, 16, hipMemcpyHostToDevice, s));
+        RL_TRY(rl::launch_max_row_norm(idx->E + (size_t)from * idx->dim, idx->n_rows - from, idx->dim, idx->split_scale, idx->d_norms, s));
+        RL_HIP(hipMemcpyAsync(bits, idx->d_norms, 16, hipMemcpyDeviceToHost, s));
         RL_HIP(hipStreamSynchronize(s));
-        std::memcpy(&idx->max_row_norm, &bits, 4);
+        std::memcpy(&idx->max_row_norm, &bits[0], 4);
+        std::memcpy(&idx->max_lo_norm, &bits[1], 4);
+        std::memcpy(&idx->max_lo_ratio, &bits[2], 4);
         idx->max_row_norm_rows = idx->n_rows;
+        idx->max_row_norm_scale = idx->split_scale;
     }
     return RL_OK;
 }
@@ -608,6 +619,7 @@ int rl_index_destroy(rl_index* idx) {
     if (idx->norm) (void)hipFree(idx->norm);
     if (idx->sumsq) (void)hipFree(idx->sumsq);
     if (idx->d_range) (void)hipFree(idx->d_range);
+    if (idx->d_norms) (void)hipFree(idx->d_norms);
     if (idx->live_chunk_bits) (void)hipFree(idx->live_chunk_bits);
     if (idx->live_row_bits) (void)hipFree(idx->live_row_bits);
     idx->maskbuf.release();
@@ -855,7 +867,7 @@ int rl_index_compact(rl_index* idx, int64_t* out_remap, int64_t* new_n_rows, int
     idx->hi_scale = 0.f;
     idx->hi_image_rows = 0;
     idx->hi_image_scale = 0.f;
-    idx->max_row_norm = 0.f;
+    idx->max_row_norm = idx->max_lo_norm = idx->max_lo_ratio = 0.f;
     idx->max_row_norm_rows = 0;
     RL_TRY(scan_row_range(idx, 0, new_n, s));
     RL_TRY(refresh_planes(idx, s));
@@ -1206,8 +1218,16 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     // ---- (2) every row that could be in the exact top-k ------------------------------------------------------------------------------------
     // 2^-10 for the dropped lo halves + 2^-11 for everything fp32 does to both passes (worst case of a 1024-term fp32 sum:
     // 6e-5 each; the query's own 2^-22 split; the metric's two roundings)
-    const float m_rel = 0x1p-10f + 0x1p-11f;
-    RL_TRY(launch_approx_threshold(ts, nb, k, d_q, dim, mode, m_rel, std::sqrt((float)dim) * idx->max_abs, thr, cnt, flag, s));
+    // The bound: what the HI halves drop is known exactly per row -- max |e_lo| / |e| (cosine) and max |e_lo| (dot) are kept by the
+    // index (refresh_hi_image) -- plus 2^-12 |e| |q| for the query's own 2^-22 split and twice the worst case of a 1024-term fp32
+    // sum (6e-5).  Without those maxima (no HI image on this index): the a-priori 2^-10 of the truncation, plus 2^-11.
+    const bool measured = idx->max_row_norm_rows == idx->n_rows && idx->max_row_norm_scale == idx->hi_scale && idx->max_row_norm > 0.f;
+    float m_rel = 0x1p-10f + 0x1p-11f, e_bound = std::sqrt((float)dim) * idx->max_abs;
+    if (measured) {
+        if (mode == SCAN_COSINE) m_rel = idx->max_lo_ratio + 0x1p-12f;
+        else { m_rel = 1.0f; e_bound = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm; }
+    }
+    RL_TRY(launch_approx_threshold(ts, nb, k, d_q, dim, mode, m_rel, e_bound, thr, cnt, flag, s));
     RL_TRY(launch_collect_above(sc, nb, n, ld, thr, mode == SCAN_COSINE ? idx->norm : nullptr, cap, ci, gn, cnt, flag, s));
     // ---- (3) exact scores of the candidates, by the kernels of the full pass (slots past a list's length hold stale row numbers:
     // gathered and scored, never ranked) ---------------------------------------------------------------------------------------------------------
@@ -1551,7 +1571,7 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
             if (n_gemm > 0 && !hi_off && hi_image_valid(idx) && k <= 512) {
                 // ---- MaxSim of a batch at two MFMA products per multiply instead of three (the headline path) -------------------------
                 // (1) approximate chunk scores: the eight-query pass over the HI image (q_hi.e_hi + q_lo.e_hi);
-                // (2) |approximate - exact| <= m = (2^-10 + 2^-11) max|e| sum_i |q_i| for every chunk (the per-pair bound of
+                // (2) |approximate - exact| <= m = (max|e_lo| + 2^-12 max|e|) sum_i |q_i| for every chunk (the per-pair bound of
                 //     search_rows_hi under the max over a chunk's rows and the sum over the query vectors), so the chunks with
                 //     approximate score >= (k-th best approximate) - 2 m contain the exact top-k: collected per query;
                 // (3) their exact scores by maxsim_pairs_kernel (fp32 matrix pipe), ranked by (score desc, chunk asc);
@@ -1576,8 +1596,10 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
                 }
                 RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // tombstones never become candidates
                 RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, ts, ti, s));
-                const float m_rel = 0x1p-10f + 0x1p-11f;
-                RL_TRY(launch_maxsim_threshold(ts, n_gemm, k, d_q, nq, idx->dim, (int64_t)q_elems, m_rel, idx->max_row_norm, thr, cnt, flag, s));
+                // per pair |approx - exact| <= |q_i| |e_lo,j| (what the HI halves drop, measured: max_lo_norm) + 2^-12 |q_i| |e_j| (the
+                // query's own 2^-22 split and twice the worst case of a 1024-term fp32 sum, 6e-5)
+                const float m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
+                RL_TRY(launch_maxsim_threshold(ts, n_gemm, k, d_q, nq, idx->dim, (int64_t)q_elems, 1.0f, m_abs, thr, cnt, flag, s));
                 RL_TRY(launch_collect_above(sc, n_gemm, idx->n_chunks, ld, thr, nullptr, cap, ci, nullptr, cnt, flag, s));
                 if (std::getenv("RAGLITE_HI_DEBUG")) {  // diagnostic: synchronises; list lengths, threshold and flag of this batch to stderr
                     std::vector<uint32_t> h_cnt(n_gemm);

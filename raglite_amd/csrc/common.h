@@ -170,8 +170,9 @@ int launch_gather_f32(const float* src, const int32_t* idx, int64_t count, float
 // the k-th score is unusable.  One block per query.
 int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, const float* Q, int32_t nq, int32_t dim, int64_t q_stride,
                             float m_rel, float e_max, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s);
-// max over rows of |e| (fp32, nudged up by 1e-6), folded into *bits (a float's bit pattern; start it at 0)
-int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, uint32_t* bits, hipStream_t s);
+// bits[0..2] = max |e|, max |e_lo|, max |e_lo| / |e| over the rows (float bit patterns, nudged up by 1e-6; start them at the
+// values so far), e_lo = what the fp16 HI halves at `scale` drop
+int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale, uint32_t* bits, hipStream_t s);
 int launch_diag_blocks(const float* src, int64_t ld, int32_t k2, int64_t count, float* dst, hipStream_t s);
 
 // mask.hip: validity bitsets (metadata filter pushed down to the device, tombstones of deleted chunks)

@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256) void collect_above_kernel(const float* __restr
 __global__ __launch_bounds__(256) void maxsim_threshold_kernel(const float* __restrict__ topk, int32_t k, const float* __restrict__ Q, int nq,
                                                                 int dim, int64_t q_stride, float m_rel, float e_max,
                                                                 float* __restrict__ thr, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag) {
-    // |approx - exact| of a chunk's MaxSim score <= sum_i max_j 2^-10 |q_i| |e_j| <= m_rel * e_max * sum_i |q_i|
+    // |approx - exact| of a chunk's MaxSim score <= sum_i max_j (|q_i| |e_lo,j| + slack |q_i| |e_j|) <= (m_rel * e_max) * sum_i |q_i|
+    // with m_rel * e_max = max_j |e_lo,j| + 2^-12 max_j |e_j| handed over by the caller
     __shared__ float part[4];
     const int b = blockIdx.x;
     const float* Qb = Q + (int64_t)b * q_stride;
@@ -121,20 +122,37 @@ __global__ __launch_bounds__(256) void maxsim_threshold_kernel(const float* __re
     if (!(t > -INFINITY)) atomicOr(flag, 1u);  // NaN or -inf: fewer than k scorable chunks
 }
 
-__global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restrict__ E, int64_t n_rows, int dim, uint32_t* __restrict__ bits) {
+// bits[0] = max |e|, bits[1] = max |e_lo|, bits[2] = max |e_lo| / |e| over the rows (float bit patterns, each nudged up by 1e-6;
+// non-negative floats order like their bits), where e_lo = e - fp16_rtz(e * scale) / scale is what the HI halves drop --
+// computed exactly (the scale is a power of two, the difference of a float and its truncation is exact).
+__global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restrict__ E, int64_t n_rows, int dim, float scale,
+                                                            uint32_t* __restrict__ bits) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
-    float mx = 0.f;
+    const float inv = 1.0f / scale;
+    float mx = 0.f, mlo = 0.f, mratio = 0.f;
     for (int64_t r = wave0; r < n_rows; r += n_waves) {
-        float ss = 0.f;
+        float ss = 0.f, sl = 0.f;
         for (int c = lane; c < dim; c += 64) {
             const float v = E[r * (int64_t)dim + c];
+            const float x = v * scale;
+            const auto h = __builtin_amdgcn_cvt_pkrtz(x, 0.f);
+            const float lo = (x - (float)h[0]) * inv;
             ss = fmaf(v, v, ss);
+            sl = fmaf(lo, lo, sl);
         }
         ss = wave_sum(ss);
-        mx = fmaxf(mx, sqrtf(ss));
+        sl = wave_sum(sl);
+        const float ne = sqrtf(ss), nl = sqrtf(sl);
+        mx = fmaxf(mx, ne);
+        mlo = fmaxf(mlo, nl);
+        if (ne > 0.f) mratio = fmaxf(mratio, nl / ne);
     }
-    if (lane == 0 && mx > 0.f) atomicMax(bits, __float_as_uint(mx * 1.000001f));  // (non-negative floats order like their bits)
+    if (lane == 0) {
+        if (mx > 0.f) atomicMax(bits + 0, __float_as_uint(mx * 1.000001f));
+        if (mlo > 0.f) atomicMax(bits + 1, __float_as_uint(mlo * 1.000001f));
+        if (mratio > 0.f) atomicMax(bits + 2, __float_as_uint(mratio * 1.000001f));
+    }
 }
 
 __global__ __launch_bounds__(256) void gather_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int64_t count,
@@ -180,10 +198,10 @@ int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, con
     return RL_OK;
 }
 
-int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, uint32_t* bits, hipStream_t s) {
+int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale, uint32_t* bits, hipStream_t s) {
     if (n_rows <= 0) return RL_OK;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_rows + 3) / 4, 256 * 8));
-    hipLaunchKernelGGL(max_row_norm_kernel, dim3(blocks), dim3(256), 0, s, E, n_rows, (int)dim, bits);
+    hipLaunchKernelGGL(max_row_norm_kernel, dim3(blocks), dim3(256), 0, s, E, n_rows, (int)dim, scale, bits);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
