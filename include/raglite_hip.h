@@ -200,7 +200,12 @@ int rl_maxsim_scores(rl_index* index, const float* query_vecs, int32_t nq, float
  * selection launch for all of them.  In RL_ARITH_F16_SPLIT arithmetic eight queries (nq <= 32) share one pass over
  * the index' pre-split corpus image (fp16 hi | lo planes written when the index is built: 4 more bytes per element
  * of device memory; RAGLITE_NO_PLANES=1 in the environment disables it), otherwise two queries or one query
- * take a pass over the fp32 / fp16 rows.
+ * take a pass over the fp32 / fp16 rows.  On a big fp32 index (>= 64 M elements) the passes of a batch of three or
+ * more queries run over an image of the hi halves only (2 more bytes per element; two MFMA products per multiply
+ * instead of three), every chunk's score error is bounded rigorously, and the chunks that could be in the top-k are
+ * re-scored with exact fp32 products: the same top-k, scores as accurate as before; where the bound does not decide
+ * (thousands of near-identical chunks) the full-precision passes run instead, on the device.
+ * RAGLITE_NO_HI_MAXSIM=1 / RAGLITE_NO_HI_PLANE=1 switch that off.
  *   query_vecs [n_queries x nq x dim] f32; out_scores / out_chunks [n_queries x k]. */
 int rl_maxsim_topk_batch(rl_index* index, const float* query_vecs, int32_t n_queries, int32_t nq, int32_t k,
                          float* out_scores, int32_t* out_chunks, int mem, void* stream);
@@ -311,8 +316,9 @@ int rl_partition_similarity(const float* X, int64_t n, int32_t dim, const int64_
  * only (no selection), 2 = the two-queries-per-pass MaxSim kernel of rl_maxsim_topk_batch (query_vecs_dev
  * then holds two queries of nq / 2 vectors each; RL_ERR_UNSUPPORTED where that kernel does not apply), 3 = the
  * eight-queries-per-pass kernel over the pre-split corpus image (eight queries of nq / 8 vectors each), 4 = the
- * ranking pass of the half-bytes search of rl_search_rows (nq <= 4 queries over the fp16 HI plane;
- * RL_ERR_UNSUPPORTED when the index has none).  Used so that roofline.achieved is measured with HIP
+ * ranking pass of the half-bytes search of rl_search_rows (nq <= 16 queries over the fp16 HI plane;
+ * RL_ERR_UNSUPPORTED when the index has none), 5 = the approximate eight-query MaxSim pass over the HI image
+ * (as kind 3).  Used so that roofline.achieved is measured with HIP
  * events on the stream the kernel runs on. */
 int rl_time_kernel(rl_index* index, int kind, const float* query_vecs_dev, int32_t nq, int32_t iters,
                    float* out_ms_total, void* stream);

@@ -155,12 +155,6 @@ __global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void gather_f32_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx, int64_t count,
-                                                          float* __restrict__ dst) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < count) dst[i] = idx[i] >= 0 ? src[idx[i]] : 0.f;
-}
-
 // dst[b * k2 + j] = src[b * ld + b * k2 + j]: query b's scores of ITS candidates out of the [nb x nb * k2] score block
 __global__ __launch_bounds__(256) void diag_blocks_kernel(const float* __restrict__ src, int64_t ld, int32_t k2, int64_t count,
                                                            float* __restrict__ dst) {
@@ -202,13 +196,6 @@ int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale
     if (n_rows <= 0) return RL_OK;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_rows + 3) / 4, 256 * 8));
     hipLaunchKernelGGL(max_row_norm_kernel, dim3(blocks), dim3(256), 0, s, E, n_rows, (int)dim, scale, bits);
-    RL_HIP(hipGetLastError());
-    return RL_OK;
-}
-
-int launch_gather_f32(const float* src, const int32_t* idx, int64_t count, float* dst, hipStream_t s) {
-    if (count <= 0) return RL_OK;
-    hipLaunchKernelGGL(gather_f32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src, idx, count, dst);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
