@@ -10,9 +10,13 @@ of 1..15 rows (mean 8, RAGLite's multi-vector chunks), resident in HBM before th
 
 A step = one batch of QUERIES_PER_STEP queries pushed through the hot path (`rl_maxsim_topk_batch` on
 device pointers): the queries' fp16 (hi, lo) fragments once, one corpus pass of the MFMA kernel per EIGHT
-queries over the index' pre-split corpus image (maxsim_gemm_kernel; one pass per query with the exact-fp32
-arithmetic), one batched exact selection, then -- N > 1 only -- the exchange step (ONE RCCL all-gather of
-every rank's local top-k, (QB, k, 2) int32) and the device merge.  value = queries / second over the whole job.
+queries over the index' image of the corpus' hi halves (maxsim_gemm_kernel, two fp16 products per multiply), the
+batched selection of the approximate scores, the collection of every chunk a rigorous error bound cannot rule out
+of the top-k (~300 of 125 k per query), their exact scores on the fp32 matrix pipe (maxsim_pairs_kernel) and the
+ranking of those -- the exact top-100 of exactly computed scores; the full-precision passes (three products, over
+the pre-split image) stand behind a device flag for corpora the bound does not decide; one pass per
+query with the exact-fp32 arithmetic -- then, N > 1 only, the exchange step (ONE RCCL all-gather of every rank's
+local top-k, (QB, k, 2) int32) and the device merge.  value = queries / second over the whole job.
 
 N > 1: the 1 M-row corpus is sharded by chunk across the ranks (strong scaling on the metric's own
 shape); every rank receives the same queries.
@@ -20,6 +24,7 @@ shape); every rank receives the same queries.
 Extra objects in the JSON line (rank 0; all but `roofline` at N = 1 only):
   roofline      dominant kernel, HIP-event timed on its launch stream
   exact_fp32    the same workload with RL_ARITH_FP32_EXACT (v_mfma_f32_16x16x4_f32 chain), >= 5 timed steps
+  f16_stored    the same corpus rounded to and stored as fp16 (the reference's pgvector halfvec), own workload name
   recall_at_100 / score_*  all QUERIES_PER_STEP queries of the last timed step against the fp32 NumPy oracle on the
                 full corpus, and against a float64 reference on a >= 50 k-row slab
   cpu_baseline  the NumPy oracle on the host cores (the time of that full-corpus check)
