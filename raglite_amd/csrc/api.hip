@@ -239,6 +239,7 @@ struct rl_index {
     // HI plane (round 2): fp16(e * split_scale) rounded toward zero, row-major [n_rows x dim] -- the hi halves of the fp16
     // split as a matrix of their own, 2 B per element: what the single-query search streams (search_rows_hi).
     rl::Pool hiplane, hibuf;
+    bool hi_rne = false;                  // experimental (RAGLITE_HI_RNE=1 when the index is created): HI halves rounded to nearest, not toward zero
     float hi_scale = 0.f;                 // the scale the plane was built with; 0 = no plane
     int64_t hi_rows = 0;                  // rows it covers
     // ... and the same halves in the one-plane IMAGE layout (maxsim_gemm.hip HALF): what the approximate MaxSim pass of a
@@ -385,7 +386,7 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
         idx->hi_image_rows = 0;
         return RL_OK;
     }
-    const int st = rl::launch_presplit_hi_rows(idx->E, first, idx->n_rows, idx->dim, idx->split_scale, idx->hi_image.p, s);
+    const int st = rl::launch_presplit_hi_rows(idx->E, first, idx->n_rows, idx->dim, idx->split_scale, idx->hi_image.p, s, idx->hi_rne);
     if (st == RL_ERR_UNSUPPORTED) {
         idx->hi_image.release();
         idx->hi_image_scale = 0.f;
@@ -407,7 +408,8 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
         std::memcpy(&bits[1], &idx->max_lo_norm, 4);
         std::memcpy(&bits[2], &idx->max_lo_ratio, 4);
         RL_HIP(hipMemcpyAsync(idx->d_norms, bits, 16, hipMemcpyHostToDevice, s));
-        RL_TRY(rl::launch_max_row_norm(idx->E + (size_t)from * idx->dim, idx->n_rows - from, idx->dim, idx->split_scale, idx->d_norms, s));
+        RL_TRY(rl::launch_max_row_norm(idx->E + (size_t)from * idx->dim, idx->n_rows - from, idx->dim, idx->split_scale, idx->d_norms, s,
+                                       idx->hi_rne));
         RL_HIP(hipMemcpyAsync(bits, idx->d_norms, 16, hipMemcpyDeviceToHost, s));
         RL_HIP(hipStreamSynchronize(s));
         std::memcpy(&idx->max_row_norm, &bits[0], 4);
@@ -443,7 +445,7 @@ int refresh_hi_plane(rl_index* idx, hipStream_t s) {
         return RL_OK;
     }
     const int st = rl::launch_cast_f16_rtz(idx->E + (size_t)first * d, idx->hiplane.as<uint16_t>() + (size_t)first * d,
-                                           (idx->n_rows - first) * d, idx->split_scale, s);
+                                           (idx->n_rows - first) * d, idx->split_scale, s, idx->hi_rne);
     if (st == RL_ERR_UNSUPPORTED) {  // caller-owned rows that are not 16-byte aligned
         idx->hiplane.release();
         idx->hi_scale = 0.f;
@@ -673,6 +675,10 @@ static int index_create_any(rl_index** out, const void* embeddings, bool f16, in
     }
     hipStream_t s = as_stream(stream);
     rl_index* idx = new rl_index();
+    {
+        const char* rne_env = std::getenv("RAGLITE_HI_RNE");  // experimental, see DESIGN.md section 8 (R3 candidates)
+        idx->hi_rne = rne_env && rne_env[0] && rne_env[0] != '0';
+    }
     idx->n_rows = n_rows;
     idx->dim = dim;
     idx->n_chunks = n_chunks;
@@ -750,12 +756,13 @@ int upload_live_bits(rl_index* idx, hipStream_t s) {
 int rl_index_delete_chunks(rl_index* idx, const int64_t* chunk_ordinals, int64_t n, void* stream) {
     if (!idx) return fail(RL_ERR_INVALID, "rl_index_delete_chunks: null index");
     if (n < 0 || (n > 0 && !chunk_ordinals)) return fail(RL_ERR_INVALID, "rl_index_delete_chunks: bad arguments");
-    for (int64_t i = 0; i < n; ++i)
-        if (chunk_ordinals[i] < 0 || chunk_ordinals[i] >= idx->n_chunks)
-            return fail(RL_ERR_INVALID, "rl_index_delete_chunks: chunk ordinal out of range");
     if (n == 0) return RL_OK;
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
+    for (int64_t i = 0; i < n; ++i)
+        if (chunk_ordinals[i] < 0 || chunk_ordinals[i] >= idx->n_chunks)
+            return fail(RL_ERR_INVALID, "rl_index_delete_chunks: chunk ordinal out of range");
+    RL_TRY(use_scratch(idx, s));  // the live bitsets are read by searches that may still run on another stream
     const size_t cw = (size_t)(idx->n_chunks + 31) / 32;
     if (idx->h_live.empty()) idx->h_live.assign(cw, 0xffffffffu);
     for (int64_t i = 0; i < n; ++i) {
@@ -883,6 +890,7 @@ int rl_index_set_arithmetic(rl_index* idx, int mode) {
     if (!idx) return fail(RL_ERR_INVALID, "rl_index_set_arithmetic: null index");
     if (mode != RL_ARITH_AUTO && mode != RL_ARITH_FP32_EXACT) return fail(RL_ERR_INVALID, "rl_index_set_arithmetic: unknown mode");
     std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, nullptr));
     idx->arithmetic = mode;
     update_split_scale(idx);
     RL_TRY(refresh_planes(idx, nullptr));
@@ -915,6 +923,7 @@ int rl_index_append(rl_index* idx, const float* rows, int64_t n_new_rows, const 
     }
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));  // storage may be reallocated under searches still running on another stream
     const int64_t old_n = idx->n_rows, new_n = old_n + n_new_rows;
     const int64_t old_c = idx->n_chunks, new_c = old_c + n_new_chunks;
     if (new_n >= (int64_t)0x7fffffff - 1) return fail(RL_ERR_UNSUPPORTED, "rl_index_append: more than 2^31-2 rows");
@@ -1577,6 +1586,11 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
                 // (3) their exact scores by maxsim_pairs_kernel (fp32 matrix pipe), ranked by (score desc, chunk asc);
                 // (4) list overflow / unusable bound -> device flag -> the full-precision passes + selection, launched always,
                 //     returning at once when the flag is clear.
+                // Experimental (RAGLITE_HI_ONE_PRODUCT=1, read per call): ONE product per multiply -- q_hi.e_hi only, a plain fp16 GEMM --
+                // with the bound widened by what the queries' hi halves drop, (max|e| + max|e_lo|) sum_i |q_lo,i| (measured per
+                // query by the threshold kernel).  Same results by the same argument; not yet measured on hardware.
+                const char* one_env = std::getenv("RAGLITE_HI_ONE_PRODUCT");
+                const bool one_product = one_env && one_env[0] && one_env[0] != '0';
                 const int32_t cap = 2048;  // (the benchmark corpus needs ~1 150: score spread sigma ~ 34, window 2 m = 34)
                 const size_t words = (size_t)n_gemm * k * 2 + (size_t)n_gemm * 2 + 16 + (size_t)n_gemm * cap * 2;
                 RL_TRY(idx->hibuf.reserve(words * 4));
@@ -1592,14 +1606,17 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
                 for (int32_t b = 0; b < n_gemm; b += GEMM_PASS_QUERIES) {
                     const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_gemm - b);
                     RL_TRY(launch_maxsim_gemm(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
-                                              idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale, true));
+                                              idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale, true,
+                                              nullptr, one_product));
                 }
                 RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // tombstones never become candidates
                 RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, ts, ti, s));
                 // per pair |approx - exact| <= |q_i| |e_lo,j| (what the HI halves drop, measured: max_lo_norm) + 2^-12 |q_i| |e_j| (the
                 // query's own 2^-22 split and twice the worst case of a 1024-term fp32 sum, 6e-5)
                 const float m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
-                RL_TRY(launch_maxsim_threshold(ts, n_gemm, k, d_q, nq, idx->dim, (int64_t)q_elems, 1.0f, m_abs, thr, cnt, flag, s));
+                const float* q_unscale = reinterpret_cast<const float*>(idx->qplanes.as<char>() + (size_t)n_queries * idx->dim * 128);  // launch_query_planes' meta
+                RL_TRY(launch_maxsim_threshold(ts, n_gemm, k, d_q, nq, idx->dim, (int64_t)q_elems, 1.0f, m_abs, thr, cnt, flag, s,
+                                               one_product ? q_unscale : nullptr, idx->max_row_norm + idx->max_lo_norm));
                 RL_TRY(launch_collect_above(sc, n_gemm, idx->n_chunks, ld, thr, nullptr, cap, ci, nullptr, cnt, flag, s));
                 if (std::getenv("RAGLITE_HI_DEBUG")) {  // diagnostic: synchronises; list lengths, threshold and flag of this batch to stderr
                     std::vector<uint32_t> h_cnt(n_gemm);
@@ -1782,6 +1799,7 @@ int rl_chunk_best_rows(rl_index* idx, const float* queries, int32_t B, const int
     if (!queries || !candidates || !out_rows) return fail(RL_ERR_INVALID, "rl_chunk_best_rows: null argument");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
     DevBuf t_q, t_c, t_o;
     const float* d_q; const int32_t* d_c; int32_t* d_o;
     RL_TRY(stage_in(queries, (size_t)B * idx->dim, mem, s, t_q, &d_q));
@@ -1800,6 +1818,7 @@ int rl_gather_rows(rl_index* idx, const int32_t* rows, int64_t n, float* out, in
     if (!rows || !out) return fail(RL_ERR_INVALID, "rl_gather_rows: null argument");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
     DevBuf t_r, t_o;
     const int32_t* d_r; float* d_o;
     RL_TRY(stage_in(rows, (size_t)n, mem, s, t_r, &d_r));
@@ -1820,7 +1839,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     const int64_t ldc = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
     if (kind == 0) RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));
     else if (kind == 2) RL_TRY(idx->scores.reserve((size_t)2 * ldc * sizeof(float)));
-    else if (kind == 3 || kind == 5) RL_TRY(idx->scores.reserve((size_t)GEMM_PASS_QUERIES * ldc * sizeof(float)));
+    else if (kind == 3 || kind == 5 || kind == 6) RL_TRY(idx->scores.reserve((size_t)GEMM_PASS_QUERIES * ldc * sizeof(float)));
     else RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)nq * ld * sizeof(float), 16)));
     hipEvent_t e0, e1;
     RL_HIP(hipEventCreate(&e0));
@@ -1830,7 +1849,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
         st = pairs_prepare(idx, q_dev, nq / 2, (int64_t)(nq / 2) * idx->dim, 2, s);
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the pair kernel does not apply to this index / shape") : st; }
     }
-    if (kind == 3 || kind == 5) {  // eight queries of nq / 8 vectors each
+    if (kind == 3 || kind == 5 || kind == 6) {  // eight queries of nq / 8 vectors each
         st = gemm_prepare(idx, q_dev, nq / GEMM_PASS_QUERIES, (int64_t)(nq / GEMM_PASS_QUERIES) * idx->dim, GEMM_PASS_QUERIES, s);
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the eight-query kernel does not apply to this index / shape") : st; }
     }
@@ -1839,10 +1858,11 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
         if (kind == 3) st = gemm_pass(idx, nq / GEMM_PASS_QUERIES, GEMM_PASS_QUERIES, 0, GEMM_PASS_QUERIES, idx->scores.as<float>(), ldc, s);
         else if (kind == 0) st = maxsim_scores_device(idx, q_dev, nq, idx->scores.as<float>(), s);
         else if (kind == 2) st = pairs_pass(idx, nq / 2, 2, 0, idx->scores.as<float>(), ldc, s);
-        else if (kind == 5) {  // the approximate MaxSim pass of a batch: eight queries over the HI image (two MFMA products)
+        else if (kind == 5 || kind == 6) {  // the approximate MaxSim pass of a batch: eight queries over the HI image (5: two MFMA products, 6: one)
             st = hi_image_valid(idx) ? launch_maxsim_gemm(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, GEMM_PASS_QUERIES, 0,
                                                           GEMM_PASS_QUERIES, nq / GEMM_PASS_QUERIES, idx->row_to_chunk, idx->offsets,
-                                                          idx->ends.as<uint32_t>(), idx->scores.as<float>(), ldc, idx->n_cu, s, idx->split_scale, true)
+                                                          idx->ends.as<uint32_t>(), idx->scores.as<float>(), ldc, idx->n_cu, s, idx->split_scale, true,
+                                                          nullptr, kind == 6)
                                      : fail(RL_ERR_UNSUPPORTED, "rl_time_kernel: the index has no HI image");
         }
         else if (kind == 4) {  // the ranking pass of the half-bytes search: the f16 stream kernel over the HI plane

@@ -116,7 +116,7 @@ int launch_row_norms16(const uint16_t* E, int64_t n, int32_t dim, float* norm, f
 int launch_row_norms(const float* E, int64_t n, int32_t dim, float* norm, float* sumsq, hipStream_t s);
 int launch_cast_f16(const float* src, uint16_t* dst, int64_t count, hipStream_t s);
 // dst = fp16(src * scale) rounded TOWARD ZERO (the hi half of the fp16 split); count % 8 == 0, 16-byte aligned pointers
-int launch_cast_f16_rtz(const float* src, uint16_t* dst, int64_t count, float scale, hipStream_t s);
+int launch_cast_f16_rtz(const float* src, uint16_t* dst, int64_t count, float scale, hipStream_t s, bool rne = false);
 int launch_fill_f32(float* dst, float value, int64_t count, hipStream_t s);
 // in-place metric transform of raw dots: scores[b*ld+i] (i<n), per-row norm / sumsq, per-query norm.
 // (pre_scale: the raw dots are multiplied by it first -- a power of two, exact; run_if as in launch_topk)
@@ -167,11 +167,15 @@ int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld,
                          int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s);
 // MaxSim flavour of the threshold: thr[b] = topk[b * k + k - 1] - 2 * m_rel * e_max * sum_i |q_i|; zeroes cnt[b]; sets *flag when
 // the k-th score is unusable.  One block per query.
+// q_unscale != nullptr (one-product pass: only the queries' fp16 hi halves were multiplied): q_unscale[2 * b] = 2^(ex - 14) of
+// query b (the meta words of launch_query_planes), and the threshold drops by another 2 * e_norm_max * sum_i |q_lo,i| with
+// q_lo,i = q_i - fp16(q_i * scale) / scale, recomputed here with the statement query_planes_kernel uses.
 int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, const float* Q, int32_t nq, int32_t dim, int64_t q_stride,
-                            float m_rel, float e_max, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s);
+                            float m_rel, float e_max, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s,
+                            const float* q_unscale = nullptr, float e_norm_max = 0.f);
 // bits[0..2] = max |e|, max |e_lo|, max |e_lo| / |e| over the rows (float bit patterns, nudged up by 1e-6; start them at the
 // values so far), e_lo = what the fp16 HI halves at `scale` drop
-int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale, uint32_t* bits, hipStream_t s);
+int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale, uint32_t* bits, hipStream_t s, bool rne = false);
 int launch_diag_blocks(const float* src, int64_t ld, int32_t k2, int64_t count, float* dst, hipStream_t s);
 
 // mask.hip: validity bitsets (metadata filter pushed down to the device, tombstones of deleted chunks)
@@ -220,7 +224,8 @@ int launch_maxsim_stream2(const void* D, bool f16, int64_t n_rows, int32_t dim, 
 size_t planes_bytes(int64_t rows, int32_t dim, bool half = false);
 int launch_presplit_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s);
 int launch_preformat_rows16(const uint16_t* E, int64_t first_row, int64_t n_rows, int32_t dim, void* planes, hipStream_t s);
-int launch_presplit_hi_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s);
+int launch_presplit_hi_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s,
+                            bool rne = false);
 size_t chunk_ends_words(int64_t rows);
 int launch_chunk_ends(const int32_t* row_to_chunk, int64_t n_rows, uint32_t* ends, hipStream_t s);
 size_t query_planes_bytes(int32_t dim, int32_t n_queries);
@@ -228,7 +233,7 @@ int launch_query_planes(const float* Q, int32_t dim, int32_t nq, int64_t q_strid
 int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first,
                        int32_t n_q, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits,
                        float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale, bool half = false,
-                       const uint32_t* run_if = nullptr);
+                       const uint32_t* run_if = nullptr, bool hi_only = false);
 size_t score_planes_scratch_floats(int32_t nb, int32_t dim);
 int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores, int64_t ld,
                         const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale,

@@ -96,27 +96,41 @@ __global__ __launch_bounds__(256) void collect_above_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void maxsim_threshold_kernel(const float* __restrict__ topk, int32_t k, const float* __restrict__ Q, int nq,
                                                                 int dim, int64_t q_stride, float m_rel, float e_max,
-                                                                float* __restrict__ thr, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag) {
+                                                                float* __restrict__ thr, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag,
+                                                                const float* __restrict__ q_unscale, float e_norm_max) {
     // |approx - exact| of a chunk's MaxSim score <= sum_i max_j (|q_i| |e_lo,j| + slack |q_i| |e_j|) <= (m_rel * e_max) * sum_i |q_i|
     // with m_rel * e_max = max_j |e_lo,j| + 2^-12 max_j |e_j| handed over by the caller
-    __shared__ float part[4];
+    // One-product pass (q_unscale != nullptr): the pass multiplied q_hi = fp16(q * q_scale) only, so every pair is also off by
+    // q_lo . e with q_lo = q - q_hi / q_scale: |.| <= |q_lo,i| max|e|, and the e_lo term meets |q_hi,i| <= |q_i| + |q_lo,i| -- together
+    // e_norm_max * sum_i |q_lo,i| with e_norm_max = max|e| + max|e_lo|.  x - fp16(x) is exact in fp32; the sums are nudged up.
+    __shared__ float part[4], part_lo[4];
     const int b = blockIdx.x;
     const float* Qb = Q + (int64_t)b * q_stride;
-    float sum_norms = 0.f;  // (thread 0)
+    const float inv_scale = q_unscale ? q_unscale[2 * b] : 1.0f, q_scale = 1.0f / inv_scale;  // powers of two
+    float sum_norms = 0.f, sum_lo = 0.f;  // (thread 0)
     for (int i = 0; i < nq; ++i) {
-        float ss = 0.f;
+        float ss = 0.f, sl = 0.f;
         for (int c = threadIdx.x; c < dim; c += 256) {
             const float v = Qb[(int64_t)i * dim + c];
             ss = fmaf(v, v, ss);
+            const float x = v * q_scale;
+            const float lo = x - (float)(_Float16)x;
+            sl = fmaf(lo, lo, sl);
         }
         ss = wave_sum(ss);
+        sl = wave_sum(sl);
         __syncthreads();
-        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+        if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = ss; part_lo[threadIdx.x >> 6] = sl; }
         __syncthreads();
-        if (threadIdx.x == 0) sum_norms += sqrtf((part[0] + part[1]) + (part[2] + part[3]));
+        if (threadIdx.x == 0) {
+            sum_norms += sqrtf((part[0] + part[1]) + (part[2] + part[3]));
+            sum_lo += sqrtf((part_lo[0] + part_lo[1]) + (part_lo[2] + part_lo[3])) * inv_scale;
+        }
     }
     if (threadIdx.x != 0) return;
-    const float t = topk[(int64_t)b * k + (k - 1)] - 2.0f * m_rel * e_max * sum_norms;
+    float m = m_rel * e_max * sum_norms;
+    if (q_unscale) m += e_norm_max * sum_lo * 1.00001f;
+    const float t = topk[(int64_t)b * k + (k - 1)] - 2.0f * m;
     thr[b] = t;
     cnt[b] = 0u;
     if (!(t > -INFINITY)) atomicOr(flag, 1u);  // NaN or -inf: fewer than k scorable chunks
@@ -126,7 +140,7 @@ __global__ __launch_bounds__(256) void maxsim_threshold_kernel(const float* __re
 // non-negative floats order like their bits), where e_lo = e - fp16_rtz(e * scale) / scale is what the HI halves drop --
 // computed exactly (the scale is a power of two, the difference of a float and its truncation is exact).
 __global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restrict__ E, int64_t n_rows, int dim, float scale,
-                                                            uint32_t* __restrict__ bits) {
+                                                            uint32_t* __restrict__ bits, int rne) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
     const float inv = 1.0f / scale;
@@ -137,7 +151,8 @@ __global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restri
             const float v = E[r * (int64_t)dim + c];
             const float x = v * scale;
             const auto h = __builtin_amdgcn_cvt_pkrtz(x, 0.f);
-            const float lo = (x - (float)h[0]) * inv;
+            const float hi = rne ? (float)(_Float16)x : (float)h[0];  // (the rounding the planes were built with)
+            const float lo = (x - hi) * inv;
             ss = fmaf(v, v, ss);
             sl = fmaf(lo, lo, sl);
         }
@@ -184,18 +199,19 @@ int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld,
 }
 
 int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, const float* Q, int32_t nq, int32_t dim, int64_t q_stride,
-                            float m_rel, float e_max, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s) {
+                            float m_rel, float e_max, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* q_unscale,
+                            float e_norm_max) {
     if (n_queries <= 0) return RL_OK;
     hipLaunchKernelGGL(maxsim_threshold_kernel, dim3(n_queries), dim3(256), 0, s, topk, k, Q, (int)nq, (int)dim, q_stride, m_rel, e_max, thr, cnt,
-                       flag);
+                       flag, q_unscale, e_norm_max);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
 
-int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale, uint32_t* bits, hipStream_t s) {
+int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale, uint32_t* bits, hipStream_t s, bool rne) {
     if (n_rows <= 0) return RL_OK;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_rows + 3) / 4, 256 * 8));
-    hipLaunchKernelGGL(max_row_norm_kernel, dim3(blocks), dim3(256), 0, s, E, n_rows, (int)dim, scale, bits);
+    hipLaunchKernelGGL(max_row_norm_kernel, dim3(blocks), dim3(256), 0, s, E, n_rows, (int)dim, scale, bits, rne ? 1 : 0);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void preformat_rows16_kernel(const uint16_t* _
 // The HI halves of the fp16 split of an fp32 corpus as a one-plane image (the layout of preformat_rows16_kernel): what the
 // approximate MaxSim pass of big batches multiplies (api.hip: maxsim_batch_hi) -- fp16(e * scale) rounded toward zero.
 __global__ __launch_bounds__(256) void presplit_hi_rows_kernel(const float* __restrict__ E, int64_t first_row, int64_t end_row,
-                                                                int64_t n_rows, int32_t dim, float scale, char* __restrict__ planes) {
+                                                                int64_t n_rows, int32_t dim, float scale, char* __restrict__ planes, int rne) {
     const int32_t nslab = dim >> 5;
     const int64_t per_row = (int64_t)nslab * 4;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -134,20 +134,31 @@ __global__ __launch_bounds__(256) void presplit_hi_rows_kernel(const float* __re
         v0 = *reinterpret_cast<const f32x4*>(p);
         v1 = *reinterpret_cast<const f32x4*>(p + 4);
     }
-    const auto p0 = __builtin_amdgcn_cvt_pkrtz(v0[0] * scale, v0[1] * scale), p1 = __builtin_amdgcn_cvt_pkrtz(v0[2] * scale, v0[3] * scale);
-    const auto p2 = __builtin_amdgcn_cvt_pkrtz(v1[0] * scale, v1[1] * scale), p3 = __builtin_amdgcn_cvt_pkrtz(v1[2] * scale, v1[3] * scale);
-    uint4 o;
-    __builtin_memcpy(&o.x, &p0, 4); __builtin_memcpy(&o.y, &p1, 4); __builtin_memcpy(&o.z, &p2, 4); __builtin_memcpy(&o.w, &p3, 4);
+    // rne (experimental, RAGLITE_HI_RNE=1 when the index is built): round to nearest even instead -- what the halves drop is then
+    // at most half an ulp instead of a whole one (max_row_norm_kernel measures it with the same rounding)
+    typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+    auto pk = [&](float a, float b) -> uint32_t {
+        uint32_t w;
+        if (rne) {
+            const h16x2 t = (h16x2){(_Float16)(a * scale), (_Float16)(b * scale)};
+            __builtin_memcpy(&w, &t, 4);
+        } else {
+            const auto t = __builtin_amdgcn_cvt_pkrtz(a * scale, b * scale);
+            __builtin_memcpy(&w, &t, 4);
+        }
+        return w;
+    };
+    const uint4 o = make_uint4(pk(v0[0], v0[1]), pk(v0[2], v0[3]), pk(v1[0], v1[1]), pk(v1[2], v1[3]));
     *reinterpret_cast<uint4*>(planes + ((row >> 4) * nslab + s) * 1024 + kq * 256 + (row & 15) * 16) = o;
 }
 
-int launch_presplit_hi_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s) {
+int launch_presplit_hi_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s, bool rne) {
     if (dim % 32 || dim < 32 || (reinterpret_cast<uintptr_t>(E) & 15)) return RL_ERR_UNSUPPORTED;
     const int64_t end_row = (n_rows + 15) / 16 * 16;
     if (end_row <= first_row) return RL_OK;
     const int64_t threads = (end_row - first_row) * (dim / 8);
     hipLaunchKernelGGL(presplit_hi_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, E, first_row, end_row, n_rows, dim,
-                       scale, static_cast<char*>(planes));
+                       scale, static_cast<char*>(planes), rne ? 1 : 0);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -449,6 +460,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     };
     const float unscale = (MODE == 0 && has_q) ? qmeta[2 * wv] * inv_e_scale : 0.f;
     auto any_lo_of = [&](int t) {
+        if (dbg & 64) return false;  // hi_only: q_hi products only (the caller's error bound then carries |q_lo| |e|, api.hip)
         if constexpr (MODE == 0) return has_q && __builtin_amdgcn_readfirstlane(__float_as_int(qmeta[2 * (has_q ? wv : 0) + 1])) != 0;
         else return group_of(t) < n_q && __builtin_amdgcn_readfirstlane(__float_as_int(rs.q_anylo[group_of(t) < n_q ? group_of(t) : 0])) != 0;
     };
@@ -806,7 +818,8 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
 // out[q * out_stride + chunk].  Needs an index without empty chunks (the chunk of an end row is found by counting ends).
 int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first,
                        int32_t n_q, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits,
-                       float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale, bool half, const uint32_t* run_if) {
+                       float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale, bool half, const uint32_t* run_if,
+                       bool hi_only) {
     if (nq < 1 || nq > 32 || n_q < 1 || n_q > MG_WAVES || n_rows < 1 || first < 0 || first + n_q > n_queries) return RL_ERR_UNSUPPORTED;
     if (dim % 32 || dim < 32 || !(split_scale > 0.f) || !planes || !ends_bits) return RL_ERR_UNSUPPORTED;
     const int32_t nslab = dim / 32;
@@ -814,7 +827,8 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
     const float* qmeta = reinterpret_cast<const float*>(static_cast<const char*>(qbuf) + (size_t)n_queries * dim * 128) + 2 * (size_t)first;
     const int64_t tiles = (n_rows + MG_TM - 1) / MG_TM;
     const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
-    static const int dbg = std::getenv("RAGLITE_GEMM_DBG") ? std::atoi(std::getenv("RAGLITE_GEMM_DBG")) : 0;  // timing experiments only
+    static const int dbg_env = std::getenv("RAGLITE_GEMM_DBG") ? std::atoi(std::getenv("RAGLITE_GEMM_DBG")) : 0;  // timing experiments only
+    const int dbg = (dbg_env & ~64) | (hi_only ? 64 : 0);
     static unsigned long long* trace = [] {
         unsigned long long* p = nullptr;
         if (std::getenv("RAGLITE_GEMM_TRACE")) { (void)hipMalloc(&p, 16 * 8 * 16 * 8); (void)hipMemset(p, 0, 16 * 8 * 16 * 8); }

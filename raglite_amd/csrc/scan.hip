@@ -291,26 +291,36 @@ int launch_cast_f16(const float* src, uint16_t* dst, int64_t count, hipStream_t 
     return RL_OK;
 }
 
-__global__ __launch_bounds__(256) void cast_f16_rtz_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t groups, float scale) {
+__global__ __launch_bounds__(256) void cast_f16_rtz_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t groups, float scale,
+                                                            int rne) {
     typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    auto pk = [&](float x, float y) -> uint32_t {  // rne: experimental (RAGLITE_HI_RNE=1), see presplit_hi_rows_kernel
+        uint32_t w;
+        if (rne) {
+            const h2 t = (h2){(_Float16)(x * scale), (_Float16)(y * scale)};
+            __builtin_memcpy(&w, &t, 4);
+        } else {
+            const auto t = __builtin_amdgcn_cvt_pkrtz(x * scale, y * scale);
+            __builtin_memcpy(&w, &t, 4);
+        }
+        return w;
+    };
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < groups; i += stride) {
         const f4 a = __builtin_nontemporal_load(reinterpret_cast<const f4*>(src) + 2 * i);
         const f4 b = __builtin_nontemporal_load(reinterpret_cast<const f4*>(src) + 2 * i + 1);
-        const auto p0 = __builtin_amdgcn_cvt_pkrtz(a[0] * scale, a[1] * scale), p1 = __builtin_amdgcn_cvt_pkrtz(a[2] * scale, a[3] * scale);
-        const auto p2 = __builtin_amdgcn_cvt_pkrtz(b[0] * scale, b[1] * scale), p3 = __builtin_amdgcn_cvt_pkrtz(b[2] * scale, b[3] * scale);
-        uint4 o;
-        __builtin_memcpy(&o.x, &p0, 4); __builtin_memcpy(&o.y, &p1, 4); __builtin_memcpy(&o.z, &p2, 4); __builtin_memcpy(&o.w, &p3, 4);
+        const uint4 o = make_uint4(pk(a[0], a[1]), pk(a[2], a[3]), pk(b[0], b[1]), pk(b[2], b[3]));
         reinterpret_cast<uint4*>(dst)[i] = o;
     }
 }
 
-int launch_cast_f16_rtz(const float* src, uint16_t* dst, int64_t count, float scale, hipStream_t s) {
+int launch_cast_f16_rtz(const float* src, uint16_t* dst, int64_t count, float scale, hipStream_t s, bool rne) {
     if (count <= 0) return RL_OK;
     if (count % 8 || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) return RL_ERR_UNSUPPORTED;
     const int64_t groups = count / 8;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((groups + 255) / 256, 8192));
-    hipLaunchKernelGGL(cast_f16_rtz_kernel, dim3(blocks), dim3(256), 0, s, src, dst, groups, scale);
+    hipLaunchKernelGGL(cast_f16_rtz_kernel, dim3(blocks), dim3(256), 0, s, src, dst, groups, scale, rne ? 1 : 0);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -1,0 +1,31 @@
+#!/bin/bash
+# One gpurun call for the switches built blind at the end of round 2 (no GPU minutes were left to measure them):
+#   RAGLITE_HI_RNE=1          HI halves rounded to nearest (read when an index is created)
+#   RAGLITE_HI_ONE_PRODUCT=1  approximate MaxSim pass with ONE fp16 MFMA product per multiply (read per call)
+# Stages: gated parity tests -> pass kernel time (rl_time_kernel kinds 5 / 6) -> headline bench under each combination.
+# Usage (repo root on the GPU box): bash scripts/r3_experiments.sh [tag]
+set -u
+TAG=${1:-r03_exp}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+echo "== $(date) start" | tee "$OUT/summary.txt"
+RAGLITE_TEST_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_hi_maxsim.py tests/test_gpu_hi_search.py -m gpu -q -x --timeout 600 > "$OUT/pytest_experimental.log" 2>&1
+echo "pytest exit $?" | tee -a "$OUT/summary.txt"; tail -15 "$OUT/pytest_experimental.log"
+timeout 600 python scripts/time_gemm_pass.py 1000000 20 3,5,6 > "$OUT/pass_times.txt" 2>&1; echo "pass times exit $?" | tee -a "$OUT/summary.txt"; cat "$OUT/pass_times.txt"
+for combo in "0 0" "1 0" "0 1" "1 1"; do
+  set -- $combo
+  RAGLITE_HI_RNE=$1 RAGLITE_HI_ONE_PRODUCT=$2 RAGLITE_HI_DEBUG=${HI_DEBUG:-} timeout 600 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-configs --no-f16 \
+      > "$OUT/bench_rne$1_one$2.json" 2> "$OUT/bench_rne$1_one$2.err"
+  echo "bench rne=$1 one=$2 exit $?" | tee -a "$OUT/summary.txt"
+  python - "$OUT/bench_rne$1_one$2.json" <<'PY' | tee -a "$OUT/summary.txt"
+import json, sys
+try:
+    r = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(f"  {r['value']:.0f} queries/s  {r['ms_per_step']:.2f} ms/step  pass {r['roofline']['kernel_ms']:.4f} ms  frac {r['roofline']['frac']:.3f}  recall {r.get('recall_at_100')}")
+except Exception as exc:  # noqa: BLE001
+    print("  (no bench line)", exc)
+PY
+done
+echo "== $(date) done" | tee -a "$OUT/summary.txt"

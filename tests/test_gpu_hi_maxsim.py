@@ -100,3 +100,70 @@ def test_near_identical_chunks_defeat_the_bound_and_the_full_passes_answer():
     assert np.array_equal(bc, fc) and np.array_equal(bs.view(np.uint32), fs.view(np.uint32))
     assert np.isin(bc, hot).all()
     idx.close()
+
+
+# ---- experimental switches (not the default path; measured first thing next round) -----------------------------------------------
+# RAGLITE_HI_RNE=1 (read when an index is created): HI halves rounded to nearest instead of toward zero -- the bound's e_lo term
+# halves.  RAGLITE_HI_ONE_PRODUCT=1 (read per call): the approximate pass multiplies q_hi . e_hi only -- a plain fp16 GEMM -- and
+# the bound carries what the queries' hi halves drop.  Results must not change.  Run with RAGLITE_TEST_EXPERIMENTAL=1.
+_experimental = pytest.mark.skipif(os.environ.get("RAGLITE_TEST_EXPERIMENTAL", "0") in ("", "0"),
+                                   reason="experimental switches: set RAGLITE_TEST_EXPERIMENTAL=1")
+
+
+@_experimental
+@pytest.mark.parametrize("rne,one", [("1", "0"), ("0", "1"), ("1", "1")])
+def test_experimental_switches_integer_bit_exact(rne, one):
+    nq, n_queries, k = 32, 9, 100
+    rng = np.random.default_rng(77)
+    off = ragged_offsets(rng, N, 1, 15)
+    E = oracle.synth_matrix(10_600, N, DIM, "small_int")
+    Qb = np.stack([oracle.synth_matrix(10_700 + i, nq, DIM, "small_int") for i in range(n_queries)])
+    with _env(RAGLITE_HI_RNE=rne, RAGLITE_HI_ONE_PRODUCT=one):
+        idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+        bs, bc = idx.maxsim_topk_batch(Qb, k)
+    for i in (0, 4, 8):
+        ws, wc = oracle.maxsim_topk(E, off, Qb[i], k, np.float32)
+        assert np.array_equal(bc[i], wc), (i, bc[i][:8], wc[:8])
+        assert np.array_equal(bs[i], ws)
+    idx.close()
+
+
+@_experimental
+@pytest.mark.parametrize("rne,one", [("1", "0"), ("0", "1"), ("1", "1")])
+def test_experimental_switches_float_data(rne, one):
+    rng = np.random.default_rng(78)
+    off = ragged_offsets(rng, N, 1, 15)
+    E = oracle.synth_matrix(10_800, N, DIM)
+    Qb = np.stack([oracle.synth_matrix(10_900 + i, 32, DIM) for i in range(9)])
+    k = 100
+    with _env(RAGLITE_HI_RNE=rne, RAGLITE_HI_ONE_PRODUCT=one):
+        idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+        bs, bc = idx.maxsim_topk_batch(Qb, k)
+        s1, r1 = idx.search_rows(Qb[0, 0], 50)  # the single-query half-bytes search reads the same (RNE) halves and norms
+    with _env(RAGLITE_NO_HI_MAXSIM="1", RAGLITE_NO_HI_SEARCH="1"):
+        fs, fc = idx.maxsim_topk_batch(Qb, k)
+        s0, r0 = idx.search_rows(Qb[0, 0], 50)
+    assert np.array_equal(r1, r0) and np.array_equal(s1.view(np.uint32), s0.view(np.uint32))
+    for i in range(9):
+        ref = oracle.maxsim_scores(E, off, Qb[i], np.float64)
+        tol = 2e-6 * float(np.abs(ref).max())
+        assert_topk_close(bs[i], bc[i], ref, k, tol)
+        assert set(bc[i].tolist()) == set(fc[i].tolist())
+    idx.close()
+
+
+@_experimental
+def test_experimental_one_product_fallback_on_near_identical_chunks():
+    rng = np.random.default_rng(79)
+    off = np.arange(N + 1, dtype=np.int64)
+    E = oracle.synth_matrix(11_000, N, DIM)
+    Qb = np.stack([oracle.synth_matrix(11_100 + i, 8, DIM) for i in range(4)])
+    hot = rng.choice(N, 4000, replace=False)
+    E[hot] = (3.0 * Qb[:, 0].sum(axis=0)[None, :] + 1e-4 * rng.standard_normal((4000, DIM))).astype(np.float32)
+    with _env(RAGLITE_HI_RNE="1", RAGLITE_HI_ONE_PRODUCT="1"):
+        idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+        bs, bc = idx.maxsim_topk_batch(Qb, 100)
+    with _env(RAGLITE_NO_HI_MAXSIM="1"):
+        fs, fc = idx.maxsim_topk_batch(Qb, 100)
+    assert np.array_equal(bc, fc) and np.array_equal(bs.view(np.uint32), fs.view(np.uint32))
+    idx.close()

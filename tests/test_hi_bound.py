@@ -72,3 +72,52 @@ def test_maxsim_chunk_bound():
     k = 10
     kth = np.sort(approx)[::-1][k - 1]
     assert (approx[np.argsort(-exact, kind="stable")[:k]] >= kth - 2 * m).all()
+
+
+def _split_hi_rne(E: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """The experimental rounding of the HI halves (RAGLITE_HI_RNE=1): fp16(e * scale) rounded to NEAREST even."""
+    mx = float(np.abs(E).max())
+    scale = 2.0 ** (14 - int(np.floor(np.log2(mx)) + 1)) if mx > 0 else 1.0
+    hi = (E.astype(np.float64) * scale).astype(np.float16).astype(np.float64) / scale
+    return hi, E.astype(np.float64) - hi
+
+
+def _query_hi(Q: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+    """What `query_planes_kernel` keeps of a query in its hi halves: fp16(q * q_scale), round to nearest, ONE power of two per
+    query (largest |element| -> [2^13, 2^14)); q_lo = q - q_hi."""
+    mx = float(np.abs(Q).max())
+    q_scale = 2.0 ** (14 - int(np.floor(np.log2(mx)) + 1)) if mx > 0 else 1.0
+    hi = (Q.astype(np.float64) * q_scale).astype(np.float16).astype(np.float64) / q_scale
+    return hi, Q.astype(np.float64) - hi
+
+
+@pytest.mark.parametrize("rne", [False, True])
+def test_one_product_maxsim_bound(rne):
+    """Experimental one-product pass (RAGLITE_HI_ONE_PRODUCT=1): approx = sum_i max_j q_hi,i . e_hi,j.  Per pair
+    s - a = q_lo . e + q_hi . e_lo, so |approx - exact| <= max|e_lo| sum_i |q_i| + (max|e| + max|e_lo|) sum_i |q_lo,i| -- the
+    threshold `maxsim_threshold_kernel` computes when it is handed the queries' scales."""
+    rng = np.random.default_rng(11 + rne)
+    n, dim, nq, k = 3000, 128, 8, 10
+    E = rng.uniform(-1, 1, (n, dim)).astype(np.float32)
+    Q = rng.uniform(-1, 1, (nq, dim)).astype(np.float32)
+    sizes = rng.integers(1, 12, 600)
+    off = np.concatenate(([0], np.cumsum(sizes)))
+    off = off[off <= n]
+    e_hi, e_lo = _split_hi_rne(E) if rne else _split_hi(E)[:2]
+    q_hi, q_lo = _query_hi(Q)
+    S, A = E.astype(np.float64) @ Q.astype(np.float64).T, e_hi @ q_hi.T
+    exact = np.array([S[off[c]:off[c + 1]].max(axis=0).sum() for c in range(len(off) - 1)])
+    approx = np.array([A[off[c]:off[c + 1]].max(axis=0).sum() for c in range(len(off) - 1)])
+    max_e, max_lo = float(np.linalg.norm(E.astype(np.float64), axis=1).max()), float(np.linalg.norm(e_lo, axis=1).max())
+    q_norms, q_lo_norms = np.linalg.norm(Q.astype(np.float64), axis=1), np.linalg.norm(q_lo, axis=1)
+    m = max_lo * float(q_norms.sum()) + (max_e + max_lo) * float(q_lo_norms.sum())
+    assert (np.abs(approx - exact) <= m * (1 + 1e-12)).all()
+    kth = np.sort(approx)[::-1][k - 1]
+    cand = approx >= kth - 2 * m
+    assert cand[np.argsort(-exact, kind="stable")[:k]].all()
+    assert cand.sum() < len(exact) // 2  # still a pruning step
+    # what rounding to nearest buys: the halves drop at most half an ulp, the bound's e_lo term roughly halves
+    if rne:
+        assert max_lo < 0.75 * float(np.linalg.norm(_split_hi(E)[1], axis=1).max())
+    # and the queries' own term is the smaller one (round to nearest, 11 bits)
+    assert (q_lo_norms <= 2.0 ** -11 * q_norms * (1 + 1e-9)).all()
