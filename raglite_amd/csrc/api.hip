@@ -1170,6 +1170,83 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
     return RL_OK;
 }
 
+// EXPERIMENTAL (RAGLITE_FUSED_HI=1, read per call; built at the end of round 2, not yet measured on hardware): the fused top-k of
+// search_rows_fused with its two GEMM passes over the HI image at ONE fp16 MFMA product per multiply (q_hi . e_hi: a third of the
+// matrix work and half the bytes of the pre-split image), made exact by the error band of search_rows_hi:
+//   (1) sample pass -> the k-th best APPROXIMATE similarity of a row subset, tau_s <= the k-th best approximate overall (A_k);
+//   (2) every row of the exact top-k has an approximate similarity >= A_k - 2 m >= tau_s - 2 m (|approximate - exact| <= m, with
+//       m from what the corpus' and the query's hi halves drop: row_threshold_kernel), so the candidate pass keeps the rows
+//       that reach tau_s - 2 m: ~k * stride per query, in lists of (approximate similarity, row);
+//   (3) each list sorted: its k-th entry IS A_k, and the entries >= A_k - 2 m -- a prefix, k + a few dozen rows -- are the only
+//       rows that can be in the exact top-k (list_prefix_kernel);
+//   (4) their exact similarities (row_dots_kernel, fp32) ranked by (score desc, row asc);
+//   (5) any overflow / unusable threshold -> device flag -> the dense full-precision GEMM + selection, launched always, returning at
+//       once when the flag is clear.
+// Results: exact top-k of exactly computed fp32 similarities (integer data: bit-identical to the oracle; float data: the last
+// bits differ from the dense path's split-arithmetic sums, as they do between any two of the paths).  cosine / dot, k <= 512,
+// no row mask; RL_ERR_UNSUPPORTED otherwise.
+int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, float* d_scores, int32_t* d_rows, int64_t ld, hipStream_t s) {
+    const char* on_env = std::getenv("RAGLITE_FUSED_HI");
+    if (!(on_env && on_env[0] && on_env[0] != '0')) return RL_ERR_UNSUPPORTED;
+    const char* two_env = std::getenv("RAGLITE_FUSED_HI_TWO_PRODUCTS");  // A/B: q_hi.e_hi + q_lo.e_hi (no |q_lo| term in the band)
+    const bool hi_only = !(two_env && two_env[0] && two_env[0] != '0');
+    const int mode = scan_mode(idx->metric);
+    if (B < GEMM_MIN_QUERIES || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT)) return RL_ERR_UNSUPPORTED;
+    if (!hi_image_valid(idx) || !image_valid(idx) || !idx->E) return RL_ERR_UNSUPPORTED;
+    if (mode == SCAN_COSINE && !idx->norm) return RL_ERR_UNSUPPORTED;
+    const int64_t n = idx->n_rows, T = (n + 255) / 256;
+    const int32_t cap = MERGE_CAP, cap2 = 1024;
+    int32_t stride = (int32_t)std::min<int64_t>(MERGE_CAP / (3 * (int64_t)k), T / 8);
+    if (const char* st_env = std::getenv("RAGLITE_FUSED_TOPK_STRIDE")) stride = std::min<int32_t>(std::atoi(st_env), (int32_t)(T / 8));  // A/B
+    if (stride < 2) return RL_ERR_UNSUPPORTED;
+    const int64_t Tv = (T + stride - 1) / stride, ld_s = Tv * 256;
+    if (ld_s < k) return RL_ERR_UNSUPPORTED;
+    // ---- scratch ------------------------------------------------------------------------------------------------------------
+    RL_TRY(idx->misc.reserve(score_planes_scratch_floats(B, idx->dim) * sizeof(float)));
+    const size_t n_sample = (size_t)B * ld_s, n_top = (size_t)B * k, n_cand = (size_t)B * cap, n_c2 = (size_t)B * cap2;
+    RL_TRY(idx->fused.reserve((n_sample + 2 * n_top + 2 * n_cand + 2 * n_c2 + 4 * (size_t)B + 16) * 4));
+    float* S_s = idx->fused.as<float>();
+    float* top_s = S_s + n_sample;
+    int32_t* top_i = reinterpret_cast<int32_t*>(top_s + n_top);
+    float* c_s = reinterpret_cast<float*>(top_i + n_top);
+    int32_t* c_i = reinterpret_cast<int32_t*>(c_s + n_cand);
+    int32_t* r_i = c_i + n_cand;                                   // [B x cap2] rows to re-score
+    float* r_s = reinterpret_cast<float*>(r_i + n_c2);             // [B x cap2] their exact similarities
+    float* thr = r_s + n_c2;                                       // [B]
+    float* window = thr + B;                                       // [B]
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(window + B);       // [B]
+    uint32_t* cnt2 = cnt + B;                                      // [B]
+    uint32_t* flag = cnt2 + B;
+    float* qs = idx->misc.as<float>();
+    const int32_t groups = (B + 31) / 32;
+    const float* q_unscale = qs + (size_t)groups * 32 * idx->dim;  // (the layout of launch_score_planes_queries)
+    const float* q_sumsq = q_unscale + B + groups;
+    float* sc = idx->scores.as<float>();  // [B x ld], reserved by the caller: only the fallback touches it
+    const void* hi = idx->hi_image.p;
+    const float sscale = idx->split_scale;
+    // ---- (1) sample pass + its exact top-k ------------------------------------------------------------------------------------
+    RL_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
+    RL_TRY(launch_score_planes_queries(d_q, B, idx->dim, qs, mode, s));
+    RL_TRY(launch_fill_f32(S_s, -std::numeric_limits<float>::infinity(), (int64_t)n_sample, s));
+    RL_TRY(launch_score_planes_pass(hi, n, idx->dim, B, qs, S_s, ld_s, idx->norm, idx->sumsq, mode, stride, nullptr, nullptr, idx->n_cu, s, sscale, true,
+                                    hi_only));
+    RL_TRY(launch_topk(S_s, B, ld_s, ld_s, k, idx->ws, top_s, top_i, s));
+    // ---- (2) thresholds lowered by the error band; candidate pass ---------------------------------------------------------------
+    RL_TRY(launch_row_threshold(top_s, B, k, d_q, idx->dim, mode, hi_only ? q_unscale : nullptr, idx->max_lo_ratio, idx->max_lo_norm, idx->max_row_norm,
+                                thr, window, cnt, cnt2, flag, s));
+    const CandArgs ca{thr, 1, c_s, c_i, cnt, flag, cap};
+    RL_TRY(launch_score_planes_pass(hi, n, idx->dim, B, qs, nullptr, 0, idx->norm, idx->sumsq, mode, 1, nullptr, &ca, idx->n_cu, s, sscale, true, hi_only));
+    // ---- (3) the rows within the band of each list's k-th entry; (4) their exact similarities, ranked -----------------------------
+    RL_TRY(launch_list_prefix(c_s, c_i, B, cap, k, cnt, window, cap2, r_i, cnt2, flag, s));
+    RL_TRY(launch_row_dots(idx->E, idx->dim, d_q, B, r_i, cnt2, cap2, mode, idx->norm, q_sumsq, r_s, s));
+    RL_TRY(launch_merge_topk(r_s, r_i, 1, B, cap2, k, d_scores, d_rows, s, cnt2));
+    // ---- (5) guarded dense fallback (full precision, over the pre-split image) ------------------------------------------------------
+    RL_TRY(launch_score_planes_pass(idx->planes.p, n, idx->dim, B, qs, sc, ld, idx->norm, idx->sumsq, mode, 1, flag, nullptr, idx->n_cu, s,
+                                    image_scale(idx), false));
+    RL_TRY(launch_topk(sc, B, n, ld, k, idx->ws, d_scores, d_rows, s, flag));
+    return RL_OK;
+}
+
 // Exact row top-k of up to 16 queries at HALF the bytes of a corpus pass (BASELINE cfg 2, `ORDER BY dist LIMIT k` of
 // src/raglite/_search.py:69-79 for one query): the single-query search is HBM-bound on the 4 B per element of the fp32 corpus,
 // and the hi halves of the fp16 split carry 11 of every element's 24 significand bits in 2 B.
@@ -1278,6 +1355,11 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
     for (int32_t b0 = 0; b0 < B; b0 += batch) {
         const int32_t nb = std::min<int32_t>(batch, B - b0);
         const bool cut = rank_limit > 0 && rank_limit < n;
+        if (!d_row_bits && !cut) {  // (experimental, opt-in: the same over the HI image at one MFMA product per multiply)
+            const int st = search_rows_fused_hi(idx, d_q + (int64_t)b0 * idx->dim, nb, k, d_scores + (int64_t)b0 * k, d_rows + (int64_t)b0 * k, ld, s);
+            if (st == RL_OK) continue;
+            if (st != RL_ERR_UNSUPPORTED) return st;
+        }
         if (!d_row_bits && !cut) {  // big batches over the pre-split image: no score matrix at all
             const int st = search_rows_fused(idx, d_q + (int64_t)b0 * idx->dim, nb, k, d_scores + (int64_t)b0 * k, d_rows + (int64_t)b0 * k, ld, s);
             if (st == RL_OK) continue;

@@ -177,6 +177,13 @@ int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, con
 // values so far), e_lo = what the fp16 HI halves at `scale` drop
 int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale, uint32_t* bits, hipStream_t s, bool rne = false);
 int launch_diag_blocks(const float* src, int64_t ld, int32_t k2, int64_t count, float* dst, hipStream_t s);
+// Batched half-bytes search (experimental, api.hip: search_rows_fused_hi) -- see the kernels' comments in hi_filter.hip / select.hip
+int launch_row_threshold(const float* topk, int32_t nb, int32_t k, const float* Q, int32_t dim, int mode, const float* q_unscale, float lo_ratio,
+                         float lo_norm, float e_norm, float* thr, float* window, uint32_t* cnt, uint32_t* cnt2, uint32_t* flag, hipStream_t s);
+int launch_row_dots(const float* E, int32_t dim, const float* Q, int32_t nb, const int32_t* rows, const uint32_t* cnt, int32_t cap, int mode,
+                    const float* row_norm, const float* q_sumsq, float* out, hipStream_t s);
+int launch_list_prefix(const float* in_scores, const int32_t* in_ids, int32_t nq, int32_t k_in, int32_t k, const uint32_t* counts,
+                       const float* window, int32_t cap2, int32_t* out_ids, uint32_t* out_cnt, uint32_t* flag, hipStream_t s);
 
 // mask.hip: validity bitsets (metadata filter pushed down to the device, tombstones of deleted chunks)
 int launch_expand_chunk_bits(const uint32_t* chunk_bits, const int32_t* row_to_chunk, int64_t n_rows,
@@ -242,7 +249,7 @@ struct CandArgs { const float* tau; int32_t tau_stride; float* scores; int32_t* 
 int launch_score_planes_queries(const float* Q, int32_t nb, int32_t dim, float* scratch, int mode, hipStream_t s);
 int launch_score_planes_pass(const void* planes, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, float* scores, int64_t ld,
                              const float* row_norm, const float* row_sumsq, int mode, int32_t tile_stride, const uint32_t* run_if,
-                             const CandArgs* cand, int n_cu, hipStream_t s, float split_scale, bool half = false);
+                             const CandArgs* cand, int n_cu, hipStream_t s, float split_scale, bool half = false, bool hi_only = false);
 // [largest |element|, smallest non-zero row maximum, non-finite flag] of an fp32 corpus, as uint32 bit patterns (device, 3 words)
 int launch_row_range(const float* E, int64_t n_rows, int32_t dim, uint32_t* range, hipStream_t s);
 // Any dim / nq: one wave per chunk (or per candidate), VALU dot products.

@@ -32,7 +32,8 @@ __global__ __launch_bounds__(256) void approx_threshold_kernel(const float* __re
         __syncthreads();
         if (threadIdx.x == 0) {
             const float qn = sqrtf((part[0] + part[1]) + (part[2] + part[3]));
-            const float m = mode == SCAN_COSINE ? m_rel : m_rel * e_norm_bound * qn;
+            // (dot: the similarity is 1 + d, rounded to fp32 in both passes -- 2^-22 absolute covers that for scores up to 2)
+            const float m = mode == SCAN_COSINE ? m_rel : m_rel * e_norm_bound * qn + 0x1p-22f;
             const float t = topk[(int64_t)b * k + (k - 1)] - 2.0f * m;
             thr[b] = t;
             cnt[b] = 0u;
@@ -136,6 +137,77 @@ __global__ __launch_bounds__(256) void maxsim_threshold_kernel(const float* __re
     if (!(t > -INFINITY)) atomicOr(flag, 1u);  // NaN or -inf: fewer than k scorable chunks
 }
 
+// Batched flavour (api.hip: search_rows_fused_hi, experimental), one block per query: thr[b] = topk[b * k + k - 1] - window[b] with
+// window[b] = 2 m_b the width of the error band of query b's approximate similarities:
+//   cosine: m = lo_ratio + 2^-12 + (1 + lo_ratio) |q_lo| / |q|        dot: m = (lo_norm + 2^-12 e_norm) |q| + (e_norm + lo_norm) |q_lo| + 2^-22
+// (lo_ratio = max |e_lo| / |e|, lo_norm = max |e_lo|, e_norm = max |e| over the rows; the |q_lo| terms only when q_unscale is given,
+// i.e. when the pass multiplied the queries' fp16 hi halves only: q_lo = q - fp16(q * scale) / scale with scale = 1 / q_unscale[b],
+// the statement of query_rows_planes_kernel).  Zeroes cnt[b] and cnt2[b]; an unusable threshold sets *flag.
+__global__ __launch_bounds__(256) void row_threshold_kernel(const float* __restrict__ topk, int32_t k, const float* __restrict__ Q, int dim, int mode,
+                                                             const float* __restrict__ q_unscale, float lo_ratio, float lo_norm, float e_norm,
+                                                             float* __restrict__ thr, float* __restrict__ window, uint32_t* __restrict__ cnt,
+                                                             uint32_t* __restrict__ cnt2, uint32_t* __restrict__ flag) {
+    __shared__ float part[4], part_lo[4];
+    const int b = blockIdx.x;
+    const float* q = Q + (int64_t)b * dim;
+    const float inv_scale = q_unscale ? q_unscale[b] : 1.0f, q_scale = 1.0f / inv_scale;  // powers of two
+    float ss = 0.f, sl = 0.f;
+    for (int c = threadIdx.x; c < dim; c += 256) {
+        const float v = q[c];
+        ss = fmaf(v, v, ss);
+        const float x = v * q_scale;
+        const float lo = x - (float)(_Float16)x;
+        sl = fmaf(lo, lo, sl);
+    }
+    ss = wave_sum(ss);
+    sl = wave_sum(sl);
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = ss; part_lo[threadIdx.x >> 6] = sl; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const float qn = sqrtf((part[0] + part[1]) + (part[2] + part[3]));
+    const float ql = q_unscale ? sqrtf((part_lo[0] + part_lo[1]) + (part_lo[2] + part_lo[3])) * inv_scale * 1.00001f : 0.f;
+    float m;
+    if (mode == SCAN_COSINE) m = lo_ratio + 0x1p-12f + (1.0f + lo_ratio) * (ql / qn) * 1.00001f;
+    else m = (lo_norm + 0x1p-12f * e_norm) * qn + (e_norm + lo_norm) * ql + 0x1p-22f;
+    const float w = 2.0f * m * 1.00001f;
+    const float t = topk[(int64_t)b * k + (k - 1)] - w;
+    thr[b] = t;
+    window[b] = w;
+    cnt[b] = 0u;
+    cnt2[b] = 0u;
+    if (!(t > -INFINITY) || !(w >= 0.f)) atomicOr(flag, 1u);  // NaN or -inf: fewer than k usable sample scores, or a degenerate query
+}
+
+// Exact similarities of (query, row) pairs: out[b * cap + p] = metric(q_b . e_row) for row = rows[b * cap + p], p < cnt[b] -- one wave
+// per pair, fp32 FMAs in a fixed order (lane l sums elements 4 l .. 4 l + 3 of every 256, then the butterfly), the metric by the
+// statements of transform_score.  What the batched half-bytes search ranks its candidates by (a few hundred per query).
+__global__ __launch_bounds__(256) void row_dots_kernel(const float* __restrict__ E, int dim, const float* __restrict__ Q, const int32_t* __restrict__ rows,
+                                                        const uint32_t* __restrict__ cnt, int32_t cap, int mode, const float* __restrict__ row_norm,
+                                                        const float* __restrict__ q_sumsq, float* __restrict__ out) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int n = (int)min(cnt[b], (uint32_t)cap);
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+    const float* q = Q + (int64_t)b * dim;
+    for (int p = wave; p < n; p += n_waves) {  // (wave-uniform)
+        const int32_t row = rows[(int64_t)b * cap + p];
+        const float* e = E + (int64_t)row * dim;
+        float acc = 0.f;
+        for (int c = 4 * lane; c < dim; c += 256) {
+            const f4 ev = *reinterpret_cast<const f4*>(e + c), qv = *reinterpret_cast<const f4*>(q + c);
+            acc = fmaf(ev[0], qv[0], acc);
+            acc = fmaf(ev[1], qv[1], acc);
+            acc = fmaf(ev[2], qv[2], acc);
+            acc = fmaf(ev[3], qv[3], acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) {
+            const float qss = mode == SCAN_COSINE ? q_sumsq[b] : 0.f;
+            out[(int64_t)b * cap + p] = transform_score(acc, mode, mode == SCAN_COSINE ? row_norm[row] : 0.f, 0.f, sqrtf(qss), qss);
+        }
+    }
+}
+
 // bits[0] = max |e|, bits[1] = max |e_lo|, bits[2] = max |e_lo| / |e| over the rows (float bit patterns, each nudged up by 1e-6;
 // non-negative floats order like their bits), where e_lo = e - fp16_rtz(e * scale) / scale is what the HI halves drop --
 // computed exactly (the scale is a power of two, the difference of a float and its truncation is exact).
@@ -204,6 +276,25 @@ int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, con
     if (n_queries <= 0) return RL_OK;
     hipLaunchKernelGGL(maxsim_threshold_kernel, dim3(n_queries), dim3(256), 0, s, topk, k, Q, (int)nq, (int)dim, q_stride, m_rel, e_max, thr, cnt,
                        flag, q_unscale, e_norm_max);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+int launch_row_threshold(const float* topk, int32_t nb, int32_t k, const float* Q, int32_t dim, int mode, const float* q_unscale, float lo_ratio,
+                         float lo_norm, float e_norm, float* thr, float* window, uint32_t* cnt, uint32_t* cnt2, uint32_t* flag, hipStream_t s) {
+    if (nb <= 0) return RL_OK;
+    hipLaunchKernelGGL(row_threshold_kernel, dim3(nb), dim3(256), 0, s, topk, k, Q, (int)dim, mode, q_unscale, lo_ratio, lo_norm, e_norm, thr, window,
+                       cnt, cnt2, flag);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+int launch_row_dots(const float* E, int32_t dim, const float* Q, int32_t nb, const int32_t* rows, const uint32_t* cnt, int32_t cap, int mode,
+                    const float* row_norm, const float* q_sumsq, float* out, hipStream_t s) {
+    if (nb <= 0 || cap <= 0) return RL_OK;
+    if (dim % 4 || (reinterpret_cast<uintptr_t>(E) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
+    if (mode != SCAN_COSINE && mode != SCAN_DOT) return RL_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(row_dots_kernel, dim3(8, nb), dim3(256), 0, s, E, (int)dim, Q, rows, cnt, cap, mode, row_norm, q_sumsq, out);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -955,7 +955,7 @@ int launch_score_planes_queries(const float* Q, int32_t nb, int32_t dim, float* 
 // tile_stride > 1).  Fused top-k (cand != nullptr): candidate lists, see RowScoreArgs.
 int launch_score_planes_pass(const void* planes, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, float* scores, int64_t ld,
                              const float* row_norm, const float* row_sumsq, int mode, int32_t tile_stride, const uint32_t* run_if,
-                             const CandArgs* cand, int n_cu, hipStream_t s, float split_scale, bool half) {
+                             const CandArgs* cand, int n_cu, hipStream_t s, float split_scale, bool half, bool hi_only) {
     if (nb < 1 || n_rows < 1 || dim % 32 || dim < 32 || !(split_scale > 0.f) || !planes || tile_stride < 1) return RL_ERR_UNSUPPORTED;
     if ((mode == SCAN_COSINE && !row_norm) || (mode == SCAN_L2 && !row_sumsq)) return RL_ERR_INVALID;
     const int32_t nslab = dim / 32, groups = (nb + 31) / 32;
@@ -976,7 +976,7 @@ int launch_score_planes_pass(const void* planes, int64_t n_rows, int32_t dim, in
 #define RL_MG_LAUNCH(MODE_, HALF_)                                                                                                      \
     hipLaunchKernelGGL((maxsim_gemm_kernel<2, false, MODE_, HALF_>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab,          \
                        reinterpret_cast<const char*>(frag), nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, \
-                       0, nullptr, rs)
+                       hi_only ? 64 : 0, nullptr, rs)
     if (half) { if (cand) RL_MG_LAUNCH(2, true); else RL_MG_LAUNCH(1, true); }
     else      { if (cand) RL_MG_LAUNCH(2, false); else RL_MG_LAUNCH(1, false); }
 #undef RL_MG_LAUNCH

@@ -804,6 +804,63 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float* __restric
     write_results(buf, total < k ? total : k, k, out_scores + (int64_t)q * k, out_ids + (int64_t)q * k);
 }
 
+// Half-bytes batched search (api.hip: search_rows_fused_hi, experimental): query q's candidate list holds min(counts[q], k_in)
+// records (APPROXIMATE score, row).  Sorted by (score desc, row asc), the records whose score reaches (k-th best) - window[q]
+// form a prefix -- every row that can be in the exact top-k when |approximate - exact| <= window[q] / 2 -- and their rows go to
+// out_ids[q * cap2 ..], out_cnt[q] of them (any order is fine for the caller: it re-scores and ranks them).  More than cap2
+// sets *flag.  Fewer than k records: all of them.
+__global__ __launch_bounds__(1024) void list_prefix_kernel(const float* __restrict__ in_scores, const int32_t* __restrict__ in_ids,
+                                                            int32_t k_in, int32_t k, const uint32_t* __restrict__ counts,
+                                                            const float* __restrict__ window, int32_t cap2, int32_t* __restrict__ out_ids,
+                                                            uint32_t* __restrict__ out_cnt, uint32_t* __restrict__ flag) {
+    __shared__ uint64_t buf[MERGE_CAP];
+    __shared__ uint32_t n_pass;
+    const int q = blockIdx.x;
+    const int total = (int)min(counts[q], (uint32_t)k_in);
+    int p2 = 64;
+    while (p2 < total) p2 <<= 1;
+    for (int i = threadIdx.x; i < p2; i += blockDim.x) {
+        uint64_t key = 0ull;
+        if (i < total) {
+            const int64_t src = (int64_t)q * k_in + i;
+            const int32_t id = in_ids[src];
+            if (id >= 0) key = make_key64(in_scores[src], (uint32_t)id);
+        }
+        buf[i] = key;
+    }
+    if (threadIdx.x == 0) n_pass = 0u;
+    __syncthreads();
+    bitonic_sort_desc(buf, p2);  // (ends with a barrier)
+    const uint64_t kth = (k <= p2) ? buf[k - 1] : 0ull;
+    const uint32_t k32 = (uint32_t)(kth >> 32);
+    const float thr = (kth != 0ull && k32 != 0u) ? key_score(k32) - window[q] : -INFINITY;  // (NaN window -> nothing passes -> flag below)
+    uint32_t mine = 0;
+    for (int i = threadIdx.x; i < total; i += blockDim.x) {
+        const uint64_t key = buf[i];
+        const uint32_t s32 = (uint32_t)(key >> 32);
+        if (key != 0ull && s32 != 0u && key_score(s32) >= thr) {
+            ++mine;
+            if (i < cap2) out_ids[(int64_t)q * cap2 + i] = (int32_t)(0xffffffffu - (uint32_t)key);  // sorted: the passing records are a prefix
+        }
+    }
+    if (mine) atomicAdd(&n_pass, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t n = n_pass;
+        out_cnt[q] = n < (uint32_t)cap2 ? n : (uint32_t)cap2;
+        if (n > (uint32_t)cap2 || !(window[q] >= 0.f) || (total > 0 && n == 0u)) atomicOr(flag, 1u);
+    }
+}
+
+int launch_list_prefix(const float* in_scores, const int32_t* in_ids, int32_t nq, int32_t k_in, int32_t k, const uint32_t* counts,
+                       const float* window, int32_t cap2, int32_t* out_ids, uint32_t* out_cnt, uint32_t* flag, hipStream_t s) {
+    if (nq <= 0 || k <= 0) return RL_OK;
+    if (k_in > MERGE_CAP || cap2 < 1) return fail(RL_ERR_UNSUPPORTED, "list_prefix: k_in must be <= 8192");
+    hipLaunchKernelGGL(list_prefix_kernel, dim3(nq), dim3(1024), 0, s, in_scores, in_ids, k_in, k, counts, window, cap2, out_ids, out_cnt, flag);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 int launch_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_lists, int32_t nq, int32_t k_in,
                       int32_t k, float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* counts) {
     if (nq <= 0 || k <= 0) return RL_OK;

@@ -2,6 +2,7 @@
 # One gpurun call for the switches built blind at the end of round 2 (no GPU minutes were left to measure them):
 #   RAGLITE_HI_RNE=1          HI halves rounded to nearest (read when an index is created)
 #   RAGLITE_HI_ONE_PRODUCT=1  approximate MaxSim pass with ONE fp16 MFMA product per multiply (read per call)
+#   RAGLITE_FUSED_HI=1        big-batch row top-k (cfg 5) over the HI image at one product per multiply (read per call)
 # Stages: gated parity tests -> pass kernel time (rl_time_kernel kinds 5 / 6) -> headline bench under each combination.
 # Usage (repo root on the GPU box): bash scripts/r3_experiments.sh [tag]
 set -u
@@ -11,7 +12,7 @@ mkdir -p "$OUT"
 export TMPDIR=/tmp
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 echo "== $(date) start" | tee "$OUT/summary.txt"
-RAGLITE_TEST_EXPERIMENTAL=1 timeout 900 python -m pytest tests/test_gpu_hi_maxsim.py tests/test_gpu_hi_search.py -m gpu -q -x --timeout 600 > "$OUT/pytest_experimental.log" 2>&1
+RAGLITE_TEST_EXPERIMENTAL=1 timeout 1200 python -m pytest tests/test_gpu_hi_maxsim.py tests/test_gpu_hi_search.py tests/test_gpu_fused_topk.py -m gpu -q --timeout 600 > "$OUT/pytest_experimental.log" 2>&1
 echo "pytest exit $?" | tee -a "$OUT/summary.txt"; tail -15 "$OUT/pytest_experimental.log"
 timeout 600 python scripts/time_gemm_pass.py 1000000 20 3,5,6 > "$OUT/pass_times.txt" 2>&1; echo "pass times exit $?" | tee -a "$OUT/summary.txt"; cat "$OUT/pass_times.txt"
 for combo in "0 0" "1 0" "0 1" "1 1"; do
@@ -27,5 +28,10 @@ try:
 except Exception as exc:  # noqa: BLE001
     print("  (no bench line)", exc)
 PY
+done
+for combo in "0 0" "1 0" "1 1"; do   # cfg 5: shipped fused top-k / over the HI image, one product / two products
+  set -- $combo
+  RAGLITE_FUSED_HI=$1 RAGLITE_FUSED_HI_TWO_PRODUCTS=$2 timeout 400 python scripts/bench_configs.py cfg5 > "$OUT/cfg5_hi$1_two$2.json" 2> "$OUT/cfg5_hi$1_two$2.err"
+  echo "cfg5 fused_hi=$1 two_products=$2 exit $?: $(tail -1 "$OUT/cfg5_hi$1_two$2.json" | cut -c1-300)" | tee -a "$OUT/summary.txt"
 done
 echo "== $(date) done" | tee -a "$OUT/summary.txt"

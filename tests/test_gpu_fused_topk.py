@@ -165,3 +165,65 @@ def test_f16_storage_big_batch_over_the_image(metric):
         S0, R0 = idx.search_rows(Qf, k)
     assert np.array_equal(R, R0) and np.array_equal(S.view(np.uint32), S0.view(np.uint32))
     idx.close()
+
+
+# ---- experimental: the fused top-k over the HI image at one MFMA product per multiply (api.hip search_rows_fused_hi) -----------------
+# Opt-in (RAGLITE_FUSED_HI=1), built at the end of round 2 without GPU time left to run it; these tests run with
+# RAGLITE_TEST_EXPERIMENTAL=1 (scripts/r3_experiments.sh).  Needs a HI image: an fp32 corpus of >= 64 M elements.
+_experimental = pytest.mark.skipif(os.environ.get("RAGLITE_TEST_EXPERIMENTAL", "0") in ("", "0"),
+                                   reason="experimental switches: set RAGLITE_TEST_EXPERIMENTAL=1")
+
+
+@_experimental
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+@pytest.mark.parametrize("two_products", ["0", "1"])
+def test_fused_hi_float_data(metric, two_products):
+    n, dim, B, k = 70_000, 1024, 130, 100
+    E = oracle.synth_matrix(7300, n, dim)
+    Q = oracle.synth_matrix(7301, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    with _env(RAGLITE_FUSED_HI="1", RAGLITE_FUSED_HI_TWO_PRODUCTS=two_products):
+        S, R = idx.search_rows(Q, k)
+    S0, R0 = idx.search_rows(Q, k)  # the shipped fused top-k over the pre-split image
+    for b in range(0, B, 13):
+        tol = _tol(E, Q[b], metric)
+        assert_topk_close(S[b], R[b], oracle.similarity(E, Q[b], metric), k, tol)
+        assert len(set(R[b].tolist()) ^ set(R0[b].tolist())) <= 2  # (scores within an ulp of the k-th may swap at the boundary)
+        np.testing.assert_allclose(S[b], S0[b], rtol=0, atol=2 * tol)
+    idx.close()
+
+
+@_experimental
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_fused_hi_integer_ties_bit_exact(metric):
+    n, dim, B, k = 70_000, 1024, 100, 64
+    E = oracle.synth_matrix(7400, n, dim, "small_int")
+    Q = oracle.synth_matrix(7401, B, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    with _env(RAGLITE_FUSED_HI="1"):
+        S, R = idx.search_rows(Q, k)
+    for b in (0, 1, 50, 99):
+        es, ei = oracle.topk_desc(sim_fp32_exact(E, Q[b], metric), k)
+        assert np.array_equal(R[b], ei)
+        if metric == "dot":  # (cosine: the exact re-scoring divides the same integers by the same norms, but sums in another order than NumPy)
+            assert np.array_equal(S[b].view(np.uint32), es.astype(np.float32).view(np.uint32))
+    idx.close()
+
+
+@_experimental
+def test_fused_hi_near_duplicates_fall_back():
+    """3 000 rows within 1e-5 of each other at the top of every ranking: more rows inside the error band than a re-scoring list
+    holds -> the device flag -> the dense full-precision path answers, bit for bit what it answers without the switch."""
+    rng = np.random.default_rng(75)
+    n, dim, B, k = 70_000, 1024, 100, 50
+    E = oracle.synth_matrix(7500, n, dim)
+    Q = oracle.synth_matrix(7501, B, dim)
+    hot = rng.choice(n, 3000, replace=False)
+    E[hot] = (Q.sum(axis=0)[None, :] + 1e-5 * rng.standard_normal((3000, dim))).astype(np.float32)
+    idx = raglite_amd.DeviceIndex(E, metric="dot")
+    with _env(RAGLITE_FUSED_HI="1"):
+        S, R = idx.search_rows(Q, k)
+    with _env(RAGLITE_NO_FUSED_TOPK="1"):
+        S0, R0 = idx.search_rows(Q, k)
+    assert np.array_equal(R, R0) and np.array_equal(S.view(np.uint32), S0.view(np.uint32))
+    idx.close()

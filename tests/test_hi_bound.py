@@ -121,3 +121,41 @@ def test_one_product_maxsim_bound(rne):
         assert max_lo < 0.75 * float(np.linalg.norm(_split_hi(E)[1], axis=1).max())
     # and the queries' own term is the smaller one (round to nearest, 11 bits)
     assert (q_lo_norms <= 2.0 ** -11 * q_norms * (1 + 1e-9)).all()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+@pytest.mark.parametrize("rne", [False, True])
+def test_one_product_row_band_and_two_stage_candidates(metric, rne):
+    """The batched half-bytes search (experimental, `api.hip: search_rows_fused_hi`): approximate similarity from q_hi . e_hi alone,
+    band m of `row_threshold_kernel`; stage 1 keeps the rows reaching (k-th best of a row SAMPLE) - 2 m, stage 2 the rows reaching
+    (k-th best approximate of those) - 2 m -- the exact top-k must survive both."""
+    rng = np.random.default_rng(21 + rne + 2 * (metric == "dot"))
+    n, dim, k, stride = 6000, 256, 20, 7
+    E = rng.standard_normal((n, dim)).astype(np.float32)
+    if metric == "dot":
+        E *= rng.uniform(0.5, 1.0, (n, 1)).astype(np.float32)
+    q = rng.standard_normal(dim).astype(np.float32)
+    e_hi, e_lo = _split_hi_rne(E) if rne else _split_hi(E)[:2]
+    q_hi, q_lo = _query_hi(q[None, :])
+    q_hi, q_lo = q_hi[0], q_lo[0]
+    E64, q64 = E.astype(np.float64), q.astype(np.float64)
+    e_norm, lo_norm = np.linalg.norm(E64, axis=1), np.linalg.norm(e_lo, axis=1)
+    qn, ql = float(np.linalg.norm(q64)), float(np.linalg.norm(q_lo))
+    d_exact, d_approx = E64 @ q64, e_hi @ q_hi
+    if metric == "cosine":
+        exact, approx = d_exact / (e_norm * qn), d_approx / (e_norm * qn)
+        ratio = float((lo_norm / e_norm).max())
+        m = ratio + (1 + ratio) * ql / qn
+    else:
+        exact, approx = 1 + d_exact, 1 + d_approx
+        m = float(lo_norm.max()) * qn + (float(e_norm.max()) + float(lo_norm.max())) * ql
+    assert (np.abs(approx - exact) <= m * (1 + 1e-9)).all()
+    top_exact = np.argsort(-exact, kind="stable")[:k]
+    tau_s = np.sort(approx[::stride])[::-1][k - 1]           # k-th best approximate of the sample: <= the k-th best overall
+    stage1 = np.flatnonzero(approx >= tau_s - 2 * m)
+    assert np.isin(top_exact, stage1).all()
+    a_k = np.sort(approx[stage1])[::-1][k - 1]
+    assert a_k == np.sort(approx)[::-1][k - 1]               # the list's k-th entry IS the k-th best approximate overall
+    stage2 = stage1[approx[stage1] >= a_k - 2 * m]
+    assert np.isin(top_exact, stage2).all()
+    assert len(stage2) < len(stage1) <= n // 2
