@@ -204,10 +204,34 @@ class ShardedIndex:
         out = _all_gather_stacked(packed, self.group)
         return out[..., 0].contiguous().view(torch.float32), out[..., 1].contiguous()
 
+    # -- filters ---------------------------------------------------------------------------------------------
+    def _local_filter(self, chunk_filter):
+        """`chunk_filter`: bool mask over the GLOBAL chunk ordinals (the host's evaluation of `metadata_filter`,
+        `src/raglite/_search.py:84-97`) -> this shard's slice of it (None stays None)."""
+        if chunk_filter is None:
+            return None
+        n_local = (len(self.local_chunk_offsets) - 1) if self.local_chunk_offsets is not None else int(self.local.n_chunks)
+        mask = np.asarray(_to_numpy(chunk_filter), dtype=bool)
+        if mask.ndim != 1 or len(mask) < self.chunk_base + n_local:
+            raise ValueError("chunk_filter must be a bool mask over all (global) chunk ordinals")
+        return np.ascontiguousarray(mask[self.chunk_base : self.chunk_base + n_local])
+
+    @staticmethod
+    def _kw(chunk_filter=None, rank_limit=None) -> dict:
+        kw = {}
+        if chunk_filter is not None:
+            kw["chunk_filter"] = chunk_filter
+        if rank_limit:
+            kw["rank_limit"] = int(rank_limit)
+        return kw
+
     # -- searches ----------------------------------------------------------------------------------------
-    def search_rows(self, queries, k: int):
-        """Global exact top-k rows: (scores (B,k), global row ordinals (B,k))."""
-        s, r = self.local.search_rows(queries, k)
+    def search_rows(self, queries, k: int, chunk_filter=None, rank_limit: int | None = None):
+        """Global exact top-k rows: (scores (B,k), global row ordinals (B,k)).  chunk_filter: bool mask over the GLOBAL chunk
+        ordinals (filter-first branch, `_search.py:105-119`).  rank_limit: the order-first branch's cut (`:120-141`) is applied
+        PER SHARD -- every shard keeps its `rank_limit` nearest rows, a superset of the global cut (exact whenever the whole
+        corpus has no more than `rank_limit` rows)."""
+        s, r = self.local.search_rows(queries, k, **self._kw(self._local_filter(chunk_filter), rank_limit))
         if _is_cuda(s):  # device-resident queries (cfg 5: B = 1000): merge on the device too
             single = s.dim() == 1
             ms, mi = self._exchange_merge_device(s.reshape(1, -1) if single else s, r.reshape(1, -1) if single else r,
@@ -217,9 +241,9 @@ class ShardedIndex:
         ms, mi = merge_topk_host(gs, gi, k)
         return (ms[0], mi[0]) if single else (ms, mi)
 
-    def maxsim_topk(self, query_vecs, k: int):
-        """Global exact top-k chunks by MaxSim: (scores (k,), global chunk ordinals (k,))."""
-        s, c = self.local.maxsim_topk(query_vecs, k)
+    def maxsim_topk(self, query_vecs, k: int, chunk_filter=None):
+        """Global exact top-k chunks by MaxSim: (scores (k,), global chunk ordinals (k,)); chunk_filter as in `search_rows`."""
+        s, c = self.local.maxsim_topk(query_vecs, k, **self._kw(self._local_filter(chunk_filter)))
         if _is_cuda(s):
             ms, mi = self._exchange_merge_device(s.reshape(1, -1), c.reshape(1, -1), self.chunk_base, k)
             return ms[0], mi[0]
@@ -241,14 +265,15 @@ class ShardedIndex:
         gs, gi, _, _ = self._exchange_host(s, c, self.chunk_base)
         return merge_topk_host(gs, gi, k)
 
-    def search_chunks(self, queries, num_hits: int, k: int):
-        """Reference two-stage semantics across shards (`src/raglite/_search.py:66-79,143-149`): every rank's
+    def search_chunks(self, queries, num_hits: int, k: int, chunk_filter=None, rank_limit: int | None = None):
+        """Reference two-stage semantics across shards (`src/raglite/_search.py:66-79,143-149`; chunk_filter / rank_limit as in
+        `search_rows`: the filtered branches `:105-141`): every rank's
         top-`num_hits` rows travel with their global chunk ordinals, are merged to the global top-`num_hits` rows
         (score desc, row asc), then grouped by chunk.  CUDA queries: two tiny all-gathers on the device (rows, chunks),
         one copy of the (world, B, num_hits) lists to the host for the merge + group-by, CUDA tensors back."""
         if self.local_chunk_offsets is None:
             raise ValueError("search_chunks needs local_chunk_offsets")
-        s, r = self.local.search_rows(queries, num_hits)
+        s, r = self.local.search_rows(queries, num_hits, **self._kw(self._local_filter(chunk_filter), rank_limit))
         device = s.device if _is_cuda(s) else None
         if device is not None:
             import torch

@@ -22,18 +22,24 @@ class _OracleLocal:
     def __init__(self, E, off, metric):
         self.E, self.off, self.metric = E, off, metric
 
-    def search_rows(self, q, k):
+    def search_rows(self, q, k, chunk_filter=None):
         q2 = np.atleast_2d(q)
         S = np.full((len(q2), k), -np.inf, np.float32)
         I = np.full((len(q2), k), -1, np.int32)
+        r2c = np.repeat(np.arange(len(self.off) - 1), np.diff(self.off))
         for b, qq in enumerate(q2):
-            s, i = oracle.search_rows(self.E, qq, k, self.metric, np.float64)
+            if chunk_filter is None:
+                s, i = oracle.search_rows(self.E, qq, k, self.metric, np.float64)
+            else:
+                assert len(chunk_filter) == len(self.off) - 1  # the shard's slice of the global mask
+                s, i = oracle.search_rows_filtered(self.E, r2c, qq, k, chunk_filter, self.metric, np.float64)
             S[b, : len(s)] = s
             I[b, : len(i)] = i
         return (S[0], I[0]) if np.ndim(q) == 1 else (S, I)
 
-    def maxsim_topk(self, Q, k):
-        s, c = oracle.maxsim_topk(self.E, self.off, Q, k)
+    def maxsim_topk(self, Q, k, chunk_filter=None):
+        s, c = (oracle.maxsim_topk(self.E, self.off, Q, k) if chunk_filter is None
+                else oracle.maxsim_topk_filtered(self.E, self.off, Q, k, chunk_filter))
         S = np.full(k, -np.inf, np.float32); C_ = np.full(k, -1, np.int32)
         S[: len(s)] = s; C_[: len(c)] = c
         return S, C_
@@ -45,6 +51,10 @@ def _corpus():
     E = oracle.synth_matrix(5, 400, 32, "small_int")  # integer data: heavy ties across shards
     Q = oracle.synth_matrix(6, 3, 32, "small_int")
     return E, off, Q
+
+
+def _chunk_mask(n_chunks):
+    return np.random.default_rng(9).random(n_chunks) < 0.3
 
 
 def _worker(rank, world, port, out_q):
@@ -60,7 +70,11 @@ def _worker(rank, world, port, out_q):
         s_rows, i_rows = sh.search_rows(Q, 25)
         s_ms, c_ms = sh.maxsim_topk(Q, 10)
         s_ch, c_ch, n_ch = sh.search_chunks(Q, 40, 6)
-        out_q.put((rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch))
+        ok = _chunk_mask(len(off) - 1)  # a metadata filter, evaluated on the host over the GLOBAL chunk ordinals
+        f_rows = sh.search_rows(Q, 25, chunk_filter=ok)
+        f_ms = sh.maxsim_topk(Q, 10, chunk_filter=ok)
+        f_ch = sh.search_chunks(Q, 40, 6, chunk_filter=ok)
+        out_q.put((rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch))
     finally:
         dist.destroy_process_group()
 
@@ -86,7 +100,18 @@ def test_two_rank_gloo_matches_single_shard():
         assert p.exitcode == 0
     E, off, Q = _corpus()
     r2c = np.repeat(np.arange(len(off) - 1), np.diff(off))
-    for rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch in results:
+    ok = _chunk_mask(len(off) - 1)
+    for rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch in results:
+        for b in range(len(Q)):  # the filtered branches across shards == the single-shard filtered oracle
+            es, ei = oracle.search_rows_filtered(E, r2c, Q[b], 25, ok, "dot")
+            assert np.array_equal(f_rows[1][b][: len(ei)], ei), f"rank {rank} query {b} (filtered)"
+            np.testing.assert_array_equal(f_rows[0][b][: len(es)], es.astype(np.float32))
+            cs, cc = oracle.search_chunks_filtered(E, r2c, Q[b], 40, 6, ok, "dot")
+            assert f_ch[2][b] == len(cc) and f_ch[1][b, : len(cc)].tolist() == cc.tolist()
+            np.testing.assert_array_equal(f_ch[0][b, : len(cc)], cs.astype(np.float32))
+        ms, mc = oracle.maxsim_topk_filtered(E, off, Q, 10, ok)
+        assert np.array_equal(f_ms[1][: len(mc)], mc)
+        np.testing.assert_array_equal(f_ms[0][: len(ms)], ms.astype(np.float32))
         for b in range(len(Q)):
             es, ei = oracle.search_rows(E, Q[b], 25, "dot")
             assert np.array_equal(i_rows[b], ei), f"rank {rank} query {b}"
