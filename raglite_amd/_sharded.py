@@ -86,6 +86,49 @@ def group_chunk_max_host(row_scores: np.ndarray, row_chunks: np.ndarray, k: int)
     return out_s, out_c, keep.sum(axis=1).astype(np.int32)
 
 
+def merge_order_torch(s, i, k: int):
+    """`_merge_order` on torch tensors (any device, nothing synchronises with the host): three stable sorts, least significant
+    key first -- id asc, score desc, then (padding, NaN) last."""
+    import torch
+
+    pad = i < 0
+    nan = torch.isnan(s)
+    key = torch.where(nan | pad, torch.full_like(s, float("-inf")), s)
+    idx = torch.argsort(i, dim=1, stable=True)
+    idx = idx.gather(1, torch.argsort(key.gather(1, idx), dim=1, descending=True, stable=True))
+    cls = pad.to(torch.int32) * 2 + nan.to(torch.int32)
+    idx = idx.gather(1, torch.argsort(cls.gather(1, idx), dim=1, stable=True))
+    order = idx[:, :k]
+    n_valid = torch.clamp((~pad).sum(dim=1), max=k)
+    return order, n_valid
+
+
+def group_chunk_max_torch(row_scores, row_chunks, k: int):
+    """`group_chunk_max_host` on torch tensors (any device, no host synchronisation: kept hits are scattered to their rank, the
+    rest to a spare column).  Returns (scores (B,k) float32, chunks (B,k) int64, counts (B,) int32)."""
+    import torch
+
+    B, H = row_chunks.shape
+    dev = row_chunks.device
+    out_s = torch.full((B, k + 1), float("-inf"), dtype=torch.float32, device=dev)
+    out_c = torch.full((B, k + 1), -1, dtype=torch.int64, device=dev)
+    if H == 0:
+        return out_s[:, :k], out_c[:, :k], torch.zeros(B, dtype=torch.int32, device=dev)
+    row_chunks = row_chunks.to(torch.int64)
+    by_chunk = torch.argsort(row_chunks, dim=1, stable=True)  # within a chunk the hits keep their rank order
+    sorted_chunks = row_chunks.gather(1, by_chunk)
+    first_sorted = torch.ones((B, H), dtype=torch.bool, device=dev)
+    first_sorted[:, 1:] = sorted_chunks[:, 1:] != sorted_chunks[:, :-1]
+    first = torch.zeros((B, H), dtype=torch.bool, device=dev).scatter_(1, by_chunk, first_sorted)
+    first &= row_chunks >= 0
+    rank = torch.cumsum(first.to(torch.int64), dim=1) - 1
+    keep = first & (rank < k)
+    slot = torch.where(keep, rank, torch.full_like(rank, k))
+    out_s.scatter_(1, slot, row_scores.to(torch.float32))
+    out_c.scatter_(1, slot, row_chunks)
+    return out_s[:, :k].contiguous(), out_c[:, :k].contiguous(), keep.sum(dim=1).to(torch.int32)
+
+
 def _all_gather_stacked(t, group):
     """(world, *t.shape) tensor of every rank's `t`.  The output is allocated in the CONCATENATED form
     `(world * t.shape[0], ...)` -- the one every backend's `all_gather_into_tensor` accepts (gloo rejects the stacked
@@ -269,8 +312,9 @@ class ShardedIndex:
         """Reference two-stage semantics across shards (`src/raglite/_search.py:66-79,143-149`; chunk_filter / rank_limit as in
         `search_rows`: the filtered branches `:105-141`): every rank's
         top-`num_hits` rows travel with their global chunk ordinals, are merged to the global top-`num_hits` rows
-        (score desc, row asc), then grouped by chunk.  CUDA queries: two tiny all-gathers on the device (rows, chunks),
-        one copy of the (world, B, num_hits) lists to the host for the merge + group-by, CUDA tensors back."""
+        (score desc, row asc), then grouped by chunk.  CUDA queries: two tiny all-gathers on the device (rows, chunks), then
+        the merge + group-by as stable sorts and scatters on the device (`merge_order_torch`, `group_chunk_max_torch`): no host
+        synchronisation, CUDA tensors back."""
         if self.local_chunk_offsets is None:
             raise ValueError("search_chunks needs local_chunk_offsets")
         s, r = self.local.search_rows(queries, num_hits, **self._kw(self._local_filter(chunk_filter), rank_limit))
@@ -285,7 +329,18 @@ class ShardedIndex:
             chunk_local = torch.where(r2 >= 0, chunk_local, torch.full_like(chunk_local, -1)).to(torch.int32)
             gs_t, gi_t = self._gather_device(s2, r2, self.row_base)
             _, gc_t = self._gather_device(s2, chunk_local, self.chunk_base)
-            gs, gi, gc = gs_t.cpu().numpy(), gi_t.cpu().numpy(), gc_t.cpu().numpy()
+            # merge + group-by on the device, nothing synchronises with the host: the same orderings as the host code below
+            world, B, kin = gs_t.shape
+            fs = gs_t.permute(1, 0, 2).reshape(B, world * kin)
+            fr = gi_t.permute(1, 0, 2).reshape(B, world * kin).to(torch.int64)
+            fc = gc_t.permute(1, 0, 2).reshape(B, world * kin).to(torch.int64)
+            order, n_valid = merge_order_torch(fs, fr, num_hits)  # the global top-num_hits rows of every query
+            real = torch.arange(order.shape[1], device=device)[None, :] < n_valid[:, None]
+            ms = torch.where(real, fs.gather(1, order), torch.full((), float("-inf"), device=device))
+            mc = torch.where(real, fc.gather(1, order), torch.full((), -1, dtype=torch.int64, device=device))
+            o_s, o_c, o_n = group_chunk_max_torch(ms, mc, k)
+            out = (o_s, o_c.to(torch.int32), o_n)
+            return tuple(o[0] for o in out) if single else out
         else:
             r_np = _to_numpy(r).astype(np.int64)
             r2n = r_np.reshape(1, -1) if r_np.ndim == 1 else r_np
@@ -301,9 +356,4 @@ class ShardedIndex:
         ms = np.where(real, np.take_along_axis(fs, order, axis=1), -np.inf).astype(np.float32)
         mc = np.where(real, np.take_along_axis(fc, order, axis=1), -1)
         out = group_chunk_max_host(ms, mc, k)
-        if device is not None:
-            import torch
-
-            out = (torch.as_tensor(out[0], device=device), torch.as_tensor(out[1].astype(np.int32), device=device),
-                   torch.as_tensor(out[2], device=device))
         return tuple(o[0] for o in out) if single else out

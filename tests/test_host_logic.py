@@ -548,3 +548,74 @@ def test_oracle_order_first_then_filter_branch():
     assert r.tolist() == [4, -1, -1]
     cs, cc = oracle.search_chunks_ranked(E, r2c, q, 3, 2, ok, 3, live, "dot")
     assert cc.tolist() == [2] and abs(cs[0] - 1.5) < 1e-6
+
+
+def test_device_side_merge_and_group_by_equal_the_host_code():
+    """`merge_order_torch` / `group_chunk_max_torch` (what ShardedIndex.search_chunks runs for CUDA tensors, no host sync) against the
+    NumPy host code on lists full of ties, padding, -inf and NaN."""
+    import torch
+
+    from raglite_amd import _sharded
+
+    rng = np.random.default_rng(3)
+    B, M, k = 7, 60, 9
+    s = rng.integers(-3, 4, (B, M)).astype(np.float32)       # heavy ties
+    s[rng.random((B, M)) < 0.05] = -np.inf
+    s[rng.random((B, M)) < 0.05] = np.nan
+    i = np.stack([rng.permutation(1000)[:M] for _ in range(B)]).astype(np.int64)
+    i[rng.random((B, M)) < 0.2] = -1                         # padding
+    i[3] = -1                                                # a query without any hit
+    for n in (1, 25, M, M + 5):
+        order, n_valid = _sharded._merge_order(s, i, n)
+        t_order, t_valid = _sharded.merge_order_torch(torch.from_numpy(s), torch.from_numpy(i), n)
+        assert np.array_equal(n_valid, t_valid.numpy())
+        for b in range(B):  # (positions of padding entries beyond n_valid are arbitrary: compare the real part)
+            assert np.array_equal(order[b, : n_valid[b]], t_order[b, : n_valid[b]].numpy())
+    chunks = rng.integers(0, 12, (B, M)).astype(np.int64)
+    chunks[i < 0] = -1
+    order, n_valid = _sharded._merge_order(s, i, 40)
+    real = np.arange(order.shape[1])[None, :] < n_valid[:, None]
+    ms = np.where(real, np.take_along_axis(s, order, axis=1), -np.inf).astype(np.float32)
+    mc = np.where(real, np.take_along_axis(chunks, order, axis=1), -1)
+    hs, hc, hn = _sharded.group_chunk_max_host(ms, mc, k)
+    ts, tc, tn = _sharded.group_chunk_max_torch(torch.from_numpy(ms), torch.from_numpy(mc), k)
+    assert np.array_equal(hn, tn.numpy()) and np.array_equal(hc, tc.numpy())
+    np.testing.assert_array_equal(hs, ts.numpy())            # (NaN == NaN here: assert_array_equal treats them as equal)
+
+
+def test_sharded_search_chunks_device_branch_on_cpu_tensors(monkeypatch):
+    """The CUDA branch of ShardedIndex.search_chunks (gathers + torch merge / group-by) driven with CPU tensors: world of one,
+    must equal the NumPy branch and the oracle."""
+    import torch
+
+    from oracle import oracle
+    from raglite_amd import _sharded
+    from tests.util import ragged_offsets
+
+    rng = np.random.default_rng(4)
+    off = ragged_offsets(rng, 300, 1, 7)
+    E = oracle.synth_matrix(21, 300, 16, "small_int")
+    Q = oracle.synth_matrix(22, 4, 16, "small_int")
+    r2c = np.repeat(np.arange(len(off) - 1), np.diff(off))
+
+    class Local:
+        def __init__(self, as_torch):
+            self.as_torch = as_torch
+
+        def search_rows(self, q, k):
+            q2 = np.atleast_2d(q.numpy() if hasattr(q, "numpy") else q)
+            S = np.full((len(q2), k), -np.inf, np.float32)
+            I = np.full((len(q2), k), -1, np.int32)
+            for b, qq in enumerate(q2):
+                s, i = oracle.search_rows(E, qq, k, "dot", np.float64)
+                S[b, : len(s)], I[b, : len(i)] = s, i
+            return (torch.from_numpy(S), torch.from_numpy(I)) if self.as_torch else (S, I)
+
+    host = _sharded.ShardedIndex(Local(False), row_base=0, chunk_base=0, local_chunk_offsets=off).search_chunks(Q, 30, 5)
+    monkeypatch.setattr(_sharded, "_is_cuda", lambda x: hasattr(x, "dim"))
+    dev = _sharded.ShardedIndex(Local(True), row_base=0, chunk_base=0, local_chunk_offsets=off).search_chunks(torch.from_numpy(Q), 30, 5)
+    for h, d in zip(host, dev):
+        np.testing.assert_array_equal(np.asarray(h), d.numpy())
+    for b in range(len(Q)):
+        cs, cc = oracle.search_chunks(E, r2c, Q[b], 30, 5, "dot")
+        assert dev[2][b] == len(cc) and dev[1][b, : len(cc)].tolist() == cc.tolist()
