@@ -74,7 +74,8 @@ def _worker(rank, world, port, out_q):
         f_rows = sh.search_rows(Q, 25, chunk_filter=ok)
         f_ms = sh.maxsim_topk(Q, 10, chunk_filter=ok)
         f_ch = sh.search_chunks(Q, 40, 6, chunk_filter=ok)
-        out_q.put((rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch))
+        b_ms = sh.maxsim_topk_batch(np.stack([Q, Q[::-1].copy()]), 10)  # a batch of two queries: one exchange for both
+        out_q.put((rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch, b_ms))
     finally:
         dist.destroy_process_group()
 
@@ -101,7 +102,11 @@ def test_two_rank_gloo_matches_single_shard():
     E, off, Q = _corpus()
     r2c = np.repeat(np.arange(len(off) - 1), np.diff(off))
     ok = _chunk_mask(len(off) - 1)
-    for rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch in results:
+    for rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch, b_ms in results:
+        for j, Qj in enumerate((Q, Q[::-1].copy())):
+            ms, mc = oracle.maxsim_topk(E, off, Qj, 10)
+            assert np.array_equal(b_ms[1][j], mc)
+            np.testing.assert_array_equal(b_ms[0][j], ms.astype(np.float32))
         for b in range(len(Q)):  # the filtered branches across shards == the single-shard filtered oracle
             es, ei = oracle.search_rows_filtered(E, r2c, Q[b], 25, ok, "dot")
             assert np.array_equal(f_rows[1][b][: len(ei)], ei), f"rank {rank} query {b} (filtered)"
