@@ -10,7 +10,7 @@ of 1..15 rows (mean 8, RAGLite's multi-vector chunks), resident in HBM before th
 
 A step = one batch of QUERIES_PER_STEP queries pushed through the hot path (`rl_maxsim_topk_batch` on
 device pointers): the queries' fp16 (hi, lo) fragments once, one corpus pass of the MFMA kernel per EIGHT
-queries over the index' image of the corpus' hi halves (maxsim_gemm_kernel, two fp16 products per multiply), the
+queries over the index' image of the corpus' hi halves (maxsim_gemm_kernel, ONE fp16 product per multiply: q_hi . e_hi), the
 batched selection of the approximate scores, the collection of every chunk a rigorous error bound cannot rule out
 of the top-k (~300 of 125 k per query), their exact scores on the fp32 matrix pipe (maxsim_pairs_kernel) and the
 ranking of those -- the exact top-100 of exactly computed scores; the full-precision passes (three products, over
@@ -202,7 +202,7 @@ def main() -> None:
         "vs_baseline": None,
         # fp32 data in, fp32 scores out, fp32 accumulation; how the products are formed is `arithmetic`
         "dtype": {"fp32_exact": "f32 (v_mfma_f32_16x16x4_f32)",
-                  "f16_split": "f32 in / f32 scores: candidate chunks found with the hi halves of the exact fp16 hi+lo split (2 x v_mfma_f32_16x16x32_f16 per "
+                  "f16_split": "f32 in / f32 scores: candidate chunks found with the fp16 hi halves of corpus and queries (1 x v_mfma_f32_16x16x32_f16 per "
                                "multiply, f32 accumulate, rigorous error bound), their scores by v_mfma_f32_16x16x4_f32 (exact f32 products); "
                                "full-precision fallback: 3 x v_mfma_f32_16x16x32_f16 on hi+lo pairs (22 bits)",
                   "f16_stored": "f16 storage, f16 x f16 -> f32 MFMA"}[arithmetic],
@@ -218,7 +218,7 @@ def main() -> None:
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, kernel only -----------------------------
     # One launch = one corpus pass of EIGHT queries through maxsim_gemm_kernel (matrix-pipe-bound).  Big fp32 corpora in split
-    # arithmetic: the approximate pass over the HI image (kind 5: 2 fp16 MFMA products per multiply; the candidates it leaves
+    # arithmetic: the approximate pass over the HI image (kind 6: 1 fp16 MFMA product per multiply; the candidates it leaves
     # are re-scored exactly on the fp32 matrix pipe), else the full-precision pass over the pre-split image (kind 3: 3 products;
     # fp16-stored corpus: 2).  Otherwise two queries or one query (exact fp32) per pass through the HBM-bound streaming kernels.
     iters = 20
@@ -227,8 +227,8 @@ def main() -> None:
     algo_bytes = elt * rows_local * DIM  # 4*N*d bytes per corpus pass (2*N*d when fp16-stored)
     streamed_bytes = algo_bytes
     kind, per_launch = 0, 1
-    # (experimental switch RAGLITE_HI_ONE_PRODUCT=1: the approximate pass multiplies q_hi.e_hi only -- kind 6)
-    hi_kind = 6 if os.environ.get("RAGLITE_HI_ONE_PRODUCT", "0") not in ("", "0") else 5
+    # (the approximate pass multiplies q_hi.e_hi only -- kind 6; A/B switch RAGLITE_HI_ONE_PRODUCT=0: two products -- kind 5)
+    hi_kind = 5 if os.environ.get("RAGLITE_HI_ONE_PRODUCT", "1") == "0" else 6
     for cand_kind, cand_q in ((hi_kind, 8), (3, 8), (2, 2)):
         if cand_kind == hi_kind and os.environ.get("RAGLITE_NO_HI_MAXSIM"):
             continue

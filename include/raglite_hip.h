@@ -201,8 +201,9 @@ int rl_maxsim_scores(rl_index* index, const float* query_vecs, int32_t nq, float
  * the index' pre-split corpus image (fp16 hi | lo planes written when the index is built: 4 more bytes per element
  * of device memory; RAGLITE_NO_PLANES=1 in the environment disables it), otherwise two queries or one query
  * take a pass over the fp32 / fp16 rows.  On a big fp32 index (>= 64 M elements) the passes of a batch of three or
- * more queries run over an image of the hi halves only (2 more bytes per element; two MFMA products per multiply
- * instead of three), every chunk's score error is bounded rigorously, and the chunks that could be in the top-k are
+ * more queries run over an image of the hi halves only (2 more bytes per element; ONE fp16 MFMA product per multiply
+ * instead of three -- q_hi . e_hi; RAGLITE_HI_ONE_PRODUCT=0: two), every chunk's score error is bounded rigorously from
+ * what the hi halves of corpus and queries drop, and the chunks that could be in the top-k are
  * re-scored with exact fp32 products: the same top-k, scores as accurate as before; where the bound does not decide
  * (thousands of near-identical chunks) the full-precision passes run instead, on the device.
  * RAGLITE_NO_HI_MAXSIM=1 / RAGLITE_NO_HI_PLANE=1 switch that off.

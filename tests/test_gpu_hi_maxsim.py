@@ -1,6 +1,6 @@
 """GPU parity of the half-bytes MaxSim batch (api.hip `rl_maxsim_topk_batch`, HI-image pipeline): batches of three or more
-queries over a big fp32 corpus make their corpus passes over the HI halves of the fp16 split (two MFMA products per multiply
-instead of three), bound every chunk's score error rigorously, and re-score the chunks that could be in the top-k exactly on
+queries over a big fp32 corpus make their corpus passes over the HI halves of the fp16 split (ONE MFMA product per multiply
+instead of three -- q_hi . e_hi; RAGLITE_HI_ONE_PRODUCT=0: two), bound every chunk's score error rigorously, and re-score the chunks that could be in the top-k exactly on
 the fp32 matrix pipe (`maxsim_pairs_kernel`).
 
 score[c] = sum_i max_{j in chunk c} Q[i].D[j] -- the multi-vector generalisation of
@@ -102,10 +102,11 @@ def test_near_identical_chunks_defeat_the_bound_and_the_full_passes_answer():
     idx.close()
 
 
-# ---- experimental switches (not the default path; measured first thing next round) -----------------------------------------------
-# RAGLITE_HI_RNE=1 (read when an index is created): HI halves rounded to nearest instead of toward zero -- the bound's e_lo term
-# halves.  RAGLITE_HI_ONE_PRODUCT=1 (read per call): the approximate pass multiplies q_hi . e_hi only -- a plain fp16 GEMM -- and
-# the bound carries what the queries' hi halves drop.  Results must not change.  Run with RAGLITE_TEST_EXPERIMENTAL=1.
+# ---- switches ----------------------------------------------------------------------------------------------------------------------
+# RAGLITE_HI_RNE=1 (read when an index is created; opt-in): HI halves rounded to nearest instead of toward zero -- the bound's e_lo
+# term halves.  RAGLITE_HI_ONE_PRODUCT (read per call; "1" is the default since the end of round 2, "0" = two products): the
+# approximate pass multiplies q_hi . e_hi only -- a plain fp16 GEMM -- and the bound carries what the queries' hi halves drop.
+# Results must not change under any combination.  Run with RAGLITE_TEST_EXPERIMENTAL=1 (scripts/r3_experiments.sh).
 _experimental = pytest.mark.skipif(os.environ.get("RAGLITE_TEST_EXPERIMENTAL", "0") in ("", "0"),
                                    reason="experimental switches: set RAGLITE_TEST_EXPERIMENTAL=1")
 
