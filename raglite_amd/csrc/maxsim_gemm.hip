@@ -321,7 +321,13 @@ struct RowScoreArgs {
 // src/raglite/_typing.py:211-232): one fp16 plane, 2 B per element -- a (block, slab) is 1 KiB laid out exactly as a wave
 // reads it (lane 16 kq + j <- k-chunk kq of row j), the slab 16 KiB, and each product is 2 MFMAs (q_hi.e + q_lo.e), exact
 // for the stored values.
-template <int NQB, bool TRACE = false, int MODE = 0, bool HALF = false>
+// HO (experimental, RAGLITE_GEMM_DEEP=1; HALF, MODE 0 only): the one-product pass with a DEEP corpus stream.  Measured
+// (profiles/r02_u_skeleton.txt): without any MFMA the HALF pass still takes 0.51 ms -- the image moves at 4 TB/s -- and the matrix work
+// is added to that, not hidden by it.  Cause: VMEM retires in order, a wave's query-fragment loads of slab g are issued after the
+// DMAs of slab g + 2, so waiting for them at the top of slab g drains every older DMA: one 16-KiB slab per CU in flight.  Here the
+// query fragments (hi halves only: two loads per slab) are loaded THREE slabs ahead into four register sets and the ring has six
+// slots: at the top of slab g the DMAs of slabs g + 2 .. g + 4 stay in flight (48 KiB per CU).
+template <int NQB, bool TRACE = false, int MODE = 0, bool HALF = false, bool HO = false>
 __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restrict__ planes, int64_t n_rows, int32_t nslab,
                                                                const char* __restrict__ qfrag, const float* __restrict__ qmeta,
                                                                int32_t n_q, const int32_t* __restrict__ row_to_chunk,
@@ -331,18 +337,20 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
                                                                RowScoreArgs rs) {
     // TRACE (diagnostic build, RAGLITE_GEMM_TRACE=1): s_memtime stamps of workgroup 7, slabs 128..143, kept in
     // LDS and copied out at the end: [slab - 128][wave][stamp 0..15] (3 + p = after pair p of the slab).
+    static_assert(!HO || (HALF && MODE == 0 && !TRACE), "HO: the one-product MaxSim pass over a one-plane image");
     constexpr int BLKB = HALF ? 1024 : 2048;   // bytes of one (16-row block, K slab) of the image
     constexpr int SLAB = MG_NBLK * BLKB;       // one K slab of a tile in LDS
-    __shared__ __attribute__((aligned(16))) char smem[MG_NSLOT * SLAB + (TRACE ? 16 * 8 * 16 * 8 : 0) + (MODE == 2 ? MG_WAVES * 4096 : 0)];
+    constexpr int NSLOT = HO ? 6 : MG_NSLOT;   // LDS ring
+    __shared__ __attribute__((aligned(16))) char smem[NSLOT * SLAB + (TRACE ? 16 * 8 * 16 * 8 : 0) + (MODE == 2 ? MG_WAVES * 4096 : 0)];
     if (rs.run_if && __builtin_amdgcn_readfirstlane((int)*rs.run_if) == 0) return;  // whole grid: the guarded fallback is not needed
     auto stamp = [&](int g, int k) {
         if constexpr (TRACE) {
             if (blockIdx.x == 7 && g >= 128 && g < 144 && (threadIdx.x & 63) == 0)
-                reinterpret_cast<unsigned long long*>(smem + MG_NSLOT * SLAB)[((g - 128) * 8 + (threadIdx.x >> 6)) * 16 + k] = __builtin_amdgcn_s_memtime();
+                reinterpret_cast<unsigned long long*>(smem + NSLOT * SLAB)[((g - 128) * 8 + (threadIdx.x >> 6)) * 16 + k] = __builtin_amdgcn_s_memtime();
         }
     };
     if constexpr (TRACE) {
-        for (int i = threadIdx.x; i < 16 * 8 * 16; i += blockDim.x) reinterpret_cast<unsigned long long*>(smem + MG_NSLOT * SLAB)[i] = 0;
+        for (int i = threadIdx.x; i < 16 * 8 * 16; i += blockDim.x) reinterpret_cast<unsigned long long*>(smem + NSLOT * SLAB)[i] = 0;
         __syncthreads();
     }
     const int lane = threadIdx.x & 63;
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
             f_s = 0;
             if (f_tile + 1 < nt) { ++f_tile; feed_tile(f_tile); }
         }
-        f_slot = f_slot + 1 == MG_NSLOT ? 0 : f_slot + 1;
+        f_slot = f_slot + 1 == NSLOT ? 0 : f_slot + 1;
         return f;
     };
     auto dma_piece = [&](const Feed& f, auto P_) {  // piece p = 2 * block + half (HALF: a block is one piece)
@@ -501,7 +509,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     auto slab = [&](f32x4 (&q)[4], f32x4 (&qn)[4], int nb, int g_trace) __attribute__((always_inline)) {
         Feed f{};
         if (feeder) f = next_feed();
-        const int next_slot = c_slot + 1 == MG_NSLOT ? 0 : c_slot + 1;
+        const int next_slot = c_slot + 1 == NSLOT ? 0 : c_slot + 1;
         if (has_q || MODE != 0) {
             // The next slab's query fragments: ONE load after each of the first four pairs.  (All four at the top of the slab
             // stalled both waves of every SIMD for ~500 cycles while the matrix pipe idled: a VMEM instruction costs its wave
@@ -557,6 +565,40 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
         c_slot = next_slot;
     };
 
+    // HO: q = the hi fragments of this slab (qb0, qb1); qn receives those of the slab three ahead -- one load after each of the
+    // first two pairs, the feeders' four DMAs after the last four.  Every wave loads and reads (a wave without a query multiplies
+    // nothing): the vmcnt bookkeeping of the main loop is the same for all of them.
+    [[maybe_unused]] auto slab_ho = [&](f32x4 (&q)[2], f32x4 (&qn)[2], int nb) __attribute__((always_inline)) {
+        Feed f{};
+        if (feeder) f = next_feed();
+        const int next_slot = c_slot + 1 == NSLOT ? 0 : c_slot + 1;
+        const char* const qp = qbase + (int64_t)q_s * 4096;  // slab q_s: [qb0 hi | qb0 lo | qb1 hi | qb1 lo] x 1 KiB
+        q_advance();
+        h16x8 qh[2];
+        __builtin_memcpy(&qh[0], &q[0], 16);
+        __builtin_memcpy(&qh[1], &q[1], 16);
+#pragma unroll
+        for (int p = 0; p < MG_NBLK / 2; ++p) {
+            if (p + 1 < MG_NBLK / 2) read_pair(c_slot, p + 1, eh[(p + 1) & 1], el[(p + 1) & 1]);
+            else read_pair(next_slot, 0, eh[0], el[0]);
+            if (2 * p < nb && has_q) {  // wave-uniform
+                const h16x8(&h)[2] = eh[p & 1];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int qb = 0; qb < NQB; ++qb)
+                        acc[qb][2 * p + i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(qh[qb], h[i], acc[qb][2 * p + i], 0, 0, 0);
+            }
+            if (p < 2) mg_load_frag(qn[p], lane16, qp + p * 2048);
+            if (feeder && p >= 4) {
+                [&]<int... P>(std::integer_sequence<int, P...>) { ((P / 2 == p - 4 ? dma_piece(f, std::integral_constant<int, P>{}) : (void)0), ...); }
+                (std::make_integer_sequence<int, 8>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        c_slot = next_slot;
+    };
+
     // ---- tile epilogue: per-chunk maxima along the DPP rows, sum over the query vectors, store ---------------------------
     auto epilogue_rows = [&](int t) __attribute__((always_inline)) {  // MODE 1: metric + store of the tile's 32 x 256 scores
         const int32_t row0 = tile_row0(t);
@@ -603,7 +645,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     // test uses reciprocals (2 VALU instead of an IEEE divide) against a threshold lowered by 1e-5; the exact similarity --
     // the formulas of MODE 1, same bits -- is computed for the few records only.
     [[maybe_unused]] int ncand = 0;  // wave-uniform
-    [[maybe_unused]] float* const rec_d = reinterpret_cast<float*>(smem + MG_NSLOT * SLAB + (TRACE ? 16 * 8 * 16 * 8 : 0) + wv * 4096);
+    [[maybe_unused]] float* const rec_d = reinterpret_cast<float*>(smem + NSLOT * SLAB + (TRACE ? 16 * 8 * 16 * 8 : 0) + wv * 4096);
     [[maybe_unused]] uint32_t* const rec_m = reinterpret_cast<uint32_t*>(rec_d + 512);
     constexpr int REC_CAP = 512;  // records a wave keeps per tile (expected: a few dozen); more -> the guarded dense fallback
     auto flush_candidates = [&](int t) __attribute__((always_inline)) {
@@ -748,17 +790,6 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
         }
     };
 
-    // ---- main loop: two slabs per iteration (two static sets of query fragment registers) ---------------------------------
-    // VMEM retires in order.  Per slab g a feeder issues Q(g + 1) (first half of the slab), then its 8 DMAs of slab g + 3; at the top of slab g it
-    // needs DMA(g + 1) and Q(g), i.e. at most the 8 DMAs of slab g + 2 outstanding.  The other waves only have Q in flight.
-    f32x4 qa[4], qb_[4];
-    {   // prologue: DMA(0), DMA(1), Q(0), DMA(2); slab 0 must have landed for everybody before its first pair is read
-        if (feeder) { const Feed f0 = next_feed(); dma_all(f0); const Feed f1 = next_feed(); dma_all(f1); }
-        if (has_q || MODE != 0) load_q(qa);
-        if (feeder) { const Feed f2 = next_feed(); dma_all(f2); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HALF ? 12 : 20) : "memory"); }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (has_q || MODE != 0) read_pair(0, 0, eh[0], el[0]);
-    }
     auto tile_nb = [&](int t) {
         const int32_t left = r_hi - tile_row0(t);
         const int nb = (left + 15) >> 4;
@@ -779,6 +810,57 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
             }
         }
     };
+    if constexpr (HO) {
+        // ---- HO main loop: four slabs per iteration (four static sets of two query fragments) --------------------------------------
+        // Issue order per slab g: Q(g + 3) (2 loads), then -- feeders -- the 4 DMAs of slab g + 5.  At the top of slab g a wave needs
+        // Q(g) and, for everybody's sake, its DMAs of slab g + 1: everything up to Q(g) has retired when at most DMA(g + 2), Q(g + 1),
+        // DMA(g + 3), Q(g + 2), DMA(g + 4) = 16 operations are outstanding (the other waves: Q(g + 1), Q(g + 2) = 4).
+        f32x4 qs0[2], qs1[2], qs2[2], qs3[2];
+        auto load_q2 = [&](f32x4 (&q)[2]) __attribute__((always_inline)) {
+            const char* p = qbase + (int64_t)q_s * 4096;
+            mg_load_frag(q[0], lane16, p);
+            mg_load_frag(q[1], lane16, p + 2048);
+            q_advance();
+        };
+        {   // prologue: DMA(0), DMA(1), Q(0), DMA(2), Q(1), DMA(3), Q(2), DMA(4): the steady-state order
+            if (feeder) { const Feed f0 = next_feed(); dma_all(f0); const Feed f1 = next_feed(); dma_all(f1); }
+            load_q2(qs0);
+            if (feeder) { const Feed f2 = next_feed(); dma_all(f2); }
+            load_q2(qs1);
+            if (feeder) { const Feed f3 = next_feed(); dma_all(f3); }
+            load_q2(qs2);
+            if (feeder) { const Feed f4 = next_feed(); dma_all(f4); asm volatile("s_waitcnt vmcnt(22)" ::: "memory"); }  // DMA(0) has landed
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            read_pair(0, 0, eh[0], el[0]);
+        }
+        auto step = [&](f32x4 (&q)[2], f32x4 (&qn)[2]) __attribute__((always_inline)) {
+            if (feeder) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            asm volatile("" : "+v"(q[0]), "+v"(q[1]));
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            slab_ho(q, qn, nb);
+            advance();
+        };
+        for (int g = 0; g < total; g += 4) {
+            step(qs0, qs3);
+            if (g + 1 < total) step(qs1, qs0);
+            if (g + 2 < total) step(qs2, qs1);
+            if (g + 3 < total) step(qs3, qs2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
+        return;
+    }
+    // ---- main loop: two slabs per iteration (two static sets of query fragment registers) ---------------------------------
+    // VMEM retires in order.  Per slab g a feeder issues Q(g + 1) (first half of the slab), then its 8 DMAs of slab g + 3; at the top of slab g it
+    // needs DMA(g + 1) and Q(g), i.e. at most the 8 DMAs of slab g + 2 outstanding.  The other waves only have Q in flight.
+    f32x4 qa[4], qb_[4];
+    {   // prologue: DMA(0), DMA(1), Q(0), DMA(2); slab 0 must have landed for everybody before its first pair is read
+        if (feeder) { const Feed f0 = next_feed(); dma_all(f0); const Feed f1 = next_feed(); dma_all(f1); }
+        if (has_q || MODE != 0) load_q(qa);
+        if (feeder) { const Feed f2 = next_feed(); dma_all(f2); asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HALF ? 12 : 20) : "memory"); }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (has_q || MODE != 0) read_pair(0, 0, eh[0], el[0]);
+    }
     auto wait_top = [&]() __attribute__((always_inline)) {
         if (feeder) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HALF ? 4 : 8) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -810,7 +892,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     if constexpr (TRACE) {
         __syncthreads();
         if (blockIdx.x == 7)
-            for (int i = threadIdx.x; i < 16 * 8 * 16; i += blockDim.x) trace[i] = reinterpret_cast<unsigned long long*>(smem + MG_NSLOT * SLAB)[i];
+            for (int i = threadIdx.x; i < 16 * 8 * 16; i += blockDim.x) trace[i] = reinterpret_cast<unsigned long long*>(smem + NSLOT * SLAB)[i];
     }
 }
 
@@ -856,7 +938,15 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
 #define RL_MG_LAUNCH(NQB_, HALF_)                                                                                                     \
     hipLaunchKernelGGL((maxsim_gemm_kernel<NQB_, false, 0, HALF_>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, \
                        qmeta, n_q, row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr, rs0)
-    if (half) { if (nq <= 16) RL_MG_LAUNCH(1, true); else RL_MG_LAUNCH(2, true); }
+    static const bool deep = std::getenv("RAGLITE_GEMM_DEEP") != nullptr && std::getenv("RAGLITE_GEMM_DEEP")[0] != '0';  // experimental (HO)
+    if (half && hi_only && deep) {
+#define RL_MG_LAUNCH_HO(NQB_)                                                                                                          \
+    hipLaunchKernelGGL((maxsim_gemm_kernel<NQB_, false, 0, true, true>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, \
+                       qmeta, n_q, row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr, rs0)
+        if (nq <= 16) RL_MG_LAUNCH_HO(1); else RL_MG_LAUNCH_HO(2);
+#undef RL_MG_LAUNCH_HO
+    }
+    else if (half) { if (nq <= 16) RL_MG_LAUNCH(1, true); else RL_MG_LAUNCH(2, true); }
     else      { if (nq <= 16) RL_MG_LAUNCH(1, false); else RL_MG_LAUNCH(2, false); }
 #undef RL_MG_LAUNCH
     RL_HIP(hipGetLastError());

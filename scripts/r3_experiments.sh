@@ -34,4 +34,12 @@ for combo in "0 0" "1 0" "1 1"; do   # cfg 5: shipped fused top-k / over the HI 
   RAGLITE_FUSED_HI=$1 RAGLITE_FUSED_HI_TWO_PRODUCTS=$2 timeout 400 python scripts/bench_configs.py cfg5 > "$OUT/cfg5_hi$1_two$2.json" 2> "$OUT/cfg5_hi$1_two$2.err"
   echo "cfg5 fused_hi=$1 two_products=$2 exit $?: $(tail -1 "$OUT/cfg5_hi$1_two$2.json" | cut -c1-300)" | tee -a "$OUT/summary.txt"
 done
+# the deep-stream build of the one-product pass (maxsim_gemm_kernel HO: query fragments three slabs ahead, six-slot ring): parity, then time
+RAGLITE_GEMM_DEEP=1 timeout 600 python -m pytest tests/test_gpu_hi_maxsim.py tests/test_gpu_fullsize.py -m gpu -q -x -k "hi_maxsim or fullsize_maxsim" --timeout 600 > "$OUT/pytest_deep.log" 2>&1
+echo "pytest deep exit $?" | tee -a "$OUT/summary.txt"; tail -5 "$OUT/pytest_deep.log"
+gcc -O2 -std=c11 -Iinclude scripts/micro/r3_probe.c -o /tmp/r3_probe -Lraglite_amd/_lib -lraglite_hip -lm -Wl,-rpath,$PWD/raglite_amd/_lib
+for deep in 0 1; do
+  echo "== RAGLITE_GEMM_DEEP=$deep" | tee -a "$OUT/summary.txt"
+  RAGLITE_GEMM_DEEP=$deep R3_PROBE_DEBUG=1 timeout 120 /tmp/r3_probe 2>&1 | tee "$OUT/probe_deep$deep.txt" | grep -E "pass kind|maxsim batch|bit-identical" | tee -a "$OUT/summary.txt"
+done
 echo "== $(date) done" | tee -a "$OUT/summary.txt"
