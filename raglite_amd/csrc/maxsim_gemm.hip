@@ -323,8 +323,9 @@ struct RowScoreArgs {
 // for the stored values.
 // HO (experimental, RAGLITE_GEMM_DEEP=1; HALF, MODE 0 only): the one-product pass with a DEEP corpus stream.  Measured
 // (profiles/r02_u_skeleton.txt): without any MFMA the HALF pass still takes 0.51 ms -- the image moves at 4 TB/s -- and the matrix work
-// is added to that, not hidden by it.  Cause: VMEM retires in order, a wave's query-fragment loads of slab g are issued after the
-// DMAs of slab g + 2, so waiting for them at the top of slab g drains every older DMA: one 16-KiB slab per CU in flight.  Here the
+// is added to that, not hidden by it.  Cause: VMEM retires in order and a wave's query-fragment loads of slab g are issued one
+// slab ahead, i.e. after every DMA but the newest slab's: waiting for them at the top of slab g drains all older DMAs -- one 16-KiB
+// slab per CU in flight, however deep the ring.  Here the
 // query fragments (hi halves only: two loads per slab) are loaded THREE slabs ahead into four register sets and the ring has six
 // slots: at the top of slab g the DMAs of slabs g + 2 .. g + 4 stay in flight (48 KiB per CU).
 template <int NQB, bool TRACE = false, int MODE = 0, bool HALF = false, bool HO = false>
