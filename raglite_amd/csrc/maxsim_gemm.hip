@@ -791,31 +791,25 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
         }
     };
 
-    auto tile_nb = [&](int t) {
-        const int32_t left = r_hi - tile_row0(t);
-        const int nb = (left + 15) >> 4;
-        return nb < MG_NBLK ? nb : MG_NBLK;
-    };
-    int nb = tile_nb(0);
-    auto advance = [&]() __attribute__((always_inline)) {
-        if (++c_s == nslab) {
-            if constexpr (MODE == 0) epilogue(c_tile);
-            else if constexpr (MODE == 1) epilogue_rows(c_tile);
-            else epilogue_cand(c_tile);
-            c_s = 0;
-            ++c_tile;
-            nb = tile_nb(c_tile);
-            if constexpr (MODE != 0) {  // the next tile's group of queries
-                has_q = group_of(c_tile) < n_q;
-                any_lo = any_lo_of(c_tile);
-            }
-        }
-    };
     if constexpr (HO) {
         // ---- HO main loop: four slabs per iteration (four static sets of two query fragments) --------------------------------------
         // Issue order per slab g: Q(g + 3) (2 loads), then -- feeders -- the 4 DMAs of slab g + 5.  At the top of slab g a wave needs
         // Q(g) and, for everybody's sake, its DMAs of slab g + 1: everything up to Q(g) has retired when at most DMA(g + 2), Q(g + 1),
         // DMA(g + 3), Q(g + 2), DMA(g + 4) = 16 operations are outstanding (the other waves: Q(g + 1), Q(g + 2) = 4).
+        auto tile_nb = [&](int t) {
+            const int32_t left = r_hi - tile_row0(t);
+            const int nb_ = (left + 15) >> 4;
+            return nb_ < MG_NBLK ? nb_ : MG_NBLK;
+        };
+        int nb = tile_nb(0);
+        auto advance = [&]() __attribute__((always_inline)) {
+            if (++c_s == nslab) {
+                epilogue(c_tile);
+                c_s = 0;
+                ++c_tile;
+                nb = tile_nb(c_tile);
+            }
+        };
         f32x4 qs0[2], qs1[2], qs2[2], qs3[2];
         auto load_q2 = [&](f32x4 (&q)[2]) __attribute__((always_inline)) {
             const char* p = qbase + (int64_t)q_s * 4096;
@@ -862,6 +856,26 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (has_q || MODE != 0) read_pair(0, 0, eh[0], el[0]);
     }
+    auto tile_nb = [&](int t) {
+        const int32_t left = r_hi - tile_row0(t);
+        const int nb = (left + 15) >> 4;
+        return nb < MG_NBLK ? nb : MG_NBLK;
+    };
+    int nb = tile_nb(0);
+    auto advance = [&]() __attribute__((always_inline)) {
+        if (++c_s == nslab) {
+            if constexpr (MODE == 0) epilogue(c_tile);
+            else if constexpr (MODE == 1) epilogue_rows(c_tile);
+            else epilogue_cand(c_tile);
+            c_s = 0;
+            ++c_tile;
+            nb = tile_nb(c_tile);
+            if constexpr (MODE != 0) {  // the next tile's group of queries
+                has_q = group_of(c_tile) < n_q;
+                any_lo = any_lo_of(c_tile);
+            }
+        }
+    };
     auto wait_top = [&]() __attribute__((always_inline)) {
         if (feeder) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(HALF ? 4 : 8) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
