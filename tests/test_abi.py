@@ -88,3 +88,20 @@ def test_graft_entry_build_runs():
     import __graft_entry__
 
     __graft_entry__.build()
+
+
+def test_c_consumers_compile_against_the_header_alone():
+    """include/raglite_hip.h is the boundary: plain C11, no HIP / torch headers.  The pure-C consumers (the GPU smoke of
+    tests/test_gpu_parity.py::test_pure_c_consumer and the measurement probe scripts/micro/r3_probe.c) must compile against it
+    with warnings as errors -- checked here without a GPU (syntax + types only)."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    gcc = shutil.which("gcc")
+    assert gcc, "gcc is part of the image"
+    for src in (root / "tests" / "c" / "abi_smoke.c", root / "scripts" / "micro" / "r3_probe.c"):
+        res = subprocess.run([gcc, "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", f"-I{root / 'include'}", str(src)],
+                             capture_output=True, text=True)
+        assert res.returncode == 0, res.stderr
