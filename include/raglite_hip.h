@@ -319,7 +319,7 @@ int rl_partition_similarity(const float* X, int64_t n, int32_t dim, const int64_
  * eight-queries-per-pass kernel over the pre-split corpus image (eight queries of nq / 8 vectors each), 4 = the
  * ranking pass of the half-bytes search of rl_search_rows (nq <= 16 queries over the fp16 HI plane;
  * RL_ERR_UNSUPPORTED when the index has none), 5 = the approximate eight-query MaxSim pass over the HI image
- * (as kind 3), 6 = the same pass with one MFMA product per multiply (experimental, RAGLITE_HI_ONE_PRODUCT).
+ * (as kind 3) with two MFMA products per multiply, 6 = the same pass with one (what rl_maxsim_topk_batch runs by default).
  * Used so that roofline.achieved is measured with HIP
  * events on the stream the kernel runs on. */
 int rl_time_kernel(rl_index* index, int kind, const float* query_vecs_dev, int32_t nq, int32_t iters,

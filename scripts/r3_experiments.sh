@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call for the switches built blind at the end of round 2 (no GPU minutes were left to measure them):
 #   RAGLITE_HI_RNE=1          HI halves rounded to nearest (read when an index is created)
-#   RAGLITE_HI_ONE_PRODUCT=1  approximate MaxSim pass with ONE fp16 MFMA product per multiply (read per call)
+#   RAGLITE_HI_ONE_PRODUCT=0|1  approximate MaxSim pass with two / ONE fp16 MFMA products per multiply (read per call; 1 is the default)
 #   RAGLITE_FUSED_HI=1        big-batch row top-k (cfg 5) over the HI image at one product per multiply (read per call)
 # Stages: gated parity tests -> pass kernel time (rl_time_kernel kinds 5 / 6) -> headline bench under each combination.
 # Usage (repo root on the GPU box): bash scripts/r3_experiments.sh [tag]

@@ -93,7 +93,7 @@ def _query_hi(Q: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
 
 @pytest.mark.parametrize("rne", [False, True])
 def test_one_product_maxsim_bound(rne):
-    """Experimental one-product pass (RAGLITE_HI_ONE_PRODUCT=1): approx = sum_i max_j q_hi,i . e_hi,j.  Per pair
+    """The one-product approximate pass (the default of the MaxSim batch; RAGLITE_HI_ONE_PRODUCT=0: two products): approx = sum_i max_j q_hi,i . e_hi,j.  Per pair
     s - a = q_lo . e + q_hi . e_lo, so |approx - exact| <= max|e_lo| sum_i |q_i| + (max|e| + max|e_lo|) sum_i |q_lo,i| -- the
     threshold `maxsim_threshold_kernel` computes when it is handed the queries' scales."""
     rng = np.random.default_rng(11 + rne)
