@@ -321,7 +321,7 @@ struct RowScoreArgs {
 // src/raglite/_typing.py:211-232): one fp16 plane, 2 B per element -- a (block, slab) is 1 KiB laid out exactly as a wave
 // reads it (lane 16 kq + j <- k-chunk kq of row j), the slab 16 KiB, and each product is 2 MFMAs (q_hi.e + q_lo.e), exact
 // for the stored values.
-// HO (experimental, RAGLITE_GEMM_DEEP=1; HALF, MODE 0 only): the one-product pass with a DEEP corpus stream.  Measured
+// HO (experimental, RAGLITE_GEMM_DEEP=1; HALF images, one product): the pass with a DEEP corpus stream.  Measured
 // (profiles/r02_u_skeleton.txt): without any MFMA the HALF pass still takes 0.51 ms -- the image moves at 4 TB/s -- and the matrix work
 // is added to that, not hidden by it.  Cause: VMEM retires in order and a wave's query-fragment loads of slab g are issued one
 // slab ahead, i.e. after every DMA but the newest slab's: waiting for them at the top of slab g drains all older DMAs -- one 16-KiB
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
                                                                RowScoreArgs rs) {
     // TRACE (diagnostic build, RAGLITE_GEMM_TRACE=1): s_memtime stamps of workgroup 7, slabs 128..143, kept in
     // LDS and copied out at the end: [slab - 128][wave][stamp 0..15] (3 + p = after pair p of the slab).
-    static_assert(!HO || (HALF && MODE == 0 && !TRACE), "HO: the one-product MaxSim pass over a one-plane image");
+    static_assert(!HO || (HALF && !TRACE), "HO: the one-product pass over a one-plane image");
     constexpr int BLKB = HALF ? 1024 : 2048;   // bytes of one (16-row block, K slab) of the image
     constexpr int SLAB = MG_NBLK * BLKB;       // one K slab of a tile in LDS
     constexpr int NSLOT = HO ? 6 : MG_NSLOT;   // LDS ring
@@ -804,10 +804,13 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
         int nb = tile_nb(0);
         auto advance = [&]() __attribute__((always_inline)) {
             if (++c_s == nslab) {
-                epilogue(c_tile);
+                if constexpr (MODE == 0) epilogue(c_tile);
+                else if constexpr (MODE == 1) epilogue_rows(c_tile);
+                else epilogue_cand(c_tile);
                 c_s = 0;
                 ++c_tile;
                 nb = tile_nb(c_tile);
+                if constexpr (MODE != 0) has_q = group_of(c_tile) < n_q;  // the next tile's group of queries
             }
         };
         f32x4 qs0[2], qs1[2], qs2[2], qs3[2];
@@ -1082,7 +1085,16 @@ int launch_score_planes_pass(const void* planes, int64_t n_rows, int32_t dim, in
     hipLaunchKernelGGL((maxsim_gemm_kernel<2, false, MODE_, HALF_>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab,          \
                        reinterpret_cast<const char*>(frag), nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, \
                        hi_only ? 64 : 0, nullptr, rs)
-    if (half) { if (cand) RL_MG_LAUNCH(2, true); else RL_MG_LAUNCH(1, true); }
+    static const bool deep = std::getenv("RAGLITE_GEMM_DEEP") != nullptr && std::getenv("RAGLITE_GEMM_DEEP")[0] != '0';  // experimental (HO)
+    if (half && hi_only && deep) {
+#define RL_MG_LAUNCH_HO(MODE_)                                                                                                         \
+    hipLaunchKernelGGL((maxsim_gemm_kernel<2, false, MODE_, true, true>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab,     \
+                       reinterpret_cast<const char*>(frag), nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, \
+                       64, nullptr, rs)
+        if (cand) RL_MG_LAUNCH_HO(2); else RL_MG_LAUNCH_HO(1);
+#undef RL_MG_LAUNCH_HO
+    }
+    else if (half) { if (cand) RL_MG_LAUNCH(2, true); else RL_MG_LAUNCH(1, true); }
     else      { if (cand) RL_MG_LAUNCH(2, false); else RL_MG_LAUNCH(1, false); }
 #undef RL_MG_LAUNCH
     RL_HIP(hipGetLastError());

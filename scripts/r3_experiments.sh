@@ -37,6 +37,8 @@ done
 # the deep-stream build of the one-product pass (maxsim_gemm_kernel HO: query fragments three slabs ahead, six-slot ring): parity, then time
 RAGLITE_GEMM_DEEP=1 timeout 600 python -m pytest tests/test_gpu_hi_maxsim.py tests/test_gpu_fullsize.py -m gpu -q -x -k "hi_maxsim or fullsize_maxsim" --timeout 600 > "$OUT/pytest_deep.log" 2>&1
 echo "pytest deep exit $?" | tee -a "$OUT/summary.txt"; tail -5 "$OUT/pytest_deep.log"
+RAGLITE_GEMM_DEEP=1 RAGLITE_TEST_EXPERIMENTAL=1 timeout 600 python -m pytest tests/test_gpu_fused_topk.py -m gpu -q -x -k fused_hi --timeout 600 > "$OUT/pytest_deep_fused.log" 2>&1
+echo "pytest deep fused_hi exit $?" | tee -a "$OUT/summary.txt"; tail -5 "$OUT/pytest_deep_fused.log"
 gcc -O2 -std=c11 -Iinclude scripts/micro/r3_probe.c -o /tmp/r3_probe -Lraglite_amd/_lib -lraglite_hip -lm -Wl,-rpath,$PWD/raglite_amd/_lib
 for deep in 0 1; do
   echo "== RAGLITE_GEMM_DEEP=$deep" | tee -a "$OUT/summary.txt"
