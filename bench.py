@@ -29,6 +29,9 @@ Extra objects in the JSON line (rank 0; all but `roofline` at N = 1 only):
                 full corpus, and against a float64 reference on a >= 50 k-row slab
   cpu_baseline  the NumPy oracle on the host cores (the time of that full-corpus check)
   configs       BASELINE.json configs 2-5 on one GPU (scripts/bench_configs.py), outside the headline's timed region
+  raglite_shaped  the headline pipeline on unit-norm fp16-rounded and on clustered corpora (what RAGLite stores): throughput,
+                candidates per query, fallback, float64 parity at 1e-4 absolute
+  candidates_per_query / fallback_steps  what the bound-filtered pipeline did on the headline's own data
 """
 
 from __future__ import annotations
@@ -94,6 +97,26 @@ def main() -> None:
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become N ranks (one process per GPU) through torch.distributed.run, exactly the
+        # command the driver would have used.  Fewer than N visible devices is an error, never a silent one-GPU run.
+        import socket
+        import subprocess
+
+        if not args.same_gpu:
+            import torch
+
+            have = torch.cuda.device_count()
+            if have < args.gpus:
+                raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible")
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     import torch
     import torch.distributed as dist
 
@@ -105,7 +128,7 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.same_gpu:
         local_rank = 0
@@ -118,6 +141,9 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        if dist.get_world_size() != args.gpus:  # n_gpus below is what the process group says, not what argv says
+            raise SystemExit(f"--gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
+        world = dist.get_world_size()
 
     n_rows = args.rows
     off = chunk_offsets(n_rows)
@@ -185,6 +211,26 @@ def main() -> None:
 
     elapsed, region_ms, last = timed_steps(args.steps, args.warmup)
 
+    # How the data decided the bound-filtered pipeline (outside the timed region: reading the counters synchronises).  The steps cycle
+    # through n_batches distinct query batches, so one more run of each tells what every timed step did.
+    filt = []
+    for i in range(min(n_batches, args.steps + args.warmup)):
+        step(i)
+        filt.append(index.filter_stats())
+    fence()
+    if filt and filt[0]["kind"] != "none":
+        fallback_steps = sum(int(filt[i % len(filt)]["fallback"]) for i in range(args.steps))
+        filter_block = {
+            "kind": filt[0]["kind"],
+            "candidates_per_query": {"mean": float(np.mean([f["candidates_per_query_mean"] for f in filt])),
+                                     "max": int(max(f["candidates_per_query_max"] for f in filt))},
+            "list_capacity": filt[0]["list_capacity"], "fallback_steps": fallback_steps, "of_steps": args.steps,
+            "note": "rank 0's shard; chunks whose approximate score is within 2m of the k-th best, re-scored exactly; fallback = the "
+                    "guarded full-precision passes ran (list overflow / unusable bound)",
+        }
+    else:
+        filter_block = {"kind": "none", "fallback_steps": 0, "of_steps": args.steps}
+
     total_queries = args.steps * qps
     exchange = ("no exchange step at N = 1" if world == 1 else
                 f"corpus sharded by chunk over {world} GPUs; per step ONE all-gather of every rank's local top-k + device merge, no host sync"
@@ -207,6 +253,9 @@ def main() -> None:
                                "full-precision fallback: 3 x v_mfma_f32_16x16x32_f16 on hi+lo pairs (22 bits)",
                   "f16_stored": "f16 storage, f16 x f16 -> f32 MFMA"}[arithmetic],
         "data": "synthetic",
+        "candidates_per_query": filter_block.get("candidates_per_query"),
+        "fallback_steps": filter_block["fallback_steps"],
+        "filter": filter_block,
         "config": {
             "workload": f"maxsim_{NQ}x{n_rows}_d{DIM}_top{TOPK}_ragged_chunks_1to15"
                         + ("" if args.storage == "f32" else "_F16_STORED_CORPUS_not_the_baseline_config"),
@@ -426,6 +475,14 @@ def main() -> None:
                 result["configs"][name] = bench_configs.run(name)
             except Exception as exc:  # noqa: BLE001 - a failing side config must not hide the headline
                 result["configs"][name] = {"error": f"{type(exc).__name__}: {exc}"}
+            torch.cuda.empty_cache()
+        # the headline pipeline on RAGLite-shaped corpora (unit-norm fp16-rounded rows; clustered): own workload names
+        result["raglite_shaped"] = {}
+        for name in ("shaped_unit", "shaped_clustered"):
+            try:
+                result["raglite_shaped"][name] = bench_configs.run(name)
+            except Exception as exc:  # noqa: BLE001
+                result["raglite_shaped"][name] = {"error": f"{type(exc).__name__}: {exc}"}
             torch.cuda.empty_cache()
         print(json.dumps(result))
         return

@@ -311,6 +311,16 @@ int rl_gather_rows(rl_index* index, const int32_t* rows, int64_t n, float* out, 
 int rl_partition_similarity(const float* X, int64_t n, int32_t dim, const int64_t* doc_offsets, int64_t n_docs,
                             const uint8_t* nonoutlying, float* out, int mem, void* stream);
 
+/* What the last bound-filtered search on this index did (diagnostic; bench.py reports it next to every timed number that depends
+ * on it).  The searches that rank on approximate scores and re-score what a rigorous bound cannot rule out -- rl_maxsim_topk_batch
+ * over the HI image, rl_search_rows for B <= 16 over the HI plane, the fused top-k of B >= 96 -- keep per-query candidate lists of a
+ * fixed capacity and a device flag on which their full-precision fallback runs.  Synchronises `stream`, then fills
+ *   out[0] = kind (rl_filter_kind; 0 = no such search ran since the index was created)   out[1] = queries of that call
+ *   out[2] = sum of the candidate counts   out[3] = largest count   out[4] = list capacity   out[5] = 1 when the fallback ran.
+ * How the data decides both numbers is the reason this exists: they are not constants of the algorithm. */
+enum rl_filter_kind { RL_FILTER_NONE = 0, RL_FILTER_MAXSIM_BATCH = 1, RL_FILTER_ROWS_HI = 2, RL_FILTER_ROWS_FUSED = 3, RL_FILTER_ROWS_FUSED_HI = 4 };
+int rl_index_filter_stats(rl_index* index, int64_t out[6], void* stream);
+
 /* Timing hook for bench.py: run `fn`-independent -- records the elapsed milliseconds between two
  * events on `stream` bracketing `iters` back-to-back launches of the named kernel path with the
  * given index / query.  kind: 0 = rl_maxsim_scores kernel only, 1 = rl_search_rows scan kernel

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "rl_index_delete_chunks": [c_void_p, c_void_p, c_i64, c_void_p],
     "rl_index_live": [c_void_p, C.POINTER(c_i64), C.POINTER(c_i64), c_void_p],
     "rl_index_compact": [c_void_p, c_void_p, C.POINTER(c_i64), C.POINTER(c_i64), c_void_p],
+    "rl_index_filter_stats": [c_void_p, C.POINTER(c_i64), c_void_p],
     "rl_index_set_arithmetic": [c_void_p, c_int],
     "rl_index_arithmetic": [c_void_p, C.POINTER(c_int)],
     "rl_search_rows_filtered": [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_int, c_void_p],

@@ -358,6 +358,19 @@ class DeviceIndex:
         check(lib().rl_index_live(self._handle, C.byref(r), C.byref(c), None))
         return int(r.value), int(c.value)
 
+    def filter_stats(self) -> dict:
+        """What the last bound-filtered search on this index did (`rl_index_filter_stats`): kind, queries, candidates per query
+        (mean / max), list capacity, and whether the guarded full-precision fallback ran.  Synchronises."""
+        out = (C.c_int64 * 6)()
+        st = _Args()
+        st._side(self.mem, self.device)  # noqa: SLF001
+        self._prep(st)
+        check(lib().rl_index_filter_stats(self._handle, out, st.stream))
+        kind = {0: "none", 1: "maxsim_batch_hi", 2: "rows_hi", 3: "rows_fused", 4: "rows_fused_hi"}[int(out[0])]
+        n = int(out[1])
+        return {"kind": kind, "queries": n, "candidates_per_query_mean": (int(out[2]) / n if n else 0.0),
+                "candidates_per_query_max": int(out[3]), "list_capacity": int(out[4]), "fallback": bool(out[5])}
+
     # -- a6 + a7 -------------------------------------------------------------------------------
     def search_rows(self, queries, k: int, chunk_filter=None, rank_limit: int | None = None):
         """Exact top-k rows: (scores (B,k) desc, rows (B,k) int32); padding = (-inf, -1).

@@ -53,11 +53,10 @@ def decode_embedding(value: Any) -> np.ndarray:
 
 def chunk_text(headings: str, body: str, metadata: dict) -> str:
     """`str(chunk)` of the reference (`_database.py:300-324`): YAML-ish front matter from filename / url / uri, the
-    contextual headings, the body -- what `rerank_chunks` hands to a reranker (`_search.py:394-396`)."""
-    def first(v):
-        return v[0] if isinstance(v, list) and v else v
-
-    lines = "\n".join(f"{key}: {first(metadata.get(key))}" for key in ("filename", "url", "uri") if metadata.get(key))
+    contextual headings, the body -- what `rerank_chunks` hands to a reranker (`_search.py:394-396`).  Metadata values are
+    formatted as stored: the reference keeps every value as a list (`_database.py:51-55`), so a chunk of `a.md` reads
+    `filename: ['a.md']`, and `url: [None]` is a (truthy) line of its own."""
+    lines = "\n".join(f"{key}: {metadata.get(key)}" for key in ("filename", "url", "uri") if metadata.get(key))
     front = f"---\n{lines}\n---" if lines else ""
     return f"{front}\n\n{(headings or '').strip()}\n\n{(body or '').strip()}".strip()
 

@@ -257,6 +257,9 @@ struct rl_index {
     bool last_stream_set = false;
     float planes_scale = 0.f;             // the scale the image was built with; 0 = no image
     int64_t planes_rows = 0;              // rows the image covers
+    // What the last bound-filtered search on this handle left behind (rl_index_filter_stats): per-query candidate counters and the
+    // device flag its guarded full-precision fallback waits on.  Pointers into the scratch above, valid until the next call.
+    struct FilterRecord { int kind = 0; int32_t n = 0, cap = 0; const uint32_t* cnt = nullptr; const uint32_t* flag = nullptr; } filt;
 };
 
 namespace {
@@ -787,6 +790,25 @@ int rl_index_live(rl_index* idx, int64_t* live_rows, int64_t* live_chunks, void*
     return RL_OK;
 }
 
+int rl_index_filter_stats(rl_index* idx, int64_t out[6], void* stream) {
+    if (!idx || !out) return fail(RL_ERR_INVALID, "rl_index_filter_stats: null argument");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
+    for (int i = 0; i < 6; ++i) out[i] = 0;
+    const auto& f = idx->filt;
+    if (f.kind == RL_FILTER_NONE || f.n <= 0) return RL_OK;
+    RL_HIP(hipStreamSynchronize(s));
+    std::vector<uint32_t> cnt((size_t)f.n);
+    uint32_t flag = 0;
+    RL_HIP(hipMemcpy(cnt.data(), f.cnt, (size_t)f.n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    RL_HIP(hipMemcpy(&flag, f.flag, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    int64_t sum = 0, mx = 0;
+    for (uint32_t c : cnt) { sum += c; mx = std::max<int64_t>(mx, c); }
+    out[0] = f.kind; out[1] = f.n; out[2] = sum; out[3] = mx; out[4] = f.cap; out[5] = flag != 0;
+    return RL_OK;
+}
+
 int rl_index_compact(rl_index* idx, int64_t* out_remap, int64_t* new_n_rows, int64_t* new_n_chunks, void* stream) {
     if (!idx) return fail(RL_ERR_INVALID, "rl_index_compact: null index");
     hipStream_t s = as_stream(stream);
@@ -1159,6 +1181,7 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
     // ---- (2) full pass keeping what reaches the bound ---------------------------------------------------------------------------
     RL_HIP(hipMemsetAsync(cnt, 0, ((size_t)B + 1) * sizeof(uint32_t), s));  // list lengths + the overflow flag; the lists need no fill
     const CandArgs ca{top_s + (k - 1), k, c_s, c_i, cnt, flag, cap};
+    idx->filt = {RL_FILTER_ROWS_FUSED, B, cap, cnt, flag};
     RL_TRY(launch_score_planes_pass(idx->planes.p, n, idx->dim, B, qs, nullptr, 0, idx->norm, idx->sumsq, mode, 1, nullptr, &ca, idx->n_cu, s,
                                     img_scale, half));
     // ---- (3) exact ranking of every list ------------------------------------------------------------------------------------------
@@ -1235,6 +1258,7 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
     RL_TRY(launch_row_threshold(top_s, B, k, d_q, idx->dim, mode, hi_only ? q_unscale : nullptr, idx->max_lo_ratio, idx->max_lo_norm, idx->max_row_norm,
                                 thr, window, cnt, cnt2, flag, s));
     const CandArgs ca{thr, 1, c_s, c_i, cnt, flag, cap};
+    idx->filt = {RL_FILTER_ROWS_FUSED_HI, B, cap, cnt, flag};
     RL_TRY(launch_score_planes_pass(hi, n, idx->dim, B, qs, nullptr, 0, idx->norm, idx->sumsq, mode, 1, nullptr, &ca, idx->n_cu, s, sscale, true, hi_only));
     // ---- (3) the rows within the band of each list's k-th entry; (4) their exact similarities, ranked -----------------------------
     RL_TRY(launch_list_prefix(c_s, c_i, B, cap, k, cnt, window, cap2, r_i, cnt2, flag, s));
@@ -1315,6 +1339,7 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     }
     RL_TRY(launch_approx_threshold(ts, nb, k, d_q, dim, mode, m_rel, e_bound, thr, cnt, flag, s));
     RL_TRY(launch_collect_above(sc, nb, n, ld, thr, mode == SCAN_COSINE ? idx->norm : nullptr, cap, ci, gn, cnt, flag, s));
+    idx->filt = {RL_FILTER_ROWS_HI, nb, cap, cnt, flag};
     // ---- (3) exact scores of the candidates, by the kernels of the full pass (slots past a list's length hold stale row numbers:
     // gathered and scored, never ranked) ---------------------------------------------------------------------------------------------------------
     RL_TRY(launch_gather_rows(idx->E, false, dim, n, ci, nc, G, s));
@@ -1715,6 +1740,7 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
                     fprintf(stderr, "HIDEBUG n=%d k=%d flag=%u max_row_norm=%g cnt mean=%.1f max=%u  q0: best=%g kth=%g thr=%g\n", n_gemm, k, h_flag,
                             idx->max_row_norm, mean / n_gemm, mx, h_ts[0], h_ts[k - 1], h_thr[0]);
                 }
+                idx->filt = {RL_FILTER_MAXSIM_BATCH, n_gemm, cap, cnt, flag};
                 RL_TRY(launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, ci, cap, n_gemm, es, s));
                 RL_TRY(launch_merge_topk(es, ci, 1, n_gemm, cap, k, d_s, d_c, s, cnt));
                 for (int32_t b = 0; b < n_gemm; b += GEMM_PASS_QUERIES) {  // (4)

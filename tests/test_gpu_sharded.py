@@ -128,6 +128,47 @@ def test_bench_two_ranks_on_one_gpu():
     assert out["roofline"]["algorithmic_bytes_per_launch"] < 4.0 * 100000 * 1024  # a shard, not the whole corpus
 
 
+def test_bench_gpus_2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun (how the driver's scaling run may call it): bench.py re-executes itself as two
+    ranks through torch.distributed.run; n_gpus in the JSON line comes from the process group."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rows", "200000", "--same-gpu",
+           "--backend", "gloo"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0
+    assert out["roofline"]["algorithmic_bytes_per_launch"] < 4.0 * 200000 * 1024  # a shard, not the whole corpus
+
+
+def test_bench_gpus_n_refuses_a_box_with_fewer_gpus():
+    """`--gpus 8` on a one-GPU box is an error (non-zero exit), never a silent single-GPU run that prints n_gpus: 1."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    import torch
+
+    root = Path(__file__).resolve().parent.parent
+    want = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", str(want), "--steps", "1", "--warmup", "0"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0
+    assert "visible" in res.stderr and not any(ln.startswith("{") for ln in res.stdout.splitlines())
+
+
 def test_rccl_communicator_world_of_one():
     """The exchange step behind the C ABI (rl_comm_* / rl_allgather_topk / rl_allgather_merge_topk over librccl) on the one
     GPU a test box has: communicator init, the all-gather and the merge with a single rank.  (Two ranks cannot share a

@@ -619,3 +619,28 @@ def test_sharded_search_chunks_device_branch_on_cpu_tensors(monkeypatch):
     for b in range(len(Q)):
         cs, cc = oracle.search_chunks(E, r2c, Q[b], 30, 5, "dot")
         assert dev[2][b] == len(cc) and dev[1][b, : len(cc)].tolist() == cc.tolist()
+
+
+def test_bench_refuses_gpus_n_without_n_devices():
+    """bench.py --gpus N must become N ranks or fail: here (no GPU at all) `--gpus 2` exits non-zero before any work, and a
+    WORLD_SIZE that disagrees with --gpus is refused as well."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    try:
+        import torch
+
+        if torch.cuda.device_count() >= 2:
+            pytest.skip("needs a box with fewer than two GPUs")
+    except ImportError:
+        pytest.skip("no torch")
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "visible" in res.stderr
+    res = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"], cwd=root,
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=300)
+    assert res.returncode != 0 and "WORLD_SIZE=2" in res.stderr

@@ -219,3 +219,18 @@ def test_adapter_application_and_num_hits_match_reference_lines():
         assert got.dtype == want.dtype and np.array_equal(got, want)
     for oversample, chunk_max_size, num_results, want in g["num_hits_cases"].tolist():
         assert oracle.num_hits(num_results, oversample, chunk_max_size) == want
+
+
+def test_chunk_text_matches_the_reference_str_chunk(golden_dir):
+    """`str(chunk)` -- what `rerank_chunks` hands the reranker (`_search.py:394-396`) and what `MaxSimRanker.rank(docs=...)` maps
+    back to chunk ordinals -- against strings produced by the reference's own `Chunk.front_matter` / `.content`
+    (`_database.py:300-320`, oracle/make_golden_chunktext.py): list-valued metadata prints as a list, `url: [None]` is a line."""
+    import json
+
+    from raglite_amd._store import chunk_text
+
+    cases = json.loads((golden_dir / "chunk_text.json").read_text())
+    assert len(cases) >= 6
+    for case in cases:
+        assert chunk_text(case["headings"], case["body"], case["metadata"]) == case["text"]
+    assert "filename: ['a.md']\nurl: [None]" in cases[0]["text"]
