@@ -277,9 +277,12 @@ def main() -> None:
     streamed_bytes = algo_bytes
     kind, per_launch = 0, 1
     # (the approximate pass multiplies q_hi.e_hi only -- kind 6; A/B switch RAGLITE_HI_ONE_PRODUCT=0: two products -- kind 5)
-    hi_kind = 5 if os.environ.get("RAGLITE_HI_ONE_PRODUCT", "1") == "0" else 6
-    for cand_kind, cand_q in ((hi_kind, 8), (3, 8), (2, 2)):
-        if cand_kind == hi_kind and os.environ.get("RAGLITE_NO_HI_MAXSIM"):
+    # kind 7: SIXTEEN queries per pass through maxsim_pp.hip (the default); RAGLITE_NO_PP=1: the eight-query pass (kind 6)
+    one_product = os.environ.get("RAGLITE_HI_ONE_PRODUCT", "1") != "0"
+    no_pp = os.environ.get("RAGLITE_NO_PP", "0") not in ("", "0")
+    hi_kind = 5 if not one_product else (6 if no_pp else 7)
+    for cand_kind, cand_q in ((hi_kind, 16 if hi_kind == 7 else 8), (6, 8), (3, 8), (2, 2)):
+        if cand_kind in (5, 6, 7) and (os.environ.get("RAGLITE_NO_HI_MAXSIM") or (cand_kind == 6 and not one_product)):
             continue
         if arithmetic in ("f16_split", "f16_stored"):
             try:
@@ -288,7 +291,7 @@ def main() -> None:
                 break
             except Exception:  # noqa: BLE001 - that kernel does not apply to this index / shape
                 continue
-    if kind in (5, 6):
+    if kind in (5, 6, 7):
         streamed_bytes = 2.0 * rows_local * DIM  # the HI image: 2 B per element
     qv = queries[0, :per_launch].reshape(per_launch * NQ, DIM)
     index.time_kernel(kind, qv, 3)  # warm
@@ -301,31 +304,32 @@ def main() -> None:
     tf = ROOT / "profiles" / "traffic.json"  # from separate rocprofv3 --pmc FETCH_SIZE passes
     if tf.exists() and args.storage == "f32" and n_rows == N_ROWS and world == 1:
         tj = json.loads(tf.read_text())
-        traffic = tj.get({5: "maxsim_gemm_hi_bytes_per_launch", 6: "maxsim_gemm_hi_bytes_per_launch", 3: "maxsim_gemm_bytes_per_launch", 2: "maxsim_stream2_bytes_per_launch"}.get(kind, "maxsim_stream_bytes_per_launch"))
+        traffic = tj.get({5: "maxsim_gemm_hi_bytes_per_launch", 6: "maxsim_gemm_hi_bytes_per_launch", 7: "maxsim_pp_bytes_per_launch", 3: "maxsim_gemm_bytes_per_launch", 2: "maxsim_stream2_bytes_per_launch"}.get(kind, "maxsim_stream_bytes_per_launch"))
         traffic_source = "static: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 for the gfx950 half-count, separate run)"
-    kernel_name = {5: "rl::maxsim_gemm_kernel<2, false, 0, true>", 6: "rl::maxsim_gemm_kernel<2, false, 0, true>",
+    kernel_name = {5: "rl::maxsim_gemm_kernel<2, false, 0, true>", 6: "rl::maxsim_gemm_kernel<2, false, 0, true>", 7: "rl::maxsim_pp_kernel<0>",
                    3: "rl::maxsim_gemm_kernel<2, false, 0, true>" if arithmetic == "f16_stored" else "rl::maxsim_gemm_kernel<2, false, 0, false>",
                    2: "rl::maxsim_stream2_kernel<256, false, true>" if arithmetic == "f16_stored" else "rl::maxsim_stream2_kernel<256, false, false>",
                    0: {"fp32_exact": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, false>",
                        "f16_split": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, true>",
                        "f16_stored": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, true, false>"}[arithmetic]}[kind] + " (as rocprofv3 names it)"
-    if kind in (3, 5, 6):
+    if kind in (3, 5, 6, 7):
         # q_hi.e_hi + q_hi.e_lo + q_lo.e_hi: what the split arithmetic needs on the fp16 pipe; an fp16-stored corpus has no e_lo,
         # and the approximate pass over the HI image (kind 5) leaves the e_lo product to the exact re-scoring of its candidates
-        products = 1.0 if kind == 6 else 2.0 if (arithmetic == "f16_stored" or kind == 5) else 3.0
+        products = 1.0 if kind in (6, 7) else 2.0 if (arithmetic == "f16_stored" or kind == 5) else 3.0
         mfma_flops = products * fp32_equiv_flops
         achieved = mfma_flops / (ms * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TF, "unit": "TFLOP/s",
                               "frac": achieved / MFMA_F16_PEAK_TF, "traffic": traffic,
                               "algorithmic_flops_per_launch": mfma_flops,
-                              "flops_note": f"{products:.0f} fp16 MFMA products per fp32-equivalent multiply-add (SURVEY.md 8d: 2*32*N*d per query), 8 queries per launch"
-                                            + ("; approximate pass over the HI image, its candidates re-scored exactly by maxsim_pairs_kernel inside the timed step" if kind in (5, 6) else ""),
+                              "flops_note": f"{products:.0f} fp16 MFMA products per fp32-equivalent multiply-add (SURVEY.md 8d: 2*32*N*d per query), {per_launch} queries per launch"
+                                            + ("; approximate pass over the HI image, its candidates re-scored exactly by maxsim_pairs_kernel inside the timed step" if kind in (5, 6, 7) else ""),
                               "hbm": hbm}
     else:
         result["roofline"] = {"bound": "hbm", **hbm, "traffic": traffic}
-    if kind in (5, 6):  # for reference: the full-precision pass the approximate one replaces (and falls back to)
-        index.time_kernel(3, qv, 2)
-        result["roofline"]["full_precision_pass_ms"] = index.time_kernel(3, qv, iters) / iters
+    if kind in (5, 6, 7):  # for reference: the full-precision pass (eight queries) the approximate one replaces (and falls back to)
+        qv8 = queries[0, :8].reshape(8 * NQ, DIM)
+        index.time_kernel(3, qv8, 2)
+        result["roofline"]["full_precision_pass_ms"] = index.time_kernel(3, qv8, iters) / iters
     result["roofline"].update({
         "kernel": kernel_name, "arithmetic": arithmetic, "queries_per_launch": per_launch, "kernel_ms": ms,
         "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes,

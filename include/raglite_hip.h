@@ -211,6 +211,17 @@ int rl_maxsim_scores(rl_index* index, const float* query_vecs, int32_t nq, float
 int rl_maxsim_topk_batch(rl_index* index, const float* query_vecs, int32_t n_queries, int32_t nq, int32_t k,
                          float* out_scores, int32_t* out_chunks, int mem, void* stream);
 
+/* rl_maxsim_approx_scores: the FIRST stage of rl_maxsim_topk_batch's bound-filtered pipeline on its own, for tests and for
+ * callers that want the bound: the approximate MaxSim score of every (query, chunk) from the hi halves of corpus and queries
+ * (one fp16 MFMA product per multiply; `kernel` = 0: the sixteen-queries-per-pass kernel of maxsim_pp.hip, 1: the
+ * eight-queries-per-pass kernel of maxsim_gemm.hip -- the same sums in the same order), and per query the rigorous bound
+ * m with |approximate - exact| <= m for EVERY chunk that rl_maxsim_topk_batch's candidate window (2 m) is built on.
+ *   query_vecs [n_queries x nq x dim] f32, nq <= 32;  out_scores [n_queries x n_chunks] f32 (tombstoned chunks included: no mask),
+ *   out_bound [n_queries] f32 or NULL.  RL_ERR_UNSUPPORTED when the index keeps no HI image (small / fp16-stored / exact-fp32
+ *   indexes, indexes with empty chunks). */
+int rl_maxsim_approx_scores(rl_index* index, const float* query_vecs, int32_t n_queries, int32_t nq, int kernel,
+                            float* out_scores, float* out_bound, int mem, void* stream);
+
 /* rl_maxsim_rerank: the rerank shape (SURVEY.md cfg 3).  `n_queries` independent queries in one
  * launch, each with its own nq query vectors and its own list of n_cand candidate chunk ordinals.
  *   query_vecs [n_queries x nq x dim] f32, candidates [n_queries x n_cand] int32
@@ -329,7 +340,9 @@ int rl_index_filter_stats(rl_index* index, int64_t out[6], void* stream);
  * eight-queries-per-pass kernel over the pre-split corpus image (eight queries of nq / 8 vectors each), 4 = the
  * ranking pass of the half-bytes search of rl_search_rows (nq <= 16 queries over the fp16 HI plane;
  * RL_ERR_UNSUPPORTED when the index has none), 5 = the approximate eight-query MaxSim pass over the HI image
- * (as kind 3) with two MFMA products per multiply, 6 = the same pass with one (what rl_maxsim_topk_batch runs by default).
+ * (as kind 3) with two MFMA products per multiply, 6 = the same pass with one,
+ * 7 = the SIXTEEN-queries-per-pass kernel over the HI image, one product (maxsim_pp.hip: what rl_maxsim_topk_batch runs by default;
+ * sixteen queries of nq / 16 vectors each).
  * Used so that roofline.achieved is measured with HIP
  * events on the stream the kernel runs on. */
 int rl_time_kernel(rl_index* index, int kind, const float* query_vecs_dev, int32_t nq, int32_t iters,

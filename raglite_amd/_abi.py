@@ -68,6 +68,7 @@ _SIGNATURES = {
     "rl_maxsim_topk": [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_int, c_void_p],
     "rl_maxsim_scores": [c_void_p, c_void_p, c_i32, c_void_p, c_int, c_void_p],
     "rl_maxsim_topk_batch": [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_int, c_void_p],
+    "rl_maxsim_approx_scores": [c_void_p, c_void_p, c_i32, c_i32, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "rl_maxsim_rerank": [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_i32, c_void_p, c_int, c_void_p],
     "rl_merge_topk": [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_int, c_void_p],
     "rl_topk": [c_void_p, c_i32, c_i64, c_i64, c_i32, c_void_p, c_void_p, c_int, c_void_p],

@@ -19,7 +19,7 @@ INCLUDE = PKG.parent / "include"
 LIB_DIR = PKG / "_lib"
 LIB_PATH = LIB_DIR / "libraglite_hip.so"
 SOURCES = ["api.hip", "synth.hip", "pool_norm.hip", "scan.hip", "select.hip", "maxsim_stream.hip", "maxsim_generic.hip",
-           "maxsim_gemm.hip", "score_gemm.hip", "mask.hip", "scan16.hip", "adapter_fit.hip", "partition_sim.hip", "comm.hip", "hi_filter.hip"]
+           "maxsim_gemm.hip", "maxsim_pp.hip", "score_gemm.hip", "mask.hip", "scan16.hip", "adapter_fit.hip", "partition_sim.hip", "comm.hip", "hi_filter.hip"]
 # No -ffast-math: parity relies on IEEE fp32 divide / sqrt and on un-fused, un-reassociated sums.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          f"-I{INCLUDE}", f"-I{CSRC}"]

@@ -436,6 +436,22 @@ class DeviceIndex:
         check(lib().rl_maxsim_topk_batch(self._handle, p_q, n_queries, nq, k, p_s, p_c, a.mem, a.stream))
         return o_s, o_c
 
+    def maxsim_approx_scores(self, query_batch, kernel: int = 0):
+        """The first stage of `maxsim_topk_batch`'s bound-filtered pipeline alone (`rl_maxsim_approx_scores`): approximate scores
+        (n_queries, n_chunks) from the hi halves of corpus and queries, and per query the rigorous bound m with
+        |approximate - exact| <= m for every chunk.  kernel 0: sixteen queries per pass (maxsim_pp.hip), 1: eight (maxsim_gemm.hip)."""
+        a = _Args()
+        p_q = a.inp(query_batch, np.float32)
+        qv = a.keep[-1]
+        if qv.ndim != 3 or int(qv.shape[2]) != self.dim:
+            raise ValueError("query_batch must be (n_queries, nq, dim)")
+        n_queries, nq = int(qv.shape[0]), int(qv.shape[1])
+        o_s, p_s = a.out((n_queries, self.n_chunks), np.float32)
+        o_b, p_b = a.out((n_queries,), np.float32)
+        self._prep(a)
+        check(lib().rl_maxsim_approx_scores(self._handle, p_q, n_queries, nq, int(kernel), p_s, p_b, a.mem, a.stream))
+        return o_s, o_b
+
     def maxsim_rerank(self, query_vecs, candidates):
         """query_vecs (n_queries, nq, dim), candidates (n_queries, n_cand) int32 -> scores (n_queries, n_cand)."""
         a = _Args()

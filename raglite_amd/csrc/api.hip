@@ -1711,7 +1711,16 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
                 float* es = reinterpret_cast<float*>(ci + (size_t)n_gemm * cap); // [n x cap] their exact scores
                 RL_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), s));
                 RL_HIP(hipMemsetAsync(ci, 0xff, (size_t)n_gemm * cap * sizeof(int32_t), s));  // unused slots: -1 = "no chunk"
-                for (int32_t b = 0; b < n_gemm; b += GEMM_PASS_QUERIES) {
+                // One product: SIXTEEN queries per pass through maxsim_pp.hip (dim >= 256; RAGLITE_NO_PP=1, read per call: the
+                // eight-query pass of maxsim_gemm.hip instead -- A/B, and what two products still use).
+                const char* nopp_env = std::getenv("RAGLITE_NO_PP");
+                const bool pp = one_product && idx->dim >= 256 && !(nopp_env && nopp_env[0] && nopp_env[0] != '0');
+                for (int32_t b = 0; pp && b < n_gemm; b += PP_PASS_QUERIES) {
+                    const int32_t n_q = std::min<int32_t>(PP_PASS_QUERIES, n_gemm - b);
+                    RL_TRY(launch_maxsim_pp(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
+                                            idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale));
+                }
+                for (int32_t b = 0; !pp && b < n_gemm; b += GEMM_PASS_QUERIES) {
                     const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_gemm - b);
                     RL_TRY(launch_maxsim_gemm(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
                                               idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale, true,
@@ -1785,6 +1794,56 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
     if (idx->live_chunk_bits) RL_TRY(launch_fix_masked(d_s, d_c, (int64_t)n_queries * k, s));
     RL_TRY(stage_out_end(out_scores, (size_t)n_queries * k, mem, s, t_s));
     RL_TRY(stage_out_end(out_chunks, (size_t)n_queries * k, mem, s, t_c));
+    return finish(mem, s);
+}
+
+int rl_maxsim_approx_scores(rl_index* idx, const float* query_vecs, int32_t n_queries, int32_t nq, int kernel, float* out_scores,
+                            float* out_bound, int mem, void* stream) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_maxsim_approx_scores: null index");
+    if (n_queries < 0 || nq < 1 || (kernel != 0 && kernel != 1)) return fail(RL_ERR_INVALID, "rl_maxsim_approx_scores: bad arguments");
+    if (n_queries == 0) return RL_OK;
+    if (!query_vecs || !out_scores) return fail(RL_ERR_INVALID, "rl_maxsim_approx_scores: null argument");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
+    if (!hi_image_valid(idx) || nq > 32 || (kernel == 0 && idx->dim < 256))
+        return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_approx_scores: this index keeps no HI image (or nq > 32 / dim < 256)");
+    DevBuf t_q, t_o, t_b;
+    const float* d_q; float* d_o; float* d_b = nullptr;
+    const size_t q_elems = (size_t)nq * idx->dim;
+    const int64_t ld = idx->n_chunks;
+    RL_TRY(stage_in(query_vecs, (size_t)n_queries * q_elems, mem, s, t_q, &d_q));
+    RL_TRY(stage_out_begin(out_scores, (size_t)n_queries * ld, mem, t_o, &d_o));
+    if (out_bound) RL_TRY(stage_out_begin(out_bound, (size_t)n_queries, mem, t_b, &d_b));
+    RL_TRY(idx->qplanes.reserve(query_planes_bytes(idx->dim, n_queries)));
+    RL_TRY(launch_query_planes(d_q, idx->dim, nq, (int64_t)q_elems, n_queries, idx->qplanes.p, s));
+    const int32_t per = kernel == 0 ? PP_PASS_QUERIES : GEMM_PASS_QUERIES;
+    for (int32_t b = 0; b < n_queries; b += per) {
+        const int32_t n_q = std::min<int32_t>(per, n_queries - b);
+        if (kernel == 0)
+            RL_TRY(launch_maxsim_pp(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk, idx->offsets,
+                                    idx->ends.as<uint32_t>(), d_o + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale));
+        else
+            RL_TRY(launch_maxsim_gemm(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk, idx->offsets,
+                                      idx->ends.as<uint32_t>(), d_o + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale, true, nullptr, true));
+    }
+    if (d_b) {  // the bound of the one-product pass, by the kernel the pipeline computes its thresholds with (k = 1 over a dummy top list)
+        const float m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
+        const float* q_unscale = reinterpret_cast<const float*>(idx->qplanes.as<char>() + (size_t)n_queries * idx->dim * 128);
+        RL_TRY(idx->hibuf.reserve((size_t)n_queries * 4 * sizeof(float) + 64));
+        float* top = idx->hibuf.as<float>();                                     // [n] "k-th best" = 0
+        float* thr = top + n_queries;                                            // [n] 0 - 2 m
+        uint32_t* cnt = reinterpret_cast<uint32_t*>(thr + n_queries);            // [n]
+        uint32_t* flag = cnt + n_queries;
+        RL_HIP(hipMemsetAsync(top, 0, (size_t)n_queries * sizeof(float), s));
+        RL_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), s));
+        RL_TRY(launch_maxsim_threshold(top, n_queries, 1, d_q, nq, idx->dim, (int64_t)q_elems, 1.0f, m_abs, thr, cnt, flag, s, q_unscale,
+                                       idx->max_row_norm + idx->max_lo_norm));
+        RL_TRY(launch_scale_f32(thr, d_b, -0.5f, n_queries, s));                // thr = -2 m  ->  m
+        idx->filt = {};
+    }
+    RL_TRY(stage_out_end(out_scores, (size_t)n_queries * ld, mem, s, t_o));
+    if (out_bound) RL_TRY(stage_out_end(out_bound, (size_t)n_queries, mem, s, t_b));
     return finish(mem, s);
 }
 
@@ -1949,6 +2008,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     if (kind == 0) RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));
     else if (kind == 2) RL_TRY(idx->scores.reserve((size_t)2 * ldc * sizeof(float)));
     else if (kind == 3 || kind == 5 || kind == 6) RL_TRY(idx->scores.reserve((size_t)GEMM_PASS_QUERIES * ldc * sizeof(float)));
+    else if (kind == 7) RL_TRY(idx->scores.reserve((size_t)PP_PASS_QUERIES * ldc * sizeof(float)));
     else RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)nq * ld * sizeof(float), 16)));
     hipEvent_t e0, e1;
     RL_HIP(hipEventCreate(&e0));
@@ -1962,9 +2022,17 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
         st = gemm_prepare(idx, q_dev, nq / GEMM_PASS_QUERIES, (int64_t)(nq / GEMM_PASS_QUERIES) * idx->dim, GEMM_PASS_QUERIES, s);
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the eight-query kernel does not apply to this index / shape") : st; }
     }
+    if (kind == 7) {  // sixteen queries of nq / 16 vectors each
+        st = gemm_prepare(idx, q_dev, nq / PP_PASS_QUERIES, (int64_t)(nq / PP_PASS_QUERIES) * idx->dim, PP_PASS_QUERIES, s);
+        if (st == RL_OK && !(hi_image_valid(idx) && idx->dim >= 256)) st = RL_ERR_UNSUPPORTED;
+        if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the sixteen-query kernel does not apply to this index / shape") : st; }
+    }
     RL_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < iters && st == RL_OK; ++i) {
-        if (kind == 3) st = gemm_pass(idx, nq / GEMM_PASS_QUERIES, GEMM_PASS_QUERIES, 0, GEMM_PASS_QUERIES, idx->scores.as<float>(), ldc, s);
+        if (kind == 7) st = launch_maxsim_pp(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, PP_PASS_QUERIES, 0, PP_PASS_QUERIES,
+                                             nq / PP_PASS_QUERIES, idx->row_to_chunk, idx->offsets, idx->ends.as<uint32_t>(), idx->scores.as<float>(), ldc,
+                                             idx->n_cu, s, idx->split_scale);
+        else if (kind == 3) st = gemm_pass(idx, nq / GEMM_PASS_QUERIES, GEMM_PASS_QUERIES, 0, GEMM_PASS_QUERIES, idx->scores.as<float>(), ldc, s);
         else if (kind == 0) st = maxsim_scores_device(idx, q_dev, nq, idx->scores.as<float>(), s);
         else if (kind == 2) st = pairs_pass(idx, nq / 2, 2, 0, idx->scores.as<float>(), ldc, s);
         else if (kind == 5 || kind == 6) {  // the approximate MaxSim pass of a batch: eight queries over the HI image (5: two MFMA products, 6: one)

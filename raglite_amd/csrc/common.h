@@ -118,6 +118,7 @@ int launch_cast_f16(const float* src, uint16_t* dst, int64_t count, hipStream_t 
 // dst = fp16(src * scale) rounded TOWARD ZERO (the hi half of the fp16 split); count % 8 == 0, 16-byte aligned pointers
 int launch_cast_f16_rtz(const float* src, uint16_t* dst, int64_t count, float scale, hipStream_t s, bool rne = false);
 int launch_fill_f32(float* dst, float value, int64_t count, hipStream_t s);
+int launch_scale_f32(const float* src, float* dst, float factor, int64_t count, hipStream_t s);  // hi_filter.hip: dst = src * factor
 // in-place metric transform of raw dots: scores[b*ld+i] (i<n), per-row norm / sumsq, per-query norm.
 // (pre_scale: the raw dots are multiplied by it first -- a power of two, exact; run_if as in launch_topk)
 int launch_transform(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm,
@@ -241,6 +242,11 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
                        int32_t n_q, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits,
                        float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale, bool half = false,
                        const uint32_t* run_if = nullptr, bool hi_only = false);
+// maxsim_pp.hip: the approximate pass of the headline pipeline -- SIXTEEN queries per pass over a one-plane image, one product
+constexpr int32_t PP_PASS_QUERIES = 16;
+int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first, int32_t n_q,
+                     int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits, float* out,
+                     int64_t out_stride, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if = nullptr);
 size_t score_planes_scratch_floats(int32_t nb, int32_t dim);
 int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores, int64_t ld,
                         const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale,

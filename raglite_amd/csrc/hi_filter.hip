@@ -270,6 +270,18 @@ int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld,
     return RL_OK;
 }
 
+__global__ __launch_bounds__(256) void scale_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, float factor, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dst[i] = src[i] * factor;
+}
+
+int launch_scale_f32(const float* src, float* dst, float factor, int64_t count, hipStream_t s) {
+    if (count <= 0) return RL_OK;
+    hipLaunchKernelGGL(scale_f32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src, dst, factor, count);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, const float* Q, int32_t nq, int32_t dim, int64_t q_stride,
                             float m_rel, float e_max, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* q_unscale,
                             float e_norm_max) {

@@ -1,0 +1,399 @@
+// a9 at batch scale, the approximate pass of the headline pipeline (api.hip: rl_maxsim_topk_batch): MaxSim of SIXTEEN queries
+// (up to 32 vectors each) per corpus pass over the HI image -- the fp16 hi halves of the corpus in the one-plane image layout of
+// maxsim_gemm.hip (preformat / presplit_hi_rows_kernel) -- at ONE fp16 MFMA product per multiply (q_hi . e_hi):
+//
+//   out[q * out_stride + c] ~ sum_{i < nq} max_{j in chunk c} Q_q[i] . D[j]      q = 0 .. n_q - 1  (n_q <= 16)
+//
+// Multi-query generalisation of src/raglite/_search.py:143-149 / src/raglite/_query_adapter.py:174 behind the reranker plugin
+// call src/raglite/_search.py:394-396; what it drops (the corpus' and the queries' lo halves) is bounded rigorously by the caller,
+// which re-scores every chunk the bound cannot rule out with exact fp32 products (maxsim_pairs_kernel).
+//
+// Why a new kernel next to maxsim_gemm_kernel<.., HALF>.  Measured in round 3 (profiles/r03_a_*): that kernel's one-product pass
+// takes 0.71 ms per eight queries where its 32 MFMAs per wave and slab are 0.26 ms of matrix pipe; a six-slot ring with the query
+// fragments three slabs ahead (its HO variant) gets 0.65 -- the corpus stream was not what it waited for.  A wave there reads its
+// corpus fragments from LDS ONE pair of blocks ahead: with three products a pair covers 12 MFMAs (~400 cycles for the two waves of
+// a SIMD), with one product 4 (~130), less than an LDS round trip under load -- the matrix pipe idles on lgkmcnt in every pair of
+// every slab.  And at eight queries per pass the pass needs 2 GB / 0.3 ms = 6.7 TB/s of HBM once the matrix pipe is fed.  So:
+//   * tile = 128 corpus rows x 512 query vectors (16 queries), K slabs of 32; wave w owns queries 2w and 2w + 1: the same 128
+//     accumulator registers (2 queries x 2 blocks of 16 vectors x 8 blocks of 16 rows), half the corpus bytes per query -- HBM
+//     3.3 TB/s at full matrix rate -- and 12 fragment reads per 32 MFMAs instead of 18;
+//   * EVERY operand goes through LDS by `global_load_lds_dwordx4`: corpus slabs (8 KiB, `nt`) in a ring of 6, query slabs (the 16
+//     queries' hi fragments, 32 KiB, L2-resident) in a ring of 3 -- no VMEM result is ever waited for in registers, so no wait
+//     drains the look-ahead (VMEM retires in order).  Waves 0 and 4 feed the corpus ring and nothing else: their `s_waitcnt vmcnt`
+//     leaves four slabs (32 KiB per CU) of HBM reads in flight; the other six feed the query ring (5, 5, 6 pieces per slab);
+//   * a wave's fragments of slab g + 1 are read from LDS WHILE it multiplies slab g from registers -- each corpus fragment
+//     register is re-loaded right after its four MFMAs, the query fragments alternate between two register sets -- i.e. a full
+//     slab (32 MFMAs, >= 512 cycles) ahead: the MFMA stream never waits for LDS;
+//   * ONE workgroup barrier per slab: the barrier at the top of slab g certifies slab g + 1 as landed (every feeder waited for
+//     its pieces) and slab g's LDS slot as free (everybody read it during slab g - 1);
+//   * tile epilogue as in maxsim_gemm_kernel (DPP segmented max-scan along the 16 rows of a block, sum over the 32 query vectors,
+//     store by the chunk's end row's lane), once per query of the wave.  Its stores share the in-order VMEM counter with the
+//     DMAs: the feeders count them (wave-uniform) and widen their next waits by exactly that many.
+// Deterministic (fixed MFMA order per (query vector, row), fixed scan / sum order; independent of the grid); integer-valued
+// data is exact.  Needs an index without empty chunks (a chunk is found by counting chunk ends), nq <= 32, dim % 32 == 0.
+#include <cstdio>
+#include <cstdlib>
+#include <utility>
+
+#include "common.h"
+
+namespace rl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+constexpr int PP_RT = 128;                       // corpus rows per tile
+constexpr int PP_NBLK = PP_RT / 16;              // 16-row blocks per tile
+constexpr int PP_QPP = 16;                       // queries per pass
+constexpr int PP_WAVES = 8;
+constexpr int PP_DC = 6, PP_DQ = 3;              // ring depths: corpus slabs, query slabs
+constexpr int PP_CSLOT = PP_NBLK * 1024;         // corpus slab: 8 blocks x 1 KiB
+constexpr int PP_QSLOT = PP_QPP * 2 * 1024;      // query slab: 16 queries x 2 blocks of 16 vectors x 1 KiB
+constexpr int PP_QOFF = PP_DC * PP_CSLOT;
+constexpr int PP_LDS = PP_QOFF + PP_DQ * PP_QSLOT;  // 147 456 B
+
+__device__ __forceinline__ int64_t pp_uniform_i64(int64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+// One 1-KiB piece HBM / L2 -> LDS: lane i copies 16 B from src + 16 i to lds + 16 i.  Invisible to the compiler's vmcnt
+// bookkeeping (asynchronous; certified by the explicit waits below).  NT: streamed once (corpus); plain: re-read by every
+// workgroup from L2 (queries).
+template <bool NT>
+__device__ __forceinline__ void pp_dma(uint32_t lds, const char* src, uint32_t lane16) {
+    const uint32_t l = __builtin_amdgcn_readfirstlane(lds);
+    const char* const p = reinterpret_cast<const char*>(pp_uniform_i64(reinterpret_cast<int64_t>(src)));
+    if constexpr (NT) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(l), "v"(lane16), "s"(p) : "memory", "m0");
+    else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(lane16), "s"(p) : "memory", "m0");
+}
+
+// s_waitcnt vmcnt(BASE + extra), extra = 0 .. 16 wave-uniform (the immediate cannot come from a register)
+template <int BASE>
+__device__ __forceinline__ void pp_wait_vm(int extra) {
+    if (extra == 0) {  // every slab but the few after a tile's epilogue
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
+        return;
+    }
+#define PP_CASE(I) case I: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + I) : "memory"); break;
+    switch (extra) {
+        PP_CASE(1) PP_CASE(2) PP_CASE(3) PP_CASE(4) PP_CASE(5) PP_CASE(6) PP_CASE(7) PP_CASE(8)
+        PP_CASE(9) PP_CASE(10) PP_CASE(11) PP_CASE(12) PP_CASE(13) PP_CASE(14) PP_CASE(15) PP_CASE(16)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // (never: at most 16 stores per tile and wave)
+    }
+#undef PP_CASE
+}
+}  // namespace
+
+#define PP_MAX_DPP(dst, src, x, CTRLSTR) asm volatile("v_max_f32_dpp %0, %1, %2 " CTRLSTR " row_mask:0xf bank_mask:0xf" : "=&v"(dst) : "v"(src), "v"(x))
+#define PP_SELECT(x, t, mask) asm volatile("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(x) : "v"(x), "v"(t), "s"(mask))
+
+// One LDS fragment read (64 lanes x 16 B) into 4 VGPRs, invisible to the compiler's lgkmcnt bookkeeping -- its own waits would sit in
+// front of every MFMA group (the loop body is not one basic block, and the pass gives up at the joins): the value is valid after the
+// `s_waitcnt lgkmcnt(0)` at the end of the slab + pp_pin().
+template <int OFF>
+__device__ __forceinline__ void pp_read(f32x4& dst, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void pp_pin(f32x4& a, f32x4& b, f32x4& c, f32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+__device__ __forceinline__ h16x8 pp_h(const f32x4& v) {
+    h16x8 r;
+    __builtin_memcpy(&r, &v, 16);
+    return r;
+}
+
+// DBG (timing experiments only, RAGLITE_PP_DBG; wrong results): 1 = no scan steps in the epilogue, 2 = no MFMAs, 8 = no LDS fragment reads
+template <int DBG>
+__global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restrict__ planes, int64_t n_rows, int32_t nslab,
+                                                           const char* __restrict__ qfrag, const float* __restrict__ qmeta, int32_t n_q,
+                                                           const int32_t* __restrict__ row_to_chunk, const int64_t* __restrict__ chunk_offsets,
+                                                           const uint32_t* __restrict__ ends_bits, float* __restrict__ out, int64_t out_stride,
+                                                           float inv_e_scale, const uint32_t* __restrict__ run_if) {
+    __shared__ __attribute__((aligned(16))) char smem[PP_LDS];
+    if (run_if && __builtin_amdgcn_readfirstlane((int)*run_if) == 0) return;  // whole grid: a guarded launch that is not needed
+    const int lane = threadIdx.x & 63;
+    const int wv = wave_id();
+    const int64_t G = gridDim.x, b = blockIdx.x;
+    // Chunk-aligned row range of this workgroup (as in maxsim_gemm.hip): first chunk boundary at or after n_rows * b / G.
+    auto boundary = [&](int64_t t) -> int64_t {
+        if (t <= 0) return 0;
+        if (t >= n_rows) return n_rows;
+        const int32_t c = row_to_chunk[t];
+        const int64_t c0 = chunk_offsets[c], c1 = chunk_offsets[c + 1];
+        return c0 == t ? t : c1;
+    };
+    const int32_t r_lo = (int32_t)pp_uniform_i64(boundary((n_rows * b) / G));
+    const int32_t r_hi = (int32_t)pp_uniform_i64((b + 1 == G) ? n_rows : boundary((n_rows * (b + 1)) / G));
+    if (r_hi <= r_lo) return;  // whole workgroup
+    const int32_t org = r_lo & ~15;  // tiles start on a 16-row block of the image
+    const int nt = (r_hi - org + PP_RT - 1) / PP_RT;
+    const int total = nt * nslab;  // K slabs this workgroup consumes, tile after tile
+    const int32_t last_blk = (int32_t)((n_rows + 15) >> 4) - 1;
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
+    const uint32_t lane16 = 16u * lane;
+    const int fj = lane & 15;
+
+    // ---- this wave's queries ------------------------------------------------------------------------------------------------
+    const bool has0 = 2 * wv < n_q, has1 = 2 * wv + 1 < n_q;  // wave-uniform
+    const float unscale0 = has0 ? qmeta[2 * (2 * wv)] * inv_e_scale : 0.f, unscale1 = has1 ? qmeta[2 * (2 * wv + 1)] * inv_e_scale : 0.f;
+    float* const out0 = out + (int64_t)(has0 ? 2 * wv : 0) * out_stride;
+    float* const out1 = out + (int64_t)(has1 ? 2 * wv + 1 : 0) * out_stride;
+
+    // ---- feeder duty -----------------------------------------------------------------------------------------------------------
+    // waves 0, 4: corpus blocks 4 (wv >> 2) .. + 3 of every slab, DC slabs ahead; waves 1-3, 5-7: query pieces
+    // 16 (wv >> 2) + j0 .. + np - 1 of every slab (piece p = 2 * query + block of 16 vectors), DQ slabs ahead.
+    const bool cfeed = (wv & 3) == 0;
+    const int grp = wv >> 2, wi = wv & 3;
+    const int j0 = cfeed ? 0 : (wi - 1) * 5, np = cfeed ? 4 : (wi == 3 ? 6 : 5);
+    const char* fbase[6];  // piece bases at slab 0 (corpus: of the tile being fetched)
+    int f_tile = 0, f_s = 0, f_slot = 0;  // position of the NEXT slab this wave fetches
+    auto feed_tile = [&](int t) __attribute__((always_inline)) {
+        const int32_t b0 = ((org + t * PP_RT) >> 4) + 4 * grp;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int32_t blk = b0 + i;
+            blk = blk < last_blk ? blk : last_blk;  // past the image: harmless re-read of the last block, never emitted
+            fbase[i] = planes + pp_uniform_i64((int64_t)blk * nslab * 1024);
+        }
+    };
+    if (cfeed) {
+        feed_tile(0);
+        fbase[4] = fbase[5] = fbase[0];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int p = 16 * grp + j0 + (i < np ? i : 0);
+            int ql = p >> 1;
+            ql = ql < n_q ? ql : n_q - 1;  // (clamped: pieces of queries the pass does not have are copied from a valid one, never used)
+            fbase[i] = qfrag + pp_uniform_i64(((int64_t)ql * nslab * 4 + 2 * (p & 1)) * 1024);  // hi fragments of block p & 1
+        }
+    }
+    auto issue_slab = [&]() __attribute__((always_inline)) {
+        if (cfeed) {
+            const uint32_t l = lds_base + (uint32_t)(f_slot * PP_CSLOT + 4 * grp * 1024);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pp_dma<true>(l + i * 1024, fbase[i] + (int64_t)f_s * 1024, lane16);
+            if (++f_s == nslab) {  // past the end: re-fetch the last tile (keeps the vmcnt bookkeeping uniform)
+                f_s = 0;
+                if (f_tile + 1 < nt) { ++f_tile; feed_tile(f_tile); }
+            }
+            f_slot = f_slot + 1 == PP_DC ? 0 : f_slot + 1;
+        } else {
+            const uint32_t l = lds_base + (uint32_t)(PP_QOFF + f_slot * PP_QSLOT + (16 * grp + j0) * 1024);
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (i < np) pp_dma<false>(l + i * 1024, fbase[i] + (int64_t)f_s * 4096, lane16);
+            if (++f_s == nslab) f_s = 0;
+            f_slot = f_slot + 1 == PP_DQ ? 0 : f_slot + 1;
+        }
+    };
+    // Wait until this wave's pieces of every slab but the newest `keep` have landed (+ `extra` newer stores).
+    int st_pending = 0, st_slabs = 0;  // epilogue stores newer than DMAs this wave still has to certify: how many, for how many more slabs
+    auto certify = [&]() __attribute__((always_inline)) {
+        const int extra = st_slabs > 0 ? st_pending : 0;
+        if (cfeed) pp_wait_vm<(PP_DC - 2) * 4>(extra);
+        else if (np == 6) pp_wait_vm<(PP_DQ - 2) * 6>(extra);
+        else pp_wait_vm<(PP_DQ - 2) * 5>(extra);
+        if (st_slabs > 0) --st_slabs;
+    };
+
+    // ---- accumulators: S^T[query vector 16 qb + 4 g + u][corpus row 16 a + j], lane = 16 g + j; [query of the wave][qb][a] ------
+    f32x4 acc[2][2][PP_NBLK];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+            for (int a = 0; a < PP_NBLK; ++a) acc[q][qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float carry[2][8];  // scanned maxima of the previous block (lane 15 of each DPP row = the chunk still open)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) carry[q][r] = -INFINITY;
+    uint32_t prev_last_end = 1;  // is the row before the tile's first row the last row of its chunk?
+
+    // ---- fragment registers ---------------------------------------------------------------------------------------------------
+    f32x4 ef[PP_NBLK];      // corpus blocks of the slab being multiplied (each re-loaded for the next slab right after its MFMAs)
+    f32x4 qA[4], qB[4];     // query fragments [2 * query of the wave + qb], two sets alternating over slabs
+    int c_slot = 0, q_slot = 0;  // ring slots of the slab whose fragments are READ next
+    const uint32_t rd_c = lds_base + lane16, rd_q = lds_base + (uint32_t)(PP_QOFF + 4 * wv * 1024) + lane16;
+    auto read_slab = [&](f32x4 (&qn)[4], auto A_) __attribute__((always_inline)) {  // reads of step a: corpus block a (+ query fragment a)
+        constexpr int a = decltype(A_)::value;
+        if constexpr (!(DBG & 8)) {
+            pp_read<a * 1024>(ef[a], rd_c + (uint32_t)(c_slot * PP_CSLOT));
+            if constexpr (a < 4) pp_read<a * 1024>(qn[a], rd_q + (uint32_t)(q_slot * PP_QSLOT));
+        }
+    };
+
+    // ---- one K slab: MFMAs of slab g from registers, fragment reads of slab g + 1, this wave's DMAs of slab g + D --------------
+    // No branch in here: every wave multiplies (one without queries multiplies what the clamped query pieces hold and never
+    // stores), so the body is one basic block and carries no wait at all.
+    auto slab = [&](f32x4 (&q)[4], f32x4 (&qn)[4]) __attribute__((always_inline)) {
+        [&]<int... A>(std::integer_sequence<int, A...>) {
+            (([&] {
+                 if constexpr (!(DBG & 2)) {
+                     acc[0][0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(q[0]), pp_h(ef[A]), acc[0][0][A], 0, 0, 0);
+                     acc[0][1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(q[1]), pp_h(ef[A]), acc[0][1][A], 0, 0, 0);
+                     acc[1][0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(q[2]), pp_h(ef[A]), acc[1][0][A], 0, 0, 0);
+                     acc[1][1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(q[3]), pp_h(ef[A]), acc[1][1][A], 0, 0, 0);
+                 }
+                 read_slab(qn, std::integral_constant<int, A>{});
+                 __builtin_amdgcn_sched_barrier(0);
+             }()),
+             ...);
+        }(std::make_integer_sequence<int, PP_NBLK>{});
+        issue_slab();
+        c_slot = c_slot + 1 == PP_DC ? 0 : c_slot + 1;
+        q_slot = q_slot + 1 == PP_DQ ? 0 : q_slot + 1;
+    };
+    auto landed = [&](f32x4 (&qn)[4]) __attribute__((always_inline)) {  // after lgkmcnt(0): the fragments just read are real values now
+        pp_pin(ef[0], ef[1], ef[2], ef[3]);
+        pp_pin(ef[4], ef[5], ef[6], ef[7]);
+        pp_pin(qn[0], qn[1], qn[2], qn[3]);
+    };
+
+    // ---- tile epilogue: per-chunk maxima along the DPP rows, sum over the query vectors, store ------------------------------------
+    auto epilogue = [&](int t) __attribute__((always_inline)) {
+        const int32_t row0 = org + t * PP_RT;
+        // "last row of its chunk" bits of the tile's 128 rows: 5 words from row0 / 32, shifted by 16 when row0 is odd in blocks
+        uint32_t m[5];
+        const uint32_t* const eb = ends_bits + (row0 >> 5);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) m[i] = eb[i];
+        const bool odd = (row0 & 16) != 0;
+        uint32_t mm[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mm[i] = odd ? (m[i] >> 16) | (m[i + 1] << 16) : m[i];
+        int n_st = 0;
+        if (has0) {
+#pragma unroll
+            for (int a = 0; a < PP_NBLK; ++a) {
+                const uint32_t E = (mm[a >> 1] >> (16 * (a & 1))) & 0xffffu;
+                const int32_t base = row0 + 16 * a;
+                const int32_t ord0 = row_to_chunk[base < (int32_t)n_rows ? base : (int32_t)n_rows];
+                // lanes whose shifted neighbour belongs to the same chunk: no chunk end in rows [j - d, j - 1]
+                const uint32_t O1 = E << 1, O2 = O1 | (O1 << 1), O4 = O2 | (O2 << 2), O8 = O4 | (O4 << 4);
+                const uint64_t rep = 0x0001000100010001ull;
+                const uint64_t F1 = (uint64_t)(~O1 & 0xfffeu) * rep, F2 = (uint64_t)(~O2 & 0xfffcu) * rep;
+                const uint64_t F4 = (uint64_t)(~O4 & 0xfff0u) * rep, F8 = (uint64_t)(~O8 & 0xff00u) * rep;
+                const uint64_t C0 = prev_last_end ? 0ull : rep;  // row 0 continues the chunk open at the end of the previous block
+                int32_t lo = r_lo - base, hi = r_hi - base;  // rows of this block inside the workgroup's range
+                lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
+                hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
+                const uint32_t EM = E & ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+                const uint32_t below = E & ((1u << fj) - 1u);
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    if (q == 1 && !has1) continue;  // wave-uniform
+                    float x[8], tmp[8];
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) x[4 * qb + u] = acc[q][qb][a][u];
+#define PP_STEP(SRC, CTRLSTR, MASK)                                                    \
+    _Pragma("unroll") for (int r = 0; r < 8; ++r) PP_MAX_DPP(tmp[r], SRC, x[r], CTRLSTR); \
+    _Pragma("unroll") for (int r = 0; r < 8; ++r) PP_SELECT(x[r], tmp[r], MASK);
+                    if constexpr (!(DBG & 1)) {
+                        PP_STEP(carry[q][r], "row_ror:1", C0)  // lane 0 <- lane 15 of the previous block's scan
+                        PP_STEP(x[r], "row_shr:1", F1)
+                        PP_STEP(x[r], "row_shr:2", F2)
+                        PP_STEP(x[r], "row_shr:4", F4)
+                        PP_STEP(x[r], "row_shr:8", F8)
+                    }
+#undef PP_STEP
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) carry[q][r] = x[r];
+                    if (EM != 0u) {  // wave-uniform: some chunk of this workgroup ends in this block
+                        float tsum = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+                        tsum += __shfl_xor(tsum, 16);
+                        tsum += __shfl_xor(tsum, 32);
+                        if (lane < 16 && ((EM >> lane) & 1u)) (q == 0 ? out0 : out1)[ord0 + __builtin_popcount(below)] = tsum * (q == 0 ? unscale0 : unscale1);
+                        ++n_st;
+                    }
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb) acc[q][qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+                prev_last_end = (E >> 15) & 1u;
+            }
+        } else {
+            prev_last_end = (mm[3] >> 31) & 1u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int a = 0; a < PP_NBLK; ++a) acc[q][qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        // The stores are newer than every DMA issued so far (up to slab g + D): they count in the waits that certify slabs
+        // g + 2 .. g + D, i.e. in this slab's wait and the next D - 2.
+        st_pending = n_st;
+        st_slabs = n_st > 0 ? (cfeed ? PP_DC - 1 : PP_DQ - 1) : 0;
+    };
+
+    // ---- prologue: slabs 0 .. D - 1 of this wave's ring in flight; slab 0 landed -> its fragments; slab 1 landed ---------------
+    {
+        const int D = cfeed ? PP_DC : PP_DQ;
+        for (int i = 0; i < D; ++i) issue_slab();
+        if (cfeed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PP_DC - 1) * 4) : "memory");
+        else if (np == 6) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PP_DQ - 1) * 6) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PP_DQ - 1) * 5) : "memory");
+        asm volatile("s_barrier" ::: "memory");
+        [&]<int... A>(std::integer_sequence<int, A...>) { (read_slab(qA, std::integral_constant<int, A>{}), ...); }
+        (std::make_integer_sequence<int, PP_NBLK>{});
+        c_slot = 1;
+        q_slot = 1;
+        certify();  // slab 1
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // slab 0's slots are free, slab 1 is readable
+        landed(qA);
+    }
+    // ---- main loop: two slabs per iteration (two static sets of query fragment registers) -----------------------------------------
+    int c_s = 0, c_tile = 0;
+    auto step = [&](f32x4 (&q)[4], f32x4 (&qn)[4]) __attribute__((always_inline)) {
+        slab(q, qn);
+        if (++c_s == nslab) {
+            epilogue(c_tile);
+            c_s = 0;
+            ++c_tile;
+        }
+        certify();  // slab g + 2
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everybody has read slab g + 1; slab g + 2 is readable
+        landed(qn);
+    };
+    for (int g = 0; g < total; g += 2) {
+        step(qA, qB);
+        if (g + 1 < total) step(qB, qA);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
+}
+
+// n_q (1..16) queries `first .. first + n_q - 1` of a launch_query_planes buffer over `n_queries`, each nq (<= 32) vectors, against
+// a one-plane image (fp16 hi halves, or an fp16-stored corpus): out[q * out_stride + chunk], one MFMA product per multiply.
+int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first, int32_t n_q,
+                     int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits, float* out,
+                     int64_t out_stride, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if) {
+    if (nq < 1 || nq > 32 || n_q < 1 || n_q > PP_QPP || n_rows < 1 || first < 0 || first + n_q > n_queries) return RL_ERR_UNSUPPORTED;
+    // dim >= 256: a tile's epilogue stores must have left the VMEM counter's window before the next tile's (see certify())
+    if (dim % 32 || dim < 256 || !(split_scale > 0.f) || !image || !ends_bits) return RL_ERR_UNSUPPORTED;
+    const int32_t nslab = dim / 32;
+    const char* qfrag = static_cast<const char*>(qbuf) + (size_t)first * nslab * 4096;
+    const float* qmeta = reinterpret_cast<const float*>(static_cast<const char*>(qbuf) + (size_t)n_queries * dim * 128) + 2 * (size_t)first;
+    const int64_t tiles = (n_rows + PP_RT - 1) / PP_RT;
+    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
+    static const int dbg = std::getenv("RAGLITE_PP_DBG") ? std::atoi(std::getenv("RAGLITE_PP_DBG")) : 0;  // timing experiments only
+#define RL_PP_LAUNCH(DBG_)                                                                                                              \
+    hipLaunchKernelGGL(maxsim_pp_kernel<DBG_>, grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk, \
+                       chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if)
+    if (dbg == 1) RL_PP_LAUNCH(1);
+    else if (dbg == 2) RL_PP_LAUNCH(2);
+    else if (dbg == 3) RL_PP_LAUNCH(3);
+    else if (dbg == 10) RL_PP_LAUNCH(10);
+    else if (dbg == 11) RL_PP_LAUNCH(11);
+    else RL_PP_LAUNCH(0);
+#undef RL_PP_LAUNCH
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+}  // namespace rl

@@ -1,0 +1,164 @@
+"""GPU parity of the sixteen-queries-per-pass approximate MaxSim kernel (raglite_amd/csrc/maxsim_pp.hip), the first stage of
+`rl_maxsim_topk_batch`'s bound-filtered pipeline, through `rl_maxsim_approx_scores`:
+
+score[c] ~ sum_i max_{j in chunk c} Q[i].D[j] from the hi halves of corpus and queries -- the multi-vector generalisation of
+`/root/reference/src/raglite/_search.py:143-149` behind the reranker plugin call (:394-396).
+
+Bars: EVERY (query, chunk) score bit-identical to the eight-queries-per-pass kernel of maxsim_gemm.hip (same products, same
+summation order: the kernels differ in how operands reach the matrix pipe, not in what is summed); integer data bit-identical to
+the oracle for every chunk (hi halves of small integers are the integers); on float data |approximate - float64| <= the bound the
+pipeline builds its candidate window on, for every chunk; and the whole pipeline over either kernel returns the same bits."""
+
+import os
+
+import numpy as np
+import pytest
+
+import raglite_amd
+from oracle import oracle
+from tests.util import ragged_offsets
+
+pytestmark = pytest.mark.gpu
+
+
+class _env:
+    def __init__(self, **kv):
+        self.kv = kv
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _torch():
+    import torch
+
+    raglite_amd.set_device(0)
+    return torch
+
+
+def _corpus(torch, n, dim, seed, kind="uniform"):
+    E = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=seed, kind=kind)
+    return E
+
+
+def _queries(torch, n_queries, nq, dim, seed, kind="uniform"):
+    Q = torch.empty((n_queries, nq, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=seed, kind=kind)
+    return Q
+
+
+@pytest.mark.parametrize("n,dim,nq,n_queries,layout", [
+    (70_003, 1024, 32, 16, "ragged"),      # the headline shape class; n not a multiple of 16
+    (70_000, 1024, 17, 21, "ragged"),      # a second, partial pass (5 queries: waves without a query, one with a single query)
+    (70_000, 1024, 1, 3, "ragged"),        # one query vector; three queries
+    (70_000, 1024, 16, 9, "ones"),         # every row its own chunk
+    (66_000, 1024, 32, 16, "giant"),       # chunks of 1 000 rows: a chunk spans eight tiles and workgroup boundaries
+    (140_000, 512, 32, 19, "ragged"),      # dim 512: 16 slabs per tile
+    (270_000, 256, 9, 16, "ragged"),       # dim 256: 8 slabs per tile (the smallest the kernel takes)
+])
+def test_pp_equals_eight_query_kernel_bitwise(n, dim, nq, n_queries, layout):
+    torch = _torch()
+    rng = np.random.default_rng(n + nq)
+    off = {"ragged": lambda: ragged_offsets(rng, n, 1, 15), "ones": lambda: None,
+           "giant": lambda: np.concatenate((np.arange(0, n, 1000), [n])).astype(np.int64)}[layout]()
+    E = _corpus(torch, n, dim, seed=900 + nq)
+    Q = _queries(torch, n_queries, nq, dim, seed=901 + nq)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    a, ma = idx.maxsim_approx_scores(Q, kernel=0)
+    b, mb = idx.maxsim_approx_scores(Q, kernel=1)
+    assert torch.equal(a, b), f"{int((a != b).sum())} of {a.numel()} scores differ"
+    assert torch.equal(ma, mb) and bool((ma > 0).all())
+    a2, _ = idx.maxsim_approx_scores(Q, kernel=0)
+    assert torch.equal(a, a2)  # deterministic
+    idx.close()
+
+
+def test_pp_integer_data_is_the_oracle_bit_for_bit():
+    torch = _torch()
+    n, dim, nq, n_queries = 70_000, 1024, 32, 5
+    rng = np.random.default_rng(7)
+    off = ragged_offsets(rng, n, 1, 15)
+    E = oracle.synth_matrix(20_000, n, dim, "small_int")
+    Qb = np.stack([oracle.synth_matrix(20_100 + i, nq, dim, "small_int") for i in range(n_queries)])
+    idx = raglite_amd.DeviceIndex(torch.from_numpy(E).cuda(), off, metric="dot")
+    got, _ = idx.maxsim_approx_scores(torch.from_numpy(Qb).cuda(), kernel=0)
+    got = got.cpu().numpy()
+    for i in (0, 2, 4):
+        want = oracle.maxsim_scores(E, off, Qb[i], np.float32)
+        assert np.array_equal(got[i], want), i
+    idx.close()
+
+
+@pytest.mark.parametrize("shape", ["uniform", "unit_fp16"])
+def test_pp_error_stays_inside_the_bound_for_every_chunk(shape):
+    """The bound the candidate window is built on, measured: |approximate - float64| <= m for EVERY chunk of every query."""
+    torch = _torch()
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "scripts"))
+    import bench_configs
+
+    n, dim, nq, n_queries = 70_000, 1024, 32, 16
+    rng = np.random.default_rng(11)
+    off = ragged_offsets(rng, n, 1, 15)
+    E = _corpus(torch, n, dim, seed=31)
+    Q = _queries(torch, n_queries, nq, dim, seed=32)
+    if shape == "unit_fp16":
+        E = torch.nn.functional.normalize(E, dim=1).half().float()
+        Q = torch.nn.functional.normalize(Q, dim=2).half().float()
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    got, m = idx.maxsim_approx_scores(Q, kernel=0)
+    ref = bench_configs.maxsim_scores_f64(E, off, Q)
+    err = (got.double() - ref).abs().max(dim=1).values
+    assert bool((err <= m.double()).all()), (err.tolist(), m.tolist())
+    assert float((err / m.double()).max()) < 0.5  # Cauchy-Schwarz is far from tight on such data: the bound has room
+    idx.close()
+
+
+def test_pipeline_over_either_kernel_returns_the_same_bits():
+    torch = _torch()
+    n, dim, nq, n_queries, k = 70_000, 1024, 32, 37, 100
+    rng = np.random.default_rng(3)
+    off = ragged_offsets(rng, n, 1, 15)
+    E = _corpus(torch, n, dim, seed=41)
+    Q = _queries(torch, n_queries, nq, dim, seed=42)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    s0, c0 = idx.maxsim_topk_batch(Q, k)
+    assert idx.filter_stats()["kind"] == "maxsim_batch_hi" and not idx.filter_stats()["fallback"]
+    with _env(RAGLITE_NO_PP="1"):
+        s1, c1 = idx.maxsim_topk_batch(Q, k)
+    assert torch.equal(s0, s1) and torch.equal(c0, c1)
+    with _env(RAGLITE_NO_HI_MAXSIM="1"):  # the full-precision passes: same chunks, scores to the last bits of the split arithmetic
+        s2, c2 = idx.maxsim_topk_batch(Q, k)
+    assert torch.equal(c0, c2)
+    assert float((s0 - s2).abs().max()) <= 2e-6 * float(s0.abs().max())
+    idx.close()
+
+
+def test_pp_after_append_and_on_a_sub_range():
+    """The image grows with the index (rl_index_append) and the kernel's row ranges follow the chunk structure."""
+    torch = _torch()
+    n, dim, nq, n_queries = 66_000, 1024, 32, 16
+    rng = np.random.default_rng(5)
+    E = _corpus(torch, n + 5_000, dim, seed=51)
+    off = ragged_offsets(rng, n, 1, 15)
+    extra = ragged_offsets(rng, 5_000, 1, 15)
+    Q = _queries(torch, n_queries, nq, dim, seed=52)
+    idx = raglite_amd.DeviceIndex(E[:n].clone(), off, metric="dot")
+    idx.append(E[n:], np.diff(extra))
+    whole = raglite_amd.DeviceIndex(E, np.concatenate((off, off[-1] + extra[1:])), metric="dot")
+    a, _ = idx.maxsim_approx_scores(Q, kernel=0)
+    b, _ = whole.maxsim_approx_scores(Q, kernel=0)
+    assert torch.equal(a, b)
+    idx.close()
+    whole.close()
