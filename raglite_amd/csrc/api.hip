@@ -239,7 +239,6 @@ struct rl_index {
     // HI plane (round 2): fp16(e * split_scale) rounded toward zero, row-major [n_rows x dim] -- the hi halves of the fp16
     // split as a matrix of their own, 2 B per element: what the single-query search streams (search_rows_hi).
     rl::Pool hiplane, hibuf;
-    bool hi_rne = false;                  // experimental (RAGLITE_HI_RNE=1 when the index is created): HI halves rounded to nearest, not toward zero
     float hi_scale = 0.f;                 // the scale the plane was built with; 0 = no plane
     int64_t hi_rows = 0;                  // rows it covers
     // ... and the same halves in the one-plane IMAGE layout (maxsim_gemm.hip HALF): what the approximate MaxSim pass of a
@@ -389,7 +388,7 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
         idx->hi_image_rows = 0;
         return RL_OK;
     }
-    const int st = rl::launch_presplit_hi_rows(idx->E, first, idx->n_rows, idx->dim, idx->split_scale, idx->hi_image.p, s, idx->hi_rne);
+    const int st = rl::launch_presplit_hi_rows(idx->E, first, idx->n_rows, idx->dim, idx->split_scale, idx->hi_image.p, s);
     if (st == RL_ERR_UNSUPPORTED) {
         idx->hi_image.release();
         idx->hi_image_scale = 0.f;
@@ -411,8 +410,7 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
         std::memcpy(&bits[1], &idx->max_lo_norm, 4);
         std::memcpy(&bits[2], &idx->max_lo_ratio, 4);
         RL_HIP(hipMemcpyAsync(idx->d_norms, bits, 16, hipMemcpyHostToDevice, s));
-        RL_TRY(rl::launch_max_row_norm(idx->E + (size_t)from * idx->dim, idx->n_rows - from, idx->dim, idx->split_scale, idx->d_norms, s,
-                                       idx->hi_rne));
+        RL_TRY(rl::launch_max_row_norm(idx->E + (size_t)from * idx->dim, idx->n_rows - from, idx->dim, idx->split_scale, idx->d_norms, s));
         RL_HIP(hipMemcpyAsync(bits, idx->d_norms, 16, hipMemcpyDeviceToHost, s));
         RL_HIP(hipStreamSynchronize(s));
         std::memcpy(&idx->max_row_norm, &bits[0], 4);
@@ -447,8 +445,8 @@ int refresh_hi_plane(rl_index* idx, hipStream_t s) {
         idx->hi_rows = 0;
         return RL_OK;
     }
-    const int st = rl::launch_cast_f16_rtz(idx->E + (size_t)first * d, idx->hiplane.as<uint16_t>() + (size_t)first * d,
-                                           (idx->n_rows - first) * d, idx->split_scale, s, idx->hi_rne);
+    const int st = rl::launch_cast_f16_scaled(idx->E + (size_t)first * d, idx->hiplane.as<uint16_t>() + (size_t)first * d,
+                                           (idx->n_rows - first) * d, idx->split_scale, s);
     if (st == RL_ERR_UNSUPPORTED) {  // caller-owned rows that are not 16-byte aligned
         idx->hiplane.release();
         idx->hi_scale = 0.f;
@@ -678,10 +676,6 @@ static int index_create_any(rl_index** out, const void* embeddings, bool f16, in
     }
     hipStream_t s = as_stream(stream);
     rl_index* idx = new rl_index();
-    {
-        const char* rne_env = std::getenv("RAGLITE_HI_RNE");  // experimental, see DESIGN.md section 8 (R3 candidates)
-        idx->hi_rne = rne_env && rne_env[0] && rne_env[0] != '0';
-    }
     idx->n_rows = n_rows;
     idx->dim = dim;
     idx->n_chunks = n_chunks;
@@ -1193,9 +1187,10 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
     return RL_OK;
 }
 
-// EXPERIMENTAL (RAGLITE_FUSED_HI=1, read per call; built at the end of round 2, not yet measured on hardware): the fused top-k of
-// search_rows_fused with its two GEMM passes over the HI image at ONE fp16 MFMA product per multiply (q_hi . e_hi: a third of the
-// matrix work and half the bytes of the pre-split image), made exact by the error band of search_rows_hi:
+// The fused top-k of search_rows_fused with its two GEMM passes over the HI image at ONE fp16 MFMA product per multiply (q_hi . e_hi:
+// a third of the matrix work and half the bytes of the pre-split image), made exact by the error band of search_rows_hi -- the default
+// for big batches over an index that keeps a HI image since round 3 (BASELINE cfg 5: 7.48 -> 3.74 ms per 1000 queries on the same box,
+// profiles/r03_a / r03_f; RAGLITE_NO_FUSED_HI=1, read per call, restores search_rows_fused: A/B):
 //   (1) sample pass -> the k-th best APPROXIMATE similarity of a row subset, tau_s <= the k-th best approximate overall (A_k);
 //   (2) every row of the exact top-k has an approximate similarity >= A_k - 2 m >= tau_s - 2 m (|approximate - exact| <= m, with
 //       m from what the corpus' and the query's hi halves drop: row_threshold_kernel), so the candidate pass keeps the rows
@@ -1209,10 +1204,11 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
 // bits differ from the dense path's split-arithmetic sums, as they do between any two of the paths).  cosine / dot, k <= 512,
 // no row mask; RL_ERR_UNSUPPORTED otherwise.
 int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, float* d_scores, int32_t* d_rows, int64_t ld, hipStream_t s) {
-    const char* on_env = std::getenv("RAGLITE_FUSED_HI");
-    if (!(on_env && on_env[0] && on_env[0] != '0')) return RL_ERR_UNSUPPORTED;
-    const char* two_env = std::getenv("RAGLITE_FUSED_HI_TWO_PRODUCTS");  // A/B: q_hi.e_hi + q_lo.e_hi (no |q_lo| term in the band)
-    const bool hi_only = !(two_env && two_env[0] && two_env[0] != '0');
+    for (const char* name : {"RAGLITE_NO_FUSED_HI", "RAGLITE_NO_FUSED_TOPK"}) {  // (the second one asks for the dense path: no fused top-k at all)
+        const char* off_env = std::getenv(name);
+        if (off_env && off_env[0] && off_env[0] != '0') return RL_ERR_UNSUPPORTED;
+    }
+    const bool hi_only = true;  // (two products -- q_hi.e_hi + q_lo.e_hi, no |q_lo| term in the band -- measured 4.88 ms against 3.51)
     const int mode = scan_mode(idx->metric);
     if (B < GEMM_MIN_QUERIES || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT)) return RL_ERR_UNSUPPORTED;
     if (!hi_image_valid(idx) || !image_valid(idx) || !idx->E) return RL_ERR_UNSUPPORTED;
@@ -1380,7 +1376,7 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
     for (int32_t b0 = 0; b0 < B; b0 += batch) {
         const int32_t nb = std::min<int32_t>(batch, B - b0);
         const bool cut = rank_limit > 0 && rank_limit < n;
-        if (!d_row_bits && !cut) {  // (experimental, opt-in: the same over the HI image at one MFMA product per multiply)
+        if (!d_row_bits && !cut) {  // big batches over an index with a HI image: fused top-k at one MFMA product per multiply
             const int st = search_rows_fused_hi(idx, d_q + (int64_t)b0 * idx->dim, nb, k, d_scores + (int64_t)b0 * k, d_rows + (int64_t)b0 * k, ld, s);
             if (st == RL_OK) continue;
             if (st != RL_ERR_UNSUPPORTED) return st;

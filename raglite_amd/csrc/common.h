@@ -115,8 +115,8 @@ int launch_scan_rows16(const uint16_t* E, int64_t n, int32_t dim, const float* q
 int launch_row_norms16(const uint16_t* E, int64_t n, int32_t dim, float* norm, float* sumsq, hipStream_t s);
 int launch_row_norms(const float* E, int64_t n, int32_t dim, float* norm, float* sumsq, hipStream_t s);
 int launch_cast_f16(const float* src, uint16_t* dst, int64_t count, hipStream_t s);
-// dst = fp16(src * scale) rounded TOWARD ZERO (the hi half of the fp16 split); count % 8 == 0, 16-byte aligned pointers
-int launch_cast_f16_rtz(const float* src, uint16_t* dst, int64_t count, float scale, hipStream_t s, bool rne = false);
+// dst = fp16(src * scale) rounded to nearest even (the HI plane); count % 8 == 0, 16-byte aligned pointers
+int launch_cast_f16_scaled(const float* src, uint16_t* dst, int64_t count, float scale, hipStream_t s);
 int launch_fill_f32(float* dst, float value, int64_t count, hipStream_t s);
 int launch_scale_f32(const float* src, float* dst, float factor, int64_t count, hipStream_t s);  // hi_filter.hip: dst = src * factor
 // in-place metric transform of raw dots: scores[b*ld+i] (i<n), per-row norm / sumsq, per-query norm.
@@ -176,7 +176,7 @@ int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, con
                             const float* q_unscale = nullptr, float e_norm_max = 0.f);
 // bits[0..2] = max |e|, max |e_lo|, max |e_lo| / |e| over the rows (float bit patterns, nudged up by 1e-6; start them at the
 // values so far), e_lo = what the fp16 HI halves at `scale` drop
-int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale, uint32_t* bits, hipStream_t s, bool rne = false);
+int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale, uint32_t* bits, hipStream_t s);
 int launch_diag_blocks(const float* src, int64_t ld, int32_t k2, int64_t count, float* dst, hipStream_t s);
 // Batched half-bytes search (experimental, api.hip: search_rows_fused_hi) -- see the kernels' comments in hi_filter.hip / select.hip
 int launch_row_threshold(const float* topk, int32_t nb, int32_t k, const float* Q, int32_t dim, int mode, const float* q_unscale, float lo_ratio,
@@ -232,8 +232,7 @@ int launch_maxsim_stream2(const void* D, bool f16, int64_t n_rows, int32_t dim, 
 size_t planes_bytes(int64_t rows, int32_t dim, bool half = false);
 int launch_presplit_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s);
 int launch_preformat_rows16(const uint16_t* E, int64_t first_row, int64_t n_rows, int32_t dim, void* planes, hipStream_t s);
-int launch_presplit_hi_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s,
-                            bool rne = false);
+int launch_presplit_hi_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s);
 size_t chunk_ends_words(int64_t rows);
 int launch_chunk_ends(const int32_t* row_to_chunk, int64_t n_rows, uint32_t* ends, hipStream_t s);
 size_t query_planes_bytes(int32_t dim, int32_t n_queries);

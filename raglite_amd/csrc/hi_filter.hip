@@ -209,10 +209,10 @@ __global__ __launch_bounds__(256) void row_dots_kernel(const float* __restrict__
 }
 
 // bits[0] = max |e|, bits[1] = max |e_lo|, bits[2] = max |e_lo| / |e| over the rows (float bit patterns, each nudged up by 1e-6;
-// non-negative floats order like their bits), where e_lo = e - fp16_rtz(e * scale) / scale is what the HI halves drop --
-// computed exactly (the scale is a power of two, the difference of a float and its truncation is exact).
+// non-negative floats order like their bits), where e_lo = e - fp16(e * scale) / scale is what the HI halves (rounded to nearest even,
+// as the plane and the image are built) drop -- computed exactly (the scale is a power of two, x - fp16(x) is exact in fp32).
 __global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restrict__ E, int64_t n_rows, int dim, float scale,
-                                                            uint32_t* __restrict__ bits, int rne) {
+                                                            uint32_t* __restrict__ bits) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
     const float inv = 1.0f / scale;
@@ -222,8 +222,7 @@ __global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restri
         for (int c = lane; c < dim; c += 64) {
             const float v = E[r * (int64_t)dim + c];
             const float x = v * scale;
-            const auto h = __builtin_amdgcn_cvt_pkrtz(x, 0.f);
-            const float hi = rne ? (float)(_Float16)x : (float)h[0];  // (the rounding the planes were built with)
+            const float hi = (float)(_Float16)x;  // (the rounding the planes were built with)
             const float lo = (x - hi) * inv;
             ss = fmaf(v, v, ss);
             sl = fmaf(lo, lo, sl);
@@ -311,10 +310,10 @@ int launch_row_dots(const float* E, int32_t dim, const float* Q, int32_t nb, con
     return RL_OK;
 }
 
-int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale, uint32_t* bits, hipStream_t s, bool rne) {
+int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale, uint32_t* bits, hipStream_t s) {
     if (n_rows <= 0) return RL_OK;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_rows + 3) / 4, 256 * 8));
-    hipLaunchKernelGGL(max_row_norm_kernel, dim3(blocks), dim3(256), 0, s, E, n_rows, (int)dim, scale, bits, rne ? 1 : 0);
+    hipLaunchKernelGGL(max_row_norm_kernel, dim3(blocks), dim3(256), 0, s, E, n_rows, (int)dim, scale, bits);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

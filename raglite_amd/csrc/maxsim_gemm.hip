@@ -119,9 +119,11 @@ __global__ __launch_bounds__(256) void preformat_rows16_kernel(const uint16_t* _
 }
 
 // The HI halves of the fp16 split of an fp32 corpus as a one-plane image (the layout of preformat_rows16_kernel): what the
-// approximate MaxSim pass of big batches multiplies (api.hip: maxsim_batch_hi) -- fp16(e * scale) rounded toward zero.
+// approximate MaxSim pass of big batches multiplies (api.hip: maxsim_batch_hi) -- fp16(e * scale) rounded to NEAREST even: what the
+// halves drop is then at most half an ulp (max_row_norm_kernel measures it with the same rounding; toward zero, the first version,
+// left 40 % more candidates for the exact re-scoring: 418 instead of 301 per query on the benchmark corpus).
 __global__ __launch_bounds__(256) void presplit_hi_rows_kernel(const float* __restrict__ E, int64_t first_row, int64_t end_row,
-                                                                int64_t n_rows, int32_t dim, float scale, char* __restrict__ planes, int rne) {
+                                                                int64_t n_rows, int32_t dim, float scale, char* __restrict__ planes) {
     const int32_t nslab = dim >> 5;
     const int64_t per_row = (int64_t)nslab * 4;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -134,31 +136,24 @@ __global__ __launch_bounds__(256) void presplit_hi_rows_kernel(const float* __re
         v0 = *reinterpret_cast<const f32x4*>(p);
         v1 = *reinterpret_cast<const f32x4*>(p + 4);
     }
-    // rne (experimental, RAGLITE_HI_RNE=1 when the index is built): round to nearest even instead -- what the halves drop is then
-    // at most half an ulp instead of a whole one (max_row_norm_kernel measures it with the same rounding)
     typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
     auto pk = [&](float a, float b) -> uint32_t {
         uint32_t w;
-        if (rne) {
-            const h16x2 t = (h16x2){(_Float16)(a * scale), (_Float16)(b * scale)};
-            __builtin_memcpy(&w, &t, 4);
-        } else {
-            const auto t = __builtin_amdgcn_cvt_pkrtz(a * scale, b * scale);
-            __builtin_memcpy(&w, &t, 4);
-        }
+        const h16x2 t = (h16x2){(_Float16)(a * scale), (_Float16)(b * scale)};
+        __builtin_memcpy(&w, &t, 4);
         return w;
     };
     const uint4 o = make_uint4(pk(v0[0], v0[1]), pk(v0[2], v0[3]), pk(v1[0], v1[1]), pk(v1[2], v1[3]));
     *reinterpret_cast<uint4*>(planes + ((row >> 4) * nslab + s) * 1024 + kq * 256 + (row & 15) * 16) = o;
 }
 
-int launch_presplit_hi_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s, bool rne) {
+int launch_presplit_hi_rows(const float* E, int64_t first_row, int64_t n_rows, int32_t dim, float scale, void* planes, hipStream_t s) {
     if (dim % 32 || dim < 32 || (reinterpret_cast<uintptr_t>(E) & 15)) return RL_ERR_UNSUPPORTED;
     const int64_t end_row = (n_rows + 15) / 16 * 16;
     if (end_row <= first_row) return RL_OK;
     const int64_t threads = (end_row - first_row) * (dim / 8);
     hipLaunchKernelGGL(presplit_hi_rows_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, E, first_row, end_row, n_rows, dim,
-                       scale, static_cast<char*>(planes), rne ? 1 : 0);
+                       scale, static_cast<char*>(planes));
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -321,7 +316,8 @@ struct RowScoreArgs {
 // src/raglite/_typing.py:211-232): one fp16 plane, 2 B per element -- a (block, slab) is 1 KiB laid out exactly as a wave
 // reads it (lane 16 kq + j <- k-chunk kq of row j), the slab 16 KiB, and each product is 2 MFMAs (q_hi.e + q_lo.e), exact
 // for the stored values.
-// HO (experimental, RAGLITE_GEMM_DEEP=1; HALF images, one product): the pass with a DEEP corpus stream.  Measured
+// HO (HALF images, one product -- what every one-product launch runs since round 3: cfg 5's fused top-k over the HI image 4.18 -> 3.74 ms,
+// the eight-query MaxSim pass 0.71 -> 0.65 ms, profiles/r03_a / r03_f): the pass with a DEEP corpus stream.  Measured
 // (profiles/r02_u_skeleton.txt): without any MFMA the HALF pass still takes 0.51 ms -- the image moves at 4 TB/s -- and the matrix work
 // is added to that, not hidden by it.  Cause: VMEM retires in order and a wave's query-fragment loads of slab g are issued one
 // slab ahead, i.e. after every DMA but the newest slab's: waiting for them at the top of slab g drains all older DMAs -- one 16-KiB
@@ -956,8 +952,7 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
 #define RL_MG_LAUNCH(NQB_, HALF_)                                                                                                     \
     hipLaunchKernelGGL((maxsim_gemm_kernel<NQB_, false, 0, HALF_>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, \
                        qmeta, n_q, row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr, rs0)
-    static const bool deep = std::getenv("RAGLITE_GEMM_DEEP") != nullptr && std::getenv("RAGLITE_GEMM_DEEP")[0] != '0';  // experimental (HO)
-    if (half && hi_only && deep) {
+    if (half && hi_only) {  // one product over a one-plane image: the deep-stream build (HO)
 #define RL_MG_LAUNCH_HO(NQB_)                                                                                                          \
     hipLaunchKernelGGL((maxsim_gemm_kernel<NQB_, false, 0, true, true>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab, qfrag, \
                        qmeta, n_q, row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, dbg, nullptr, rs0)
@@ -1085,8 +1080,7 @@ int launch_score_planes_pass(const void* planes, int64_t n_rows, int32_t dim, in
     hipLaunchKernelGGL((maxsim_gemm_kernel<2, false, MODE_, HALF_>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab,          \
                        reinterpret_cast<const char*>(frag), nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, \
                        hi_only ? 64 : 0, nullptr, rs)
-    static const bool deep = std::getenv("RAGLITE_GEMM_DEEP") != nullptr && std::getenv("RAGLITE_GEMM_DEEP")[0] != '0';  // experimental (HO)
-    if (half && hi_only && deep) {
+    if (half && hi_only) {  // one product over a one-plane image: the deep-stream build (HO)
 #define RL_MG_LAUNCH_HO(MODE_)                                                                                                         \
     hipLaunchKernelGGL((maxsim_gemm_kernel<2, false, MODE_, true, true>), grid, blk, 0, s, static_cast<const char*>(planes), n_rows, nslab,     \
                        reinterpret_cast<const char*>(frag), nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, \

@@ -21,6 +21,7 @@
 //     queries' hi fragments, 32 KiB, L2-resident) in a ring of 3 -- no VMEM result is ever waited for in registers, so no wait
 //     drains the look-ahead (VMEM retires in order).  Waves 0 and 4 feed the corpus ring and nothing else: their `s_waitcnt vmcnt`
 //     leaves four slabs (32 KiB per CU) of HBM reads in flight; the other six feed the query ring (5, 5, 6 pieces per slab);
+//     (a wave issues its pieces of slab g + D during the first MFMA groups of slab g, whose slot the barrier just freed);
 //   * a wave's fragments of slab g + 1 are read from LDS WHILE it multiplies slab g from registers -- each corpus fragment
 //     register is re-loaded right after its four MFMAs, the query fragments alternate between two register sets -- i.e. a full
 //     slab (32 MFMAs, >= 512 cycles) ahead: the MFMA stream never waits for LDS;
@@ -47,11 +48,8 @@ constexpr int PP_RT = 128;                       // corpus rows per tile
 constexpr int PP_NBLK = PP_RT / 16;              // 16-row blocks per tile
 constexpr int PP_QPP = 16;                       // queries per pass
 constexpr int PP_WAVES = 8;
-constexpr int PP_DC = 6, PP_DQ = 3;              // ring depths: corpus slabs, query slabs
 constexpr int PP_CSLOT = PP_NBLK * 1024;         // corpus slab: 8 blocks x 1 KiB
 constexpr int PP_QSLOT = PP_QPP * 2 * 1024;      // query slab: 16 queries x 2 blocks of 16 vectors x 1 KiB
-constexpr int PP_QOFF = PP_DC * PP_CSLOT;
-constexpr int PP_LDS = PP_QOFF + PP_DQ * PP_QSLOT;  // 147 456 B
 
 __device__ __forceinline__ int64_t pp_uniform_i64(int64_t v) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v);
@@ -104,14 +102,33 @@ __device__ __forceinline__ h16x8 pp_h(const f32x4& v) {
     return r;
 }
 
-// DBG (timing experiments only, RAGLITE_PP_DBG; wrong results): 1 = no scan steps in the epilogue, 2 = no MFMAs, 8 = no LDS fragment reads
-template <int DBG>
+// DBG (timing experiments only, RAGLITE_PP_DBG; wrong results): 1 = no scan steps in the epilogue, 2 = no MFMAs, 8 = no LDS fragment reads,
+// 16 = no corpus DMAs, 32 = no query DMAs
+// PP_DC / PP_DQ: ring depths in slabs (corpus: 8 KiB each, query: 32 KiB each; at most 160 KiB together).
+// FEED 0: waves 0, 4 feed the corpus ring, the other six the query ring.  FEED 1: waves 0-3 (one per SIMD) feed both rings -- per slab 8
+// query pieces, then 2 corpus pieces -- and waves 4-7 only multiply: a VMEM instruction blocks its wave until the address path takes it
+// (~35 cycles per KiB with every CU streaming), and a blocked wave issues no MFMAs; with one feeder per SIMD its partner keeps the
+// matrix pipe busy meanwhile.
+template <int DBG, int PP_DC, int PP_DQ, int FEED>
 __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restrict__ planes, int64_t n_rows, int32_t nslab,
                                                            const char* __restrict__ qfrag, const float* __restrict__ qmeta, int32_t n_q,
                                                            const int32_t* __restrict__ row_to_chunk, const int64_t* __restrict__ chunk_offsets,
                                                            const uint32_t* __restrict__ ends_bits, float* __restrict__ out, int64_t out_stride,
-                                                           float inv_e_scale, const uint32_t* __restrict__ run_if) {
-    __shared__ __attribute__((aligned(16))) char smem[PP_LDS];
+                                                           float inv_e_scale, const uint32_t* __restrict__ run_if, unsigned long long* __restrict__ trace) {
+    constexpr int PP_QOFF = PP_DC * PP_CSLOT, PP_LDS = PP_QOFF + PP_DQ * PP_QSLOT;
+    static_assert(PP_LDS <= 160 * 1024 && PP_DC >= 3 && PP_DQ >= 3, "ring depths");
+    static_assert(FEED == 0 || (PP_DC == 4 && PP_DQ == 3), "FEED 1: query slab g + 3 and corpus slab g + 4 are issued during slab g");
+    // DBG & 64 (RAGLITE_PP_TRACE=1): s_memtime stamps of workgroup 7, slabs 64..79, in LDS behind the rings, copied out at the end:
+    // [slab - 64][wave][0: top of the slab, 1: after the MFMA / read / DMA steps, 2: after the feeder's wait, 3: after the barrier]
+    constexpr bool TRACE = (DBG & 64) != 0;
+    __shared__ __attribute__((aligned(16))) char smem[PP_LDS + (TRACE ? 16 * 8 * 4 * 8 : 0)];
+    [[maybe_unused]] int g_now = 0;
+    auto stamp = [&](int k) __attribute__((always_inline)) {
+        if constexpr (TRACE) {
+            if (blockIdx.x == 7 && g_now >= 64 && g_now < 80 && (threadIdx.x & 63) == 0)
+                reinterpret_cast<unsigned long long*>(smem + PP_LDS)[((g_now - 64) * 8 + (threadIdx.x >> 6)) * 4 + k] = __builtin_amdgcn_s_memtime();
+        }
+    };
     if (run_if && __builtin_amdgcn_readfirstlane((int)*run_if) == 0) return;  // whole grid: a guarded launch that is not needed
     const int lane = threadIdx.x & 63;
     const int wv = wave_id();
@@ -170,32 +187,82 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
             fbase[i] = qfrag + pp_uniform_i64(((int64_t)ql * nslab * 4 + 2 * (p & 1)) * 1024);  // hi fragments of block p & 1
         }
     }
-    auto issue_slab = [&]() __attribute__((always_inline)) {
-        if (cfeed) {
-            const uint32_t l = lds_base + (uint32_t)(f_slot * PP_CSLOT + 4 * grp * 1024);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) pp_dma<true>(l + i * 1024, fbase[i] + (int64_t)f_s * 1024, lane16);
-            if (++f_s == nslab) {  // past the end: re-fetch the last tile (keeps the vmcnt bookkeeping uniform)
-                f_s = 0;
-                if (f_tile + 1 < nt) { ++f_tile; feed_tile(f_tile); }
-            }
-            f_slot = f_slot + 1 == PP_DC ? 0 : f_slot + 1;
-        } else {
-            const uint32_t l = lds_base + (uint32_t)(PP_QOFF + f_slot * PP_QSLOT + (16 * grp + j0) * 1024);
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-                if (i < np) pp_dma<false>(l + i * 1024, fbase[i] + (int64_t)f_s * 4096, lane16);
-            if (++f_s == nslab) f_s = 0;
-            f_slot = f_slot + 1 == PP_DQ ? 0 : f_slot + 1;
+    // Piece i of the NEXT slab this wave fetches (i < np; wave-uniform), then issue_advance() once per slab.
+    auto issue_piece = [&](int i) __attribute__((always_inline)) {
+        if (i >= np) return;
+        if constexpr (DBG & 16) { if (cfeed) return; }
+        if constexpr (DBG & 32) { if (!cfeed) return; }
+        if (cfeed) pp_dma<true>(lds_base + (uint32_t)(f_slot * PP_CSLOT + (4 * grp + i) * 1024), fbase[i] + (int64_t)f_s * 1024, lane16);
+        else pp_dma<false>(lds_base + (uint32_t)(PP_QOFF + f_slot * PP_QSLOT + (16 * grp + j0 + i) * 1024), fbase[i] + (int64_t)f_s * 4096, lane16);
+    };
+    auto issue_advance = [&]() __attribute__((always_inline)) {
+        if (++f_s == nslab) {  // corpus: past the end re-fetch the last tile (keeps the vmcnt bookkeeping uniform)
+            f_s = 0;
+            if (cfeed && f_tile + 1 < nt) { ++f_tile; feed_tile(f_tile); }
         }
+        f_slot = f_slot + 1 == (cfeed ? PP_DC : PP_DQ) ? 0 : f_slot + 1;
+    };
+    auto issue_slab = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) issue_piece(i);
+        issue_advance();
+    };
+    // ---- FEED 1: waves 0-3 fetch query pieces 8 wv .. + 7 of slab g + 3, then corpus blocks 2 wv, 2 wv + 1 of slab g + 4 ----------
+    const bool feeder1 = wv < 4;
+    const char* qb1[8];
+    const char* cb1[2];
+    int fq_s = 0, fq_slot = 0, fc_s = 0, fc_tile = 0, fc_slot = 0;
+    auto feed1_tile = [&](int t) __attribute__((always_inline)) {
+        const int32_t b0 = ((org + t * PP_RT) >> 4) + 2 * (wv & 3);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int32_t blk = b0 + i;
+            blk = blk < last_blk ? blk : last_blk;
+            cb1[i] = planes + pp_uniform_i64((int64_t)blk * nslab * 1024);
+        }
+    };
+    if constexpr (FEED == 1) {
+        feed1_tile(0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = 8 * (wv & 3) + i;
+            int ql = p >> 1;
+            ql = ql < n_q ? ql : n_q - 1;
+            qb1[i] = qfrag + pp_uniform_i64(((int64_t)ql * nslab * 4 + 2 * (p & 1)) * 1024);
+        }
+    }
+    auto issue1_q = [&](int i) __attribute__((always_inline)) {
+        if (!feeder1) return;
+        pp_dma<false>(lds_base + (uint32_t)(PP_QOFF + fq_slot * PP_QSLOT + (8 * wv + i) * 1024), qb1[i] + (int64_t)fq_s * 4096, lane16);
+    };
+    auto advance1_q = [&]() __attribute__((always_inline)) {
+        if (++fq_s == nslab) fq_s = 0;
+        fq_slot = fq_slot + 1 == PP_DQ ? 0 : fq_slot + 1;
+    };
+    auto issue1_c = [&]() __attribute__((always_inline)) {
+        if (!feeder1) return;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) pp_dma<true>(lds_base + (uint32_t)(fc_slot * PP_CSLOT + (2 * wv + i) * 1024), cb1[i] + (int64_t)fc_s * 1024, lane16);
+    };
+    auto advance1_c = [&]() __attribute__((always_inline)) {
+        if (++fc_s == nslab) {
+            fc_s = 0;
+            if (fc_tile + 1 < nt) { ++fc_tile; feed1_tile(fc_tile); }
+        }
+        fc_slot = fc_slot + 1 == PP_DC ? 0 : fc_slot + 1;
     };
     // Wait until this wave's pieces of every slab but the newest `keep` have landed (+ `extra` newer stores).
     int st_pending = 0, st_slabs = 0;  // epilogue stores newer than DMAs this wave still has to certify: how many, for how many more slabs
     auto certify = [&]() __attribute__((always_inline)) {
         const int extra = st_slabs > 0 ? st_pending : 0;
-        if (cfeed) pp_wait_vm<(PP_DC - 2) * 4>(extra);
-        else if (np == 6) pp_wait_vm<(PP_DQ - 2) * 6>(extra);
-        else pp_wait_vm<(PP_DQ - 2) * 5>(extra);
+        if constexpr (FEED == 1) {
+            // queue, old -> new, at the end of slab g: .. Q(g+2) x8 | C(g+3) x2, Q(g+3) x8, C(g+4) x2: slab g + 2 is complete when 12 are left
+            if (feeder1) pp_wait_vm<12>(extra);
+        } else {
+            if (cfeed) pp_wait_vm<(PP_DC - 2) * 4>(extra);
+            else if (np == 6) pp_wait_vm<(PP_DQ - 2) * 6>(extra);
+            else pp_wait_vm<(PP_DQ - 2) * 5>(extra);
+        }
         if (st_slabs > 0) --st_slabs;
     };
 
@@ -240,11 +307,20 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
                      acc[1][1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(q[3]), pp_h(ef[A]), acc[1][1][A], 0, 0, 0);
                  }
                  read_slab(qn, std::integral_constant<int, A>{});
+                 // this wave's DMAs of slab g + D, one per step: in flight while it multiplies
+                 if constexpr (FEED == 1) issue1_q(A);
+                 else if constexpr (A < 6) issue_piece(A);
                  __builtin_amdgcn_sched_barrier(0);
              }()),
              ...);
         }(std::make_integer_sequence<int, PP_NBLK>{});
-        issue_slab();
+        if constexpr (FEED == 1) {
+            issue1_c();
+            advance1_q();
+            advance1_c();
+        } else {
+            issue_advance();
+        }
         c_slot = c_slot + 1 == PP_DC ? 0 : c_slot + 1;
         q_slot = q_slot + 1 == PP_DQ ? 0 : q_slot + 1;
     };
@@ -329,11 +405,27 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         // The stores are newer than every DMA issued so far (up to slab g + D): they count in the waits that certify slabs
         // g + 2 .. g + D, i.e. in this slab's wait and the next D - 2.
         st_pending = n_st;
-        st_slabs = n_st > 0 ? (cfeed ? PP_DC - 1 : PP_DQ - 1) : 0;
+        st_slabs = n_st > 0 ? (FEED == 1 ? 2 : (cfeed ? PP_DC - 1 : PP_DQ - 1)) : 0;
     };
 
     // ---- prologue: slabs 0 .. D - 1 of this wave's ring in flight; slab 0 landed -> its fragments; slab 1 landed ---------------
-    {
+    if constexpr (FEED == 1) {
+        if (feeder1) {  // Q(0..2), C(0..3): the steady state issues Q(g + 3), C(g + 4) during slab g
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) issue1_q(j);
+                advance1_q();
+            }
+            for (int i = 0; i < 4; ++i) { issue1_c(); advance1_c(); }
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        [&]<int... A>(std::integer_sequence<int, A...>) { (read_slab(qA, std::integral_constant<int, A>{}), ...); }
+        (std::make_integer_sequence<int, PP_NBLK>{});
+        c_slot = 1;
+        q_slot = 1;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        landed(qA);
+    } else {
         const int D = cfeed ? PP_DC : PP_DQ;
         for (int i = 0; i < D; ++i) issue_slab();
         if (cfeed) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PP_DC - 1) * 4) : "memory");
@@ -351,21 +443,31 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     // ---- main loop: two slabs per iteration (two static sets of query fragment registers) -----------------------------------------
     int c_s = 0, c_tile = 0;
     auto step = [&](f32x4 (&q)[4], f32x4 (&qn)[4]) __attribute__((always_inline)) {
+        stamp(0);
         slab(q, qn);
+        stamp(1);
         if (++c_s == nslab) {
             epilogue(c_tile);
             c_s = 0;
             ++c_tile;
         }
         certify();  // slab g + 2
+        stamp(2);
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // everybody has read slab g + 1; slab g + 2 is readable
         landed(qn);
+        stamp(3);
+        if constexpr (TRACE) ++g_now;
     };
     for (int g = 0; g < total; g += 2) {
         step(qA, qB);
         if (g + 1 < total) step(qB, qA);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
+    if constexpr (TRACE) {
+        __syncthreads();
+        if (blockIdx.x == 7 && trace)
+            for (int i = threadIdx.x; i < 16 * 8 * 4; i += blockDim.x) trace[i] = reinterpret_cast<unsigned long long*>(smem + PP_LDS)[i];
+    }
 }
 
 // n_q (1..16) queries `first .. first + n_q - 1` of a launch_query_planes buffer over `n_queries`, each nq (<= 32) vectors, against
@@ -382,15 +484,46 @@ int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void*
     const int64_t tiles = (n_rows + PP_RT - 1) / PP_RT;
     const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
     static const int dbg = std::getenv("RAGLITE_PP_DBG") ? std::atoi(std::getenv("RAGLITE_PP_DBG")) : 0;  // timing experiments only
-#define RL_PP_LAUNCH(DBG_)                                                                                                              \
-    hipLaunchKernelGGL(maxsim_pp_kernel<DBG_>, grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk, \
-                       chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if)
-    if (dbg == 1) RL_PP_LAUNCH(1);
-    else if (dbg == 2) RL_PP_LAUNCH(2);
-    else if (dbg == 3) RL_PP_LAUNCH(3);
-    else if (dbg == 10) RL_PP_LAUNCH(10);
-    else if (dbg == 11) RL_PP_LAUNCH(11);
-    else RL_PP_LAUNCH(0);
+#define RL_PP_LAUNCH(DBG_, DC_, DQ_, FEED_)                                                                                               \
+    hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, DC_, DQ_, FEED_>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, \
+                       n_q, row_to_chunk, chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if, trace)
+    static unsigned long long* trace = [] {
+        unsigned long long* p = nullptr;
+        if (std::getenv("RAGLITE_PP_TRACE")) { (void)hipMalloc(&p, 16 * 8 * 4 * 8); (void)hipMemset(p, 0, 16 * 8 * 4 * 8); }
+        return p;
+    }();
+    static const int feed = std::getenv("RAGLITE_PP_FEED") ? std::atoi(std::getenv("RAGLITE_PP_FEED")) : 0;  // A/B
+    if (trace && n_q == PP_QPP) {  // diagnostic build: dump the 10th launch's slab timeline to stderr
+        static int calls = 0;
+        if (feed == 1) RL_PP_LAUNCH(64, 4, 3, 1);
+        else RL_PP_LAUNCH(64, 6, 3, 0);
+        if (++calls == 10) {
+            static unsigned long long h[16 * 8 * 4];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
+            fprintf(stderr, "PPTRACE columns: top-of-slab after-steps after-feeder-wait after-barrier (shader cycles, relative)\n");
+            for (int g = 0; g < 16; ++g)
+                for (int w = 0; w < 8; ++w) {
+                    fprintf(stderr, "PPTRACE slab %d wave %d:", g + 64, w);
+                    for (int k = 0; k < 4; ++k) fprintf(stderr, " %7lld", (long long)(h[(g * 8 + w) * 4 + k] - h[0]));
+                    fprintf(stderr, "\n");
+                }
+        }
+        RL_HIP(hipGetLastError());
+        return RL_OK;
+    }
+    if (feed == 1) {
+        if (dbg == 11) RL_PP_LAUNCH(11, 4, 3, 1);
+        else if (dbg == 2) RL_PP_LAUNCH(2, 4, 3, 1);
+        else RL_PP_LAUNCH(0, 4, 3, 1);
+    }
+    else if (dbg == 1) RL_PP_LAUNCH(1, 6, 3, 0);
+    else if (dbg == 2) RL_PP_LAUNCH(2, 6, 3, 0);
+    else if (dbg == 11) RL_PP_LAUNCH(11, 6, 3, 0);
+    else if (dbg == 59) RL_PP_LAUNCH(59, 6, 3, 0);
+    else if (dbg == 48) RL_PP_LAUNCH(48, 6, 3, 0);
+    else if (dbg == 49) RL_PP_LAUNCH(49, 6, 3, 0);
+    else RL_PP_LAUNCH(0, 6, 3, 0);
 #undef RL_PP_LAUNCH
     RL_HIP(hipGetLastError());
     return RL_OK;

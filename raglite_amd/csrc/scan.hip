@@ -291,19 +291,14 @@ int launch_cast_f16(const float* src, uint16_t* dst, int64_t count, hipStream_t 
     return RL_OK;
 }
 
-__global__ __launch_bounds__(256) void cast_f16_rtz_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t groups, float scale,
-                                                            int rne) {
+// dst = fp16(src * scale), rounded to nearest even: the HI plane of an fp32 corpus (api.hip: refresh_hi_plane)
+__global__ __launch_bounds__(256) void cast_f16_scaled_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t groups, float scale) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-    auto pk = [&](float x, float y) -> uint32_t {  // rne: experimental (RAGLITE_HI_RNE=1), see presplit_hi_rows_kernel
+    auto pk = [&](float x, float y) -> uint32_t {
         uint32_t w;
-        if (rne) {
-            const h2 t = (h2){(_Float16)(x * scale), (_Float16)(y * scale)};
-            __builtin_memcpy(&w, &t, 4);
-        } else {
-            const auto t = __builtin_amdgcn_cvt_pkrtz(x * scale, y * scale);
-            __builtin_memcpy(&w, &t, 4);
-        }
+        const h2 t = (h2){(_Float16)(x * scale), (_Float16)(y * scale)};
+        __builtin_memcpy(&w, &t, 4);
         return w;
     };
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -315,12 +310,12 @@ __global__ __launch_bounds__(256) void cast_f16_rtz_kernel(const float* __restri
     }
 }
 
-int launch_cast_f16_rtz(const float* src, uint16_t* dst, int64_t count, float scale, hipStream_t s, bool rne) {
+int launch_cast_f16_scaled(const float* src, uint16_t* dst, int64_t count, float scale, hipStream_t s) {
     if (count <= 0) return RL_OK;
     if (count % 8 || (reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(dst) & 15)) return RL_ERR_UNSUPPORTED;
     const int64_t groups = count / 8;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((groups + 255) / 256, 8192));
-    hipLaunchKernelGGL(cast_f16_rtz_kernel, dim3(blocks), dim3(256), 0, s, src, dst, groups, scale, rne ? 1 : 0);
+    hipLaunchKernelGGL(cast_f16_scaled_kernel, dim3(blocks), dim3(256), 0, s, src, dst, groups, scale);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -24,7 +24,6 @@ namespace rl {
 
 constexpr int CNT_SEL = HIST_BINS + 0;   // counters live right after the bins
 constexpr int CNT_CAND = HIST_BINS + 1;
-constexpr int CNT_DONE = HIST_BINS + 2;  // topk_filter_final_kernel: blocks of the query that have filtered
 constexpr int HIST_STRIDE = HIST_BINS + 8;
 constexpr int RANK_MAX = 1024;        // up to this many keys are ordered by counting instead of a bitonic network
 
@@ -283,7 +282,7 @@ __device__ __forceinline__ void write_results(const uint64_t* sorted, int n_vali
     }
 }
 
-// LDS of the final step (56 KiB), shared by topk_final_kernel and topk_filter_final_kernel.
+// LDS of the final step (56 KiB).
 struct FinalLds {
     uint64_t buf[CAND_CAP];   // 32 KiB: candidate sort, then reused as the result sort buffer
     uint64_t fin[K_MAX];      // 16 KiB
@@ -436,61 +435,6 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restric
     topk_final_body(scores, n, ld, k, ws_hist, ws_sel, ws_cand, out_scores, out_ids, (int)blockIdx.x, L);
 }
 
-// Filter AND final step in one launch (opt-in experiment, see launch_topk: it measured slower), for the few-query searches whose
-// selection is launch-latency (B = 1 over 1 M scores: filter 8 us + final 8 us, of which the work is a fraction): the blocks of a query filter as topk_filter_kernel does, then
-// take a ticket; the block that draws the last one has everybody's `sel` / `cand` entries in memory -- every thread fences
-// its stores before the block's ticket, the last block fences again before it reads (the threadFenceReduction pattern:
-// release / acquire at agent scope, which on this chip also writes back and invalidates the XCDs' non-coherent L2s) -- and
-// runs the final step.  Same results, same bits, as the two kernels.
-__global__ __launch_bounds__(1024) void topk_filter_final_kernel(const float* __restrict__ scores, int64_t n, int64_t ld, int32_t k,
-                                                                  uint32_t* __restrict__ ws_hist, uint64_t* __restrict__ ws_sel,
-                                                                  uint64_t* __restrict__ ws_cand, float* __restrict__ out_scores,
-                                                                  int32_t* __restrict__ out_ids) {
-    __shared__ FinalLds L;
-    __shared__ uint32_t ticket_sh;
-    const int q = blockIdx.y;
-    uint32_t* g = ws_hist + (int64_t)q * HIST_STRIDE;
-    for (int i = threadIdx.x; i < HIST_BINS; i += 1024) L.h[i] = g[i];
-    __syncthreads();
-    const uint32_t need = (uint32_t)std::min<int64_t>(k, n);
-    find_threshold_bin(L.h, HIST_BINS, need, L.scratch, L.thr);
-    const uint32_t bstar = L.thr[0];
-    const float* s = scores + (int64_t)q * ld;
-    uint64_t* sel = ws_sel + (int64_t)q * K_MAX;
-    uint64_t* cand = ws_cand + (int64_t)q * CAND_CAP;
-    const int64_t stride = (int64_t)gridDim.x * 1024;
-    auto visit = [&](float v, int64_t i) {
-        const uint32_t bin = score_key(v) >> 21;
-        if (bin > bstar) {
-            const uint32_t p = atomicAdd(&g[CNT_SEL], 1u);
-            if (p < (uint32_t)K_MAX) sel[p] = make_key64(v, (uint32_t)i);
-        } else if (bin == bstar) {
-            const uint32_t p = atomicAdd(&g[CNT_CAND], 1u);
-            if (p < (uint32_t)CAND_CAP) cand[p] = make_key64(v, (uint32_t)i);
-        }
-    };
-    if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0) {
-        typedef float f4 __attribute__((ext_vector_type(4)));
-        const f4* s4 = reinterpret_cast<const f4*>(s);
-        const int64_t n4 = n >> 2;
-        for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n4; i += stride) {
-            const f4 v = __builtin_nontemporal_load(s4 + i);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) visit(v[u], (i << 2) + u);
-        }
-        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) visit(s[(n4 << 2) + threadIdx.x], (n4 << 2) + threadIdx.x);
-    } else {
-        for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n; i += stride) visit(s[i], i);
-    }
-    __threadfence();  // this thread's sel / cand entries are out before the block's ticket is
-    __syncthreads();
-    if (threadIdx.x == 0) ticket_sh = atomicAdd(&g[CNT_DONE], 1u);
-    __syncthreads();
-    if (ticket_sh != gridDim.x - 1) return;  // (block-uniform)
-    __threadfence();  // the last block: everybody else's entries are visible from here on
-    topk_final_body(scores, n, ld, k, ws_hist, ws_sel, ws_cand, out_scores, out_ids, q, L);
-}
-
 int select_workspace_reserve(SelectWorkspace& ws, int32_t nq, hipStream_t s) {
     if (nq > ws.capacity_queries) {
         select_workspace_free(ws);
@@ -541,26 +485,14 @@ int launch_topk(const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t 
         RL_TRY(select_workspace_reserve(ws, nq, s));
     }
     ws.dirty = true;
-    // Opt-in (RAGLITE_FILTER_FINAL=1): measured at B = 1 over 1 M scores the one-launch version is SLOWER, 0.628 / 0.679 ms
-    // per query against 0.613 / 0.662 ms with two launches on the same boxes -- the agent-scope release / acquire of the
-    // last-block pattern (buffer_wbl2 + buffer_inv on eight non-coherent L2s) costs more than the launch it saves.
-    static const bool fuse_env = std::getenv("RAGLITE_FILTER_FINAL") != nullptr;
-    const bool fuse = n > 0 && nq <= 4 && !run_if && fuse_env;
+    // (Filter and final step as ONE launch by the last-block pattern measured slower at B = 1 over 1 M scores -- 0.628 / 0.679 ms per
+    // query against 0.613 / 0.662 ms: the agent-scope release / acquire costs more than the launch it saves -- and was removed in round 3.)
     if (n > 0) {
         const int bx = hist_grid(n, nq);
         if (!have_hist) hipLaunchKernelGGL(topk_hist_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, ws.hist, run_if);
-        if (fuse) {
-            const int bf = (int)std::max<int64_t>(1, std::min<int64_t>((n + 16383) / 16384, 256));
-            hipLaunchKernelGGL(topk_filter_final_kernel, dim3(bf, nq), dim3(1024), 0, s, scores, n, ld, k, ws.hist, ws.sel, ws.cand,
-                               out_scores, out_ids);
-        } else {
-            hipLaunchKernelGGL(topk_filter_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, k, ws.hist, ws.sel,
-                               ws.cand, run_if);
-        }
+        hipLaunchKernelGGL(topk_filter_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, k, ws.hist, ws.sel, ws.cand, run_if);
     }
-    if (!fuse)
-        hipLaunchKernelGGL(topk_final_kernel, dim3(nq), dim3(1024), 0, s, scores, n, ld, k, ws.hist, ws.sel, ws.cand,
-                           out_scores, out_ids, run_if);
+    hipLaunchKernelGGL(topk_final_kernel, dim3(nq), dim3(1024), 0, s, scores, n, ld, k, ws.hist, ws.sel, ws.cand, out_scores, out_ids, run_if);
     RL_HIP(hipGetLastError());
     ws.dirty = false;  // every row this selection touched is zero again once the final kernel has run
     return RL_OK;

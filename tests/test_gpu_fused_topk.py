@@ -50,7 +50,8 @@ def test_fused_equals_dense_path_bitwise(metric, n, dim, B, k):
     E = oracle.synth_matrix(7000 + n, n, dim)
     Q = oracle.synth_matrix(7100 + B, B, dim)
     idx = raglite_amd.DeviceIndex(E, metric=metric)
-    S, R = idx.search_rows(Q, k)
+    with _env(RAGLITE_NO_FUSED_HI="1"):  # (the 70 000 x 1024 case keeps a HI image: its default is the fused top-k over THAT, tested below)
+        S, R = idx.search_rows(Q, k)
     with _env(RAGLITE_NO_FUSED_TOPK="1"):
         S0, R0 = idx.search_rows(Q, k)
     assert np.array_equal(R, R0)
@@ -167,24 +168,22 @@ def test_f16_storage_big_batch_over_the_image(metric):
     idx.close()
 
 
-# ---- experimental: the fused top-k over the HI image at one MFMA product per multiply (api.hip search_rows_fused_hi) -----------------
-# Opt-in (RAGLITE_FUSED_HI=1), built at the end of round 2 without GPU time left to run it; these tests run with
-# RAGLITE_TEST_EXPERIMENTAL=1 (scripts/r3_experiments.sh).  Needs a HI image: an fp32 corpus of >= 64 M elements.
-_experimental = pytest.mark.skipif(os.environ.get("RAGLITE_TEST_EXPERIMENTAL", "0") in ("", "0"),
-                                   reason="experimental switches: set RAGLITE_TEST_EXPERIMENTAL=1")
+# ---- the fused top-k over the HI image at one MFMA product per multiply (api.hip search_rows_fused_hi): the default for big batches over
+# an fp32 corpus of >= 64 M elements (it keeps a HI image) since round 3; RAGLITE_NO_FUSED_HI=1 restores the fused top-k over the
+# pre-split image, RAGLITE_NO_FUSED_TOPK=1 the dense path. ------------------------------------------------------------------------------
 
 
-@_experimental
 @pytest.mark.parametrize("metric", ["cosine", "dot"])
-@pytest.mark.parametrize("two_products", ["0", "1"])
-def test_fused_hi_float_data(metric, two_products):
+def test_fused_hi_float_data(metric):
     n, dim, B, k = 70_000, 1024, 130, 100
     E = oracle.synth_matrix(7300, n, dim)
     Q = oracle.synth_matrix(7301, B, dim)
     idx = raglite_amd.DeviceIndex(E, metric=metric)
-    with _env(RAGLITE_FUSED_HI="1", RAGLITE_FUSED_HI_TWO_PRODUCTS=two_products):
-        S, R = idx.search_rows(Q, k)
-    S0, R0 = idx.search_rows(Q, k)  # the shipped fused top-k over the pre-split image
+    S, R = idx.search_rows(Q, k)
+    assert idx.filter_stats()["kind"] == "rows_fused_hi" and not idx.filter_stats()["fallback"]
+    with _env(RAGLITE_NO_FUSED_HI="1"):
+        S0, R0 = idx.search_rows(Q, k)  # the fused top-k over the pre-split image (three products)
+    assert idx.filter_stats()["kind"] == "rows_fused"
     for b in range(0, B, 13):
         tol = _tol(E, Q[b], metric)
         assert_topk_close(S[b], R[b], oracle.similarity(E, Q[b], metric), k, tol)
@@ -193,15 +192,13 @@ def test_fused_hi_float_data(metric, two_products):
     idx.close()
 
 
-@_experimental
 @pytest.mark.parametrize("metric", ["cosine", "dot"])
 def test_fused_hi_integer_ties_bit_exact(metric):
     n, dim, B, k = 70_000, 1024, 100, 64
     E = oracle.synth_matrix(7400, n, dim, "small_int")
     Q = oracle.synth_matrix(7401, B, dim, "small_int")
     idx = raglite_amd.DeviceIndex(E, metric=metric)
-    with _env(RAGLITE_FUSED_HI="1"):
-        S, R = idx.search_rows(Q, k)
+    S, R = idx.search_rows(Q, k)
     for b in (0, 1, 50, 99):
         es, ei = oracle.topk_desc(sim_fp32_exact(E, Q[b], metric), k)
         assert np.array_equal(R[b], ei)
@@ -210,7 +207,6 @@ def test_fused_hi_integer_ties_bit_exact(metric):
     idx.close()
 
 
-@_experimental
 def test_fused_hi_near_duplicates_fall_back():
     """3 000 rows within 1e-5 of each other at the top of every ranking: more rows inside the error band than a re-scoring list
     holds -> the device flag -> the dense full-precision path answers, bit for bit what it answers without the switch."""
@@ -221,8 +217,8 @@ def test_fused_hi_near_duplicates_fall_back():
     hot = rng.choice(n, 3000, replace=False)
     E[hot] = (Q.sum(axis=0)[None, :] + 1e-5 * rng.standard_normal((3000, dim))).astype(np.float32)
     idx = raglite_amd.DeviceIndex(E, metric="dot")
-    with _env(RAGLITE_FUSED_HI="1"):
-        S, R = idx.search_rows(Q, k)
+    S, R = idx.search_rows(Q, k)
+    assert idx.filter_stats()["kind"] == "rows_fused_hi" and idx.filter_stats()["fallback"]
     with _env(RAGLITE_NO_FUSED_TOPK="1"):
         S0, R0 = idx.search_rows(Q, k)
     assert np.array_equal(R, R0) and np.array_equal(S.view(np.uint32), S0.view(np.uint32))

@@ -103,23 +103,19 @@ def test_near_identical_chunks_defeat_the_bound_and_the_full_passes_answer():
 
 
 # ---- switches ----------------------------------------------------------------------------------------------------------------------
-# RAGLITE_HI_RNE=1 (read when an index is created; opt-in): HI halves rounded to nearest instead of toward zero -- the bound's e_lo
-# term halves.  RAGLITE_HI_ONE_PRODUCT (read per call; "1" is the default since the end of round 2, "0" = two products): the
-# approximate pass multiplies q_hi . e_hi only -- a plain fp16 GEMM -- and the bound carries what the queries' hi halves drop.
-# Results must not change under any combination.  Run with RAGLITE_TEST_EXPERIMENTAL=1 (scripts/r3_experiments.sh).
-_experimental = pytest.mark.skipif(os.environ.get("RAGLITE_TEST_EXPERIMENTAL", "0") in ("", "0"),
-                                   reason="experimental switches: set RAGLITE_TEST_EXPERIMENTAL=1")
+# RAGLITE_HI_ONE_PRODUCT (read per call; "1" is the default, "0" = two products: q_hi . e_hi + q_lo . e_hi through the eight-query
+# kernel): the approximate pass multiplies q_hi . e_hi only -- a plain fp16 GEMM -- and the bound carries what the queries' hi halves
+# drop.  RAGLITE_NO_PP=1: the one-product pass through the eight-query kernel instead of maxsim_pp.hip.  Results must not change.
 
 
-@_experimental
-@pytest.mark.parametrize("rne,one", [("1", "0"), ("0", "1"), ("1", "1")])
-def test_experimental_switches_integer_bit_exact(rne, one):
+@pytest.mark.parametrize("one,nopp", [("0", "0"), ("1", "1"), ("1", "0")])
+def test_switches_integer_bit_exact(one, nopp):
     nq, n_queries, k = 32, 9, 100
     rng = np.random.default_rng(77)
     off = ragged_offsets(rng, N, 1, 15)
     E = oracle.synth_matrix(10_600, N, DIM, "small_int")
     Qb = np.stack([oracle.synth_matrix(10_700 + i, nq, DIM, "small_int") for i in range(n_queries)])
-    with _env(RAGLITE_HI_RNE=rne, RAGLITE_HI_ONE_PRODUCT=one):
+    with _env(RAGLITE_HI_ONE_PRODUCT=one, RAGLITE_NO_PP=nopp):
         idx = raglite_amd.DeviceIndex(E, off, metric="dot")
         bs, bc = idx.maxsim_topk_batch(Qb, k)
     for i in (0, 4, 8):
@@ -129,18 +125,17 @@ def test_experimental_switches_integer_bit_exact(rne, one):
     idx.close()
 
 
-@_experimental
-@pytest.mark.parametrize("rne,one", [("1", "0"), ("0", "1"), ("1", "1")])
-def test_experimental_switches_float_data(rne, one):
+@pytest.mark.parametrize("one,nopp", [("0", "0"), ("1", "1"), ("1", "0")])
+def test_switches_float_data(one, nopp):
     rng = np.random.default_rng(78)
     off = ragged_offsets(rng, N, 1, 15)
     E = oracle.synth_matrix(10_800, N, DIM)
     Qb = np.stack([oracle.synth_matrix(10_900 + i, 32, DIM) for i in range(9)])
     k = 100
-    with _env(RAGLITE_HI_RNE=rne, RAGLITE_HI_ONE_PRODUCT=one):
+    with _env(RAGLITE_HI_ONE_PRODUCT=one, RAGLITE_NO_PP=nopp):
         idx = raglite_amd.DeviceIndex(E, off, metric="dot")
         bs, bc = idx.maxsim_topk_batch(Qb, k)
-        s1, r1 = idx.search_rows(Qb[0, 0], 50)  # the single-query half-bytes search reads the same (RNE) halves and norms
+        s1, r1 = idx.search_rows(Qb[0, 0], 50)  # the single-query half-bytes search reads the same halves and norms
     with _env(RAGLITE_NO_HI_MAXSIM="1", RAGLITE_NO_HI_SEARCH="1"):
         fs, fc = idx.maxsim_topk_batch(Qb, k)
         s0, r0 = idx.search_rows(Qb[0, 0], 50)
@@ -153,17 +148,16 @@ def test_experimental_switches_float_data(rne, one):
     idx.close()
 
 
-@_experimental
-def test_experimental_one_product_fallback_on_near_identical_chunks():
+def test_one_product_fallback_on_near_identical_chunks():
     rng = np.random.default_rng(79)
     off = np.arange(N + 1, dtype=np.int64)
     E = oracle.synth_matrix(11_000, N, DIM)
     Qb = np.stack([oracle.synth_matrix(11_100 + i, 8, DIM) for i in range(4)])
     hot = rng.choice(N, 4000, replace=False)
     E[hot] = (3.0 * Qb[:, 0].sum(axis=0)[None, :] + 1e-4 * rng.standard_normal((4000, DIM))).astype(np.float32)
-    with _env(RAGLITE_HI_RNE="1", RAGLITE_HI_ONE_PRODUCT="1"):
-        idx = raglite_amd.DeviceIndex(E, off, metric="dot")
-        bs, bc = idx.maxsim_topk_batch(Qb, 100)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    bs, bc = idx.maxsim_topk_batch(Qb, 100)
+    assert idx.filter_stats()["fallback"]
     with _env(RAGLITE_NO_HI_MAXSIM="1"):
         fs, fc = idx.maxsim_topk_batch(Qb, 100)
     assert np.array_equal(bc, fc) and np.array_equal(bs.view(np.uint32), fs.view(np.uint32))

@@ -75,7 +75,7 @@ def test_maxsim_chunk_bound():
 
 
 def _split_hi_rne(E: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
-    """The experimental rounding of the HI halves (RAGLITE_HI_RNE=1): fp16(e * scale) rounded to NEAREST even."""
+    """The rounding of the HI halves as the index builds them (since round 3): fp16(e * scale) rounded to NEAREST even."""
     mx = float(np.abs(E).max())
     scale = 2.0 ** (14 - int(np.floor(np.log2(mx)) + 1)) if mx > 0 else 1.0
     hi = (E.astype(np.float64) * scale).astype(np.float16).astype(np.float64) / scale
