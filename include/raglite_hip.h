@@ -214,8 +214,7 @@ int rl_maxsim_topk_batch(rl_index* index, const float* query_vecs, int32_t n_que
 /* rl_maxsim_approx_scores: the FIRST stage of rl_maxsim_topk_batch's bound-filtered pipeline on its own, for tests and for
  * callers that want the bound: the approximate MaxSim score of every (query, chunk) from the hi halves of corpus and queries
  * (one fp16 MFMA product per multiply; `kernel` = 0: the sixteen-queries-per-pass kernel of maxsim_pp.hip, 1: the
- * eight-queries-per-pass kernel of maxsim_gemm.hip, 2: the eight-queries-per-pass, two-row-stream kernel of maxsim_pp.hip -- the same
- * sums in the same order), and per query the rigorous bound
+ * eight-queries-per-pass kernel of maxsim_gemm.hip -- the same sums in the same order), and per query the rigorous bound
  * m with |approximate - exact| <= m for EVERY chunk that rl_maxsim_topk_batch's candidate window (2 m) is built on.
  *   query_vecs [n_queries x nq x dim] f32, nq <= 32;  out_scores [n_queries x n_chunks] f32 (tombstoned chunks included: no mask),
  *   out_bound [n_queries] f32 or NULL.  RL_ERR_UNSUPPORTED when the index keeps no HI image (small / fp16-stored / exact-fp32
@@ -343,7 +342,7 @@ int rl_index_filter_stats(rl_index* index, int64_t out[6], void* stream);
  * RL_ERR_UNSUPPORTED when the index has none), 5 = the approximate eight-query MaxSim pass over the HI image
  * (as kind 3) with two MFMA products per multiply, 6 = the same pass with one,
  * 7 = the SIXTEEN-queries-per-pass kernel over the HI image, one product (maxsim_pp.hip: what rl_maxsim_topk_batch runs by default;
-* sixteen queries of nq / 16 vectors each), 8 = maxsim_pp.hip's eight-queries-per-pass kernel with two row streams per workgroup.
+ * sixteen queries of nq / 16 vectors each).
  * Used so that roofline.achieved is measured with HIP
  * events on the stream the kernel runs on. */
 int rl_time_kernel(rl_index* index, int kind, const float* query_vecs_dev, int32_t nq, int32_t iters,

@@ -243,7 +243,8 @@ def distance(E: np.ndarray, q: np.ndarray, metric: str = "cosine", dtype=np.floa
     TWO roots and a product, because ||e|| is precomputed per row when the index is built.  In IEEE arithmetic the two
     forms differ by the roundings of one extra sqrt and one multiply: at most 1.5 ulp of the denominator, i.e. <= 2 ulp
     (2.4e-7 relative) of the similarity -- three orders of magnitude inside the 1e-4 bar, and it cannot change a ranking
-    of scores that differ by more than that.  On integer-valued data with perfect-square norms both forms are exact."""
+    of scores that differ by more than that.  On integer-valued data with perfect-square norms both forms are exact.
+    `distance_duckdb_fp32` below restates DuckDB's own formulation in float32 so that the gap is MEASURED, not argued."""
     E = np.asarray(E, dtype=dtype)
     q = np.asarray(q, dtype=dtype)
     if metric == "cosine":
@@ -254,6 +255,50 @@ def distance(E: np.ndarray, q: np.ndarray, metric: str = "cosine", dtype=np.floa
     if metric == "l2":
         return np.linalg.norm(E - q[None, :], axis=1)
     raise ValueError(f"Unsupported metric: {metric}")
+
+
+def _seq_dot_f32(A: np.ndarray, B: np.ndarray) -> np.ndarray:
+    """sum_k A[:, k] * B[:, k] accumulated in ELEMENT ORDER in float32 (acc += x * y, one rounding per product and per add, as a scalar
+    C++ loop over `float` without FMA contraction computes it)."""
+    acc = np.zeros(A.shape[0], dtype=np.float32)
+    for k in range(A.shape[1]):
+        acc = (acc + (A[:, k] * B[:, k]).astype(np.float32)).astype(np.float32)
+    return acc
+
+
+def distance_duckdb_fp32(E: np.ndarray, q: np.ndarray, metric: str = "cosine") -> np.ndarray:
+    """The as-computed variant for a6 in DuckDB's own formulation -- parity stays UNPINNED (DuckDB >= 1.1.3 is the reference's
+    dependency, `pyproject.toml`, absent from /root/reference and from this image; what follows restates its published
+    `array_cosine_distance` / `array_negative_inner_product` / `array_distance` for FLOAT[d], the functions the reference's SQL calls at
+    `src/raglite/_typing.py:123-134`): everything in float32, one pass over the elements in order,
+        cosine  1 - clamp(dot / sqrt(norm_a * norm_b), -1, 1)     ONE square root of the product of the squared norms, clamped
+        dot     -(dot)                                            (array_negative_inner_product)
+        l2      sqrt(sum (a_i - b_i)^2)
+    DuckDB may vectorise the loop (another summation order, same bound); the element-order sum is the canonical scalar form.  This
+    function exists to MEASURE how far the formulation used by this repository (`distance(..., np.float32)`: two roots and a product,
+    pairwise / blocked sums) is from it -- tests/test_oracle_props.py bounds the gap in float32 ulps on fp16-rounded unit rows (what
+    RAGLite stores, `_embed.py:138-140`), tests/test_gpu_parity.py holds the kernels to that bound + 2 ulp."""
+    E = np.ascontiguousarray(E, dtype=np.float32)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    Q = np.broadcast_to(q[None, :], E.shape)
+    one = np.float32(1.0)
+    if metric == "cosine":
+        dot, na, nb = _seq_dot_f32(E, Q), _seq_dot_f32(E, E), _seq_dot_f32(Q, Q)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            sim = (dot / np.sqrt((na * nb).astype(np.float32)).astype(np.float32)).astype(np.float32)
+        sim = np.where(np.isnan(sim), sim, np.clip(sim, np.float32(-1.0), one)).astype(np.float32)
+        return (one - sim).astype(np.float32)
+    if metric == "dot":
+        return (-_seq_dot_f32(E, Q)).astype(np.float32)
+    if metric == "l2":
+        D = (E - Q).astype(np.float32)
+        return np.sqrt(_seq_dot_f32(D, D)).astype(np.float32)
+    raise ValueError(f"Unsupported metric: {metric}")
+
+
+def similarity_duckdb_fp32(E: np.ndarray, q: np.ndarray, metric: str = "cosine") -> np.ndarray:
+    """`sim = 1.0 - dist` (`_search.py:72`) over `distance_duckdb_fp32`, in float32 (DuckDB FLOAT arithmetic)."""
+    return (np.float32(1.0) - distance_duckdb_fp32(E, q, metric)).astype(np.float32)
 
 
 def similarity(E: np.ndarray, q: np.ndarray, metric: str = "cosine", dtype=np.float64) -> np.ndarray:

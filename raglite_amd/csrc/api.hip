@@ -1707,19 +1707,11 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
                 float* es = reinterpret_cast<float*>(ci + (size_t)n_gemm * cap); // [n x cap] their exact scores
                 RL_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), s));
                 RL_HIP(hipMemsetAsync(ci, 0xff, (size_t)n_gemm * cap * sizeof(int32_t), s));  // unused slots: -1 = "no chunk"
-                // One product: the passes go through maxsim_pp.hip (dim >= 256) -- RAGLITE_PP_KERNEL (read per call) = 2: eight queries per
-                // pass, two row streams per workgroup, the waves of a SIMD in alternating phases (maxsim_pp2_kernel); 1: sixteen queries
-                // per pass (maxsim_pp_kernel); RAGLITE_NO_PP=1: the eight-query pass of maxsim_gemm.hip (A/B, and what two products use).
+                // One product: SIXTEEN queries per pass through maxsim_pp.hip (dim >= 256; RAGLITE_NO_PP=1, read per call: the
+                // eight-query pass of maxsim_gemm.hip instead -- A/B, and what two products still use).
                 const char* nopp_env = std::getenv("RAGLITE_NO_PP");
-                const char* ppk_env = std::getenv("RAGLITE_PP_KERNEL");
-                const int ppk = ppk_env && ppk_env[0] ? std::atoi(ppk_env) : PP_DEFAULT_KERNEL;
                 const bool pp = one_product && idx->dim >= 256 && !(nopp_env && nopp_env[0] && nopp_env[0] != '0');
-                for (int32_t b = 0; pp && ppk == 2 && b < n_gemm; b += 8) {
-                    const int32_t n_q = std::min<int32_t>(8, n_gemm - b);
-                    RL_TRY(launch_maxsim_pp2(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
-                                             idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale));
-                }
-                for (int32_t b = 0; pp && ppk != 2 && b < n_gemm; b += PP_PASS_QUERIES) {
+                for (int32_t b = 0; pp && b < n_gemm; b += PP_PASS_QUERIES) {
                     const int32_t n_q = std::min<int32_t>(PP_PASS_QUERIES, n_gemm - b);
                     RL_TRY(launch_maxsim_pp(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
                                             idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale));
@@ -1804,13 +1796,13 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
 int rl_maxsim_approx_scores(rl_index* idx, const float* query_vecs, int32_t n_queries, int32_t nq, int kernel, float* out_scores,
                             float* out_bound, int mem, void* stream) {
     if (!idx) return fail(RL_ERR_INVALID, "rl_maxsim_approx_scores: null index");
-    if (n_queries < 0 || nq < 1 || kernel < 0 || kernel > 2) return fail(RL_ERR_INVALID, "rl_maxsim_approx_scores: bad arguments");
+    if (n_queries < 0 || nq < 1 || (kernel != 0 && kernel != 1)) return fail(RL_ERR_INVALID, "rl_maxsim_approx_scores: bad arguments");
     if (n_queries == 0) return RL_OK;
     if (!query_vecs || !out_scores) return fail(RL_ERR_INVALID, "rl_maxsim_approx_scores: null argument");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
     RL_TRY(use_scratch(idx, s));
-    if (!hi_image_valid(idx) || nq > 32 || (kernel != 1 && idx->dim < 256))
+    if (!hi_image_valid(idx) || nq > 32 || (kernel == 0 && idx->dim < 256))
         return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_approx_scores: this index keeps no HI image (or nq > 32 / dim < 256)");
     DevBuf t_q, t_o, t_b;
     const float* d_q; float* d_o; float* d_b = nullptr;
@@ -1821,13 +1813,10 @@ int rl_maxsim_approx_scores(rl_index* idx, const float* query_vecs, int32_t n_qu
     if (out_bound) RL_TRY(stage_out_begin(out_bound, (size_t)n_queries, mem, t_b, &d_b));
     RL_TRY(idx->qplanes.reserve(query_planes_bytes(idx->dim, n_queries)));
     RL_TRY(launch_query_planes(d_q, idx->dim, nq, (int64_t)q_elems, n_queries, idx->qplanes.p, s));
-    const int32_t per = kernel == 0 ? PP_PASS_QUERIES : GEMM_PASS_QUERIES;  // (kernel 2: eight, like kernel 1)
+    const int32_t per = kernel == 0 ? PP_PASS_QUERIES : GEMM_PASS_QUERIES;
     for (int32_t b = 0; b < n_queries; b += per) {
         const int32_t n_q = std::min<int32_t>(per, n_queries - b);
-        if (kernel == 2)
-            RL_TRY(launch_maxsim_pp2(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk, idx->offsets,
-                                     idx->ends.as<uint32_t>(), d_o + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale));
-        else if (kernel == 0)
+        if (kernel == 0)
             RL_TRY(launch_maxsim_pp(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk, idx->offsets,
                                     idx->ends.as<uint32_t>(), d_o + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale));
         else
@@ -2014,7 +2003,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     const int64_t ldc = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
     if (kind == 0) RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));
     else if (kind == 2) RL_TRY(idx->scores.reserve((size_t)2 * ldc * sizeof(float)));
-    else if (kind == 3 || kind == 5 || kind == 6 || kind == 8) RL_TRY(idx->scores.reserve((size_t)GEMM_PASS_QUERIES * ldc * sizeof(float)));
+    else if (kind == 3 || kind == 5 || kind == 6) RL_TRY(idx->scores.reserve((size_t)GEMM_PASS_QUERIES * ldc * sizeof(float)));
     else if (kind == 7) RL_TRY(idx->scores.reserve((size_t)PP_PASS_QUERIES * ldc * sizeof(float)));
     else RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)nq * ld * sizeof(float), 16)));
     hipEvent_t e0, e1;
@@ -2025,7 +2014,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
         st = pairs_prepare(idx, q_dev, nq / 2, (int64_t)(nq / 2) * idx->dim, 2, s);
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the pair kernel does not apply to this index / shape") : st; }
     }
-    if (kind == 3 || kind == 5 || kind == 6 || kind == 8) {  // eight queries of nq / 8 vectors each
+    if (kind == 3 || kind == 5 || kind == 6) {  // eight queries of nq / 8 vectors each
         st = gemm_prepare(idx, q_dev, nq / GEMM_PASS_QUERIES, (int64_t)(nq / GEMM_PASS_QUERIES) * idx->dim, GEMM_PASS_QUERIES, s);
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the eight-query kernel does not apply to this index / shape") : st; }
     }
@@ -2036,12 +2025,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     }
     RL_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < iters && st == RL_OK; ++i) {
-        if (kind == 8) st = (hi_image_valid(idx) && idx->dim >= 256)
-                                 ? launch_maxsim_pp2(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, GEMM_PASS_QUERIES, 0, GEMM_PASS_QUERIES,
-                                                     nq / GEMM_PASS_QUERIES, idx->row_to_chunk, idx->offsets, idx->ends.as<uint32_t>(), idx->scores.as<float>(),
-                                                     ldc, idx->n_cu, s, idx->split_scale)
-                                 : fail(RL_ERR_UNSUPPORTED, "rl_time_kernel: the two-stream kernel does not apply to this index / shape");
-        else if (kind == 7) st = launch_maxsim_pp(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, PP_PASS_QUERIES, 0, PP_PASS_QUERIES,
+        if (kind == 7) st = launch_maxsim_pp(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, PP_PASS_QUERIES, 0, PP_PASS_QUERIES,
                                              nq / PP_PASS_QUERIES, idx->row_to_chunk, idx->offsets, idx->ends.as<uint32_t>(), idx->scores.as<float>(), ldc,
                                              idx->n_cu, s, idx->split_scale);
         else if (kind == 3) st = gemm_pass(idx, nq / GEMM_PASS_QUERIES, GEMM_PASS_QUERIES, 0, GEMM_PASS_QUERIES, idx->scores.as<float>(), ldc, s);

@@ -243,13 +243,9 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
                        const uint32_t* run_if = nullptr, bool hi_only = false);
 // maxsim_pp.hip: the approximate pass of the headline pipeline -- SIXTEEN queries per pass over a one-plane image, one product
 constexpr int32_t PP_PASS_QUERIES = 16;
-constexpr int PP_DEFAULT_KERNEL = 1;  // RAGLITE_PP_KERNEL: 1 = maxsim_pp_kernel (16 queries per pass), 2 = maxsim_pp2_kernel (8, two row streams)
 int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first, int32_t n_q,
                      int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits, float* out,
                      int64_t out_stride, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if = nullptr);
-int launch_maxsim_pp2(const void* image, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first, int32_t n_q,
-                      int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits, float* out,
-                      int64_t out_stride, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if = nullptr);
 size_t score_planes_scratch_floats(int32_t nb, int32_t dim);
 int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores, int64_t ld,
                         const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale,

@@ -31,6 +31,12 @@
 //   * tile epilogue as in maxsim_gemm_kernel (DPP segmented max-scan along the 16 rows of a block, sum over the 32 query vectors,
 //     store by the chunk's end row's lane), once per query of the wave.  Its stores share the in-order VMEM counter with the
 //     DMAs: the feeders count them (wave-uniform) and widen their next waits by exactly that many.
+// Tried on top of this and removed (profiles/r03_j, r03_k; commit 'maxsim_pp2_kernel ... for the record'): eight queries per pass
+// over TWO row streams per workgroup (32 KiB per slab instead of 40) with the two waves of a SIMD in alternating phases (one multiplies,
+// its partner loads and feeds).  Correct -- bit-identical -- and without its epilogue it sits on the operand stream with the MFMAs
+// hidden (0.36 ms per eight queries); but the tile epilogue (2 200 straight-line VALU / SALU instructions per wave, ~10 cycles each
+// when a wave runs alone on its SIMD) then runs once per GROUP, back to back: 0.72 ms per eight queries against 0.58 here.  The
+// epilogue, not the main loop, is what the next version has to make cheaper.
 // Deterministic (fixed MFMA order per (query vector, row), fixed scan / sum order; independent of the grid); integer-valued
 // data is exact.  Needs an index without empty chunks (a chunk is found by counting chunk ends), nq <= 32, dim % 32 == 0.
 #include <cstdio>
@@ -491,303 +497,6 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     }
 }
 
-// ======================================================================================================================================
-// maxsim_pp2_kernel: EIGHT queries per pass, TWO row streams per workgroup, the two waves of every SIMD in alternating phases.
-//
-// What the measurements of maxsim_pp_kernel said (profiles/r03_b .. r03_i): its operand stream costs 34-35 cycles per KiB of
-// `global_load_lds_dwordx4` with every CU streaming (the L2 -> CU path delivers ~18 TB/s chip-wide: scripts/micro/l2_dma_rate.hip,
-// plain loads the same), i.e. ~1 400 cycles per slab for its 40 KiB against 1 024 cycles of matrix work -- and a wave is BLOCKED while
-// its DMA instruction waits for the address path, so the MFMAs behind it in program order wait too: the pass took the SUM of both
-// (DMAs alone 0.67 ms, MFMAs + LDS reads alone 0.86, together 1.15-1.25).  Two changes:
-//   * 32 KiB per slab instead of 40: a workgroup walks TWO independent row streams (the halves of its chunk-aligned row range; waves 0-3
-//     multiply a 128-row tile of the first, waves 4-7 of the second) against the SAME eight queries -- the query slab (16 KiB) is fetched
-//     once for both, each stream adds its 8 KiB of corpus.  Costs the corpus a second trip from HBM per sixteen queries (2 GB per pass of
-//     eight: 4-5 TB/s at the speeds in reach), saves a fifth of the bytes on the path that is the bottleneck;
-//   * the two waves of a SIMD alternate: while one multiplies a slab out of its registers (32 MFMAs, nothing else), its partner reads its
-//     next fragments from LDS, issues its DMAs (two query pieces, two corpus pieces) and finishes a tile if one ended -- separated by a
-//     workgroup barrier per phase.  A blocked DMA issue now blocks a wave that has nothing to multiply.
-// Schedule (A = waves 0-3, B = waves 4-7; phase 2g: A multiplies slab g, B loads slab g; phase 2g + 1: B multiplies slab g, A loads
-// slab g + 1).  L_X(j) -- X's load phase for slab j -- reads slab j's fragments and issues X's query pieces of slab j - 1 + DQ and its
-// corpus pieces of slab j - 1 + DC (DC = DQ + 1), whose slots the previous phases' reads have left.  Slab h is first read in phase 2h - 1, so
-// both groups wait for their pieces of it before the barrier that ends phase 2h - 2 (A after multiplying, B after loading): everything up
-// to its query pieces of slab h has retired when 2 + 4 (DQ - 2) VMEM operations are outstanding (+ a finished tile's stores while they are
-// newer).  Same sums in the same order as maxsim_pp_kernel / maxsim_gemm_kernel: bit-identical scores.
-template <int DBG>
-__global__ __launch_bounds__(512, 2) void maxsim_pp2_kernel(const char* __restrict__ planes, int64_t n_rows, int32_t nslab,
-                                                            const char* __restrict__ qfrag, const float* __restrict__ qmeta, int32_t n_q,
-                                                            const int32_t* __restrict__ row_to_chunk, const int64_t* __restrict__ chunk_offsets,
-                                                            const uint32_t* __restrict__ ends_bits, float* __restrict__ out, int64_t out_stride,
-                                                            float inv_e_scale, const uint32_t* __restrict__ run_if) {
-    constexpr int DQ = 4, DC = 5;                               // ring depths in slabs
-    constexpr int QSLOT = 8 * 2 * 1024;                         // query slab: 8 queries x 2 blocks of 16 vectors x 1 KiB
-    constexpr int CSLOT = PP_NBLK * 1024;                       // one stream's corpus slab: 8 blocks x 1 KiB
-    constexpr int COFF = DQ * QSLOT, LDS = COFF + 2 * DC * CSLOT;  // 64 + 80 = 144 KiB
-    __shared__ __attribute__((aligned(16))) char smem[LDS];
-    if (run_if && __builtin_amdgcn_readfirstlane((int)*run_if) == 0) return;
-    const int lane = threadIdx.x & 63;
-    const int wv = wave_id(), grp = wv >> 2, wi = wv & 3;
-    const int64_t G = gridDim.x, b = blockIdx.x;
-    auto boundary = [&](int64_t t) -> int64_t {  // first chunk boundary at or after row t
-        if (t <= 0) return 0;
-        if (t >= n_rows) return n_rows;
-        const int32_t c = row_to_chunk[t];
-        const int64_t c0 = chunk_offsets[c], c1 = chunk_offsets[c + 1];
-        return c0 == t ? t : c1;
-    };
-    const int32_t R0 = (int32_t)pp_uniform_i64(boundary((n_rows * b) / G));
-    const int32_t R1 = (int32_t)pp_uniform_i64((b + 1 == G) ? n_rows : boundary((n_rows * (b + 1)) / G));
-    if (R1 <= R0) return;  // whole workgroup
-    int32_t mid = (int32_t)pp_uniform_i64(boundary(((int64_t)R0 + R1) / 2));
-    mid = mid < R0 ? R0 : (mid > R1 ? R1 : mid);
-    const int32_t r_lo = grp == 0 ? R0 : mid, r_hi = grp == 0 ? mid : R1;  // this wave's stream (may be empty)
-    const int32_t org = r_lo & ~15;
-    auto tiles_of = [&](int32_t lo, int32_t hi) { return hi > lo ? (hi - (lo & ~15) + PP_RT - 1) / PP_RT : 0; };
-    const int nt0 = tiles_of(R0, mid), nt1 = tiles_of(mid, R1);
-    const int nt_max = nt0 > nt1 ? nt0 : nt1;
-    const int total = nt_max * nslab;  // K slabs, the same for all eight waves
-    const int32_t last_blk = (int32_t)((n_rows + 15) >> 4) - 1;
-    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
-    const uint32_t lane16 = 16u * lane;
-    const int fj = lane & 15;
-
-    // ---- this wave's queries: 2 wi and 2 wi + 1 of the pass ----------------------------------------------------------------------------
-    const bool live = r_hi > r_lo;
-    const bool has0 = live && 2 * wi < n_q, has1 = live && 2 * wi + 1 < n_q;  // wave-uniform
-    const float unscale0 = has0 ? qmeta[2 * (2 * wi)] * inv_e_scale : 0.f, unscale1 = has1 ? qmeta[2 * (2 * wi + 1)] * inv_e_scale : 0.f;
-    float* const out0 = out + (int64_t)(has0 ? 2 * wi : 0) * out_stride;
-    float* const out1 = out + (int64_t)(has1 ? 2 * wi + 1 : 0) * out_stride;
-
-    // ---- feeder duty: query pieces 8 grp + 2 wi, + 1 (piece = 2 * query + block of 16 vectors); this stream's corpus blocks 2 wi, + 1 ----
-    const char* qb[2];
-    const char* cb[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int p = 8 * grp + 2 * wi + i;
-        int ql = p >> 1;
-        ql = ql < n_q ? ql : n_q - 1;  // (clamped: a piece of a query the pass does not have is copied from a valid one, never used)
-        qb[i] = qfrag + pp_uniform_i64(((int64_t)ql * nslab * 4 + 2 * (p & 1)) * 1024);
-    }
-    int fq_s = 0, fq_slot = 0, fc_s = 0, fc_tile = 0, fc_slot = 0;  // the NEXT slab this wave fetches
-    auto feed_tile = [&](int t) __attribute__((always_inline)) {
-        const int32_t b0 = ((org + t * PP_RT) >> 4) + 2 * wi;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int32_t blk = b0 + i;
-            blk = blk < last_blk ? blk : last_blk;  // past the image: harmless re-read of the last block, never emitted
-            blk = blk > 0 ? blk : 0;
-            cb[i] = planes + pp_uniform_i64((int64_t)blk * nslab * 1024);
-        }
-    };
-    feed_tile(0);
-    auto issue = [&]() __attribute__((always_inline)) {  // Q, Q, C, C of the next slabs
-        if constexpr (!(DBG & 32)) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                pp_dma<false>(lds_base + (uint32_t)(fq_slot * QSLOT + (8 * grp + 2 * wi + i) * 1024), qb[i] + (int64_t)fq_s * 4096, lane16);
-        }
-        if constexpr (!(DBG & 16)) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                pp_dma<true>(lds_base + (uint32_t)(COFF + (grp * DC + fc_slot) * CSLOT + (2 * wi + i) * 1024), cb[i] + (int64_t)fc_s * 1024, lane16);
-        }
-        if (++fq_s == nslab) fq_s = 0;
-        fq_slot = fq_slot + 1 == DQ ? 0 : fq_slot + 1;
-        if (++fc_s == nslab) {
-            fc_s = 0;
-            if (fc_tile + 1 < nt_max) { ++fc_tile; feed_tile(fc_tile); }
-        }
-        fc_slot = fc_slot + 1 == DC ? 0 : fc_slot + 1;
-    };
-    int st_pending = 0, st_slabs = 0;  // a finished tile's stores newer than the pieces to certify: how many, for how many more waits
-    auto certify = [&]() __attribute__((always_inline)) {
-        pp_wait_vm<2 + 4 * (DQ - 2)>(st_slabs > 0 ? st_pending : 0);
-        if (st_slabs > 0) --st_slabs;
-    };
-
-    // ---- accumulators, scan state ---------------------------------------------------------------------------------------------------------
-    f32x4 acc[2][2][PP_NBLK];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int a = 0; a < PP_NBLK; ++a) acc[q][h][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float carry[2][8];
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) carry[q][r] = -INFINITY;
-    uint32_t prev_last_end = 1;
-    int32_t ord_run = __builtin_amdgcn_readfirstlane(row_to_chunk[org < (int32_t)n_rows ? org : (int32_t)n_rows]);
-
-    // ---- fragments ---------------------------------------------------------------------------------------------------------------------
-    f32x4 ef[PP_NBLK], qf[4];
-    int c_slot = 0, q_slot = 0;  // ring slots of the slab whose fragments are read next
-    const uint32_t rd_c = lds_base + (uint32_t)(COFF + grp * DC * CSLOT) + lane16, rd_q = lds_base + (uint32_t)(4 * wi * 1024) + lane16;
-    auto read_frags = [&]() __attribute__((always_inline)) {
-        if constexpr (!(DBG & 8)) {
-            const uint32_t ac = rd_c + (uint32_t)(c_slot * CSLOT), aq = rd_q + (uint32_t)(q_slot * QSLOT);
-            [&]<int... A>(std::integer_sequence<int, A...>) { (pp_read<A * 1024>(ef[A], ac), ...); }(std::make_integer_sequence<int, PP_NBLK>{});
-            [&]<int... F>(std::integer_sequence<int, F...>) { (pp_read<F * 1024>(qf[F], aq), ...); }(std::make_integer_sequence<int, 4>{});
-        }
-        c_slot = c_slot + 1 == DC ? 0 : c_slot + 1;
-        q_slot = q_slot + 1 == DQ ? 0 : q_slot + 1;
-    };
-    auto landed = [&]() __attribute__((always_inline)) {
-        pp_pin(ef[0], ef[1], ef[2], ef[3]);
-        pp_pin(ef[4], ef[5], ef[6], ef[7]);
-        pp_pin(qf[0], qf[1], qf[2], qf[3]);
-    };
-    auto compute = [&]() __attribute__((always_inline)) {
-        if constexpr (!(DBG & 2)) {
-            [&]<int... A>(std::integer_sequence<int, A...>) {
-                (([&] {
-                     acc[0][0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(qf[0]), pp_h(ef[A]), acc[0][0][A], 0, 0, 0);
-                     acc[0][1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(qf[1]), pp_h(ef[A]), acc[0][1][A], 0, 0, 0);
-                     acc[1][0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(qf[2]), pp_h(ef[A]), acc[1][0][A], 0, 0, 0);
-                     acc[1][1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(qf[3]), pp_h(ef[A]), acc[1][1][A], 0, 0, 0);
-                 }()),
-                 ...);
-            }(std::make_integer_sequence<int, PP_NBLK>{});
-        }
-    };
-
-    // ---- tile epilogue (the one of maxsim_pp_kernel): per-chunk maxima along the DPP rows, sum over the query vectors, store ---------------
-    auto epilogue = [&](int t) __attribute__((always_inline)) {
-        if constexpr (DBG & 128) return;  // (timing experiments: no epilogue at all)
-        const int32_t row0 = org + t * PP_RT;
-        uint32_t m[5];
-        const uint32_t* const eb = ends_bits + (row0 >> 5);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) m[i] = eb[i];
-        const bool odd = (row0 & 16) != 0;
-        uint32_t mm[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mm[i] = odd ? (m[i] >> 16) | (m[i + 1] << 16) : m[i];
-        int n_st = 0;
-        if (has0) {
-#pragma unroll
-            for (int a = 0; a < PP_NBLK; ++a) {
-                const uint32_t E = (mm[a >> 1] >> (16 * (a & 1))) & 0xffffu;
-                const int32_t base = row0 + 16 * a;
-                const int32_t ord0 = ord_run;
-                ord_run += __builtin_popcount(E);
-                const uint32_t O1 = E << 1, O2 = O1 | (O1 << 1), O4 = O2 | (O2 << 2), O8 = O4 | (O4 << 4);
-                const uint64_t rep = 0x0001000100010001ull;
-                const uint64_t F1 = (uint64_t)(~O1 & 0xfffeu) * rep, F2 = (uint64_t)(~O2 & 0xfffcu) * rep;
-                const uint64_t F4 = (uint64_t)(~O4 & 0xfff0u) * rep, F8 = (uint64_t)(~O8 & 0xff00u) * rep;
-                const uint64_t C0 = prev_last_end ? 0ull : rep;
-                int32_t lo = r_lo - base, hi = r_hi - base;
-                lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
-                hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
-                const uint32_t EM = E & ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-                const uint32_t below = E & ((1u << fj) - 1u);
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    if (q == 1 && !has1) continue;  // wave-uniform
-                    float x[8], tmp[8];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) x[4 * h + u] = acc[q][h][a][u];
-#define PP_STEP(SRC, CTRLSTR, MASK)                                                    \
-    _Pragma("unroll") for (int r = 0; r < 8; ++r) PP_MAX_DPP(tmp[r], SRC, x[r], CTRLSTR); \
-    _Pragma("unroll") for (int r = 0; r < 8; ++r) PP_SELECT(x[r], tmp[r], MASK);
-                    if constexpr (!(DBG & 1)) {
-                        PP_STEP(carry[q][r], "row_ror:1", C0)
-                        PP_STEP(x[r], "row_shr:1", F1)
-                        PP_STEP(x[r], "row_shr:2", F2)
-                        PP_STEP(x[r], "row_shr:4", F4)
-                        PP_STEP(x[r], "row_shr:8", F8)
-                    }
-#undef PP_STEP
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) carry[q][r] = x[r];
-                    if (EM != 0u) {
-                        float tsum = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
-                        const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(tsum), __float_as_uint(tsum), false, false);
-                        tsum = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
-                        const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(tsum), __float_as_uint(tsum), false, false);
-                        tsum = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
-                        if (lane < 16 && ((EM >> lane) & 1u)) (q == 0 ? out0 : out1)[ord0 + __builtin_popcount(below)] = tsum * (q == 0 ? unscale0 : unscale1);
-                        ++n_st;
-                    }
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) acc[q][h][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-                prev_last_end = (E >> 15) & 1u;
-            }
-        } else {
-            prev_last_end = (mm[3] >> 31) & 1u;
-            ord_run += __builtin_popcount(mm[0]) + __builtin_popcount(mm[1]) + __builtin_popcount(mm[2]) + __builtin_popcount(mm[3]);
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int a = 0; a < PP_NBLK; ++a) acc[q][h][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        st_pending = n_st;
-        st_slabs = n_st > 0 ? DQ - 2 : 0;
-    };
-
-    // ---- load phase for slab j: (a tile that just ended), this wave's fragments of slab j, its DMAs of slabs j - 1 + DQ / j - 1 + DC ---------
-    int c_s = 0, c_tile = 0;   // slab / tile this wave multiplies next
-    bool tile_done = false;    // its last multiply closed a tile
-    auto load = [&]() __attribute__((always_inline)) {
-        if (tile_done) {
-            epilogue(c_tile);
-            ++c_tile;
-            tile_done = false;
-        }
-        read_frags();
-        issue();
-    };
-    auto multiply = [&]() __attribute__((always_inline)) {
-        compute();
-        if (++c_s == nslab) { c_s = 0; tile_done = true; }
-    };
-
-    // ---- prologue: slabs 0 .. DQ - 2 (query) / 0 .. DC - 2 (corpus) landed -------------------------------------------------------------------
-    for (int i = 0; i < DQ - 1; ++i) {
-        if constexpr (!(DBG & 32)) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-                pp_dma<false>(lds_base + (uint32_t)(fq_slot * QSLOT + (8 * grp + 2 * wi + k) * 1024), qb[k] + (int64_t)fq_s * 4096, lane16);
-        }
-        if (++fq_s == nslab) fq_s = 0;
-        fq_slot = fq_slot + 1 == DQ ? 0 : fq_slot + 1;
-    }
-    for (int i = 0; i < DC - 1; ++i) {
-        if constexpr (!(DBG & 16)) {
-#pragma unroll
-            for (int k = 0; k < 2; ++k)
-                pp_dma<true>(lds_base + (uint32_t)(COFF + (grp * DC + fc_slot) * CSLOT + (2 * wi + k) * 1024), cb[k] + (int64_t)fc_s * 1024, lane16);
-        }
-        if (++fc_s == nslab) {
-            fc_s = 0;
-            if (fc_tile + 1 < nt_max) { ++fc_tile; feed_tile(fc_tile); }
-        }
-        fc_slot = fc_slot + 1 == DC ? 0 : fc_slot + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    // ---- main loop.  A: L(0) | C(0) L(1) | C(1) L(2) ..., B: - | L(0) C(0) | L(1) C(1) ...: the same body "load, barrier, multiply, barrier"
-    // for both, B one barrier behind (and A one barrier longer at the end). -----------------------------------------------------------------
-    if (grp == 1) asm volatile("s_barrier" ::: "memory");
-    for (int g = 0; g < total; ++g) {
-        load();                                                    // A: phase 2g - 1, B: phase 2g
-        if (grp == 1) certify();                                   // B's pieces of slab g + 1 (read from phase 2g + 1 on)
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        landed();
-        multiply();                                                // A: phase 2g, B: phase 2g + 1
-        if (grp == 0) certify();                                   // A's pieces of slab g + 1
-        asm volatile("s_barrier" ::: "memory");
-    }
-    if (grp == 0) asm volatile("s_barrier" ::: "memory");
-    if (tile_done) epilogue(c_tile);  // the last tile
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
-}
-
 // n_q (1..16) queries `first .. first + n_q - 1` of a launch_query_planes buffer over `n_queries`, each nq (<= 32) vectors, against
 // a one-plane image (fp16 hi halves, or an fp16-stored corpus): out[q * out_stride + chunk], one MFMA product per multiply.
 int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first, int32_t n_q,
@@ -843,36 +552,6 @@ int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void*
     else if (dbg == 49) RL_PP_LAUNCH(49, 6, 3, 0);
     else RL_PP_LAUNCH(0, 6, 3, 0);
 #undef RL_PP_LAUNCH
-    RL_HIP(hipGetLastError());
-    return RL_OK;
-}
-
-// maxsim_pp2_kernel: n_q (1..8) queries per pass.
-int launch_maxsim_pp2(const void* image, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first, int32_t n_q,
-                      int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits, float* out,
-                      int64_t out_stride, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if) {
-    if (nq < 1 || nq > 32 || n_q < 1 || n_q > 8 || n_rows < 1 || first < 0 || first + n_q > n_queries) return RL_ERR_UNSUPPORTED;
-    // dim >= 256: a tile's epilogue stores must have left the VMEM counter's window before the next tile's (see certify())
-    if (dim % 32 || dim < 256 || !(split_scale > 0.f) || !image || !ends_bits) return RL_ERR_UNSUPPORTED;
-    const int32_t nslab = dim / 32;
-    const char* qfrag = static_cast<const char*>(qbuf) + (size_t)first * nslab * 4096;
-    const float* qmeta = reinterpret_cast<const float*>(static_cast<const char*>(qbuf) + (size_t)n_queries * dim * 128) + 2 * (size_t)first;
-    const int64_t tiles = (n_rows + 2 * PP_RT - 1) / (2 * PP_RT);
-    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
-    static const int dbg = std::getenv("RAGLITE_PP_DBG") ? std::atoi(std::getenv("RAGLITE_PP_DBG")) : 0;  // timing experiments only
-#define RL_PP2_LAUNCH(DBG_)                                                                                                              \
-    hipLaunchKernelGGL(maxsim_pp2_kernel<DBG_>, grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk, \
-                       chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if)
-    if (dbg == 1) RL_PP2_LAUNCH(1);
-    else if (dbg == 2) RL_PP2_LAUNCH(2);
-    else if (dbg == 11) RL_PP2_LAUNCH(11);
-    else if (dbg == 48) RL_PP2_LAUNCH(48);
-    else if (dbg == 59) RL_PP2_LAUNCH(59);
-    else if (dbg == 187) RL_PP2_LAUNCH(187);
-    else if (dbg == 128) RL_PP2_LAUNCH(128);
-    else if (dbg == 130) RL_PP2_LAUNCH(130);
-    else RL_PP2_LAUNCH(0);
-#undef RL_PP2_LAUNCH
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -162,6 +162,34 @@ def test_search_rows_uniform_data_batched(metric, B):
     idx.close()
 
 
+@pytest.mark.parametrize("kind", ["unit_fp16", "uniform"])
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+@pytest.mark.parametrize("B", [1, 33, 130])
+def test_search_rows_against_duckdb_fp32_formulation(metric, kind, B):
+    """a6 / a7 against the as-computed variant in DuckDB's own formulation (`oracle.distance_duckdb_fp32`: float32, element-order
+    sums, one square root of the product of the squared norms, clamp -- `/root/reference/src/raglite/_typing.py:123-134` calls DuckDB's
+    `array_cosine_distance` / `array_negative_inner_product` / `array_distance`): every similarity of every row (k = n) through the
+    single-query, the batched and the GEMM kernels stays within the measured gap between the two formulations
+    (tests/test_oracle_props.py: DUCKDB_GAP_ULPS) + 2 ulp of the score scale."""
+    from tests.test_oracle_props import DUCKDB_GAP_ULPS
+
+    n, dim = 1800, 1024
+    E = oracle.synth_matrix(8100, n, dim)
+    Q = oracle.synth_matrix(8101, B, dim)
+    if kind == "unit_fp16":
+        E = (E / np.linalg.norm(E, axis=1, keepdims=True)).astype(np.float16).astype(np.float32)
+        Q = (Q / np.linalg.norm(Q, axis=1, keepdims=True)).astype(np.float16).astype(np.float32)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    S, R = idx.search_rows(Q, n)
+    for b in sorted({0, B // 2, B - 1}):
+        duck = oracle.similarity_duckdb_fp32(E, Q[b], metric).astype(np.float64)
+        got = np.empty(n, dtype=np.float64)
+        got[R[b]] = S[b]
+        unit = 2.0 ** -24 * max(1.0, float(np.abs(duck).max()))
+        assert float(np.abs(got - duck).max()) <= (DUCKDB_GAP_ULPS + 2) * unit
+    idx.close()
+
+
 @pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
 @pytest.mark.parametrize("n,dim,B", [(1000, 1024, 96), (4100, 1024, 130), (777, 128, 257), (2049, 384, 128), (130, 64, 100)])
 def test_search_rows_gemm_path_integer_bit_exact(metric, n, dim, B):

@@ -75,10 +75,8 @@ def test_pp_equals_eight_query_kernel_bitwise(n, dim, nq, n_queries, layout):
     idx = raglite_amd.DeviceIndex(E, off, metric="dot")
     a, ma = idx.maxsim_approx_scores(Q, kernel=0)
     b, mb = idx.maxsim_approx_scores(Q, kernel=1)
-    c, mc = idx.maxsim_approx_scores(Q, kernel=2)  # eight queries per pass, two row streams per workgroup
     assert torch.equal(a, b), f"{int((a != b).sum())} of {a.numel()} scores differ"
-    assert torch.equal(c, b), f"two-stream kernel: {int((c != b).sum())} of {c.numel()} scores differ"
-    assert torch.equal(ma, mb) and torch.equal(mc, mb) and bool((ma > 0).all())
+    assert torch.equal(ma, mb) and bool((ma > 0).all())
     a2, _ = idx.maxsim_approx_scores(Q, kernel=0)
     assert torch.equal(a, a2)  # deterministic
     idx.close()
@@ -140,10 +138,9 @@ def test_pipeline_over_either_kernel_returns_the_same_bits():
     with _env(RAGLITE_NO_PP="1"):
         s1, c1 = idx.maxsim_topk_batch(Q, k)
     assert torch.equal(s0, s1) and torch.equal(c0, c1)
-    for ppk in ("1", "2"):
-        with _env(RAGLITE_PP_KERNEL=ppk):
-            s3, c3 = idx.maxsim_topk_batch(Q, k)
-        assert torch.equal(s0, s3) and torch.equal(c0, c3), ppk
+    with _env(RAGLITE_PP_FEED="0"):  # every wave feeds (A/B; read once per process, so this only differs in a fresh process)
+        s3, c3 = idx.maxsim_topk_batch(Q, k)
+    assert torch.equal(s0, s3) and torch.equal(c0, c3)
     with _env(RAGLITE_NO_HI_MAXSIM="1"):  # the full-precision passes: same chunks, scores to the last bits of the split arithmetic
         s2, c2 = idx.maxsim_topk_batch(Q, k)
     assert torch.equal(c0, c2)

@@ -93,3 +93,43 @@ def test_shard_bounds():
         b = oracle.shard_bounds_by_chunk(off, w)
         assert b[0][0] == 0 and b[-1][1] == len(off) - 1
         assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+# ---- a6 in DuckDB's own formulation (parity unpinned: DuckDB is absent; this MEASURES the gap between formulations) ----------------
+DUCKDB_GAP_ULPS = 32  # |repository form - DuckDB form| in units of 2^-24 x max(1, |similarity| scale); measured: <= 24 (l2, unit rows)
+
+
+@pytest.mark.parametrize("kind", ["unit_fp16", "uniform"])
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+def test_duckdb_fp32_formulation_gap_is_bounded(kind, metric):
+    """`/root/reference/src/raglite/_typing.py:123-134` evaluates the distance inside DuckDB: float32, element-order sums, ONE square
+    root of the product of the squared norms for the cosine, a clamp to [-1, 1].  The repository's as-computed form (two roots and a
+    product, blocked sums) differs from it by a few float32 ulps -- measured here, on fp16-rounded unit rows (what RAGLite stores,
+    `_embed.py:138-140`) and on the benchmark's U(-1, 1) rows; both stay ~3 orders of magnitude inside the 1e-4 bar against float64."""
+    n, d = 3000, 1024
+    E = oracle.synth_matrix(11, n, d)
+    q = oracle.synth_matrix(12, 1, d)[0]
+    if kind == "unit_fp16":
+        E = (E / np.linalg.norm(E, axis=1, keepdims=True)).astype(np.float16).astype(np.float32)
+        q = (q / np.linalg.norm(q)).astype(np.float16).astype(np.float32)
+    ours = (1.0 - oracle.distance(E, q, metric, np.float32)).astype(np.float64)
+    duck = oracle.similarity_duckdb_fp32(E, q, metric).astype(np.float64)
+    truth = 1.0 - oracle.distance(E, q, metric, np.float64)
+    unit = 2.0 ** -24 * max(1.0, float(np.abs(truth).max()))
+    assert float(np.abs(ours - duck).max()) <= DUCKDB_GAP_ULPS * unit
+    assert float(np.abs(duck - truth).max()) <= DUCKDB_GAP_ULPS * unit  # the sequential float32 sums are the less accurate of the two
+    assert float(np.abs(ours - truth).max()) <= 8 * unit
+    if kind == "unit_fp16" or metric == "cosine":  # similarities of scale 1: the literal 1e-4 of north_star, with a factor 10 to spare
+        assert DUCKDB_GAP_ULPS * unit < 1e-5
+
+
+def test_duckdb_fp32_cosine_clamps_and_uses_one_root():
+    """The two features of DuckDB's cosine this repository's form does not have: the similarity is clamped to [-1, 1] (so the distance
+    of a vector to itself is >= 0, never -1e-7), and norms multiply BEFORE the root (a row of norm 1e-30 against a query of norm 1e30:
+    the product is finite where either root alone is fine too -- and a row of norm 1e-25 squared underflows in both forms)."""
+    e = np.full((1, 8), 0.35355338, dtype=np.float32)
+    d = oracle.distance_duckdb_fp32(e, e[0], "cosine")
+    assert d.dtype == np.float32 and 0.0 <= float(d[0]) <= 2.0 ** -22
+    z = np.zeros((1, 8), dtype=np.float32)
+    assert np.isnan(oracle.distance_duckdb_fp32(z, e[0], "cosine")[0])  # 0 / 0: NaN in DuckDB as well (ranks last here)
+    assert float(oracle.distance_duckdb_fp32(e, e[0], "dot")[0]) == -float(np.float32(8 * np.float32(0.35355338) ** 2))
