@@ -176,6 +176,31 @@ int rl_index_arithmetic(rl_index* index, int* in_effect);
 int rl_search_rows(rl_index* index, const float* queries, int32_t n_queries, int32_t k,
                    float* out_scores, int32_t* out_rows, int mem, void* stream);
 
+/* ---- the order-first cut over a corpus SHARDED across several indexes (SURVEY.md section 8e with 8f-1's rank_limit) -----
+ * `rank_limit` of rl_search_rows_ranked is the reference's `ORDER BY dist LIMIT 1_000_000` over the WHOLE table
+ * (src/raglite/_search.py:120-141); applied per shard it would admit up to world x rank_limit rows.  The cut is a three-level radix
+ * select (11 + 11 + 10 bits of the order-preserving score key) whose histograms are additive, so the shards walk to the GLOBAL
+ * threshold together when the caller sums each level over them:
+ *     rl_rank_cut_begin(index, queries, B)                                  similarities of every live row, kept by the index
+ *     for level in 0, 1, 2:
+ *         rl_rank_cut_level(index, level, rank_limit, hist)                 hist [B x 2048] uint32: this shard's histogram of the level
+ *         <sum hist over the shards: rl_allreduce_sum_u32, or any all-reduce>
+ *         rl_rank_cut_level_done(index, level, hist)                        the summed histogram back
+ *     rl_rank_cut_ties(index, rank_limit, ties)                             ties [B]: this shard's rows ON the threshold key
+ *     <all-gather ties; ties_before[q] = sum of ties[q] over the shards holding LOWER global rows>
+ *     rl_rank_cut_finish(index, rank_limit, ties_before, chunk_filter, k, out_scores, out_rows)
+ * out_* [B x k]: this shard's top-k among the rows that are inside the global cut (ties on the threshold taken in global row order,
+ * as the single-index cut takes them) and pass the filter; merging the shards' lists (rl_allgather_merge_topk) gives bit for bit what
+ * ONE index over the whole corpus returns for rl_search_rows_ranked.  rank_limit must be smaller than the total number of rows of all
+ * shards (otherwise there is no cut: call rl_search_rows_filtered).  The calls of one search must not be interleaved with other
+ * searches on the same index; B x n_rows x 4 bytes of scores must fit one score batch (8 GB). */
+int rl_rank_cut_begin(rl_index* index, const float* queries, int32_t n_queries, int mem, void* stream);
+int rl_rank_cut_level(rl_index* index, int level, int64_t rank_limit, uint32_t* out_hist, int mem, void* stream);
+int rl_rank_cut_level_done(rl_index* index, int level, const uint32_t* hist_sum, int mem, void* stream);
+int rl_rank_cut_ties(rl_index* index, int64_t rank_limit, uint32_t* out_ties, int mem, void* stream);
+int rl_rank_cut_finish(rl_index* index, int64_t rank_limit, const uint32_t* ties_before, const uint32_t* chunk_filter, int32_t k,
+                       float* out_scores, int32_t* out_rows, int mem, void* stream);
+
 /* ---- a6 + a7 + a8: the reference's two-stage semantics ------------------------------------------
  * top-`num_hits` rows -> max(sim) GROUP BY chunk -> top-`k` chunks (src/raglite/_search.py:66-67,
  * 75-79,143-149).  out_counts[b] (<= k) chunks are valid per query; the rest is -inf / -1. */
@@ -258,6 +283,10 @@ int rl_allgather_topk(rl_comm* comm, const float* local_scores, const int32_t* l
                       int32_t id_offset, float* out_scores, int32_t* out_ids, void* stream);
 int rl_allgather_merge_topk(rl_comm* comm, const float* local_scores, const int32_t* local_ids, int32_t n_queries,
                             int32_t k_in, int32_t id_offset, int32_t k, float* out_scores, int32_t* out_ids, void* stream);
+/* The two small collectives the sharded rank cut (rl_rank_cut_*) needs, on DEVICE buffers, asynchronous on `stream`:
+ * buf[i] <- sum over the ranks of buf[i] (in place), and out [world x count] <- every rank's local [count]. */
+int rl_allreduce_sum_u32(rl_comm* comm, uint32_t* buf, int64_t count, void* stream);
+int rl_allgather_u32(rl_comm* comm, const uint32_t* local, int64_t count, uint32_t* out, void* stream);
 
 /* Generic exact top-k over a dense score matrix [n_queries x n] (row stride ld), the selection
  * stage used by every search above; exposed for tests and for callers that score elsewhere. */

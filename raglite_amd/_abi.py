@@ -79,6 +79,13 @@ _SIGNATURES = {
     "rl_comm_destroy": [c_void_p],
     "rl_allgather_topk": [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p],
     "rl_allgather_merge_topk": [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p],
+    "rl_allreduce_sum_u32": [c_void_p, c_void_p, c_i64, c_void_p],
+    "rl_allgather_u32": [c_void_p, c_void_p, c_i64, c_void_p, c_void_p],
+    "rl_rank_cut_begin": [c_void_p, c_void_p, c_i32, c_int, c_void_p],
+    "rl_rank_cut_level": [c_void_p, c_int, c_i64, c_void_p, c_int, c_void_p],
+    "rl_rank_cut_level_done": [c_void_p, c_int, c_void_p, c_int, c_void_p],
+    "rl_rank_cut_ties": [c_void_p, c_i64, c_void_p, c_int, c_void_p],
+    "rl_rank_cut_finish": [c_void_p, c_i64, c_void_p, c_void_p, c_i32, c_void_p, c_void_p, c_int, c_void_p],
 }
 COMM_ID_BYTES = 128
 _RESTYPES = {"rl_last_error": c_char_p}

@@ -92,3 +92,25 @@ class Communicator:
         o_i, q_i = a.out((nq, k), np.int32)
         check(lib().rl_allgather_merge_topk(self._handle, p_s, p_i, nq, k_in, int(id_offset), int(k), q_s, q_i, a.stream))
         return o_s, o_i
+
+    def allreduce_sum_(self, t):
+        """In place: t (CUDA int32 tensor) <- the sum over the ranks (`rl_allreduce_sum_u32`; the counters are non-negative)."""
+        import torch
+
+        if not (t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()):
+            raise ValueError("allreduce_sum_ needs a contiguous CUDA int32 tensor")
+        _ops._ensure_init(t.device.index or 0)
+        check(lib().rl_allreduce_sum_u32(self._handle, t.data_ptr(), t.numel(), torch.cuda.current_stream(t.device).cuda_stream))
+        return t
+
+    def allgather(self, t):
+        """(world, *t.shape) of every rank's CUDA int32 tensor t (`rl_allgather_u32`)."""
+        import torch
+
+        if not (t.is_cuda and t.dtype == torch.int32):
+            raise ValueError("allgather needs a CUDA int32 tensor")
+        t = t.contiguous()
+        out = torch.empty((self.world, *t.shape), dtype=torch.int32, device=t.device)
+        _ops._ensure_init(t.device.index or 0)
+        check(lib().rl_allgather_u32(self._handle, t.data_ptr(), t.numel(), out.data_ptr(), torch.cuda.current_stream(t.device).cuda_stream))
+        return out

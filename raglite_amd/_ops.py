@@ -386,6 +386,55 @@ class DeviceIndex:
         check(lib().rl_search_rows_ranked(self._handle, p_q, B, k, p_f, int(rank_limit or 0), p_s, p_r, a.mem, a.stream))
         return (o_s[0], o_r[0]) if single else (o_s, o_r)
 
+    # -- the order-first cut of a SHARDED corpus, in stages (rl_rank_cut_*; driven by ShardedIndex.search_rows) -------------------
+    def rank_cut_begin(self, queries) -> int:
+        """Similarities of every live row for `queries` (B, dim), kept by the index until `rank_cut_finish`.  Returns B."""
+        a = _Args()
+        p_q, B, _ = self._queries(a, queries)
+        self._prep(a)
+        check(lib().rl_rank_cut_begin(self._handle, p_q, B, a.mem, a.stream))
+        self._rank_side = (a.mem, a.device, B)
+        return B
+
+    def _rank_args(self) -> tuple[_Args, int]:
+        mem, device, B = self._rank_side
+        a = _Args()
+        a._side(mem, device)  # noqa: SLF001
+        self._prep(a)
+        return a, B
+
+    def rank_cut_level(self, level: int, rank_limit: int):
+        """This shard's histogram of radix level 0..2 (B, 2048) int32 under the prefix the summed previous levels define."""
+        a, B = self._rank_args()
+        o, p = a.out((B, 2048), np.int32)
+        check(lib().rl_rank_cut_level(self._handle, int(level), int(rank_limit), p, a.mem, a.stream))
+        return o
+
+    def rank_cut_level_done(self, level: int, hist_sum) -> None:
+        """The level's histogram summed over all shards."""
+        a, B = self._rank_args()
+        p = a.inp(hist_sum, np.int32)
+        if tuple(a.keep[-1].shape) != (B, 2048):
+            raise ValueError("hist_sum must be (n_queries, 2048)")
+        check(lib().rl_rank_cut_level_done(self._handle, int(level), p, a.mem, a.stream))
+
+    def rank_cut_ties(self, rank_limit: int):
+        """(B,) int32: this shard's rows whose key is the global threshold key."""
+        a, B = self._rank_args()
+        o, p = a.out((B,), np.int32)
+        check(lib().rl_rank_cut_ties(self._handle, int(rank_limit), p, a.mem, a.stream))
+        return o
+
+    def rank_cut_finish(self, rank_limit: int, ties_before, k: int, chunk_filter=None):
+        """This shard's top-k inside the global cut: (scores (B, k), rows (B, k) int32, padding (-inf, -1))."""
+        a, B = self._rank_args()
+        p_t = a.inp(ties_before, np.int32)
+        o_s, p_s = a.out((B, k), np.float32)
+        o_r, p_r = a.out((B, k), np.int32)
+        p_f = self._filter(a, chunk_filter)
+        check(lib().rl_rank_cut_finish(self._handle, int(rank_limit), p_t, p_f, int(k), p_s, p_r, a.mem, a.stream))
+        return o_s, o_r
+
     # -- a6 + a7 + a8 ----------------------------------------------------------------------------
     def search_chunks(self, queries, num_hits: int, k: int, chunk_filter=None, rank_limit: int | None = None):
         """Reference two-stage semantics (`src/raglite/_search.py:66-79,143-149`; with chunk_filter the

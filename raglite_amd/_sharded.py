@@ -221,18 +221,32 @@ class ShardedIndex:
         (the host only enqueues).  Through the C ABI when a Communicator is attached."""
         import torch
 
-        if self.comm is not None:
+        big = self._world() * int(scores.shape[-1]) > 8192  # more candidates per query than rl_merge_topk's kernel sorts in LDS
+        if self.comm is not None and not big:
             return self.comm.allgather_merge_topk(scores, ids_local.to(torch.int32), base, k)
         from . import _ops
 
-        gid = torch.where(ids_local >= 0, ids_local + base, torch.full_like(ids_local, -1)).to(torch.int32)
-        if self._world() == 1:
-            return scores, gid
-        packed = torch.stack([scores.contiguous().view(torch.int32), gid], dim=-1).contiguous()  # (B, k, 2)
-        out = _all_gather_stacked(packed, self.group)
-        gs = out[..., 0].contiguous().view(torch.float32)  # (world, B, k)
-        gi = out[..., 1].contiguous()
-        return _ops.merge_topk(gs, gi, k)
+        if self.comm is not None:
+            gs, gi = self.comm.allgather_topk(scores, ids_local.to(torch.int32), base)
+        else:
+            gid = torch.where(ids_local >= 0, ids_local + base, torch.full_like(ids_local, -1)).to(torch.int32)
+            if self._world() == 1:
+                return scores, gid
+            packed = torch.stack([scores.contiguous().view(torch.int32), gid], dim=-1).contiguous()  # (B, k, 2)
+            out = _all_gather_stacked(packed, self.group)
+            gs = out[..., 0].contiguous().view(torch.float32)  # (world, B, k)
+            gi = out[..., 1].contiguous()
+        if not big:
+            return _ops.merge_topk(gs, gi, k)
+        # e.g. k = 2048 on 8 GPUs: the same ordering by three stable sorts on the device (merge_order_torch), still no host sync
+        world, B, kin = gs.shape
+        fs = gs.permute(1, 0, 2).reshape(B, world * kin)
+        fi = gi.permute(1, 0, 2).reshape(B, world * kin).to(torch.int64)
+        order, n_valid = merge_order_torch(fs, fi, k)
+        real = torch.arange(order.shape[1], device=fs.device)[None, :] < n_valid[:, None]
+        ms = torch.where(real, fs.gather(1, order), torch.full((), float("-inf"), device=fs.device))
+        mi = torch.where(real, fi.gather(1, order), torch.full((), -1, dtype=torch.int64, device=fs.device)).to(torch.int32)
+        return ms, mi
 
     def _gather_device(self, scores, ids, offset: int):
         """(B, k) CUDA lists -> (world, B, k) of every rank's, ids + offset (-1 stays -1)."""
@@ -269,12 +283,69 @@ class ShardedIndex:
         return kw
 
     # -- searches ----------------------------------------------------------------------------------------
+    # -- small integer collectives of the global rank cut (host arrays: torch.distributed; CUDA tensors: the Communicator or RCCL) ----
+    def _allreduce_sum_int(self, x):
+        if self._world() == 1:
+            return x
+        if _is_cuda(x):
+            if self.comm is not None:
+                return self.comm.allreduce_sum_(x.contiguous())
+            import torch.distributed as dist
+
+            x = x.contiguous()
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+            return x
+        return self._all_gather(np.ascontiguousarray(x, dtype=np.int32)).astype(np.int64).sum(axis=0).astype(np.int32)
+
+    def _allgather_int(self, x):
+        """(world, *x.shape)."""
+        if _is_cuda(x):
+            if self.comm is not None:
+                return self.comm.allgather(x)
+            return x[None] if self._world() == 1 else _all_gather_stacked(x, self.group)
+        return self._all_gather(np.ascontiguousarray(x, dtype=np.int32))
+
+    def _rank(self) -> int:
+        if self.comm is not None:
+            return self.comm.rank
+        import torch.distributed as dist
+
+        return dist.get_rank(self.group) if (dist.is_available() and dist.is_initialized()) else 0
+
+    def _local_rows_ranked(self, queries, k: int, chunk_filter, rank_limit):
+        """The local search of `search_rows` / `search_chunks`.  With a rank cut over several shards the cut is the GLOBAL one
+        (`ORDER BY dist LIMIT rank_limit` over the whole table, `_search.py:120-141`): the shards walk the three radix levels of the
+        cut together -- each level's histogram summed over the ranks -- and take ties on the threshold in global row order
+        (`rl_rank_cut_*`); shards hold ascending row ranges in rank order.  Falls back to the per-shard cut (a superset) for local
+        objects without the staged calls."""
+        local_filter = self._local_filter(chunk_filter)
+        if not rank_limit or self._world() == 1 or not hasattr(self.local, "rank_cut_begin"):
+            return self.local.search_rows(queries, k, **self._kw(local_filter, rank_limit))
+        n_local = np.asarray([int(self.local.n_rows)], dtype=np.int32)
+        n_total = int(np.asarray(self._all_gather(n_local)).astype(np.int64).sum())
+        if int(rank_limit) >= n_total:  # no cut at all: the filter-first search
+            return self.local.search_rows(queries, k, **self._kw(local_filter, None))
+        single = getattr(queries, "ndim", 2) == 1
+        self.local.rank_cut_begin(queries)
+        for level in range(3):
+            self.local.rank_cut_level_done(level, self._allreduce_sum_int(self.local.rank_cut_level(level, rank_limit)))
+        ties = self.local.rank_cut_ties(rank_limit)
+        all_ties = self._allgather_int(ties)  # (world, B)
+        before = all_ties[: self._rank()].sum(0) if self._rank() > 0 else all_ties[0] * 0
+        if _is_cuda(ties):
+            import torch
+
+            before = before.to(torch.int32)
+        else:
+            before = np.asarray(before, dtype=np.int32)
+        s, r = self.local.rank_cut_finish(rank_limit, before, k, chunk_filter=local_filter)
+        return (s[0], r[0]) if single else (s, r)
+
     def search_rows(self, queries, k: int, chunk_filter=None, rank_limit: int | None = None):
         """Global exact top-k rows: (scores (B,k), global row ordinals (B,k)).  chunk_filter: bool mask over the GLOBAL chunk
-        ordinals (filter-first branch, `_search.py:105-119`).  rank_limit: the order-first branch's cut (`:120-141`) is applied
-        PER SHARD -- every shard keeps its `rank_limit` nearest rows, a superset of the global cut (exact whenever the whole
-        corpus has no more than `rank_limit` rows)."""
-        s, r = self.local.search_rows(queries, k, **self._kw(self._local_filter(chunk_filter), rank_limit))
+        ordinals (filter-first branch, `_search.py:105-119`).  rank_limit: the order-first branch's cut (`:120-141`), over the WHOLE
+        corpus (see `_local_rows_ranked`): the same rows, bit for bit, as one index holding everything returns."""
+        s, r = self._local_rows_ranked(queries, k, chunk_filter, rank_limit)
         if _is_cuda(s):  # device-resident queries (cfg 5: B = 1000): merge on the device too
             single = s.dim() == 1
             ms, mi = self._exchange_merge_device(s.reshape(1, -1) if single else s, r.reshape(1, -1) if single else r,
@@ -317,7 +388,7 @@ class ShardedIndex:
         synchronisation, CUDA tensors back."""
         if self.local_chunk_offsets is None:
             raise ValueError("search_chunks needs local_chunk_offsets")
-        s, r = self.local.search_rows(queries, num_hits, **self._kw(self._local_filter(chunk_filter), rank_limit))
+        s, r = self._local_rows_ranked(queries, num_hits, chunk_filter, rank_limit)
         device = s.device if _is_cuda(s) else None
         if device is not None:
             import torch

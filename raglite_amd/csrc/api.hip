@@ -258,6 +258,9 @@ struct rl_index {
     int64_t planes_rows = 0;              // rows the image covers
     // What the last bound-filtered search on this handle left behind (rl_index_filter_stats): per-query candidate counters and the
     // device flag its guarded full-precision fallback waits on.  Pointers into the scratch above, valid until the next call.
+    // rl_rank_cut_*: the staged rank cut of a SHARDED corpus keeps its queries and scores here between the calls
+    int32_t rank_B = 0;                   // queries of the running rl_rank_cut_begin (0: none)
+    rl::Pool rank_q;                      // their device copy (the l2 re-scoring of rl_rank_cut_finish needs them)
     struct FilterRecord { int kind = 0; int32_t n = 0, cap = 0; const uint32_t* cnt = nullptr; const uint32_t* flag = nullptr; } filt;
 };
 
@@ -1359,6 +1362,27 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     return RL_OK;
 }
 
+// The exact top-k of idx->scores [nb x ld] (+ for l2 batches the exact re-scoring of the hits): the tail of every row search.
+int select_from_scores(rl_index* idx, const float* d_qb, int32_t nb, int32_t k, float* o_s, int32_t* o_r, int64_t ld, bool hist_done, hipStream_t s) {
+    const int64_t n = idx->n_rows;
+    RL_TRY(launch_topk(idx->scores.as<float>(), nb, n, ld, k, idx->ws, o_s, o_r, s, nullptr, hist_done));
+    if (idx->metric == RL_L2 && (nb > 4)) {
+        // The batched paths rank by |e|^2 + |q|^2 - 2 e.q; re-score the k hits of every query with the exact
+        // sum (e - q)^2 and re-sort them (near-duplicates would otherwise report a cancelled distance).
+        const int64_t items = (int64_t)nb * k;
+        RL_TRY(idx->misc.reserve((size_t)items * (sizeof(float) + 2 * sizeof(int32_t))));
+        float* re = idx->misc.as<float>();
+        int32_t* pos = reinterpret_cast<int32_t*>(re + items);
+        int32_t* tmp_rows = pos + items;
+        RL_TRY(launch_rescore_l2(idx->E16 ? (const void*)idx->E16 : (const void*)idx->E, idx->E16 != nullptr, idx->dim, d_qb, o_r, o_s, k, items,
+                                 re, s));
+        RL_HIP(hipMemcpyAsync(tmp_rows, o_r, (size_t)items * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
+        RL_TRY(launch_topk(re, nb, k, k, k, idx->ws, o_s, pos, s));
+        RL_TRY(launch_permute_rows(tmp_rows, pos, k, items, o_r, s));
+    }
+    return RL_OK;
+}
+
 // rank_limit > 0: the order-first-then-filter branch (src/raglite/_search.py:120-141) -- only the rank_limit nearest LIVE
 // rows of a query are eligible, and among those the rows d_row_bits lets through are ranked.
 int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, float* d_scores, int32_t* d_rows,
@@ -1401,23 +1425,7 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
         } else if (d_row_bits) {
             RL_TRY(launch_mask_scores(idx->scores.as<float>(), nb, n, ld, d_row_bits, s));
         }
-        float* o_s = d_scores + (int64_t)b0 * k;
-        int32_t* o_r = d_rows + (int64_t)b0 * k;
-        RL_TRY(launch_topk(idx->scores.as<float>(), nb, n, ld, k, idx->ws, o_s, o_r, s, nullptr, hist_done));
-        if (idx->metric == RL_L2 && (nb > 4)) {
-            // The batched paths rank by |e|^2 + |q|^2 - 2 e.q; re-score the k hits of every query with the exact
-            // sum (e - q)^2 and re-sort them (near-duplicates would otherwise report a cancelled distance).
-            const int64_t items = (int64_t)nb * k;
-            RL_TRY(idx->misc.reserve((size_t)items * (sizeof(float) + 2 * sizeof(int32_t))));
-            float* re = idx->misc.as<float>();
-            int32_t* pos = reinterpret_cast<int32_t*>(re + items);
-            int32_t* tmp_rows = pos + items;
-            RL_TRY(launch_rescore_l2(idx->E16 ? (const void*)idx->E16 : (const void*)idx->E, idx->E16 != nullptr, idx->dim,
-                                     d_q + (int64_t)b0 * idx->dim, o_r, o_s, k, items, re, s));
-            RL_HIP(hipMemcpyAsync(tmp_rows, o_r, (size_t)items * sizeof(int32_t), hipMemcpyDeviceToDevice, s));
-            RL_TRY(launch_topk(re, nb, k, k, k, idx->ws, o_s, pos, s));
-            RL_TRY(launch_permute_rows(tmp_rows, pos, k, items, o_r, s));
-        }
+        RL_TRY(select_from_scores(idx, d_q + (int64_t)b0 * idx->dim, nb, k, d_scores + (int64_t)b0 * k, d_rows + (int64_t)b0 * k, ld, hist_done, s));
     }
     if (d_row_bits || (rank_limit > 0 && rank_limit < n)) RL_TRY(launch_fix_masked(d_scores, d_rows, (int64_t)B * k, s));  // masked rows are "no hit"
     return RL_OK;
@@ -1465,6 +1473,115 @@ int rl_search_rows_filtered(rl_index* idx, const float* queries, int32_t B, int3
 int rl_search_rows(rl_index* idx, const float* queries, int32_t B, int32_t k, float* out_scores, int32_t* out_rows,
                    int mem, void* stream) {
     return rl_search_rows_filtered(idx, queries, B, k, nullptr, out_scores, out_rows, mem, stream);
+}
+
+// ---- the order-first cut over a SHARDED corpus, in stages (include/raglite_hip.h) ---------------------------------------------------------
+int rl_rank_cut_begin(rl_index* idx, const float* queries, int32_t B, int mem, void* stream) {
+    RL_TRY(check_search_args(idx, queries, B, 1, "rl_rank_cut_begin"));
+    if (B < 1) return fail(RL_ERR_INVALID, "rl_rank_cut_begin: need at least one query");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
+    idx->rank_B = 0;
+    const int64_t n = idx->n_rows, ld = std::max<int64_t>((n + 3) & ~int64_t(3), 4);
+    if ((int64_t)B * ld * 4 > (int64_t)SCORE_BATCH_BYTES) return fail(RL_ERR_UNSUPPORTED, "rl_rank_cut_begin: too many queries for one score batch (split the batch)");
+    DevBuf t_q;
+    const float* d_q;
+    RL_TRY(stage_in(queries, (size_t)B * idx->dim, mem, s, t_q, &d_q));
+    RL_TRY(idx->rank_q.reserve((size_t)B * idx->dim * sizeof(float)));
+    RL_HIP(hipMemcpyAsync(idx->rank_q.p, d_q, (size_t)B * idx->dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+    RL_TRY(idx->scores.reserve((size_t)B * ld * sizeof(float)));
+    RL_TRY(idx->rankbuf.reserve(rank_stage_scratch_bytes(B, std::max<int64_t>(n, 1))));
+    if (n > 0) {
+        RL_TRY(score_rows(idx, idx->rank_q.as<float>(), B, ld, s, nullptr));
+        if (idx->live_row_bits) RL_TRY(launch_mask_scores(idx->scores.as<float>(), B, n, ld, idx->live_row_bits, s));  // tombstones are not in the table
+    }
+    idx->rank_B = B;
+    return finish(mem, s);
+}
+
+namespace {
+uint32_t* rank_level_buf(rl_index* idx) { return reinterpret_cast<uint32_t*>(idx->rankbuf.as<char>() + rank_cut_scratch_bytes(idx->rank_B, std::max<int64_t>(idx->n_rows, 1))); }
+}
+
+int rl_rank_cut_level(rl_index* idx, int level, int64_t rank_limit, uint32_t* out_hist, int mem, void* stream) {
+    if (!idx || !out_hist) return fail(RL_ERR_INVALID, "rl_rank_cut_level: null argument");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
+    if (idx->rank_B < 1) return fail(RL_ERR_INVALID, "rl_rank_cut_level: no rl_rank_cut_begin in progress on this index");
+    if (level < 0 || level > 2 || rank_limit < 1) return fail(RL_ERR_INVALID, "rl_rank_cut_level: level must be 0..2 and rank_limit >= 1");
+    const int64_t n = idx->n_rows, ld = std::max<int64_t>((n + 3) & ~int64_t(3), 4);
+    DevBuf t_o;
+    uint32_t* d_o;
+    const size_t words = (size_t)idx->rank_B * HIST_BINS;
+    RL_TRY(stage_out_begin(out_hist, words, mem, t_o, &d_o));
+    uint32_t* lvl = mem == RL_MEM_DEVICE ? d_o : rank_level_buf(idx);
+    RL_TRY(launch_rank_stage_level(idx->scores.as<float>(), idx->rank_B, n, ld, rank_limit, level, idx->rankbuf.p, lvl, s));
+    if (lvl != d_o) RL_HIP(hipMemcpyAsync(d_o, lvl, words * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    RL_TRY(stage_out_end(out_hist, words, mem, s, t_o));
+    return finish(mem, s);
+}
+
+int rl_rank_cut_level_done(rl_index* idx, int level, const uint32_t* hist_sum, int mem, void* stream) {
+    if (!idx || !hist_sum) return fail(RL_ERR_INVALID, "rl_rank_cut_level_done: null argument");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
+    if (idx->rank_B < 1) return fail(RL_ERR_INVALID, "rl_rank_cut_level_done: no rl_rank_cut_begin in progress on this index");
+    if (level < 0 || level > 2) return fail(RL_ERR_INVALID, "rl_rank_cut_level_done: level must be 0..2");
+    DevBuf t_i;
+    const uint32_t* d_i;
+    RL_TRY(stage_in(hist_sum, (size_t)idx->rank_B * HIST_BINS, mem, s, t_i, &d_i));
+    RL_TRY(launch_rank_stage_set_level(idx->rank_B, level, idx->rankbuf.p, d_i, s));
+    return finish(mem, s);
+}
+
+int rl_rank_cut_ties(rl_index* idx, int64_t rank_limit, uint32_t* out_ties, int mem, void* stream) {
+    if (!idx || !out_ties) return fail(RL_ERR_INVALID, "rl_rank_cut_ties: null argument");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
+    if (idx->rank_B < 1 || rank_limit < 1) return fail(RL_ERR_INVALID, "rl_rank_cut_ties: no rl_rank_cut_begin in progress on this index");
+    const int64_t n = idx->n_rows, ld = std::max<int64_t>((n + 3) & ~int64_t(3), 4);
+    DevBuf t_o;
+    uint32_t* d_o;
+    RL_TRY(stage_out_begin(out_ties, (size_t)idx->rank_B, mem, t_o, &d_o));
+    RL_TRY(launch_rank_stage_ties(idx->scores.as<float>(), idx->rank_B, n, ld, rank_limit, idx->rankbuf.p, d_o, s));
+    RL_TRY(stage_out_end(out_ties, (size_t)idx->rank_B, mem, s, t_o));
+    return finish(mem, s);
+}
+
+int rl_rank_cut_finish(rl_index* idx, int64_t rank_limit, const uint32_t* ties_before, const uint32_t* chunk_filter, int32_t k,
+                       float* out_scores, int32_t* out_rows, int mem, void* stream) {
+    if (!idx || !ties_before || !out_scores || !out_rows) return fail(RL_ERR_INVALID, "rl_rank_cut_finish: null argument");
+    if (k < 1 || k > K_MAX || rank_limit < 1) return fail(RL_ERR_INVALID, "rl_rank_cut_finish: k must be in [1, 2048] and rank_limit >= 1");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
+    const int32_t B = idx->rank_B;
+    if (B < 1) return fail(RL_ERR_INVALID, "rl_rank_cut_finish: no rl_rank_cut_begin in progress on this index");
+    idx->rank_B = 0;
+    const int64_t n = idx->n_rows, ld = std::max<int64_t>((n + 3) & ~int64_t(3), 4);
+    DevBuf t_b, t_f, t_s, t_r;
+    const uint32_t* d_b; const uint32_t* d_f = nullptr; const uint32_t* d_bits = nullptr;
+    float* d_s; int32_t* d_r;
+    RL_TRY(stage_in(ties_before, (size_t)B, mem, s, t_b, &d_b));
+    if (chunk_filter) RL_TRY(stage_in(chunk_filter, (size_t)((idx->n_chunks + 31) / 32), mem, s, t_f, &d_f));
+    RL_TRY(effective_row_mask(idx, d_f, s, &d_bits));
+    RL_TRY(stage_out_begin(out_scores, (size_t)B * k, mem, t_s, &d_s));
+    RL_TRY(stage_out_begin(out_rows, (size_t)B * k, mem, t_r, &d_r));
+    if (n == 0) {
+        RL_TRY(launch_fill_f32(d_s, -std::numeric_limits<float>::infinity(), (int64_t)B * k, s));
+        RL_HIP(hipMemsetAsync(d_r, 0xff, (size_t)B * k * sizeof(int32_t), s));
+    } else {
+        RL_TRY(launch_rank_stage_apply(idx->scores.as<float>(), B, n, ld, rank_limit, d_bits, idx->rankbuf.p, d_b, s));
+        RL_TRY(select_from_scores(idx, idx->rank_q.as<float>(), B, k, d_s, d_r, ld, false, s));
+        RL_TRY(launch_fix_masked(d_s, d_r, (int64_t)B * k, s));  // rows outside the cut / the filter are "no hit"
+    }
+    RL_TRY(stage_out_end(out_scores, (size_t)B * k, mem, s, t_s));
+    RL_TRY(stage_out_end(out_rows, (size_t)B * k, mem, s, t_r));
+    return finish(mem, s);
 }
 
 // ---- a6 + a7 + a8 --------------------------------------------------------------------------------------

@@ -24,6 +24,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
@@ -44,6 +45,7 @@ RcclApi& rccl() {
         RL_SYM(GetUniqueId, "ncclGetUniqueId")
         RL_SYM(CommInitRank, "ncclCommInitRank")
         RL_SYM(AllGather, "ncclAllGather")
+        RL_SYM(AllReduce, "ncclAllReduce")
         RL_SYM(CommDestroy, "ncclCommDestroy")
         RL_SYM(GetErrorString, "ncclGetErrorString")
 #undef RL_SYM
@@ -86,11 +88,21 @@ struct rl_comm {
     float* g_scores = nullptr;   // rl_allgather_merge_topk: [world x n]
     int32_t* g_ids = nullptr;
     size_t cap = 0;         // records (n) the buffers hold
+    // The buffers above are shared by all calls on this communicator; `mu` serialises only their host side.  Calls are asynchronous,
+    // so a call arriving on a DIFFERENT stream than the previous one first waits for that stream (as rl_index does for its scratch).
+    hipStream_t last_stream = nullptr;
+    bool last_stream_set = false;
 };
 
 using namespace rl;
 
 namespace {
+int comm_use(rl_comm* c, hipStream_t s) {
+    if (c->last_stream_set && c->last_stream != s) RL_HIP(hipStreamSynchronize(c->last_stream));
+    c->last_stream = s;
+    c->last_stream_set = true;
+    return RL_OK;
+}
 int comm_reserve(rl_comm* c, size_t n) {
     if (n <= c->cap) return RL_OK;
     for (void* p : {c->send, c->recv, (void*)c->g_scores, (void*)c->g_ids}) if (p) (void)hipFree(p);
@@ -171,6 +183,7 @@ int rl_allgather_topk(rl_comm* comm, const float* local_scores, const int32_t* l
     if (n_queries == 0) return RL_OK;
     if (!local_scores || !local_ids || !out_scores || !out_ids) return fail(RL_ERR_INVALID, "rl_allgather_topk: null argument");
     std::lock_guard<std::mutex> lock(comm->mu);
+    RL_TRY(comm_use(comm, reinterpret_cast<hipStream_t>(stream)));
     return allgather_locked(comm, local_scores, local_ids, (int64_t)n_queries * k, id_offset, out_scores, out_ids,
                             reinterpret_cast<hipStream_t>(stream));
 }
@@ -185,9 +198,31 @@ int rl_allgather_merge_topk(rl_comm* comm, const float* local_scores, const int3
     if (!local_scores || !local_ids || !out_scores || !out_ids) return fail(RL_ERR_INVALID, "rl_allgather_merge_topk: null argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     std::lock_guard<std::mutex> lock(comm->mu);
+    RL_TRY(comm_use(comm, s));
     RL_TRY(comm_reserve(comm, (size_t)n_queries * k_in));
     RL_TRY(allgather_locked(comm, local_scores, local_ids, (int64_t)n_queries * k_in, id_offset, comm->g_scores, comm->g_ids, s));
     return launch_merge_topk(comm->g_scores, comm->g_ids, comm->world, n_queries, k_in, k, out_scores, out_ids, s);
+}
+
+int rl_allreduce_sum_u32(rl_comm* comm, uint32_t* buf, int64_t count, void* stream) {
+    if (!comm || (!buf && count > 0) || count < 0) return fail(RL_ERR_INVALID, "rl_allreduce_sum_u32: bad arguments");
+    if (count == 0 || comm->world == 1) return RL_OK;
+    std::lock_guard<std::mutex> lock(comm->mu);
+    RL_NCCL(rccl().AllReduce(buf, buf, (size_t)count, ncclUint32, ncclSum, comm->comm, reinterpret_cast<hipStream_t>(stream)));
+    return RL_OK;
+}
+
+int rl_allgather_u32(rl_comm* comm, const uint32_t* local, int64_t count, uint32_t* out, void* stream) {
+    if (!comm || count < 0 || (count > 0 && (!local || !out))) return fail(RL_ERR_INVALID, "rl_allgather_u32: bad arguments");
+    if (count == 0) return RL_OK;
+    std::lock_guard<std::mutex> lock(comm->mu);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (comm->world == 1) {
+        if (out != local) RL_HIP(hipMemcpyAsync(out, local, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+        return RL_OK;
+    }
+    RL_NCCL(rccl().AllGather(local, out, (size_t)count, ncclUint32, comm->comm, s));
+    return RL_OK;
 }
 
 }  // extern "C"

@@ -157,6 +157,15 @@ int launch_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_l
 
 // select.hip, rank cut (order-first-then-filter, src/raglite/_search.py:120-141): rows outside the rank_limit best of their
 // query, and rows whose keep bit is clear, become -inf
+// the cut in stages (a corpus sharded over several indexes sums each level's histogram over the shards between them)
+size_t rank_stage_scratch_bytes(int32_t n_queries, int64_t n);
+int launch_rank_stage_level(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int64_t rank_limit, int level, void* scratch,
+                            uint32_t* level_out, hipStream_t s);
+int launch_rank_stage_set_level(int32_t n_queries, int level, void* scratch, const uint32_t* level_in, hipStream_t s);
+int launch_rank_stage_ties(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int64_t rank_limit, void* scratch,
+                           uint32_t* totals_out, hipStream_t s);
+int launch_rank_stage_apply(float* scores, int32_t n_queries, int64_t n, int64_t ld, int64_t rank_limit, const uint32_t* keep_bits,
+                            void* scratch, const uint32_t* tie_base, hipStream_t s);
 size_t rank_cut_scratch_bytes(int32_t n_queries, int64_t n);
 int launch_rank_cut(float* scores, int32_t n_queries, int64_t n, int64_t ld, int64_t rank_limit, const uint32_t* keep_bits,
                     void* scratch, hipStream_t s);

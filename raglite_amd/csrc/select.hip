@@ -576,14 +576,14 @@ __global__ __launch_bounds__(256) void rank_tie_count_kernel(const float* __rest
 // its bit is set (the metadata filter expanded to rows, tombstones included).
 __global__ __launch_bounds__(256) void rank_cut_kernel(float* __restrict__ scores, int64_t n, int64_t ld, uint32_t L,
                                                         const uint32_t* __restrict__ hists, const uint32_t* __restrict__ tie_counts,
-                                                        const uint32_t* __restrict__ keep_bits) {
+                                                        const uint32_t* __restrict__ keep_bits, const uint32_t* __restrict__ tie_base) {
     __shared__ uint32_t h[HIST_BINS];
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t thr[2];
     const int q = blockIdx.y;
     uint32_t T, need_eq;
     rank_prefix(hists + (int64_t)q * 3 * HIST_BINS, 3, L, h, scratch, thr, T, need_eq);
-    uint32_t before = 0;  // ties in the blocks before this one
+    uint32_t before = (tie_base && threadIdx.x == 0) ? tie_base[q] : 0u;  // ties in the shards before this one (sharded cut), then in the blocks before this one
     for (int b = threadIdx.x; b < (int)blockIdx.x; b += 256) before += tie_counts[(int64_t)q * gridDim.x + b];
     uint32_t running;
     (void)block_inclusive_scan(before, scratch, running);
@@ -626,7 +626,82 @@ int launch_rank_cut(float* scores, int32_t nq, int64_t n, int64_t ld, int64_t ra
     hipLaunchKernelGGL(rank_level_kernel<1>, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, L, hists);
     hipLaunchKernelGGL(rank_level_kernel<2>, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, L, hists);
     hipLaunchKernelGGL(rank_tie_count_kernel, dim3(nblk, nq), dim3(256), 0, s, scores, n, ld, L, hists, ties);
-    hipLaunchKernelGGL(rank_cut_kernel, dim3(nblk, nq), dim3(256), 0, s, scores, n, ld, L, hists, ties, keep_bits);
+    hipLaunchKernelGGL(rank_cut_kernel, dim3(nblk, nq), dim3(256), 0, s, scores, n, ld, L, hists, ties, keep_bits, nullptr);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// ---- the same cut in stages, for a corpus SHARDED over several indexes: the histograms of a level are additive,
+// so a caller that sums each level's histogram over the shards between the stages makes every shard walk to the GLOBAL threshold key;
+// ties on it are taken in global row order (tie_base = ties in the shards holding lower rows).  scratch as in launch_rank_cut, +
+// nq x (HIST_BINS + 1) words behind it (a contiguous copy of one level, the per-query tie totals).
+size_t rank_stage_scratch_bytes(int32_t nq, int64_t n) { return rank_cut_scratch_bytes(nq, n) + (size_t)nq * (HIST_BINS + 1) * sizeof(uint32_t); }
+
+__global__ __launch_bounds__(256) void rank_level_copy_kernel(uint32_t* __restrict__ hists, int level, uint32_t* __restrict__ buf, int to_buf) {
+    const int q = blockIdx.x;
+    for (int i = threadIdx.x; i < HIST_BINS; i += 256) {
+        uint32_t* a = hists + ((int64_t)q * 3 + level) * HIST_BINS + i;
+        uint32_t* b = buf + (int64_t)q * HIST_BINS + i;
+        if (to_buf) *b = *a; else *a = *b;
+    }
+}
+__global__ __launch_bounds__(256) void rank_tie_total_kernel(const uint32_t* __restrict__ ties, int nblk, uint32_t* __restrict__ totals) {
+    __shared__ uint32_t scratch[8];
+    const int q = blockIdx.x;
+    uint32_t c = 0;
+    for (int b = threadIdx.x; b < nblk; b += 256) c += ties[(int64_t)q * nblk + b];
+    uint32_t total;
+    (void)block_inclusive_scan(c, scratch, total);
+    if (threadIdx.x == 0) totals[q] = total;
+}
+
+// level 0 .. 2 of the radix walk over this shard's scores; the level's histogram [nq x HIST_BINS] -> level_out (device)
+int launch_rank_stage_level(const float* scores, int32_t nq, int64_t n, int64_t ld, int64_t rank_limit, int level, void* scratch,
+                            uint32_t* level_out, hipStream_t s) {
+    if (nq <= 0 || level < 0 || level > 2 || rank_limit < 1) return fail(RL_ERR_INVALID, "rank cut: bad stage arguments");
+    if (n >= (int64_t)0x7fffffff) return fail(RL_ERR_UNSUPPORTED, "rank cut: more than 2^31-2 elements per query");
+    uint32_t* hists = static_cast<uint32_t*>(scratch);
+    const uint32_t L = (uint32_t)std::min<int64_t>(rank_limit, 0xffffffffll);
+    if (level == 0) RL_HIP(hipMemsetAsync(hists, 0, (size_t)nq * 3 * HIST_BINS * sizeof(uint32_t), s));
+    if (n > 0) {
+        const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((n + 4095) / 4096, nq >= 64 ? 64 : 512));
+        if (level == 0) hipLaunchKernelGGL(rank_level_kernel<0>, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, L, hists);
+        else if (level == 1) hipLaunchKernelGGL(rank_level_kernel<1>, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, L, hists);
+        else hipLaunchKernelGGL(rank_level_kernel<2>, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, L, hists);
+    }
+    hipLaunchKernelGGL(rank_level_copy_kernel, dim3(nq), dim3(256), 0, s, hists, level, level_out, 1);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+// the level's histogram summed over the shards <- level_in (device)
+int launch_rank_stage_set_level(int32_t nq, int level, void* scratch, const uint32_t* level_in, hipStream_t s) {
+    if (nq <= 0 || level < 0 || level > 2) return fail(RL_ERR_INVALID, "rank cut: bad stage arguments");
+    hipLaunchKernelGGL(rank_level_copy_kernel, dim3(nq), dim3(256), 0, s, static_cast<uint32_t*>(scratch), level, const_cast<uint32_t*>(level_in), 0);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+// rows of this shard whose key is the global threshold key, per query -> totals_out [nq] (device)
+int launch_rank_stage_ties(const float* scores, int32_t nq, int64_t n, int64_t ld, int64_t rank_limit, void* scratch, uint32_t* totals_out,
+                           hipStream_t s) {
+    if (nq <= 0) return RL_OK;
+    uint32_t* hists = static_cast<uint32_t*>(scratch);
+    uint32_t* ties = hists + (size_t)nq * 3 * HIST_BINS;
+    const int nblk = (int)std::max<int64_t>(1, (n + RANK_CHUNK - 1) / RANK_CHUNK);
+    const uint32_t L = (uint32_t)std::min<int64_t>(rank_limit, 0xffffffffll);
+    hipLaunchKernelGGL(rank_tie_count_kernel, dim3(nblk, nq), dim3(256), 0, s, scores, n, ld, L, hists, ties);
+    hipLaunchKernelGGL(rank_tie_total_kernel, dim3(nq), dim3(256), 0, s, ties, nblk, totals_out);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+// the cut (+ filter) in place, ties in row order after the tie_base[q] ties of the shards before this one
+int launch_rank_stage_apply(float* scores, int32_t nq, int64_t n, int64_t ld, int64_t rank_limit, const uint32_t* keep_bits, void* scratch,
+                            const uint32_t* tie_base, hipStream_t s) {
+    if (nq <= 0 || n <= 0) return RL_OK;
+    uint32_t* hists = static_cast<uint32_t*>(scratch);
+    uint32_t* ties = hists + (size_t)nq * 3 * HIST_BINS;
+    const int nblk = (int)((n + RANK_CHUNK - 1) / RANK_CHUNK);
+    const uint32_t L = (uint32_t)std::min<int64_t>(rank_limit, 0xffffffffll);
+    hipLaunchKernelGGL(rank_cut_kernel, dim3(nblk, nq), dim3(256), 0, s, scores, n, ld, L, hists, ties, keep_bits, tie_base);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -135,3 +135,58 @@ def test_vector_search_takes_the_order_first_branch(monkeypatch):
     cs2, cc2 = oracle.search_chunks_filtered(E, r2c, q, 4 * 10, 5, ok, "cosine")
     assert got_ids2 == [ids[c] for c in cc2]
     gi.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+@pytest.mark.parametrize("on_device", [False, True])
+def test_staged_cut_over_three_shards_equals_single_index(metric, on_device):
+    """The order-first cut of a SHARDED corpus (`rl_rank_cut_*`, driven by `ShardedIndex._local_rows_ranked`): three shards walk the
+    radix levels together -- each level's histogram summed over the shards, here in plain Python instead of an all-reduce -- and the
+    merge of their lists is bit for bit what ONE index over the whole corpus returns for `rl_search_rows_ranked`
+    (`/root/reference/src/raglite/_search.py:120-141`: `ORDER BY dist LIMIT rank_limit` over the whole table, then the filter).
+    Integer data: thousands of ties, many of them ON the threshold key and spread over the shards."""
+    import torch
+
+    n, dim, B, k, L = 9000, 64, 7, 40, 2500
+    rng = np.random.default_rng(17)
+    E = oracle.synth_matrix(9100, n, dim, "small_int")
+    Q = oracle.synth_matrix(9101, B, dim, "small_int")
+    off = np.concatenate(([0], np.sort(rng.choice(np.arange(1, n), 1200, replace=False)), [n])).astype(np.int64)
+    ok = rng.random(len(off) - 1) < 0.6
+    whole = raglite_amd.DeviceIndex(E, off, metric=metric)
+    ws, wr = whole.search_rows(Q, k, chunk_filter=ok, rank_limit=L)
+    cuts = [0, 400, 801, len(off) - 1]  # chunk ranges of the three shards
+    shards, bases = [], []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        r0, r1 = int(off[lo]), int(off[hi])
+        Es = torch.from_numpy(E[r0:r1]).cuda() if on_device else E[r0:r1]
+        shards.append(raglite_amd.DeviceIndex(Es, off[lo : hi + 1] - off[lo], metric=metric))
+        bases.append((r0, lo, hi))
+    Qs = torch.from_numpy(Q).cuda() if on_device else Q
+    for sh in shards:
+        sh.rank_cut_begin(Qs)
+    for level in range(3):
+        hists = [sh.rank_cut_level(level, L) for sh in shards]
+        total = hists[0] + hists[1] + hists[2]
+        for sh in shards:
+            sh.rank_cut_level_done(level, total)
+    ties = [sh.rank_cut_ties(L) for sh in shards]
+    assert int(sum(int(t.sum()) for t in ties)) > B  # the threshold key IS tied (else this test would not test the tie order)
+    lists_s, lists_r = [], []
+    for i, sh in enumerate(shards):
+        before = ties[0] * 0
+        for t in ties[:i]:
+            before = before + t
+        s, r = sh.rank_cut_finish(L, before, k, chunk_filter=ok[bases[i][1] : bases[i][2]])
+        s, r = (s.cpu().numpy(), r.cpu().numpy()) if on_device else (s, r)
+        lists_s.append(s)
+        lists_r.append(np.where(r >= 0, r + bases[i][0], -1))
+    from raglite_amd._sharded import merge_topk_host
+
+    ms, mr = merge_topk_host(np.stack(lists_s), np.stack(lists_r), k)
+    assert np.array_equal(mr, wr.astype(np.int64)) and np.array_equal(ms.view(np.uint32), np.asarray(ws).view(np.uint32))
+    # ... and the per-shard cut this replaces would have admitted other rows: the test corpus is bigger than the limit on every shard
+    es, er = oracle.search_rows_ranked(E, np.repeat(np.arange(len(off) - 1), np.diff(off)), Q[0], k, ok, L, None, metric, np.float32)
+    assert np.array_equal(mr[0], er)
+    for i in [whole, *shards]:
+        i.close()

@@ -22,7 +22,8 @@ class _OracleLocal:
     def __init__(self, E, off, metric):
         self.E, self.off, self.metric = E, off, metric
 
-    def search_rows(self, q, k, chunk_filter=None):
+    def search_rows(self, q, k, chunk_filter=None, rank_limit=None):
+        assert rank_limit is None  # (over several shards the cut goes through the staged calls below)
         q2 = np.atleast_2d(q)
         S = np.full((len(q2), k), -np.inf, np.float32)
         I = np.full((len(q2), k), -1, np.int32)
@@ -36,6 +37,82 @@ class _OracleLocal:
             S[b, : len(s)] = s
             I[b, : len(i)] = i
         return (S[0], I[0]) if np.ndim(q) == 1 else (S, I)
+
+    # -- the staged rank cut (rl_rank_cut_*), restated in NumPy: order-preserving 32-bit keys, three radix levels (11 + 11 + 10 bits)
+    @property
+    def n_rows(self):
+        return len(self.E)
+
+    @staticmethod
+    def _key(s):
+        u = np.ascontiguousarray(s, dtype=np.float32).view(np.uint32).astype(np.uint64)
+        key = np.where(u & 0x80000000, ~u & 0xFFFFFFFF, u | 0x80000000)
+        return np.where(np.isnan(s), 0, key).astype(np.uint64)
+
+    def search_rows_ranked_single(self, q, k, chunk_ok, rank_limit):
+        r2c = np.repeat(np.arange(len(self.off) - 1), np.diff(self.off))
+        return oracle.search_rows_ranked(self.E, r2c, q, k, chunk_ok, rank_limit, None, self.metric, np.float32)
+
+    def rank_cut_begin(self, queries):
+        q2 = np.atleast_2d(queries)
+        self._sims = np.stack([oracle.similarity(self.E, qq, self.metric, np.float32).astype(np.float32) for qq in q2])
+        self._keys = self._key(self._sims)
+        self._hist = np.zeros((len(q2), 3, 2048), dtype=np.int64)
+        return len(q2)
+
+    def _walk(self, levels, L):
+        """(prefix, need) per query after `levels` summed levels -- find_threshold_bin of select.hip: the bin b with
+        count(bins > b) < need <= count(bins >= b)."""
+        B = len(self._keys)
+        prefix, need = np.zeros(B, dtype=np.uint64), np.full(B, int(L), dtype=np.int64)
+        for lv in range(levels):
+            nb = 1024 if lv == 2 else 2048
+            for b in range(B):
+                h = self._hist[b, lv, :nb]
+                above = np.concatenate(([0], np.cumsum(h[::-1])))[:-1][::-1]  # elements in bins > bin
+                ok = np.nonzero((above < need[b]) & (need[b] <= above + h))[0]
+                binb = int(ok[0]) if len(ok) else 0
+                prefix[b] = (prefix[b] << np.uint64(10 if lv == 2 else 11)) | np.uint64(binb)
+                need[b] -= int(above[binb]) if len(ok) else int(h.sum() - h[0])
+        return prefix, need
+
+    def rank_cut_level(self, level, rank_limit):
+        prefix, _ = self._walk(level, rank_limit)
+        out = np.zeros((len(self._keys), 2048), dtype=np.int32)
+        for b, keys in enumerate(self._keys):
+            if level == 0:
+                sel, bins = np.ones(len(keys), bool), keys >> np.uint64(21)
+            elif level == 1:
+                sel, bins = (keys >> np.uint64(21)) == prefix[b], (keys >> np.uint64(10)) & np.uint64(2047)
+            else:
+                sel, bins = (keys >> np.uint64(10)) == prefix[b], keys & np.uint64(1023)
+            out[b] = np.bincount(bins[sel].astype(np.int64), minlength=2048)
+        return out
+
+    def rank_cut_level_done(self, level, hist_sum):
+        self._hist[:, level, :] = np.asarray(hist_sum, dtype=np.int64)
+
+    def rank_cut_ties(self, rank_limit):
+        T, _ = self._walk(3, rank_limit)
+        return np.array([(self._keys[b] == T[b]).sum() for b in range(len(self._keys))], dtype=np.int32)
+
+    def rank_cut_finish(self, rank_limit, ties_before, k, chunk_filter=None):
+        T, need_eq = self._walk(3, rank_limit)
+        B, n = self._keys.shape
+        r2c = np.repeat(np.arange(len(self.off) - 1), np.diff(self.off))
+        S = np.full((B, k), -np.inf, np.float32)
+        R = np.full((B, k), -1, np.int32)
+        for b in range(B):
+            eq = self._keys[b] == T[b]
+            taken = eq & (np.cumsum(eq) - 1 + int(ties_before[b]) < need_eq[b])  # ties in (global) row order
+            keep = (self._keys[b] > T[b]) | taken
+            if chunk_filter is not None:
+                keep &= np.asarray(chunk_filter, dtype=bool)[r2c]
+            s, r = oracle.topk_desc(np.where(keep, self._sims[b], -np.inf), k)
+            dead = (r >= 0) & ~keep[np.clip(r, 0, n - 1)]
+            S[b, : len(s)] = np.where(dead, -np.inf, s)
+            R[b, : len(r)] = np.where(dead, -1, r)
+        return S, R
 
     def maxsim_topk(self, Q, k, chunk_filter=None):
         s, c = (oracle.maxsim_topk(self.E, self.off, Q, k) if chunk_filter is None
@@ -75,7 +152,12 @@ def _worker(rank, world, port, out_q):
         f_ms = sh.maxsim_topk(Q, 10, chunk_filter=ok)
         f_ch = sh.search_chunks(Q, 40, 6, chunk_filter=ok)
         b_ms = sh.maxsim_topk_batch(np.stack([Q, Q[::-1].copy()]), 10)  # a batch of two queries: one exchange for both
-        out_q.put((rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch, b_ms))
+        # the order-first branch: a GLOBAL cut to the 150 nearest of the 400 rows (integer data: dozens of ties ON the threshold,
+        # split between the shards), then the filter, then top-25 / the two-stage search
+        k_rows = sh.search_rows(Q, 25, chunk_filter=ok, rank_limit=150)
+        k_ch = sh.search_chunks(Q, 40, 6, chunk_filter=ok, rank_limit=150)
+        k_all = sh.search_rows(Q, 25, chunk_filter=ok, rank_limit=4000)  # a limit above the corpus: no cut
+        out_q.put((rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch, b_ms, k_rows, k_ch, k_all))
     finally:
         dist.destroy_process_group()
 
@@ -102,7 +184,15 @@ def test_two_rank_gloo_matches_single_shard():
     E, off, Q = _corpus()
     r2c = np.repeat(np.arange(len(off) - 1), np.diff(off))
     ok = _chunk_mask(len(off) - 1)
-    for rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch, b_ms in results:
+    for rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch, b_ms, k_rows, k_ch, k_all in results:
+        for b in range(len(Q)):  # the rank cut across shards == the single-table cut (`_search.py:120-141`), ties included
+            es, ei = oracle.search_rows_ranked(E, r2c, Q[b], 25, ok, 150, None, "dot", np.float32)
+            assert np.array_equal(k_rows[1][b], ei), f"rank {rank} query {b} (rank cut): {k_rows[1][b][:8]} vs {ei[:8]}"
+            np.testing.assert_array_equal(k_rows[0][b], es.astype(np.float32))
+            cs, cc = oracle.search_chunks_ranked(E, r2c, Q[b], 40, 6, ok, 150, None, "dot", np.float32)
+            assert k_ch[2][b] == len(cc) and k_ch[1][b, : len(cc)].tolist() == cc.tolist()
+            np.testing.assert_array_equal(k_ch[0][b, : len(cc)], cs.astype(np.float32))
+            assert np.array_equal(k_all[1][b], f_rows[1][b]) and np.array_equal(k_all[0][b], f_rows[0][b])
         for j, Qj in enumerate((Q, Q[::-1].copy())):
             ms, mc = oracle.maxsim_topk(E, off, Qj, 10)
             assert np.array_equal(b_ms[1][j], mc)
