@@ -62,12 +62,11 @@ namespace {
 constexpr int PP_RT = 128;                       // corpus rows per tile
 constexpr int PP_NBLK = PP_RT / 16;              // 16-row blocks per tile
 constexpr int PP_QPP = 16;                       // queries per pass
-constexpr int PP_DC = 4, PP_DQ = 3;              // ring depths: corpus slabs, query slabs
+constexpr int PP_DC = 4, PP_DQ = 4;              // ring depths: corpus slabs, query slabs
 constexpr int PP_CSLOT = PP_NBLK * 1024;         // corpus slab: 8 blocks x 1 KiB
 constexpr int PP_QSLOT = PP_QPP * 2 * 1024;      // query slab: 16 queries x 2 blocks of 16 vectors x 1 KiB
 constexpr int PP_QOFF = PP_DC * PP_CSLOT;
-constexpr int PP_STAGE = PP_QOFF + PP_DQ * PP_QSLOT;  // epilogue staging: 4 KiB per wave
-constexpr int PP_LDS = PP_STAGE + 8 * 4096;           // 32 + 96 + 32 = 160 KiB: all of a CU's LDS
+constexpr int PP_LDS = PP_QOFF + PP_DQ * PP_QSLOT;    // 32 + 128 = 160 KiB: all of a CU's LDS
 
 __device__ __forceinline__ int64_t pp_uniform_i64(int64_t v) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v);
@@ -123,7 +122,7 @@ __device__ __forceinline__ h16x8 pp_h(const f32x4& v) {
 }  // namespace
 
 // DBG (timing experiments only, RAGLITE_PP_DBG; wrong results): 2 = no MFMAs, 8 = no LDS fragment reads, 16 = no corpus DMAs,
-// 32 = no query DMAs, 128 = no tile epilogue, 256 = no stores, 8192 = epilogue timeline (RAGLITE_PP_TRACE=1)
+// 32 = no query DMAs, 64 = every corpus DMA re-reads the first tile (L2 hits), 128 = no tile epilogue (the MFMAs stay), 256 = no stores, 1024 = waves 4-7 run the stream of waves 0-3 (no lag), 8192 = epilogue timeline (RAGLITE_PP_TRACE=1)
 template <int DBG>
 __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restrict__ planes, int64_t n_rows, int32_t nslab,
                                                            const char* __restrict__ qfrag, const float* __restrict__ qmeta, int32_t n_q,
@@ -164,16 +163,18 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     // ---- this wave's queries: 2 wv and 2 wv + 1 ---------------------------------------------------------------------------------------
     const bool has0 = 2 * wv < n_q, has1 = 2 * wv + 1 < n_q;  // wave-uniform
 
-    // ---- feeder duty: waves 0-3 fetch query pieces 8 wv .. + 7 (piece = 2 * query + block of 16 vectors) of slab g + 3, then corpus
+    // ---- feeder duty: waves 0-3 fetch query pieces 8 wv .. + 7 (piece = 2 * query + block of 16 vectors) of slab g + 4, then corpus
     // blocks 2 wv, 2 wv + 1 of slab g + 4, during slab g ------------------------------------------------------------------------
+    constexpr int QPW = 8, CPW = 2;  // pieces per feeder and slab
     const bool feeder = wv < 4;
-    const char* qb1[8];
-    const char* cb1[2];
+    const char* qb1[QPW];
+    const char* cb1[CPW];
     int fq_s = 0, fq_slot = 0, fc_s = 0, fc_tile = 0, fc_slot = 0;
     auto feed_tile = [&](int t) __attribute__((always_inline)) {
-        const int32_t b0 = ((org + t * PP_RT) >> 4) + 2 * (wv & 3);
+        if constexpr (DBG & 64) t = 0;  // (timing: the corpus stream out of L2)
+        const int32_t b0 = ((org + t * PP_RT) >> 4) + CPW * (wv & 3);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < CPW; ++i) {
             int32_t blk = b0 + i;
             blk = blk < last_blk ? blk : last_blk;  // past the image: harmless re-read of the last block, never emitted
             cb1[i] = planes + pp_uniform_i64((int64_t)blk * nslab * 1024);
@@ -181,8 +182,8 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     };
     feed_tile(0);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int p = 8 * (wv & 3) + i;
+    for (int i = 0; i < QPW; ++i) {
+        const int p = QPW * (wv & 3) + i;
         int ql = p >> 1;
         ql = ql < n_q ? ql : n_q - 1;  // (clamped: pieces of queries the pass does not have are copied from a valid one, never used)
         qb1[i] = qfrag + pp_uniform_i64(((int64_t)ql * nslab * 4 + 2 * (p & 1)) * 1024);  // hi fragments of block p & 1
@@ -190,17 +191,16 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     auto issue_q = [&](int i) __attribute__((always_inline)) {
         if (!feeder) return;
         if constexpr (DBG & 32) return;
-        pp_dma<false>(lds_base + (uint32_t)(PP_QOFF + fq_slot * PP_QSLOT + (8 * wv + i) * 1024), qb1[i] + (int64_t)fq_s * 4096, lane16);
+        pp_dma<false>(lds_base + (uint32_t)(PP_QOFF + fq_slot * PP_QSLOT + (QPW * wv + i) * 1024), qb1[i] + (int64_t)fq_s * 4096, lane16);
     };
     auto advance_q = [&]() __attribute__((always_inline)) {
         if (++fq_s == nslab) fq_s = 0;
         fq_slot = fq_slot + 1 == PP_DQ ? 0 : fq_slot + 1;
     };
-    auto issue_c = [&]() __attribute__((always_inline)) {
+    auto issue_c1 = [&](int i) __attribute__((always_inline)) {
         if (!feeder) return;
         if constexpr (DBG & 16) return;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) pp_dma<true>(lds_base + (uint32_t)(fc_slot * PP_CSLOT + (2 * wv + i) * 1024), cb1[i] + (int64_t)fc_s * 1024, lane16);
+        pp_dma<true>(lds_base + (uint32_t)(fc_slot * PP_CSLOT + (CPW * wv + i) * 1024), cb1[i] + (int64_t)fc_s * 1024, lane16);
     };
     auto advance_c = [&]() __attribute__((always_inline)) {
         if (++fc_s == nslab) {  // past the end: re-fetch the last tile (keeps the vmcnt bookkeeping uniform)
@@ -209,16 +209,16 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         }
         fc_slot = fc_slot + 1 == PP_DC ? 0 : fc_slot + 1;
     };
-    // A feeder's queue, old -> new, half-way through slab g: .. Q(g+1) x8 | C(g+2) x2, Q(g+2) x8, C(g+3) x2 -- everything up to its query
-    // pieces of slab g + 1 (and with them the corpus pieces of slab g + 1, older) has retired when 12 operations are outstanding, plus
-    // the stores of a tile that finished since (newer than all of these for the two waits after it).
+    // A feeder's queue, old -> new, half-way through slab g: .. Q(g+2) x8, C(g+2) x2 | Q(g+3) x8, C(g+3) x2 -- everything up to its pieces of
+    // slab g + 2 has retired when 10 operations are outstanding, plus the stores of a tile that finished since (newer than all of these for
+    // the two waits after it).
     int st_pending = 0, st_slabs = 0;
     auto certify = [&]() __attribute__((always_inline)) {
-        if (feeder) pp_wait_vm<12>(st_slabs > 0 ? st_pending : 0);
+        if (feeder) pp_wait_vm<QPW + CPW>(st_slabs > 0 ? st_pending : 0);
         if (st_slabs > 0) --st_slabs;
     };
 
-    // ---- accumulators: S^T[query vector 16 qb + 4 g + u][corpus row 16 a + j], lane = 16 g + j; [query of the wave][qb][a] ------
+    // ---- accumulators: S[corpus row 16 a + 4 g + u][query vector 16 qb + n], lane = 16 g + n; [query of the wave][qb][a] ------
     f32x4 acc[2][2][PP_NBLK];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
@@ -240,70 +240,204 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         }
     };
 
-    // ---- one K slab: MFMAs of slab g from registers; HALF-WAY through, the feeders' wait and the workgroup barrier -- they certify slab
-    // g + 1 as landed and slab g's LDS slot as free -- then, between the remaining MFMAs, the fragment reads of slab g + 1 and this
-    // wave's DMAs.  The first four MFMA groups need nothing from anybody: whoever is late (a feeder waiting for its pieces, the younger
-    // wave of a SIMD) is late while the matrix pipe still has work.  No compiler-visible memory operation in here: the body carries no
-    // wait but the two written out.
+    // ---- one K slab: MFMAs of slab g from registers, and after each block's four MFMAs the LDS read that re-loads its fragment register for
+    // slab g + 1 (the query fragments go with the first four) -- the wave's 12 KiB of fragment reads spread over the whole slab: squeezed
+    // into its second half, as in the first version, all eight waves' reads (96 KiB, 768 cycles of LDS bandwidth) did not fit beside 512 cycles
+    // of MFMAs and every slab ended waiting for LDS (measured: 0.71 ms per pass without any DMA where the MFMAs alone are 0.42).  HALF-WAY
+    // through, the feeders' wait and the workgroup barrier: they certify slab g + 2 as landed -- the reads of the NEXT slab may start with its
+    // first MFMA -- and slab g's LDS slots as free (everybody read them during slab g - 1): this wave's DMAs of slab g + 4 follow, between the
+    // remaining MFMAs.  No compiler-visible memory operation in here: the body carries no wait but the two written out.
     auto mfma_group = [&](f32x4 (&q)[4], auto A_) __attribute__((always_inline)) {
         constexpr int A = decltype(A_)::value;
         if constexpr (!(DBG & 2)) {
-            acc[0][0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(q[0]), pp_h(ef[A]), acc[0][0][A], 0, 0, 0);
-            acc[0][1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(q[1]), pp_h(ef[A]), acc[0][1][A], 0, 0, 0);
-            acc[1][0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(q[2]), pp_h(ef[A]), acc[1][0][A], 0, 0, 0);
-            acc[1][1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(q[3]), pp_h(ef[A]), acc[1][1][A], 0, 0, 0);
+            acc[0][0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(ef[A]), pp_h(q[0]), acc[0][0][A], 0, 0, 0);
+            acc[0][1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(ef[A]), pp_h(q[1]), acc[0][1][A], 0, 0, 0);
+            acc[1][0][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(ef[A]), pp_h(q[2]), acc[1][0][A], 0, 0, 0);
+            acc[1][1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(ef[A]), pp_h(q[3]), acc[1][1][A], 0, 0, 0);
         }
     };
-    auto slab = [&](f32x4 (&q)[4], f32x4 (&qn)[4]) __attribute__((always_inline)) {
-        [&]<int... A>(std::integer_sequence<int, A...>) {
-            ((mfma_group(q, std::integral_constant<int, A>{}), __builtin_amdgcn_sched_barrier(0)), ...);
-        }(std::make_integer_sequence<int, 4>{});
-        certify();  // this wave's pieces of slab g + 1
-        asm volatile("s_barrier" ::: "memory");  // slab g + 1 is readable; everybody finished reading slab g (lgkmcnt(0) at the end of slab g - 1)
-        [&]<int... A>(std::integer_sequence<int, A...>) { (read_slab(qn, std::integral_constant<int, A>{}), ...); }
-        (std::make_integer_sequence<int, 4>{});  // corpus blocks 0-3 (their MFMAs are done) and the four query fragments of slab g + 1
-        [&]<int... B>(std::integer_sequence<int, B...>) {
-            (([&] {
-                 constexpr int A = 4 + B;
-                 mfma_group(q, std::integral_constant<int, A>{});
-                 read_slab(qn, std::integral_constant<int, A>{});
-                 issue_q(2 * B);  // this wave's DMAs, spread over the steps: in flight while it multiplies
-                 issue_q(2 * B + 1);
-                 __builtin_amdgcn_sched_barrier(0);
-             }()),
-             ...);
-        }(std::make_integer_sequence<int, 4>{});
-        issue_c();
+    // The two waves of a SIMD (w and w + 4) run the same stream half a step apart: waves 4-7 (LAG) issue each fragment read one MFMA group later
+    // than waves 0-3, so that one wave's LDS instructions (a ds_read_b128 holds its wave's issue for ~30 cycles) sit beside its partner's
+    // four MFMAs instead of beside the partner's own reads -- an in-order wave cannot put an MFMA into matrix-pipe time that is idle while it
+    // is itself busy issuing something else.
+    auto slab = [&](f32x4 (&q)[4], f32x4 (&qn)[4], auto LAG_) __attribute__((always_inline)) {
+        constexpr bool LAG = decltype(LAG_)::value;
+        auto G = [&](auto A_) __attribute__((always_inline)) { mfma_group(q, A_); };
+        auto R = [&](auto A_) __attribute__((always_inline)) { read_slab(qn, A_); };
+        auto D = [&](auto B_) __attribute__((always_inline)) {  // a quarter of this wave's query pieces of slab g + 4
+            constexpr int B = decltype(B_)::value;
+            issue_q(2 * B);
+            issue_q(2 * B + 1);
+        };
+#define PP_I(N) std::integral_constant<int, N>{}
+        if constexpr (!LAG) {
+            G(PP_I(0)); R(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(1)); R(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(2)); R(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(3)); R(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the reads of the previous slab's second half: corpus blocks 4-7 of slab g (issued half a slab ago)
+        } else {
+            G(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(1)); R(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(2)); R(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(3)); R(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        }
+        pp_pin(ef[4], ef[5], ef[6], ef[7]);
+        certify();  // this wave's pieces of slab g + 2
+        asm volatile("s_barrier" ::: "memory");  // slab g + 2 is readable from the next slab on; everybody finished reading slab g (its last reads were waited for just above)
+        if constexpr (!LAG) {
+            G(PP_I(4)); R(PP_I(4)); D(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(5)); R(PP_I(5)); D(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(6)); R(PP_I(6)); D(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(7)); R(PP_I(7)); D(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
+        } else {
+            G(PP_I(4)); R(PP_I(3)); D(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(5)); R(PP_I(4)); D(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(6)); R(PP_I(5)); D(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(7)); R(PP_I(6)); D(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
+            R(PP_I(7)); __builtin_amdgcn_sched_barrier(0);
+        }
+#undef PP_I
+        issue_c1(0);
+        issue_c1(1);
         advance_q();
         advance_c();
         c_slot = c_slot + 1 == PP_DC ? 0 : c_slot + 1;
         q_slot = q_slot + 1 == PP_DQ ? 0 : q_slot + 1;
     };
-    auto landed = [&](f32x4 (&qn)[4]) __attribute__((always_inline)) {  // after lgkmcnt(0): the fragments just read are real values now
+    // LDS reads return in order: with the four reads of blocks 4-7 still outstanding, the eight in front of them (blocks 0-3 and the query
+    // fragments of slab g + 1) are real values now -- a wait that was served half a slab ago instead of one that exposes an LDS round trip
+    // under load at the end of every slab (lgkmcnt(0) there: + 0.18 ms per pass).  Blocks 4-7 are waited for before the next barrier.
+    auto landed = [&](f32x4 (&qn)[4]) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
         pp_pin(ef[0], ef[1], ef[2], ef[3]);
-        pp_pin(ef[4], ef[5], ef[6], ef[7]);
         pp_pin(qn[0], qn[1], qn[2], qn[3]);
     };
 
-    // ---- tile epilogue -----------------------------------------------------------------------------------------------------------
-    // Straight-line and branch-free, three LDS round trips per block of 16 rows (the first versions walked the chunk ends with scalar
-    // branches and summed each finished chunk on the spot: ~1 700 cycles of dependent latencies per block, profiles/r03_p):
-    //   (1) the block's 16 x 64 scores (both queries of the wave) -> this wave's 4 KiB of staging, read back with lane = query vector,
-    //       register = row;  (2) a running maximum down the rows, restarted after every chunk end (a select on a scalar condition), every
-    //       row's running value back into the staging area;  (3) read back with lane = (row, query, half of the vectors): 16 values, a tree
-    //       of adds, one lane swap for the other half -- the MaxSim score of the chunk ENDING in that row, and one masked store for all the
-    //       chunks that end in the block.
-    // Staging layout: [16 rows][16 chunks of 4 query vectors] x 16 B, chunk c of row r at position c ^ r: every access below touches each bank once.
-    char* const stage = smem + PP_STAGE + wv * 4096;
-    const int fj = lane & 15, fg = lane >> 4;
-    float run = -INFINITY;  // maximum over the rows of the chunk still open, for this lane's (query, vector); lives across blocks and tiles
+    // ---- tile epilogue: all in registers ----------------------------------------------------------------------------------------------
+    // A block's 16 x 64 scores sit in 16 registers: register (c = 2 q + qb, u), lane (g, n) = row 4 g + u, vector n of set c.  Per block:
+    //   (1) 4 x 4 transposes between the register index c and the lane group g (v_permlane32_swap / v_permlane16_swap, 16 instructions):
+    //       afterwards lane (G, n) owns query vector n of set G and register 4 c + u is corpus row 4 c + u -- every row of the block in one lane;
+    //   (2) the per-chunk maximum is a running v_max down the 16 registers; a chunk end is the same row in every lane, so "restart here"
+    //       is EXEC = 0 for that one instruction (s_bitcmp1 + s_cselect on the scalar unit): 16 VALU operations for all 64 query vectors.
+    //       The chunk still open at the end of the block is register 15, carried in `run` across blocks and tiles;
+    //   (3) the sum over the 32 vectors of a query, for all 16 rows at once: the two sets of a query are neighbouring lane groups (one
+    //       v_permlane16_swap + add per PAIR of rows leaves rows r, r + 8 of both queries in the four lane groups), then a reduction over the 16
+    //       lanes of a DPP row in which every step also halves the number of registers (bank-masked v_add_f32_dpp at distances 8 and 4,
+    //       quad permutes for 2 and 1): 32 instructions, one register of results -- lane 16 G + 4 b + t holds row
+    //       (t >> 1) + 2 (b & 1) + 4 (b >> 1) + 8 (G & 1) of query G >> 1 -- and one masked store for all the chunks that end in the block.
+    // ~75 VALU operations per block and no LDS traffic (the first in-register version, a segmented DPP scan along the lanes with the rows
+    // across a DPP row, took ~275; the LDS transpose before this one ~170 plus 16 KiB of LDS traffic per block and wave: profiles/r03_l..q).
+    const int fG = lane >> 4, fb = (lane >> 2) & 3, ft = lane & 3;
+    const int my_row = (ft >> 1) + 2 * (fb & 1) + 4 * (fb >> 1) + 8 * (fG & 1);
+    const uint32_t my_bit = 1u << my_row, my_below = my_bit - 1u;
+    float run = -INFINITY;  // maximum over the rows of the chunk still open, for this lane's query vector; lives across blocks and tiles
+    uint32_t prev_last_end = 1;  // the row before the workgroup's first block closes a chunk as far as this workgroup is concerned
     // chunk ordinal of the next chunk to finish: no chunk is empty, so it advances by one per chunk end -- one scalar load per workgroup
     int32_t ord_run = __builtin_amdgcn_readfirstlane(row_to_chunk[org]);
-    // lane = (row fj, query e_q, vector half e_h) of step (3)
-    const int e_q = (lane >> 4) & 1, e_h = lane >> 5;
-    const bool e_has = e_q == 0 ? has0 : has1;
+    const int e_q = fG >> 1;
+    const bool e_has = (e_q == 0 ? has0 : has1) && (ft & 1) == 0;  // (lanes t and t ^ 1 hold the same sum)
     const float e_unscale = e_has ? qmeta[2 * (2 * wv + e_q)] * inv_e_scale : 0.f;
     float* const e_out = out + (int64_t)(e_has ? 2 * wv + e_q : 0) * out_stride;
+    const uint64_t odd_pairs = 0xccccccccccccccccull;  // lanes with t >= 2
+    auto swap32 = [](float& x, float& y) __attribute__((always_inline)) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+        x = __uint_as_float(r[0]);
+        y = __uint_as_float(r[1]);
+    };
+    auto swap16 = [](float& x, float& y) __attribute__((always_inline)) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+        x = __uint_as_float(r[0]);
+        y = __uint_as_float(r[1]);
+    };
+    auto block_epilogue = [&](auto A_, uint32_t E, int32_t base, int& n_st) __attribute__((always_inline)) {
+        constexpr int a = decltype(A_)::value;
+        float z[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = acc[r >> 3][(r >> 2) & 1][a][r & 3];
+        // (1)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { swap32(z[u], z[8 + u]); swap32(z[4 + u], z[12 + u]); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { swap16(z[u], z[4 + u]); swap16(z[8 + u], z[12 + u]); }
+        // (2)
+        uint64_t saved;
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "s_bitcmp1_b32 %[ple], 0\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z0], %[z0], %[run]\n\t"
+            "s_bitcmp1_b32 %[E], 0\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z1], %[z1], %[z0]\n\t"
+            "s_bitcmp1_b32 %[E], 1\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z2], %[z2], %[z1]\n\t"
+            "s_bitcmp1_b32 %[E], 2\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z3], %[z3], %[z2]\n\t"
+            "s_bitcmp1_b32 %[E], 3\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z4], %[z4], %[z3]\n\t"
+            "s_bitcmp1_b32 %[E], 4\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z5], %[z5], %[z4]\n\t"
+            "s_bitcmp1_b32 %[E], 5\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z6], %[z6], %[z5]\n\t"
+            "s_bitcmp1_b32 %[E], 6\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z7], %[z7], %[z6]\n\t"
+            "s_bitcmp1_b32 %[E], 7\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z8], %[z8], %[z7]\n\t"
+            "s_bitcmp1_b32 %[E], 8\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z9], %[z9], %[z8]\n\t"
+            "s_bitcmp1_b32 %[E], 9\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z10], %[z10], %[z9]\n\t"
+            "s_bitcmp1_b32 %[E], 10\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z11], %[z11], %[z10]\n\t"
+            "s_bitcmp1_b32 %[E], 11\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z12], %[z12], %[z11]\n\t"
+            "s_bitcmp1_b32 %[E], 12\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z13], %[z13], %[z12]\n\t"
+            "s_bitcmp1_b32 %[E], 13\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z14], %[z14], %[z13]\n\t"
+            "s_bitcmp1_b32 %[E], 14\n\ts_cselect_b64 exec, 0, -1\n\tv_max_f32 %[z15], %[z15], %[z14]\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [sv] "=&s"(saved), [z0] "+v"(z[0]), [z1] "+v"(z[1]), [z2] "+v"(z[2]), [z3] "+v"(z[3]), [z4] "+v"(z[4]), [z5] "+v"(z[5]),
+              [z6] "+v"(z[6]), [z7] "+v"(z[7]), [z8] "+v"(z[8]), [z9] "+v"(z[9]), [z10] "+v"(z[10]), [z11] "+v"(z[11]), [z12] "+v"(z[12]),
+              [z13] "+v"(z[13]), [z14] "+v"(z[14]), [z15] "+v"(z[15])
+            : [run] "v"(run), [E] "s"(E), [ple] "s"(prev_last_end)
+            : "scc");
+        run = z[15];  // (used only if row 15 does not end a chunk: prev_last_end)
+        prev_last_end = (E >> 15) & 1u;
+        // (3) rows r and r + 8 of both queries: lane groups (0: r of query 0, 1: r + 8 of query 0, 2: r of query 1, 3: r + 8 of query 1)
+        float s8[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            swap16(z[k], z[k + 8]);
+            s8[k] = z[k] + z[k + 8];
+        }
+        float t0, t1, w;
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %[s0], %[s0], %[s0] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %[s1], %[s1], %[s1] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %[s2], %[s2], %[s2] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %[s3], %[s3], %[s3] row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+            "v_add_f32_dpp %[s0], %[s4], %[s4] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %[s1], %[s5], %[s5] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %[s2], %[s6], %[s6] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %[s3], %[s7], %[s7] row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+            "v_add_f32_dpp %[s0], %[s0], %[s0] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %[s1], %[s1], %[s1] row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_add_f32_dpp %[s0], %[s2], %[s2] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "v_add_f32_dpp %[s1], %[s3], %[s3] row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %[t0], %[s0], %[s0] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_add_f32_dpp %[t1], %[s1], %[s1] quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+            "v_cndmask_b32_e64 %[w], %[t0], %[t1], %[odd]\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32_dpp %[w], %[w], %[w] quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf"
+            : [s0] "+v"(s8[0]), [s1] "+v"(s8[1]), [s2] "+v"(s8[2]), [s3] "+v"(s8[3]), [t0] "=&v"(t0), [t1] "=&v"(t1), [w] "=&v"(w)
+            : [s4] "v"(s8[4]), [s5] "v"(s8[5]), [s6] "v"(s8[6]), [s7] "v"(s8[7]), [odd] "s"(odd_pairs));
+        int32_t lo = r_lo - base, hi = r_hi - base;  // rows of this block inside the workgroup's range
+        lo = lo < 0 ? 0 : lo;
+        hi = hi < 0 ? 0 : hi;
+        asm("" : "+s"(lo), "+s"(hi));  // (stay on the scalar unit: the clamp is a v_med3 otherwise)
+        lo = lo > 16 ? 16 : lo;
+        hi = hi > 16 ? 16 : hi;
+        uint32_t EM = E & ((1u << hi) - 1u) & ~((1u << lo) - 1u);
+        asm("" : "+s"(EM));
+        if (EM != 0u) {  // wave-uniform: some chunk of this workgroup ends in this block
+            if ((EM & my_bit) && e_has && !(DBG & 256)) e_out[ord_run + __builtin_popcount(E & my_below)] = w * e_unscale;
+            if constexpr (DBG & 256) run += w;  // (timing: no store, the sum stays live)
+            ++n_st;
+        }
+        ord_run += __builtin_popcount(E);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) acc[q][qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
     auto epilogue = [&](int t) __attribute__((always_inline)) {
         if constexpr (DBG & 128) return;
         tile_now = t;
@@ -319,88 +453,65 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
 #pragma unroll
         for (int i = 0; i < 4; ++i) mm[i] = odd ? (m[i] >> 16) | (m[i + 1] << 16) : m[i];
         int n_st = 0;
-#pragma unroll
-        for (int a = 0; a < PP_NBLK; ++a) {
-            const uint32_t E = (mm[a >> 1] >> (16 * (a & 1))) & 0xffffu;
-            const int32_t base = row0 + 16 * a;
-            // (1) transpose through LDS (this wave's own 4 KiB; the LDS operations of one wave execute in order)
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    *reinterpret_cast<f32x4*>(stage + fj * 256 + (((8 * q + 4 * qb + fg) ^ fj) << 4)) = acc[q][qb][a];
-                    acc[q][qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
-            float x[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = *reinterpret_cast<const float*>(stage + r * 256 + ((((lane >> 2) ^ r) & 15) << 4) + ((lane & 3) << 2));
-            // (2) running maximum; row r's value goes back to where x[r] came from
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                asm("v_max_f32 %0, %1, %2" : "=v"(run) : "v"(run), "v"(x[r]));  // (fmaxf would quiet both operands first: three instructions)
-                *reinterpret_cast<float*>(stage + r * 256 + ((((lane >> 2) ^ r) & 15) << 4) + ((lane & 3) << 2)) = run;
-                run = ((E >> r) & 1u) ? -INFINITY : run;  // wave-uniform condition
-            }
-            // (3) lane (row fj, query e_q, half e_h): vectors 16 e_h .. + 15 of the query = chunks 8 e_q + 4 e_h + i of row fj
-            f32x4 v[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(stage + fj * 256 + (((8 * e_q + 4 * e_h + i) ^ fj) << 4));
-            const f32x4 w4 = (v[0] + v[1]) + (v[2] + v[3]);
-            float tsum = (w4[0] + w4[1]) + (w4[2] + w4[3]);
-            const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(tsum), __float_as_uint(tsum), false, false);  // + the other half
-            tsum = __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
-            int32_t lo = r_lo - base, hi = r_hi - base;  // rows of this block inside the workgroup's range
-            lo = lo < 0 ? 0 : (lo > 16 ? 16 : lo);
-            hi = hi < 0 ? 0 : (hi > 16 ? 16 : hi);
-            const uint32_t EM = E & ((1u << hi) - 1u) & ~((1u << lo) - 1u);
-            if (EM != 0u) {  // wave-uniform: some chunk of this workgroup ends in this block
-                const uint32_t below = E & ((1u << fj) - 1u);
-                if (lane < 32 && ((EM >> fj) & 1u) && e_has && !(DBG & 256)) e_out[ord_run + __builtin_popcount(below)] = tsum * e_unscale;
-                if constexpr (DBG & 256) run += tsum;  // (timing: no store, the sum stays live)
-                ++n_st;
-            }
-            ord_run += __builtin_popcount(E);
-            stamp(1 + a);
-        }
+        [&]<int... A>(std::integer_sequence<int, A...>) {
+            ((block_epilogue(std::integral_constant<int, A>{}, (mm[A >> 1] >> (16 * (A & 1))) & 0xffffu, row0 + 16 * A, n_st), stamp(1 + A)), ...);
+        }(std::make_integer_sequence<int, PP_NBLK>{});
         stamp(9);
         // The stores are newer than every DMA issued so far: they count in the feeders' next two waits (see certify()).
         st_pending = n_st;
         st_slabs = n_st > 0 ? 2 : 0;
     };
 
-    // ---- prologue: Q(0..2), C(0..3) landed (the steady state issues Q(g + 3), C(g + 4) during slab g); slab 0's fragments ----------
+    // ---- prologue: Q(0..3), C(0..3) landed (the steady state issues Q(g + 4), C(g + 4) during slab g); slab 0's fragments ----------
     if (feeder) {
-        for (int i = 0; i < 3; ++i) {
+        for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) issue_q(j);
+            for (int j = 0; j < CPW; ++j) issue_c1(j);
+#pragma unroll
+            for (int j = 0; j < QPW; ++j) issue_q(j);
             advance_q();
+            advance_c();
         }
-        for (int i = 0; i < 4; ++i) { issue_c(); advance_c(); }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     [&]<int... A>(std::integer_sequence<int, A...>) { (read_slab(qA, std::integral_constant<int, A>{}), ...); }
     (std::make_integer_sequence<int, PP_NBLK>{});
     c_slot = 1;
     q_slot = 1;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     landed(qA);
     // ---- main loop: two slabs per iteration (two static sets of query fragment registers) -----------------------------------------
     int c_s = 0, c_tile = 0;
-    auto step = [&](f32x4 (&q)[4], f32x4 (&qn)[4]) __attribute__((always_inline)) {
-        slab(q, qn);
-        if (++c_s == nslab) {
-            epilogue(c_tile);
-            c_s = 0;
-            ++c_tile;
+    auto main_loop = [&](auto LAG_) __attribute__((always_inline)) {
+        auto step = [&](f32x4 (&q)[4], f32x4 (&qn)[4]) __attribute__((always_inline)) {
+            slab(q, qn, LAG_);
+            if (++c_s == nslab) {
+                epilogue(c_tile);
+                c_s = 0;
+                ++c_tile;
+            }
+            landed(qn);
+        };
+        for (int g = 0; g < total; g += 2) {
+            step(qA, qB);
+            if (g + 1 < total) step(qB, qA);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's fragments of slab g + 1 are in its registers
-        landed(qn);
     };
-    for (int g = 0; g < total; g += 2) {
-        step(qA, qB);
-        if (g + 1 < total) step(qB, qA);
-    }
+    constexpr bool no_lag = (DBG & 1024) != 0;  // (timing: every wave runs the same stream)
+    if (wv < 4 || no_lag) main_loop(std::false_type{});
+    else main_loop(std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
+    if constexpr (DBG & 128) {  // (timing without the epilogue: the accumulators must stay live, or the compiler deletes the MFMAs with it)
+        if (n_q > 1000) {
+            f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int a = 0; a < PP_NBLK; ++a) t += acc[q][qb][a];
+            out[lane] = (t[0] + t[1]) + (t[2] + t[3]);
+        }
+    }
 }
 
 // n_q (1..16) queries `first .. first + n_q - 1` of a launch_query_planes buffer over `n_queries`, each nq (<= 32) vectors, against
@@ -427,7 +538,7 @@ int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void*
                        chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if, trace)
     if (trace) {
         static int calls = 0;
-        if (dbg == 58) RL_PP_LAUNCH(8250); else RL_PP_LAUNCH(8192);
+        RL_PP_LAUNCH(8192);
         if (++calls == 10) {
             static unsigned long long h[8 * 16];
             (void)hipStreamSynchronize(s);
@@ -442,12 +553,11 @@ int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void*
         return RL_OK;
     }
     if (dbg == 2) RL_PP_LAUNCH(2);
-    else if (dbg == 48) RL_PP_LAUNCH(48);
-    else if (dbg == 58) RL_PP_LAUNCH(58);
+    else if (dbg == 1024) RL_PP_LAUNCH(1024);
+    else if (dbg == 1152) RL_PP_LAUNCH(1152);
+    else if (dbg == 176) RL_PP_LAUNCH(176);
+    else if (dbg == 184) RL_PP_LAUNCH(184);
     else if (dbg == 128) RL_PP_LAUNCH(128);
-    else if (dbg == 186) RL_PP_LAUNCH(186);
-    else if (dbg == 256) RL_PP_LAUNCH(256);
-    else if (dbg == 314) RL_PP_LAUNCH(314);
     else RL_PP_LAUNCH(0);
 #undef RL_PP_LAUNCH
     RL_HIP(hipGetLastError());
