@@ -1,6 +1,6 @@
 """bench.py -- the headline metric of BASELINE.json on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]         (N > 1: launches its own N ranks over 127.0.0.1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Workload (config.workload): MaxSim late-interaction retrieval, 32 query vectors x 1,000,000 chunk
@@ -9,8 +9,8 @@ synthetic U(-1,1) (counter-based generator, identical bits on CPU and GPU) group
 of 1..15 rows (mean 8, RAGLite's multi-vector chunks), resident in HBM before the timed region.
 
 A step = one batch of QUERIES_PER_STEP queries pushed through the hot path (`rl_maxsim_topk_batch` on
-device pointers): the queries' fp16 (hi, lo) fragments once, one corpus pass of the MFMA kernel per EIGHT
-queries over the index' image of the corpus' hi halves (maxsim_gemm_kernel, ONE fp16 product per multiply: q_hi . e_hi), the
+device pointers): the queries' fp16 (hi, lo) fragments once, one corpus pass of the MFMA kernel per SIXTEEN
+queries over the index' image of the corpus' hi halves (maxsim_pp_kernel, ONE fp16 product per multiply: q_hi . e_hi), the
 batched selection of the approximate scores, the collection of every chunk a rigorous error bound cannot rule out
 of the top-k (~300 of 125 k per query), their exact scores on the fp32 matrix pipe (maxsim_pairs_kernel) and the
 ranking of those -- the exact top-100 of exactly computed scores; the full-precision passes (three products, over

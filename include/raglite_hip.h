@@ -227,7 +227,8 @@ int rl_maxsim_scores(rl_index* index, const float* query_vecs, int32_t nq, float
  * of device memory; RAGLITE_NO_PLANES=1 in the environment disables it), otherwise two queries or one query
  * take a pass over the fp32 / fp16 rows.  On a big fp32 index (>= 64 M elements) the passes of a batch of three or
  * more queries run over an image of the hi halves only (2 more bytes per element; ONE fp16 MFMA product per multiply
- * instead of three -- q_hi . e_hi; RAGLITE_HI_ONE_PRODUCT=0: two), every chunk's score error is bounded rigorously from
+ * instead of three -- q_hi . e_hi; RAGLITE_HI_ONE_PRODUCT=0: two), SIXTEEN queries per pass (maxsim_pp.hip; dim >= 256;
+ * RAGLITE_NO_PP=1 or smaller dims: eight, maxsim_gemm.hip), every chunk's score error is bounded rigorously from
  * what the hi halves of corpus and queries drop, and the chunks that could be in the top-k are
  * re-scored with exact fp32 products: the same top-k, scores as accurate as before; where the bound does not decide
  * (thousands of near-identical chunks) the full-precision passes run instead, on the device.
@@ -239,7 +240,8 @@ int rl_maxsim_topk_batch(rl_index* index, const float* query_vecs, int32_t n_que
 /* rl_maxsim_approx_scores: the FIRST stage of rl_maxsim_topk_batch's bound-filtered pipeline on its own, for tests and for
  * callers that want the bound: the approximate MaxSim score of every (query, chunk) from the hi halves of corpus and queries
  * (one fp16 MFMA product per multiply; `kernel` = 0: the sixteen-queries-per-pass kernel of maxsim_pp.hip, 1: the
- * eight-queries-per-pass kernel of maxsim_gemm.hip -- the same sums in the same order), and per query the rigorous bound
+ * eight-queries-per-pass kernel of maxsim_gemm.hip -- the same products and the same sums over K; the 32 per-vector maxima of a
+ * chunk are added in another order, so float scores agree to the last bits, integer-valued ones exactly), and per query the rigorous bound
  * m with |approximate - exact| <= m for EVERY chunk that rl_maxsim_topk_batch's candidate window (2 m) is built on.
  *   query_vecs [n_queries x nq x dim] f32, nq <= 32;  out_scores [n_queries x n_chunks] f32 (tombstoned chunks included: no mask),
  *   out_bound [n_queries] f32 or NULL.  RL_ERR_UNSUPPORTED when the index keeps no HI image (small / fp16-stored / exact-fp32

@@ -1,5 +1,5 @@
 """Times rl_pool_norm on the BASELINE cfg 4 shape (3.2 M x 1024 token rows -> 100 k spans, fp16 out) -- for A/B runs under
-RAGLITE_POOL_COOP=1 / RAGLITE_POOL_DBG.  python scripts/time_pool.py [tag]"""
+RAGLITE_POOL_VGPR=1 / RAGLITE_POOL_BATCH.  python scripts/time_pool.py [tag]"""
 import os
 import sys
 
