@@ -118,6 +118,13 @@ int rl_index_create_f16(rl_index** out, const uint16_t* embeddings_f16, int64_t 
                         const int64_t* chunk_offsets, int64_t n_chunks, int metric, int mem, void* stream);
 int rl_index_destroy(rl_index* index);
 int rl_index_info(const rl_index* index, int64_t* n_rows, int32_t* dim, int64_t* n_chunks, int* metric);
+/* Device memory of an index, in bytes: out[0] the stored rows (borrowed or owned), out[1] the pre-split corpus image (0: not built),
+ * out[2] the image of the hi halves, out[3] the row-major HI plane, out[4] the per-call scratch grown so far, out[5] / out[6] free /
+ * total device memory now, out[7] the headroom an image has to leave free to be built.  The three images are optional accelerators
+ * (4 + 2 + 2 bytes per element next to the 4 of an fp32 corpus): each is built only while it leaves max(2 GiB, 1/16 of the device) --
+ * RAGLITE_IMAGE_HEADROOM_MB overrides -- free for the scratch and the caller; without them the same calls run through the kernels over
+ * the stored rows (same results: every image path is bit-identical to, or re-scored exactly against, the rows). */
+int rl_index_memory(const rl_index* index, int64_t out[8]);
 
 /* ---- index lifecycle beyond create/destroy -----------------------------
  * rl_index_append: the device image of `insert_documents` appending `chunk_embedding` rows

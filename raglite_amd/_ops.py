@@ -371,6 +371,15 @@ class DeviceIndex:
         return {"kind": kind, "queries": n, "candidates_per_query_mean": (int(out[2]) / n if n else 0.0),
                 "candidates_per_query_max": int(out[3]), "list_capacity": int(out[4]), "fallback": bool(out[5])}
 
+    def memory(self) -> dict:
+        """Device memory of this index in bytes (`rl_index_memory`): the stored rows, the three optional images (0 = not built: the
+        device was too full, the index too small for them to pay, or a switch), the scratch grown so far, free / total device memory
+        and the headroom an image must leave free to be built."""
+        out = (C.c_int64 * 8)()
+        check(lib().rl_index_memory(self._handle, out))
+        keys = ("rows", "presplit_image", "hi_image", "hi_plane", "scratch", "device_free", "device_total", "image_headroom")
+        return {k: int(v) for k, v in zip(keys, out)}
+
     # -- a6 + a7 -------------------------------------------------------------------------------
     def search_rows(self, queries, k: int, chunk_filter=None, rank_limit: int | None = None):
         """Exact top-k rows: (scores (B,k) desc, rows (B,k) int32); padding = (-inf, -1).

@@ -317,8 +317,27 @@ bool image_valid(const rl_index* idx) {
     return idx->planes_scale > 0.f && idx->planes_scale == image_scale(idx) && idx->planes_rows == idx->n_rows && idx->n_rows > 0;
 }
 
+// The images are optional accelerators (pre-split image 4 B, HI image 2 B, HI plane 2 B per element next to the rows): one is only
+// built while it leaves `image_headroom()` of the device free for the per-call scratch (score batches up to 8 GB, selection workspace,
+// candidate lists) and for the caller -- an index close to the device's capacity searches through the kernels over the stored rows
+// instead of failing an allocation in the middle of a search.  RAGLITE_IMAGE_HEADROOM_MB overrides the default
+// max(2 GiB, 1/16 of the device); rl_index_memory reports what was built.
+size_t image_headroom() {
+    static const long long env = std::getenv("RAGLITE_IMAGE_HEADROOM_MB") ? std::atoll(std::getenv("RAGLITE_IMAGE_HEADROOM_MB")) : -1;
+    if (env >= 0) return (size_t)env << 20;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return (size_t)2 << 30; }
+    return std::max<size_t>((size_t)2 << 30, total_b / 16);
+}
+bool image_fits(const rl::Pool& pool, size_t need) {
+    if (pool.cap >= need) return true;  // already paid for
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return true; }
+    return free_b + pool.cap >= need + image_headroom();  // (reserve() frees the old block before it allocates)
+}
+
 // Builds / extends the corpus image so that it covers rows [0, idx->n_rows) at image_scale(idx).  Not having the image is
-// never an error (the streaming kernels read the stored rows): an allocation failure just leaves it absent.
+// never an error (the streaming kernels read the stored rows): an allocation failure or a device too full just leaves it absent.
 
 int refresh_planes(rl_index* idx, hipStream_t s) {
     static const bool no_planes = std::getenv("RAGLITE_NO_PLANES") != nullptr;  // A/B switch
@@ -336,7 +355,7 @@ int refresh_planes(rl_index* idx, hipStream_t s) {
     const size_t need = rl::planes_bytes(cap, idx->dim, half), need_e = rl::chunk_ends_words(cap) * sizeof(uint32_t);
     int64_t first = idx->planes_scale == image_scale(idx) ? (idx->planes_rows & ~int64_t(15)) : 0;
     if (idx->planes.cap < need) first = 0;  // Pool::reserve does not keep the contents
-    if (idx->planes.reserve(need) != RL_OK || idx->ends.reserve(need_e) != RL_OK) {
+    if (!image_fits(idx->planes, need + need_e) || idx->planes.reserve(need) != RL_OK || idx->ends.reserve(need_e) != RL_OK) {
         (void)hipGetLastError();
         idx->planes.release();
         idx->ends.release();
@@ -384,7 +403,7 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
     const size_t need = rl::planes_bytes(cap, idx->dim, true);
     int64_t first = idx->hi_image_scale == idx->split_scale ? (idx->hi_image_rows & ~int64_t(15)) : 0;
     if (idx->hi_image.cap < need) first = 0;
-    if (idx->hi_image.reserve(need) != RL_OK) {
+    if (!image_fits(idx->hi_image, need) || idx->hi_image.reserve(need) != RL_OK) {
         (void)hipGetLastError();
         idx->hi_image.release();
         idx->hi_image_scale = 0.f;
@@ -441,7 +460,7 @@ int refresh_hi_plane(rl_index* idx, hipStream_t s) {
     const size_t need = (size_t)cap * d * sizeof(uint16_t);
     int64_t first = idx->hi_scale == idx->split_scale ? idx->hi_rows : 0;
     if (idx->hiplane.cap < need) first = 0;  // Pool::reserve does not keep the contents
-    if (idx->hiplane.reserve(need) != RL_OK) {
+    if (!image_fits(idx->hiplane, need) || idx->hiplane.reserve(need) != RL_OK) {
         (void)hipGetLastError();
         idx->hiplane.release();
         idx->hi_scale = 0.f;
@@ -1041,6 +1060,22 @@ int rl_index_info(const rl_index* idx, int64_t* n_rows, int32_t* dim, int64_t* n
     if (dim) *dim = idx->dim;
     if (n_chunks) *n_chunks = idx->n_chunks;
     if (metric) *metric = idx->metric;
+    return RL_OK;
+}
+
+int rl_index_memory(const rl_index* idx, int64_t out[8]) {
+    if (!idx || !out) return fail(RL_ERR_INVALID, "rl_index_memory: null argument");
+    out[0] = (int64_t)idx->n_rows * idx->dim * (idx->E16 ? 2 : 4);
+    out[1] = image_valid(idx) ? (int64_t)idx->planes.cap : 0;
+    out[2] = hi_image_valid(idx) ? (int64_t)idx->hi_image.cap : 0;
+    out[3] = hi_valid(idx) ? (int64_t)idx->hiplane.cap : 0;
+    out[4] = (int64_t)(idx->scores.cap + idx->hits.cap + idx->misc.cap + idx->maskbuf.cap + idx->qsplit.cap + idx->qplanes.cap + idx->cand.cap +
+                       idx->fused.cap + idx->rankbuf.cap + idx->hibuf.cap + idx->ends.cap);
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = total_b = 0; }
+    out[5] = (int64_t)free_b;
+    out[6] = (int64_t)total_b;
+    out[7] = (int64_t)image_headroom();
     return RL_OK;
 }
 

@@ -45,29 +45,32 @@ __global__ __launch_bounds__(256) void approx_threshold_kernel(const float* __re
 
 // Rows whose approximate score reaches thr[b] -> ids[b * cap + p] (any order; with row_norm their norms next to them, for the
 // cosine transform of the re-scored candidates), cnt[b] = how many; more than cap sets *flag.
+// A workgroup gathers its hits in LDS first (one LDS atomic per wave and visit) and takes its range of the list with ONE global atomic:
+// a MaxSim batch collects ~300 chunks for each of 128 queries, and 300 returning atomics on one word are 300 dependent L2 round trips
+// -- the kernel took 0.16 ms for 64 MB of scores with one global atomic per hit-carrying wave (profiles/r03_ac_bench_kernel_stats.csv).
+// More than LOCAL hits in one workgroup's ~4 k scores: the guarded full-precision path answers (*flag), as for a full list.
 __global__ __launch_bounds__(256) void collect_above_kernel(const float* __restrict__ scores, int64_t n, int64_t ld, const float* __restrict__ thr,
                                                              const float* __restrict__ row_norm, int32_t cap, int32_t* __restrict__ ids,
                                                              float* __restrict__ norms, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag) {
+    constexpr uint32_t LOCAL = 1024;
+    __shared__ int32_t l_ids[LOCAL];
+    __shared__ uint32_t l_n, l_base;
     const int b = blockIdx.y;
     const float t = thr[b];
     const float* s = scores + (int64_t)b * ld;
-    // one atomic per wave and call, not per row (a MaxSim batch collects ~1 000 chunks for each of 128 queries: 128 hot words)
+    if (threadIdx.x == 0) l_n = 0u;
+    __syncthreads();
     auto visit = [&](float v, int64_t i, bool in_range) {
         const bool hit = in_range && v >= t;
         const uint64_t mask = __builtin_amdgcn_ballot_w64(hit);
         if (mask == 0ull) return;  // (wave-uniform)
         const int lane = threadIdx.x & 63;
         uint32_t base = 0;
-        if (lane == __builtin_ctzll(mask)) base = atomicAdd(cnt + b, (uint32_t)__builtin_popcountll(mask));
+        if (lane == __builtin_ctzll(mask)) base = atomicAdd(&l_n, (uint32_t)__builtin_popcountll(mask));
         base = __builtin_amdgcn_readlane(base, __builtin_ctzll(mask));
         if (hit) {
             const uint32_t p = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            if (p < (uint32_t)cap) {
-                ids[(int64_t)b * cap + p] = (int32_t)i;
-                if (row_norm) norms[(int64_t)b * cap + p] = row_norm[i];
-            } else {
-                atomicOr(flag, 1u);
-            }
+            if (p < LOCAL) l_ids[p] = (int32_t)i;
         }
     };
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -91,6 +94,26 @@ __global__ __launch_bounds__(256) void collect_above_kernel(const float* __restr
         for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n; i0 += stride) {
             const int64_t i = i0 + threadIdx.x;
             visit(i < n ? s[i] : 0.f, i, i < n);
+        }
+    }
+    __syncthreads();
+    const uint32_t found = l_n;
+    if (found == 0u) return;  // (workgroup-uniform)
+    const uint32_t mine = found < LOCAL ? found : LOCAL;
+    if (threadIdx.x == 0) {
+        l_base = atomicAdd(cnt + b, mine);
+        if (found > LOCAL) atomicOr(flag, 1u);
+    }
+    __syncthreads();
+    const uint32_t base = l_base;
+    for (uint32_t j = threadIdx.x; j < mine; j += 256) {
+        const uint32_t p = base + j;
+        if (p < (uint32_t)cap) {
+            const int32_t i = l_ids[j];
+            ids[(int64_t)b * cap + p] = i;
+            if (row_norm) norms[(int64_t)b * cap + p] = row_norm[i];
+        } else {
+            atomicOr(flag, 1u);
         }
     }
 }
