@@ -122,7 +122,7 @@ __device__ __forceinline__ h16x8 pp_h(const f32x4& v) {
 }  // namespace
 
 // DBG (timing experiments only, RAGLITE_PP_DBG; wrong results): 2 = no MFMAs, 8 = no LDS fragment reads, 16 = no corpus DMAs,
-// 32 = no query DMAs, 64 = every corpus DMA re-reads the first tile (L2 hits), 128 = no tile epilogue (the MFMAs stay), 256 = no stores, 1024 = waves 4-7 run the stream of waves 0-3 (no lag), 8192 = epilogue timeline (RAGLITE_PP_TRACE=1)
+// 32 = no query DMAs, 64 = every corpus DMA re-reads the first tile (L2 hits), 128 = no tile epilogue (the MFMAs stay), 256 = no stores, 1024 = waves 4-7 run the stream of waves 0-3 (no lag), 2048 = no LDS reads of the QUERY fragments, 8192 = epilogue timeline (RAGLITE_PP_TRACE=1)
 template <int DBG>
 __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restrict__ planes, int64_t n_rows, int32_t nslab,
                                                            const char* __restrict__ qfrag, const float* __restrict__ qmeta, int32_t n_q,
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         constexpr int a = decltype(A_)::value;
         if constexpr (!(DBG & 8)) {
             pp_read<a * 1024>(ef[a], rd_c + (uint32_t)(c_slot * PP_CSLOT));
-            if constexpr (a < 4) pp_read<a * 1024>(qn[a], rd_q + (uint32_t)(q_slot * PP_QSLOT));
+            if constexpr (a < 4 && !(DBG & 2048)) pp_read<a * 1024>(qn[a], rd_q + (uint32_t)(q_slot * PP_QSLOT));
         }
     };
 
@@ -554,6 +554,9 @@ int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void*
     }
     if (dbg == 2) RL_PP_LAUNCH(2);
     else if (dbg == 1024) RL_PP_LAUNCH(1024);
+    else if (dbg == 2208) RL_PP_LAUNCH(2208);
+    else if (dbg == 160) RL_PP_LAUNCH(160);
+    else if (dbg == 2176) RL_PP_LAUNCH(2176);
     else if (dbg == 1152) RL_PP_LAUNCH(1152);
     else if (dbg == 176) RL_PP_LAUNCH(176);
     else if (dbg == 184) RL_PP_LAUNCH(184);
