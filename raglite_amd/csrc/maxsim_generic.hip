@@ -97,17 +97,25 @@ static int generic_t(const float* D, int32_t dim, const float* Q, int32_t nq, co
 // maxsim_pairs_kernel: exact MaxSim of arbitrary (query, chunk) pairs at any dim % 16 == 0, dim <= 1024, nq <= 32 -- the
 // rerank shape beyond dim 128 and the re-scoring step of the half-bytes MaxSim batch (api.hip: maxsim_batch_hi).
 // One workgroup of eight waves serves ONE query (blockIdx.y; blockIdx.x splits its candidate list): the query's [32 x dim] fp32 matrix sits
-// in LDS (pitch dim + 4 floats: the 16 lanes of a fragment read hit 16 different bank quads), every wave takes candidates
-// round robin: per 16-row tile of the chunk and 16-wide k step one 16-B global load per lane (16 rows x 64 B: every byte
+// in LDS (pitch dim + 8 floats: a ds_read_b128 serves 8 rows x 2 k-quads per cycle, and + 32 B per row spreads those over all 64
+// banks -- with + 16 B, as this kernel had it until round 3, 42 % of its LDS cycles were bank conflicts: profiles/r03_ai_*), every wave
+// takes candidates round robin: per 16-row tile of the chunk and 16-wide k step one 16-B global load per lane (16 rows x 64 B: every byte
 // of a row fetched once) feeds four v_mfma_f32_16x16x4_f32 steps per 16-column half of the query -- exact fp32 products,
 // fp32 accumulation -- then max over the chunk's rows (rows past its end masked), sum over the query vectors in a fixed
 // order.  Candidates < 0 (padding, sanitised ordinals) and empty chunks score -inf.
+// Software pipeline (round 3): a wave is alone with one partner on its SIMD (the query fills the CU's LDS), so nothing hides a load it
+// waits for.  The rows of the NEXT block of 128 k (the next tile's first, the next candidate's first) are requested before the 64 MFMAs
+// of the current one, and the next candidate's ordinal and row range -- two dependent loads -- a whole candidate ahead: the counters
+// showed the waves waiting on memory for 41 % of their cycles with the matrix pipe 46 % busy.
+// KB: k per block (NL = KB / 16 loads per lane in flight ahead of their MFMAs: 256 k = 128 MFMAs = ~2 us of matrix pipe, about the
+// latency of an HBM load under load; 128 left a third of it exposed);  FULL: dim % KB == 0 (no partial block: no branches in a block)
+template <bool FULL, int KB>
 __global__ __launch_bounds__(512) void maxsim_pairs_kernel(const float* __restrict__ D, int dim, const float* __restrict__ Q, int nq,
                                                             int64_t q_stride, const int64_t* __restrict__ offsets,
                                                             const int32_t* __restrict__ candidates, int64_t n_items,
                                                             float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float qs[];  // [32][dim + 4]
-    const int pitch = dim + 4;
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [32][dim + 8]
+    const int pitch = dim + 8;
     const float* Qb = Q + (int64_t)blockIdx.y * q_stride;
     const int32_t* cb = candidates + (int64_t)blockIdx.y * n_items;
     float* ob = out + (int64_t)blockIdx.y * n_items;
@@ -118,51 +126,103 @@ __global__ __launch_bounds__(512) void maxsim_pairs_kernel(const float* __restri
         *reinterpret_cast<f32x4*>(qs + n * pitch + c) = v;
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = wave_id();
     const int m = lane & 15, g = lane >> 4;  // A: row m of the tile, k quad g;  B / C: query column m, k quad / row quad g
     const float* q0 = qs + m * pitch + 4 * g;
     const float* q1 = qs + (16 + m) * pitch + 4 * g;
-    for (int64_t item = (int64_t)blockIdx.x * 8 + w; item < n_items; item += (int64_t)gridDim.x * 8) {
-        const int64_t chunk = cb[item];
-        const int64_t b = chunk >= 0 ? offsets[chunk] : 0, e = chunk >= 0 ? offsets[chunk + 1] : 0;
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    // the 16 rows x 128 k of a block, one 16-B load per lane and 16-wide k step (rows past the chunk: its last row again, masked later)
+    constexpr int NL = KB / 16;
+    auto request = [&](f32x4 (&x)[NL], int64_t e, int64_t r0, int t0) __attribute__((always_inline)) {
+        const int64_t row = r0 + m < e ? r0 + m : e - 1;
+        const float* a = D + row * (int64_t)dim + 4 * g + t0;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) x[j] = (FULL || t0 + 16 * j < dim) ? *reinterpret_cast<const f32x4*>(a + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    auto lane_i64 = [](int64_t v, int k) __attribute__((always_inline)) {  // lane k's value, k wave-uniform
+        const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)(uint64_t)v, k), hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)v >> 32), k);
+        return (int64_t)(((uint64_t)hi << 32) | lo);
+    };
+    f32x4 xc[NL], xn[NL];
+    // 64 of this wave's candidates at a time: lane L looks up the L-th one's row range (two dependent loads, once per 64 candidates and
+    // for all of them at the same time), candidates without rows get their -inf at once, the others are walked in lane order
+    for (int64_t base = (int64_t)blockIdx.x * 8 + w; base < n_items; base += 64 * stride) {
+        const int64_t mine = base + (int64_t)lane * stride;
+        int64_t vb = 0, ve = 0;
+        if (mine < n_items) {
+            const int64_t chunk = cb[mine];
+            if (chunk >= 0) { vb = offsets[chunk]; ve = offsets[chunk + 1]; }
+            if (ve <= vb) ob[mine] = -INFINITY;
+        }
+        const uint64_t todo = __builtin_amdgcn_ballot_w64(ve > vb);
+        if (todo == 0ull) continue;  // (wave-uniform)
+        int k = __builtin_ctzll(todo);
+        int64_t e = lane_i64(ve, k), r0 = lane_i64(vb, k);
+        int t0 = 0;
+        request(xc, e, r0, 0);
+        f32x4 y0 = *reinterpret_cast<const f32x4*>(q0), y1 = *reinterpret_cast<const f32x4*>(q1);  // query fragments of the step being multiplied
         float best0 = -INFINITY, best1 = -INFINITY;  // running max over the chunk's rows of this lane's column (both halves)
-        for (int64_t r0 = b; r0 < e; r0 += 16) {
-            const int64_t row = r0 + m < e ? r0 + m : e - 1;  // rows past the chunk: re-read its last row, masked below
-            const float* a = D + row * (int64_t)dim + 4 * g;
-            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-            // eight 16-B row loads in flight per lane ahead of their MFMAs (with the query in LDS a workgroup is alone on its
-            // CU: nothing else hides the rows' HBM latency)
-            for (int t0 = 0; t0 < dim; t0 += 128) {
-                f32x4 x[8];
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        for (;;) {
+            // the block after this one -- same tile, next tile, the next candidate's first -- chosen without a branch and requested before
+            // this block's 8 NL MFMAs (after the last block of the 64 candidates: the current candidate's first block again, unused)
+            const bool more_k = t0 + KB < dim, more_rows = r0 + 16 < e;
+            const uint64_t rest = todo & ~((2ull << k) - 1ull);
+            const int nk = rest ? __builtin_ctzll(rest) : k;
+            const int64_t ne = lane_i64(ve, nk), nb = lane_i64(vb, nk);
+            const int64_t n_e = (more_k || more_rows) ? e : ne;
+            const int64_t n_r0 = more_k ? r0 : (more_rows ? r0 + 16 : nb);
+            const int n_t0 = more_k ? t0 + KB : 0;
+            request(xn, n_e, n_r0, n_t0);
+            __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the loads below the MFMAs: they have to be in flight DURING them)
+            // the query fragments of step j + 1 (of the next block's first step after the last) are read from LDS before the eight MFMAs
+            // of step j: left to the compiler the reads sat right in front of their MFMAs, an LDS round trip exposed every 256 cycles
 #pragma unroll
-                for (int j = 0; j < 8; ++j) x[j] = t0 + 16 * j < dim ? *reinterpret_cast<const f32x4*>(a + t0 + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NL; ++j) {
+                if (!FULL && t0 + 16 * j >= dim) break;  // (uniform)
+                const int tn = j + 1 < NL ? t0 + 16 * (j + 1) : n_t0;  // (a partial block's steps past dim: a fragment nobody multiplies)
+                const int tr = (FULL || tn < dim) ? tn : 0;
+                const f32x4 z0 = *reinterpret_cast<const f32x4*>(q0 + tr);
+                const f32x4 z1 = *reinterpret_cast<const f32x4*>(q1 + tr);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    if (t0 + 16 * j >= dim) break;  // (uniform)
-                    const f32x4 y0 = *reinterpret_cast<const f32x4*>(q0 + t0 + 16 * j);
-                    const f32x4 y1 = *reinterpret_cast<const f32x4*>(q1 + t0 + 16 * j);
+                for (int u = 0; u < 4; ++u) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j][u], y0[u], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j][u], y1[u], acc1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                y0 = z0;
+                y1 = z1;
+            }
+            bool last = false;
+            if (!more_k) {  // the tile is complete.  C layout: this lane holds rows 4 g + i (i = 0..3) of column m
+                float v0 = -INFINITY, v1 = -INFINITY;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][u], y0[u], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j][u], y1[u], acc1, 0, 0, 0);
-                    }
+                for (int i = 0; i < 4; ++i)
+                    if (r0 + 4 * g + i < e) { v0 = fmaxf(v0, acc0[i]); v1 = fmaxf(v1, acc1[i]); }
+                v0 = fmaxf(v0, __shfl_xor(v0, 16)); v0 = fmaxf(v0, __shfl_xor(v0, 32));
+                v1 = fmaxf(v1, __shfl_xor(v1, 16)); v1 = fmaxf(v1, __shfl_xor(v1, 32));
+                best0 = fmaxf(best0, v0);
+                best1 = fmaxf(best1, v1);
+                acc0 = acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!more_rows) {  // ... and so is the candidate: sum over the 32 query vectors, 16 columns per half by a 4-step butterfly,
+                                   // then the two halves -- a fixed order
+                    float s0 = best0, s1 = best1;
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+                    if (lane == 0) ob[base + (int64_t)k * stride] = s0 + s1;
+                    best0 = best1 = -INFINITY;
+                    last = rest == 0ull;
+                    k = nk;
                 }
             }
-            // C layout: this lane holds rows 4 g + i (i = 0..3) of column m
-            float v0 = -INFINITY, v1 = -INFINITY;
+            if (last) break;
+            e = n_e;
+            r0 = n_r0;
+            t0 = n_t0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (r0 + 4 * g + i < e) { v0 = fmaxf(v0, acc0[i]); v1 = fmaxf(v1, acc1[i]); }
-            v0 = fmaxf(v0, __shfl_xor(v0, 16)); v0 = fmaxf(v0, __shfl_xor(v0, 32));
-            v1 = fmaxf(v1, __shfl_xor(v1, 16)); v1 = fmaxf(v1, __shfl_xor(v1, 32));
-            best0 = fmaxf(best0, v0);
-            best1 = fmaxf(best1, v1);
+            for (int j = 0; j < NL; ++j) xc[j] = xn[j];
         }
-        // sum over the 32 query vectors: 16 columns per half by a 4-step butterfly, then the two halves -- a fixed order
-        float s0 = best0, s1 = best1;
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
-        if (lane == 0) ob[item] = e > b ? s0 + s1 : -INFINITY;
     }
 }
 
@@ -171,16 +231,23 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
     if (n_items_per_query <= 0 || n_queries <= 0) return RL_OK;
     if (nq < 1 || nq > 32 || dim % 16 || dim < 16 || dim > 1024 || !candidates) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
-    const size_t lds = (size_t)32 * (dim + 4) * sizeof(float);
+    const size_t lds = (size_t)32 * (dim + 8) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
-        RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_kernel<true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_kernel<true, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     // workgroups per query: enough to fill the chip when there are few queries, at most one wave per candidate
     int per_query = (int)std::max<int64_t>(1, std::min<int64_t>((n_items_per_query + 7) / 8, std::max<int64_t>(1, 512 / n_queries)));
-    hipLaunchKernelGGL(maxsim_pairs_kernel, dim3(per_query, n_queries), dim3(512), lds, s, D, (int)dim, Q, (int)nq, q_stride, offsets,
-                       candidates, n_items_per_query, out);
+#define RL_PAIRS(FULL_, KB_)                                                                                                               \
+    hipLaunchKernelGGL((maxsim_pairs_kernel<FULL_, KB_>), dim3(per_query, n_queries), dim3(512), lds, s, D, (int)dim, Q, (int)nq, q_stride, \
+                       offsets, candidates, n_items_per_query, out)
+    if (dim % 256 == 0) RL_PAIRS(true, 256);
+    else if (dim % 128 == 0) RL_PAIRS(true, 128);
+    else RL_PAIRS(false, 128);
+#undef RL_PAIRS
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

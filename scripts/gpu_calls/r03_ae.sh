@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3, GPU call AE: collect_above_kernel with per-workgroup aggregation (one global atomic per workgroup instead of one per hit-carrying wave):
+# Round 3, GPU call AE (also used for AJ: the software-pipelined maxsim_pairs_kernel): tests of every bound-filtered path and the rerank paths, kernel stats of the headline step, bench.
 # the tests of every bound-filtered path, kernel stats of the headline step, bench.
 set -u
 TAG=${1:-r03_ae}
@@ -7,7 +7,7 @@ OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 echo "== $(date) start" | tee "$OUT/summary.txt"
-timeout 1200 python -m pytest tests -m gpu -q -x --timeout 600 -k "hi_ or hi_maxsim or half_bytes or shaped or pp_ or fused or memory or fullsize" > "$OUT/pytest.log" 2>&1
+timeout 1200 python -m pytest tests -m gpu -q -x --timeout 600 -k "hi_ or hi_maxsim or half_bytes or shaped or pp_ or fused or memory or fullsize or rerank or pairs or generic or maxsim" > "$OUT/pytest.log" 2>&1
 echo "pytest exit $?" | tee -a "$OUT/summary.txt"; tail -4 "$OUT/pytest.log"
 ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$OUT/prof" -o bench -- python "$OLDPWD/bench.py" --steps 10 --warmup 2 --no-cpu-baseline --no-configs --no-f16 > "$OLDPWD/$OUT/prof_bench.json" 2> "$OLDPWD/$OUT/prof.err" ); echo "prof exit $?" | tee -a "$OUT/summary.txt"
 find "$OUT/prof" -name "*kernel_stats*" | head -1 | while read f; do cp "$f" "$OUT/bench_kernel_stats.csv"; head -14 "$f" | cut -c1-150; done
