@@ -15,8 +15,9 @@ batched selection of the approximate scores, the collection of every chunk a rig
 of the top-k (~300 of 125 k per query), their exact scores on the fp32 matrix pipe (maxsim_pairs_kernel) and the
 ranking of those -- the exact top-100 of exactly computed scores; the full-precision passes (three products, over
 the pre-split image) stand behind a device flag for corpora the bound does not decide; one pass per
-query with the exact-fp32 arithmetic -- then, N > 1 only, the exchange step (ONE RCCL all-gather of every rank's
-local top-k, (QB, k, 2) int32) and the device merge.  value = queries / second over the whole job.
+query with the exact-fp32 arithmetic -- and, N > 1 only, two exchange steps: an RCCL all-gather of every rank's k best
+approximate scores and bound, (QB, k + 1) float32, before the candidates are collected (one threshold for all shards), and one of
+its exact local top-k, (QB, k, 2) int32, with the device merge.  value = queries / second over the whole job.
 
 N > 1: the 1 M-row corpus is sharded by chunk across the ranks (strong scaling on the metric's own
 shape); every rank receives the same queries.
@@ -233,7 +234,7 @@ def main() -> None:
 
     total_queries = args.steps * qps
     exchange = ("no exchange step at N = 1" if world == 1 else
-                f"corpus sharded by chunk over {world} GPUs; per step ONE all-gather of every rank's local top-k + device merge, no host sync"
+                f"corpus sharded by chunk over {world} GPUs; per step one all-gather of every rank's k best approximate scores (one candidate threshold for all shards), one of its exact local top-k + device merge, no host sync"
                 + (" (rl_allgather_merge_topk: librccl through the C ABI)" if comm is not None else " (torch.distributed)"))
     result = {
         "metric": "queries/sec, MaxSim 32x1M d=1024 exact top-100",

@@ -244,6 +244,27 @@ int rl_maxsim_scores(rl_index* index, const float* query_vecs, int32_t nq, float
 int rl_maxsim_topk_batch(rl_index* index, const float* query_vecs, int32_t n_queries, int32_t nq, int32_t k,
                          float* out_scores, int32_t* out_chunks, int mem, void* stream);
 
+/* ---- rl_maxsim_topk_batch over a corpus SHARDED across several indexes, with ONE candidate threshold for all shards -----------------
+ * Every shard calling rl_maxsim_topk_batch on its own re-scores the chunks near ITS k-th best approximate score: ~235 candidates per
+ * query on each of eight shards of the benchmark corpus where one index re-scores 307 in all, and that work does not shrink with the
+ * shard (profiles/r03_ah_shard_step_times.txt).  The threshold only needs the k-th best approximate score over ALL shards -- which lies
+ * in the union of the shards' k best -- and the largest of the shards' error bounds:
+ *     rl_maxsim_batch_begin(index, queries, B, nq, k, approx)        approximate passes over this shard; approx [B x (k + 1)] f32:
+ *                                                                     its k best approximate scores per query (descending), then its bound m
+ *     <all-gather approx over the shards: all_approx [world x B x (k + 1)]   (rl_allgather_u32 on the bits, or any all-gather)>
+ *     rl_maxsim_batch_finish(index, queries, all_approx, world, rank, out_scores, out_chunks)
+ *                                                                     candidates above (global k-th best) - max m - own m, re-scored exactly
+ * out_* [B x k]: this shard's chunks of that candidate set, ranked by exact score (fewer than k: padded with -inf / -1); merging the shards'
+ * lists (rl_allgather_merge_topk) gives bit for bit what rl_maxsim_topk_batch returns for ONE index over the whole corpus.  A shard whose
+ * bound does not decide (list overflow, fewer than k scorable chunks anywhere) answers with its exact local top-k instead, on the device,
+ * as the unsharded call does.  `queries` must be the same buffer contents in both calls; no other call on this index in between.
+ * RL_ERR_UNSUPPORTED from _begin (no image of the hi halves on this index, fewer than three queries, a batch size with n % 8 in {1, 2},
+ * nq > 32, k > 512): call rl_maxsim_topk_batch instead -- the merge accepts either. */
+int rl_maxsim_batch_begin(rl_index* index, const float* query_vecs, int32_t n_queries, int32_t nq, int32_t k, float* out_approx, int mem,
+                          void* stream);
+int rl_maxsim_batch_finish(rl_index* index, const float* query_vecs, const float* all_approx, int32_t world, int32_t rank, float* out_scores,
+                           int32_t* out_chunks, int mem, void* stream);
+
 /* rl_maxsim_approx_scores: the FIRST stage of rl_maxsim_topk_batch's bound-filtered pipeline on its own, for tests and for
  * callers that want the bound: the approximate MaxSim score of every (query, chunk) from the hi halves of corpus and queries
  * (one fp16 MFMA product per multiply; `kernel` = 0: the sixteen-queries-per-pass kernel of maxsim_pp.hip, 1: the

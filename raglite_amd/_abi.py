@@ -70,6 +70,8 @@ _SIGNATURES = {
     "rl_maxsim_scores": [c_void_p, c_void_p, c_i32, c_void_p, c_int, c_void_p],
     "rl_maxsim_topk_batch": [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_int, c_void_p],
     "rl_maxsim_approx_scores": [c_void_p, c_void_p, c_i32, c_i32, c_int, c_void_p, c_void_p, c_int, c_void_p],
+    "rl_maxsim_batch_begin": [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_int, c_void_p],
+    "rl_maxsim_batch_finish": [c_void_p, c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_int, c_void_p],
     "rl_maxsim_rerank": [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_i32, c_void_p, c_int, c_void_p],
     "rl_merge_topk": [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_int, c_void_p],
     "rl_topk": [c_void_p, c_i32, c_i64, c_i64, c_i32, c_void_p, c_void_p, c_int, c_void_p],
@@ -95,6 +97,11 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
 class RagliteHipError(RuntimeError):
     """HIP runtime failure inside libraglite_hip.so."""
+
+
+class UnsupportedError(ValueError):
+    """RL_ERR_UNSUPPORTED: the arguments are valid but this entry point does not cover them (a ValueError, as before; its own type so
+    that callers with another path -- `ShardedIndex.maxsim_topk_batch` -- can take it)."""
 
 
 @functools.lru_cache(maxsize=1)
@@ -129,7 +136,9 @@ def check(status: int) -> None:
     if status == RL_OK:
         return
     msg = last_error() or f"libraglite_hip status {status}"
-    if status in (RL_ERR_INVALID, RL_ERR_UNSUPPORTED):
+    if status == RL_ERR_UNSUPPORTED:
+        raise UnsupportedError(msg)
+    if status == RL_ERR_INVALID:
         raise ValueError(msg)
     if status == RL_ERR_NOMEM:
         raise MemoryError(msg)

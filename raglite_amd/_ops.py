@@ -510,6 +510,41 @@ class DeviceIndex:
         check(lib().rl_maxsim_approx_scores(self._handle, p_q, n_queries, nq, int(kernel), p_s, p_b, a.mem, a.stream))
         return o_s, o_b
 
+    def maxsim_batch_begin(self, query_batch, k: int):
+        """First half of `maxsim_topk_batch` over one shard of a SHARDED corpus (`rl_maxsim_batch_begin`): the approximate passes; returns
+        (n_queries, k + 1) float32 -- this shard's k best approximate scores per query (descending) and its error bound -- for the
+        all-gather in front of `maxsim_batch_finish`.  Raises RaglitHipError(UNSUPPORTED) where the bound-filtered pipeline does not cover
+        the batch: use `maxsim_topk_batch` then."""
+        a = _Args()
+        p_q = a.inp(query_batch, np.float32)
+        qv = a.keep[-1]
+        if qv.ndim != 3 or int(qv.shape[2]) != self.dim:
+            raise ValueError("query_batch must be (n_queries, nq, dim)")
+        n_queries, nq = int(qv.shape[0]), int(qv.shape[1])
+        o, p_o = a.out((n_queries, int(k) + 1), np.float32)
+        self._prep(a)
+        check(lib().rl_maxsim_batch_begin(self._handle, p_q, n_queries, nq, int(k), p_o, a.mem, a.stream))
+        return o
+
+    def maxsim_batch_finish(self, query_batch, all_approx, rank: int, k: int):
+        """Second half (`rl_maxsim_batch_finish`): all_approx (world, n_queries, k + 1) = every shard's `maxsim_batch_begin` result;
+        returns (scores (n_queries, k), LOCAL chunk ordinals (n_queries, k)) of this shard's chunks that could be in the global top-k,
+        ranked by exact score, padded with (-inf, -1)."""
+        a = _Args()
+        p_q = a.inp(query_batch, np.float32)
+        qv = a.keep[-1]
+        n_queries = int(qv.shape[0])
+        p_a = a.inp(all_approx, np.float32)
+        av = a.keep[-1]
+        if av.ndim != 3 or int(av.shape[1]) != n_queries or int(av.shape[2]) != int(k) + 1:
+            raise ValueError("all_approx must be (world, n_queries, k + 1)")
+        world = int(av.shape[0])
+        o_s, p_s = a.out((n_queries, int(k)), np.float32)
+        o_c, p_c = a.out((n_queries, int(k)), np.int32)
+        self._prep(a)
+        check(lib().rl_maxsim_batch_finish(self._handle, p_q, p_a, world, int(rank), p_s, p_c, a.mem, a.stream))
+        return o_s, o_c
+
     def maxsim_rerank(self, query_vecs, candidates):
         """query_vecs (n_queries, nq, dim), candidates (n_queries, n_cand) int32 -> scores (n_queries, n_cand)."""
         a = _Args()

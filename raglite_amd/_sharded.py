@@ -370,7 +370,7 @@ class ShardedIndex:
         (on the device without any host synchronisation when the queries are CUDA tensors, else on the host).
         Returns (scores (QB,k), global chunk ordinals (QB,k))."""
         if hasattr(self.local, "maxsim_topk_batch"):
-            s, c = self.local.maxsim_topk_batch(query_batch, k)
+            s, c = self._local_maxsim_batch(query_batch, k)
             if _is_cuda(s):  # device-resident queries: results stay on the device
                 return self._exchange_merge_device(s, c, self.chunk_base, k)
         else:
@@ -378,6 +378,49 @@ class ShardedIndex:
             s, c = np.stack([_to_numpy(o[0]) for o in outs]), np.stack([_to_numpy(o[1]) for o in outs])
         gs, gi, _, _ = self._exchange_host(s, c, self.chunk_base)
         return merge_topk_host(gs, gi, k)
+
+    def _local_maxsim_batch(self, query_batch, k: int):
+        """This shard's part of a MaxSim batch.  Over several shards the bound-filtered pipeline takes ONE candidate threshold for all of
+        them (`rl_maxsim_batch_begin` -> all-gather of every shard's k best approximate scores and bound, (world, B, k + 1) float32 ->
+        `rl_maxsim_batch_finish`): a shard on its own re-scores the chunks near ITS k-th best approximate score, ~235 per query on each of
+        eight shards where one index re-scores 307 in all.  The decision to exchange is taken from the batch shape alone (the same on every
+        rank: the exchange is a collective); a shard whose index cannot take part (no image of the hi halves) contributes an empty list
+        and a zero bound -- which only lowers the others' threshold -- and answers with its exact local top-k."""
+        staged_shape = (
+            self._world() > 1
+            and hasattr(self.local, "maxsim_batch_begin")
+            and getattr(query_batch, "ndim", 0) == 3
+            and int(query_batch.shape[0]) >= 3
+            and int(query_batch.shape[0]) % 8 not in (1, 2)
+            and int(query_batch.shape[1]) <= 32
+            and int(k) <= 512
+        )
+        if not staged_shape:
+            return self.local.maxsim_topk_batch(query_batch, k)
+        from ._abi import UnsupportedError
+
+        B = int(query_batch.shape[0])
+        try:
+            approx = self.local.maxsim_batch_begin(query_batch, k)
+            staged = True
+        except UnsupportedError:
+            staged = False
+            if _is_cuda(query_batch):
+                import torch
+
+                approx = torch.full((B, int(k) + 1), float("-inf"), dtype=torch.float32, device=query_batch.device)
+            else:
+                approx = np.full((B, int(k) + 1), -np.inf, dtype=np.float32)
+            approx[:, int(k)] = 0.0
+        if _is_cuda(approx):
+            import torch
+
+            all_approx = self._allgather_int(approx.contiguous().view(torch.int32)).view(torch.float32)
+        else:
+            all_approx = np.ascontiguousarray(self._allgather_int(np.ascontiguousarray(approx, dtype=np.float32).view(np.int32))).view(np.float32)
+        if not staged:
+            return self.local.maxsim_topk_batch(query_batch, k)
+        return self.local.maxsim_batch_finish(query_batch, all_approx, self._rank(), k)
 
     def search_chunks(self, queries, num_hits: int, k: int, chunk_filter=None, rank_limit: int | None = None):
         """Reference two-stage semantics across shards (`src/raglite/_search.py:66-79,143-149`; chunk_filter / rank_limit as in

@@ -260,6 +260,7 @@ struct rl_index {
     // device flag its guarded full-precision fallback waits on.  Pointers into the scratch above, valid until the next call.
     // rl_rank_cut_*: the staged rank cut of a SHARDED corpus keeps its queries and scores here between the calls
     int32_t rank_B = 0;                   // queries of the running rl_rank_cut_begin (0: none)
+    int32_t mb_B = 0, mb_nq = 0, mb_k = 0;  // rl_maxsim_batch_begin in progress: queries, vectors per query, k (0: none)
     rl::Pool rank_q;                      // their device copy (the l2 re-scoring of rl_rank_cut_finish needs them)
     struct FilterRecord { int kind = 0; int32_t n = 0, cap = 0; const uint32_t* cnt = nullptr; const uint32_t* flag = nullptr; } filt;
 };
@@ -1793,6 +1794,89 @@ int rl_maxsim_topk(rl_index* idx, const float* query_vecs, int32_t nq, int32_t k
     return rl_maxsim_topk_filtered(idx, query_vecs, nq, k, nullptr, out_scores, out_chunks, mem, stream);
 }
 
+namespace {
+// The bound-filtered MaxSim batch in two halves, so that a SHARDED corpus can put one exchange between them
+// (rl_maxsim_batch_begin / _finish): (a) approximate passes + the local top-k of the approximate scores, (b) given thr[] / cnt[] = 0:
+// candidate collection, exact re-scoring, ranking, and the guarded full-precision fallback.
+struct HiBatch {
+    float* ts; int32_t* ti; float* thr; uint32_t* cnt; uint32_t* flag; int32_t* ci; float* es;
+    int32_t cap; bool one_product; float m_abs; const float* q_unscale;
+};
+int hi_batch_approx(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queries, int32_t n_gemm, int32_t k, float* sc, int64_t ld, HiBatch& hb,
+                    hipStream_t s) {
+    // ONE product per multiply -- q_hi.e_hi only, a plain fp16 GEMM -- with the bound widened by what the queries' hi halves drop,
+    // (max|e| + max|e_lo|) sum_i |q_lo,i| (measured per query by the threshold kernel).  RAGLITE_HI_ONE_PRODUCT=0 (read per call): two products.
+    const char* one_env = std::getenv("RAGLITE_HI_ONE_PRODUCT");
+    hb.one_product = !(one_env && one_env[0] == '0');
+    hb.cap = 2048;  // (the benchmark corpus needs ~300 -- 1 150 with the a-priori bound: score spread sigma ~ 34, window 2 m = 15..34)
+    const int32_t cap = hb.cap;
+    const size_t words = (size_t)n_gemm * k * 2 + (size_t)n_gemm * 2 + 16 + (size_t)n_gemm * cap * 2;
+    RL_TRY(idx->hibuf.reserve(words * 4));
+    hb.ts = idx->hibuf.as<float>();                                        // [n x k] approximate top-k scores
+    hb.ti = reinterpret_cast<int32_t*>(hb.ts + (size_t)n_gemm * k);
+    hb.thr = reinterpret_cast<float*>(hb.ti + (size_t)n_gemm * k);         // [n]
+    hb.cnt = reinterpret_cast<uint32_t*>(hb.thr + n_gemm);                 // [n]
+    hb.flag = hb.cnt + n_gemm;                                             // (16 words)
+    hb.ci = reinterpret_cast<int32_t*>(hb.flag + 16);                      // [n x cap] candidate chunks
+    hb.es = reinterpret_cast<float*>(hb.ci + (size_t)n_gemm * cap);        // [n x cap] their exact scores
+    // per pair |approx - exact| <= |q_i| |e_lo,j| (what the HI halves drop, measured: max_lo_norm) + 2^-12 |q_i| |e_j| (the
+    // query's own 2^-22 split and twice the worst case of a 1024-term fp32 sum, 6e-5)
+    hb.m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
+    hb.q_unscale = reinterpret_cast<const float*>(idx->qplanes.as<char>() + (size_t)n_queries * idx->dim * 128);  // launch_query_planes' meta
+    RL_HIP(hipMemsetAsync(hb.flag, 0, 16 * sizeof(uint32_t), s));
+    RL_HIP(hipMemsetAsync(hb.ci, 0xff, (size_t)n_gemm * cap * sizeof(int32_t), s));  // unused slots: -1 = "no chunk"
+    // One product: SIXTEEN queries per pass through maxsim_pp.hip (dim >= 256; RAGLITE_NO_PP=1, read per call: the
+    // eight-query pass of maxsim_gemm.hip instead -- A/B, and what two products still use).
+    const char* nopp_env = std::getenv("RAGLITE_NO_PP");
+    const bool pp = hb.one_product && idx->dim >= 256 && !(nopp_env && nopp_env[0] && nopp_env[0] != '0');
+    for (int32_t b = 0; pp && b < n_gemm; b += PP_PASS_QUERIES) {
+        const int32_t n_q = std::min<int32_t>(PP_PASS_QUERIES, n_gemm - b);
+        RL_TRY(launch_maxsim_pp(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
+                                idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale));
+    }
+    for (int32_t b = 0; !pp && b < n_gemm; b += GEMM_PASS_QUERIES) {
+        const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_gemm - b);
+        RL_TRY(launch_maxsim_gemm(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
+                                  idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale, true,
+                                  nullptr, hb.one_product));
+    }
+    RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // tombstones never become candidates
+    RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, hb.ts, hb.ti, s));
+    return RL_OK;
+}
+int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queries, int32_t n_gemm, int32_t k, float* sc, int64_t ld,
+                     const HiBatch& hb, float* d_s, int32_t* d_c, hipStream_t s) {
+    const size_t q_elems = (size_t)nq * idx->dim;
+    RL_TRY(launch_collect_above(sc, n_gemm, idx->n_chunks, ld, hb.thr, nullptr, hb.cap, hb.ci, nullptr, hb.cnt, hb.flag, s));
+    if (std::getenv("RAGLITE_HI_DEBUG")) {  // diagnostic: synchronises; list lengths, threshold and flag of this batch to stderr
+        std::vector<uint32_t> h_cnt(n_gemm);
+        std::vector<float> h_thr(n_gemm), h_ts((size_t)n_gemm * k);
+        uint32_t h_flag = 0;
+        RL_HIP(hipStreamSynchronize(s));
+        RL_HIP(hipMemcpy(h_cnt.data(), hb.cnt, (size_t)n_gemm * 4, hipMemcpyDeviceToHost));
+        RL_HIP(hipMemcpy(h_thr.data(), hb.thr, (size_t)n_gemm * 4, hipMemcpyDeviceToHost));
+        RL_HIP(hipMemcpy(h_ts.data(), hb.ts, (size_t)n_gemm * k * 4, hipMemcpyDeviceToHost));
+        RL_HIP(hipMemcpy(&h_flag, hb.flag, 4, hipMemcpyDeviceToHost));
+        uint32_t mx = 0; double mean = 0;
+        for (int32_t b = 0; b < n_gemm; ++b) { mx = std::max(mx, h_cnt[b]); mean += h_cnt[b]; }
+        fprintf(stderr, "HIDEBUG n=%d k=%d flag=%u max_row_norm=%g cnt mean=%.1f max=%u  q0: best=%g kth=%g thr=%g\n", n_gemm, k, h_flag,
+                idx->max_row_norm, mean / n_gemm, mx, h_ts[0], h_ts[k - 1], h_thr[0]);
+    }
+    idx->filt = {RL_FILTER_MAXSIM_BATCH, n_gemm, hb.cap, hb.cnt, hb.flag};
+    RL_TRY(launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap, n_gemm, hb.es, s));
+    RL_TRY(launch_merge_topk(hb.es, hb.ci, 1, n_gemm, hb.cap, k, d_s, d_c, s, hb.cnt));
+    for (int32_t b = 0; b < n_gemm; b += GEMM_PASS_QUERIES) {  // list overflow / unusable bound: the full-precision passes, behind the flag
+        const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_gemm - b);
+        RL_TRY(launch_maxsim_gemm(idx->planes.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
+                                  idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, image_scale(idx),
+                                  idx->E16 != nullptr, hb.flag));
+    }
+    RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // (harmless on scores nobody reads)
+    RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, d_s, d_c, s, hb.flag));
+    return RL_OK;
+}
+}  // namespace
+
 int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queries, int32_t nq, int32_t k,
                          float* out_scores, int32_t* out_chunks, int mem, void* stream) {
     if (!idx) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: null index");
@@ -1845,69 +1929,11 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
                 // halves drop, (max|e| + max|e_lo|) sum_i |q_lo,i| (measured per query by the threshold kernel): same results by the
                 // same argument (bit-identical on the benchmark shape, profiles/r02_u_probe.txt), the pass 1.01 -> 0.71 ms, 418 instead of
                 // 307 candidates per query, the 128-query step 17.1 -> 12.8 ms.  RAGLITE_HI_ONE_PRODUCT=0 (read per call): two products.
-                const char* one_env = std::getenv("RAGLITE_HI_ONE_PRODUCT");
-                const bool one_product = !(one_env && one_env[0] == '0');
-                const int32_t cap = 2048;  // (the benchmark corpus needs ~1 150: score spread sigma ~ 34, window 2 m = 34)
-                const size_t words = (size_t)n_gemm * k * 2 + (size_t)n_gemm * 2 + 16 + (size_t)n_gemm * cap * 2;
-                RL_TRY(idx->hibuf.reserve(words * 4));
-                float* ts = idx->hibuf.as<float>();                            // [n x k] approximate top-k scores
-                int32_t* ti = reinterpret_cast<int32_t*>(ts + (size_t)n_gemm * k);
-                float* thr = reinterpret_cast<float*>(ti + (size_t)n_gemm * k);  // [n]
-                uint32_t* cnt = reinterpret_cast<uint32_t*>(thr + n_gemm);       // [n]
-                uint32_t* flag = cnt + n_gemm;                                   // (16 words)
-                int32_t* ci = reinterpret_cast<int32_t*>(flag + 16);             // [n x cap] candidate chunks
-                float* es = reinterpret_cast<float*>(ci + (size_t)n_gemm * cap); // [n x cap] their exact scores
-                RL_HIP(hipMemsetAsync(flag, 0, 16 * sizeof(uint32_t), s));
-                RL_HIP(hipMemsetAsync(ci, 0xff, (size_t)n_gemm * cap * sizeof(int32_t), s));  // unused slots: -1 = "no chunk"
-                // One product: SIXTEEN queries per pass through maxsim_pp.hip (dim >= 256; RAGLITE_NO_PP=1, read per call: the
-                // eight-query pass of maxsim_gemm.hip instead -- A/B, and what two products still use).
-                const char* nopp_env = std::getenv("RAGLITE_NO_PP");
-                const bool pp = one_product && idx->dim >= 256 && !(nopp_env && nopp_env[0] && nopp_env[0] != '0');
-                for (int32_t b = 0; pp && b < n_gemm; b += PP_PASS_QUERIES) {
-                    const int32_t n_q = std::min<int32_t>(PP_PASS_QUERIES, n_gemm - b);
-                    RL_TRY(launch_maxsim_pp(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
-                                            idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale));
-                }
-                for (int32_t b = 0; !pp && b < n_gemm; b += GEMM_PASS_QUERIES) {
-                    const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_gemm - b);
-                    RL_TRY(launch_maxsim_gemm(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
-                                              idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale, true,
-                                              nullptr, one_product));
-                }
-                RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // tombstones never become candidates
-                RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, ts, ti, s));
-                // per pair |approx - exact| <= |q_i| |e_lo,j| (what the HI halves drop, measured: max_lo_norm) + 2^-12 |q_i| |e_j| (the
-                // query's own 2^-22 split and twice the worst case of a 1024-term fp32 sum, 6e-5)
-                const float m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
-                const float* q_unscale = reinterpret_cast<const float*>(idx->qplanes.as<char>() + (size_t)n_queries * idx->dim * 128);  // launch_query_planes' meta
-                RL_TRY(launch_maxsim_threshold(ts, n_gemm, k, d_q, nq, idx->dim, (int64_t)q_elems, 1.0f, m_abs, thr, cnt, flag, s,
-                                               one_product ? q_unscale : nullptr, idx->max_row_norm + idx->max_lo_norm));
-                RL_TRY(launch_collect_above(sc, n_gemm, idx->n_chunks, ld, thr, nullptr, cap, ci, nullptr, cnt, flag, s));
-                if (std::getenv("RAGLITE_HI_DEBUG")) {  // diagnostic: synchronises; list lengths, threshold and flag of this batch to stderr
-                    std::vector<uint32_t> h_cnt(n_gemm);
-                    std::vector<float> h_thr(n_gemm), h_ts((size_t)n_gemm * k);
-                    uint32_t h_flag = 0;
-                    RL_HIP(hipStreamSynchronize(s));
-                    RL_HIP(hipMemcpy(h_cnt.data(), cnt, (size_t)n_gemm * 4, hipMemcpyDeviceToHost));
-                    RL_HIP(hipMemcpy(h_thr.data(), thr, (size_t)n_gemm * 4, hipMemcpyDeviceToHost));
-                    RL_HIP(hipMemcpy(h_ts.data(), ts, (size_t)n_gemm * k * 4, hipMemcpyDeviceToHost));
-                    RL_HIP(hipMemcpy(&h_flag, flag, 4, hipMemcpyDeviceToHost));
-                    uint32_t mx = 0; double mean = 0;
-                    for (int32_t b = 0; b < n_gemm; ++b) { mx = std::max(mx, h_cnt[b]); mean += h_cnt[b]; }
-                    fprintf(stderr, "HIDEBUG n=%d k=%d flag=%u max_row_norm=%g cnt mean=%.1f max=%u  q0: best=%g kth=%g thr=%g\n", n_gemm, k, h_flag,
-                            idx->max_row_norm, mean / n_gemm, mx, h_ts[0], h_ts[k - 1], h_thr[0]);
-                }
-                idx->filt = {RL_FILTER_MAXSIM_BATCH, n_gemm, cap, cnt, flag};
-                RL_TRY(launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, ci, cap, n_gemm, es, s));
-                RL_TRY(launch_merge_topk(es, ci, 1, n_gemm, cap, k, d_s, d_c, s, cnt));
-                for (int32_t b = 0; b < n_gemm; b += GEMM_PASS_QUERIES) {  // (4)
-                    const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_gemm - b);
-                    RL_TRY(launch_maxsim_gemm(idx->planes.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
-                                              idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, image_scale(idx),
-                                              idx->E16 != nullptr, flag));
-                }
-                RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // (harmless on scores nobody reads)
-                RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, d_s, d_c, s, flag));
+                HiBatch hb;
+                RL_TRY(hi_batch_approx(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, s));
+                RL_TRY(launch_maxsim_threshold(hb.ts, n_gemm, k, d_q, nq, idx->dim, (int64_t)q_elems, 1.0f, hb.m_abs, hb.thr, hb.cnt, hb.flag, s,
+                                               hb.one_product ? hb.q_unscale : nullptr, idx->max_row_norm + idx->max_lo_norm));
+                RL_TRY(hi_batch_rescore(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, d_s, d_c, s));
                 base = n_gemm;
                 hi_done = true;
             } else {
@@ -1939,6 +1965,92 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
                                d_c + (int64_t)first * k, s));
         }
     }
+    if (idx->live_chunk_bits) RL_TRY(launch_fix_masked(d_s, d_c, (int64_t)n_queries * k, s));
+    RL_TRY(stage_out_end(out_scores, (size_t)n_queries * k, mem, s, t_s));
+    RL_TRY(stage_out_end(out_chunks, (size_t)n_queries * k, mem, s, t_c));
+    return finish(mem, s);
+}
+
+// ---- the MaxSim batch of a corpus SHARDED over several indexes, with ONE candidate threshold for all shards (header: protocol) ------------
+int rl_maxsim_batch_begin(rl_index* idx, const float* query_vecs, int32_t n_queries, int32_t nq, int32_t k, float* out_approx, int mem,
+                          void* stream) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_maxsim_batch_begin: null index");
+    if (n_queries < 1 || nq < 1 || k < 1) return fail(RL_ERR_INVALID, "rl_maxsim_batch_begin: bad sizes");
+    if (!query_vecs || !out_approx) return fail(RL_ERR_INVALID, "rl_maxsim_batch_begin: null argument");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
+    idx->mb_B = 0;
+    // the bound-filtered pipeline must cover the WHOLE batch (rl_maxsim_topk_batch takes other kernels for what it leaves over)
+    const char* off_env = std::getenv("RAGLITE_NO_HI_MAXSIM");
+    const bool hi_off = off_env && off_env[0] && off_env[0] != '0';
+    const bool whole = n_queries % GEMM_PASS_QUERIES == 0 || n_queries % GEMM_PASS_QUERIES >= GEMM_PASS_MIN_QUERIES;
+    if (hi_off || !whole || n_queries < GEMM_PASS_MIN_QUERIES || k > 512 || nq > 32)
+        return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_batch_begin: needs >= 3 queries (n % 8 == 0 or n % 8 >= 3), nq <= 32 and k <= 512");
+    DevBuf t_q, t_o;
+    const float* d_q; float* d_o;
+    const size_t q_elems = (size_t)nq * idx->dim;
+    RL_TRY(stage_in(query_vecs, (size_t)n_queries * q_elems, mem, s, t_q, &d_q));
+    RL_TRY(stage_out_begin(out_approx, (size_t)n_queries * (k + 1), mem, t_o, &d_o));
+    const int64_t ld = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
+    RL_TRY(idx->scores.reserve((size_t)n_queries * ld * sizeof(float)));
+    float* sc = idx->scores.as<float>();
+    {
+        const int st = gemm_prepare(idx, d_q, nq, (int64_t)q_elems, n_queries, s);
+        if (st != RL_OK) return st == RL_ERR_UNSUPPORTED ? fail(RL_ERR_UNSUPPORTED, "rl_maxsim_batch_begin: this index keeps no corpus image") : st;
+    }
+    if (!hi_image_valid(idx)) return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_batch_begin: this index keeps no HI image (small, fp16-stored or exact-fp32 index)");
+    HiBatch hb;
+    RL_TRY(hi_batch_approx(idx, d_q, nq, n_queries, n_queries, k, sc, ld, hb, s));
+    // this shard's bound m_b: the threshold kernel over a "k-th best" of zero leaves -2 m_b
+    RL_HIP(hipMemsetAsync(hb.es, 0, (size_t)n_queries * sizeof(float), s));
+    RL_TRY(launch_maxsim_threshold(hb.es, n_queries, 1, d_q, nq, idx->dim, (int64_t)q_elems, 1.0f, hb.m_abs, hb.thr, hb.cnt, hb.flag, s,
+                                   hb.one_product ? hb.q_unscale : nullptr, idx->max_row_norm + idx->max_lo_norm));
+    RL_TRY(launch_pack_approx(hb.ts, hb.thr, n_queries, k, d_o, s));
+    idx->mb_B = n_queries;
+    idx->mb_nq = nq;
+    idx->mb_k = k;
+    RL_TRY(stage_out_end(out_approx, (size_t)n_queries * (k + 1), mem, s, t_o));
+    return finish(mem, s);
+}
+
+int rl_maxsim_batch_finish(rl_index* idx, const float* query_vecs, const float* all_approx, int32_t world, int32_t rank, float* out_scores,
+                           int32_t* out_chunks, int mem, void* stream) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_maxsim_batch_finish: null index");
+    if (!query_vecs || !all_approx || !out_scores || !out_chunks) return fail(RL_ERR_INVALID, "rl_maxsim_batch_finish: null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(RL_ERR_INVALID, "rl_maxsim_batch_finish: bad world / rank");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
+    if (idx->mb_B < 1) return fail(RL_ERR_INVALID, "rl_maxsim_batch_finish: no rl_maxsim_batch_begin in progress on this index");
+    const int32_t n_queries = idx->mb_B, nq = idx->mb_nq, k = idx->mb_k;
+    idx->mb_B = 0;
+    DevBuf t_q, t_a, t_s, t_c;
+    const float* d_q; const float* d_a; float* d_s; int32_t* d_c;
+    const size_t q_elems = (size_t)nq * idx->dim;
+    RL_TRY(stage_in(query_vecs, (size_t)n_queries * q_elems, mem, s, t_q, &d_q));
+    RL_TRY(stage_in(all_approx, (size_t)world * n_queries * (k + 1), mem, s, t_a, &d_a));
+    RL_TRY(stage_out_begin(out_scores, (size_t)n_queries * k, mem, t_s, &d_s));
+    RL_TRY(stage_out_begin(out_chunks, (size_t)n_queries * k, mem, t_c, &d_c));
+    const int64_t ld = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
+    float* sc = idx->scores.as<float>();
+    HiBatch hb;  // the layout of rl_maxsim_batch_begin (same sizes: nothing is reallocated, the approximate scores are still in `sc`)
+    {
+        const char* one_env = std::getenv("RAGLITE_HI_ONE_PRODUCT");
+        hb.one_product = !(one_env && one_env[0] == '0');
+        hb.cap = 2048;
+        hb.ts = idx->hibuf.as<float>();
+        hb.ti = reinterpret_cast<int32_t*>(hb.ts + (size_t)n_queries * k);
+        hb.thr = reinterpret_cast<float*>(hb.ti + (size_t)n_queries * k);
+        hb.cnt = reinterpret_cast<uint32_t*>(hb.thr + n_queries);
+        hb.flag = hb.cnt + n_queries;
+        hb.ci = reinterpret_cast<int32_t*>(hb.flag + 16);
+        hb.es = reinterpret_cast<float*>(hb.ci + (size_t)n_queries * hb.cap);
+        hb.m_abs = 0.f;
+        hb.q_unscale = nullptr;
+    }
+    RL_TRY(launch_global_threshold(d_a, world, n_queries, k, rank, hb.thr, hb.cnt, hb.flag, s));
+    RL_TRY(hi_batch_rescore(idx, d_q, nq, n_queries, n_queries, k, sc, ld, hb, d_s, d_c, s));
     if (idx->live_chunk_bits) RL_TRY(launch_fix_masked(d_s, d_c, (int64_t)n_queries * k, s));
     RL_TRY(stage_out_end(out_scores, (size_t)n_queries * k, mem, s, t_s));
     RL_TRY(stage_out_end(out_chunks, (size_t)n_queries * k, mem, s, t_c));

@@ -57,6 +57,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -183,6 +188,11 @@ int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld,
 int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, const float* Q, int32_t nq, int32_t dim, int64_t q_stride,
                             float m_rel, float e_max, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s,
                             const float* q_unscale = nullptr, float e_norm_max = 0.f);
+// A MaxSim batch over a sharded corpus (api.hip: rl_maxsim_batch_begin / _finish): out[b] = top[b][0 .. k) ++ {m_b} with neg2m[b] = -2 m_b;
+// thr[b] = (k-th best of all shards' lists [world][B][k + 1]) - max_r m_r - m_rank, cnt[b] = 0, *flag on an unusable threshold
+int launch_pack_approx(const float* top, const float* neg2m, int32_t B, int32_t k, float* out, hipStream_t s);
+int launch_global_threshold(const float* lists, int32_t world, int32_t B, int32_t k, int32_t rank, float* thr, uint32_t* cnt, uint32_t* flag,
+                            hipStream_t s);
 // bits[0..2] = max |e|, max |e_lo|, max |e_lo| / |e| over the rows (float bit patterns, nudged up by 1e-6; start them at the
 // values so far), e_lo = what the fp16 HI halves at `scale` drop
 int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale, uint32_t* bits, hipStream_t s);

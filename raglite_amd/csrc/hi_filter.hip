@@ -275,6 +275,73 @@ __global__ __launch_bounds__(256) void diag_blocks_kernel(const float* __restric
 
 }  // namespace
 
+// ---- a MaxSim batch over a SHARDED corpus: one threshold for all shards (api.hip: rl_maxsim_batch_begin / _finish) -------------------------
+// out[b][0 .. k) = this shard's k best approximate scores of query b (descending), out[b][k] = its bound m_b (neg2m = -2 m_b)
+__global__ __launch_bounds__(256) void pack_approx_kernel(const float* __restrict__ top, const float* __restrict__ neg2m, int32_t k, int64_t count,
+                                                           float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const int64_t b = i / (k + 1);
+    const int32_t j = (int32_t)(i - b * (k + 1));
+    out[i] = j < k ? top[b * k + j] : -0.5f * neg2m[b];
+}
+
+// One block per query.  lists [world][B][k + 1]: every shard's k best approximate scores (descending) and its bound.  A = the k-th best
+// approximate score over ALL shards (the global top-k by approximate score lies inside the union of the shards' top-k), m* = the
+// largest bound: at least k chunks have an exact score >= A - m*, so a chunk of the exact global top-k on this shard has an exact score
+// >= A - m* and an approximate one >= A - m* - m_rank.  thr[b] = that; cnt[b] = 0; an unusable threshold (fewer than k scorable chunks
+// over all shards, NaN) sets *flag: this shard's guarded full-precision path then returns ITS exact top-k, which the merge accepts as well.
+__global__ __launch_bounds__(256) void global_threshold_kernel(const float* __restrict__ lists, int32_t world, int32_t B, int32_t k, int32_t rank,
+                                                                float* __restrict__ thr, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag) {
+    __shared__ float part[4];
+    const int b = blockIdx.x;
+    const int64_t stride = (int64_t)B * (k + 1);
+    const float* mine = lists + (int64_t)b * (k + 1);
+    float best = -INFINITY;  // the largest value with at least k values >= it
+    for (int i = threadIdx.x; i < world * k; i += 256) {
+        const float v = mine[(int64_t)(i / k) * stride + (i % k)];
+        if (!(v > -INFINITY)) continue;  // (-inf padding and NaN never are the k-th best of k scorable chunks)
+        int32_t c = 0;
+        for (int r = 0; r < world && c < k; ++r) {  // how many of shard r's values are >= v: its list is sorted, descending
+            const float* l = mine + (int64_t)r * stride;
+            int32_t lo = 0, hi = k;
+            while (lo < hi) {
+                const int32_t mid = (lo + hi) >> 1;
+                if (l[mid] >= v) lo = mid + 1; else hi = mid;
+            }
+            c += lo;
+        }
+        if (c >= k) best = fmaxf(best, v);
+    }
+    best = wave_max(best);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const float A = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    float m_max = 0.f;
+    for (int r = 0; r < world; ++r) m_max = fmaxf(m_max, mine[(int64_t)r * stride + k]);
+    const float t = A - (m_max + mine[(int64_t)rank * stride + k]) * 1.00001f;
+    thr[b] = t;
+    cnt[b] = 0u;
+    if (!(t > -INFINITY)) atomicOr(flag, 1u);
+}
+
+int launch_pack_approx(const float* top, const float* neg2m, int32_t B, int32_t k, float* out, hipStream_t s) {
+    const int64_t count = (int64_t)B * (k + 1);
+    if (count <= 0) return RL_OK;
+    hipLaunchKernelGGL(pack_approx_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, top, neg2m, k, count, out);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+int launch_global_threshold(const float* lists, int32_t world, int32_t B, int32_t k, int32_t rank, float* thr, uint32_t* cnt, uint32_t* flag,
+                            hipStream_t s) {
+    if (B <= 0) return RL_OK;
+    hipLaunchKernelGGL(global_threshold_kernel, dim3(B), dim3(256), 0, s, lists, world, B, k, rank, thr, cnt, flag);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const float* queries, int32_t dim, int mode, float m_rel,
                             float e_norm_bound, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s) {
     hipLaunchKernelGGL(approx_threshold_kernel, dim3(1), dim3(256), 0, s, topk, nb, k, queries, (int)dim, mode, m_rel, e_norm_bound, thr, cnt,

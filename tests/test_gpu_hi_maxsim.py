@@ -162,3 +162,89 @@ def test_one_product_fallback_on_near_identical_chunks():
         fs, fc = idx.maxsim_topk_batch(Qb, 100)
     assert np.array_equal(bc, fc) and np.array_equal(bs.view(np.uint32), fs.view(np.uint32))
     idx.close()
+
+
+def _torch():
+    import torch
+
+    raglite_amd.set_device(0)
+    return torch
+
+
+def _corpus(torch, n, dim, seed, kind="uniform"):
+    E = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=seed, kind=kind)
+    return E
+
+
+def _queries(torch, n_queries, nq, dim, seed, kind="uniform"):
+    Q = torch.empty((n_queries, nq, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=seed, kind=kind)
+    return Q
+
+
+@pytest.mark.parametrize("kind,n_queries", [("small_int", 16), ("uniform", 21), ("uniform", 8)])
+def test_sharded_batch_with_one_global_threshold_equals_single_index(kind, n_queries):
+    """`rl_maxsim_batch_begin` / `_finish` (driven by `ShardedIndex._local_maxsim_batch`): three shards of one corpus exchange their k best
+    approximate scores and bounds -- stacked in plain Python here instead of an all-gather -- and re-score only what could be in the GLOBAL
+    top-k.  The merge of their lists is what ONE index over the whole corpus returns (`/root/reference/src/raglite/_search.py:143-149`
+    semantics, MaxSim generalisation behind the reranker plugin call `:394-396`): bit for bit on integer data, the same chunks with
+    scores to the last bits of the fp32 sums on float data (both come from the same exact re-scoring kernel).  And the shards together
+    re-score far fewer candidates than each would alone."""
+    torch = _torch()
+    n, dim, nq, k = 210_000, 1024, 32, 50
+    rng = np.random.default_rng(23)
+    off = ragged_offsets(rng, n, 1, 15)
+    E = _corpus(torch, n, dim, seed=77, kind=kind)
+    Q = _queries(torch, n_queries, nq, dim, seed=78, kind=kind)
+    whole = raglite_amd.DeviceIndex(E, off, metric="dot")
+    ws, wc = whole.maxsim_topk_batch(Q, k)
+    assert whole.filter_stats()["kind"] == "maxsim_batch_hi" and not whole.filter_stats()["fallback"]
+    n_chunks = len(off) - 1
+    cuts = [0, n_chunks // 3, 2 * n_chunks // 3 + 5, n_chunks]
+    shards = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        r0, r1 = int(off[lo]), int(off[hi])
+        shards.append((raglite_amd.DeviceIndex(E[r0:r1].clone(), off[lo : hi + 1] - off[lo], metric="dot"), lo))
+    approx = [sh.maxsim_batch_begin(Q, k) for sh, _ in shards]
+    for a in approx:  # k best approximate scores, descending, then a positive bound
+        assert tuple(a.shape) == (n_queries, k + 1) and bool((a[:, : k - 1] >= a[:, 1:k]).all()) and bool((a[:, k] > 0).all())
+    allg = torch.stack(approx)
+    lists_s, lists_c, staged_candidates = [], [], 0.0
+    for r, (sh, lo) in enumerate(shards):
+        s, c = sh.maxsim_batch_finish(Q, allg, r, k)
+        st = sh.filter_stats()
+        assert st["kind"] == "maxsim_batch_hi" and not st["fallback"]
+        staged_candidates += st["candidates_per_query_mean"]
+        lists_s.append(s)
+        lists_c.append(torch.where(c >= 0, c + lo, torch.full_like(c, -1)))
+    ms, mc = raglite_amd.merge_topk(torch.stack(lists_s), torch.stack(lists_c).to(torch.int32), k)
+    assert torch.equal(mc.to(torch.int64), wc.to(torch.int64))
+    if kind == "small_int":
+        assert torch.equal(ms, ws)
+    else:
+        assert float((ms - ws).abs().max()) <= 2e-6 * float(ws.abs().max())
+    alone = 0.0
+    for sh, _ in shards:  # what the shards re-score without the exchange
+        sh.maxsim_topk_batch(Q, k)
+        alone += sh.filter_stats()["candidates_per_query_mean"]
+    single = whole.filter_stats()["candidates_per_query_mean"]
+    assert staged_candidates <= 1.3 * single + 3 and staged_candidates < 0.75 * alone, (staged_candidates, single, alone)
+    for i in [whole, *[sh for sh, _ in shards]]:
+        i.close()
+
+
+def test_batch_begin_refuses_what_the_pipeline_does_not_cover():
+    torch = _torch()
+    from raglite_amd._abi import UnsupportedError
+
+    small = raglite_amd.DeviceIndex(_corpus(torch, 5_000, 256, seed=5), None, metric="dot")  # no image of the hi halves
+    with pytest.raises(UnsupportedError):
+        small.maxsim_batch_begin(_queries(torch, 8, 4, 256, seed=6), 10)
+    big = raglite_amd.DeviceIndex(_corpus(torch, 70_000, 1024, seed=7), None, metric="dot")
+    with pytest.raises(UnsupportedError):
+        big.maxsim_batch_begin(_queries(torch, 2, 4, 1024, seed=8), 10)  # two queries: the pair kernel's business
+    with pytest.raises(ValueError):
+        big.maxsim_batch_finish(_queries(torch, 8, 4, 1024, seed=8), torch.zeros((2, 8, 11), device="cuda"), 0, 10)  # no begin in progress
+    small.close()
+    big.close()

@@ -122,6 +122,45 @@ class _OracleLocal:
         return S, C_
 
 
+    # -- the MaxSim batch with one candidate threshold for all shards (rl_maxsim_batch_begin / _finish), restated in NumPy: the
+    # "approximate" score of a chunk is its exact one rounded down to a multiple of 4 (error < m = 4 on integer data)
+    M_BOUND = 4.0
+
+    def _all_scores(self, Qb):
+        return np.stack([oracle.maxsim_scores(self.E, self.off, Q, np.float32) for Q in Qb]).astype(np.float32)
+
+    def maxsim_topk_batch(self, Qb, k):
+        outs = [self.maxsim_topk(Q, k) for Q in Qb]
+        return np.stack([o[0] for o in outs]), np.stack([o[1] for o in outs])
+
+    def maxsim_batch_begin(self, Qb, k):
+        self._exact = self._all_scores(Qb)
+        self._approx = (np.floor(self._exact / 4.0) * 4.0).astype(np.float32)
+        out = np.full((len(Qb), k + 1), -np.inf, np.float32)
+        for b in range(len(Qb)):
+            top = np.sort(self._approx[b])[::-1][:k]
+            out[b, : len(top)] = top
+        out[:, k] = self.M_BOUND
+        self.begin_calls = getattr(self, "begin_calls", 0) + 1
+        return out
+
+    def maxsim_batch_finish(self, Qb, all_approx, rank, k):
+        world, B, _ = all_approx.shape
+        S = np.full((B, k), -np.inf, np.float32)
+        C_ = np.full((B, k), -1, np.int32)
+        self.finish_candidates = 0
+        for b in range(B):
+            pool = np.sort(all_approx[:, b, :k].reshape(-1))[::-1]
+            A = pool[k - 1]
+            thr = A - all_approx[:, b, k].max() - all_approx[rank, b, k]
+            cand = np.nonzero(self._approx[b] >= thr)[0]
+            self.finish_candidates += len(cand)
+            order = np.lexsort((cand, -self._exact[b][cand].astype(np.float64)))[:k]
+            S[b, : len(order)] = self._exact[b][cand][order]
+            C_[b, : len(order)] = cand[order]
+        return S, C_
+
+
 def _corpus():
     rng = np.random.default_rng(42)
     off = ragged_offsets(rng, 400, 1, 9)
@@ -152,12 +191,16 @@ def _worker(rank, world, port, out_q):
         f_ms = sh.maxsim_topk(Q, 10, chunk_filter=ok)
         f_ch = sh.search_chunks(Q, 40, 6, chunk_filter=ok)
         b_ms = sh.maxsim_topk_batch(np.stack([Q, Q[::-1].copy()]), 10)  # a batch of two queries: one exchange for both
+        # a batch of five: the shards agree on ONE candidate threshold first (an all-gather of their k best approximate scores)
+        Q5 = np.stack([np.roll(Q, i, axis=0) * (1 + i % 2) for i in range(5)]).astype(np.float32)
+        g_ms = sh.maxsim_topk_batch(Q5, 10)
+        assert local.begin_calls == 1 and 0 < local.finish_candidates < 5 * (len(local_off) - 1) // 2  # (staged, and selective)
         # the order-first branch: a GLOBAL cut to the 150 nearest of the 400 rows (integer data: dozens of ties ON the threshold,
         # split between the shards), then the filter, then top-25 / the two-stage search
         k_rows = sh.search_rows(Q, 25, chunk_filter=ok, rank_limit=150)
         k_ch = sh.search_chunks(Q, 40, 6, chunk_filter=ok, rank_limit=150)
         k_all = sh.search_rows(Q, 25, chunk_filter=ok, rank_limit=4000)  # a limit above the corpus: no cut
-        out_q.put((rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch, b_ms, k_rows, k_ch, k_all))
+        out_q.put((rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch, b_ms, k_rows, k_ch, k_all, g_ms))
     finally:
         dist.destroy_process_group()
 
@@ -184,7 +227,12 @@ def test_two_rank_gloo_matches_single_shard():
     E, off, Q = _corpus()
     r2c = np.repeat(np.arange(len(off) - 1), np.diff(off))
     ok = _chunk_mask(len(off) - 1)
-    for rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch, b_ms, k_rows, k_ch, k_all in results:
+    for rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch, b_ms, k_rows, k_ch, k_all, g_ms in results:
+        for j in range(5):  # one threshold for all shards == the single index
+            Qj = (np.roll(Q, j, axis=0) * (1 + j % 2)).astype(np.float32)
+            ms, mc = oracle.maxsim_topk(E, off, Qj, 10)
+            assert np.array_equal(g_ms[1][j], mc), f"rank {rank} batch query {j}: {g_ms[1][j]} vs {mc}"
+            np.testing.assert_array_equal(g_ms[0][j], ms.astype(np.float32))
         for b in range(len(Q)):  # the rank cut across shards == the single-table cut (`_search.py:120-141`), ties included
             es, ei = oracle.search_rows_ranked(E, r2c, Q[b], 25, ok, 150, None, "dot", np.float32)
             assert np.array_equal(k_rows[1][b], ei), f"rank {rank} query {b} (rank cut): {k_rows[1][b][:8]} vs {ei[:8]}"
