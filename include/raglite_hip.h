@@ -239,7 +239,9 @@ int rl_maxsim_scores(rl_index* index, const float* query_vecs, int32_t nq, float
  * what the hi halves of corpus and queries drop, and the chunks that could be in the top-k are
  * re-scored with exact fp32 products: the same top-k, scores as accurate as before; where the bound does not decide
  * (thousands of near-identical chunks) the full-precision passes run instead, on the device.
- * RAGLITE_NO_HI_MAXSIM=1 / RAGLITE_NO_HI_PLANE=1 switch that off.
+ * RAGLITE_NO_HI_MAXSIM=1 / RAGLITE_NO_HI_PLANE=1 switch that off.  A big fp16-STORED index (rl_index_create_f16) takes the same
+ * pipeline with its stored halves as that image: the approximate pass multiplies q_hi . e (what it drops, q_lo . e, is bounded the same
+ * way), the candidates are re-scored over the stored rows, the two-product passes are the guarded fallback.
  *   query_vecs [n_queries x nq x dim] f32; out_scores / out_chunks [n_queries x k]. */
 int rl_maxsim_topk_batch(rl_index* index, const float* query_vecs, int32_t n_queries, int32_t nq, int32_t k,
                          float* out_scores, int32_t* out_chunks, int mem, void* stream);
@@ -272,7 +274,7 @@ int rl_maxsim_batch_finish(rl_index* index, const float* query_vecs, const float
  * chunk are added in another order, so float scores agree to the last bits, integer-valued ones exactly), and per query the rigorous bound
  * m with |approximate - exact| <= m for EVERY chunk that rl_maxsim_topk_batch's candidate window (2 m) is built on.
  *   query_vecs [n_queries x nq x dim] f32, nq <= 32;  out_scores [n_queries x n_chunks] f32 (tombstoned chunks included: no mask),
- *   out_bound [n_queries] f32 or NULL.  RL_ERR_UNSUPPORTED when the index keeps no HI image (small / fp16-stored / exact-fp32
+ *   out_bound [n_queries] f32 or NULL.  RL_ERR_UNSUPPORTED when the index keeps no image for the approximate pass (small / exact-fp32
  *   indexes, indexes with empty chunks). */
 int rl_maxsim_approx_scores(rl_index* index, const float* query_vecs, int32_t n_queries, int32_t nq, int kernel,
                             float* out_scores, float* out_bound, int mem, void* stream);

@@ -340,6 +340,7 @@ bool image_fits(const rl::Pool& pool, size_t need) {
 // Builds / extends the corpus image so that it covers rows [0, idx->n_rows) at image_scale(idx).  Not having the image is
 // never an error (the streaming kernels read the stored rows): an allocation failure or a device too full just leaves it absent.
 
+int refresh_row_norm16(rl_index* idx, hipStream_t s);
 int refresh_planes(rl_index* idx, hipStream_t s) {
     static const bool no_planes = std::getenv("RAGLITE_NO_PLANES") != nullptr;  // A/B switch
     const bool half = idx->E16 != nullptr;
@@ -377,6 +378,7 @@ int refresh_planes(rl_index* idx, hipStream_t s) {
     RL_TRY(rl::launch_chunk_ends(idx->row_to_chunk, idx->n_rows, idx->ends.as<uint32_t>(), s));
     idx->planes_scale = image_scale(idx);
     idx->planes_rows = idx->n_rows;
+    if (half) RL_TRY(refresh_row_norm16(idx, s));
     return RL_OK;
 }
 
@@ -389,6 +391,41 @@ bool hi_image_valid(const rl_index* idx) {
     return idx->hi_image_scale > 0.f && idx->hi_image_scale == idx->split_scale && idx->hi_image_rows == idx->n_rows && idx->n_rows > 0 &&
            idx->max_row_norm_rows == idx->n_rows && idx->max_row_norm > 0.f;
 }
+// What the approximate MaxSim pass of a batch multiplies at ONE fp16 product per multiply: the image of the hi halves of an fp32 corpus --
+// or the image of an fp16-STORED corpus itself (the stored halves ARE the corpus: the pass then drops only the queries' lo halves, the
+// bound has no e_lo term, and the candidates are re-scored over the stored rows).  Same size gate for both (>= 64 M elements).
+bool approx_image_valid(const rl_index* idx) {
+    if (!idx->E16) return hi_image_valid(idx);
+    return image_valid(idx) && (int64_t)idx->n_rows * idx->dim >= (int64_t(64) << 20) && idx->dim <= 1024 && idx->max_row_norm_rows == idx->n_rows &&
+           idx->max_row_norm > 0.f;
+}
+const void* approx_image(const rl_index* idx) { return idx->E16 ? idx->planes.p : idx->hi_image.p; }
+float approx_scale(const rl_index* idx) { return idx->E16 ? 1.0f : idx->split_scale; }
+
+// max |e| over the rows of an fp16-stored corpus, folded in as rows arrive (synchronises the stream: build / append / compact only)
+int refresh_row_norm16(rl_index* idx, hipStream_t s) {
+    static const bool off = std::getenv("RAGLITE_NO_HI_PLANE") != nullptr;  // (the A/B switch of the half-bytes paths)
+    if (!idx->E16 || off || !image_valid(idx) || (int64_t)idx->n_rows * idx->dim < (int64_t(64) << 20)) {
+        if (idx->E16) { idx->max_row_norm = 0.f; idx->max_row_norm_rows = 0; }
+        return RL_OK;
+    }
+    if (idx->max_row_norm_rows > idx->n_rows) { idx->max_row_norm = 0.f; idx->max_row_norm_rows = 0; }  // (compacted: start over)
+    if (idx->max_row_norm_rows == idx->n_rows) return RL_OK;
+    const int64_t from = idx->max_row_norm_rows;
+    if (!idx->d_norms) RL_HIP(hipMalloc(&idx->d_norms, 16));
+    uint32_t bits[4] = {0, 0, 0, 0};
+    std::memcpy(&bits[0], &idx->max_row_norm, 4);
+    RL_HIP(hipMemcpyAsync(idx->d_norms, bits, 16, hipMemcpyHostToDevice, s));
+    RL_TRY(rl::launch_max_row_norm16(idx->E16 + (size_t)from * idx->dim, idx->n_rows - from, idx->dim, idx->d_norms, s));
+    RL_HIP(hipMemcpyAsync(bits, idx->d_norms, 16, hipMemcpyDeviceToHost, s));
+    RL_HIP(hipStreamSynchronize(s));
+    std::memcpy(&idx->max_row_norm, &bits[0], 4);
+    idx->max_lo_norm = idx->max_lo_ratio = 0.f;
+    idx->max_row_norm_rows = idx->n_rows;
+    idx->max_row_norm_scale = 1.0f;
+    return RL_OK;
+}
+
 // The HI halves in image layout + the largest row norm (synchronises the stream: build / append / compact only).
 int refresh_hi_image(rl_index* idx, hipStream_t s) {
     static const bool off = std::getenv("RAGLITE_NO_HI_PLANE") != nullptr;  // A/B switch (shared with the row-major plane)
@@ -1831,13 +1868,13 @@ int hi_batch_approx(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queri
     const bool pp = hb.one_product && idx->dim >= 256 && !(nopp_env && nopp_env[0] && nopp_env[0] != '0');
     for (int32_t b = 0; pp && b < n_gemm; b += PP_PASS_QUERIES) {
         const int32_t n_q = std::min<int32_t>(PP_PASS_QUERIES, n_gemm - b);
-        RL_TRY(launch_maxsim_pp(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
-                                idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale));
+        RL_TRY(launch_maxsim_pp(approx_image(idx), idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
+                                idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, approx_scale(idx)));
     }
     for (int32_t b = 0; !pp && b < n_gemm; b += GEMM_PASS_QUERIES) {
         const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_gemm - b);
-        RL_TRY(launch_maxsim_gemm(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
-                                  idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale, true,
+        RL_TRY(launch_maxsim_gemm(approx_image(idx), idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
+                                  idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, approx_scale(idx), true,
                                   nullptr, hb.one_product));
     }
     RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // tombstones never become candidates
@@ -1863,7 +1900,8 @@ int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_quer
                 idx->max_row_norm, mean / n_gemm, mx, h_ts[0], h_ts[k - 1], h_thr[0]);
     }
     idx->filt = {RL_FILTER_MAXSIM_BATCH, n_gemm, hb.cap, hb.cnt, hb.flag};
-    RL_TRY(launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap, n_gemm, hb.es, s));
+    RL_TRY(launch_maxsim_pairs(idx->E16 ? reinterpret_cast<const float*>(idx->E16) : idx->E, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci,
+                               hb.cap, n_gemm, hb.es, s, idx->E16 != nullptr));
     RL_TRY(launch_merge_topk(hb.es, hb.ci, 1, n_gemm, hb.cap, k, d_s, d_c, s, hb.cnt));
     for (int32_t b = 0; b < n_gemm; b += GEMM_PASS_QUERIES) {  // list overflow / unusable bound: the full-precision passes, behind the flag
         const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_gemm - b);
@@ -1916,7 +1954,9 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
                                        : 0;
             const char* off_env = std::getenv("RAGLITE_NO_HI_MAXSIM");  // A/B switch, read per call (tests flip it)
             const bool hi_off = off_env && off_env[0] && off_env[0] != '0';
-            if (n_gemm > 0 && !hi_off && hi_image_valid(idx) && k <= 512) {
+            const char* one_env0 = std::getenv("RAGLITE_HI_ONE_PRODUCT");
+            const bool two_products = one_env0 && one_env0[0] == '0';  // (over an fp16-stored corpus two products ARE the full precision)
+            if (n_gemm > 0 && !hi_off && approx_image_valid(idx) && k <= 512 && !(idx->E16 && two_products)) {
                 // ---- MaxSim of a batch at two MFMA products per multiply instead of three (the headline path) -------------------------
                 // (1) approximate chunk scores: the eight-query pass over the HI image (q_hi.e_hi + q_lo.e_hi);
                 // (2) |approximate - exact| <= m = (max|e_lo| + 2^-12 max|e|) sum_i |q_i| for every chunk (the per-pair bound of
@@ -1999,7 +2039,7 @@ int rl_maxsim_batch_begin(rl_index* idx, const float* query_vecs, int32_t n_quer
         const int st = gemm_prepare(idx, d_q, nq, (int64_t)q_elems, n_queries, s);
         if (st != RL_OK) return st == RL_ERR_UNSUPPORTED ? fail(RL_ERR_UNSUPPORTED, "rl_maxsim_batch_begin: this index keeps no corpus image") : st;
     }
-    if (!hi_image_valid(idx)) return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_batch_begin: this index keeps no HI image (small, fp16-stored or exact-fp32 index)");
+    if (!approx_image_valid(idx)) return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_batch_begin: this index keeps no image for the approximate pass (small or exact-fp32 index)");
     HiBatch hb;
     RL_TRY(hi_batch_approx(idx, d_q, nq, n_queries, n_queries, k, sc, ld, hb, s));
     // this shard's bound m_b: the threshold kernel over a "k-th best" of zero leaves -2 m_b
@@ -2066,7 +2106,7 @@ int rl_maxsim_approx_scores(rl_index* idx, const float* query_vecs, int32_t n_qu
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
     RL_TRY(use_scratch(idx, s));
-    if (!hi_image_valid(idx) || nq > 32 || (kernel == 0 && idx->dim < 256))
+    if (!approx_image_valid(idx) || nq > 32 || (kernel == 0 && idx->dim < 256))
         return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_approx_scores: this index keeps no HI image (or nq > 32 / dim < 256)");
     DevBuf t_q, t_o, t_b;
     const float* d_q; float* d_o; float* d_b = nullptr;
@@ -2081,11 +2121,11 @@ int rl_maxsim_approx_scores(rl_index* idx, const float* query_vecs, int32_t n_qu
     for (int32_t b = 0; b < n_queries; b += per) {
         const int32_t n_q = std::min<int32_t>(per, n_queries - b);
         if (kernel == 0)
-            RL_TRY(launch_maxsim_pp(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk, idx->offsets,
-                                    idx->ends.as<uint32_t>(), d_o + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale));
+            RL_TRY(launch_maxsim_pp(approx_image(idx), idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk, idx->offsets,
+                                    idx->ends.as<uint32_t>(), d_o + (int64_t)b * ld, ld, idx->n_cu, s, approx_scale(idx)));
         else
-            RL_TRY(launch_maxsim_gemm(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk, idx->offsets,
-                                      idx->ends.as<uint32_t>(), d_o + (int64_t)b * ld, ld, idx->n_cu, s, idx->split_scale, true, nullptr, true));
+            RL_TRY(launch_maxsim_gemm(approx_image(idx), idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk, idx->offsets,
+                                      idx->ends.as<uint32_t>(), d_o + (int64_t)b * ld, ld, idx->n_cu, s, approx_scale(idx), true, nullptr, true));
     }
     if (d_b) {  // the bound of the one-product pass, by the kernel the pipeline computes its thresholds with (k = 1 over a dummy top list)
         const float m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
@@ -2284,14 +2324,14 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     }
     if (kind == 7) {  // sixteen queries of nq / 16 vectors each
         st = gemm_prepare(idx, q_dev, nq / PP_PASS_QUERIES, (int64_t)(nq / PP_PASS_QUERIES) * idx->dim, PP_PASS_QUERIES, s);
-        if (st == RL_OK && !(hi_image_valid(idx) && idx->dim >= 256)) st = RL_ERR_UNSUPPORTED;
+        if (st == RL_OK && !(approx_image_valid(idx) && idx->dim >= 256)) st = RL_ERR_UNSUPPORTED;
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the sixteen-query kernel does not apply to this index / shape") : st; }
     }
     RL_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < iters && st == RL_OK; ++i) {
-        if (kind == 7) st = launch_maxsim_pp(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, PP_PASS_QUERIES, 0, PP_PASS_QUERIES,
+        if (kind == 7) st = launch_maxsim_pp(approx_image(idx), idx->n_rows, idx->dim, idx->qplanes.p, PP_PASS_QUERIES, 0, PP_PASS_QUERIES,
                                              nq / PP_PASS_QUERIES, idx->row_to_chunk, idx->offsets, idx->ends.as<uint32_t>(), idx->scores.as<float>(), ldc,
-                                             idx->n_cu, s, idx->split_scale);
+                                             idx->n_cu, s, approx_scale(idx));
         else if (kind == 3) st = gemm_pass(idx, nq / GEMM_PASS_QUERIES, GEMM_PASS_QUERIES, 0, GEMM_PASS_QUERIES, idx->scores.as<float>(), ldc, s);
         else if (kind == 0) st = maxsim_scores_device(idx, q_dev, nq, idx->scores.as<float>(), s);
         else if (kind == 2) st = pairs_pass(idx, nq / 2, 2, 0, idx->scores.as<float>(), ldc, s);

@@ -196,6 +196,7 @@ int launch_global_threshold(const float* lists, int32_t world, int32_t B, int32_
 // bits[0..2] = max |e|, max |e_lo|, max |e_lo| / |e| over the rows (float bit patterns, nudged up by 1e-6; start them at the
 // values so far), e_lo = what the fp16 HI halves at `scale` drop
 int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale, uint32_t* bits, hipStream_t s);
+int launch_max_row_norm16(const uint16_t* E, int64_t n_rows, int32_t dim, uint32_t* bits, hipStream_t s);  // fp16-stored rows: bits[0] only
 int launch_diag_blocks(const float* src, int64_t ld, int32_t k2, int64_t count, float* dst, hipStream_t s);
 // Batched half-bytes search (experimental, api.hip: search_rows_fused_hi) -- see the kernels' comments in hi_filter.hip / select.hip
 int launch_row_threshold(const float* topk, int32_t nb, int32_t k, const float* Q, int32_t dim, int mode, const float* q_unscale, float lo_ratio,
@@ -288,7 +289,8 @@ int launch_maxsim_stream16(const uint16_t* D, int64_t n_rows, int32_t dim, const
                            float* out, int64_t ld, int n_cu, hipStream_t s);
 // exact MaxSim of (query, candidate chunk) pairs, all queries in one launch: dim % 16 == 0, dim <= 1024, nq <= 32, fp32 MFMA
 int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride, const int64_t* chunk_offsets,
-                        const int32_t* candidates, int64_t n_items_per_query, int32_t n_queries, float* out, hipStream_t s);
+                        const int32_t* candidates, int64_t n_items_per_query, int32_t n_queries, float* out, hipStream_t s,
+                        bool rows16 = false);  // rows16: D points at fp16 rows (an fp16-stored corpus)
 int launch_maxsim_generic(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride_queries,
                           const int64_t* chunk_offsets, const int32_t* candidates, int64_t n_items,
                           int32_t n_queries, float* out, hipStream_t s);

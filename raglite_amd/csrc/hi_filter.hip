@@ -264,6 +264,22 @@ __global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restri
     }
 }
 
+// The same maximum over an fp16-STORED corpus (bits[0] only: the stored halves are the corpus, nothing is dropped)
+__global__ __launch_bounds__(256) void max_row_norm16_kernel(const uint16_t* __restrict__ E, int64_t n_rows, int dim, uint32_t* __restrict__ bits) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
+    float mx = 0.f;
+    for (int64_t r = wave0; r < n_rows; r += n_waves) {
+        float ss = 0.f;
+        for (int c = lane; c < dim; c += 64) {
+            const float v = (float)reinterpret_cast<const _Float16*>(E)[r * (int64_t)dim + c];
+            ss = fmaf(v, v, ss);
+        }
+        mx = fmaxf(mx, sqrtf(wave_sum(ss)));
+    }
+    if (lane == 0 && mx > 0.f) atomicMax(bits + 0, __float_as_uint(mx * 1.000001f));
+}
+
 // dst[b * k2 + j] = src[b * ld + b * k2 + j]: query b's scores of ITS candidates out of the [nb x nb * k2] score block
 __global__ __launch_bounds__(256) void diag_blocks_kernel(const float* __restrict__ src, int64_t ld, int32_t k2, int64_t count,
                                                            float* __restrict__ dst) {
@@ -404,6 +420,14 @@ int launch_max_row_norm(const float* E, int64_t n_rows, int32_t dim, float scale
     if (n_rows <= 0) return RL_OK;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_rows + 3) / 4, 256 * 8));
     hipLaunchKernelGGL(max_row_norm_kernel, dim3(blocks), dim3(256), 0, s, E, n_rows, (int)dim, scale, bits);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+int launch_max_row_norm16(const uint16_t* E, int64_t n_rows, int32_t dim, uint32_t* bits, hipStream_t s) {
+    if (n_rows <= 0) return RL_OK;
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n_rows + 3) / 4, 256 * 8));
+    hipLaunchKernelGGL(max_row_norm16_kernel, dim3(blocks), dim3(256), 0, s, E, n_rows, (int)dim, bits);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -109,7 +109,9 @@ static int generic_t(const float* D, int32_t dim, const float* Q, int32_t nq, co
 // showed the waves waiting on memory for 41 % of their cycles with the matrix pipe 46 % busy.
 // KB: k per block (NL = KB / 16 loads per lane in flight ahead of their MFMAs: 256 k = 128 MFMAs = ~2 us of matrix pipe, about the
 // latency of an HBM load under load; 128 left a third of it exposed);  FULL: dim % KB == 0 (no partial block: no branches in a block)
-template <bool FULL, int KB>
+// ROW16: the rows are stored as fp16 (`D` points at halves): 8 B per lane and k step, converted to fp32 on the way in -- the stored
+// halves ARE the corpus, the products are as exact as over an fp32 corpus
+template <bool FULL, int KB, bool ROW16 = false>
 __global__ __launch_bounds__(512) void maxsim_pairs_kernel(const float* __restrict__ D, int dim, const float* __restrict__ Q, int nq,
                                                             int64_t q_stride, const int64_t* __restrict__ offsets,
                                                             const int32_t* __restrict__ candidates, int64_t n_items,
@@ -135,9 +137,20 @@ __global__ __launch_bounds__(512) void maxsim_pairs_kernel(const float* __restri
     constexpr int NL = KB / 16;
     auto request = [&](f32x4 (&x)[NL], int64_t e, int64_t r0, int t0) __attribute__((always_inline)) {
         const int64_t row = r0 + m < e ? r0 + m : e - 1;
-        const float* a = D + row * (int64_t)dim + 4 * g + t0;
+        if constexpr (ROW16) {
+            typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+            const _Float16* a = reinterpret_cast<const _Float16*>(D) + row * (int64_t)dim + 4 * g + t0;
 #pragma unroll
-        for (int j = 0; j < NL; ++j) x[j] = (FULL || t0 + 16 * j < dim) ? *reinterpret_cast<const f32x4*>(a + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NL; ++j) {
+                h16x4 h = (h16x4){0, 0, 0, 0};
+                if (FULL || t0 + 16 * j < dim) h = *reinterpret_cast<const h16x4*>(a + 16 * j);
+                x[j] = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+            }
+        } else {
+            const float* a = D + row * (int64_t)dim + 4 * g + t0;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) x[j] = (FULL || t0 + 16 * j < dim) ? *reinterpret_cast<const f32x4*>(a + 16 * j) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
     };
     auto lane_i64 = [](int64_t v, int k) __attribute__((always_inline)) {  // lane k's value, k wave-uniform
         const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)(uint64_t)v, k), hi = __builtin_amdgcn_readlane((uint32_t)((uint64_t)v >> 32), k);
@@ -227,23 +240,34 @@ __global__ __launch_bounds__(512) void maxsim_pairs_kernel(const float* __restri
 }
 
 int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride, const int64_t* offsets,
-                        const int32_t* candidates, int64_t n_items_per_query, int32_t n_queries, float* out, hipStream_t s) {
+                        const int32_t* candidates, int64_t n_items_per_query, int32_t n_queries, float* out, hipStream_t s, bool rows16) {
     if (n_items_per_query <= 0 || n_queries <= 0) return RL_OK;
     if (nq < 1 || nq > 32 || dim % 16 || dim < 16 || dim > 1024 || !candidates) return RL_ERR_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(D) & (rows16 ? 7 : 15)) || (reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
     const size_t lds = (size_t)32 * (dim + 8) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
-        RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_kernel<true, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_kernel<true, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_kernel<false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+#define RL_PAIRS_ATTR(...) RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        RL_PAIRS_ATTR(true, 256, false);
+        RL_PAIRS_ATTR(true, 128, false);
+        RL_PAIRS_ATTR(false, 128, false);
+        RL_PAIRS_ATTR(true, 256, true);
+        RL_PAIRS_ATTR(true, 128, true);
+        RL_PAIRS_ATTR(false, 128, true);
+#undef RL_PAIRS_ATTR
         attr_set = true;
     }
     // workgroups per query: enough to fill the chip when there are few queries, at most one wave per candidate
     int per_query = (int)std::max<int64_t>(1, std::min<int64_t>((n_items_per_query + 7) / 8, std::max<int64_t>(1, 512 / n_queries)));
 #define RL_PAIRS(FULL_, KB_)                                                                                                               \
-    hipLaunchKernelGGL((maxsim_pairs_kernel<FULL_, KB_>), dim3(per_query, n_queries), dim3(512), lds, s, D, (int)dim, Q, (int)nq, q_stride, \
-                       offsets, candidates, n_items_per_query, out)
+    do {                                                                                                                                   \
+        if (rows16)                                                                                                                        \
+            hipLaunchKernelGGL((maxsim_pairs_kernel<FULL_, KB_, true>), dim3(per_query, n_queries), dim3(512), lds, s, D, (int)dim, Q, (int)nq, \
+                               q_stride, offsets, candidates, n_items_per_query, out);                                                     \
+        else                                                                                                                               \
+            hipLaunchKernelGGL((maxsim_pairs_kernel<FULL_, KB_, false>), dim3(per_query, n_queries), dim3(512), lds, s, D, (int)dim, Q, (int)nq, \
+                               q_stride, offsets, candidates, n_items_per_query, out);                                                     \
+    } while (0)
     if (dim % 256 == 0) RL_PAIRS(true, 256);
     else if (dim % 128 == 0) RL_PAIRS(true, 128);
     else RL_PAIRS(false, 128);

@@ -248,3 +248,64 @@ def test_batch_begin_refuses_what_the_pipeline_does_not_cover():
         big.maxsim_batch_finish(_queries(torch, 8, 4, 1024, seed=8), torch.zeros((2, 8, 11), device="cuda"), 0, 10)  # no begin in progress
     small.close()
     big.close()
+
+
+# ---- fp16-STORED corpus (what RAGLite keeps: `/root/reference/src/raglite/_embed.py:140`, pgvector halfvec `_typing.py:211-232`): the same
+# pipeline with the stored halves as the image of the approximate pass -- one fp16 MFMA product per multiply, q_hi . e; the bound has no
+# e_lo term; the candidates are re-scored over the stored rows (fp16 -> fp32 on the way into v_mfma_f32_16x16x4_f32)
+@pytest.mark.parametrize("n_queries,nq,k", [(16, 32, 100), (11, 17, 20)])
+def test_f16_stored_batch_integer_bit_exact(n_queries, nq, k):
+    rng = np.random.default_rng(n_queries)
+    off = ragged_offsets(rng, N, 1, 15)
+    E = oracle.synth_matrix(12_000 + nq, N, DIM, "small_int")  # exact in fp16
+    Qb = np.stack([oracle.synth_matrix(12_100 + i, nq, DIM, "small_int") for i in range(n_queries)])
+    idx = raglite_amd.DeviceIndex(E.astype(np.float16), off, metric="dot", storage="f16")
+    assert idx.arithmetic == "f16_stored" and idx.memory()["hi_image"] == 0 and idx.memory()["presplit_image"] > 0
+    bs, bc = idx.maxsim_topk_batch(Qb, k)
+    st = idx.filter_stats()
+    assert st["kind"] == "maxsim_batch_hi" and st["queries"] == n_queries
+    for i in sorted({0, n_queries // 2, n_queries - 1}):
+        ws, wc = oracle.maxsim_topk(E, off, Qb[i], k, np.float32)
+        assert np.array_equal(bc[i], wc), (i, bc[i][:8], wc[:8])
+        assert np.array_equal(bs[i], ws)
+    with _env(RAGLITE_NO_HI_MAXSIM="1"):  # the eight-query two-product passes this replaces: the same bits on integer data
+        s2, c2 = idx.maxsim_topk_batch(Qb, k)
+    assert np.array_equal(bc, c2) and np.array_equal(bs, s2)
+    idx.close()
+
+
+def test_f16_stored_batch_float_data_bound_append_and_approx_scores():
+    torch = _torch()
+    n, nq, n_queries, k = 72_000, 32, 16, 100
+    rng = np.random.default_rng(9)
+    off = ragged_offsets(rng, n, 1, 15)
+    E = torch.nn.functional.normalize(_corpus(torch, n, DIM, seed=91), dim=1).half()  # unit-norm rows rounded to fp16: what RAGLite stores
+    Q = torch.nn.functional.normalize(_queries(torch, n_queries, nq, DIM, seed=92), dim=2)
+    cut = len(off) // 2
+    idx = raglite_amd.DeviceIndex(E[: int(off[cut])].clone(), off[: cut + 1], metric="dot", storage="f16")
+    idx.append(E[int(off[cut]) :].float(), np.diff(off[cut:]))  # (the row-norm maximum follows the index)
+    s, c = idx.maxsim_topk_batch(Q, k)
+    st = idx.filter_stats()
+    assert st["kind"] == "maxsim_batch_hi" and not st["fallback"] and k <= st["candidates_per_query_max"] < 1500
+    # every score against float64 over the STORED values, the chunk sets tie-aware
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "scripts"))
+    import bench_configs
+
+    ref = bench_configs.maxsim_scores_f64(E.float(), off, Q)
+    ref_top = ref.topk(k, dim=1)
+    assert float((s.double() - ref_top.values).abs().max()) <= 2e-6 * float(ref_top.values.abs().max())
+    kth = ref_top.values[:, -1:]
+    got_ref = torch.gather(ref, 1, c.to(torch.int64))
+    assert bool((got_ref >= kth - 1e-6).all())
+    # the approximate scores stay inside the bound for EVERY chunk
+    a, m = idx.maxsim_approx_scores(Q, kernel=0)
+    err = (a.double() - ref).abs().max(dim=1).values
+    assert bool((err <= m.double()).all()) and bool((m > 0).all())
+    with _env(RAGLITE_NO_HI_MAXSIM="1"):
+        s2, c2 = idx.maxsim_topk_batch(Q, k)
+    assert torch.equal(c.to(torch.int64), c2.to(torch.int64))
+    assert float((s - s2).abs().max()) <= 2e-6 * float(s.abs().max())
+    idx.close()
