@@ -261,6 +261,7 @@ struct rl_index {
     // rl_rank_cut_*: the staged rank cut of a SHARDED corpus keeps its queries and scores here between the calls
     int32_t rank_B = 0;                   // queries of the running rl_rank_cut_begin (0: none)
     int32_t mb_B = 0, mb_nq = 0, mb_k = 0;  // rl_maxsim_batch_begin in progress: queries, vectors per query, k (0: none)
+    uint64_t scratch_epoch = 0, mb_epoch = 0;  // calls that used the scratch so far; the value right after that rl_maxsim_batch_begin
     rl::Pool rank_q;                      // their device copy (the l2 re-scoring of rl_rank_cut_finish needs them)
     struct FilterRecord { int kind = 0; int32_t n = 0, cap = 0; const uint32_t* cnt = nullptr; const uint32_t* flag = nullptr; } filt;
 };
@@ -269,6 +270,7 @@ namespace {
 // Called (under idx->mu) by every entry point that uses the index' shared scratch: a call on another stream than the
 // previous one waits for the previous stream's work on this handle (host-side; the rare case).
 int use_scratch(rl_index* idx, hipStream_t s) {
+    ++idx->scratch_epoch;  // (staged calls check that nothing else used the scratch between their stages)
     if (idx->last_stream_set && idx->last_stream != s) RL_HIP(hipStreamSynchronize(idx->last_stream));
     idx->last_stream = s;
     idx->last_stream_set = true;
@@ -2050,6 +2052,7 @@ int rl_maxsim_batch_begin(rl_index* idx, const float* query_vecs, int32_t n_quer
     idx->mb_B = n_queries;
     idx->mb_nq = nq;
     idx->mb_k = k;
+    idx->mb_epoch = idx->scratch_epoch;
     RL_TRY(stage_out_end(out_approx, (size_t)n_queries * (k + 1), mem, s, t_o));
     return finish(mem, s);
 }
@@ -2063,6 +2066,10 @@ int rl_maxsim_batch_finish(rl_index* idx, const float* query_vecs, const float* 
     std::lock_guard<std::mutex> lock(idx->mu);
     RL_TRY(use_scratch(idx, s));
     if (idx->mb_B < 1) return fail(RL_ERR_INVALID, "rl_maxsim_batch_finish: no rl_maxsim_batch_begin in progress on this index");
+    if (idx->scratch_epoch != idx->mb_epoch + 1) {  // (this call's own use_scratch is the + 1)
+        idx->mb_B = 0;
+        return fail(RL_ERR_INVALID, "rl_maxsim_batch_finish: another call used this index since rl_maxsim_batch_begin (its approximate scores are gone)");
+    }
     const int32_t n_queries = idx->mb_B, nq = idx->mb_nq, k = idx->mb_k;
     idx->mb_B = 0;
     DevBuf t_q, t_a, t_s, t_c;

@@ -246,6 +246,15 @@ def test_batch_begin_refuses_what_the_pipeline_does_not_cover():
         big.maxsim_batch_begin(_queries(torch, 2, 4, 1024, seed=8), 10)  # two queries: the pair kernel's business
     with pytest.raises(ValueError):
         big.maxsim_batch_finish(_queries(torch, 8, 4, 1024, seed=8), torch.zeros((2, 8, 11), device="cuda"), 0, 10)  # no begin in progress
+    q8 = _queries(torch, 8, 4, 1024, seed=8)
+    a = big.maxsim_batch_begin(q8, 10)
+    big.search_rows(q8[:, 0, :].contiguous(), 5)  # another call on the index: the approximate scores of the batch are gone
+    with pytest.raises(ValueError, match="another call"):
+        big.maxsim_batch_finish(q8, torch.stack([a, a]), 0, 10)
+    a = big.maxsim_batch_begin(q8, 10)
+    s1, c1 = big.maxsim_batch_finish(q8, a[None], 0, 10)  # a world of one: the plain batch
+    s0, c0 = big.maxsim_topk_batch(q8, 10)
+    assert torch.equal(c0.to(torch.int64), c1.to(torch.int64)) and torch.equal(s0, s1)
     small.close()
     big.close()
 
