@@ -195,12 +195,23 @@ def _worker(rank, world, port, out_q):
         Q5 = np.stack([np.roll(Q, i, axis=0) * (1 + i % 2) for i in range(5)]).astype(np.float32)
         g_ms = sh.maxsim_topk_batch(Q5, 10)
         assert local.begin_calls == 1 and 0 < local.finish_candidates < 5 * (len(local_off) - 1) // 2  # (staged, and selective)
+        # ... and when ONE shard cannot take part (an index without the image of the hi halves: RL_ERR_UNSUPPORTED from _begin) it hands
+        # in an empty list and answers with its exact local top-k; the exchange stays a collective, the result the single index's
+        if rank == 1:
+            from raglite_amd._abi import UnsupportedError
+
+            def refuse(Qb, k):
+                raise UnsupportedError("rl_maxsim_batch_begin: this index keeps no image for the approximate pass")
+
+            local.maxsim_batch_begin = refuse
+        h_ms = sh.maxsim_topk_batch(Q5, 10)
+        assert local.begin_calls == (2 if rank == 0 else 1)
         # the order-first branch: a GLOBAL cut to the 150 nearest of the 400 rows (integer data: dozens of ties ON the threshold,
         # split between the shards), then the filter, then top-25 / the two-stage search
         k_rows = sh.search_rows(Q, 25, chunk_filter=ok, rank_limit=150)
         k_ch = sh.search_chunks(Q, 40, 6, chunk_filter=ok, rank_limit=150)
         k_all = sh.search_rows(Q, 25, chunk_filter=ok, rank_limit=4000)  # a limit above the corpus: no cut
-        out_q.put((rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch, b_ms, k_rows, k_ch, k_all, g_ms))
+        out_q.put((rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch, b_ms, k_rows, k_ch, k_all, g_ms, h_ms))
     finally:
         dist.destroy_process_group()
 
@@ -227,7 +238,8 @@ def test_two_rank_gloo_matches_single_shard():
     E, off, Q = _corpus()
     r2c = np.repeat(np.arange(len(off) - 1), np.diff(off))
     ok = _chunk_mask(len(off) - 1)
-    for rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch, b_ms, k_rows, k_ch, k_all, g_ms in results:
+    for rank, s_rows, i_rows, s_ms, c_ms, s_ch, c_ch, n_ch, f_rows, f_ms, f_ch, b_ms, k_rows, k_ch, k_all, g_ms, h_ms in results:
+        assert np.array_equal(h_ms[1], g_ms[1]) and np.array_equal(h_ms[0], g_ms[0])  # (one shard without the staged calls: same answer)
         for j in range(5):  # one threshold for all shards == the single index
             Qj = (np.roll(Q, j, axis=0) * (1 + j % 2)).astype(np.float32)
             ms, mc = oracle.maxsim_topk(E, off, Qj, 10)
