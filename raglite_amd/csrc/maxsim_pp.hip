@@ -8,45 +8,42 @@
 // call src/raglite/_search.py:394-396; what it drops (the corpus' and the queries' lo halves) is bounded rigorously by the caller,
 // which re-scores every chunk the bound cannot rule out with exact fp32 products (maxsim_pairs_kernel).
 //
-// Why a new kernel next to maxsim_gemm_kernel<.., HALF>.  Measured in round 3 (profiles/r03_a_*): that kernel's one-product pass
-// takes 0.71 ms per eight queries where its 32 MFMAs per wave and slab are 0.26 ms of matrix pipe; a six-slot ring with the query
-// fragments three slabs ahead (its HO variant) gets 0.65 -- the corpus stream was not what it waited for.  A wave there reads its
-// corpus fragments from LDS ONE pair of blocks ahead: with three products a pair covers 12 MFMAs (~400 cycles for the two waves of
-// a SIMD), with one product 4 (~130), less than an LDS round trip under load -- the matrix pipe idles on lgkmcnt in every pair of
-// every slab.  And at eight queries per pass the pass needs 2 GB / 0.3 ms = 6.7 TB/s of HBM once the matrix pipe is fed.  So:
+// Why a kernel of its own next to maxsim_gemm_kernel<.., HALF>.  Measured at the start of round 3 (profiles/r03_a_*): that kernel's
+// one-product pass takes 0.71 ms per eight queries where its 32 MFMAs per wave and slab are 0.26 ms of matrix pipe; a six-slot ring with
+// the query fragments three slabs ahead gets 0.65 -- the corpus stream was not what it waited for.  A wave there reads its corpus
+// fragments from LDS ONE pair of blocks ahead: with one product that covers 4 MFMAs (~130 cycles for the two waves of a SIMD), less than
+// an LDS round trip under load.  Here (DESIGN.md 4.1e has the measurements behind every point):
 //   * tile = 128 corpus rows x 512 query vectors (16 queries), K slabs of 32; wave w owns queries 2w and 2w + 1: the same 128
-//     accumulator registers (2 queries x 2 blocks of 16 vectors x 8 blocks of 16 rows), half the corpus bytes per query -- HBM
-//     3.3 TB/s at full matrix rate -- and 12 fragment reads per 32 MFMAs instead of 18;
+//     accumulator registers (2 queries x 2 blocks of 16 vectors x 8 blocks of 16 rows), half the corpus bytes per query, 12 fragment
+//     reads per 32 MFMAs instead of 18.  The CORPUS block is the A operand of v_mfma_f32_16x16x32_f16: lane (g, n) of accumulator
+//     register u holds row 4 g + u of the block, query vector n of the register's set;
 //   * EVERY operand goes through LDS by `global_load_lds_dwordx4`: corpus slabs (8 KiB, `nt`) in a ring of 4, query slabs (the 16
-//     queries' hi fragments, 32 KiB, L2-resident) in a ring of 3 -- no VMEM result is ever waited for in registers.  Waves 0-3 (one
-//     per SIMD) feed both rings -- per slab 8 query pieces of slab g + 3, then 2 corpus pieces of slab g + 4 -- and waves 4-7 only
-//     multiply: a VMEM instruction blocks its wave until the address path takes it (~35 cycles per KiB with every CU streaming: the
-//     L2 -> CU path delivers ~18 TB/s chip-wide, scripts/micro/l2_dma_rate.hip), and a blocked wave issues no MFMAs; with one feeder
-//     per SIMD its partner keeps the matrix pipe busy meanwhile (every wave feeding: 1.31 ms per pass against 1.155);
-//   * a wave's fragments of slab g + 1 are read from LDS WHILE it multiplies slab g from registers -- each corpus fragment
-//     register is re-loaded right after its four MFMAs, the query fragments alternate between two register sets -- i.e. a full
-//     slab (32 MFMAs, >= 512 cycles) ahead: the MFMA stream never waits for LDS;
-//   * ONE workgroup barrier per slab, HALF-WAY through it: it certifies slab g + 1 as landed (every feeder waited for its pieces)
-//     and slab g's LDS slot as free (everybody read it during slab g - 1); the four MFMA groups in front of it depend on nobody, so
-//     a late feeder or a slow wave costs matrix-pipe time only when it is later than that;
-//   * tile epilogue through an LDS TRANSPOSE: the C / D layout of the MFMA puts the 16 rows of a block along a DPP row, so a per-chunk
-//     maximum there is a segmented scan over lanes -- 10 dependent VALU operations per accumulator register, 2 200 straight-line
-//     instructions per wave and tile, a third of the pass (profiles/r03_k: without its epilogue the pass took half the time).  Here a
-//     wave writes a block's 16 x 64 scores (both its queries) into 4 KiB of its own LDS and reads them back with lane = query vector,
-//     register = row: the scan is ONE running `v_max` per row restarted after every chunk end (a select on a scalar condition), the open
-//     chunk simply stays in the register across blocks and tiles; the rows' running values go back through the staging area to lanes
-//     (row, query, half of the vectors), which add their 16 values and swap halves: one masked store per block for all its chunks.
-//     Its stores share the in-order VMEM counter with the DMAs: the feeders count them (wave-uniform) and widen their next waits by
+//     queries' hi fragments, 32 KiB, L2-resident) in a ring of 4 -- 160 KiB, all of a CU's LDS; no VMEM result is ever waited for in
+//     registers.  Waves 0-3 (one per SIMD) feed both rings -- per slab 8 query pieces and 2 corpus pieces of slab g + 4 -- and waves 4-7
+//     only multiply: a VMEM instruction holds its wave's issue until the address path takes it (the L2 -> CU path delivers ~18 TB/s
+//     chip-wide, scripts/micro/l2_dma_rate.hip), and a wave that is held issues no MFMAs; with one feeder per SIMD its partner keeps
+//     the matrix pipe busy meanwhile (every wave feeding: 1.12 ms per pass against 1.00);
+//   * a wave's fragments of slab g + 1 are read from LDS WHILE it multiplies slab g from registers -- each corpus fragment register is
+//     re-loaded right after its four MFMAs, the query fragments alternate between two register sets -- through inline asm, waited for by
+//     COUNT (LDS reads return in order: lgkmcnt(4) at the top of a slab, lgkmcnt(8) before the barrier);
+//   * ONE workgroup barrier per slab, HALF-WAY through it: the feeders' `vmcnt(10)` (VMEM retires in order) and the barrier certify
+//     slab g + 2 as landed and slab g's LDS slots as free; the four MFMA groups in front of it depend on nobody;
+//   * waves 4-7 issue every fragment read one MFMA group later than their SIMD partners (LAG), so one wave's LDS / DMA instructions sit
+//     beside the partner's MFMAs instead of beside the partner's own (- 5 %);
+//   * tile epilogue in REGISTERS (third version; the comment in front of it has the steps): permlane transposes put all 16 rows of a
+//     query vector in one lane, the per-chunk maximum is a running v_max down 16 registers with EXEC = 0 where a chunk ended, the sums over
+//     the 32 vectors are a bank-masked DPP reduction that halves the register count per step: ~93 VALU instructions per block, no LDS.
+//     Its stores share the in-order VMEM counter with the DMAs: the feeders count them (wave-uniform) and widen their next two waits by
 //     exactly that many.
-// Tried on top of this and removed (profiles/r03_j, r03_k; commit 'maxsim_pp2_kernel ... for the record'): eight queries per pass
-// over TWO row streams per workgroup (32 KiB per slab instead of 40) with the two waves of a SIMD in alternating phases (one multiplies,
-// its partner loads and feeds).  Correct -- bit-identical -- and without its epilogue it sits on the operand stream with the MFMAs
-// hidden (0.36 ms per eight queries); but the tile epilogue (2 200 straight-line VALU / SALU instructions per wave, ~10 cycles each
-// when a wave runs alone on its SIMD) then runs once per GROUP, back to back: 0.72 ms per eight queries against 0.58 here.  The
-// epilogue, not the main loop, is what the next version has to make cheaper.
+// Measured (1 M x 1024, 16 x 32 vectors): 0.91-0.97 ms per pass = 0.43-0.46 of the dense fp16 peak; MFMAs alone 0.50, + fragment reads
+// 0.65-0.68, + DMAs 0.88-0.94, + epilogue 0.91-1.0: the costs add.  The operand stream (40 KiB per slab and CU, 10.2 GB per launch over
+// an 18 TB/s path) is as close a bound as the matrix pipe.  Tried and removed: strictly alternating compute / load segments for the two
+// waves of a SIMD (on this tile and, as maxsim_pp2_kernel, on two row streams), every wave feeding, DMAs spread over the whole slab,
+// static wave priorities, the LDS-transposed and the DPP-scan epilogues.
 // Deterministic (fixed MFMA order per (query vector, row), fixed sum tree over the query vectors; independent of the grid);
 // integer-valued data is exact.  Same products and the same sums over K as maxsim_gemm_kernel's one-product pass; the 32 per-vector maxima
-// are added in another order (a tree over lanes instead of registers first): scores agree to the last bits, not bit for bit, on float data.  Needs an index without empty chunks (a chunk is found by counting chunk ends), nq <= 32, dim % 32 == 0.
+// are added in another order: scores agree to the last bits, not bit for bit, on float data.  Needs an index without empty chunks (a chunk
+// is found by counting chunk ends), nq <= 32, dim % 32 == 0, dim >= 256.
 #include <cstdio>
 #include <cstdlib>
 #include <utility>
