@@ -236,7 +236,7 @@ struct rl_index {
     rl::Pool cand;                        // rl_maxsim_rerank: sanitised candidate ordinals
     rl::Pool fused;                       // fused batched top-k: sample scores, thresholds, candidate lists, counters
     rl::Pool rankbuf;                     // rank cut (order-first-then-filter): histogram levels + tie counts
-    // HI plane (round 2): fp16(e * split_scale) rounded toward zero, row-major [n_rows x dim] -- the hi halves of the fp16
+    // HI plane (round 2): fp16(e * split_scale) rounded to nearest (toward zero until round 3), row-major [n_rows x dim] -- the hi halves of the fp16
     // split as a matrix of their own, 2 B per element: what the single-query search streams (search_rows_hi).
     rl::Pool hiplane, hibuf;
     float hi_scale = 0.f;                 // the scale the plane was built with; 0 = no plane
@@ -1350,7 +1350,7 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
 // and the hi halves of the fp16 split carry 11 of every element's 24 significand bits in 2 B.
 //   (1) the f16 stream kernel over the HI plane -> approximate dots (query in full hi + lo precision), the metric, their exact
 //       top-k;
-//   (2) |approximate - exact| <= m for every row, rigorously: the dropped lo half is < 2^-10 of its element (truncation), so
+//   (2) |approximate - exact| <= m for every row, rigorously: the dropped lo half is at most 2^-11 of its element (nearest), so
 //       the dot product moves by <= 2^-10 |e| |q| (Cauchy-Schwarz) -- m = 2^-10 for a cosine, 2^-10 sqrt(dim) max|e| |q| for a
 //       dot product, plus 2^-11 for the fp32 roundings of both passes.  A row can belong to the exact top-k only if its
 //       approximate score reaches (k-th best approximate) - 2 m: one more pass over the 4 B per row of approximate scores
