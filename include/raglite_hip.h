@@ -122,7 +122,7 @@ int rl_index_info(const rl_index* index, int64_t* n_rows, int32_t* dim, int64_t*
  * out[2] the image of the hi halves, out[3] the row-major HI plane, out[4] the per-call scratch grown so far, out[5] / out[6] free /
  * total device memory now, out[7] the headroom an image has to leave free to be built.  The three images are optional accelerators
  * (4 + 2 + 2 bytes per element next to the 4 of an fp32 corpus): each is built only while it leaves max(2 GiB, 1/16 of the device) --
- * RAGLITE_IMAGE_HEADROOM_MB overrides -- free for the scratch and the caller; without them the same calls run through the kernels over
+ * RL_OPT_IMAGE_HEADROOM_MB overrides -- free for the scratch and the caller; without them the same calls run through the kernels over
  * the stored rows (same results: every image path is bit-identical to, or re-scored exactly against, the rows). */
 int rl_index_memory(const rl_index* index, int64_t out[8]);
 
@@ -160,14 +160,57 @@ int rl_index_compact(rl_index* index, int64_t* out_remap, int64_t* new_n_rows, i
  *                        float64 is that of the fp32 chain; the kernel becomes
  *                        HBM-bound (10 % faster at 32 x 1M x 1024).
  * Default RL_ARITH_AUTO: F16_SPLIT when every element is finite and the largest elements of all non-zero rows
- * lie within a factor 2^10 of each other (any normalised corpus), FP32_EXACT otherwise; the environment variable
- * RAGLITE_EXACT_FP32=1 forces FP32_EXACT for the whole process.  The batched GEMM (>= 96 queries) follows the
+ * lie within a factor 2^10 of each other (any normalised corpus), FP32_EXACT otherwise;
+ * rl_set_default_option(RL_OPT_ARITHMETIC, RL_ARITH_FP32_EXACT) makes FP32_EXACT the start value of every index created
+ * afterwards.  The batched GEMM (>= 96 queries) follows the
  * same setting (22 -> 11 ms at 1000 x 1.25 M x 1024) and so does rl_maxsim_rerank's dim-128 MFMA kernel (718 k -> 875 k
  * queries/s at 32 x (256 x 64) x 128); the single-query VALU scan always computes in fp32.
  * rl_index_set_arithmetic: mode = RL_ARITH_AUTO | RL_ARITH_FP32_EXACT.
  * rl_index_arithmetic: what is in effect (FP32_EXACT, F16_SPLIT or F16_STORED). */
 int rl_index_set_arithmetic(rl_index* index, int mode);
 int rl_index_arithmetic(rl_index* index, int* in_effect);
+
+/* ---- options ---------------------------------------------------------------------------------------------------------------
+ * Every search below has ONE result whatever route it takes (exact top-k of exactly computed scores); the routes differ in speed
+ * and memory.  The options choose routes: they exist for A/B measurements, for tests that must force a fallback, and for deployments
+ * that want a smaller index.  NO environment variable is read by the library: an option is a property of an index, fixed when the
+ * index is created from the process-wide defaults (rl_set_default_option: affects indexes created AFTERWARDS) and changed only
+ * through rl_index_set_option -- which takes the index' mutex like every call on the handle, so a change never lands in the middle
+ * of a search.  Timing-experiment builds of the kernels (instantiations that skip work and return WRONG results) are not in this
+ * library at all: they are compiled only with -DRAGLITE_EXPERIMENTS (raglite_amd._build.build(experiments=True) ->
+ * libraglite_hip_exp.so, used by scripts/gpu_calls/ only).
+ *   key                         values (default)   what it routes
+ *   RL_OPT_HI_SEARCH            0 / 1 (1)          B <= 16 row searches rank on the fp16 HI plane + exact re-scoring (else: full pass)
+ *   RL_OPT_HI_MAXSIM            0 / 1 (1)          MaxSim batches rank on the HI image + exact re-scoring (else: full-precision passes)
+ *   RL_OPT_HI_PRODUCTS          1 / 2 (1)          fp16 MFMA products per multiply in that approximate pass
+ *   RL_OPT_PP_PASS              0 / 1 (1)          its sixteen-query kernel (maxsim_pp.hip; 0: the eight-query kernel)
+ *   RL_OPT_FUSED_TOPK           0 / 1 (1)          B >= 96 row searches keep candidate lists instead of a score matrix
+ *   RL_OPT_FUSED_HI             0 / 1 (1)          ... with both GEMM passes over the HI image at one product
+ *   RL_OPT_FUSED_PP             0 / 1 (1)          ... and the candidate pass on the sixteen-group tile of maxsim_pp.hip
+ *   RL_OPT_FUSED_TOPK_CAP       0 | 1..8192 (0)    list capacity of the fused top-k (0: built-in; tests force overflows with it)
+ *   RL_OPT_FUSED_TOPK_STRIDE    0 | >= 2 (0)       sample stride of the fused top-k (0: built-in rule)
+ *   RL_OPT_GEMM_PASS            0 / 1 (1)          MaxSim batches of >= 3 queries share passes over the pre-split image
+ *   RL_OPT_QUERY_PAIRS          0 / 1 (1)          two-query passes of the streaming kernel
+ *   RL_OPT_PLANES_GEMM          0 / 1 (1)          dense row-score GEMM over the image for B >= 96 (else: score_gemm over the rows)
+ *   RL_OPT_KEEP_IMAGE           0 / 1 (1)          keep the pre-split corpus image (4 B per element; 0 releases it)
+ *   RL_OPT_KEEP_HI              0 / 1 (1)          keep the HI plane and the HI image (2 + 2 B per element; 0 releases them)
+ *   RL_OPT_IMAGE_HEADROOM_MB    -1 | >= 0 (-1)     device memory the images must leave free (-1: max(2 GiB, 1/16 of the device))
+ *   RL_OPT_ARITHMETIC           rl_arith (AUTO)    same as rl_index_set_arithmetic
+ *   RL_OPT_EXACT_KTH_THRESHOLD  0 / 1 (1)          MaxSim batches: second, tighter candidate threshold from the EXACT scores of the
+ *                                                  approximate top-k (exact k-th - m instead of approximate k-th - 2 m)
+ * KEEP_* and IMAGE_HEADROOM_MB rebuild / release the images at once (synchronous).  Unknown key or a value outside the column above:
+ * RL_ERR_INVALID.  rl_index_get_option returns what is set (not whether a route is usable on this index: rl_index_memory and
+ * rl_index_filter_stats report that). */
+typedef enum {
+    RL_OPT_HI_SEARCH = 1, RL_OPT_HI_MAXSIM = 2, RL_OPT_HI_PRODUCTS = 3, RL_OPT_PP_PASS = 4, RL_OPT_FUSED_TOPK = 5, RL_OPT_FUSED_HI = 6,
+    RL_OPT_FUSED_PP = 7, RL_OPT_FUSED_TOPK_CAP = 8, RL_OPT_FUSED_TOPK_STRIDE = 9, RL_OPT_GEMM_PASS = 10, RL_OPT_QUERY_PAIRS = 11,
+    RL_OPT_PLANES_GEMM = 12, RL_OPT_KEEP_IMAGE = 13, RL_OPT_KEEP_HI = 14, RL_OPT_IMAGE_HEADROOM_MB = 15, RL_OPT_ARITHMETIC = 16,
+    RL_OPT_EXACT_KTH_THRESHOLD = 17, RL_OPT_COUNT_ = 18
+} rl_option;
+int rl_set_default_option(int key, int64_t value);
+int rl_get_default_option(int key, int64_t* value);
+int rl_index_set_option(rl_index* index, int key, int64_t value);
+int rl_index_get_option(rl_index* index, int key, int64_t* value);
 
 /* ---- a6 + a7: similarity + exact row top-k ----------------------------------------------------
  * Replaces the SQL at src/raglite/_search.py:69-79 (`sim = 1 - dist`, ORDER BY dist LIMIT k) with
@@ -231,15 +274,15 @@ int rl_maxsim_scores(rl_index* index, const float* query_vecs, int32_t nq, float
 /* rl_maxsim_topk_batch: `n_queries` independent queries (each nq vectors) against every chunk, then ONE batched
  * selection launch for all of them.  In RL_ARITH_F16_SPLIT arithmetic eight queries (nq <= 32) share one pass over
  * the index' pre-split corpus image (fp16 hi | lo planes written when the index is built: 4 more bytes per element
- * of device memory; RAGLITE_NO_PLANES=1 in the environment disables it), otherwise two queries or one query
+ * of device memory; RL_OPT_KEEP_IMAGE = 0 releases it), otherwise two queries or one query
  * take a pass over the fp32 / fp16 rows.  On a big fp32 index (>= 64 M elements) the passes of a batch of three or
  * more queries run over an image of the hi halves only (2 more bytes per element; ONE fp16 MFMA product per multiply
- * instead of three -- q_hi . e_hi; RAGLITE_HI_ONE_PRODUCT=0: two), SIXTEEN queries per pass (maxsim_pp.hip; dim >= 256;
- * RAGLITE_NO_PP=1 or smaller dims: eight, maxsim_gemm.hip), every chunk's score error is bounded rigorously from
+ * instead of three -- q_hi . e_hi; RL_OPT_HI_PRODUCTS = 2: two), SIXTEEN queries per pass (maxsim_pp.hip; dim >= 256;
+ * RL_OPT_PP_PASS = 0 or smaller dims: eight, maxsim_gemm.hip), every chunk's score error is bounded rigorously from
  * what the hi halves of corpus and queries drop, and the chunks that could be in the top-k are
  * re-scored with exact fp32 products: the same top-k, scores as accurate as before; where the bound does not decide
  * (thousands of near-identical chunks) the full-precision passes run instead, on the device.
- * RAGLITE_NO_HI_MAXSIM=1 / RAGLITE_NO_HI_PLANE=1 switch that off.  A big fp16-STORED index (rl_index_create_f16) takes the same
+ * RL_OPT_HI_MAXSIM = 0 / RL_OPT_KEEP_HI = 0 switch that off.  A big fp16-STORED index (rl_index_create_f16) takes the same
  * pipeline with its stored halves as that image: the approximate pass multiplies q_hi . e (what it drops, q_lo . e, is bounded the same
  * way), the candidates are re-scored over the stored rows, the two-product passes are the guarded fallback.
  *   query_vecs [n_queries x nq x dim] f32; out_scores / out_chunks [n_queries x k]. */
@@ -403,7 +446,9 @@ int rl_index_filter_stats(rl_index* index, int64_t out[6], void* stream);
  * RL_ERR_UNSUPPORTED when the index has none), 5 = the approximate eight-query MaxSim pass over the HI image
  * (as kind 3) with two MFMA products per multiply, 6 = the same pass with one,
  * 7 = the SIXTEEN-queries-per-pass kernel over the HI image, one product (maxsim_pp.hip: what rl_maxsim_topk_batch runs by default;
- * sixteen queries of nq / 16 vectors each).
+ * sixteen queries of nq / 16 vectors each), 8 = the candidate pass of the LAST rl_search_rows call of >= 96 queries on this index that
+ * went through the fused top-k over the HI image, replayed with that call's queries and thresholds (query_vecs_dev / nq are not read;
+ * RL_ERR_UNSUPPORTED when no such call ran or the index' scratch has been resized since).
  * Used so that roofline.achieved is measured with HIP
  * events on the stream the kernel runs on. */
 int rl_time_kernel(rl_index* index, int kind, const float* query_vecs_dev, int32_t nq, int32_t iters,

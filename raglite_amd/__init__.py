@@ -21,7 +21,9 @@ from raglite_amd._ops import (
     adapter_apply,
     merge_topk,
     pack_bits,
+    get_default_option,
     pool_norm,
+    set_default_option,
     set_device,
     synth_fill,
     topk,
@@ -47,6 +49,8 @@ from raglite_amd._comm import Communicator
 from raglite_amd._sharded import ShardedIndex, merge_topk_host, shard_bounds_by_chunk
 
 __all__ = [
+    "set_default_option",
+    "get_default_option",
     "partition_cost",
     "partition_similarities",
     "split_chunks",

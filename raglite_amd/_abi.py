@@ -14,13 +14,20 @@ import functools
 import os
 from pathlib import Path
 
-# RAGLITE_HIP_LIB: developer hook for same-box A/B timing of kernel variants (scripts/ab_variant.sh); unset in normal use.
+# RAGLITE_HIP_LIB: developer hook of the PYTHON loader for same-box A/B timing of kernel variants and for the experiments build
+# (libraglite_hip_exp.so, scripts/gpu_calls/); unset in normal use.  The library itself reads no environment variable.
 LIB_PATH = Path(os.environ.get("RAGLITE_HIP_LIB") or Path(__file__).resolve().parent / "_lib" / "libraglite_hip.so")
 
 RL_OK, RL_ERR_INVALID, RL_ERR_HIP, RL_ERR_UNSUPPORTED, RL_ERR_NOMEM = 0, -1, -2, -3, -4
 MEM_HOST, MEM_DEVICE = 0, 1
 METRICS = {"cosine": 0, "dot": 1, "l2": 2}
 SYNTH_KINDS = {"uniform": 0, "small_int": 1}
+# rl_option (include/raglite_hip.h "options"): route switches of an index; the library reads no environment variable
+OPTIONS = {
+    "hi_search": 1, "hi_maxsim": 2, "hi_products": 3, "pp_pass": 4, "fused_topk": 5, "fused_hi": 6, "fused_pp": 7, "fused_topk_cap": 8,
+    "fused_topk_stride": 9, "gemm_pass": 10, "query_pairs": 11, "planes_gemm": 12, "keep_image": 13, "keep_hi": 14,
+    "image_headroom_mb": 15, "arithmetic": 16, "exact_kth_threshold": 17,
+}
 
 c_void_p, c_int, c_i32, c_i64, c_u64, c_size_t = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t
 c_double, c_char_p = C.c_double, C.c_char_p
@@ -57,6 +64,10 @@ _SIGNATURES = {
     "rl_index_filter_stats": [c_void_p, C.POINTER(c_i64), c_void_p],
     "rl_index_set_arithmetic": [c_void_p, c_int],
     "rl_index_arithmetic": [c_void_p, C.POINTER(c_int)],
+    "rl_set_default_option": [c_int, c_i64],
+    "rl_get_default_option": [c_int, C.POINTER(c_i64)],
+    "rl_index_set_option": [c_void_p, c_int, c_i64],
+    "rl_index_get_option": [c_void_p, c_int, C.POINTER(c_i64)],
     "rl_search_rows_filtered": [c_void_p, c_void_p, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "rl_search_chunks_filtered": [c_void_p, c_void_p, c_i32, c_i32, c_i32, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int, c_void_p],

@@ -39,17 +39,25 @@ def _newer(target: Path, deps: list[Path]) -> bool:
     return any(d.stat().st_mtime > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
+EXP_LIB_PATH = LIB_DIR / "libraglite_hip_exp.so"
+
+
+def build(force: bool = False, verbose: bool = False, experiments: bool = False) -> Path:
+    """`experiments=True` builds a SECOND library, libraglite_hip_exp.so, with -DRAGLITE_EXPERIMENTS: the timing-skeleton / trace
+    instantiations of the kernels (some return wrong results by design) and their RAGLITE_* environment switches exist only there.
+    scripts/gpu_calls/ load it through RAGLITE_HIP_LIB; nothing else does."""
     LIB_DIR.mkdir(exist_ok=True)
-    obj_dir = LIB_DIR / "obj"
+    obj_dir = LIB_DIR / ("obj_exp" if experiments else "obj")
     obj_dir.mkdir(exist_ok=True)
+    lib_path = EXP_LIB_PATH if experiments else LIB_PATH
+    flags = FLAGS + (["-DRAGLITE_EXPERIMENTS"] if experiments else [])
     headers = [CSRC / "common.h", INCLUDE / "raglite_hip.h"]
     hipcc = _hipcc()
 
     def compile_one(src: str) -> Path:
         obj = obj_dir / (src + ".o")
         if force or _newer(obj, [CSRC / src, *headers]):
-            cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+            cmd = [hipcc, *flags, "-c", str(CSRC / src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             res = subprocess.run(cmd, capture_output=True, text=True)
@@ -59,13 +67,13 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
         objs = list(pool.map(compile_one, SOURCES))
-    if force or _newer(LIB_PATH, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(LIB_PATH)]
+    if force or _newer(lib_path, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(lib_path)]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError(f"link failed:\n{res.stderr}")
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, experiments="--experiments" in sys.argv))

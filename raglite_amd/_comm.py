@@ -54,6 +54,39 @@ class Communicator:
             raise RuntimeError(f"rank 0 could not create an RCCL unique id: {box[0]}")
         return cls(rank, world, bytes(box[0]))
 
+    @classmethod
+    def agreed(cls, group: Any = None, *, _probe=None):
+        """(Communicator, None) on EVERY rank of the group, or (None, this rank's error or None) on every rank: the ranks agree -- with
+        one all-reduce over torch.distributed -- that each of them can take part BEFORE the collective `rl_comm_init` is entered (a rank
+        that cannot load librccl would otherwise leave the others waiting inside it), and once more that it succeeded everywhere.  What
+        `bench.py --gpus N` and any multi-rank caller use, so that all ranks take the same exchange path."""
+        import torch
+        import torch.distributed as dist
+
+        def all_ok(flag: bool) -> bool:
+            dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return bool(int(t.item()))
+
+        err = None
+        try:  # rank-local precondition: librccl loads and hands out an id (no collective involved)
+            (_probe or cls.unique_id)()
+        except Exception as exc:  # noqa: BLE001
+            err = exc
+        if not all_ok(err is None):
+            return None, err
+        comm = None
+        try:
+            comm = cls.from_torch_distributed(group)
+        except Exception as exc:  # noqa: BLE001
+            err = exc
+        if not all_ok(comm is not None):
+            if comm is not None:
+                comm.close()
+            return None, err
+        return comm, None
+
     def close(self) -> None:
         if self._handle is not None:
             check(lib().rl_comm_destroy(self._handle))

@@ -101,6 +101,17 @@ def set_device(device: int) -> None:
 
 
 # ----------------------------------------------------------------------------------------------
+def set_default_option(name: str, value: int) -> None:
+    """`rl_set_default_option`: the start value of a route option for every index created AFTERWARDS in this process."""
+    check(lib().rl_set_default_option(_abi.OPTIONS[name], int(value)))
+
+
+def get_default_option(name: str) -> int:
+    v = C.c_int64(0)
+    check(lib().rl_get_default_option(_abi.OPTIONS[name], C.byref(v)))
+    return int(v.value)
+
+
 def synth_fill(out, seed: int, start: int = 0, kind: str = "uniform"):
     """Fill a float32 CUDA tensor with the counter-based synthetic stream (oracle-identical bits)."""
     a = _Args()
@@ -339,6 +350,33 @@ class DeviceIndex:
             self.n_rows, self.n_chunks = int(n_rows.value), int(n_chunks.value)
             self._keep = None  # the index owns its (rewritten) storage
         return remap
+
+    def set_option(self, name: str, value: int) -> None:
+        """`rl_index_set_option`: choose a route of this index (`_abi.OPTIONS` names the keys; include/raglite_hip.h "options" says what
+        each one does).  Results never depend on an option; speed and memory do."""
+        check(lib().rl_index_set_option(self._handle, _abi.OPTIONS[name], int(value)))
+
+    def get_option(self, name: str) -> int:
+        v = C.c_int64(0)
+        check(lib().rl_index_get_option(self._handle, _abi.OPTIONS[name], C.byref(v)))
+        return int(v.value)
+
+    def options(self, **kv: int):
+        """Context manager: set the options, run the block, restore the previous values (what the A/B tests use)."""
+        index = self
+
+        class _Ctx:
+            def __enter__(self):
+                self.old = {k: index.get_option(k) for k in kv}
+                for k, v in kv.items():
+                    index.set_option(k, v)
+                return index
+
+            def __exit__(self, *exc):
+                for k, v in self.old.items():
+                    index.set_option(k, v)
+
+        return _Ctx()
 
     def set_exact_fp32(self, exact: bool = True) -> None:
         """Make the MFMA streaming kernel use exact fp32 MFMAs (an ordered fmaf chain) instead of the default fp16

@@ -162,7 +162,12 @@ class ShardedIndex:
     comm                  a `raglite_amd.Communicator`: the exchange goes through the C ABI / librccl instead
     """
 
-    def __init__(self, local: Any, *, row_base: int, chunk_base: int, local_chunk_offsets=None, group=None, comm=None) -> None:
+    def __init__(self, local: Any, *, row_base: int, chunk_base: int, local_chunk_offsets=None, group=None, comm=None,
+                 check_failures: bool = False) -> None:
+        """check_failures: device-path MaxSim batches read back one flag per call to learn that ANOTHER rank failed in its local step (a
+        host synchronisation per call; host-array calls check for free).  Without it a failing rank still takes part in every collective
+        of the call with empty lists -- nobody hangs -- and raises afterwards; the other ranks return a merge without that shard."""
+        self.check_failures = bool(check_failures)
         self.local = local
         self.row_base = int(row_base)
         self.chunk_base = int(chunk_base)
@@ -197,6 +202,24 @@ class ShardedIndex:
             dist.all_gather(parts, t, group=self.group)
             out = torch.stack(parts)
         return out.cpu().numpy()
+
+    def _allgather_host(self, x: np.ndarray) -> np.ndarray:
+        """int32 host array (same shape on every rank) -> (world, *shape) through WHATEVER transport this index has: torch.distributed
+        when it is initialised, else the attached Communicator (librccl through the C ABI, staged through a device tensor), else -- one
+        rank -- the array itself.  Several ranks and no transport for host arrays is an error, not a silent "world of one"."""
+        x = np.ascontiguousarray(x, dtype=np.int32)
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized():
+            return self._all_gather(x)
+        if self.comm is not None and self.comm.world > 1:
+            import torch
+
+            t = torch.from_numpy(x).cuda()
+            return self.comm.allgather(t).cpu().numpy()
+        if self._world() > 1:
+            raise RuntimeError("ShardedIndex: several ranks but neither torch.distributed nor a Communicator can exchange host arrays")
+        return x[None]
 
     @staticmethod
     def _pack(*cols: np.ndarray) -> np.ndarray:
@@ -295,7 +318,7 @@ class ShardedIndex:
             x = x.contiguous()
             dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
             return x
-        return self._all_gather(np.ascontiguousarray(x, dtype=np.int32)).astype(np.int64).sum(axis=0).astype(np.int32)
+        return self._allgather_host(x).astype(np.int64).sum(axis=0).astype(np.int32)
 
     def _allgather_int(self, x):
         """(world, *x.shape)."""
@@ -303,7 +326,7 @@ class ShardedIndex:
             if self.comm is not None:
                 return self.comm.allgather(x)
             return x[None] if self._world() == 1 else _all_gather_stacked(x, self.group)
-        return self._all_gather(np.ascontiguousarray(x, dtype=np.int32))
+        return self._allgather_host(x)
 
     def _rank(self) -> int:
         if self.comm is not None:
@@ -321,11 +344,29 @@ class ShardedIndex:
         local_filter = self._local_filter(chunk_filter)
         if not rank_limit or self._world() == 1 or not hasattr(self.local, "rank_cut_begin"):
             return self.local.search_rows(queries, k, **self._kw(local_filter, rank_limit))
-        n_local = np.asarray([int(self.local.n_rows)], dtype=np.int32)
-        n_total = int(np.asarray(self._all_gather(n_local)).astype(np.int64).sum())
+        # every rank's row count, through the transport this index really has (with a Communicator and no torch.distributed the torch
+        # transport would report a world of one: the cut would be decided per rank, and the ranks would take different branches)
+        counts = self._allgather_host(np.asarray([int(self.local.n_rows)], dtype=np.int32)).astype(np.int64).reshape(-1)
+        n_total, n_max = int(counts.sum()), int(counts.max())
         if int(rank_limit) >= n_total:  # no cut at all: the filter-first search
             return self.local.search_rows(queries, k, **self._kw(local_filter, None))
         single = getattr(queries, "ndim", 2) == 1
+        # `rl_rank_cut_begin` scores the whole batch into one [B x n_local] matrix (<= 8 GB).  The sub-batch size is derived from the
+        # LARGEST shard, so that every rank makes the same split and enters the same collectives the same number of times.
+        B = 1 if single else int(queries.shape[0])
+        per = max(1, int(self.rank_cut_scratch_bytes // (4 * max(n_max, 1) + 64)))
+        if B <= per:
+            s, r = self._rank_cut_batch(queries, k, local_filter, rank_limit)
+            return (s[0], r[0]) if single else (s, r)
+        outs = [self._rank_cut_batch(queries[b0 : b0 + per], k, local_filter, rank_limit) for b0 in range(0, B, per)]
+        if _is_cuda(outs[0][0]):
+            import torch
+
+            return torch.cat([o[0] for o in outs]), torch.cat([o[1] for o in outs])
+        return np.concatenate([_to_numpy(o[0]) for o in outs]), np.concatenate([_to_numpy(o[1]) for o in outs])
+
+    def _rank_cut_batch(self, queries, k: int, local_filter, rank_limit):
+        """One (sub-)batch through the staged global rank cut; (scores (B, k), local rows (B, k))."""
         self.local.rank_cut_begin(queries)
         for level in range(3):
             self.local.rank_cut_level_done(level, self._allreduce_sum_int(self.local.rank_cut_level(level, rank_limit)))
@@ -338,8 +379,7 @@ class ShardedIndex:
             before = before.to(torch.int32)
         else:
             before = np.asarray(before, dtype=np.int32)
-        s, r = self.local.rank_cut_finish(rank_limit, before, k, chunk_filter=local_filter)
-        return (s[0], r[0]) if single else (s, r)
+        return self.local.rank_cut_finish(rank_limit, before, k, chunk_filter=local_filter)
 
     def search_rows(self, queries, k: int, chunk_filter=None, rank_limit: int | None = None):
         """Global exact top-k rows: (scores (B,k), global row ordinals (B,k)).  chunk_filter: bool mask over the GLOBAL chunk
@@ -369,15 +409,27 @@ class ShardedIndex:
         """A batch of queries (QB, nq, dim): the local batched search, ONE all-gather of (QB, k, 2) int32, one merge
         (on the device without any host synchronisation when the queries are CUDA tensors, else on the host).
         Returns (scores (QB,k), global chunk ordinals (QB,k))."""
+        self._deferred_error = None
         if hasattr(self.local, "maxsim_topk_batch"):
             s, c = self._local_maxsim_batch(query_batch, k)
             if _is_cuda(s):  # device-resident queries: results stay on the device
-                return self._exchange_merge_device(s, c, self.chunk_base, k)
+                out = self._exchange_merge_device(s, c, self.chunk_base, k)
+                self._raise_deferred()
+                return out
         else:
             outs = [self.local.maxsim_topk(query_batch[b], k) for b in range(len(query_batch))]
             s, c = np.stack([_to_numpy(o[0]) for o in outs]), np.stack([_to_numpy(o[1]) for o in outs])
         gs, gi, _, _ = self._exchange_host(s, c, self.chunk_base)
+        self._raise_deferred()
         return merge_topk_host(gs, gi, k)
+
+    _deferred_error = None
+    rank_cut_scratch_bytes = 8 << 30  # what rl_rank_cut_begin accepts for its [B x n_local] score matrix
+
+    def _raise_deferred(self) -> None:
+        err, self._deferred_error = self._deferred_error, None
+        if err is not None:
+            raise err
 
     def _local_maxsim_batch(self, query_batch, k: int):
         """This shard's part of a MaxSim batch.  Over several shards the bound-filtered pipeline takes ONE candidate threshold for all of
@@ -400,24 +452,39 @@ class ShardedIndex:
         from ._abi import UnsupportedError
 
         B = int(query_batch.shape[0])
+        failed = None  # an exception that is NOT "this index cannot take part": this rank still enters every collective, then raises
         try:
             approx = self.local.maxsim_batch_begin(query_batch, k)
             staged = True
-        except UnsupportedError:
+        except Exception as exc:  # noqa: BLE001 - whatever it is, the other ranks are already waiting in the all-gather
             staged = False
+            if not isinstance(exc, UnsupportedError):
+                failed = exc
             if _is_cuda(query_batch):
                 import torch
 
                 approx = torch.full((B, int(k) + 1), float("-inf"), dtype=torch.float32, device=query_batch.device)
             else:
                 approx = np.full((B, int(k) + 1), -np.inf, dtype=np.float32)
-            approx[:, int(k)] = 0.0
+            approx[:, int(k)] = float("nan") if failed is not None else 0.0  # (a NaN bound marks the failure; fmaxf ignores it on the device)
         if _is_cuda(approx):
             import torch
 
             all_approx = self._allgather_int(approx.contiguous().view(torch.int32)).view(torch.float32)
+            someone_failed = bool(torch.isnan(all_approx[:, :, int(k)]).any().item()) if self.check_failures else False
         else:
             all_approx = np.ascontiguousarray(self._allgather_int(np.ascontiguousarray(approx, dtype=np.float32).view(np.int32))).view(np.float32)
+            someone_failed = bool(np.isnan(all_approx[:, :, int(k)]).any())
+        if failed is not None:  # empty lists into the merge that follows (nobody hangs), the error once it is through
+            self._deferred_error = failed
+            if _is_cuda(query_batch):
+                import torch
+
+                return (torch.full((B, int(k)), float("-inf"), dtype=torch.float32, device=query_batch.device),
+                        torch.full((B, int(k)), -1, dtype=torch.int32, device=query_batch.device))
+            return np.full((B, int(k)), -np.inf, dtype=np.float32), np.full((B, int(k)), -1, dtype=np.int32)
+        if someone_failed:
+            self._deferred_error = RuntimeError("ShardedIndex.maxsim_topk_batch: another rank failed in its local step; this merge lacks its shard")
         if not staged:
             return self.local.maxsim_topk_batch(query_batch, k)
         return self.local.maxsim_batch_finish(query_batch, all_approx, self._rank(), k)

@@ -192,6 +192,37 @@ int scan_mode(int metric) {
 
 constexpr size_t SCORE_BATCH_BYTES = size_t(8) << 30;  // cap of the [B x N] score scratch per sub-batch
 
+// Route options (raglite_hip.h "options"): per index, copied from the process-wide defaults when the index is created.  The library
+// reads no environment variable.
+struct Options {
+    int64_t v[RL_OPT_COUNT_];
+    Options() {
+        for (auto& x : v) x = 0;
+        v[RL_OPT_HI_SEARCH] = v[RL_OPT_HI_MAXSIM] = v[RL_OPT_HI_PRODUCTS] = v[RL_OPT_PP_PASS] = v[RL_OPT_FUSED_TOPK] = v[RL_OPT_FUSED_HI] = 1;
+        v[RL_OPT_FUSED_PP] = v[RL_OPT_GEMM_PASS] = v[RL_OPT_QUERY_PAIRS] = v[RL_OPT_PLANES_GEMM] = v[RL_OPT_KEEP_IMAGE] = v[RL_OPT_KEEP_HI] = 1;
+        v[RL_OPT_EXACT_KTH_THRESHOLD] = 1;
+        v[RL_OPT_IMAGE_HEADROOM_MB] = -1;
+        v[RL_OPT_ARITHMETIC] = RL_ARITH_AUTO;
+    }
+    bool on(int key) const { return v[key] != 0; }
+};
+std::mutex g_default_opts_mu;
+Options g_default_opts;
+bool option_value_ok(int key, int64_t value) {
+    switch (key) {
+        case RL_OPT_HI_SEARCH: case RL_OPT_HI_MAXSIM: case RL_OPT_PP_PASS: case RL_OPT_FUSED_TOPK: case RL_OPT_FUSED_HI: case RL_OPT_FUSED_PP:
+        case RL_OPT_GEMM_PASS: case RL_OPT_QUERY_PAIRS: case RL_OPT_PLANES_GEMM: case RL_OPT_KEEP_IMAGE: case RL_OPT_KEEP_HI:
+        case RL_OPT_EXACT_KTH_THRESHOLD:
+            return value == 0 || value == 1;
+        case RL_OPT_HI_PRODUCTS: return value == 1 || value == 2;
+        case RL_OPT_FUSED_TOPK_CAP: return value >= 0 && value <= MERGE_CAP;
+        case RL_OPT_FUSED_TOPK_STRIDE: return value == 0 || (value >= 2 && value <= (int64_t(1) << 20));
+        case RL_OPT_IMAGE_HEADROOM_MB: return value >= -1 && value <= (int64_t(1) << 30);
+        case RL_OPT_ARITHMETIC: return value == RL_ARITH_AUTO || value == RL_ARITH_FP32_EXACT;
+        default: return false;
+    }
+}
+
 }  // namespace
 }  // namespace rl
 
@@ -235,6 +266,7 @@ struct rl_index {
     rl::Pool planes, ends, qplanes;
     rl::Pool cand;                        // rl_maxsim_rerank: sanitised candidate ordinals
     rl::Pool fused;                       // fused batched top-k: sample scores, thresholds, candidate lists, counters
+    rl::Pool pp_work;                     // ... on the sixteen-group tile: wave-private record logs, block norm ranges (maxsim_pp.hip MODE 2)
     rl::Pool rankbuf;                     // rank cut (order-first-then-filter): histogram levels + tie counts
     // HI plane (round 2): fp16(e * split_scale) rounded to nearest (toward zero until round 3), row-major [n_rows x dim] -- the hi halves of the fp16
     // split as a matrix of their own, 2 B per element: what the single-query search streams (search_rows_hi).
@@ -264,6 +296,13 @@ struct rl_index {
     uint64_t scratch_epoch = 0, mb_epoch = 0;  // calls that used the scratch so far; the value right after that rl_maxsim_batch_begin
     rl::Pool rank_q;                      // their device copy (the l2 re-scoring of rl_rank_cut_finish needs them)
     struct FilterRecord { int kind = 0; int32_t n = 0, cap = 0; const uint32_t* cnt = nullptr; const uint32_t* flag = nullptr; } filt;
+    rl::Options opt;                      // route options (rl_index_set_option)
+    // rl_time_kernel kind 8: what the candidate pass of the last fused-HI row search ran with (pointers into misc / fused / pp_work: valid
+    // while those pools have not been re-reserved, which `pools` pins down)
+    struct FusedReplay {
+        bool valid = false, pp = false; int32_t B = 0, log_cap = 0; int mode = 0; float* qs = nullptr; rl::CandArgs ca{}; uint32_t* cnt = nullptr;
+        const void* pools[3] = {nullptr, nullptr, nullptr};
+    } replay;
 };
 
 namespace {
@@ -271,6 +310,7 @@ namespace {
 // previous one waits for the previous stream's work on this handle (host-side; the rare case).
 int use_scratch(rl_index* idx, hipStream_t s) {
     ++idx->scratch_epoch;  // (staged calls check that nothing else used the scratch between their stages)
+    idx->filt = {};        // its pointers go into scratch this call may re-reserve: whoever filters next records itself again
     if (idx->last_stream_set && idx->last_stream != s) RL_HIP(hipStreamSynchronize(idx->last_stream));
     idx->last_stream = s;
     idx->last_stream_set = true;
@@ -284,9 +324,8 @@ int use_scratch(rl_index* idx, hipStream_t s) {
 // rest.  So SPLIT is used only when the largest elements of all non-zero rows lie within a factor 2^10 of each other
 // (every normalised corpus does), everything is finite, and the caller has not asked for the exact chain.
 void update_split_scale(rl_index* idx) {
-    static const bool env_exact = std::getenv("RAGLITE_EXACT_FP32") != nullptr;
     idx->split_scale = 0.f;
-    if (idx->E16 || !idx->E || env_exact || idx->arithmetic == RL_ARITH_FP32_EXACT || idx->nonfinite) return;
+    if (idx->E16 || !idx->E || idx->arithmetic == RL_ARITH_FP32_EXACT || idx->nonfinite) return;
     if (idx->dim % 4) return;
     if (idx->max_abs == 0.f) { idx->split_scale = 1.f; return; }  // all-zero (or empty) corpus: nothing to lose
     if (!(idx->max_abs / idx->min_row_max <= 1024.f)) return;      // row magnitudes spread over more than 2^10
@@ -323,20 +362,20 @@ bool image_valid(const rl_index* idx) {
 // The images are optional accelerators (pre-split image 4 B, HI image 2 B, HI plane 2 B per element next to the rows): one is only
 // built while it leaves `image_headroom()` of the device free for the per-call scratch (score batches up to 8 GB, selection workspace,
 // candidate lists) and for the caller -- an index close to the device's capacity searches through the kernels over the stored rows
-// instead of failing an allocation in the middle of a search.  RAGLITE_IMAGE_HEADROOM_MB overrides the default
+// instead of failing an allocation in the middle of a search.  RL_OPT_IMAGE_HEADROOM_MB overrides the default
 // max(2 GiB, 1/16 of the device); rl_index_memory reports what was built.
-size_t image_headroom() {
-    static const long long env = std::getenv("RAGLITE_IMAGE_HEADROOM_MB") ? std::atoll(std::getenv("RAGLITE_IMAGE_HEADROOM_MB")) : -1;
-    if (env >= 0) return (size_t)env << 20;
+size_t image_headroom(const rl_index* idx) {
+    const int64_t mb = idx->opt.v[RL_OPT_IMAGE_HEADROOM_MB];
+    if (mb >= 0) return (size_t)mb << 20;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return (size_t)2 << 30; }
     return std::max<size_t>((size_t)2 << 30, total_b / 16);
 }
-bool image_fits(const rl::Pool& pool, size_t need) {
-    if (pool.cap >= need) return true;  // already paid for
+bool image_fits(const rl_index* idx, const rl::Pool& pool, size_t need) {
+    if (pool.cap >= need) return true;  // already paid for: nothing has to grow
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return true; }
-    return free_b + pool.cap >= need + image_headroom();  // (reserve() frees the old block before it allocates)
+    return free_b + pool.cap >= need + image_headroom(idx);  // (reserve() frees the old block before it allocates)
 }
 
 // Builds / extends the corpus image so that it covers rows [0, idx->n_rows) at image_scale(idx).  Not having the image is
@@ -344,9 +383,8 @@ bool image_fits(const rl::Pool& pool, size_t need) {
 
 int refresh_row_norm16(rl_index* idx, hipStream_t s);
 int refresh_planes(rl_index* idx, hipStream_t s) {
-    static const bool no_planes = std::getenv("RAGLITE_NO_PLANES") != nullptr;  // A/B switch
     const bool half = idx->E16 != nullptr;
-    const bool want = !no_planes && (idx->E16 || idx->E) && image_scale(idx) > 0.f && idx->dim % 32 == 0 && idx->dim >= 32 &&
+    const bool want = idx->opt.on(RL_OPT_KEEP_IMAGE) && (idx->E16 || idx->E) && image_scale(idx) > 0.f && idx->dim % 32 == 0 && idx->dim >= 32 &&
                       idx->n_rows > 0;
     if (!want) {
         idx->planes.release();
@@ -359,7 +397,10 @@ int refresh_planes(rl_index* idx, hipStream_t s) {
     const size_t need = rl::planes_bytes(cap, idx->dim, half), need_e = rl::chunk_ends_words(cap) * sizeof(uint32_t);
     int64_t first = idx->planes_scale == image_scale(idx) ? (idx->planes_rows & ~int64_t(15)) : 0;
     if (idx->planes.cap < need) first = 0;  // Pool::reserve does not keep the contents
-    if (!image_fits(idx->planes, need + need_e) || idx->planes.reserve(need) != RL_OK || idx->ends.reserve(need_e) != RL_OK) {
+    // (each pool against its own need: an exactly sized image is "already paid for" and must survive an append into spare capacity
+    // however full the device has become since)
+    if (!image_fits(idx, idx->planes, need) || !image_fits(idx, idx->ends, need_e) || idx->planes.reserve(need) != RL_OK ||
+        idx->ends.reserve(need_e) != RL_OK) {
         (void)hipGetLastError();
         idx->planes.release();
         idx->ends.release();
@@ -406,7 +447,7 @@ float approx_scale(const rl_index* idx) { return idx->E16 ? 1.0f : idx->split_sc
 
 // max |e| over the rows of an fp16-stored corpus, folded in as rows arrive (synchronises the stream: build / append / compact only)
 int refresh_row_norm16(rl_index* idx, hipStream_t s) {
-    static const bool off = std::getenv("RAGLITE_NO_HI_PLANE") != nullptr;  // (the A/B switch of the half-bytes paths)
+    const bool off = !idx->opt.on(RL_OPT_KEEP_HI);  // (the switch of the half-bytes paths)
     if (!idx->E16 || off || !image_valid(idx) || (int64_t)idx->n_rows * idx->dim < (int64_t(64) << 20)) {
         if (idx->E16) { idx->max_row_norm = 0.f; idx->max_row_norm_rows = 0; }
         return RL_OK;
@@ -430,7 +471,7 @@ int refresh_row_norm16(rl_index* idx, hipStream_t s) {
 
 // The HI halves in image layout + the largest row norm (synchronises the stream: build / append / compact only).
 int refresh_hi_image(rl_index* idx, hipStream_t s) {
-    static const bool off = std::getenv("RAGLITE_NO_HI_PLANE") != nullptr;  // A/B switch (shared with the row-major plane)
+    const bool off = !idx->opt.on(RL_OPT_KEEP_HI);  // (shared with the row-major plane)
     const bool want = !off && !idx->E16 && idx->E && idx->split_scale > 0.f && idx->dim % 32 == 0 && idx->dim >= 32 && idx->dim <= 1024 &&
                       (int64_t)idx->n_rows * idx->dim >= (int64_t(64) << 20) && image_valid(idx);
     if (!want) {
@@ -443,7 +484,7 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
     const size_t need = rl::planes_bytes(cap, idx->dim, true);
     int64_t first = idx->hi_image_scale == idx->split_scale ? (idx->hi_image_rows & ~int64_t(15)) : 0;
     if (idx->hi_image.cap < need) first = 0;
-    if (!image_fits(idx->hi_image, need) || idx->hi_image.reserve(need) != RL_OK) {
+    if (!image_fits(idx, idx->hi_image, need) || idx->hi_image.reserve(need) != RL_OK) {
         (void)hipGetLastError();
         idx->hi_image.release();
         idx->hi_image_scale = 0.f;
@@ -485,7 +526,7 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
 }
 int refresh_hi_plane(rl_index* idx, hipStream_t s) {
     RL_TRY(refresh_hi_image(idx, s));
-    static const bool off = std::getenv("RAGLITE_NO_HI_PLANE") != nullptr;  // A/B switch
+    const bool off = !idx->opt.on(RL_OPT_KEEP_HI);
     const int32_t d = idx->dim;
     const bool dim_ok = d == 128 || d == 256 || d == 384 || d == 512 || d == 768 || d == 1024;
     const bool want = !off && !idx->E16 && idx->E && idx->split_scale > 0.f && dim_ok &&
@@ -500,7 +541,7 @@ int refresh_hi_plane(rl_index* idx, hipStream_t s) {
     const size_t need = (size_t)cap * d * sizeof(uint16_t);
     int64_t first = idx->hi_scale == idx->split_scale ? idx->hi_rows : 0;
     if (idx->hiplane.cap < need) first = 0;  // Pool::reserve does not keep the contents
-    if (!image_fits(idx->hiplane, need) || idx->hiplane.reserve(need) != RL_OK) {
+    if (!image_fits(idx, idx->hiplane, need) || idx->hiplane.reserve(need) != RL_OK) {
         (void)hipGetLastError();
         idx->hiplane.release();
         idx->hi_scale = 0.f;
@@ -694,6 +735,7 @@ int rl_index_destroy(rl_index* idx) {
     idx->qplanes.release();
     idx->cand.release();
     idx->fused.release();
+    idx->pp_work.release();
     idx->rankbuf.release();
     idx->hiplane.release();
     idx->hibuf.release();
@@ -738,6 +780,11 @@ static int index_create_any(rl_index** out, const void* embeddings, bool f16, in
     }
     hipStream_t s = as_stream(stream);
     rl_index* idx = new rl_index();
+    {   // route options: the process-wide defaults as they are now
+        std::lock_guard<std::mutex> lock(g_default_opts_mu);
+        idx->opt = g_default_opts;
+    }
+    idx->arithmetic = (int)idx->opt.v[RL_OPT_ARITHMETIC];
     idx->n_rows = n_rows;
     idx->dim = dim;
     idx->n_chunks = n_chunks;
@@ -850,9 +897,10 @@ int rl_index_filter_stats(rl_index* idx, int64_t out[6], void* stream) {
     if (!idx || !out) return fail(RL_ERR_INVALID, "rl_index_filter_stats: null argument");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
+    const auto f = idx->filt;  // (use_scratch forgets the record: every other call may re-reserve the pools it points into; this one does not)
     RL_TRY(use_scratch(idx, s));
+    idx->filt = f;
     for (int i = 0; i < 6; ++i) out[i] = 0;
-    const auto& f = idx->filt;
     if (f.kind == RL_FILTER_NONE || f.n <= 0) return RL_OK;
     RL_HIP(hipStreamSynchronize(s));
     std::vector<uint32_t> cnt((size_t)f.n);
@@ -970,10 +1018,52 @@ int rl_index_set_arithmetic(rl_index* idx, int mode) {
     std::lock_guard<std::mutex> lock(idx->mu);
     RL_TRY(use_scratch(idx, nullptr));
     idx->arithmetic = mode;
+    idx->opt.v[RL_OPT_ARITHMETIC] = mode;
     update_split_scale(idx);
     RL_TRY(refresh_planes(idx, nullptr));
     RL_TRY(refresh_hi_plane(idx, nullptr));
     RL_HIP(hipStreamSynchronize(nullptr));
+    return RL_OK;
+}
+
+int rl_set_default_option(int key, int64_t value) {
+    if (!option_value_ok(key, value)) return fail(RL_ERR_INVALID, "rl_set_default_option: unknown key or value out of range");
+    std::lock_guard<std::mutex> lock(g_default_opts_mu);
+    g_default_opts.v[key] = value;
+    return RL_OK;
+}
+
+int rl_get_default_option(int key, int64_t* value) {
+    if (!value || key < 1 || key >= RL_OPT_COUNT_) return fail(RL_ERR_INVALID, "rl_get_default_option: unknown key");
+    std::lock_guard<std::mutex> lock(g_default_opts_mu);
+    *value = g_default_opts.v[key];
+    return RL_OK;
+}
+
+int rl_index_set_option(rl_index* idx, int key, int64_t value) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_index_set_option: null index");
+    if (!option_value_ok(key, value)) return fail(RL_ERR_INVALID, "rl_index_set_option: unknown key or value out of range");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    if (idx->opt.v[key] == value) return RL_OK;
+    idx->opt.v[key] = value;
+    if (key == RL_OPT_KEEP_IMAGE || key == RL_OPT_KEEP_HI || key == RL_OPT_IMAGE_HEADROOM_MB || key == RL_OPT_ARITHMETIC) {
+        // what the index keeps in device memory changes: rebuild / release now (synchronous, like rl_index_set_arithmetic)
+        RL_TRY(use_scratch(idx, nullptr));
+        if (key == RL_OPT_ARITHMETIC) {
+            idx->arithmetic = (int)value;
+            update_split_scale(idx);
+        }
+        RL_TRY(refresh_planes(idx, nullptr));
+        RL_TRY(refresh_hi_plane(idx, nullptr));
+        RL_HIP(hipStreamSynchronize(nullptr));
+    }
+    return RL_OK;
+}
+
+int rl_index_get_option(rl_index* idx, int key, int64_t* value) {
+    if (!idx || !value || key < 1 || key >= RL_OPT_COUNT_) return fail(RL_ERR_INVALID, "rl_index_get_option: null argument or unknown key");
+    std::lock_guard<std::mutex> lock(idx->mu);
+    *value = idx->opt.v[key];
     return RL_OK;
 }
 
@@ -1110,12 +1200,12 @@ int rl_index_memory(const rl_index* idx, int64_t out[8]) {
     out[2] = hi_image_valid(idx) ? (int64_t)idx->hi_image.cap : 0;
     out[3] = hi_valid(idx) ? (int64_t)idx->hiplane.cap : 0;
     out[4] = (int64_t)(idx->scores.cap + idx->hits.cap + idx->misc.cap + idx->maskbuf.cap + idx->qsplit.cap + idx->qplanes.cap + idx->cand.cap +
-                       idx->fused.cap + idx->rankbuf.cap + idx->hibuf.cap + idx->ends.cap);
+                       idx->fused.cap + idx->pp_work.cap + idx->rankbuf.cap + idx->hibuf.cap + idx->ends.cap);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = total_b = 0; }
     out[5] = (int64_t)free_b;
     out[6] = (int64_t)total_b;
-    out[7] = (int64_t)image_headroom();
+    out[7] = (int64_t)image_headroom(idx);
     return RL_OK;
 }
 
@@ -1138,8 +1228,7 @@ int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStrea
     if (nb >= GEMM_MIN_QUERIES && image_valid(idx)) {
         // the row-score GEMM over the corpus image (maxsim_gemm.hip MODE 1; fp32 corpus: pre-split planes, fp16-stored corpus:
         // its one-plane image): no conversion in the loop
-        static const bool off = std::getenv("RAGLITE_NO_PLANES_GEMM") != nullptr;  // A/B switch
-        if (!off) {
+        if (idx->opt.on(RL_OPT_PLANES_GEMM)) {
             RL_TRY(idx->misc.reserve(score_planes_scratch_floats(nb, idx->dim) * sizeof(float)));
             const int st = launch_score_planes(idx->planes.p, idx->n_rows, idx->dim, d_q, nb, sc, ld, idx->norm, idx->sumsq,
                                                idx->misc.as<float>(), mode, idx->n_cu, s, image_scale(idx), idx->E16 != nullptr);
@@ -1210,11 +1299,8 @@ int effective_row_mask(rl_index* idx, const uint32_t* d_chunk_filter, hipStream_
 // nothing here synchronises with the host.  cosine / dot, k <= 512, no row mask; RL_ERR_UNSUPPORTED otherwise.
 int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, float* d_scores, int32_t* d_rows, int64_t ld,
                       hipStream_t s) {
-    // read per call (two getenv's against a multi-millisecond batch) so that a test can flip them inside one process
-    const char* off_env = std::getenv("RAGLITE_NO_FUSED_TOPK");                        // A/B switch
-    const bool off = off_env && off_env[0] && off_env[0] != '0';
-    const char* cap_str = std::getenv("RAGLITE_FUSED_TOPK_CAP");                       // tests: force list overflows
-    const int cap_env = cap_str ? std::atoi(cap_str) : 0;
+    const bool off = !idx->opt.on(RL_OPT_FUSED_TOPK);
+    const int cap_env = (int)idx->opt.v[RL_OPT_FUSED_TOPK_CAP];  // tests: force list overflows
     const int mode = scan_mode(idx->metric);
     if (off || B < GEMM_MIN_QUERIES || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT)) return RL_ERR_UNSUPPORTED;
     if (!image_valid(idx)) return RL_ERR_UNSUPPORTED;
@@ -1227,7 +1313,7 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
     // (more sample work), 39 (two pairs per workgroup in the sample pass instead of 2.83): 8.0 -- the candidates' epilogue and
     // list work grows faster than the sample pass shrinks.
     int32_t stride = (int32_t)std::min<int64_t>(MERGE_CAP / (3 * (int64_t)k), T / 8);
-    if (const char* st_env = std::getenv("RAGLITE_FUSED_TOPK_STRIDE")) stride = std::min<int32_t>(std::atoi(st_env), (int32_t)(T / 8));  // A/B
+    if (idx->opt.v[RL_OPT_FUSED_TOPK_STRIDE] > 0) stride = (int32_t)std::min<int64_t>(idx->opt.v[RL_OPT_FUSED_TOPK_STRIDE], T / 8);  // A/B
     if (stride < 2) return RL_ERR_UNSUPPORTED;
     const int64_t Tv = (T + stride - 1) / stride, ld_s = Tv * 256;
     if (ld_s < k) return RL_ERR_UNSUPPORTED;
@@ -1282,10 +1368,7 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
 // bits differ from the dense path's split-arithmetic sums, as they do between any two of the paths).  cosine / dot, k <= 512,
 // no row mask; RL_ERR_UNSUPPORTED otherwise.
 int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, float* d_scores, int32_t* d_rows, int64_t ld, hipStream_t s) {
-    for (const char* name : {"RAGLITE_NO_FUSED_HI", "RAGLITE_NO_FUSED_TOPK"}) {  // (the second one asks for the dense path: no fused top-k at all)
-        const char* off_env = std::getenv(name);
-        if (off_env && off_env[0] && off_env[0] != '0') return RL_ERR_UNSUPPORTED;
-    }
+    if (!idx->opt.on(RL_OPT_FUSED_HI) || !idx->opt.on(RL_OPT_FUSED_TOPK)) return RL_ERR_UNSUPPORTED;  // (the second asks for the dense path: no fused top-k at all)
     const bool hi_only = true;  // (two products -- q_hi.e_hi + q_lo.e_hi, no |q_lo| term in the band -- measured 4.88 ms against 3.51)
     const int mode = scan_mode(idx->metric);
     if (B < GEMM_MIN_QUERIES || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT)) return RL_ERR_UNSUPPORTED;
@@ -1294,7 +1377,7 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
     const int64_t n = idx->n_rows, T = (n + 255) / 256;
     const int32_t cap = MERGE_CAP, cap2 = 1024;
     int32_t stride = (int32_t)std::min<int64_t>(MERGE_CAP / (3 * (int64_t)k), T / 8);
-    if (const char* st_env = std::getenv("RAGLITE_FUSED_TOPK_STRIDE")) stride = std::min<int32_t>(std::atoi(st_env), (int32_t)(T / 8));  // A/B
+    if (idx->opt.v[RL_OPT_FUSED_TOPK_STRIDE] > 0) stride = (int32_t)std::min<int64_t>(idx->opt.v[RL_OPT_FUSED_TOPK_STRIDE], T / 8);  // A/B
     if (stride < 2) return RL_ERR_UNSUPPORTED;
     const int64_t Tv = (T + stride - 1) / stride, ld_s = Tv * 256;
     if (ld_s < k) return RL_ERR_UNSUPPORTED;
@@ -1333,7 +1416,26 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
                                 thr, window, cnt, cnt2, flag, s));
     const CandArgs ca{thr, 1, c_s, c_i, cnt, flag, cap};
     idx->filt = {RL_FILTER_ROWS_FUSED_HI, B, cap, cnt, flag};
-    RL_TRY(launch_score_planes_pass(hi, n, idx->dim, B, qs, nullptr, 0, idx->norm, idx->sumsq, mode, 1, nullptr, &ca, idx->n_cu, s, sscale, true, hi_only));
+    // The candidate pass on the sixteen-group tile of maxsim_pp.hip (round 4: 128 rows x 512 queries per workgroup, every operand through
+    // LDS-DMA rings, wave-private record logs; dim % 64 == 0, dim >= 256; RL_OPT_FUSED_PP = 0: the eight-group tile of maxsim_gemm.hip)
+    int st_pp = RL_ERR_UNSUPPORTED;
+    if (idx->opt.on(RL_OPT_FUSED_PP) && idx->dim % 64 == 0 && idx->dim >= 256) {
+        int32_t log_cap = 0;
+        const size_t work_bytes = pp_rows_scratch_bytes(n, B, idx->n_cu, (int32_t)std::min<int64_t>((int64_t)k * stride, cap), &log_cap);
+        RL_TRY(idx->pp_work.reserve(work_bytes));
+        st_pp = launch_pp_rows_pass(hi, n, idx->dim, B, qs, idx->norm, mode, &ca, idx->pp_work.p, log_cap, idx->n_cu, s, sscale);
+        if (st_pp != RL_OK && st_pp != RL_ERR_UNSUPPORTED) return st_pp;
+    }
+    if (st_pp != RL_OK)
+        RL_TRY(launch_score_planes_pass(hi, n, idx->dim, B, qs, nullptr, 0, idx->norm, idx->sumsq, mode, 1, nullptr, &ca, idx->n_cu, s, sscale, true, hi_only));
+    {
+        auto& r = idx->replay;
+        r.valid = true; r.pp = st_pp == RL_OK; r.B = B; r.mode = mode; r.qs = qs; r.ca = ca; r.cnt = cnt;
+        r.pools[0] = idx->misc.p; r.pools[1] = idx->fused.p; r.pools[2] = idx->pp_work.p;
+        int32_t lc = 0;
+        (void)pp_rows_scratch_bytes(n, B, idx->n_cu, (int32_t)std::min<int64_t>((int64_t)k * stride, cap), &lc);
+        r.log_cap = lc;
+    }
     // ---- (3) the rows within the band of each list's k-th entry; (4) their exact similarities, ranked -----------------------------
     RL_TRY(launch_list_prefix(c_s, c_i, B, cap, k, cnt, window, cap2, r_i, cnt2, flag, s));
     RL_TRY(launch_row_dots(idx->E, idx->dim, d_q, B, r_i, cnt2, cap2, mode, idx->norm, q_sumsq, r_s, s));
@@ -1365,8 +1467,7 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
 // candidates); RL_ERR_UNSUPPORTED otherwise.
 int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float* d_scores, int32_t* d_rows, int64_t ld, hipStream_t s,
                    const uint32_t* d_row_bits) {
-    const char* off_env = std::getenv("RAGLITE_NO_HI_SEARCH");  // A/B switch, read per call (tests flip it)
-    if (off_env && off_env[0] && off_env[0] != '0') return RL_ERR_UNSUPPORTED;
+    if (!idx->opt.on(RL_OPT_HI_SEARCH)) return RL_ERR_UNSUPPORTED;
     const int mode = scan_mode(idx->metric);
     const int64_t n = idx->n_rows;
     if (!hi_valid(idx) || nb > 16 || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT) || n < 65536) return RL_ERR_UNSUPPORTED;
@@ -1720,8 +1821,7 @@ int mask_chunk_scores(rl_index* idx, float* d_scores, int32_t nb, int64_t ld, co
 // `first + 1` of them.  RL_ERR_UNSUPPORTED when the shape or the index' arithmetic does not allow it -- the caller then
 // makes one pass per query.
 int pairs_prepare(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, int32_t n_queries, hipStream_t s) {
-    static const bool no_pairs = std::getenv("RAGLITE_NO_QUERY_PAIRS") != nullptr;  // A/B switch
-    if (no_pairs || idx->n_rows == 0 || idx->n_chunks == 0) return RL_ERR_UNSUPPORTED;
+    if (!idx->opt.on(RL_OPT_QUERY_PAIRS) || idx->n_rows == 0 || idx->n_chunks == 0) return RL_ERR_UNSUPPORTED;
     if (!idx->E16 && !(idx->E && idx->split_scale > 0.f)) return RL_ERR_UNSUPPORTED;  // fp16-stored, or fp32 in split arithmetic
     if (nq <= 16 || nq > 32 || n_queries < 2) return RL_ERR_UNSUPPORTED;
     const int32_t d = idx->dim;
@@ -1746,8 +1846,7 @@ int pairs_pass(rl_index* idx, int32_t nq, int32_t n_queries, int32_t first, floa
 // counting chunk ends) or the shape is outside the kernel -- the caller then uses the streaming kernels.
 constexpr int32_t GEMM_PASS_QUERIES = 8, GEMM_PASS_MIN_QUERIES = 3;
 int gemm_prepare(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, int32_t n_queries, hipStream_t s) {
-    static const bool off = std::getenv("RAGLITE_NO_GEMM_PASS") != nullptr;  // A/B switch
-    if (off || !image_valid(idx)) return RL_ERR_UNSUPPORTED;
+    if (!idx->opt.on(RL_OPT_GEMM_PASS) || !image_valid(idx)) return RL_ERR_UNSUPPORTED;
     if (idx->has_empty_chunk || idx->n_chunks == 0 || nq < 1 || nq > 32 || n_queries < GEMM_PASS_MIN_QUERIES) return RL_ERR_UNSUPPORTED;
     RL_TRY(idx->qplanes.reserve(query_planes_bytes(idx->dim, n_queries)));
     return launch_query_planes(d_q, idx->dim, nq, q_stride, n_queries, idx->qplanes.p, s);
@@ -1839,35 +1938,42 @@ namespace {
 // candidate collection, exact re-scoring, ranking, and the guarded full-precision fallback.
 struct HiBatch {
     float* ts; int32_t* ti; float* thr; uint32_t* cnt; uint32_t* flag; int32_t* ci; float* es;
+    float* m; float* es_top;  // [n] the bound m_b of every query; [n x k] exact scores of the approximate top-k (second threshold)
     int32_t cap; bool one_product; float m_abs; const float* q_unscale;
+    bool exact_kth;           // second, tighter threshold from the exact scores of the approximate top-k (RL_OPT_EXACT_KTH_THRESHOLD)
 };
+// The scratch layout of a bound-filtered MaxSim batch of n queries (the same in every call that works on the batch)
+void hi_batch_layout(rl_index* idx, int32_t n, int32_t k, HiBatch& hb) {
+    hb.cap = 2048;  // (the benchmark corpus needs ~300 -- 1 150 with the a-priori bound: score spread sigma ~ 34, window 2 m = 15..34)
+    hb.ts = idx->hibuf.as<float>();                                        // [n x k] approximate top-k scores
+    hb.ti = reinterpret_cast<int32_t*>(hb.ts + (size_t)n * k);
+    hb.thr = reinterpret_cast<float*>(hb.ti + (size_t)n * k);              // [n]
+    hb.cnt = reinterpret_cast<uint32_t*>(hb.thr + n);                      // [n]
+    hb.flag = hb.cnt + n;                                                  // (16 words)
+    hb.ci = reinterpret_cast<int32_t*>(hb.flag + 16);                      // [n x cap] candidate chunks
+    hb.es = reinterpret_cast<float*>(hb.ci + (size_t)n * hb.cap);          // [n x cap] their exact scores
+    hb.m = hb.es + (size_t)n * hb.cap;                                     // [n]
+    hb.es_top = hb.m + n;                                                  // [n x k]
+}
+size_t hi_batch_words(int32_t n, int32_t k) { return (size_t)n * k * 3 + (size_t)n * 3 + 16 + (size_t)n * 2048 * 2; }
 int hi_batch_approx(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queries, int32_t n_gemm, int32_t k, float* sc, int64_t ld, HiBatch& hb,
                     hipStream_t s) {
     // ONE product per multiply -- q_hi.e_hi only, a plain fp16 GEMM -- with the bound widened by what the queries' hi halves drop,
-    // (max|e| + max|e_lo|) sum_i |q_lo,i| (measured per query by the threshold kernel).  RAGLITE_HI_ONE_PRODUCT=0 (read per call): two products.
-    const char* one_env = std::getenv("RAGLITE_HI_ONE_PRODUCT");
-    hb.one_product = !(one_env && one_env[0] == '0');
-    hb.cap = 2048;  // (the benchmark corpus needs ~300 -- 1 150 with the a-priori bound: score spread sigma ~ 34, window 2 m = 15..34)
+    // (max|e| + max|e_lo|) sum_i |q_lo,i| (measured per query by the threshold kernel).  RL_OPT_HI_PRODUCTS = 2: two products.
+    hb.one_product = idx->opt.v[RL_OPT_HI_PRODUCTS] == 1;
+    hb.exact_kth = idx->opt.on(RL_OPT_EXACT_KTH_THRESHOLD);
+    RL_TRY(idx->hibuf.reserve(hi_batch_words(n_gemm, k) * 4));
+    hi_batch_layout(idx, n_gemm, k, hb);
     const int32_t cap = hb.cap;
-    const size_t words = (size_t)n_gemm * k * 2 + (size_t)n_gemm * 2 + 16 + (size_t)n_gemm * cap * 2;
-    RL_TRY(idx->hibuf.reserve(words * 4));
-    hb.ts = idx->hibuf.as<float>();                                        // [n x k] approximate top-k scores
-    hb.ti = reinterpret_cast<int32_t*>(hb.ts + (size_t)n_gemm * k);
-    hb.thr = reinterpret_cast<float*>(hb.ti + (size_t)n_gemm * k);         // [n]
-    hb.cnt = reinterpret_cast<uint32_t*>(hb.thr + n_gemm);                 // [n]
-    hb.flag = hb.cnt + n_gemm;                                             // (16 words)
-    hb.ci = reinterpret_cast<int32_t*>(hb.flag + 16);                      // [n x cap] candidate chunks
-    hb.es = reinterpret_cast<float*>(hb.ci + (size_t)n_gemm * cap);        // [n x cap] their exact scores
     // per pair |approx - exact| <= |q_i| |e_lo,j| (what the HI halves drop, measured: max_lo_norm) + 2^-12 |q_i| |e_j| (the
     // query's own 2^-22 split and twice the worst case of a 1024-term fp32 sum, 6e-5)
     hb.m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
     hb.q_unscale = reinterpret_cast<const float*>(idx->qplanes.as<char>() + (size_t)n_queries * idx->dim * 128);  // launch_query_planes' meta
     RL_HIP(hipMemsetAsync(hb.flag, 0, 16 * sizeof(uint32_t), s));
     RL_HIP(hipMemsetAsync(hb.ci, 0xff, (size_t)n_gemm * cap * sizeof(int32_t), s));  // unused slots: -1 = "no chunk"
-    // One product: SIXTEEN queries per pass through maxsim_pp.hip (dim >= 256; RAGLITE_NO_PP=1, read per call: the
-    // eight-query pass of maxsim_gemm.hip instead -- A/B, and what two products still use).
-    const char* nopp_env = std::getenv("RAGLITE_NO_PP");
-    const bool pp = hb.one_product && idx->dim >= 256 && !(nopp_env && nopp_env[0] && nopp_env[0] != '0');
+    // One product: SIXTEEN queries per pass through maxsim_pp.hip (dim >= 256; RL_OPT_PP_PASS = 0: the eight-query pass of
+    // maxsim_gemm.hip instead -- A/B, and what two products still use).
+    const bool pp = hb.one_product && idx->dim >= 256 && idx->opt.on(RL_OPT_PP_PASS);
     for (int32_t b = 0; pp && b < n_gemm; b += PP_PASS_QUERIES) {
         const int32_t n_q = std::min<int32_t>(PP_PASS_QUERIES, n_gemm - b);
         RL_TRY(launch_maxsim_pp(approx_image(idx), idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
@@ -1886,24 +1992,23 @@ int hi_batch_approx(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queri
 int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queries, int32_t n_gemm, int32_t k, float* sc, int64_t ld,
                      const HiBatch& hb, float* d_s, int32_t* d_c, hipStream_t s) {
     const size_t q_elems = (size_t)nq * idx->dim;
-    RL_TRY(launch_collect_above(sc, n_gemm, idx->n_chunks, ld, hb.thr, nullptr, hb.cap, hb.ci, nullptr, hb.cnt, hb.flag, s));
-    if (std::getenv("RAGLITE_HI_DEBUG")) {  // diagnostic: synchronises; list lengths, threshold and flag of this batch to stderr
-        std::vector<uint32_t> h_cnt(n_gemm);
-        std::vector<float> h_thr(n_gemm), h_ts((size_t)n_gemm * k);
-        uint32_t h_flag = 0;
-        RL_HIP(hipStreamSynchronize(s));
-        RL_HIP(hipMemcpy(h_cnt.data(), hb.cnt, (size_t)n_gemm * 4, hipMemcpyDeviceToHost));
-        RL_HIP(hipMemcpy(h_thr.data(), hb.thr, (size_t)n_gemm * 4, hipMemcpyDeviceToHost));
-        RL_HIP(hipMemcpy(h_ts.data(), hb.ts, (size_t)n_gemm * k * 4, hipMemcpyDeviceToHost));
-        RL_HIP(hipMemcpy(&h_flag, hb.flag, 4, hipMemcpyDeviceToHost));
-        uint32_t mx = 0; double mean = 0;
-        for (int32_t b = 0; b < n_gemm; ++b) { mx = std::max(mx, h_cnt[b]); mean += h_cnt[b]; }
-        fprintf(stderr, "HIDEBUG n=%d k=%d flag=%u max_row_norm=%g cnt mean=%.1f max=%u  q0: best=%g kth=%g thr=%g\n", n_gemm, k, h_flag,
-                idx->max_row_norm, mean / n_gemm, mx, h_ts[0], h_ts[k - 1], h_thr[0]);
-    }
+    const float* rows = idx->E16 ? reinterpret_cast<const float*>(idx->E16) : idx->E;
+    const bool rows16 = idx->E16 != nullptr;
     idx->filt = {RL_FILTER_MAXSIM_BATCH, n_gemm, hb.cap, hb.cnt, hb.flag};
-    RL_TRY(launch_maxsim_pairs(idx->E16 ? reinterpret_cast<const float*>(idx->E16) : idx->E, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci,
-                               hb.cap, n_gemm, hb.es, s, idx->E16 != nullptr));
+    if (hb.exact_kth && k <= hb.cap) {
+        // Second threshold (hi_filter.hip: exact_threshold_kernel): the approximate top-k is scored exactly FIRST; the k-th best of those
+        // exact scores bounds the k-th best overall from below, so a candidate needs approx >= that - m instead of (k-th approx) - 2 m: about
+        // half as many chunks beyond the top-k to re-score.  The approximate top-k becomes the head of the list; the collection appends only
+        // what ranks below it, and only those entries are scored by the second launch.
+        RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ti, k, n_gemm, hb.es_top, s, rows16));
+        RL_TRY(launch_exact_threshold(hb.es_top, hb.ti, n_gemm, k, hb.m, hb.cap, hb.thr, hb.cnt, hb.ci, hb.es, hb.flag, s));
+        RL_TRY(launch_collect_above(sc, n_gemm, idx->n_chunks, ld, hb.thr, nullptr, hb.cap, hb.ci, nullptr, hb.cnt, hb.flag, s, hb.ts, hb.ti, k));
+        if (hb.cap > k)
+            RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap - k, n_gemm, hb.es, s, rows16, hb.cap, k));
+    } else {
+        RL_TRY(launch_collect_above(sc, n_gemm, idx->n_chunks, ld, hb.thr, nullptr, hb.cap, hb.ci, nullptr, hb.cnt, hb.flag, s));
+        RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap, n_gemm, hb.es, s, rows16));
+    }
     RL_TRY(launch_merge_topk(hb.es, hb.ci, 1, n_gemm, hb.cap, k, d_s, d_c, s, hb.cnt));
     for (int32_t b = 0; b < n_gemm; b += GEMM_PASS_QUERIES) {  // list overflow / unusable bound: the full-precision passes, behind the flag
         const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_gemm - b);
@@ -1954,10 +2059,8 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
                                        ? (n_queries / GEMM_PASS_QUERIES) * GEMM_PASS_QUERIES +
                                              ((n_queries % GEMM_PASS_QUERIES) >= GEMM_PASS_MIN_QUERIES ? n_queries % GEMM_PASS_QUERIES : 0)
                                        : 0;
-            const char* off_env = std::getenv("RAGLITE_NO_HI_MAXSIM");  // A/B switch, read per call (tests flip it)
-            const bool hi_off = off_env && off_env[0] && off_env[0] != '0';
-            const char* one_env0 = std::getenv("RAGLITE_HI_ONE_PRODUCT");
-            const bool two_products = one_env0 && one_env0[0] == '0';  // (over an fp16-stored corpus two products ARE the full precision)
+            const bool hi_off = !idx->opt.on(RL_OPT_HI_MAXSIM);
+            const bool two_products = idx->opt.v[RL_OPT_HI_PRODUCTS] == 2;  // (over an fp16-stored corpus two products ARE the full precision)
             if (n_gemm > 0 && !hi_off && approx_image_valid(idx) && k <= 512 && !(idx->E16 && two_products)) {
                 // ---- MaxSim of a batch at two MFMA products per multiply instead of three (the headline path) -------------------------
                 // (1) approximate chunk scores: the eight-query pass over the HI image (q_hi.e_hi + q_lo.e_hi);
@@ -1970,11 +2073,11 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
                 // ONE product per multiply -- q_hi.e_hi only, a plain fp16 GEMM -- with the bound widened by what the queries' hi
                 // halves drop, (max|e| + max|e_lo|) sum_i |q_lo,i| (measured per query by the threshold kernel): same results by the
                 // same argument (bit-identical on the benchmark shape, profiles/r02_u_probe.txt), the pass 1.01 -> 0.71 ms, 418 instead of
-                // 307 candidates per query, the 128-query step 17.1 -> 12.8 ms.  RAGLITE_HI_ONE_PRODUCT=0 (read per call): two products.
+                // 307 candidates per query, the 128-query step 17.1 -> 12.8 ms.  RL_OPT_HI_PRODUCTS = 2: two products.
                 HiBatch hb;
                 RL_TRY(hi_batch_approx(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, s));
                 RL_TRY(launch_maxsim_threshold(hb.ts, n_gemm, k, d_q, nq, idx->dim, (int64_t)q_elems, 1.0f, hb.m_abs, hb.thr, hb.cnt, hb.flag, s,
-                                               hb.one_product ? hb.q_unscale : nullptr, idx->max_row_norm + idx->max_lo_norm));
+                                               hb.one_product ? hb.q_unscale : nullptr, idx->max_row_norm + idx->max_lo_norm, hb.m));
                 RL_TRY(hi_batch_rescore(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, d_s, d_c, s));
                 base = n_gemm;
                 hi_done = true;
@@ -2024,8 +2127,7 @@ int rl_maxsim_batch_begin(rl_index* idx, const float* query_vecs, int32_t n_quer
     RL_TRY(use_scratch(idx, s));
     idx->mb_B = 0;
     // the bound-filtered pipeline must cover the WHOLE batch (rl_maxsim_topk_batch takes other kernels for what it leaves over)
-    const char* off_env = std::getenv("RAGLITE_NO_HI_MAXSIM");
-    const bool hi_off = off_env && off_env[0] && off_env[0] != '0';
+    const bool hi_off = !idx->opt.on(RL_OPT_HI_MAXSIM);
     const bool whole = n_queries % GEMM_PASS_QUERIES == 0 || n_queries % GEMM_PASS_QUERIES >= GEMM_PASS_MIN_QUERIES;
     if (hi_off || !whole || n_queries < GEMM_PASS_MIN_QUERIES || k > 512 || nq > 32)
         return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_batch_begin: needs >= 3 queries (n % 8 == 0 or n % 8 >= 3), nq <= 32 and k <= 512");
@@ -2082,20 +2184,11 @@ int rl_maxsim_batch_finish(rl_index* idx, const float* query_vecs, const float* 
     const int64_t ld = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
     float* sc = idx->scores.as<float>();
     HiBatch hb;  // the layout of rl_maxsim_batch_begin (same sizes: nothing is reallocated, the approximate scores are still in `sc`)
-    {
-        const char* one_env = std::getenv("RAGLITE_HI_ONE_PRODUCT");
-        hb.one_product = !(one_env && one_env[0] == '0');
-        hb.cap = 2048;
-        hb.ts = idx->hibuf.as<float>();
-        hb.ti = reinterpret_cast<int32_t*>(hb.ts + (size_t)n_queries * k);
-        hb.thr = reinterpret_cast<float*>(hb.ti + (size_t)n_queries * k);
-        hb.cnt = reinterpret_cast<uint32_t*>(hb.thr + n_queries);
-        hb.flag = hb.cnt + n_queries;
-        hb.ci = reinterpret_cast<int32_t*>(hb.flag + 16);
-        hb.es = reinterpret_cast<float*>(hb.ci + (size_t)n_queries * hb.cap);
-        hb.m_abs = 0.f;
-        hb.q_unscale = nullptr;
-    }
+    hi_batch_layout(idx, n_queries, k, hb);
+    hb.one_product = idx->opt.v[RL_OPT_HI_PRODUCTS] == 1;
+    hb.exact_kth = false;  // (the shards' ONE threshold comes from the exchange of their approximate lists)
+    hb.m_abs = 0.f;
+    hb.q_unscale = nullptr;
     RL_TRY(launch_global_threshold(d_a, world, n_queries, k, rank, hb.thr, hb.cnt, hb.flag, s));
     RL_TRY(hi_batch_rescore(idx, d_q, nq, n_queries, n_queries, k, sc, ld, hb, d_s, d_c, s));
     if (idx->live_chunk_bits) RL_TRY(launch_fix_masked(d_s, d_c, (int64_t)n_queries * k, s));
@@ -2113,6 +2206,9 @@ int rl_maxsim_approx_scores(rl_index* idx, const float* query_vecs, int32_t n_qu
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
     RL_TRY(use_scratch(idx, s));
+    // (both pass kernels find a chunk by counting chunk ends: an empty chunk would shift every score behind it to the wrong chunk)
+    if (idx->has_empty_chunk || idx->n_chunks == 0)
+        return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_approx_scores: the approximate pass needs an index without empty chunks");
     if (!approx_image_valid(idx) || nq > 32 || (kernel == 0 && idx->dim < 256))
         return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_approx_scores: this index keeps no HI image (or nq > 32 / dim < 256)");
     DevBuf t_q, t_o, t_b;
@@ -2316,6 +2412,11 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     else if (kind == 2) RL_TRY(idx->scores.reserve((size_t)2 * ldc * sizeof(float)));
     else if (kind == 3 || kind == 5 || kind == 6) RL_TRY(idx->scores.reserve((size_t)GEMM_PASS_QUERIES * ldc * sizeof(float)));
     else if (kind == 7) RL_TRY(idx->scores.reserve((size_t)PP_PASS_QUERIES * ldc * sizeof(float)));
+    else if (kind == 8) {  // replays the candidate pass of the last fused-HI row search (same queries, same thresholds)
+        const auto& r = idx->replay;
+        if (!r.valid || r.pools[0] != idx->misc.p || r.pools[1] != idx->fused.p || r.pools[2] != idx->pp_work.p || !hi_image_valid(idx))
+            return fail(RL_ERR_UNSUPPORTED, "rl_time_kernel kind 8: no fused-HI row search ran on this index since its scratch was last resized");
+    }
     else RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)nq * ld * sizeof(float), 16)));
     hipEvent_t e0, e1;
     RL_HIP(hipEventCreate(&e0));
@@ -2340,6 +2441,14 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
                                              nq / PP_PASS_QUERIES, idx->row_to_chunk, idx->offsets, idx->ends.as<uint32_t>(), idx->scores.as<float>(), ldc,
                                              idx->n_cu, s, approx_scale(idx));
         else if (kind == 3) st = gemm_pass(idx, nq / GEMM_PASS_QUERIES, GEMM_PASS_QUERIES, 0, GEMM_PASS_QUERIES, idx->scores.as<float>(), ldc, s);
+        else if (kind == 8) {
+            const auto& r = idx->replay;
+            if (hipMemsetAsync(r.cnt, 0, (size_t)r.B * sizeof(uint32_t), s) != hipSuccess) st = RL_ERR_HIP;  // the lists fill up again on every run
+            else if (r.pp) st = launch_pp_rows_pass(idx->hi_image.p, idx->n_rows, idx->dim, r.B, r.qs, idx->norm, r.mode, &r.ca, idx->pp_work.p, r.log_cap,
+                                                    idx->n_cu, s, idx->split_scale);
+            else st = launch_score_planes_pass(idx->hi_image.p, idx->n_rows, idx->dim, r.B, r.qs, nullptr, 0, idx->norm, idx->sumsq, r.mode, 1, nullptr, &r.ca,
+                                               idx->n_cu, s, idx->split_scale, true, true);
+        }
         else if (kind == 0) st = maxsim_scores_device(idx, q_dev, nq, idx->scores.as<float>(), s);
         else if (kind == 2) st = pairs_pass(idx, nq / 2, 2, 0, idx->scores.as<float>(), ldc, s);
         else if (kind == 5 || kind == 6) {  // the approximate MaxSim pass of a batch: eight queries over the HI image (5: two MFMA products, 6: one)

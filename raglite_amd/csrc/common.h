@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <string>
 
 #include "raglite_hip.h"
@@ -27,6 +28,15 @@ int fail(int code, const std::string& msg);
         int _s = (expr);          \
         if (_s != RL_OK) return _s; \
     } while (0)
+
+// Experiment switches (kernel A/B variants, timing skeletons, s_memtime traces) are read from the environment ONLY in experiment
+// builds (-DRAGLITE_EXPERIMENTS: raglite_amd._build.build(experiments=True) -> libraglite_hip_exp.so, used by scripts/gpu_calls/).  The
+// shipped library reads no environment variable: there every switch folds to "off" at compile time.
+#ifdef RAGLITE_EXPERIMENTS
+inline const char* exp_env(const char* name) { return std::getenv(name); }
+#else
+inline const char* exp_env(const char*) { return nullptr; }
+#endif
 
 constexpr int WAVE = 64;
 constexpr int K_MAX = 2048;       // largest top-k the selection stage supports
@@ -178,8 +188,14 @@ int launch_rank_cut(float* scores, int32_t n_queries, int64_t n, int64_t ld, int
 // hi_filter.hip: helpers of the half-bytes single-query search (api.hip: search_rows_hi)
 int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const float* queries, int32_t dim, int mode, float m_rel,
                             float e_norm_bound, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s);  // also zeroes cnt[0..nb) and *flag
+// top_s / top_i [nb x k] (optional): the approximate top-k in selection order -- only entries ranking BELOW its k-th one are collected
 int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld, const float* thr, const float* row_norm, int32_t cap,
-                         int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s);
+                         int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* top_s = nullptr,
+                         const int32_t* top_i = nullptr, int32_t k = 0);
+// thr[b] = min_j exact[b][j] - m[b] (the k-th best EXACT score of the approximate top-k bounds the k-th best overall from below);
+// ids[b][0 .. k) = top_i[b], es[b][0 .. k) = exact[b], cnt[b] = k; unusable -> *flag, thr = +inf, cnt = 0.  See exact_threshold_kernel.
+int launch_exact_threshold(const float* exact, const int32_t* top_i, int32_t n_queries, int32_t k, const float* m, int32_t cap, float* thr,
+                           uint32_t* cnt, int32_t* ids, float* es, uint32_t* flag, hipStream_t s);
 // MaxSim flavour of the threshold: thr[b] = topk[b * k + k - 1] - 2 * m_rel * e_max * sum_i |q_i|; zeroes cnt[b]; sets *flag when
 // the k-th score is unusable.  One block per query.
 // q_unscale != nullptr (one-product pass: only the queries' fp16 hi halves were multiplied): q_unscale[2 * b] = 2^(ex - 14) of
@@ -187,7 +203,7 @@ int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld,
 // q_lo,i = q_i - fp16(q_i * scale) / scale, recomputed here with the statement query_planes_kernel uses.
 int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, const float* Q, int32_t nq, int32_t dim, int64_t q_stride,
                             float m_rel, float e_max, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s,
-                            const float* q_unscale = nullptr, float e_norm_max = 0.f);
+                            const float* q_unscale = nullptr, float e_norm_max = 0.f, float* m_out = nullptr);  // m_out[b] = the bound m_b
 // A MaxSim batch over a sharded corpus (api.hip: rl_maxsim_batch_begin / _finish): out[b] = top[b][0 .. k) ++ {m_b} with neg2m[b] = -2 m_b;
 // thr[b] = (k-th best of all shards' lists [world][B][k + 1]) - max_r m_r - m_rank, cnt[b] = 0, *flag on an unusable threshold
 int launch_pack_approx(const float* top, const float* neg2m, int32_t B, int32_t k, float* out, hipStream_t s);
@@ -266,12 +282,16 @@ constexpr int32_t PP_PASS_QUERIES = 16;
 int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first, int32_t n_q,
                      int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits, float* out,
                      int64_t out_stride, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if = nullptr);
+// the candidate pass of the fused row top-k on that kernel's tile (MODE 2; see maxsim_pp.hip) -- declared after CandArgs below
 size_t score_planes_scratch_floats(int32_t nb, int32_t dim);
 int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores, int64_t ld,
                         const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale,
                         bool half = false);
 struct CandArgs { const float* tau; int32_t tau_stride; float* scores; int32_t* ids; uint32_t* cnt; uint32_t* overflow; int32_t cap; };
 int launch_score_planes_queries(const float* Q, int32_t nb, int32_t dim, float* scratch, int mode, hipStream_t s);
+size_t pp_rows_scratch_bytes(int64_t n_rows, int32_t nb, int n_cu, int32_t expected_per_query, int32_t* log_cap_out);
+int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, const float* row_norm, int mode,
+                        const CandArgs* cand, void* work, int32_t log_cap, int n_cu, hipStream_t s, float split_scale);
 int launch_score_planes_pass(const void* planes, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, float* scores, int64_t ld,
                              const float* row_norm, const float* row_sumsq, int mode, int32_t tile_stride, const uint32_t* run_if,
                              const CandArgs* cand, int n_cu, hipStream_t s, float split_scale, bool half = false, bool hi_only = false);
@@ -290,7 +310,9 @@ int launch_maxsim_stream16(const uint16_t* D, int64_t n_rows, int32_t dim, const
 // exact MaxSim of (query, candidate chunk) pairs, all queries in one launch: dim % 16 == 0, dim <= 1024, nq <= 32, fp32 MFMA
 int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride, const int64_t* chunk_offsets,
                         const int32_t* candidates, int64_t n_items_per_query, int32_t n_queries, float* out, hipStream_t s,
-                        bool rows16 = false);  // rows16: D points at fp16 rows (an fp16-stored corpus)
+                        bool rows16 = false,  // rows16: D points at fp16 rows (an fp16-stored corpus)
+                        int64_t item_stride = 0, int64_t first_item = 0);  // lists of `item_stride` (0: n_items_per_query) entries per query, of
+                                                                           // which entries first_item .. first_item + n_items_per_query - 1 are scored
 int launch_maxsim_generic(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride_queries,
                           const int64_t* chunk_offsets, const int32_t* candidates, int64_t n_items,
                           int32_t n_queries, float* out, hipStream_t s);

@@ -49,19 +49,30 @@ __global__ __launch_bounds__(256) void approx_threshold_kernel(const float* __re
 // a MaxSim batch collects ~300 chunks for each of 128 queries, and 300 returning atomics on one word are 300 dependent L2 round trips
 // -- the kernel took 0.16 ms for 64 MB of scores with one global atomic per hit-carrying wave (profiles/r03_ac_bench_kernel_stats.csv).
 // More than LOCAL hits in one workgroup's ~4 k scores: the guarded full-precision path answers (*flag), as for a full list.
+// top_s / top_i != nullptr (the second, tighter threshold of a MaxSim batch, api.hip: hi_batch_rescore): [nb x k] the approximate top-k
+// in selection order (score desc, id asc) -- its members are already in the list (positions 0 .. k - 1, cnt[b] starts at k) and are NOT
+// collected again: an entry is taken only if it ranks BELOW the k-th one, (key, id) < (key_k, id_k) in the selection's own order.
 __global__ __launch_bounds__(256) void collect_above_kernel(const float* __restrict__ scores, int64_t n, int64_t ld, const float* __restrict__ thr,
                                                              const float* __restrict__ row_norm, int32_t cap, int32_t* __restrict__ ids,
-                                                             float* __restrict__ norms, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag) {
+                                                             float* __restrict__ norms, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag,
+                                                             const float* __restrict__ top_s, const int32_t* __restrict__ top_i, int32_t k) {
     constexpr uint32_t LOCAL = 1024;
     __shared__ int32_t l_ids[LOCAL];
     __shared__ uint32_t l_n, l_base;
     const int b = blockIdx.y;
     const float t = thr[b];
     const float* s = scores + (int64_t)b * ld;
+    const bool below_top = top_s != nullptr;
+    const uint32_t key_k = below_top ? score_key(top_s[(int64_t)b * k + (k - 1)]) : 0u;
+    const int64_t id_k = below_top ? (int64_t)top_i[(int64_t)b * k + (k - 1)] : -1;
     if (threadIdx.x == 0) l_n = 0u;
     __syncthreads();
     auto visit = [&](float v, int64_t i, bool in_range) {
-        const bool hit = in_range && v >= t;
+        bool hit = in_range && v >= t;
+        if (below_top) {
+            const uint32_t kv = score_key(v);
+            hit = hit && (kv < key_k || (kv == key_k && i > id_k));
+        }
         const uint64_t mask = __builtin_amdgcn_ballot_w64(hit);
         if (mask == 0ull) return;  // (wave-uniform)
         const int lane = threadIdx.x & 63;
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(256) void collect_above_kernel(const float* __restr
 __global__ __launch_bounds__(256) void maxsim_threshold_kernel(const float* __restrict__ topk, int32_t k, const float* __restrict__ Q, int nq,
                                                                 int dim, int64_t q_stride, float m_rel, float e_max,
                                                                 float* __restrict__ thr, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag,
-                                                                const float* __restrict__ q_unscale, float e_norm_max) {
+                                                                const float* __restrict__ q_unscale, float e_norm_max, float* __restrict__ m_out) {
     // |approx - exact| of a chunk's MaxSim score <= sum_i max_j (|q_i| |e_lo,j| + slack |q_i| |e_j|) <= (m_rel * e_max) * sum_i |q_i|
     // with m_rel * e_max = max_j |e_lo,j| + 2^-12 max_j |e_j| handed over by the caller
     // One-product pass (q_unscale != nullptr): the pass multiplied q_hi = fp16(q * q_scale) only, so every pair is also off by
@@ -155,7 +166,49 @@ __global__ __launch_bounds__(256) void maxsim_threshold_kernel(const float* __re
     const float t = topk[(int64_t)b * k + (k - 1)] - 2.0f * m;
     thr[b] = t;
     cnt[b] = 0u;
+    if (m_out) m_out[b] = m;
     if (!(t > -INFINITY)) atomicOr(flag, 1u);  // NaN or -inf: fewer than k scorable chunks
+}
+
+// The second, tighter threshold of a MaxSim batch.  exact[b][0 .. k) = the EXACT scores of query b's approximate top-k chunks top_i[b][.]
+// (maxsim_pairs_kernel).  L = their minimum is the k-th best exact score of a k-subset, hence <= the k-th best exact score overall; a
+// chunk of the exact top-k has exact >= L and |approx - exact| <= m_b, so its approximate score is >= L - m_b =: thr[b] -- against
+// (k-th best approximate) - 2 m_b of the first threshold, and never below it (every member of the approximate top-k has exact >=
+// approx - m >= k-th approximate - m).  The approximate top-k itself passes (approx >= exact - m >= L - m): it becomes the head of the
+// candidate list -- ids[b][0 .. k), es[b][0 .. k), cnt[b] = k -- and collect_above_kernel appends only what ranks below it.
+// Fewer than k scorable chunks (an id < 0, a NaN): *flag, nothing collected (thr = +inf): the guarded full-precision path answers.
+__global__ __launch_bounds__(256) void exact_threshold_kernel(const float* __restrict__ exact, const int32_t* __restrict__ top_i, int32_t k,
+                                                               const float* __restrict__ m, int32_t cap, float* __restrict__ thr,
+                                                               uint32_t* __restrict__ cnt, int32_t* __restrict__ ids, float* __restrict__ es,
+                                                               uint32_t* __restrict__ flag) {
+    __shared__ float part[4];
+    __shared__ int bad_sh;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) bad_sh = 0;
+    __syncthreads();
+    float mn = INFINITY;
+    bool bad = false;
+    for (int j = threadIdx.x; j < k; j += 256) {
+        const float v = exact[(int64_t)b * k + j];
+        const int32_t c = top_i[(int64_t)b * k + j];
+        bad |= c < 0 || !(v > -INFINITY);
+        mn = fminf(mn, v);
+        ids[(int64_t)b * cap + j] = c;
+        es[(int64_t)b * cap + j] = v;
+    }
+    if (bad) bad_sh = 1;  // (benign race: every writer stores 1)
+    mn = -wave_max(-mn);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mn;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const float L = fminf(fminf(part[0], part[1]), fminf(part[2], part[3]));
+    const float mb = m[b];
+    float t = L - mb * 1.00001f;
+    t -= fabsf(t) * 0x1p-22f;  // (the subtraction's own rounding)
+    const bool unusable = bad_sh != 0 || k > cap || !(t > -INFINITY) || !(mb >= 0.f);
+    thr[b] = unusable ? INFINITY : t;
+    cnt[b] = unusable ? 0u : (uint32_t)k;
+    if (unusable) atomicOr(flag, 1u);
 }
 
 // Batched flavour (api.hip: search_rows_fused_hi, experimental), one block per query: thr[b] = topk[b * k + k - 1] - window[b] with
@@ -365,10 +418,12 @@ int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const floa
 }
 
 int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld, const float* thr, const float* row_norm, int32_t cap,
-                         int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s) {
+                         int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* top_s, const int32_t* top_i,
+                         int32_t k) {
     if (n <= 0 || nb <= 0) return RL_OK;
+    if ((top_s != nullptr) != (top_i != nullptr) || (top_s && k < 1)) return RL_ERR_INVALID;
     const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((n + 4095) / 4096, 512));
-    hipLaunchKernelGGL(collect_above_kernel, dim3(bx, nb), dim3(256), 0, s, scores, n, ld, thr, row_norm, cap, ids, norms, cnt, flag);
+    hipLaunchKernelGGL(collect_above_kernel, dim3(bx, nb), dim3(256), 0, s, scores, n, ld, thr, row_norm, cap, ids, norms, cnt, flag, top_s, top_i, k);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -387,10 +442,18 @@ int launch_scale_f32(const float* src, float* dst, float factor, int64_t count, 
 
 int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, const float* Q, int32_t nq, int32_t dim, int64_t q_stride,
                             float m_rel, float e_max, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* q_unscale,
-                            float e_norm_max) {
+                            float e_norm_max, float* m_out) {
     if (n_queries <= 0) return RL_OK;
     hipLaunchKernelGGL(maxsim_threshold_kernel, dim3(n_queries), dim3(256), 0, s, topk, k, Q, (int)nq, (int)dim, q_stride, m_rel, e_max, thr, cnt,
-                       flag, q_unscale, e_norm_max);
+                       flag, q_unscale, e_norm_max, m_out);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+int launch_exact_threshold(const float* exact, const int32_t* top_i, int32_t n_queries, int32_t k, const float* m, int32_t cap, float* thr,
+                           uint32_t* cnt, int32_t* ids, float* es, uint32_t* flag, hipStream_t s) {
+    if (n_queries <= 0) return RL_OK;
+    hipLaunchKernelGGL(exact_threshold_kernel, dim3(n_queries), dim3(256), 0, s, exact, top_i, k, m, cap, thr, cnt, ids, es, flag);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -923,11 +923,12 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
     const float* qmeta = reinterpret_cast<const float*>(static_cast<const char*>(qbuf) + (size_t)n_queries * dim * 128) + 2 * (size_t)first;
     const int64_t tiles = (n_rows + MG_TM - 1) / MG_TM;
     const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
-    static const int dbg_env = std::getenv("RAGLITE_GEMM_DBG") ? std::atoi(std::getenv("RAGLITE_GEMM_DBG")) : 0;  // timing experiments only
+    static const int dbg_env = exp_env("RAGLITE_GEMM_DBG") ? std::atoi(exp_env("RAGLITE_GEMM_DBG")) : 0;  // timing experiments only
     const int dbg = (dbg_env & ~64) | (hi_only ? 64 : 0);
+#ifdef RAGLITE_EXPERIMENTS  // the slab-timeline build of the kernel exists in experiment builds only
     static unsigned long long* trace = [] {
         unsigned long long* p = nullptr;
-        if (std::getenv("RAGLITE_GEMM_TRACE")) { (void)hipMalloc(&p, 16 * 8 * 16 * 8); (void)hipMemset(p, 0, 16 * 8 * 16 * 8); }
+        if (exp_env("RAGLITE_GEMM_TRACE")) { (void)hipMalloc(&p, 16 * 8 * 16 * 8); (void)hipMemset(p, 0, 16 * 8 * 16 * 8); }
         return p;
     }();
     if (trace && nq > 16 && !half) {  // diagnostic build: dump the 10th launch's slab timeline to stderr
@@ -947,6 +948,7 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
         }
         return RL_OK;
     }
+#endif
     RowScoreArgs rs0{};
     rs0.run_if = run_if;
 #define RL_MG_LAUNCH(NQB_, HALF_)                                                                                                     \
@@ -1070,7 +1072,7 @@ int launch_score_planes_pass(const void* planes, int64_t n_rows, int32_t dim, in
     rs.S = scores; rs.ld = ld; rs.row_norm = mode == SCAN_COSINE ? row_norm : row_sumsq; rs.q_sumsq = qss; rs.q_unscale = unscale;
     rs.q_anylo = anylo; rs.B = nb; rs.QT = (groups + MG_WAVES - 1) / MG_WAVES; rs.metric = mode; rs.tile_stride = tile_stride;
     rs.compact = tile_stride > 1 ? 1 : 0; rs.run_if = run_if;
-    static const int q_inner_env = std::getenv("RAGLITE_GEMM_Q_INNER") ? 1 : 0;  // A/B: query tile fastest (the first version)
+    static const int q_inner_env = exp_env("RAGLITE_GEMM_Q_INNER") ? 1 : 0;  // A/B: query tile fastest (the first version)
     rs.q_outer = q_inner_env ? 0 : 1;
     if (cand) { rs.tau = cand->tau; rs.tau_stride = cand->tau_stride; rs.cand_scores = cand->scores; rs.cand_ids = cand->ids; rs.cand_cnt = cand->cnt;
                 rs.overflow = cand->overflow; rs.cap = cand->cap; }

@@ -114,13 +114,13 @@ static int generic_t(const float* D, int32_t dim, const float* Q, int32_t nq, co
 template <bool FULL, int KB, bool ROW16 = false>
 __global__ __launch_bounds__(512) void maxsim_pairs_kernel(const float* __restrict__ D, int dim, const float* __restrict__ Q, int nq,
                                                             int64_t q_stride, const int64_t* __restrict__ offsets,
-                                                            const int32_t* __restrict__ candidates, int64_t n_items,
+                                                            const int32_t* __restrict__ candidates, int64_t n_items, int64_t item_stride,
                                                             float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [32][dim + 8]
     const int pitch = dim + 8;
     const float* Qb = Q + (int64_t)blockIdx.y * q_stride;
-    const int32_t* cb = candidates + (int64_t)blockIdx.y * n_items;
-    float* ob = out + (int64_t)blockIdx.y * n_items;
+    const int32_t* cb = candidates + (int64_t)blockIdx.y * item_stride;
+    float* ob = out + (int64_t)blockIdx.y * item_stride;
     for (int i = threadIdx.x * 4; i < 32 * dim; i += 512 * 4) {
         const int n = i / dim, c = i - n * dim;
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};  // query vectors past nq: zeros (their maxima are 0 and add nothing)
@@ -240,8 +240,13 @@ __global__ __launch_bounds__(512) void maxsim_pairs_kernel(const float* __restri
 }
 
 int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride, const int64_t* offsets,
-                        const int32_t* candidates, int64_t n_items_per_query, int32_t n_queries, float* out, hipStream_t s, bool rows16) {
+                        const int32_t* candidates, int64_t n_items_per_query, int32_t n_queries, float* out, hipStream_t s, bool rows16,
+                        int64_t item_stride, int64_t first_item) {
     if (n_items_per_query <= 0 || n_queries <= 0) return RL_OK;
+    if (item_stride <= 0) item_stride = n_items_per_query;
+    if (first_item < 0 || first_item + n_items_per_query > item_stride) return RL_ERR_INVALID;
+    if (candidates) candidates += first_item;
+    if (out) out += first_item;
     if (nq < 1 || nq > 32 || dim % 16 || dim < 16 || dim > 1024 || !candidates) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(D) & (rows16 ? 7 : 15)) || (reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
     const size_t lds = (size_t)32 * (dim + 8) * sizeof(float);
@@ -263,10 +268,10 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
     do {                                                                                                                                   \
         if (rows16)                                                                                                                        \
             hipLaunchKernelGGL((maxsim_pairs_kernel<FULL_, KB_, true>), dim3(per_query, n_queries), dim3(512), lds, s, D, (int)dim, Q, (int)nq, \
-                               q_stride, offsets, candidates, n_items_per_query, out);                                                     \
+                               q_stride, offsets, candidates, n_items_per_query, item_stride, out);                                        \
         else                                                                                                                               \
             hipLaunchKernelGGL((maxsim_pairs_kernel<FULL_, KB_, false>), dim3(per_query, n_queries), dim3(512), lds, s, D, (int)dim, Q, (int)nq, \
-                               q_stride, offsets, candidates, n_items_per_query, out);                                                     \
+                               q_stride, offsets, candidates, n_items_per_query, item_stride, out);                                        \
     } while (0)
     if (dim % 256 == 0) RL_PAIRS(true, 256);
     else if (dim % 128 == 0) RL_PAIRS(true, 128);

@@ -44,6 +44,16 @@
 // integer-valued data is exact.  Same products and the same sums over K as maxsim_gemm_kernel's one-product pass; the 32 per-vector maxima
 // are added in another order: scores agree to the last bits, not bit for bit, on float data.  Needs an index without empty chunks (a chunk
 // is found by counting chunk ends), nq <= 32, dim % 32 == 0, dim >= 256.
+//
+// MODE 2 (round 4): the same main loop as the candidate pass of the fused exact row top-k (api.hip: search_rows_fused_hi; BASELINE cfg 5,
+// src/raglite/_search.py:69-79 at B = 1000): a "query" of the tile is a GROUP of 32 single-vector queries (the fragment layout of
+// query_rows_planes_kernel is that of query_planes_kernel), a workgroup walks (128-row tile, 512-query tile) pairs, and the tile epilogue
+// compares every accumulator with its query's threshold -- one v_cmp + one scalar branch per register; for cosines against
+// thr_q * min / max |e| of the register's 16-row block (two scalars per block, a superset of the exact test) -- and appends what passes
+// to a WAVE-PRIVATE log in global memory (plain stores: LDS is full of operand rings, and a returning atomic per hit would stall the
+// epilogue for an L2 round trip).  When the workgroup is done each wave re-evaluates its records with the exact formulas of
+// maxsim_gemm.hip MODE 2 (same statements, same bits), keeps those that reach the threshold exactly, and appends them to the per-query
+// candidate lists (one atomic per record, ~1 400 records per wave at cfg 5).
 #include <cstdio>
 #include <cstdlib>
 #include <utility>
@@ -111,6 +121,23 @@ __device__ __forceinline__ void pp_read(f32x4& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void pp_pin(f32x4& a, f32x4& b, f32x4& c, f32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
+// MODE 2: loads the compiler must not see.  A compiler-visible VMEM load anywhere in the K loop makes its wait-count pass put
+// `s_waitcnt vmcnt(0)` at the loop header -- which drains the feeders' look-ahead DMAs on every iteration.  The value is valid after an
+// explicit wait + pp_pin1().
+__device__ __forceinline__ float pp_gload(const float* p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void pp_pin1(float& a) { asm volatile("" : "+v"(a)); }
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// 16 consecutive floats at a wave-uniform, 64-byte aligned address through the scalar cache (waits for it: also for the LDS reads in flight)
+__device__ __forceinline__ f32x16 pp_sload16(const float* p) {
+    f32x16 v;
+    const float* const u = reinterpret_cast<const float*>(pp_uniform_i64(reinterpret_cast<int64_t>(p)));
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(u) : "memory");
+    return v;
+}
 __device__ __forceinline__ h16x8 pp_h(const f32x4& v) {
     h16x8 r;
     __builtin_memcpy(&r, &v, 16);
@@ -118,14 +145,28 @@ __device__ __forceinline__ h16x8 pp_h(const f32x4& v) {
 }
 }  // namespace
 
-// DBG (timing experiments only, RAGLITE_PP_DBG; wrong results): 2 = no MFMAs, 8 = no LDS fragment reads, 16 = no corpus DMAs,
+// MODE 2 arguments (see the header comment).  Queries come in groups of 32 (n_q = groups); a query tile is 16 groups.
+struct PpRows {
+    const float* tau;                     // [B] threshold on the similarity of query q (row_threshold_kernel: k-th of the sample - window)
+    const float* q_unscale;               // [B] 2^(ex - 14) per query
+    const float* q_sumsq;                 // [B] |q|^2 (cosine)
+    const float* row_norm;                // [n_rows] |e| (cosine)
+    const float* blk_minmax;              // [ceil(n_rows / 16)][2] min / max |e| over the rows of a 16-row block (cosine)
+    int32_t B, QT, metric;                // queries, query tiles (of 512) per row tile, SCAN_COSINE | SCAN_DOT
+    float* cand_scores; int32_t* cand_ids; uint32_t* cand_cnt; uint32_t* overflow; int32_t cap;  // per-query lists (as maxsim_gemm.hip MODE 2)
+    uint2* log; int32_t log_cap;          // [gridDim.x * 8][log_cap] wave-private records (raw accumulator, packed coordinates)
+};
+
+// DBG (experiment builds only, -DRAGLITE_EXPERIMENTS + RAGLITE_PP_DBG; wrong results): 2 = no MFMAs, 8 = no LDS fragment reads, 16 = no corpus DMAs,
 // 32 = no query DMAs, 64 = every corpus DMA re-reads the first tile (L2 hits), 128 = no tile epilogue (the MFMAs stay), 256 = no stores, 1024 = waves 4-7 run the stream of waves 0-3 (no lag), 2048 = no LDS reads of the QUERY fragments, 8192 = epilogue timeline (RAGLITE_PP_TRACE=1)
-template <int DBG>
+template <int DBG, int MODE = 0>
 __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restrict__ planes, int64_t n_rows, int32_t nslab,
                                                            const char* __restrict__ qfrag, const float* __restrict__ qmeta, int32_t n_q,
                                                            const int32_t* __restrict__ row_to_chunk, const int64_t* __restrict__ chunk_offsets,
                                                            const uint32_t* __restrict__ ends_bits, float* __restrict__ out, int64_t out_stride,
-                                                           float inv_e_scale, const uint32_t* __restrict__ run_if, unsigned long long* __restrict__ trace) {
+                                                           float inv_e_scale, const uint32_t* __restrict__ run_if, unsigned long long* __restrict__ trace,
+                                                           PpRows rs) {
+    constexpr bool ROWS = MODE == 2;
     __shared__ __attribute__((aligned(16))) char smem[PP_LDS];
     // DBG & 8192 (RAGLITE_PP_TRACE=1, timing experiments): s_memtime stamps of workgroup 7's tile 3 epilogue, per wave: [wave][0: start, 1 + a: after
     // block a, 9: end] straight to global memory
@@ -139,7 +180,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     const int lane = threadIdx.x & 63;
     const int wv = wave_id();
     const int64_t G = gridDim.x, b = blockIdx.x;
-    // Chunk-aligned row range of this workgroup (as in maxsim_gemm.hip): first chunk boundary at or after n_rows * b / G.
+    // MODE 0: chunk-aligned row range of this workgroup (as in maxsim_gemm.hip): first chunk boundary at or after n_rows * b / G.
     auto boundary = [&](int64_t t) -> int64_t {
         if (t <= 0) return 0;
         if (t >= n_rows) return n_rows;
@@ -147,11 +188,29 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         const int64_t c0 = chunk_offsets[c], c1 = chunk_offsets[c + 1];
         return c0 == t ? t : c1;
     };
-    const int32_t r_lo = (int32_t)pp_uniform_i64(boundary((n_rows * b) / G));
-    const int32_t r_hi = (int32_t)pp_uniform_i64((b + 1 == G) ? n_rows : boundary((n_rows * (b + 1)) / G));
-    if (r_hi <= r_lo) return;  // whole workgroup
-    const int32_t org = r_lo & ~15;  // tiles start on a 16-row block of the image
-    const int nt = (r_hi - org + PP_RT - 1) / PP_RT;
+    int32_t r_lo = 0, r_hi = 0, vt0 = 0, Tr = 1, nt_rows = 0;
+    if constexpr (!ROWS) {
+        r_lo = (int32_t)pp_uniform_i64(boundary((n_rows * b) / G));
+        r_hi = (int32_t)pp_uniform_i64((b + 1 == G) ? n_rows : boundary((n_rows * (b + 1)) / G));
+        if (r_hi <= r_lo) return;  // whole workgroup
+    } else {
+        // MODE 2: the workgroups share the (row tile, query tile) PAIRS evenly, query tile outermost (pair i = query tile i / Tr, row tile
+        // i % Tr): at any time the whole chip works on one 1-MiB query-tile image, as in MODE 0
+        Tr = (int32_t)((n_rows + PP_RT - 1) / PP_RT);
+        const int64_t items = (int64_t)Tr * rs.QT;
+        vt0 = (int32_t)((items * b) / G);
+        nt_rows = (int32_t)((items * (b + 1)) / G) - vt0;
+        if (nt_rows <= 0) return;  // whole workgroup
+        r_hi = (int32_t)n_rows;
+    }
+    const int32_t org = r_lo & ~15;  // MODE 0: tiles start on a 16-row block of the image
+    const int nt = ROWS ? nt_rows : (r_hi - org + PP_RT - 1) / PP_RT;
+    // MODE 2: (row tile, query tile) of the workgroup's pair t, walked incrementally by each of its three users (the feeders' corpus and
+    // query streams, the multiplying side) -- one integer division per workgroup, none per tile
+    struct PairPos { int32_t rt, qt; };
+    const PairPos pos0 = ROWS ? PairPos{(int32_t)(vt0 % Tr), (int32_t)(vt0 / Tr)} : PairPos{0, 0};
+    auto next_pair = [&](PairPos& p) __attribute__((always_inline)) { if (++p.rt == Tr) { p.rt = 0; ++p.qt; } };
+    PairPos fc_pos = pos0, fq_pos = pos0, c_pos = pos0;
     const int total = nt * nslab;  // K slabs this workgroup consumes, tile after tile
     const int32_t last_blk = (int32_t)((n_rows + 15) >> 4) - 1;
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
@@ -169,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     int fq_s = 0, fq_slot = 0, fc_s = 0, fc_tile = 0, fc_slot = 0;
     auto feed_tile = [&](int t) __attribute__((always_inline)) {
         if constexpr (DBG & 64) t = 0;  // (timing: the corpus stream out of L2)
-        const int32_t b0 = ((org + t * PP_RT) >> 4) + CPW * (wv & 3);
+        const int32_t b0 = ((ROWS ? fc_pos.rt * PP_RT : org + t * PP_RT) >> 4) + CPW * (wv & 3);
 #pragma unroll
         for (int i = 0; i < CPW; ++i) {
             int32_t blk = b0 + i;
@@ -178,20 +237,35 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         }
     };
     feed_tile(0);
+    // query pieces of a tile's query tile (MODE 0: the pass' 16 queries; MODE 2: groups 16 qt .. 16 qt + 15)
+    int fq_tile = 0;
+    auto feed_q = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < QPW; ++i) {
-        const int p = QPW * (wv & 3) + i;
-        int ql = p >> 1;
-        ql = ql < n_q ? ql : n_q - 1;  // (clamped: pieces of queries the pass does not have are copied from a valid one, never used)
-        qb1[i] = qfrag + pp_uniform_i64(((int64_t)ql * nslab * 4 + 2 * (p & 1)) * 1024);  // hi fragments of block p & 1
-    }
+        for (int i = 0; i < QPW; ++i) {
+            const int p = QPW * (wv & 3) + i;
+            int ql = 16 * fq_pos.qt + (p >> 1);
+            ql = ql < n_q ? ql : n_q - 1;  // (clamped: pieces of queries the pass does not have are copied from a valid one, never used)
+            qb1[i] = qfrag + pp_uniform_i64(((int64_t)ql * nslab * 4 + 2 * (p & 1)) * 1024);  // hi fragments of block p & 1
+        }
+    };
+    feed_q();
     auto issue_q = [&](int i) __attribute__((always_inline)) {
         if (!feeder) return;
         if constexpr (DBG & 32) return;
         pp_dma<false>(lds_base + (uint32_t)(PP_QOFF + fq_slot * PP_QSLOT + (QPW * wv + i) * 1024), qb1[i] + (int64_t)fq_s * 4096, lane16);
     };
     auto advance_q = [&]() __attribute__((always_inline)) {
-        if (++fq_s == nslab) fq_s = 0;
+        if (++fq_s == nslab) {
+            fq_s = 0;
+            if constexpr (ROWS) {  // the next pair may belong to the next query tile (once or twice per workgroup)
+                if (fq_tile + 1 < nt) {
+                    ++fq_tile;
+                    const int32_t before = fq_pos.qt;
+                    next_pair(fq_pos);
+                    if (fq_pos.qt != before) feed_q();
+                }
+            }
+        }
         fq_slot = fq_slot + 1 == PP_DQ ? 0 : fq_slot + 1;
     };
     auto issue_c1 = [&](int i) __attribute__((always_inline)) {
@@ -202,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     auto advance_c = [&]() __attribute__((always_inline)) {
         if (++fc_s == nslab) {  // past the end: re-fetch the last tile (keeps the vmcnt bookkeeping uniform)
             fc_s = 0;
-            if (fc_tile + 1 < nt) { ++fc_tile; feed_tile(fc_tile); }
+            if (fc_tile + 1 < nt) { ++fc_tile; next_pair(fc_pos); feed_tile(fc_tile); }
         }
         fc_slot = fc_slot + 1 == PP_DC ? 0 : fc_slot + 1;
     };
@@ -332,9 +406,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     float run = -INFINITY;  // maximum over the rows of the chunk still open, for this lane's query vector; lives across blocks and tiles
     uint32_t prev_last_end = 1;  // the row before the workgroup's first block closes a chunk as far as this workgroup is concerned
     // chunk ordinal of the next chunk to finish: no chunk is empty, so it advances by one per chunk end -- one scalar load per workgroup
-    int32_t ord_run = __builtin_amdgcn_readfirstlane(row_to_chunk[org]);
+    int32_t ord_run = ROWS ? 0 : __builtin_amdgcn_readfirstlane(row_to_chunk[org]);
     const int e_q = fG >> 1;
-    const bool e_has = (e_q == 0 ? has0 : has1) && (ft & 1) == 0;  // (lanes t and t ^ 1 hold the same sum)
+    const bool e_has = !ROWS && (e_q == 0 ? has0 : has1) && (ft & 1) == 0;  // (lanes t and t ^ 1 hold the same sum)
     const float e_unscale = e_has ? qmeta[2 * (2 * wv + e_q)] * inv_e_scale : 0.f;
     float* const e_out = out + (int64_t)(e_has ? 2 * wv + e_q : 0) * out_stride;
     const uint64_t odd_pairs = 0xccccccccccccccccull;  // lanes with t >= 2
@@ -435,8 +509,140 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) acc[q][qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
     };
+
+    // ---- MODE 2 tile epilogue: threshold test of every accumulator, records into the wave-private log ---------------------------------------
+    // Register (c = 2 q + qb, a, u), lane (g, n) = corpus row 16 a + 4 g + u of the tile against query 32 (16 qt + 2 wv + q) + 16 qb + n.
+    // T4[c]: a lower bound of what the raw accumulator must reach (cosine: divided by the row's |e|), per lane, recomputed when the query
+    // tile changes: the statements of maxsim_gemm.hip's epilogue_cand (1e-5 of slack for the roundings of 1 - (1 - c); thresholds of
+    // queries past B are +inf).  Cosine: acc >= T |e_row| follows from acc >= min(T min|e|, T max|e|) over the row's 16-row block.
+    [[maybe_unused]] float T4[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+    [[maybe_unused]] int cur_qt = -1;
+    [[maybe_unused]] uint32_t ncand = 0;  // wave-uniform: records this wave has logged
+    [[maybe_unused]] uint2* const my_log = ROWS ? rs.log + ((size_t)blockIdx.x * 8 + wv) * (size_t)rs.log_cap : nullptr;
+    [[maybe_unused]] auto epilogue_rows = [&](int t) __attribute__((always_inline)) {
+        if constexpr (ROWS) {
+            const int32_t row0 = c_pos.rt * PP_RT;
+            const int qt = c_pos.qt;
+            const bool cosine = rs.metric == SCAN_COSINE;
+            // Opaque copies of the lane coordinates: with the plain values every record word below (128 of them) is loop-invariant, the
+            // compiler hoists them out of the K loop and spills them (the note in maxsim_gemm.hip's epilogue_cand)
+            int ln = lane & 15;
+            uint32_t lane_code = ((uint32_t)(lane & 15) << 7) | (uint32_t)(4 * (lane >> 4));  // (query column, first row of the lane's quad)
+            asm volatile("" : "+v"(ln), "+v"(lane_code));
+            if (qt != cur_qt) {  // (wave-uniform; once or twice per workgroup: the loads below drain the feeders' look-ahead, rarely)
+                cur_qt = qt;
+                bool bad = false;
+                float l_us[4], l_tq[4], l_ss[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int32_t q = (16 * qt + 2 * wv + (c >> 1)) * 32 + 16 * (c & 1) + ln;
+                    const int32_t qc = q < rs.B ? q : rs.B - 1;
+                    l_us[c] = pp_gload(rs.q_unscale + qc);
+                    l_tq[c] = pp_gload(rs.tau + qc);
+                    l_ss[c] = cosine ? pp_gload(rs.q_sumsq + qc) : 0.f;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    pp_pin1(l_us[c]);
+                    pp_pin1(l_tq[c]);
+                    pp_pin1(l_ss[c]);
+                    const int32_t q = (16 * qt + 2 * wv + (c >> 1)) * 32 + 16 * (c & 1) + ln;
+                    const float us = l_us[c] * inv_e_scale;  // > 0, a power of two
+                    const float tq = l_tq[c];
+                    bad |= q < rs.B && !(tq > -INFINITY);  // NaN or -inf: unusable
+                    const float slack = 1e-5f * fmaxf(1.0f, fabsf(tq));
+                    const float t_dot = cosine ? (tq - slack) * sqrtf(l_ss[c]) : (tq - 1.0f) - slack;  // bound on d (cosine: on d / |e|)
+                    T4[c] = q < rs.B ? (t_dot - fabsf(t_dot) * 1e-6f) / us : INFINITY;
+                }
+                if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *rs.overflow = 1u;
+            }
+            int n_st = 0;
+            f32x16 mm16 = {};
+            if (cosine) mm16 = pp_sload16(rs.blk_minmax + 2 * (row0 >> 4));  // (min, max) |e| of the tile's eight blocks
+            [&]<int... A>(std::integer_sequence<int, A...>) {
+                ([&] {
+                    constexpr int a = A;
+                    const int32_t base = row0 + 16 * a;
+                    if (base < (int32_t)n_rows) {  // (wave-uniform) blocks past the corpus are re-reads of its last block: not scored
+                        float t4[4];
+                        if (cosine) {
+                            // two scalars per block, slightly widened: T * |e| is formed with one rounding here and none in the exact test
+                            const float nmin = mm16[2 * a] * 0.999999f, nmax = mm16[2 * a + 1] * 1.000001f;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) t4[c] = fminf(T4[c] * nmin, T4[c] * nmax);
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) t4[c] = T4[c];
+                        }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            // one test per (block, query column) on the largest of the lane's four rows; the rare group that has a hit
+                            // (~0.2 % of the scores reach a threshold: about every other group of 256) is looked at register by register
+                            const f32x4 v4 = acc[c >> 1][c & 1][a];
+                            const float top = fmaxf(fmaxf(v4[0], v4[1]), fmaxf(v4[2], v4[3]));
+                            if (__builtin_amdgcn_ballot_w64(top >= t4[c]) != 0ull) {  // (wave-uniform)
+                                const uint32_t code = ((uint32_t)t << 13) | ((uint32_t)c << 11) | (uint32_t)(16 * a);
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const bool pass = v4[u] >= t4[c];
+                                    const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
+                                    if (mask != 0ull) {
+                                        const uint32_t pos = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                                        if (pass && pos < (uint32_t)rs.log_cap) my_log[pos] = make_uint2(__float_as_uint(v4[u]), (code + (uint32_t)u) | lane_code);
+                                        ncand += (uint32_t)__builtin_popcountll(mask);
+                                        ++n_st;
+                                    }
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+#pragma unroll
+                        for (int qb = 0; qb < 2; ++qb) acc[q][qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    __builtin_amdgcn_sched_barrier(0);  // one block at a time
+                }(), ...);
+            }(std::make_integer_sequence<int, PP_NBLK>{});
+            // the log stores are newer than every DMA issued so far: they count in the feeders' next two waits (see certify())
+            st_pending = n_st;
+            st_slabs = n_st > 0 ? 2 : 0;
+        }
+    };
+    // When the workgroup's pairs are done: every record once more with the exact formulas (maxsim_gemm.hip flush_candidates: same
+    // statements, same bits), kept if it reaches its query's threshold exactly, appended to the query's list.
+    [[maybe_unused]] auto flush_rows = [&]() __attribute__((always_inline)) {
+        if constexpr (ROWS) {
+            if (ncand > (uint32_t)rs.log_cap) {  // (wave-uniform) more than the log holds: let the dense path decide
+                if (lane == 0) *rs.overflow = 1u;
+                ncand = (uint32_t)rs.log_cap;
+            }
+            const int mode = rs.metric;
+            for (uint32_t i = lane; i < ncand; i += 64) {
+                const uint2 rec = my_log[i];
+                const uint32_t m = rec.y;
+                const int t = (int)(m >> 13), c = (int)((m >> 11) & 3u), n = (int)((m >> 7) & 15u), r = (int)(m & 127u);
+                const int32_t pair = vt0 + t;  // (one division per RECORD, after the loop: ~1 400 per wave)
+                const int32_t q = (16 * (pair / Tr) + 2 * wv + (c >> 1)) * 32 + 16 * (c & 1) + n, row = (pair % Tr) * PP_RT + r;
+                if (q >= rs.B || row >= (int32_t)n_rows) continue;
+                const float d = __uint_as_float(rec.x) * (rs.q_unscale[q] * inv_e_scale);  // the dot product, as MODE 1 of maxsim_gemm.hip forms it
+                float v = d;
+                if (mode == SCAN_COSINE) v = 1.0f - (1.0f - d / (rs.row_norm[row] * sqrtf(rs.q_sumsq[q])));
+                else if (mode == SCAN_DOT) v = 1.0f + d;
+                if (!(v >= rs.tau[q])) continue;  // (the block-wide cosine test is a superset)
+                const uint32_t slot = atomicAdd(rs.cand_cnt + q, 1u);
+                if (slot < (uint32_t)rs.cap) {
+                    rs.cand_scores[(int64_t)q * rs.cap + slot] = v;
+                    rs.cand_ids[(int64_t)q * rs.cap + slot] = row;
+                } else {
+                    *rs.overflow = 1u;
+                }
+            }
+        }
+    };
     auto epilogue = [&](int t) __attribute__((always_inline)) {
         if constexpr (DBG & 128) return;
+        if constexpr (ROWS) { epilogue_rows(t); return; }
         tile_now = t;
         stamp(0);
         const int32_t row0 = org + t * PP_RT;
@@ -479,24 +685,29 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     // ---- main loop: two slabs per iteration (two static sets of query fragment registers) -----------------------------------------
     int c_s = 0, c_tile = 0;
     auto main_loop = [&](auto LAG_) __attribute__((always_inline)) {
-        auto step = [&](f32x4 (&q)[4], f32x4 (&qn)[4]) __attribute__((always_inline)) {
+        // MODE 2 needs an even number of K slabs (dim % 64 == 0): a tile then ends in the SECOND step of an iteration only, and the long
+        // epilogue is instantiated once per loop instead of twice (the kernel's code has to stay inside the instruction cache)
+        auto step = [&](f32x4 (&q)[4], f32x4 (&qn)[4], auto CHECK_) __attribute__((always_inline)) {
             slab(q, qn, LAG_);
-            if (++c_s == nslab) {
+            ++c_s;
+            if (decltype(CHECK_)::value && c_s == nslab) {
                 epilogue(c_tile);
                 c_s = 0;
                 ++c_tile;
+                if constexpr (ROWS) next_pair(c_pos);
             }
             landed(qn);
         };
         for (int g = 0; g < total; g += 2) {
-            step(qA, qB);
-            if (g + 1 < total) step(qB, qA);
+            step(qA, qB, std::integral_constant<bool, !ROWS>{});
+            if (ROWS || g + 1 < total) step(qB, qA, std::true_type{});
         }
     };
     constexpr bool no_lag = (DBG & 1024) != 0;  // (timing: every wave runs the same stream)
     if (wv < 4 || no_lag) main_loop(std::false_type{});
     else main_loop(std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
+    flush_rows();
     if constexpr (DBG & 128) {  // (timing without the epilogue: the accumulators must stay live, or the compiler deletes the MFMAs with it)
         if (n_q > 1000) {
             f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -524,15 +735,20 @@ int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void*
     const float* qmeta = reinterpret_cast<const float*>(static_cast<const char*>(qbuf) + (size_t)n_queries * dim * 128) + 2 * (size_t)first;
     const int64_t tiles = (n_rows + PP_RT - 1) / PP_RT;
     const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
-    static const int dbg = std::getenv("RAGLITE_PP_DBG") ? std::atoi(std::getenv("RAGLITE_PP_DBG")) : 0;  // timing experiments only
-    static unsigned long long* trace = [] {
+    unsigned long long* trace = nullptr;
+#define RL_PP_LAUNCH(DBG_)                                                                                                              \
+    hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 0>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk, \
+                       chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if, trace, PpRows{})
+#ifdef RAGLITE_EXPERIMENTS
+    // Experiment builds only (libraglite_hip_exp.so, scripts/gpu_calls/): instantiations that skip parts of the kernel to time the rest --
+    // WRONG results -- and the s_memtime trace of one tile's epilogue.  None of this is compiled into the shipped library.
+    static const int dbg = std::getenv("RAGLITE_PP_DBG") ? std::atoi(std::getenv("RAGLITE_PP_DBG")) : 0;
+    static unsigned long long* trace_buf = [] {
         unsigned long long* p = nullptr;
         if (std::getenv("RAGLITE_PP_TRACE")) { (void)hipMalloc(&p, 8 * 16 * 8); (void)hipMemset(p, 0, 8 * 16 * 8); }
         return p;
     }();
-#define RL_PP_LAUNCH(DBG_)                                                                                                              \
-    hipLaunchKernelGGL(maxsim_pp_kernel<DBG_>, grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk, \
-                       chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if, trace)
+    trace = trace_buf;
     if (trace) {
         static int calls = 0;
         RL_PP_LAUNCH(8192);
@@ -559,7 +775,71 @@ int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void*
     else if (dbg == 184) RL_PP_LAUNCH(184);
     else if (dbg == 128) RL_PP_LAUNCH(128);
     else RL_PP_LAUNCH(0);
+#else
+    RL_PP_LAUNCH(0);
+#endif
 #undef RL_PP_LAUNCH
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// ---- MODE 2: the candidate pass of the fused exact row top-k on the sixteen-group tile ---------------------------------------------------
+// min / max |e| over every 16-row block of the image (rows past n_rows do not count): what the cosine test of the tile epilogue multiplies
+__global__ __launch_bounds__(256) void block_norm_minmax_kernel(const float* __restrict__ row_norm, int64_t n_rows, int64_t n_blocks,
+                                                                 float* __restrict__ out) {
+    const int64_t blk = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (blk >= n_blocks) return;
+    float mn = INFINITY, mx = 0.f;
+    for (int i = 0; i < 16; ++i) {
+        const int64_t r = blk * 16 + i;
+        if (r < n_rows) { const float v = row_norm[r]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+    }
+    out[2 * blk] = mn;
+    out[2 * blk + 1] = mx;
+}
+
+size_t pp_rows_scratch_bytes(int64_t n_rows, int32_t nb, int n_cu, int32_t expected_per_query, int32_t* log_cap_out) {
+    const int64_t grid = n_cu > 0 ? n_cu : 256;
+    // records a wave logs: expected_per_query * nb over grid * 8 waves, x 4 for the block-wide cosine test and uneven data; at least 4096
+    int64_t cap = ((int64_t)expected_per_query * nb * 4) / (grid * 8) + 1;
+    cap = std::max<int64_t>(4096, (cap + 1023) & ~int64_t(1023));
+    cap = std::min<int64_t>(cap, int64_t(1) << 19);  // (the record's tile index has 19 bits; 4 MiB per wave is past any sensible list anyway)
+    if (log_cap_out) *log_cap_out = (int32_t)cap;
+    const size_t blocks = (size_t)((n_rows + 15) / 16);
+    return (size_t)grid * 8 * (size_t)cap * sizeof(uint2) + blocks * 2 * sizeof(float) + 256;
+}
+
+// The candidate pass of the fused top-k (maxsim_gemm.hip MODE 2 semantics: per-query lists of (similarity, row) for every row whose
+// similarity reaches cand->tau[q]) over a ONE-PLANE image at one product per multiply, on the 128-row x 512-query tile.  `scratch`: the
+// query side as launch_score_planes_queries left it; `work`: pp_rows_scratch_bytes bytes.  cosine / dot; dim % 64 == 0, dim >= 256.
+int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, const float* row_norm, int mode,
+                        const CandArgs* cand, void* work, int32_t log_cap, int n_cu, hipStream_t s, float split_scale) {
+    if (nb < 1 || n_rows < 1 || dim % 64 || dim < 256 || !(split_scale > 0.f) || !image || !cand || !work) return RL_ERR_UNSUPPORTED;
+    if (mode != SCAN_COSINE && mode != SCAN_DOT) return RL_ERR_UNSUPPORTED;
+    if (mode == SCAN_COSINE && !row_norm) return RL_ERR_INVALID;
+    if (cand->tau_stride != 1) return RL_ERR_UNSUPPORTED;
+    const int32_t nslab = dim / 32, groups = (nb + 31) / 32;
+    float* frag = scratch;  // the layout of launch_score_planes_queries
+    float* unscale = frag + (size_t)groups * 32 * dim;
+    float* anylo = unscale + nb;
+    float* qss = anylo + groups;
+    const int64_t grid_cu = n_cu > 0 ? n_cu : 256;
+    const int64_t Tr = (n_rows + PP_RT - 1) / PP_RT;
+    PpRows rs{};
+    rs.tau = cand->tau; rs.q_unscale = unscale; rs.q_sumsq = qss; rs.row_norm = row_norm; rs.B = nb; rs.QT = (groups + PP_QPP - 1) / PP_QPP;
+    rs.metric = mode; rs.cand_scores = cand->scores; rs.cand_ids = cand->ids; rs.cand_cnt = cand->cnt; rs.overflow = cand->overflow; rs.cap = cand->cap;
+    rs.log = static_cast<uint2*>(work);
+    rs.log_cap = log_cap;
+    if (Tr * rs.QT / std::max<int64_t>(1, std::min<int64_t>(grid_cu, Tr * rs.QT)) + 2 >= (int64_t(1) << 19)) return RL_ERR_UNSUPPORTED;  // tile index bits of a record
+    float* blk_mm = reinterpret_cast<float*>(static_cast<char*>(work) + (size_t)grid_cu * 8 * (size_t)log_cap * sizeof(uint2));
+    rs.blk_minmax = blk_mm;
+    if (mode == SCAN_COSINE) {
+        const int64_t n_blocks = (n_rows + 15) / 16;
+        hipLaunchKernelGGL(block_norm_minmax_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, s, row_norm, n_rows, n_blocks, blk_mm);
+    }
+    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(grid_cu, Tr * rs.QT))), blk(512);
+    hipLaunchKernelGGL((maxsim_pp_kernel<0, 2>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, reinterpret_cast<const char*>(frag),
+                       nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, nullptr, nullptr, rs);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

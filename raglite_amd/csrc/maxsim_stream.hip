@@ -1013,9 +1013,10 @@ static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t d
     if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
     const int64_t tiles = (n_rows + TR - 1) / TR;
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles));
+#ifdef RAGLITE_EXPERIMENTS  // the tile-timeline build of the kernel exists in experiment builds only
     static unsigned long long* trace = [] {
         unsigned long long* p = nullptr;
-        if (std::getenv("RAGLITE_HIP_TRACE")) { (void)hipMalloc(&p, 8 * 8 * 8 * 8); (void)hipMemset(p, 0, 8 * 8 * 8 * 8); }
+        if (exp_env("RAGLITE_HIP_TRACE")) { (void)hipMalloc(&p, 8 * 8 * 8 * 8); (void)hipMemset(p, 0, 8 * 8 * 8 * 8); }
         return p;
     }();
     if (trace && !f16 && mode == 0 && nq > 16 && dim == 1024) {  // diagnostic build: dump the 30th launch's timeline to stderr
@@ -1042,6 +1043,7 @@ static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t d
         }
         return RL_OK;
     }
+#endif
     const StreamArgs a{D, n_rows, Q, (int)nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, dim3(grid), s,
                        reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(run_if)), split_scale};
     const bool split = !f16 && split_scale > 0.f;  // 0: the exact fp32 MFMA chain
@@ -1099,9 +1101,10 @@ int launch_maxsim_stream2(const void* Dv, bool f16, int64_t n_rows, int32_t dim,
     const float* qmeta = reinterpret_cast<const float*>(static_cast<const char*>(split_buf) + (size_t)n_queries * per_query * 16) + (size_t)first * 8;
     const int64_t tiles = (n_rows + TR - 1) / TR;
     const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
+#ifdef RAGLITE_EXPERIMENTS  // the tile-timeline build of the kernel exists in experiment builds only
     static unsigned long long* trace = [] {
         unsigned long long* p = nullptr;
-        if (std::getenv("RAGLITE_HIP_TRACE2")) { (void)hipMalloc(&p, 4096); (void)hipMemset(p, 0, 4096); }
+        if (exp_env("RAGLITE_HIP_TRACE2")) { (void)hipMalloc(&p, 4096); (void)hipMemset(p, 0, 4096); }
         return p;
     }();
     if (trace && dim == 1024 && !f16) {  // diagnostic build: dump the 30th launch's tile timeline to stderr
@@ -1122,6 +1125,7 @@ int launch_maxsim_stream2(const void* Dv, bool f16, int64_t n_rows, int32_t dim,
         }
         return RL_OK;
     }
+#endif
 #define RL_STREAM2(KW) do { if (f16) hipLaunchKernelGGL((maxsim_stream2_kernel<KW, false, true>), grid, blk, 0, s, D, n_rows, qfrag, qmeta, \
                                                         (int)nq, row_to_chunk, chunk_offsets, n_chunks, out, out_stride, 1.f, nullptr); \
                             else hipLaunchKernelGGL((maxsim_stream2_kernel<KW, false, false>), grid, blk, 0, s, D, n_rows, qfrag, qmeta, \

@@ -347,14 +347,14 @@ int launch_pool_norm(const float* tokens, int32_t dim, const int64_t* sb, const 
                      int normalize, double eps, float* o32, uint16_t* o16, hipStream_t s) {
     if (n_spans <= 0) return RL_OK;
     // dim = 256 * NV with fp32-vector-aligned buffers: the LDS-DMA stream (RAGLITE_POOL_VGPR=1 keeps the register-staged kernel)
-    static const bool vgpr_only = std::getenv("RAGLITE_POOL_VGPR") != nullptr;
+    static const bool vgpr_only = exp_env("RAGLITE_POOL_VGPR") != nullptr;
     if (!vgpr_only && (dim == 256 || dim == 512 || dim == 1024) && n_spans >= 64 && (reinterpret_cast<uintptr_t>(tokens) & 15) == 0 &&
         (!o32 || (reinterpret_cast<uintptr_t>(o32) & 15) == 0) && (!o16 || (reinterpret_cast<uintptr_t>(o16) & 7) == 0)) {
         if (unsigned int* counter = next_span_counter(s)) {
             int n_cu = 256, dev = 0;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
             const int blocks = (int)std::min<int64_t>(n_cu, (n_spans + 63) / 64);
-            static const int tune = std::getenv("RAGLITE_POOL_BATCH") ? std::atoi(std::getenv("RAGLITE_POOL_BATCH")) : 0;
+            static const int tune = exp_env("RAGLITE_POOL_BATCH") ? std::atoi(exp_env("RAGLITE_POOL_BATCH")) : 0;
             // (A workgroup-cooperative stream -- one contiguous row range per workgroup, tiles of 8 rows, finisher waves -- streamed at
             // 6.9 TB/s with the spans left unfinished but landed where this kernel is once they were finished, 2.38 vs 2.37 ms, wherever the
             // finishing arithmetic ran: profiles/r02_pool_experiments.txt, DESIGN.md 4.9.  Removed in round 3.)

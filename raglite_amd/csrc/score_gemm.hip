@@ -536,7 +536,7 @@ int launch_score_gemm(const float* E, int64_t n_rows, int32_t dim, const float* 
         float* Qs = q_sumsq_scratch + (((size_t)2 * nb + 7) & ~(size_t)7);  // 32-B aligned behind q_sumsq and q_scale
         if (reinterpret_cast<uintptr_t>(Qs) & 15) return RL_ERR_UNSUPPORTED;
         hipLaunchKernelGGL(query_presplit_kernel, dim3(nb), dim3(256), 0, s, Q, (int)dim, q_scale, reinterpret_cast<uint4*>(Qs));
-        static const bool tile128 = std::getenv("RAGLITE_GEMM_TILE128") != nullptr;  // A/B switch
+        static const bool tile128 = exp_env("RAGLITE_GEMM_TILE128") != nullptr;  // A/B switch
         if (!tile128 && nb > GM) {  // 128 x 256 tiles: 25 % fewer bytes into the CU per flop
             const int32_t QT2 = (nb + GM2 - 1) / GM2;
             const int64_t n_tiles2 = ((RT + 7) / 8) * 8 * QT2;

@@ -83,9 +83,9 @@ def cfg2():
     # index keeps one, else the fp32 stream pass (4 B per element)
     try:
         ms_scan, streamed, kernel = idx.time_kernel(4, q[:1], 20) / 20, 2.0 * n * d, "maxsim_stream_kernel<256, 1, 1, false, 6, true, false> over the HI plane"
-    except Exception:  # noqa: BLE001 - no HI plane (RAGLITE_NO_HI_PLANE / RAGLITE_NO_HI_SEARCH runs)
+    except Exception:  # noqa: BLE001 - no HI plane (keep_hi = 0 / hi_search = 0 runs)
         ms_scan, streamed, kernel = idx.time_kernel(1, q[:1], 20) / 20, 4.0 * n * d, "maxsim_stream_kernel<256, 1, 1, false, 6, false, true>"
-    if os.environ.get("RAGLITE_NO_HI_SEARCH"):
+    if not idx.get_option("hi_search"):
         ms_scan, streamed, kernel = idx.time_kernel(1, q[:1], 20) / 20, 4.0 * n * d, "maxsim_stream_kernel<256, 1, 1, false, 6, false, true>"
     # spot check + CPU reference: the fp32 NumPy oracle over the FULL corpus for 2 queries
     Eh = E.cpu().numpy()
@@ -224,17 +224,41 @@ def cfg5():
         rec.append(_recall(rr, r[b]))
         err.append(float(np.abs(np.asarray(rs) - s[b]).max()))
     arith = idx.arithmetic
+    stats = idx.filter_stats() if hasattr(idx, "filter_stats") else {"kind": "none"}
+    # Which route ran decides what the matrix pipe executed per multiply: the fused top-k over the HI image multiplies q_hi . e_hi ONCE
+    # (rows_fused_hi: a plain fp16 GEMM; the exact fp32 similarities are computed for the ~k + a few dozen candidates only), the fused
+    # top-k over the pre-split image three times (rows_fused), the dense fp16-split GEMM three times, the exact-fp32 chain once on the
+    # fp32 pipe.  The roofline line prices EXACTLY that -- not the fp32-equivalent work.
+    route = stats["kind"]
+    split = arith == "f16_split"
+    products = 1.0 if route == "rows_fused_hi" else (3.0 if split else 1.0)
+    kernel, kernel_ms = None, None
+    if route == "rows_fused_hi":
+        try:  # the candidate pass alone, replayed with the thresholds of the search above, HIP events on the stream it runs on
+            idx.time_kernel(8, Q[:1], 2)
+            kernel_ms = idx.time_kernel(8, Q[:1], 10) / 10
+            kernel = ("maxsim_pp_kernel<0, 2> (candidate pass on the 128-row x 512-query tile over the HI image)" if idx.get_option("fused_pp") and d % 64 == 0
+                      else "maxsim_gemm_kernel<2, false, 2, true, true> (candidate pass on the 256 x 256 tile over the HI image)")
+        except Exception as exc:  # noqa: BLE001
+            kernel = f"(not timed: {exc})"
     idx.close()
     fp32_flops = 2.0 * B * n * d
-    split = arith == "f16_split"
-    achieved = (3.0 if split else 1.0) * fp32_flops / (ms * 1e-3) / 1e12
+    peak = MFMA_F16_PEAK if (split or route == "rows_fused_hi") else MFMA_F32_PEAK
+    achieved = products * fp32_flops / (ms * 1e-3) / 1e12
+    roof = {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+            "mfma_products_per_multiply": products, "route": route,
+            "note": "whole batch incl. sample pass, list ranking, exact re-scoring and selection; flops = products x 2 x B x N x d as the launched kernels execute them",
+            "fp32_equivalent_tflops": fp32_flops / (ms * 1e-3) / 1e12}
+    if kernel_ms:
+        k_ach = products * fp32_flops / (kernel_ms * 1e-3) / 1e12
+        roof.update({"kernel": kernel, "kernel_ms": float(kernel_ms), "kernel_achieved": k_ach, "kernel_frac": k_ach / peak})
+    elif kernel:
+        roof["kernel"] = kernel
     return {
         "workload": "cfg5 (one of 8 shards): 1.25M x 1024 fp32, B=1000 cosine exact top-100", "value": B / (ms * 1e-3),
         "unit": "queries/s over this shard", "ms_per_batch": float(ms), "timing": ms.stats, "arithmetic": arith,
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK if split else MFMA_F32_PEAK, "unit": "TFLOP/s",
-                     "frac": achieved / (MFMA_F16_PEAK if split else MFMA_F32_PEAK),
-                     "note": "whole batch incl. exact selection; 3 fp16 MFMA products per fp32-equivalent multiply in split arithmetic",
-                     "fp32_equivalent_tflops": fp32_flops / (ms * 1e-3) / 1e12},
+        "roofline": roof, "candidates_per_query": {"mean": stats.get("candidates_per_query_mean"), "max": stats.get("candidates_per_query_max"),
+                                                   "list_capacity": stats.get("list_capacity"), "fallback": stats.get("fallback")},
         "check": {"recall_at_100": float(np.mean(rec)), "score_max_abs_err": float(np.max(err)), "queries": 3,
                   "against": "fp32 NumPy oracle, full shard"},
     }

@@ -17,10 +17,7 @@ idx = raglite_amd.DeviceIndex(E, metric="cosine")
 for B in (1, 4, 8, 16, 32):
     row = []
     for off in ("", "1"):
-        if off:
-            os.environ["RAGLITE_NO_HI_SEARCH"] = "1"
-        else:
-            os.environ.pop("RAGLITE_NO_HI_SEARCH", None)
+        idx.set_option("hi_search", 0 if off else 1)
         q = Q[:B] if B > 1 else Q[0]
         for _ in range(3):
             idx.search_rows(q, k)
@@ -33,4 +30,4 @@ for B in (1, 4, 8, 16, 32):
         torch.cuda.synchronize()
         row.append(e0.elapsed_time(e1) / 20)
     print(f"B = {B:3d}: half-bytes {row[0]:7.3f} ms ({B / row[0] * 1e3:8.0f} q/s)   full precision {row[1]:7.3f} ms ({B / row[1] * 1e3:8.0f} q/s)", flush=True)
-os.environ.pop("RAGLITE_NO_HI_SEARCH", None)
+idx.set_option("hi_search", 1)

@@ -27,21 +27,6 @@ def _tol(E, q, metric):
     return TOL * max(1.0, float(np.linalg.norm(E, axis=1).max() * np.linalg.norm(q)))
 
 
-class _env:
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        os.environ.update(self.kv)
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
 
 @pytest.mark.parametrize("metric", ["cosine", "dot"])
 @pytest.mark.parametrize("n,dim,B,k", [(4096, 64, 96, 10), (5000, 128, 128, 100), (20_001, 384, 200, 7), (70_000, 1024, 97, 512),
@@ -50,9 +35,9 @@ def test_fused_equals_dense_path_bitwise(metric, n, dim, B, k):
     E = oracle.synth_matrix(7000 + n, n, dim)
     Q = oracle.synth_matrix(7100 + B, B, dim)
     idx = raglite_amd.DeviceIndex(E, metric=metric)
-    with _env(RAGLITE_NO_FUSED_HI="1"):  # (the 70 000 x 1024 case keeps a HI image: its default is the fused top-k over THAT, tested below)
+    with idx.options(fused_hi=0):  # (the 70 000 x 1024 case keeps a HI image: its default is the fused top-k over THAT, tested below)
         S, R = idx.search_rows(Q, k)
-    with _env(RAGLITE_NO_FUSED_TOPK="1"):
+    with idx.options(fused_topk=0):
         S0, R0 = idx.search_rows(Q, k)
     assert np.array_equal(R, R0)
     assert np.array_equal(S.view(np.uint32), S0.view(np.uint32))
@@ -74,7 +59,7 @@ def test_fused_integer_ties_bit_exact(metric):
         es, ei = oracle.topk_desc(sim_fp32_exact(E, Q[b], metric), k)
         assert np.array_equal(R[b], ei)
         assert np.array_equal(S[b].view(np.uint32), es.astype(np.float32).view(np.uint32))
-    with _env(RAGLITE_NO_FUSED_TOPK="1"):
+    with idx.options(fused_topk=0):
         S0, R0 = idx.search_rows(Q, k)
     assert np.array_equal(R, R0) and np.array_equal(S.view(np.uint32), S0.view(np.uint32))
     idx.close()
@@ -99,9 +84,9 @@ def test_forced_list_overflow_falls_back_exactly(cap):
     E = oracle.synth_matrix(7400, n, dim)
     Q = oracle.synth_matrix(7401, B, dim)
     idx = raglite_amd.DeviceIndex(E, metric="cosine")
-    with _env(RAGLITE_NO_FUSED_TOPK="1"):
+    with idx.options(fused_topk=0):
         S0, R0 = idx.search_rows(Q, k)
-    with _env(RAGLITE_FUSED_TOPK_CAP=cap):
+    with idx.options(fused_topk_cap=int(cap)):
         S, R = idx.search_rows(Q, k)
     assert np.array_equal(R, R0) and np.array_equal(S.view(np.uint32), S0.view(np.uint32))
     S, R = idx.search_rows(Q, k)  # and the flag is re-armed per call: the next batch takes the lists again
@@ -119,7 +104,7 @@ def test_fused_after_append_and_delete():
     idx.append(E[8000:])
     S, R = idx.search_rows(Q, k)
     ref = raglite_amd.DeviceIndex(E, metric="cosine")
-    with _env(RAGLITE_NO_FUSED_TOPK="1"):
+    with ref.options(fused_topk=0):
         S0, R0 = ref.search_rows(Q, k)
     assert np.array_equal(R, R0) and np.array_equal(S.view(np.uint32), S0.view(np.uint32))
     for b in (0, 50, 99):
@@ -162,7 +147,7 @@ def test_f16_storage_big_batch_over_the_image(metric):
     Ev = E16.astype(np.float32)
     for b in (0, B - 1):
         assert_topk_close(S[b], R[b], oracle.similarity(Ev, Qf[b], metric), k, 1e-5 if metric == "l2" else _tol(Ev, Qf[b], metric))
-    with _env(RAGLITE_NO_FUSED_TOPK="1"):
+    with idx.options(fused_topk=0):
         S0, R0 = idx.search_rows(Qf, k)
     assert np.array_equal(R, R0) and np.array_equal(S.view(np.uint32), S0.view(np.uint32))
     idx.close()
@@ -181,7 +166,7 @@ def test_fused_hi_float_data(metric):
     idx = raglite_amd.DeviceIndex(E, metric=metric)
     S, R = idx.search_rows(Q, k)
     assert idx.filter_stats()["kind"] == "rows_fused_hi" and not idx.filter_stats()["fallback"]
-    with _env(RAGLITE_NO_FUSED_HI="1"):
+    with idx.options(fused_hi=0):
         S0, R0 = idx.search_rows(Q, k)  # the fused top-k over the pre-split image (three products)
     assert idx.filter_stats()["kind"] == "rows_fused"
     for b in range(0, B, 13):
@@ -219,7 +204,7 @@ def test_fused_hi_near_duplicates_fall_back():
     idx = raglite_amd.DeviceIndex(E, metric="dot")
     S, R = idx.search_rows(Q, k)
     assert idx.filter_stats()["kind"] == "rows_fused_hi" and idx.filter_stats()["fallback"]
-    with _env(RAGLITE_NO_FUSED_TOPK="1"):
+    with idx.options(fused_topk=0):
         S0, R0 = idx.search_rows(Q, k)
     assert np.array_equal(R, R0) and np.array_equal(S.view(np.uint32), S0.view(np.uint32))
     idx.close()

@@ -21,21 +21,6 @@ from tests.util import assert_topk_close, ragged_offsets
 pytestmark = pytest.mark.gpu
 
 
-class _env:
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        os.environ.update(self.kv)
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
 
 N, DIM = 70_000, 1024  # >= 64 M elements: the index keeps a HI image
 
@@ -64,7 +49,7 @@ def test_hi_maxsim_float_data_tombstones_and_switch():
     idx = raglite_amd.DeviceIndex(E, off, metric="dot")
     k = 100
     bs, bc = idx.maxsim_topk_batch(Qb, k)
-    with _env(RAGLITE_NO_HI_MAXSIM="1"):
+    with idx.options(hi_maxsim=0):
         fs, fc = idx.maxsim_topk_batch(Qb, k)
     for i in range(9):
         ref = oracle.maxsim_scores(E, off, Qb[i], np.float64)
@@ -95,7 +80,7 @@ def test_near_identical_chunks_defeat_the_bound_and_the_full_passes_answer():
     E[hot] = (3.0 * Qb[:, 0].sum(axis=0)[None, :] + 1e-4 * rng.standard_normal((4000, DIM))).astype(np.float32)
     idx = raglite_amd.DeviceIndex(E, off, metric="dot")
     bs, bc = idx.maxsim_topk_batch(Qb, 100)
-    with _env(RAGLITE_NO_HI_MAXSIM="1"):
+    with idx.options(hi_maxsim=0):
         fs, fc = idx.maxsim_topk_batch(Qb, 100)
     assert np.array_equal(bc, fc) and np.array_equal(bs.view(np.uint32), fs.view(np.uint32))
     assert np.isin(bc, hot).all()
@@ -115,8 +100,8 @@ def test_switches_integer_bit_exact(one, nopp):
     off = ragged_offsets(rng, N, 1, 15)
     E = oracle.synth_matrix(10_600, N, DIM, "small_int")
     Qb = np.stack([oracle.synth_matrix(10_700 + i, nq, DIM, "small_int") for i in range(n_queries)])
-    with _env(RAGLITE_HI_ONE_PRODUCT=one, RAGLITE_NO_PP=nopp):
-        idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    with idx.options(hi_products=1 if one == "1" else 2, pp_pass=0 if nopp == "1" else 1):
         bs, bc = idx.maxsim_topk_batch(Qb, k)
     for i in (0, 4, 8):
         ws, wc = oracle.maxsim_topk(E, off, Qb[i], k, np.float32)
@@ -132,11 +117,11 @@ def test_switches_float_data(one, nopp):
     E = oracle.synth_matrix(10_800, N, DIM)
     Qb = np.stack([oracle.synth_matrix(10_900 + i, 32, DIM) for i in range(9)])
     k = 100
-    with _env(RAGLITE_HI_ONE_PRODUCT=one, RAGLITE_NO_PP=nopp):
-        idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    with idx.options(hi_products=1 if one == "1" else 2, pp_pass=0 if nopp == "1" else 1):
         bs, bc = idx.maxsim_topk_batch(Qb, k)
         s1, r1 = idx.search_rows(Qb[0, 0], 50)  # the single-query half-bytes search reads the same halves and norms
-    with _env(RAGLITE_NO_HI_MAXSIM="1", RAGLITE_NO_HI_SEARCH="1"):
+    with idx.options(hi_maxsim=0, hi_search=0):
         fs, fc = idx.maxsim_topk_batch(Qb, k)
         s0, r0 = idx.search_rows(Qb[0, 0], 50)
     assert np.array_equal(r1, r0) and np.array_equal(s1.view(np.uint32), s0.view(np.uint32))
@@ -158,7 +143,7 @@ def test_one_product_fallback_on_near_identical_chunks():
     idx = raglite_amd.DeviceIndex(E, off, metric="dot")
     bs, bc = idx.maxsim_topk_batch(Qb, 100)
     assert idx.filter_stats()["fallback"]
-    with _env(RAGLITE_NO_HI_MAXSIM="1"):
+    with idx.options(hi_maxsim=0):
         fs, fc = idx.maxsim_topk_batch(Qb, 100)
     assert np.array_equal(bc, fc) and np.array_equal(bs.view(np.uint32), fs.view(np.uint32))
     idx.close()
@@ -277,7 +262,7 @@ def test_f16_stored_batch_integer_bit_exact(n_queries, nq, k):
         ws, wc = oracle.maxsim_topk(E, off, Qb[i], k, np.float32)
         assert np.array_equal(bc[i], wc), (i, bc[i][:8], wc[:8])
         assert np.array_equal(bs[i], ws)
-    with _env(RAGLITE_NO_HI_MAXSIM="1"):  # the eight-query two-product passes this replaces: the same bits on integer data
+    with idx.options(hi_maxsim=0):  # the eight-query two-product passes this replaces: the same bits on integer data
         s2, c2 = idx.maxsim_topk_batch(Qb, k)
     assert np.array_equal(bc, c2) and np.array_equal(bs, s2)
     idx.close()
@@ -313,7 +298,7 @@ def test_f16_stored_batch_float_data_bound_append_and_approx_scores():
     a, m = idx.maxsim_approx_scores(Q, kernel=0)
     err = (a.double() - ref).abs().max(dim=1).values
     assert bool((err <= m.double()).all()) and bool((m > 0).all())
-    with _env(RAGLITE_NO_HI_MAXSIM="1"):
+    with idx.options(hi_maxsim=0):
         s2, c2 = idx.maxsim_topk_batch(Q, k)
     assert torch.equal(c.to(torch.int64), c2.to(torch.int64))
     assert float((s - s2).abs().max()) <= 2e-6 * float(s.abs().max())

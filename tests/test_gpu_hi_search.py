@@ -18,21 +18,6 @@ from tests.util import assert_topk_close, sim_fp32_exact
 pytestmark = pytest.mark.gpu
 
 
-class _env:
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        os.environ.update(self.kv)
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
 
 def _same(a, b):
     return np.array_equal(np.asarray(a).view(np.uint32), np.asarray(b).view(np.uint32))
@@ -46,7 +31,7 @@ def test_hi_search_equals_full_pass_bitwise(metric, n, dim, B, k):
     Q = oracle.synth_matrix(9600 + B, B, dim)
     idx = raglite_amd.DeviceIndex(E, metric=metric)
     S, R = idx.search_rows(Q if B > 1 else Q[0], k)
-    with _env(RAGLITE_NO_HI_SEARCH="1"):
+    with idx.options(hi_search=0):
         S0, R0 = idx.search_rows(Q if B > 1 else Q[0], k)
     assert np.array_equal(R, R0) and _same(S, S0)
     S, R = np.atleast_2d(S), np.atleast_2d(R)
@@ -82,7 +67,7 @@ def test_near_duplicates_defeat_the_bound_and_the_full_pass_answers(metric):
     E[dup] = (q[None, :] * 0.9 + 1e-4 * rng.standard_normal((5000, dim))).astype(np.float32)
     idx = raglite_amd.DeviceIndex(E, metric=metric)
     S, R = idx.search_rows(q, k)
-    with _env(RAGLITE_NO_HI_SEARCH="1"):
+    with idx.options(hi_search=0):
         S0, R0 = idx.search_rows(q, k)
     assert np.array_equal(R, R0) and _same(S, S0)
     assert np.isin(R, dup).all()
@@ -97,7 +82,7 @@ def test_hi_plane_follows_append_and_two_stage_search():
     idx.append(E[n:])
     S, R = idx.search_rows(q, 50)
     ref = raglite_amd.DeviceIndex(E, metric="cosine")
-    with _env(RAGLITE_NO_HI_SEARCH="1"):
+    with ref.options(hi_search=0):
         S0, R0 = ref.search_rows(q, 50)
     assert np.array_equal(R, R0) and _same(S, S0)
     cs, cc, cn = idx.search_chunks(q, 40, 5)  # every row its own chunk here: the two-stage search rides on the same path
@@ -118,19 +103,19 @@ def test_hi_search_with_filter_and_tombstones(metric):
     idx = raglite_amd.DeviceIndex(E, metric=metric)
     ok = rng.random(n) < 0.4
     S, R = idx.search_rows(Q, k, chunk_filter=ok)
-    with _env(RAGLITE_NO_HI_SEARCH="1"):
+    with idx.options(hi_search=0):
         S0, R0 = idx.search_rows(Q, k, chunk_filter=ok)
     assert np.array_equal(R, R0) and _same(S, S0) and ok[R].all()
     dead = np.unique(R[:, :30])
     idx.delete_chunks(dead)
     S1, R1 = idx.search_rows(Q, k)
-    with _env(RAGLITE_NO_HI_SEARCH="1"):
+    with idx.options(hi_search=0):
         S2, R2 = idx.search_rows(Q, k)
     assert np.array_equal(R1, R2) and _same(S1, S2) and not np.isin(R1, dead).any()
     few = np.zeros(n, bool)
     few[rng.choice(n, 37, replace=False)] = True
     S3, R3 = idx.search_rows(Q[0], k, chunk_filter=few)
-    with _env(RAGLITE_NO_HI_SEARCH="1"):
+    with idx.options(hi_search=0):
         S4, R4 = idx.search_rows(Q[0], k, chunk_filter=few)
     assert np.array_equal(R3, R4) and _same(S3, S4) and (R3 >= 0).sum() <= 37
     idx.close()

@@ -21,6 +21,9 @@ import json, sys
 import numpy as np, torch
 import raglite_amd
 raglite_amd.set_device(0)
+headroom_mb = int(sys.argv[1])
+if headroom_mb >= 0:
+    raglite_amd.set_default_option("image_headroom_mb", headroom_mb)  # start value of every index created from here on
 n, dim, nq, B, k = 70_000, 1024, 32, 5, 20
 E = torch.empty((n, dim), dtype=torch.float32, device="cuda"); raglite_amd.synth_fill(E, seed=3, kind="small_int")
 Q = torch.empty((B, nq, dim), dtype=torch.float32, device="cuda"); raglite_amd.synth_fill(Q, seed=4, kind="small_int")
@@ -36,25 +39,57 @@ print(json.dumps({"mem": mem, "scores": s.cpu().numpy().tolist(), "chunks": c.cp
 """
 
 
-def _run(extra_env):
-    env = dict(os.environ, **extra_env)
-    res = subprocess.run([sys.executable, "-c", CHILD], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+def _run(headroom_mb):
+    res = subprocess.run([sys.executable, "-c", CHILD, str(headroom_mb)], cwd=ROOT, env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     return json.loads(res.stdout.strip().splitlines()[-1])
 
 
 def test_index_without_room_for_its_images_gives_the_same_results():
-    with_images = _run({})
+    with_images = _run(-1)
     m = with_images["mem"]
     assert m["rows"] == 70_000 * 1024 * 4
     assert m["presplit_image"] >= m["rows"] and m["hi_image"] >= m["rows"] // 2 and m["hi_plane"] >= m["rows"] // 2
     assert m["device_total"] > m["device_free"] > 0 and m["image_headroom"] >= 2 << 30
     assert with_images["filter"] in ("maxsim_batch_hi", "rows_hi")
     # a headroom nobody can leave: no image is built, every call runs over the stored rows
-    without = _run({"RAGLITE_IMAGE_HEADROOM_MB": str(1 << 30)})
+    without = _run(1 << 30)
     w = without["mem"]
     assert w["presplit_image"] == 0 and w["hi_image"] == 0 and w["hi_plane"] == 0 and w["rows"] == m["rows"]
     assert without["filter"] == "none"
     # integer-valued data: every path is exact, so the bits agree
     assert without["chunks"] == with_images["chunks"] and without["scores"] == with_images["scores"]
     assert without["rows"] == with_images["rows"] and without["row_scores"] == with_images["row_scores"]
+
+
+def test_options_release_and_rebuild_the_images():
+    """`rl_index_set_option(KEEP_IMAGE / KEEP_HI)` releases and rebuilds the accelerators of a live index; results do not move."""
+    import raglite_amd
+    from oracle import oracle
+
+    n, dim = 70_000, 1024
+    E = oracle.synth_matrix(31, n, dim, "small_int")
+    q = oracle.synth_matrix(32, 1, dim, "small_int")[0]
+    idx = raglite_amd.DeviceIndex(E, metric="dot")
+    m0 = idx.memory()
+    s0, r0 = idx.search_rows(q, 10)
+    assert m0["presplit_image"] > 0 and m0["hi_plane"] > 0 and idx.filter_stats()["kind"] == "rows_hi"
+    idx.set_option("keep_hi", 0)
+    m1 = idx.memory()
+    assert m1["hi_plane"] == 0 and m1["hi_image"] == 0 and m1["presplit_image"] == m0["presplit_image"]
+    s1, r1 = idx.search_rows(q, 10)
+    assert idx.filter_stats()["kind"] == "none"
+    idx.set_option("keep_image", 0)
+    assert idx.memory()["presplit_image"] == 0
+    s2, r2 = idx.search_rows(q, 10)
+    idx.set_option("keep_image", 1)
+    idx.set_option("keep_hi", 1)
+    m3 = idx.memory()
+    assert m3["presplit_image"] == m0["presplit_image"] and m3["hi_plane"] == m0["hi_plane"] and m3["hi_image"] == m0["hi_image"]
+    s3, r3 = idx.search_rows(q, 10)
+    for s, r in ((s1, r1), (s2, r2), (s3, r3)):
+        assert np.array_equal(r, r0) and np.array_equal(s, s0)
+    with pytest.raises(ValueError):
+        idx.set_option("hi_products", 3)
+    assert idx.get_option("hi_products") == 1 and idx.get_option("keep_hi") == 1
+    idx.close()

@@ -23,21 +23,6 @@ from tests.util import ragged_offsets
 pytestmark = pytest.mark.gpu
 
 
-class _env:
-    def __init__(self, **kv):
-        self.kv = kv
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        os.environ.update(self.kv)
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
-
 
 def _torch():
     import torch
@@ -142,10 +127,10 @@ def test_pipeline_over_either_kernel_returns_the_same_bits():
     idx = raglite_amd.DeviceIndex(E, off, metric="dot")
     s0, c0 = idx.maxsim_topk_batch(Q, k)
     assert idx.filter_stats()["kind"] == "maxsim_batch_hi" and not idx.filter_stats()["fallback"]
-    with _env(RAGLITE_NO_PP="1"):
+    with idx.options(pp_pass=0):
         s1, c1 = idx.maxsim_topk_batch(Q, k)
     assert torch.equal(s0, s1) and torch.equal(c0, c1)
-    with _env(RAGLITE_NO_HI_MAXSIM="1"):  # the full-precision passes: same chunks, scores to the last bits of the split arithmetic
+    with idx.options(hi_maxsim=0):  # the full-precision passes: same chunks, scores to the last bits of the split arithmetic
         s2, c2 = idx.maxsim_topk_batch(Q, k)
     assert torch.equal(c0, c2)
     assert float((s0 - s2).abs().max()) <= 2e-6 * float(s0.abs().max())
