@@ -95,6 +95,8 @@ def main() -> None:
     # Test hooks for the N > 1 code path on a ONE-GPU box (scripts/test_multirank_one_gpu.sh): every rank uses cuda:0
     # and the collective runs over gloo.  Never used by the driver.
     ap.add_argument("--split", action="store_true", help="also at N = 1: per-rank split of a step into passes / other local work / exchange")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="route option set as a process-wide default before any index exists (A/B runs; see include/raglite_hip.h 'options')")
     ap.add_argument("--same-gpu", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -136,6 +138,9 @@ def main() -> None:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     raglite_amd.set_device(local_rank)
+    for item in args.opt:
+        opt_name, opt_value = item.split("=", 1)
+        raglite_amd.set_default_option(opt_name, int(opt_value))
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -250,6 +255,7 @@ def main() -> None:
                                "full-precision fallback: 3 x v_mfma_f32_16x16x32_f16 on hi+lo pairs (22 bits)",
                   "f16_stored": "f16 storage, f16 x f16 -> f32 MFMA"}[arithmetic],
         "data": "synthetic",
+        "route_options": {"non_default": args.opt, "note": "none = the shipped defaults; set with --opt NAME=VALUE (rl_set_default_option), never from the environment"},
         "candidates_per_query": filter_block.get("candidates_per_query"),
         "fallback_steps": filter_block["fallback_steps"],
         "filter": filter_block,

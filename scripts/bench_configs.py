@@ -379,6 +379,12 @@ def run(name: str) -> dict:
 
 if __name__ == "__main__":
     raglite_amd.set_device(0)
+    # A/B runs: `name=value` arguments are route options set as process-wide defaults before any index exists (the library reads no
+    # environment variable), e.g. `python scripts/bench_configs.py fused_pp=0 cfg5`
+    for arg in [a for a in sys.argv[1:] if "=" in a]:
+        name, value = arg.split("=", 1)
+        raglite_amd.set_default_option(name, int(value))
+        sys.argv.remove(arg)
     which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4", "cfg5"]
     for name in which:
         print(json.dumps(run(name)), flush=True)

@@ -105,3 +105,35 @@ def test_c_consumers_compile_against_the_header_alone():
         res = subprocess.run([gcc, "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", f"-I{root / 'include'}", str(src)],
                              capture_output=True, text=True)
         assert res.returncode == 0, res.stderr
+
+
+def test_shipped_library_reads_no_environment_variable():
+    """Route switches are options of an index (`rl_index_set_option`); timing-experiment builds of the kernels exist only in
+    libraglite_hip_exp.so.  The shipped library does not even import getenv, and carries no RAGLITE_* string."""
+    import subprocess
+
+    syms = subprocess.run(["nm", "-D", "--undefined-only", str(_abi.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms, [ln for ln in syms.splitlines() if "getenv" in ln]
+    blob = Path(_abi.LIB_PATH).read_bytes()
+    assert b"RAGLITE_" not in blob
+
+
+def test_default_options_without_gpu():
+    """`rl_set_default_option` / `rl_get_default_option` touch no device: defaults, validation, round trip."""
+    lib = _abi.lib()
+    v = C.c_int64(-7)
+    defaults = {"hi_search": 1, "hi_maxsim": 1, "hi_products": 1, "pp_pass": 1, "fused_topk": 1, "fused_hi": 1, "fused_pp": 1,
+                "fused_topk_cap": 0, "fused_topk_stride": 0, "gemm_pass": 1, "query_pairs": 1, "planes_gemm": 1, "keep_image": 1,
+                "keep_hi": 1, "image_headroom_mb": -1, "arithmetic": 0, "exact_kth_threshold": 1}
+    assert set(defaults) == set(_abi.OPTIONS)
+    for name, want in defaults.items():
+        assert lib.rl_get_default_option(_abi.OPTIONS[name], C.byref(v)) == _abi.RL_OK and v.value == want, name
+    for key, value in ((0, 1), (18, 1), (99, 0), (_abi.OPTIONS["hi_products"], 3), (_abi.OPTIONS["hi_search"], 2),
+                       (_abi.OPTIONS["fused_topk_cap"], 8193), (_abi.OPTIONS["fused_topk_stride"], 1), (_abi.OPTIONS["arithmetic"], 2),
+                       (_abi.OPTIONS["image_headroom_mb"], -2)):
+        assert lib.rl_set_default_option(key, value) == _abi.RL_ERR_INVALID, (key, value)
+    assert "rl_set_default_option" in _abi.last_error()
+    assert lib.rl_set_default_option(_abi.OPTIONS["fused_topk_cap"], 64) == _abi.RL_OK
+    assert lib.rl_get_default_option(_abi.OPTIONS["fused_topk_cap"], C.byref(v)) == _abi.RL_OK and v.value == 64
+    assert lib.rl_set_default_option(_abi.OPTIONS["fused_topk_cap"], 0) == _abi.RL_OK
+    assert lib.rl_index_set_option(None, 1, 1) == _abi.RL_ERR_INVALID and lib.rl_index_get_option(None, 1, C.byref(v)) == _abi.RL_ERR_INVALID

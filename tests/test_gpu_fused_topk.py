@@ -208,3 +208,85 @@ def test_fused_hi_near_duplicates_fall_back():
         S0, R0 = idx.search_rows(Q, k)
     assert np.array_equal(R, R0) and np.array_equal(S.view(np.uint32), S0.view(np.uint32))
     idx.close()
+
+
+
+# ---- round 4: the candidate pass of the fused top-k over the HI image on the sixteen-group tile of maxsim_pp.hip (MODE 2; option fused_pp) ----
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+@pytest.mark.parametrize("n,dim,B,k", [
+    (70_000, 1024, 130, 100),    # one partial query tile (5 groups of 16)
+    (70_001, 1024, 1000, 10),    # two query tiles (the cfg 5 batch), n not a multiple of 128 / 16
+    (66_000, 1024, 2000, 7),     # four query tiles over 516 row tiles: workgroups whose pairs cross query tiles
+    (140_000, 512, 600, 100),    # 16 K slabs per tile
+    (262_200, 256, 513, 33),     # 8 K slabs per tile (the smallest the tile takes); a query tile with ONE query
+    (66_000, 1024, 96, 512),     # k = 512: sample stride at its lower end
+])
+def test_fused_pp_tile_equals_the_eight_group_tile_bitwise(metric, n, dim, B, k):
+    """Both candidate passes multiply the same fp16 halves and keep the rows whose approximate similarity reaches the same threshold;
+    what is returned are the exact fp32 similarities of the same candidates: the same bits, whichever tile found them."""
+    import torch
+
+    raglite_amd.set_device(0)
+    E = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=8000 + n % 97)
+    Q = torch.empty((B, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=8100 + B)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    assert idx.get_option("fused_pp") == 1
+    S, R = idx.search_rows(Q, k)
+    st = idx.filter_stats()
+    assert st["kind"] == "rows_fused_hi" and not st["fallback"], st
+    with idx.options(fused_pp=0):
+        S0, R0 = idx.search_rows(Q, k)
+        st0 = idx.filter_stats()
+    assert st0["kind"] == "rows_fused_hi" and not st0["fallback"]
+    assert torch.equal(R, R0) and torch.equal(S.view(torch.int32), S0.view(torch.int32))
+    # about the same lists: the sixteen-group tile keeps exactly the rows that reach the threshold, the eight-group tile also those within
+    # the 1e-5 of slack of its in-loop test
+    assert st["candidates_per_query_mean"] <= st0["candidates_per_query_mean"] <= 1.05 * st["candidates_per_query_mean"] + 1, (st, st0)
+    Eh = E.cpu().numpy()
+    for b in (0, B // 2, B - 1):
+        assert_topk_close(S[b].cpu().numpy(), R[b].cpu().numpy(), oracle.similarity(Eh, Q[b].cpu().numpy(), metric), k, _tol(Eh, Q[b].cpu().numpy(), metric))
+    idx.close()
+
+
+@pytest.mark.parametrize("cap", [16, 700])
+def test_fused_pp_forced_overflow_falls_back_exactly(cap):
+    n, dim, B, k = 70_000, 1024, 200, 10
+    E = oracle.synth_matrix(8300, n, dim)
+    Q = oracle.synth_matrix(8301, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric="cosine")
+    with idx.options(fused_topk=0):
+        S0, R0 = idx.search_rows(Q, k)
+    with idx.options(fused_topk_cap=cap, fused_hi=0):  # (the capacity switch acts on the lists of the pre-split-image path)
+        S1, R1 = idx.search_rows(Q, k)
+        assert idx.filter_stats()["fallback"]
+    assert np.array_equal(R1, R0) and np.array_equal(S1.view(np.uint32), S0.view(np.uint32))
+    S, R = idx.search_rows(Q, k)  # the sixteen-group tile again, flag re-armed
+    assert idx.filter_stats()["kind"] == "rows_fused_hi" and not idx.filter_stats()["fallback"]
+    for b in (0, 100, 199):
+        assert_topk_close(S[b], R[b], oracle.similarity(E, Q[b], "cosine"), k, TOL)
+    idx.close()
+
+
+def test_fused_pp_integer_ties_and_lifecycle():
+    """Thousands of ties on every threshold (integer data), then append / delete / compact under the sixteen-group tile."""
+    n, dim, B, k = 70_000, 1024, 160, 64
+    E = oracle.synth_matrix(8400, n + 4000, dim, "small_int")
+    Q = oracle.synth_matrix(8401, B, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E[:n], metric="dot")
+    idx.append(E[n:])
+    S, R = idx.search_rows(Q, k)
+    assert idx.filter_stats()["kind"] == "rows_fused_hi"
+    for b in (0, 77, 159):
+        es, ei = oracle.topk_desc(sim_fp32_exact(E, Q[b], "dot"), k)
+        assert np.array_equal(R[b], ei) and np.array_equal(S[b].view(np.uint32), es.astype(np.float32).view(np.uint32))
+    dead = np.unique(R[:, 0])[:30]
+    idx.delete_chunks(dead)
+    S1, R1 = idx.search_rows(Q, k)
+    assert not np.isin(R1, dead).any()
+    idx.compact()
+    S2, R2 = idx.search_rows(Q, k)
+    live = np.setdiff1d(np.arange(n + 4000), dead)
+    assert np.array_equal(live[R2], R1) and np.array_equal(S2.view(np.uint32), S1.view(np.uint32))
+    idx.close()

@@ -303,3 +303,71 @@ def test_f16_stored_batch_float_data_bound_append_and_approx_scores():
     assert torch.equal(c.to(torch.int64), c2.to(torch.int64))
     assert float((s - s2).abs().max()) <= 2e-6 * float(s.abs().max())
     idx.close()
+
+
+
+# ---- round 4: the second, tighter candidate threshold (option exact_kth_threshold) and the option plumbing ------------------------------------
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+def test_exact_kth_threshold_same_bits_fewer_candidates(storage):
+    """The approximate top-k is scored exactly first; the k-th best of THOSE scores, minus m, replaces (k-th approximate) - 2 m as the
+    candidate threshold.  The result cannot move (both windows contain the exact top-k, the scores come from the same kernel); the
+    number of chunks scored exactly goes down."""
+    import torch
+
+    raglite_amd.set_device(0)
+    n, dim, nq, n_queries, k = 70_000, 1024, 32, 24, 100
+    rng = np.random.default_rng(91)
+    off = ragged_offsets(rng, n, 1, 15)
+    E = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=9100)
+    Q = torch.empty((n_queries, nq, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=9101)
+    idx = raglite_amd.DeviceIndex(E.half() if storage == "f16" else E, off, metric="dot", storage=storage)
+    assert idx.get_option("exact_kth_threshold") == 1
+    s1, c1 = idx.maxsim_topk_batch(Q, k)
+    st1 = idx.filter_stats()
+    with idx.options(exact_kth_threshold=0):
+        s0, c0 = idx.maxsim_topk_batch(Q, k)
+        st0 = idx.filter_stats()
+    assert st1["kind"] == st0["kind"] == "maxsim_batch_hi" and not st1["fallback"] and not st0["fallback"]
+    assert torch.equal(c1, c0) and torch.equal(s1, s0)
+    assert k <= st1["candidates_per_query_mean"] < st0["candidates_per_query_mean"], (st1, st0)
+    print(f"[{storage}] candidates per query: {st0['candidates_per_query_mean']:.0f} -> {st1['candidates_per_query_mean']:.0f} (max {st0['candidates_per_query_max']} -> {st1['candidates_per_query_max']})")
+    # k larger than the number of chunks a query can rank: the threshold is unusable, the flag answers
+    tiny = raglite_amd.DeviceIndex(E[:66_000], np.concatenate((np.arange(0, 66_000, 1000), [66_000])).astype(np.int64), metric="dot")
+    s2, c2 = tiny.maxsim_topk_batch(Q[:8], 100)
+    with tiny.options(hi_maxsim=0):
+        s3, c3 = tiny.maxsim_topk_batch(Q[:8], 100)
+    assert torch.equal(c2, c3) and int((c2 >= 0).sum()) == 8 * 66
+    assert float((s2[c2 >= 0] - s3[c3 >= 0]).abs().max()) <= 2e-6 * float(s3[c3 >= 0].abs().max())
+    tiny.close()
+    idx.close()
+
+
+def test_the_shipped_library_ignores_experiment_environment_variables(monkeypatch):
+    """RAGLITE_PP_DBG=2 selects a kernel without MFMAs in the experiments build (wrong results by design).  The shipped library has no
+    such kernel and reads no environment variable: same bits with the variable set."""
+    import torch
+
+    raglite_amd.set_device(0)
+    n, dim, nq, n_queries, k = 70_000, 1024, 32, 16, 20
+    rng = np.random.default_rng(92)
+    off = ragged_offsets(rng, n, 1, 15)
+    E = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=9200)
+    Q = torch.empty((n_queries, nq, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=9201)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    a0, _ = idx.maxsim_approx_scores(Q, kernel=0)
+    s0, c0 = idx.maxsim_topk_batch(Q, k)
+    for name, value in (("RAGLITE_PP_DBG", "2"), ("RAGLITE_GEMM_DBG", "2"), ("RAGLITE_NO_HI_MAXSIM", "1"), ("RAGLITE_HI_ONE_PRODUCT", "0"),
+                        ("RAGLITE_NO_PP", "1"), ("RAGLITE_EXACT_FP32", "1")):
+        monkeypatch.setenv(name, value)
+    idx2 = raglite_amd.DeviceIndex(E, off, metric="dot")  # (an index created with the variables set: nothing is read at creation either)
+    assert idx2.arithmetic == "f16_split"
+    a1, _ = idx2.maxsim_approx_scores(Q, kernel=0)
+    s1, c1 = idx2.maxsim_topk_batch(Q, k)
+    assert idx2.filter_stats()["kind"] == "maxsim_batch_hi"
+    assert torch.equal(a0, a1) and torch.equal(s0, s1) and torch.equal(c0, c1)
+    idx.close()
+    idx2.close()

@@ -3,7 +3,7 @@ the ranking pass streams only the HI halves of the fp16 split (2 B per element),
 into a candidate set that contains the exact top-k, and the candidates are re-scored by the exact kernels.
 
 Contract: the same bits as the full-precision pass (`ORDER BY dist LIMIT k`, `/root/reference/src/raglite/_search.py:69-79`,
-ranked exactly) -- checked against RAGLITE_NO_HI_SEARCH=1 bit for bit, against the oracle, and on corpora built to defeat the
+ranked exactly) -- checked against the option hi_search = 0 bit for bit, against the oracle, and on corpora built to defeat the
 bound (thousands of near-duplicates of the best row), where the guarded full-precision pass has to answer."""
 
 import os
@@ -118,4 +118,41 @@ def test_hi_search_with_filter_and_tombstones(metric):
     with idx.options(hi_search=0):
         S4, R4 = idx.search_rows(Q[0], k, chunk_filter=few)
     assert np.array_equal(R3, R4) and _same(S3, S4) and (R3 >= 0).sum() <= 37
+    idx.close()
+
+
+# ---- adversarial inputs for the single-vector bounds (round 4): the twins of tests/test_gpu_pp_pass.py's MaxSim cases ---------------------
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+@pytest.mark.parametrize("kind", ["aligned", "positive", "subnormal", "giant"])
+@pytest.mark.parametrize("B", [1, 7, 128])
+def test_row_searches_on_adversarial_data_equal_the_full_passes(kind, B, metric):
+    """B <= 16: ranking on the HI plane (`search_rows_hi`); B >= 96: the fused top-k over the HI image (`search_rows_fused_hi`, candidate
+    pass on the sixteen-group tile).  On corpora built to meet the error bound (residuals parallel to the query, no cancellation,
+    subnormal hi halves, one giant row) both must return what the full-precision paths return: the same rows; the same score bits for the
+    small batches (their candidates are re-scored by the very kernels of the full pass), and for the big ones the exact fp32 similarities,
+    within a few ulps of the dense path's split-arithmetic sums."""
+    import torch
+
+    from tests.test_gpu_pp_pass import _adversarial
+
+    raglite_amd.set_device(0)
+    n, dim, k = 70_000, 1024, 40
+    E, Q3 = _adversarial(torch, kind, n, dim, max(B, 2), 1)
+    Q = Q3[:B, 0, :].contiguous()
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    S, R = idx.search_rows(Q if B > 1 else Q[0], k)
+    st = idx.filter_stats()
+    assert st["kind"] == ("rows_hi" if B <= 16 else "rows_fused_hi"), st
+    with idx.options(hi_search=0, fused_topk=0):
+        S0, R0 = idx.search_rows(Q if B > 1 else Q[0], k)
+    assert idx.filter_stats()["kind"] == "none"
+    if B <= 16:
+        assert torch.equal(R, R0) and torch.equal(S.view(torch.int32), S0.view(torch.int32)), (kind, B, metric, st)
+    else:
+        scale = float(S0.abs().max())
+        assert float((S - S0).abs().max()) <= 4e-6 * scale  # exact fp32 similarities vs the dense path's split-arithmetic sums
+        differ = R != R0  # rows may swap only where the two arithmetics order near-equal scores differently
+        assert float(differ.float().mean()) <= 0.02, float(differ.float().mean())
+        assert torch.equal(torch.sort(R, dim=1).values[~differ.any(dim=1)], torch.sort(R0, dim=1).values[~differ.any(dim=1)])
+    print(f"[{kind} B={B} {metric}] candidates per query mean {st['candidates_per_query_mean']:.0f} max {st['candidates_per_query_max']}, fallback {st['fallback']}")
     idx.close()

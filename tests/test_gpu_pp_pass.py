@@ -154,3 +154,140 @@ def test_pp_after_append_and_on_a_sub_range():
     assert torch.equal(a, b)
     idx.close()
     whole.close()
+
+
+# ---- adversarial inputs for the bound (round 4) -----------------------------------------------------------------------------------------
+# The candidate window of the headline pipeline is exact only if |approximate - exact| <= m holds for EVERY chunk on ANY data.  The random
+# corpora above sit far inside the bound (Cauchy-Schwarz is loose on them); these are built to come as close to it as the construction allows:
+#   aligned     every row is e = H + 0.45 q with H fp16-representable at the index' scale (scale = 1: one element is 2^13) and the SAME q as
+#               all 32 vectors of every query: what the hi halves drop, e_lo = 0.45 q, is parallel to every query vector -- |q . e_lo| =
+#               |q| |e_lo| for every pair, every chunk, with one sign: the per-pair bound is met with equality and the 32 errors add up
+#   positive    corpus and queries all positive (no cancellation in any dot product)
+#   subnormal   half the rows 2^-9 of the others with heavy-tailed elements: their hi halves are fp16 subnormals or zero
+#   giant       one row 500 x the norm of the rest: the bound takes the MAXIMUM of |e_lo| and |e| over the rows, so m is 500 x what the
+#               other rows need -- valid but useless: the window holds every chunk, the lists overflow, and the guarded full-precision
+#               passes must answer (flag asserted)
+# Asserted for each: err <= m per chunk (err / m is printed: how close the worst case comes), and the pipeline's top-k equals the
+# full-precision passes' (same chunks; scores to the last bits of the two arithmetics) and the float64 ranking.
+
+
+def _adversarial(torch, kind, n, dim, n_queries, nq):
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    U = lambda *shape: torch.rand(*shape, generator=g, device="cuda") * 2 - 1  # noqa: E731
+    if kind == "aligned":
+        levels = torch.tensor([-1.0, -0.75, -0.5, -0.25, 0.25, 0.5, 0.75, 1.0], device="cuda")
+        q = levels[torch.randint(0, 8, (n_queries, 1, dim), generator=g, device="cuda")]  # fp16-representable at any power-of-two scale
+        Q = q.expand(n_queries, nq, dim).contiguous()
+        H = torch.randint(1024, 2048, (n, dim), generator=g, device="cuda").float() * torch.where(U(n, dim) < 0, -1.0, 1.0)
+        E = H + 0.45 * Q[0, 0][None, :]  # aligned with query 0's vectors (the other queries see a generic residual)
+        E[0, 0] = 8192.0  # pins the index' scale to 1: fp16 spacing is 1 in [1024, 2048), so hi = H exactly
+        return E.contiguous(), Q
+    if kind == "positive":
+        return U(n, dim).abs().contiguous(), U(n_queries, nq, dim).abs().contiguous()
+    if kind == "subnormal":
+        E = U(n, dim)
+        small = torch.arange(n, device="cuda") % 2 == 1
+        E[small] = (E[small].sign() * E[small].abs() ** 6) * 2.0 ** -9
+        return E.contiguous(), U(n_queries, nq, dim).contiguous()
+    if kind == "giant":
+        E = U(n, dim)
+        E[n // 2] *= 500.0
+        return E.contiguous(), U(n_queries, nq, dim).contiguous()
+    raise AssertionError(kind)
+
+
+@pytest.mark.parametrize("kind", ["aligned", "positive", "subnormal"])
+def test_pp_bound_holds_on_adversarial_data(kind):
+    torch = _torch()
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "scripts"))
+    import bench_configs
+
+    n, dim, nq, n_queries, k = 70_000, 1024, 32, 16, 50
+    rng = np.random.default_rng(17)
+    off = ragged_offsets(rng, n, 1, 15)
+    E, Q = _adversarial(torch, kind, n, dim, n_queries, nq)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    assert idx.arithmetic == "f16_split"
+    got, m = idx.maxsim_approx_scores(Q, kernel=0)
+    got8, m8 = idx.maxsim_approx_scores(Q, kernel=1)
+    ref = bench_configs.maxsim_scores_f64(E, off, Q)
+    for name, a in (("sixteen-query kernel", got), ("eight-query kernel", got8)):
+        err = (a.double() - ref).abs().max(dim=1).values
+        ratio = (err / m.double())
+        print(f"[{kind}] {name}: worst err / m = {float(ratio.max()):.3f} (query {int(ratio.argmax())}), m = {float(m[int(ratio.argmax())]):.4g}, "
+              f"score scale {float(ref.abs().max()):.4g}")
+        assert bool((err <= m.double()).all()), (kind, name, err.tolist(), m.tolist())
+    if kind == "aligned":  # query 0 meets the per-pair bound with equality: the measured error must be most of what the e_lo term allows
+        e_lo_term = 0.45 * float(Q[0, 0].norm()) * float(Q[0].norm(dim=1).sum())
+        err0 = float((got[0].double() - ref[0]).abs().max())
+        assert err0 >= 0.98 * e_lo_term, (err0, e_lo_term)
+    s, c = idx.maxsim_topk_batch(Q, k)
+    st = idx.filter_stats()
+    assert st["kind"] == "maxsim_batch_hi"
+    with idx.options(hi_maxsim=0):
+        s0, c0 = idx.maxsim_topk_batch(Q, k)
+    ref_top = torch.topk(ref, k, dim=1)
+    scale = float(ref.abs().max())
+    for b in range(n_queries):
+        want = set(ref_top.indices[b].tolist())
+        # the float64 ranking, up to swaps among scores closer than the fp32 arithmetic resolves
+        for got_c, got_s in ((c[b], s[b]), (c0[b], s0[b])):
+            extra = set(got_c.tolist()) ^ want
+            if extra:
+                kth = float(ref_top.values[b, -1])
+                assert all(abs(float(ref[b, e]) - kth) <= 4e-6 * scale for e in extra), (kind, b, sorted(extra)[:6])
+            assert float((got_s.double() - ref[b, got_c.long()]).abs().max()) <= 2e-6 * scale
+    idx.close()
+
+
+def test_giant_row_defeats_the_bound_and_the_fallback_answers():
+    torch = _torch()
+    import sys
+    from pathlib import Path
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "scripts"))
+    import bench_configs
+
+    n, dim, nq, n_queries, k = 70_000, 1024, 32, 8, 20
+    rng = np.random.default_rng(19)
+    off = ragged_offsets(rng, n, 1, 15)
+    E, Q = _adversarial(torch, "giant", n, dim, n_queries, nq)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    assert idx.arithmetic == "f16_split"  # (500 x is inside the 2^10 window that keeps the split arithmetic)
+    got, m = idx.maxsim_approx_scores(Q, kernel=0)
+    ref = bench_configs.maxsim_scores_f64(E, off, Q)
+    err = (got.double() - ref).abs().max(dim=1).values
+    print(f"[giant] worst err / m = {float((err / m.double()).max()):.3f}; m / score spread = {float(m.max() / ref.std(dim=1).min()):.1f}")
+    assert bool((err <= m.double()).all())
+    s, c = idx.maxsim_topk_batch(Q, k)
+    st = idx.filter_stats()
+    assert st["kind"] == "maxsim_batch_hi" and st["fallback"], st  # the window holds (nearly) every chunk: the lists overflow
+    with idx.options(hi_maxsim=0):
+        s0, c0 = idx.maxsim_topk_batch(Q, k)
+    assert torch.equal(c, c0) and torch.equal(s, s0)  # the SAME passes answered both times
+    idx.close()
+
+
+def test_approx_scores_refuse_an_index_with_an_empty_chunk():
+    """Both pass kernels find a chunk by counting chunk ends; an empty chunk would shift every score behind it.  The header promises
+    RL_ERR_UNSUPPORTED (ValueError) -- and the batch search over the same index takes the streaming kernels and stays correct."""
+    torch = _torch()
+    n, dim, nq = 70_000, 1024, 8
+    rng = np.random.default_rng(23)
+    off = ragged_offsets(rng, n, 1, 15, empty_every=1000)
+    assert (np.diff(off) == 0).any()
+    E = _corpus(torch, n, dim, seed=61, kind="small_int")
+    Q = _queries(torch, 4, nq, dim, seed=62, kind="small_int")
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    for kernel in (0, 1):
+        with pytest.raises(ValueError, match="empty chunk"):
+            idx.maxsim_approx_scores(Q, kernel=kernel)
+    s, c = idx.maxsim_topk_batch(Q, 10)
+    Eh, Qh = E.cpu().numpy(), Q.cpu().numpy()
+    for b in range(4):
+        ws, wc = oracle.maxsim_topk(Eh, off, Qh[b], 10, np.float32)
+        assert np.array_equal(c[b].cpu().numpy(), wc) and np.array_equal(s[b].cpu().numpy(), ws)
+    idx.close()
