@@ -43,12 +43,13 @@ from raglite_amd._search import (
     vector_search,
 )
 from raglite_amd._cross_encoder import CrossEncoderShape, TorchCrossEncoderRanker
-from raglite_amd._torch_embedder import EncoderShape, HashTokenizer, TorchTokenEmbedder
+from raglite_amd._torch_embedder import EncoderShape, HashTokenizer, SentencePieceTokenizer, TorchTokenEmbedder
 from raglite_amd._query_adapter import update_query_adapter
 from raglite_amd._comm import Communicator
 from raglite_amd._sharded import ShardedIndex, merge_topk_host, shard_bounds_by_chunk
 
 __all__ = [
+    "SentencePieceTokenizer",
     "set_default_option",
     "get_default_option",
     "partition_cost",

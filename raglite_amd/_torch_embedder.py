@@ -12,9 +12,10 @@ leaving HBM.  PyTorch is plumbing here (GEMMs through hipBLASLt, attention throu
 owns start at the pooling seam.
 
 No checkpoint can be fetched in this environment: weights are random-initialised in the architecture's shape unless a
-state dict is supplied (`load_state_dict`), and the default tokenizer is a deterministic hashing word-piece splitter;
-pass `tokenizer=` (anything with `encode(str) -> list[int]` / `decode(list[int]) -> str`, e.g. a `tokenizers`
-SentencePiece model of bge-m3) for real text.
+state dict is supplied (`load_state_dict`).  Tokenizers: `SentencePieceTokenizer(model_file)` loads a SentencePiece model the way
+bge-m3's `sentencepiece.bpe.model` is used (XLM-R id layout; tests/test_spm_tokenizer.py runs the reference's own token-count code on
+it); without a model file the fallback is `HashTokenizer`, a deterministic hashing word-piece splitter.  Anything with
+`encode(str) -> list[int]` / `decode(list[int]) -> str` can be passed as `tokenizer=`.
 """
 
 from __future__ import annotations
@@ -81,6 +82,39 @@ class HashTokenizer:
 
     def decode(self, ids: list[int]) -> str:
         return "".join(self._piece_of.get(t, "") for t in ids)
+
+
+class SentencePieceTokenizer:
+    """A SentencePiece model behind the `encode` / `decode` surface `TorchTokenEmbedder` expects, in XLM-RoBERTa's id layout -- the one
+    bge-m3's published `sentencepiece.bpe.model` is used with: `<s>` = 0, `<pad>` = 1, `</s>` = 2, `<unk>` = 3, every other piece at its
+    SentencePiece id + 1 (the fairseq offset).  This is the loading path a real bge-m3 tokenizer file takes:
+
+        TorchTokenEmbedder.bge_m3_shaped(tokenizer=SentencePieceTokenizer("sentencepiece.bpe.model"))
+
+    The reference counts tokens with the embedding model's own tokenizer (`src/raglite/_embed.py:64-93`, the sentinel trick of
+    `:20-36`); with this class the same calls run through `sentencepiece` instead of the hashing stand-in."""
+
+    FAIRSEQ_OFFSET = 1
+    UNK_ID = 3
+
+    def __init__(self, model_file: str | None = None, *, model_proto: bytes | None = None) -> None:
+        import sentencepiece as spm
+
+        if (model_file is None) == (model_proto is None):
+            raise ValueError("SentencePieceTokenizer needs exactly one of model_file / model_proto")
+        self.sp = spm.SentencePieceProcessor(model_file=str(model_file)) if model_file is not None else spm.SentencePieceProcessor(model_proto=model_proto)
+        if self.sp.unk_id() != 0:
+            raise ValueError("expected a SentencePiece model with <unk> = 0 (the XLM-RoBERTa / bge-m3 layout)")
+
+    @property
+    def vocab_size(self) -> int:
+        return len(self.sp) + self.FAIRSEQ_OFFSET
+
+    def encode(self, text: str) -> list[int]:
+        return [i + self.FAIRSEQ_OFFSET if i else self.UNK_ID for i in self.sp.encode(text)]
+
+    def decode(self, ids: list[int]) -> str:
+        return self.sp.decode([i - self.FAIRSEQ_OFFSET for i in ids if i > self.UNK_ID])
 
 
 def _build_encoder(shape: EncoderShape):
