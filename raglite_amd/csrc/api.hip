@@ -1417,9 +1417,9 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
     const CandArgs ca{thr, 1, c_s, c_i, cnt, flag, cap};
     idx->filt = {RL_FILTER_ROWS_FUSED_HI, B, cap, cnt, flag};
     // The candidate pass on the sixteen-group tile of maxsim_pp.hip (round 4: 128 rows x 512 queries per workgroup, every operand through
-    // LDS-DMA rings, wave-private record logs; dim % 64 == 0, dim >= 256; RL_OPT_FUSED_PP = 0: the eight-group tile of maxsim_gemm.hip)
+    // LDS-DMA rings, wave-private record logs; dim % 32 == 0, dim >= 256; RL_OPT_FUSED_PP = 0: the eight-group tile of maxsim_gemm.hip)
     int st_pp = RL_ERR_UNSUPPORTED;
-    if (idx->opt.on(RL_OPT_FUSED_PP) && idx->dim % 64 == 0 && idx->dim >= 256) {
+    if (idx->opt.on(RL_OPT_FUSED_PP) && idx->dim % 32 == 0 && idx->dim >= 256) {
         int32_t log_cap = 0;
         const size_t work_bytes = pp_rows_scratch_bytes(n, B, idx->n_cu, (int32_t)std::min<int64_t>((int64_t)k * stride, cap), &log_cap);
         RL_TRY(idx->pp_work.reserve(work_bytes));

@@ -121,21 +121,14 @@ __device__ __forceinline__ void pp_read(f32x4& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void pp_pin(f32x4& a, f32x4& b, f32x4& c, f32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
-// MODE 2: loads the compiler must not see.  A compiler-visible VMEM load anywhere in the K loop makes its wait-count pass put
-// `s_waitcnt vmcnt(0)` at the loop header -- which drains the feeders' look-ahead DMAs on every iteration.  The value is valid after an
-// explicit wait + pp_pin1().
-__device__ __forceinline__ float pp_gload(const float* p) {
-    float v;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void pp_pin1(float& a) { asm volatile("" : "+v"(a)); }
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-// 16 consecutive floats at a wave-uniform, 64-byte aligned address through the scalar cache (waits for it: also for the LDS reads in flight)
-__device__ __forceinline__ f32x16 pp_sload16(const float* p) {
-    f32x16 v;
+// MODE 2: a load the compiler must not see (a compiler-visible VMEM load anywhere in the K loop makes its wait-count pass put
+// `s_waitcnt vmcnt(0)` at the loop header, which drains the feeders' look-ahead DMAs on every iteration) goes through the scalar cache:
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+// two consecutive floats at a wave-uniform, 8-byte aligned address through the scalar cache (waits for it: also for the LDS reads in flight)
+__device__ __forceinline__ f32x2s pp_sload2(const float* p) {
+    f32x2s v;
     const float* const u = reinterpret_cast<const float*>(pp_uniform_i64(reinterpret_cast<int64_t>(p)));
-    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(u) : "memory");
+    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(u) : "memory");
     return v;
 }
 __device__ __forceinline__ h16x8 pp_h(const f32x4& v) {
@@ -157,9 +150,25 @@ struct PpRows {
     uint2* log; int32_t log_cap;          // [gridDim.x * 8][log_cap] wave-private records (raw accumulator, packed coordinates)
 };
 
-// DBG (experiment builds only, -DRAGLITE_EXPERIMENTS + RAGLITE_PP_DBG; wrong results): 2 = no MFMAs, 8 = no LDS fragment reads, 16 = no corpus DMAs,
-// 32 = no query DMAs, 64 = every corpus DMA re-reads the first tile (L2 hits), 128 = no tile epilogue (the MFMAs stay), 256 = no stores, 1024 = waves 4-7 run the stream of waves 0-3 (no lag), 2048 = no LDS reads of the QUERY fragments, 8192 = epilogue timeline (RAGLITE_PP_TRACE=1)
-template <int DBG, int MODE = 0>
+// DBG (experiment builds only, -DRAGLITE_EXPERIMENTS + RAGLITE_PP_DBG / RAGLITE_PP_ROWS_DBG; wrong results): 2 = no MFMAs, 8 = no LDS fragment
+// reads, 16 = no corpus DMAs, 32 = no query DMAs, 64 = every corpus DMA re-reads the first tile (L2 hits), 128 = no block epilogues (the MFMAs
+// stay), 256 = no stores, 512 = MODE 2 without the flush of its record logs, 1024 = waves 4-7 run the stream of waves 0-3 (no lag),
+// 2048 = no LDS reads of the QUERY fragments
+//
+// STAG (round 4; an EXPERIMENT that is measured, correct, and NOT shipped -- the shipped instantiations have STAG = false): the epilogue of a
+// tile, block by block, INSIDE the main loop.  Every wave runs the eight block epilogues of a tile back to back after the tile's last K
+// slab -- ~750 VALU instructions (MODE 2: more, with its scalar branches) during which both waves of every SIMD issue no MFMA: 11 % of the
+// MaxSim pass and 20 % of the candidate pass of cfg 5 (profiles/r04_c_*).  With STAG the eight 16-row blocks of a tile run their K loop
+// ROTATED against each other: block a multiplies tile T during stream slabs [T nslab + a, (T + 1) nslab + a) -- K slabs a, a + 1, ..,
+// nslab - 1, 0, .., a - 1 of its rows (a dot product does not care about the order of its terms; integer data stays exact) -- so the
+// blocks finish in eight DIFFERENT slabs, one block's epilogue is issued by the lead wave of a SIMD right after the slab's barrier while its
+// partner issues MFMAs, and by the partner at the end of its slab while the lead wave issues the next slab's; the feeders fetch every block
+// from its own tile; a workgroup streams nt nslab + 8 slabs.  All 86 parity tests of the two modes pass with it.  Measured, same box
+// (profiles/r04_d_*): MaxSim pass 1.0425 ms against 1.0354 without, candidate pass of cfg 5 2.99 against 2.82 -- NO gain: the epilogue
+// costs the same 0.10 ms per pass wherever it runs.  The VALU instructions of one wave do not execute under the MFMAs of its SIMD partner:
+// the epilogue runs at exactly the VALU issue rate of a SIMD (2 waves x 750 instructions x 4 cycles per tile), and that time is taken from
+// the matrix pipe whether it is taken in one piece or in eight.  What is left is to make the epilogue SHORTER, not to move it.
+template <int DBG, int MODE = 0, bool STAG = false>
 __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restrict__ planes, int64_t n_rows, int32_t nslab,
                                                            const char* __restrict__ qfrag, const float* __restrict__ qmeta, int32_t n_q,
                                                            const int32_t* __restrict__ row_to_chunk, const int64_t* __restrict__ chunk_offsets,
@@ -168,14 +177,6 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
                                                            PpRows rs) {
     constexpr bool ROWS = MODE == 2;
     __shared__ __attribute__((aligned(16))) char smem[PP_LDS];
-    // DBG & 8192 (RAGLITE_PP_TRACE=1, timing experiments): s_memtime stamps of workgroup 7's tile 3 epilogue, per wave: [wave][0: start, 1 + a: after
-    // block a, 9: end] straight to global memory
-    [[maybe_unused]] int tile_now = 0;
-    auto stamp = [&](int k) __attribute__((always_inline)) {
-        if constexpr (DBG & 8192) {
-            if (blockIdx.x == 7 && tile_now == 3 && (threadIdx.x & 63) == 0) trace[(threadIdx.x >> 6) * 16 + k] = __builtin_amdgcn_s_memtime();
-        }
-    };
     if (run_if && __builtin_amdgcn_readfirstlane((int)*run_if) == 0) return;  // whole grid: a guarded launch that is not needed
     const int lane = threadIdx.x & 63;
     const int wv = wave_id();
@@ -188,33 +189,30 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         const int64_t c0 = chunk_offsets[c], c1 = chunk_offsets[c + 1];
         return c0 == t ? t : c1;
     };
-    int32_t r_lo = 0, r_hi = 0, vt0 = 0, Tr = 1, nt_rows = 0;
+    int32_t r_lo = 0, r_hi = 0, nt_rows = 0;
     if constexpr (!ROWS) {
         r_lo = (int32_t)pp_uniform_i64(boundary((n_rows * b) / G));
         r_hi = (int32_t)pp_uniform_i64((b + 1 == G) ? n_rows : boundary((n_rows * (b + 1)) / G));
         if (r_hi <= r_lo) return;  // whole workgroup
     } else {
-        // MODE 2: the workgroups share the (row tile, query tile) PAIRS evenly, query tile outermost (pair i = query tile i / Tr, row tile
-        // i % Tr): at any time the whole chip works on one 1-MiB query-tile image, as in MODE 0
-        Tr = (int32_t)((n_rows + PP_RT - 1) / PP_RT);
-        const int64_t items = (int64_t)Tr * rs.QT;
-        vt0 = (int32_t)((items * b) / G);
-        nt_rows = (int32_t)((items * (b + 1)) / G) - vt0;
+        // MODE 2: blockIdx.y = the query tile (16 groups of 32 queries), the workgroups of a grid row share the 128-row tiles evenly: a
+        // workgroup multiplies ONE set of queries for its whole life, like a MaxSim pass
+        const int64_t Tr = (n_rows + PP_RT - 1) / PP_RT;
+        const int64_t t0 = (Tr * b) / G, t1 = (Tr * (b + 1)) / G;
+        nt_rows = (int32_t)(t1 - t0);
         if (nt_rows <= 0) return;  // whole workgroup
+        r_lo = (int32_t)(t0 * PP_RT);
         r_hi = (int32_t)n_rows;
     }
-    const int32_t org = r_lo & ~15;  // MODE 0: tiles start on a 16-row block of the image
+    const int32_t org = r_lo & ~15;  // tiles start on a 16-row block of the image
     const int nt = ROWS ? nt_rows : (r_hi - org + PP_RT - 1) / PP_RT;
-    // MODE 2: (row tile, query tile) of the workgroup's pair t, walked incrementally by each of its three users (the feeders' corpus and
-    // query streams, the multiplying side) -- one integer division per workgroup, none per tile
-    struct PairPos { int32_t rt, qt; };
-    const PairPos pos0 = ROWS ? PairPos{(int32_t)(vt0 % Tr), (int32_t)(vt0 / Tr)} : PairPos{0, 0};
-    auto next_pair = [&](PairPos& p) __attribute__((always_inline)) { if (++p.rt == Tr) { p.rt = 0; ++p.qt; } };
-    PairPos fc_pos = pos0, fq_pos = pos0, c_pos = pos0;
-    const int total = nt * nslab;  // K slabs this workgroup consumes, tile after tile
+    const int qt = ROWS ? (int)blockIdx.y : 0;  // query tile
+    constexpr int TAIL = STAG ? PP_NBLK : 0;    // slabs after the last tile's first block is done, for the blocks behind it
+    const int total = nt * nslab + TAIL;        // K slabs this workgroup streams
     const int32_t last_blk = (int32_t)((n_rows + 15) >> 4) - 1;
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
     const uint32_t lane16 = 16u * lane;
+    auto lag_of = [](int a) { return STAG ? a : 0; };  // slabs by which block a's tiles start after block 0's
 
     // ---- this wave's queries: 2 wv and 2 wv + 1 ---------------------------------------------------------------------------------------
     const bool has0 = 2 * wv < n_q, has1 = 2 * wv + 1 < n_q;  // wave-uniform
@@ -224,69 +222,54 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     constexpr int QPW = 8, CPW = 2;  // pieces per feeder and slab
     const bool feeder = wv < 4;
     const char* qb1[QPW];
-    const char* cb1[CPW];
-    int fq_s = 0, fq_slot = 0, fc_s = 0, fc_tile = 0, fc_slot = 0;
-    auto feed_tile = [&](int t) __attribute__((always_inline)) {
-        if constexpr (DBG & 64) t = 0;  // (timing: the corpus stream out of L2)
-        const int32_t b0 = ((ROWS ? fc_pos.rt * PP_RT : org + t * PP_RT) >> 4) + CPW * (wv & 3);
+    int fq_s = 0, fq_slot = 0, fc_s = 0, fc_r = 0, fc_slot = 0;  // K slab (and round = tile of block 0) of the NEXT fetch, ring slots
 #pragma unroll
-        for (int i = 0; i < CPW; ++i) {
-            int32_t blk = b0 + i;
-            blk = blk < last_blk ? blk : last_blk;  // past the image: harmless re-read of the last block, never emitted
-            cb1[i] = planes + pp_uniform_i64((int64_t)blk * nslab * 1024);
-        }
-    };
-    feed_tile(0);
-    // query pieces of a tile's query tile (MODE 0: the pass' 16 queries; MODE 2: groups 16 qt .. 16 qt + 15)
-    int fq_tile = 0;
-    auto feed_q = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < QPW; ++i) {
-            const int p = QPW * (wv & 3) + i;
-            int ql = 16 * fq_pos.qt + (p >> 1);
-            ql = ql < n_q ? ql : n_q - 1;  // (clamped: pieces of queries the pass does not have are copied from a valid one, never used)
-            qb1[i] = qfrag + pp_uniform_i64(((int64_t)ql * nslab * 4 + 2 * (p & 1)) * 1024);  // hi fragments of block p & 1
-        }
-    };
-    feed_q();
+    for (int i = 0; i < QPW; ++i) {
+        const int p = QPW * (wv & 3) + i;
+        int ql = 16 * qt + (p >> 1);
+        ql = ql < n_q ? ql : n_q - 1;  // (clamped: pieces of queries the pass does not have are copied from a valid one, never used)
+        qb1[i] = qfrag + pp_uniform_i64(((int64_t)ql * nslab * 4 + 2 * (p & 1)) * 1024);  // hi fragments of block p & 1
+    }
     auto issue_q = [&](int i) __attribute__((always_inline)) {
         if (!feeder) return;
         if constexpr (DBG & 32) return;
         pp_dma<false>(lds_base + (uint32_t)(PP_QOFF + fq_slot * PP_QSLOT + (QPW * wv + i) * 1024), qb1[i] + (int64_t)fq_s * 4096, lane16);
     };
     auto advance_q = [&]() __attribute__((always_inline)) {
-        if (++fq_s == nslab) {
-            fq_s = 0;
-            if constexpr (ROWS) {  // the next pair may belong to the next query tile (once or twice per workgroup)
-                if (fq_tile + 1 < nt) {
-                    ++fq_tile;
-                    const int32_t before = fq_pos.qt;
-                    next_pair(fq_pos);
-                    if (fq_pos.qt != before) feed_q();
-                }
-            }
-        }
+        if (++fq_s == nslab) fq_s = 0;
         fq_slot = fq_slot + 1 == PP_DQ ? 0 : fq_slot + 1;
     };
-    auto issue_c1 = [&](int i) __attribute__((always_inline)) {
+    // corpus block a = 2 (wv & 3) + i of the slab being fetched: K slab fc_s of ITS current tile -- round fc_r once the slab index has
+    // reached the block's lag, the round before until then (before the first tile and after the last: some valid tile, multiplied into
+    // sums nobody reads)
+    const int32_t blk_org = (org >> 4) + CPW * (wv & 3);
+    const int64_t slab_bytes = (int64_t)nslab * 1024;
+    auto issue_c1 = [&](auto I_) __attribute__((always_inline)) {
+        constexpr int i = decltype(I_)::value;
         if (!feeder) return;
         if constexpr (DBG & 16) return;
-        pp_dma<true>(lds_base + (uint32_t)(fc_slot * PP_CSLOT + (CPW * wv + i) * 1024), cb1[i] + (int64_t)fc_s * 1024, lane16);
+        int t = fc_r - (fc_s < lag_of(CPW * (wv & 3) + i) ? 1 : 0);
+        t = t < 0 ? 0 : (t < nt ? t : nt - 1);
+        if constexpr (DBG & 64) t = 0;  // (timing: the corpus stream out of L2)
+        int32_t blk = blk_org + i + t * PP_NBLK;
+        blk = blk < last_blk ? blk : last_blk;  // past the image: harmless re-read of the last block, never emitted
+        const char* src = planes + pp_uniform_i64((int64_t)blk * slab_bytes + (int64_t)fc_s * 1024);
+        pp_dma<true>(lds_base + (uint32_t)(fc_slot * PP_CSLOT + (CPW * wv + i) * 1024), src, lane16);
     };
     auto advance_c = [&]() __attribute__((always_inline)) {
-        if (++fc_s == nslab) {  // past the end: re-fetch the last tile (keeps the vmcnt bookkeeping uniform)
-            fc_s = 0;
-            if (fc_tile + 1 < nt) { ++fc_tile; next_pair(fc_pos); feed_tile(fc_tile); }
-        }
+        if (++fc_s == nslab) { fc_s = 0; ++fc_r; }
         fc_slot = fc_slot + 1 == PP_DC ? 0 : fc_slot + 1;
     };
     // A feeder's queue, old -> new, half-way through slab g: .. Q(g+2) x8, C(g+2) x2 | Q(g+3) x8, C(g+3) x2 -- everything up to its pieces of
-    // slab g + 2 has retired when 10 operations are outstanding, plus the stores of a tile that finished since (newer than all of these for
-    // the two waits after it).
-    int st_pending = 0, st_slabs = 0;
+    // slab g + 2 has retired when 10 operations are outstanding, plus the epilogue stores issued since that are NEWER than the pieces of
+    // slab g + 2: st_a for the next wait, st_b for the one after.  A block epilogue right after the barrier of slab g (STAG, lead waves)
+    // stores before the DMAs of slab g + 4 are issued: it counts in the next wait only; an epilogue at the end of a slab stores after
+    // them: it counts in the next two.
+    int st_a = 0, st_b = 0;
     auto certify = [&]() __attribute__((always_inline)) {
-        if (feeder) pp_wait_vm<QPW + CPW>(st_slabs > 0 ? st_pending : 0);
-        if (st_slabs > 0) --st_slabs;
+        if (feeder) pp_wait_vm<QPW + CPW>(st_a);
+        st_a = st_b;
+        st_b = 0;
     };
 
     // ---- accumulators: S[corpus row 16 a + 4 g + u][query vector 16 qb + n], lane = 16 g + n; [query of the wave][qb][a] ------
@@ -310,14 +293,6 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
             if constexpr (a < 4 && !(DBG & 2048)) pp_read<a * 1024>(qn[a], rd_q + (uint32_t)(q_slot * PP_QSLOT));
         }
     };
-
-    // ---- one K slab: MFMAs of slab g from registers, and after each block's four MFMAs the LDS read that re-loads its fragment register for
-    // slab g + 1 (the query fragments go with the first four) -- the wave's 12 KiB of fragment reads spread over the whole slab: squeezed
-    // into its second half, as in the first version, all eight waves' reads (96 KiB, 768 cycles of LDS bandwidth) did not fit beside 512 cycles
-    // of MFMAs and every slab ended waiting for LDS (measured: 0.71 ms per pass without any DMA where the MFMAs alone are 0.42).  HALF-WAY
-    // through, the feeders' wait and the workgroup barrier: they certify slab g + 2 as landed -- the reads of the NEXT slab may start with its
-    // first MFMA -- and slab g's LDS slots as free (everybody read them during slab g - 1): this wave's DMAs of slab g + 4 follow, between the
-    // remaining MFMAs.  No compiler-visible memory operation in here: the body carries no wait but the two written out.
     auto mfma_group = [&](f32x4 (&q)[4], auto A_) __attribute__((always_inline)) {
         constexpr int A = decltype(A_)::value;
         if constexpr (!(DBG & 2)) {
@@ -327,67 +302,10 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
             acc[1][1][A] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(ef[A]), pp_h(q[3]), acc[1][1][A], 0, 0, 0);
         }
     };
-    // The two waves of a SIMD (w and w + 4) run the same stream half a step apart: waves 4-7 (LAG) issue each fragment read one MFMA group later
-    // than waves 0-3, so that one wave's LDS instructions (a ds_read_b128 holds its wave's issue for ~30 cycles) sit beside its partner's
-    // four MFMAs instead of beside the partner's own reads -- an in-order wave cannot put an MFMA into matrix-pipe time that is idle while it
-    // is itself busy issuing something else.
-    auto slab = [&](f32x4 (&q)[4], f32x4 (&qn)[4], auto LAG_) __attribute__((always_inline)) {
-        constexpr bool LAG = decltype(LAG_)::value;
-        auto G = [&](auto A_) __attribute__((always_inline)) { mfma_group(q, A_); };
-        auto R = [&](auto A_) __attribute__((always_inline)) { read_slab(qn, A_); };
-        auto D = [&](auto B_) __attribute__((always_inline)) {  // a quarter of this wave's query pieces of slab g + 4
-            constexpr int B = decltype(B_)::value;
-            issue_q(2 * B);
-            issue_q(2 * B + 1);
-        };
-#define PP_I(N) std::integral_constant<int, N>{}
-        if constexpr (!LAG) {
-            G(PP_I(0)); R(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(1)); R(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(2)); R(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(3)); R(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the reads of the previous slab's second half: corpus blocks 4-7 of slab g (issued half a slab ago)
-        } else {
-            G(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(1)); R(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(2)); R(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(3)); R(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-        }
-        pp_pin(ef[4], ef[5], ef[6], ef[7]);
-        certify();  // this wave's pieces of slab g + 2
-        asm volatile("s_barrier" ::: "memory");  // slab g + 2 is readable from the next slab on; everybody finished reading slab g (its last reads were waited for just above)
-        if constexpr (!LAG) {
-            G(PP_I(4)); R(PP_I(4)); D(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(5)); R(PP_I(5)); D(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(6)); R(PP_I(6)); D(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(7)); R(PP_I(7)); D(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
-        } else {
-            G(PP_I(4)); R(PP_I(3)); D(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(5)); R(PP_I(4)); D(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(6)); R(PP_I(5)); D(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(7)); R(PP_I(6)); D(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
-            R(PP_I(7)); __builtin_amdgcn_sched_barrier(0);
-        }
-#undef PP_I
-        issue_c1(0);
-        issue_c1(1);
-        advance_q();
-        advance_c();
-        c_slot = c_slot + 1 == PP_DC ? 0 : c_slot + 1;
-        q_slot = q_slot + 1 == PP_DQ ? 0 : q_slot + 1;
-    };
-    // LDS reads return in order: with the four reads of blocks 4-7 still outstanding, the eight in front of them (blocks 0-3 and the query
-    // fragments of slab g + 1) are real values now -- a wait that was served half a slab ago instead of one that exposes an LDS round trip
-    // under load at the end of every slab (lgkmcnt(0) there: + 0.18 ms per pass).  Blocks 4-7 are waited for before the next barrier.
-    auto landed = [&](f32x4 (&qn)[4]) __attribute__((always_inline)) {
-        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-        pp_pin(ef[0], ef[1], ef[2], ef[3]);
-        pp_pin(qn[0], qn[1], qn[2], qn[3]);
-    };
 
-    // ---- tile epilogue: all in registers ----------------------------------------------------------------------------------------------
-    // A block's 16 x 64 scores sit in 16 registers: register (c = 2 q + qb, u), lane (g, n) = row 4 g + u, vector n of set c.  Per block:
+    // ---- block epilogues ---------------------------------------------------------------------------------------------------------------
+    // MODE 0, all in registers.  A block's 16 x 64 scores sit in 16 registers: register (c = 2 q + qb, u), lane (g, n) = row 4 g + u, vector n
+    // of set c:
     //   (1) 4 x 4 transposes between the register index c and the lane group g (v_permlane32_swap / v_permlane16_swap, 16 instructions):
     //       afterwards lane (G, n) owns query vector n of set G and register 4 c + u is corpus row 4 c + u -- every row of the block in one lane;
     //   (2) the per-chunk maximum is a running v_max down the 16 registers; a chunk end is the same row in every lane, so "restart here"
@@ -398,8 +316,6 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     //       lanes of a DPP row in which every step also halves the number of registers (bank-masked v_add_f32_dpp at distances 8 and 4,
     //       quad permutes for 2 and 1): 32 instructions, one register of results -- lane 16 G + 4 b + t holds row
     //       (t >> 1) + 2 (b & 1) + 4 (b >> 1) + 8 (G & 1) of query G >> 1 -- and one masked store for all the chunks that end in the block.
-    // ~75 VALU operations per block and no LDS traffic (the first in-register version, a segmented DPP scan along the lanes with the rows
-    // across a DPP row, took ~275; the LDS transpose before this one ~170 plus 16 KiB of LDS traffic per block and wave: profiles/r03_l..q).
     const int fG = lane >> 4, fb = (lane >> 2) & 3, ft = lane & 3;
     const int my_row = (ft >> 1) + 2 * (fb & 1) + 4 * (fb >> 1) + 8 * (fG & 1);
     const uint32_t my_bit = 1u << my_row, my_below = my_bit - 1u;
@@ -422,8 +338,19 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         x = __uint_as_float(r[0]);
         y = __uint_as_float(r[1]);
     };
-    auto block_epilogue = [&](auto A_, uint32_t E, int32_t base, int& n_st) __attribute__((always_inline)) {
+    auto zero_block = [&](auto A_) __attribute__((always_inline)) {
         constexpr int a = decltype(A_)::value;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) acc[q][qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    };
+    // returns the number of store instructions it issued (wave-uniform)
+    [[maybe_unused]] auto block_epilogue_maxsim = [&](auto A_, int T) __attribute__((always_inline)) -> int {
+        constexpr int a = decltype(A_)::value;
+        const int32_t base = org + T * PP_RT + 16 * a;
+        // "last row of its chunk" bits of the block's 16 rows: half a word of the bitmap
+        const uint32_t E = (ends_bits[base >> 5] >> (base & 16)) & 0xffffu;
         float z[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[r] = acc[r >> 3][(r >> 2) & 1][a][r & 3];
@@ -498,121 +425,97 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         hi = hi > 16 ? 16 : hi;
         uint32_t EM = E & ((1u << hi) - 1u) & ~((1u << lo) - 1u);
         asm("" : "+s"(EM));
+        int n_st = 0;
         if (EM != 0u) {  // wave-uniform: some chunk of this workgroup ends in this block
             if ((EM & my_bit) && e_has && !(DBG & 256)) e_out[ord_run + __builtin_popcount(E & my_below)] = w * e_unscale;
             if constexpr (DBG & 256) run += w;  // (timing: no store, the sum stays live)
-            ++n_st;
+            n_st = 1;
         }
         ord_run += __builtin_popcount(E);
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb) acc[q][qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        zero_block(A_);
+        return n_st;
     };
 
-    // ---- MODE 2 tile epilogue: threshold test of every accumulator, records into the wave-private log ---------------------------------------
-    // Register (c = 2 q + qb, a, u), lane (g, n) = corpus row 16 a + 4 g + u of the tile against query 32 (16 qt + 2 wv + q) + 16 qb + n.
-    // T4[c]: a lower bound of what the raw accumulator must reach (cosine: divided by the row's |e|), per lane, recomputed when the query
-    // tile changes: the statements of maxsim_gemm.hip's epilogue_cand (1e-5 of slack for the roundings of 1 - (1 - c); thresholds of
-    // queries past B are +inf).  Cosine: acc >= T |e_row| follows from acc >= min(T min|e|, T max|e|) over the row's 16-row block.
-    [[maybe_unused]] float T4[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
-    [[maybe_unused]] int cur_qt = -1;
+    // MODE 2: threshold test of every accumulator of the block, records into the wave-private log.  Register (c = 2 q + qb, a, u), lane
+    // (g, n) = corpus row 16 a + 4 g + u of the tile against query 32 (16 qt + 2 wv + q) + 16 qb + n.  T4[c]: a lower bound of what the raw
+    // accumulator must reach (cosine: divided by the row's |e|), per lane, computed once per workgroup: the statements of maxsim_gemm.hip's
+    // epilogue_cand (1e-5 of slack for the roundings of 1 - (1 - c); thresholds of queries past B are +inf).  Cosine: acc >= T |e_row| follows
+    // from acc >= min(T min|e|, T max|e|) over the row's 16-row block.
+    // The four thresholds of a lane live in ONE register across the K loop (T4x: lane group g holds the threshold of column set c = g; the
+    // block epilogue hands every lane its four values back with ds_bpermute, the LDS crossbar without any LDS memory) -- as four registers
+    // they were what the allocator spilled, and a scratch reload inside the loop puts `s_waitcnt vmcnt(0)` at its header.
+    [[maybe_unused]] float T4x = INFINITY;
     [[maybe_unused]] uint32_t ncand = 0;  // wave-uniform: records this wave has logged
-    [[maybe_unused]] uint2* const my_log = ROWS ? rs.log + ((size_t)blockIdx.x * 8 + wv) * (size_t)rs.log_cap : nullptr;
-    [[maybe_unused]] auto epilogue_rows = [&](int t) __attribute__((always_inline)) {
-        if constexpr (ROWS) {
-            const int32_t row0 = c_pos.rt * PP_RT;
-            const int qt = c_pos.qt;
-            const bool cosine = rs.metric == SCAN_COSINE;
-            // Opaque copies of the lane coordinates: with the plain values every record word below (128 of them) is loop-invariant, the
-            // compiler hoists them out of the K loop and spills them (the note in maxsim_gemm.hip's epilogue_cand)
-            int ln = lane & 15;
+    [[maybe_unused]] uint2* const my_log = ROWS ? rs.log + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv) * (size_t)rs.log_cap : nullptr;
+    [[maybe_unused]] const bool cosine = ROWS && rs.metric == SCAN_COSINE;
+    if constexpr (ROWS) {  // (before the first DMA: these loads are ordinary ones)
+        const int c = lane >> 4;
+        const int32_t q = (16 * qt + 2 * wv + (c >> 1)) * 32 + 16 * (c & 1) + (lane & 15);
+        const int32_t qc = q < rs.B ? q : rs.B - 1;
+        const float us = rs.q_unscale[qc] * inv_e_scale;  // > 0, a power of two
+        const float tq = rs.tau[qc];
+        const bool bad = q < rs.B && !(tq > -INFINITY);  // NaN or -inf: unusable
+        const float slack = 1e-5f * fmaxf(1.0f, fabsf(tq));
+        const float t_dot = cosine ? (tq - slack) * sqrtf(rs.q_sumsq[qc]) : (tq - 1.0f) - slack;  // bound on d (cosine: on d / |e|)
+        T4x = q < rs.B ? (t_dot - fabsf(t_dot) * 1e-6f) / us : INFINITY;
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *rs.overflow = 1u;
+    }
+    [[maybe_unused]] auto block_epilogue_rows = [&](auto A_, int T) __attribute__((always_inline)) -> int {
+        constexpr int a = decltype(A_)::value;
+        int n_st = 0;
+        const int32_t base = org + T * PP_RT + 16 * a;
+        if (base < (int32_t)n_rows) {  // (wave-uniform) blocks past the corpus are re-reads of its last block: not scored
+            // Opaque copy of the lane's coordinates: with the plain value every record word below is loop-invariant, the compiler hoists
+            // them out of the K loop and spills them (the note in maxsim_gemm.hip's epilogue_cand)
             uint32_t lane_code = ((uint32_t)(lane & 15) << 7) | (uint32_t)(4 * (lane >> 4));  // (query column, first row of the lane's quad)
-            asm volatile("" : "+v"(ln), "+v"(lane_code));
-            if (qt != cur_qt) {  // (wave-uniform; once or twice per workgroup: the loads below drain the feeders' look-ahead, rarely)
-                cur_qt = qt;
-                bool bad = false;
-                float l_us[4], l_tq[4], l_ss[4];
+            asm volatile("" : "+v"(lane_code));
+            float t4[4];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int32_t q = (16 * qt + 2 * wv + (c >> 1)) * 32 + 16 * (c & 1) + ln;
-                    const int32_t qc = q < rs.B ? q : rs.B - 1;
-                    l_us[c] = pp_gload(rs.q_unscale + qc);
-                    l_tq[c] = pp_gload(rs.tau + qc);
-                    l_ss[c] = cosine ? pp_gload(rs.q_sumsq + qc) : 0.f;
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (int c = 0; c < 4; ++c)  // column set c's thresholds sit in lane group c of T4x
+                t4[c] = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(((uint32_t)c << 6) | ((uint32_t)(lane & 15) << 2)), __float_as_int(T4x)));
+            if (cosine) {
+                // two scalars per block, slightly widened: T * |e| is formed with one rounding here and none in the exact test
+                const f32x2s mm = pp_sload2(rs.blk_minmax + 2 * (base >> 4));
+                const float nmin = mm[0] * 0.999999f, nmax = mm[1] * 1.000001f;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    pp_pin1(l_us[c]);
-                    pp_pin1(l_tq[c]);
-                    pp_pin1(l_ss[c]);
-                    const int32_t q = (16 * qt + 2 * wv + (c >> 1)) * 32 + 16 * (c & 1) + ln;
-                    const float us = l_us[c] * inv_e_scale;  // > 0, a power of two
-                    const float tq = l_tq[c];
-                    bad |= q < rs.B && !(tq > -INFINITY);  // NaN or -inf: unusable
-                    const float slack = 1e-5f * fmaxf(1.0f, fabsf(tq));
-                    const float t_dot = cosine ? (tq - slack) * sqrtf(l_ss[c]) : (tq - 1.0f) - slack;  // bound on d (cosine: on d / |e|)
-                    T4[c] = q < rs.B ? (t_dot - fabsf(t_dot) * 1e-6f) / us : INFINITY;
-                }
-                if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *rs.overflow = 1u;
+                for (int c = 0; c < 4; ++c) t4[c] = fminf(t4[c] * nmin, t4[c] * nmax);
             }
-            int n_st = 0;
-            f32x16 mm16 = {};
-            if (cosine) mm16 = pp_sload16(rs.blk_minmax + 2 * (row0 >> 4));  // (min, max) |e| of the tile's eight blocks
-            [&]<int... A>(std::integer_sequence<int, A...>) {
-                ([&] {
-                    constexpr int a = A;
-                    const int32_t base = row0 + 16 * a;
-                    if (base < (int32_t)n_rows) {  // (wave-uniform) blocks past the corpus are re-reads of its last block: not scored
-                        float t4[4];
-                        if (cosine) {
-                            // two scalars per block, slightly widened: T * |e| is formed with one rounding here and none in the exact test
-                            const float nmin = mm16[2 * a] * 0.999999f, nmax = mm16[2 * a + 1] * 1.000001f;
+            const uint32_t code_a = ((uint32_t)T << 13) | (uint32_t)(16 * a);
 #pragma unroll
-                            for (int c = 0; c < 4; ++c) t4[c] = fminf(T4[c] * nmin, T4[c] * nmax);
-                        } else {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) t4[c] = T4[c];
+            for (int c = 0; c < 4; ++c) {
+                // one test per (block, query column) on the largest of the lane's four rows; the rare group that has a hit (~0.2 % of the
+                // scores reach a threshold: about every other group of 256) is looked at register by register -- in a LOOP of four trips
+                // that rotates the four values through one register (this code exists once per block, slab parity and wave role: unrolled
+                // it alone would be larger than the instruction cache)
+                const f32x4 v4 = acc[c >> 1][c & 1][a];
+                const float top = fmaxf(fmaxf(v4[0], v4[1]), fmaxf(v4[2], v4[3]));
+                if (__builtin_amdgcn_ballot_w64(top >= t4[c]) != 0ull) {  // (wave-uniform)
+                    float r0 = v4[0], r1 = v4[1], r2 = v4[2], r3 = v4[3];
+                    uint32_t code = (code_a + ((uint32_t)c << 11)) | lane_code;
+#pragma nounroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool pass = r0 >= t4[c];
+                        const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
+                        if (mask != 0ull) {
+                            const uint32_t pos = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                            if (pass && pos < (uint32_t)rs.log_cap) my_log[pos] = make_uint2(__float_as_uint(r0), code);
+                            ncand += (uint32_t)__builtin_popcountll(mask);
+                            ++n_st;
                         }
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) {
-                            // one test per (block, query column) on the largest of the lane's four rows; the rare group that has a hit
-                            // (~0.2 % of the scores reach a threshold: about every other group of 256) is looked at register by register
-                            const f32x4 v4 = acc[c >> 1][c & 1][a];
-                            const float top = fmaxf(fmaxf(v4[0], v4[1]), fmaxf(v4[2], v4[3]));
-                            if (__builtin_amdgcn_ballot_w64(top >= t4[c]) != 0ull) {  // (wave-uniform)
-                                const uint32_t code = ((uint32_t)t << 13) | ((uint32_t)c << 11) | (uint32_t)(16 * a);
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    const bool pass = v4[u] >= t4[c];
-                                    const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
-                                    if (mask != 0ull) {
-                                        const uint32_t pos = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                                        if (pass && pos < (uint32_t)rs.log_cap) my_log[pos] = make_uint2(__float_as_uint(v4[u]), (code + (uint32_t)u) | lane_code);
-                                        ncand += (uint32_t)__builtin_popcountll(mask);
-                                        ++n_st;
-                                    }
-                                }
-                            }
-                        }
+                        r0 = r1; r1 = r2; r2 = r3;
+                        ++code;
+                        asm volatile("" : "+v"(r0), "+v"(code));  // (keeps the loop a loop)
                     }
-#pragma unroll
-                    for (int q = 0; q < 2; ++q)
-#pragma unroll
-                        for (int qb = 0; qb < 2; ++qb) acc[q][qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    __builtin_amdgcn_sched_barrier(0);  // one block at a time
-                }(), ...);
-            }(std::make_integer_sequence<int, PP_NBLK>{});
-            // the log stores are newer than every DMA issued so far: they count in the feeders' next two waits (see certify())
-            st_pending = n_st;
-            st_slabs = n_st > 0 ? 2 : 0;
+                }
+            }
         }
+        zero_block(A_);
+        return n_st;
     };
-    // When the workgroup's pairs are done: every record once more with the exact formulas (maxsim_gemm.hip flush_candidates: same
+    // When the workgroup's tiles are done: every record once more with the exact formulas (maxsim_gemm.hip flush_candidates: same
     // statements, same bits), kept if it reaches its query's threshold exactly, appended to the query's list.
     [[maybe_unused]] auto flush_rows = [&]() __attribute__((always_inline)) {
-        if constexpr (ROWS) {
+        if constexpr (ROWS && !(DBG & 512)) {
             if (ncand > (uint32_t)rs.log_cap) {  // (wave-uniform) more than the log holds: let the dense path decide
                 if (lane == 0) *rs.overflow = 1u;
                 ncand = (uint32_t)rs.log_cap;
@@ -621,9 +524,8 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
             for (uint32_t i = lane; i < ncand; i += 64) {
                 const uint2 rec = my_log[i];
                 const uint32_t m = rec.y;
-                const int t = (int)(m >> 13), c = (int)((m >> 11) & 3u), n = (int)((m >> 7) & 15u), r = (int)(m & 127u);
-                const int32_t pair = vt0 + t;  // (one division per RECORD, after the loop: ~1 400 per wave)
-                const int32_t q = (16 * (pair / Tr) + 2 * wv + (c >> 1)) * 32 + 16 * (c & 1) + n, row = (pair % Tr) * PP_RT + r;
+                const int T = (int)(m >> 13), c = (int)((m >> 11) & 3u), n = (int)((m >> 7) & 15u), r = (int)(m & 127u);
+                const int32_t q = (16 * qt + 2 * wv + (c >> 1)) * 32 + 16 * (c & 1) + n, row = org + T * PP_RT + r;
                 if (q >= rs.B || row >= (int32_t)n_rows) continue;
                 const float d = __uint_as_float(rec.x) * (rs.q_unscale[q] * inv_e_scale);  // the dot product, as MODE 1 of maxsim_gemm.hip forms it
                 float v = d;
@@ -640,36 +542,134 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
             }
         }
     };
-    auto epilogue = [&](int t) __attribute__((always_inline)) {
+    // One block's epilogue for tile T of this workgroup (T outside [0, nt): sums nobody reads -- before a block's first tile, after its
+    // last); the stores it issued go into the feeders' wait bookkeeping: `both` = it ran at the END of a slab (see certify()).
+    // (A runtime block index -- one copy of this code for all eight blocks -- does not work: the accumulators would have to be indexed at
+    // run time, which puts them in scratch memory, or be merged over eight predecessors, which the register allocator answers with
+    // hundreds of spills: both tried, round 4.)
+    auto block_epilogue = [&](auto A_, int T, bool both) __attribute__((always_inline)) {
         if constexpr (DBG & 128) return;
-        if constexpr (ROWS) { epilogue_rows(t); return; }
-        tile_now = t;
-        stamp(0);
-        const int32_t row0 = org + t * PP_RT;
-        // "last row of its chunk" bits of the tile's 128 rows: 5 words from row0 / 32, shifted by 16 when row0 is odd in blocks
-        uint32_t m[5];
-        const uint32_t* const eb = ends_bits + (row0 >> 5);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) m[i] = eb[i];
-        const bool odd = (row0 & 16) != 0;
-        uint32_t mm[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mm[i] = odd ? (m[i] >> 16) | (m[i + 1] << 16) : m[i];
-        int n_st = 0;
-        [&]<int... A>(std::integer_sequence<int, A...>) {
-            ((block_epilogue(std::integral_constant<int, A>{}, (mm[A >> 1] >> (16 * (A & 1))) & 0xffffu, row0 + 16 * A, n_st), stamp(1 + A)), ...);
-        }(std::make_integer_sequence<int, PP_NBLK>{});
-        stamp(9);
-        // The stores are newer than every DMA issued so far: they count in the feeders' next two waits (see certify()).
-        st_pending = n_st;
-        st_slabs = n_st > 0 ? 2 : 0;
+        if (T < 0 || T >= nt) {  // (wave-uniform)
+            zero_block(A_);
+            return;
+        }
+        int n_st;
+        if constexpr (ROWS) n_st = block_epilogue_rows(A_, T);
+        else n_st = block_epilogue_maxsim(A_, T);
+        st_a += n_st;
+        if (both) st_b += n_st;
+    };
+
+    // ---- one K slab: MFMAs of slab g from registers, and after each block's four MFMAs the LDS read that re-loads its fragment register for
+    // slab g + 1 (the query fragments go with the first four) -- the wave's 12 KiB of fragment reads spread over the whole slab.  HALF-WAY
+    // through, the feeders' wait and the workgroup barrier: they certify slab g + 2 as landed -- the reads of the NEXT slab may start with its
+    // first MFMA -- and slab g's LDS slots as free (everybody read them during slab g - 1): this wave's DMAs of slab g + 4 follow, between the
+    // remaining MFMAs.  No compiler-visible memory LOAD in here: the body carries no wait but the ones written out.
+    // The two waves of a SIMD (w and w + 4) run the same stream half a step apart: waves 4-7 (LAG) issue each fragment read one MFMA group later
+    // than waves 0-3, so that one wave's LDS instructions sit beside its partner's four MFMAs instead of beside the partner's own reads.
+    // Block epilogues (k = the slab's K index, r = its round: the tile block 0 is multiplying):
+    //   STAG, lead waves: right after the barrier -- block a of tile r - 1 at k = a - 1 (a = 1..3: its last MFMAs were in the first half of this
+    //                     slab) or k = a (a = 4..7: its last MFMAs were in the second half of the previous slab, its first of the next tile come
+    //                     later in this half); block 0 of tile r at k = nslab - 1;
+    //   STAG, lag waves:  at the end of the slab -- block a of tile r - 1 at k = a - 1, block 0 of tile r at k = nslab - 1;
+    //   !STAG:            all eight blocks of tile r at the end of slab nslab - 1.
+    // In every case a block's epilogue sits between its last MFMA of one tile and its first of the next, the epilogues of a wave run in
+    // row order (the open chunk's maximum and the chunk ordinal are carried from one to the next), and with dim = 256 (nslab = 8) the two
+    // epilogues that share slab 7 (block 7 of tile r - 1, block 0 of tile r) run in that order.
+    int c_s = 0, c_r = 0;  // K slab and round of the slab being multiplied
+#define PP_I(N) std::integral_constant<int, N>{}
+    auto hook_mid = [&](auto LAG_) __attribute__((always_inline)) {
+        if constexpr (STAG && !decltype(LAG_)::value) {
+            if (c_s == 0) block_epilogue(PP_I(1), c_r - 1, false);
+            if (c_s == 1) block_epilogue(PP_I(2), c_r - 1, false);
+            if (c_s == 2) block_epilogue(PP_I(3), c_r - 1, false);
+            if (c_s == 4) block_epilogue(PP_I(4), c_r - 1, false);
+            if (c_s == 5) block_epilogue(PP_I(5), c_r - 1, false);
+            if (c_s == 6) block_epilogue(PP_I(6), c_r - 1, false);
+            if (c_s == 7) block_epilogue(PP_I(7), c_r - 1, false);
+            if (c_s == nslab - 1) block_epilogue(PP_I(0), c_r, false);
+        }
+    };
+    auto hook_end = [&](auto LAG_) __attribute__((always_inline)) {
+        if constexpr (STAG && decltype(LAG_)::value) {
+            if (c_s == 0) block_epilogue(PP_I(1), c_r - 1, true);
+            if (c_s == 1) block_epilogue(PP_I(2), c_r - 1, true);
+            if (c_s == 2) block_epilogue(PP_I(3), c_r - 1, true);
+            if (c_s == 3) block_epilogue(PP_I(4), c_r - 1, true);
+            if (c_s == 4) block_epilogue(PP_I(5), c_r - 1, true);
+            if (c_s == 5) block_epilogue(PP_I(6), c_r - 1, true);
+            if (c_s == 6) block_epilogue(PP_I(7), c_r - 1, true);
+            if (c_s == nslab - 1) block_epilogue(PP_I(0), c_r, true);
+        }
+        if constexpr (!STAG) {
+            if (c_s == nslab - 1) {
+                [&]<int... A>(std::integer_sequence<int, A...>) { (block_epilogue(std::integral_constant<int, A>{}, c_r, true), ...); }
+                (std::make_integer_sequence<int, PP_NBLK>{});
+            }
+        }
+    };
+    auto slab = [&](f32x4 (&q)[4], f32x4 (&qn)[4], auto LAG_) __attribute__((always_inline)) {
+        constexpr bool LAG = decltype(LAG_)::value;
+        auto G = [&](auto A_) __attribute__((always_inline)) { mfma_group(q, A_); };
+        auto R = [&](auto A_) __attribute__((always_inline)) { read_slab(qn, A_); };
+        auto D = [&](auto B_) __attribute__((always_inline)) {  // a quarter of this wave's query pieces of slab g + 4
+            constexpr int B = decltype(B_)::value;
+            issue_q(2 * B);
+            issue_q(2 * B + 1);
+        };
+        if constexpr (!LAG) {
+            G(PP_I(0)); R(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(1)); R(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(2)); R(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(3)); R(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the reads of the previous slab's second half: corpus blocks 4-7 of slab g (issued half a slab ago)
+        } else {
+            G(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(1)); R(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(2)); R(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(3)); R(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        }
+        pp_pin(ef[4], ef[5], ef[6], ef[7]);
+        certify();  // this wave's pieces of slab g + 2
+        asm volatile("s_barrier" ::: "memory");  // slab g + 2 is readable from the next slab on; everybody finished reading slab g (its last reads were waited for just above)
+        hook_mid(LAG_);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!LAG) {
+            G(PP_I(4)); R(PP_I(4)); D(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(5)); R(PP_I(5)); D(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(6)); R(PP_I(6)); D(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(7)); R(PP_I(7)); D(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
+        } else {
+            G(PP_I(4)); R(PP_I(3)); D(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(5)); R(PP_I(4)); D(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(6)); R(PP_I(5)); D(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(7)); R(PP_I(6)); D(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
+            R(PP_I(7)); __builtin_amdgcn_sched_barrier(0);
+        }
+        issue_c1(PP_I(0));
+        issue_c1(PP_I(1));
+        advance_q();
+        advance_c();
+        c_slot = c_slot + 1 == PP_DC ? 0 : c_slot + 1;
+        q_slot = q_slot + 1 == PP_DQ ? 0 : q_slot + 1;
+        hook_end(LAG_);
+        if (++c_s == nslab) { c_s = 0; ++c_r; }
+    };
+    // LDS reads return in order: with the four reads of blocks 4-7 still outstanding, the eight in front of them (blocks 0-3 and the query
+    // fragments of slab g + 1) are real values now -- a wait that was served half a slab ago instead of one that exposes an LDS round trip
+    // under load at the end of every slab (lgkmcnt(0) there: + 0.18 ms per pass).  Blocks 4-7 are waited for before the next barrier.
+    auto landed = [&](f32x4 (&qn)[4]) __attribute__((always_inline)) {
+        asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        pp_pin(ef[0], ef[1], ef[2], ef[3]);
+        pp_pin(qn[0], qn[1], qn[2], qn[3]);
     };
 
     // ---- prologue: Q(0..3), C(0..3) landed (the steady state issues Q(g + 4), C(g + 4) during slab g); slab 0's fragments ----------
     if (feeder) {
         for (int i = 0; i < 4; ++i) {
-#pragma unroll
-            for (int j = 0; j < CPW; ++j) issue_c1(j);
+            issue_c1(PP_I(0));
+            issue_c1(PP_I(1));
 #pragma unroll
             for (int j = 0; j < QPW; ++j) issue_q(j);
             advance_q();
@@ -683,26 +683,17 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     q_slot = 1;
     landed(qA);
     // ---- main loop: two slabs per iteration (two static sets of query fragment registers) -----------------------------------------
-    int c_s = 0, c_tile = 0;
     auto main_loop = [&](auto LAG_) __attribute__((always_inline)) {
-        // MODE 2 needs an even number of K slabs (dim % 64 == 0): a tile then ends in the SECOND step of an iteration only, and the long
-        // epilogue is instantiated once per loop instead of twice (the kernel's code has to stay inside the instruction cache)
-        auto step = [&](f32x4 (&q)[4], f32x4 (&qn)[4], auto CHECK_) __attribute__((always_inline)) {
-            slab(q, qn, LAG_);
-            ++c_s;
-            if (decltype(CHECK_)::value && c_s == nslab) {
-                epilogue(c_tile);
-                c_s = 0;
-                ++c_tile;
-                if constexpr (ROWS) next_pair(c_pos);
-            }
-            landed(qn);
-        };
         for (int g = 0; g < total; g += 2) {
-            step(qA, qB, std::integral_constant<bool, !ROWS>{});
-            if (ROWS || g + 1 < total) step(qB, qA, std::true_type{});
+            slab(qA, qB, LAG_);
+            landed(qB);
+            if (g + 1 < total) {
+                slab(qB, qA, LAG_);
+                landed(qA);
+            }
         }
     };
+#undef PP_I
     constexpr bool no_lag = (DBG & 1024) != 0;  // (timing: every wave runs the same stream)
     if (wv < 4 || no_lag) main_loop(std::false_type{});
     else main_loop(std::true_type{});
@@ -735,42 +726,23 @@ int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void*
     const float* qmeta = reinterpret_cast<const float*>(static_cast<const char*>(qbuf) + (size_t)n_queries * dim * 128) + 2 * (size_t)first;
     const int64_t tiles = (n_rows + PP_RT - 1) / PP_RT;
     const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
-    unsigned long long* trace = nullptr;
-#define RL_PP_LAUNCH(DBG_)                                                                                                              \
-    hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 0>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk, \
+    unsigned long long* const trace = nullptr;
+#define RL_PP_LAUNCH_S(DBG_, STAG_)                                                                                                     \
+    hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 0, STAG_>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk, \
                        chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if, trace, PpRows{})
+#define RL_PP_LAUNCH(DBG_) RL_PP_LAUNCH_S(DBG_, false)
 #ifdef RAGLITE_EXPERIMENTS
     // Experiment builds only (libraglite_hip_exp.so, scripts/gpu_calls/): instantiations that skip parts of the kernel to time the rest --
-    // WRONG results -- and the s_memtime trace of one tile's epilogue.  None of this is compiled into the shipped library.
+    // WRONG results -- and RAGLITE_PP_STAG=1, the block epilogues inside the main loop (correct results; measured, not shipped: see STAG).
+    // None of this is compiled into the shipped library.
     static const int dbg = std::getenv("RAGLITE_PP_DBG") ? std::atoi(std::getenv("RAGLITE_PP_DBG")) : 0;
-    static unsigned long long* trace_buf = [] {
-        unsigned long long* p = nullptr;
-        if (std::getenv("RAGLITE_PP_TRACE")) { (void)hipMalloc(&p, 8 * 16 * 8); (void)hipMemset(p, 0, 8 * 16 * 8); }
-        return p;
-    }();
-    trace = trace_buf;
-    if (trace) {
-        static int calls = 0;
-        RL_PP_LAUNCH(8192);
-        if (++calls == 10) {
-            static unsigned long long h[8 * 16];
-            (void)hipStreamSynchronize(s);
-            (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
-            for (int w = 0; w < 8; ++w) {
-                fprintf(stderr, "PPTRACE epilogue of tile 3, wave %d:", w);
-                for (int k = 0; k < 10; ++k) fprintf(stderr, " %7lld", (long long)(h[w * 16 + k] - h[0]));
-                fprintf(stderr, "\n");
-            }
-        }
-        RL_HIP(hipGetLastError());
-        return RL_OK;
-    }
-    if (dbg == 2) RL_PP_LAUNCH(2);
+    static const bool stag = std::getenv("RAGLITE_PP_STAG") && std::getenv("RAGLITE_PP_STAG")[0] == '1';
+    if (stag) { if (dbg == 128) RL_PP_LAUNCH_S(128, true); else RL_PP_LAUNCH_S(0, true); }
+    else if (dbg == 2) RL_PP_LAUNCH(2);
     else if (dbg == 1024) RL_PP_LAUNCH(1024);
     else if (dbg == 2208) RL_PP_LAUNCH(2208);
     else if (dbg == 160) RL_PP_LAUNCH(160);
     else if (dbg == 2176) RL_PP_LAUNCH(2176);
-    else if (dbg == 1152) RL_PP_LAUNCH(1152);
     else if (dbg == 176) RL_PP_LAUNCH(176);
     else if (dbg == 184) RL_PP_LAUNCH(184);
     else if (dbg == 128) RL_PP_LAUNCH(128);
@@ -778,6 +750,7 @@ int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void*
 #else
     RL_PP_LAUNCH(0);
 #endif
+#undef RL_PP_LAUNCH_S
 #undef RL_PP_LAUNCH
     RL_HIP(hipGetLastError());
     return RL_OK;
@@ -811,10 +784,10 @@ size_t pp_rows_scratch_bytes(int64_t n_rows, int32_t nb, int n_cu, int32_t expec
 
 // The candidate pass of the fused top-k (maxsim_gemm.hip MODE 2 semantics: per-query lists of (similarity, row) for every row whose
 // similarity reaches cand->tau[q]) over a ONE-PLANE image at one product per multiply, on the 128-row x 512-query tile.  `scratch`: the
-// query side as launch_score_planes_queries left it; `work`: pp_rows_scratch_bytes bytes.  cosine / dot; dim % 64 == 0, dim >= 256.
+// query side as launch_score_planes_queries left it; `work`: pp_rows_scratch_bytes bytes.  cosine / dot; dim % 32 == 0, dim >= 256.
 int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, const float* row_norm, int mode,
                         const CandArgs* cand, void* work, int32_t log_cap, int n_cu, hipStream_t s, float split_scale) {
-    if (nb < 1 || n_rows < 1 || dim % 64 || dim < 256 || !(split_scale > 0.f) || !image || !cand || !work) return RL_ERR_UNSUPPORTED;
+    if (nb < 1 || n_rows < 1 || dim % 32 || dim < 256 || !(split_scale > 0.f) || !image || !cand || !work) return RL_ERR_UNSUPPORTED;
     if (mode != SCAN_COSINE && mode != SCAN_DOT) return RL_ERR_UNSUPPORTED;
     if (mode == SCAN_COSINE && !row_norm) return RL_ERR_INVALID;
     if (cand->tau_stride != 1) return RL_ERR_UNSUPPORTED;
@@ -830,16 +803,33 @@ int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t 
     rs.metric = mode; rs.cand_scores = cand->scores; rs.cand_ids = cand->ids; rs.cand_cnt = cand->cnt; rs.overflow = cand->overflow; rs.cap = cand->cap;
     rs.log = static_cast<uint2*>(work);
     rs.log_cap = log_cap;
-    if (Tr * rs.QT / std::max<int64_t>(1, std::min<int64_t>(grid_cu, Tr * rs.QT)) + 2 >= (int64_t(1) << 19)) return RL_ERR_UNSUPPORTED;  // tile index bits of a record
+    if (rs.QT > grid_cu || Tr + 2 >= (int64_t(1) << 19)) return RL_ERR_UNSUPPORTED;  // one grid row per query tile; tile index bits of a record
     float* blk_mm = reinterpret_cast<float*>(static_cast<char*>(work) + (size_t)grid_cu * 8 * (size_t)log_cap * sizeof(uint2));
     rs.blk_minmax = blk_mm;
     if (mode == SCAN_COSINE) {
         const int64_t n_blocks = (n_rows + 15) / 16;
         hipLaunchKernelGGL(block_norm_minmax_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, s, row_norm, n_rows, n_blocks, blk_mm);
     }
-    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(grid_cu, Tr * rs.QT))), blk(512);
-    hipLaunchKernelGGL((maxsim_pp_kernel<0, 2>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, reinterpret_cast<const char*>(frag),
-                       nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, nullptr, nullptr, rs);
+    // blockIdx.y = the query tile; the workgroups of a grid row share the row tiles (QT <= CUs: checked above)
+    const int64_t gx = std::max<int64_t>(1, std::min<int64_t>(grid_cu / rs.QT, Tr));
+    const dim3 grid((unsigned)gx, (unsigned)rs.QT), blk(512);
+#define RL_PP_ROWS_S(DBG_, STAG_)                                                                                                         \
+    hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 2, STAG_>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, reinterpret_cast<const char*>(frag), \
+                       nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, nullptr, nullptr, rs)
+#define RL_PP_ROWS(DBG_) RL_PP_ROWS_S(DBG_, false)
+#ifdef RAGLITE_EXPERIMENTS  // timing skeletons (wrong results): 128 = no block epilogues, 512 = no flush of the record logs, 640 = neither; RAGLITE_PP_STAG=1
+    static const int dbg = std::getenv("RAGLITE_PP_ROWS_DBG") ? std::atoi(std::getenv("RAGLITE_PP_ROWS_DBG")) : 0;
+    static const bool stag = std::getenv("RAGLITE_PP_STAG") && std::getenv("RAGLITE_PP_STAG")[0] == '1';
+    if (stag) { if (dbg == 128) RL_PP_ROWS_S(128, true); else RL_PP_ROWS_S(0, true); }
+    else if (dbg == 128) RL_PP_ROWS(128);
+    else if (dbg == 512) RL_PP_ROWS(512);
+    else if (dbg == 640) RL_PP_ROWS(640);
+    else RL_PP_ROWS(0);
+#else
+    RL_PP_ROWS(0);
+#endif
+#undef RL_PP_ROWS_S
+#undef RL_PP_ROWS
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
