@@ -187,6 +187,7 @@ int rl_index_arithmetic(rl_index* index, int* in_effect);
  *   RL_OPT_FUSED_TOPK           0 / 1 (1)          B >= 96 row searches keep candidate lists instead of a score matrix
  *   RL_OPT_FUSED_HI             0 / 1 (1)          ... with both GEMM passes over the HI image at one product
  *   RL_OPT_FUSED_PP             0 / 1 (1)          ... and the candidate pass on the sixteen-group tile of maxsim_pp.hip
+ *   RL_OPT_FUSED_TWO_ROUNDS     0 / 1 (1)          ... in two rounds: thresholds tightened from the first 3/16 of the rows (0: one round)
  *   RL_OPT_FUSED_TOPK_CAP       0 | 1..8192 (0)    list capacity of the fused top-k (0: built-in; tests force overflows with it)
  *   RL_OPT_FUSED_TOPK_STRIDE    0 | >= 2 (0)       sample stride of the fused top-k (0: built-in rule)
  *   RL_OPT_GEMM_PASS            0 / 1 (1)          MaxSim batches of >= 3 queries share passes over the pre-split image
@@ -205,7 +206,7 @@ typedef enum {
     RL_OPT_HI_SEARCH = 1, RL_OPT_HI_MAXSIM = 2, RL_OPT_HI_PRODUCTS = 3, RL_OPT_PP_PASS = 4, RL_OPT_FUSED_TOPK = 5, RL_OPT_FUSED_HI = 6,
     RL_OPT_FUSED_PP = 7, RL_OPT_FUSED_TOPK_CAP = 8, RL_OPT_FUSED_TOPK_STRIDE = 9, RL_OPT_GEMM_PASS = 10, RL_OPT_QUERY_PAIRS = 11,
     RL_OPT_PLANES_GEMM = 12, RL_OPT_KEEP_IMAGE = 13, RL_OPT_KEEP_HI = 14, RL_OPT_IMAGE_HEADROOM_MB = 15, RL_OPT_ARITHMETIC = 16,
-    RL_OPT_EXACT_KTH_THRESHOLD = 17, RL_OPT_COUNT_ = 18
+    RL_OPT_EXACT_KTH_THRESHOLD = 17, RL_OPT_FUSED_TWO_ROUNDS = 18, RL_OPT_COUNT_ = 19
 } rl_option;
 int rl_set_default_option(int key, int64_t value);
 int rl_get_default_option(int key, int64_t* value);

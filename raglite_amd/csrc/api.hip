@@ -200,7 +200,7 @@ struct Options {
         for (auto& x : v) x = 0;
         v[RL_OPT_HI_SEARCH] = v[RL_OPT_HI_MAXSIM] = v[RL_OPT_HI_PRODUCTS] = v[RL_OPT_PP_PASS] = v[RL_OPT_FUSED_TOPK] = v[RL_OPT_FUSED_HI] = 1;
         v[RL_OPT_FUSED_PP] = v[RL_OPT_GEMM_PASS] = v[RL_OPT_QUERY_PAIRS] = v[RL_OPT_PLANES_GEMM] = v[RL_OPT_KEEP_IMAGE] = v[RL_OPT_KEEP_HI] = 1;
-        v[RL_OPT_EXACT_KTH_THRESHOLD] = 1;
+        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = 1;
         v[RL_OPT_IMAGE_HEADROOM_MB] = -1;
         v[RL_OPT_ARITHMETIC] = RL_ARITH_AUTO;
     }
@@ -212,7 +212,7 @@ bool option_value_ok(int key, int64_t value) {
     switch (key) {
         case RL_OPT_HI_SEARCH: case RL_OPT_HI_MAXSIM: case RL_OPT_PP_PASS: case RL_OPT_FUSED_TOPK: case RL_OPT_FUSED_HI: case RL_OPT_FUSED_PP:
         case RL_OPT_GEMM_PASS: case RL_OPT_QUERY_PAIRS: case RL_OPT_PLANES_GEMM: case RL_OPT_KEEP_IMAGE: case RL_OPT_KEEP_HI:
-        case RL_OPT_EXACT_KTH_THRESHOLD:
+        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS:
             return value == 0 || value == 1;
         case RL_OPT_HI_PRODUCTS: return value == 1 || value == 2;
         case RL_OPT_FUSED_TOPK_CAP: return value >= 0 && value <= MERGE_CAP;
@@ -301,6 +301,7 @@ struct rl_index {
     // while those pools have not been re-reserved, which `pools` pins down)
     struct FusedReplay {
         bool valid = false, pp = false; int32_t B = 0, log_cap = 0; int mode = 0; float* qs = nullptr; rl::CandArgs ca{}; uint32_t* cnt = nullptr;
+        const float* thr1 = nullptr; int64_t round1_tiles = 0;  // two-round candidate pass: the first round's thresholds and tiles
         const void* pools[3] = {nullptr, nullptr, nullptr};
     } replay;
 };
@@ -1332,7 +1333,7 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
     float* sc = idx->scores.as<float>();  // [B x ld], reserved by the caller: only the fallback touches it
     // ---- (1) sample pass + its exact top-k --------------------------------------------------------------------------------------
     RL_TRY(launch_score_planes_queries(d_q, B, idx->dim, qs, mode, s));
-    RL_TRY(launch_fill_f32(S_s, -std::numeric_limits<float>::infinity(), (int64_t)n_sample, s));  // rows past the corpus in the last tile
+    // (rows past the corpus in the last sampled tile: the pass writes them as -inf itself)
     RL_TRY(launch_score_planes_pass(idx->planes.p, n, idx->dim, B, qs, S_s, ld_s, idx->norm, idx->sumsq, mode, stride, nullptr, nullptr,
                                     idx->n_cu, s, img_scale, half));
     RL_TRY(launch_topk(S_s, B, ld_s, ld_s, k, idx->ws, top_s, top_i, s));
@@ -1384,7 +1385,7 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
     // ---- scratch ------------------------------------------------------------------------------------------------------------
     RL_TRY(idx->misc.reserve(score_planes_scratch_floats(B, idx->dim) * sizeof(float)));
     const size_t n_sample = (size_t)B * ld_s, n_top = (size_t)B * k, n_cand = (size_t)B * cap, n_c2 = (size_t)B * cap2;
-    RL_TRY(idx->fused.reserve((n_sample + 2 * n_top + 2 * n_cand + 2 * n_c2 + 4 * (size_t)B + 16) * 4));
+    RL_TRY(idx->fused.reserve((n_sample + 2 * n_top + 2 * n_cand + 2 * n_c2 + 5 * (size_t)B + 16) * 4));
     float* S_s = idx->fused.as<float>();
     float* top_s = S_s + n_sample;
     int32_t* top_i = reinterpret_cast<int32_t*>(top_s + n_top);
@@ -1394,7 +1395,8 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
     float* r_s = reinterpret_cast<float*>(r_i + n_c2);             // [B x cap2] their exact similarities
     float* thr = r_s + n_c2;                                       // [B]
     float* window = thr + B;                                       // [B]
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(window + B);       // [B]
+    float* thr1 = window + B;                                      // [B] the first round's thresholds (two-round candidate pass)
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(thr1 + B);         // [B]
     uint32_t* cnt2 = cnt + B;                                      // [B]
     uint32_t* flag = cnt2 + B;
     float* qs = idx->misc.as<float>();
@@ -1407,7 +1409,6 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
     // ---- (1) sample pass + its exact top-k ------------------------------------------------------------------------------------
     RL_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
     RL_TRY(launch_score_planes_queries(d_q, B, idx->dim, qs, mode, s));
-    RL_TRY(launch_fill_f32(S_s, -std::numeric_limits<float>::infinity(), (int64_t)n_sample, s));
     RL_TRY(launch_score_planes_pass(hi, n, idx->dim, B, qs, S_s, ld_s, idx->norm, idx->sumsq, mode, stride, nullptr, nullptr, idx->n_cu, s, sscale, true,
                                     hi_only));
     RL_TRY(launch_topk(S_s, B, ld_s, ld_s, k, idx->ws, top_s, top_i, s));
@@ -1418,19 +1419,38 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
     idx->filt = {RL_FILTER_ROWS_FUSED_HI, B, cap, cnt, flag};
     // The candidate pass on the sixteen-group tile of maxsim_pp.hip (round 4: 128 rows x 512 queries per workgroup, every operand through
     // LDS-DMA rings, wave-private record logs; dim % 32 == 0, dim >= 256; RL_OPT_FUSED_PP = 0: the eight-group tile of maxsim_gemm.hip)
+    // In TWO rounds: the threshold of the first comes from the row sample (every stride-th tile: ~k * stride rows per query reach it);
+    // after 3/16 of the row tiles every list holds its query's candidates among those rows, and the k-th best of THEM -- a subset 5 x the
+    // sample -- minus the band is a valid, much tighter threshold for the other 13/16 (the k-th best of any subset bounds the k-th best
+    // overall from below): ~2.8 x fewer records to log, flush and rank (expected 2 700 f + 100 (1 - f) / f per query at k = 100, least at
+    // f = 0.19).  Both rounds append to the same lists.
     int st_pp = RL_ERR_UNSUPPORTED;
+    int64_t round1_tiles = 0;
     if (idx->opt.on(RL_OPT_FUSED_PP) && idx->dim % 32 == 0 && idx->dim >= 256) {
         int32_t log_cap = 0;
         const size_t work_bytes = pp_rows_scratch_bytes(n, B, idx->n_cu, (int32_t)std::min<int64_t>((int64_t)k * stride, cap), &log_cap);
         RL_TRY(idx->pp_work.reserve(work_bytes));
-        st_pp = launch_pp_rows_pass(hi, n, idx->dim, B, qs, idx->norm, mode, &ca, idx->pp_work.p, log_cap, idx->n_cu, s, sscale);
+        const int64_t Tr = (n + 127) / 128;
+        round1_tiles = (Tr >= 64 && idx->opt.on(RL_OPT_FUSED_TWO_ROUNDS)) ? (3 * Tr) / 16 : 0;  // (small corpora: one round)
+        if (round1_tiles > 0) {
+            RL_HIP(hipMemcpyAsync(thr1, thr, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));  // (kept for rl_time_kernel's replay)
+            st_pp = launch_pp_rows_pass(hi, n, idx->dim, B, qs, idx->norm, mode, &ca, idx->pp_work.p, log_cap, idx->n_cu, s, sscale, 0, round1_tiles);
+            if (st_pp == RL_OK) {
+                RL_TRY(launch_merge_topk(c_s, c_i, 1, B, cap, k, top_s, top_i, s, cnt));  // (top_s / top_i: the sample's top-k is not needed any more)
+                RL_TRY(launch_raise_threshold(thr, top_s, B, k, window, s));
+                st_pp = launch_pp_rows_pass(hi, n, idx->dim, B, qs, idx->norm, mode, &ca, idx->pp_work.p, log_cap, idx->n_cu, s, sscale, round1_tiles,
+                                            Tr - round1_tiles, true);
+            }
+        } else {
+            st_pp = launch_pp_rows_pass(hi, n, idx->dim, B, qs, idx->norm, mode, &ca, idx->pp_work.p, log_cap, idx->n_cu, s, sscale);
+        }
         if (st_pp != RL_OK && st_pp != RL_ERR_UNSUPPORTED) return st_pp;
     }
     if (st_pp != RL_OK)
         RL_TRY(launch_score_planes_pass(hi, n, idx->dim, B, qs, nullptr, 0, idx->norm, idx->sumsq, mode, 1, nullptr, &ca, idx->n_cu, s, sscale, true, hi_only));
     {
         auto& r = idx->replay;
-        r.valid = true; r.pp = st_pp == RL_OK; r.B = B; r.mode = mode; r.qs = qs; r.ca = ca; r.cnt = cnt;
+        r.valid = true; r.pp = st_pp == RL_OK; r.B = B; r.mode = mode; r.qs = qs; r.ca = ca; r.cnt = cnt; r.thr1 = thr1; r.round1_tiles = round1_tiles;
         r.pools[0] = idx->misc.p; r.pools[1] = idx->fused.p; r.pools[2] = idx->pp_work.p;
         int32_t lc = 0;
         (void)pp_rows_scratch_bytes(n, B, idx->n_cu, (int32_t)std::min<int64_t>((int64_t)k * stride, cap), &lc);
@@ -2010,12 +2030,10 @@ int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_quer
         RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap, n_gemm, hb.es, s, rows16));
     }
     RL_TRY(launch_merge_topk(hb.es, hb.ci, 1, n_gemm, hb.cap, k, d_s, d_c, s, hb.cnt));
-    for (int32_t b = 0; b < n_gemm; b += GEMM_PASS_QUERIES) {  // list overflow / unusable bound: the full-precision passes, behind the flag
-        const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_gemm - b);
-        RL_TRY(launch_maxsim_gemm(idx->planes.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
-                                  idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, image_scale(idx),
-                                  idx->E16 != nullptr, hb.flag));
-    }
+    // list overflow / unusable bound: the full-precision passes, behind the flag -- ONE launch for all of them (gridDim.y = passes: sixteen
+    // guarded launches that return at once were 0.08 ms of every 128-query step)
+    RL_TRY(launch_maxsim_gemm(idx->planes.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, 0, n_gemm, nq, idx->row_to_chunk, idx->offsets,
+                              idx->ends.as<uint32_t>(), sc, ld, idx->n_cu, s, image_scale(idx), idx->E16 != nullptr, hb.flag, false, true));
     RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // (harmless on scores nobody reads)
     RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, d_s, d_c, s, hb.flag));
     return RL_OK;
@@ -2444,6 +2462,15 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
         else if (kind == 8) {
             const auto& r = idx->replay;
             if (hipMemsetAsync(r.cnt, 0, (size_t)r.B * sizeof(uint32_t), s) != hipSuccess) st = RL_ERR_HIP;  // the lists fill up again on every run
+            else if (r.pp && r.round1_tiles > 0) {  // both rounds with the thresholds each of them ran with (the ranking between them is not replayed)
+                CandArgs ca1 = r.ca;
+                ca1.tau = r.thr1;
+                st = launch_pp_rows_pass(idx->hi_image.p, idx->n_rows, idx->dim, r.B, r.qs, idx->norm, r.mode, &ca1, idx->pp_work.p, r.log_cap, idx->n_cu, s,
+                                         idx->split_scale, 0, r.round1_tiles);
+                if (st == RL_OK)
+                    st = launch_pp_rows_pass(idx->hi_image.p, idx->n_rows, idx->dim, r.B, r.qs, idx->norm, r.mode, &r.ca, idx->pp_work.p, r.log_cap, idx->n_cu, s,
+                                             idx->split_scale, r.round1_tiles, -1, true);
+            }
             else if (r.pp) st = launch_pp_rows_pass(idx->hi_image.p, idx->n_rows, idx->dim, r.B, r.qs, idx->norm, r.mode, &r.ca, idx->pp_work.p, r.log_cap,
                                                     idx->n_cu, s, idx->split_scale);
             else st = launch_score_planes_pass(idx->hi_image.p, idx->n_rows, idx->dim, r.B, r.qs, nullptr, 0, idx->norm, idx->sumsq, r.mode, 1, nullptr, &r.ca,

@@ -276,7 +276,7 @@ int launch_query_planes(const float* Q, int32_t dim, int32_t nq, int64_t q_strid
 int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first,
                        int32_t n_q, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits,
                        float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale, bool half = false,
-                       const uint32_t* run_if = nullptr, bool hi_only = false);
+                       const uint32_t* run_if = nullptr, bool hi_only = false, bool all_passes = false);  // all_passes: n_q > 8 in one launch
 // maxsim_pp.hip: the approximate pass of the headline pipeline -- SIXTEEN queries per pass over a one-plane image, one product
 constexpr int32_t PP_PASS_QUERIES = 16;
 int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first, int32_t n_q,
@@ -290,8 +290,14 @@ int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const f
 struct CandArgs { const float* tau; int32_t tau_stride; float* scores; int32_t* ids; uint32_t* cnt; uint32_t* overflow; int32_t cap; };
 int launch_score_planes_queries(const float* Q, int32_t nb, int32_t dim, float* scratch, int mode, hipStream_t s);
 size_t pp_rows_scratch_bytes(int64_t n_rows, int32_t nb, int n_cu, int32_t expected_per_query, int32_t* log_cap_out);
+// row tiles (of 128 rows) [tile_begin, tile_begin + tile_count) only (tile_count < 0: to the end); norms_ready: the block norm ranges in
+// `work` are those of an earlier launch of the same search
 int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, const float* row_norm, int mode,
-                        const CandArgs* cand, void* work, int32_t log_cap, int n_cu, hipStream_t s, float split_scale);
+                        const CandArgs* cand, void* work, int32_t log_cap, int n_cu, hipStream_t s, float split_scale, int64_t tile_begin = 0,
+                        int64_t tile_count = -1, bool norms_ready = false);
+// thr[q] = max(thr[q], kth[q * k + k - 1] - window[q]): the k-th best approximate similarity of ANY subset of the rows bounds the k-th best
+// overall from below (select.hip; the second round of the fused top-k's candidate pass)
+int launch_raise_threshold(float* thr, const float* kth, int32_t nq, int32_t k, const float* window, hipStream_t s);
 int launch_score_planes_pass(const void* planes, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, float* scores, int64_t ld,
                              const float* row_norm, const float* row_sumsq, int mode, int32_t tile_stride, const uint32_t* run_if,
                              const CandArgs* cand, int n_cu, hipStream_t s, float split_scale, bool half = false, bool hi_only = false);

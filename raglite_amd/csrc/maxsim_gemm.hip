@@ -353,6 +353,14 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
     const int lane = threadIdx.x & 63;
     const int wv = wave_id();  // 0..7 = the query this wave scores
     const int64_t G = gridDim.x, b = blockIdx.x;
+    if constexpr (MODE == 0) {  // gridDim.y > 1: ONE launch for several passes (the guarded fallback of a whole batch): pass blockIdx.y scores
+                                // queries 8 y .. 8 y + 7 of the n_q the launch was given -- its own fragments, meta words and output rows
+        const int y = (int)blockIdx.y;
+        qfrag += (int64_t)y * MG_WAVES * nslab * 4096;
+        qmeta += 2 * MG_WAVES * y;
+        out += (int64_t)y * MG_WAVES * out_stride;
+        n_q = n_q - MG_WAVES * y < MG_WAVES ? n_q - MG_WAVES * y : MG_WAVES;
+    }
     // Chunk-aligned row range of this workgroup (as in maxsim_stream.hip): first chunk boundary at or after n_rows * b / G.
     auto boundary = [&](int64_t t) -> int64_t {
         if (t <= 0) return 0;
@@ -630,7 +638,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
                     if (mode == SCAN_COSINE) v = 1.0f - (1.0f - d / (rn * qn[r]));
                     else if (mode == SCAN_DOT) v = 1.0f + d;
                     else if (mode == SCAN_L2) v = 1.0f - sqrtf(fmaxf(rn + qss[r] - 2.0f * d, 0.f));
-                    if (q < rs.B && row < (int32_t)n_rows) rs.S[(int64_t)q * rs.ld + col0 + row] = v;
+                    // (compact sample layout: every column of S belongs to a sampled tile -- rows past the corpus in the last one
+                    // are written as -inf here, so the caller needs no fill pass over the sample matrix)
+                    if (q < rs.B && (row < (int32_t)n_rows || rs.compact)) rs.S[(int64_t)q * rs.ld + col0 + row] = row < (int32_t)n_rows ? v : -INFINITY;
                 }
 #pragma unroll
             for (int qb = 0; qb < NQB; ++qb) acc[qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -915,14 +925,15 @@ __global__ __launch_bounds__(512, 2) void maxsim_gemm_kernel(const char* __restr
 int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first,
                        int32_t n_q, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits,
                        float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale, bool half, const uint32_t* run_if,
-                       bool hi_only) {
-    if (nq < 1 || nq > 32 || n_q < 1 || n_q > MG_WAVES || n_rows < 1 || first < 0 || first + n_q > n_queries) return RL_ERR_UNSUPPORTED;
+                       bool hi_only, bool all_passes) {
+    // all_passes: n_q may exceed 8 -- ceil(n_q / 8) passes in ONE launch (gridDim.y), pass y writing out + 8 y out_stride
+    if (nq < 1 || nq > 32 || n_q < 1 || (n_q > MG_WAVES && !all_passes) || n_rows < 1 || first < 0 || first + n_q > n_queries) return RL_ERR_UNSUPPORTED;
     if (dim % 32 || dim < 32 || !(split_scale > 0.f) || !planes || !ends_bits) return RL_ERR_UNSUPPORTED;
     const int32_t nslab = dim / 32;
     const char* qfrag = static_cast<const char*>(qbuf) + (size_t)first * nslab * 4096;
     const float* qmeta = reinterpret_cast<const float*>(static_cast<const char*>(qbuf) + (size_t)n_queries * dim * 128) + 2 * (size_t)first;
     const int64_t tiles = (n_rows + MG_TM - 1) / MG_TM;
-    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
+    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles)), (unsigned)((n_q + MG_WAVES - 1) / MG_WAVES)), blk(512);
     static const int dbg_env = exp_env("RAGLITE_GEMM_DBG") ? std::atoi(exp_env("RAGLITE_GEMM_DBG")) : 0;  // timing experiments only
     const int dbg = (dbg_env & ~64) | (hi_only ? 64 : 0);
 #ifdef RAGLITE_EXPERIMENTS  // the slab-timeline build of the kernel exists in experiment builds only

@@ -53,7 +53,8 @@
 // to a WAVE-PRIVATE log in global memory (plain stores: LDS is full of operand rings, and a returning atomic per hit would stall the
 // epilogue for an L2 round trip).  When the workgroup is done each wave re-evaluates its records with the exact formulas of
 // maxsim_gemm.hip MODE 2 (same statements, same bits), keeps those that reach the threshold exactly, and appends them to the per-query
-// candidate lists (one atomic per record, ~1 400 records per wave at cfg 5).
+// candidate lists (one atomic per record, ~1 400 records per wave at cfg 5).  A launch covers a RANGE of row tiles: api.hip runs the pass in
+// two rounds and tightens the thresholds between them.
 #include <cstdio>
 #include <cstdlib>
 #include <utility>
@@ -124,6 +125,14 @@ __device__ __forceinline__ void pp_pin(f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
 // MODE 2: a load the compiler must not see (a compiler-visible VMEM load anywhere in the K loop makes its wait-count pass put
 // `s_waitcnt vmcnt(0)` at the loop header, which drains the feeders' look-ahead DMAs on every iteration) goes through the scalar cache:
 typedef float f32x2s __attribute__((ext_vector_type(2)));
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+// (the same for 16 floats at a 64-byte aligned address: a tile's eight (min, max) pairs)
+__device__ __forceinline__ f32x16s pp_sload16(const float* p) {
+    f32x16s v;
+    const float* const u = reinterpret_cast<const float*>(pp_uniform_i64(reinterpret_cast<int64_t>(p)));
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(u) : "memory");
+    return v;
+}
 // two consecutive floats at a wave-uniform, 8-byte aligned address through the scalar cache (waits for it: also for the LDS reads in flight)
 __device__ __forceinline__ f32x2s pp_sload2(const float* p) {
     f32x2s v;
@@ -147,7 +156,8 @@ struct PpRows {
     const float* blk_minmax;              // [ceil(n_rows / 16)][2] min / max |e| over the rows of a 16-row block (cosine)
     int32_t B, QT, metric;                // queries, query tiles (of 512) per row tile, SCAN_COSINE | SCAN_DOT
     float* cand_scores; int32_t* cand_ids; uint32_t* cand_cnt; uint32_t* overflow; int32_t cap;  // per-query lists (as maxsim_gemm.hip MODE 2)
-    uint2* log; int32_t log_cap;          // [gridDim.x * 8][log_cap] wave-private records (raw accumulator, packed coordinates)
+    uint2* log; int32_t log_cap;          // [workgroups * 8][log_cap] wave-private records (raw accumulator, packed coordinates)
+    int32_t tile_begin, tile_count;       // the 128-row tiles this launch covers: [tile_begin, tile_begin + tile_count)
 };
 
 // DBG (experiment builds only, -DRAGLITE_EXPERIMENTS + RAGLITE_PP_DBG / RAGLITE_PP_ROWS_DBG; wrong results): 2 = no MFMAs, 8 = no LDS fragment
@@ -197,11 +207,11 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     } else {
         // MODE 2: blockIdx.y = the query tile (16 groups of 32 queries), the workgroups of a grid row share the 128-row tiles evenly: a
         // workgroup multiplies ONE set of queries for its whole life, like a MaxSim pass
-        const int64_t Tr = (n_rows + PP_RT - 1) / PP_RT;
+        const int64_t Tr = rs.tile_count;  // (of this launch: the candidate pass runs in rounds over ranges of row tiles, api.hip)
         const int64_t t0 = (Tr * b) / G, t1 = (Tr * (b + 1)) / G;
         nt_rows = (int32_t)(t1 - t0);
         if (nt_rows <= 0) return;  // whole workgroup
-        r_lo = (int32_t)(t0 * PP_RT);
+        r_lo = (int32_t)((rs.tile_begin + t0) * PP_RT);
         r_hi = (int32_t)n_rows;
     }
     const int32_t org = r_lo & ~15;  // tiles start on a 16-row block of the image
@@ -460,7 +470,13 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         T4x = q < rs.B ? (t_dot - fabsf(t_dot) * 1e-6f) / us : INFINITY;
         if (__builtin_amdgcn_ballot_w64(bad) != 0 && lane == 0) *rs.overflow = 1u;
     }
-    [[maybe_unused]] auto block_epilogue_rows = [&](auto A_, int T) __attribute__((always_inline)) -> int {
+    // tq4: the lane's four thresholds (T4x handed back by rows_thresholds()); nmin / nmax: the block's norm range (cosine)
+    [[maybe_unused]] auto rows_thresholds = [&](float (&tq4)[4]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)  // column set c's thresholds sit in lane group c of T4x
+            tq4[c] = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(((uint32_t)c << 6) | ((uint32_t)(lane & 15) << 2)), __float_as_int(T4x)));
+    };
+    [[maybe_unused]] auto block_epilogue_rows = [&](auto A_, int T, const float (&tq4)[4], float nmin, float nmax) __attribute__((always_inline)) -> int {
         constexpr int a = decltype(A_)::value;
         int n_st = 0;
         const int32_t base = org + T * PP_RT + 16 * a;
@@ -471,12 +487,11 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
             asm volatile("" : "+v"(lane_code));
             float t4[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c)  // column set c's thresholds sit in lane group c of T4x
-                t4[c] = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(((uint32_t)c << 6) | ((uint32_t)(lane & 15) << 2)), __float_as_int(T4x)));
+            for (int c = 0; c < 4; ++c) t4[c] = tq4[c];
             if (cosine) {
                 // two scalars per block, slightly widened: T * |e| is formed with one rounding here and none in the exact test
-                const f32x2s mm = pp_sload2(rs.blk_minmax + 2 * (base >> 4));
-                const float nmin = mm[0] * 0.999999f, nmax = mm[1] * 1.000001f;
+                nmin *= 0.999999f;
+                nmax *= 1.000001f;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) t4[c] = fminf(t4[c] * nmin, t4[c] * nmax);
             }
@@ -554,8 +569,19 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
             return;
         }
         int n_st;
-        if constexpr (ROWS) n_st = block_epilogue_rows(A_, T);
-        else n_st = block_epilogue_maxsim(A_, T);
+        if constexpr (ROWS) {  // (the STAG arrangement: one block at a time, its thresholds and norm range fetched for it alone)
+            float tq4[4];
+            rows_thresholds(tq4);
+            float nmin = 1.f, nmax = 1.f;
+            if (cosine) {
+                const f32x2s mm = pp_sload2(rs.blk_minmax + 2 * ((org + T * PP_RT + 16 * decltype(A_)::value) >> 4));
+                nmin = mm[0];
+                nmax = mm[1];
+            }
+            n_st = block_epilogue_rows(A_, T, tq4, nmin, nmax);
+        } else {
+            n_st = block_epilogue_maxsim(A_, T);
+        }
         st_a += n_st;
         if (both) st_b += n_st;
     };
@@ -602,9 +628,24 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
             if (c_s == nslab - 1) block_epilogue(PP_I(0), c_r, true);
         }
         if constexpr (!STAG) {
-            if (c_s == nslab - 1) {
-                [&]<int... A>(std::integer_sequence<int, A...>) { (block_epilogue(std::integral_constant<int, A>{}, c_r, true), ...); }
-                (std::make_integer_sequence<int, PP_NBLK>{});
+            if (c_s == nslab - 1) {  // the tile is complete: its eight blocks back to back
+                if constexpr (ROWS && !(DBG & 128)) {
+                    // ONE scalar load and one LDS round trip per tile: the eight (min, max) norm pairs (64 B) and the lane's four
+                    // thresholds -- a wait per block would expose a scalar-cache miss eight times per tile (the array has 625 KB)
+                    float tq4[4];
+                    rows_thresholds(tq4);
+                    f32x16s mm = {};
+                    if (cosine) mm = pp_sload16(rs.blk_minmax + 2 * ((org + c_r * PP_RT) >> 4));
+                    int n_st = 0;
+                    [&]<int... A>(std::integer_sequence<int, A...>) {
+                        ((n_st += block_epilogue_rows(std::integral_constant<int, A>{}, c_r, tq4, mm[2 * A], mm[2 * A + 1])), ...);
+                    }(std::make_integer_sequence<int, PP_NBLK>{});
+                    st_a += n_st;
+                    st_b += n_st;
+                } else {
+                    [&]<int... A>(std::integer_sequence<int, A...>) { (block_epilogue(std::integral_constant<int, A>{}, c_r, true), ...); }
+                    (std::make_integer_sequence<int, PP_NBLK>{});
+                }
             }
         }
     };
@@ -786,7 +827,8 @@ size_t pp_rows_scratch_bytes(int64_t n_rows, int32_t nb, int n_cu, int32_t expec
 // similarity reaches cand->tau[q]) over a ONE-PLANE image at one product per multiply, on the 128-row x 512-query tile.  `scratch`: the
 // query side as launch_score_planes_queries left it; `work`: pp_rows_scratch_bytes bytes.  cosine / dot; dim % 32 == 0, dim >= 256.
 int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, const float* row_norm, int mode,
-                        const CandArgs* cand, void* work, int32_t log_cap, int n_cu, hipStream_t s, float split_scale) {
+                        const CandArgs* cand, void* work, int32_t log_cap, int n_cu, hipStream_t s, float split_scale, int64_t tile_begin,
+                        int64_t tile_count, bool norms_ready) {
     if (nb < 1 || n_rows < 1 || dim % 32 || dim < 256 || !(split_scale > 0.f) || !image || !cand || !work) return RL_ERR_UNSUPPORTED;
     if (mode != SCAN_COSINE && mode != SCAN_DOT) return RL_ERR_UNSUPPORTED;
     if (mode == SCAN_COSINE && !row_norm) return RL_ERR_INVALID;
@@ -797,16 +839,21 @@ int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t 
     float* anylo = unscale + nb;
     float* qss = anylo + groups;
     const int64_t grid_cu = n_cu > 0 ? n_cu : 256;
-    const int64_t Tr = (n_rows + PP_RT - 1) / PP_RT;
+    const int64_t Tr_all = (n_rows + PP_RT - 1) / PP_RT;
+    if (tile_count < 0) tile_count = Tr_all - tile_begin;
+    if (tile_begin < 0 || tile_count < 1 || tile_begin + tile_count > Tr_all) return RL_ERR_INVALID;
+    const int64_t Tr = tile_count;
     PpRows rs{};
+    rs.tile_begin = (int32_t)tile_begin;
+    rs.tile_count = (int32_t)tile_count;
     rs.tau = cand->tau; rs.q_unscale = unscale; rs.q_sumsq = qss; rs.row_norm = row_norm; rs.B = nb; rs.QT = (groups + PP_QPP - 1) / PP_QPP;
     rs.metric = mode; rs.cand_scores = cand->scores; rs.cand_ids = cand->ids; rs.cand_cnt = cand->cnt; rs.overflow = cand->overflow; rs.cap = cand->cap;
     rs.log = static_cast<uint2*>(work);
     rs.log_cap = log_cap;
-    if (rs.QT > grid_cu || Tr + 2 >= (int64_t(1) << 19)) return RL_ERR_UNSUPPORTED;  // one grid row per query tile; tile index bits of a record
+    if (rs.QT > grid_cu || Tr_all + 2 >= (int64_t(1) << 19)) return RL_ERR_UNSUPPORTED;  // one grid row per query tile; tile index bits of a record
     float* blk_mm = reinterpret_cast<float*>(static_cast<char*>(work) + (size_t)grid_cu * 8 * (size_t)log_cap * sizeof(uint2));
     rs.blk_minmax = blk_mm;
-    if (mode == SCAN_COSINE) {
+    if (mode == SCAN_COSINE && !norms_ready) {  // (once per search: the rounds of a search share it)
         const int64_t n_blocks = (n_rows + 15) / 16;
         hipLaunchKernelGGL(block_norm_minmax_kernel, dim3((unsigned)((n_blocks + 255) / 256)), dim3(256), 0, s, row_norm, n_rows, n_blocks, blk_mm);
     }

@@ -868,6 +868,22 @@ int launch_list_prefix(const float* in_scores, const int32_t* in_ids, int32_t nq
     return RL_OK;
 }
 
+__global__ __launch_bounds__(256) void raise_threshold_kernel(float* __restrict__ thr, const float* __restrict__ kth, int32_t nq, int32_t k,
+                                                               const float* __restrict__ window) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= nq) return;
+    const float a = kth[(int64_t)q * k + (k - 1)];  // -inf: the subset held fewer than k rows that reached the first threshold
+    const float t = a - window[q];
+    if (t > thr[q]) thr[q] = t;  // (NaN never raises it)
+}
+
+int launch_raise_threshold(float* thr, const float* kth, int32_t nq, int32_t k, const float* window, hipStream_t s) {
+    if (nq <= 0) return RL_OK;
+    hipLaunchKernelGGL(raise_threshold_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s, thr, kth, nq, k, window);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 int launch_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_lists, int32_t nq, int32_t k_in,
                       int32_t k, float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* counts) {
     if (nq <= 0 || k <= 0) return RL_OK;

@@ -241,9 +241,14 @@ def test_fused_pp_tile_equals_the_eight_group_tile_bitwise(metric, n, dim, B, k)
         st0 = idx.filter_stats()
     assert st0["kind"] == "rows_fused_hi" and not st0["fallback"]
     assert torch.equal(R, R0) and torch.equal(S.view(torch.int32), S0.view(torch.int32))
-    # about the same lists: the sixteen-group tile keeps exactly the rows that reach the threshold, the eight-group tile also those within
-    # the 1e-5 of slack of its in-loop test
-    assert st["candidates_per_query_mean"] <= st0["candidates_per_query_mean"] <= 1.05 * st["candidates_per_query_mean"] + 1, (st, st0)
+    # fewer candidates: the sixteen-group tile runs in two rounds and tightens its thresholds after the first (and keeps exactly the rows
+    # that reach the threshold; the eight-group tile also those within the 1e-5 of slack of its in-loop test); in ONE round about the same
+    assert st["candidates_per_query_mean"] <= st0["candidates_per_query_mean"], (st, st0)
+    with idx.options(fused_two_rounds=0):
+        S1, R1 = idx.search_rows(Q, k)
+        st1 = idx.filter_stats()
+    assert torch.equal(R, R1) and torch.equal(S.view(torch.int32), S1.view(torch.int32))
+    assert st1["candidates_per_query_mean"] <= st0["candidates_per_query_mean"] <= 1.05 * st1["candidates_per_query_mean"] + 1, (st1, st0)
     Eh = E.cpu().numpy()
     for b in (0, B // 2, B - 1):
         assert_topk_close(S[b].cpu().numpy(), R[b].cpu().numpy(), oracle.similarity(Eh, Q[b].cpu().numpy(), metric), k, _tol(Eh, Q[b].cpu().numpy(), metric))
