@@ -268,6 +268,11 @@ def main() -> None:
         },
     }
 
+    mem = index.memory()
+    kept = {name: mem[name] for name in ("rows", "presplit_image", "hi_image", "hi_plane")}
+    result["index_memory"] = {**kept, "times_corpus": sum(kept.values()) / max(1, kept["rows"]),
+                              "note": "rank 0's shard, bytes; --opt keep_image=0 --opt keep_hi_plane=0: rows + HI image (1.5 x), same results"}
+
     # ---- roofline of the dominant kernel: HIP events on the launch stream, kernel only -----------------------------
     # One launch = one corpus pass of EIGHT queries through maxsim_gemm_kernel (matrix-pipe-bound).  Big fp32 corpora in split
     # arithmetic: the approximate pass over the HI image (kind 6: 1 fp16 MFMA product per multiply; the candidates it leaves

@@ -123,7 +123,13 @@ int rl_index_info(const rl_index* index, int64_t* n_rows, int32_t* dim, int64_t*
  * total device memory now, out[7] the headroom an image has to leave free to be built.  The three images are optional accelerators
  * (4 + 2 + 2 bytes per element next to the 4 of an fp32 corpus): each is built only while it leaves max(2 GiB, 1/16 of the device) --
  * RL_OPT_IMAGE_HEADROOM_MB overrides -- free for the scratch and the caller; without them the same calls run through the kernels over
- * the stored rows (same results: every image path is bit-identical to, or re-scored exactly against, the rows). */
+ * the stored rows (same results: every image path is bit-identical to, or re-scored exactly against, the rows).
+ * Index footprint: all three images make an fp32 index 3 x its corpus.  The headline path -- MaxSim batches -- needs only the HI image:
+ * with RL_OPT_KEEP_IMAGE = 0 and RL_OPT_KEEP_HI_PLANE = 0 an fp32 index of dim 256 / 384 / 512 / 768 / 1024 holds rows + HI image
+ * (1.5 x) and rl_maxsim_topk_batch / rl_maxsim_batch_begin run the same pipeline with the same results: approximate pass over the HI
+ * image, exact re-scoring over the rows; only the guarded full-precision fallback (list overflow, unusable bound) changes kernel -- the
+ * streaming kernels over the rows instead of the eight-query pass over the pre-split image.  Row searches on such an index take the
+ * kernels over the rows (B <= 16: the full fp32 pass; B >= 96: score_gemm instead of the fused top-k). */
 int rl_index_memory(const rl_index* index, int64_t out[8]);
 
 /* ---- index lifecycle beyond create/destroy -----------------------------
@@ -193,8 +199,10 @@ int rl_index_arithmetic(rl_index* index, int* in_effect);
  *   RL_OPT_GEMM_PASS            0 / 1 (1)          MaxSim batches of >= 3 queries share passes over the pre-split image
  *   RL_OPT_QUERY_PAIRS          0 / 1 (1)          two-query passes of the streaming kernel
  *   RL_OPT_PLANES_GEMM          0 / 1 (1)          dense row-score GEMM over the image for B >= 96 (else: score_gemm over the rows)
- *   RL_OPT_KEEP_IMAGE           0 / 1 (1)          keep the pre-split corpus image (4 B per element; 0 releases it)
+ *   RL_OPT_KEEP_IMAGE           0 / 1 (1)          keep the pre-split corpus image (4 B per element; 0 releases it -- MaxSim batches of an
+ *                                                  fp32 index then run on rows + HI image alone, see "index footprint" below)
  *   RL_OPT_KEEP_HI              0 / 1 (1)          keep the HI plane and the HI image (2 + 2 B per element; 0 releases them)
+ *   RL_OPT_KEEP_HI_PLANE        0 / 1 (1)          keep the row-major HI plane (2 B per element; what B <= 16 row searches rank on)
  *   RL_OPT_IMAGE_HEADROOM_MB    -1 | >= 0 (-1)     device memory the images must leave free (-1: max(2 GiB, 1/16 of the device))
  *   RL_OPT_ARITHMETIC           rl_arith (AUTO)    same as rl_index_set_arithmetic
  *   RL_OPT_EXACT_KTH_THRESHOLD  0 / 1 (1)          MaxSim batches: second, tighter candidate threshold from the EXACT scores of the
@@ -206,7 +214,7 @@ typedef enum {
     RL_OPT_HI_SEARCH = 1, RL_OPT_HI_MAXSIM = 2, RL_OPT_HI_PRODUCTS = 3, RL_OPT_PP_PASS = 4, RL_OPT_FUSED_TOPK = 5, RL_OPT_FUSED_HI = 6,
     RL_OPT_FUSED_PP = 7, RL_OPT_FUSED_TOPK_CAP = 8, RL_OPT_FUSED_TOPK_STRIDE = 9, RL_OPT_GEMM_PASS = 10, RL_OPT_QUERY_PAIRS = 11,
     RL_OPT_PLANES_GEMM = 12, RL_OPT_KEEP_IMAGE = 13, RL_OPT_KEEP_HI = 14, RL_OPT_IMAGE_HEADROOM_MB = 15, RL_OPT_ARITHMETIC = 16,
-    RL_OPT_EXACT_KTH_THRESHOLD = 17, RL_OPT_FUSED_TWO_ROUNDS = 18, RL_OPT_COUNT_ = 19
+    RL_OPT_EXACT_KTH_THRESHOLD = 17, RL_OPT_FUSED_TWO_ROUNDS = 18, RL_OPT_KEEP_HI_PLANE = 19, RL_OPT_COUNT_ = 20
 } rl_option;
 int rl_set_default_option(int key, int64_t value);
 int rl_get_default_option(int key, int64_t* value);

@@ -200,7 +200,7 @@ struct Options {
         for (auto& x : v) x = 0;
         v[RL_OPT_HI_SEARCH] = v[RL_OPT_HI_MAXSIM] = v[RL_OPT_HI_PRODUCTS] = v[RL_OPT_PP_PASS] = v[RL_OPT_FUSED_TOPK] = v[RL_OPT_FUSED_HI] = 1;
         v[RL_OPT_FUSED_PP] = v[RL_OPT_GEMM_PASS] = v[RL_OPT_QUERY_PAIRS] = v[RL_OPT_PLANES_GEMM] = v[RL_OPT_KEEP_IMAGE] = v[RL_OPT_KEEP_HI] = 1;
-        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = 1;
+        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = 1;
         v[RL_OPT_IMAGE_HEADROOM_MB] = -1;
         v[RL_OPT_ARITHMETIC] = RL_ARITH_AUTO;
     }
@@ -212,7 +212,7 @@ bool option_value_ok(int key, int64_t value) {
     switch (key) {
         case RL_OPT_HI_SEARCH: case RL_OPT_HI_MAXSIM: case RL_OPT_PP_PASS: case RL_OPT_FUSED_TOPK: case RL_OPT_FUSED_HI: case RL_OPT_FUSED_PP:
         case RL_OPT_GEMM_PASS: case RL_OPT_QUERY_PAIRS: case RL_OPT_PLANES_GEMM: case RL_OPT_KEEP_IMAGE: case RL_OPT_KEEP_HI:
-        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS:
+        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE:
             return value == 0 || value == 1;
         case RL_OPT_HI_PRODUCTS: return value == 1 || value == 2;
         case RL_OPT_FUSED_TOPK_CAP: return value >= 0 && value <= MERGE_CAP;
@@ -286,6 +286,7 @@ struct rl_index {
     // asynchronous, so a call arriving on a DIFFERENT stream than the previous one first waits for that stream.
     hipStream_t last_stream = nullptr;
     bool last_stream_set = false;
+    int64_t ends_rows = -1;               // rows the `ends` bitmap covers (-1: not built); kept by both images
     float planes_scale = 0.f;             // the scale the image was built with; 0 = no image
     int64_t planes_rows = 0;              // rows the image covers
     // What the last bound-filtered search on this handle left behind (rl_index_filter_stats): per-query candidate counters and the
@@ -383,28 +384,34 @@ bool image_fits(const rl_index* idx, const rl::Pool& pool, size_t need) {
 // never an error (the streaming kernels read the stored rows): an allocation failure or a device too full just leaves it absent.
 
 int refresh_row_norm16(rl_index* idx, hipStream_t s);
+// "last row of its chunk" bitmap over the current rows: what the batch kernels over either image find chunk ends with (125 KB per 1 M rows)
+int refresh_ends(rl_index* idx, hipStream_t s) {
+    if (idx->ends_rows == idx->n_rows && idx->ends.p) return RL_OK;
+    const int64_t cap = std::max<int64_t>(idx->n_rows, idx->owns_E ? idx->cap_rows : idx->n_rows);
+    RL_TRY(idx->ends.reserve(rl::chunk_ends_words(cap) * sizeof(uint32_t)));
+    RL_TRY(rl::launch_chunk_ends(idx->row_to_chunk, idx->n_rows, idx->ends.as<uint32_t>(), s));
+    idx->ends_rows = idx->n_rows;
+    return RL_OK;
+}
 int refresh_planes(rl_index* idx, hipStream_t s) {
     const bool half = idx->E16 != nullptr;
     const bool want = idx->opt.on(RL_OPT_KEEP_IMAGE) && (idx->E16 || idx->E) && image_scale(idx) > 0.f && idx->dim % 32 == 0 && idx->dim >= 32 &&
                       idx->n_rows > 0;
+    idx->ends_rows = -1;  // (rows or chunk structure may have changed: whoever needs the bitmap rebuilds it)
     if (!want) {
         idx->planes.release();
-        idx->ends.release();
         idx->planes_scale = 0.f;
         idx->planes_rows = 0;
         return RL_OK;
     }
     const int64_t cap = std::max<int64_t>(idx->n_rows, idx->owns_E ? idx->cap_rows : idx->n_rows);
-    const size_t need = rl::planes_bytes(cap, idx->dim, half), need_e = rl::chunk_ends_words(cap) * sizeof(uint32_t);
+    const size_t need = rl::planes_bytes(cap, idx->dim, half);
     int64_t first = idx->planes_scale == image_scale(idx) ? (idx->planes_rows & ~int64_t(15)) : 0;
     if (idx->planes.cap < need) first = 0;  // Pool::reserve does not keep the contents
-    // (each pool against its own need: an exactly sized image is "already paid for" and must survive an append into spare capacity
-    // however full the device has become since)
-    if (!image_fits(idx, idx->planes, need) || !image_fits(idx, idx->ends, need_e) || idx->planes.reserve(need) != RL_OK ||
-        idx->ends.reserve(need_e) != RL_OK) {
+    // (an exactly sized image is "already paid for" and must survive an append into spare capacity however full the device has become)
+    if (!image_fits(idx, idx->planes, need) || idx->planes.reserve(need) != RL_OK) {
         (void)hipGetLastError();
         idx->planes.release();
-        idx->ends.release();
         idx->planes_scale = 0.f;
         idx->planes_rows = 0;
         return RL_OK;
@@ -413,13 +420,12 @@ int refresh_planes(rl_index* idx, hipStream_t s) {
                         : rl::launch_presplit_rows(idx->E, first, idx->n_rows, idx->dim, idx->split_scale, idx->planes.p, s);
     if (st == RL_ERR_UNSUPPORTED) {  // e.g. caller-owned rows that are not 16-byte aligned: no image, the streaming kernels serve
         idx->planes.release();
-        idx->ends.release();
         idx->planes_scale = 0.f;
         idx->planes_rows = 0;
         return RL_OK;
     }
     RL_TRY(st);
-    RL_TRY(rl::launch_chunk_ends(idx->row_to_chunk, idx->n_rows, idx->ends.as<uint32_t>(), s));
+    RL_TRY(refresh_ends(idx, s));
     idx->planes_scale = image_scale(idx);
     idx->planes_rows = idx->n_rows;
     if (half) RL_TRY(refresh_row_norm16(idx, s));
@@ -473,8 +479,10 @@ int refresh_row_norm16(rl_index* idx, hipStream_t s) {
 // The HI halves in image layout + the largest row norm (synchronises the stream: build / append / compact only).
 int refresh_hi_image(rl_index* idx, hipStream_t s) {
     const bool off = !idx->opt.on(RL_OPT_KEEP_HI);  // (shared with the row-major plane)
+    // (round 4: independent of the pre-split image -- an index with RL_OPT_KEEP_IMAGE = 0 keeps rows + HI image, 1.5 x the corpus, and its
+    // MaxSim batches fall back to the streaming kernels over the rows)
     const bool want = !off && !idx->E16 && idx->E && idx->split_scale > 0.f && idx->dim % 32 == 0 && idx->dim >= 32 && idx->dim <= 1024 &&
-                      (int64_t)idx->n_rows * idx->dim >= (int64_t(64) << 20) && image_valid(idx);
+                      (int64_t)idx->n_rows * idx->dim >= (int64_t(64) << 20);
     if (!want) {
         idx->hi_image.release();
         idx->hi_image_scale = 0.f;
@@ -500,6 +508,7 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
         return RL_OK;
     }
     RL_TRY(st);
+    RL_TRY(refresh_ends(idx, s));
     idx->hi_image_scale = idx->split_scale;
     idx->hi_image_rows = idx->n_rows;
     if (idx->max_row_norm_rows != idx->n_rows || idx->max_row_norm_scale != idx->split_scale) {  // fold the new rows' norms in
@@ -527,7 +536,7 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
 }
 int refresh_hi_plane(rl_index* idx, hipStream_t s) {
     RL_TRY(refresh_hi_image(idx, s));
-    const bool off = !idx->opt.on(RL_OPT_KEEP_HI);
+    const bool off = !idx->opt.on(RL_OPT_KEEP_HI) || !idx->opt.on(RL_OPT_KEEP_HI_PLANE);
     const int32_t d = idx->dim;
     const bool dim_ok = d == 128 || d == 256 || d == 384 || d == 512 || d == 768 || d == 1024;
     const bool want = !off && !idx->E16 && idx->E && idx->split_scale > 0.f && dim_ok &&
@@ -1047,7 +1056,7 @@ int rl_index_set_option(rl_index* idx, int key, int64_t value) {
     std::lock_guard<std::mutex> lock(idx->mu);
     if (idx->opt.v[key] == value) return RL_OK;
     idx->opt.v[key] = value;
-    if (key == RL_OPT_KEEP_IMAGE || key == RL_OPT_KEEP_HI || key == RL_OPT_IMAGE_HEADROOM_MB || key == RL_OPT_ARITHMETIC) {
+    if (key == RL_OPT_KEEP_IMAGE || key == RL_OPT_KEEP_HI || key == RL_OPT_KEEP_HI_PLANE || key == RL_OPT_IMAGE_HEADROOM_MB || key == RL_OPT_ARITHMETIC) {
         // what the index keeps in device memory changes: rebuild / release now (synchronous, like rl_index_set_arithmetic)
         RL_TRY(use_scratch(idx, nullptr));
         if (key == RL_OPT_ARITHMETIC) {
@@ -1865,8 +1874,16 @@ int pairs_pass(rl_index* idx, int32_t nq, int32_t n_queries, int32_t first, floa
 // n_q - 1 of them.  RL_ERR_UNSUPPORTED when the index has no image, has an empty chunk (the kernel finds a chunk by
 // counting chunk ends) or the shape is outside the kernel -- the caller then uses the streaming kernels.
 constexpr int32_t GEMM_PASS_QUERIES = 8, GEMM_PASS_MIN_QUERIES = 3;
+// An index WITHOUT the pre-split image (RL_OPT_KEEP_IMAGE = 0: rows + HI image, 1.5 x the corpus) still runs the bound-filtered batch: the
+// approximate pass reads the HI image, the exact re-scoring the rows, and the guarded full-precision fallback the rows through the streaming
+// kernels (one launch, grid row = query) -- which is what decides the shapes this holds for.
+bool slim_batch_ok(const rl_index* idx, const float* d_q) {
+    const int32_t d = idx->dim;
+    return !image_valid(idx) && !idx->E16 && idx->E && hi_image_valid(idx) && (d == 256 || d == 384 || d == 512 || d == 768 || d == 1024) &&
+           !(reinterpret_cast<uintptr_t>(d_q) & 15) && !(reinterpret_cast<uintptr_t>(idx->E) & 15);
+}
 int gemm_prepare(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, int32_t n_queries, hipStream_t s) {
-    if (!idx->opt.on(RL_OPT_GEMM_PASS) || !image_valid(idx)) return RL_ERR_UNSUPPORTED;
+    if (!idx->opt.on(RL_OPT_GEMM_PASS) || !(image_valid(idx) || slim_batch_ok(idx, d_q))) return RL_ERR_UNSUPPORTED;
     if (idx->has_empty_chunk || idx->n_chunks == 0 || nq < 1 || nq > 32 || n_queries < GEMM_PASS_MIN_QUERIES) return RL_ERR_UNSUPPORTED;
     RL_TRY(idx->qplanes.reserve(query_planes_bytes(idx->dim, n_queries)));
     return launch_query_planes(d_q, idx->dim, nq, q_stride, n_queries, idx->qplanes.p, s);
@@ -2032,8 +2049,14 @@ int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_quer
     RL_TRY(launch_merge_topk(hb.es, hb.ci, 1, n_gemm, hb.cap, k, d_s, d_c, s, hb.cnt));
     // list overflow / unusable bound: the full-precision passes, behind the flag -- ONE launch for all of them (gridDim.y = passes: sixteen
     // guarded launches that return at once were 0.08 ms of every 128-query step)
-    RL_TRY(launch_maxsim_gemm(idx->planes.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, 0, n_gemm, nq, idx->row_to_chunk, idx->offsets,
-                              idx->ends.as<uint32_t>(), sc, ld, idx->n_cu, s, image_scale(idx), idx->E16 != nullptr, hb.flag, false, true));
+    // (no pre-split image: the streaming kernels over the rows, one launch with a grid row per query -- the same arithmetic, an order of
+    // magnitude slower, and as rare)
+    if (image_valid(idx))
+        RL_TRY(launch_maxsim_gemm(idx->planes.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, 0, n_gemm, nq, idx->row_to_chunk, idx->offsets,
+                                  idx->ends.as<uint32_t>(), sc, ld, idx->n_cu, s, image_scale(idx), idx->E16 != nullptr, hb.flag, false, true));
+    else
+        RL_TRY(launch_maxsim_stream_batch(idx->E, false, idx->n_rows, idx->dim, d_q, nq, (int64_t)q_elems, n_gemm, idx->row_to_chunk, idx->offsets,
+                                          idx->n_chunks, sc, ld, idx->n_cu, s, idx->split_scale, hb.flag));
     RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // (harmless on scores nobody reads)
     RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, d_s, d_c, s, hb.flag));
     return RL_OK;
@@ -2079,7 +2102,9 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
                                        : 0;
             const bool hi_off = !idx->opt.on(RL_OPT_HI_MAXSIM);
             const bool two_products = idx->opt.v[RL_OPT_HI_PRODUCTS] == 2;  // (over an fp16-stored corpus two products ARE the full precision)
-            if (n_gemm > 0 && !hi_off && approx_image_valid(idx) && k <= 512 && !(idx->E16 && two_products)) {
+            const bool pp_route = idx->opt.v[RL_OPT_HI_PRODUCTS] == 1 && idx->dim >= 256 && idx->opt.on(RL_OPT_PP_PASS);
+            const bool slim = !image_valid(idx);  // (gemm_prepare accepted it: slim_batch_ok) -- only the sixteen-query pass reads the HI image alone
+            if (n_gemm > 0 && !hi_off && approx_image_valid(idx) && k <= 512 && !(idx->E16 && two_products) && (!slim || pp_route)) {
                 // ---- MaxSim of a batch at two MFMA products per multiply instead of three (the headline path) -------------------------
                 // (1) approximate chunk scores: the eight-query pass over the HI image (q_hi.e_hi + q_lo.e_hi);
                 // (2) |approximate - exact| <= m = (max|e_lo| + 2^-12 max|e|) sum_i |q_i| for every chunk (the per-pair bound of
@@ -2099,7 +2124,7 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
                 RL_TRY(hi_batch_rescore(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, d_s, d_c, s));
                 base = n_gemm;
                 hi_done = true;
-            } else {
+            } else if (!slim) {
                 while (n_queries - base >= GEMM_PASS_MIN_QUERIES) {
                     const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_queries - base);
                     RL_TRY(gemm_pass(idx, nq, n_queries, base, n_q, sc + (int64_t)base * ld, ld, s));
@@ -2162,6 +2187,8 @@ int rl_maxsim_batch_begin(rl_index* idx, const float* query_vecs, int32_t n_quer
         if (st != RL_OK) return st == RL_ERR_UNSUPPORTED ? fail(RL_ERR_UNSUPPORTED, "rl_maxsim_batch_begin: this index keeps no corpus image") : st;
     }
     if (!approx_image_valid(idx)) return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_batch_begin: this index keeps no image for the approximate pass (small or exact-fp32 index)");
+    if (!image_valid(idx) && !(idx->opt.v[RL_OPT_HI_PRODUCTS] == 1 && idx->dim >= 256 && idx->opt.on(RL_OPT_PP_PASS)))
+        return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_batch_begin: without the pre-split image only the sixteen-query pass (hi_products = 1, pp_pass = 1) runs");
     HiBatch hb;
     RL_TRY(hi_batch_approx(idx, d_q, nq, n_queries, n_queries, k, sc, ld, hb, s));
     // this shard's bound m_b: the threshold kernel over a "k-th best" of zero leaves -2 m_b
@@ -2446,6 +2473,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     }
     if (kind == 3 || kind == 5 || kind == 6) {  // eight queries of nq / 8 vectors each
         st = gemm_prepare(idx, q_dev, nq / GEMM_PASS_QUERIES, (int64_t)(nq / GEMM_PASS_QUERIES) * idx->dim, GEMM_PASS_QUERIES, s);
+        if (st == RL_OK && !image_valid(idx)) st = RL_ERR_UNSUPPORTED;  // (an index of rows + HI image: only the sixteen-query pass applies)
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the eight-query kernel does not apply to this index / shape") : st; }
     }
     if (kind == 7) {  // sixteen queries of nq / 16 vectors each

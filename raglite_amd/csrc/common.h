@@ -257,6 +257,9 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
                          const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
                          float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale = 0.f,
                          const uint32_t* run_if = nullptr);  // run_if: the kernel returns at once unless *run_if != 0
+int launch_maxsim_stream_batch(const void* D, bool f16, int64_t n_rows, int32_t dim, const float* Q, int32_t nq, int64_t q_stride,
+                               int32_t n_queries, const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, float* out,
+                               int64_t out_stride, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if = nullptr);
 size_t query_split_bytes(int32_t dim, int32_t n_queries);
 int launch_query_split(const float* Q, int32_t dim, int32_t nq, int64_t q_stride, int32_t n_queries, void* buf, bool f16_corpus,
                        hipStream_t s);

@@ -95,8 +95,13 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
                                                                  const int32_t* __restrict__ row_to_chunk,
                                                                  const int64_t* __restrict__ chunk_offsets,
                                                                  int64_t n_chunks, float* __restrict__ out,
-                                                                 int64_t ld, unsigned long long* trace, float e_scale) {
+                                                                 int64_t ld, unsigned long long* trace, float e_scale,
+                                                                 int64_t q_batch_stride, int64_t out_batch_stride) {
     static_assert(!(F16 && SPLIT), "SPLIT is a way to multiply an fp32-stored corpus");
+    // gridDim.y > 1: ONE launch for a batch of queries (the guarded full-precision fallback of a MaxSim batch over an index that keeps no
+    // pre-split image): grid row y scores query y -- its own vectors, its own output row
+    Q += (int64_t)blockIdx.y * q_batch_stride;
+    out += (int64_t)blockIdx.y * out_batch_stride;
     if constexpr (!TRACE) {  // production build: `trace` carries an optional run-if flag (a guarded fallback launch returns at once)
         if (trace && __builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const uint32_t*>(trace)) == 0) return;  // whole grid
     }
@@ -991,12 +996,14 @@ namespace {
 struct StreamArgs {
     const float* D; int64_t n_rows; const float* Q; int nq; const int32_t* r2c; const int64_t* off; int64_t n_chunks;
     int mode; float* out; int64_t ld; dim3 grid; hipStream_t s; unsigned long long* trace; float e_scale;
+    int64_t q_batch_stride = 0, out_batch_stride = 0;
 };
 template <int KW, bool F16, bool SPLIT = false>
 void launch_kw(const StreamArgs& a) {
     const dim3 blk(512);
 #define RL_STREAM(NQT, MODE) hipLaunchKernelGGL((maxsim_stream_kernel<KW, NQT, MODE, false, 6, F16, SPLIT>), a.grid, blk, 0, a.s, a.D, \
-                                                a.n_rows, a.Q, a.nq, a.r2c, a.off, a.n_chunks, a.out, a.ld, a.trace, a.e_scale)
+                                                a.n_rows, a.Q, a.nq, a.r2c, a.off, a.n_chunks, a.out, a.ld, a.trace, a.e_scale, a.q_batch_stride, \
+                                                a.out_batch_stride)
     if (a.mode == 0) { if (a.nq <= 16) RL_STREAM(1, 0); else RL_STREAM(2, 0); }
     else             { if (a.nq <= 16) RL_STREAM(1, 1); else RL_STREAM(2, 1); }
 #undef RL_STREAM
@@ -1007,8 +1014,9 @@ void launch_kw(const StreamArgs& a) {
 // f16 = the corpus is stored as IEEE fp16 (D then points at uint16_t data); queries and scores stay fp32.
 static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
                              const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
-                             float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale = 0.f, const uint32_t* run_if = nullptr) {
-    if (nq < 1 || nq > 32 || n_rows < 1) return RL_ERR_UNSUPPORTED;
+                             float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale = 0.f, const uint32_t* run_if = nullptr,
+                             int32_t n_batch = 1, int64_t q_batch_stride = 0, int64_t out_batch_stride = 0) {
+    if (nq < 1 || nq > 32 || n_rows < 1 || n_batch < 1 || n_batch > 65535 || (n_batch > 1 && mode != 0)) return RL_ERR_UNSUPPORTED;
     if (dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
     const int64_t tiles = (n_rows + TR - 1) / TR;
@@ -1022,7 +1030,7 @@ static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t d
     if (trace && !f16 && mode == 0 && nq > 16 && dim == 1024) {  // diagnostic build: dump the 30th launch's timeline to stderr
         static int calls = 0;
         hipLaunchKernelGGL((maxsim_stream_kernel<256, 2, 0, true>), dim3(grid), dim3(512), 0, s, D, n_rows, Q, nq,
-                           row_to_chunk, chunk_offsets, n_chunks, out, ld, trace, 1.f);
+                           row_to_chunk, chunk_offsets, n_chunks, out, ld, trace, 1.f, (int64_t)0, (int64_t)0);
         if (++calls == 30) {
             unsigned long long h[8 * 8 * 8];
             (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
@@ -1044,8 +1052,8 @@ static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t d
         return RL_OK;
     }
 #endif
-    const StreamArgs a{D, n_rows, Q, (int)nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, dim3(grid), s,
-                       reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(run_if)), split_scale};
+    const StreamArgs a{D, n_rows, Q, (int)nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, dim3(grid, (unsigned)n_batch), s,
+                       reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(run_if)), split_scale, q_batch_stride, out_batch_stride};
     const bool split = !f16 && split_scale > 0.f;  // 0: the exact fp32 MFMA chain
 #define RL_DIMS(...) switch (dim) { \
         case 128: launch_kw<32, __VA_ARGS__>(a); break; case 256: launch_kw<64, __VA_ARGS__>(a); break; case 384: launch_kw<96, __VA_ARGS__>(a); break; \
@@ -1061,6 +1069,15 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
                          float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if) {
     return launch_stream_any(D, false, n_rows, dim, Q, nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, n_cu, s,
                              split_scale, run_if);
+}
+
+// MaxSim chunk scores of a BATCH of queries in one launch (grid row y = query y: Q + y q_stride -> out + y out_stride), fp32 or fp16 rows;
+// what the guarded fallback of a MaxSim batch runs over an index without a pre-split image.  nq <= 32 per query.
+int launch_maxsim_stream_batch(const void* D, bool f16, int64_t n_rows, int32_t dim, const float* Q, int32_t nq, int64_t q_stride,
+                               int32_t n_queries, const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, float* out,
+                               int64_t out_stride, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if) {
+    return launch_stream_any(static_cast<const float*>(D), f16, n_rows, dim, Q, nq, row_to_chunk, chunk_offsets, n_chunks, 0, out, 0, n_cu, s,
+                             f16 ? 0.f : split_scale, run_if, n_queries, q_stride, out_stride);
 }
 
 // Two queries (17..32 vectors each, q_stride floats apart) per corpus pass over an fp32 corpus in SPLIT arithmetic:

@@ -376,3 +376,90 @@ def test_the_shipped_library_ignores_experiment_environment_variables(monkeypatc
     assert torch.equal(a0, a1) and torch.equal(s0, s1) and torch.equal(c0, c1)
     idx.close()
     idx2.close()
+
+
+# ---- index footprint: rows + HI image only (RL_OPT_KEEP_IMAGE = 0, RL_OPT_KEEP_HI_PLANE = 0 -- 1.5 x the corpus instead of 3 x) -----------------
+# The bound-filtered batch reads the HI image (approximate pass) and the rows (exact re-scoring); only its guarded full-precision fallback
+# ever read the pre-split image.  Without that image the fallback runs the streaming kernels over the rows (one launch, grid row = query).
+
+
+def test_slim_index_rows_plus_hi_image_same_bits():
+    torch = _torch()
+    rng = np.random.default_rng(41)
+    off = ragged_offsets(rng, N, 1, 15)
+    E = _corpus(torch, N, DIM, seed=12_000)
+    Qb = _queries(torch, 19, 32, DIM, seed=12_001)  # 16 + 3: two passes of the sixteen-query kernel
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    m0 = idx.memory()
+    assert m0["presplit_image"] > 0 and m0["hi_plane"] > 0 and m0["hi_image"] > 0
+    s0, c0 = idx.maxsim_topk_batch(Qb, 100)
+    st0 = idx.filter_stats()
+    idx.set_option("keep_image", 0)
+    idx.set_option("keep_hi_plane", 0)
+    m1 = idx.memory()
+    assert m1["presplit_image"] == 0 and m1["hi_plane"] == 0 and m1["hi_image"] == m0["hi_image"]
+    assert m1["rows"] + m1["hi_image"] <= 1.51 * m1["rows"]
+    s1, c1 = idx.maxsim_topk_batch(Qb, 100)
+    st1 = idx.filter_stats()
+    assert st1["kind"] == st0["kind"] == "maxsim_batch_hi" and not st1["fallback"] and not st0["fallback"]
+    assert st1["candidates_per_query_max"] == st0["candidates_per_query_max"]
+    assert torch.equal(c0, c1) and torch.equal(s0, s1)
+    # the staged form (what a shard of a ShardedIndex runs) on the slim index
+    a = idx.maxsim_batch_begin(Qb, 100)
+    s2, c2 = idx.maxsim_batch_finish(Qb, a[None], 0, 100)
+    assert torch.equal(c0.to(torch.int64), c2.to(torch.int64)) and torch.equal(s0, s2)
+    # the eight-query kernel reads the pre-split image's layout partner: not available here, the call says so instead of reading freed memory
+    with idx.options(pp_pass=0):
+        s3, c3 = idx.maxsim_topk_batch(Qb, 100)  # (falls to the streaming kernels: same chunks, scores within the paths' rounding)
+    assert idx.filter_stats()["kind"] == "none"
+    for i in range(Qb.shape[0]):
+        assert set(c3[i].tolist()) == set(c0[i].tolist())
+    torch.testing.assert_close(s3.sort(dim=1).values, s0.sort(dim=1).values, rtol=0, atol=2e-6 * float(s0.abs().max()))
+    # appends keep the slim layout and its results
+    extra = _corpus(torch, 4_000, DIM, seed=12_002)
+    idx.append(extra, np.full(1000, 4, dtype=np.int64))
+    full = raglite_amd.DeviceIndex(torch.cat([E, extra]), np.concatenate([off, off[-1] + 4 * np.arange(1, 1001)]), metric="dot")
+    m2 = idx.memory()
+    assert m2["presplit_image"] == 0 and m2["hi_plane"] == 0 and m2["hi_image"] > 0
+    s4, c4 = idx.maxsim_topk_batch(Qb, 100)
+    s5, c5 = full.maxsim_topk_batch(Qb, 100)
+    assert torch.equal(c4, c5) and torch.equal(s4, s5)
+    idx.close()
+    full.close()
+
+
+@pytest.mark.parametrize("data", ["integer_ties", "near_identical"])
+def test_slim_index_fallback_runs_the_streaming_kernels(data):
+    """More candidates than a list holds: the flag goes up and the guarded fallback answers -- over the rows when there is no pre-split image."""
+    rng = np.random.default_rng(43)
+    off = np.arange(N + 1, dtype=np.int64)
+    if data == "integer_ties":  # 6 000 identical one-row chunks at the top of every ranking; integer data: every path is exact
+        E = oracle.synth_matrix(12_100, N, DIM, "small_int")
+        Qb = np.stack([oracle.synth_matrix(12_200 + i, 8, DIM, "small_int") for i in range(5)])
+        hot = rng.choice(N, 6000, replace=False)
+        E[hot] = np.sign(Qb[:, 0].sum(axis=0))[None, :] * 3.0
+    else:
+        E = oracle.synth_matrix(12_300, N, DIM)
+        Qb = np.stack([oracle.synth_matrix(12_400 + i, 8, DIM) for i in range(5)])
+        hot = rng.choice(N, 4000, replace=False)
+        E[hot] = (3.0 * Qb[:, 0].sum(axis=0)[None, :] + 1e-4 * rng.standard_normal((4000, DIM))).astype(np.float32)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    fs, fc = idx.maxsim_topk_batch(Qb, 100)
+    assert idx.filter_stats()["fallback"]
+    idx.set_option("keep_image", 0)
+    idx.set_option("keep_hi_plane", 0)
+    assert idx.memory()["presplit_image"] == 0
+    bs, bc = idx.maxsim_topk_batch(Qb, 100)
+    st = idx.filter_stats()
+    assert st["kind"] == "maxsim_batch_hi" and st["fallback"]
+    if data == "integer_ties":
+        assert np.array_equal(bc, fc) and np.array_equal(bs.view(np.uint32), fs.view(np.uint32))
+        for i in (0, 4):
+            ref = oracle.maxsim_scores(E, off, Qb[i], np.float64)
+            order = np.lexsort((np.arange(len(ref)), -ref))[:100]
+            assert np.array_equal(bc[i], order) and np.array_equal(bs[i].astype(np.float64), ref[order])
+    else:  # float data: the streaming kernels and the eight-query pass sum in different orders -- same chunks, scores within the rounding
+        for i in range(5):
+            ref = oracle.maxsim_scores(E, off, Qb[i], np.float64)
+            assert_topk_close(bs[i], bc[i], ref, 100, 2e-6 * float(np.abs(ref).max()))
+    idx.close()
