@@ -299,8 +299,14 @@ def main() -> None:
                 break
             except Exception:  # noqa: BLE001 - that kernel does not apply to this index / shape
                 continue
+    if kind == 7 and NQ == 32 and qps >= 32:
+        # the batch pipeline launches ALL the passes of a step at once (grid row = pass of sixteen queries): the launch that is timed -- and
+        # that rocprofv3 sees -- is that one, per_launch queries = per_launch / 16 passes over the HI image
+        per_launch = (qps // 16) * 16
+    passes_per_launch = per_launch // 16 if kind == 7 else 1
+    algo_bytes *= passes_per_launch
     if kind in (5, 6, 7):
-        streamed_bytes = 2.0 * rows_local * DIM  # the HI image: 2 B per element
+        streamed_bytes = 2.0 * rows_local * DIM * passes_per_launch  # the HI image: 2 B per element, once per pass
     qv = queries[0, :per_launch].reshape(per_launch * NQ, DIM)
     index.time_kernel(kind, qv, 3)  # warm
     ms = index.time_kernel(kind, qv, iters) / iters
@@ -312,7 +318,9 @@ def main() -> None:
     tf = ROOT / "profiles" / "traffic.json"  # from separate rocprofv3 --pmc FETCH_SIZE passes
     if tf.exists() and args.storage == "f32" and n_rows == N_ROWS and world == 1:
         tj = json.loads(tf.read_text())
-        traffic = tj.get({5: "maxsim_gemm_hi_bytes_per_launch", 6: "maxsim_gemm_hi_bytes_per_launch", 7: "maxsim_pp_bytes_per_launch", 3: "maxsim_gemm_bytes_per_launch", 2: "maxsim_stream2_bytes_per_launch"}.get(kind, "maxsim_stream_bytes_per_launch"))
+        traffic = tj.get({5: "maxsim_gemm_hi_bytes_per_launch", 6: "maxsim_gemm_hi_bytes_per_launch", 7: "maxsim_pp_bytes_per_pass", 3: "maxsim_gemm_bytes_per_launch", 2: "maxsim_stream2_bytes_per_launch"}.get(kind, "maxsim_stream_bytes_per_launch"))
+        if traffic is not None:
+            traffic *= passes_per_launch  # (the counters were collected per pass of sixteen queries)
         traffic_source = "static: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 for the gfx950 half-count, separate run)"
     kernel_name = {5: "rl::maxsim_gemm_kernel<2, false, 0, true>", 6: "rl::maxsim_gemm_kernel<2, false, 0, true>", 7: "rl::maxsim_pp_kernel<0, 0, false>",
                    3: "rl::maxsim_gemm_kernel<2, false, 0, true>" if arithmetic == "f16_stored" else "rl::maxsim_gemm_kernel<2, false, 0, false>",
@@ -336,17 +344,22 @@ def main() -> None:
         result["roofline"] = {"bound": "hbm", **hbm, "traffic": traffic}
     if kind in (5, 6, 7):  # for reference: the full-precision pass (eight queries) the approximate one replaces (and falls back to)
         qv8 = queries[0, :8].reshape(8 * NQ, DIM)
-        index.time_kernel(3, qv8, 2)
-        result["roofline"]["full_precision_pass_ms"] = index.time_kernel(3, qv8, iters) / iters
+        try:
+            index.time_kernel(3, qv8, 2)
+            result["roofline"]["full_precision_pass_ms"] = index.time_kernel(3, qv8, iters) / iters
+        except raglite_amd._abi.UnsupportedError:  # --opt keep_image=0: no pre-split image, the fallback is the streaming kernel over the rows
+            result["roofline"]["full_precision_pass_ms"] = None
     result["roofline"].update({
-        "kernel": kernel_name, "arithmetic": arithmetic, "queries_per_launch": per_launch, "kernel_ms": ms,
+        "kernel": kernel_name, "arithmetic": arithmetic, "queries_per_launch": per_launch, "passes_per_launch": passes_per_launch, "kernel_ms": ms,
+        "kernel_ms_per_pass": ms / passes_per_launch,
         "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes,
         # HIP events around the whole timed region / corpus passes in it: the kernel + its share of query split and selection
         "timed_region_ms_per_pass": region_ms / (args.steps * qps) * per_launch,
         "fp32_equivalent_tflops": fp32_equiv_flops / (ms * 1e-3) / 1e12,
         "fp32_equivalent_tflops_over_fp32_mfma_peak": fp32_equiv_flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
     })
-    result["config"]["corpus_passes_per_step"] = -(-qps // per_launch)
+    result["config"]["corpus_passes_per_step"] = -(-qps // per_launch) * passes_per_launch
+    result["config"]["launches_per_step"] = -(-qps // per_launch)
 
     # ---- where a rank's step goes (N > 1, or --split): passes / the rest of its local work / the exchanges ----------------------------
     # Outside the timed region, the stages of ShardedIndex.maxsim_topk_batch's staged path issued one by one with HIP events between them

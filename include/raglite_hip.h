@@ -455,7 +455,8 @@ int rl_index_filter_stats(rl_index* index, int64_t out[6], void* stream);
  * RL_ERR_UNSUPPORTED when the index has none), 5 = the approximate eight-query MaxSim pass over the HI image
  * (as kind 3) with two MFMA products per multiply, 6 = the same pass with one,
  * 7 = the SIXTEEN-queries-per-pass kernel over the HI image, one product (maxsim_pp.hip: what rl_maxsim_topk_batch runs by default;
- * sixteen queries of nq / 16 vectors each), 8 = the candidate pass of the LAST rl_search_rows call of >= 96 queries on this index that
+ * sixteen queries of nq / 16 vectors each; nq > 512: nq / 32 queries of 32 vectors, all their passes in ONE launch -- grid row = pass --
+ * as the batch pipeline launches them), 8 = the candidate pass of the LAST rl_search_rows call of >= 96 queries on this index that
  * went through the fused top-k over the HI image, replayed with that call's queries and thresholds (query_vecs_dev / nq are not read;
  * RL_ERR_UNSUPPORTED when no such call ran or the index' scratch has been resized since).
  * Used so that roofline.achieved is measured with HIP

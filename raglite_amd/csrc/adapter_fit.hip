@@ -85,13 +85,23 @@ __global__ __launch_bounds__(256) void permute_rows_kernel(const int32_t* __rest
 template <typename ET>
 __global__ __launch_bounds__(256) void gather_rows_kernel(const ET* __restrict__ E, int dim, int64_t n_rows,
                                                            const int32_t* __restrict__ rows, int64_t n,
-                                                           float* __restrict__ out) {
+                                                           float* __restrict__ out, const uint32_t* __restrict__ counts, int cap) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
     for (int64_t i = wave0; i < n; i += n_waves) {
+        if (counts && (uint32_t)(i % cap) >= counts[i / cap]) continue;  // a slot past its list's length: nothing to gather (wave-uniform)
         const int64_t r = rows[i];
         const bool ok = r >= 0 && r < n_rows;
+        if constexpr (sizeof(ET) == 4) {
+            if ((dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(E) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {  // 16 B per lane
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                const f4* src = reinterpret_cast<const f4*>(E + (ok ? r : 0) * (int64_t)dim);
+                f4* dst = reinterpret_cast<f4*>(out + i * (int64_t)dim);
+                for (int k = lane; k < (dim >> 2); k += 64) dst[k] = ok ? src[k] : (f4){NAN, NAN, NAN, NAN};
+                continue;
+            }
+        }
         for (int k = lane; k < dim; k += 64) out[i * (int64_t)dim + k] = ok ? elt<ET>(E + r * (int64_t)dim + k) : NAN;
     }
 }
@@ -158,15 +168,16 @@ int launch_compact_rows(const void* src, int64_t row_bytes, const int64_t* old_r
 }
 
 int launch_gather_rows(const void* E, bool f16, int32_t dim, int64_t n_rows, const int32_t* rows, int64_t n, float* out,
-                       hipStream_t s) {
+                       hipStream_t s, const uint32_t* counts, int32_t cap) {
     if (n <= 0) return RL_OK;
+    if (counts && (cap < 1 || n % cap)) return RL_ERR_INVALID;
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>((n + 3) / 4, 256 * 16));
     if (f16)
         hipLaunchKernelGGL((gather_rows_kernel<uint16_t>), dim3(blocks), dim3(256), 0, s, static_cast<const uint16_t*>(E),
-                           (int)dim, n_rows, rows, n, out);
+                           (int)dim, n_rows, rows, n, out, counts, (int)cap);
     else
         hipLaunchKernelGGL((gather_rows_kernel<float>), dim3(blocks), dim3(256), 0, s, static_cast<const float*>(E),
-                           (int)dim, n_rows, rows, n, out);
+                           (int)dim, n_rows, rows, n, out, counts, (int)cap);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

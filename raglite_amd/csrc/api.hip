@@ -1525,13 +1525,11 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
         RL_TRY(launch_transform(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, s, 1.0f / idx->hi_scale));
         RL_TRY(launch_mask_scores(sc, nb, n, ld, d_row_bits, s));
         RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s));
-    } else {
-        RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f / idx->hi_scale));
+    } else {  // (this launch also zeroes the candidate counters and the flag: cnt[0 .. 32))
+        RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f / idx->hi_scale, nullptr, cnt, 32));
         RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s, nullptr, true));
     }
     // ---- (2) every row that could be in the exact top-k ------------------------------------------------------------------------------------
-    // 2^-10 for the dropped lo halves + 2^-11 for everything fp32 does to both passes (worst case of a 1024-term fp32 sum:
-    // 6e-5 each; the query's own 2^-22 split; the metric's two roundings)
     // The bound: what the HI halves drop is known exactly per row -- max |e_lo| / |e| (cosine) and max |e_lo| (dot) are kept by the
     // index (refresh_hi_image) -- plus 2^-12 |e| |q| for the query's own 2^-22 split and twice the worst case of a 1024-term fp32
     // sum (6e-5).  Without those maxima (no HI image on this index): the a-priori 2^-10 of the truncation, plus 2^-11.
@@ -1541,17 +1539,27 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
         if (mode == SCAN_COSINE) m_rel = idx->max_lo_ratio + 0x1p-12f;
         else { m_rel = 1.0f; e_bound = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm; }
     }
-    RL_TRY(launch_approx_threshold(ts, nb, k, d_q, dim, mode, m_rel, e_bound, thr, cnt, flag, s));
-    RL_TRY(launch_collect_above(sc, nb, n, ld, thr, mode == SCAN_COSINE ? idx->norm : nullptr, cap, ci, gn, cnt, flag, s));
+    // Round 4 (cfg 2: thirteen launches of 4.6 - 9.9 us behind a 0.31 ms pass): the threshold is computed by the collecting workgroups
+    // themselves, the counters are zeroed by the histogram launch above, the gather skips the empty slots of the lists, and the metric
+    // transform of the re-scored candidates happens on the way into the final ranking -- three launches fewer, same statements, same bits.
+    if (d_row_bits) {
+        RL_TRY(launch_approx_threshold(ts, nb, k, d_q, dim, mode, m_rel, e_bound, thr, cnt, flag, s));
+        RL_TRY(launch_collect_above(sc, nb, n, ld, thr, mode == SCAN_COSINE ? idx->norm : nullptr, cap, ci, gn, cnt, flag, s));
+    } else {
+        SelfThreshold self;
+        self.topk = ts; self.queries = d_q; self.k = k; self.dim = dim; self.mode = mode; self.m_rel = m_rel; self.e_norm_bound = e_bound;
+        RL_TRY(launch_collect_above(sc, nb, n, ld, thr, mode == SCAN_COSINE ? idx->norm : nullptr, cap, ci, gn, cnt, flag, s, nullptr, nullptr, 0, &self));
+    }
     idx->filt = {RL_FILTER_ROWS_HI, nb, cap, cnt, flag};
-    // ---- (3) exact scores of the candidates, by the kernels of the full pass (slots past a list's length hold stale row numbers:
-    // gathered and scored, never ranked) ---------------------------------------------------------------------------------------------------------
-    RL_TRY(launch_gather_rows(idx->E, false, dim, n, ci, nc, G, s));
+    // ---- (3) exact scores of the candidates, by the kernels of the full pass (slots past a list's length are neither gathered nor
+    // ranked: the pass multiplies whatever their rows of G hold) ---------------------------------------------------------------------
+    RL_TRY(launch_gather_rows(idx->E, false, dim, n, ci, nc, G, s, cnt, cap));
     st = launch_maxsim_stream(G, nc, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, xs, ldx, idx->n_cu, s, idx->split_scale);
     if (st != RL_OK) return st;
-    RL_TRY(launch_transform(xs, nb, nc, ldx, gn, nullptr, d_q, dim, mode, s));
     if (nb > 1) RL_TRY(launch_diag_blocks(xs, ldx, cap, nc, es, s));  // (one query: the block IS its diagonal)
-    RL_TRY(launch_merge_topk(nb > 1 ? es : xs, ci, 1, nb, cap, k, d_scores, d_rows, s, cnt));
+    MergeTransform tr;
+    tr.row_norm = gn; tr.queries = d_q; tr.dim = dim; tr.mode = mode;
+    RL_TRY(launch_merge_topk(nb > 1 ? es : xs, ci, 1, nb, cap, k, d_scores, d_rows, s, cnt, &tr));
     // ---- (4) guarded full-precision pass ------------------------------------------------------------------------------------------
     st = launch_maxsim_stream(idx->E, n, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, sc, ld, idx->n_cu, s, idx->split_scale,
                               flag);
@@ -2011,11 +2019,10 @@ int hi_batch_approx(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queri
     // One product: SIXTEEN queries per pass through maxsim_pp.hip (dim >= 256; RL_OPT_PP_PASS = 0: the eight-query pass of
     // maxsim_gemm.hip instead -- A/B, and what two products still use).
     const bool pp = hb.one_product && idx->dim >= 256 && idx->opt.on(RL_OPT_PP_PASS);
-    for (int32_t b = 0; pp && b < n_gemm; b += PP_PASS_QUERIES) {
-        const int32_t n_q = std::min<int32_t>(PP_PASS_QUERIES, n_gemm - b);
-        RL_TRY(launch_maxsim_pp(approx_image(idx), idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
-                                idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, approx_scale(idx)));
-    }
+    // (round 4: ONE launch for all of the batch's passes -- grid row = pass -- so that a pass starts on the CUs the previous one leaves)
+    if (pp)
+        RL_TRY(launch_maxsim_pp(approx_image(idx), idx->n_rows, idx->dim, idx->qplanes.p, n_queries, 0, n_gemm, nq, idx->row_to_chunk,
+                                idx->offsets, idx->ends.as<uint32_t>(), sc, ld, idx->n_cu, s, approx_scale(idx)));
     for (int32_t b = 0; !pp && b < n_gemm; b += GEMM_PASS_QUERIES) {
         const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_gemm - b);
         RL_TRY(launch_maxsim_gemm(approx_image(idx), idx->n_rows, idx->dim, idx->qplanes.p, n_queries, b, n_q, nq, idx->row_to_chunk,
@@ -2265,7 +2272,7 @@ int rl_maxsim_approx_scores(rl_index* idx, const float* query_vecs, int32_t n_qu
     if (out_bound) RL_TRY(stage_out_begin(out_bound, (size_t)n_queries, mem, t_b, &d_b));
     RL_TRY(idx->qplanes.reserve(query_planes_bytes(idx->dim, n_queries)));
     RL_TRY(launch_query_planes(d_q, idx->dim, nq, (int64_t)q_elems, n_queries, idx->qplanes.p, s));
-    const int32_t per = kernel == 0 ? PP_PASS_QUERIES : GEMM_PASS_QUERIES;
+    const int32_t per = kernel == 0 ? n_queries : GEMM_PASS_QUERIES;  // (the sixteen-query kernel takes all its passes in one launch)
     for (int32_t b = 0; b < n_queries; b += per) {
         const int32_t n_q = std::min<int32_t>(per, n_queries - b);
         if (kernel == 0)
@@ -2456,7 +2463,12 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     if (kind == 0) RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));
     else if (kind == 2) RL_TRY(idx->scores.reserve((size_t)2 * ldc * sizeof(float)));
     else if (kind == 3 || kind == 5 || kind == 6) RL_TRY(idx->scores.reserve((size_t)GEMM_PASS_QUERIES * ldc * sizeof(float)));
-    else if (kind == 7) RL_TRY(idx->scores.reserve((size_t)PP_PASS_QUERIES * ldc * sizeof(float)));
+    // kind 7: sixteen queries of nq / 16 vectors each -- or, nq > 16 * 32, nq / 32 queries of 32 vectors: all their passes in ONE launch, as
+    // the batch pipeline launches them
+    const int32_t pp_vec = nq / PP_PASS_QUERIES <= 32 ? nq / PP_PASS_QUERIES : 32;
+    const int32_t pp_n = nq / PP_PASS_QUERIES <= 32 ? PP_PASS_QUERIES : nq / 32;
+    if (kind == 7) RL_TRY(idx->scores.reserve((size_t)pp_n * ldc * sizeof(float)));
+    else if (kind == 0 || kind == 2 || kind == 3 || kind == 5 || kind == 6) {}
     else if (kind == 8) {  // replays the candidate pass of the last fused-HI row search (same queries, same thresholds)
         const auto& r = idx->replay;
         if (!r.valid || r.pools[0] != idx->misc.p || r.pools[1] != idx->fused.p || r.pools[2] != idx->pp_work.p || !hi_image_valid(idx))
@@ -2476,15 +2488,15 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
         if (st == RL_OK && !image_valid(idx)) st = RL_ERR_UNSUPPORTED;  // (an index of rows + HI image: only the sixteen-query pass applies)
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the eight-query kernel does not apply to this index / shape") : st; }
     }
-    if (kind == 7) {  // sixteen queries of nq / 16 vectors each
-        st = gemm_prepare(idx, q_dev, nq / PP_PASS_QUERIES, (int64_t)(nq / PP_PASS_QUERIES) * idx->dim, PP_PASS_QUERIES, s);
+    if (kind == 7) {
+        st = pp_vec >= 1 && pp_vec * pp_n == nq ? gemm_prepare(idx, q_dev, pp_vec, (int64_t)pp_vec * idx->dim, pp_n, s) : RL_ERR_UNSUPPORTED;
         if (st == RL_OK && !(approx_image_valid(idx) && idx->dim >= 256)) st = RL_ERR_UNSUPPORTED;
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the sixteen-query kernel does not apply to this index / shape") : st; }
     }
     RL_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < iters && st == RL_OK; ++i) {
-        if (kind == 7) st = launch_maxsim_pp(approx_image(idx), idx->n_rows, idx->dim, idx->qplanes.p, PP_PASS_QUERIES, 0, PP_PASS_QUERIES,
-                                             nq / PP_PASS_QUERIES, idx->row_to_chunk, idx->offsets, idx->ends.as<uint32_t>(), idx->scores.as<float>(), ldc,
+        if (kind == 7) st = launch_maxsim_pp(approx_image(idx), idx->n_rows, idx->dim, idx->qplanes.p, pp_n, 0, pp_n,
+                                             pp_vec, idx->row_to_chunk, idx->offsets, idx->ends.as<uint32_t>(), idx->scores.as<float>(), ldc,
                                              idx->n_cu, s, approx_scale(idx));
         else if (kind == 3) st = gemm_pass(idx, nq / GEMM_PASS_QUERIES, GEMM_PASS_QUERIES, 0, GEMM_PASS_QUERIES, idx->scores.as<float>(), ldc, s);
         else if (kind == 8) {

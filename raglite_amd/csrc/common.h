@@ -160,15 +160,24 @@ int launch_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, i
 // launch_transform (scan.hip) + the selection's histogram pass in ONE launch: raw dots -> similarities in place, and their
 // 2048-bin key histogram into ws.hist (same statements as transform_kernel: same bits).  Follow with launch_topk(have_hist).
 // pre_scale: the raw dots are multiplied by it first (a power of two: exact; 1 = the plain transform); run_if as in launch_topk.
+// zero_words / n_zero (<= 256): words this launch also sets to zero (the candidate counters + flag of a B <= 16 row search: no memset launch).
 int launch_transform_hist(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm, const float* row_sumsq,
                           const float* queries, int32_t dim, int mode, SelectWorkspace& ws, hipStream_t s, float pre_scale = 1.0f,
-                          const uint32_t* run_if = nullptr);
+                          const uint32_t* run_if = nullptr, uint32_t* zero_words = nullptr, int n_zero = 0);
 int launch_group_chunk_max(const float* hit_scores, const int32_t* hit_rows, int32_t n_queries,
                            int32_t num_hits, const int64_t* chunk_offsets, int64_t n_chunks, int32_t k,
                            float* out_scores, int32_t* out_chunks, int32_t* out_counts, hipStream_t s);
+// The metric transform of raw dots applied on the way into the merge (n_lists == 1): record j of query q is transform_score(in_scores, mode,
+// row_norm[q * k_in + j], .., |queries[q]|) -- the statements of transform_kernel (same bits), without its launch.
+struct MergeTransform {
+    const float* row_norm = nullptr;  // [n_queries x k_in] (cosine), else unused
+    const float* queries = nullptr;   // [n_queries x dim]; nullptr = no transform
+    int dim = 0, mode = 0;
+};
 int launch_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_lists, int32_t n_queries,
                       int32_t k_in, int32_t k, float* out_scores, int32_t* out_ids, hipStream_t s,
-                      const uint32_t* counts = nullptr);  // counts (n_lists == 1): records list q really holds
+                      const uint32_t* counts = nullptr,  // counts (n_lists == 1): records list q really holds
+                      const MergeTransform* transform = nullptr);
 
 // select.hip, rank cut (order-first-then-filter, src/raglite/_search.py:120-141): rows outside the rank_limit best of their
 // query, and rows whose keep bit is clear, become -inf
@@ -189,9 +198,17 @@ int launch_rank_cut(float* scores, int32_t n_queries, int64_t n, int64_t ld, int
 int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const float* queries, int32_t dim, int mode, float m_rel,
                             float e_norm_bound, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s);  // also zeroes cnt[0..nb) and *flag
 // top_s / top_i [nb x k] (optional): the approximate top-k in selection order -- only entries ranking BELOW its k-th one are collected
-int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld, const float* thr, const float* row_norm, int32_t cap,
+// self != nullptr: every workgroup computes thr[b] itself from the approximate top-k (launch_approx_threshold's statements, without its launch;
+// cnt / flag must be zero already); thr[] is then an output
+struct SelfThreshold {
+    const float* topk = nullptr;     // [nb x k] approximate top-k scores, descending; nullptr = read thr[]
+    const float* queries = nullptr;  // [nb x dim]
+    int k = 0, dim = 0, mode = 0;
+    float m_rel = 0.f, e_norm_bound = 0.f;
+};
+int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld, float* thr, const float* row_norm, int32_t cap,
                          int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* top_s = nullptr,
-                         const int32_t* top_i = nullptr, int32_t k = 0);
+                         const int32_t* top_i = nullptr, int32_t k = 0, const SelfThreshold* self = nullptr);
 // thr[b] = min_j exact[b][j] - m[b] (the k-th best EXACT score of the approximate top-k bounds the k-th best overall from below);
 // ids[b][0 .. k) = top_i[b], es[b][0 .. k) = exact[b], cnt[b] = k; unusable -> *flag, thr = +inf, cnt = 0.  See exact_threshold_kernel.
 int launch_exact_threshold(const float* exact, const int32_t* top_i, int32_t n_queries, int32_t k, const float* m, int32_t cap, float* thr,
@@ -237,8 +254,10 @@ int launch_rescore_l2(const void* E, bool f16, int32_t dim, const float* Q, cons
                       int32_t k, int64_t n_items, float* out, hipStream_t s);
 int launch_permute_rows(const int32_t* rows_in, const int32_t* pos, int32_t k, int64_t n_items, int32_t* rows_out,
                         hipStream_t s);
+// counts / cap (optional): rows[] is nq lists of cap slots of which list q holds min(counts[q], cap) -- the other slots are skipped (their
+// output rows keep whatever they held)
 int launch_gather_rows(const void* E, bool f16, int32_t dim, int64_t n_rows, const int32_t* rows, int64_t n, float* out,
-                       hipStream_t s);
+                       hipStream_t s, const uint32_t* counts = nullptr, int32_t cap = 0);
 int launch_compact_rows(const void* src, int64_t row_bytes, const int64_t* old_row, int64_t n, void* dst, hipStream_t s);
 
 // partition_sim.hip: semantic-chunking similarities (src/raglite/_split_chunks.py:54-72), batched over documents

@@ -264,6 +264,12 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
     }
     // workgroups per query: enough to fill the chip when there are few queries, at most one wave per candidate
     int per_query = (int)std::max<int64_t>(1, std::min<int64_t>((n_items_per_query + 7) / 8, std::max<int64_t>(1, 512 / n_queries)));
+#ifdef RAGLITE_EXPERIMENTS  // A/B of the split of a query's list over workgroups (scripts/gpu_calls/)
+    if (const char* e = exp_env("RAGLITE_PAIRS_WG_BUDGET")) {
+        const int budget = std::atoi(e);
+        if (budget > 0) per_query = (int)std::max<int64_t>(1, std::min<int64_t>((n_items_per_query + 7) / 8, std::max<int64_t>(1, budget / n_queries)));
+    }
+#endif
 #define RL_PAIRS(FULL_, KB_)                                                                                                               \
     do {                                                                                                                                   \
         if (rows16)                                                                                                                        \

@@ -216,7 +216,10 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     }
     const int32_t org = r_lo & ~15;  // tiles start on a 16-row block of the image
     const int nt = ROWS ? nt_rows : (r_hi - org + PP_RT - 1) / PP_RT;
-    const int qt = ROWS ? (int)blockIdx.y : 0;  // query tile
+    // query tile: MODE 2 -- 16 groups of 32 queries; MODE 0 -- the launch's passes (16 queries each) as grid rows: ONE launch for a batch's
+    // passes instead of one per pass, so a pass's workgroups start on the CUs the previous pass's leave instead of behind a launch boundary
+    const int qt = (int)blockIdx.y;
+    const int q_base = ROWS ? 0 : PP_QPP * qt;  // first query of this workgroup's pass
     constexpr int TAIL = STAG ? PP_NBLK : 0;    // slabs after the last tile's first block is done, for the blocks behind it
     const int total = nt * nslab + TAIL;        // K slabs this workgroup streams
     const int32_t last_blk = (int32_t)((n_rows + 15) >> 4) - 1;
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     auto lag_of = [](int a) { return STAG ? a : 0; };  // slabs by which block a's tiles start after block 0's
 
     // ---- this wave's queries: 2 wv and 2 wv + 1 ---------------------------------------------------------------------------------------
-    const bool has0 = 2 * wv < n_q, has1 = 2 * wv + 1 < n_q;  // wave-uniform
+    const bool has0 = q_base + 2 * wv < n_q, has1 = q_base + 2 * wv + 1 < n_q;  // wave-uniform
 
     // ---- feeder duty: waves 0-3 fetch query pieces 8 wv .. + 7 (piece = 2 * query + block of 16 vectors) of slab g + 4, then corpus
     // blocks 2 wv, 2 wv + 1 of slab g + 4, during slab g ------------------------------------------------------------------------
@@ -335,8 +338,8 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     int32_t ord_run = ROWS ? 0 : __builtin_amdgcn_readfirstlane(row_to_chunk[org]);
     const int e_q = fG >> 1;
     const bool e_has = !ROWS && (e_q == 0 ? has0 : has1) && (ft & 1) == 0;  // (lanes t and t ^ 1 hold the same sum)
-    const float e_unscale = e_has ? qmeta[2 * (2 * wv + e_q)] * inv_e_scale : 0.f;
-    float* const e_out = out + (int64_t)(e_has ? 2 * wv + e_q : 0) * out_stride;
+    const float e_unscale = e_has ? qmeta[2 * (q_base + 2 * wv + e_q)] * inv_e_scale : 0.f;
+    float* const e_out = out + (int64_t)(e_has ? q_base + 2 * wv + e_q : 0) * out_stride;
     const uint64_t odd_pairs = 0xccccccccccccccccull;  // lanes with t >= 2
     auto swap32 = [](float& x, float& y) __attribute__((always_inline)) {
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
@@ -754,19 +757,20 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     }
 }
 
-// n_q (1..16) queries `first .. first + n_q - 1` of a launch_query_planes buffer over `n_queries`, each nq (<= 32) vectors, against
+// n_q queries `first .. first + n_q - 1` of a launch_query_planes buffer over `n_queries`, each nq (<= 32) vectors, against
 // a one-plane image (fp16 hi halves, or an fp16-stored corpus): out[q * out_stride + chunk], one MFMA product per multiply.
+// Sixteen queries per pass over the image; n_q > 16: ceil(n_q / 16) passes in ONE launch (grid rows).
 int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first, int32_t n_q,
                      int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits, float* out,
                      int64_t out_stride, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if) {
-    if (nq < 1 || nq > 32 || n_q < 1 || n_q > PP_QPP || n_rows < 1 || first < 0 || first + n_q > n_queries) return RL_ERR_UNSUPPORTED;
+    if (nq < 1 || nq > 32 || n_q < 1 || n_q > PP_QPP * 4096 || n_rows < 1 || first < 0 || first + n_q > n_queries) return RL_ERR_UNSUPPORTED;
     // dim >= 256: a tile's epilogue stores must have left the VMEM counter's window before the next tile's (see certify())
     if (dim % 32 || dim < 256 || !(split_scale > 0.f) || !image || !ends_bits) return RL_ERR_UNSUPPORTED;
     const int32_t nslab = dim / 32;
     const char* qfrag = static_cast<const char*>(qbuf) + (size_t)first * nslab * 4096;
     const float* qmeta = reinterpret_cast<const float*>(static_cast<const char*>(qbuf) + (size_t)n_queries * dim * 128) + 2 * (size_t)first;
     const int64_t tiles = (n_rows + PP_RT - 1) / PP_RT;
-    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles))), blk(512);
+    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles)), (unsigned)((n_q + PP_QPP - 1) / PP_QPP)), blk(512);
     unsigned long long* const trace = nullptr;
 #define RL_PP_LAUNCH_S(DBG_, STAG_)                                                                                                     \
     hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 0, STAG_>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk, \

@@ -153,11 +153,13 @@ __global__ __launch_bounds__(256) void transform_hist_kernel(float* __restrict__
                                                               const float* __restrict__ row_sumsq,
                                                               const float* __restrict__ queries, int dim, int mode,
                                                               uint32_t* __restrict__ ws_hist, float pre_scale,
-                                                              const uint32_t* __restrict__ run_if) {
+                                                              const uint32_t* __restrict__ run_if, uint32_t* __restrict__ zero_words,
+                                                              int n_zero) {
     __shared__ uint32_t h[HIST_COPIES * HIST_COPY_STRIDE];
     __shared__ float part[4];
     if (run_if && *run_if == 0u) return;
     const int b = blockIdx.y;
+    if (blockIdx.x == 0 && b == 0 && (int)threadIdx.x < n_zero) zero_words[threadIdx.x] = 0u;
     typedef float f4 __attribute__((ext_vector_type(4)));
     float* const sb = scores + (int64_t)b * ld;
     const int64_t stride = (int64_t)gridDim.x * 256;
@@ -464,12 +466,13 @@ static int hist_grid(int64_t n, int32_t nq) {
 
 int launch_transform_hist(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm, const float* row_sumsq,
                           const float* queries, int32_t dim, int mode, SelectWorkspace& ws, hipStream_t s, float pre_scale,
-                          const uint32_t* run_if) {
+                          const uint32_t* run_if, uint32_t* zero_words, int n_zero) {
     if (n <= 0 || nb <= 0) return RL_OK;
+    if (n_zero < 0 || n_zero > 256 || (n_zero > 0 && !zero_words)) return RL_ERR_INVALID;
     RL_TRY(select_workspace_reserve(ws, nb, s));
     ws.dirty = true;  // the histogram rows stay non-zero until launch_topk(have_hist) has run its final kernel
     hipLaunchKernelGGL(transform_hist_kernel, dim3(hist_grid(n, nb), nb), dim3(256), 0, s, scores, n, ld, row_norm, row_sumsq,
-                       queries, (int)dim, mode, ws.hist, pre_scale, run_if);
+                       queries, (int)dim, mode, ws.hist, pre_scale, run_if, zero_words, n_zero);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -788,9 +791,25 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float* __restric
                                                            int32_t n_queries, int32_t k_in, int32_t k,
                                                            float* __restrict__ out_scores,
                                                            int32_t* __restrict__ out_ids,
-                                                           const uint32_t* __restrict__ counts) {
+                                                           const uint32_t* __restrict__ counts, MergeTransform tr) {
     __shared__ uint64_t buf[MERGE_CAP];
+    __shared__ float part[4];
     const int q = blockIdx.x;
+    float qss = 0.f, qn = 0.f;
+    if (tr.queries) {  // |q|^2 exactly as transform_kernel sums it: 256 lanes stride the query, wave sums, (p0 + p1) + (p2 + p3)
+        if (threadIdx.x < 256) {
+            float ss = 0.f;
+            for (int c = threadIdx.x; c < tr.dim; c += 256) {
+                const float v = tr.queries[(int64_t)q * tr.dim + c];
+                ss = fmaf(v, v, ss);
+            }
+            ss = wave_sum(ss);
+            if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+        }
+        __syncthreads();
+        qss = (part[0] + part[1]) + (part[2] + part[3]);
+        qn = sqrtf(qss);
+    }
     // counts (one list per query only): the list of query q holds min(counts[q], k_in) records, the rest of its k_in slots
     // was never written -- the sort then runs over the next power of two of THAT (the fused top-k's lists are a third full)
     const int total = counts ? (int)min(counts[q], (uint32_t)k_in) : n_lists * k_in;
@@ -802,7 +821,11 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float* __restric
             const int l = i / k_in, j = i % k_in;
             const int64_t src = ((int64_t)l * n_queries + q) * k_in + j;
             const int32_t id = in_ids[src];
-            if (id >= 0) key = make_key64(in_scores[src], (uint32_t)id);
+            if (id >= 0) {
+                float v = in_scores[src];
+                if (tr.queries) v = transform_score(v * 1.0f, tr.mode, tr.mode == SCAN_COSINE ? tr.row_norm[src] : 1.f, 0.f, qn, qss);
+                key = make_key64(v, (uint32_t)id);
+            }
         }
         buf[i] = key;
     }
@@ -885,12 +908,15 @@ int launch_raise_threshold(float* thr, const float* kth, int32_t nq, int32_t k, 
 }
 
 int launch_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_lists, int32_t nq, int32_t k_in,
-                      int32_t k, float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* counts) {
+                      int32_t k, float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* counts, const MergeTransform* transform) {
     if (nq <= 0 || k <= 0) return RL_OK;
+    if (transform && (n_lists != 1 || transform->mode == SCAN_L2 || (transform->mode == SCAN_COSINE && !transform->row_norm)))
+        return fail(RL_ERR_INVALID, "merge: the fused transform needs n_lists == 1 and cosine (with norms) or dot");
+    const MergeTransform tr = transform ? *transform : MergeTransform{};
     if ((int64_t)n_lists * k_in > MERGE_CAP) return fail(RL_ERR_UNSUPPORTED, "merge: n_lists * k_in must be <= 8192");
     if (counts && n_lists != 1) return fail(RL_ERR_INVALID, "merge: per-query counts need n_lists == 1");
     hipLaunchKernelGGL(merge_topk_kernel, dim3(nq), dim3(1024), 0, s, in_scores, in_ids, n_lists, nq, k_in, k,
-                       out_scores, out_ids, counts);
+                       out_scores, out_ids, counts, tr);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
