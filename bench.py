@@ -450,10 +450,13 @@ def main() -> None:
             f_ms = idx16.time_kernel(7, qv16, iters) / iters
             f_kernel, f_per, f_products = "rl::maxsim_pp_kernel<0, 0, false>", 16, 1.0
         except ValueError:  # (no image for the approximate pass: the eight-query kernel at two products, q_hi.e + q_lo.e)
-            qv8 = queries[0, :8].reshape(8 * NQ, DIM)
-            idx16.time_kernel(3, qv8, 3)
-            f_ms = idx16.time_kernel(3, qv8, iters) / iters
-            f_kernel, f_per, f_products = "rl::maxsim_gemm_kernel<2, false, 0, true>", 8, 2.0
+            try:
+                qv8 = queries[0, :8].reshape(8 * NQ, DIM)
+                idx16.time_kernel(3, qv8, 3)
+                f_ms = idx16.time_kernel(3, qv8, iters) / iters
+                f_kernel, f_per, f_products = "rl::maxsim_gemm_kernel<2, false, 0, true>", 8, 2.0
+            except ValueError:  # (--opt keep_image=0: an fp16-stored index has no image at all, its batches stream the stored rows)
+                f_ms, f_kernel, f_per, f_products = float("nan"), "none (no image: --opt keep_image=0)", 1, 0.0
         f_flops = f_products * 2.0 * f_per * NQ * rows_local * DIM
         # spot check: query 0 of the last batch against the fp32 NumPy oracle over the stored (fp16) values, first 50 k rows
         result["f16_stored"] = {

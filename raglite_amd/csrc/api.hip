@@ -1504,12 +1504,13 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     const int64_t nc = (int64_t)nb * cap, ldx = nc;
     // ---- scratch: approximate top-k scores (+ unused ids), thresholds, counters + flag, candidate rows, their norms, the
     // gathered rows, the exact score block and its diagonal -------------------------------------------------------------------------
-    const size_t words = (size_t)nb * k * 2 + 16 + 32 + (size_t)nc * 2 + (size_t)nc * dim + (size_t)nb * ldx + (size_t)nc;
+    const size_t words = (size_t)nb * k * 2 + 32 + 32 + (size_t)nc * 2 + (size_t)nc * dim + (size_t)nb * ldx + (size_t)nc;
     RL_TRY(idx->hibuf.reserve(words * 4));
     float* ts = idx->hibuf.as<float>();                        // [nb x k]
     int32_t* ti = reinterpret_cast<int32_t*>(ts + (size_t)nb * k);
     float* thr = reinterpret_cast<float*>(ti + (size_t)nb * k);  // [nb] (16 words)
-    uint32_t* cnt = reinterpret_cast<uint32_t*>(thr + 16);       // [nb] counters, then the flag at cnt[16]
+    float* mb = thr + 16;                                        // [nb] (16 words) the error bound of each query
+    uint32_t* cnt = reinterpret_cast<uint32_t*>(mb + 16);        // [nb] counters, then the flag at cnt[16]
     uint32_t* flag = cnt + 16;
     int32_t* ci = reinterpret_cast<int32_t*>(cnt + 32);        // [nb x cap]
     float* gn = reinterpret_cast<float*>(ci + nc);             // [nb x cap]
@@ -1517,19 +1518,11 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     float* xs = G + (size_t)nc * dim;                          // [nb x nb * cap]
     float* es = xs + (size_t)nb * ldx;                         // [nb x cap]
     float* sc = idx->scores.as<float>();
-    // ---- (1) approximate pass over the HI plane, its exact top-k -----------------------------------------------------------------------
+    // ---- (1) approximate pass over the HI plane ---------------------------------------------------------------------------------------------
     int st = launch_maxsim_stream16(idx->hiplane.as<uint16_t>(), n, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, sc, ld,
                                     idx->n_cu, s);
     if (st != RL_OK) return st;
-    if (d_row_bits) {  // tombstones / metadata filter: masked rows rank -inf, so they reach neither the top-k nor the candidates
-        RL_TRY(launch_transform(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, s, 1.0f / idx->hi_scale));
-        RL_TRY(launch_mask_scores(sc, nb, n, ld, d_row_bits, s));
-        RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s));
-    } else {  // (this launch also zeroes the candidate counters and the flag: cnt[0 .. 32))
-        RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f / idx->hi_scale, nullptr, cnt, 32));
-        RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s, nullptr, true));
-    }
-    // ---- (2) every row that could be in the exact top-k ------------------------------------------------------------------------------------
+    // ---- (2) its exact top-k, and every row that could be in the exact top-k of the full-precision scores ----------------------------------
     // The bound: what the HI halves drop is known exactly per row -- max |e_lo| / |e| (cosine) and max |e_lo| (dot) are kept by the
     // index (refresh_hi_image) -- plus 2^-12 |e| |q| for the query's own 2^-22 split and twice the worst case of a 1024-term fp32
     // sum (6e-5).  Without those maxima (no HI image on this index): the a-priori 2^-10 of the truncation, plus 2^-11.
@@ -1539,38 +1532,45 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
         if (mode == SCAN_COSINE) m_rel = idx->max_lo_ratio + 0x1p-12f;
         else { m_rel = 1.0f; e_bound = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm; }
     }
-    // Round 4 (cfg 2: thirteen launches of 4.6 - 9.9 us behind a 0.31 ms pass): the threshold is computed by the collecting workgroups
-    // themselves, the counters are zeroed by the histogram launch above, the gather skips the empty slots of the lists, and the metric
-    // transform of the re-scored candidates happens on the way into the final ranking -- three launches fewer, same statements, same bits.
-    if (d_row_bits) {
+    if (d_row_bits) {  // tombstones / metadata filter: masked rows rank -inf, so they reach neither the top-k nor the candidates
+        RL_TRY(launch_transform(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, s, 1.0f / idx->hi_scale));
+        RL_TRY(launch_mask_scores(sc, nb, n, ld, d_row_bits, s));
+        RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s));
         RL_TRY(launch_approx_threshold(ts, nb, k, d_q, dim, mode, m_rel, e_bound, thr, cnt, flag, s));
         RL_TRY(launch_collect_above(sc, nb, n, ld, thr, mode == SCAN_COSINE ? idx->norm : nullptr, cap, ci, gn, cnt, flag, s));
     } else {
-        SelfThreshold self;
-        self.topk = ts; self.queries = d_q; self.k = k; self.dim = dim; self.mode = mode; self.m_rel = m_rel; self.e_norm_bound = e_bound;
-        RL_TRY(launch_collect_above(sc, nb, n, ld, thr, mode == SCAN_COSINE ? idx->norm : nullptr, cap, ci, gn, cnt, flag, s, nullptr, nullptr, 0, &self));
+        // Round 4 (cfg 2: thirteen launches of 4.6 - 9.9 us behind a 0.31 ms pass; now eight): the transform + histogram launch also zeroes
+        // the candidate counters and the flag (cnt[0 .. 32)) and leaves each query's bound m; the selection's filter keeps what lies less
+        // than 2 m below the threshold bin, and its final kernel -- which knows the k-th best -- lists every row within 2 m of it: no
+        // threshold kernel, no collecting pass over the scores.
+        HiBound bound;
+        bound.m_out = mb; bound.m_rel = m_rel; bound.e_norm_bound = e_bound;
+        RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f / idx->hi_scale, nullptr, cnt, 32, &bound));
+        HiEmit emit;
+        emit.m = mb; emit.cap = cap; emit.ids = ci; emit.norms = gn; emit.row_norm = mode == SCAN_COSINE ? idx->norm : nullptr;
+        emit.cnt = cnt; emit.flag = flag; emit.thr = thr;
+        RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s, nullptr, true, &emit));
     }
     idx->filt = {RL_FILTER_ROWS_HI, nb, cap, cnt, flag};
     // ---- (3) exact scores of the candidates, by the kernels of the full pass (slots past a list's length are neither gathered nor
-    // ranked: the pass multiplies whatever their rows of G hold) ---------------------------------------------------------------------
+    // ranked: the pass multiplies whatever their rows of G hold) -- and (4), the guarded full-precision pass over the corpus, as the
+    // second grid row of the SAME launch: it returns at once unless a list overflowed / a bound was unusable ---------------------------------
     RL_TRY(launch_gather_rows(idx->E, false, dim, n, ci, nc, G, s, cnt, cap));
-    st = launch_maxsim_stream(G, nc, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, xs, ldx, idx->n_cu, s, idx->split_scale);
+    StreamSecondJob full;
+    full.D = idx->E; full.n_rows = n; full.out = sc; full.ld = ld; full.run_if = flag;
+    st = launch_maxsim_stream_two(G, nc, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, xs, ldx, idx->n_cu, s, idx->split_scale, full);
     if (st != RL_OK) return st;
     if (nb > 1) RL_TRY(launch_diag_blocks(xs, ldx, cap, nc, es, s));  // (one query: the block IS its diagonal)
-    MergeTransform tr;
+    MergeTransform tr;  // (the metric transform of the re-scored candidates happens on the way into the ranking: transform_kernel's statements)
     tr.row_norm = gn; tr.queries = d_q; tr.dim = dim; tr.mode = mode;
     RL_TRY(launch_merge_topk(nb > 1 ? es : xs, ci, 1, nb, cap, k, d_scores, d_rows, s, cnt, &tr));
-    // ---- (4) guarded full-precision pass ------------------------------------------------------------------------------------------
-    st = launch_maxsim_stream(idx->E, n, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, sc, ld, idx->n_cu, s, idx->split_scale,
-                              flag);
-    if (st != RL_OK) return st;
+    // ---- (4b) ... and its selection -------------------------------------------------------------------------------------------------------
     if (d_row_bits) {  // (the mask needs no guard: applied to scores nobody reads it changes nothing)
         RL_TRY(launch_transform(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, s, 1.0f, flag));
         RL_TRY(launch_mask_scores(sc, nb, n, ld, d_row_bits, s));
         RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, d_scores, d_rows, s, flag));
-    } else {
-        RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f, flag));
-        RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, d_scores, d_rows, s, flag, true));
+    } else {  // transform + exact top-k in ONE guarded launch (a block per query: slow, and run once in a blue moon)
+        RL_TRY(launch_guarded_select(sc, nb, n, ld, k, idx->norm, idx->sumsq, d_q, dim, mode, 1.0f, d_scores, d_rows, flag, s));
     }
     return RL_OK;
 }

@@ -154,16 +154,37 @@ int select_workspace_reserve(SelectWorkspace& ws, int32_t n_queries, hipStream_t
 void select_workspace_free(SelectWorkspace& ws);
 // run_if != nullptr: the three kernels return at once unless *run_if != 0 (the guarded dense fallback of the fused top-k).
 // have_hist: the histogram of `scores` is already in ws.hist (launch_transform_hist) -- skip that pass.
+// emit (the half-bytes row search, api.hip: search_rows_hi): the selection also lists every row whose score is within 2 m[q] of the k-th best
+// -- the candidates of the exact re-scoring -- without another pass over the scores (topk_filter_kernel / topk_final_body have the argument)
+struct HiEmit {
+    const float* m = nullptr;         // [n_queries] error bound per query (launch_transform_hist: HiBound)
+    int32_t cap = 0;                  // slots per candidate list
+    int32_t* ids = nullptr;           // [n_queries x cap] rows; nullptr = no emission
+    float* norms = nullptr;           // [n_queries x cap] their norms (with row_norm)
+    const float* row_norm = nullptr;  // [n] (cosine) or nullptr
+    uint32_t* cnt = nullptr;          // [n_queries], zero on entry
+    uint32_t* flag = nullptr;         // set on overflow / unusable threshold
+    float* thr = nullptr;             // [n_queries] (optional) the thresholds, for diagnostics
+};
 int launch_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32_t k,
                 SelectWorkspace& ws, float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* run_if = nullptr,
-                bool have_hist = false);
+                bool have_hist = false, const HiEmit* emit = nullptr);
+// Transform + exact top-k of raw dots in ONE guarded launch, one block per query (slow: the fallback of the half-bytes row search)
+int launch_guarded_select(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t k, const float* row_norm, const float* row_sumsq,
+                          const float* queries, int32_t dim, int mode, float pre_scale, float* out_scores, int32_t* out_ids,
+                          const uint32_t* run_if, hipStream_t s);
 // launch_transform (scan.hip) + the selection's histogram pass in ONE launch: raw dots -> similarities in place, and their
 // 2048-bin key histogram into ws.hist (same statements as transform_kernel: same bits).  Follow with launch_topk(have_hist).
 // pre_scale: the raw dots are multiplied by it first (a power of two: exact; 1 = the plain transform); run_if as in launch_topk.
 // zero_words / n_zero (<= 256): words this launch also sets to zero (the candidate counters + flag of a B <= 16 row search: no memset launch).
+// bound: m_out[b] = the half-bytes search's error bound of query b -- cosine: m_rel; dot: m_rel * e_norm_bound * |q_b| + 2^-22
+struct HiBound {
+    float* m_out = nullptr;
+    float m_rel = 0.f, e_norm_bound = 0.f;
+};
 int launch_transform_hist(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm, const float* row_sumsq,
                           const float* queries, int32_t dim, int mode, SelectWorkspace& ws, hipStream_t s, float pre_scale = 1.0f,
-                          const uint32_t* run_if = nullptr, uint32_t* zero_words = nullptr, int n_zero = 0);
+                          const uint32_t* run_if = nullptr, uint32_t* zero_words = nullptr, int n_zero = 0, const HiBound* bound = nullptr);
 int launch_group_chunk_max(const float* hit_scores, const int32_t* hit_rows, int32_t n_queries,
                            int32_t num_hits, const int64_t* chunk_offsets, int64_t n_chunks, int32_t k,
                            float* out_scores, int32_t* out_chunks, int32_t* out_counts, hipStream_t s);
@@ -198,17 +219,9 @@ int launch_rank_cut(float* scores, int32_t n_queries, int64_t n, int64_t ld, int
 int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const float* queries, int32_t dim, int mode, float m_rel,
                             float e_norm_bound, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s);  // also zeroes cnt[0..nb) and *flag
 // top_s / top_i [nb x k] (optional): the approximate top-k in selection order -- only entries ranking BELOW its k-th one are collected
-// self != nullptr: every workgroup computes thr[b] itself from the approximate top-k (launch_approx_threshold's statements, without its launch;
-// cnt / flag must be zero already); thr[] is then an output
-struct SelfThreshold {
-    const float* topk = nullptr;     // [nb x k] approximate top-k scores, descending; nullptr = read thr[]
-    const float* queries = nullptr;  // [nb x dim]
-    int k = 0, dim = 0, mode = 0;
-    float m_rel = 0.f, e_norm_bound = 0.f;
-};
-int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld, float* thr, const float* row_norm, int32_t cap,
+int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld, const float* thr, const float* row_norm, int32_t cap,
                          int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* top_s = nullptr,
-                         const int32_t* top_i = nullptr, int32_t k = 0, const SelfThreshold* self = nullptr);
+                         const int32_t* top_i = nullptr, int32_t k = 0);
 // thr[b] = min_j exact[b][j] - m[b] (the k-th best EXACT score of the approximate top-k bounds the k-th best overall from below);
 // ids[b][0 .. k) = top_i[b], es[b][0 .. k) = exact[b], cnt[b] = k; unusable -> *flag, thr = +inf, cnt = 0.  See exact_threshold_kernel.
 int launch_exact_threshold(const float* exact, const int32_t* top_i, int32_t n_queries, int32_t k, const float* m, int32_t cap, float* thr,
@@ -276,6 +289,16 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
                          const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
                          float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale = 0.f,
                          const uint32_t* run_if = nullptr);  // run_if: the kernel returns at once unless *run_if != 0
+struct StreamSecondJob {  // launch_maxsim_stream_two: what grid row 1 runs
+    const float* D = nullptr;
+    int64_t n_rows = 0;
+    float* out = nullptr;
+    int64_t ld = 0;
+    const uint32_t* run_if = nullptr;  // the row returns at once unless *run_if != 0 (nullptr: always runs)
+};
+int launch_maxsim_stream_two(const float* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq, const int32_t* row_to_chunk,
+                             const int64_t* chunk_offsets, int64_t n_chunks, float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale,
+                             const StreamSecondJob& job2);
 int launch_maxsim_stream_batch(const void* D, bool f16, int64_t n_rows, int32_t dim, const float* Q, int32_t nq, int64_t q_stride,
                                int32_t n_queries, const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, float* out,
                                int64_t out_stride, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if = nullptr);

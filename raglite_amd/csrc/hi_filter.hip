@@ -52,42 +52,15 @@ __global__ __launch_bounds__(256) void approx_threshold_kernel(const float* __re
 // top_s / top_i != nullptr (the second, tighter threshold of a MaxSim batch, api.hip: hi_batch_rescore): [nb x k] the approximate top-k
 // in selection order (score desc, id asc) -- its members are already in the list (positions 0 .. k - 1, cnt[b] starts at k) and are NOT
 // collected again: an entry is taken only if it ranks BELOW the k-th one, (key, id) < (key_k, id_k) in the selection's own order.
-__global__ __launch_bounds__(256) void collect_above_kernel(const float* __restrict__ scores, int64_t n, int64_t ld, float* __restrict__ thr,
+__global__ __launch_bounds__(256) void collect_above_kernel(const float* __restrict__ scores, int64_t n, int64_t ld, const float* __restrict__ thr,
                                                              const float* __restrict__ row_norm, int32_t cap, int32_t* __restrict__ ids,
                                                              float* __restrict__ norms, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag,
-                                                             const float* __restrict__ top_s, const int32_t* __restrict__ top_i, int32_t k,
-                                                             SelfThreshold st) {
+                                                             const float* __restrict__ top_s, const int32_t* __restrict__ top_i, int32_t k) {
     constexpr uint32_t LOCAL = 1024;
     __shared__ int32_t l_ids[LOCAL];
     __shared__ uint32_t l_n, l_base;
-    __shared__ float l_part[4];
     const int b = blockIdx.y;
-    float t;
-    if (st.topk) {
-        // st.topk != nullptr (B <= 16 row searches): every workgroup derives its query's threshold itself -- the statements of
-        // approx_threshold_kernel, whose launch this saves (4.8 us of a 0.39 ms single-query search); cnt / flag were zeroed by an earlier
-        // kernel of the call (launch_transform_hist: zero_words)
-        float qn = 0.f;
-        if (st.mode != SCAN_COSINE) {
-            float ss = 0.f;
-            for (int c = threadIdx.x; c < st.dim; c += 256) {
-                const float v = st.queries[(int64_t)b * st.dim + c];
-                ss = fmaf(v, v, ss);
-            }
-            ss = wave_sum(ss);
-            if ((threadIdx.x & 63) == 0) l_part[threadIdx.x >> 6] = ss;
-            __syncthreads();
-            qn = sqrtf((l_part[0] + l_part[1]) + (l_part[2] + l_part[3]));
-        }
-        const float m = st.mode == SCAN_COSINE ? st.m_rel : st.m_rel * st.e_norm_bound * qn + 0x1p-22f;
-        t = st.topk[(int64_t)b * st.k + (st.k - 1)] - 2.0f * m;
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
-            thr[b] = t;
-            if (!(t > -INFINITY)) atomicOr(flag, 1u);  // NaN or -inf: the guarded full-precision pass answers
-        }
-    } else {
-        t = thr[b];
-    }
+    const float t = thr[b];
     const float* s = scores + (int64_t)b * ld;
     const bool below_top = top_s != nullptr;
     const uint32_t key_k = below_top ? score_key(top_s[(int64_t)b * k + (k - 1)]) : 0u;
@@ -470,14 +443,13 @@ int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const floa
     return RL_OK;
 }
 
-int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld, float* thr, const float* row_norm, int32_t cap,
+int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld, const float* thr, const float* row_norm, int32_t cap,
                          int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* top_s, const int32_t* top_i,
-                         int32_t k, const SelfThreshold* self) {
+                         int32_t k) {
     if (n <= 0 || nb <= 0) return RL_OK;
-    const SelfThreshold st = self ? *self : SelfThreshold{};
     if ((top_s != nullptr) != (top_i != nullptr) || (top_s && k < 1)) return RL_ERR_INVALID;
     const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((n + 4095) / 4096, 512));
-    hipLaunchKernelGGL(collect_above_kernel, dim3(bx, nb), dim3(256), 0, s, scores, n, ld, thr, row_norm, cap, ids, norms, cnt, flag, top_s, top_i, k, st);
+    hipLaunchKernelGGL(collect_above_kernel, dim3(bx, nb), dim3(256), 0, s, scores, n, ld, thr, row_norm, cap, ids, norms, cnt, flag, top_s, top_i, k);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -96,8 +96,18 @@ __global__ __launch_bounds__(512, 2) void maxsim_stream_kernel(const float* __re
                                                                  const int64_t* __restrict__ chunk_offsets,
                                                                  int64_t n_chunks, float* __restrict__ out,
                                                                  int64_t ld, unsigned long long* trace, float e_scale,
-                                                                 int64_t q_batch_stride, int64_t out_batch_stride) {
+                                                                 int64_t q_batch_stride, int64_t out_batch_stride, StreamSecondJob j2) {
     static_assert(!(F16 && SPLIT), "SPLIT is a way to multiply an fp32-stored corpus");
+    // j2.D != nullptr: TWO jobs in one launch -- grid row 1 runs the same queries over another matrix into another output, behind its own
+    // run-if flag (the guarded full-precision pass of the half-bytes row search rides on the launch that re-scores its candidates: a guarded
+    // launch that returns at once still costs 4.6 us of a 0.37 ms single-query search)
+    if (j2.D && blockIdx.y == 1) {
+        D = j2.D;
+        n_rows = j2.n_rows;
+        out = j2.out;
+        ld = j2.ld;
+        trace = reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(j2.run_if));
+    }
     // gridDim.y > 1: ONE launch for a batch of queries (the guarded full-precision fallback of a MaxSim batch over an index that keeps no
     // pre-split image): grid row y scores query y -- its own vectors, its own output row
     Q += (int64_t)blockIdx.y * q_batch_stride;
@@ -997,13 +1007,14 @@ struct StreamArgs {
     const float* D; int64_t n_rows; const float* Q; int nq; const int32_t* r2c; const int64_t* off; int64_t n_chunks;
     int mode; float* out; int64_t ld; dim3 grid; hipStream_t s; unsigned long long* trace; float e_scale;
     int64_t q_batch_stride = 0, out_batch_stride = 0;
+    StreamSecondJob j2 = {};
 };
 template <int KW, bool F16, bool SPLIT = false>
 void launch_kw(const StreamArgs& a) {
     const dim3 blk(512);
 #define RL_STREAM(NQT, MODE) hipLaunchKernelGGL((maxsim_stream_kernel<KW, NQT, MODE, false, 6, F16, SPLIT>), a.grid, blk, 0, a.s, a.D, \
                                                 a.n_rows, a.Q, a.nq, a.r2c, a.off, a.n_chunks, a.out, a.ld, a.trace, a.e_scale, a.q_batch_stride, \
-                                                a.out_batch_stride)
+                                                a.out_batch_stride, a.j2)
     if (a.mode == 0) { if (a.nq <= 16) RL_STREAM(1, 0); else RL_STREAM(2, 0); }
     else             { if (a.nq <= 16) RL_STREAM(1, 1); else RL_STREAM(2, 1); }
 #undef RL_STREAM
@@ -1015,12 +1026,14 @@ void launch_kw(const StreamArgs& a) {
 static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
                              const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
                              float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale = 0.f, const uint32_t* run_if = nullptr,
-                             int32_t n_batch = 1, int64_t q_batch_stride = 0, int64_t out_batch_stride = 0) {
+                             int32_t n_batch = 1, int64_t q_batch_stride = 0, int64_t out_batch_stride = 0, const StreamSecondJob* job2 = nullptr) {
     if (nq < 1 || nq > 32 || n_rows < 1 || n_batch < 1 || n_batch > 65535 || (n_batch > 1 && mode != 0)) return RL_ERR_UNSUPPORTED;
+    if (job2 && (n_batch != 1 || !job2->D || job2->n_rows < 1 || (reinterpret_cast<uintptr_t>(job2->D) & 15))) return RL_ERR_UNSUPPORTED;
     if (dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15)) return RL_ERR_UNSUPPORTED;
-    const int64_t tiles = (n_rows + TR - 1) / TR;
+    const int64_t tiles = (std::max<int64_t>(n_rows, job2 ? job2->n_rows : 0) + TR - 1) / TR;  // (workgroups without a tile of their job return)
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles));
+    if (job2) { n_batch = 2; q_batch_stride = out_batch_stride = 0; }  // grid row 1 = the second job (same queries)
 #ifdef RAGLITE_EXPERIMENTS  // the tile-timeline build of the kernel exists in experiment builds only
     static unsigned long long* trace = [] {
         unsigned long long* p = nullptr;
@@ -1030,7 +1043,7 @@ static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t d
     if (trace && !f16 && mode == 0 && nq > 16 && dim == 1024) {  // diagnostic build: dump the 30th launch's timeline to stderr
         static int calls = 0;
         hipLaunchKernelGGL((maxsim_stream_kernel<256, 2, 0, true>), dim3(grid), dim3(512), 0, s, D, n_rows, Q, nq,
-                           row_to_chunk, chunk_offsets, n_chunks, out, ld, trace, 1.f, (int64_t)0, (int64_t)0);
+                           row_to_chunk, chunk_offsets, n_chunks, out, ld, trace, 1.f, (int64_t)0, (int64_t)0, StreamSecondJob{});
         if (++calls == 30) {
             unsigned long long h[8 * 8 * 8];
             (void)hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost);
@@ -1053,7 +1066,8 @@ static int launch_stream_any(const float* D, bool f16, int64_t n_rows, int32_t d
     }
 #endif
     const StreamArgs a{D, n_rows, Q, (int)nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, dim3(grid, (unsigned)n_batch), s,
-                       reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(run_if)), split_scale, q_batch_stride, out_batch_stride};
+                       reinterpret_cast<unsigned long long*>(const_cast<uint32_t*>(run_if)), split_scale, q_batch_stride, out_batch_stride,
+                       job2 ? *job2 : StreamSecondJob{}};
     const bool split = !f16 && split_scale > 0.f;  // 0: the exact fp32 MFMA chain
 #define RL_DIMS(...) switch (dim) { \
         case 128: launch_kw<32, __VA_ARGS__>(a); break; case 256: launch_kw<64, __VA_ARGS__>(a); break; case 384: launch_kw<96, __VA_ARGS__>(a); break; \
@@ -1069,6 +1083,15 @@ int launch_maxsim_stream(const float* D, int64_t n_rows, int32_t dim, const floa
                          float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if) {
     return launch_stream_any(D, false, n_rows, dim, Q, nq, row_to_chunk, chunk_offsets, n_chunks, mode, out, ld, n_cu, s,
                              split_scale, run_if);
+}
+
+// launch_maxsim_stream with a SECOND job in the same launch (grid row 1): the same queries over job2's matrix into job2's output, behind
+// job2's run-if flag.  Mode 1 (row scores) only; fp32 rows.
+int launch_maxsim_stream_two(const float* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq, const int32_t* row_to_chunk,
+                             const int64_t* chunk_offsets, int64_t n_chunks, float* out, int64_t ld, int n_cu, hipStream_t s, float split_scale,
+                             const StreamSecondJob& job2) {
+    return launch_stream_any(D, false, n_rows, dim, Q, nq, row_to_chunk, chunk_offsets, n_chunks, 1, out, ld, n_cu, s, split_scale, nullptr, 1, 0,
+                             0, &job2);
 }
 
 // MaxSim chunk scores of a BATCH of queries in one launch (grid row y = query y: Q + y q_stride -> out + y out_stride), fp32 or fp16 rows;

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void transform_hist_kernel(float* __restrict__
                                                               const float* __restrict__ queries, int dim, int mode,
                                                               uint32_t* __restrict__ ws_hist, float pre_scale,
                                                               const uint32_t* __restrict__ run_if, uint32_t* __restrict__ zero_words,
-                                                              int n_zero) {
+                                                              int n_zero, HiBound hb) {
     __shared__ uint32_t h[HIST_COPIES * HIST_COPY_STRIDE];
     __shared__ float part[4];
     if (run_if && *run_if == 0u) return;
@@ -194,6 +194,10 @@ __global__ __launch_bounds__(256) void transform_hist_kernel(float* __restrict__
     __syncthreads();
     const float qss = (part[0] + part[1]) + (part[2] + part[3]);
     const float qn = sqrtf(qss);
+    // the error bound of the half-bytes search for this query (the statements of approx_threshold_kernel: same bits), for the filter and
+    // the final kernel of the selection that follows
+    if (hb.m_out && blockIdx.x == 0 && threadIdx.x == 0)
+        hb.m_out[b] = mode == SCAN_COSINE ? hb.m_rel : hb.m_rel * hb.e_norm_bound * qn + 0x1p-22f;
     auto one = [&](int64_t i) {  // scalar tail / unaligned layout
         const float o = transform_score(sb[i] * pre_scale, mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
         hist_add(h, o);
@@ -227,7 +231,8 @@ __global__ __launch_bounds__(256) void transform_hist_kernel(float* __restrict__
 __global__ __launch_bounds__(256) void topk_filter_kernel(const float* __restrict__ scores, int64_t n, int64_t ld,
                                                            int32_t k, uint32_t* __restrict__ ws_hist,
                                                            uint64_t* __restrict__ ws_sel,
-                                                           uint64_t* __restrict__ ws_cand, const uint32_t* __restrict__ run_if) {
+                                                           uint64_t* __restrict__ ws_cand, const uint32_t* __restrict__ run_if,
+                                                           const float* __restrict__ below_m) {
     __shared__ uint32_t h[HIST_BINS];
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t thr[2];
@@ -243,12 +248,16 @@ __global__ __launch_bounds__(256) void topk_filter_kernel(const float* __restric
     uint64_t* sel = ws_sel + (int64_t)q * K_MAX;
     uint64_t* cand = ws_cand + (int64_t)q * CAND_CAP;
     const int64_t stride = (int64_t)gridDim.x * 256;
+    // below_m != nullptr (the half-bytes row search, api.hip: search_rows_hi): scores less than 2 m below the threshold bin's lower edge
+    // are candidates too -- the final kernel then finds every score within 2 m of the k-th best among sel + cand (the k-th best lies IN the
+    // bin), and no separate pass over the scores has to collect them.  They rank below the whole bin: the selection itself is unchanged.
+    const float low = below_m ? key_score(bstar << 21) - 2.0002f * below_m[q] : INFINITY;
     auto visit = [&](float v, int64_t i) {
         const uint32_t bin = score_key(v) >> 21;
         if (bin > bstar) {
             const uint32_t p = atomicAdd(&g[CNT_SEL], 1u);
             if (p < (uint32_t)K_MAX) sel[p] = make_key64(v, (uint32_t)i);
-        } else if (bin == bstar) {
+        } else if (bin == bstar || v >= low) {
             const uint32_t p = atomicAdd(&g[CNT_CAND], 1u);
             if (p < (uint32_t)CAND_CAP) cand[p] = make_key64(v, (uint32_t)i);
         }
@@ -284,6 +293,71 @@ __device__ __forceinline__ void write_results(const uint64_t* sorted, int n_vali
     }
 }
 
+// The `need` best keys among the scores whose key falls into bin `bstar` (any number of them), by one block: two more radix passes over the
+// scores fix the exact 32-bit threshold, a third takes what lies above it and the ties on it in index order -- slow but exact.  Results
+// go to fin[n_sel .. n_sel + need).  h: HIST_BINS words of LDS, scratch >= 20, thr 2, sh_cnt 3.  Every thread of the block must call.
+__device__ __forceinline__ void refine_in_bin(const float* __restrict__ s, int64_t n, uint32_t bstar, uint32_t need, uint32_t n_sel,
+                                              uint64_t* fin, uint32_t* h, uint32_t* scratch, uint32_t* thr, uint32_t* sh_cnt) {
+    __syncthreads();
+    // pass A: bits [20:10] among keys in bin b*
+    for (int i = threadIdx.x; i < HIST_BINS; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t key = score_key(s[i]);
+        if ((key >> 21) == bstar) atomicAdd(&h[(key >> 10) & 2047u], 1u);
+    }
+    __syncthreads();
+    find_threshold_bin(h, HIST_BINS, need, scratch, thr);
+    const uint32_t b1 = thr[0];
+    const uint32_t need1 = need - thr[1];
+    __syncthreads();
+    // pass B: bits [9:0] among keys matching (b*, b1)
+    for (int i = threadIdx.x; i < HIST_BINS; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const uint32_t prefix22 = (bstar << 11) | b1;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t key = score_key(s[i]);
+        if ((key >> 10) == prefix22) atomicAdd(&h[key & 1023u], 1u);
+    }
+    __syncthreads();
+    find_threshold_bin(h, 1024, need1, scratch, thr);
+    const uint32_t t32 = (prefix22 << 10) | thr[0];
+    const uint32_t need_eq = need1 - thr[1];  // ties on the exact threshold value still to take
+    __syncthreads();
+    // pass C: keys in bin b* above t32 (any order) + the first `need_eq` keys == t32 by index.
+    if (threadIdx.x == 0) { sh_cnt[0] = 0; sh_cnt[1] = 0; }
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        uint32_t key = 0;
+        float v = 0.f;
+        if (i < n) { v = s[i]; key = score_key(v); }
+        const bool gt = (i < n) && ((key >> 21) == bstar) && (key > t32);
+        const bool eq = (i < n) && (key == t32);
+        if (gt) {
+            const uint32_t p = atomicAdd(&sh_cnt[0], 1u);
+            fin[n_sel + p] = make_key64(v, (uint32_t)i);
+        }
+        uint32_t tot;
+        const uint32_t incl = block_inclusive_scan(eq ? 1u : 0u, scratch, tot);
+        const uint32_t rank = sh_cnt[1] + incl - 1;  // 0-based rank of this tie in index order
+        __syncthreads();
+        if (eq && rank < need_eq) fin[n_sel + (need - need_eq) + rank] = make_key64(v, (uint32_t)i);
+        // The exit decision is taken by ONE thread and published in LDS: every thread reading the counters itself would
+        // race with a faster wave already counting the next iteration's `gt` hits (a non-uniform break leaves waves
+        // behind at the scan's barriers).
+        if (threadIdx.x == 0) {
+            sh_cnt[1] += tot;
+            sh_cnt[2] = (sh_cnt[1] >= need_eq && sh_cnt[0] >= need - need_eq) ? 1u : 0u;
+        }
+        __syncthreads();
+        const bool done = sh_cnt[2] != 0;
+        __syncthreads();  // nobody writes sh_cnt again before everybody has read the flag
+        if (done) break;
+    }
+    __syncthreads();
+}
+
 // LDS of the final step (56 KiB).
 struct FinalLds {
     uint64_t buf[CAND_CAP];   // 32 KiB: candidate sort, then reused as the result sort buffer
@@ -298,7 +372,7 @@ struct FinalLds {
 __device__ __forceinline__ void topk_final_body(const float* __restrict__ scores, int64_t n, int64_t ld, int32_t k,
                                                 uint32_t* __restrict__ ws_hist, const uint64_t* __restrict__ ws_sel,
                                                 const uint64_t* __restrict__ ws_cand, float* __restrict__ out_scores,
-                                                int32_t* __restrict__ out_ids, int q, FinalLds& L) {
+                                                int32_t* __restrict__ out_ids, int q, FinalLds& L, const HiEmit& em = HiEmit{}) {
     uint64_t* const buf = L.buf;
     uint64_t* const fin = L.fin;
     uint32_t* const h = L.h;
@@ -314,6 +388,31 @@ __device__ __forceinline__ void topk_final_body(const float* __restrict__ scores
     const uint32_t n_sel = g[CNT_SEL];
     const uint32_t n_cand = g[CNT_CAND];
     const uint32_t need = kk - n_sel;  // >= 1 whenever kk >= 1 (the threshold bin is never empty)
+    // em.ids != nullptr (the half-bytes row search): every score within 2 m of the k-th best is a candidate for exact re-scoring -- all of
+    // sel (above the k-th best) and the part of cand (threshold bin + the filter's margin below it) that reaches thr = (k-th best) - 2 m.
+    // Their rows go to em.ids[q * cap ..] (any order; with em.row_norm their norms next to them), em.cnt[q] = how many; more than cap,
+    // fewer than k rows, a candidate list the filter could not hold, or an unusable threshold: *em.flag (the guarded full pass answers).
+    const bool emit = em.ids != nullptr;
+    auto emit_key = [&](uint64_t key, float t) {
+        const uint32_t k32 = (uint32_t)(key >> 32);
+        if (key == 0ull || k32 == 0u || !(key_score(k32) >= t)) return;
+        const int32_t row = (int32_t)(0xffffffffu - (uint32_t)key);
+        const uint32_t p = atomicAdd(&em.cnt[q], 1u);
+        if (p < (uint32_t)em.cap) {
+            em.ids[(int64_t)q * em.cap + p] = row;
+            if (em.row_norm) em.norms[(int64_t)q * em.cap + p] = em.row_norm[row];
+        } else {
+            atomicOr(em.flag, 1u);
+        }
+    };
+    auto emit_threshold = [&](uint64_t kth_key) -> float {  // (every thread computes the same value)
+        const float t = key_score((uint32_t)(kth_key >> 32)) - 2.0f * em.m[q];
+        if (threadIdx.x == 0) {
+            if (em.thr) em.thr[q] = t;
+            if (!(t > -INFINITY) || kk < (uint32_t)k) atomicOr(em.flag, 1u);  // NaN / -inf, or fewer than k rows
+        }
+        return t;
+    };
     // This block is the last reader of the query's histogram row: keep the bins (the slow path wants them) and hand the row
     // back all zero, which is what the next selection's histogram pass expects (no memset launch per top-k).
     for (int i = threadIdx.x; i < HIST_BINS; i += blockDim.x) h[i] = g[i];
@@ -334,6 +433,12 @@ __device__ __forceinline__ void topk_final_body(const float* __restrict__ scores
             if (rank < need) fin[n_sel + rank] = mine;
         }
         __syncthreads();
+        if (emit) {  // fin[kk - 1] is the k-th best (the need-th of cand); buf still holds cand
+            const float t = emit_threshold(fin[kk - 1]);
+            if (threadIdx.x < n_cand) emit_key(buf[threadIdx.x], t);
+            for (int i = threadIdx.x; i < (int)n_sel; i += blockDim.x) emit_key(fin[i], t);
+            __syncthreads();
+        }
     } else if (n_cand <= (uint32_t)CAND_CAP) {
         int p2 = 64;
         while (p2 < (int)n_cand) p2 <<= 1;
@@ -342,69 +447,18 @@ __device__ __forceinline__ void topk_final_body(const float* __restrict__ scores
         bitonic_sort_desc(buf, p2);
         for (int i = threadIdx.x; i < (int)need; i += blockDim.x) fin[n_sel + i] = buf[i];
         __syncthreads();
+        if (emit) {
+            const float t = emit_threshold(buf[need - 1]);
+            for (int i = threadIdx.x; i < (int)n_cand; i += blockDim.x) emit_key(buf[i], t);
+            for (int i = threadIdx.x; i < (int)n_sel; i += blockDim.x) emit_key(fin[i], t);
+            __syncthreads();
+        }
     } else {
+        if (emit && threadIdx.x == 0) atomicOr(em.flag, 1u);  // (more candidates than the filter's list holds: no emission from it)
         // Slow exact path: refine the 32-bit threshold inside bin b*, then take ties in index order.
         // (Recompute b* from the histogram -- copied to LDS above -- exactly as the filter kernel did.)
         find_threshold_bin(h, HIST_BINS, kk, scratch, thr);
-        const uint32_t bstar = thr[0];
-        const float* s = scores + (int64_t)q * ld;
-        // pass A: bits [20:10] among keys in bin b*
-        for (int i = threadIdx.x; i < HIST_BINS; i += blockDim.x) h[i] = 0;
-        __syncthreads();
-        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint32_t key = score_key(s[i]);
-            if ((key >> 21) == bstar) atomicAdd(&h[(key >> 10) & 2047u], 1u);
-        }
-        __syncthreads();
-        find_threshold_bin(h, HIST_BINS, need, scratch, thr);
-        const uint32_t b1 = thr[0];
-        const uint32_t need1 = need - thr[1];
-        __syncthreads();
-        // pass B: bits [9:0] among keys matching (b*, b1)
-        for (int i = threadIdx.x; i < HIST_BINS; i += blockDim.x) h[i] = 0;
-        __syncthreads();
-        const uint32_t prefix22 = (bstar << 11) | b1;
-        for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint32_t key = score_key(s[i]);
-            if ((key >> 10) == prefix22) atomicAdd(&h[key & 1023u], 1u);
-        }
-        __syncthreads();
-        find_threshold_bin(h, 1024, need1, scratch, thr);
-        const uint32_t t32 = (prefix22 << 10) | thr[0];
-        const uint32_t need_eq = need1 - thr[1];  // ties on the exact threshold value still to take
-        __syncthreads();
-        // pass C: keys in bin b* above t32 (any order) + the first `need_eq` keys == t32 by index.
-        if (threadIdx.x == 0) { sh_cnt[0] = 0; sh_cnt[1] = 0; }
-        __syncthreads();
-        for (int64_t base = 0; base < n; base += blockDim.x) {
-            const int64_t i = base + threadIdx.x;
-            uint32_t key = 0;
-            float v = 0.f;
-            if (i < n) { v = s[i]; key = score_key(v); }
-            const bool gt = (i < n) && ((key >> 21) == bstar) && (key > t32);
-            const bool eq = (i < n) && (key == t32);
-            if (gt) {
-                const uint32_t p = atomicAdd(&sh_cnt[0], 1u);
-                fin[n_sel + p] = make_key64(v, (uint32_t)i);
-            }
-            uint32_t tot;
-            const uint32_t incl = block_inclusive_scan(eq ? 1u : 0u, scratch, tot);
-            const uint32_t rank = sh_cnt[1] + incl - 1;  // 0-based rank of this tie in index order
-            __syncthreads();
-            if (eq && rank < need_eq) fin[n_sel + (need - need_eq) + rank] = make_key64(v, (uint32_t)i);
-            // The exit decision is taken by ONE thread and published in LDS: every thread reading the counters itself would
-            // race with a faster wave already counting the next iteration's `gt` hits (a non-uniform break leaves waves
-            // behind at the scan's barriers).
-            if (threadIdx.x == 0) {
-                sh_cnt[1] += tot;
-                sh_cnt[2] = (sh_cnt[1] >= need_eq && sh_cnt[0] >= need - need_eq) ? 1u : 0u;
-            }
-            __syncthreads();
-            const bool done = sh_cnt[2] != 0;
-            __syncthreads();  // nobody writes sh_cnt again before everybody has read the flag
-            if (done) break;
-        }
-        __syncthreads();
+        refine_in_bin(scores + (int64_t)q * ld, n, thr[0], need, n_sel, fin, h, scratch, thr, sh_cnt);
     }
     // Order the kk survivors (all distinct keys) and write them out.
     if (kk <= (uint32_t)RANK_MAX) {
@@ -431,10 +485,79 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restric
                                                            const uint64_t* __restrict__ ws_sel,
                                                            const uint64_t* __restrict__ ws_cand,
                                                            float* __restrict__ out_scores,
-                                                           int32_t* __restrict__ out_ids, const uint32_t* __restrict__ run_if) {
+                                                           int32_t* __restrict__ out_ids, const uint32_t* __restrict__ run_if, HiEmit em) {
     __shared__ FinalLds L;
     if (run_if && *run_if == 0u) return;
-    topk_final_body(scores, n, ld, k, ws_hist, ws_sel, ws_cand, out_scores, out_ids, (int)blockIdx.x, L);
+    topk_final_body(scores, n, ld, k, ws_hist, ws_sel, ws_cand, out_scores, out_ids, (int)blockIdx.x, L, em);
+}
+
+// ---- the guarded fallback of the half-bytes row search in ONE launch -------------------------------------------------------------------
+// Raw dots -> similarities (in place; transform_kernel's statements) and their exact top-k, by ONE block per query: histogram of the key's
+// top 11 bits in LDS, the keys above the threshold bin, then refine_in_bin for the bin itself.  ~1 ms per query over 1 M scores -- it runs
+// only when *run_if != 0 (a candidate list overflowed, an unusable bound); the point is that the launch that usually returns at once is
+// ONE launch instead of three (transform + histogram, filter, final: 14 us of a 0.38 ms single-query search).
+__global__ __launch_bounds__(1024) void guarded_select_kernel(float* __restrict__ scores, int64_t n, int64_t ld, int32_t k,
+                                                               const float* __restrict__ row_norm, const float* __restrict__ row_sumsq,
+                                                               const float* __restrict__ queries, int dim, int mode, float pre_scale,
+                                                               float* __restrict__ out_scores, int32_t* __restrict__ out_ids,
+                                                               const uint32_t* __restrict__ run_if) {
+    __shared__ FinalLds L;
+    __shared__ float part[4];
+    if (run_if && *run_if == 0u) return;
+    const int q = blockIdx.x;
+    float* const sb = scores + (int64_t)q * ld;
+    if (threadIdx.x < 256) {
+        float ss = 0.f;
+        for (int c = threadIdx.x; c < dim; c += 256) {
+            const float v = queries[(int64_t)q * dim + c];
+            ss = fmaf(v, v, ss);
+        }
+        ss = wave_sum(ss);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    }
+    for (int i = threadIdx.x; i < HIST_BINS; i += blockDim.x) L.h[i] = 0u;
+    for (int i = threadIdx.x; i < K_MAX; i += blockDim.x) L.fin[i] = 0ull;
+    if (threadIdx.x == 0) L.sh_cnt[0] = 0u;
+    __syncthreads();
+    const float qss = (part[0] + part[1]) + (part[2] + part[3]);
+    const float qn = sqrtf(qss);
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        const float o = transform_score(sb[i] * pre_scale, mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
+        sb[i] = o;
+        atomicAdd(&L.h[score_key(o) >> 21], 1u);
+    }
+    __syncthreads();
+    const uint32_t kk = (uint32_t)std::min<int64_t>(k, n);
+    float* os = out_scores + (int64_t)q * k;
+    int32_t* oi = out_ids + (int64_t)q * k;
+    if (kk == 0) { write_results(L.fin, 0, k, os, oi); return; }
+    find_threshold_bin(L.h, HIST_BINS, kk, L.scratch, L.thr);
+    const uint32_t bstar = L.thr[0], n_sel = L.thr[1];
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {  // the keys above the threshold bin (fewer than kk), any order
+        const float v = sb[i];
+        if ((score_key(v) >> 21) > bstar) L.fin[atomicAdd(&L.sh_cnt[0], 1u)] = make_key64(v, (uint32_t)i);
+    }
+    __syncthreads();
+    refine_in_bin(sb, n, bstar, kk - n_sel, n_sel, L.fin, L.h, L.scratch, L.thr, L.sh_cnt);
+    int p2 = 64;
+    while (p2 < (int)kk) p2 <<= 1;
+    for (int i = threadIdx.x; i < p2; i += blockDim.x) L.buf[i] = (i < (int)kk) ? L.fin[i] : 0ull;
+    __syncthreads();
+    bitonic_sort_desc(L.buf, p2);
+    write_results(L.buf, (int)kk, k, os, oi);
+}
+
+int launch_guarded_select(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t k, const float* row_norm, const float* row_sumsq,
+                          const float* queries, int32_t dim, int mode, float pre_scale, float* out_scores, int32_t* out_ids,
+                          const uint32_t* run_if, hipStream_t s) {
+    if (nb <= 0 || k <= 0) return RL_OK;
+    if (k > K_MAX) return fail(RL_ERR_UNSUPPORTED, "top-k: k must be <= 2048");
+    if (n >= (int64_t)0x7fffffff) return fail(RL_ERR_UNSUPPORTED, "top-k: more than 2^31-2 elements per query");
+    hipLaunchKernelGGL(guarded_select_kernel, dim3(nb), dim3(1024), 0, s, scores, n, ld, k, row_norm, row_sumsq, queries, (int)dim, mode, pre_scale,
+                       out_scores, out_ids, run_if);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
 }
 
 int select_workspace_reserve(SelectWorkspace& ws, int32_t nq, hipStream_t s) {
@@ -466,20 +589,23 @@ static int hist_grid(int64_t n, int32_t nq) {
 
 int launch_transform_hist(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm, const float* row_sumsq,
                           const float* queries, int32_t dim, int mode, SelectWorkspace& ws, hipStream_t s, float pre_scale,
-                          const uint32_t* run_if, uint32_t* zero_words, int n_zero) {
+                          const uint32_t* run_if, uint32_t* zero_words, int n_zero, const HiBound* bound) {
     if (n <= 0 || nb <= 0) return RL_OK;
+    const HiBound hb = bound ? *bound : HiBound{};
     if (n_zero < 0 || n_zero > 256 || (n_zero > 0 && !zero_words)) return RL_ERR_INVALID;
     RL_TRY(select_workspace_reserve(ws, nb, s));
     ws.dirty = true;  // the histogram rows stay non-zero until launch_topk(have_hist) has run its final kernel
     hipLaunchKernelGGL(transform_hist_kernel, dim3(hist_grid(n, nb), nb), dim3(256), 0, s, scores, n, ld, row_norm, row_sumsq,
-                       queries, (int)dim, mode, ws.hist, pre_scale, run_if, zero_words, n_zero);
+                       queries, (int)dim, mode, ws.hist, pre_scale, run_if, zero_words, n_zero, hb);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
 
 int launch_topk(const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t k, SelectWorkspace& ws,
-                float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* run_if, bool have_hist) {
+                float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* run_if, bool have_hist, const HiEmit* emit) {
     if (nq <= 0 || k <= 0) return RL_OK;
+    if (emit && (!emit->m || !emit->ids || !emit->cnt || !emit->flag || emit->cap < 1 || (emit->row_norm && !emit->norms))) return RL_ERR_INVALID;
+    const HiEmit em = emit ? *emit : HiEmit{};
     if (k > K_MAX) return fail(RL_ERR_UNSUPPORTED, "top-k: k must be <= 2048");
     if (n >= (int64_t)0x7fffffff) return fail(RL_ERR_UNSUPPORTED, "top-k: more than 2^31-2 elements per query");
     if (have_hist) {
@@ -493,9 +619,9 @@ int launch_topk(const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t 
     if (n > 0) {
         const int bx = hist_grid(n, nq);
         if (!have_hist) hipLaunchKernelGGL(topk_hist_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, ws.hist, run_if);
-        hipLaunchKernelGGL(topk_filter_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, k, ws.hist, ws.sel, ws.cand, run_if);
+        hipLaunchKernelGGL(topk_filter_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, k, ws.hist, ws.sel, ws.cand, run_if, em.m);
     }
-    hipLaunchKernelGGL(topk_final_kernel, dim3(nq), dim3(1024), 0, s, scores, n, ld, k, ws.hist, ws.sel, ws.cand, out_scores, out_ids, run_if);
+    hipLaunchKernelGGL(topk_final_kernel, dim3(nq), dim3(1024), 0, s, scores, n, ld, k, ws.hist, ws.sel, ws.cand, out_scores, out_ids, run_if, em);
     RL_HIP(hipGetLastError());
     ws.dirty = false;  // every row this selection touched is zero again once the final kernel has run
     return RL_OK;
