@@ -397,14 +397,19 @@ __device__ __forceinline__ void topk_final_body(const float* __restrict__ scores
         const uint32_t k32 = (uint32_t)(key >> 32);
         if (key == 0ull || k32 == 0u || !(key_score(k32) >= t)) return;
         const int32_t row = (int32_t)(0xffffffffu - (uint32_t)key);
-        const uint32_t p = atomicAdd(&em.cnt[q], 1u);
+        const uint32_t p = atomicAdd(&sh_cnt[0], 1u);  // (this block is the only writer of the query's list: the counter lives in LDS)
         if (p < (uint32_t)em.cap) {
             em.ids[(int64_t)q * em.cap + p] = row;
             if (em.row_norm) em.norms[(int64_t)q * em.cap + p] = em.row_norm[row];
-        } else {
-            atomicOr(em.flag, 1u);
         }
     };
+    auto emit_done = [&]() {  // (after a barrier behind the last emit_key)
+        if (threadIdx.x == 0) {
+            em.cnt[q] = sh_cnt[0];
+            if (sh_cnt[0] > (uint32_t)em.cap) atomicOr(em.flag, 1u);
+        }
+    };
+    if (emit && threadIdx.x == 0) sh_cnt[0] = 0u;  // (ordered before the first emit_key by the barriers below)
     auto emit_threshold = [&](uint64_t kth_key) -> float {  // (every thread computes the same value)
         const float t = key_score((uint32_t)(kth_key >> 32)) - 2.0f * em.m[q];
         if (threadIdx.x == 0) {
@@ -438,6 +443,7 @@ __device__ __forceinline__ void topk_final_body(const float* __restrict__ scores
             if (threadIdx.x < n_cand) emit_key(buf[threadIdx.x], t);
             for (int i = threadIdx.x; i < (int)n_sel; i += blockDim.x) emit_key(fin[i], t);
             __syncthreads();
+            emit_done();
         }
     } else if (n_cand <= (uint32_t)CAND_CAP) {
         int p2 = 64;
@@ -452,6 +458,7 @@ __device__ __forceinline__ void topk_final_body(const float* __restrict__ scores
             for (int i = threadIdx.x; i < (int)n_cand; i += blockDim.x) emit_key(buf[i], t);
             for (int i = threadIdx.x; i < (int)n_sel; i += blockDim.x) emit_key(fin[i], t);
             __syncthreads();
+            emit_done();
         }
     } else {
         if (emit && threadIdx.x == 0) atomicOr(em.flag, 1u);  // (more candidates than the filter's list holds: no emission from it)

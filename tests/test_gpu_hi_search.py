@@ -156,3 +156,49 @@ def test_row_searches_on_adversarial_data_equal_the_full_passes(kind, B, metric)
         assert torch.equal(torch.sort(R, dim=1).values[~differ.any(dim=1)], torch.sort(R0, dim=1).values[~differ.any(dim=1)])
     print(f"[{kind} B={B} {metric}] candidates per query mean {st['candidates_per_query_mean']:.0f} max {st['candidates_per_query_max']}, fallback {st['fallback']}")
     idx.close()
+
+
+# ---- round 4: the unfiltered search lists its candidates from the selection's final kernel (select.hip: HiEmit), the filtered one still
+# collects them with a pass over the scores (hi_filter.hip: collect_above_kernel) -- the two must see the same candidates ----------------------
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+@pytest.mark.parametrize("B", [1, 5, 16])
+def test_candidates_listed_by_the_selection_equal_the_collected_ones(metric, B):
+    n, dim, k = 70_000, 1024, 100
+    E = oracle.synth_matrix(9960, n, dim)
+    Q = oracle.synth_matrix(9961 + B, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    S, R = idx.search_rows(Q, k)
+    st = idx.filter_stats()
+    everything = np.ones(n, bool)
+    Sf, Rf = idx.search_rows(Q, k, chunk_filter=everything)  # same rows eligible, through the collecting flow
+    stf = idx.filter_stats()
+    assert st["kind"] == stf["kind"] == "rows_hi" and not st["fallback"] and not stf["fallback"]
+    assert st["candidates_per_query_max"] == stf["candidates_per_query_max"]
+    assert abs(st["candidates_per_query_mean"] - stf["candidates_per_query_mean"]) < 1e-9
+    assert k <= st["candidates_per_query_max"] < 1024
+    assert np.array_equal(R, Rf) and _same(S, Sf)
+    with idx.options(hi_search=0):
+        S0, R0 = idx.search_rows(Q, k)
+    assert np.array_equal(R, R0) and _same(S, S0)
+    idx.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_one_launch_fallback_selection_on_massive_ties(metric):
+    """Every list overflows (3 000 copies of the best row per query) AND the scores tie massively: the guarded pass + the one-block
+    selection (select.hip: guarded_select_kernel -> refine_in_bin) must return what the three-launch selection of the full path returns."""
+    rng = np.random.default_rng(5)
+    n, dim, k = 70_000, 1024, 100
+    E = oracle.synth_matrix(9970, n, dim, "small_int")
+    Q = oracle.synth_matrix(9971, 3, dim, "small_int")
+    hot = rng.choice(n, 3000, replace=False)
+    E[hot] = (2.0 * np.sign(Q.sum(axis=0)))[None, :]
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    S, R = idx.search_rows(Q, k)
+    assert idx.filter_stats()["fallback"]
+    with idx.options(hi_search=0):
+        S0, R0 = idx.search_rows(Q, k)
+    assert np.array_equal(R, R0) and _same(S, S0)
+    ref_s, ref_r = oracle.search_rows(E, Q[0], k, metric, np.float64)
+    assert np.array_equal(R[0], ref_r)
+    idx.close()

@@ -291,3 +291,19 @@ def test_approx_scores_refuse_an_index_with_an_empty_chunk():
         ws, wc = oracle.maxsim_topk(Eh, off, Qh[b], 10, np.float32)
         assert np.array_equal(c[b].cpu().numpy(), wc) and np.array_equal(s[b].cpu().numpy(), ws)
     idx.close()
+
+
+def test_all_passes_in_one_launch_equal_one_launch_per_pass():
+    """Round 4: a batch's passes are grid rows of ONE launch.  40 queries (two and a half passes) against the same queries in groups of at
+    most sixteen: the same bits, chunk for chunk."""
+    torch = _torch()
+    n, dim, nq = 70_000, 1024, 32
+    rng = np.random.default_rng(77)
+    off = ragged_offsets(rng, n, 1, 15)
+    idx = raglite_amd.DeviceIndex(_corpus(torch, n, dim, seed=881), off, metric="dot")
+    Q = _queries(torch, 40, nq, dim, seed=882)
+    whole, bound = idx.maxsim_approx_scores(Q, kernel=0)
+    for lo, hi in ((0, 16), (16, 32), (32, 40), (3, 12)):
+        part, b = idx.maxsim_approx_scores(Q[lo:hi].contiguous(), kernel=0)
+        assert torch.equal(part, whole[lo:hi]) and torch.equal(b, bound[lo:hi])
+    idx.close()
