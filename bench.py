@@ -354,7 +354,7 @@ def main() -> None:
         "kernel_ms_per_pass": ms / passes_per_launch,
         "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes,
         # HIP events around the whole timed region / corpus passes in it: the kernel + its share of query split and selection
-        "timed_region_ms_per_pass": region_ms / (args.steps * qps) * per_launch,
+        "timed_region_ms_per_launch": region_ms / (args.steps * qps) * per_launch,
         "fp32_equivalent_tflops": fp32_equiv_flops / (ms * 1e-3) / 1e12,
         "fp32_equivalent_tflops_over_fp32_mfma_peak": fp32_equiv_flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
     })
