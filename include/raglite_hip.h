@@ -205,6 +205,8 @@ int rl_index_arithmetic(rl_index* index, int* in_effect);
  *   RL_OPT_KEEP_HI_PLANE        0 / 1 (1)          keep the row-major HI plane (2 B per element; what B <= 16 row searches rank on)
  *   RL_OPT_IMAGE_HEADROOM_MB    -1 | >= 0 (-1)     device memory the images must leave free (-1: max(2 GiB, 1/16 of the device))
  *   RL_OPT_ARITHMETIC           rl_arith (AUTO)    same as rl_index_set_arithmetic
+ *   RL_OPT_PAIRS_PACKED         0 / 1 (1)          exact re-scoring of (query, chunk) pairs packs the candidates' rows into shared 16-row MFMA
+ *                                                  tiles (0: every chunk its own tiles; same bits)
  *   RL_OPT_EXACT_KTH_THRESHOLD  0 / 1 (1)          MaxSim batches: second, tighter candidate threshold from the EXACT scores of the
  *                                                  approximate top-k (exact k-th - m instead of approximate k-th - 2 m)
  * KEEP_* and IMAGE_HEADROOM_MB rebuild / release the images at once (synchronous).  Unknown key or a value outside the column above:
@@ -214,7 +216,7 @@ typedef enum {
     RL_OPT_HI_SEARCH = 1, RL_OPT_HI_MAXSIM = 2, RL_OPT_HI_PRODUCTS = 3, RL_OPT_PP_PASS = 4, RL_OPT_FUSED_TOPK = 5, RL_OPT_FUSED_HI = 6,
     RL_OPT_FUSED_PP = 7, RL_OPT_FUSED_TOPK_CAP = 8, RL_OPT_FUSED_TOPK_STRIDE = 9, RL_OPT_GEMM_PASS = 10, RL_OPT_QUERY_PAIRS = 11,
     RL_OPT_PLANES_GEMM = 12, RL_OPT_KEEP_IMAGE = 13, RL_OPT_KEEP_HI = 14, RL_OPT_IMAGE_HEADROOM_MB = 15, RL_OPT_ARITHMETIC = 16,
-    RL_OPT_EXACT_KTH_THRESHOLD = 17, RL_OPT_FUSED_TWO_ROUNDS = 18, RL_OPT_KEEP_HI_PLANE = 19, RL_OPT_COUNT_ = 20
+    RL_OPT_EXACT_KTH_THRESHOLD = 17, RL_OPT_FUSED_TWO_ROUNDS = 18, RL_OPT_KEEP_HI_PLANE = 19, RL_OPT_PAIRS_PACKED = 20, RL_OPT_COUNT_ = 21
 } rl_option;
 int rl_set_default_option(int key, int64_t value);
 int rl_get_default_option(int key, int64_t* value);

@@ -200,7 +200,7 @@ struct Options {
         for (auto& x : v) x = 0;
         v[RL_OPT_HI_SEARCH] = v[RL_OPT_HI_MAXSIM] = v[RL_OPT_HI_PRODUCTS] = v[RL_OPT_PP_PASS] = v[RL_OPT_FUSED_TOPK] = v[RL_OPT_FUSED_HI] = 1;
         v[RL_OPT_FUSED_PP] = v[RL_OPT_GEMM_PASS] = v[RL_OPT_QUERY_PAIRS] = v[RL_OPT_PLANES_GEMM] = v[RL_OPT_KEEP_IMAGE] = v[RL_OPT_KEEP_HI] = 1;
-        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = 1;
+        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = 1;
         v[RL_OPT_IMAGE_HEADROOM_MB] = -1;
         v[RL_OPT_ARITHMETIC] = RL_ARITH_AUTO;
     }
@@ -212,7 +212,7 @@ bool option_value_ok(int key, int64_t value) {
     switch (key) {
         case RL_OPT_HI_SEARCH: case RL_OPT_HI_MAXSIM: case RL_OPT_PP_PASS: case RL_OPT_FUSED_TOPK: case RL_OPT_FUSED_HI: case RL_OPT_FUSED_PP:
         case RL_OPT_GEMM_PASS: case RL_OPT_QUERY_PAIRS: case RL_OPT_PLANES_GEMM: case RL_OPT_KEEP_IMAGE: case RL_OPT_KEEP_HI:
-        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE:
+        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED:
             return value == 0 || value == 1;
         case RL_OPT_HI_PRODUCTS: return value == 1 || value == 2;
         case RL_OPT_FUSED_TOPK_CAP: return value >= 0 && value <= MERGE_CAP;
@@ -2039,19 +2039,20 @@ int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_quer
     const float* rows = idx->E16 ? reinterpret_cast<const float*>(idx->E16) : idx->E;
     const bool rows16 = idx->E16 != nullptr;
     idx->filt = {RL_FILTER_MAXSIM_BATCH, n_gemm, hb.cap, hb.cnt, hb.flag};
+    const bool packed = idx->opt.on(RL_OPT_PAIRS_PACKED);
     if (hb.exact_kth && k <= hb.cap) {
         // Second threshold (hi_filter.hip: exact_threshold_kernel): the approximate top-k is scored exactly FIRST; the k-th best of those
         // exact scores bounds the k-th best overall from below, so a candidate needs approx >= that - m instead of (k-th approx) - 2 m: about
         // half as many chunks beyond the top-k to re-score.  The approximate top-k becomes the head of the list; the collection appends only
         // what ranks below it, and only those entries are scored by the second launch.
-        RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ti, k, n_gemm, hb.es_top, s, rows16));
+        RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ti, k, n_gemm, hb.es_top, s, rows16, 0, 0, packed));
         RL_TRY(launch_exact_threshold(hb.es_top, hb.ti, n_gemm, k, hb.m, hb.cap, hb.thr, hb.cnt, hb.ci, hb.es, hb.flag, s));
         RL_TRY(launch_collect_above(sc, n_gemm, idx->n_chunks, ld, hb.thr, nullptr, hb.cap, hb.ci, nullptr, hb.cnt, hb.flag, s, hb.ts, hb.ti, k));
         if (hb.cap > k)
-            RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap - k, n_gemm, hb.es, s, rows16, hb.cap, k));
+            RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap - k, n_gemm, hb.es, s, rows16, hb.cap, k, packed));
     } else {
         RL_TRY(launch_collect_above(sc, n_gemm, idx->n_chunks, ld, hb.thr, nullptr, hb.cap, hb.ci, nullptr, hb.cnt, hb.flag, s));
-        RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap, n_gemm, hb.es, s, rows16));
+        RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap, n_gemm, hb.es, s, rows16, 0, 0, packed));
     }
     RL_TRY(launch_merge_topk(hb.es, hb.ci, 1, n_gemm, hb.cap, k, d_s, d_c, s, hb.cnt));
     // list overflow / unusable bound: the full-precision passes, behind the flag -- ONE launch for all of them (gridDim.y = passes: sixteen
@@ -2332,7 +2333,8 @@ int rl_maxsim_rerank(rl_index* idx, const float* query_vecs, int32_t n_queries, 
     int st = idx->E16 ? launch_maxsim_cand16(idx->E16, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s)
                       : launch_maxsim_cand(idx->E, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s, idx->split_scale);
     if (st == RL_ERR_UNSUPPORTED && !idx->E16)  // other dims: the fp32-MFMA pairs kernel (dim % 16 == 0, <= 1024, nq <= 32) ...
-        st = launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, d_c, n_cand, n_queries, d_o, s);
+        st = launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, d_c, n_cand, n_queries, d_o, s, false, 0, 0,
+                                 idx->opt.on(RL_OPT_PAIRS_PACKED));
     if (st == RL_ERR_UNSUPPORTED && !idx->E16)  // ... and the VALU backstop for everything else
         st = launch_maxsim_generic(idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, d_c, n_cand,
                                    n_queries, d_o, s);

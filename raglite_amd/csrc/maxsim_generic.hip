@@ -239,9 +239,172 @@ __global__ __launch_bounds__(512) void maxsim_pairs_kernel(const float* __restri
     }
 }
 
+// maxsim_pairs_packed_kernel (round 4): the same scores, bit for bit, at about half the matrix work when the chunks are short.
+// maxsim_pairs_kernel gives every candidate chunk its own 16-row MFMA tiles: at 1-15 rows per chunk (the RAGLite shape) half of every tile
+// is padding, and the kernel is bound by the fp32 matrix pipe (512 v_mfma_f32_16x16x4_f32 per tile at dim 1024: 2 x 0.18 ms of every
+// 128-query step of the headline pipeline).  Here a wave PACKS the rows of its (up to 64) candidates back to back into tiles: slot m of a
+// tile is the next row of the current candidate, whichever that is -- a scalar walk over the candidates' row ranges (they sit in lanes:
+// v_readlane) hands every lane its row and leaves a 16-bit mask of the slots that end a candidate; the tile epilogue takes the maximum per
+// SEGMENT of slots (a candidate that straddles two tiles carries its column maxima over) and sums the 32 query vectors in the order of
+// maxsim_pairs_kernel.  Per (row, query vector) the k steps accumulate in the same order whatever slot the row sits in, the maximum is
+// exact, the sum tree is the same: identical bits (tests/test_gpu_pairs_packed.py).  dim % KB == 0 only (the other shapes keep the kernel above).
+template <int KB, bool ROW16>
+__global__ __launch_bounds__(512) void maxsim_pairs_packed_kernel(const float* __restrict__ D, int dim, const float* __restrict__ Q, int nq,
+                                                                   int64_t q_stride, const int64_t* __restrict__ offsets,
+                                                                   const int32_t* __restrict__ candidates, int64_t n_items, int64_t item_stride,
+                                                                   float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [32][dim + 8]
+    const int pitch = dim + 8;
+    const float* Qb = Q + (int64_t)blockIdx.y * q_stride;
+    const int32_t* cb = candidates + (int64_t)blockIdx.y * item_stride;
+    float* ob = out + (int64_t)blockIdx.y * item_stride;
+    for (int i = threadIdx.x * 4; i < 32 * dim; i += 512 * 4) {
+        const int n = i / dim, c = i - n * dim;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (n < nq) v = *reinterpret_cast<const f32x4*>(Qb + (int64_t)n * dim + c);
+        *reinterpret_cast<f32x4*>(qs + n * pitch + c) = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = wave_id();
+    const int m = lane & 15, g = lane >> 4;
+    const float* q0 = qs + m * pitch + 4 * g;
+    const float* q1 = qs + (16 + m) * pitch + 4 * g;
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    constexpr int NL = KB / 16;
+    auto request = [&](f32x4 (&x)[NL], int32_t row, int t0) __attribute__((always_inline)) {
+        if constexpr (ROW16) {
+            typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+            const _Float16* a = reinterpret_cast<const _Float16*>(D) + (int64_t)row * dim + 4 * g + t0;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const h16x4 h = *reinterpret_cast<const h16x4*>(a + 16 * j);
+                x[j] = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+            }
+        } else {
+            const float* a = D + (int64_t)row * dim + 4 * g + t0;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) x[j] = *reinterpret_cast<const f32x4*>(a + 16 * j);
+        }
+    };
+    f32x4 xc[NL], xn[NL];
+    for (int64_t base = (int64_t)blockIdx.x * 8 + w; base < n_items; base += 64 * stride) {
+        const int64_t mine = base + (int64_t)lane * stride;
+        int32_t vb = 0, ve = 0;  // (row numbers fit 31 bits: rl_index_create)
+        if (mine < n_items) {
+            const int64_t chunk = cb[mine];
+            if (chunk >= 0) { vb = (int32_t)offsets[chunk]; ve = (int32_t)offsets[chunk + 1]; }
+            if (ve <= vb) ob[mine] = -INFINITY;
+        }
+        const uint64_t todo = __builtin_amdgcn_ballot_w64(ve > vb);
+        if (todo == 0ull) continue;  // (wave-uniform)
+        int total = ve > vb ? ve - vb : 0;  // rows of all this wave's candidates
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+        const int R = __builtin_amdgcn_readfirstlane(total), n_tiles = (R + 15) >> 4;
+        // ---- the walk: candidate `cur` (a lane number), its next row, its end, the candidates still to come -- all scalar ----
+        int cur = __builtin_ctzll(todo);
+        uint64_t rest = todo & (todo - 1ull);
+        int32_t cur_row = __builtin_amdgcn_readlane(vb, cur), cur_end = __builtin_amdgcn_readlane(ve, cur);
+        // one tile: lane (m, g) gets the row of slot m (slots past the last row: the tile's first row, never read back), `cand` the lane
+        // number of the slot's candidate; returns the mask of the slots that END a candidate
+        auto next_tile = [&](int32_t& row, int& cand) __attribute__((always_inline)) -> uint32_t {
+            uint32_t ends = 0u;
+            row = cur_row;
+            cand = cur;
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) {
+                if (cur >= 0) {  // (scalar)
+                    if (m == sl) { row = cur_row; cand = cur; }
+                    if (++cur_row == cur_end) {
+                        ends |= 1u << sl;
+                        if (rest != 0ull) {
+                            cur = __builtin_ctzll(rest);
+                            rest &= rest - 1ull;
+                            cur_row = __builtin_amdgcn_readlane(vb, cur);
+                            cur_end = __builtin_amdgcn_readlane(ve, cur);
+                        } else {
+                            cur = -1;
+                        }
+                    }
+                }
+            }
+            return ends;
+        };
+        int32_t row_c, row_n = 0;
+        int cand_c, cand_n = 0;
+        uint32_t ends_c = next_tile(row_c, cand_c), ends_n = 0u;
+        int tile = 0, t0 = 0;
+        request(xc, row_c, 0);
+        f32x4 y0 = *reinterpret_cast<const f32x4*>(q0), y1 = *reinterpret_cast<const f32x4*>(q1);
+        float carry0 = -INFINITY, carry1 = -INFINITY;  // column maxima of the candidate left open by the previous tile
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        for (;;) {
+            const bool more_k = t0 + KB < dim, more_tiles = tile + 1 < n_tiles;  // (scalar)
+            if (!more_k && more_tiles) ends_n = next_tile(row_n, cand_n);
+            const int32_t n_row = (more_k || !more_tiles) ? row_c : row_n;
+            const int n_t0 = more_k ? t0 + KB : 0;
+            request(xn, n_row, n_t0);  // (after the last block of the batch: the current tile's first block again, unused)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int tn = j + 1 < NL ? t0 + 16 * (j + 1) : n_t0;
+                const f32x4 z0 = *reinterpret_cast<const f32x4*>(q0 + tn);
+                const f32x4 z1 = *reinterpret_cast<const f32x4*>(q1 + tn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j][u], y0[u], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j][u], y1[u], acc1, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                y0 = z0;
+                y1 = z1;
+            }
+            if (!more_k) {  // the tile is complete: this lane holds rows (slots) 4 g + i, i = 0..3, of column m
+                const int n_valid = R - 16 * tile < 16 ? R - 16 * tile : 16;
+                uint32_t em = ends_c;
+                int s_lo = 0;
+                while (s_lo < n_valid) {  // (scalar) one trip per candidate segment of the tile
+                    const bool closes = em != 0u;
+                    const int e = closes ? __builtin_ctz(em) : 15;  // (no end left: the candidate runs on into the next tile)
+                    float v0 = -INFINITY, v1 = -INFINITY;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (4 * g + i >= s_lo && 4 * g + i <= e) { v0 = fmaxf(v0, acc0[i]); v1 = fmaxf(v1, acc1[i]); }
+                    v0 = fmaxf(v0, __shfl_xor(v0, 16)); v0 = fmaxf(v0, __shfl_xor(v0, 32));
+                    v1 = fmaxf(v1, __shfl_xor(v1, 16)); v1 = fmaxf(v1, __shfl_xor(v1, 32));
+                    const float best0 = fmaxf(carry0, v0), best1 = fmaxf(carry1, v1);
+                    if (closes) {  // sum over the 32 query vectors: 16 columns per half by a 4-step butterfly, then the two halves
+                        float s0 = best0, s1 = best1;
+#pragma unroll
+                        for (int o = 1; o < 16; o <<= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+                        const int c = __builtin_amdgcn_readlane(cand_c, e);  // (lane e = slot e of row group 0)
+                        if (lane == 0) ob[base + (int64_t)c * stride] = s0 + s1;
+                        carry0 = carry1 = -INFINITY;
+                        em &= em - 1u;
+                    } else {
+                        carry0 = best0;
+                        carry1 = best1;
+                    }
+                    s_lo = e + 1;
+                }
+                acc0 = acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!more_tiles) break;
+                ++tile;
+                row_c = row_n;
+                cand_c = cand_n;
+                ends_c = ends_n;
+            }
+            t0 = n_t0;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) xc[j] = xn[j];
+        }
+    }
+}
+
 int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride, const int64_t* offsets,
                         const int32_t* candidates, int64_t n_items_per_query, int32_t n_queries, float* out, hipStream_t s, bool rows16,
-                        int64_t item_stride, int64_t first_item) {
+                        int64_t item_stride, int64_t first_item, bool packed) {
     if (n_items_per_query <= 0 || n_queries <= 0) return RL_OK;
     if (item_stride <= 0) item_stride = n_items_per_query;
     if (first_item < 0 || first_item + n_items_per_query > item_stride) return RL_ERR_INVALID;
@@ -253,6 +416,12 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in
 #define RL_PAIRS_ATTR(...) RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+#define RL_PACKED_ATTR(...) RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_packed_kernel<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))
+        RL_PACKED_ATTR(256, false);
+        RL_PACKED_ATTR(128, false);
+        RL_PACKED_ATTR(256, true);
+        RL_PACKED_ATTR(128, true);
+#undef RL_PACKED_ATTR
         RL_PAIRS_ATTR(true, 256, false);
         RL_PAIRS_ATTR(true, 128, false);
         RL_PAIRS_ATTR(false, 128, false);
@@ -263,7 +432,10 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
         attr_set = true;
     }
     // workgroups per query: enough to fill the chip when there are few queries, at most one wave per candidate
-    int per_query = (int)std::max<int64_t>(1, std::min<int64_t>((n_items_per_query + 7) / 8, std::max<int64_t>(1, 512 / n_queries)));
+    // (the packing kernel wants MANY candidates per wave -- its padding is one partial tile per wave and batch: one workgroup per CU and round)
+    const bool full = dim % 128 == 0;
+    packed = packed && full;
+    int per_query = (int)std::max<int64_t>(1, std::min<int64_t>((n_items_per_query + 7) / 8, std::max<int64_t>(1, (packed ? 256 : 512) / n_queries)));
 #ifdef RAGLITE_EXPERIMENTS  // A/B of the split of a query's list over workgroups (scripts/gpu_calls/)
     if (const char* e = exp_env("RAGLITE_PAIRS_WG_BUDGET")) {
         const int budget = std::atoi(e);
@@ -279,9 +451,21 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
             hipLaunchKernelGGL((maxsim_pairs_kernel<FULL_, KB_, false>), dim3(per_query, n_queries), dim3(512), lds, s, D, (int)dim, Q, (int)nq, \
                                q_stride, offsets, candidates, n_items_per_query, item_stride, out);                                        \
     } while (0)
-    if (dim % 256 == 0) RL_PAIRS(true, 256);
+#define RL_PACKED(KB_)                                                                                                                     \
+    do {                                                                                                                                   \
+        if (rows16)                                                                                                                        \
+            hipLaunchKernelGGL((maxsim_pairs_packed_kernel<KB_, true>), dim3(per_query, n_queries), dim3(512), lds, s, D, (int)dim, Q, (int)nq, \
+                               q_stride, offsets, candidates, n_items_per_query, item_stride, out);                                        \
+        else                                                                                                                               \
+            hipLaunchKernelGGL((maxsim_pairs_packed_kernel<KB_, false>), dim3(per_query, n_queries), dim3(512), lds, s, D, (int)dim, Q, (int)nq, \
+                               q_stride, offsets, candidates, n_items_per_query, item_stride, out);                                        \
+    } while (0)
+    if (packed && dim % 256 == 0) RL_PACKED(256);
+    else if (packed && dim % 128 == 0) RL_PACKED(128);
+    else if (dim % 256 == 0) RL_PAIRS(true, 256);
     else if (dim % 128 == 0) RL_PAIRS(true, 128);
     else RL_PAIRS(false, 128);
+#undef RL_PACKED
 #undef RL_PAIRS
     RL_HIP(hipGetLastError());
     return RL_OK;
