@@ -248,7 +248,9 @@ __global__ __launch_bounds__(512) void maxsim_pairs_kernel(const float* __restri
 // SEGMENT of slots (a candidate that straddles two tiles carries its column maxima over) and sums the 32 query vectors in the order of
 // maxsim_pairs_kernel.  Per (row, query vector) the k steps accumulate in the same order whatever slot the row sits in, the maximum is
 // exact, the sum tree is the same: identical bits (tests/test_gpu_pairs_packed.py).  dim % KB == 0 only (the other shapes keep the kernel above).
-template <int KB, bool ROW16>
+// DBG (experiment builds only, WRONG results): 1 = no MFMAs (the loads and the walk alone), 2 = the rows are loaded once per batch (the matrix
+// work and the walk alone), 4 = no query staging
+template <int KB, bool ROW16, int DBG = 0>
 __global__ __launch_bounds__(512) void maxsim_pairs_packed_kernel(const float* __restrict__ D, int dim, const float* __restrict__ Q, int nq,
                                                                    int64_t q_stride, const int64_t* __restrict__ offsets,
                                                                    const int32_t* __restrict__ candidates, int64_t n_items, int64_t item_stride,
@@ -258,13 +260,15 @@ __global__ __launch_bounds__(512) void maxsim_pairs_packed_kernel(const float* _
     const float* Qb = Q + (int64_t)blockIdx.y * q_stride;
     const int32_t* cb = candidates + (int64_t)blockIdx.y * item_stride;
     float* ob = out + (int64_t)blockIdx.y * item_stride;
-    for (int i = threadIdx.x * 4; i < 32 * dim; i += 512 * 4) {
+    if constexpr ((DBG & 16) != 0) return;  // (timing: the launch alone)
+    for (int i = threadIdx.x * 4; i < 32 * dim && !(DBG & 4); i += 512 * 4) {
         const int n = i / dim, c = i - n * dim;
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (n < nq) v = *reinterpret_cast<const f32x4*>(Qb + (int64_t)n * dim + c);
         *reinterpret_cast<f32x4*>(qs + n * pitch + c) = v;
     }
     __syncthreads();
+    if constexpr ((DBG & 8) != 0) return;  // (timing: launch + query staging)
     const int lane = threadIdx.x & 63, w = wave_id();
     const int m = lane & 15, g = lane >> 4;
     const float* q0 = qs + m * pitch + 4 * g;
@@ -272,6 +276,7 @@ __global__ __launch_bounds__(512) void maxsim_pairs_packed_kernel(const float* _
     const int64_t stride = (int64_t)gridDim.x * 8;
     constexpr int NL = KB / 16;
     auto request = [&](f32x4 (&x)[NL], int32_t row, int t0) __attribute__((always_inline)) {
+        if constexpr ((DBG & 2) != 0) row = m;  // (timing: always the same sixteen rows, cache-resident)
         if constexpr (ROW16) {
             typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
             const _Float16* a = reinterpret_cast<const _Float16*>(D) + (int64_t)row * dim + 4 * g + t0;
@@ -351,10 +356,15 @@ __global__ __launch_bounds__(512) void maxsim_pairs_packed_kernel(const float* _
                 const f32x4 z0 = *reinterpret_cast<const f32x4*>(q0 + tn);
                 const f32x4 z1 = *reinterpret_cast<const f32x4*>(q1 + tn);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr ((DBG & 1) != 0) {  // (timing: no matrix work -- the loaded values must stay live)
+                    acc0 += xc[j] * y0;
+                    acc1 += xc[j] * y1;
+                } else {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j][u], y0[u], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j][u], y1[u], acc1, 0, 0, 0);
+                    for (int u = 0; u < 4; ++u) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j][u], y0[u], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j][u], y1[u], acc1, 0, 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 y0 = z0;
@@ -460,6 +470,29 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
             hipLaunchKernelGGL((maxsim_pairs_packed_kernel<KB_, false>), dim3(per_query, n_queries), dim3(512), lds, s, D, (int)dim, Q, (int)nq, \
                                q_stride, offsets, candidates, n_items_per_query, item_stride, out);                                        \
     } while (0)
+#ifdef RAGLITE_EXPERIMENTS
+    static const int pdbg = exp_env("RAGLITE_PAIRS_DBG") ? std::atoi(exp_env("RAGLITE_PAIRS_DBG")) : 0;
+    if (packed && dim % 256 == 0 && !rows16 && pdbg) {
+#define RL_PDBG(D_) hipLaunchKernelGGL((maxsim_pairs_packed_kernel<256, false, D_>), dim3(per_query, n_queries), dim3(512), lds, s, D, (int)dim, Q, (int)nq, \
+                                       q_stride, offsets, candidates, n_items_per_query, item_stride, out)
+        static bool dbg_attr = false;
+        if (!dbg_attr) {
+            RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_packed_kernel<256, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_packed_kernel<256, false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_packed_kernel<256, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_packed_kernel<256, false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_packed_kernel<256, false, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_packed_kernel<256, false, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_packed_kernel<256, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            dbg_attr = true;
+        }
+        if (pdbg == 1) RL_PDBG(1); else if (pdbg == 2) RL_PDBG(2); else if (pdbg == 3) RL_PDBG(3); else if (pdbg == 4) RL_PDBG(4); else if (pdbg == 8) RL_PDBG(8);
+        else if (pdbg == 16) RL_PDBG(16); else RL_PDBG(7);
+#undef RL_PDBG
+        RL_HIP(hipGetLastError());
+        return RL_OK;
+    }
+#endif
     if (packed && dim % 256 == 0) RL_PACKED(256);
     else if (packed && dim % 128 == 0) RL_PACKED(128);
     else if (dim % 256 == 0) RL_PAIRS(true, 256);
