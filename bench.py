@@ -322,7 +322,7 @@ def main() -> None:
         if traffic is not None:
             traffic *= passes_per_launch  # (the counters were collected per pass of sixteen queries)
         traffic_source = "static: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 for the gfx950 half-count, separate run)"
-    kernel_name = {5: "rl::maxsim_gemm_kernel<2, false, 0, true>", 6: "rl::maxsim_gemm_kernel<2, false, 0, true>", 7: "rl::maxsim_pp_kernel<0, 0, false>",
+    kernel_name = {5: "rl::maxsim_gemm_kernel<2, false, 0, true>", 6: "rl::maxsim_gemm_kernel<2, false, 0, true>", 7: "rl::maxsim_pp_kernel<0, 0, false, true>",
                    3: "rl::maxsim_gemm_kernel<2, false, 0, true>" if arithmetic == "f16_stored" else "rl::maxsim_gemm_kernel<2, false, 0, false>",
                    2: "rl::maxsim_stream2_kernel<256, false, true>" if arithmetic == "f16_stored" else "rl::maxsim_stream2_kernel<256, false, false>",
                    0: {"fp32_exact": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, false>",
@@ -448,7 +448,7 @@ def main() -> None:
             qv16 = queries[0, :16].reshape(16 * NQ, DIM)
             idx16.time_kernel(7, qv16, 3)
             f_ms = idx16.time_kernel(7, qv16, iters) / iters
-            f_kernel, f_per, f_products = "rl::maxsim_pp_kernel<0, 0, false>", 16, 1.0
+            f_kernel, f_per, f_products = "rl::maxsim_pp_kernel<0, 0, false, true>", 16, 1.0
         except ValueError:  # (no image for the approximate pass: the eight-query kernel at two products, q_hi.e + q_lo.e)
             try:
                 qv8 = queries[0, :8].reshape(8 * NQ, DIM)

@@ -17,12 +17,20 @@
 //     accumulator registers (2 queries x 2 blocks of 16 vectors x 8 blocks of 16 rows), half the corpus bytes per query, 12 fragment
 //     reads per 32 MFMAs instead of 18.  The CORPUS block is the A operand of v_mfma_f32_16x16x32_f16: lane (g, n) of accumulator
 //     register u holds row 4 g + u of the block, query vector n of the register's set;
-//   * EVERY operand goes through LDS by `global_load_lds_dwordx4`: corpus slabs (8 KiB, `nt`) in a ring of 4, query slabs (the 16
-//     queries' hi fragments, 32 KiB, L2-resident) in a ring of 4 -- 160 KiB, all of a CU's LDS; no VMEM result is ever waited for in
-//     registers.  Waves 0-3 (one per SIMD) feed both rings -- per slab 8 query pieces and 2 corpus pieces of slab g + 4 -- and waves 4-7
-//     only multiply: a VMEM instruction holds its wave's issue until the address path takes it (the L2 -> CU path delivers ~18 TB/s
-//     chip-wide, scripts/micro/l2_dma_rate.hip), and a wave that is held issues no MFMAs; with one feeder per SIMD its partner keeps
-//     the matrix pipe busy meanwhile (every wave feeding: 1.12 ms per pass against 1.00);
+//   * the CORPUS slabs (8 KiB, `nt`) go through LDS by `global_load_lds_dwordx4` into a ring, fed by waves 0-3 (one per SIMD; waves 4-7
+//     only multiply): a VMEM instruction holds its wave's issue until the address path takes it, and a wave that is held issues no MFMAs;
+//     with one feeder per SIMD its partner keeps the matrix pipe busy meanwhile (every wave feeding: 1.12 ms per pass against 1.00);
+//   * the QUERY fragments (32 KiB per slab, L2-resident) -- round 4, the shipped MaxSim pass (QREG): straight to REGISTERS.  A wave owns its
+//     two queries, nobody else reads their fragments: every wave issues four `global_load_dwordx4` at the top of slab g for slab g + 1, into
+//     the register set slab g - 1 multiplied from, and waits for them by COUNT at the end of the slab (VMEM returns in order: the feeders
+//     issue their two corpus pieces right AFTER the query loads, so those stay outstanding across the wait -- an HBM piece gets two slabs
+//     to land -- and the corpus ring is 8 slots deep with slab g + 6 issued during slab g).  That takes 80 % of the LDS-DMA instructions and a
+//     third of the fragment reads out of the loop and halves the LDS traffic (136 -> 72 KiB per slab and CU, against 128 B / clk): main
+//     loop 0.832 -> 0.784 ms.  The RESULTS then wait in the 96 KiB of LDS the query ring left free until the workgroup is done (or the
+//     buffer is nearly full): a store from the main loop sits in its wave's in-order queue in front of every later query load and takes
+//     ~2 us to retire (pass without any store 0.893 ms, with a store per block 0.981; results staged 0.895 -- profiles/r04_r_*).
+//     MODE 2 and the experiment builds keep the round-3 arrangement: query slabs through a second LDS ring of 4 (128 KiB), fed by the
+//     same four waves, 8 pieces per feeder and slab, `vmcnt(10)` + the barrier certifying slab g + 2;
 //   * a wave's fragments of slab g + 1 are read from LDS WHILE it multiplies slab g from registers -- each corpus fragment register is
 //     re-loaded right after its four MFMAs, the query fragments alternate between two register sets -- through inline asm, waited for by
 //     COUNT (LDS reads return in order: lgkmcnt(4) at the top of a slab, lgkmcnt(8) before the barrier);
@@ -35,8 +43,8 @@
 //     the 32 vectors are a bank-masked DPP reduction that halves the register count per step: ~93 VALU instructions per block, no LDS.
 //     Its stores share the in-order VMEM counter with the DMAs: the feeders count them (wave-uniform) and widen their next two waits by
 //     exactly that many.
-// Measured (1 M x 1024, 16 x 32 vectors): 0.91-0.97 ms per pass = 0.43-0.46 of the dense fp16 peak; MFMAs alone 0.50, + fragment reads
-// 0.65-0.68, + DMAs 0.88-0.94, + epilogue 0.91-1.0: the costs add.  The operand stream (40 KiB per slab and CU, 10.2 GB per launch over
+// Measured (1 M x 1024, 16 x 32 vectors), the LDS-ring arrangement: 0.91-0.97 ms per pass = 0.43-0.46 of the dense fp16 peak; MFMAs alone
+// 0.50, + fragment reads 0.65-0.68, + DMAs 0.88-0.94, + epilogue 0.91-1.0: the costs add.  QREG on the same box: 0.957 -> 0.895 ms.  The operand stream (40 KiB per slab and CU, 10.2 GB per launch over
 // an 18 TB/s path) is as close a bound as the matrix pipe.  Tried and removed: strictly alternating compute / load segments for the two
 // waves of a SIMD (on this tile and, as maxsim_pp2_kernel, on two row streams), every wave feeding, DMAs spread over the whole slab,
 // static wave priorities, the LDS-transposed and the DPP-scan epilogues.
@@ -178,7 +186,13 @@ struct PpRows {
 // costs the same 0.10 ms per pass wherever it runs.  The VALU instructions of one wave do not execute under the MFMAs of its SIMD partner:
 // the epilogue runs at exactly the VALU issue rate of a SIMD (2 waves x 750 instructions x 4 cycles per tile), and that time is taken from
 // the matrix pipe whether it is taken in one piece or in eight.  What is left is to make the epilogue SHORTER, not to move it.
-template <int DBG, int MODE = 0, bool STAG = false>
+// QREG (round 4, MODE 0): the query fragments go STRAIGHT TO REGISTERS -- a wave owns its two queries, nobody else reads their fragments, so
+// the LDS ring they went through was 80 % of the LDS-DMA instructions, a third of the fragment reads and 128 of the 160 KiB: every wave
+// issues four global_load_dwordx4 at the top of slab g for the fragments of slab g + 1 (the register set the previous slab multiplied from)
+// and waits for them BY COUNT at the end of the slab -- VMEM returns in order, so the feeders issue their two corpus pieces right AFTER the
+// query loads (they stay outstanding across that wait: an HBM piece gets two slabs to land) and the corpus ring is 8 slots deep with the
+// pieces of slab g + 6 issued at the top of slab g (slot (g + 6) % 8 is neither slab g's, which a lagging wave may still read, nor g + 1's).
+template <int DBG, int MODE = 0, bool STAG = false, bool QREG = false>
 __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restrict__ planes, int64_t n_rows, int32_t nslab,
                                                            const char* __restrict__ qfrag, const float* __restrict__ qmeta, int32_t n_q,
                                                            const int32_t* __restrict__ row_to_chunk, const int64_t* __restrict__ chunk_offsets,
@@ -186,7 +200,14 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
                                                            float inv_e_scale, const uint32_t* __restrict__ run_if, unsigned long long* __restrict__ trace,
                                                            PpRows rs) {
     constexpr bool ROWS = MODE == 2;
-    __shared__ __attribute__((aligned(16))) char smem[PP_LDS];
+    static_assert(!(QREG && (STAG || ROWS)), "QREG: the plain MaxSim pass only");
+    constexpr int DC = QREG ? 8 : PP_DC;        // corpus ring depth
+    constexpr int LC = QREG ? 6 : PP_DC;        // corpus look-ahead: the pieces of slab g + LC are issued during slab g
+    // QREG: the 96 KiB the query ring occupied hold the workgroup's RESULTS until it is done (8 waves x 2 queries x OUT_CAP chunk scores): a
+    // store per block in the main loop sits in its wave's in-order VMEM queue in front of every later query load, and a store takes ~2 us
+    // to retire under this load (measured: the pass without its stores 0.918 ms, with them 0.981; the LDS-ring kernel 0.954 / 0.985)
+    constexpr int OUT_CAP = 1536;
+    __shared__ __attribute__((aligned(16))) char smem[QREG ? 8 * PP_CSLOT + 16 * OUT_CAP * 4 : PP_LDS];
     if (run_if && __builtin_amdgcn_readfirstlane((int)*run_if) == 0) return;  // whole grid: a guarded launch that is not needed
     const int lane = threadIdx.x & 63;
     const int wv = wave_id();
@@ -243,8 +264,31 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         ql = ql < n_q ? ql : n_q - 1;  // (clamped: pieces of queries the pass does not have are copied from a valid one, never used)
         qb1[i] = qfrag + pp_uniform_i64(((int64_t)ql * nslab * 4 + 2 * (p & 1)) * 1024);  // hi fragments of block p & 1
     }
+    // QREG: this wave's own two queries, hi fragments of block 0 at K slab 0 (block 1: + 2 KiB; K slab s: + 4 KiB s)
+    const char* qp0 = qfrag;
+    const char* qp1 = qfrag;
+    if constexpr (QREG) {
+        int ql0 = q_base + 2 * wv, ql1 = q_base + 2 * wv + 1;
+        ql0 = ql0 < n_q ? ql0 : n_q - 1;  // (queries the pass does not have: a valid one's fragments, never emitted)
+        ql1 = ql1 < n_q ? ql1 : n_q - 1;
+        qp0 = qfrag + pp_uniform_i64((int64_t)ql0 * nslab * 4096);
+        qp1 = qfrag + pp_uniform_i64((int64_t)ql1 * nslab * 4096);
+    }
+    int qr_s = 0;  // QREG: K slab of the NEXT query-fragment load
+    auto issue_qregs = [&](f32x4 (&qn)[4]) __attribute__((always_inline)) {
+        if constexpr (QREG && !(DBG & 32)) {
+            const char* const a0 = reinterpret_cast<const char*>(pp_uniform_i64(reinterpret_cast<int64_t>(qp0 + (int64_t)qr_s * 4096)));
+            const char* const a1 = reinterpret_cast<const char*>(pp_uniform_i64(reinterpret_cast<int64_t>(qp1 + (int64_t)qr_s * 4096)));
+            asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:2048"
+                         : "=&v"(qn[0]), "=&v"(qn[1]) : "v"(lane16), "s"(a0) : "memory");
+            asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:2048"
+                         : "=&v"(qn[2]), "=&v"(qn[3]) : "v"(lane16), "s"(a1) : "memory");
+            if (++qr_s == nslab) qr_s = 0;
+        }
+    };
     auto issue_q = [&](int i) __attribute__((always_inline)) {
         if (!feeder) return;
+        if constexpr (QREG) return;
         if constexpr (DBG & 32) return;
         pp_dma<false>(lds_base + (uint32_t)(PP_QOFF + fq_slot * PP_QSLOT + (QPW * wv + i) * 1024), qb1[i] + (int64_t)fq_s * 4096, lane16);
     };
@@ -271,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     };
     auto advance_c = [&]() __attribute__((always_inline)) {
         if (++fc_s == nslab) { fc_s = 0; ++fc_r; }
-        fc_slot = fc_slot + 1 == PP_DC ? 0 : fc_slot + 1;
+        fc_slot = fc_slot + 1 == DC ? 0 : fc_slot + 1;
     };
     // A feeder's queue, old -> new, half-way through slab g: .. Q(g+2) x8, C(g+2) x2 | Q(g+3) x8, C(g+3) x2 -- everything up to its pieces of
     // slab g + 2 has retired when 10 operations are outstanding, plus the epilogue stores issued since that are NEWER than the pieces of
@@ -279,8 +323,11 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     // stores before the DMAs of slab g + 4 are issued: it counts in the next wait only; an epilogue at the end of a slab stores after
     // them: it counts in the next two.
     int st_a = 0, st_b = 0;
+    [[maybe_unused]] int st_q = 0;  // QREG: stores issued since this slab's query loads
     auto certify = [&]() __attribute__((always_inline)) {
-        if (feeder) pp_wait_vm<QPW + CPW>(st_a);
+        if constexpr (!QREG) {
+            if (feeder) pp_wait_vm<QPW + CPW>(st_a);
+        }  // (QREG: every wave's wait for its query fragments at the end of a slab has retired its corpus pieces of two slabs ago)
         st_a = st_b;
         st_b = 0;
     };
@@ -303,7 +350,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         constexpr int a = decltype(A_)::value;
         if constexpr (!(DBG & 8)) {
             pp_read<a * 1024>(ef[a], rd_c + (uint32_t)(c_slot * PP_CSLOT));
-            if constexpr (a < 4 && !(DBG & 2048)) pp_read<a * 1024>(qn[a], rd_q + (uint32_t)(q_slot * PP_QSLOT));
+            if constexpr (a < 4 && !(DBG & 2048) && !QREG) pp_read<a * 1024>(qn[a], rd_q + (uint32_t)(q_slot * PP_QSLOT));
         }
     };
     auto mfma_group = [&](f32x4 (&q)[4], auto A_) __attribute__((always_inline)) {
@@ -340,6 +387,25 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     const bool e_has = !ROWS && (e_q == 0 ? has0 : has1) && (ft & 1) == 0;  // (lanes t and t ^ 1 hold the same sum)
     const float e_unscale = e_has ? qmeta[2 * (q_base + 2 * wv + e_q)] * inv_e_scale : 0.f;
     float* const e_out = out + (int64_t)(e_has ? q_base + 2 * wv + e_q : 0) * out_stride;
+    // QREG: results wait in LDS -- slot = the chunk's ordinal among the chunks this workgroup OWNS (they end inside [r_lo, r_hi): consecutive
+    // ordinals from ord_lo on) minus what has been flushed
+    [[maybe_unused]] float* const o_buf = reinterpret_cast<float*>(smem + 8 * PP_CSLOT) + (2 * wv + e_q) * OUT_CAP;
+    [[maybe_unused]] const int32_t ord_lo = (QREG && !ROWS) ? __builtin_amdgcn_readfirstlane(row_to_chunk[r_lo]) : 0;
+    [[maybe_unused]] int32_t own_cnt = 0, own_flushed = 0;  // owned chunks finished so far / already written out
+    [[maybe_unused]] auto flush_out = [&]() __attribute__((always_inline)) {
+        if constexpr (QREG) {
+            const int n = own_cnt - own_flushed;  // (wave-uniform)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own LDS writes
+            const float* const b0 = reinterpret_cast<const float*>(smem + 8 * PP_CSLOT) + (2 * wv) * OUT_CAP;
+            float* const g0 = out + (int64_t)(q_base + 2 * wv) * out_stride + ord_lo + own_flushed;
+            if (has0)
+                for (int i = lane; i < n; i += 64) g0[i] = b0[i];
+            if (has1)
+                for (int i = lane; i < n; i += 64) g0[out_stride + i] = b0[OUT_CAP + i];
+            own_flushed = own_cnt;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (rare: once per workgroup on RAGLite-shaped chunks)
+        }
+    };
     const uint64_t odd_pairs = 0xccccccccccccccccull;  // lanes with t >= 2
     auto swap32 = [](float& x, float& y) __attribute__((always_inline)) {
         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
@@ -440,9 +506,14 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         asm("" : "+s"(EM));
         int n_st = 0;
         if (EM != 0u) {  // wave-uniform: some chunk of this workgroup ends in this block
-            if ((EM & my_bit) && e_has && !(DBG & 256)) e_out[ord_run + __builtin_popcount(E & my_below)] = w * e_unscale;
-            if constexpr (DBG & 256) run += w;  // (timing: no store, the sum stays live)
-            n_st = 1;
+            if constexpr (QREG) {
+                if ((EM & my_bit) && e_has) o_buf[ord_run - ord_lo - own_flushed + __builtin_popcount(E & my_below)] = w * e_unscale;
+                own_cnt += __builtin_popcount(EM);
+            } else {
+                if ((EM & my_bit) && e_has && !(DBG & 256)) e_out[ord_run + __builtin_popcount(E & my_below)] = w * e_unscale;
+                if constexpr (DBG & 256) run += w;  // (timing: no store, the sum stays live)
+                n_st = (DBG & 256) ? 0 : 1;
+            }
         }
         ord_run += __builtin_popcount(E);
         zero_block(A_);
@@ -587,6 +658,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         }
         st_a += n_st;
         if (both) st_b += n_st;
+        st_q += n_st;
     };
 
     // ---- one K slab: MFMAs of slab g from registers, and after each block's four MFMAs the LDS read that re-loads its fragment register for
@@ -648,6 +720,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
                 } else {
                     [&]<int... A>(std::integer_sequence<int, A...>) { (block_epilogue(std::integral_constant<int, A>{}, c_r, true), ...); }
                     (std::make_integer_sequence<int, PP_NBLK>{});
+                    if constexpr (QREG) {
+                        if (own_cnt - own_flushed > OUT_CAP - PP_RT) flush_out();  // (a tile finishes at most PP_RT chunks)
+                    }
                 }
             }
         }
@@ -661,18 +736,28 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
             issue_q(2 * B);
             issue_q(2 * B + 1);
         };
+        if constexpr (QREG) {  // the query fragments of the next slab, then (feeders) the corpus pieces of slab g + LC: see the template's comment
+            issue_qregs(qn);
+            issue_c1(PP_I(0));
+            issue_c1(PP_I(1));
+            advance_c();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (!LAG) {
             G(PP_I(0)); R(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
             G(PP_I(1)); R(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
             G(PP_I(2)); R(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
             G(PP_I(3)); R(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");  // the reads of the previous slab's second half: corpus blocks 4-7 of slab g (issued half a slab ago)
+            // the reads of the previous slab's second half: corpus blocks 4-7 of slab g (issued half a slab ago)
+            if constexpr (QREG) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
         } else {
             G(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
             G(PP_I(1)); R(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
             G(PP_I(2)); R(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
             G(PP_I(3)); R(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            if constexpr (QREG) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
         }
         pp_pin(ef[4], ef[5], ef[6], ef[7]);
         certify();  // this wave's pieces of slab g + 2
@@ -691,11 +776,13 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
             G(PP_I(7)); R(PP_I(6)); D(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
             R(PP_I(7)); __builtin_amdgcn_sched_barrier(0);
         }
-        issue_c1(PP_I(0));
-        issue_c1(PP_I(1));
-        advance_q();
-        advance_c();
-        c_slot = c_slot + 1 == PP_DC ? 0 : c_slot + 1;
+        if constexpr (!QREG) {
+            issue_c1(PP_I(0));
+            issue_c1(PP_I(1));
+            advance_q();
+            advance_c();
+        }
+        c_slot = c_slot + 1 == DC ? 0 : c_slot + 1;
         q_slot = q_slot + 1 == PP_DQ ? 0 : q_slot + 1;
         hook_end(LAG_);
         if (++c_s == nslab) { c_s = 0; ++c_r; }
@@ -705,13 +792,21 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     // under load at the end of every slab (lgkmcnt(0) there: + 0.18 ms per pass).  Blocks 4-7 are waited for before the next barrier.
     auto landed = [&](f32x4 (&qn)[4]) __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        if constexpr (QREG) {
+            // this wave's queue, old -> new: .. C(g + LC - 1) x2 | Q(g + 1) x4, C(g + LC) x2 [feeders], the stores of this slab's epilogue:
+            // the query fragments have landed when only what follows them is outstanding
+            const int extra = st_q;  // (0 in this kernel: its results wait in LDS; kept for a variant that stores from the main loop)
+            st_q = 0;
+            if (feeder) pp_wait_vm<CPW>(extra);
+            else pp_wait_vm<0>(extra);
+        }
         pp_pin(ef[0], ef[1], ef[2], ef[3]);
         pp_pin(qn[0], qn[1], qn[2], qn[3]);
     };
 
     // ---- prologue: Q(0..3), C(0..3) landed (the steady state issues Q(g + 4), C(g + 4) during slab g); slab 0's fragments ----------
     if (feeder) {
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < LC; ++i) {
             issue_c1(PP_I(0));
             issue_c1(PP_I(1));
 #pragma unroll
@@ -720,6 +815,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
             advance_c();
         }
     }
+    issue_qregs(qA);  // (QREG: slab 0's query fragments)
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
     [&]<int... A>(std::integer_sequence<int, A...>) { (read_slab(qA, std::integral_constant<int, A>{}), ...); }
     (std::make_integer_sequence<int, PP_NBLK>{});
@@ -743,6 +839,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     else main_loop(std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
     flush_rows();
+    if constexpr (QREG) flush_out();
     if constexpr (DBG & 128) {  // (timing without the epilogue: the accumulators must stay live, or the compiler deletes the MFMAs with it)
         if (n_q > 1000) {
             f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -778,11 +875,17 @@ int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void*
 #define RL_PP_LAUNCH(DBG_) RL_PP_LAUNCH_S(DBG_, false)
 #ifdef RAGLITE_EXPERIMENTS
     // Experiment builds only (libraglite_hip_exp.so, scripts/gpu_calls/): instantiations that skip parts of the kernel to time the rest --
-    // WRONG results -- and RAGLITE_PP_STAG=1, the block epilogues inside the main loop (correct results; measured, not shipped: see STAG).
+    // WRONG results -- RAGLITE_PP_STAG=1, the block epilogues inside the main loop (correct results; measured, not shipped: see STAG), and
+    // RAGLITE_PP_QREG=0, the round-3 arrangement with the query fragments through an LDS ring (correct results; for A/B runs).
     // None of this is compiled into the shipped library.
     static const int dbg = std::getenv("RAGLITE_PP_DBG") ? std::atoi(std::getenv("RAGLITE_PP_DBG")) : 0;
     static const bool stag = std::getenv("RAGLITE_PP_STAG") && std::getenv("RAGLITE_PP_STAG")[0] == '1';
-    if (stag) { if (dbg == 128) RL_PP_LAUNCH_S(128, true); else RL_PP_LAUNCH_S(0, true); }
+    static const int qreg = std::getenv("RAGLITE_PP_QREG") ? std::atoi(std::getenv("RAGLITE_PP_QREG")) : -1;
+#define RL_PP_LAUNCH_Q(DBG_)                                                                                                              \
+    hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 0, false, true>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk, \
+                       chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if, trace, PpRows{})
+    if (qreg != 0 && !stag && (dbg == 0 || dbg == 128 || dbg == 256)) { if (dbg == 128) RL_PP_LAUNCH_Q(128); else if (dbg == 256) RL_PP_LAUNCH_Q(256); else RL_PP_LAUNCH_Q(0); }
+    else if (stag) { if (dbg == 128) RL_PP_LAUNCH_S(128, true); else RL_PP_LAUNCH_S(0, true); }
     else if (dbg == 2) RL_PP_LAUNCH(2);
     else if (dbg == 1024) RL_PP_LAUNCH(1024);
     else if (dbg == 2208) RL_PP_LAUNCH(2208);
@@ -791,12 +894,18 @@ int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void*
     else if (dbg == 176) RL_PP_LAUNCH(176);
     else if (dbg == 184) RL_PP_LAUNCH(184);
     else if (dbg == 128) RL_PP_LAUNCH(128);
+    else if (dbg == 256) RL_PP_LAUNCH(256);
     else RL_PP_LAUNCH(0);
 #else
-    RL_PP_LAUNCH(0);
+    // the shipped pass: query fragments straight to registers, results staged in LDS (QREG)
+    hipLaunchKernelGGL((maxsim_pp_kernel<0, 0, false, true>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk,
+                       chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if, trace, PpRows{});
 #endif
 #undef RL_PP_LAUNCH_S
 #undef RL_PP_LAUNCH
+#ifdef RAGLITE_EXPERIMENTS
+#undef RL_PP_LAUNCH_Q
+#endif
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
