@@ -200,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
                                                            float inv_e_scale, const uint32_t* __restrict__ run_if, unsigned long long* __restrict__ trace,
                                                            PpRows rs) {
     constexpr bool ROWS = MODE == 2;
-    static_assert(!(QREG && (STAG || ROWS)), "QREG: the plain MaxSim pass only");
+    static_assert(!(QREG && STAG), "QREG: not with the staggered epilogues");
     constexpr int DC = QREG ? 8 : PP_DC;        // corpus ring depth
     constexpr int LC = QREG ? 6 : PP_DC;        // corpus look-ahead: the pieces of slab g + LC are issued during slab g
     // QREG: the 96 KiB the query ring occupied hold the workgroup's RESULTS until it is done (8 waves x 2 queries x OUT_CAP chunk scores): a
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     const char* qp0 = qfrag;
     const char* qp1 = qfrag;
     if constexpr (QREG) {
-        int ql0 = q_base + 2 * wv, ql1 = q_base + 2 * wv + 1;
+        int ql0 = PP_QPP * qt + 2 * wv, ql1 = PP_QPP * qt + 2 * wv + 1;
         ql0 = ql0 < n_q ? ql0 : n_q - 1;  // (queries the pass does not have: a valid one's fragments, never emitted)
         ql1 = ql1 < n_q ? ql1 : n_q - 1;
         qp0 = qfrag + pp_uniform_i64((int64_t)ql0 * nslab * 4096);
@@ -393,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     [[maybe_unused]] const int32_t ord_lo = (QREG && !ROWS) ? __builtin_amdgcn_readfirstlane(row_to_chunk[r_lo]) : 0;
     [[maybe_unused]] int32_t own_cnt = 0, own_flushed = 0;  // owned chunks finished so far / already written out
     [[maybe_unused]] auto flush_out = [&]() __attribute__((always_inline)) {
-        if constexpr (QREG) {
+        if constexpr (QREG && !ROWS) {
             const int n = own_cnt - own_flushed;  // (wave-uniform)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own LDS writes
             const float* const b0 = reinterpret_cast<const float*>(smem + 8 * PP_CSLOT) + (2 * wv) * OUT_CAP;
@@ -530,6 +530,13 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     // they were what the allocator spilled, and a scratch reload inside the loop puts `s_waitcnt vmcnt(0)` at its header.
     [[maybe_unused]] float T4x = INFINITY;
     [[maybe_unused]] uint32_t ncand = 0;  // wave-uniform: records this wave has logged
+    // QREG: the records wait in LDS (the 96 KiB the query ring left: LOG_CAP records per wave) and go to the wave's log in global memory in
+    // coalesced bursts -- when the buffer is half full at the end of a tile, and when the workgroup is done; a store from the main loop would
+    // sit in front of every later query load of its wave (see the template's comment).  A tile that logs more than the buffer's free half
+    // loses records: the overflow flag, the dense path decides (as for a full global log).
+    constexpr uint32_t LOG_CAP = 1536;
+    [[maybe_unused]] uint2* const l_log = reinterpret_cast<uint2*>(smem + 8 * PP_CSLOT) + wv * LOG_CAP;
+    [[maybe_unused]] uint32_t ncand_out = 0;  // records already moved to the global log
     [[maybe_unused]] uint2* const my_log = ROWS ? rs.log + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv) * (size_t)rs.log_cap : nullptr;
     [[maybe_unused]] const bool cosine = ROWS && rs.metric == SCAN_COSINE;
     if constexpr (ROWS) {  // (before the first DMA: these loads are ordinary ones)
@@ -546,9 +553,13 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     }
     // tq4: the lane's four thresholds (T4x handed back by rows_thresholds()); nmin / nmax: the block's norm range (cosine)
     [[maybe_unused]] auto rows_thresholds = [&](float (&tq4)[4]) __attribute__((always_inline)) {
+        // (the four lane addresses are re-derived per call from one opaque value: hoisted out of the K loop they are four registers, one of
+        // which the allocator spills -- and a scratch reload brings `s_waitcnt vmcnt(0)` with it)
+        uint32_t b = (uint32_t)(lane & 15) << 2;
+        asm volatile("" : "+v"(b));
 #pragma unroll
         for (int c = 0; c < 4; ++c)  // column set c's thresholds sit in lane group c of T4x
-            tq4[c] = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(((uint32_t)c << 6) | ((uint32_t)(lane & 15) << 2)), __float_as_int(T4x)));
+            tq4[c] = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(((uint32_t)c << 6) | b), __float_as_int(T4x)));
     };
     [[maybe_unused]] auto block_epilogue_rows = [&](auto A_, int T, const float (&tq4)[4], float nmin, float nmax) __attribute__((always_inline)) -> int {
         constexpr int a = decltype(A_)::value;
@@ -587,9 +598,13 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
                         const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
                         if (mask != 0ull) {
                             const uint32_t pos = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                            if (pass && pos < (uint32_t)rs.log_cap) my_log[pos] = make_uint2(__float_as_uint(r0), code);
+                            if constexpr (QREG) {
+                                if (pass && pos - ncand_out < LOG_CAP) l_log[pos - ncand_out] = make_uint2(__float_as_uint(r0), code);
+                            } else {
+                                if (pass && pos < (uint32_t)rs.log_cap) my_log[pos] = make_uint2(__float_as_uint(r0), code);
+                                ++n_st;
+                            }
                             ncand += (uint32_t)__builtin_popcountll(mask);
-                            ++n_st;
                         }
                         r0 = r1; r1 = r2; r2 = r3;
                         ++code;
@@ -600,6 +615,20 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         }
         zero_block(A_);
         return n_st;
+    };
+    [[maybe_unused]] auto dump_log = [&]() __attribute__((always_inline)) {  // LDS -> this wave's log in global memory
+        if constexpr (QREG && ROWS) {
+            uint32_t n = ncand - ncand_out;  // (wave-uniform)
+            if (n > LOG_CAP) {  // a tile logged more than the buffer held: records were lost
+                if (lane == 0) *rs.overflow = 1u;
+                n = LOG_CAP;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (uint32_t i = lane; i < n; i += 64)
+                if (ncand_out + i < (uint32_t)rs.log_cap) my_log[ncand_out + i] = l_log[i];
+            ncand_out = ncand;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     };
     // When the workgroup's tiles are done: every record once more with the exact formulas (maxsim_gemm.hip flush_candidates: same
     // statements, same bits), kept if it reaches its query's threshold exactly, appended to the query's list.
@@ -717,6 +746,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
                     }(std::make_integer_sequence<int, PP_NBLK>{});
                     st_a += n_st;
                     st_b += n_st;
+                    if constexpr (QREG) {
+                        if (ncand - ncand_out > LOG_CAP / 2) dump_log();
+                    }
                 } else {
                     [&]<int... A>(std::integer_sequence<int, A...>) { (block_epilogue(std::integral_constant<int, A>{}, c_r, true), ...); }
                     (std::make_integer_sequence<int, PP_NBLK>{});
@@ -838,6 +870,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     if (wv < 4 || no_lag) main_loop(std::false_type{});
     else main_loop(std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
+    dump_log();
     flush_rows();
     if constexpr (QREG) flush_out();
     if constexpr (DBG & 128) {  // (timing without the epilogue: the accumulators must stay live, or the compiler deletes the MFMAs with it)
@@ -977,17 +1010,24 @@ int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t 
     hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 2, STAG_>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, reinterpret_cast<const char*>(frag), \
                        nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, nullptr, nullptr, rs)
 #define RL_PP_ROWS(DBG_) RL_PP_ROWS_S(DBG_, false)
+#define RL_PP_ROWS_Q(DBG_)                                                                                                                \
+    hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 2, false, true>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, reinterpret_cast<const char*>(frag), \
+                       nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, nullptr, nullptr, rs)
 #ifdef RAGLITE_EXPERIMENTS  // timing skeletons (wrong results): 128 = no block epilogues, 512 = no flush of the record logs, 640 = neither; RAGLITE_PP_STAG=1
     static const int dbg = std::getenv("RAGLITE_PP_ROWS_DBG") ? std::atoi(std::getenv("RAGLITE_PP_ROWS_DBG")) : 0;
     static const bool stag = std::getenv("RAGLITE_PP_STAG") && std::getenv("RAGLITE_PP_STAG")[0] == '1';
+    static const int qreg = std::getenv("RAGLITE_PP_QREG") ? std::atoi(std::getenv("RAGLITE_PP_QREG")) : -1;
     if (stag) { if (dbg == 128) RL_PP_ROWS_S(128, true); else RL_PP_ROWS_S(0, true); }
+    else if (qreg != 0 && dbg == 0) RL_PP_ROWS_Q(0);
+    else if (qreg != 0 && dbg == 128) RL_PP_ROWS_Q(128);
     else if (dbg == 128) RL_PP_ROWS(128);
     else if (dbg == 512) RL_PP_ROWS(512);
     else if (dbg == 640) RL_PP_ROWS(640);
     else RL_PP_ROWS(0);
 #else
-    RL_PP_ROWS(0);
+    RL_PP_ROWS_Q(0);  // (query fragments to registers, records staged in LDS: QREG)
 #endif
+#undef RL_PP_ROWS_Q
 #undef RL_PP_ROWS_S
 #undef RL_PP_ROWS
     RL_HIP(hipGetLastError());
