@@ -307,3 +307,22 @@ def test_all_passes_in_one_launch_equal_one_launch_per_pass():
         part, b = idx.maxsim_approx_scores(Q[lo:hi].contiguous(), kernel=0)
         assert torch.equal(part, whole[lo:hi]) and torch.equal(b, bound[lo:hi])
     idx.close()
+
+
+def test_results_staged_in_lds_are_flushed_when_the_buffer_fills():
+    """The pass keeps a workgroup's chunk scores in LDS (1 536 per query of a wave) and writes them out when the workgroup is done -- or when
+    the buffer is nearly full: 420 000 one-row chunks put ~1 640 chunks into every workgroup's range, so each flushes in the middle of its
+    rows.  Integer data: the oracle bit for bit (a score written twice, or into the neighbour's ordinals, would show)."""
+    n, dim, nq = 420_000, 256, 5
+    off = np.arange(n + 1, dtype=np.int64)
+    E = oracle.synth_matrix(889, n, dim, "small_int")
+    Qb = np.stack([oracle.synth_matrix(890 + i, nq, dim, "small_int") for i in range(19)])  # a full pass and a partial one (3 of 16 queries)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    approx, _ = idx.maxsim_approx_scores(Qb, kernel=0)
+    for b in (0, 15, 16, 18):
+        assert np.array_equal(approx[b].astype(np.float64), oracle.maxsim_scores(E, off, Qb[b], np.float64)), b
+    s, c = idx.maxsim_topk_batch(Qb, 50)
+    for b in (3, 17):
+        ws, wc = oracle.maxsim_topk(E, off, Qb[b], 50, np.float32)
+        assert np.array_equal(c[b], wc) and np.array_equal(s[b], ws)
+    idx.close()
