@@ -555,8 +555,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     [[maybe_unused]] auto rows_thresholds = [&](float (&tq4)[4]) __attribute__((always_inline)) {
         // (the four lane addresses are re-derived per call from one opaque value: hoisted out of the K loop they are four registers, one of
         // which the allocator spills -- and a scratch reload brings `s_waitcnt vmcnt(0)` with it)
-        uint32_t b = (uint32_t)(lane & 15) << 2;
-        asm volatile("" : "+v"(b));
+        uint32_t b;  // the lane number, re-read here (volatile: not hoisted), -> (lane & 15) << 2
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(b));
+        b = (b & 15u) << 2;
 #pragma unroll
         for (int c = 0; c < 4; ++c)  // column set c's thresholds sit in lane group c of T4x
             tq4[c] = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(((uint32_t)c << 6) | b), __float_as_int(T4x)));
