@@ -2066,7 +2066,9 @@ int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_quer
         RL_TRY(launch_maxsim_stream_batch(idx->E, false, idx->n_rows, idx->dim, d_q, nq, (int64_t)q_elems, n_gemm, idx->row_to_chunk, idx->offsets,
                                           idx->n_chunks, sc, ld, idx->n_cu, s, idx->split_scale, hb.flag));
     RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // (harmless on scores nobody reads)
-    RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, d_s, d_c, s, hb.flag));
+    // (the exact top-k of the fallback's scores in ONE guarded launch, a block per query -- select.hip: guarded_select_kernel -- instead of the
+    // selection's three: what usually returns at once is one launch shorter by two)
+    RL_TRY(launch_guarded_select(sc, n_gemm, idx->n_chunks, ld, k, nullptr, nullptr, nullptr, 0, SCAN_RAW_DOT, 1.0f, d_s, d_c, hb.flag, s));
     return RL_OK;
 }
 }  // namespace

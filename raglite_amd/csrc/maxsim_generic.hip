@@ -302,10 +302,12 @@ __global__ __launch_bounds__(512) void maxsim_pairs_packed_kernel(const float* _
         }
         const uint64_t todo = __builtin_amdgcn_ballot_w64(ve > vb);
         if (todo == 0ull) continue;  // (wave-uniform)
-        int total = ve > vb ? ve - vb : 0;  // rows of all this wave's candidates
+        // rows of all this wave's candidates (the same long chunk may be listed 64 times: the sum is taken in 32-bit halves, exactly)
+        uint32_t t_lo = ve > vb ? (uint32_t)(ve - vb) & 0xffffu : 0u, t_hi = ve > vb ? (uint32_t)(ve - vb) >> 16 : 0u;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-        const int R = __builtin_amdgcn_readfirstlane(total), n_tiles = (R + 15) >> 4;
+        for (int o = 32; o > 0; o >>= 1) { t_lo += __shfl_xor(t_lo, o); t_hi += __shfl_xor(t_hi, o); }
+        const int64_t R = ((int64_t)__builtin_amdgcn_readfirstlane(t_hi) << 16) + (int64_t)__builtin_amdgcn_readfirstlane(t_lo);
+        const int64_t n_tiles = (R + 15) >> 4;
         // ---- the walk: candidate `cur` (a lane number), its next row, its end, the candidates still to come -- all scalar ----
         int cur = __builtin_ctzll(todo);
         uint64_t rest = todo & (todo - 1ull);
@@ -338,7 +340,8 @@ __global__ __launch_bounds__(512) void maxsim_pairs_packed_kernel(const float* _
         int32_t row_c, row_n = 0;
         int cand_c, cand_n = 0;
         uint32_t ends_c = next_tile(row_c, cand_c), ends_n = 0u;
-        int tile = 0, t0 = 0;
+        int64_t tile = 0;
+        int t0 = 0;
         request(xc, row_c, 0);
         f32x4 y0 = *reinterpret_cast<const f32x4*>(q0), y1 = *reinterpret_cast<const f32x4*>(q1);
         float carry0 = -INFINITY, carry1 = -INFINITY;  // column maxima of the candidate left open by the previous tile
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(512) void maxsim_pairs_packed_kernel(const float* _
                 y1 = z1;
             }
             if (!more_k) {  // the tile is complete: this lane holds rows (slots) 4 g + i, i = 0..3, of column m
-                const int n_valid = R - 16 * tile < 16 ? R - 16 * tile : 16;
+                const int n_valid = R - 16 * tile < 16 ? (int)(R - 16 * tile) : 16;
                 uint32_t em = ends_c;
                 int s_lo = 0;
                 while (s_lo < n_valid) {  // (scalar) one trip per candidate segment of the tile
