@@ -253,8 +253,12 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
 
     // ---- feeder duty: waves 0-3 fetch query pieces 8 wv .. + 7 (piece = 2 * query + block of 16 vectors) of slab g + 4, then corpus
     // blocks 2 wv, 2 wv + 1 of slab g + 4, during slab g ------------------------------------------------------------------------
-    constexpr int QPW = 8, CPW = 2;  // pieces per feeder and slab
-    const bool feeder = wv < 4;
+    // FEED8 (with QREG; DBG bit 4096 switches it off in experiment builds): every wave fetches ONE corpus piece per slab instead of waves 0-3
+    // two each -- with the query loads in every wave's queue anyway the waves are symmetric again (- 1 % per pass, profiles/r04_y_*)
+    constexpr bool FEED8 = QREG && (DBG & 4096) == 0;
+    constexpr int QPW = 8, CPW = FEED8 ? 1 : 2;  // pieces per feeder and slab
+    const bool feeder = FEED8 || wv < 4;
+    const int fw = FEED8 ? wv : (wv & 3);  // this feeder's number
     const char* qb1[QPW];
     int fq_s = 0, fq_slot = 0, fc_s = 0, fc_r = 0, fc_slot = 0;  // K slab (and round = tile of block 0) of the NEXT fetch, ring slots
 #pragma unroll
@@ -299,19 +303,20 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     // corpus block a = 2 (wv & 3) + i of the slab being fetched: K slab fc_s of ITS current tile -- round fc_r once the slab index has
     // reached the block's lag, the round before until then (before the first tile and after the last: some valid tile, multiplied into
     // sums nobody reads)
-    const int32_t blk_org = (org >> 4) + CPW * (wv & 3);
+    const int32_t blk_org = (org >> 4) + CPW * fw;
     const int64_t slab_bytes = (int64_t)nslab * 1024;
     auto issue_c1 = [&](auto I_) __attribute__((always_inline)) {
         constexpr int i = decltype(I_)::value;
         if (!feeder) return;
+        if constexpr (i >= CPW) return;
         if constexpr (DBG & 16) return;
-        int t = fc_r - (fc_s < lag_of(CPW * (wv & 3) + i) ? 1 : 0);
+        int t = fc_r - (fc_s < lag_of(CPW * fw + i) ? 1 : 0);
         t = t < 0 ? 0 : (t < nt ? t : nt - 1);
         if constexpr (DBG & 64) t = 0;  // (timing: the corpus stream out of L2)
         int32_t blk = blk_org + i + t * PP_NBLK;
         blk = blk < last_blk ? blk : last_blk;  // past the image: harmless re-read of the last block, never emitted
         const char* src = planes + pp_uniform_i64((int64_t)blk * slab_bytes + (int64_t)fc_s * 1024);
-        pp_dma<true>(lds_base + (uint32_t)(fc_slot * PP_CSLOT + (CPW * wv + i) * 1024), src, lane16);
+        pp_dma<true>(lds_base + (uint32_t)(fc_slot * PP_CSLOT + (CPW * fw + i) * 1024), src, lane16);
     };
     auto advance_c = [&]() __attribute__((always_inline)) {
         if (++fc_s == nslab) { fc_s = 0; ++fc_r; }
@@ -918,7 +923,9 @@ int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void*
 #define RL_PP_LAUNCH_Q(DBG_)                                                                                                              \
     hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 0, false, true>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk, \
                        chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if, trace, PpRows{})
-    if (qreg != 0 && !stag && (dbg == 0 || dbg == 128 || dbg == 256)) { if (dbg == 128) RL_PP_LAUNCH_Q(128); else if (dbg == 256) RL_PP_LAUNCH_Q(256); else RL_PP_LAUNCH_Q(0); }
+    if (qreg != 0 && !stag && (dbg == 0 || dbg == 128 || dbg == 256 || dbg == 4096)) {
+        if (dbg == 128) RL_PP_LAUNCH_Q(128); else if (dbg == 256) RL_PP_LAUNCH_Q(256); else if (dbg == 4096) RL_PP_LAUNCH_Q(4096); else RL_PP_LAUNCH_Q(0);
+    }
     else if (stag) { if (dbg == 128) RL_PP_LAUNCH_S(128, true); else RL_PP_LAUNCH_S(0, true); }
     else if (dbg == 2) RL_PP_LAUNCH(2);
     else if (dbg == 1024) RL_PP_LAUNCH(1024);
@@ -1021,6 +1028,7 @@ int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t 
     if (stag) { if (dbg == 128) RL_PP_ROWS_S(128, true); else RL_PP_ROWS_S(0, true); }
     else if (qreg != 0 && dbg == 0) RL_PP_ROWS_Q(0);
     else if (qreg != 0 && dbg == 128) RL_PP_ROWS_Q(128);
+    else if (qreg != 0 && dbg == 4096) RL_PP_ROWS_Q(4096);
     else if (dbg == 128) RL_PP_ROWS(128);
     else if (dbg == 512) RL_PP_ROWS(512);
     else if (dbg == 640) RL_PP_ROWS(640);
