@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round 4, GPU call V: full verification on one fresh box -- smoke, the whole GPU suite, the full bench line (every block), rocprofv3
+# Round 4, GPU call AB (final): full verification on one fresh box -- smoke, the whole GPU suite, the full bench line (every block), rocprofv3
 # kernel stats of the headline step, of cfg 5 and of cfg 2, PMC passes (own runs, kernel trace only) over the pass kernel and the cfg 5 candidate pass.
 set -u
-TAG=${1:-r04_v}
+TAG=${1:-r04_ab}
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
