@@ -279,6 +279,7 @@ struct rl_index {
     float hi_image_scale = 0.f;
     int64_t hi_image_rows = 0;
     float max_row_norm = 0.f, max_lo_norm = 0.f, max_lo_ratio = 0.f;  // max |e|, max |e_lo|, max |e_lo| / |e| (e_lo: what the HI halves drop)
+    float min_row_norm = std::numeric_limits<float>::infinity();  // min |e| over the rows folded in so far (never raised by deletions: conservative)
     float max_row_norm_scale = 0.f;       // the split scale they were computed at
     uint32_t* d_norms = nullptr;          // device scratch of launch_max_row_norm (4 words)
     int64_t max_row_norm_rows = 0;        // rows folded into them
@@ -301,7 +302,7 @@ struct rl_index {
     // rl_time_kernel kind 8: what the candidate pass of the last fused-HI row search ran with (pointers into misc / fused / pp_work: valid
     // while those pools have not been re-reserved, which `pools` pins down)
     struct FusedReplay {
-        bool valid = false, pp = false; int32_t B = 0, log_cap = 0; int mode = 0; float* qs = nullptr; rl::CandArgs ca{}; uint32_t* cnt = nullptr;
+        bool valid = false, pp = false, row_test = false; int32_t B = 0, log_cap = 0; int mode = 0; float* qs = nullptr; rl::CandArgs ca{}; uint32_t* cnt = nullptr;
         const float* thr1 = nullptr; int64_t round1_tiles = 0;  // two-round candidate pass: the first round's thresholds and tiles
         const void* pools[3] = {nullptr, nullptr, nullptr};
     } replay;
@@ -514,6 +515,7 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
     if (idx->max_row_norm_rows != idx->n_rows || idx->max_row_norm_scale != idx->split_scale) {  // fold the new rows' norms in
         if (idx->max_row_norm_scale != idx->split_scale) {  // (the dropped halves depend on the scale: start over)
             idx->max_row_norm = idx->max_lo_norm = idx->max_lo_ratio = 0.f;
+            idx->min_row_norm = std::numeric_limits<float>::infinity();
             idx->max_row_norm_rows = 0;
         }
         const int64_t from = std::min<int64_t>(idx->max_row_norm_rows, idx->n_rows);
@@ -522,6 +524,7 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
         std::memcpy(&bits[0], &idx->max_row_norm, 4);
         std::memcpy(&bits[1], &idx->max_lo_norm, 4);
         std::memcpy(&bits[2], &idx->max_lo_ratio, 4);
+        std::memcpy(&bits[3], &idx->min_row_norm, 4);
         RL_HIP(hipMemcpyAsync(idx->d_norms, bits, 16, hipMemcpyHostToDevice, s));
         RL_TRY(rl::launch_max_row_norm(idx->E + (size_t)from * idx->dim, idx->n_rows - from, idx->dim, idx->split_scale, idx->d_norms, s));
         RL_HIP(hipMemcpyAsync(bits, idx->d_norms, 16, hipMemcpyDeviceToHost, s));
@@ -529,6 +532,7 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
         std::memcpy(&idx->max_row_norm, &bits[0], 4);
         std::memcpy(&idx->max_lo_norm, &bits[1], 4);
         std::memcpy(&idx->max_lo_ratio, &bits[2], 4);
+        std::memcpy(&idx->min_row_norm, &bits[3], 4);
         idx->max_row_norm_rows = idx->n_rows;
         idx->max_row_norm_scale = idx->split_scale;
     }
@@ -1011,6 +1015,7 @@ int rl_index_compact(rl_index* idx, int64_t* out_remap, int64_t* new_n_rows, int
     idx->hi_image_rows = 0;
     idx->hi_image_scale = 0.f;
     idx->max_row_norm = idx->max_lo_norm = idx->max_lo_ratio = 0.f;
+    idx->min_row_norm = std::numeric_limits<float>::infinity();
     idx->max_row_norm_rows = 0;
     RL_TRY(scan_row_range(idx, 0, new_n, s));
     RL_TRY(refresh_planes(idx, s));
@@ -1435,23 +1440,28 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
     // f = 0.19).  Both rounds append to the same lists.
     int st_pp = RL_ERR_UNSUPPORTED;
     int64_t round1_tiles = 0;
+    bool row_test = false;
     if (idx->opt.on(RL_OPT_FUSED_PP) && idx->dim % 32 == 0 && idx->dim >= 256) {
         int32_t log_cap = 0;
         const size_t work_bytes = pp_rows_scratch_bytes(n, B, idx->n_cu, (int32_t)std::min<int64_t>((int64_t)k * stride, cap), &log_cap);
         RL_TRY(idx->pp_work.reserve(work_bytes));
         const int64_t Tr = (n + 127) / 128;
+        // cosines over rows whose norms span more than a factor of four: the candidate pass tests its hits row by row (maxsim_pp.hip: the
+        // ROW-NORM variant) -- the block-wide bound would pass most of a block that holds a short row next to long ones
+        row_test = mode == SCAN_COSINE && !(idx->min_row_norm * 4.0f >= idx->max_row_norm);
         round1_tiles = (Tr >= 64 && idx->opt.on(RL_OPT_FUSED_TWO_ROUNDS)) ? (3 * Tr) / 16 : 0;  // (small corpora: one round)
         if (round1_tiles > 0) {
             RL_HIP(hipMemcpyAsync(thr1, thr, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));  // (kept for rl_time_kernel's replay)
-            st_pp = launch_pp_rows_pass(hi, n, idx->dim, B, qs, idx->norm, mode, &ca, idx->pp_work.p, log_cap, idx->n_cu, s, sscale, 0, round1_tiles);
+            st_pp = launch_pp_rows_pass(hi, n, idx->dim, B, qs, idx->norm, mode, &ca, idx->pp_work.p, log_cap, idx->n_cu, s, sscale, 0, round1_tiles, false,
+                                        row_test);
             if (st_pp == RL_OK) {
                 RL_TRY(launch_merge_topk(c_s, c_i, 1, B, cap, k, top_s, top_i, s, cnt));  // (top_s / top_i: the sample's top-k is not needed any more)
                 RL_TRY(launch_raise_threshold(thr, top_s, B, k, window, s));
                 st_pp = launch_pp_rows_pass(hi, n, idx->dim, B, qs, idx->norm, mode, &ca, idx->pp_work.p, log_cap, idx->n_cu, s, sscale, round1_tiles,
-                                            Tr - round1_tiles, true);
+                                            Tr - round1_tiles, true, row_test);
             }
         } else {
-            st_pp = launch_pp_rows_pass(hi, n, idx->dim, B, qs, idx->norm, mode, &ca, idx->pp_work.p, log_cap, idx->n_cu, s, sscale);
+            st_pp = launch_pp_rows_pass(hi, n, idx->dim, B, qs, idx->norm, mode, &ca, idx->pp_work.p, log_cap, idx->n_cu, s, sscale, 0, -1, false, row_test);
         }
         if (st_pp != RL_OK && st_pp != RL_ERR_UNSUPPORTED) return st_pp;
     }
@@ -1459,7 +1469,7 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
         RL_TRY(launch_score_planes_pass(hi, n, idx->dim, B, qs, nullptr, 0, idx->norm, idx->sumsq, mode, 1, nullptr, &ca, idx->n_cu, s, sscale, true, hi_only));
     {
         auto& r = idx->replay;
-        r.valid = true; r.pp = st_pp == RL_OK; r.B = B; r.mode = mode; r.qs = qs; r.ca = ca; r.cnt = cnt; r.thr1 = thr1; r.round1_tiles = round1_tiles;
+        r.valid = true; r.pp = st_pp == RL_OK; r.B = B; r.mode = mode; r.qs = qs; r.ca = ca; r.cnt = cnt; r.thr1 = thr1; r.round1_tiles = round1_tiles; r.row_test = row_test;
         r.pools[0] = idx->misc.p; r.pools[1] = idx->fused.p; r.pools[2] = idx->pp_work.p;
         int32_t lc = 0;
         (void)pp_rows_scratch_bytes(n, B, idx->n_cu, (int32_t)std::min<int64_t>((int64_t)k * stride, cap), &lc);
@@ -2510,13 +2520,13 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
                 CandArgs ca1 = r.ca;
                 ca1.tau = r.thr1;
                 st = launch_pp_rows_pass(idx->hi_image.p, idx->n_rows, idx->dim, r.B, r.qs, idx->norm, r.mode, &ca1, idx->pp_work.p, r.log_cap, idx->n_cu, s,
-                                         idx->split_scale, 0, r.round1_tiles);
+                                         idx->split_scale, 0, r.round1_tiles, false, r.row_test);
                 if (st == RL_OK)
                     st = launch_pp_rows_pass(idx->hi_image.p, idx->n_rows, idx->dim, r.B, r.qs, idx->norm, r.mode, &r.ca, idx->pp_work.p, r.log_cap, idx->n_cu, s,
-                                             idx->split_scale, r.round1_tiles, -1, true);
+                                             idx->split_scale, r.round1_tiles, -1, true, r.row_test);
             }
             else if (r.pp) st = launch_pp_rows_pass(idx->hi_image.p, idx->n_rows, idx->dim, r.B, r.qs, idx->norm, r.mode, &r.ca, idx->pp_work.p, r.log_cap,
-                                                    idx->n_cu, s, idx->split_scale);
+                                                    idx->n_cu, s, idx->split_scale, 0, -1, false, r.row_test);
             else st = launch_score_planes_pass(idx->hi_image.p, idx->n_rows, idx->dim, r.B, r.qs, nullptr, 0, idx->norm, idx->sumsq, r.mode, 1, nullptr, &r.ca,
                                                idx->n_cu, s, idx->split_scale, true, true);
         }

@@ -339,7 +339,8 @@ size_t pp_rows_scratch_bytes(int64_t n_rows, int32_t nb, int n_cu, int32_t expec
 // `work` are those of an earlier launch of the same search
 int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, const float* row_norm, int mode,
                         const CandArgs* cand, void* work, int32_t log_cap, int n_cu, hipStream_t s, float split_scale, int64_t tile_begin = 0,
-                        int64_t tile_count = -1, bool norms_ready = false);
+                        int64_t tile_count = -1, bool norms_ready = false,
+                        bool row_norm_test = false);  // cosine: test hits row by row against their own norms (wild norm spread)
 // thr[q] = max(thr[q], kth[q * k + k - 1] - window[q]): the k-th best approximate similarity of ANY subset of the rows bounds the k-th best
 // overall from below (select.hip; the second round of the fused top-k's candidate pass)
 int launch_raise_threshold(float* thr, const float* kth, int32_t nq, int32_t k, const float* window, hipStream_t s);

@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void row_dots_kernel(const float* __restrict__
     }
 }
 
-// bits[0] = max |e|, bits[1] = max |e_lo|, bits[2] = max |e_lo| / |e| over the rows (float bit patterns, each nudged up by 1e-6;
+// bits[0] = max |e|, bits[1] = max |e_lo|, bits[2] = max |e_lo| / |e|, bits[3] = min |e| over the rows (float bit patterns, the maxima nudged up by 1e-6;
 // non-negative floats order like their bits), where e_lo = e - fp16(e * scale) / scale is what the HI halves (rounded to nearest even,
 // as the plane and the image are built) drop -- computed exactly (the scale is a power of two, x - fp16(x) is exact in fp32).
 __global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restrict__ E, int64_t n_rows, int dim, float scale,
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restri
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = (int64_t)gridDim.x * 4;
     const float inv = 1.0f / scale;
-    float mx = 0.f, mlo = 0.f, mratio = 0.f;
+    float mx = 0.f, mlo = 0.f, mratio = 0.f, mn = INFINITY;
     for (int64_t r = wave0; r < n_rows; r += n_waves) {
         float ss = 0.f, sl = 0.f;
         for (int c = lane; c < dim; c += 64) {
@@ -331,10 +331,12 @@ __global__ __launch_bounds__(256) void max_row_norm_kernel(const float* __restri
         sl = wave_sum(sl);
         const float ne = sqrtf(ss), nl = sqrtf(sl);
         mx = fmaxf(mx, ne);
+        mn = fminf(mn, ne);
         mlo = fmaxf(mlo, nl);
         if (ne > 0.f) mratio = fmaxf(mratio, nl / ne);
     }
     if (lane == 0) {
+        if (mn < INFINITY) atomicMin(bits + 3, __float_as_uint(mn));  // bits[3] = min |e| (the caller starts it at its current minimum)
         if (mx > 0.f) atomicMax(bits + 0, __float_as_uint(mx * 1.000001f));
         if (mlo > 0.f) atomicMax(bits + 1, __float_as_uint(mlo * 1.000001f));
         if (mratio > 0.f) atomicMax(bits + 2, __float_as_uint(mratio * 1.000001f));

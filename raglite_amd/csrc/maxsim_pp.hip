@@ -587,34 +587,92 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
                 for (int c = 0; c < 4; ++c) t4[c] = fminf(t4[c] * nmin, t4[c] * nmax);
             }
             const uint32_t code_a = ((uint32_t)T << 13) | (uint32_t)(16 * a);
+            if constexpr ((DBG & 65536) != 0) {
+                // ROW-NORM variant (api.hip launches it for cosines over an index whose row norms span more than a factor of four): the
+                // block-wide bound is only the PREFILTER; a group that passes it is tested row by row against T * |e_row| -- the block's
+                // sixteen norms by ONE scalar load, only in blocks where some group gets that far.  With norms that differ wildly inside a
+                // block the block-wide bound passes nearly everything, the record logs fill and the dense path has to answer; on unit-norm
+                // corpora it costs 4 % for nothing (profiles/r04_ag_*), hence two instantiations.  The corpus' last, partial block keeps
+                // the block-wide bound (its norms end with the array).
+                float top4[4];
+                bool any_hit = false;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                // one test per (block, query column) on the largest of the lane's four rows; the rare group that has a hit (~0.2 % of the
-                // scores reach a threshold: about every other group of 256) is looked at register by register -- in a LOOP of four trips
-                // that rotates the four values through one register (this code exists once per block, slab parity and wave role: unrolled
-                // it alone would be larger than the instruction cache)
-                const f32x4 v4 = acc[c >> 1][c & 1][a];
-                const float top = fmaxf(fmaxf(v4[0], v4[1]), fmaxf(v4[2], v4[3]));
-                if (__builtin_amdgcn_ballot_w64(top >= t4[c]) != 0ull) {  // (wave-uniform)
-                    float r0 = v4[0], r1 = v4[1], r2 = v4[2], r3 = v4[3];
-                    uint32_t code = (code_a + ((uint32_t)c << 11)) | lane_code;
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 v4 = acc[c >> 1][c & 1][a];
+                    top4[c] = fmaxf(fmaxf(v4[0], v4[1]), fmaxf(v4[2], v4[3]));
+                    any_hit |= __builtin_amdgcn_ballot_w64(top4[c] >= t4[c]) != 0ull;
+                }
+                float nv0 = 1.f, nv1 = 1.f, nv2 = 1.f, nv3 = 1.f;
+                const bool row_norms = cosine && base + 16 <= (int32_t)n_rows;  // (wave-uniform)
+                if (any_hit && row_norms) {
+                    const f32x16s nr = pp_sload16(rs.row_norm + base);
+                    const int gq = lane >> 4;
+                    nv0 = gq == 0 ? nr[0] : gq == 1 ? nr[4] : gq == 2 ? nr[8] : nr[12];
+                    nv1 = gq == 0 ? nr[1] : gq == 1 ? nr[5] : gq == 2 ? nr[9] : nr[13];
+                    nv2 = gq == 0 ? nr[2] : gq == 1 ? nr[6] : gq == 2 ? nr[10] : nr[14];
+                    nv3 = gq == 0 ? nr[3] : gq == 1 ? nr[7] : gq == 2 ? nr[11] : nr[15];
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 v4 = acc[c >> 1][c & 1][a];
+                    if (__builtin_amdgcn_ballot_w64(top4[c] >= t4[c]) != 0ull) {  // (wave-uniform)
+                        float r0 = v4[0], r1 = v4[1], r2 = v4[2], r3 = v4[3];
+                        const float tc = tq4[c];
+                        float n0 = nv0, n1 = nv1, n2 = nv2, n3 = nv3;
+                        if (cosine && !row_norms) n0 = n1 = n2 = n3 = tc >= 0.f ? nmin : nmax;  // (nmin / nmax carry their 1e-6 already)
+                        uint32_t code = (code_a + ((uint32_t)c << 11)) | lane_code;
 #pragma nounroll
-                    for (int u = 0; u < 4; ++u) {
-                        const bool pass = r0 >= t4[c];
-                        const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
-                        if (mask != 0ull) {
-                            const uint32_t pos = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                            if constexpr (QREG) {
-                                if (pass && pos - ncand_out < LOG_CAP) l_log[pos - ncand_out] = make_uint2(__float_as_uint(r0), code);
-                            } else {
-                                if (pass && pos < (uint32_t)rs.log_cap) my_log[pos] = make_uint2(__float_as_uint(r0), code);
-                                ++n_st;
+                        for (int u = 0; u < 4; ++u) {
+                            const float tn = tc * n0;  // T |e_row|, widened by 1e-6 (one rounding here, none in the exact test)
+                            const bool pass = r0 >= fminf(tn * 0.999999f, tn * 1.000001f);
+                            const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
+                            if (mask != 0ull) {
+                                const uint32_t pos = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                                if constexpr (QREG) {
+                                    if (pass && pos - ncand_out < LOG_CAP) l_log[pos - ncand_out] = make_uint2(__float_as_uint(r0), code);
+                                } else {
+                                    if (pass && pos < (uint32_t)rs.log_cap) my_log[pos] = make_uint2(__float_as_uint(r0), code);
+                                    ++n_st;
+                                }
+                                ncand += (uint32_t)__builtin_popcountll(mask);
                             }
-                            ncand += (uint32_t)__builtin_popcountll(mask);
+                            r0 = r1; r1 = r2; r2 = r3;
+                            n0 = n1; n1 = n2; n2 = n3;
+                            ++code;
+                            asm volatile("" : "+v"(r0), "+v"(code), "+v"(n0));  // (keeps the loop a loop)
                         }
-                        r0 = r1; r1 = r2; r2 = r3;
-                        ++code;
-                        asm volatile("" : "+v"(r0), "+v"(code));  // (keeps the loop a loop)
+                    }
+                }
+            } else {
+    #pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // one test per (block, query column) on the largest of the lane's four rows; the rare group that has a hit (~0.2 % of the
+                    // scores reach a threshold: about every other group of 256) is looked at register by register -- in a LOOP of four trips
+                    // that rotates the four values through one register (this code exists once per block, slab parity and wave role: unrolled
+                    // it alone would be larger than the instruction cache)
+                    const f32x4 v4 = acc[c >> 1][c & 1][a];
+                    const float top = fmaxf(fmaxf(v4[0], v4[1]), fmaxf(v4[2], v4[3]));
+                    if (__builtin_amdgcn_ballot_w64(top >= t4[c]) != 0ull) {  // (wave-uniform)
+                        float r0 = v4[0], r1 = v4[1], r2 = v4[2], r3 = v4[3];
+                        uint32_t code = (code_a + ((uint32_t)c << 11)) | lane_code;
+    #pragma nounroll
+                        for (int u = 0; u < 4; ++u) {
+                            const bool pass = r0 >= t4[c];
+                            const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
+                            if (mask != 0ull) {
+                                const uint32_t pos = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                                if constexpr (QREG) {
+                                    if (pass && pos - ncand_out < LOG_CAP) l_log[pos - ncand_out] = make_uint2(__float_as_uint(r0), code);
+                                } else {
+                                    if (pass && pos < (uint32_t)rs.log_cap) my_log[pos] = make_uint2(__float_as_uint(r0), code);
+                                    ++n_st;
+                                }
+                                ncand += (uint32_t)__builtin_popcountll(mask);
+                            }
+                            r0 = r1; r1 = r2; r2 = r3;
+                            ++code;
+                            asm volatile("" : "+v"(r0), "+v"(code));  // (keeps the loop a loop)
+                        }
                     }
                 }
             }
@@ -982,7 +1040,7 @@ size_t pp_rows_scratch_bytes(int64_t n_rows, int32_t nb, int n_cu, int32_t expec
 // query side as launch_score_planes_queries left it; `work`: pp_rows_scratch_bytes bytes.  cosine / dot; dim % 32 == 0, dim >= 256.
 int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, const float* row_norm, int mode,
                         const CandArgs* cand, void* work, int32_t log_cap, int n_cu, hipStream_t s, float split_scale, int64_t tile_begin,
-                        int64_t tile_count, bool norms_ready) {
+                        int64_t tile_count, bool norms_ready, bool row_norm_test) {
     if (nb < 1 || n_rows < 1 || dim % 32 || dim < 256 || !(split_scale > 0.f) || !image || !cand || !work) return RL_ERR_UNSUPPORTED;
     if (mode != SCAN_COSINE && mode != SCAN_DOT) return RL_ERR_UNSUPPORTED;
     if (mode == SCAN_COSINE && !row_norm) return RL_ERR_INVALID;
@@ -1026,7 +1084,7 @@ int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t 
     static const bool stag = std::getenv("RAGLITE_PP_STAG") && std::getenv("RAGLITE_PP_STAG")[0] == '1';
     static const int qreg = std::getenv("RAGLITE_PP_QREG") ? std::atoi(std::getenv("RAGLITE_PP_QREG")) : -1;
     if (stag) { if (dbg == 128) RL_PP_ROWS_S(128, true); else RL_PP_ROWS_S(0, true); }
-    else if (qreg != 0 && dbg == 0) RL_PP_ROWS_Q(0);
+    else if (qreg != 0 && dbg == 0) { if (row_norm_test) RL_PP_ROWS_Q(65536); else RL_PP_ROWS_Q(0); }
     else if (qreg != 0 && dbg == 128) RL_PP_ROWS_Q(128);
     else if (qreg != 0 && dbg == 4096) RL_PP_ROWS_Q(4096);
     else if (dbg == 128) RL_PP_ROWS(128);
@@ -1034,7 +1092,10 @@ int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t 
     else if (dbg == 640) RL_PP_ROWS(640);
     else RL_PP_ROWS(0);
 #else
-    RL_PP_ROWS_Q(0);  // (query fragments to registers, records staged in LDS: QREG)
+    // (query fragments to registers, records staged in LDS: QREG; 65536 = the row-by-row cosine test in the hit path, for indexes whose row norms
+    // differ wildly)
+    if (row_norm_test) RL_PP_ROWS_Q(65536);
+    else RL_PP_ROWS_Q(0);
 #endif
 #undef RL_PP_ROWS_Q
 #undef RL_PP_ROWS_S

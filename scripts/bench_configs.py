@@ -237,7 +237,7 @@ def cfg5():
         try:  # the candidate pass alone, replayed with the thresholds of the search above, HIP events on the stream it runs on
             idx.time_kernel(8, Q[:1], 2)
             kernel_ms = idx.time_kernel(8, Q[:1], 10) / 10
-            kernel = ("rl::maxsim_pp_kernel<0, 2, false> (as rocprofv3 names it; the candidate pass on the 128-row x 512-query tile over the HI image, both rounds)" if idx.get_option("fused_pp") and d % 32 == 0 and d >= 256
+            kernel = ("rl::maxsim_pp_kernel<0, 2, false, true> (as rocprofv3 names it; the candidate pass on the 128-row x 512-query tile over the HI image, both rounds)" if idx.get_option("fused_pp") and d % 32 == 0 and d >= 256
                       else "maxsim_gemm_kernel<2, false, 2, true, true> (candidate pass on the 256 x 256 tile over the HI image)")
         except Exception as exc:  # noqa: BLE001
             kernel = f"(not timed: {exc})"

@@ -295,3 +295,34 @@ def test_fused_pp_integer_ties_and_lifecycle():
     live = np.setdiff1d(np.arange(n + 4000), dead)
     assert np.array_equal(live[R2], R1) and np.array_equal(S2.view(np.uint32), S1.view(np.uint32))
     idx.close()
+
+
+def test_fused_pp_rows_of_wildly_different_norms_stay_on_the_candidate_pass():
+    """Cosines over a corpus where a few thousand short rows (|e| ~ 0.02) sit among long ones (|e| ~ 13): the block-wide bound of the
+    candidate pass would pass most of every block that holds a short row -- the record logs fill and the dense path answers.  The index
+    knows the spread of its row norms (min / max |e|) and launches the variant that tests hits row by row: no fallback, the same result as
+    the dense path's ranking, the oracle's rows."""
+    import torch
+
+    raglite_amd.set_device(0)
+    n, dim, B, k = 162_724, 512, 512, 100
+    E = torch.empty((n, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=8500)
+    Q = torch.empty((B, dim), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=8501)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    hot = torch.randperm(n, device="cuda", generator=g)[:3000]
+    E[hot] = Q.mean(dim=0, keepdim=True) + 1e-3 * torch.randn((3000, dim), device="cuda", generator=g)
+    idx = raglite_amd.DeviceIndex(E, metric="cosine")
+    S, R = idx.search_rows(Q, k)
+    st = idx.filter_stats()
+    assert st["kind"] == "rows_fused_hi" and not st["fallback"], st
+    Eh = E.cpu().numpy()
+    for b in (0, B // 2, B - 1):
+        qh = Q[b].cpu().numpy()
+        assert_topk_close(S[b].cpu().numpy(), R[b].cpu().numpy(), oracle.similarity(Eh, qh, "cosine"), k, _tol(Eh, qh, "cosine"))
+    with idx.options(fused_pp=0):  # the eight-group tile tests row by row as well: same candidates' exact similarities, same bits
+        S0, R0 = idx.search_rows(Q, k)
+        assert not idx.filter_stats()["fallback"]
+    assert torch.equal(R, R0) and torch.equal(S.view(torch.int32), S0.view(torch.int32))
+    idx.close()
