@@ -138,3 +138,24 @@ def test_default_options_without_gpu():
     assert lib.rl_get_default_option(_abi.OPTIONS["fused_topk_cap"], C.byref(v)) == _abi.RL_OK and v.value == 64
     assert lib.rl_set_default_option(_abi.OPTIONS["fused_topk_cap"], 0) == _abi.RL_OK
     assert lib.rl_index_set_option(None, 1, 1) == _abi.RL_ERR_INVALID and lib.rl_index_get_option(None, 1, C.byref(v)) == _abi.RL_ERR_INVALID
+
+
+def test_option_keys_match_the_header_enum():
+    """`raglite_amd._abi.OPTIONS` is the Python spelling of `enum rl_option` in include/raglite_hip.h: same names, same numbers, and every
+    key the header declares is documented in its options table."""
+    import re
+    from pathlib import Path
+
+    from raglite_amd import _abi
+
+    text = (Path(__file__).resolve().parent.parent / "include" / "raglite_hip.h").read_text()
+    end = text.index("} rl_option;")
+    start = text.rindex("enum", 0, end)
+    body = text[start:end]
+    pairs = {m.group(1): int(m.group(2)) for m in re.finditer(r"RL_OPT_([A-Z0-9_]+)\s*=\s*(\d+)", body)}
+    count = pairs.pop("COUNT_")
+    assert count == max(pairs.values()) + 1 and sorted(pairs.values()) == list(range(1, count))
+    assert {name.lower(): key for name, key in pairs.items()} == _abi.OPTIONS
+    table = text[:start]
+    for name in pairs:
+        assert f"RL_OPT_{name} " in table or f"RL_OPT_{name}\n" in table, f"RL_OPT_{name} is not in the header's options table"
