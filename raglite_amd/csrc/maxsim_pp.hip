@@ -2,67 +2,45 @@
 // (up to 32 vectors each) per corpus pass over the HI image -- the fp16 hi halves of the corpus in the one-plane image layout of
 // maxsim_gemm.hip (preformat / presplit_hi_rows_kernel) -- at ONE fp16 MFMA product per multiply (q_hi . e_hi):
 //
-//   out[q * out_stride + c] ~ sum_{i < nq} max_{j in chunk c} Q_q[i] . D[j]      q = 0 .. n_q - 1  (n_q <= 16)
+//   out[q * out_stride + c] ~ sum_{i < nq} max_{j in chunk c} Q_q[i] . D[j]      q = 0 .. n_q - 1
 //
 // Multi-query generalisation of src/raglite/_search.py:143-149 / src/raglite/_query_adapter.py:174 behind the reranker plugin
 // call src/raglite/_search.py:394-396; what it drops (the corpus' and the queries' lo halves) is bounded rigorously by the caller,
 // which re-scores every chunk the bound cannot rule out with exact fp32 products (maxsim_pairs_kernel).
 //
-// Why a kernel of its own next to maxsim_gemm_kernel<.., HALF>.  Measured at the start of round 3 (profiles/r03_a_*): that kernel's
-// one-product pass takes 0.71 ms per eight queries where its 32 MFMAs per wave and slab are 0.26 ms of matrix pipe; a six-slot ring with
-// the query fragments three slabs ahead gets 0.65 -- the corpus stream was not what it waited for.  A wave there reads its corpus
-// fragments from LDS ONE pair of blocks ahead: with one product that covers 4 MFMAs (~130 cycles for the two waves of a SIMD), less than
-// an LDS round trip under load.  Here (DESIGN.md 4.1e has the measurements behind every point):
-//   * tile = 128 corpus rows x 512 query vectors (16 queries), K slabs of 32; wave w owns queries 2w and 2w + 1: the same 128
-//     accumulator registers (2 queries x 2 blocks of 16 vectors x 8 blocks of 16 rows), half the corpus bytes per query, 12 fragment
-//     reads per 32 MFMAs instead of 18.  The CORPUS block is the A operand of v_mfma_f32_16x16x32_f16: lane (g, n) of accumulator
-//     register u holds row 4 g + u of the block, query vector n of the register's set;
-//   * the CORPUS slabs (8 KiB, `nt`) go through LDS by `global_load_lds_dwordx4` into a ring, fed by waves 0-3 (one per SIMD; waves 4-7
-//     only multiply): a VMEM instruction holds its wave's issue until the address path takes it, and a wave that is held issues no MFMAs;
-//     with one feeder per SIMD its partner keeps the matrix pipe busy meanwhile (every wave feeding: 1.12 ms per pass against 1.00);
-//   * the QUERY fragments (32 KiB per slab, L2-resident) -- round 4, the shipped MaxSim pass (QREG): straight to REGISTERS.  A wave owns its
-//     two queries, nobody else reads their fragments: every wave issues four `global_load_dwordx4` at the top of slab g for slab g + 1, into
-//     the register set slab g - 1 multiplied from, and waits for them by COUNT at the end of the slab (VMEM returns in order: the feeders
-//     issue their two corpus pieces right AFTER the query loads, so those stay outstanding across the wait -- an HBM piece gets two slabs
-//     to land -- and the corpus ring is 8 slots deep with slab g + 6 issued during slab g).  That takes 80 % of the LDS-DMA instructions and a
-//     third of the fragment reads out of the loop and halves the LDS traffic (136 -> 72 KiB per slab and CU, against 128 B / clk): main
-//     loop 0.832 -> 0.784 ms.  The RESULTS then wait in the 96 KiB of LDS the query ring left free until the workgroup is done (or the
-//     buffer is nearly full): a store from the main loop sits in its wave's in-order queue in front of every later query load and takes
-//     ~2 us to retire (pass without any store 0.893 ms, with a store per block 0.981; results staged 0.895 -- profiles/r04_r_*).
-//     MODE 2 and the experiment builds keep the round-3 arrangement: query slabs through a second LDS ring of 4 (128 KiB), fed by the
-//     same four waves, 8 pieces per feeder and slab, `vmcnt(10)` + the barrier certifying slab g + 2;
-//   * a wave's fragments of slab g + 1 are read from LDS WHILE it multiplies slab g from registers -- each corpus fragment register is
-//     re-loaded right after its four MFMAs, the query fragments alternate between two register sets -- through inline asm, waited for by
-//     COUNT (LDS reads return in order: lgkmcnt(4) at the top of a slab, lgkmcnt(8) before the barrier);
-//   * ONE workgroup barrier per slab, HALF-WAY through it: the feeders' `vmcnt(10)` (VMEM retires in order) and the barrier certify
-//     slab g + 2 as landed and slab g's LDS slots as free; the four MFMA groups in front of it depend on nobody;
-//   * waves 4-7 issue every fragment read one MFMA group later than their SIMD partners (LAG), so one wave's LDS / DMA instructions sit
-//     beside the partner's MFMAs instead of beside the partner's own (- 5 %);
-//   * tile epilogue in REGISTERS (third version; the comment in front of it has the steps): permlane transposes put all 16 rows of a
-//     query vector in one lane, the per-chunk maximum is a running v_max down 16 registers with EXEC = 0 where a chunk ended, the sums over
-//     the 32 vectors are a bank-masked DPP reduction that halves the register count per step: ~93 VALU instructions per block, no LDS.
-//     Its stores share the in-order VMEM counter with the DMAs: the feeders count them (wave-uniform) and widen their next two waits by
-//     exactly that many.
-// Measured (1 M x 1024, 16 x 32 vectors), the LDS-ring arrangement: 0.91-0.97 ms per pass = 0.43-0.46 of the dense fp16 peak; MFMAs alone
-// 0.50, + fragment reads 0.65-0.68, + DMAs 0.88-0.94, + epilogue 0.91-1.0: the costs add.  QREG on the same box: 0.957 -> 0.895 ms.  The operand stream (40 KiB per slab and CU, 10.2 GB per launch over
-// an 18 TB/s path) is as close a bound as the matrix pipe.  Tried and removed: strictly alternating compute / load segments for the two
-// waves of a SIMD (on this tile and, as maxsim_pp2_kernel, on two row streams), every wave feeding, DMAs spread over the whole slab,
-// static wave priorities, the LDS-transposed and the DPP-scan epilogues.
+// The arrangement (DESIGN.md 4.1 has the measurements behind every point; what was tried and removed: docs/history_r04_pp_kernel.md):
+//   * tile = 128 corpus rows x 512 query vectors (16 queries), K slabs of 32; 8 waves, wave w owns queries 2w and 2w + 1: 128
+//     accumulator registers (2 queries x 2 blocks of 16 vectors x 8 blocks of 16 rows).  The CORPUS block is the A operand of
+//     v_mfma_f32_16x16x32_f16: lane (g, n) of accumulator register u holds row 4 g + u of the block, query vector n of the register's set;
+//   * the CORPUS slabs (8 KiB, `nt`) go through an LDS ring of 8 by `global_load_lds_dwordx4`, one 1-KiB piece per wave and slab, the
+//     pieces of slab g + 6 issued at the top of slab g (slot (g + 6) % 8 is neither slab g's, which a lagging wave may still read, nor
+//     g + 1's);
+//   * the QUERY fragments (32 KiB per slab, L2-resident) go STRAIGHT TO REGISTERS: a wave owns its two queries, nobody else reads their
+//     fragments.  Every wave issues four `global_load_dwordx4` at the top of slab g for slab g + 1, into the register set slab g - 1
+//     multiplied from, and waits for them BY COUNT at the end of the slab (VMEM returns in order: the corpus piece is issued right AFTER the
+//     query loads and stays outstanding across that wait -- an HBM piece gets two slabs to land);
+//   * NO store enters a wave's VMEM queue inside the loop (it would sit in front of every later query load and takes ~2 us to retire under
+//     this load): the RESULTS wait in the 96 KiB of LDS next to the ring (slot = the chunk's ordinal among the chunks the workgroup owns)
+//     and are written out with coalesced stores when the workgroup is done, or the buffer nearly full;
+//   * a wave's corpus fragments of slab g + 1 are read from LDS WHILE it multiplies slab g from registers -- each fragment register is
+//     re-loaded right after its four MFMAs -- through inline asm, waited for by COUNT (LDS reads return in order);
+//   * ONE workgroup barrier per slab, HALF-WAY through it; waves 4-7 issue every fragment read one MFMA group later than their SIMD
+//     partners (LAG), so one wave's LDS instructions sit beside the partner's MFMAs instead of beside the partner's own;
+//   * tile epilogue in REGISTERS (the comment in front of it has the steps): ~93 VALU instructions per 16-row block, no LDS traffic but
+//     the staged results.
 // Deterministic (fixed MFMA order per (query vector, row), fixed sum tree over the query vectors; independent of the grid);
 // integer-valued data is exact.  Same products and the same sums over K as maxsim_gemm_kernel's one-product pass; the 32 per-vector maxima
 // are added in another order: scores agree to the last bits, not bit for bit, on float data.  Needs an index without empty chunks (a chunk
 // is found by counting chunk ends), nq <= 32, dim % 32 == 0, dim >= 256.
 //
-// MODE 2 (round 4): the same main loop as the candidate pass of the fused exact row top-k (api.hip: search_rows_fused_hi; BASELINE cfg 5,
+// MODE 2: the same main loop as the candidate pass of the fused exact row top-k (api.hip: search_rows_fused_hi; BASELINE cfg 5,
 // src/raglite/_search.py:69-79 at B = 1000): a "query" of the tile is a GROUP of 32 single-vector queries (the fragment layout of
-// query_rows_planes_kernel is that of query_planes_kernel), a workgroup walks (128-row tile, 512-query tile) pairs, and the tile epilogue
-// compares every accumulator with its query's threshold -- one v_cmp + one scalar branch per register; for cosines against
-// thr_q * min / max |e| of the register's 16-row block (two scalars per block, a superset of the exact test) -- and appends what passes
-// to a WAVE-PRIVATE log in global memory (plain stores: LDS is full of operand rings, and a returning atomic per hit would stall the
-// epilogue for an L2 round trip).  When the workgroup is done each wave re-evaluates its records with the exact formulas of
-// maxsim_gemm.hip MODE 2 (same statements, same bits), keeps those that reach the threshold exactly, and appends them to the per-query
-// candidate lists (one atomic per record, ~1 400 records per wave at cfg 5).  A launch covers a RANGE of row tiles: api.hip runs the pass in
-// two rounds and tightens the thresholds between them.
+// query_rows_planes_kernel is that of query_planes_kernel), blockIdx.y = the query tile, and the tile epilogue compares every accumulator
+// with its query's threshold -- one test per (block, column set) on the largest of a lane's four rows; for cosines against
+// thr_q * min / max |e| of the register's 16-row block (a superset of the exact test) -- and appends what passes to a WAVE-PRIVATE log:
+// staged in LDS, moved to global memory in coalesced bursts.  When the workgroup is done each wave re-evaluates its records with the exact
+// formulas of maxsim_gemm.hip MODE 2 (same statements, same bits), keeps those that reach the threshold exactly, and appends them to the
+// per-query candidate lists.  A launch covers a RANGE of row tiles: api.hip runs the pass in two rounds and tightens the thresholds between.
 #include <cstdio>
 #include <cstdlib>
 #include <utility>
@@ -78,11 +56,11 @@ namespace {
 constexpr int PP_RT = 128;                       // corpus rows per tile
 constexpr int PP_NBLK = PP_RT / 16;              // 16-row blocks per tile
 constexpr int PP_QPP = 16;                       // queries per pass
-constexpr int PP_DC = 4, PP_DQ = 4;              // ring depths: corpus slabs, query slabs
+constexpr int PP_DC = 8;                         // corpus ring depth (slabs)
+constexpr int PP_LC = 6;                         // corpus look-ahead: the pieces of slab g + PP_LC are issued during slab g
 constexpr int PP_CSLOT = PP_NBLK * 1024;         // corpus slab: 8 blocks x 1 KiB
-constexpr int PP_QSLOT = PP_QPP * 2 * 1024;      // query slab: 16 queries x 2 blocks of 16 vectors x 1 KiB
-constexpr int PP_QOFF = PP_DC * PP_CSLOT;
-constexpr int PP_LDS = PP_QOFF + PP_DQ * PP_QSLOT;    // 32 + 128 = 160 KiB: all of a CU's LDS
+constexpr int PP_STAGE = 1536;                   // staged results per query (MODE 0) / records per wave (MODE 2)
+constexpr int PP_LDS = PP_DC * PP_CSLOT + 16 * PP_STAGE * 4;    // 64 + 96 = 160 KiB: all of a CU's LDS
 
 __device__ __forceinline__ int64_t pp_uniform_i64(int64_t v) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)v);
@@ -90,62 +68,30 @@ __device__ __forceinline__ int64_t pp_uniform_i64(int64_t v) {
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-// One 1-KiB piece HBM / L2 -> LDS: lane i copies 16 B from src + 16 i to lds + 16 i.  Invisible to the compiler's vmcnt
-// bookkeeping (asynchronous; certified by the explicit waits below).  NT: streamed once (corpus); plain: re-read by every
-// workgroup from L2 (queries).
-template <bool NT>
+// One 1-KiB piece HBM -> LDS: lane i copies 16 B from src + 16 i to lds + 16 i.  Invisible to the compiler's vmcnt bookkeeping
+// (asynchronous; certified by the explicit waits below).  `nt`: streamed once.
 __device__ __forceinline__ void pp_dma(uint32_t lds, const char* src, uint32_t lane16) {
     const uint32_t l = __builtin_amdgcn_readfirstlane(lds);
     const char* const p = reinterpret_cast<const char*>(pp_uniform_i64(reinterpret_cast<int64_t>(src)));
-    if constexpr (NT) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(l), "v"(lane16), "s"(p) : "memory", "m0");
-    else asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(l), "v"(lane16), "s"(p) : "memory", "m0");
-}
-
-// s_waitcnt vmcnt(BASE + extra), extra wave-uniform (the immediate cannot come from a register); more than 48 -- a tile of tiny
-// chunks stores that often -- drains the queue instead (vmcnt is a 6-bit field: BASE + 48 <= 63).
-template <int BASE>
-__device__ __forceinline__ void pp_wait_vm(int extra) {
-    if (extra == 0) {  // every slab but the few after a tile's epilogue
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE) : "memory");
-        return;
-    }
-#define PP_CASE(I) case I: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BASE + I) : "memory"); break;
-    switch (extra) {
-        PP_CASE(1) PP_CASE(2) PP_CASE(3) PP_CASE(4) PP_CASE(5) PP_CASE(6) PP_CASE(7) PP_CASE(8)
-        PP_CASE(9) PP_CASE(10) PP_CASE(11) PP_CASE(12) PP_CASE(13) PP_CASE(14) PP_CASE(15) PP_CASE(16)
-        PP_CASE(17) PP_CASE(18) PP_CASE(19) PP_CASE(20) PP_CASE(21) PP_CASE(22) PP_CASE(23) PP_CASE(24)
-        PP_CASE(25) PP_CASE(26) PP_CASE(27) PP_CASE(28) PP_CASE(29) PP_CASE(30) PP_CASE(31) PP_CASE(32)
-        PP_CASE(33) PP_CASE(34) PP_CASE(35) PP_CASE(36) PP_CASE(37) PP_CASE(38) PP_CASE(39) PP_CASE(40)
-        PP_CASE(41) PP_CASE(42) PP_CASE(43) PP_CASE(44) PP_CASE(45) PP_CASE(46) PP_CASE(47) PP_CASE(48)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-#undef PP_CASE
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt" ::"s"(l), "v"(lane16), "s"(p) : "memory", "m0");
 }
 
 // One LDS fragment read (64 lanes x 16 B) into 4 VGPRs, invisible to the compiler's lgkmcnt bookkeeping -- its own waits would sit in
 // front of every MFMA group (the loop body is not one basic block, and the pass gives up at the joins): the value is valid after the
-// `s_waitcnt lgkmcnt(0)` at the end of the slab + pp_pin().
+// counted `s_waitcnt lgkmcnt` + pp_pin().
 template <int OFF>
 __device__ __forceinline__ void pp_read(f32x4& dst, uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void pp_pin(f32x4& a, f32x4& b, f32x4& c, f32x4& d) { asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 // MODE 2: a load the compiler must not see (a compiler-visible VMEM load anywhere in the K loop makes its wait-count pass put
-// `s_waitcnt vmcnt(0)` at the loop header, which drains the feeders' look-ahead DMAs on every iteration) goes through the scalar cache:
-typedef float f32x2s __attribute__((ext_vector_type(2)));
+// `s_waitcnt vmcnt(0)` at the loop header, which drains the look-ahead DMAs on every iteration) goes through the scalar cache:
 typedef float f32x16s __attribute__((ext_vector_type(16)));
-// (the same for 16 floats at a 64-byte aligned address: a tile's eight (min, max) pairs)
+// 16 floats at a 64-byte aligned address: a tile's eight (min, max) pairs / a block's sixteen row norms
 __device__ __forceinline__ f32x16s pp_sload16(const float* p) {
     f32x16s v;
     const float* const u = reinterpret_cast<const float*>(pp_uniform_i64(reinterpret_cast<int64_t>(p)));
     asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(u) : "memory");
-    return v;
-}
-// two consecutive floats at a wave-uniform, 8-byte aligned address through the scalar cache (waits for it: also for the LDS reads in flight)
-__device__ __forceinline__ f32x2s pp_sload2(const float* p) {
-    f32x2s v;
-    const float* const u = reinterpret_cast<const float*>(pp_uniform_i64(reinterpret_cast<int64_t>(p)));
-    asm volatile("s_load_dwordx2 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(u) : "memory");
     return v;
 }
 __device__ __forceinline__ h16x8 pp_h(const f32x4& v) {
@@ -168,46 +114,17 @@ struct PpRows {
     int32_t tile_begin, tile_count;       // the 128-row tiles this launch covers: [tile_begin, tile_begin + tile_count)
 };
 
-// DBG (experiment builds only, -DRAGLITE_EXPERIMENTS + RAGLITE_PP_DBG / RAGLITE_PP_ROWS_DBG; wrong results): 2 = no MFMAs, 8 = no LDS fragment
-// reads, 16 = no corpus DMAs, 32 = no query DMAs, 64 = every corpus DMA re-reads the first tile (L2 hits), 128 = no block epilogues (the MFMAs
-// stay), 256 = no stores, 512 = MODE 2 without the flush of its record logs, 1024 = waves 4-7 run the stream of waves 0-3 (no lag),
-// 2048 = no LDS reads of the QUERY fragments
-//
-// STAG (round 4; an EXPERIMENT that is measured, correct, and NOT shipped -- the shipped instantiations have STAG = false): the epilogue of a
-// tile, block by block, INSIDE the main loop.  Every wave runs the eight block epilogues of a tile back to back after the tile's last K
-// slab -- ~750 VALU instructions (MODE 2: more, with its scalar branches) during which both waves of every SIMD issue no MFMA: 11 % of the
-// MaxSim pass and 20 % of the candidate pass of cfg 5 (profiles/r04_c_*).  With STAG the eight 16-row blocks of a tile run their K loop
-// ROTATED against each other: block a multiplies tile T during stream slabs [T nslab + a, (T + 1) nslab + a) -- K slabs a, a + 1, ..,
-// nslab - 1, 0, .., a - 1 of its rows (a dot product does not care about the order of its terms; integer data stays exact) -- so the
-// blocks finish in eight DIFFERENT slabs, one block's epilogue is issued by the lead wave of a SIMD right after the slab's barrier while its
-// partner issues MFMAs, and by the partner at the end of its slab while the lead wave issues the next slab's; the feeders fetch every block
-// from its own tile; a workgroup streams nt nslab + 8 slabs.  All 86 parity tests of the two modes pass with it.  Measured, same box
-// (profiles/r04_d_*): MaxSim pass 1.0425 ms against 1.0354 without, candidate pass of cfg 5 2.99 against 2.82 -- NO gain: the epilogue
-// costs the same 0.10 ms per pass wherever it runs.  The VALU instructions of one wave do not execute under the MFMAs of its SIMD partner:
-// the epilogue runs at exactly the VALU issue rate of a SIMD (2 waves x 750 instructions x 4 cycles per tile), and that time is taken from
-// the matrix pipe whether it is taken in one piece or in eight.  What is left is to make the epilogue SHORTER, not to move it.
-// QREG (round 4, MODE 0): the query fragments go STRAIGHT TO REGISTERS -- a wave owns its two queries, nobody else reads their fragments, so
-// the LDS ring they went through was 80 % of the LDS-DMA instructions, a third of the fragment reads and 128 of the 160 KiB: every wave
-// issues four global_load_dwordx4 at the top of slab g for the fragments of slab g + 1 (the register set the previous slab multiplied from)
-// and waits for them BY COUNT at the end of the slab -- VMEM returns in order, so the feeders issue their two corpus pieces right AFTER the
-// query loads (they stay outstanding across that wait: an HBM piece gets two slabs to land) and the corpus ring is 8 slots deep with the
-// pieces of slab g + 6 issued at the top of slab g (slot (g + 6) % 8 is neither slab g's, which a lagging wave may still read, nor g + 1's).
-template <int DBG, int MODE = 0, bool STAG = false, bool QREG = false>
+// DBG: timing skeletons (experiment builds only, -DRAGLITE_EXPERIMENTS + RAGLITE_PP_DBG / RAGLITE_PP_ROWS_DBG; WRONG results):
+// 2 = no MFMAs, 8 = no LDS fragment reads, 16 = no corpus DMAs, 32 = no query loads, 128 = no block epilogues (the MFMAs stay).
+// ROWNORM (MODE 2, cosine): the block-wide bound is only the PREFILTER; a group that passes it is tested row by row against T |e_row|.
+template <int DBG, int MODE, bool ROWNORM>
 __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restrict__ planes, int64_t n_rows, int32_t nslab,
                                                            const char* __restrict__ qfrag, const float* __restrict__ qmeta, int32_t n_q,
                                                            const int32_t* __restrict__ row_to_chunk, const int64_t* __restrict__ chunk_offsets,
                                                            const uint32_t* __restrict__ ends_bits, float* __restrict__ out, int64_t out_stride,
-                                                           float inv_e_scale, const uint32_t* __restrict__ run_if, unsigned long long* __restrict__ trace,
-                                                           PpRows rs) {
+                                                           float inv_e_scale, const uint32_t* __restrict__ run_if, PpRows rs) {
     constexpr bool ROWS = MODE == 2;
-    static_assert(!(QREG && STAG), "QREG: not with the staggered epilogues");
-    constexpr int DC = QREG ? 8 : PP_DC;        // corpus ring depth
-    constexpr int LC = QREG ? 6 : PP_DC;        // corpus look-ahead: the pieces of slab g + LC are issued during slab g
-    // QREG: the 96 KiB the query ring occupied hold the workgroup's RESULTS until it is done (8 waves x 2 queries x OUT_CAP chunk scores): a
-    // store per block in the main loop sits in its wave's in-order VMEM queue in front of every later query load, and a store takes ~2 us
-    // to retire under this load (measured: the pass without its stores 0.918 ms, with them 0.981; the LDS-ring kernel 0.954 / 0.985)
-    constexpr int OUT_CAP = 1536;
-    __shared__ __attribute__((aligned(16))) char smem[QREG ? 8 * PP_CSLOT + 16 * OUT_CAP * 4 : PP_LDS];
+    __shared__ __attribute__((aligned(16))) char smem[PP_LDS];
     if (run_if && __builtin_amdgcn_readfirstlane((int)*run_if) == 0) return;  // whole grid: a guarded launch that is not needed
     const int lane = threadIdx.x & 63;
     const int wv = wave_id();
@@ -241,46 +158,22 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     // passes instead of one per pass, so a pass's workgroups start on the CUs the previous pass's leave instead of behind a launch boundary
     const int qt = (int)blockIdx.y;
     const int q_base = ROWS ? 0 : PP_QPP * qt;  // first query of this workgroup's pass
-    constexpr int TAIL = STAG ? PP_NBLK : 0;    // slabs after the last tile's first block is done, for the blocks behind it
-    const int total = nt * nslab + TAIL;        // K slabs this workgroup streams
+    const int total = nt * nslab;               // K slabs this workgroup streams
     const int32_t last_blk = (int32_t)((n_rows + 15) >> 4) - 1;
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
     const uint32_t lane16 = 16u * lane;
-    auto lag_of = [](int a) { return STAG ? a : 0; };  // slabs by which block a's tiles start after block 0's
 
     // ---- this wave's queries: 2 wv and 2 wv + 1 ---------------------------------------------------------------------------------------
     const bool has0 = q_base + 2 * wv < n_q, has1 = q_base + 2 * wv + 1 < n_q;  // wave-uniform
-
-    // ---- feeder duty: waves 0-3 fetch query pieces 8 wv .. + 7 (piece = 2 * query + block of 16 vectors) of slab g + 4, then corpus
-    // blocks 2 wv, 2 wv + 1 of slab g + 4, during slab g ------------------------------------------------------------------------
-    // FEED8 (with QREG; DBG bit 4096 switches it off in experiment builds): every wave fetches ONE corpus piece per slab instead of waves 0-3
-    // two each -- with the query loads in every wave's queue anyway the waves are symmetric again (- 1 % per pass, profiles/r04_y_*)
-    constexpr bool FEED8 = QREG && (DBG & 4096) == 0;
-    constexpr int QPW = 8, CPW = FEED8 ? 1 : 2;  // pieces per feeder and slab
-    const bool feeder = FEED8 || wv < 4;
-    const int fw = FEED8 ? wv : (wv & 3);  // this feeder's number
-    const char* qb1[QPW];
-    int fq_s = 0, fq_slot = 0, fc_s = 0, fc_r = 0, fc_slot = 0;  // K slab (and round = tile of block 0) of the NEXT fetch, ring slots
-#pragma unroll
-    for (int i = 0; i < QPW; ++i) {
-        const int p = QPW * (wv & 3) + i;
-        int ql = 16 * qt + (p >> 1);
-        ql = ql < n_q ? ql : n_q - 1;  // (clamped: pieces of queries the pass does not have are copied from a valid one, never used)
-        qb1[i] = qfrag + pp_uniform_i64(((int64_t)ql * nslab * 4 + 2 * (p & 1)) * 1024);  // hi fragments of block p & 1
-    }
-    // QREG: this wave's own two queries, hi fragments of block 0 at K slab 0 (block 1: + 2 KiB; K slab s: + 4 KiB s)
-    const char* qp0 = qfrag;
-    const char* qp1 = qfrag;
-    if constexpr (QREG) {
-        int ql0 = PP_QPP * qt + 2 * wv, ql1 = PP_QPP * qt + 2 * wv + 1;
-        ql0 = ql0 < n_q ? ql0 : n_q - 1;  // (queries the pass does not have: a valid one's fragments, never emitted)
-        ql1 = ql1 < n_q ? ql1 : n_q - 1;
-        qp0 = qfrag + pp_uniform_i64((int64_t)ql0 * nslab * 4096);
-        qp1 = qfrag + pp_uniform_i64((int64_t)ql1 * nslab * 4096);
-    }
-    int qr_s = 0;  // QREG: K slab of the NEXT query-fragment load
+    // hi fragments of block 0 at K slab 0 (block 1: + 2 KiB; K slab s: + 4 KiB s)
+    int ql0 = PP_QPP * qt + 2 * wv, ql1 = PP_QPP * qt + 2 * wv + 1;
+    ql0 = ql0 < n_q ? ql0 : n_q - 1;  // (queries the pass does not have: a valid one's fragments, never emitted)
+    ql1 = ql1 < n_q ? ql1 : n_q - 1;
+    const char* const qp0 = qfrag + pp_uniform_i64((int64_t)ql0 * nslab * 4096);
+    const char* const qp1 = qfrag + pp_uniform_i64((int64_t)ql1 * nslab * 4096);
+    int qr_s = 0;  // K slab of the NEXT query-fragment load
     auto issue_qregs = [&](f32x4 (&qn)[4]) __attribute__((always_inline)) {
-        if constexpr (QREG && !(DBG & 32)) {
+        if constexpr (!(DBG & 32)) {
             const char* const a0 = reinterpret_cast<const char*>(pp_uniform_i64(reinterpret_cast<int64_t>(qp0 + (int64_t)qr_s * 4096)));
             const char* const a1 = reinterpret_cast<const char*>(pp_uniform_i64(reinterpret_cast<int64_t>(qp1 + (int64_t)qr_s * 4096)));
             asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:2048"
@@ -290,51 +183,20 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
             if (++qr_s == nslab) qr_s = 0;
         }
     };
-    auto issue_q = [&](int i) __attribute__((always_inline)) {
-        if (!feeder) return;
-        if constexpr (QREG) return;
-        if constexpr (DBG & 32) return;
-        pp_dma<false>(lds_base + (uint32_t)(PP_QOFF + fq_slot * PP_QSLOT + (QPW * wv + i) * 1024), qb1[i] + (int64_t)fq_s * 4096, lane16);
-    };
-    auto advance_q = [&]() __attribute__((always_inline)) {
-        if (++fq_s == nslab) fq_s = 0;
-        fq_slot = fq_slot + 1 == PP_DQ ? 0 : fq_slot + 1;
-    };
-    // corpus block a = 2 (wv & 3) + i of the slab being fetched: K slab fc_s of ITS current tile -- round fc_r once the slab index has
-    // reached the block's lag, the round before until then (before the first tile and after the last: some valid tile, multiplied into
-    // sums nobody reads)
-    const int32_t blk_org = (org >> 4) + CPW * fw;
+    // ---- feeder duty: every wave fetches corpus block wv of slab g + PP_LC during slab g ------------------------------------------------
+    int fc_s = 0, fc_r = 0, fc_slot = 0;  // K slab and tile of the NEXT fetch, its ring slot
+    const int32_t blk_org = (org >> 4) + wv;
     const int64_t slab_bytes = (int64_t)nslab * 1024;
-    auto issue_c1 = [&](auto I_) __attribute__((always_inline)) {
-        constexpr int i = decltype(I_)::value;
-        if (!feeder) return;
-        if constexpr (i >= CPW) return;
-        if constexpr (DBG & 16) return;
-        int t = fc_r - (fc_s < lag_of(CPW * fw + i) ? 1 : 0);
-        t = t < 0 ? 0 : (t < nt ? t : nt - 1);
-        if constexpr (DBG & 64) t = 0;  // (timing: the corpus stream out of L2)
-        int32_t blk = blk_org + i + t * PP_NBLK;
-        blk = blk < last_blk ? blk : last_blk;  // past the image: harmless re-read of the last block, never emitted
-        const char* src = planes + pp_uniform_i64((int64_t)blk * slab_bytes + (int64_t)fc_s * 1024);
-        pp_dma<true>(lds_base + (uint32_t)(fc_slot * PP_CSLOT + (CPW * fw + i) * 1024), src, lane16);
-    };
-    auto advance_c = [&]() __attribute__((always_inline)) {
+    auto issue_c = [&]() __attribute__((always_inline)) {
+        if constexpr (!(DBG & 16)) {
+            const int t = fc_r < nt ? fc_r : nt - 1;  // (after the last tile: some valid tile, multiplied into sums nobody reads)
+            int32_t blk = blk_org + t * PP_NBLK;
+            blk = blk < last_blk ? blk : last_blk;  // past the image: harmless re-read of the last block, never emitted
+            const char* src = planes + pp_uniform_i64((int64_t)blk * slab_bytes + (int64_t)fc_s * 1024);
+            pp_dma(lds_base + (uint32_t)(fc_slot * PP_CSLOT + wv * 1024), src, lane16);
+        }
         if (++fc_s == nslab) { fc_s = 0; ++fc_r; }
-        fc_slot = fc_slot + 1 == DC ? 0 : fc_slot + 1;
-    };
-    // A feeder's queue, old -> new, half-way through slab g: .. Q(g+2) x8, C(g+2) x2 | Q(g+3) x8, C(g+3) x2 -- everything up to its pieces of
-    // slab g + 2 has retired when 10 operations are outstanding, plus the epilogue stores issued since that are NEWER than the pieces of
-    // slab g + 2: st_a for the next wait, st_b for the one after.  A block epilogue right after the barrier of slab g (STAG, lead waves)
-    // stores before the DMAs of slab g + 4 are issued: it counts in the next wait only; an epilogue at the end of a slab stores after
-    // them: it counts in the next two.
-    int st_a = 0, st_b = 0;
-    [[maybe_unused]] int st_q = 0;  // QREG: stores issued since this slab's query loads
-    auto certify = [&]() __attribute__((always_inline)) {
-        if constexpr (!QREG) {
-            if (feeder) pp_wait_vm<QPW + CPW>(st_a);
-        }  // (QREG: every wave's wait for its query fragments at the end of a slab has retired its corpus pieces of two slabs ago)
-        st_a = st_b;
-        st_b = 0;
+        fc_slot = fc_slot + 1 == PP_DC ? 0 : fc_slot + 1;
     };
 
     // ---- accumulators: S[corpus row 16 a + 4 g + u][query vector 16 qb + n], lane = 16 g + n; [query of the wave][qb][a] ------
@@ -349,14 +211,11 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     // ---- fragment registers ---------------------------------------------------------------------------------------------------
     f32x4 ef[PP_NBLK];      // corpus blocks of the slab being multiplied (each re-loaded for the next slab right after its MFMAs)
     f32x4 qA[4], qB[4];     // query fragments [2 * query of the wave + qb], two sets alternating over slabs
-    int c_slot = 0, q_slot = 0;  // ring slots of the slab whose fragments are READ next
-    const uint32_t rd_c = lds_base + lane16, rd_q = lds_base + (uint32_t)(PP_QOFF + 4 * wv * 1024) + lane16;
-    auto read_slab = [&](f32x4 (&qn)[4], auto A_) __attribute__((always_inline)) {  // reads of step a: corpus block a (+ query fragment a)
+    int c_slot = 0;         // ring slot of the slab whose fragments are READ next
+    const uint32_t rd_c = lds_base + lane16;
+    auto read_slab = [&](auto A_) __attribute__((always_inline)) {  // corpus block a of the next slab
         constexpr int a = decltype(A_)::value;
-        if constexpr (!(DBG & 8)) {
-            pp_read<a * 1024>(ef[a], rd_c + (uint32_t)(c_slot * PP_CSLOT));
-            if constexpr (a < 4 && !(DBG & 2048) && !QREG) pp_read<a * 1024>(qn[a], rd_q + (uint32_t)(q_slot * PP_QSLOT));
-        }
+        if constexpr (!(DBG & 8)) pp_read<a * 1024>(ef[a], rd_c + (uint32_t)(c_slot * PP_CSLOT));
     };
     auto mfma_group = [&](f32x4 (&q)[4], auto A_) __attribute__((always_inline)) {
         constexpr int A = decltype(A_)::value;
@@ -380,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     //       v_permlane16_swap + add per PAIR of rows leaves rows r, r + 8 of both queries in the four lane groups), then a reduction over the 16
     //       lanes of a DPP row in which every step also halves the number of registers (bank-masked v_add_f32_dpp at distances 8 and 4,
     //       quad permutes for 2 and 1): 32 instructions, one register of results -- lane 16 G + 4 b + t holds row
-    //       (t >> 1) + 2 (b & 1) + 4 (b >> 1) + 8 (G & 1) of query G >> 1 -- and one masked store for all the chunks that end in the block.
+    //       (t >> 1) + 2 (b & 1) + 4 (b >> 1) + 8 (G & 1) of query G >> 1 -- staged in LDS for all the chunks that end in the block.
     const int fG = lane >> 4, fb = (lane >> 2) & 3, ft = lane & 3;
     const int my_row = (ft >> 1) + 2 * (fb & 1) + 4 * (fb >> 1) + 8 * (fG & 1);
     const uint32_t my_bit = 1u << my_row, my_below = my_bit - 1u;
@@ -391,22 +250,21 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     const int e_q = fG >> 1;
     const bool e_has = !ROWS && (e_q == 0 ? has0 : has1) && (ft & 1) == 0;  // (lanes t and t ^ 1 hold the same sum)
     const float e_unscale = e_has ? qmeta[2 * (q_base + 2 * wv + e_q)] * inv_e_scale : 0.f;
-    float* const e_out = out + (int64_t)(e_has ? q_base + 2 * wv + e_q : 0) * out_stride;
-    // QREG: results wait in LDS -- slot = the chunk's ordinal among the chunks this workgroup OWNS (they end inside [r_lo, r_hi): consecutive
+    // the results wait in LDS -- slot = the chunk's ordinal among the chunks this workgroup OWNS (they end inside [r_lo, r_hi): consecutive
     // ordinals from ord_lo on) minus what has been flushed
-    [[maybe_unused]] float* const o_buf = reinterpret_cast<float*>(smem + 8 * PP_CSLOT) + (2 * wv + e_q) * OUT_CAP;
-    [[maybe_unused]] const int32_t ord_lo = (QREG && !ROWS) ? __builtin_amdgcn_readfirstlane(row_to_chunk[r_lo]) : 0;
+    [[maybe_unused]] float* const o_buf = reinterpret_cast<float*>(smem + PP_DC * PP_CSLOT) + (2 * wv + e_q) * PP_STAGE;
+    [[maybe_unused]] const int32_t ord_lo = !ROWS ? __builtin_amdgcn_readfirstlane(row_to_chunk[r_lo]) : 0;
     [[maybe_unused]] int32_t own_cnt = 0, own_flushed = 0;  // owned chunks finished so far / already written out
     [[maybe_unused]] auto flush_out = [&]() __attribute__((always_inline)) {
-        if constexpr (QREG && !ROWS) {
+        if constexpr (!ROWS) {
             const int n = own_cnt - own_flushed;  // (wave-uniform)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own LDS writes
-            const float* const b0 = reinterpret_cast<const float*>(smem + 8 * PP_CSLOT) + (2 * wv) * OUT_CAP;
+            const float* const b0 = reinterpret_cast<const float*>(smem + PP_DC * PP_CSLOT) + (2 * wv) * PP_STAGE;
             float* const g0 = out + (int64_t)(q_base + 2 * wv) * out_stride + ord_lo + own_flushed;
             if (has0)
                 for (int i = lane; i < n; i += 64) g0[i] = b0[i];
             if (has1)
-                for (int i = lane; i < n; i += 64) g0[out_stride + i] = b0[OUT_CAP + i];
+                for (int i = lane; i < n; i += 64) g0[out_stride + i] = b0[PP_STAGE + i];
             own_flushed = own_cnt;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (rare: once per workgroup on RAGLite-shaped chunks)
         }
@@ -429,8 +287,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) acc[q][qb][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
     };
-    // returns the number of store instructions it issued (wave-uniform)
-    [[maybe_unused]] auto block_epilogue_maxsim = [&](auto A_, int T) __attribute__((always_inline)) -> int {
+    [[maybe_unused]] auto block_epilogue_maxsim = [&](auto A_, int T) __attribute__((always_inline)) {
         constexpr int a = decltype(A_)::value;
         const int32_t base = org + T * PP_RT + 16 * a;
         // "last row of its chunk" bits of the block's 16 rows: half a word of the bitmap
@@ -509,20 +366,12 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         hi = hi > 16 ? 16 : hi;
         uint32_t EM = E & ((1u << hi) - 1u) & ~((1u << lo) - 1u);
         asm("" : "+s"(EM));
-        int n_st = 0;
         if (EM != 0u) {  // wave-uniform: some chunk of this workgroup ends in this block
-            if constexpr (QREG) {
-                if ((EM & my_bit) && e_has) o_buf[ord_run - ord_lo - own_flushed + __builtin_popcount(E & my_below)] = w * e_unscale;
-                own_cnt += __builtin_popcount(EM);
-            } else {
-                if ((EM & my_bit) && e_has && !(DBG & 256)) e_out[ord_run + __builtin_popcount(E & my_below)] = w * e_unscale;
-                if constexpr (DBG & 256) run += w;  // (timing: no store, the sum stays live)
-                n_st = (DBG & 256) ? 0 : 1;
-            }
+            if ((EM & my_bit) && e_has) o_buf[ord_run - ord_lo - own_flushed + __builtin_popcount(E & my_below)] = w * e_unscale;
+            own_cnt += __builtin_popcount(EM);
         }
         ord_run += __builtin_popcount(E);
         zero_block(A_);
-        return n_st;
     };
 
     // MODE 2: threshold test of every accumulator of the block, records into the wave-private log.  Register (c = 2 q + qb, a, u), lane
@@ -535,12 +384,11 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     // they were what the allocator spilled, and a scratch reload inside the loop puts `s_waitcnt vmcnt(0)` at its header.
     [[maybe_unused]] float T4x = INFINITY;
     [[maybe_unused]] uint32_t ncand = 0;  // wave-uniform: records this wave has logged
-    // QREG: the records wait in LDS (the 96 KiB the query ring left: LOG_CAP records per wave) and go to the wave's log in global memory in
-    // coalesced bursts -- when the buffer is half full at the end of a tile, and when the workgroup is done; a store from the main loop would
-    // sit in front of every later query load of its wave (see the template's comment).  A tile that logs more than the buffer's free half
-    // loses records: the overflow flag, the dense path decides (as for a full global log).
-    constexpr uint32_t LOG_CAP = 1536;
-    [[maybe_unused]] uint2* const l_log = reinterpret_cast<uint2*>(smem + 8 * PP_CSLOT) + wv * LOG_CAP;
+    // The records wait in LDS (PP_STAGE per wave) and go to the wave's log in global memory in coalesced bursts -- when the buffer is half
+    // full at the end of a tile, and when the workgroup is done.  A tile that logs more than the buffer's free half loses records: the
+    // overflow flag, the dense path decides (as for a full global log).
+    constexpr uint32_t LOG_CAP = PP_STAGE;
+    [[maybe_unused]] uint2* const l_log = reinterpret_cast<uint2*>(smem + PP_DC * PP_CSLOT) + wv * LOG_CAP;
     [[maybe_unused]] uint32_t ncand_out = 0;  // records already moved to the global log
     [[maybe_unused]] uint2* const my_log = ROWS ? rs.log + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv) * (size_t)rs.log_cap : nullptr;
     [[maybe_unused]] const bool cosine = ROWS && rs.metric == SCAN_COSINE;
@@ -567,9 +415,8 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         for (int c = 0; c < 4; ++c)  // column set c's thresholds sit in lane group c of T4x
             tq4[c] = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(((uint32_t)c << 6) | b), __float_as_int(T4x)));
     };
-    [[maybe_unused]] auto block_epilogue_rows = [&](auto A_, int T, const float (&tq4)[4], float nmin, float nmax) __attribute__((always_inline)) -> int {
+    [[maybe_unused]] auto block_epilogue_rows = [&](auto A_, int T, const float (&tq4)[4], float nmin, float nmax) __attribute__((always_inline)) {
         constexpr int a = decltype(A_)::value;
-        int n_st = 0;
         const int32_t base = org + T * PP_RT + 16 * a;
         if (base < (int32_t)n_rows) {  // (wave-uniform) blocks past the corpus are re-reads of its last block: not scored
             // Opaque copy of the lane's coordinates: with the plain value every record word below is loop-invariant, the compiler hoists
@@ -587,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
                 for (int c = 0; c < 4; ++c) t4[c] = fminf(t4[c] * nmin, t4[c] * nmax);
             }
             const uint32_t code_a = ((uint32_t)T << 13) | (uint32_t)(16 * a);
-            if constexpr ((DBG & 65536) != 0) {
+            if constexpr (ROWNORM) {
                 // ROW-NORM variant (api.hip launches it for cosines over an index whose row norms span more than a factor of four): the
                 // block-wide bound is only the PREFILTER; a group that passes it is tested row by row against T * |e_row| -- the block's
                 // sixteen norms by ONE scalar load, only in blocks where some group gets that far.  With norms that differ wildly inside a
@@ -628,12 +475,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
                             const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
                             if (mask != 0ull) {
                                 const uint32_t pos = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                                if constexpr (QREG) {
-                                    if (pass && pos - ncand_out < LOG_CAP) l_log[pos - ncand_out] = make_uint2(__float_as_uint(r0), code);
-                                } else {
-                                    if (pass && pos < (uint32_t)rs.log_cap) my_log[pos] = make_uint2(__float_as_uint(r0), code);
-                                    ++n_st;
-                                }
+                                if (pass && pos - ncand_out < LOG_CAP) l_log[pos - ncand_out] = make_uint2(__float_as_uint(r0), code);
                                 ncand += (uint32_t)__builtin_popcountll(mask);
                             }
                             r0 = r1; r1 = r2; r2 = r3;
@@ -661,12 +503,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
                             const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
                             if (mask != 0ull) {
                                 const uint32_t pos = ncand + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                                if constexpr (QREG) {
-                                    if (pass && pos - ncand_out < LOG_CAP) l_log[pos - ncand_out] = make_uint2(__float_as_uint(r0), code);
-                                } else {
-                                    if (pass && pos < (uint32_t)rs.log_cap) my_log[pos] = make_uint2(__float_as_uint(r0), code);
-                                    ++n_st;
-                                }
+                                if (pass && pos - ncand_out < LOG_CAP) l_log[pos - ncand_out] = make_uint2(__float_as_uint(r0), code);
                                 ncand += (uint32_t)__builtin_popcountll(mask);
                             }
                             r0 = r1; r1 = r2; r2 = r3;
@@ -678,10 +515,9 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
             }
         }
         zero_block(A_);
-        return n_st;
     };
     [[maybe_unused]] auto dump_log = [&]() __attribute__((always_inline)) {  // LDS -> this wave's log in global memory
-        if constexpr (QREG && ROWS) {
+        if constexpr (ROWS) {
             uint32_t n = ncand - ncand_out;  // (wave-uniform)
             if (n > LOG_CAP) {  // a tile logged more than the buffer held: records were lost
                 if (lane == 0) *rs.overflow = 1u;
@@ -697,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     // When the workgroup's tiles are done: every record once more with the exact formulas (maxsim_gemm.hip flush_candidates: same
     // statements, same bits), kept if it reaches its query's threshold exactly, appended to the query's list.
     [[maybe_unused]] auto flush_rows = [&]() __attribute__((always_inline)) {
-        if constexpr (ROWS && !(DBG & 512)) {
+        if constexpr (ROWS) {
             if (ncand > (uint32_t)rs.log_cap) {  // (wave-uniform) more than the log holds: let the dense path decide
                 if (lane == 0) *rs.overflow = 1u;
                 ncand = (uint32_t)rs.log_cap;
@@ -724,199 +560,98 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
             }
         }
     };
-    // One block's epilogue for tile T of this workgroup (T outside [0, nt): sums nobody reads -- before a block's first tile, after its
-    // last); the stores it issued go into the feeders' wait bookkeeping: `both` = it ran at the END of a slab (see certify()).
-    // (A runtime block index -- one copy of this code for all eight blocks -- does not work: the accumulators would have to be indexed at
-    // run time, which puts them in scratch memory, or be merged over eight predecessors, which the register allocator answers with
-    // hundreds of spills: both tried, round 4.)
-    auto block_epilogue = [&](auto A_, int T, bool both) __attribute__((always_inline)) {
-        if constexpr (DBG & 128) return;
-        if (T < 0 || T >= nt) {  // (wave-uniform)
-            zero_block(A_);
-            return;
-        }
-        int n_st;
-        if constexpr (ROWS) {  // (the STAG arrangement: one block at a time, its thresholds and norm range fetched for it alone)
-            float tq4[4];
-            rows_thresholds(tq4);
-            float nmin = 1.f, nmax = 1.f;
-            if (cosine) {
-                const f32x2s mm = pp_sload2(rs.blk_minmax + 2 * ((org + T * PP_RT + 16 * decltype(A_)::value) >> 4));
-                nmin = mm[0];
-                nmax = mm[1];
-            }
-            n_st = block_epilogue_rows(A_, T, tq4, nmin, nmax);
-        } else {
-            n_st = block_epilogue_maxsim(A_, T);
-        }
-        st_a += n_st;
-        if (both) st_b += n_st;
-        st_q += n_st;
-    };
 
     // ---- one K slab: MFMAs of slab g from registers, and after each block's four MFMAs the LDS read that re-loads its fragment register for
-    // slab g + 1 (the query fragments go with the first four) -- the wave's 12 KiB of fragment reads spread over the whole slab.  HALF-WAY
-    // through, the feeders' wait and the workgroup barrier: they certify slab g + 2 as landed -- the reads of the NEXT slab may start with its
-    // first MFMA -- and slab g's LDS slots as free (everybody read them during slab g - 1): this wave's DMAs of slab g + 4 follow, between the
-    // remaining MFMAs.  No compiler-visible memory LOAD in here: the body carries no wait but the ones written out.
+    // slab g + 1.  HALF-WAY through, the workgroup barrier: with every wave's count-wait for its query fragments at the end of the previous slab
+    // (which retired its corpus piece of two slabs ago) it certifies slab g + 2 as landed and slab g's LDS slot as free.  No compiler-visible
+    // memory LOAD in here: the body carries no wait but the ones written out.
     // The two waves of a SIMD (w and w + 4) run the same stream half a step apart: waves 4-7 (LAG) issue each fragment read one MFMA group later
     // than waves 0-3, so that one wave's LDS instructions sit beside its partner's four MFMAs instead of beside the partner's own reads.
-    // Block epilogues (k = the slab's K index, r = its round: the tile block 0 is multiplying):
-    //   STAG, lead waves: right after the barrier -- block a of tile r - 1 at k = a - 1 (a = 1..3: its last MFMAs were in the first half of this
-    //                     slab) or k = a (a = 4..7: its last MFMAs were in the second half of the previous slab, its first of the next tile come
-    //                     later in this half); block 0 of tile r at k = nslab - 1;
-    //   STAG, lag waves:  at the end of the slab -- block a of tile r - 1 at k = a - 1, block 0 of tile r at k = nslab - 1;
-    //   !STAG:            all eight blocks of tile r at the end of slab nslab - 1.
-    // In every case a block's epilogue sits between its last MFMA of one tile and its first of the next, the epilogues of a wave run in
-    // row order (the open chunk's maximum and the chunk ordinal are carried from one to the next), and with dim = 256 (nslab = 8) the two
-    // epilogues that share slab 7 (block 7 of tile r - 1, block 0 of tile r) run in that order.
-    int c_s = 0, c_r = 0;  // K slab and round of the slab being multiplied
+    // The eight block epilogues of a tile run back to back at the end of its last slab (a runtime block index -- one copy of the epilogue code
+    // for all eight blocks -- does not work: the accumulators would have to be indexed at run time, which puts them in scratch memory, or be
+    // merged over eight predecessors, which the register allocator answers with hundreds of spills: both tried, round 4).
+    int c_s = 0, c_r = 0;  // K slab and tile of the slab being multiplied
 #define PP_I(N) std::integral_constant<int, N>{}
-    auto hook_mid = [&](auto LAG_) __attribute__((always_inline)) {
-        if constexpr (STAG && !decltype(LAG_)::value) {
-            if (c_s == 0) block_epilogue(PP_I(1), c_r - 1, false);
-            if (c_s == 1) block_epilogue(PP_I(2), c_r - 1, false);
-            if (c_s == 2) block_epilogue(PP_I(3), c_r - 1, false);
-            if (c_s == 4) block_epilogue(PP_I(4), c_r - 1, false);
-            if (c_s == 5) block_epilogue(PP_I(5), c_r - 1, false);
-            if (c_s == 6) block_epilogue(PP_I(6), c_r - 1, false);
-            if (c_s == 7) block_epilogue(PP_I(7), c_r - 1, false);
-            if (c_s == nslab - 1) block_epilogue(PP_I(0), c_r, false);
-        }
-    };
-    auto hook_end = [&](auto LAG_) __attribute__((always_inline)) {
-        if constexpr (STAG && decltype(LAG_)::value) {
-            if (c_s == 0) block_epilogue(PP_I(1), c_r - 1, true);
-            if (c_s == 1) block_epilogue(PP_I(2), c_r - 1, true);
-            if (c_s == 2) block_epilogue(PP_I(3), c_r - 1, true);
-            if (c_s == 3) block_epilogue(PP_I(4), c_r - 1, true);
-            if (c_s == 4) block_epilogue(PP_I(5), c_r - 1, true);
-            if (c_s == 5) block_epilogue(PP_I(6), c_r - 1, true);
-            if (c_s == 6) block_epilogue(PP_I(7), c_r - 1, true);
-            if (c_s == nslab - 1) block_epilogue(PP_I(0), c_r, true);
-        }
-        if constexpr (!STAG) {
-            if (c_s == nslab - 1) {  // the tile is complete: its eight blocks back to back
-                if constexpr (ROWS && !(DBG & 128)) {
-                    // ONE scalar load and one LDS round trip per tile: the eight (min, max) norm pairs (64 B) and the lane's four
-                    // thresholds -- a wait per block would expose a scalar-cache miss eight times per tile (the array has 625 KB)
-                    float tq4[4];
-                    rows_thresholds(tq4);
-                    f32x16s mm = {};
-                    if (cosine) mm = pp_sload16(rs.blk_minmax + 2 * ((org + c_r * PP_RT) >> 4));
-                    int n_st = 0;
-                    [&]<int... A>(std::integer_sequence<int, A...>) {
-                        ((n_st += block_epilogue_rows(std::integral_constant<int, A>{}, c_r, tq4, mm[2 * A], mm[2 * A + 1])), ...);
-                    }(std::make_integer_sequence<int, PP_NBLK>{});
-                    st_a += n_st;
-                    st_b += n_st;
-                    if constexpr (QREG) {
-                        if (ncand - ncand_out > LOG_CAP / 2) dump_log();
-                    }
-                } else {
-                    [&]<int... A>(std::integer_sequence<int, A...>) { (block_epilogue(std::integral_constant<int, A>{}, c_r, true), ...); }
-                    (std::make_integer_sequence<int, PP_NBLK>{});
-                    if constexpr (QREG) {
-                        if (own_cnt - own_flushed > OUT_CAP - PP_RT) flush_out();  // (a tile finishes at most PP_RT chunks)
-                    }
-                }
+    auto tile_end = [&]() __attribute__((always_inline)) {
+        if constexpr (DBG & 128) return;
+        if (c_s == nslab - 1) {  // the tile is complete: its eight blocks back to back
+            if constexpr (ROWS) {
+                // ONE scalar load and one LDS round trip per tile: the eight (min, max) norm pairs (64 B) and the lane's four
+                // thresholds -- a wait per block would expose a scalar-cache miss eight times per tile (the array has 625 KB)
+                float tq4[4];
+                rows_thresholds(tq4);
+                f32x16s mm = {};
+                if (cosine) mm = pp_sload16(rs.blk_minmax + 2 * ((org + c_r * PP_RT) >> 4));
+                [&]<int... A>(std::integer_sequence<int, A...>) {
+                    (block_epilogue_rows(std::integral_constant<int, A>{}, c_r, tq4, mm[2 * A], mm[2 * A + 1]), ...);
+                }(std::make_integer_sequence<int, PP_NBLK>{});
+                if (ncand - ncand_out > LOG_CAP / 2) dump_log();
+            } else {
+                [&]<int... A>(std::integer_sequence<int, A...>) { (block_epilogue_maxsim(std::integral_constant<int, A>{}, c_r), ...); }
+                (std::make_integer_sequence<int, PP_NBLK>{});
+                if (own_cnt - own_flushed > PP_STAGE - PP_RT) flush_out();  // (a tile finishes at most PP_RT chunks)
             }
         }
     };
     auto slab = [&](f32x4 (&q)[4], f32x4 (&qn)[4], auto LAG_) __attribute__((always_inline)) {
         constexpr bool LAG = decltype(LAG_)::value;
         auto G = [&](auto A_) __attribute__((always_inline)) { mfma_group(q, A_); };
-        auto R = [&](auto A_) __attribute__((always_inline)) { read_slab(qn, A_); };
-        auto D = [&](auto B_) __attribute__((always_inline)) {  // a quarter of this wave's query pieces of slab g + 4
-            constexpr int B = decltype(B_)::value;
-            issue_q(2 * B);
-            issue_q(2 * B + 1);
-        };
-        if constexpr (QREG) {  // the query fragments of the next slab, then (feeders) the corpus pieces of slab g + LC: see the template's comment
-            issue_qregs(qn);
-            issue_c1(PP_I(0));
-            issue_c1(PP_I(1));
-            advance_c();
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        auto R = [&](auto A_) __attribute__((always_inline)) { read_slab(A_); };
+        // the query fragments of the next slab, then the corpus piece of slab g + PP_LC
+        issue_qregs(qn);
+        issue_c();
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (!LAG) {
             G(PP_I(0)); R(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
             G(PP_I(1)); R(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
             G(PP_I(2)); R(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
             G(PP_I(3)); R(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
             // the reads of the previous slab's second half: corpus blocks 4-7 of slab g (issued half a slab ago)
-            if constexpr (QREG) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
         } else {
             G(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
             G(PP_I(1)); R(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
             G(PP_I(2)); R(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
             G(PP_I(3)); R(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
-            if constexpr (QREG) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
         }
         pp_pin(ef[4], ef[5], ef[6], ef[7]);
-        certify();  // this wave's pieces of slab g + 2
         asm volatile("s_barrier" ::: "memory");  // slab g + 2 is readable from the next slab on; everybody finished reading slab g (its last reads were waited for just above)
-        hook_mid(LAG_);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (!LAG) {
-            G(PP_I(4)); R(PP_I(4)); D(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(5)); R(PP_I(5)); D(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(6)); R(PP_I(6)); D(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(7)); R(PP_I(7)); D(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(4)); R(PP_I(4)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(5)); R(PP_I(5)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(6)); R(PP_I(6)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(7)); R(PP_I(7)); __builtin_amdgcn_sched_barrier(0);
         } else {
-            G(PP_I(4)); R(PP_I(3)); D(PP_I(0)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(5)); R(PP_I(4)); D(PP_I(1)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(6)); R(PP_I(5)); D(PP_I(2)); __builtin_amdgcn_sched_barrier(0);
-            G(PP_I(7)); R(PP_I(6)); D(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(4)); R(PP_I(3)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(5)); R(PP_I(4)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(6)); R(PP_I(5)); __builtin_amdgcn_sched_barrier(0);
+            G(PP_I(7)); R(PP_I(6)); __builtin_amdgcn_sched_barrier(0);
             R(PP_I(7)); __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (!QREG) {
-            issue_c1(PP_I(0));
-            issue_c1(PP_I(1));
-            advance_q();
-            advance_c();
-        }
-        c_slot = c_slot + 1 == DC ? 0 : c_slot + 1;
-        q_slot = q_slot + 1 == PP_DQ ? 0 : q_slot + 1;
-        hook_end(LAG_);
+        c_slot = c_slot + 1 == PP_DC ? 0 : c_slot + 1;
+        tile_end();
         if (++c_s == nslab) { c_s = 0; ++c_r; }
     };
-    // LDS reads return in order: with the four reads of blocks 4-7 still outstanding, the eight in front of them (blocks 0-3 and the query
-    // fragments of slab g + 1) are real values now -- a wait that was served half a slab ago instead of one that exposes an LDS round trip
-    // under load at the end of every slab (lgkmcnt(0) there: + 0.18 ms per pass).  Blocks 4-7 are waited for before the next barrier.
+    // LDS reads return in order: with the four reads of blocks 4-7 still outstanding, the four in front of them (blocks 0-3 of slab g + 1)
+    // are real values now -- a wait that was served half a slab ago instead of one that exposes an LDS round trip under load at the end of
+    // every slab.  Blocks 4-7 are waited for before the next barrier.  This wave's VMEM queue, old -> new: .. C(g + LC - 1) | Q(g + 1) x4,
+    // C(g + LC): the query fragments have landed when only the piece that follows them is outstanding.
     auto landed = [&](f32x4 (&qn)[4]) __attribute__((always_inline)) {
         asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
-        if constexpr (QREG) {
-            // this wave's queue, old -> new: .. C(g + LC - 1) x2 | Q(g + 1) x4, C(g + LC) x2 [feeders], the stores of this slab's epilogue:
-            // the query fragments have landed when only what follows them is outstanding
-            const int extra = st_q;  // (0 in this kernel: its results wait in LDS; kept for a variant that stores from the main loop)
-            st_q = 0;
-            if (feeder) pp_wait_vm<CPW>(extra);
-            else pp_wait_vm<0>(extra);
-        }
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         pp_pin(ef[0], ef[1], ef[2], ef[3]);
         pp_pin(qn[0], qn[1], qn[2], qn[3]);
     };
 
-    // ---- prologue: Q(0..3), C(0..3) landed (the steady state issues Q(g + 4), C(g + 4) during slab g); slab 0's fragments ----------
-    if (feeder) {
-        for (int i = 0; i < LC; ++i) {
-            issue_c1(PP_I(0));
-            issue_c1(PP_I(1));
-#pragma unroll
-            for (int j = 0; j < QPW; ++j) issue_q(j);
-            advance_q();
-            advance_c();
-        }
-    }
-    issue_qregs(qA);  // (QREG: slab 0's query fragments)
+    // ---- prologue: C(0 .. LC - 1) and slab 0's query fragments landed; slab 0's corpus fragments ------------------------------------------
+    for (int i = 0; i < PP_LC; ++i) issue_c();
+    issue_qregs(qA);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-    [&]<int... A>(std::integer_sequence<int, A...>) { (read_slab(qA, std::integral_constant<int, A>{}), ...); }
+    [&]<int... A>(std::integer_sequence<int, A...>) { (read_slab(std::integral_constant<int, A>{}), ...); }
     (std::make_integer_sequence<int, PP_NBLK>{});
     c_slot = 1;
-    q_slot = 1;
     landed(qA);
     // ---- main loop: two slabs per iteration (two static sets of query fragment registers) -----------------------------------------
     auto main_loop = [&](auto LAG_) __attribute__((always_inline)) {
@@ -930,15 +665,14 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         }
     };
 #undef PP_I
-    constexpr bool no_lag = (DBG & 1024) != 0;  // (timing: every wave runs the same stream)
-    if (wv < 4 || no_lag) main_loop(std::false_type{});
+    if (wv < 4) main_loop(std::false_type{});
     else main_loop(std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // look-ahead DMAs must not outlive the workgroup's LDS
     dump_log();
     flush_rows();
-    if constexpr (QREG) flush_out();
+    flush_out();
     if constexpr (DBG & 128) {  // (timing without the epilogue: the accumulators must stay live, or the compiler deletes the MFMAs with it)
-        if (n_q > 1000) {
+        if (n_q > 1000000) {
             f32x4 t = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -958,53 +692,29 @@ int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void*
                      int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits, float* out,
                      int64_t out_stride, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if) {
     if (nq < 1 || nq > 32 || n_q < 1 || n_q > PP_QPP * 4096 || n_rows < 1 || first < 0 || first + n_q > n_queries) return RL_ERR_UNSUPPORTED;
-    // dim >= 256: a tile's epilogue stores must have left the VMEM counter's window before the next tile's (see certify())
     if (dim % 32 || dim < 256 || !(split_scale > 0.f) || !image || !ends_bits) return RL_ERR_UNSUPPORTED;
     const int32_t nslab = dim / 32;
     const char* qfrag = static_cast<const char*>(qbuf) + (size_t)first * nslab * 4096;
     const float* qmeta = reinterpret_cast<const float*>(static_cast<const char*>(qbuf) + (size_t)n_queries * dim * 128) + 2 * (size_t)first;
     const int64_t tiles = (n_rows + PP_RT - 1) / PP_RT;
     const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(n_cu > 0 ? n_cu : 256, tiles)), (unsigned)((n_q + PP_QPP - 1) / PP_QPP)), blk(512);
-    unsigned long long* const trace = nullptr;
-#define RL_PP_LAUNCH_S(DBG_, STAG_)                                                                                                     \
-    hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 0, STAG_>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk, \
-                       chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if, trace, PpRows{})
-#define RL_PP_LAUNCH(DBG_) RL_PP_LAUNCH_S(DBG_, false)
+#define RL_PP_LAUNCH(DBG_)                                                                                                                 \
+    hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 0, false>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk, \
+                       chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if, PpRows{})
 #ifdef RAGLITE_EXPERIMENTS
-    // Experiment builds only (libraglite_hip_exp.so, scripts/gpu_calls/): instantiations that skip parts of the kernel to time the rest --
-    // WRONG results -- RAGLITE_PP_STAG=1, the block epilogues inside the main loop (correct results; measured, not shipped: see STAG), and
-    // RAGLITE_PP_QREG=0, the round-3 arrangement with the query fragments through an LDS ring (correct results; for A/B runs).
-    // None of this is compiled into the shipped library.
+    // Experiment builds only (libraglite_hip_exp.so, scripts/gpu_calls/): timing skeletons that skip parts of the kernel -- WRONG results.
     static const int dbg = std::getenv("RAGLITE_PP_DBG") ? std::atoi(std::getenv("RAGLITE_PP_DBG")) : 0;
-    static const bool stag = std::getenv("RAGLITE_PP_STAG") && std::getenv("RAGLITE_PP_STAG")[0] == '1';
-    static const int qreg = std::getenv("RAGLITE_PP_QREG") ? std::atoi(std::getenv("RAGLITE_PP_QREG")) : -1;
-#define RL_PP_LAUNCH_Q(DBG_)                                                                                                              \
-    hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 0, false, true>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk, \
-                       chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if, trace, PpRows{})
-    if (qreg != 0 && !stag && (dbg == 0 || dbg == 128 || dbg == 256 || dbg == 4096)) {
-        if (dbg == 128) RL_PP_LAUNCH_Q(128); else if (dbg == 256) RL_PP_LAUNCH_Q(256); else if (dbg == 4096) RL_PP_LAUNCH_Q(4096); else RL_PP_LAUNCH_Q(0);
-    }
-    else if (stag) { if (dbg == 128) RL_PP_LAUNCH_S(128, true); else RL_PP_LAUNCH_S(0, true); }
-    else if (dbg == 2) RL_PP_LAUNCH(2);
-    else if (dbg == 1024) RL_PP_LAUNCH(1024);
-    else if (dbg == 2208) RL_PP_LAUNCH(2208);
-    else if (dbg == 160) RL_PP_LAUNCH(160);
-    else if (dbg == 2176) RL_PP_LAUNCH(2176);
-    else if (dbg == 176) RL_PP_LAUNCH(176);
-    else if (dbg == 184) RL_PP_LAUNCH(184);
+    if (dbg == 2) RL_PP_LAUNCH(2);
     else if (dbg == 128) RL_PP_LAUNCH(128);
-    else if (dbg == 256) RL_PP_LAUNCH(256);
+    else if (dbg == 136) RL_PP_LAUNCH(136);
+    else if (dbg == 144) RL_PP_LAUNCH(144);
+    else if (dbg == 160) RL_PP_LAUNCH(160);
+    else if (dbg == 184) RL_PP_LAUNCH(184);
     else RL_PP_LAUNCH(0);
 #else
-    // the shipped pass: query fragments straight to registers, results staged in LDS (QREG)
-    hipLaunchKernelGGL((maxsim_pp_kernel<0, 0, false, true>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, qfrag, qmeta, n_q, row_to_chunk,
-                       chunk_offsets, ends_bits, out, out_stride, 1.0f / split_scale, run_if, trace, PpRows{});
+    RL_PP_LAUNCH(0);
 #endif
-#undef RL_PP_LAUNCH_S
 #undef RL_PP_LAUNCH
-#ifdef RAGLITE_EXPERIMENTS
-#undef RL_PP_LAUNCH_Q
-#endif
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -1072,33 +782,19 @@ int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t 
     // blockIdx.y = the query tile; the workgroups of a grid row share the row tiles (QT <= CUs: checked above)
     const int64_t gx = std::max<int64_t>(1, std::min<int64_t>(grid_cu / rs.QT, Tr));
     const dim3 grid((unsigned)gx, (unsigned)rs.QT), blk(512);
-#define RL_PP_ROWS_S(DBG_, STAG_)                                                                                                         \
-    hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 2, STAG_>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, reinterpret_cast<const char*>(frag), \
-                       nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, nullptr, nullptr, rs)
-#define RL_PP_ROWS(DBG_) RL_PP_ROWS_S(DBG_, false)
-#define RL_PP_ROWS_Q(DBG_)                                                                                                                \
-    hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 2, false, true>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, reinterpret_cast<const char*>(frag), \
-                       nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, nullptr, nullptr, rs)
-#ifdef RAGLITE_EXPERIMENTS  // timing skeletons (wrong results): 128 = no block epilogues, 512 = no flush of the record logs, 640 = neither; RAGLITE_PP_STAG=1
+#define RL_PP_ROWS(DBG_, RN_)                                                                                                             \
+    hipLaunchKernelGGL((maxsim_pp_kernel<DBG_, 2, RN_>), grid, blk, 0, s, static_cast<const char*>(image), n_rows, nslab, reinterpret_cast<const char*>(frag), \
+                       nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 1.0f / split_scale, nullptr, rs)
+#ifdef RAGLITE_EXPERIMENTS  // timing skeleton (wrong results): 128 = no block epilogues
     static const int dbg = std::getenv("RAGLITE_PP_ROWS_DBG") ? std::atoi(std::getenv("RAGLITE_PP_ROWS_DBG")) : 0;
-    static const bool stag = std::getenv("RAGLITE_PP_STAG") && std::getenv("RAGLITE_PP_STAG")[0] == '1';
-    static const int qreg = std::getenv("RAGLITE_PP_QREG") ? std::atoi(std::getenv("RAGLITE_PP_QREG")) : -1;
-    if (stag) { if (dbg == 128) RL_PP_ROWS_S(128, true); else RL_PP_ROWS_S(0, true); }
-    else if (qreg != 0 && dbg == 0) { if (row_norm_test) RL_PP_ROWS_Q(65536); else RL_PP_ROWS_Q(0); }
-    else if (qreg != 0 && dbg == 128) RL_PP_ROWS_Q(128);
-    else if (qreg != 0 && dbg == 4096) RL_PP_ROWS_Q(4096);
-    else if (dbg == 128) RL_PP_ROWS(128);
-    else if (dbg == 512) RL_PP_ROWS(512);
-    else if (dbg == 640) RL_PP_ROWS(640);
-    else RL_PP_ROWS(0);
+    if (dbg == 128) RL_PP_ROWS(128, false);
+    else if (row_norm_test) RL_PP_ROWS(0, true);
+    else RL_PP_ROWS(0, false);
 #else
-    // (query fragments to registers, records staged in LDS: QREG; 65536 = the row-by-row cosine test in the hit path, for indexes whose row norms
-    // differ wildly)
-    if (row_norm_test) RL_PP_ROWS_Q(65536);
-    else RL_PP_ROWS_Q(0);
+    // (ROWNORM: the row-by-row cosine test in the hit path, for indexes whose row norms differ wildly)
+    if (row_norm_test) RL_PP_ROWS(0, true);
+    else RL_PP_ROWS(0, false);
 #endif
-#undef RL_PP_ROWS_Q
-#undef RL_PP_ROWS_S
 #undef RL_PP_ROWS
     RL_HIP(hipGetLastError());
     return RL_OK;
