@@ -29,7 +29,7 @@ Extra objects in the JSON line (rank 0; all but `roofline` at N = 1 only):
   recall_at_100 / score_*  all QUERIES_PER_STEP queries of the last timed step against the fp32 NumPy oracle on the
                 full corpus, and against a float64 reference on a >= 50 k-row slab
   cpu_baseline  the NumPy oracle on the host cores (the time of that full-corpus check)
-  configs       BASELINE.json configs 2-5 on one GPU (scripts/bench_configs.py), outside the headline's timed region
+  configs       BASELINE.json configs 1-5 on one GPU (scripts/bench_configs.py), outside the headline's timed region
   raglite_shaped  the headline pipeline on unit-norm fp16-rounded and on clustered corpora (what RAGLite stores): throughput,
                 candidates per query, fallback, float64 parity at 1e-4 absolute
   candidates_per_query / fallback_steps  what the bound-filtered pipeline did on the headline's own data
@@ -281,8 +281,8 @@ def main() -> None:
     iters = 20
     rows_local = r_hi - r_lo
     elt = 4.0 if args.storage == "f32" else 2.0
-    algo_bytes = elt * rows_local * DIM  # 4*N*d bytes per corpus pass (2*N*d when fp16-stored)
-    streamed_bytes = algo_bytes
+    algo_bytes_per_pass = elt * rows_local * DIM  # 4*N*d bytes per corpus pass (2*N*d when fp16-stored)
+    streamed_bytes = algo_bytes_per_pass
     kind, per_launch = 0, 1
     # (the approximate pass multiplies q_hi.e_hi only -- kind 6; option hi_products = 2: two products -- kind 5)
     # kind 7: SIXTEEN queries per pass through maxsim_pp.hip (the default); option pp_pass = 0: the eight-query pass (kind 6)
@@ -304,7 +304,9 @@ def main() -> None:
         # that rocprofv3 sees -- is that one, per_launch queries = per_launch / 16 passes over the HI image
         per_launch = (qps // 16) * 16
     passes_per_launch = per_launch // 16 if kind == 7 else 1
-    algo_bytes *= passes_per_launch
+    # two variables on purpose (round 4 printed an HBM fraction of 6.08 by reusing the per-LAUNCH figure for a one-pass kernel):
+    # `algo_bytes_per_pass` is one corpus pass, `algo_bytes_per_launch` what the timed launch of `passes_per_launch` passes stands for
+    algo_bytes_per_launch = algo_bytes_per_pass * passes_per_launch
     if kind in (5, 6, 7):
         streamed_bytes = 2.0 * rows_local * DIM * passes_per_launch  # the HI image: 2 B per element, once per pass
     qv = queries[0, :per_launch].reshape(per_launch * NQ, DIM)
@@ -312,22 +314,25 @@ def main() -> None:
     ms = index.time_kernel(kind, qv, iters) / iters
     fp32_equiv_flops = 2.0 * per_launch * NQ * rows_local * DIM  # 2*nq*N*d per query
     hbm = {"achieved": streamed_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": streamed_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes,
+           "frac": streamed_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes_per_launch,
            "streamed_bytes_per_launch": streamed_bytes}
-    traffic, traffic_source = None, None
-    tf = ROOT / "profiles" / "traffic.json"  # from separate rocprofv3 --pmc FETCH_SIZE passes
-    if tf.exists() and args.storage == "f32" and n_rows == N_ROWS and world == 1:
-        tj = json.loads(tf.read_text())
-        traffic = tj.get({5: "maxsim_gemm_hi_bytes_per_launch", 6: "maxsim_gemm_hi_bytes_per_launch", 7: "maxsim_pp_bytes_per_pass", 3: "maxsim_gemm_bytes_per_launch", 2: "maxsim_stream2_bytes_per_launch"}.get(kind, "maxsim_stream_bytes_per_launch"))
-        if traffic is not None:
-            traffic *= passes_per_launch  # (the counters were collected per pass of sixteen queries)
-        traffic_source = "static: profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE x 2 for the gfx950 half-count, separate run)"
-    kernel_name = {5: "rl::maxsim_gemm_kernel<2, false, 0, true>", 6: "rl::maxsim_gemm_kernel<2, false, 0, true>", 7: "rl::maxsim_pp_kernel<0, 0, false, true>",
-                   3: "rl::maxsim_gemm_kernel<2, false, 0, true>" if arithmetic == "f16_stored" else "rl::maxsim_gemm_kernel<2, false, 0, false>",
+    kernel_name = {5: "rl::maxsim_gemm_kernel<2, false, 0, true, false>", 6: "rl::maxsim_gemm_kernel<2, false, 0, true, true>", 7: "rl::maxsim_pp_kernel<0, 0, false>",
+                   3: "rl::maxsim_gemm_kernel<2, false, 0, true, false>" if arithmetic == "f16_stored" else "rl::maxsim_gemm_kernel<2, false, 0, false, false>",
                    2: "rl::maxsim_stream2_kernel<256, false, true>" if arithmetic == "f16_stored" else "rl::maxsim_stream2_kernel<256, false, false>",
                    0: {"fp32_exact": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, false>",
                        "f16_split": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, true>",
-                       "f16_stored": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, true, false>"}[arithmetic]}[kind] + " (as rocprofv3 names it)"
+                       "f16_stored": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, true, false>"}[arithmetic]}[kind]
+    # HBM traffic: FETCH_SIZE of a separate rocprofv3 --pmc pass, taken ONLY from a record filed under the very kernel
+    # name this block reports (profiles/traffic.json "by_kernel", written by scripts/summarize_pmc.py --traffic-json) -- else null
+    traffic, traffic_source = None, None
+    tf = ROOT / "profiles" / "traffic.json"
+    if tf.exists() and args.storage == "f32" and n_rows == N_ROWS and world == 1:
+        rec = (json.loads(tf.read_text()).get("by_kernel") or {}).get(kernel_name)
+        if rec and rec.get("passes_per_launch") and rec.get("bytes_per_launch"):
+            traffic = float(rec["bytes_per_launch"]) / rec["passes_per_launch"] * passes_per_launch
+            traffic_source = (f"static: profiles/traffic.json by_kernel[{kernel_name!r}] <- {rec.get('source')} (rocprofv3 --pmc FETCH_SIZE x 2 for the "
+                              f"gfx950 half-count, separate run; {rec.get('dispatches')} dispatches of {rec['passes_per_launch']} passes)")
+    kernel_name += " (as rocprofv3 names it)"
     if kind in (3, 5, 6, 7):
         # q_hi.e_hi + q_hi.e_lo + q_lo.e_hi: what the split arithmetic needs on the fp16 pipe; an fp16-stored corpus has no e_lo,
         # and the approximate pass over the HI image (kind 5) leaves the e_lo product to the exact re-scoring of its candidates
@@ -340,6 +345,21 @@ def main() -> None:
                               "flops_note": f"{products:.0f} fp16 MFMA products per fp32-equivalent multiply-add (SURVEY.md 8d: 2*32*N*d per query), {per_launch} queries per launch"
                                             + ("; approximate pass over the HI image, its candidates re-scored exactly by maxsim_pairs_kernel inside the timed step" if kind in (5, 6, 7) else ""),
                               "hbm": hbm}
+        # The same fraction against what the matrix pipe SUSTAINS on this box in this run: the pass kernel's MFMA stream alone (8 waves per CU,
+        # 128 accumulators each, register-resident pseudo-random fp16 operands; no loads, no LDS, no epilogue -- rl_time_kernel kind 9).
+        # The nominal 2.5 PFLOP/s is 16 cycles per MFMA at 2.4 GHz; under a full MFMA load the shader clock settles well below that.
+        try:
+            index.time_kernel(9, qv, 3)
+            rate_ms = index.time_kernel(9, qv, iters) / iters
+            n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+            rate_tf = n_cu * 8 * 1000 * 32 * (2.0 * 16 * 16 * 32) / (rate_ms * 1e-3) / 1e12
+            result["roofline"]["sustained"] = {
+                "mfma_f16_tflops": rate_tf, "frac_of_nominal_peak": rate_tf / MFMA_F16_PEAK_TF, "frac_of_sustained": achieved / rate_tf,
+                "implied_shader_clock_ghz": rate_tf / MFMA_F16_PEAK_TF * 2.4, "kernel": "rl::mfma_f16_rate_kernel", "kernel_ms": rate_ms,
+                "how": f"same run, right after the pass kernel: {iters} launches of {n_cu} workgroups x 8 waves x 32 000 v_mfma_f32_16x16x32_f16 on "
+                       "register-resident pseudo-random operands (HIP events); `frac` above stays against the nominal peak"}
+        except Exception as exc:  # noqa: BLE001 - a diagnostic must not take the bench line down
+            result["roofline"]["sustained"] = {"error": f"{type(exc).__name__}: {exc}"}
     else:
         result["roofline"] = {"bound": "hbm", **hbm, "traffic": traffic}
     if kind in (5, 6, 7):  # for reference: the full-precision pass (eight queries) the approximate one replaces (and falls back to)
@@ -352,7 +372,7 @@ def main() -> None:
     result["roofline"].update({
         "kernel": kernel_name, "arithmetic": arithmetic, "queries_per_launch": per_launch, "passes_per_launch": passes_per_launch, "kernel_ms": ms,
         "kernel_ms_per_pass": ms / passes_per_launch,
-        "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes,
+        "traffic_source": traffic_source, "algorithmic_bytes_per_launch": algo_bytes_per_launch, "algorithmic_bytes_per_pass": algo_bytes_per_pass,
         # HIP events around the whole timed region / corpus passes in it: the kernel + its share of query split and selection
         "timed_region_ms_per_launch": region_ms / (args.steps * qps) * per_launch,
         "fp32_equivalent_tflops": fp32_equiv_flops / (ms * 1e-3) / 1e12,
@@ -370,29 +390,47 @@ def main() -> None:
     if (world > 1 or args.split) and hasattr(index, "maxsim_batch_begin") and kind in (5, 6, 7):
         n_split = max(3, min(args.steps, 10))
         acc_ms = np.zeros(4)
-        try:
-            for it in range(n_split + 1):
-                q_b = queries[it % n_batches]
-                ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-                ev[0].record()
-                approx = index.maxsim_batch_begin(q_b, TOPK)
-                ev[1].record()
-                all_approx = sharded._allgather_int(approx.contiguous().view(torch.int32)).view(torch.float32)  # noqa: SLF001
-                ev[2].record()
-                s_loc, c_loc = index.maxsim_batch_finish(q_b, all_approx, rank, TOPK)
-                ev[3].record()
-                sharded._exchange_merge_device(s_loc, c_loc, c_lo, TOPK)  # noqa: SLF001
-                ev[4].record()
-                fence()
-                if it > 0:  # (the first round warms the staged path up)
-                    acc_ms += np.array([ev[j].elapsed_time(ev[j + 1]) for j in range(4)])
+        # A diagnostic must not take the bench line down -- and must not hang it either: the two LOCAL stages run under try, the two
+        # COLLECTIVES are always entered (with empty lists once a local stage has failed on this rank), the error is reported afterwards.
+        split_err = None
+        for it in range(n_split + 1):
+            q_b = queries[it % n_batches]
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+            ev[0].record()
+            approx = None
+            if split_err is None:
+                try:
+                    approx = index.maxsim_batch_begin(q_b, TOPK)
+                except Exception as exc:  # noqa: BLE001
+                    split_err = exc
+            if approx is None:
+                approx = torch.full((qps, TOPK + 1), float("-inf"), dtype=torch.float32, device=dev)
+            ev[1].record()
+            all_approx = sharded._allgather_int(approx.contiguous().view(torch.int32)).view(torch.float32)  # noqa: SLF001
+            ev[2].record()
+            s_loc = c_loc = None
+            if split_err is None:
+                try:
+                    s_loc, c_loc = index.maxsim_batch_finish(q_b, all_approx, rank, TOPK)
+                except Exception as exc:  # noqa: BLE001
+                    split_err = exc
+            if s_loc is None:
+                s_loc = torch.full((qps, TOPK), float("-inf"), dtype=torch.float32, device=dev)
+                c_loc = torch.full((qps, TOPK), -1, dtype=torch.int32, device=dev)
+            ev[3].record()
+            sharded._exchange_merge_device(s_loc, c_loc, c_lo, TOPK)  # noqa: SLF001
+            ev[4].record()
+            fence()
+            if it > 0:  # (the first round warms the staged path up)
+                acc_ms += np.array([ev[j].elapsed_time(ev[j + 1]) for j in range(4)])
+        if split_err is None:
             begin_ms, gather_ms, finish_ms, merge_ms = (acc_ms / n_split).tolist()
             pass_ms = -(-qps // per_launch) * ms
             mine = {"rank": rank, "rows": int(r_hi - r_lo), "step_ms": begin_ms + gather_ms + finish_ms + merge_ms, "pass_ms": pass_ms,
                     "local_other_ms": begin_ms + finish_ms - pass_ms, "exchange_ms": gather_ms + merge_ms,
                     "stages_ms": {"begin": begin_ms, "allgather_approx": gather_ms, "finish": finish_ms, "allgather_merge_topk": merge_ms}}
-        except Exception as exc:  # noqa: BLE001 - a diagnostic must not take the bench line down
-            mine = {"rank": rank, "error": f"{type(exc).__name__}: {exc}"}
+        else:
+            mine = {"rank": rank, "error": f"{type(split_err).__name__}: {split_err}"}
         if world > 1:
             everyone = [None] * world
             dist.all_gather_object(everyone, mine)
@@ -415,7 +453,8 @@ def main() -> None:
             "value": ex_steps * qps / ex_elapsed, "unit": "queries/s", "steps": ex_steps, "ms_per_step": 1e3 * ex_elapsed / ex_steps,
             "arithmetic": index.arithmetic, "kernel": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, false, false>",
             "kernel_ms": ex_ms, "queries_per_launch": 1,
-            "frac": algo_bytes / (ex_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bound": "hbm",
+            "algorithmic_bytes_per_launch": algo_bytes_per_pass,  # ONE query per corpus pass, one pass per launch
+            "frac": algo_bytes_per_pass / (ex_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bound": "hbm",
             "fp32_mfma_tflops": 2.0 * NQ * rows_local * DIM / (ex_ms * 1e-3) / 1e12,
             "fp32_mfma_frac": 2.0 * NQ * rows_local * DIM / (ex_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
         }
@@ -448,13 +487,13 @@ def main() -> None:
             qv16 = queries[0, :16].reshape(16 * NQ, DIM)
             idx16.time_kernel(7, qv16, 3)
             f_ms = idx16.time_kernel(7, qv16, iters) / iters
-            f_kernel, f_per, f_products = "rl::maxsim_pp_kernel<0, 0, false, true>", 16, 1.0
+            f_kernel, f_per, f_products = "rl::maxsim_pp_kernel<0, 0, false>", 16, 1.0
         except ValueError:  # (no image for the approximate pass: the eight-query kernel at two products, q_hi.e + q_lo.e)
             try:
                 qv8 = queries[0, :8].reshape(8 * NQ, DIM)
                 idx16.time_kernel(3, qv8, 3)
                 f_ms = idx16.time_kernel(3, qv8, iters) / iters
-                f_kernel, f_per, f_products = "rl::maxsim_gemm_kernel<2, false, 0, true>", 8, 2.0
+                f_kernel, f_per, f_products = "rl::maxsim_gemm_kernel<2, false, 0, true, false>", 8, 2.0
             except ValueError:  # (--opt keep_image=0: an fp16-stored index has no image at all, its batches stream the stored rows)
                 f_ms, f_kernel, f_per, f_products = float("nan"), "none (no image: --opt keep_image=0)", 1, 0.0
         f_flops = f_products * 2.0 * f_per * NQ * rows_local * DIM
@@ -540,7 +579,7 @@ def main() -> None:
         }
         del E_host, ref_scores, ref64
 
-    # ---- BASELINE.json configs 2-5 on this GPU, outside the headline's timed region -----------------------------------
+    # ---- BASELINE.json configs 1-5 on this GPU, outside the headline's timed region -----------------------------------
     if single and not args.no_configs and args.storage == "f32" and n_rows == N_ROWS:
         index.close()
         del E, queries, index, sharded
@@ -549,7 +588,7 @@ def main() -> None:
         import bench_configs
 
         result["configs"] = {}
-        for name in ("cfg2", "cfg3", "cfg4", "cfg5"):
+        for name in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"):
             try:
                 result["configs"][name] = bench_configs.run(name)
             except Exception as exc:  # noqa: BLE001 - a failing side config must not hide the headline
@@ -563,15 +602,50 @@ def main() -> None:
             except Exception as exc:  # noqa: BLE001
                 result["raglite_shaped"][name] = {"error": f"{type(exc).__name__}: {exc}"}
             torch.cuda.empty_cache()
-        _add_score_tolerance(result)
-        print(json.dumps(result))
+        print(_finish(result))
         return
     if rank == 0:
-        _add_score_tolerance(result)
-        print(json.dumps(result))
+        print(_finish(result))
     index.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+BENCH_SCHEMA = 5  # round 5: per-pass / per-launch byte counts kept apart, every printed fraction checked by fraction_violations()
+
+
+def fraction_violations(node, path: str = "") -> list[str]:
+    """Every printed fraction of a roofline must lie in (0, 1]; every HBM-bound block's algorithmic bytes / kernel time must stay
+    below the HBM peak unless the block NAMES the narrower image its kernel streams (`narrower_image`).  Returns the violations
+    (tests/test_bench_line.py runs this over every recorded line of this schema; main() prints the list in `fraction_check`)."""
+    bad: list[str] = []
+    if isinstance(node, dict):
+        narrower = bool(node.get("narrower_image"))
+        for key, val in node.items():
+            here = f"{path}.{key}" if path else key
+            is_frac = key == "frac" or key.endswith("_frac") or key.startswith("frac_")
+            if is_frac and isinstance(val, (int, float)) and not isinstance(val, bool):
+                allowed_above_one = narrower and key == "frac_vs_4B_per_element_whole_query"
+                if not (val == val and val > 0.0 and (val <= 1.0 or allowed_above_one)):
+                    bad.append(f"{here} = {val!r} is not in (0, 1]")
+            bad += fraction_violations(val, here)
+        if node.get("bound") == "hbm" and not narrower:
+            nbytes = node.get("algorithmic_bytes_per_launch", node.get("algorithmic_bytes"))
+            ms = node.get("kernel_ms")
+            if isinstance(nbytes, (int, float)) and isinstance(ms, (int, float)) and ms > 0 and nbytes / (ms * 1e-3) / 1e9 > HBM_PEAK_GBS:
+                bad.append(f"{path or '<root>'}: algorithmic bytes / kernel_ms = {nbytes / (ms * 1e-3) / 1e9:.0f} GB/s exceeds the HBM peak and the block names no narrower image")
+    elif isinstance(node, list):
+        for i, val in enumerate(node):
+            bad += fraction_violations(val, f"{path}[{i}]")
+    return bad
+
+
+def _finish(result: dict) -> str:
+    _add_score_tolerance(result)
+    result["bench_schema"] = BENCH_SCHEMA
+    bad = fraction_violations(result)
+    result["fraction_check"] = "ok: every frac / *_frac in (0, 1]" if not bad else {"violations": bad}
+    return json.dumps(result)
 
 
 def _add_score_tolerance(result: dict) -> None:

@@ -460,7 +460,10 @@ int rl_index_filter_stats(rl_index* index, int64_t out[6], void* stream);
  * sixteen queries of nq / 16 vectors each; nq > 512: nq / 32 queries of 32 vectors, all their passes in ONE launch -- grid row = pass --
  * as the batch pipeline launches them), 8 = the candidate pass of the LAST rl_search_rows call of >= 96 queries on this index that
  * went through the fused top-k over the HI image, replayed with that call's queries and thresholds (query_vecs_dev / nq are not read;
- * RL_ERR_UNSUPPORTED when no such call ran or the index' scratch has been resized since).
+ * RL_ERR_UNSUPPORTED when no such call ran or any other search used the index since), 9 = the matrix pipe alone: the sixteen-query
+ * kernel's MFMA stream (8 waves per CU, 128 accumulators each) on register-resident pseudo-random fp16 operands -- no loads, no LDS, no
+ * epilogue; one launch = compute units x 8 waves x 32 000 v_mfma_f32_16x16x32_f16 (x 16 384 flop): the SUSTAINED fp16 rate of this
+ * device at the clock it settles at, which bench.py prints next to the nominal peak (query_vecs_dev / nq are not read).
  * Used so that roofline.achieved is measured with HIP
  * events on the stream the kernel runs on. */
 int rl_time_kernel(rl_index* index, int kind, const float* query_vecs_dev, int32_t nq, int32_t iters,

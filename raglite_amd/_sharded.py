@@ -166,7 +166,8 @@ class ShardedIndex:
                  check_failures: bool = False) -> None:
         """check_failures: device-path MaxSim batches read back one flag per call to learn that ANOTHER rank failed in its local step (a
         host synchronisation per call; host-array calls check for free).  Without it a failing rank still takes part in every collective
-        of the call with empty lists -- nobody hangs -- and raises afterwards; the other ranks return a merge without that shard."""
+        of the call with empty lists -- nobody hangs -- and raises afterwards; the other ranks do not raise, but what they return is
+        POISONED on the device (every score NaN, every id -1): a merge that lacks a shard never looks like an answer."""
         self.check_failures = bool(check_failures)
         self.local = local
         self.row_base = int(row_base)
@@ -215,7 +216,9 @@ class ShardedIndex:
         if self.comm is not None and self.comm.world > 1:
             import torch
 
-            t = torch.from_numpy(x).cuda()
+            t = torch.from_numpy(x)
+            if torch.cuda.is_available():  # (librccl moves device memory; a test double without a device takes the host tensor)
+                t = t.cuda()
             return self.comm.allgather(t).cpu().numpy()
         if self._world() > 1:
             raise RuntimeError("ShardedIndex: several ranks but neither torch.distributed nor a Communicator can exchange host arrays")
@@ -234,7 +237,8 @@ class ShardedIndex:
         i2 = i.reshape(1, -1) if i.ndim == 1 else i
         gid = np.where(i2 >= 0, i2 + base, -1)
         cols = [s2, gid] if extra is None else [s2, gid, extra]
-        g = self._all_gather(self._pack(*cols))  # (world, B, k, ncols)
+        # (through WHATEVER transport the index has: a Communicator-only index without torch.distributed used to merge its own shard alone here)
+        g = self._allgather_host(self._pack(*cols))  # (world, B, k, ncols)
         gs = np.ascontiguousarray(g[..., 0]).view(np.float32)
         return gs, g[..., 1], (g[..., 2] if extra is not None else None), s.ndim == 1
 
@@ -410,10 +414,16 @@ class ShardedIndex:
         (on the device without any host synchronisation when the queries are CUDA tensors, else on the host).
         Returns (scores (QB,k), global chunk ordinals (QB,k))."""
         self._deferred_error = None
+        self._poison = None
         if hasattr(self.local, "maxsim_topk_batch"):
             s, c = self._local_maxsim_batch(query_batch, k)
             if _is_cuda(s):  # device-resident queries: results stay on the device
                 out = self._exchange_merge_device(s, c, self.chunk_base, k)
+                if self._poison is not None:  # a rank failed in its local step: this merge lacks its shard -- make it unusable, not plausible
+                    import torch
+
+                    ms, mi = out
+                    out = (torch.where(self._poison, torch.full_like(ms, float("nan")), ms), torch.where(self._poison, torch.full_like(mi, -1), mi))
                 self._raise_deferred()
                 return out
         else:
@@ -424,6 +434,7 @@ class ShardedIndex:
         return merge_topk_host(gs, gi, k)
 
     _deferred_error = None
+    _poison = None  # device bool: some rank's bound came back NaN in the last staged MaxSim batch (its shard is missing from the merge)
     rank_cut_scratch_bytes = 8 << 30  # what rl_rank_cut_begin accepts for its [B x n_local] score matrix
 
     def _raise_deferred(self) -> None:
@@ -471,7 +482,11 @@ class ShardedIndex:
             import torch
 
             all_approx = self._allgather_int(approx.contiguous().view(torch.int32)).view(torch.float32)
-            someone_failed = bool(torch.isnan(all_approx[:, :, int(k)]).any().item()) if self.check_failures else False
+            shard_missing = torch.isnan(all_approx[:, :, int(k)]).any()  # (a device scalar, the same on every rank)
+            someone_failed = bool(shard_missing.item()) if self.check_failures else False
+            # without the read-back nobody raises on the healthy ranks -- but nobody gets a plausible answer either: maxsim_topk_batch
+            # poisons the merged lists (NaN scores, ids -1) on the device when a shard is missing, on every rank alike, without a host sync
+            self._poison = shard_missing
         else:
             all_approx = np.ascontiguousarray(self._allgather_int(np.ascontiguousarray(approx, dtype=np.float32).view(np.int32))).view(np.float32)
             someone_failed = bool(np.isnan(all_approx[:, :, int(k)]).any())

@@ -314,6 +314,7 @@ namespace {
 int use_scratch(rl_index* idx, hipStream_t s) {
     ++idx->scratch_epoch;  // (staged calls check that nothing else used the scratch between their stages)
     idx->filt = {};        // its pointers go into scratch this call may re-reserve: whoever filters next records itself again
+    idx->replay.valid = false;  // likewise: a later search overwrites the queries / thresholds the record points at (rl_time_kernel restores it for itself)
     if (idx->last_stream_set && idx->last_stream != s) RL_HIP(hipStreamSynchronize(idx->last_stream));
     idx->last_stream = s;
     idx->last_stream_set = true;
@@ -426,7 +427,13 @@ int refresh_planes(rl_index* idx, hipStream_t s) {
         return RL_OK;
     }
     RL_TRY(st);
-    RL_TRY(refresh_ends(idx, s));
+    if (refresh_ends(idx, s) != RL_OK) {  // (the bitmap could not be allocated: no image either -- "never an error", as above)
+        (void)hipGetLastError();
+        idx->planes.release();
+        idx->planes_scale = 0.f;
+        idx->planes_rows = 0;
+        return RL_OK;
+    }
     idx->planes_scale = image_scale(idx);
     idx->planes_rows = idx->n_rows;
     if (half) RL_TRY(refresh_row_norm16(idx, s));
@@ -509,7 +516,13 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
         return RL_OK;
     }
     RL_TRY(st);
-    RL_TRY(refresh_ends(idx, s));
+    if (refresh_ends(idx, s) != RL_OK) {  // (as for the pre-split image: without the bitmap the image is just absent)
+        (void)hipGetLastError();
+        idx->hi_image.release();
+        idx->hi_image_scale = 0.f;
+        idx->hi_image_rows = 0;
+        return RL_OK;
+    }
     idx->hi_image_scale = idx->split_scale;
     idx->hi_image_rows = idx->n_rows;
     if (idx->max_row_norm_rows != idx->n_rows || idx->max_row_norm_scale != idx->split_scale) {  // fold the new rows' norms in
@@ -911,9 +924,11 @@ int rl_index_filter_stats(rl_index* idx, int64_t out[6], void* stream) {
     if (!idx || !out) return fail(RL_ERR_INVALID, "rl_index_filter_stats: null argument");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
-    const auto f = idx->filt;  // (use_scratch forgets the record: every other call may re-reserve the pools it points into; this one does not)
+    const auto f = idx->filt;  // (use_scratch forgets the records: every other call may re-reserve the pools they point into; this one does not)
+    const bool replay_valid = idx->replay.valid;
     RL_TRY(use_scratch(idx, s));
     idx->filt = f;
+    idx->replay.valid = replay_valid;
     for (int i = 0; i < 6; ++i) out[i] = 0;
     if (f.kind == RL_FILTER_NONE || f.n <= 0) return RL_OK;
     RL_HIP(hipStreamSynchronize(s));
@@ -2471,7 +2486,9 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     if (!idx || !q_dev || !out_ms_total || iters < 1 || nq < 1) return fail(RL_ERR_INVALID, "rl_time_kernel: bad arguments");
     hipStream_t s = as_stream(stream);
     std::lock_guard<std::mutex> lock(idx->mu);
+    const bool replay_valid = idx->replay.valid;  // (use_scratch forgets the record; kind 8 touches nothing it points at)
     RL_TRY(use_scratch(idx, s));
+    if (kind == 8) idx->replay.valid = replay_valid;
     const int64_t ld = (idx->n_rows + 3) & ~int64_t(3);
     const int64_t ldc = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
     if (kind == 0) RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));
@@ -2483,6 +2500,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
     const int32_t pp_n = nq / PP_PASS_QUERIES <= 32 ? PP_PASS_QUERIES : nq / 32;
     if (kind == 7) RL_TRY(idx->scores.reserve((size_t)pp_n * ldc * sizeof(float)));
     else if (kind == 0 || kind == 2 || kind == 3 || kind == 5 || kind == 6) {}
+    else if (kind == 9) RL_TRY(idx->scores.reserve((size_t)(idx->n_cu > 0 ? idx->n_cu : 256) * 512 * sizeof(float)));
     else if (kind == 8) {  // replays the candidate pass of the last fused-HI row search (same queries, same thresholds)
         const auto& r = idx->replay;
         if (!r.valid || r.pools[0] != idx->misc.p || r.pools[1] != idx->fused.p || r.pools[2] != idx->pp_work.p || !hi_image_valid(idx))
@@ -2531,6 +2549,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
                                                idx->n_cu, s, idx->split_scale, true, true);
         }
         else if (kind == 0) st = maxsim_scores_device(idx, q_dev, nq, idx->scores.as<float>(), s);
+        else if (kind == 9) st = launch_mfma_f16_rate(idx->scores.as<float>(), idx->n_cu, MFMA_RATE_ITERS, s, nullptr);
         else if (kind == 2) st = pairs_pass(idx, nq / 2, 2, 0, idx->scores.as<float>(), ldc, s);
         else if (kind == 5 || kind == 6) {  // the approximate MaxSim pass of a batch: eight queries over the HI image (5: two MFMA products, 6: one)
             st = hi_image_valid(idx) ? launch_maxsim_gemm(idx->hi_image.p, idx->n_rows, idx->dim, idx->qplanes.p, GEMM_PASS_QUERIES, 0,

@@ -327,6 +327,9 @@ constexpr int32_t PP_PASS_QUERIES = 16;
 int launch_maxsim_pp(const void* image, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first, int32_t n_q,
                      int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits, float* out,
                      int64_t out_stride, int n_cu, hipStream_t s, float split_scale, const uint32_t* run_if = nullptr);
+// the matrix pipe's sustained fp16 rate under the pass kernel's own MFMA stream (no loads, no epilogue): rl_time_kernel kind 9
+constexpr int32_t MFMA_RATE_ITERS = 1000;  // x 32 MFMAs per wave: the MFMA count of a wave over one pass of 1 M rows x 1024
+int launch_mfma_f16_rate(float* out, int n_cu, int32_t iters, hipStream_t s, double* flops);
 // the candidate pass of the fused row top-k on that kernel's tile (MODE 2; see maxsim_pp.hip) -- declared after CandArgs below
 size_t score_planes_scratch_floats(int32_t nb, int32_t dim);
 int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const float* Q, int32_t nb, float* scores, int64_t ld,

@@ -800,4 +800,58 @@ int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t 
     return RL_OK;
 }
 
+// ---- the matrix pipe's SUSTAINED rate, measured next to the pass kernel (rl_time_kernel kind 9; bench.py: roofline.sustained) -----------
+// The pass kernel's MFMA stream and nothing else: 8 waves per workgroup (two per SIMD), one workgroup per CU, 128 accumulator registers per
+// wave, 32 v_mfma_f32_16x16x32_f16 per iteration (8 "corpus" fragments x 4 "query" fragments, like a K slab of the pass), operands that
+// differ from lane to lane and from fragment to fragment (hash of the lane: the multipliers toggle like real data, not like constants).
+// No loads, no LDS, no epilogue: what the chip delivers when only the matrix pipe is asked -- at the clock it settles at under that load
+// (the nominal 2.5 PFLOP/s is 16 cycles per MFMA at 2.4 GHz; under a full MFMA load the shader clock settles near 1.75-1.85 GHz).
+__global__ __launch_bounds__(512, 2) void mfma_f16_rate_kernel(float* __restrict__ out, int32_t iters) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    f32x4 ef[8], qf[4];
+    auto frag = [&](uint32_t tag) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t h = (lane * 0x9E3779B1u) ^ ((tag * 4u + (uint32_t)i + 1u) * 0x85EBCA77u) ^ (wv * 0xC2B2AE3Du) ^ (blockIdx.x * 0x27D4EB2Fu);
+            h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+            // two fp16 values in [-1, 1): sign, exponent 0b01110 or 0b01101 or below (values < 1), random mantissa
+            const uint32_t lo = (h & 0x83FFu) | (((h >> 10) & 3u) + 11u) << 10, hi = ((h >> 16) & 0x83FFu) | (((h >> 26) & 3u) + 11u) << 10;
+            v[i] = __uint_as_float(lo | (hi << 16));
+        }
+        return v;
+    };
+#pragma unroll
+    for (int a = 0; a < 8; ++a) ef[a] = frag(a);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) qf[c] = frag(8 + c);
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int32_t t = 0; t < iters; ++t) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[a][c] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pp_h(ef[a]), pp_h(qf[c]), acc[a][c], 0, 0, 0);
+    }
+    f32x4 t4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t4 += acc[a][c];
+    out[(size_t)blockIdx.x * 512 + threadIdx.x] = (t4[0] + t4[1]) + (t4[2] + t4[3]);
+}
+
+// One launch: n_cu workgroups x 8 waves x iters x 32 MFMAs of 2 * 16 * 16 * 32 flop; `out`: n_cu * 512 floats.  *flops = what the launch executes.
+int launch_mfma_f16_rate(float* out, int n_cu, int32_t iters, hipStream_t s, double* flops) {
+    if (!out || iters < 1) return RL_ERR_INVALID;
+    const int grid = n_cu > 0 ? n_cu : 256;
+    hipLaunchKernelGGL(mfma_f16_rate_kernel, dim3((unsigned)grid), dim3(512), 0, s, out, iters);
+    RL_HIP(hipGetLastError());
+    if (flops) *flops = (double)grid * 8.0 * (double)iters * 32.0 * (2.0 * 16 * 16 * 32);
+    return RL_OK;
+}
+
 }  // namespace rl

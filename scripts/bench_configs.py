@@ -1,6 +1,6 @@
-"""Throughput of BASELINE.json configs 2-5 on one MI355X, each with a spot check against the oracle.
+"""Throughput of BASELINE.json configs 1-5 on one MI355X, each with a spot check against the oracle.
 
-    python scripts/bench_configs.py [cfg2 cfg3 cfg3_f16 cfg4 cfg5]   -> one JSON object per config on stdout
+    python scripts/bench_configs.py [cfg1 cfg2 cfg3 cfg3_f16 cfg4 cfg5]   -> one JSON object per config on stdout
     bench.py imports `run(name)` and prints the results in its `configs` block (outside the headline's timed region).
 
 Everything is resident in HBM before timing; kernels are launched on torch's current stream and timed with
@@ -62,6 +62,58 @@ def _recall(ref_ids, got_ids) -> float:
     return len(set(np.asarray(ref_ids).tolist()) & set(np.asarray(got_ids).tolist())) / max(1, len(ref_ids))
 
 
+def cfg1():
+    """BASELINE cfg 1 -- the reference's own CPU-runnable case: 10 000 x 1024 fp32 rows = 2 000 chunks x 5 rows, unit-norm
+    rows rounded through fp16 (`_embed.py:139-140`), one query, cosine, the two-stage search of `vector_search`
+    (`_search.py:66-79,143-149`: num_hits rows -> per-chunk max -> top-10 chunks).  GPU: rl_search_chunks; CPU: the NumPy oracle of the
+    same search, timed on this box's host cores in the same run (DuckDB is not installed: SURVEY.md 8c)."""
+    from oracle import oracle
+
+    n, d, k, rows_per_chunk = 10_000, 1024, 10, 5
+    num_hits = oracle.num_hits(k, 4, 2048) if hasattr(oracle, "num_hits") else 40  # oversample 4, chunk_max_size 2048: round(4) * max(10, 10)
+    E = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=1)
+    E = (E / E.norm(dim=1, keepdim=True)).half().float().contiguous()
+    off = np.arange(0, n + 1, rows_per_chunk, dtype=np.int64)
+    q = torch.empty((64, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(q, seed=10)
+    idx = raglite_amd.DeviceIndex(E, off, metric="cosine")
+    i = [0]
+
+    def one():
+        idx.search_chunks(q[i[0] % 64], num_hits, k)
+        i[0] += 1
+
+    ms = timed(one, 200, 10)
+    Eh = E.cpu().numpy()
+    r2c = np.repeat(np.arange(n // rows_per_chunk), rows_per_chunk)
+    err, same, cpu = [], [], []
+    for b in range(8):
+        qh = q[b].cpu().numpy()
+        t0 = time.perf_counter()
+        es, ec = oracle.search_chunks(Eh, r2c, qh, num_hits, k, "cosine")
+        cpu.append(time.perf_counter() - t0)
+        s, c, cnt = idx.search_chunks(q[b], num_hits, k)
+        cnt = int(cnt)
+        same.append(cnt == len(ec) and c.cpu().numpy()[:cnt].tolist() == np.asarray(ec).tolist())
+        err.append(float(np.abs(s.cpu().numpy()[:cnt] - np.asarray(es)[:cnt]).max()))
+    idx.close()
+    cpu_ms = 1e3 * float(np.median(cpu))
+    return {
+        "workload": f"cfg1: 10k x 1024 fp32 (2000 chunks x 5 rows, unit rows through fp16), B=1 cosine, num_hits={num_hits} rows -> top-{k} chunks",
+        "value": 1e3 / ms, "unit": "queries/s", "ms_per_query": float(ms), "timing": ms.stats,
+        # 41 MB of rows: the corpus sits in the 256 MB Infinity Cache / partly in L2 after the first query, and a query is ~10 launches of a
+        # few microseconds each -- the figure that bounds this shape is launch latency, not a memory or matrix roofline
+        "roofline": {"bound": "latency", "algorithmic_bytes": 4.0 * n * d, "algorithmic_GBs_over_query_time": 4.0 * n * d / (ms * 1e-3) / 1e9,
+                     "note": "cache-resident corpus, launch-latency-bound; no HBM fraction is claimed for this shape"},
+        "check": {"chunks_identical": bool(all(same)), "score_max_abs_err": float(np.max(err)), "queries": 8,
+                  "against": "oracle.search_chunks (NumPy restatement of the reference's two-stage SQL), full corpus"},
+        "cpu_numpy": {"queries_per_s": 1e3 / cpu_ms, "ms_per_query": cpu_ms, "threads": int(os.cpu_count() or 1),
+                      "how": "oracle.search_chunks on the host (NumPy / OpenBLAS), median of 8 queries; the reference's own engine for this config "
+                             "(DuckDB in-memory) is not installed in this image"},
+    }
+
+
 def cfg2():
     """BASELINE cfg 2: 1 M x 1024 fp32, single-query cosine top-100 (src/raglite/_search.py:69-79)."""
     from oracle import oracle
@@ -98,7 +150,9 @@ def cfg2():
         s, r = idx.search_rows(q[b], k)
         rec.append(_recall(rr, r.cpu().numpy()))
         err.append(float(np.abs(np.asarray(rs) - s.cpu().numpy()).max()))
+    mem = idx.memory()
     idx.close()
+    half_route = streamed == 2.0 * n * d
     return {
         "workload": "cfg2: 1M x 1024 fp32, B=1 cosine exact top-100", "value": 1e3 / ms, "unit": "queries/s", "ms_per_query": float(ms), "timing": ms.stats,
         # achieved = the bytes the dominant kernel STREAMS / its time (what the HBM roofline bounds); the SURVEY 8d figure of
@@ -107,7 +161,18 @@ def cfg2():
         "roofline": {"bound": "hbm", "kernel": kernel, "kernel_ms": ms_scan, "streamed_bytes": streamed,
                      "achieved": streamed / (ms_scan * 1e-3) / 1e9, "peak": HBM_PEAK, "unit": "GB/s",
                      "frac": streamed / (ms_scan * 1e-3) / 1e9 / HBM_PEAK,
-                     "algorithmic_bytes": 4.0 * n * d, "algorithmic_GBs_over_query_time": 4.0 * n * d / (ms * 1e-3) / 1e9},
+                     "algorithmic_bytes": 4.0 * n * d, "algorithmic_GBs_over_query_time": 4.0 * n * d / (ms * 1e-3) / 1e9,
+                     # the two readings side by side: the kernel against the bytes it streams (2 B per element on the half-bytes route),
+                     # and the WHOLE query against SURVEY 8d's 4*N*d -- above 1 exactly because the route reads a narrower image,
+                     # which is paid for in resident memory, not in bandwidth:
+                     "frac_vs_2B_per_element_kernel": 2.0 * n * d / (ms_scan * 1e-3) / 1e9 / HBM_PEAK if half_route else None,
+                     "frac_vs_4B_per_element_whole_query": 4.0 * n * d / (ms * 1e-3) / 1e9 / HBM_PEAK,
+                     "whole_query_frac_of_streamed": streamed / (ms * 1e-3) / 1e9 / HBM_PEAK,
+                     "narrower_image": "fp16 HI plane, 2 B per element" if half_route else None,
+                     "extra_resident_bytes": int(mem["hi_plane"]) if half_route else 0,
+                     "extra_resident_note": "the HI plane this route streams instead of the fp32 rows: + 0.5 x the corpus in HBM (results are "
+                                            "exact: every row within the bound of the k-th best is re-scored from the fp32 rows)"},
+        "index_memory": {name: int(mem[name]) for name in ("rows", "presplit_image", "hi_image", "hi_plane")},
         "check": {"recall_at_100": float(np.mean(rec)), "score_max_abs_err": float(np.max(err)), "queries": 2,
                   "against": "fp32 NumPy oracle, full corpus"},
         "cpu_numpy_queries_per_s": 1.0 / float(np.mean(cpu)),
@@ -237,7 +302,7 @@ def cfg5():
         try:  # the candidate pass alone, replayed with the thresholds of the search above, HIP events on the stream it runs on
             idx.time_kernel(8, Q[:1], 2)
             kernel_ms = idx.time_kernel(8, Q[:1], 10) / 10
-            kernel = ("rl::maxsim_pp_kernel<0, 2, false, true> (as rocprofv3 names it; the candidate pass on the 128-row x 512-query tile over the HI image, both rounds)" if idx.get_option("fused_pp") and d % 32 == 0 and d >= 256
+            kernel = ("rl::maxsim_pp_kernel<0, 2, false> (as rocprofv3 names it; the candidate pass on the 128-row x 512-query tile over the HI image, both rounds)" if idx.get_option("fused_pp") and d % 32 == 0 and d >= 256
                       else "maxsim_gemm_kernel<2, false, 2, true, true> (candidate pass on the 256 x 256 tile over the HI image)")
         except Exception as exc:  # noqa: BLE001
             kernel = f"(not timed: {exc})"
@@ -385,6 +450,6 @@ if __name__ == "__main__":
         name, value = arg.split("=", 1)
         raglite_amd.set_default_option(name, int(value))
         sys.argv.remove(arg)
-    which = sys.argv[1:] or ["cfg2", "cfg3", "cfg4", "cfg5"]
+    which = sys.argv[1:] or ["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"]
     for name in which:
         print(json.dumps(run(name)), flush=True)

@@ -211,3 +211,80 @@ def test_merge_order_torch_equals_the_host_order_on_ties_padding_and_nan():
     for b in range(B):
         v = int(nv_n[b])
         assert np.array_equal(np.take_along_axis(i[b], order_t.numpy()[b], 0)[:v], np.take_along_axis(i[b], order_n[b], 0)[:v])
+
+
+class _ReplayComm:
+    """A Communicator double for ONE process: world = 2, no torch.distributed.  `allgather` records what this rank hands in and answers
+    with both ranks' arrays for the exchanges whose partner array is already known from an earlier pass (a dummy -- twice its own array
+    -- otherwise), so that a few passes over both ranks converge on exactly what two real ranks would have exchanged."""
+
+    world = 2
+
+    def __init__(self, rank, known):
+        self.rank, self.known, self.mine, self.complete = rank, known, [], True
+
+    def allgather(self, t):
+        j = len(self.mine)
+        self.mine.append(t.clone())
+        other = self.known[1 - self.rank][j] if j < len(self.known[1 - self.rank]) else None
+        if other is None or other.shape != t.shape:
+            self.complete = False
+            other = t
+        parts = [t, other] if self.rank == 0 else [other, t]
+        return torch.stack(parts)
+
+
+def test_communicator_only_index_merges_host_arrays_over_all_ranks():
+    """ShardedIndex(comm=Communicator(world > 1)) WITHOUT torch.distributed and with host (NumPy) queries: `search_rows`, `maxsim_topk` and
+    the host path of `maxsim_topk_batch` must exchange through the communicator.  (Round 4's `_exchange_host` went to the torch-only
+    gather, read "world of one" there and returned the local shard's lists as the global top-k.)"""
+    assert not (dist.is_available() and dist.is_initialized())
+    rng = np.random.default_rng(77)
+    off = ragged_offsets(rng, 400, 1, 9)
+    n = int(off[-1])
+    E = oracle.synth_matrix(21, n, 32, "small_int")
+    Q = oracle.synth_matrix(22, 3, 32, "small_int")
+    Q5 = np.stack([np.roll(Q, i, axis=0) * (1 + i % 2) for i in range(5)]).astype(np.float32)
+    cut = (len(off) - 1) // 3  # uneven: a third / two thirds of the chunks
+    bounds = [(0, cut), (cut, len(off) - 1)]
+
+    def run(call):
+        known = [[], []]
+        for _ in range(4):  # (a call makes at most two exchanges: two passes fix them, the third confirms)
+            outs, comms = [], []
+            for rank, (c_lo, c_hi) in enumerate(bounds):
+                r_lo, r_hi = int(off[c_lo]), int(off[c_hi])
+                local_off = off[c_lo : c_hi + 1] - off[c_lo]
+                comm = _ReplayComm(rank, known)
+                sh = ShardedIndex(_Local(E[r_lo:r_hi], local_off, "dot"), row_base=r_lo, chunk_base=c_lo, local_chunk_offsets=local_off, comm=comm)
+                outs.append(call(sh))
+                comms.append(comm)
+            known = [c.mine for c in comms]
+            if all(c.complete for c in comms):
+                assert all(len(c.mine) >= 1 for c in comms), "no exchange went through the communicator"
+                return outs
+        raise AssertionError("the replayed exchanges did not converge")
+
+    for rank_out in run(lambda sh: sh.search_rows(Q, 25)):
+        for b in range(len(Q)):
+            es, ei = oracle.search_rows(E, Q[b], 25, "dot", np.float32)
+            assert np.array_equal(rank_out[1][b], ei)
+            np.testing.assert_array_equal(rank_out[0][b], np.asarray(es, np.float32))
+    for rank_out in run(lambda sh: sh.maxsim_topk(Q, 10)):
+        ms, mc = oracle.maxsim_topk(E, off, Q, 10)
+        assert np.array_equal(rank_out[1], mc)
+        np.testing.assert_array_equal(rank_out[0], ms.astype(np.float32))
+    for rank_out in run(lambda sh: sh.maxsim_topk_batch(Q5, 10)):
+        for j in range(5):
+            ms, mc = oracle.maxsim_topk(E, off, Q5[j], 10)
+            assert np.array_equal(rank_out[1][j], mc), f"batch query {j}"
+            np.testing.assert_array_equal(rank_out[0][j], ms.astype(np.float32))
+    # several ranks and NO transport for host arrays is an error, never a silent world of one
+    class _NoTransport:
+        world, rank = 2, 0
+        allgather = None
+
+    sh = ShardedIndex(_Local(E[: int(off[cut])], off[: cut + 1], "dot"), row_base=0, chunk_base=0, local_chunk_offsets=off[: cut + 1])
+    sh._world = lambda: 2  # noqa: SLF001
+    with pytest.raises(RuntimeError, match="neither torch.distributed nor a Communicator"):
+        sh.search_rows(Q, 5)
