@@ -26,6 +26,7 @@ Extra objects in the JSON line (rank 0; all but `roofline` at N = 1 only):
   roofline      dominant kernel, HIP-event timed on its launch stream
   exact_fp32    the same workload with RL_ARITH_FP32_EXACT (v_mfma_f32_16x16x4_f32 chain), >= 5 timed steps
   f16_stored    the same corpus rounded to and stored as fp16 (the reference's pgvector halfvec), own workload name
+  f16_queries   ... and the queries as fp16 values too (what embed_strings returns): the one-product pass is exact, its top-k is the result
   recall_at_100 / score_*  all QUERIES_PER_STEP queries of the last timed step against the fp32 NumPy oracle on the
                 full corpus, and against a float64 reference on a >= 50 k-row slab
   cpu_baseline  the NumPy oracle on the host cores (the time of that full-corpus check)
@@ -510,6 +511,31 @@ def main() -> None:
         }
         f16_last = tuple(x.clone() for x in last16)
         f16_index, f16_matrix = idx16, E16
+        # ---- ... and with the QUERIES as fp16 values too (what embed_strings and the query adapter hand over, `_embed.py:140`,
+        # `_search.py:62`): rl_maxsim_topk_batch_f16 -- the one-product pass is exact there, its top-k is the result (no bound, no
+        # candidate list, no re-scoring kernel).  Own workload name, driver-timed like the block above.
+        q16 = queries.half()
+
+        def step16h(i: int):
+            return idx16.maxsim_topk_batch(q16[i % n_batches], TOPK)
+
+        for i in range(2):
+            step16h(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(f_steps):
+            last16h = step16h(i)
+        fence()
+        h_elapsed = time.perf_counter() - t0
+        h_stats = idx16.filter_stats()
+        result["f16_queries"] = {
+            "workload": "maxsim_32x1000000_d1024_top100_F16_STORED_CORPUS_F16_QUERIES_not_the_baseline_config",
+            "value": f_steps * qps / h_elapsed, "unit": "queries/s", "steps": f_steps, "ms_per_step": 1e3 * h_elapsed / f_steps,
+            "route": h_stats["kind"], "candidates_per_query": {"mean": h_stats["candidates_per_query_mean"], "max": h_stats["candidates_per_query_max"]},
+            "fallback": h_stats["fallback"], "kernel": f_kernel, "kernel_ms": f_ms,
+            "note": "fp16 x fp16 products are exact in fp32 and neither side has a dropped half: the pass's exact top-k is returned as is",
+        }
+        del last16h
     else:
         f16_last = None
 
@@ -560,7 +586,7 @@ def main() -> None:
         if f16_last is not None:  # the fp16-stored run: same slab check over the STORED (fp16) values
             slab16 = raglite_amd.DeviceIndex(f16_matrix[:r1], off[: c1 + 1], metric="dot", storage="f16")
             s16, c16 = (x.cpu().numpy() for x in slab16.maxsim_topk_batch(queries[(args.steps - 1) % n_batches], ks))
-            slab16.close()
+            slab16b = slab16
             ref16 = oracle.maxsim_scores_batch(f16_matrix[:r1].float().cpu().numpy(), off[: c1 + 1], q_host, np.float64)
             got16 = np.take_along_axis(ref16, c16.astype(np.int64), axis=1)
             top16 = np.argsort(-ref16, axis=1, kind="stable")[:, :TOPK]
@@ -569,7 +595,20 @@ def main() -> None:
                 "recall_at_100_slab": float(np.mean([len(set(top16[b].tolist()) & set(c16[b][:TOPK].tolist())) / TOPK for b in range(qps)])),
                 "check": f"{qps} queries x top-{ks} of the first {c1} chunks against float64 over the stored fp16 values",
             })
-            del ref16
+            # fp16 queries: the same slab check against float64 over the fp16 values of BOTH sides
+            q16_slab = queries[(args.steps - 1) % n_batches].half()
+            s16h, c16h = (x.cpu().numpy() for x in slab16b.maxsim_topk_batch(q16_slab, ks))
+            route16h = slab16b.filter_stats()["kind"]
+            ref16h = oracle.maxsim_scores_batch(f16_matrix[:r1].float().cpu().numpy(), off[: c1 + 1], q16_slab.float().cpu().numpy(), np.float64)
+            got16h = np.take_along_axis(ref16h, c16h.astype(np.int64), axis=1)
+            top16h = np.argsort(-ref16h, axis=1, kind="stable")[:, :TOPK]
+            result["f16_queries"].update({
+                "score_max_rel_err": float(np.max(np.abs(s16h - got16h) / np.maximum(np.abs(got16h), 1e-30))),
+                "recall_at_100_slab": float(np.mean([len(set(top16h[b].tolist()) & set(c16h[b][:TOPK].tolist())) / TOPK for b in range(qps)])),
+                "check": f"{qps} queries x top-{ks} of the first {c1} chunks against float64 over the fp16 values of corpus and queries (route on the slab: {route16h})",
+            })
+            slab16b.close()
+            del ref16, ref16h
             f16_index.close()
         result["cpu_baseline"] = {
             "value": qps / cpu_s, "unit": "queries/s", "cores": int(cores), "blas_threads": int(cores), "kind": "port",

@@ -209,6 +209,8 @@ int rl_index_arithmetic(rl_index* index, int* in_effect);
  *                                                  tiles (0: every chunk its own tiles; same bits)
  *   RL_OPT_EXACT_KTH_THRESHOLD  0 / 1 (1)          MaxSim batches: second, tighter candidate threshold from the EXACT scores of the
  *                                                  approximate top-k (exact k-th - m instead of approximate k-th - 2 m)
+ *   RL_OPT_F16_EXACT            0 / 1 (1)          rl_maxsim_topk_batch_f16 over an fp16-stored index returns the one-product pass's own top-k
+ *                                                  (exact: fp16 x fp16 products, fp32 sums); 0: the bound-filtered pipeline with exact re-scoring
  * KEEP_* and IMAGE_HEADROOM_MB rebuild / release the images at once (synchronous).  Unknown key or a value outside the column above:
  * RL_ERR_INVALID.  rl_index_get_option returns what is set (not whether a route is usable on this index: rl_index_memory and
  * rl_index_filter_stats report that). */
@@ -216,7 +218,8 @@ typedef enum {
     RL_OPT_HI_SEARCH = 1, RL_OPT_HI_MAXSIM = 2, RL_OPT_HI_PRODUCTS = 3, RL_OPT_PP_PASS = 4, RL_OPT_FUSED_TOPK = 5, RL_OPT_FUSED_HI = 6,
     RL_OPT_FUSED_PP = 7, RL_OPT_FUSED_TOPK_CAP = 8, RL_OPT_FUSED_TOPK_STRIDE = 9, RL_OPT_GEMM_PASS = 10, RL_OPT_QUERY_PAIRS = 11,
     RL_OPT_PLANES_GEMM = 12, RL_OPT_KEEP_IMAGE = 13, RL_OPT_KEEP_HI = 14, RL_OPT_IMAGE_HEADROOM_MB = 15, RL_OPT_ARITHMETIC = 16,
-    RL_OPT_EXACT_KTH_THRESHOLD = 17, RL_OPT_FUSED_TWO_ROUNDS = 18, RL_OPT_KEEP_HI_PLANE = 19, RL_OPT_PAIRS_PACKED = 20, RL_OPT_COUNT_ = 21
+    RL_OPT_EXACT_KTH_THRESHOLD = 17, RL_OPT_FUSED_TWO_ROUNDS = 18, RL_OPT_KEEP_HI_PLANE = 19, RL_OPT_PAIRS_PACKED = 20,
+    RL_OPT_F16_EXACT = 21, RL_OPT_COUNT_ = 22
 } rl_option;
 int rl_set_default_option(int key, int64_t value);
 int rl_get_default_option(int key, int64_t* value);
@@ -299,6 +302,20 @@ int rl_maxsim_scores(rl_index* index, const float* query_vecs, int32_t nq, float
  *   query_vecs [n_queries x nq x dim] f32; out_scores / out_chunks [n_queries x k]. */
 int rl_maxsim_topk_batch(rl_index* index, const float* query_vecs, int32_t n_queries, int32_t nq, int32_t k,
                          float* out_scores, int32_t* out_chunks, int mem, void* stream);
+/* rl_maxsim_topk_batch_f16: the same search for queries that ARE IEEE fp16 values -- what the reference's embed_strings returns
+ * (src/raglite/_embed.py:140,164: `astype(np.float16)`) and what its query adapter hands on (src/raglite/_search.py:62 casts the adapted
+ * query back to the query's dtype).  The queries are widened on the device (exact) and take the route of rl_maxsim_topk_batch -- with one
+ * difference over an fp16-STORED index (rl_index_create_f16; batches of >= 3 queries, dim % 32 == 0, dim >= 256, no empty chunk): the product of
+ * two fp16 values is exact in fp32, the index stores e itself and an fp16 query has no lo half, so the ONE-product pass of SIXTEEN queries
+ * (maxsim_pp.hip) already accumulates q . e in fp32 -- its exact top-k IS the result: no error bound, no candidate list, no re-scoring
+ * kernel (RL_OPT_F16_EXACT = 0: the bound-filtered pipeline of rl_maxsim_topk_batch, for A/B and parity tests).  Scores: fp32-accumulated
+ * dot products in the pass's summation order (integer-valued data: bit-identical to every other route; float data: within 2^-12 relative
+ * of float64, like them).  A query whose elements do not survive the pass's power-of-two scaling (a dynamic range of more than 2^24 inside
+ * one query) or an index with fewer than k scorable chunks raises a device flag and the full-precision passes answer the batch (as the
+ * bound-filtered pipeline's fallback; rl_index_filter_stats reports kind RL_FILTER_MAXSIM_F16_EXACT, 0 candidates, the flag).
+ *   query_vecs_f16 [n_queries x nq x dim] IEEE fp16 bits, 8-byte aligned; outputs as rl_maxsim_topk_batch. */
+int rl_maxsim_topk_batch_f16(rl_index* index, const uint16_t* query_vecs_f16, int32_t n_queries, int32_t nq, int32_t k,
+                             float* out_scores, int32_t* out_chunks, int mem, void* stream);
 
 /* ---- rl_maxsim_topk_batch over a corpus SHARDED across several indexes, with ONE candidate threshold for all shards -----------------
  * Every shard calling rl_maxsim_topk_batch on its own re-scores the chunks near ITS k-th best approximate score: ~235 candidates per
@@ -444,7 +461,8 @@ int rl_partition_similarity(const float* X, int64_t n, int32_t dim, const int64_
  *   out[0] = kind (rl_filter_kind; 0 = no such search ran since the index was created)   out[1] = queries of that call
  *   out[2] = sum of the candidate counts   out[3] = largest count   out[4] = list capacity   out[5] = 1 when the fallback ran.
  * How the data decides both numbers is the reason this exists: they are not constants of the algorithm. */
-enum rl_filter_kind { RL_FILTER_NONE = 0, RL_FILTER_MAXSIM_BATCH = 1, RL_FILTER_ROWS_HI = 2, RL_FILTER_ROWS_FUSED = 3, RL_FILTER_ROWS_FUSED_HI = 4 };
+enum rl_filter_kind { RL_FILTER_NONE = 0, RL_FILTER_MAXSIM_BATCH = 1, RL_FILTER_ROWS_HI = 2, RL_FILTER_ROWS_FUSED = 3, RL_FILTER_ROWS_FUSED_HI = 4,
+                      RL_FILTER_MAXSIM_F16_EXACT = 5 };
 int rl_index_filter_stats(rl_index* index, int64_t out[6], void* stream);
 
 /* Timing hook for bench.py: run `fn`-independent -- records the elapsed milliseconds between two

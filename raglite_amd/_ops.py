@@ -30,6 +30,13 @@ def _torch():
     return torch
 
 
+def _is_half(x: Any) -> bool:
+    """IEEE fp16 data (NumPy float16 or torch.float16)?"""
+    if _is_torch(x):
+        return x.dtype == _torch().float16
+    return getattr(x, "dtype", None) == np.float16
+
+
 class _Args:
     """Collects the pointers of one call and enforces that they all live on the same side."""
 
@@ -404,7 +411,7 @@ class DeviceIndex:
         st._side(self.mem, self.device)  # noqa: SLF001
         self._prep(st)
         check(lib().rl_index_filter_stats(self._handle, out, st.stream))
-        kind = {0: "none", 1: "maxsim_batch_hi", 2: "rows_hi", 3: "rows_fused", 4: "rows_fused_hi"}[int(out[0])]
+        kind = {0: "none", 1: "maxsim_batch_hi", 2: "rows_hi", 3: "rows_fused", 4: "rows_fused_hi", 5: "maxsim_batch_f16_exact"}[int(out[0])]
         n = int(out[1])
         return {"kind": kind, "queries": n, "candidates_per_query_mean": (int(out[2]) / n if n else 0.0),
                 "candidates_per_query_max": int(out[3]), "list_capacity": int(out[4]), "fallback": bool(out[5])}
@@ -521,7 +528,10 @@ class DeviceIndex:
         """query_batch (n_queries, nq, dim) -> (scores (n_queries, k), chunk ordinals (n_queries, k)); one corpus
         pass per query and one batched selection launch."""
         a = _Args()
-        p_q = a.inp(query_batch, np.float32)
+        # fp16 queries -- what the reference's embed_strings / query adapter hand over (`_embed.py:140`, `_search.py:62`) -- go in as fp16
+        # (`rl_maxsim_topk_batch_f16`): over an fp16-stored index the one-product pass is then exact and its top-k is the result
+        half = _is_half(query_batch)
+        p_q = a.inp(query_batch, np.float16 if half else np.float32)
         qv = a.keep[-1]
         if qv.ndim != 3 or int(qv.shape[2]) != self.dim:
             raise ValueError("query_batch must be (n_queries, nq, dim)")
@@ -529,7 +539,8 @@ class DeviceIndex:
         o_s, p_s = a.out((n_queries, k), np.float32)
         o_c, p_c = a.out((n_queries, k), np.int32)
         self._prep(a)
-        check(lib().rl_maxsim_topk_batch(self._handle, p_q, n_queries, nq, k, p_s, p_c, a.mem, a.stream))
+        fn = lib().rl_maxsim_topk_batch_f16 if half else lib().rl_maxsim_topk_batch
+        check(fn(self._handle, p_q, n_queries, nq, k, p_s, p_c, a.mem, a.stream))
         return o_s, o_c
 
     def maxsim_approx_scores(self, query_batch, kernel: int = 0):

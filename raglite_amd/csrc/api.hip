@@ -200,7 +200,7 @@ struct Options {
         for (auto& x : v) x = 0;
         v[RL_OPT_HI_SEARCH] = v[RL_OPT_HI_MAXSIM] = v[RL_OPT_HI_PRODUCTS] = v[RL_OPT_PP_PASS] = v[RL_OPT_FUSED_TOPK] = v[RL_OPT_FUSED_HI] = 1;
         v[RL_OPT_FUSED_PP] = v[RL_OPT_GEMM_PASS] = v[RL_OPT_QUERY_PAIRS] = v[RL_OPT_PLANES_GEMM] = v[RL_OPT_KEEP_IMAGE] = v[RL_OPT_KEEP_HI] = 1;
-        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = 1;
+        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = v[RL_OPT_F16_EXACT] = 1;
         v[RL_OPT_IMAGE_HEADROOM_MB] = -1;
         v[RL_OPT_ARITHMETIC] = RL_ARITH_AUTO;
     }
@@ -212,7 +212,7 @@ bool option_value_ok(int key, int64_t value) {
     switch (key) {
         case RL_OPT_HI_SEARCH: case RL_OPT_HI_MAXSIM: case RL_OPT_PP_PASS: case RL_OPT_FUSED_TOPK: case RL_OPT_FUSED_HI: case RL_OPT_FUSED_PP:
         case RL_OPT_GEMM_PASS: case RL_OPT_QUERY_PAIRS: case RL_OPT_PLANES_GEMM: case RL_OPT_KEEP_IMAGE: case RL_OPT_KEEP_HI:
-        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED:
+        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED: case RL_OPT_F16_EXACT:
             return value == 0 || value == 1;
         case RL_OPT_HI_PRODUCTS: return value == 1 || value == 2;
         case RL_OPT_FUSED_TOPK_CAP: return value >= 0 && value <= MERGE_CAP;
@@ -264,6 +264,7 @@ struct rl_index {
     // Pre-split corpus image of maxsim_gemm.hip (fp16 hi | lo planes in the kernel's LDS layout, 4 B per element) and
     // the "last row of its chunk" bitmap; built with the index, extended on append, rebuilt when split_scale changes.
     rl::Pool planes, ends, qplanes;
+    rl::Pool q32;                         // rl_maxsim_topk_batch_f16: the fp16 queries widened to fp32 (what the query-side kernels read)
     rl::Pool cand;                        // rl_maxsim_rerank: sanitised candidate ordinals
     rl::Pool fused;                       // fused batched top-k: sample scores, thresholds, candidate lists, counters
     rl::Pool pp_work;                     // ... on the sixteen-group tile: wave-private record logs, block norm ranges (maxsim_pp.hip MODE 2)
@@ -760,6 +761,7 @@ int rl_index_destroy(rl_index* idx) {
     idx->planes.release();
     idx->ends.release();
     idx->qplanes.release();
+    idx->q32.release();
     idx->cand.release();
     idx->fused.release();
     idx->pp_work.release();
@@ -1229,7 +1231,7 @@ int rl_index_memory(const rl_index* idx, int64_t out[8]) {
     out[1] = image_valid(idx) ? (int64_t)idx->planes.cap : 0;
     out[2] = hi_image_valid(idx) ? (int64_t)idx->hi_image.cap : 0;
     out[3] = hi_valid(idx) ? (int64_t)idx->hiplane.cap : 0;
-    out[4] = (int64_t)(idx->scores.cap + idx->hits.cap + idx->misc.cap + idx->maskbuf.cap + idx->qsplit.cap + idx->qplanes.cap + idx->cand.cap +
+    out[4] = (int64_t)(idx->scores.cap + idx->hits.cap + idx->misc.cap + idx->maskbuf.cap + idx->qsplit.cap + idx->qplanes.cap + idx->q32.cap + idx->cand.cap +
                        idx->fused.cap + idx->pp_work.cap + idx->rankbuf.cap + idx->hibuf.cap + idx->ends.cap);
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = total_b = 0; }
@@ -2058,6 +2060,8 @@ int hi_batch_approx(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queri
     RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, hb.ts, hb.ti, s));
     return RL_OK;
 }
+int hi_batch_fallback(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queries, int32_t n_gemm, int32_t k, float* sc, int64_t ld,
+                      const HiBatch& hb, float* d_s, int32_t* d_c, hipStream_t s);
 int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queries, int32_t n_gemm, int32_t k, float* sc, int64_t ld,
                      const HiBatch& hb, float* d_s, int32_t* d_c, hipStream_t s) {
     const size_t q_elems = (size_t)nq * idx->dim;
@@ -2080,6 +2084,11 @@ int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_quer
         RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap, n_gemm, hb.es, s, rows16, 0, 0, packed));
     }
     RL_TRY(launch_merge_topk(hb.es, hb.ci, 1, n_gemm, hb.cap, k, d_s, d_c, s, hb.cnt));
+    return hi_batch_fallback(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, d_s, d_c, s);
+}
+int hi_batch_fallback(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queries, int32_t n_gemm, int32_t k, float* sc, int64_t ld,
+                      const HiBatch& hb, float* d_s, int32_t* d_c, hipStream_t s) {
+    const size_t q_elems = (size_t)nq * idx->dim;
     // list overflow / unusable bound: the full-precision passes, behind the flag -- ONE launch for all of them (gridDim.y = passes: sixteen
     // guarded launches that return at once were 0.08 ms of every 128-query step)
     // (no pre-split image: the streaming kernels over the rows, one launch with a grid row per query -- the same arithmetic, an order of
@@ -2098,8 +2107,10 @@ int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_quer
 }
 }  // namespace
 
-int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queries, int32_t nq, int32_t k,
-                         float* out_scores, int32_t* out_chunks, int mem, void* stream) {
+// query_vecs: [n_queries x nq x dim] fp32 -- or, q16, IEEE fp16 (rl_maxsim_topk_batch_f16): widened on the device (exact), and over an
+// fp16-stored index the one-product pass then IS the score (hi_filter.hip: f16_exact_finish_kernel)
+static int maxsim_topk_batch_any(rl_index* idx, const void* query_vecs, bool q16, int32_t n_queries, int32_t nq, int32_t k,
+                                 float* out_scores, int32_t* out_chunks, int mem, void* stream) {
     if (!idx) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: null index");
     if (n_queries < 0 || nq < 1) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: bad sizes");
     if (k < 1) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: k must be >= 1");
@@ -2112,7 +2123,16 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
     DevBuf t_q, t_s, t_c;
     const float* d_q; float* d_s; int32_t* d_c;
     const size_t q_elems = (size_t)nq * idx->dim;
-    RL_TRY(stage_in(query_vecs, (size_t)n_queries * q_elems, mem, s, t_q, &d_q));
+    if (q16) {
+        const uint16_t* d_q16;
+        RL_TRY(stage_in(static_cast<const uint16_t*>(query_vecs), (size_t)n_queries * q_elems, mem, s, t_q, &d_q16));
+        RL_TRY(idx->q32.reserve((size_t)n_queries * q_elems * sizeof(float)));
+        if (launch_widen_f16(d_q16, idx->q32.as<float>(), (int64_t)n_queries * (int64_t)q_elems, s) != RL_OK)
+            return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch_f16: query_vecs_f16 must be 8-byte aligned");
+        d_q = idx->q32.as<float>();
+    } else {
+        RL_TRY(stage_in(static_cast<const float*>(query_vecs), (size_t)n_queries * q_elems, mem, s, t_q, &d_q));
+    }
     RL_TRY(stage_out_begin(out_scores, (size_t)n_queries * k, mem, t_s, &d_s));
     RL_TRY(stage_out_begin(out_chunks, (size_t)n_queries * k, mem, t_c, &d_c));
     const int64_t ld = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
@@ -2154,9 +2174,17 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
                 // 307 candidates per query, the 128-query step 17.1 -> 12.8 ms.  RL_OPT_HI_PRODUCTS = 2: two products.
                 HiBatch hb;
                 RL_TRY(hi_batch_approx(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, s));
-                RL_TRY(launch_maxsim_threshold(hb.ts, n_gemm, k, d_q, nq, idx->dim, (int64_t)q_elems, 1.0f, hb.m_abs, hb.thr, hb.cnt, hb.flag, s,
-                                               hb.one_product ? hb.q_unscale : nullptr, idx->max_row_norm + idx->max_lo_norm, hb.m));
-                RL_TRY(hi_batch_rescore(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, d_s, d_c, s));
+                if (q16 && idx->E16 && hb.one_product && idx->opt.on(RL_OPT_F16_EXACT)) {
+                    // fp16 queries x fp16-stored corpus: q_hi . e IS q . e (products of two fp16 values are exact in fp32; the sums are the
+                    // pass's fp32 accumulation) -- its top-k is the result; certified per query, the full-precision passes behind the flag
+                    RL_TRY(launch_f16_exact_finish(d_q, nq, idx->dim, (int64_t)q_elems, hb.q_unscale, hb.ts, hb.ti, n_gemm, k, d_s, d_c, hb.cnt, hb.flag, s));
+                    RL_TRY(hi_batch_fallback(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, d_s, d_c, s));
+                    idx->filt = {RL_FILTER_MAXSIM_F16_EXACT, n_gemm, hb.cap, hb.cnt, hb.flag};
+                } else {
+                    RL_TRY(launch_maxsim_threshold(hb.ts, n_gemm, k, d_q, nq, idx->dim, (int64_t)q_elems, 1.0f, hb.m_abs, hb.thr, hb.cnt, hb.flag, s,
+                                                   hb.one_product ? hb.q_unscale : nullptr, idx->max_row_norm + idx->max_lo_norm, hb.m));
+                    RL_TRY(hi_batch_rescore(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, d_s, d_c, s));
+                }
                 base = n_gemm;
                 hi_done = true;
             } else if (!slim) {
@@ -2192,6 +2220,16 @@ int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queri
     RL_TRY(stage_out_end(out_scores, (size_t)n_queries * k, mem, s, t_s));
     RL_TRY(stage_out_end(out_chunks, (size_t)n_queries * k, mem, s, t_c));
     return finish(mem, s);
+}
+
+int rl_maxsim_topk_batch(rl_index* idx, const float* query_vecs, int32_t n_queries, int32_t nq, int32_t k,
+                         float* out_scores, int32_t* out_chunks, int mem, void* stream) {
+    return maxsim_topk_batch_any(idx, query_vecs, false, n_queries, nq, k, out_scores, out_chunks, mem, stream);
+}
+
+int rl_maxsim_topk_batch_f16(rl_index* idx, const uint16_t* query_vecs_f16, int32_t n_queries, int32_t nq, int32_t k,
+                             float* out_scores, int32_t* out_chunks, int mem, void* stream) {
+    return maxsim_topk_batch_any(idx, query_vecs_f16, true, n_queries, nq, k, out_scores, out_chunks, mem, stream);
 }
 
 // ---- the MaxSim batch of a corpus SHARDED over several indexes, with ONE candidate threshold for all shards (header: protocol) ------------

@@ -224,6 +224,12 @@ int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld,
                          const int32_t* top_i = nullptr, int32_t k = 0);
 // thr[b] = min_j exact[b][j] - m[b] (the k-th best EXACT score of the approximate top-k bounds the k-th best overall from below);
 // ids[b][0 .. k) = top_i[b], es[b][0 .. k) = exact[b], cnt[b] = k; unusable -> *flag, thr = +inf, cnt = 0.  See exact_threshold_kernel.
+// fp16 queries over an fp16-stored corpus: widen the queries (exact), certify per query that the one-product pass lost nothing and hand its
+// top-k out as the result (hi_filter.hip)
+int launch_widen_f16(const uint16_t* src, float* dst, int64_t count, hipStream_t s);
+int launch_f16_exact_finish(const float* Q, int32_t nq, int32_t dim, int64_t q_stride, const float* q_unscale, const float* top_s,
+                            const int32_t* top_i, int32_t n_queries, int32_t k, float* out_s, int32_t* out_i, uint32_t* cnt, uint32_t* flag,
+                            hipStream_t s);
 int launch_exact_threshold(const float* exact, const int32_t* top_i, int32_t n_queries, int32_t k, const float* m, int32_t cap, float* thr,
                            uint32_t* cnt, int32_t* ids, float* es, uint32_t* flag, hipStream_t s);
 // MaxSim flavour of the threshold: thr[b] = topk[b * k + k - 1] - 2 * m_rel * e_max * sum_i |q_i|; zeroes cnt[b]; sets *flag when

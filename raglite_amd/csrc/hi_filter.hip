@@ -456,9 +456,73 @@ int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld,
     return RL_OK;
 }
 
+// ---- fp16 queries over an fp16-STORED corpus (rl_maxsim_topk_batch_f16): the one-product pass IS the score --------------------------
+// RAGLite's stored embeddings AND its query embeddings are fp16 values (src/raglite/_embed.py:140,164; the adapter's result is cast back,
+// src/raglite/_search.py:62).  The product of two fp16 values is exact in fp32, the index stores e itself (no e_lo), and a query whose
+// elements survive its own power-of-two scaling has no q_lo: what maxsim_pp_kernel accumulates is then the fp32-accumulated dot product
+// itself -- no bound, no candidate list, no re-scoring.  This kernel certifies that per query and hands the pass's top-k out as the result:
+// a query with a lost bit (elements spread over more than fp16's exponent range around the scaled maximum), or without k scorable chunks,
+// raises the device flag and the guarded full-precision passes answer the batch instead.
+__global__ __launch_bounds__(256) void widen_f16_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, int64_t count) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 3 < count) {
+        const uint2 v = *reinterpret_cast<const uint2*>(src + i);  // (i % 4 == 0 and the buffers are 16-byte aligned)
+        _Float16 h[4];
+        __builtin_memcpy(h, &v, 8);
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        *reinterpret_cast<f4*>(dst + i) = (f4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+    } else {
+        for (int64_t j = i; j < count; ++j) {
+            _Float16 h;
+            __builtin_memcpy(&h, src + j, 2);
+            dst[j] = (float)h;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void f16_exact_finish_kernel(const float* __restrict__ Q, int nq, int dim, int64_t q_stride,
+                                                                const float* __restrict__ q_unscale, const float* __restrict__ top_s,
+                                                                const int32_t* __restrict__ top_i, int32_t k, float* __restrict__ out_s,
+                                                                int32_t* __restrict__ out_i, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag) {
+    const int b = blockIdx.x;
+    const float* Qb = Q + (int64_t)b * q_stride;
+    const float q_scale = 1.0f / q_unscale[2 * b];  // a power of two (query_planes_kernel)
+    bool lost = false;
+    for (int64_t c = threadIdx.x; c < (int64_t)nq * dim; c += 256) {
+        const float x = Qb[c] * q_scale;
+        lost |= (float)(_Float16)x != x;  // (also true for NaN / inf elements)
+    }
+    if (__syncthreads_or(lost ? 1 : 0) || !(top_s[(int64_t)b * k + (k - 1)] > -INFINITY)) {
+        if (threadIdx.x == 0) atomicOr(flag, 1u);
+    }
+    for (int j = threadIdx.x; j < k; j += 256) {
+        out_s[(int64_t)b * k + j] = top_s[(int64_t)b * k + j];
+        out_i[(int64_t)b * k + j] = top_i[(int64_t)b * k + j];
+    }
+    if (threadIdx.x == 0) cnt[b] = 0u;  // (rl_index_filter_stats: no candidate is re-scored on this route)
+}
+
 __global__ __launch_bounds__(256) void scale_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, float factor, int64_t count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) dst[i] = src[i] * factor;
+}
+
+int launch_widen_f16(const uint16_t* src, float* dst, int64_t count, hipStream_t s) {
+    if (count <= 0) return RL_OK;
+    if ((reinterpret_cast<uintptr_t>(src) & 7) || (reinterpret_cast<uintptr_t>(dst) & 15)) return RL_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(widen_f16_kernel, dim3((unsigned)((count + 1023) / 1024)), dim3(256), 0, s, src, dst, count);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+int launch_f16_exact_finish(const float* Q, int32_t nq, int32_t dim, int64_t q_stride, const float* q_unscale, const float* top_s,
+                            const int32_t* top_i, int32_t n_queries, int32_t k, float* out_s, int32_t* out_i, uint32_t* cnt, uint32_t* flag,
+                            hipStream_t s) {
+    if (n_queries <= 0) return RL_OK;
+    hipLaunchKernelGGL(f16_exact_finish_kernel, dim3(n_queries), dim3(256), 0, s, Q, (int)nq, (int)dim, q_stride, q_unscale, top_s, top_i, k, out_s,
+                       out_i, cnt, flag);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
 }
 
 int launch_scale_f32(const float* src, float* dst, float factor, int64_t count, hipStream_t s) {

@@ -91,7 +91,7 @@ def cfg1():
     for b in range(8):
         qh = q[b].cpu().numpy()
         t0 = time.perf_counter()
-        es, ec = oracle.search_chunks(Eh, r2c, qh, num_hits, k, "cosine")
+        es, ec = oracle.search_chunks(Eh, r2c, qh, num_hits, k, "cosine", np.float32)  # (fp32, as DuckDB's FLOAT[d] arithmetic)
         cpu.append(time.perf_counter() - t0)
         s, c, cnt = idx.search_chunks(q[b], num_hits, k)
         cnt = int(cnt)
@@ -109,7 +109,7 @@ def cfg1():
         "check": {"chunks_identical": bool(all(same)), "score_max_abs_err": float(np.max(err)), "queries": 8,
                   "against": "oracle.search_chunks (NumPy restatement of the reference's two-stage SQL), full corpus"},
         "cpu_numpy": {"queries_per_s": 1e3 / cpu_ms, "ms_per_query": cpu_ms, "threads": int(os.cpu_count() or 1),
-                      "how": "oracle.search_chunks on the host (NumPy / OpenBLAS), median of 8 queries; the reference's own engine for this config "
+                      "how": "oracle.search_chunks in fp32 on the host (NumPy / OpenBLAS), median of 8 queries; the reference's own engine for this config "
                              "(DuckDB in-memory) is not installed in this image"},
     }
 
