@@ -272,7 +272,9 @@ def main() -> None:
     mem = index.memory()
     kept = {name: mem[name] for name in ("rows", "presplit_image", "hi_image", "hi_plane")}
     result["index_memory"] = {**kept, "times_corpus": sum(kept.values()) / max(1, kept["rows"]),
-                              "note": "rank 0's shard, bytes; --opt keep_image=0 --opt keep_hi_plane=0: rows + HI image (1.5 x), same results"}
+                              "note": "rank 0's shard, bytes, right after the timed steps: what an index that serves this workload HAS (lazy images, the "
+                                      "default since round 5: an image is built by the first call whose route reads it -- MaxSim batches the HI image; "
+                                      "--opt lazy_images=0: every image with the index, 3 x)"}
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, kernel only -----------------------------
     # One launch = one corpus pass of EIGHT queries through maxsim_gemm_kernel (matrix-pipe-bound).  Big fp32 corpora in split

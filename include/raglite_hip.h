@@ -211,6 +211,11 @@ int rl_index_arithmetic(rl_index* index, int* in_effect);
  *                                                  approximate top-k (exact k-th - m instead of approximate k-th - 2 m)
  *   RL_OPT_F16_EXACT            0 / 1 (1)          rl_maxsim_topk_batch_f16 over an fp16-stored index returns the one-product pass's own top-k
  *                                                  (exact: fp16 x fp16 products, fp32 sums); 0: the bound-filtered pipeline with exact re-scoring
+ *   RL_OPT_LAZY_IMAGES          0 / 1 (1)          an image is built by the FIRST call whose route reads it (allocation + one pass over the rows,
+ *                                                  ~2 ms per image at 1 M x 1024, inside that call) instead of with the index: MaxSim batches ask
+ *                                                  for the HI image, row searches of <= 16 queries for the HI plane, of >= 96 queries for the
+ *                                                  pre-split image + HI image -- a MaxSim-only or a single-query deployment keeps 1.5 x the corpus
+ *                                                  (0: every image the KEEP_* options allow is built with the index: 3 x, no first-call cost)
  * KEEP_* and IMAGE_HEADROOM_MB rebuild / release the images at once (synchronous).  Unknown key or a value outside the column above:
  * RL_ERR_INVALID.  rl_index_get_option returns what is set (not whether a route is usable on this index: rl_index_memory and
  * rl_index_filter_stats report that). */
@@ -219,7 +224,7 @@ typedef enum {
     RL_OPT_FUSED_PP = 7, RL_OPT_FUSED_TOPK_CAP = 8, RL_OPT_FUSED_TOPK_STRIDE = 9, RL_OPT_GEMM_PASS = 10, RL_OPT_QUERY_PAIRS = 11,
     RL_OPT_PLANES_GEMM = 12, RL_OPT_KEEP_IMAGE = 13, RL_OPT_KEEP_HI = 14, RL_OPT_IMAGE_HEADROOM_MB = 15, RL_OPT_ARITHMETIC = 16,
     RL_OPT_EXACT_KTH_THRESHOLD = 17, RL_OPT_FUSED_TWO_ROUNDS = 18, RL_OPT_KEEP_HI_PLANE = 19, RL_OPT_PAIRS_PACKED = 20,
-    RL_OPT_F16_EXACT = 21, RL_OPT_COUNT_ = 22
+    RL_OPT_F16_EXACT = 21, RL_OPT_LAZY_IMAGES = 22, RL_OPT_COUNT_ = 23
 } rl_option;
 int rl_set_default_option(int key, int64_t value);
 int rl_get_default_option(int key, int64_t* value);
@@ -305,7 +310,8 @@ int rl_maxsim_topk_batch(rl_index* index, const float* query_vecs, int32_t n_que
 /* rl_maxsim_topk_batch_f16: the same search for queries that ARE IEEE fp16 values -- what the reference's embed_strings returns
  * (src/raglite/_embed.py:140,164: `astype(np.float16)`) and what its query adapter hands on (src/raglite/_search.py:62 casts the adapted
  * query back to the query's dtype).  The queries are widened on the device (exact) and take the route of rl_maxsim_topk_batch -- with one
- * difference over an fp16-STORED index (rl_index_create_f16; batches of >= 3 queries, dim % 32 == 0, dim >= 256, no empty chunk): the product of
+ * difference over an fp16-STORED index (rl_index_create_f16) or an fp32-stored one whose every element is an fp16 value (measured when its HI
+ * image is built: max |e_lo| == 0); batches of >= 3 queries, dim % 32 == 0, dim >= 256, no empty chunk: the product of
  * two fp16 values is exact in fp32, the index stores e itself and an fp16 query has no lo half, so the ONE-product pass of SIXTEEN queries
  * (maxsim_pp.hip) already accumulates q . e in fp32 -- its exact top-k IS the result: no error bound, no candidate list, no re-scoring
  * kernel (RL_OPT_F16_EXACT = 0: the bound-filtered pipeline of rl_maxsim_topk_batch, for A/B and parity tests).  Scores: fp32-accumulated

@@ -449,8 +449,14 @@ class ShardedIndex:
         eight shards where one index re-scores 307 in all.  The decision to exchange is taken from the batch shape alone (the same on every
         rank: the exchange is a collective); a shard whose index cannot take part (no image of the hi halves) contributes an empty list
         and a zero bound -- which only lowers the others' threshold -- and answers with its exact local top-k."""
+        # fp16 queries over fp16-STORED shards (what RAGLite's embeddings are on both sides, `_embed.py:140`): every shard's one-product pass
+        # is exact (`rl_maxsim_topk_batch_f16`), its local top-k needs no candidate threshold -- nothing to exchange before the merge.  Taken
+        # from the query dtype and the local storage, which are the same on every rank of one index (the exchange below is a collective).
+        f16_exact = getattr(query_batch, "dtype", None) is not None and str(query_batch.dtype).endswith("float16") \
+            and getattr(self.local, "storage", None) == "f16"
         staged_shape = (
             self._world() > 1
+            and not f16_exact
             and hasattr(self.local, "maxsim_batch_begin")
             and getattr(query_batch, "ndim", 0) == 3
             and int(query_batch.shape[0]) >= 3

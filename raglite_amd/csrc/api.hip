@@ -200,7 +200,7 @@ struct Options {
         for (auto& x : v) x = 0;
         v[RL_OPT_HI_SEARCH] = v[RL_OPT_HI_MAXSIM] = v[RL_OPT_HI_PRODUCTS] = v[RL_OPT_PP_PASS] = v[RL_OPT_FUSED_TOPK] = v[RL_OPT_FUSED_HI] = 1;
         v[RL_OPT_FUSED_PP] = v[RL_OPT_GEMM_PASS] = v[RL_OPT_QUERY_PAIRS] = v[RL_OPT_PLANES_GEMM] = v[RL_OPT_KEEP_IMAGE] = v[RL_OPT_KEEP_HI] = 1;
-        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = v[RL_OPT_F16_EXACT] = 1;
+        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = v[RL_OPT_F16_EXACT] = v[RL_OPT_LAZY_IMAGES] = 1;
         v[RL_OPT_IMAGE_HEADROOM_MB] = -1;
         v[RL_OPT_ARITHMETIC] = RL_ARITH_AUTO;
     }
@@ -212,7 +212,7 @@ bool option_value_ok(int key, int64_t value) {
     switch (key) {
         case RL_OPT_HI_SEARCH: case RL_OPT_HI_MAXSIM: case RL_OPT_PP_PASS: case RL_OPT_FUSED_TOPK: case RL_OPT_FUSED_HI: case RL_OPT_FUSED_PP:
         case RL_OPT_GEMM_PASS: case RL_OPT_QUERY_PAIRS: case RL_OPT_PLANES_GEMM: case RL_OPT_KEEP_IMAGE: case RL_OPT_KEEP_HI:
-        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED: case RL_OPT_F16_EXACT:
+        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED: case RL_OPT_F16_EXACT: case RL_OPT_LAZY_IMAGES:
             return value == 0 || value == 1;
         case RL_OPT_HI_PRODUCTS: return value == 1 || value == 2;
         case RL_OPT_FUSED_TOPK_CAP: return value >= 0 && value <= MERGE_CAP;
@@ -300,6 +300,13 @@ struct rl_index {
     rl::Pool rank_q;                      // their device copy (the l2 re-scoring of rl_rank_cut_finish needs them)
     struct FilterRecord { int kind = 0; int32_t n = 0, cap = 0; const uint32_t* cnt = nullptr; const uint32_t* flag = nullptr; } filt;
     rl::Options opt;                      // route options (rl_index_set_option)
+    // RL_OPT_LAZY_IMAGES (round 5, the default): an image is built by the first call whose route reads it -- which images this index
+    // has been asked for so far (IMG_* bits); with the option off every image the KEEP_* options allow is built with the index
+    uint32_t demanded = 0;
+    // ... and a pinned host word every bound-filtered MaxSim batch copies its fallback flag to when it is done (asynchronously): a batch
+    // that finds the previous one fell back asks for the pre-split image, so that an index whose data keeps defeating the bound runs its
+    // full-precision passes through the eight-query kernel instead of the streaming kernels (3-4 x faster) from the second batch on
+    uint32_t* h_fell_back = nullptr;
     // rl_time_kernel kind 8: what the candidate pass of the last fused-HI row search ran with (pointers into misc / fused / pp_work: valid
     // while those pools have not been re-reserved, which `pools` pins down)
     struct FusedReplay {
@@ -360,6 +367,9 @@ int scan_row_range(rl_index* idx, int64_t first, int64_t n, hipStream_t s) {
 // Scale of the corpus image the index should have: the split scale of an fp32 corpus, 1 for an fp16-stored one (its image is
 // the stored halves, permuted), 0 = no image.
 float image_scale(const rl_index* idx) { return idx->E16 ? 1.0f : idx->split_scale; }
+// Which of the three images may exist right now: all of them, or -- lazy images -- those some call has asked for (demand_images)
+enum : uint32_t { IMG_PLANES = 1u, IMG_HI_IMAGE = 2u, IMG_HI_PLANE = 4u, IMG_ALL = 7u };
+uint32_t image_need(const rl_index* idx) { return idx->opt.on(RL_OPT_LAZY_IMAGES) ? idx->demanded : IMG_ALL; }
 bool image_valid(const rl_index* idx) {
     return idx->planes_scale > 0.f && idx->planes_scale == image_scale(idx) && idx->planes_rows == idx->n_rows && idx->n_rows > 0;
 }
@@ -399,7 +409,7 @@ int refresh_ends(rl_index* idx, hipStream_t s) {
 int refresh_planes(rl_index* idx, hipStream_t s) {
     const bool half = idx->E16 != nullptr;
     const bool want = idx->opt.on(RL_OPT_KEEP_IMAGE) && (idx->E16 || idx->E) && image_scale(idx) > 0.f && idx->dim % 32 == 0 && idx->dim >= 32 &&
-                      idx->n_rows > 0;
+                      idx->n_rows > 0 && (image_need(idx) & IMG_PLANES);
     idx->ends_rows = -1;  // (rows or chunk structure may have changed: whoever needs the bitmap rebuilds it)
     if (!want) {
         idx->planes.release();
@@ -485,13 +495,42 @@ int refresh_row_norm16(rl_index* idx, hipStream_t s) {
     return RL_OK;
 }
 
+// max |e|, max |e_lo|, max |e_lo| / |e|, min |e| over the rows at the current split scale: what the error bounds of BOTH half-bytes routes are
+// made of (the HI image's and the HI plane's), folded in as rows arrive (synchronises the stream: image builds only)
+int refresh_hi_norms(rl_index* idx, hipStream_t s) {
+    if (idx->max_row_norm_rows != idx->n_rows || idx->max_row_norm_scale != idx->split_scale) {  // fold the new rows' norms in
+        if (idx->max_row_norm_scale != idx->split_scale) {  // (the dropped halves depend on the scale: start over)
+            idx->max_row_norm = idx->max_lo_norm = idx->max_lo_ratio = 0.f;
+            idx->min_row_norm = std::numeric_limits<float>::infinity();
+            idx->max_row_norm_rows = 0;
+        }
+        const int64_t from = std::min<int64_t>(idx->max_row_norm_rows, idx->n_rows);
+        if (!idx->d_norms) RL_HIP(hipMalloc(&idx->d_norms, 16));
+        uint32_t bits[4] = {0, 0, 0, 0};
+        std::memcpy(&bits[0], &idx->max_row_norm, 4);
+        std::memcpy(&bits[1], &idx->max_lo_norm, 4);
+        std::memcpy(&bits[2], &idx->max_lo_ratio, 4);
+        std::memcpy(&bits[3], &idx->min_row_norm, 4);
+        RL_HIP(hipMemcpyAsync(idx->d_norms, bits, 16, hipMemcpyHostToDevice, s));
+        RL_TRY(rl::launch_max_row_norm(idx->E + (size_t)from * idx->dim, idx->n_rows - from, idx->dim, idx->split_scale, idx->d_norms, s));
+        RL_HIP(hipMemcpyAsync(bits, idx->d_norms, 16, hipMemcpyDeviceToHost, s));
+        RL_HIP(hipStreamSynchronize(s));
+        std::memcpy(&idx->max_row_norm, &bits[0], 4);
+        std::memcpy(&idx->max_lo_norm, &bits[1], 4);
+        std::memcpy(&idx->max_lo_ratio, &bits[2], 4);
+        std::memcpy(&idx->min_row_norm, &bits[3], 4);
+        idx->max_row_norm_rows = idx->n_rows;
+        idx->max_row_norm_scale = idx->split_scale;
+    }
+    return RL_OK;
+}
 // The HI halves in image layout + the largest row norm (synchronises the stream: build / append / compact only).
 int refresh_hi_image(rl_index* idx, hipStream_t s) {
     const bool off = !idx->opt.on(RL_OPT_KEEP_HI);  // (shared with the row-major plane)
     // (round 4: independent of the pre-split image -- an index with RL_OPT_KEEP_IMAGE = 0 keeps rows + HI image, 1.5 x the corpus, and its
     // MaxSim batches fall back to the streaming kernels over the rows)
     const bool want = !off && !idx->E16 && idx->E && idx->split_scale > 0.f && idx->dim % 32 == 0 && idx->dim >= 32 && idx->dim <= 1024 &&
-                      (int64_t)idx->n_rows * idx->dim >= (int64_t(64) << 20);
+                      (int64_t)idx->n_rows * idx->dim >= (int64_t(64) << 20) && (image_need(idx) & IMG_HI_IMAGE);
     if (!want) {
         idx->hi_image.release();
         idx->hi_image_scale = 0.f;
@@ -526,30 +565,7 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
     }
     idx->hi_image_scale = idx->split_scale;
     idx->hi_image_rows = idx->n_rows;
-    if (idx->max_row_norm_rows != idx->n_rows || idx->max_row_norm_scale != idx->split_scale) {  // fold the new rows' norms in
-        if (idx->max_row_norm_scale != idx->split_scale) {  // (the dropped halves depend on the scale: start over)
-            idx->max_row_norm = idx->max_lo_norm = idx->max_lo_ratio = 0.f;
-            idx->min_row_norm = std::numeric_limits<float>::infinity();
-            idx->max_row_norm_rows = 0;
-        }
-        const int64_t from = std::min<int64_t>(idx->max_row_norm_rows, idx->n_rows);
-        if (!idx->d_norms) RL_HIP(hipMalloc(&idx->d_norms, 16));
-        uint32_t bits[4] = {0, 0, 0, 0};
-        std::memcpy(&bits[0], &idx->max_row_norm, 4);
-        std::memcpy(&bits[1], &idx->max_lo_norm, 4);
-        std::memcpy(&bits[2], &idx->max_lo_ratio, 4);
-        std::memcpy(&bits[3], &idx->min_row_norm, 4);
-        RL_HIP(hipMemcpyAsync(idx->d_norms, bits, 16, hipMemcpyHostToDevice, s));
-        RL_TRY(rl::launch_max_row_norm(idx->E + (size_t)from * idx->dim, idx->n_rows - from, idx->dim, idx->split_scale, idx->d_norms, s));
-        RL_HIP(hipMemcpyAsync(bits, idx->d_norms, 16, hipMemcpyDeviceToHost, s));
-        RL_HIP(hipStreamSynchronize(s));
-        std::memcpy(&idx->max_row_norm, &bits[0], 4);
-        std::memcpy(&idx->max_lo_norm, &bits[1], 4);
-        std::memcpy(&idx->max_lo_ratio, &bits[2], 4);
-        std::memcpy(&idx->min_row_norm, &bits[3], 4);
-        idx->max_row_norm_rows = idx->n_rows;
-        idx->max_row_norm_scale = idx->split_scale;
-    }
+    RL_TRY(refresh_hi_norms(idx, s));
     return RL_OK;
 }
 int refresh_hi_plane(rl_index* idx, hipStream_t s) {
@@ -558,7 +574,8 @@ int refresh_hi_plane(rl_index* idx, hipStream_t s) {
     const int32_t d = idx->dim;
     const bool dim_ok = d == 128 || d == 256 || d == 384 || d == 512 || d == 768 || d == 1024;
     const bool want = !off && !idx->E16 && idx->E && idx->split_scale > 0.f && dim_ok &&
-                      (int64_t)idx->n_rows * d >= (int64_t(64) << 20) && (idx->metric == RL_COSINE || idx->metric == RL_DOT);
+                      (int64_t)idx->n_rows * d >= (int64_t(64) << 20) && (idx->metric == RL_COSINE || idx->metric == RL_DOT) &&
+                      (image_need(idx) & IMG_HI_PLANE);
     if (!want) {
         idx->hiplane.release();
         idx->hi_scale = 0.f;
@@ -585,10 +602,26 @@ int refresh_hi_plane(rl_index* idx, hipStream_t s) {
         return RL_OK;
     }
     RL_TRY(st);
+    RL_TRY(refresh_hi_norms(idx, s));  // (the plane's bound needs them whether or not the HI image exists)
     idx->hi_scale = idx->split_scale;
     idx->hi_rows = idx->n_rows;
     return RL_OK;
 }
+
+// Lazy images: called (under idx->mu, on the call's stream) by every route that reads an image, BEFORE it tests the image's validity.  The
+// first call that asks for an image builds it (allocation + one pass over the rows: ~2 ms per image at 1 M x 1024, synchronous); later
+// calls find the bit set.  What an index has built is a function of the calls it has served: a MaxSim-only deployment keeps rows + HI
+// image (1.5 x the corpus), a single-query search service rows + HI plane (1.5 x), batches of >= 96 row queries add the pre-split image.
+int demand_images(rl_index* idx, uint32_t bits, hipStream_t s) {
+    if (!idx->opt.on(RL_OPT_LAZY_IMAGES) || (idx->demanded & bits) == bits) return RL_OK;
+    const uint32_t fresh = bits & ~idx->demanded;
+    idx->demanded |= bits;
+    if (fresh & IMG_PLANES) RL_TRY(refresh_planes(idx, s));
+    if (fresh & (IMG_HI_IMAGE | IMG_HI_PLANE)) RL_TRY(refresh_hi_plane(idx, s));
+    return RL_OK;
+}
+// the image the approximate MaxSim pass of a batch multiplies: the HI image of an fp32 index, the (only) image of an fp16-stored one
+uint32_t approx_image_bit(const rl_index* idx) { return idx->E16 ? IMG_PLANES : IMG_HI_IMAGE; }
 }  // namespace
 
 using namespace rl;
@@ -762,6 +795,7 @@ int rl_index_destroy(rl_index* idx) {
     idx->ends.release();
     idx->qplanes.release();
     idx->q32.release();
+    if (idx->h_fell_back) (void)hipHostFree(idx->h_fell_back);
     idx->cand.release();
     idx->fused.release();
     idx->pp_work.release();
@@ -1078,7 +1112,8 @@ int rl_index_set_option(rl_index* idx, int key, int64_t value) {
     std::lock_guard<std::mutex> lock(idx->mu);
     if (idx->opt.v[key] == value) return RL_OK;
     idx->opt.v[key] = value;
-    if (key == RL_OPT_KEEP_IMAGE || key == RL_OPT_KEEP_HI || key == RL_OPT_KEEP_HI_PLANE || key == RL_OPT_IMAGE_HEADROOM_MB || key == RL_OPT_ARITHMETIC) {
+    if (key == RL_OPT_KEEP_IMAGE || key == RL_OPT_KEEP_HI || key == RL_OPT_KEEP_HI_PLANE || key == RL_OPT_IMAGE_HEADROOM_MB || key == RL_OPT_ARITHMETIC ||
+        key == RL_OPT_LAZY_IMAGES) {
         // what the index keeps in device memory changes: rebuild / release now (synchronous, like rl_index_set_arithmetic)
         RL_TRY(use_scratch(idx, nullptr));
         if (key == RL_OPT_ARITHMETIC) {
@@ -1257,6 +1292,7 @@ int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStrea
     };
     const int mode = scan_mode(idx->metric);
     float* sc = idx->scores.as<float>();
+    if (nb >= GEMM_MIN_QUERIES && idx->opt.on(RL_OPT_PLANES_GEMM)) RL_TRY(demand_images(idx, IMG_PLANES, s));
     if (nb >= GEMM_MIN_QUERIES && image_valid(idx)) {
         // the row-score GEMM over the corpus image (maxsim_gemm.hip MODE 1; fp32 corpus: pre-split planes, fp16-stored corpus:
         // its one-plane image): no conversion in the loop
@@ -1640,6 +1676,10 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
     for (int32_t b0 = 0; b0 < B; b0 += batch) {
         const int32_t nb = std::min<int32_t>(batch, B - b0);
         const bool cut = rank_limit > 0 && rank_limit < n;
+        // lazy images: the routes below test what the index HAS; ask for what this batch's route reads first
+        if (!d_row_bits && !cut && nb >= GEMM_MIN_QUERIES && k <= 512 && idx->opt.on(RL_OPT_FUSED_TOPK))
+            RL_TRY(demand_images(idx, IMG_PLANES | (idx->opt.on(RL_OPT_FUSED_HI) ? IMG_HI_IMAGE : 0u), s));
+        if (!cut && nb <= 16 && k <= 512 && idx->opt.on(RL_OPT_HI_SEARCH)) RL_TRY(demand_images(idx, IMG_HI_PLANE, s));
         if (!d_row_bits && !cut) {  // big batches over an index with a HI image: fused top-k at one MFMA product per multiply
             const int st = search_rows_fused_hi(idx, d_q + (int64_t)b0 * idx->dim, nb, k, d_scores + (int64_t)b0 * k, d_rows + (int64_t)b0 * k, ld, s);
             if (st == RL_OK) continue;
@@ -1917,9 +1957,16 @@ bool slim_batch_ok(const rl_index* idx, const float* d_q) {
     return !image_valid(idx) && !idx->E16 && idx->E && hi_image_valid(idx) && (d == 256 || d == 384 || d == 512 || d == 768 || d == 1024) &&
            !(reinterpret_cast<uintptr_t>(d_q) & 15) && !(reinterpret_cast<uintptr_t>(idx->E) & 15);
 }
-int gemm_prepare(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, int32_t n_queries, hipStream_t s) {
-    if (!idx->opt.on(RL_OPT_GEMM_PASS) || !(image_valid(idx) || slim_batch_ok(idx, d_q))) return RL_ERR_UNSUPPORTED;
+int gemm_prepare(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, int32_t n_queries, hipStream_t s, bool want_planes = false) {
+    if (!idx->opt.on(RL_OPT_GEMM_PASS)) return RL_ERR_UNSUPPORTED;
     if (idx->has_empty_chunk || idx->n_chunks == 0 || nq < 1 || nq > 32 || n_queries < GEMM_PASS_MIN_QUERIES) return RL_ERR_UNSUPPORTED;
+    // lazy images: the image the approximate pass multiplies; the pre-split image only where the batch cannot run on rows + HI image
+    // (options that route it through the eight-query kernel, shapes outside the slim batch, or the caller says so: k > 512, timing hooks)
+    RL_TRY(demand_images(idx, approx_image_bit(idx), s));
+    const bool hi_route = idx->opt.on(RL_OPT_HI_MAXSIM) && idx->opt.v[RL_OPT_HI_PRODUCTS] == 1 && idx->dim >= 256 && idx->opt.on(RL_OPT_PP_PASS);
+    const bool fell_back = idx->h_fell_back && *static_cast<volatile uint32_t*>(idx->h_fell_back) != 0u;  // (the previous batch's flag, if it has arrived)
+    if (want_planes || !hi_route || fell_back || (!image_valid(idx) && !slim_batch_ok(idx, d_q))) RL_TRY(demand_images(idx, IMG_PLANES, s));
+    if (!(image_valid(idx) || slim_batch_ok(idx, d_q))) return RL_ERR_UNSUPPORTED;
     RL_TRY(idx->qplanes.reserve(query_planes_bytes(idx->dim, n_queries)));
     return launch_query_planes(d_q, idx->dim, nq, q_stride, n_queries, idx->qplanes.p, s);
 }
@@ -2103,6 +2150,13 @@ int hi_batch_fallback(rl_index* idx, const float* d_q, int32_t nq, int32_t n_que
     // (the exact top-k of the fallback's scores in ONE guarded launch, a block per query -- select.hip: guarded_select_kernel -- instead of the
     // selection's three: what usually returns at once is one launch shorter by two)
     RL_TRY(launch_guarded_select(sc, n_gemm, idx->n_chunks, ld, k, nullptr, nullptr, nullptr, 0, SCAN_RAW_DOT, 1.0f, d_s, d_c, hb.flag, s));
+    if (idx->opt.on(RL_OPT_LAZY_IMAGES) && !image_valid(idx)) {  // (lazy images: let the next batch know whether this one fell back)
+        if (!idx->h_fell_back) {
+            RL_HIP(hipHostMalloc(reinterpret_cast<void**>(&idx->h_fell_back), sizeof(uint32_t), hipHostMallocDefault));
+            *idx->h_fell_back = 0u;
+        }
+        RL_HIP(hipMemcpyAsync(idx->h_fell_back, hb.flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
     return RL_OK;
 }
 }  // namespace
@@ -2149,7 +2203,7 @@ static int maxsim_topk_batch_any(rl_index* idx, const void* query_vecs, bool q16
     int32_t base = 0;
     bool hi_done = false;  // queries [0, base) were ranked by the half-bytes pipeline below (results already in d_s / d_c)
     {
-        const int st = gemm_prepare(idx, d_q, nq, (int64_t)q_elems, n_queries, s);
+        const int st = gemm_prepare(idx, d_q, nq, (int64_t)q_elems, n_queries, s, k > 512);
         if (st == RL_OK) {
             const int32_t n_gemm = n_queries - base >= GEMM_PASS_MIN_QUERIES
                                        ? (n_queries / GEMM_PASS_QUERIES) * GEMM_PASS_QUERIES +
@@ -2174,7 +2228,9 @@ static int maxsim_topk_batch_any(rl_index* idx, const void* query_vecs, bool q16
                 // 307 candidates per query, the 128-query step 17.1 -> 12.8 ms.  RL_OPT_HI_PRODUCTS = 2: two products.
                 HiBatch hb;
                 RL_TRY(hi_batch_approx(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, s));
-                if (q16 && idx->E16 && hb.one_product && idx->opt.on(RL_OPT_F16_EXACT)) {
+                // (an fp32-STORED corpus whose every element is an fp16 value at the split scale -- what its HI halves drop was measured as
+                // exactly zero when the image was built -- is the same case: RAGLite's embeddings handed over as float32 arrays)
+                if (q16 && (idx->E16 || idx->max_lo_norm == 0.f) && hb.one_product && idx->opt.on(RL_OPT_F16_EXACT)) {
                     // fp16 queries x fp16-stored corpus: q_hi . e IS q . e (products of two fp16 values are exact in fp32; the sums are the
                     // pass's fp32 accumulation) -- its top-k is the result; certified per query, the full-precision passes behind the flag
                     RL_TRY(launch_f16_exact_finish(d_q, nq, idx->dim, (int64_t)q_elems, hb.q_unscale, hb.ts, hb.ti, n_gemm, k, d_s, d_c, hb.cnt, hb.flag, s));
@@ -2327,6 +2383,7 @@ int rl_maxsim_approx_scores(rl_index* idx, const float* query_vecs, int32_t n_qu
     // (both pass kernels find a chunk by counting chunk ends: an empty chunk would shift every score behind it to the wrong chunk)
     if (idx->has_empty_chunk || idx->n_chunks == 0)
         return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_approx_scores: the approximate pass needs an index without empty chunks");
+    RL_TRY(demand_images(idx, approx_image_bit(idx), s));
     if (!approx_image_valid(idx) || nq > 32 || (kernel == 0 && idx->dim < 256))
         return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_approx_scores: this index keeps no HI image (or nq > 32 / dim < 256)");
     DevBuf t_q, t_o, t_b;
@@ -2554,7 +2611,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the pair kernel does not apply to this index / shape") : st; }
     }
     if (kind == 3 || kind == 5 || kind == 6) {  // eight queries of nq / 8 vectors each
-        st = gemm_prepare(idx, q_dev, nq / GEMM_PASS_QUERIES, (int64_t)(nq / GEMM_PASS_QUERIES) * idx->dim, GEMM_PASS_QUERIES, s);
+        st = gemm_prepare(idx, q_dev, nq / GEMM_PASS_QUERIES, (int64_t)(nq / GEMM_PASS_QUERIES) * idx->dim, GEMM_PASS_QUERIES, s, true);
         if (st == RL_OK && !image_valid(idx)) st = RL_ERR_UNSUPPORTED;  // (an index of rows + HI image: only the sixteen-query pass applies)
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the eight-query kernel does not apply to this index / shape") : st; }
     }
@@ -2597,6 +2654,8 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
                                      : fail(RL_ERR_UNSUPPORTED, "rl_time_kernel: the index has no HI image");
         }
         else if (kind == 4) {  // the ranking pass of the half-bytes search: the f16 stream kernel over the HI plane
+            if (i == 0) st = demand_images(idx, IMG_HI_PLANE, s);
+            if (st != RL_OK) break;
             st = hi_valid(idx) ? launch_maxsim_stream16(idx->hiplane.as<uint16_t>(), idx->n_rows, idx->dim, q_dev, nq, idx->row_to_chunk, idx->offsets,
                                                         idx->n_chunks, 1, idx->scores.as<float>(), ld, idx->n_cu, s)
                                : fail(RL_ERR_UNSUPPORTED, "rl_time_kernel: the index has no HI plane");

@@ -416,8 +416,21 @@ def shaped(kind: str, n: int = 1_000_000, n_queries: int = 128, steps: int = 10)
     rec_tol = float((got_at >= kth - 1e-4).double().mean())
     missed = int(((ref > (S[:, -1:].double() + 2e-4)).sum(dim=1) > k).sum())  # queries with > k chunks clearly above the returned k-th
     arith = idx.arithmetic
+    # The same queries handed over as what they ARE -- fp16 values (`_embed.py:140`): rl_maxsim_topk_batch_f16.  The corpus rows are fp16
+    # values too (stored as float32 here; the index measured max |e_lo| = 0 when it built the HI image), so the one-product pass is exact
+    # and its own top-k is the result: no candidate list, no re-scoring kernel.
+    Q16 = Q.half()
+    ms16 = timed(lambda: idx.maxsim_topk_batch(Q16, k), steps)
+    S16, C16 = idx.maxsim_topk_batch(Q16, k)
+    stats16 = idx.filter_stats()
+    got16 = torch.gather(ref, 1, C16.long())
+    f16_block = {"value": n_queries / (ms16 * 1e-3), "unit": "queries/s", "ms_per_step": float(ms16), "route": stats16["kind"],
+                 "fallback": bool(stats16["fallback"]), "score_max_abs_err_vs_f64": float((S16.double() - got16).abs().max()),
+                 "recall_at_100_within_tol": float((got16 >= kth - 1e-4).double().mean()),
+                 "same_chunk_sets_as_fp32_queries": bool(all(set(a.tolist()) == set(b.tolist()) for a, b in zip(C16.cpu().numpy(), C.cpu().numpy())))}
     idx.close()
     return {
+        "f16_queries": f16_block,
         "workload": f"maxsim_{nq}x{n}_d{d}_top{k}_ragged_chunks_1to15_RAGLITE_SHAPED_{kind}_not_the_baseline_config",
         "value": n_queries / (ms * 1e-3), "unit": "queries/s", "ms_per_step": float(ms), "timing": ms.stats, "arithmetic": arith,
         "queries_per_step": n_queries, "filter": stats, "candidates_per_query": {"mean": stats["candidates_per_query_mean"], "max": stats["candidates_per_query_max"]},

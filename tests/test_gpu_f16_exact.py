@@ -136,15 +136,48 @@ def test_fewer_chunks_than_k_tombstones_and_small_batches():
     idx.close()
 
 
-def test_fp16_queries_over_an_fp32_index_are_widened_and_filtered_as_before():
+def test_fp16_queries_over_an_fp32_index_of_fp16_values_take_the_exact_route_too():
+    """RAGLite's embeddings handed over as float32 arrays: the index measures what its HI halves drop when it builds their image -- exactly
+    zero here -- and the fp16 queries' pass is exact again."""
     rng = np.random.default_rng(12)
     off = ragged_offsets(rng, N, 1, 15)
     E = oracle.synth_matrix(20_800, N, DIM, "small_int")
     Q16 = np.stack([oracle.synth_matrix(20_900 + i, 32, DIM, "small_int") for i in range(8)]).astype(np.float16)
     idx = raglite_amd.DeviceIndex(E, off, metric="dot")
     bs, bc = idx.maxsim_topk_batch(Q16, 100)
+    assert _stats(idx) == ("maxsim_batch_f16_exact", 0, False)
+    with idx.options(f16_exact=0):
+        fs, fc = idx.maxsim_topk_batch(Q16, 100)
     assert _stats(idx)[0] == "maxsim_batch_hi"
+    assert np.array_equal(bc, fc) and np.array_equal(bs.view(np.uint32), fs.view(np.uint32))
     for i in (0, 7):
         ws, wc = oracle.maxsim_topk(E, off, Q16[i].astype(np.float32), 100, np.float32)
         assert np.array_equal(bc[i], wc) and np.array_equal(bs[i], ws)
+    # unit rows rounded through fp16 (`_embed.py:139-140`), stored as float32: float data, the same route, the route's tolerance
+    U = oracle.synth_matrix(20_850, N, DIM)
+    U = (U / np.linalg.norm(U, axis=1, keepdims=True)).astype(np.float16).astype(np.float32)
+    Qu = np.stack([oracle.synth_matrix(20_950 + i, 32, DIM) for i in range(5)])
+    Qu = (Qu / np.linalg.norm(Qu, axis=2, keepdims=True)).astype(np.float16)
+    idu = raglite_amd.DeviceIndex(U, off, metric="dot")
+    us, uc = idu.maxsim_topk_batch(Qu, 100)
+    assert _stats(idu) == ("maxsim_batch_f16_exact", 0, False)
+    for i in range(5):
+        ref = oracle.maxsim_scores(U.astype(np.float64), off, Qu[i].astype(np.float64), np.float64)
+        assert_topk_close(us[i], uc[i], ref, 100, 1e-4)  # north_star's absolute bar on unit-norm scores (<= 32)
+        np.testing.assert_allclose(us[i], ref[uc[i]], rtol=0, atol=2e-5)
+    idu.close()
+    idx.close()
+
+
+def test_fp16_queries_over_an_fp32_index_of_other_values_are_widened_and_filtered_as_before():
+    rng = np.random.default_rng(13)
+    off = ragged_offsets(rng, N, 1, 15)
+    E = oracle.synth_matrix(20_860, N, DIM)  # U(-1, 1): not fp16 values
+    Q16 = np.stack([oracle.synth_matrix(20_960 + i, 32, DIM) for i in range(8)]).astype(np.float16)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    bs, bc = idx.maxsim_topk_batch(Q16, 100)
+    assert _stats(idx)[0] == "maxsim_batch_hi"
+    for i in (0, 7):
+        ref = oracle.maxsim_scores(E, off, Q16[i].astype(np.float64), np.float64)
+        assert_topk_close(bs[i], bc[i], ref, 100, 2e-6 * float(np.abs(ref).max()))
     idx.close()

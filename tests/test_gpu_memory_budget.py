@@ -22,6 +22,7 @@ import numpy as np, torch
 import raglite_amd
 raglite_amd.set_device(0)
 headroom_mb = int(sys.argv[1])
+raglite_amd.set_default_option("lazy_images", int(sys.argv[2]))
 if headroom_mb >= 0:
     raglite_amd.set_default_option("image_headroom_mb", headroom_mb)  # start value of every index created from here on
 n, dim, nq, B, k = 70_000, 1024, 32, 5, 20
@@ -31,16 +32,18 @@ rng = np.random.default_rng(1)
 sizes = rng.integers(1, 16, n); off = np.concatenate(([0], np.cumsum(sizes))); off = off[off <= n]
 if off[-1] != n: off = np.concatenate((off, [n]))
 idx = raglite_amd.DeviceIndex(E, off.astype(np.int64), metric="dot")
-mem = idx.memory()
+mem0 = idx.memory()
 s, c = idx.maxsim_topk_batch(Q, k)
+mem1 = idx.memory()
 rs, rr = idx.search_rows(Q[:, 0, :].contiguous(), k)
-print(json.dumps({"mem": mem, "scores": s.cpu().numpy().tolist(), "chunks": c.cpu().numpy().tolist(),
+mem = idx.memory()
+print(json.dumps({"mem": mem, "mem_after_create": mem0, "mem_after_maxsim": mem1, "scores": s.cpu().numpy().tolist(), "chunks": c.cpu().numpy().tolist(),
                   "row_scores": rs.cpu().numpy().tolist(), "rows": rr.cpu().numpy().tolist(), "filter": idx.filter_stats()["kind"]}))
 """
 
 
-def _run(headroom_mb):
-    res = subprocess.run([sys.executable, "-c", CHILD, str(headroom_mb)], cwd=ROOT, env=dict(os.environ), capture_output=True, text=True, timeout=600)
+def _run(headroom_mb, lazy=0):
+    res = subprocess.run([sys.executable, "-c", CHILD, str(headroom_mb), str(lazy)], cwd=ROOT, env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     return json.loads(res.stdout.strip().splitlines()[-1])
 
@@ -62,6 +65,40 @@ def test_index_without_room_for_its_images_gives_the_same_results():
     assert without["rows"] == with_images["rows"] and without["row_scores"] == with_images["row_scores"]
 
 
+def test_lazy_images_are_built_by_the_first_call_that_reads_them():
+    """`lazy_images` (the default since round 5): nothing but the rows after `rl_index_create`; a MaxSim batch builds the HI image (1.5 x the
+    corpus), a search of five row queries the HI plane, and the pre-split image (4 B per element) only arrives with a batch of >= 96 row
+    queries.  Same results as an index that built everything at once."""
+    eager, lazy = _run(-1, 0), _run(-1, 1)
+    rows = lazy["mem"]["rows"]
+    a, b, c = lazy["mem_after_create"], lazy["mem_after_maxsim"], lazy["mem"]
+    assert a["presplit_image"] == a["hi_image"] == a["hi_plane"] == 0
+    assert b["hi_image"] >= rows // 2 and b["presplit_image"] == 0 and b["hi_plane"] == 0
+    assert c["hi_image"] == b["hi_image"] and c["hi_plane"] >= rows // 2 and c["presplit_image"] == 0
+    assert eager["mem_after_create"]["presplit_image"] >= rows and eager["mem_after_create"]["hi_plane"] >= rows // 2
+    assert lazy["filter"] == eager["filter"] == "rows_hi"
+    for key in ("chunks", "scores", "rows", "row_scores"):
+        assert lazy[key] == eager[key], key
+    import raglite_amd
+    from oracle import oracle
+
+    n, dim = 70_000, 1024
+    E = oracle.synth_matrix(33, n, dim, "small_int")
+    Q = oracle.synth_matrix(34, 100, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E, metric="dot")
+    assert idx.get_option("lazy_images") == 1 and idx.memory()["presplit_image"] == 0
+    s, r = idx.search_rows(Q, 10)  # 100 queries: the fused top-k over HI image + pre-split image
+    m = idx.memory()
+    assert m["presplit_image"] >= m["rows"] and m["hi_image"] >= m["rows"] // 2 and m["hi_plane"] == 0
+    assert idx.filter_stats()["kind"] == "rows_fused_hi"
+    for b in (0, 99):
+        es, er = oracle.search_rows(E, Q[b], 10, "dot", np.float32)
+        assert np.array_equal(r[b], er) and np.array_equal(s[b], np.asarray(es, np.float32))
+    idx.set_option("lazy_images", 0)  # everything the KEEP_* options allow, now
+    assert idx.memory()["hi_plane"] >= m["rows"] // 2
+    idx.close()
+
+
 def test_options_release_and_rebuild_the_images():
     """`rl_index_set_option(KEEP_IMAGE / KEEP_HI)` releases and rebuilds the accelerators of a live index; results do not move."""
     import raglite_amd
@@ -71,6 +108,7 @@ def test_options_release_and_rebuild_the_images():
     E = oracle.synth_matrix(31, n, dim, "small_int")
     q = oracle.synth_matrix(32, 1, dim, "small_int")[0]
     idx = raglite_amd.DeviceIndex(E, metric="dot")
+    idx.set_option("lazy_images", 0)  # every image at once, as before round 5
     m0 = idx.memory()
     s0, r0 = idx.search_rows(q, 10)
     assert m0["presplit_image"] > 0 and m0["hi_plane"] > 0 and idx.filter_stats()["kind"] == "rows_hi"

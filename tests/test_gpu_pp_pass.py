@@ -256,6 +256,7 @@ def test_giant_row_defeats_the_bound_and_the_fallback_answers():
     off = ragged_offsets(rng, n, 1, 15)
     E, Q = _adversarial(torch, "giant", n, dim, n_queries, nq)
     idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    idx.set_option("lazy_images", 0)  # (the pre-split image from the start: the guarded fallback is the eight-query full-precision pass)
     assert idx.arithmetic == "f16_split"  # (500 x is inside the 2^10 window that keeps the split arithmetic)
     got, m = idx.maxsim_approx_scores(Q, kernel=0)
     ref = bench_configs.maxsim_scores_f64(E, off, Q)

@@ -288,3 +288,29 @@ def test_communicator_only_index_merges_host_arrays_over_all_ranks():
     sh._world = lambda: 2  # noqa: SLF001
     with pytest.raises(RuntimeError, match="neither torch.distributed nor a Communicator"):
         sh.search_rows(Q, 5)
+
+
+def test_fp16_queries_over_fp16_stored_shards_skip_the_threshold_exchange():
+    """`ShardedIndex.maxsim_topk_batch`: with fp16 queries and fp16-stored shards every shard's pass is exact, so the staged form (begin ->
+    all-gather of approximate lists -> finish) is not entered; any other combination still takes it."""
+    calls = []
+
+    class _Local:
+        storage = "f16"
+
+        def maxsim_topk_batch(self, Qb, k):
+            calls.append(("batch", str(Qb.dtype)))
+            return np.zeros((len(Qb), k), np.float32), np.zeros((len(Qb), k), np.int32)
+
+        def maxsim_batch_begin(self, Qb, k):
+            calls.append(("begin", str(Qb.dtype)))
+            raise RuntimeError("staged")
+
+    sh = ShardedIndex(_Local(), row_base=0, chunk_base=0)
+    sh._world = lambda: 8  # noqa: SLF001
+    sh._local_maxsim_batch(np.zeros((8, 4, 32), np.float16), 5)  # noqa: SLF001
+    assert calls == [("batch", "float16")]
+    calls.clear()
+    sh._allgather_int = lambda x: np.stack([x] * 8)  # noqa: SLF001
+    sh._local_maxsim_batch(np.zeros((8, 4, 32), np.float32), 5)  # noqa: SLF001
+    assert calls[0] == ("begin", "float32")
