@@ -2143,9 +2143,11 @@ int hi_batch_fallback(rl_index* idx, const float* d_q, int32_t nq, int32_t n_que
     if (image_valid(idx))
         RL_TRY(launch_maxsim_gemm(idx->planes.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, 0, n_gemm, nq, idx->row_to_chunk, idx->offsets,
                                   idx->ends.as<uint32_t>(), sc, ld, idx->n_cu, s, image_scale(idx), idx->E16 != nullptr, hb.flag, false, true));
-    else
+    else  // (grid row = query: with many queries a grid column of n_cu workgroups per query is 32 k workgroups that return at once behind the
+          // flag -- 25 us of every step; n_cu / 8 columns keep the device as full when the passes do run and cost 3 us when they do not)
         RL_TRY(launch_maxsim_stream_batch(idx->E, false, idx->n_rows, idx->dim, d_q, nq, (int64_t)q_elems, n_gemm, idx->row_to_chunk, idx->offsets,
-                                          idx->n_chunks, sc, ld, idx->n_cu, s, idx->split_scale, hb.flag));
+                                          idx->n_chunks, sc, ld, std::max(1, idx->n_cu / std::min<int32_t>(8, std::max<int32_t>(1, n_gemm / 4))), s,
+                                          idx->split_scale, hb.flag));
     RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // (harmless on scores nobody reads)
     // (the exact top-k of the fallback's scores in ONE guarded launch, a block per query -- select.hip: guarded_select_kernel -- instead of the
     // selection's three: what usually returns at once is one launch shorter by two)

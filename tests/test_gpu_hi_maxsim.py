@@ -477,3 +477,23 @@ def test_slim_index_fallback_runs_the_streaming_kernels(data):
             ref = oracle.maxsim_scores(E, off, Qb[i], np.float64)
             assert_topk_close(bs[i], bc[i], ref, 100, 2e-6 * float(np.abs(ref).max()))
     idx.close()
+
+
+def test_streaming_fallback_of_a_big_batch_runs_on_a_narrower_grid_with_the_same_bits():
+    """Rows + HI image (lazy images, first batch): 32 queries fall back through the streaming kernels on n_cu / 8 grid columns per query
+    (the guarded launch of a 128-query step would otherwise be 32 k workgroups that return at once).  Integer data: exact, whatever the grid."""
+    rng = np.random.default_rng(47)
+    off = np.arange(N + 1, dtype=np.int64)
+    E = oracle.synth_matrix(12_500, N, DIM, "small_int")
+    Qb = np.stack([oracle.synth_matrix(12_600 + i, 8, DIM, "small_int") for i in range(32)])
+    hot = rng.choice(N, 6000, replace=False)
+    E[hot] = np.sign(Qb[:, 0].sum(axis=0) + 0.5)[None, :] * 3.0  # 6 000 identical one-row chunks at the top of every ranking
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    bs, bc = idx.maxsim_topk_batch(Qb, 100)
+    st = idx.filter_stats()
+    assert st["kind"] == "maxsim_batch_hi" and st["fallback"] and idx.memory()["presplit_image"] == 0
+    for i in (0, 13, 31):
+        ref = oracle.maxsim_scores(E, off, Qb[i], np.float64)
+        order = np.lexsort((np.arange(len(ref)), -ref))[:100]
+        assert np.array_equal(bc[i], order) and np.array_equal(bs[i].astype(np.float64), ref[order])
+    idx.close()
