@@ -2153,11 +2153,11 @@ int hi_batch_fallback(rl_index* idx, const float* d_q, int32_t nq, int32_t n_que
     // selection's three: what usually returns at once is one launch shorter by two)
     RL_TRY(launch_guarded_select(sc, n_gemm, idx->n_chunks, ld, k, nullptr, nullptr, nullptr, 0, SCAN_RAW_DOT, 1.0f, d_s, d_c, hb.flag, s));
     if (idx->opt.on(RL_OPT_LAZY_IMAGES) && !image_valid(idx)) {  // (lazy images: let the next batch know whether this one fell back)
-        if (!idx->h_fell_back) {
-            RL_HIP(hipHostMalloc(reinterpret_cast<void**>(&idx->h_fell_back), sizeof(uint32_t), hipHostMallocDefault));
-            *idx->h_fell_back = 0u;
+        if (!idx->h_fell_back) {  // (no pinned word: no signal -- the fallback then stays on the streaming kernels, results unchanged)
+            if (hipHostMalloc(reinterpret_cast<void**>(&idx->h_fell_back), sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) *idx->h_fell_back = 0u;
+            else { idx->h_fell_back = nullptr; (void)hipGetLastError(); }
         }
-        RL_HIP(hipMemcpyAsync(idx->h_fell_back, hb.flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (idx->h_fell_back) RL_HIP(hipMemcpyAsync(idx->h_fell_back, hb.flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
     return RL_OK;
 }
