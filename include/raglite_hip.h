@@ -193,6 +193,8 @@ int rl_index_arithmetic(rl_index* index, int* in_effect);
  *   RL_OPT_FUSED_TOPK           0 / 1 (1)          B >= 96 row searches keep candidate lists instead of a score matrix
  *   RL_OPT_FUSED_HI             0 / 1 (1)          ... with both GEMM passes over the HI image at one product
  *   RL_OPT_FUSED_PP             0 / 1 (1)          ... and the candidate pass on the sixteen-group tile of maxsim_pp.hip
+ *   RL_OPT_FUSED_PP_SAMPLE      0 / 1 (1)          ... and the sample pass before it on the same tile (0: the eight-group kernel of maxsim_gemm.hip)
+ *   RL_OPT_LIST_SELECT          0 / 1 (1)          ... whose per-query lists are cut by a radix SELECT of their k-th best score (0: by sorting them)
  *   RL_OPT_FUSED_TWO_ROUNDS     0 / 1 (1)          ... in two rounds: thresholds tightened from the first 3/16 of the rows (0: one round)
  *   RL_OPT_FUSED_TOPK_CAP       0 | 1..8192 (0)    list capacity of the fused top-k (0: built-in; tests force overflows with it)
  *   RL_OPT_FUSED_TOPK_STRIDE    0 | >= 2 (0)       sample stride of the fused top-k (0: built-in rule)
@@ -224,7 +226,8 @@ typedef enum {
     RL_OPT_FUSED_PP = 7, RL_OPT_FUSED_TOPK_CAP = 8, RL_OPT_FUSED_TOPK_STRIDE = 9, RL_OPT_GEMM_PASS = 10, RL_OPT_QUERY_PAIRS = 11,
     RL_OPT_PLANES_GEMM = 12, RL_OPT_KEEP_IMAGE = 13, RL_OPT_KEEP_HI = 14, RL_OPT_IMAGE_HEADROOM_MB = 15, RL_OPT_ARITHMETIC = 16,
     RL_OPT_EXACT_KTH_THRESHOLD = 17, RL_OPT_FUSED_TWO_ROUNDS = 18, RL_OPT_KEEP_HI_PLANE = 19, RL_OPT_PAIRS_PACKED = 20,
-    RL_OPT_F16_EXACT = 21, RL_OPT_LAZY_IMAGES = 22, RL_OPT_COUNT_ = 23
+    RL_OPT_F16_EXACT = 21, RL_OPT_LAZY_IMAGES = 22, RL_OPT_FUSED_PP_SAMPLE = 23,
+    RL_OPT_LIST_SELECT = 24, RL_OPT_COUNT_ = 25
 } rl_option;
 int rl_set_default_option(int key, int64_t value);
 int rl_get_default_option(int key, int64_t* value);

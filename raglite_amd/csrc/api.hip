@@ -200,7 +200,7 @@ struct Options {
         for (auto& x : v) x = 0;
         v[RL_OPT_HI_SEARCH] = v[RL_OPT_HI_MAXSIM] = v[RL_OPT_HI_PRODUCTS] = v[RL_OPT_PP_PASS] = v[RL_OPT_FUSED_TOPK] = v[RL_OPT_FUSED_HI] = 1;
         v[RL_OPT_FUSED_PP] = v[RL_OPT_GEMM_PASS] = v[RL_OPT_QUERY_PAIRS] = v[RL_OPT_PLANES_GEMM] = v[RL_OPT_KEEP_IMAGE] = v[RL_OPT_KEEP_HI] = 1;
-        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = v[RL_OPT_F16_EXACT] = v[RL_OPT_LAZY_IMAGES] = 1;
+        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = v[RL_OPT_F16_EXACT] = v[RL_OPT_LAZY_IMAGES] = v[RL_OPT_FUSED_PP_SAMPLE] = v[RL_OPT_LIST_SELECT] = 1;
         v[RL_OPT_IMAGE_HEADROOM_MB] = -1;
         v[RL_OPT_ARITHMETIC] = RL_ARITH_AUTO;
     }
@@ -212,7 +212,7 @@ bool option_value_ok(int key, int64_t value) {
     switch (key) {
         case RL_OPT_HI_SEARCH: case RL_OPT_HI_MAXSIM: case RL_OPT_PP_PASS: case RL_OPT_FUSED_TOPK: case RL_OPT_FUSED_HI: case RL_OPT_FUSED_PP:
         case RL_OPT_GEMM_PASS: case RL_OPT_QUERY_PAIRS: case RL_OPT_PLANES_GEMM: case RL_OPT_KEEP_IMAGE: case RL_OPT_KEEP_HI:
-        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED: case RL_OPT_F16_EXACT: case RL_OPT_LAZY_IMAGES:
+        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED: case RL_OPT_F16_EXACT: case RL_OPT_LAZY_IMAGES: case RL_OPT_FUSED_PP_SAMPLE: case RL_OPT_LIST_SELECT:
             return value == 0 || value == 1;
         case RL_OPT_HI_PRODUCTS: return value == 1 || value == 2;
         case RL_OPT_FUSED_TOPK_CAP: return value >= 0 && value <= MERGE_CAP;
@@ -879,7 +879,7 @@ static int index_create_any(rl_index** out, const void* embeddings, bool f16, in
     RL_IDX_HIP(hipMemcpyAsync(idx->offsets, chunk_offsets, (size_t)(n_chunks + 1) * sizeof(int64_t), hipMemcpyHostToDevice, s));
     RL_IDX_HIP(hipMalloc(&idx->row_to_chunk, (size_t)(n_rows + 65) * sizeof(int32_t)));  // +1 terminator, +64 pad
     RL_IDX(launch_row_to_chunk(idx->offsets, n_chunks, n_rows, idx->row_to_chunk, s));
-    if (metric == RL_COSINE) RL_IDX_HIP(hipMalloc(&idx->norm, std::max<size_t>((size_t)n_rows * sizeof(float), 16)));
+    if (metric == RL_COSINE) RL_IDX_HIP(hipMalloc(&idx->norm, (size_t)n_rows * sizeof(float) + 64));  // (+ 64 B: a 16-row block's norms are readable with one scalar load)
     if (metric == RL_L2) RL_IDX_HIP(hipMalloc(&idx->sumsq, std::max<size_t>((size_t)n_rows * sizeof(float), 16)));
     if (idx->norm || idx->sumsq)
         RL_IDX(f16 ? launch_row_norms16(idx->E16, n_rows, dim, idx->norm, idx->sumsq, s)
@@ -1020,7 +1020,7 @@ int rl_index_compact(rl_index* idx, int64_t* out_remap, int64_t* new_n_rows, int
 #define RL_CMP(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return undo(fail(_e == hipErrorOutOfMemory ? RL_ERR_NOMEM : RL_ERR_HIP, std::string("rl_index_compact: ") + hipGetErrorString(_e))); } while (0)
     RL_CMP(hipMalloc(&e, std::max<size_t>((size_t)new_n * row_bytes, 16)));
     RL_CMP(hipMalloc(&map, std::max<size_t>((size_t)new_n * sizeof(int64_t), 16)));
-    if (idx->norm) RL_CMP(hipMalloc(&nn, std::max<size_t>((size_t)new_n * sizeof(float), 16)));
+    if (idx->norm) RL_CMP(hipMalloc(&nn, (size_t)new_n * sizeof(float) + 64));
     if (idx->sumsq) RL_CMP(hipMalloc(&ns, std::max<size_t>((size_t)new_n * sizeof(float), 16)));
     RL_CMP(hipMalloc(&r2c, (size_t)(new_n + 65) * sizeof(int32_t)));
     RL_CMP(hipMalloc(&o, (size_t)(new_c + 1) * sizeof(int64_t)));
@@ -1183,7 +1183,7 @@ int rl_index_append(rl_index* idx, const float* rows, int64_t n_new_rows, const 
 #define RL_GROW(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) return undo(fail(_e == hipErrorOutOfMemory ? RL_ERR_NOMEM : RL_ERR_HIP, std::string("rl_index_append: ") + hipGetErrorString(_e))); } while (0)
         if (grow_rows) {
             RL_GROW(hipMalloc(&e, std::max<size_t>((size_t)cap * row_bytes, 16)));
-            if (idx->norm) RL_GROW(hipMalloc(&nn, std::max<size_t>((size_t)cap * sizeof(float), 16)));
+            if (idx->norm) RL_GROW(hipMalloc(&nn, (size_t)cap * sizeof(float) + 64));
             if (idx->sumsq) RL_GROW(hipMalloc(&ns, std::max<size_t>((size_t)cap * sizeof(float), 16)));
             RL_GROW(hipMalloc(&r2c, (size_t)(cap + 65) * sizeof(int32_t)));
         }
@@ -1476,8 +1476,15 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
     // ---- (1) sample pass + its exact top-k ------------------------------------------------------------------------------------
     RL_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
     RL_TRY(launch_score_planes_queries(d_q, B, idx->dim, qs, mode, s));
-    RL_TRY(launch_score_planes_pass(hi, n, idx->dim, B, qs, S_s, ld_s, idx->norm, idx->sumsq, mode, stride, nullptr, nullptr, idx->n_cu, s, sscale, true,
-                                    hi_only));
+    // (round 5: on the sixteen-group tile of maxsim_pp.hip, MODE 1 -- the eight-group kernel gives every workgroup ONE 256 x 256 tile and is
+    // start-up bound there; RL_OPT_FUSED_PP_SAMPLE = 0 or shapes outside the tile: the eight-group kernel)
+    int st_sample = RL_ERR_UNSUPPORTED;
+    if (idx->opt.on(RL_OPT_FUSED_PP) && idx->opt.on(RL_OPT_FUSED_PP_SAMPLE) && hi_only && idx->dim % 32 == 0 && idx->dim >= 256)
+        st_sample = launch_pp_rows_sample(hi, n, idx->dim, B, qs, idx->norm, mode, S_s, ld_s, stride, idx->n_cu, s, sscale);
+    if (st_sample == RL_ERR_UNSUPPORTED)
+        st_sample = launch_score_planes_pass(hi, n, idx->dim, B, qs, S_s, ld_s, idx->norm, idx->sumsq, mode, stride, nullptr, nullptr, idx->n_cu, s, sscale,
+                                             true, hi_only);
+    RL_TRY(st_sample);
     RL_TRY(launch_topk(S_s, B, ld_s, ld_s, k, idx->ws, top_s, top_i, s));
     // ---- (2) thresholds lowered by the error band; candidate pass ---------------------------------------------------------------
     RL_TRY(launch_row_threshold(top_s, B, k, d_q, idx->dim, mode, hi_only ? q_unscale : nullptr, idx->max_lo_ratio, idx->max_lo_norm, idx->max_row_norm,
@@ -1508,8 +1515,12 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
             st_pp = launch_pp_rows_pass(hi, n, idx->dim, B, qs, idx->norm, mode, &ca, idx->pp_work.p, log_cap, idx->n_cu, s, sscale, 0, round1_tiles, false,
                                         row_test);
             if (st_pp == RL_OK) {
-                RL_TRY(launch_merge_topk(c_s, c_i, 1, B, cap, k, top_s, top_i, s, cnt));  // (top_s / top_i: the sample's top-k is not needed any more)
-                RL_TRY(launch_raise_threshold(thr, top_s, B, k, window, s));
+                if (idx->opt.on(RL_OPT_LIST_SELECT)) {  // (round 5: the k-th best of every list by a radix select, threshold raised in the same launch)
+                    RL_TRY(launch_list_raise_threshold(c_s, c_i, B, cap, k, cnt, window, thr, s));
+                } else {
+                    RL_TRY(launch_merge_topk(c_s, c_i, 1, B, cap, k, top_s, top_i, s, cnt));  // (top_s / top_i: the sample's top-k is not needed any more)
+                    RL_TRY(launch_raise_threshold(thr, top_s, B, k, window, s));
+                }
                 st_pp = launch_pp_rows_pass(hi, n, idx->dim, B, qs, idx->norm, mode, &ca, idx->pp_work.p, log_cap, idx->n_cu, s, sscale, round1_tiles,
                                             Tr - round1_tiles, true, row_test);
             }
@@ -1529,7 +1540,8 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
         r.log_cap = lc;
     }
     // ---- (3) the rows within the band of each list's k-th entry; (4) their exact similarities, ranked -----------------------------
-    RL_TRY(launch_list_prefix(c_s, c_i, B, cap, k, cnt, window, cap2, r_i, cnt2, flag, s));
+    if (idx->opt.on(RL_OPT_LIST_SELECT)) RL_TRY(launch_list_select(c_s, c_i, B, cap, k, cnt, window, cap2, r_i, cnt2, flag, s));
+    else RL_TRY(launch_list_prefix(c_s, c_i, B, cap, k, cnt, window, cap2, r_i, cnt2, flag, s));
     RL_TRY(launch_row_dots(idx->E, idx->dim, d_q, B, r_i, cnt2, cap2, mode, idx->norm, q_sumsq, r_s, s));
     RL_TRY(launch_merge_topk(r_s, r_i, 1, B, cap2, k, d_scores, d_rows, s, cnt2));
     // ---- (5) guarded dense fallback (full precision, over the pre-split image) ------------------------------------------------------

@@ -257,6 +257,12 @@ int launch_row_dots(const float* E, int32_t dim, const float* Q, int32_t nb, con
                     const float* row_norm, const float* q_sumsq, float* out, hipStream_t s);
 int launch_list_prefix(const float* in_scores, const int32_t* in_ids, int32_t nq, int32_t k_in, int32_t k, const uint32_t* counts,
                        const float* window, int32_t cap2, int32_t* out_ids, uint32_t* out_cnt, uint32_t* flag, hipStream_t s);
+// the same contract by a radix SELECT of the list's k-th best score instead of a sort (round 5; out_ids in any order), and the step between
+// the two rounds of the candidate pass -- thr[q] = max(thr[q], (k-th best of list q) - window[q]) -- as one launch of the same kernel
+int launch_list_select(const float* in_scores, const int32_t* in_ids, int32_t nq, int32_t k_in, int32_t k, const uint32_t* counts,
+                       const float* window, int32_t cap2, int32_t* out_ids, uint32_t* out_cnt, uint32_t* flag, hipStream_t s);
+int launch_list_raise_threshold(const float* in_scores, const int32_t* in_ids, int32_t nq, int32_t k_in, int32_t k, const uint32_t* counts,
+                                const float* window, float* thr, hipStream_t s);
 
 // mask.hip: validity bitsets (metadata filter pushed down to the device, tombstones of deleted chunks)
 int launch_expand_chunk_bits(const uint32_t* chunk_bits, const int32_t* row_to_chunk, int64_t n_rows,
@@ -350,6 +356,9 @@ int launch_pp_rows_pass(const void* image, int64_t n_rows, int32_t dim, int32_t 
                         const CandArgs* cand, void* work, int32_t log_cap, int n_cu, hipStream_t s, float split_scale, int64_t tile_begin = 0,
                         int64_t tile_count = -1, bool norms_ready = false,
                         bool row_norm_test = false);  // cosine: test hits row by row against their own norms (wild norm spread)
+// the sample pass of the same search on that tile (MODE 1): S[q * ld_s + 256 j + r] = similarity of query q with row 256 stride j + r
+int launch_pp_rows_sample(const void* image, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, const float* row_norm, int mode, float* S,
+                          int64_t ld_s, int32_t stride, int n_cu, hipStream_t s, float split_scale);
 // thr[q] = max(thr[q], kth[q * k + k - 1] - window[q]): the k-th best approximate similarity of ANY subset of the rows bounds the k-th best
 // overall from below (select.hip; the second round of the fused top-k's candidate pass)
 int launch_raise_threshold(float* thr, const float* kth, int32_t nq, int32_t k, const float* window, hipStream_t s);

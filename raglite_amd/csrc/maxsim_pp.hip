@@ -33,6 +33,11 @@
 // are added in another order: scores agree to the last bits, not bit for bit, on float data.  Needs an index without empty chunks (a chunk
 // is found by counting chunk ends), nq <= 32, dim % 32 == 0, dim >= 256.
 //
+// MODE 1 (round 5): the SAMPLE pass of the same search on the same tile -- the similarities of every stride-th 256-row tile with all queries,
+// written out (the tile epilogue applies the metric's transform; its stores sit in the wave's in-order VMEM queue in front of the next tile's
+// first query loads, a stall of a few microseconds per 25-us tile that a pass of two or three tiles per workgroup can afford).  Was the
+// eight-group kernel of maxsim_gemm.hip (one tile per workgroup, start-up bound): profiles/r05_*.
+//
 // MODE 2: the same main loop as the candidate pass of the fused exact row top-k (api.hip: search_rows_fused_hi; BASELINE cfg 5,
 // src/raglite/_search.py:69-79 at B = 1000): a "query" of the tile is a GROUP of 32 single-vector queries (the fragment layout of
 // query_rows_planes_kernel is that of query_planes_kernel), blockIdx.y = the query tile, and the tile epilogue compares every accumulator
@@ -112,6 +117,9 @@ struct PpRows {
     float* cand_scores; int32_t* cand_ids; uint32_t* cand_cnt; uint32_t* overflow; int32_t cap;  // per-query lists (as maxsim_gemm.hip MODE 2)
     uint2* log; int32_t log_cap;          // [workgroups * 8][log_cap] wave-private records (raw accumulator, packed coordinates)
     int32_t tile_begin, tile_count;       // the 128-row tiles this launch covers: [tile_begin, tile_begin + tile_count)
+    // MODE 1 (the SAMPLE pass of the fused top-k): scores of every `stride`-th 256-row tile, S[q * ld_s + 256 j + r] = similarity of query q with
+    // row 256 stride j + r (rows past the corpus: -inf); tile_count = 2 x the sampled 256-row tiles (a launch tile has 128 rows)
+    float* S; int64_t ld_s; int32_t stride;
 };
 
 // DBG: timing skeletons (experiment builds only, -DRAGLITE_EXPERIMENTS + RAGLITE_PP_DBG / RAGLITE_PP_ROWS_DBG; WRONG results):
@@ -123,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
                                                            const int32_t* __restrict__ row_to_chunk, const int64_t* __restrict__ chunk_offsets,
                                                            const uint32_t* __restrict__ ends_bits, float* __restrict__ out, int64_t out_stride,
                                                            float inv_e_scale, const uint32_t* __restrict__ run_if, PpRows rs) {
-    constexpr bool ROWS = MODE == 2;
+    constexpr bool ROWS = MODE == 2, SCORES = MODE == 1, GROUPS = ROWS || SCORES;  // GROUPS: a "query" of the tile is a group of 32 single-vector queries
     __shared__ __attribute__((aligned(16))) char smem[PP_LDS];
     if (run_if && __builtin_amdgcn_readfirstlane((int)*run_if) == 0) return;  // whole grid: a guarded launch that is not needed
     const int lane = threadIdx.x & 63;
@@ -138,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         return c0 == t ? t : c1;
     };
     int32_t r_lo = 0, r_hi = 0, nt_rows = 0;
-    if constexpr (!ROWS) {
+    if constexpr (!GROUPS) {
         r_lo = (int32_t)pp_uniform_i64(boundary((n_rows * b) / G));
         r_hi = (int32_t)pp_uniform_i64((b + 1 == G) ? n_rows : boundary((n_rows * (b + 1)) / G));
         if (r_hi <= r_lo) return;  // whole workgroup
@@ -149,15 +157,25 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         const int64_t t0 = (Tr * b) / G, t1 = (Tr * (b + 1)) / G;
         nt_rows = (int32_t)(t1 - t0);
         if (nt_rows <= 0) return;  // whole workgroup
-        r_lo = (int32_t)((rs.tile_begin + t0) * PP_RT);
+        r_lo = (int32_t)((rs.tile_begin + t0) * PP_RT);  // (MODE 1: the ORDINAL of the workgroup's first sample tile x 128 -- see tile_blk)
         r_hi = (int32_t)n_rows;
     }
     const int32_t org = r_lo & ~15;  // tiles start on a 16-row block of the image
-    const int nt = ROWS ? nt_rows : (r_hi - org + PP_RT - 1) / PP_RT;
+    const int nt = GROUPS ? nt_rows : (r_hi - org + PP_RT - 1) / PP_RT;
+    // first 16-row block of the workgroup's tile t.  MODE 1 walks SAMPLE tiles: ordinal o = org / 128 + t is the (o & 1)-th half of the
+    // (o >> 1)-th sampled 256-row tile, which starts at row 256 stride (o >> 1)
+    auto tile_blk = [&](int t) __attribute__((always_inline)) -> int32_t {
+        if constexpr (SCORES) {
+            const int32_t o = (org >> 7) + t;
+            return ((o >> 1) * 2 * rs.stride + (o & 1)) * PP_NBLK;
+        } else {
+            return (org >> 4) + t * PP_NBLK;
+        }
+    };
     // query tile: MODE 2 -- 16 groups of 32 queries; MODE 0 -- the launch's passes (16 queries each) as grid rows: ONE launch for a batch's
     // passes instead of one per pass, so a pass's workgroups start on the CUs the previous pass's leave instead of behind a launch boundary
     const int qt = (int)blockIdx.y;
-    const int q_base = ROWS ? 0 : PP_QPP * qt;  // first query of this workgroup's pass
+    const int q_base = GROUPS ? 0 : PP_QPP * qt;  // first query of this workgroup's pass
     const int total = nt * nslab;               // K slabs this workgroup streams
     const int32_t last_blk = (int32_t)((n_rows + 15) >> 4) - 1;
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) char*)smem);
@@ -190,7 +208,7 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     auto issue_c = [&]() __attribute__((always_inline)) {
         if constexpr (!(DBG & 16)) {
             const int t = fc_r < nt ? fc_r : nt - 1;  // (after the last tile: some valid tile, multiplied into sums nobody reads)
-            int32_t blk = blk_org + t * PP_NBLK;
+            int32_t blk = SCORES ? tile_blk(t) + wv : blk_org + t * PP_NBLK;
             blk = blk < last_blk ? blk : last_blk;  // past the image: harmless re-read of the last block, never emitted
             const char* src = planes + pp_uniform_i64((int64_t)blk * slab_bytes + (int64_t)fc_s * 1024);
             pp_dma(lds_base + (uint32_t)(fc_slot * PP_CSLOT + wv * 1024), src, lane16);
@@ -246,17 +264,17 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     float run = -INFINITY;  // maximum over the rows of the chunk still open, for this lane's query vector; lives across blocks and tiles
     uint32_t prev_last_end = 1;  // the row before the workgroup's first block closes a chunk as far as this workgroup is concerned
     // chunk ordinal of the next chunk to finish: no chunk is empty, so it advances by one per chunk end -- one scalar load per workgroup
-    int32_t ord_run = ROWS ? 0 : __builtin_amdgcn_readfirstlane(row_to_chunk[org]);
+    int32_t ord_run = GROUPS ? 0 : __builtin_amdgcn_readfirstlane(row_to_chunk[org]);
     const int e_q = fG >> 1;
-    const bool e_has = !ROWS && (e_q == 0 ? has0 : has1) && (ft & 1) == 0;  // (lanes t and t ^ 1 hold the same sum)
+    const bool e_has = !GROUPS && (e_q == 0 ? has0 : has1) && (ft & 1) == 0;  // (lanes t and t ^ 1 hold the same sum)
     const float e_unscale = e_has ? qmeta[2 * (q_base + 2 * wv + e_q)] * inv_e_scale : 0.f;
     // the results wait in LDS -- slot = the chunk's ordinal among the chunks this workgroup OWNS (they end inside [r_lo, r_hi): consecutive
     // ordinals from ord_lo on) minus what has been flushed
     [[maybe_unused]] float* const o_buf = reinterpret_cast<float*>(smem + PP_DC * PP_CSLOT) + (2 * wv + e_q) * PP_STAGE;
-    [[maybe_unused]] const int32_t ord_lo = !ROWS ? __builtin_amdgcn_readfirstlane(row_to_chunk[r_lo]) : 0;
+    [[maybe_unused]] const int32_t ord_lo = !GROUPS ? __builtin_amdgcn_readfirstlane(row_to_chunk[r_lo]) : 0;
     [[maybe_unused]] int32_t own_cnt = 0, own_flushed = 0;  // owned chunks finished so far / already written out
     [[maybe_unused]] auto flush_out = [&]() __attribute__((always_inline)) {
-        if constexpr (!ROWS) {
+        if constexpr (!GROUPS) {
             const int n = own_cnt - own_flushed;  // (wave-uniform)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own LDS writes
             const float* const b0 = reinterpret_cast<const float*>(smem + PP_DC * PP_CSLOT) + (2 * wv) * PP_STAGE;
@@ -391,7 +409,17 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     [[maybe_unused]] uint2* const l_log = reinterpret_cast<uint2*>(smem + PP_DC * PP_CSLOT) + wv * LOG_CAP;
     [[maybe_unused]] uint32_t ncand_out = 0;  // records already moved to the global log
     [[maybe_unused]] uint2* const my_log = ROWS ? rs.log + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 + wv) * (size_t)rs.log_cap : nullptr;
-    [[maybe_unused]] const bool cosine = ROWS && rs.metric == SCAN_COSINE;
+    [[maybe_unused]] const bool cosine = GROUPS && rs.metric == SCAN_COSINE;
+    // MODE 1: the lane's four unscale factors and four 1 / |q| live in ONE register each across the K loop, like T4x (lane group g holds
+    // column set c = g's value; the tile epilogue hands them back with ds_bpermute)
+    [[maybe_unused]] float Ux = 0.f, Rx = 0.f;
+    if constexpr (SCORES) {  // (before the first DMA: these loads are ordinary ones)
+        const int c = lane >> 4;
+        const int32_t q = (16 * qt + 2 * wv + (c >> 1)) * 32 + 16 * (c & 1) + (lane & 15);
+        const int32_t qc = q < rs.B ? q : rs.B - 1;
+        Ux = q < rs.B ? rs.q_unscale[qc] * inv_e_scale : 0.f;  // (0: a query past B -- its column is not stored)
+        Rx = cosine ? 1.0f / sqrtf(rs.q_sumsq[qc]) : 1.0f;
+    }
     if constexpr (ROWS) {  // (before the first DMA: these loads are ordinary ones)
         const int c = lane >> 4;
         const int32_t q = (16 * qt + 2 * wv + (c >> 1)) * 32 + 16 * (c & 1) + (lane & 15);
@@ -516,6 +544,42 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
         }
         zero_block(A_);
     };
+    // MODE 1: similarities of the block's 16 rows with the wave's 64 queries, written out.  Register (c, a, u), lane (g, n) = row 16 a + 4 g + u
+    // of the tile against query 32 (16 qt + 2 wv + (c >> 1)) + 16 (c & 1) + n: a lane's four rows of one query are 16 contiguous bytes of S.
+    // cosine: 1 - (1 - d / (|e| |q|)) (scan.hip's form); dot: 1 + d; rows past the corpus: -inf.  The 16 row norms of a block come by ONE
+    // scalar load (no compiler-visible VMEM load may sit in the K loop: its wait would drain the look-ahead DMAs on every slab).
+    [[maybe_unused]] auto block_epilogue_scores = [&](auto A_, int T, const float (&us4)[4], const float (&rq4)[4], uint32_t n_op) __attribute__((always_inline)) {
+        constexpr int a = decltype(A_)::value;
+        const int32_t o = (org >> 7) + T;                                           // sample-tile ordinal
+        const int32_t base = (tile_blk(T) + a) * 16;                                // first corpus row of the block
+        const int64_t col = (int64_t)(o >> 1) * 256 + (o & 1) * 128 + 16 * a;       // its column in S
+        const int gq = lane >> 4;
+        float rn[4] = {1.f, 1.f, 1.f, 1.f};                                         // 1 / |e| of the lane's four rows (cosine)
+        if (cosine && base < (int32_t)n_rows) {                                     // (wave-uniform; the norm array is padded to whole blocks)
+            const f32x16s nr = pp_sload16(rs.row_norm + base);
+            rn[0] = 1.0f / (gq == 0 ? nr[0] : gq == 1 ? nr[4] : gq == 2 ? nr[8] : nr[12]);
+            rn[1] = 1.0f / (gq == 0 ? nr[1] : gq == 1 ? nr[5] : gq == 2 ? nr[9] : nr[13]);
+            rn[2] = 1.0f / (gq == 0 ? nr[2] : gq == 1 ? nr[6] : gq == 2 ? nr[10] : nr[14]);
+            rn[3] = 1.0f / (gq == 0 ? nr[3] : gq == 1 ? nr[7] : gq == 2 ? nr[11] : nr[15]);
+        }
+        const int32_t left = (int32_t)n_rows - (base + 4 * gq);                     // rows of the lane's quad inside the corpus
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 v4 = acc[c >> 1][c & 1][a];
+            f32x4 o4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float d = v4[u] * us4[c];
+                float v = cosine ? 1.0f - (1.0f - d * rn[u] * rq4[c]) : 1.0f + d;
+                o4[u] = u < left ? v : -INFINITY;
+            }
+            // (n_op: the lane's column, re-read per tile -- with the plain value the four S addresses of a lane are loop-invariant, get hoisted
+            // out of the K loop and spilled)
+            const int32_t q = (16 * qt + 2 * wv + (c >> 1)) * 32 + 16 * (c & 1) + (int32_t)n_op;
+            if (q < rs.B) *reinterpret_cast<f32x4*>(rs.S + (int64_t)q * rs.ld_s + col + 4 * gq) = o4;
+        }
+        zero_block(A_);
+    };
     [[maybe_unused]] auto dump_log = [&]() __attribute__((always_inline)) {  // LDS -> this wave's log in global memory
         if constexpr (ROWS) {
             uint32_t n = ncand - ncand_out;  // (wave-uniform)
@@ -575,7 +639,20 @@ __global__ __launch_bounds__(512, 2) void maxsim_pp_kernel(const char* __restric
     auto tile_end = [&]() __attribute__((always_inline)) {
         if constexpr (DBG & 128) return;
         if (c_s == nslab - 1) {  // the tile is complete: its eight blocks back to back
-            if constexpr (ROWS) {
+            if constexpr (SCORES) {
+                float us4[4], rq4[4];
+                uint32_t bl;  // the lane number, re-read here (volatile: not hoisted), -> (lane & 15) << 2
+                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(bl));
+                bl = (bl & 15u) << 2;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    us4[c] = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(((uint32_t)c << 6) | bl), __float_as_int(Ux)));
+                    rq4[c] = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(((uint32_t)c << 6) | bl), __float_as_int(Rx)));
+                }
+                [&]<int... A>(std::integer_sequence<int, A...>) {
+                    (block_epilogue_scores(std::integral_constant<int, A>{}, c_r, us4, rq4, bl >> 2), ...);
+                }(std::make_integer_sequence<int, PP_NBLK>{});
+            } else if constexpr (ROWS) {
                 // ONE scalar load and one LDS round trip per tile: the eight (min, max) norm pairs (64 B) and the lane's four
                 // thresholds -- a wait per block would expose a scalar-cache miss eight times per tile (the array has 625 KB)
                 float tq4[4];
@@ -732,6 +809,37 @@ __global__ __launch_bounds__(256) void block_norm_minmax_kernel(const float* __r
     }
     out[2 * blk] = mn;
     out[2 * blk + 1] = mx;
+}
+
+// The sample pass of the fused top-k on the sixteen-group tile (MODE 1): similarities of every `stride`-th 256-row tile with all nb queries,
+// S[q * ld_s + 256 j + r] (ld_s = 256 x sampled tiles; rows past the corpus: -inf).  `scratch`: the query side as launch_score_planes_queries
+// left it.  cosine / dot; dim % 32 == 0, dim >= 256; the row-norm array must be readable up to the next multiple of 16 rows.
+int launch_pp_rows_sample(const void* image, int64_t n_rows, int32_t dim, int32_t nb, float* scratch, const float* row_norm, int mode, float* S,
+                          int64_t ld_s, int32_t stride, int n_cu, hipStream_t s, float split_scale) {
+    if (nb < 1 || n_rows < 1 || dim % 32 || dim < 256 || !(split_scale > 0.f) || !image || !S || stride < 1) return RL_ERR_UNSUPPORTED;
+    if (mode != SCAN_COSINE && mode != SCAN_DOT) return RL_ERR_UNSUPPORTED;
+    if (mode == SCAN_COSINE && !row_norm) return RL_ERR_INVALID;
+    if ((ld_s & 255) || (reinterpret_cast<uintptr_t>(S) & 15)) return RL_ERR_UNSUPPORTED;
+    const int32_t nslab = dim / 32, groups = (nb + 31) / 32;
+    float* frag = scratch;  // the layout of launch_score_planes_queries
+    float* unscale = frag + (size_t)groups * 32 * dim;
+    float* anylo = unscale + nb;
+    float* qss = anylo + groups;
+    const int64_t grid_cu = n_cu > 0 ? n_cu : 256;
+    const int64_t T256 = (n_rows + 255) / 256, Tv = (T256 + stride - 1) / stride;
+    if (Tv * 256 != ld_s) return RL_ERR_INVALID;
+    PpRows rs{};
+    rs.tile_begin = 0;
+    rs.tile_count = (int32_t)(2 * Tv);
+    rs.q_unscale = unscale; rs.q_sumsq = qss; rs.row_norm = row_norm; rs.B = nb; rs.QT = (groups + PP_QPP - 1) / PP_QPP; rs.metric = mode;
+    rs.S = S; rs.ld_s = ld_s; rs.stride = stride;
+    if (rs.QT > grid_cu) return RL_ERR_UNSUPPORTED;
+    const int64_t gx = std::max<int64_t>(1, std::min<int64_t>(grid_cu / rs.QT, 2 * Tv));
+    hipLaunchKernelGGL((maxsim_pp_kernel<0, 1, false>), dim3((unsigned)gx, (unsigned)rs.QT), dim3(512), 0, s, static_cast<const char*>(image), n_rows,
+                       nslab, reinterpret_cast<const char*>(frag), nullptr, groups, nullptr, nullptr, nullptr, nullptr, (int64_t)0,
+                       1.0f / split_scale, nullptr, rs);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
 }
 
 size_t pp_rows_scratch_bytes(int64_t n_rows, int32_t nb, int n_cu, int32_t expected_per_query, int32_t* log_cap_out) {

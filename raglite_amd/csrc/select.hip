@@ -1024,6 +1024,133 @@ int launch_list_prefix(const float* in_scores, const int32_t* in_ids, int32_t nq
     return RL_OK;
 }
 
+// ---- round 5: the two list steps of the fused top-k by SELECTION instead of a sort ------------------------------------------------------
+// list_prefix_kernel and the merge between the two rounds of the candidate pass sort a whole list (bitonic over up to 8192 64-bit keys: 66
+// barrier-separated stages at 2048) to learn ONE number -- the k-th best score of the list -- and then, respectively, keep what lies within a
+// window of it / raise a threshold to it.  A radix select on the 32-bit order-preserving score keys finds that number in four passes of
+// 256 bins (three barriers each), every thread holding its share of the list in registers.  Ties on the k-th score do not matter to either
+// caller: both compare SCORES with (k-th score - window).
+//   MODE_RAISE == false (list_prefix): the rows whose score reaches (k-th best) - window[q] go to out_ids[q * cap2 ..] in any order (the
+//     caller re-scores and ranks them), out_cnt[q] of them; more than cap2, a NaN window or an empty result set *flag -- list_prefix_kernel's
+//     contract (fewer than k records: all of them).
+//   MODE_RAISE == true: thr[q] = max(thr[q], (k-th best) - window[q]) (fewer than k records: unchanged) -- launch_merge_topk +
+//     launch_raise_threshold in one launch.
+template <bool MODE_RAISE>
+__global__ __launch_bounds__(1024) void list_select_kernel(const float* __restrict__ in_scores, const int32_t* __restrict__ in_ids, int32_t k_in,
+                                                            int32_t k, const uint32_t* __restrict__ counts, const float* __restrict__ window,
+                                                            int32_t cap2, int32_t* __restrict__ out_ids, uint32_t* __restrict__ out_cnt,
+                                                            uint32_t* __restrict__ flag, float* __restrict__ thr) {
+    constexpr int PER = MERGE_CAP / 1024;  // records per thread (8)
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sh_prefix, sh_need, n_pass;
+    const int q = blockIdx.x;
+    const int total = (int)min(counts[q], (uint32_t)k_in);
+    uint32_t key[PER];
+    int32_t id[PER];
+    uint32_t valid = 0u;  // records of the list that can rank (a real row, a comparable score)
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int i = (int)threadIdx.x + j * 1024;
+        key[j] = 0u;
+        id[j] = -1;
+        if (i < total) {
+            const int64_t src = (int64_t)q * k_in + i;
+            id[j] = in_ids[src];
+            if (id[j] >= 0) key[j] = score_key(in_scores[src]);
+            valid += key[j] != 0u;
+        }
+    }
+    if (threadIdx.x == 0) { sh_prefix = 0u; sh_need = (uint32_t)k; n_pass = 0u; }
+    if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+    __syncthreads();
+    if (valid) atomicAdd(&n_pass, valid);
+    __syncthreads();
+    const uint32_t n_valid = n_pass;
+    __syncthreads();
+    if (threadIdx.x == 0) n_pass = 0u;
+    __syncthreads();
+    float kth = -INFINITY;
+    bool have_kth = false;
+    if (n_valid >= (uint32_t)k) {  // (block-uniform)
+        // the k-th largest key: digit by digit from the top
+        for (int shift = 24; shift >= 0; shift -= 8) {
+            const uint32_t prefix = sh_prefix;
+#pragma unroll
+            for (int j = 0; j < PER; ++j)
+                if (key[j] != 0u && (shift == 24 || (key[j] >> (shift + 8)) == prefix)) atomicAdd(&hist[(key[j] >> shift) & 255u], 1u);
+            __syncthreads();
+            if (threadIdx.x < 64) {  // one wave walks the 256 bins from the top: lane l owns bins 4 l .. 4 l + 3
+                const int l = (int)threadIdx.x;
+                const uint32_t c0 = hist[4 * l], c1 = hist[4 * l + 1], c2 = hist[4 * l + 2], c3 = hist[4 * l + 3];
+                uint32_t above = c0 + c1 + c2 + c3;  // -> records in bins above this lane's four (suffix sum over the lanes, exclusive)
+                uint32_t incl = above;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = __shfl_down(incl, o, 64);
+                    if (l + o < 64) incl += t;
+                }
+                above = incl - above;
+                const uint32_t need = sh_need;
+                // the bin b with  count(bins > b) < need <= count(bins >= b)
+                const uint32_t a3 = above, a2 = a3 + c3, a1 = a2 + c2, a0 = a1 + c1;
+                int b = -1;
+                uint32_t ab = 0u;
+                if (a3 < need && need <= a3 + c3) { b = 4 * l + 3; ab = a3; }
+                else if (a2 < need && need <= a2 + c2) { b = 4 * l + 2; ab = a2; }
+                else if (a1 < need && need <= a1 + c1) { b = 4 * l + 1; ab = a1; }
+                else if (a0 < need && need <= a0 + c0) { b = 4 * l; ab = a0; }
+                if (b >= 0) { sh_prefix = (prefix << 8) | (uint32_t)b; sh_need = need - ab; }
+            }
+            __syncthreads();
+            if (threadIdx.x < 256) hist[threadIdx.x] = 0u;
+            __syncthreads();
+        }
+        kth = key_score(sh_prefix);
+        have_kth = true;
+    }
+    if constexpr (MODE_RAISE) {
+        if (threadIdx.x == 0 && have_kth) {
+            const float t = kth - window[q];
+            if (t > thr[q]) thr[q] = t;  // (NaN never raises it)
+        }
+    } else {
+        const float t = have_kth ? kth - window[q] : -INFINITY;  // (NaN window -> nothing passes -> flag below)
+#pragma unroll
+        for (int j = 0; j < PER; ++j)
+            if (key[j] != 0u && key_score(key[j]) >= t) {
+                const uint32_t slot = atomicAdd(&n_pass, 1u);
+                if (slot < (uint32_t)cap2) out_ids[(int64_t)q * cap2 + slot] = id[j];
+            }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t n = n_pass;
+            out_cnt[q] = n < (uint32_t)cap2 ? n : (uint32_t)cap2;
+            if (n > (uint32_t)cap2 || !(window[q] >= 0.f) || (total > 0 && n == 0u)) atomicOr(flag, 1u);
+        }
+    }
+}
+
+int launch_list_select(const float* in_scores, const int32_t* in_ids, int32_t nq, int32_t k_in, int32_t k, const uint32_t* counts,
+                       const float* window, int32_t cap2, int32_t* out_ids, uint32_t* out_cnt, uint32_t* flag, hipStream_t s) {
+    if (nq <= 0 || k <= 0) return RL_OK;
+    if (k_in > MERGE_CAP || cap2 < 1) return fail(RL_ERR_UNSUPPORTED, "list_select: k_in must be <= 8192");
+    hipLaunchKernelGGL(list_select_kernel<false>, dim3(nq), dim3(1024), 0, s, in_scores, in_ids, k_in, k, counts, window, cap2, out_ids, out_cnt, flag,
+                       static_cast<float*>(nullptr));
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// thr[q] = max(thr[q], (k-th best score of list q) - window[q]); lists with fewer than k records leave thr[q] alone
+int launch_list_raise_threshold(const float* in_scores, const int32_t* in_ids, int32_t nq, int32_t k_in, int32_t k, const uint32_t* counts,
+                                const float* window, float* thr, hipStream_t s) {
+    if (nq <= 0 || k <= 0) return RL_OK;
+    if (k_in > MERGE_CAP) return fail(RL_ERR_UNSUPPORTED, "list_raise_threshold: k_in must be <= 8192");
+    hipLaunchKernelGGL(list_select_kernel<true>, dim3(nq), dim3(1024), 0, s, in_scores, in_ids, k_in, k, counts, window, 1, static_cast<int32_t*>(nullptr),
+                       static_cast<uint32_t*>(nullptr), static_cast<uint32_t*>(nullptr), thr);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 __global__ __launch_bounds__(256) void raise_threshold_kernel(float* __restrict__ thr, const float* __restrict__ kth, int32_t nq, int32_t k,
                                                                const float* __restrict__ window) {
     const int q = blockIdx.x * 256 + threadIdx.x;

@@ -249,6 +249,23 @@ def test_fused_pp_tile_equals_the_eight_group_tile_bitwise(metric, n, dim, B, k)
         st1 = idx.filter_stats()
     assert torch.equal(R, R1) and torch.equal(S.view(torch.int32), S1.view(torch.int32))
     assert st1["candidates_per_query_mean"] <= st0["candidates_per_query_mean"] <= 1.05 * st1["candidates_per_query_mean"] + 1, (st1, st0)
+    # round 5: the SAMPLE pass on the sixteen-group tile too (MODE 1; option fused_pp_sample) -- the thresholds it leads to agree with the
+    # eight-group kernel's to the last bits of an fp32 sum, the candidates they admit to within a few rows, the results bit for bit
+    assert idx.get_option("fused_pp_sample") == 1
+    with idx.options(fused_pp_sample=0):
+        S2, R2 = idx.search_rows(Q, k)
+        st2 = idx.filter_stats()
+    assert st2["kind"] == "rows_fused_hi" and not st2["fallback"]
+    assert torch.equal(R, R2) and torch.equal(S.view(torch.int32), S2.view(torch.int32))
+    assert abs(st["candidates_per_query_mean"] - st2["candidates_per_query_mean"]) <= 0.02 * st2["candidates_per_query_mean"] + 1, (st, st2)
+    # ... and the lists cut by a radix select of their k-th best score (option list_select) instead of by sorting them: the same k-th score,
+    # hence the same raised thresholds, the same rows to re-score, the same bits
+    assert idx.get_option("list_select") == 1
+    with idx.options(list_select=0):
+        S3, R3 = idx.search_rows(Q, k)
+        st3 = idx.filter_stats()
+    assert torch.equal(R, R3) and torch.equal(S.view(torch.int32), S3.view(torch.int32))
+    assert st3["candidates_per_query_mean"] == st["candidates_per_query_mean"] and st3["candidates_per_query_max"] == st["candidates_per_query_max"]
     Eh = E.cpu().numpy()
     for b in (0, B // 2, B - 1):
         assert_topk_close(S[b].cpu().numpy(), R[b].cpu().numpy(), oracle.similarity(Eh, Q[b].cpu().numpy(), metric), k, _tol(Eh, Q[b].cpu().numpy(), metric))
