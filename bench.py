@@ -12,9 +12,11 @@ A step = one batch of QUERIES_PER_STEP queries pushed through the hot path (`rl_
 device pointers): the queries' fp16 (hi, lo) fragments once, one corpus pass of the MFMA kernel per SIXTEEN
 queries over the index' image of the corpus' hi halves (maxsim_pp_kernel, ONE fp16 product per multiply: q_hi . e_hi), the
 batched selection of the approximate scores, the collection of every chunk a rigorous error bound cannot rule out
-of the top-k (~300 of 125 k per query), their exact scores on the fp32 matrix pipe (maxsim_pairs_kernel) and the
-ranking of those -- the exact top-100 of exactly computed scores; the full-precision passes (three products, over
-the pre-split image) stand behind a device flag for corpora the bound does not decide; one pass per
+of the top-k (~180 of 125 k per query), their exact scores on the fp32 matrix pipe (maxsim_pairs_packed_kernel) and the
+ranking of those -- the exact top-100 of exactly computed scores; the full-precision passes stand behind a device flag
+for corpora the bound does not decide (over the rows by the streaming kernels on an index of rows + HI
+image, which is what this workload builds -- lazy images, DESIGN.md 3 -- and over the pre-split image once a batch has
+fallen back); one pass per
 query with the exact-fp32 arithmetic -- and, N > 1 only, two exchange steps: an RCCL all-gather of every rank's k best
 approximate scores and bound, (QB, k + 1) float32, before the candidates are collected (one threshold for all shards), and one of
 its exact local top-k, (QB, k, 2) int32, with the device merge.  value = queries / second over the whole job.
@@ -23,7 +25,8 @@ N > 1: the 1 M-row corpus is sharded by chunk across the ranks (strong scaling o
 shape); every rank receives the same queries.
 
 Extra objects in the JSON line (rank 0; all but `roofline` at N = 1 only):
-  roofline      dominant kernel, HIP-event timed on its launch stream
+  roofline      dominant kernel, HIP-event timed on its launch stream; `sustained`: the fp16 MFMA rate of this box measured in the same run
+  fraction_check / bench_schema  every printed fraction verified to lie in (0, 1] before the line leaves (fraction_violations)
   exact_fp32    the same workload with RL_ARITH_FP32_EXACT (v_mfma_f32_16x16x4_f32 chain), >= 5 timed steps
   f16_stored    the same corpus rounded to and stored as fp16 (the reference's pgvector halfvec), own workload name
   f16_queries   ... and the queries as fp16 values too (what embed_strings returns): the one-product pass is exact, its top-k is the result
