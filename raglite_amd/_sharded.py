@@ -256,6 +256,8 @@ class ShardedIndex:
         if self.comm is not None:
             gs, gi = self.comm.allgather_topk(scores, ids_local.to(torch.int32), base)
         else:
+            if self._world() == 1 and base == 0:  # one shard that starts at ordinal 0: local ordinals ARE the global ones (no kernel at all)
+                return scores, ids_local.to(torch.int32)
             gid = torch.where(ids_local >= 0, ids_local + base, torch.full_like(ids_local, -1)).to(torch.int32)
             if self._world() == 1:
                 return scores, gid
