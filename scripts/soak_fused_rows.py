@@ -24,9 +24,14 @@ from oracle import oracle  # noqa: E402
 
 
 def main() -> None:
-    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    opts = [a for a in sys.argv[1:] if "=" in a]  # NAME=VALUE: route options set as process-wide defaults (A/B of the soak itself)
+    argv = [a for a in sys.argv[1:] if "=" not in a]
+    budget = float(argv[0]) if len(argv) > 0 else 60.0
+    rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 1)
     raglite_amd.set_device(0)
+    for item in opts:
+        name, value = item.split("=", 1)
+        raglite_amd.set_default_option(name, int(value))
     t0 = time.time()
     cases = fallbacks = 0
     while time.time() - t0 < budget:
@@ -52,15 +57,29 @@ def main() -> None:
         with idx.options(**({"fused_topk": 0} if st["fallback"] else {"fused_pp": 0})):
             S0, R0 = idx.search_rows(Q, k)
             st0 = idx.filter_stats()
-        if not st["fallback"] and st0["fallback"]:  # (the eight-group tile gave up where the sixteen-group one did not: dense again)
+        if not st["fallback"] and st0["fallback"]:
+            # the eight-group tile gave up where the sixteen-group one did not (it keeps more rows per list): no like to compare with --
+            # the dense path's split-arithmetic sums differ from the exact re-scoring in the last bits, and on clustered data a few
+            # near-tied rows then change places (round 5, seed 51: 19-26 of 51 200 rows, scores 1.8e-7 apart).  Hold the scores instead.
             with idx.options(fused_topk=0):
                 S0, R0 = idx.search_rows(Q, k)
-        assert torch.equal(R, R0) and torch.equal(S.view(torch.int32), S0.view(torch.int32)), ("pp != yardstick", metric, dim, n, B, k, kind, st, st0)
+            assert torch.allclose(S, S0, rtol=0, atol=2e-6), ("pp vs dense scores", metric, dim, n, B, k, kind, float((S - S0).abs().max()))
+            S0, R0 = S, R
+        if not (torch.equal(R, R0) and torch.equal(S.view(torch.int32), S0.view(torch.int32))):
+            nd = int((R != R0).sum()); ds = float((S - S0).abs().max())
+            raise AssertionError(("pp != yardstick", metric, dim, n, B, k, kind, st, st0, "rows differing", nd, "max |score diff|", ds))
         with idx.options(fused_two_rounds=0):
             S1, R1 = idx.search_rows(Q, k)
             st1 = idx.filter_stats()
         if st1["fallback"] == st["fallback"]:
             assert torch.equal(R, R1) and torch.equal(S.view(torch.int32), S1.view(torch.int32)), ("two rounds != one", metric, dim, n, B, k, kind, st)
+        # round 5: the tail of round 4 (sample pass on the eight-group kernel, lists cut by sorting) against the shipped one (sample pass on the
+        # sixteen-group tile, lists cut by a radix select): the same bits whenever both answered through the candidate pass
+        with idx.options(fused_pp_sample=0, list_select=0):
+            S2, R2 = idx.search_rows(Q, k)
+            st2 = idx.filter_stats()
+        if st2["fallback"] == st["fallback"]:
+            assert torch.equal(R, R2) and torch.equal(S.view(torch.int32), S2.view(torch.int32)), ("new tail != old tail", metric, dim, n, B, k, kind, st, st2)
         if kind == "small_int" and metric == "dot":
             Eh = E.cpu().numpy()
             for b in (0, B - 1):

@@ -44,7 +44,7 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     raglite_amd.set_device(0)
-    t_end, cases, sharded = time.time() + seconds, 0, 0
+    t_end, cases, sharded, f16_routes = time.time() + seconds, 0, 0, 0
     while time.time() < t_end:
         dim = int(rng.choice([1024, 1024, 512]))
         n = int(rng.integers(66_000, 140_000)) * (1024 // dim)
@@ -78,6 +78,13 @@ def main():
             gs, gc = s[b].cpu().numpy(), c[b].cpu().numpy()
             assert np.array_equal(gc[: len(wc)], wc), (tag, b, gc[:6], wc[:6])
             assert np.array_equal(gs[: len(ws)], np.asarray(ws, np.float32)), (tag, b)
+        # round 5: the same queries handed over as fp16 values (rl_maxsim_topk_batch_f16): over fp16 values -- an fp16-stored corpus, or this
+        # fp32-stored one whose integer entries ARE fp16 values -- the one-product pass is exact and its own top-k is returned: the same bits
+        hs, hc = idx.maxsim_topk_batch(Q.half(), k)
+        sth = idx.filter_stats()
+        assert torch.equal(hc, c) and torch.equal(hs, s), ("fp16 queries", tag, sth)
+        assert sth["kind"] in ("maxsim_batch_f16_exact", "maxsim_batch_hi") or B % 8 in (1, 2), (tag, sth)
+        f16_routes += int(sth["kind"] == "maxsim_batch_f16_exact")
         if dead is None and storage == "f32" and n >= 3 * 66_000 * (1024 // dim) - 70_000 and rng.random() < 0.5 and B % 8 not in (1, 2):
             cuts = [0, n_chunks // 2, n_chunks]  # two shards, one threshold
             if all(int(off[hi] - off[lo]) * dim >= (64 << 20) for lo, hi in zip(cuts[:-1], cuts[1:])):
@@ -97,7 +104,7 @@ def main():
         cases += 1
         if cases % 5 == 0:
             print(f"{cases} cases ({sharded} sharded) ok; last: {tag}", flush=True)
-    print(f"soak_hi_batch: {cases} cases ({sharded} sharded), no failure, seed {seed}")
+    print(f"soak_hi_batch: {cases} cases ({sharded} sharded, {f16_routes} fp16-query batches through the exact route), no failure, seed {seed}")
 
 
 if __name__ == "__main__":
