@@ -14,6 +14,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a gfx950 GPU (runs through libraglite_hip.so)")
 
 
+def pytest_sessionstart(session):
+    """The library is a build artefact (git-ignored): a fresh checkout has none.  Build it once (hipcc cross-compiles gfx950 without a GPU,
+    ~2 minutes cold) instead of failing the first test that binds the C ABI; a checkout that has it pays one `stat`."""
+    from raglite_amd import _build
+
+    if not _build.LIB_PATH.exists():
+        _build.build()
+
+
 def _have_gpu() -> bool:
     try:
         import torch
