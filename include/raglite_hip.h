@@ -132,6 +132,19 @@ int rl_index_info(const rl_index* index, int64_t* n_rows, int32_t* dim, int64_t*
  * kernels over the rows (B <= 16: the full fp32 pass; B >= 96: score_gemm instead of the fused top-k). */
 int rl_index_memory(const rl_index* index, int64_t out[8]);
 
+/* Warm-up for lazy images (RL_OPT_LAZY_IMAGES, the default): build the images in `images` (RL_IMAGE_* bits) NOW, on `stream`, instead of
+ * inside the first search whose route reads them -- that first call otherwise allocates device memory (0.5 x / 1 x the corpus per image),
+ * makes one pass over the rows and synchronises the stream once (the norm statistics of the error bounds come back to the host), inside
+ * an entry point that is asynchronous from then on.  `built` (nullable) receives the bits of the images the index holds afterwards: an
+ * image the options / the shape / the free memory do not allow is simply absent (never an error -- the routes over the stored rows
+ * answer, same results).  An image skipped for lack of room (it would not have left RL_OPT_IMAGE_HEADROOM_MB free) is asked for again
+ * by later searches -- at most one call in 64 retries -- and by every rl_index_prepare.  Which images a workload reads: MaxSim batches
+ * RL_IMAGE_HI; row searches of <= 16 queries RL_IMAGE_HI_PLANE, of >= 96 queries RL_IMAGE_PRESPLIT | RL_IMAGE_HI (table above). */
+#define RL_IMAGE_PRESPLIT 1u
+#define RL_IMAGE_HI 2u
+#define RL_IMAGE_HI_PLANE 4u
+int rl_index_prepare(rl_index* index, uint32_t images, uint32_t* built, void* stream);
+
 /* ---- index lifecycle beyond create/destroy -----------------------------
  * rl_index_append: the device image of `insert_documents` appending `chunk_embedding` rows
  * (src/raglite/_insert.py:247-272, rows ordered by chunk, src/raglite/_database.py:403-430).
@@ -384,8 +397,12 @@ int rl_merge_topk(const float* in_scores, const int32_t* in_ids, int32_t n_lists
  * out_* [world x n_queries x k] on every rank.  rl_allgather_merge_topk: the same followed by rl_merge_topk's kernel:
  * out_* [n_queries x k] = the global top-k by (score desc, id asc), identical on every rank and identical to what one
  * GPU holding the whole corpus returns.  Nothing synchronises with the host.  A communicator is used by one
- * thread at a time (calls serialise on an internal mutex).  RL_ERR_UNSUPPORTED when librccl cannot be loaded. */
+ * thread at a time (calls serialise on an internal mutex).  RL_ERR_UNSUPPORTED when librccl cannot be loaded.
+ * A rank whose LOCAL step failed still has to enter the collective (the others are waiting in it): it contributes lists whose
+ * ids are RL_ID_SHARD_MISSING (scores ignored).  rl_allgather_topk hands the marker through; rl_allgather_merge_topk answers
+ * with every score NaN and every id -1 on EVERY rank -- a merge that lacks a shard never looks like an answer (no host read-back). */
 #define RL_COMM_ID_BYTES 128
+#define RL_ID_SHARD_MISSING (-2)
 typedef struct rl_comm rl_comm;
 int rl_comm_unique_id(void* out_id /* RL_COMM_ID_BYTES */);
 int rl_comm_init(rl_comm** out, int rank, int world, const void* unique_id);

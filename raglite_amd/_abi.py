@@ -54,6 +54,7 @@ _SIGNATURES = {
     "rl_index_destroy": [c_void_p],
     "rl_index_info": [c_void_p, C.POINTER(c_i64), C.POINTER(c_i32), C.POINTER(c_i64), C.POINTER(c_int)],
     "rl_index_memory": [c_void_p, C.POINTER(c_i64)],
+    "rl_index_prepare": [c_void_p, C.c_uint32, C.POINTER(C.c_uint32), c_void_p],
     "rl_partition_similarity": [c_void_p, c_i64, c_i32, c_void_p, c_i64, c_void_p, c_void_p, c_int, c_void_p],
     "rl_chunk_best_rows": [c_void_p, c_void_p, c_i32, c_void_p, c_i32, c_void_p, c_int, c_void_p],
     "rl_gather_rows": [c_void_p, c_void_p, c_i64, c_void_p, c_int, c_void_p],

@@ -425,6 +425,28 @@ class DeviceIndex:
         keys = ("rows", "presplit_image", "hi_image", "hi_plane", "scratch", "device_free", "device_total", "image_headroom")
         return {k: int(v) for k, v in zip(keys, out)}
 
+    IMAGES = {"presplit": 1, "hi_image": 2, "hi_plane": 4}  # include/raglite_hip.h: RL_IMAGE_*
+
+    def prepare(self, *images: str) -> tuple[str, ...]:
+        """`rl_index_prepare`: build the named lazy images ("presplit", "hi_image", "hi_plane"; none named = all three) NOW, outside the
+        hot path, instead of inside the first search whose route reads them (device allocation + one pass over the rows + one stream
+        synchronisation in that call).  Returns the images the index holds afterwards -- one that the options, the shape or the free
+        memory do not allow is simply absent (the routes over the stored rows answer, same results)."""
+        bits = 0
+        for name in images or tuple(self.IMAGES):
+            if name not in self.IMAGES:
+                raise ValueError(f"unknown image {name!r}: one of {sorted(self.IMAGES)}")
+            bits |= self.IMAGES[name]
+        built = C.c_uint32(0)
+        if self.mem == MEM_DEVICE:
+            _ensure_init(self.device.index or 0)
+            stream = _torch().cuda.current_stream(self.device).cuda_stream
+        else:
+            _ensure_init(_current_device())
+            stream = 0
+        check(lib().rl_index_prepare(self._handle, bits, C.byref(built), stream))
+        return tuple(name for name, bit in self.IMAGES.items() if built.value & bit)
+
     # -- a6 + a7 -------------------------------------------------------------------------------
     def search_rows(self, queries, k: int, chunk_filter=None, rank_limit: int | None = None):
         """Exact top-k rows: (scores (B,k) desc, rows (B,k) int32); padding = (-inf, -1).

@@ -22,6 +22,9 @@ from typing import Any
 import numpy as np
 
 
+SHARD_MISSING = -2  # include/raglite_hip.h: RL_ID_SHARD_MISSING -- the id a rank that failed in its local step sends into the merge
+
+
 def shard_bounds_by_chunk(chunk_offsets, world: int) -> list[tuple[int, int]]:
     """Chunk ranges [lo, hi) per rank: contiguous, balanced by row count, chunks never split."""
     off = np.asarray(chunk_offsets, dtype=np.int64)
@@ -166,8 +169,10 @@ class ShardedIndex:
                  check_failures: bool = False) -> None:
         """check_failures: device-path MaxSim batches read back one flag per call to learn that ANOTHER rank failed in its local step (a
         host synchronisation per call; host-array calls check for free).  Without it a failing rank still takes part in every collective
-        of the call with empty lists -- nobody hangs -- and raises afterwards; the other ranks do not raise, but what they return is
-        POISONED on the device (every score NaN, every id -1): a merge that lacks a shard never looks like an answer."""
+        of the call -- with empty lists whose ids are SHARD_MISSING, on EVERY route: the staged one and the ones that go straight to the
+        merge (fp16 queries over fp16-stored shards, tiny batches) -- so nobody hangs, and raises afterwards; the other ranks do not
+        raise, but what they return is POISONED on the device by the merge itself (`rl_allgather_merge_topk`: every score NaN, every id
+        -1): a merge that lacks a shard never looks like an answer."""
         self.check_failures = bool(check_failures)
         self.local = local
         self.row_base = int(row_base)
@@ -235,7 +240,7 @@ class ShardedIndex:
         i = _to_numpy(ids_local).astype(np.int64)
         s2 = s.reshape(1, -1) if s.ndim == 1 else s
         i2 = i.reshape(1, -1) if i.ndim == 1 else i
-        gid = np.where(i2 >= 0, i2 + base, -1)
+        gid = np.where(i2 >= 0, i2 + base, i2)  # (-1: an empty slot; SHARD_MISSING: this rank failed in its local step)
         cols = [s2, gid] if extra is None else [s2, gid, extra]
         # (through WHATEVER transport the index has: a Communicator-only index without torch.distributed used to merge its own shard alone here)
         g = self._allgather_host(self._pack(*cols))  # (world, B, k, ncols)
@@ -250,6 +255,7 @@ class ShardedIndex:
 
         big = self._world() * int(scores.shape[-1]) > 8192  # more candidates per query than rl_merge_topk's kernel sorts in LDS
         if self.comm is not None and not big:
+            # pack (ids made global, markers kept) -> ONE ncclAllGather -> merge -> poisoned when a shard is missing: all behind the C ABI
             return self.comm.allgather_merge_topk(scores, ids_local.to(torch.int32), base, k)
         from . import _ops
 
@@ -258,24 +264,27 @@ class ShardedIndex:
         else:
             if self._world() == 1 and base == 0:  # one shard that starts at ordinal 0: local ordinals ARE the global ones (no kernel at all)
                 return scores, ids_local.to(torch.int32)
-            gid = torch.where(ids_local >= 0, ids_local + base, torch.full_like(ids_local, -1)).to(torch.int32)
+            gid = torch.where(ids_local >= 0, ids_local + base, ids_local).to(torch.int32)
             if self._world() == 1:
                 return scores, gid
             packed = torch.stack([scores.contiguous().view(torch.int32), gid], dim=-1).contiguous()  # (B, k, 2)
             out = _all_gather_stacked(packed, self.group)
             gs = out[..., 0].contiguous().view(torch.float32)  # (world, B, k)
             gi = out[..., 1].contiguous()
+        # (the torch transport / the > 8192-record merge: what rl_allgather_merge_topk does behind the C ABI, as torch kernels)
+        missing = (gi == SHARD_MISSING).any()
         if not big:
-            return _ops.merge_topk(gs, gi, k)
-        # e.g. k = 2048 on 8 GPUs: the same ordering by three stable sorts on the device (merge_order_torch), still no host sync
-        world, B, kin = gs.shape
-        fs = gs.permute(1, 0, 2).reshape(B, world * kin)
-        fi = gi.permute(1, 0, 2).reshape(B, world * kin).to(torch.int64)
-        order, n_valid = merge_order_torch(fs, fi, k)
-        real = torch.arange(order.shape[1], device=fs.device)[None, :] < n_valid[:, None]
-        ms = torch.where(real, fs.gather(1, order), torch.full((), float("-inf"), device=fs.device))
-        mi = torch.where(real, fi.gather(1, order), torch.full((), -1, dtype=torch.int64, device=fs.device)).to(torch.int32)
-        return ms, mi
+            ms, mi = _ops.merge_topk(gs, gi, k)
+        else:
+            # e.g. k = 2048 on 8 GPUs: the same ordering by three stable sorts on the device (merge_order_torch), still no host sync
+            world, B, kin = gs.shape
+            fs = gs.permute(1, 0, 2).reshape(B, world * kin)
+            fi = gi.permute(1, 0, 2).reshape(B, world * kin).to(torch.int64)
+            order, n_valid = merge_order_torch(fs, fi, k)
+            real = torch.arange(order.shape[1], device=fs.device)[None, :] < n_valid[:, None]
+            ms = torch.where(real, fs.gather(1, order), torch.full((), float("-inf"), device=fs.device))
+            mi = torch.where(real, fi.gather(1, order), torch.full((), -1, dtype=torch.int64, device=fs.device)).to(torch.int32)
+        return torch.where(missing, torch.full_like(ms, float("nan")), ms), torch.where(missing, torch.full_like(mi, -1), mi)
 
     def _gather_device(self, scores, ids, offset: int):
         """(B, k) CUDA lists -> (world, B, k) of every rank's, ids + offset (-1 stays -1)."""
@@ -283,7 +292,7 @@ class ShardedIndex:
 
         if self.comm is not None:
             return self.comm.allgather_topk(scores, ids.to(torch.int32), offset)
-        gid = torch.where(ids >= 0, ids + offset, torch.full_like(ids, -1)).to(torch.int32)
+        gid = torch.where(ids >= 0, ids + offset, ids).to(torch.int32)
         if self._world() == 1:
             return scores[None], gid[None]
         packed = torch.stack([scores.contiguous().view(torch.int32), gid], dim=-1).contiguous()
@@ -416,27 +425,29 @@ class ShardedIndex:
         (on the device without any host synchronisation when the queries are CUDA tensors, else on the host).
         Returns (scores (QB,k), global chunk ordinals (QB,k))."""
         self._deferred_error = None
-        self._poison = None
         if hasattr(self.local, "maxsim_topk_batch"):
             s, c = self._local_maxsim_batch(query_batch, k)
             if _is_cuda(s):  # device-resident queries: results stay on the device
+                # a rank that failed in its local step sent SHARD_MISSING ids: the merge every rank gets back is poisoned on the device
+                # (every score NaN, every id -1 -- `rl_allgather_merge_topk`), unusable rather than plausible, without a host read-back
                 out = self._exchange_merge_device(s, c, self.chunk_base, k)
-                if self._poison is not None:  # a rank failed in its local step: this merge lacks its shard -- make it unusable, not plausible
+                if self.check_failures and self._deferred_error is None and self._world() > 1:
                     import torch
 
-                    ms, mi = out
-                    out = (torch.where(self._poison, torch.full_like(ms, float("nan")), ms), torch.where(self._poison, torch.full_like(mi, -1), mi))
+                    if bool(torch.isnan(out[0]).all().item()):
+                        self._deferred_error = RuntimeError("ShardedIndex.maxsim_topk_batch: another rank failed in its local step; this merge lacks its shard")
                 self._raise_deferred()
                 return out
         else:
             outs = [self.local.maxsim_topk(query_batch[b], k) for b in range(len(query_batch))]
             s, c = np.stack([_to_numpy(o[0]) for o in outs]), np.stack([_to_numpy(o[1]) for o in outs])
         gs, gi, _, _ = self._exchange_host(s, c, self.chunk_base)
+        if self._deferred_error is None and bool((gi == SHARD_MISSING).any()):
+            self._deferred_error = RuntimeError("ShardedIndex.maxsim_topk_batch: another rank failed in its local step; this merge lacks its shard")
         self._raise_deferred()
         return merge_topk_host(gs, gi, k)
 
     _deferred_error = None
-    _poison = None  # device bool: some rank's bound came back NaN in the last staged MaxSim batch (its shard is missing from the merge)
     rank_cut_scratch_bytes = 8 << 30  # what rl_rank_cut_begin accepts for its [B x n_local] score matrix
 
     def _raise_deferred(self) -> None:
@@ -454,8 +465,9 @@ class ShardedIndex:
         # fp16 queries over fp16-STORED shards (what RAGLite's embeddings are on both sides, `_embed.py:140`): every shard's one-product pass
         # is exact (`rl_maxsim_topk_batch_f16`), its local top-k needs no candidate threshold -- nothing to exchange before the merge.  Taken
         # from the query dtype and the local storage, which are the same on every rank of one index (the exchange below is a collective).
-        f16_exact = getattr(query_batch, "dtype", None) is not None and str(query_batch.dtype).endswith("float16") \
-            and getattr(self.local, "storage", None) == "f16"
+        from ._ops import _is_half
+
+        f16_exact = _is_half(query_batch) and getattr(self.local, "storage", None) == "f16"  # (IEEE fp16 exactly: bfloat16 is not it)
         staged_shape = (
             self._world() > 1
             and not f16_exact
@@ -466,11 +478,30 @@ class ShardedIndex:
             and int(query_batch.shape[1]) <= 32
             and int(k) <= 512
         )
+        B = int(query_batch.shape[0]) if getattr(query_batch, "ndim", 0) == 3 else len(query_batch)
+
+        def empty_lists():
+            """What a rank that failed locally feeds into the merge every other rank is about to enter: no candidates, ids SHARD_MISSING."""
+            if _is_cuda(query_batch):
+                import torch
+
+                return (torch.full((B, int(k)), float("-inf"), dtype=torch.float32, device=query_batch.device),
+                        torch.full((B, int(k)), SHARD_MISSING, dtype=torch.int32, device=query_batch.device))
+            return np.full((B, int(k)), -np.inf, dtype=np.float32), np.full((B, int(k)), SHARD_MISSING, dtype=np.int32)
+
         if not staged_shape:
-            return self.local.maxsim_topk_batch(query_batch, k)
+            if self._world() == 1:
+                return self.local.maxsim_topk_batch(query_batch, k)
+            # several ranks, no threshold exchange (fp16 queries over fp16-stored shards, tiny batches, k > 512): the merge all-gather is
+            # still a collective the other ranks enter -- a local failure (out of memory, a HIP error, a first-call image build) must
+            # not leave them waiting in it
+            try:
+                return self.local.maxsim_topk_batch(query_batch, k)
+            except Exception as exc:  # noqa: BLE001
+                self._deferred_error = exc
+                return empty_lists()
         from ._abi import UnsupportedError
 
-        B = int(query_batch.shape[0])
         failed = None  # an exception that is NOT "this index cannot take part": this rank still enters every collective, then raises
         try:
             approx = self.local.maxsim_batch_begin(query_batch, k)
@@ -490,27 +521,22 @@ class ShardedIndex:
             import torch
 
             all_approx = self._allgather_int(approx.contiguous().view(torch.int32)).view(torch.float32)
-            shard_missing = torch.isnan(all_approx[:, :, int(k)]).any()  # (a device scalar, the same on every rank)
-            someone_failed = bool(shard_missing.item()) if self.check_failures else False
-            # without the read-back nobody raises on the healthy ranks -- but nobody gets a plausible answer either: maxsim_topk_batch
-            # poisons the merged lists (NaN scores, ids -1) on the device when a shard is missing, on every rank alike, without a host sync
-            self._poison = shard_missing
         else:
             all_approx = np.ascontiguousarray(self._allgather_int(np.ascontiguousarray(approx, dtype=np.float32).view(np.int32))).view(np.float32)
-            someone_failed = bool(np.isnan(all_approx[:, :, int(k)]).any())
-        if failed is not None:  # empty lists into the merge that follows (nobody hangs), the error once it is through
+        if failed is not None:  # empty lists into the merge that follows (nobody hangs, everybody's merge is poisoned), the error once it is through
             self._deferred_error = failed
-            if _is_cuda(query_batch):
-                import torch
-
-                return (torch.full((B, int(k)), float("-inf"), dtype=torch.float32, device=query_batch.device),
-                        torch.full((B, int(k)), -1, dtype=torch.int32, device=query_batch.device))
-            return np.full((B, int(k)), -np.inf, dtype=np.float32), np.full((B, int(k)), -1, dtype=np.int32)
-        if someone_failed:
-            self._deferred_error = RuntimeError("ShardedIndex.maxsim_topk_batch: another rank failed in its local step; this merge lacks its shard")
+            return empty_lists()
         if not staged:
-            return self.local.maxsim_topk_batch(query_batch, k)
-        return self.local.maxsim_batch_finish(query_batch, all_approx, self._rank(), k)
+            try:
+                return self.local.maxsim_topk_batch(query_batch, k)
+            except Exception as exc:  # noqa: BLE001
+                self._deferred_error = exc
+                return empty_lists()
+        try:
+            return self.local.maxsim_batch_finish(query_batch, all_approx, self._rank(), k)
+        except Exception as exc:  # noqa: BLE001 - one more collective (the merge) is still ahead of every rank
+            self._deferred_error = exc
+            return empty_lists()
 
     def search_chunks(self, queries, num_hits: int, k: int, chunk_filter=None, rank_limit: int | None = None):
         """Reference two-stage semantics across shards (`src/raglite/_search.py:66-79,143-149`; chunk_filter / rank_limit as in

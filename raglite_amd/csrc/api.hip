@@ -303,6 +303,8 @@ struct rl_index {
     // RL_OPT_LAZY_IMAGES (round 5, the default): an image is built by the first call whose route reads it -- which images this index
     // has been asked for so far (IMG_* bits); with the option off every image the KEEP_* options allow is built with the index
     uint32_t demanded = 0;
+    uint32_t no_room = 0;                 // IMG_* bits whose last build was skipped because it would not have left the headroom free
+    uint64_t no_room_retry_epoch = 0;     // ... and the scratch epoch from which demand_images asks for them again
     // ... and a pinned host word every bound-filtered MaxSim batch copies its fallback flag to when it is done (asynchronously): a batch
     // that finds the previous one fell back asks for the pre-split image, so that an index whose data keeps defeating the bound runs its
     // full-precision passes through the eight-query kernel instead of the streaming kernels (3-4 x faster) from the second batch on
@@ -424,6 +426,7 @@ int refresh_planes(rl_index* idx, hipStream_t s) {
     // (an exactly sized image is "already paid for" and must survive an append into spare capacity however full the device has become)
     if (!image_fits(idx, idx->planes, need) || idx->planes.reserve(need) != RL_OK) {
         (void)hipGetLastError();
+        idx->no_room |= IMG_PLANES;
         idx->planes.release();
         idx->planes_scale = 0.f;
         idx->planes_rows = 0;
@@ -543,6 +546,7 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
     if (idx->hi_image.cap < need) first = 0;
     if (!image_fits(idx, idx->hi_image, need) || idx->hi_image.reserve(need) != RL_OK) {
         (void)hipGetLastError();
+        idx->no_room |= IMG_HI_IMAGE;
         idx->hi_image.release();
         idx->hi_image_scale = 0.f;
         idx->hi_image_rows = 0;
@@ -588,6 +592,7 @@ int refresh_hi_plane(rl_index* idx, hipStream_t s) {
     if (idx->hiplane.cap < need) first = 0;  // Pool::reserve does not keep the contents
     if (!image_fits(idx, idx->hiplane, need) || idx->hiplane.reserve(need) != RL_OK) {
         (void)hipGetLastError();
+        idx->no_room |= IMG_HI_PLANE;
         idx->hiplane.release();
         idx->hi_scale = 0.f;
         idx->hi_rows = 0;
@@ -615,9 +620,18 @@ int refresh_hi_plane(rl_index* idx, hipStream_t s) {
 int demand_images(rl_index* idx, uint32_t bits, hipStream_t s) {
     if (!idx->opt.on(RL_OPT_LAZY_IMAGES) || (idx->demanded & bits) == bits) return RL_OK;
     const uint32_t fresh = bits & ~idx->demanded;
+    if ((fresh & idx->no_room) && idx->scratch_epoch < idx->no_room_retry_epoch && !(fresh & ~idx->no_room)) return RL_OK;  // (asked recently, no room then)
     idx->demanded |= bits;
+    idx->no_room &= ~fresh;
     if (fresh & IMG_PLANES) RL_TRY(refresh_planes(idx, s));
     if (fresh & (IMG_HI_IMAGE | IMG_HI_PLANE)) RL_TRY(refresh_hi_plane(idx, s));
+    // An image that was NOT built because the device was too full at this moment (scratch pools and the caller's allocator have grown
+    // since the index was created) must not leave the route on its slow path for good: its demand bit is cleared again, and a later
+    // call -- at most one in 64, a hipMemGetInfo each -- asks again.  (An image the options / the shape do not allow stays "demanded".)
+    if (const uint32_t retry = fresh & idx->no_room) {
+        idx->demanded &= ~retry;
+        idx->no_room_retry_epoch = idx->scratch_epoch + 64;
+    }
     return RL_OK;
 }
 // the image the approximate MaxSim pass of a batch multiplies: the HI image of an fp32 index, the (only) image of an fp16-stored one
@@ -1257,6 +1271,18 @@ int rl_index_info(const rl_index* idx, int64_t* n_rows, int32_t* dim, int64_t* n
     if (dim) *dim = idx->dim;
     if (n_chunks) *n_chunks = idx->n_chunks;
     if (metric) *metric = idx->metric;
+    return RL_OK;
+}
+
+int rl_index_prepare(rl_index* idx, uint32_t images, uint32_t* built, void* stream) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_index_prepare: null index");
+    if (images & ~(uint32_t)IMG_ALL) return fail(RL_ERR_INVALID, "rl_index_prepare: unknown image bit");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
+    idx->no_room_retry_epoch = 0;  // (an explicit request always tries)
+    RL_TRY(demand_images(idx, images, s));
+    if (built) *built = (image_valid(idx) ? IMG_PLANES : 0u) | (hi_image_valid(idx) ? IMG_HI_IMAGE : 0u) | (hi_valid(idx) ? IMG_HI_PLANE : 0u);
     return RL_OK;
 }
 
@@ -2195,8 +2221,9 @@ static int maxsim_topk_batch_any(rl_index* idx, const void* query_vecs, bool q16
         const uint16_t* d_q16;
         RL_TRY(stage_in(static_cast<const uint16_t*>(query_vecs), (size_t)n_queries * q_elems, mem, s, t_q, &d_q16));
         RL_TRY(idx->q32.reserve((size_t)n_queries * q_elems * sizeof(float)));
-        if (launch_widen_f16(d_q16, idx->q32.as<float>(), (int64_t)n_queries * (int64_t)q_elems, s) != RL_OK)
-            return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch_f16: query_vecs_f16 must be 8-byte aligned");
+        const int st_w = launch_widen_f16(d_q16, idx->q32.as<float>(), (int64_t)n_queries * (int64_t)q_elems, s);
+        if (st_w == RL_ERR_UNSUPPORTED) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch_f16: query_vecs_f16 must be 2-byte aligned");
+        RL_TRY(st_w);  // (a launch failure stays what it is)
         d_q = idx->q32.as<float>();
     } else {
         RL_TRY(stage_in(static_cast<const float*>(query_vecs), (size_t)n_queries * q_elems, mem, s, t_q, &d_q));
@@ -2634,6 +2661,10 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
         if (st == RL_OK && !(approx_image_valid(idx) && idx->dim >= 256)) st = RL_ERR_UNSUPPORTED;
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the sixteen-query kernel does not apply to this index / shape") : st; }
     }
+    if (kind == 4) {  // (the lazy image is built BEFORE the timed region, like gemm_prepare's above)
+        st = demand_images(idx, IMG_HI_PLANE, s);
+        if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st; }
+    }
     RL_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < iters && st == RL_OK; ++i) {
         if (kind == 7) st = launch_maxsim_pp(approx_image(idx), idx->n_rows, idx->dim, idx->qplanes.p, pp_n, 0, pp_n,
@@ -2668,8 +2699,6 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
                                      : fail(RL_ERR_UNSUPPORTED, "rl_time_kernel: the index has no HI image");
         }
         else if (kind == 4) {  // the ranking pass of the half-bytes search: the f16 stream kernel over the HI plane
-            if (i == 0) st = demand_images(idx, IMG_HI_PLANE, s);
-            if (st != RL_OK) break;
             st = hi_valid(idx) ? launch_maxsim_stream16(idx->hiplane.as<uint16_t>(), idx->n_rows, idx->dim, q_dev, nq, idx->row_to_chunk, idx->offsets,
                                                         idx->n_chunks, 1, idx->scores.as<float>(), ld, idx->n_cu, s)
                                : fail(RL_ERR_UNSUPPORTED, "rl_time_kernel: the index has no HI plane");

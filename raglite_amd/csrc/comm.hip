@@ -59,21 +59,34 @@ RcclApi& rccl() {
         if (_r != ncclSuccess) return ::rl::fail(RL_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(_r)); \
     } while (0)
 
-// (score bits, id + offset) pairs, -1 ids stay -1: the record every rank contributes
+// (score bits, id + offset) pairs, negative ids stay what they are (-1: an empty slot; RL_ID_SHARD_MISSING: the rank that sends it failed
+// in its local step and its lists are empty): the record every rank contributes.  Zeroes the communicator's "a shard is missing" word for
+// the unpack that follows the all-gather on the same stream.
 __global__ __launch_bounds__(256) void pack_topk_kernel(const float* __restrict__ scores, const int32_t* __restrict__ ids, int64_t n,
-                                                         int32_t id_offset, int2* __restrict__ out) {
+                                                         int32_t id_offset, int2* __restrict__ out, uint32_t* __restrict__ missing) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *missing = 0u;
     if (i >= n) return;
     const int32_t id = ids[i];
-    out[i] = make_int2(__float_as_int(scores[i]), id >= 0 ? id + id_offset : -1);
+    out[i] = make_int2(__float_as_int(scores[i]), id >= 0 ? id + id_offset : id);
 }
 __global__ __launch_bounds__(256) void unpack_topk_kernel(const int2* __restrict__ in, int64_t n, float* __restrict__ scores,
-                                                           int32_t* __restrict__ ids) {
+                                                           int32_t* __restrict__ ids, uint32_t* __restrict__ missing) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int2 v = in[i];
     scores[i] = __int_as_float(v.x);
     ids[i] = v.y;
+    if (v.y == RL_ID_SHARD_MISSING) atomicOr(missing, 1u);
+}
+// A merge that lacks a shard must never look like an answer: every score NaN, every id -1, on every rank alike, without a host read-back.
+__global__ __launch_bounds__(256) void poison_if_missing_kernel(const uint32_t* __restrict__ missing, int64_t n, float* __restrict__ scores,
+                                                                 int32_t* __restrict__ ids) {
+    if (*missing == 0u) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    scores[i] = __int_as_float(0x7fc00000);
+    ids[i] = -1;
 }
 
 }  // namespace
@@ -87,6 +100,7 @@ struct rl_comm {
     void* recv = nullptr;   // [world x n x int2]
     float* g_scores = nullptr;   // rl_allgather_merge_topk: [world x n]
     int32_t* g_ids = nullptr;
+    uint32_t* missing = nullptr;  // device word: some rank's records of the last exchange carried RL_ID_SHARD_MISSING
     size_t cap = 0;         // records (n) the buffers hold
     // The buffers above are shared by all calls on this communicator; `mu` serialises only their host side.  Calls are asynchronous,
     // so a call arriving on a DIFFERENT stream than the previous one first waits for that stream (as rl_index does for its scratch).
@@ -104,6 +118,7 @@ int comm_use(rl_comm* c, hipStream_t s) {
     return RL_OK;
 }
 int comm_reserve(rl_comm* c, size_t n) {
+    if (!c->missing) RL_HIP(hipMalloc(&c->missing, sizeof(uint32_t)));
     if (n <= c->cap) return RL_OK;
     for (void* p : {c->send, c->recv, (void*)c->g_scores, (void*)c->g_ids}) if (p) (void)hipFree(p);
     c->send = c->recv = nullptr; c->g_scores = nullptr; c->g_ids = nullptr; c->cap = 0;
@@ -119,10 +134,12 @@ int allgather_locked(rl_comm* c, const float* local_scores, const int32_t* local
                      int32_t* out_ids, hipStream_t s) {
     RL_TRY(comm_reserve(c, (size_t)n));
     const unsigned blocks = (unsigned)((n + 255) / 256), gblocks = (unsigned)((n * c->world + 255) / 256);
-    hipLaunchKernelGGL(pack_topk_kernel, dim3(blocks), dim3(256), 0, s, local_scores, local_ids, n, id_offset, static_cast<int2*>(c->send));
+    hipLaunchKernelGGL(pack_topk_kernel, dim3(blocks), dim3(256), 0, s, local_scores, local_ids, n, id_offset, static_cast<int2*>(c->send),
+                       c->missing);
     RL_HIP(hipGetLastError());
     RL_NCCL(rccl().AllGather(c->send, c->recv, (size_t)n * 2, ncclInt32, c->comm, s));
-    hipLaunchKernelGGL(unpack_topk_kernel, dim3(gblocks), dim3(256), 0, s, static_cast<const int2*>(c->recv), n * c->world, out_scores, out_ids);
+    hipLaunchKernelGGL(unpack_topk_kernel, dim3(gblocks), dim3(256), 0, s, static_cast<const int2*>(c->recv), n * c->world, out_scores, out_ids,
+                       c->missing);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -171,7 +188,7 @@ int rl_comm_info(const rl_comm* comm, int* rank, int* world) {
 int rl_comm_destroy(rl_comm* comm) {
     if (!comm) return RL_OK;
     if (comm->comm) (void)rccl().CommDestroy(comm->comm);
-    for (void* p : {comm->send, comm->recv, (void*)comm->g_scores, (void*)comm->g_ids}) if (p) (void)hipFree(p);
+    for (void* p : {comm->send, comm->recv, (void*)comm->g_scores, (void*)comm->g_ids, (void*)comm->missing}) if (p) (void)hipFree(p);
     delete comm;
     return RL_OK;
 }
@@ -201,7 +218,11 @@ int rl_allgather_merge_topk(rl_comm* comm, const float* local_scores, const int3
     RL_TRY(comm_use(comm, s));
     RL_TRY(comm_reserve(comm, (size_t)n_queries * k_in));
     RL_TRY(allgather_locked(comm, local_scores, local_ids, (int64_t)n_queries * k_in, id_offset, comm->g_scores, comm->g_ids, s));
-    return launch_merge_topk(comm->g_scores, comm->g_ids, comm->world, n_queries, k_in, k, out_scores, out_ids, s);
+    RL_TRY(launch_merge_topk(comm->g_scores, comm->g_ids, comm->world, n_queries, k_in, k, out_scores, out_ids, s));
+    const int64_t n_out = (int64_t)n_queries * k;
+    hipLaunchKernelGGL(poison_if_missing_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), 0, s, comm->missing, n_out, out_scores, out_ids);
+    RL_HIP(hipGetLastError());
+    return RL_OK;
 }
 
 int rl_allreduce_sum_u32(rl_comm* comm, uint32_t* buf, int64_t count, void* stream) {

@@ -463,12 +463,19 @@ int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld,
 // itself -- no bound, no candidate list, no re-scoring.  This kernel certifies that per query and hands the pass's top-k out as the result:
 // a query with a lost bit (elements spread over more than fp16's exponent range around the scaled maximum), or without k scorable chunks,
 // raises the device flag and the guarded full-precision passes answer the batch instead.
+// ALIGNED: src is 8-byte aligned (one 8-byte load per four elements); else four 2-byte loads (a contiguous slice of a caller's fp16
+// array may start at any element: the values are what matters, not where they lie)
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void widen_f16_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, int64_t count) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < count) {
-        const uint2 v = *reinterpret_cast<const uint2*>(src + i);  // (i % 4 == 0 and the buffers are 16-byte aligned)
         _Float16 h[4];
-        __builtin_memcpy(h, &v, 8);
+        if constexpr (ALIGNED) {
+            const uint2 v = *reinterpret_cast<const uint2*>(src + i);  // (i % 4 == 0 and the buffer is 8-byte aligned)
+            __builtin_memcpy(h, &v, 8);
+        } else {
+            __builtin_memcpy(h, src + i, 8);  // (2-byte aligned only: the compiler emits element loads)
+        }
         typedef float f4 __attribute__((ext_vector_type(4)));
         *reinterpret_cast<f4*>(dst + i) = (f4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
     } else {
@@ -509,8 +516,10 @@ __global__ __launch_bounds__(256) void scale_f32_kernel(const float* __restrict_
 
 int launch_widen_f16(const uint16_t* src, float* dst, int64_t count, hipStream_t s) {
     if (count <= 0) return RL_OK;
-    if ((reinterpret_cast<uintptr_t>(src) & 7) || (reinterpret_cast<uintptr_t>(dst) & 15)) return RL_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(widen_f16_kernel, dim3((unsigned)((count + 1023) / 1024)), dim3(256), 0, s, src, dst, count);
+    if ((reinterpret_cast<uintptr_t>(src) & 1) || (reinterpret_cast<uintptr_t>(dst) & 15)) return RL_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)((count + 1023) / 1024));
+    if (reinterpret_cast<uintptr_t>(src) & 7) hipLaunchKernelGGL(widen_f16_kernel<false>, grid, dim3(256), 0, s, src, dst, count);
+    else hipLaunchKernelGGL(widen_f16_kernel<true>, grid, dim3(256), 0, s, src, dst, count);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

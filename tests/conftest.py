@@ -17,10 +17,20 @@ def pytest_configure(config):
 def pytest_sessionstart(session):
     """The library is a build artefact (git-ignored): a fresh checkout has none.  Build it once (hipcc cross-compiles gfx950 without a GPU,
     ~2 minutes cold) instead of failing the first test that binds the C ABI; a checkout that has it pays one `stat`."""
+    import os
+    import warnings
+
     from raglite_amd import _build
 
-    if not _build.LIB_PATH.exists():
+    # Only the controller of an xdist run builds (its workers would race into the same object directory), and not when the loader is
+    # pointed at another library (RAGLITE_HIP_LIB).  A box without hipcc must not abort the session with an INTERNALERROR: the tests
+    # that bind the C ABI then fail one by one with the loader's own message, the pure-Python ones still run.
+    if _build.LIB_PATH.exists() or os.environ.get("RAGLITE_HIP_LIB") or os.environ.get("PYTEST_XDIST_WORKER"):
+        return
+    try:
         _build.build()
+    except Exception as exc:  # noqa: BLE001 - FileNotFoundError (no hipcc), RuntimeError (compile error), ...
+        warnings.warn(f"libraglite_hip.so is missing and could not be built: {type(exc).__name__}: {exc}", stacklevel=1)
 
 
 def _have_gpu() -> bool:

@@ -75,6 +75,16 @@ def test_float_data_device_tensors_tolerance_and_agreement_with_the_filtered_rou
         np.testing.assert_allclose(bs[i], ref[bc[i]], rtol=0, atol=2e-6 * float(np.abs(ref).max()))
         assert set(bc[i].tolist()) == set(fc[i].tolist())  # (the two routes' scores differ in the last bits: order may too)
         np.testing.assert_allclose(np.sort(bs[i]), np.sort(fs[i]), rtol=0, atol=4e-6 * float(np.abs(ref).max()))
+    # a contiguous slice of the caller's fp16 tensor that starts at an element offset not divisible by four (2-byte aligned only):
+    # round 5 answered "must be 8-byte aligned"; the values are what matters
+    flat = torch.zeros(Qd.numel() + 8, dtype=torch.float16, device="cuda")
+    for shift in (1, 2, 3):
+        view = flat[shift : shift + Qd.numel()].view(Qd.shape)
+        view.copy_(Qd)
+        assert view.is_contiguous() and view.data_ptr() % 8 == 2 * shift
+        us, uc = idx.maxsim_topk_batch(view, k)
+        assert _stats(idx) == ("maxsim_batch_f16_exact", 0, False)
+        assert np.array_equal(us.cpu().numpy(), bs) and np.array_equal(uc.cpu().numpy(), bc)
     idx.close()
 
 

@@ -131,3 +131,38 @@ def test_options_release_and_rebuild_the_images():
         idx.set_option("hi_products", 3)
     assert idx.get_option("hi_products") == 1 and idx.get_option("keep_hi") == 1
     idx.close()
+
+
+def test_prepare_builds_the_lazy_images_outside_the_hot_path_and_a_skipped_image_is_retried():
+    """`rl_index_prepare` (round 6): the warm-up for lazy images -- and an image that was skipped because the device was too full at that
+    moment is asked for again once there is room (round 5 left the route on its slow path for good)."""
+    import raglite_amd
+    from oracle import oracle
+
+    n, dim = 70_000, 1024
+    E = oracle.synth_matrix(35, n, dim, "small_int")
+    q = oracle.synth_matrix(36, 1, dim, "small_int")[0]
+    idx = raglite_amd.DeviceIndex(E, metric="dot")
+    assert idx.memory()["hi_plane"] == 0
+    assert idx.prepare("hi_plane") == ("hi_image", "hi_plane")  # (the plane's bound statistics come with the HI image)
+    m = idx.memory()
+    assert m["hi_plane"] >= m["rows"] // 2 and m["presplit_image"] == 0
+    s0, r0 = idx.search_rows(q, 10)
+    assert idx.filter_stats()["kind"] == "rows_hi"
+    assert set(idx.prepare()) == {"presplit", "hi_image", "hi_plane"}
+    with pytest.raises(ValueError):
+        idx.prepare("everything")
+    idx.close()
+    # no room: an absurd headroom makes every build "not fit"; the route answers from the rows, and asks again once the headroom is sane
+    idx = raglite_amd.DeviceIndex(E, metric="dot")
+    idx.set_option("image_headroom_mb", 1 << 22)
+    assert idx.prepare("hi_plane") == ()
+    s1, r1 = idx.search_rows(q, 10)
+    assert idx.filter_stats()["kind"] == "none" and idx.memory()["hi_plane"] == 0
+    idx.set_option("image_headroom_mb", 0)
+    for _ in range(70):  # at most one call in 64 asks again
+        s2, r2 = idx.search_rows(q, 10)
+    assert idx.memory()["hi_plane"] >= m["rows"] // 2 and idx.filter_stats()["kind"] == "rows_hi"
+    for s, r in ((s1, r1), (s2, r2)):
+        assert np.array_equal(r, r0) and np.array_equal(s, s0)
+    idx.close()

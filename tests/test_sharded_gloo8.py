@@ -139,6 +139,31 @@ def _worker_body(rank, port, out_q):
             out["failure"] = f"MemoryError: {exc}"
         except RuntimeError as exc:
             out["failure"] = f"RuntimeError: {exc}"
+        # (6) the same failure on the route WITHOUT a threshold exchange (fp16 queries over fp16-stored shards: the local batch goes
+        # straight to the merge all-gather) -- round 5 let the exception escape before the collective and the other ranks hung in it.
+        # Torch tensors over gloo stand in for the device tensors (the code path is the device one: the merge comes back poisoned).
+        local.storage = "f16"
+        if rank == 2:
+            local.maxsim_batch_begin = _Local.maxsim_batch_begin.__get__(local)
+
+            def boom16(Qb, k):
+                raise MemoryError("first-call image build failed (injected)")
+
+            local.maxsim_topk_batch = boom16
+        try:
+            sh.maxsim_topk_batch(Q5.astype(np.float16), 10)
+            out["failure16"] = "no error"
+        except MemoryError as exc:
+            out["failure16"] = f"MemoryError: {exc}"
+        except RuntimeError as exc:
+            out["failure16"] = f"RuntimeError: {exc}"
+        out["staged_after_16"] = getattr(local, "begin_calls", 0)
+        # (the merge itself, 8800 records wide so that CPU tensors can take it: rank 2 sends the marker a failed rank sends)
+        if rank != 2:
+            ms, mi = sh._exchange_merge_device(torch.from_numpy(s_np.copy()), torch.from_numpy(i_np.astype(np.int32)), r_lo, 1100)  # noqa: SLF001
+        else:
+            ms, mi = sh._exchange_merge_device(torch.full((len(Q), 1100), float("-inf")), torch.full((len(Q), 1100), -2, dtype=torch.int32), r_lo, 1100)  # noqa: SLF001
+        out["poisoned"] = bool(torch.isnan(ms).all()) and bool((mi == -1).all())
         # ... and the group is still usable afterwards
         t = torch.tensor([rank], dtype=torch.int64)
         dist.all_reduce(t)
@@ -194,6 +219,12 @@ def test_eight_ranks_uneven_and_empty_shards_match_the_single_index():
             assert out["failure"].startswith("MemoryError: hipMalloc failed")
         else:
             assert out["failure"].startswith("RuntimeError: ShardedIndex.maxsim_topk_batch: another rank failed")
+        if rank == 2:
+            assert out["failure16"].startswith("MemoryError: first-call image build failed")
+        else:
+            assert out["failure16"].startswith("RuntimeError: ShardedIndex.maxsim_topk_batch: another rank failed")
+        assert out["staged_after_16"] == out["staged"] + (1 if rank != 2 else 0)  # (5) staged once more on the healthy ranks, (6) never
+        assert out["poisoned"], f"rank {rank}: a merge that lacks a shard came back looking like an answer"
         assert out["after"] == sum(range(WORLD))
 
 
@@ -311,6 +342,12 @@ def test_fp16_queries_over_fp16_stored_shards_skip_the_threshold_exchange():
     sh._local_maxsim_batch(np.zeros((8, 4, 32), np.float16), 5)  # noqa: SLF001
     assert calls == [("batch", "float16")]
     calls.clear()
+    sh._local_maxsim_batch(torch.zeros((8, 4, 32), dtype=torch.float16), 5)  # noqa: SLF001
+    assert calls == [("batch", "torch.float16")]
+    calls.clear()
     sh._allgather_int = lambda x: np.stack([x] * 8)  # noqa: SLF001
     sh._local_maxsim_batch(np.zeros((8, 4, 32), np.float32), 5)  # noqa: SLF001
     assert calls[0] == ("begin", "float32")
+    calls.clear()
+    sh._local_maxsim_batch(torch.zeros((8, 4, 32), dtype=torch.bfloat16), 5)  # noqa: SLF001  (bfloat16 is not IEEE fp16: staged like fp32)
+    assert calls[0] == ("begin", "torch.bfloat16")
