@@ -81,6 +81,67 @@ def blas_threads() -> int:
         return int(os.cpu_count() or 1)
 
 
+def vendor_gemm_calibration(dev, n_rows: int, iters: int = 20) -> dict:
+    """The external yardstick of the pass kernel's main loop (round-5 review, item 1): the VENDOR's fp16 GEMM (hipBLASLt / rocBLAS through
+    `torch.matmul`) on the same box, in the same run, on the same pseudo-random data, at the shapes the pass kernel multiplies --
+    [n_rows x 1024] . [1024 x 512] (one pass of sixteen 32-vector queries) and . [1024 x 4096] (a whole 128-query step) -- HIP events on
+    torch's current stream (the stream torch launches its GEMM on), `iters` launches each.  The vendor kernel also WRITES its C matrix
+    (1 GB / 8 GB in fp16) where the pass kernel reduces it to 125 k chunk maxima per query in registers, so a third, square shape
+    (8192^3: C traffic negligible) says what the library's best loop sustains on this box when nothing but the main loop matters.
+    torch is the sanctioned owner of device memory; this block is a measurement, not on the product path."""
+    import torch
+
+    import raglite_amd
+
+    out: dict = {}
+
+    def rate(m: int, n: int, k: int, out_dtype=None) -> float:
+        a32 = torch.empty((m, k), dtype=torch.float32, device=dev)
+        raglite_amd.synth_fill(a32, seed=SEED_CORPUS)
+        a = a32.half()
+        del a32
+        b32 = torch.empty((k, n), dtype=torch.float32, device=dev)
+        raglite_amd.synth_fill(b32, seed=SEED_QUERY)
+        b = b32.half()
+        del b32
+        c = torch.empty((m, n), dtype=out_dtype or torch.float16, device=dev)
+
+        def mm():
+            if out_dtype is None:
+                torch.mm(a, b, out=c)
+            else:
+                torch.mm(a, b, out_dtype=out_dtype, out=c)
+
+        for _ in range(3):
+            mm()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            mm()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        del a, b, c
+        torch.cuda.empty_cache()
+        return ms
+
+    for name, (m, n, k) in (("pass_shape", (n_rows, 16 * NQ, DIM)), ("step_shape", (n_rows, QUERIES_PER_STEP * NQ, DIM)), ("square_8192", (8192, 8192, 8192))):
+        try:
+            ms = rate(m, n, k)
+            out[f"{name}_ms"] = ms
+            out[f"{name}_tflops"] = 2.0 * m * n * k / (ms * 1e-3) / 1e12
+        except Exception as exc:  # noqa: BLE001 - a diagnostic must not take the bench line down
+            out[f"{name}_error"] = f"{type(exc).__name__}: {exc}"
+    try:  # fp32 C (what the pass kernel accumulates in; twice the C bytes)
+        ms = rate(n_rows, 16 * NQ, DIM, torch.float32)
+        out["pass_shape_f32_out_ms"] = ms
+        out["pass_shape_f32_out_tflops"] = 2.0 * n_rows * 16 * NQ * DIM / (ms * 1e-3) / 1e12
+    except Exception as exc:  # noqa: BLE001 (torch builds without `out_dtype`)
+        out["pass_shape_f32_out_error"] = f"{type(exc).__name__}: {exc}"[:200]
+    return out
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +150,7 @@ def main() -> None:
     ap.add_argument("--rows", type=int, default=N_ROWS, help=argparse.SUPPRESS)  # debugging only
     ap.add_argument("--no-cpu-baseline", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-configs", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-vendor-gemm", action="store_true", help=argparse.SUPPRESS)
     # NOT the BASELINE.json configuration (that one is fp32, the default): the fp16-stored index of SURVEY.md 8f-1,
     # reported under its own workload name so it can never be mistaken for the headline number.
     ap.add_argument("--storage", choices=("f32", "f16"), default="f32", help=argparse.SUPPRESS)
@@ -279,6 +341,8 @@ def main() -> None:
                                       "default since round 5: an image is built by the first call whose route reads it -- MaxSim batches the HI image; "
                                       "--opt lazy_images=0: every image with the index, 3 x)"}
 
+    result["index_memory_times_corpus"] = result["index_memory"]["times_corpus"]  # (top-level scalar: the driver's record keeps scalars)
+
     # ---- roofline of the dominant kernel: HIP events on the launch stream, kernel only -----------------------------
     # One launch = one corpus pass of EIGHT queries through maxsim_gemm_kernel (matrix-pipe-bound).  Big fp32 corpora in split
     # arithmetic: the approximate pass over the HI image (kind 6: 1 fp16 MFMA product per multiply; the candidates it leaves
@@ -354,18 +418,36 @@ def main() -> None:
         # The same fraction against what the matrix pipe SUSTAINS on this box in this run: the pass kernel's MFMA stream alone (8 waves per CU,
         # 128 accumulators each, register-resident pseudo-random fp16 operands; no loads, no LDS, no epilogue -- rl_time_kernel kind 9).
         # The nominal 2.5 PFLOP/s is 16 cycles per MFMA at 2.4 GHz; under a full MFMA load the shader clock settles well below that.
+        rl_block = result["roofline"]
         try:
             index.time_kernel(9, qv, 3)
             rate_ms = index.time_kernel(9, qv, iters) / iters
             n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
             rate_tf = n_cu * 8 * 1000 * 32 * (2.0 * 16 * 16 * 32) / (rate_ms * 1e-3) / 1e12
-            result["roofline"]["sustained"] = {
-                "mfma_f16_tflops": rate_tf, "frac_of_nominal_peak": rate_tf / MFMA_F16_PEAK_TF, "frac_of_sustained": achieved / rate_tf,
-                "implied_shader_clock_ghz": rate_tf / MFMA_F16_PEAK_TF * 2.4, "kernel": "rl::mfma_f16_rate_kernel", "kernel_ms": rate_ms,
-                "how": f"same run, right after the pass kernel: {iters} launches of {n_cu} workgroups x 8 waves x 32 000 v_mfma_f32_16x16x32_f16 on "
-                       "register-resident pseudo-random operands (HIP events); `frac` above stays against the nominal peak"}
+            # SCALARS of the roofline block itself (the driver's record keeps scalars only: round 5's nested `sustained` never reached it)
+            rl_block.update({
+                "sustained_tflops": rate_tf, "frac_of_sustained": achieved / rate_tf, "sustained_frac_of_nominal_peak": rate_tf / MFMA_F16_PEAK_TF,
+                "shader_clock_ghz": rate_tf / MFMA_F16_PEAK_TF * 2.4, "sustained_kernel_ms": rate_ms,
+                "sustained_how": f"rl::mfma_f16_rate_kernel, same run, right after the pass kernel: {iters} launches of {n_cu} workgroups x 8 waves x 32 000 "
+                                 "v_mfma_f32_16x16x32_f16 on register-resident pseudo-random operands (HIP events); `frac` stays against the nominal peak"})
         except Exception as exc:  # noqa: BLE001 - a diagnostic must not take the bench line down
-            result["roofline"]["sustained"] = {"error": f"{type(exc).__name__}: {exc}"}
+            rl_block["sustained_error"] = f"{type(exc).__name__}: {exc}"
+        # ... and against the vendor's GEMM on the same box in the same run (vendor_gemm_calibration): the yardstick the main loop is held to
+        if rank == 0 and world == 1 and kind == 7 and not args.no_vendor_gemm:
+            try:
+                vg = vendor_gemm_calibration(dev, rows_local, iters)
+            except Exception as exc:  # noqa: BLE001
+                vg = {"error": f"{type(exc).__name__}: {exc}"}
+            for key, val in vg.items():
+                rl_block[f"vendor_gemm_{key}"] = val
+            best_like = max((vg.get(f"{n}_tflops") or 0.0) for n in ("pass_shape", "step_shape", "pass_shape_f32_out"))
+            if best_like > 0.0:
+                rl_block["vendor_gemm_tflops"] = best_like  # the vendor's best on the pass kernel's own shapes
+                rl_block["pass_kernel_over_vendor"] = achieved / best_like  # whole pass kernel (main loop + tile epilogues + flush) / vendor GEMM (main loop + C store)
+            if vg.get("square_8192_tflops"):
+                rl_block["pass_kernel_over_vendor_square"] = achieved / vg["square_8192_tflops"]
+            rl_block["vendor_gemm_how"] = (f"torch.mm (hipBLASLt / rocBLAS) fp16 x fp16 -> fp16 (fp32 accumulate), {iters} launches each, HIP events, same run, same "
+                                           f"pseudo-random data: [{rows_local} x {DIM}] . [{DIM} x {16 * NQ}] (one pass), . [{DIM} x {QUERIES_PER_STEP * NQ}] (a step), 8192^3")
     else:
         result["roofline"] = {"bound": "hbm", **hbm, "traffic": traffic}
     if kind in (5, 6, 7):  # for reference: the full-precision pass (eight queries) the approximate one replaces (and falls back to)
@@ -540,6 +622,7 @@ def main() -> None:
             "fallback": h_stats["fallback"], "kernel": f_kernel, "kernel_ms": f_ms,
             "note": "fp16 x fp16 products are exact in fp32 and neither side has a dropped half: the pass's exact top-k is returned as is",
         }
+        result["f16_queries_value"] = result["f16_queries"]["value"]  # (top-level scalar: the driver's record keeps scalars)
         del last16h
     else:
         f16_last = None
@@ -632,7 +715,7 @@ def main() -> None:
         import bench_configs
 
         result["configs"] = {}
-        for name in ("cfg1", "cfg2", "cfg3", "cfg4", "cfg5"):
+        for name in ("cfg1", "cfg2", "cfg3", "cfg3_pool2g", "cfg4", "cfg5", "cfg5_full_one_gpu"):
             try:
                 result["configs"][name] = bench_configs.run(name)
             except Exception as exc:  # noqa: BLE001 - a failing side config must not hide the headline
@@ -655,7 +738,7 @@ def main() -> None:
         dist.destroy_process_group()
 
 
-BENCH_SCHEMA = 5  # round 5: per-pass / per-launch byte counts kept apart, every printed fraction checked by fraction_violations()
+BENCH_SCHEMA = 6  # round 6: sustained / vendor-GEMM yardsticks as SCALARS of `roofline`, index_memory_times_corpus and f16_queries_value at top level; round 5: per-pass / per-launch byte counts kept apart, every printed fraction checked by fraction_violations()
 
 
 def fraction_violations(node, path: str = "") -> list[str]:

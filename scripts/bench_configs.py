@@ -1,6 +1,6 @@
 """Throughput of BASELINE.json configs 1-5 on one MI355X, each with a spot check against the oracle.
 
-    python scripts/bench_configs.py [cfg1 cfg2 cfg3 cfg3_f16 cfg4 cfg5]   -> one JSON object per config on stdout
+    python scripts/bench_configs.py [cfg1 cfg2 cfg3 cfg3_f16 cfg4 cfg5 cfg5_full_one_gpu]   -> one JSON object per config on stdout
     bench.py imports `run(name)` and prints the results in its `configs` block (outside the headline's timed region).
 
 Everything is resident in HBM before timing; kernels are launched on torch's current stream and timed with
@@ -179,12 +179,26 @@ def cfg2():
     }
 
 
-def cfg3(storage="f32"):
+def _traffic(kernel: str, key: str | None = None):
+    """bytes per launch from profiles/traffic.json by_kernel (a separate rocprofv3 --pmc FETCH_SIZE pass, x 2 for the gfx950 half-count), or
+    None: only a record filed under this very kernel name (and, where one kernel serves several workloads, this workload key) counts."""
+    tf = ROOT / "profiles" / "traffic.json"
+    if not tf.exists():
+        return None, None
+    rec = (json.loads(tf.read_text()).get("by_workload" if key else "by_kernel") or {}).get(key or kernel)
+    if not rec or (key and rec.get("kernel") != kernel) or not rec.get("bytes_per_launch"):
+        return None, None
+    return float(rec["bytes_per_launch"]), f"static: profiles/traffic.json <- {rec.get('source')} ({rec.get('dispatches')} dispatches)"
+
+
+def cfg3(storage="f32", n_chunks=16384, name="cfg3"):
     """BASELINE cfg 3: ColBERT rerank, 32 query vectors x 256 candidate chunks x 64 vectors/chunk, d = 128, 4096
-    independent queries per launch (the reranker plugin call, src/raglite/_search.py:394-396)."""
+    independent queries per launch (the reranker plugin call, src/raglite/_search.py:394-396).  `n_chunks` sizes the pool the candidates
+    are drawn from: 16 384 chunks = 1 M vectors = 512 MB (round 1-5's block: twice the 256-MiB Infinity Cache, so part of every launch is
+    served on-die), 65 536 chunks = 4 M vectors = 2.1 GB (`cfg3_pool2g`: eight times the cache -- nothing much is resident)."""
     from oracle import oracle
 
-    d, nq, n_cand, rows, n_chunks = 128, 32, 256, 64, 16384  # 1 M candidate vectors in the pool
+    d, nq, n_cand, rows = 128, 32, 256, 64
     E = torch.empty((n_chunks * rows, d), dtype=torch.float32, device="cuda")
     raglite_amd.synth_fill(E, seed=3)
     E /= E.norm(dim=1, keepdim=True)  # ColBERT convention: unit rows
@@ -207,15 +221,33 @@ def cfg3(storage="f32"):
     arith = idx.arithmetic
     idx.close()
     qps = nb / (ms * 1e-3)
-    bytes_q, flops_q = n_cand * rows * d * (2.0 if storage == "f16" else 4.0), 2.0 * nq * n_cand * rows * d
+    elt = 2.0 if storage == "f16" else 4.0
+    bytes_q, flops_q = n_cand * rows * d * elt, 2.0 * nq * n_cand * rows * d
+    pool_bytes = n_chunks * rows * d * elt
+    # distinct chunks a launch touches (4096 x 256 draws with replacement from n_chunks): what HBM has to deliver at least once per launch
+    distinct = n_chunks * (1.0 - (1.0 - 1.0 / n_chunks) ** (nb * n_cand))
+    kernel = "rl::maxsim_cand_kernel<2, true, false>" if storage == "f16" else ("rl::maxsim_cand_kernel<2, false, true>" if arith == "f16_split" else "rl::maxsim_cand_kernel<2, false, false>")
+    traffic, traffic_source = _traffic(kernel, f"{name}:{storage}")
+    roof = {"bound": "hbm", "achieved": qps * bytes_q / 1e9, "peak": HBM_PEAK, "unit": "GB/s", "frac": qps * bytes_q / 1e9 / HBM_PEAK,
+            "fp32_equivalent_tflops": qps * flops_q / 1e12, "kernel": kernel + " (as rocprofv3 names it)", "kernel_ms": float(ms),
+            "algorithmic_bytes_per_launch": nb * bytes_q, "pool_bytes": pool_bytes, "distinct_pool_bytes_per_launch": distinct * rows * d * elt,
+            "traffic": traffic, "traffic_source": traffic_source,
+            "frac_of_hbm_from_counters": (traffic / (ms * 1e-3) / 1e9 / HBM_PEAK) if traffic else None,
+            "note": f"`frac` is ALGORITHMIC bytes (every candidate row of every query once) / time: 4096 x 256 candidates are drawn from a {pool_bytes / 1e6:.0f} MB pool, so a "
+                    f"launch re-reads every pool chunk {nb * n_cand / n_chunks:.0f} x on average; L2 (32 MiB) and the Infinity Cache (256 MiB) absorb what they can hold. "
+                    "`traffic` = FETCH_SIZE x 2 of a separate PMC pass: the L2's fabric-side requests, Infinity-Cache hits INCLUDED (MI355X_MICROARCH.md) -- it "
+                    "bounds HBM traffic from above; cfg3_pool2g is the same launch over a pool eight times the cache"}
     return {
-        "workload": f"cfg3: MaxSim rerank 32 x (256 x 64) x 128, 4096 queries per launch, unit rows, {storage}-stored corpus",
+        "workload": f"{name}: MaxSim rerank 32 x (256 x 64) x 128, 4096 queries per launch, unit rows, {storage}-stored corpus, candidates drawn from a pool of "
+                    f"{n_chunks} chunks ({pool_bytes / 1e9:.2f} GB)",
         "value": qps, "unit": "queries/s", "ms_per_launch": float(ms), "timing": ms.stats, "arithmetic": arith,
-        "roofline": {"bound": "hbm", "achieved": qps * bytes_q / 1e9, "peak": HBM_PEAK, "unit": "GB/s", "frac": qps * bytes_q / 1e9 / HBM_PEAK,
-                     "fp32_equivalent_tflops": qps * flops_q / 1e12,
-                     "note": "candidates are drawn from a 1M-vector pool (512 MB): partly L2 / Infinity-Cache resident"},
+        "roofline": roof,
         "check": {"score_max_abs_err": err, "queries": 3, "against": "float64 oracle (unit rows: scores <= 32)"},
     }
+
+
+def cfg3_pool2g():
+    return cfg3("f32", 65536, "cfg3_pool2g")
 
 
 def cfg3_f16():
@@ -326,6 +358,70 @@ def cfg5():
                                                    "list_capacity": stats.get("list_capacity"), "fallback": stats.get("fallback")},
         "check": {"recall_at_100": float(np.mean(rec)), "score_max_abs_err": float(np.max(err)), "queries": 3,
                   "against": "fp32 NumPy oracle, full shard"},
+    }
+
+
+def cfg5_full_one_gpu():
+    """BASELINE cfg 5 AS SURVEY.md 8d WROTE IT, on ONE device: the whole 10 M x 1024 fp32 corpus (41 GB -- 10.24 G elements, five times
+    what a 32-bit element offset reaches) cut into the eight logical shards of SURVEY.md 8e (1.25 M rows each, one DeviceIndex per shard
+    over its slice of the same tensor), 1000 queries, cosine exact top-100: every shard's `rl_search_rows`, then the REAL merge
+    (`rl_merge_topk`: the kernel `rl_allgather_merge_topk` runs after its all-gather).  One device, no RCCL: the eight shard searches run
+    one after the other, so `ms_per_batch` is the SUM of what eight GPUs would do side by side plus the merge -- not a scaling figure.
+    Checked two ways: the merged lists against ONE index over all 10 M rows (bit for bit: `ORDER BY dist LIMIT k` of the whole table,
+    `_search.py:75-79`), and three queries against float64 cosines of every row (PyTorch-ROCm fp64 on the device)."""
+    n, d, B, k, world = 10_000_000, 1024, 1000, 100, 8
+    E = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=5)
+    Q = torch.empty((B, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=50)
+    bounds = [(n * r // world, n * (r + 1) // world) for r in range(world)]
+    shards = [raglite_amd.DeviceIndex(E[lo:hi], metric="cosine") for lo, hi in bounds]
+    bases = torch.tensor([lo for lo, _ in bounds], dtype=torch.int32, device="cuda").view(world, 1, 1)
+
+    def step():
+        outs = [sh.search_rows(Q, k) for sh in shards]
+        gs = torch.stack([o[0] for o in outs])
+        gi = torch.stack([o[1] for o in outs]) + bases  # (local ordinals are >= 0 here: every shard holds >= k rows)
+        return raglite_amd.merge_topk(gs, gi, k)
+
+    ms = timed(step, 20)
+    ms_shard0 = timed(lambda: shards[0].search_rows(Q, k), 20)
+    s, r = step()
+    routes = sorted({sh.filter_stats()["kind"] for sh in shards})
+    fallbacks = sum(int(sh.filter_stats()["fallback"]) for sh in shards)
+    mem_shards = sum(sum(sh.memory()[key] for key in ("presplit_image", "hi_image", "hi_plane")) for sh in shards)
+    for sh in shards:
+        sh.close()
+    torch.cuda.empty_cache()
+    whole = raglite_amd.DeviceIndex(E, metric="cosine")
+    ws, wr = whole.search_rows(Q, k)
+    whole_route = whole.filter_stats()["kind"]
+    ms_whole = timed(lambda: whole.search_rows(Q, k), 5, 1)
+    identical = bool(torch.equal(ws, s) and torch.equal(wr, r))
+    whole.close()
+    torch.cuda.empty_cache()
+    s_np, r_np = s.cpu().numpy(), r.cpu().numpy()
+    rec, err = [], []
+    for b in (0, 499, 999):
+        q64 = Q[b].double()
+        ref = torch.empty(n, dtype=torch.float64, device="cuda")
+        for lo in range(0, n, 1 << 19):
+            blk = E[lo : lo + (1 << 19)].double()
+            ref[lo : lo + (1 << 19)] = (blk @ q64) / (blk.norm(dim=1) * q64.norm())
+        top = torch.topk(ref, k).indices.cpu().numpy()
+        rec.append(_recall(top, r_np[b]))
+        err.append(float(np.abs(ref[torch.as_tensor(r_np[b].astype(np.int64), device="cuda")].cpu().numpy() - s_np[b]).max()))
+        del ref
+    fp32_flops = 2.0 * B * n * d
+    return {
+        "workload": "cfg5 as SURVEY wrote it, on ONE GPU: 10M x 1024 fp32 (41 GB, 10.24 G elements) as eight logical shards of 1.25M rows, B=1000 cosine exact "
+                    "top-100, rl_merge_topk of the eight lists; one device, no RCCL -- the shard searches run one after the other",
+        "value": B / (ms * 1e-3), "unit": "queries/s over all eight shards on one device", "ms_per_batch": float(ms), "timing": ms.stats,
+        "ms_per_batch_shard0": float(ms_shard0), "ms_per_batch_one_index_over_10M_rows": float(ms_whole), "routes": routes, "route_one_index": whole_route,
+        "fallbacks": fallbacks, "image_bytes_all_shards": int(mem_shards),
+        "fp16_mfma_tflops": fp32_flops / (ms * 1e-3) / 1e12, "frac": fp32_flops / (ms * 1e-3) / 1e12 / MFMA_F16_PEAK,
+        "check": {"merged_equals_one_index_bitwise": identical, "recall_at_100": float(np.mean(rec)), "score_max_abs_err_vs_f64": float(np.max(err)),
+                  "queries": 3, "against": "one DeviceIndex over all 10M rows (every query, bit for bit); float64 cosines of every row (torch on the device), 3 queries"},
     }
 
 

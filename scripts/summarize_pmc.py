@@ -41,4 +41,15 @@ if "--traffic-json" in opts:
         table[m.group(1)] = {"fetch_kib_mean": mean_kib, "bytes_per_launch": mean_kib * 1024 * 2, "dispatches": n,
                              # (the batch pipeline launches all passes of a step as grid rows of ONE launch of the sixteen-query kernel)
                              "passes_per_launch": int(opts.get("--passes-per-launch", 1)) if "maxsim_pp_kernel<0, 0" in m.group(1) else 1, "source": opts.get("--source", str(out))}
+    # --workload KEY=KERNEL_SUBSTRING [--workload2 ...]: one kernel serves several workloads (cfg 3 at two pool sizes) -- file the record under
+    # by_workload[KEY] with the kernel's name, so that the bench block of THAT workload can pick it up and no other
+    for opt, val in opts.items():
+        if not opt.startswith("--workload"):
+            continue
+        wkey, needle = val.split("=", 1)
+        for k, (mean_kib, n) in fetch.items():
+            m = re.match(r"^(?:void )?(rl::[\w:]*\w+(?:<[^(]*>)?)\(", k)
+            if m and needle in m.group(1):
+                tj.setdefault("by_workload", {})[wkey] = {"kernel": m.group(1), "fetch_kib_mean": mean_kib, "bytes_per_launch": mean_kib * 1024 * 2,
+                                                          "dispatches": n, "source": opts.get("--source", str(out))}
     path.write_text(json.dumps(tj, indent=2) + "\n")

@@ -71,6 +71,15 @@ def test_recorded_lines_of_this_schema_have_sane_fractions():
             ex = doc["exact_fp32"]
             # one query per pass, one pass per launch: the fraction IS 4 N d bytes over the kernel time
             assert ex["frac"] == pytest.approx(ex["algorithmic_bytes_per_launch"] / (ex["kernel_ms"] * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, rel=1e-9), name
+        # round 6: what the review's arguments lean on must be SCALARS where the driver keeps them (its record drops nested objects)
+        for key in ("sustained_tflops", "frac_of_sustained", "shader_clock_ghz"):
+            assert isinstance(roof.get(key), float), f"{name}: roofline.{key}"
+        if doc.get("n_gpus") == 1 and "vendor_gemm_error" not in roof:
+            for key in ("vendor_gemm_tflops", "pass_kernel_over_vendor"):
+                assert isinstance(roof.get(key), float), f"{name}: roofline.{key}"
+        assert isinstance(doc.get("index_memory_times_corpus"), float), name
+        if doc.get("f16_queries"):
+            assert isinstance(doc.get("f16_queries_value"), float), name
         if roof.get("traffic") is not None:  # only ever from a PMC record filed under the kernel the block reports
             assert roof["kernel"].split(" (")[0] in roof["traffic_source"], name
 

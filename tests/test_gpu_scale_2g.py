@@ -1,0 +1,282 @@
+"""An index of MORE than 2^31 elements (round-5 review, "What's missing" 3): 2 300 000 rows x 1024 = 2.36 G elements, so every row past
+2 097 152 lies beyond what a 32-bit element offset reaches -- a single-GPU RAGLite store of that many chunklet rows is ordinary
+(`/root/reference/src/raglite/_database.py:403-430`: one `chunk_embedding` row per chunklet).  Every full-size test until round 5 stopped
+at 1.0-1.3 G elements; 10 700 lines of HIP with int32 row ids, int tile ordinals and 4-byte LDS / image offsets had nothing that would
+catch one 32-bit product.
+
+What is held here, through the C ABI, on the routes the sizes select by themselves (checked with `filter_stats`):
+  * PLANTED answers in the last 1 % of the corpus (rows >= 2 277 000): rows built from the queries so that the top of every result is
+    known by construction -- a route that wraps an offset cannot find them;
+  * every returned list against a float64 reference over the WHOLE corpus (PyTorch-ROCm's fp64 GEMM on the device, an independent
+    implementation; tie-aware check of `tests/util.py`), scores within north_star's 1e-4 on cosines, 2e-6 of the score scale on MaxSim;
+  * the NumPy ORACLE on a 64 k-row slab that straddles element 2^31 (rows 2 064 384 .. 2 129 920): the filtered searches of the big index
+    restricted to the slab's chunks against `oracle.search_rows` / `oracle.maxsim_topk` on the slab's host copy;
+  * `search_rows` at B = 1 (half-bytes route over the HI plane), 16, 1000 (fused exact top-k over the HI image), `search_chunks`
+    (`_search.py:66-79,143-149`), `maxsim_topk_batch` with fp32 queries (bound-filtered pipeline) and with fp16 queries over the
+    fp16-stored corpus (the exact one-product route), and APPEND across the boundary (bit-identical to an index built at once).
+"""
+
+import numpy as np
+import pytest
+
+import raglite_amd
+from bench import chunk_offsets
+from oracle import oracle
+from tests.util import assert_topk_close
+
+pytestmark = pytest.mark.gpu
+N, D = 2_300_000, 1024
+BOUNDARY_ROW = (1 << 31) // D  # 2 097 152: the first row whose elements lie past element 2^31
+TAIL0 = N - N // 100  # the last 1 % of the corpus
+N_PLANT_Q, N_PLANT = 16, 5  # planted rows: queries 0..15, five each
+SLAB = (BOUNDARY_ROW - 32768, BOUNDARY_ROW + 32768)
+
+
+def _plant_row(b: int, j: int) -> int:
+    return TAIL0 + 251 * (N_PLANT * b + j) + 13
+
+
+@pytest.fixture(scope="module")
+def big():
+    import torch
+
+    raglite_amd.set_device(0)
+    E = torch.empty((N, D), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=66)
+    Q = torch.empty((1000, D), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=67)
+    # planted rows: cos(q_b, q_b + 0.2 j u) ~ 1 / sqrt(1 + (0.2 j)^2) = 1, .98, .93, .86, .78 against ~ 0.17 for the best random row
+    for b in range(N_PLANT_Q):
+        for j in range(N_PLANT):
+            r = _plant_row(b, j)
+            assert TAIL0 <= r < N and r > BOUNDARY_ROW
+            E[r] = Q[b] + 0.2 * j * E[r]
+    off = chunk_offsets(N)
+    # planted CHUNKS for the MaxSim batches: chunk c's rows = alpha x the query's first vectors; chunks of >= 8 rows in the last 1 %
+    Qb = torch.empty((19, 32, D), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Qb, seed=68)
+    sizes = np.diff(off)
+    c_tail = int(np.searchsorted(off, TAIL0 + 251 * N_PLANT * N_PLANT_Q + 100, side="left"))  # (behind the planted rows)
+    cands = [c for c in range(c_tail, len(sizes)) if sizes[c] >= 8][: 3 * 4]
+    planted_chunks = {}
+    for b in range(4):
+        planted_chunks[b] = []
+        for j, alpha in enumerate((0.9, 0.8, 0.7)):
+            c = cands[3 * b + j]
+            r0 = int(off[c])
+            assert r0 > BOUNDARY_ROW
+            E[r0 : r0 + 8] = alpha * Qb[b, :8]
+            planted_chunks[b].append(c)
+    torch.cuda.synchronize()
+    yield torch, E, Q, Qb, off, planted_chunks
+    del E
+    torch.cuda.empty_cache()
+
+
+def _ref_cos64(torch, E, q):
+    """float64 cosines of q with EVERY row, slab by slab (torch on the device: an independent implementation)."""
+    out = torch.empty(E.shape[0], dtype=torch.float64, device=E.device)
+    q64 = q.double()
+    for lo in range(0, E.shape[0], 262144):
+        blk = E[lo : lo + 262144].double()
+        out[lo : lo + 262144] = (blk @ q64) / (blk.norm(dim=1) * q64.norm())
+    return out.cpu().numpy()
+
+
+def _ref_maxsim64(torch, E, off, Qq):
+    """float64 MaxSim score of EVERY chunk: slabs cut at chunk boundaries."""
+    n_chunks = len(off) - 1
+    out = torch.empty(n_chunks, dtype=torch.float64, device=E.device)
+    Q64 = Qq.double()
+    step = 32768
+    for c0 in range(0, n_chunks, step):
+        c1 = min(n_chunks, c0 + step)
+        r0, r1 = int(off[c0]), int(off[c1])
+        S = E[r0:r1].double() @ Q64.T  # (rows, nq)
+        lengths = torch.as_tensor(np.diff(off[c0 : c1 + 1]), device=E.device)
+        out[c0:c1] = torch.segment_reduce(S, "max", lengths=lengths, axis=0).sum(dim=1)
+    return out.cpu().numpy()
+
+
+def _planted_on_top(rows, b):
+    want = [_plant_row(b, j) for j in range(N_PLANT)]
+    assert rows[:N_PLANT].tolist() == want, f"query {b}: planted rows {want} not on top: {rows[:8].tolist()}"
+
+
+def test_row_searches_past_2g_elements_b1_b16_b1000(big):
+    torch, E, Q, _, off, _ = big
+    idx = raglite_amd.DeviceIndex(E, off, metric="cosine")
+    refs = {b: _ref_cos64(torch, E, Q[b]) for b in (0, 15, 999)}
+    # B = 1: the half-bytes route (ranking pass over the HI plane + exact re-scoring)
+    for b in (0, 15):
+        s, r = idx.search_rows(Q[b], 100)
+        assert idx.filter_stats()["kind"] == "rows_hi" and not idx.filter_stats()["fallback"]
+        s, r = s.cpu().numpy(), r.cpu().numpy()
+        _planted_on_top(r, b)
+        assert_topk_close(s, r, refs[b], 100, 1e-4)
+    # B = 16
+    S, R = idx.search_rows(Q[:16], 100)
+    assert idx.filter_stats()["kind"] == "rows_hi" and not idx.filter_stats()["fallback"]
+    S, R = S.cpu().numpy(), R.cpu().numpy()
+    for b in range(16):
+        _planted_on_top(R[b], b)
+    for b in (0, 15):
+        assert_topk_close(S[b], R[b], refs[b], 100, 1e-4)
+    # B = 1000: the fused exact top-k over the HI image (candidate pass on the sixteen-group tile)
+    S, R = idx.search_rows(Q, 100)
+    st = idx.filter_stats()
+    assert st["kind"] == "rows_fused_hi" and not st["fallback"], st
+    S, R = S.cpu().numpy(), R.cpu().numpy()
+    for b in range(16):
+        _planted_on_top(R[b], b)
+    for b in (0, 15, 999):
+        assert_topk_close(S[b], R[b], refs[b], 100, 1e-4)
+    assert (R[:, 0] >= 0).all() and (R < N).all()
+    # a8 on top of it (`_search.py:143-149`): chunks of the top-40 rows, first occurrence wins -- against the rows this index itself returns
+    r2c = np.repeat(np.arange(len(off) - 1), np.diff(off))
+    cs, cc, cn = idx.search_chunks(Q[:4], 40, 10)
+    cs, cc, cn = cs.cpu().numpy(), cc.cpu().numpy(), cn.cpu().numpy()
+    s40, r40 = idx.search_rows(Q[:4], 40)
+    s40, r40 = s40.cpu().numpy(), r40.cpu().numpy()
+    for b in range(4):
+        want_c, want_s = [], []
+        for s_, r_ in zip(s40[b], r40[b]):
+            c = int(r2c[r_])
+            if c not in want_c:
+                want_c.append(c)
+                want_s.append(s_)
+        kk = min(10, len(want_c))
+        assert int(cn[b]) == kk and cc[b, :kk].tolist() == want_c[:kk]
+        np.testing.assert_array_equal(cs[b, :kk], np.asarray(want_s[:kk], np.float32))
+        assert int(cc[b, 0]) == int(r2c[_plant_row(b, 0)])
+    idx.close()
+
+
+def test_oracle_on_a_slab_that_straddles_element_2_to_the_31(big):
+    """The filtered searches of the BIG index restricted to the chunks of rows 2 064 384 .. 2 129 920 against the NumPy oracle on the slab's
+    host copy: ids are ordinals of the big index, so an offset that wraps inside the slab shows up as a wrong row or a wrong score."""
+    torch, E, Q, Qb, off, _ = big
+    c0 = int(np.searchsorted(off, SLAB[0], side="left"))
+    c1 = int(np.searchsorted(off, SLAB[1], side="right")) - 1
+    r0, r1 = int(off[c0]), int(off[c1])
+    assert r0 < BOUNDARY_ROW < r1 and r1 - r0 > 60_000
+    E_slab = E[r0:r1].cpu().numpy()
+    off_slab = off[c0 : c1 + 1] - off[c0]
+    mask = np.zeros(len(off) - 1, dtype=bool)
+    mask[c0:c1] = True
+    for metric in ("cosine", "dot"):
+        idx = raglite_amd.DeviceIndex(E, off, metric=metric)
+        for b in (0, 1):
+            q = Q[b].cpu().numpy()
+            s, r = idx.search_rows(Q[b], 50, chunk_filter=mask)
+            s, r = s.cpu().numpy(), r.cpu().numpy()
+            assert ((r >= r0) & (r < r1)).all()
+            ref = oracle.similarity(E_slab, q, metric, np.float64)
+            tol = 1e-4 if metric == "cosine" else 2e-6 * float(np.abs(ref).max())
+            assert_topk_close(s, r - r0, ref, 50, tol)
+            es, er = oracle.search_rows(E_slab, q, 50, metric, np.float32)  # fp32 as the reference computes it
+            assert set(er.tolist()) == set((r - r0).tolist())
+        if metric == "dot":
+            for b in (0, 1):
+                Qq = Qb[b].cpu().numpy()
+                s, c = idx.maxsim_topk(Qb[b], 20, chunk_filter=mask)
+                s, c = s.cpu().numpy(), c.cpu().numpy()
+                ref = oracle.maxsim_scores(E_slab, off_slab, Qq, np.float64)
+                assert_topk_close(s, c - c0, ref, 20, 2e-6 * float(np.abs(ref).max()))
+                ms, mc = oracle.maxsim_topk(E_slab, off_slab, Qq, 20, np.float32)
+                assert set(mc.tolist()) == set((c - c0).tolist())
+        idx.close()
+
+
+def test_maxsim_batches_past_2g_elements_fp32_and_fp16_queries(big):
+    torch, E, _, Qb, off, planted = big
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    k = 100
+    bs, bc = idx.maxsim_topk_batch(Qb, k)
+    st = idx.filter_stats()
+    assert st["kind"] == "maxsim_batch_hi" and not st["fallback"], st
+    bs, bc = bs.cpu().numpy(), bc.cpu().numpy()
+    for b in range(4):
+        assert bc[b, :3].tolist() == planted[b], f"query {b}: planted chunks {planted[b]} not on top: {bc[b, :5].tolist()}"
+    for b in (0, 3, 18):
+        ref = _ref_maxsim64(torch, E, off, Qb[b])
+        assert_topk_close(bs[b], bc[b], ref, k, 2e-6 * float(np.abs(ref).max()))
+        if b == 3:  # one query at a time (the interactive route) against the same reference
+            s1, c1 = idx.maxsim_topk(Qb[3], k)
+            s1, c1 = s1.cpu().numpy(), c1.cpu().numpy()
+            assert c1[:3].tolist() == planted[3]
+            assert_topk_close(s1, c1, ref, k, 2e-6 * float(np.abs(ref).max()))
+    idx.close()
+    # fp16 queries over the fp16-STORED corpus: the one-product pass is exact, its top-k is the result
+    E16 = E.half()
+    idx16 = raglite_amd.DeviceIndex(E16, off, metric="dot", storage="f16")
+    Q16 = Qb.half()
+    hs, hc = idx16.maxsim_topk_batch(Q16, k)
+    st = idx16.filter_stats()
+    assert st["kind"] == "maxsim_batch_f16_exact" and not st["fallback"], st
+    hs, hc = hs.cpu().numpy(), hc.cpu().numpy()
+    for b in range(4):
+        assert hc[b, :3].tolist() == planted[b]
+    E16f = E16.float()
+    for b in (0, 18):
+        ref = _ref_maxsim64(torch, E16f, off, Q16[b].float())
+        assert_topk_close(hs[b], hc[b], ref, k, 2e-6 * float(np.abs(ref).max()))
+    del E16f
+    # ... and fp32 queries over the same fp16-stored corpus (bound-filtered, re-scored over the stored rows)
+    fs, fc = idx16.maxsim_topk_batch(Qb, k)
+    assert idx16.filter_stats()["kind"] == "maxsim_batch_hi"
+    for b in range(4):
+        assert fc[b, :3].cpu().numpy().tolist() == planted[b]
+    idx16.close()
+    del E16
+    torch.cuda.empty_cache()
+
+
+def test_append_across_the_2g_boundary_equals_an_index_built_at_once(big):
+    """`insert_documents` appends `chunk_embedding` rows (`_insert.py:247-272`): an index of 2 090 000 rows grown by 200 000 rows -- across
+    element 2^31, into storage the index had to re-allocate -- answers bit for bit like an index over the 2 290 000 rows built at once."""
+    torch, E, Q, Qb, off, planted = big
+    c_a = int(np.searchsorted(off, 2_090_000, side="left"))
+    c_b = int(np.searchsorted(off, 2_290_000, side="left"))
+    r_a, r_b = int(off[c_a]), int(off[c_b])
+    assert r_a < BOUNDARY_ROW < r_b
+    whole = raglite_amd.DeviceIndex(E[:r_b], off[: c_b + 1], metric="dot")
+    grown = raglite_amd.DeviceIndex(E[:r_a], off[: c_a + 1], metric="dot")
+    step = (c_b - c_a) // 3
+    cuts = [c_a, c_a + step, c_a + 2 * step, c_b]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        grown.append(E[int(off[lo]) : int(off[hi])], np.diff(off[lo : hi + 1]))
+    assert (grown.n_rows, grown.n_chunks) == (r_b, c_b)
+    for idx in (whole, grown):
+        idx.prepare()  # every image: the appended rows went into each of them
+    ws, wr = whole.search_rows(Q[:16], 50)
+    gs, gr = grown.search_rows(Q[:16], 50)
+    assert torch.equal(ws, gs) and torch.equal(wr, gr)
+    assert int(wr[0, 0]) == _plant_row(0, 0)  # (the planted rows below 2 290 000 are in: the first eleven queries' all lie there)
+    ws, wr = whole.search_rows(Q[:200], 50)
+    gs, gr = grown.search_rows(Q[:200], 50)
+    assert torch.equal(ws, gs) and torch.equal(wr, gr)
+    ws, wc = whole.maxsim_topk_batch(Qb, 50)
+    gs, gc = grown.maxsim_topk_batch(Qb, 50)
+    assert torch.equal(ws, gs) and torch.equal(wc, gc)
+    whole.close()
+    grown.close()
+
+
+def test_cfg5_as_survey_wrote_it_ten_million_rows_on_one_gpu_as_eight_shards():
+    """BASELINE cfg 5 at ITS size -- 10 M x 1024 fp32 = 10.24 G elements on one device, eight logical shards, the real merge kernel; what
+    `bench.py` reports as `configs.cfg5_full_one_gpu` (one device, no RCCL): the merged lists equal ONE index over all 10 M rows bit for
+    bit (`ORDER BY dist LIMIT k` over the whole table, `/root/reference/src/raglite/_search.py:75-79`) and float64 cosines of every row."""
+    import sys
+    from pathlib import Path
+
+    import torch
+
+    torch.cuda.empty_cache()
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "scripts"))
+    import bench_configs
+
+    out = bench_configs.run("cfg5_full_one_gpu")
+    assert out["check"]["merged_equals_one_index_bitwise"], out
+    assert out["check"]["recall_at_100"] == 1.0 and out["check"]["score_max_abs_err_vs_f64"] <= 1e-4, out["check"]
+    assert out["routes"] == ["rows_fused_hi"] and out["route_one_index"] == "rows_fused_hi" and out["fallbacks"] == 0, out
