@@ -200,7 +200,7 @@ struct Options {
         for (auto& x : v) x = 0;
         v[RL_OPT_HI_SEARCH] = v[RL_OPT_HI_MAXSIM] = v[RL_OPT_HI_PRODUCTS] = v[RL_OPT_PP_PASS] = v[RL_OPT_FUSED_TOPK] = v[RL_OPT_FUSED_HI] = 1;
         v[RL_OPT_FUSED_PP] = v[RL_OPT_GEMM_PASS] = v[RL_OPT_QUERY_PAIRS] = v[RL_OPT_PLANES_GEMM] = v[RL_OPT_KEEP_IMAGE] = v[RL_OPT_KEEP_HI] = 1;
-        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = v[RL_OPT_F16_EXACT] = v[RL_OPT_LAZY_IMAGES] = v[RL_OPT_FUSED_PP_SAMPLE] = v[RL_OPT_LIST_SELECT] = 1;
+        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = v[RL_OPT_F16_EXACT] = v[RL_OPT_LAZY_IMAGES] = v[RL_OPT_FUSED_PP_SAMPLE] = v[RL_OPT_LIST_SELECT] = v[RL_OPT_HI_FEW] = 1;
         v[RL_OPT_IMAGE_HEADROOM_MB] = -1;
         v[RL_OPT_ARITHMETIC] = RL_ARITH_AUTO;
     }
@@ -212,7 +212,7 @@ bool option_value_ok(int key, int64_t value) {
     switch (key) {
         case RL_OPT_HI_SEARCH: case RL_OPT_HI_MAXSIM: case RL_OPT_PP_PASS: case RL_OPT_FUSED_TOPK: case RL_OPT_FUSED_HI: case RL_OPT_FUSED_PP:
         case RL_OPT_GEMM_PASS: case RL_OPT_QUERY_PAIRS: case RL_OPT_PLANES_GEMM: case RL_OPT_KEEP_IMAGE: case RL_OPT_KEEP_HI:
-        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED: case RL_OPT_F16_EXACT: case RL_OPT_LAZY_IMAGES: case RL_OPT_FUSED_PP_SAMPLE: case RL_OPT_LIST_SELECT:
+        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED: case RL_OPT_F16_EXACT: case RL_OPT_LAZY_IMAGES: case RL_OPT_FUSED_PP_SAMPLE: case RL_OPT_LIST_SELECT: case RL_OPT_HI_FEW:
             return value == 0 || value == 1;
         case RL_OPT_HI_PRODUCTS: return value == 1 || value == 2;
         case RL_OPT_FUSED_TOPK_CAP: return value >= 0 && value <= MERGE_CAP;
@@ -2037,6 +2037,8 @@ int maxsim_scores_device(rl_index* idx, const float* d_q, int32_t nq, float* d_o
     return st;
 }
 
+int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, int32_t k, float* sc, int64_t ld, float* d_s, int32_t* d_c,
+                        hipStream_t s);  // (defined behind the batch pipeline it shares its stages with)
 }  // namespace
 
 int rl_maxsim_scores(rl_index* idx, const float* query_vecs, int32_t nq, float* out_scores, int mem, void* stream) {
@@ -2074,6 +2076,18 @@ int rl_maxsim_topk_filtered(rl_index* idx, const float* query_vecs, int32_t nq, 
     RL_TRY(stage_out_begin(out_scores, (size_t)k, mem, t_s, &d_s));
     RL_TRY(stage_out_begin(out_chunks, (size_t)k, mem, t_c, &d_c));
     RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));
+    if (!d_f) {  // one user query at a time, no metadata filter: the half-width route over the HI plane where the index has (or may build) one
+        const int64_t ld1 = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
+        RL_TRY(idx->scores.reserve((size_t)ld1 * sizeof(float)));
+        const int st = maxsim_few_hi_plane(idx, d_q, nq, 1, k, idx->scores.as<float>(), ld1, d_s, d_c, s);
+        if (st == RL_OK) {
+            if (idx->live_chunk_bits) RL_TRY(launch_fix_masked(d_s, d_c, k, s));
+            RL_TRY(stage_out_end(out_scores, (size_t)k, mem, s, t_s));
+            RL_TRY(stage_out_end(out_chunks, (size_t)k, mem, s, t_c));
+            return finish(mem, s);
+        }
+        if (st != RL_ERR_UNSUPPORTED) return st;
+    }
     RL_TRY(maxsim_scores_device(idx, d_q, nq, idx->scores.as<float>(), s));
     const bool masked = d_f || idx->live_chunk_bits;
     RL_TRY(mask_chunk_scores(idx, idx->scores.as<float>(), 1, idx->n_chunks, d_f, s));
@@ -2145,10 +2159,12 @@ int hi_batch_approx(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queri
     RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, hb.ts, hb.ti, s));
     return RL_OK;
 }
+// rows_only: the caller laid out no query fragments (the few-queries route over the HI plane) -- the guarded fallback then streams the rows even
+// where the pre-split image exists
 int hi_batch_fallback(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queries, int32_t n_gemm, int32_t k, float* sc, int64_t ld,
-                      const HiBatch& hb, float* d_s, int32_t* d_c, hipStream_t s);
+                      const HiBatch& hb, float* d_s, int32_t* d_c, hipStream_t s, bool rows_only = false);
 int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queries, int32_t n_gemm, int32_t k, float* sc, int64_t ld,
-                     const HiBatch& hb, float* d_s, int32_t* d_c, hipStream_t s) {
+                     const HiBatch& hb, float* d_s, int32_t* d_c, hipStream_t s, bool rows_only = false) {
     const size_t q_elems = (size_t)nq * idx->dim;
     const float* rows = idx->E16 ? reinterpret_cast<const float*>(idx->E16) : idx->E;
     const bool rows16 = idx->E16 != nullptr;
@@ -2169,16 +2185,16 @@ int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_quer
         RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap, n_gemm, hb.es, s, rows16, 0, 0, packed));
     }
     RL_TRY(launch_merge_topk(hb.es, hb.ci, 1, n_gemm, hb.cap, k, d_s, d_c, s, hb.cnt));
-    return hi_batch_fallback(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, d_s, d_c, s);
+    return hi_batch_fallback(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, d_s, d_c, s, rows_only);
 }
 int hi_batch_fallback(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queries, int32_t n_gemm, int32_t k, float* sc, int64_t ld,
-                      const HiBatch& hb, float* d_s, int32_t* d_c, hipStream_t s) {
+                      const HiBatch& hb, float* d_s, int32_t* d_c, hipStream_t s, bool rows_only) {
     const size_t q_elems = (size_t)nq * idx->dim;
     // list overflow / unusable bound: the full-precision passes, behind the flag -- ONE launch for all of them (gridDim.y = passes: sixteen
     // guarded launches that return at once were 0.08 ms of every 128-query step)
     // (no pre-split image: the streaming kernels over the rows, one launch with a grid row per query -- the same arithmetic, an order of
     // magnitude slower, and as rare)
-    if (image_valid(idx))
+    if (image_valid(idx) && !rows_only)
         RL_TRY(launch_maxsim_gemm(idx->planes.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, 0, n_gemm, nq, idx->row_to_chunk, idx->offsets,
                                   idx->ends.as<uint32_t>(), sc, ld, idx->n_cu, s, image_scale(idx), idx->E16 != nullptr, hb.flag, false, true));
     else  // (grid row = query: with many queries a grid column of n_cu workgroups per query is 32 k workgroups that return at once behind the
@@ -2190,7 +2206,7 @@ int hi_batch_fallback(rl_index* idx, const float* d_q, int32_t nq, int32_t n_que
     // (the exact top-k of the fallback's scores in ONE guarded launch, a block per query -- select.hip: guarded_select_kernel -- instead of the
     // selection's three: what usually returns at once is one launch shorter by two)
     RL_TRY(launch_guarded_select(sc, n_gemm, idx->n_chunks, ld, k, nullptr, nullptr, nullptr, 0, SCAN_RAW_DOT, 1.0f, d_s, d_c, hb.flag, s));
-    if (idx->opt.on(RL_OPT_LAZY_IMAGES) && !image_valid(idx)) {  // (lazy images: let the next batch know whether this one fell back)
+    if (idx->opt.on(RL_OPT_LAZY_IMAGES) && !image_valid(idx) && !rows_only) {  // (lazy images: let the next batch know whether this one fell back)
         if (!idx->h_fell_back) {  // (no pinned word: no signal -- the fallback then stays on the streaming kernels, results unchanged)
             if (hipHostMalloc(reinterpret_cast<void**>(&idx->h_fell_back), sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) *idx->h_fell_back = 0u;
             else { idx->h_fell_back = nullptr; (void)hipGetLastError(); }
@@ -2198,6 +2214,55 @@ int hi_batch_fallback(rl_index* idx, const float* d_q, int32_t nq, int32_t n_que
         if (idx->h_fell_back) RL_HIP(hipMemcpyAsync(idx->h_fell_back, hb.flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     }
     return RL_OK;
+}
+
+// ---- one or two MaxSim queries over an fp32 index in split arithmetic: the half-width route (round 6) ------------------------------------
+// How the reference calls the reranker -- one user query at a time (src/raglite/_search.py:394-396) -- used to stream the fp32 rows (4 B per
+// element: maxsim_stream_kernel / maxsim_stream2_kernel, 0.58-0.67 ms per pass at 1 M x 1024): the bound-filtered pipeline of the batches
+// starts at three queries because its sixteen-query pass is matrix-pipe-bound whatever the number of queries.  For one or two queries the
+// APPROXIMATE pass is the HBM-bound streaming kernel over the row-major fp16 HI plane (2 B per element: the image the single-query row search
+// ranks from) -- both halves of the query multiplied, so all it drops is e_lo -- and the rest is the batch's own pipeline: exact top-k of the
+// approximate scores, |approximate - exact| <= m = (max|e_lo| + 2^-12 max|e|) sum_i |q_i|, second threshold from the exact scores of the
+// approximate top-k, exact re-scoring of the candidates over the rows (maxsim_pairs_kernel), ranking; list overflow / unusable bound ->
+// device flag -> the streaming pass over the rows + exact selection behind it.  Results: the exact top-k of exactly computed scores.
+// d_q: the n (1 or 2) queries, q_elems floats apart; sc: [n x ld] scratch rows; d_s / d_c: [n x k].  RL_ERR_UNSUPPORTED where the route
+// does not apply (the caller keeps the streaming kernels over the rows).
+int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, int32_t k, float* sc, int64_t ld, float* d_s, int32_t* d_c,
+                        hipStream_t s) {
+    if (n < 1 || n > 2 || nq < 1 || nq > 32 || k > 512 || !idx->opt.on(RL_OPT_HI_MAXSIM) || !idx->opt.on(RL_OPT_HI_FEW)) return RL_ERR_UNSUPPORTED;
+    if (idx->E16 || !idx->E || !(idx->split_scale > 0.f) || idx->has_empty_chunk || idx->n_chunks == 0 || idx->n_rows == 0) return RL_ERR_UNSUPPORTED;
+    RL_TRY(demand_images(idx, IMG_HI_PLANE, s));
+    if (!hi_valid(idx) || idx->max_row_norm_rows != idx->n_rows || !(idx->max_row_norm > 0.f)) return RL_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(d_q) & 15) || (reinterpret_cast<uintptr_t>(idx->E) & 15)) return RL_ERR_UNSUPPORTED;
+    const int64_t q_elems = (int64_t)nq * idx->dim;
+    int st = RL_ERR_UNSUPPORTED;
+    if (n == 2 && nq > 16 && idx->opt.on(RL_OPT_QUERY_PAIRS)) {  // two queries of 17..32 vectors share ONE pass over the plane
+        RL_TRY(idx->qsplit.reserve(query_split_bytes(idx->dim, 2)));
+        st = launch_query_split(d_q, idx->dim, nq, q_elems, 2, idx->qsplit.as<char>(), true, s);
+        if (st == RL_OK)
+            st = launch_maxsim_stream2(idx->hiplane.p, true, idx->n_rows, idx->dim, idx->qsplit.as<char>(), 2, 0, nq, idx->row_to_chunk, idx->offsets,
+                                       idx->n_chunks, sc, ld, idx->n_cu, s, 1.f);
+    }
+    if (st == RL_ERR_UNSUPPORTED)  // one pass per query, one launch (grid row = query)
+        st = launch_maxsim_stream_batch(idx->hiplane.p, true, idx->n_rows, idx->dim, d_q, nq, q_elems, n, idx->row_to_chunk, idx->offsets,
+                                        idx->n_chunks, sc, ld, idx->n_cu, s, 0.f, nullptr);
+    if (st != RL_OK) return st;
+    // the plane holds fp16(e * scale), scale a power of two: undone exactly
+    RL_TRY(launch_scale_f32(sc, sc, 1.0f / idx->split_scale, (int64_t)(n - 1) * ld + idx->n_chunks, s));
+    HiBatch hb;
+    hb.one_product = false;  // q_hi . e_hi + q_lo . e_hi: nothing of the query is dropped
+    hb.exact_kth = idx->opt.on(RL_OPT_EXACT_KTH_THRESHOLD);
+    RL_TRY(idx->hibuf.reserve(hi_batch_words(n, k) * 4));
+    hi_batch_layout(idx, n, k, hb);
+    hb.m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
+    hb.q_unscale = nullptr;
+    RL_HIP(hipMemsetAsync(hb.flag, 0, 16 * sizeof(uint32_t), s));
+    RL_HIP(hipMemsetAsync(hb.ci, 0xff, (size_t)n * hb.cap * sizeof(int32_t), s));
+    RL_TRY(mask_chunk_scores(idx, sc, n, ld, nullptr, s));  // tombstones never become candidates
+    RL_TRY(launch_topk(sc, n, idx->n_chunks, ld, k, idx->ws, hb.ts, hb.ti, s));
+    RL_TRY(launch_maxsim_threshold(hb.ts, n, k, d_q, nq, idx->dim, q_elems, 1.0f, hb.m_abs, hb.thr, hb.cnt, hb.flag, s, nullptr,
+                                   idx->max_row_norm + idx->max_lo_norm, hb.m));
+    return hi_batch_rescore(idx, d_q, nq, n, n, k, sc, ld, hb, d_s, d_c, s, true);
 }
 }  // namespace
 
@@ -2295,7 +2360,14 @@ static int maxsim_topk_batch_any(rl_index* idx, const void* query_vecs, bool q16
             return st;
         }
     }
-    const int32_t rest = n_queries - base;
+    int32_t rest = n_queries - base;
+    int32_t few = 0;  // queries [base, base + few) were ranked by the few-queries route over the HI plane
+    if (rest >= 1 && rest <= 2) {
+        const int st = maxsim_few_hi_plane(idx, d_q + (size_t)base * q_elems, nq, rest, k, sc + (int64_t)base * ld, ld, d_s + (int64_t)base * k,
+                                           d_c + (int64_t)base * k, s);
+        if (st == RL_OK) { few = rest; rest = 0; }
+        else if (st != RL_ERR_UNSUPPORTED) return st;
+    }
     int32_t paired = 0;
     if (rest >= 2) {
         const int st = pairs_prepare(idx, d_q + (size_t)base * q_elems, nq, (int64_t)q_elems, rest & ~1, s);
@@ -2303,10 +2375,10 @@ static int maxsim_topk_batch_any(rl_index* idx, const void* query_vecs, bool q16
         else if (st != RL_ERR_UNSUPPORTED) return st;
     }
     for (int32_t b = 0; b < paired; b += 2) RL_TRY(pairs_pass(idx, nq, paired, b, sc + (int64_t)(base + b) * ld, ld, s));
-    for (int32_t b = base + paired; b < n_queries; ++b)
+    for (int32_t b = base + paired; b < n_queries - few; ++b)
         RL_TRY(maxsim_scores_device(idx, d_q + (size_t)b * q_elems, nq, sc + (int64_t)b * ld, s));
-    {   // what the half-bytes pipeline did not rank: every query, or the one or two left over
-        const int32_t first = hi_done ? base : 0;
+    {   // what the half-bytes pipelines did not rank: every query, or the one or two left over
+        const int32_t first = few ? n_queries : (hi_done ? base : 0);
         if (n_queries > first) {
             RL_TRY(mask_chunk_scores(idx, sc + (int64_t)first * ld, n_queries - first, ld, nullptr, s));  // tombstones (no-op without deletions)
             RL_TRY(launch_topk(sc + (int64_t)first * ld, n_queries - first, idx->n_chunks, ld, k, idx->ws, d_s + (int64_t)first * k,

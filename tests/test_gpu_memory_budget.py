@@ -144,7 +144,7 @@ def test_prepare_builds_the_lazy_images_outside_the_hot_path_and_a_skipped_image
     q = oracle.synth_matrix(36, 1, dim, "small_int")[0]
     idx = raglite_amd.DeviceIndex(E, metric="dot")
     assert idx.memory()["hi_plane"] == 0
-    assert idx.prepare("hi_plane") == ("hi_image", "hi_plane")  # (the plane's bound statistics come with the HI image)
+    assert idx.prepare("hi_plane") == ("hi_plane",)
     m = idx.memory()
     assert m["hi_plane"] >= m["rows"] // 2 and m["presplit_image"] == 0
     s0, r0 = idx.search_rows(q, 10)

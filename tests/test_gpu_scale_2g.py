@@ -240,8 +240,8 @@ def test_append_across_the_2g_boundary_equals_an_index_built_at_once(big):
     c_b = int(np.searchsorted(off, 2_290_000, side="left"))
     r_a, r_b = int(off[c_a]), int(off[c_b])
     assert r_a < BOUNDARY_ROW < r_b
-    whole = raglite_amd.DeviceIndex(E[:r_b], off[: c_b + 1], metric="dot")
-    grown = raglite_amd.DeviceIndex(E[:r_a], off[: c_a + 1], metric="dot")
+    whole = raglite_amd.DeviceIndex(E[:r_b], off[: c_b + 1], metric="cosine")
+    grown = raglite_amd.DeviceIndex(E[:r_a], off[: c_a + 1], metric="cosine")
     step = (c_b - c_a) // 3
     cuts = [c_a, c_a + step, c_a + 2 * step, c_b]
     for lo, hi in zip(cuts[:-1], cuts[1:]):
