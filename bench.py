@@ -552,6 +552,53 @@ def main() -> None:
     else:
         exact_last = None
 
+    # ---- ONE user query at a time: how the reference calls the reranker (`_search.py:394-396`) -- rl_maxsim_topk per query, host loop ------
+    # Round 6: one or two queries rank from the row-major fp16 HI plane (2 B per element, HBM-bound streaming kernel) and re-score their
+    # candidates exactly over the rows (option hi_few; `rows_route`: the streaming kernel over the fp32 rows it replaces, same results).
+    if single and arithmetic == "f16_split" and not args.exact_fp32 and hasattr(index, "maxsim_topk"):
+        n_one = min(64, qps)
+        qs1 = queries[(args.steps - 1) % n_batches][:n_one]
+
+        def one_by_one():
+            outs = [index.maxsim_topk(qs1[i], TOPK) for i in range(n_one)]
+            return torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs])
+
+        def timed_loop():
+            for i in range(3):
+                index.maxsim_topk(qs1[i], TOPK)
+            fence()
+            t0 = time.perf_counter()
+            got = one_by_one()
+            fence()
+            return time.perf_counter() - t0, got
+
+        one_s, (o_s, o_c) = timed_loop()
+        one_stats = index.filter_stats()
+        block = {"workload": f"maxsim_{NQ}x{n_rows}_d{DIM}_top{TOPK}_ONE_QUERY_PER_CALL", "value": n_one / one_s, "unit": "queries/s", "queries": n_one,
+                 "ms_per_query": 1e3 * one_s / n_one, "route": one_stats["kind"], "fallback": one_stats["fallback"],
+                 "candidates_per_query": {"mean": one_stats["candidates_per_query_mean"], "max": one_stats["candidates_per_query_max"]}}
+        if last is not None:  # the same queries went through the batch pipeline in the last timed step: same chunks, same exactly re-scored scores
+            b_s, b_c = last[0][:n_one], last[1][:n_one]
+            block["chunks_identical_to_batch"] = bool(torch.equal(torch.sort(o_c, dim=1).values, torch.sort(b_c.to(o_c.dtype), dim=1).values))
+            block["score_max_abs_diff_vs_batch"] = float((torch.sort(o_s, dim=1).values - torch.sort(b_s, dim=1).values).abs().max())
+        try:
+            index.time_kernel(10, qs1[0], 3)
+            k_ms = index.time_kernel(10, qs1[0], iters) / iters
+            plane_bytes = 2.0 * rows_local * DIM
+            block.update({"kernel": "rl::maxsim_stream_kernel<256, 2, 0, false, 6, true, false>", "kernel_ms": k_ms, "bound": "hbm",
+                          "narrower_image": "row-major fp16 HI plane, 2 B per element (+ 0.5 x the corpus resident)",
+                          "streamed_bytes_per_launch": plane_bytes, "frac": plane_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          "frac_vs_4B_per_element_whole_query": algo_bytes_per_pass / (one_s / n_one) / 1e9 / HBM_PEAK_GBS})
+        except Exception as exc:  # noqa: BLE001
+            block["kernel_error"] = f"{type(exc).__name__}: {exc}"
+        with index.options(hi_few=0):
+            rows_s, (r_s, r_c) = timed_loop()
+        block["rows_route"] = {"value": n_one / rows_s, "ms_per_query": 1e3 * rows_s / n_one,
+                               "chunks_identical": bool(torch.equal(torch.sort(o_c, dim=1).values, torch.sort(r_c, dim=1).values)),
+                               "note": "--opt hi_few=0: the streaming kernel over the fp32 rows (4 B per element), what rounds 1-5 ran"}
+        result["one_query"] = block
+        result["one_query_value"] = block["value"]
+
     # ---- the reference's real storage dtype (pgvector halfvec, `_typing.py:211-232`; `_embed.py:140` casts to fp16): the same
     # workload over the SAME corpus rounded to fp16, under its own workload name -- not the BASELINE config, driver-timed ----------
     if single and args.storage == "f32" and not args.exact_fp32 and not args.no_f16:

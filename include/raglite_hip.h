@@ -509,7 +509,9 @@ int rl_index_filter_stats(rl_index* index, int64_t out[6], void* stream);
  * RL_ERR_UNSUPPORTED when no such call ran or any other search used the index since), 9 = the matrix pipe alone: the sixteen-query
  * kernel's MFMA stream (8 waves per CU, 128 accumulators each) on register-resident pseudo-random fp16 operands -- no loads, no LDS, no
  * epilogue; one launch = compute units x 8 waves x 32 000 v_mfma_f32_16x16x32_f16 (x 16 384 flop): the SUSTAINED fp16 rate of this
- * device at the clock it settles at, which bench.py prints next to the nominal peak (query_vecs_dev / nq are not read).
+ * device at the clock it settles at, which bench.py prints next to the nominal peak (query_vecs_dev / nq are not read),
+ * 10 = the approximate pass of the few-queries MaxSim route (rl_maxsim_topk, batches of < 3; RL_OPT_HI_FEW): ONE query of nq <= 32 vectors,
+ * MaxSim over the row-major fp16 HI plane (RL_ERR_UNSUPPORTED when the index has none).
  * Used so that roofline.achieved is measured with HIP
  * events on the stream the kernel runs on. */
 int rl_time_kernel(rl_index* index, int kind, const float* query_vecs_dev, int32_t nq, int32_t iters,

@@ -2733,7 +2733,7 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
         if (st == RL_OK && !(approx_image_valid(idx) && idx->dim >= 256)) st = RL_ERR_UNSUPPORTED;
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st == RL_ERR_UNSUPPORTED ? fail(st, "rl_time_kernel: the sixteen-query kernel does not apply to this index / shape") : st; }
     }
-    if (kind == 4) {  // (the lazy image is built BEFORE the timed region, like gemm_prepare's above)
+    if (kind == 4 || kind == 10) {  // (the lazy image is built BEFORE the timed region, like gemm_prepare's above)
         st = demand_images(idx, IMG_HI_PLANE, s);
         if (st != RL_OK) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return st; }
     }
@@ -2774,6 +2774,12 @@ int rl_time_kernel(rl_index* idx, int kind, const float* q_dev, int32_t nq, int3
             st = hi_valid(idx) ? launch_maxsim_stream16(idx->hiplane.as<uint16_t>(), idx->n_rows, idx->dim, q_dev, nq, idx->row_to_chunk, idx->offsets,
                                                         idx->n_chunks, 1, idx->scores.as<float>(), ld, idx->n_cu, s)
                                : fail(RL_ERR_UNSUPPORTED, "rl_time_kernel: the index has no HI plane");
+        }
+        else if (kind == 10) {  // the approximate pass of the few-queries MaxSim route: ONE query of nq vectors, MaxSim over the HI plane
+            st = hi_valid(idx) && nq <= 32 ? launch_maxsim_stream_batch(idx->hiplane.p, true, idx->n_rows, idx->dim, q_dev, nq, (int64_t)nq * idx->dim, 1,
+                                                                        idx->row_to_chunk, idx->offsets, idx->n_chunks, idx->scores.as<float>(), ldc, idx->n_cu, s,
+                                                                        0.f, nullptr)
+                                           : fail(RL_ERR_UNSUPPORTED, "rl_time_kernel: the index has no HI plane (or nq > 32)");
         }
         else st = score_rows(idx, q_dev, nq, ld, s);
     }

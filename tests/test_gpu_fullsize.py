@@ -133,11 +133,15 @@ def test_fullsize_maxsim_32x1m(corpus):
     tol = 2e-6 * scale
     scores = idx.maxsim_scores(Q)
     assert float((scores.double() - ref).abs().max()) <= tol
-    s, c = idx.maxsim_topk(Q, 100)
+    s, c = idx.maxsim_topk(Q, 100)  # one query: ranked from the HI plane, re-scored exactly over the rows (round 6)
+    assert idx.filter_stats()["kind"] == "maxsim_batch_hi" and not idx.filter_stats()["fallback"]
     _check_topk_against(torch, s, c, ref, 100, tol)
+    with idx.options(hi_few=0):  # the streaming kernel over the fp32 rows it replaces: the same chunks
+        s_rows, c_rows = idx.maxsim_topk(Q, 100)
+    assert set(c_rows.tolist()) == set(c.tolist())
     # top-k of OUR scores is exact (bitwise) with ties to the lowest chunk ordinal
     order = torch.sort(scores, descending=True, stable=True).indices[:100]
-    assert torch.equal(c.long(), order) and torch.equal(s, scores[order])
+    assert torch.equal(c_rows.long(), order) and torch.equal(s_rows, scores[order])
     # size-independent properties
     assert torch.equal(idx.maxsim_scores(2.0 * Q), 2.0 * scores)  # exact linearity in powers of two
     assert torch.equal(idx.maxsim_scores(Q), scores)  # deterministic
