@@ -200,7 +200,7 @@ struct Options {
         for (auto& x : v) x = 0;
         v[RL_OPT_HI_SEARCH] = v[RL_OPT_HI_MAXSIM] = v[RL_OPT_HI_PRODUCTS] = v[RL_OPT_PP_PASS] = v[RL_OPT_FUSED_TOPK] = v[RL_OPT_FUSED_HI] = 1;
         v[RL_OPT_FUSED_PP] = v[RL_OPT_GEMM_PASS] = v[RL_OPT_QUERY_PAIRS] = v[RL_OPT_PLANES_GEMM] = v[RL_OPT_KEEP_IMAGE] = v[RL_OPT_KEEP_HI] = 1;
-        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = v[RL_OPT_F16_EXACT] = v[RL_OPT_LAZY_IMAGES] = v[RL_OPT_FUSED_PP_SAMPLE] = v[RL_OPT_LIST_SELECT] = v[RL_OPT_HI_FEW] = 1;
+        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = v[RL_OPT_F16_EXACT] = v[RL_OPT_LAZY_IMAGES] = v[RL_OPT_FUSED_PP_SAMPLE] = v[RL_OPT_LIST_SELECT] = v[RL_OPT_HI_FEW] = v[RL_OPT_TOPK_BLOCK] = 1;
         v[RL_OPT_IMAGE_HEADROOM_MB] = -1;
         v[RL_OPT_ARITHMETIC] = RL_ARITH_AUTO;
     }
@@ -212,7 +212,7 @@ bool option_value_ok(int key, int64_t value) {
     switch (key) {
         case RL_OPT_HI_SEARCH: case RL_OPT_HI_MAXSIM: case RL_OPT_PP_PASS: case RL_OPT_FUSED_TOPK: case RL_OPT_FUSED_HI: case RL_OPT_FUSED_PP:
         case RL_OPT_GEMM_PASS: case RL_OPT_QUERY_PAIRS: case RL_OPT_PLANES_GEMM: case RL_OPT_KEEP_IMAGE: case RL_OPT_KEEP_HI:
-        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED: case RL_OPT_F16_EXACT: case RL_OPT_LAZY_IMAGES: case RL_OPT_FUSED_PP_SAMPLE: case RL_OPT_LIST_SELECT: case RL_OPT_HI_FEW:
+        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED: case RL_OPT_F16_EXACT: case RL_OPT_LAZY_IMAGES: case RL_OPT_FUSED_PP_SAMPLE: case RL_OPT_LIST_SELECT: case RL_OPT_HI_FEW: case RL_OPT_TOPK_BLOCK:
             return value == 0 || value == 1;
         case RL_OPT_HI_PRODUCTS: return value == 1 || value == 2;
         case RL_OPT_FUSED_TOPK_CAP: return value >= 0 && value <= MERGE_CAP;
@@ -324,6 +324,7 @@ namespace {
 int use_scratch(rl_index* idx, hipStream_t s) {
     ++idx->scratch_epoch;  // (staged calls check that nothing else used the scratch between their stages)
     idx->filt = {};        // its pointers go into scratch this call may re-reserve: whoever filters next records itself again
+    idx->ws.block_route = idx->opt.on(RL_OPT_TOPK_BLOCK);
     idx->replay.valid = false;  // likewise: a later search overwrites the queries / thresholds the record points at (rl_time_kernel restores it for itself)
     if (idx->last_stream_set && idx->last_stream != s) RL_HIP(hipStreamSynchronize(idx->last_stream));
     idx->last_stream = s;
@@ -2613,6 +2614,10 @@ int rl_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32
     RL_TRY(stage_out_begin(out_scores, n_out, mem, t_os, &d_os));
     RL_TRY(stage_out_begin(out_ids, n_out, mem, t_oi, &d_oi));
     SelectWorkspace ws;  // one-off workspace: this entry point is for tests / external scorers
+    {
+        std::lock_guard<std::mutex> lock(g_default_opts_mu);
+        ws.block_route = g_default_opts.on(RL_OPT_TOPK_BLOCK);
+    }
     int st = launch_topk(d_in, n_queries, n, ld, k, ws, d_os, d_oi, s);
     if (st == RL_OK) st = stage_out_end(out_scores, n_out, mem, s, t_os);
     if (st == RL_OK) st = stage_out_end(out_ids, n_out, mem, s, t_oi);

@@ -149,6 +149,7 @@ struct SelectWorkspace {      // device buffers sized for `capacity_queries`
     uint64_t* cand = nullptr; // [B][CAND_CAP]
     int32_t capacity_queries = 0;
     bool dirty = false;       // a launch sequence was cut short by an error: re-zero `hist` before the next use
+    bool block_route = true;  // RL_OPT_TOPK_BLOCK: selections of <= 256 k scores per query in ONE launch, one block per query (select.hip)
 };
 int select_workspace_reserve(SelectWorkspace& ws, int32_t n_queries, hipStream_t s);
 void select_workspace_free(SelectWorkspace& ws);

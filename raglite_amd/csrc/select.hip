@@ -498,6 +498,158 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restric
     topk_final_body(scores, n, ld, k, ws_hist, ws_sel, ws_cand, out_scores, out_ids, (int)blockIdx.x, L, em);
 }
 
+// ---- round 6: the whole selection of a query in ONE launch, one block per query ("block route") ------------------------------------------
+// hist -> filter -> final is three launches, a global histogram, two global candidate lists and a sort of the threshold bin (a MaxSim score of
+// ~700 falls into the bin [704, 768) with a few thousand others: 45 us of bitonic network per step of the headline pipeline, 113 us for the
+// three kernels; the sample of the fused row top-k pays 100 us per search for the same).  When a query's scores are few enough to be read
+// twice by ONE block out of L2 / the Infinity Cache -- n <= 256 k: MaxSim chunk scores, the fused top-k's sample, rerank lists -- the block does
+// it all by itself: (1) histogram of the key's top 11 bits in LDS (four lane-interleaved copies), threshold bin b*; (2) second read: keys
+// above b* go to the result list, the keys IN b* to an LDS buffer; (3) inside the buffer a second radix level (key bits 20..10) leaves a
+// handful of keys on the threshold value, which are ranked by counting; (4) the k survivors are ordered and written.  No workspace, no
+// global atomics, the same (score desc, id asc) order on the same unique 64-bit keys: bit-identical results.  More keys in b* than the buffer
+// holds, or more than 1024 on one 22-bit prefix (massive ties): refine_in_bin over the global scores, the exact slow path of the final kernel.
+constexpr int BLOCK_BUF = 8192;          // keys of the threshold bin kept in LDS
+constexpr int64_t BLOCK_ROUTE_MAX_N = 262144;
+struct BlockLds {
+    uint64_t buf[BLOCK_BUF];                      // 64 KiB: the threshold bin; later the sort buffer of the results
+    uint64_t fin[K_MAX];                          // 16 KiB
+    uint64_t tie[RANK_MAX];                       //  8 KiB: keys on the threshold sub-bin
+    uint32_t h[HIST_COPIES * HIST_COPY_STRIDE];   // 33 KiB
+    uint32_t scratch[20];
+    uint32_t thr[2];
+    uint32_t sh_cnt[4];
+};
+// position of this lane's element in a list that `pred` lanes of the wave append to (one LDS atomic per wave)
+__device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
+    const uint64_t mask = __builtin_amdgcn_ballot_w64(pred);
+    if (mask == 0ull) return 0u;
+    uint32_t base = 0u;
+    if ((threadIdx.x & 63) == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(counter, (uint32_t)__builtin_popcountll(mask));
+    base = __builtin_amdgcn_readlane(base, __builtin_ctzll(mask));
+    return base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+__global__ __launch_bounds__(1024) void topk_block_kernel(const float* __restrict__ scores, int64_t n, int64_t ld, int32_t k,
+                                                           float* __restrict__ out_scores, int32_t* __restrict__ out_ids) {
+    __shared__ BlockLds L;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int q = blockIdx.x;
+    const float* const s = scores + (int64_t)q * ld;
+    float* const os = out_scores + (int64_t)q * k;
+    int32_t* const oi = out_ids + (int64_t)q * k;
+    const uint32_t kk = (uint32_t)std::min<int64_t>(k, n);
+    if (kk == 0) { write_results(L.fin, 0, k, os, oi); return; }
+    const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0;
+    const int64_t n4 = vec ? n >> 2 : 0;
+    // (1) histogram of the top 11 key bits
+    hist_zero(L.h);
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < n4; i += 1024) {
+        const f4 v = reinterpret_cast<const f4*>(s)[i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) hist_add(L.h, v[u]);
+    }
+    for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 1024) hist_add(L.h, s[i]);
+    __syncthreads();
+    for (int i = threadIdx.x; i < HIST_BINS; i += 1024) {
+        uint32_t c = 0;
+#pragma unroll
+        for (int j = 0; j < HIST_COPIES; ++j) c += L.h[j * HIST_COPY_STRIDE + i];
+        L.h[i] = c;  // (copy 0 now holds the sums: bin i of copy 0 is read and written by this thread only)
+    }
+    if (threadIdx.x < 4) L.sh_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    find_threshold_bin(L.h, HIST_BINS, kk, L.scratch, L.thr);
+    const uint32_t bstar = L.thr[0];
+    // (2) keys above b* -> fin, keys in b* -> buf
+    auto visit = [&](float v, int64_t i, bool live) {
+        const uint32_t bin = score_key(v) >> 21;
+        const bool above = live && bin > bstar, in_bin = live && bin == bstar;
+        const uint32_t pa = wave_append(&L.sh_cnt[0], above);
+        if (above) L.fin[pa] = make_key64(v, (uint32_t)i);  // (fewer than kk <= K_MAX keys lie above b*)
+        const uint32_t pb = wave_append(&L.sh_cnt[1], in_bin);
+        if (in_bin && pb < (uint32_t)BLOCK_BUF) L.buf[pb] = make_key64(v, (uint32_t)i);
+    };
+    for (int64_t i0 = 0; i0 < n4; i0 += 1024) {  // (whole waves stay in the loop: wave_append is wave-wide)
+        const int64_t i = i0 + threadIdx.x;
+        const bool live = i < n4;
+        f4 v = (f4){0.f, 0.f, 0.f, 0.f};
+        if (live) v = reinterpret_cast<const f4*>(s)[i];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) visit(v[u], (i << 2) + u, live);
+    }
+    for (int64_t i0 = n4 << 2; i0 < n; i0 += 1024) {
+        const int64_t i = i0 + threadIdx.x;
+        visit(i < n ? s[i] : 0.f, i, i < n);
+    }
+    __syncthreads();
+    const uint32_t n_sel = L.sh_cnt[0], n_bin = L.sh_cnt[1];
+    const uint32_t need = kk - n_sel;  // >= 1: the threshold bin is never empty
+    __syncthreads();
+    if (n_bin <= (uint32_t)RANK_MAX) {
+        // a small bin: every thread ranks one key by counting the larger ones (all keys are distinct)
+        if (threadIdx.x < n_bin) {
+            const uint64_t mine = L.buf[threadIdx.x];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n_bin; ++j) rank += L.buf[j] > mine;
+            if (rank < need) L.fin[n_sel + rank] = mine;
+        }
+        __syncthreads();
+    } else if (n_bin <= (uint32_t)BLOCK_BUF) {
+        // (3) second radix level inside the buffer: key bits 20..10
+        for (int i = threadIdx.x; i < HIST_BINS; i += 1024) L.h[i] = 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n_bin; i += 1024) atomicAdd(&L.h[(uint32_t)(L.buf[i] >> 42) & 2047u], 1u);
+        __syncthreads();
+        find_threshold_bin(L.h, HIST_BINS, need, L.scratch, L.thr);
+        const uint32_t b1 = L.thr[0], above1 = L.thr[1];
+        const uint32_t n_tie = L.h[b1];
+        __syncthreads();
+        if (n_tie <= (uint32_t)RANK_MAX) {
+            for (uint32_t i0 = 0; i0 < n_bin; i0 += 1024) {
+                const uint32_t i = i0 + threadIdx.x;
+                const bool live = i < n_bin;
+                const uint64_t key = live ? L.buf[i] : 0ull;
+                const uint32_t sub = (uint32_t)(key >> 42) & 2047u;
+                const uint32_t pa = wave_append(&L.sh_cnt[2], live && sub > b1);
+                if (live && sub > b1) L.fin[n_sel + pa] = key;
+                const uint32_t pt = wave_append(&L.sh_cnt[3], live && sub == b1);
+                if (live && sub == b1) L.tie[pt] = key;
+            }
+            __syncthreads();
+            const uint32_t need1 = need - above1;  // of the n_tie keys on the threshold sub-bin
+            if (threadIdx.x < n_tie) {
+                const uint64_t mine = L.tie[threadIdx.x];
+                uint32_t rank = 0;
+                for (uint32_t j = 0; j < n_tie; ++j) rank += L.tie[j] > mine;
+                if (rank < need1) L.fin[n_sel + above1 + rank] = mine;
+            }
+            __syncthreads();
+        } else {
+            refine_in_bin(s, n, bstar, need, n_sel, L.fin, L.h, L.scratch, L.thr, L.sh_cnt);
+        }
+    } else {
+        refine_in_bin(s, n, bstar, need, n_sel, L.fin, L.h, L.scratch, L.thr, L.sh_cnt);
+    }
+    // (4) order the kk survivors (all distinct keys) and write them out
+    if (kk <= (uint32_t)RANK_MAX) {
+        if (threadIdx.x < kk) {
+            const uint64_t mine = L.fin[threadIdx.x];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < kk; ++j) rank += L.fin[j] > mine;
+            L.buf[rank] = mine;
+        }
+        __syncthreads();
+        write_results(L.buf, (int)kk, k, os, oi);
+        return;
+    }
+    int p2 = 64;
+    while (p2 < (int)kk) p2 <<= 1;
+    for (int i = threadIdx.x; i < p2; i += 1024) L.buf[i] = (i < (int)kk) ? L.fin[i] : 0ull;
+    __syncthreads();
+    bitonic_sort_desc(L.buf, p2);
+    write_results(L.buf, (int)kk, k, os, oi);
+}
+
 // ---- the guarded fallback of the half-bytes row search in ONE launch -------------------------------------------------------------------
 // Raw dots -> similarities (in place; transform_kernel's statements) and their exact top-k, by ONE block per query: histogram of the key's
 // top 11 bits in LDS, the keys above the threshold bin, then refine_in_bin for the bin itself.  ~1 ms per query over 1 M scores -- it runs
@@ -619,6 +771,12 @@ int launch_topk(const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t 
         if (nq > ws.capacity_queries || !ws.dirty) return fail(RL_ERR_INVALID, "top-k: no histogram in the workspace");
     } else {
         RL_TRY(select_workspace_reserve(ws, nq, s));
+    }
+    // The block route (round 6): a query whose scores one block can read twice out of L2 is selected by ONE launch that touches no workspace
+    if (!run_if && !have_hist && !emit && ws.block_route && n > 0 && n <= BLOCK_ROUTE_MAX_N) {
+        hipLaunchKernelGGL(topk_block_kernel, dim3(nq), dim3(1024), 0, s, scores, n, ld, k, out_scores, out_ids);
+        RL_HIP(hipGetLastError());
+        return RL_OK;
     }
     ws.dirty = true;
     // (Filter and final step as ONE launch by the last-block pattern measured slower at B = 1 over 1 M scores -- 0.628 / 0.679 ms per
