@@ -448,6 +448,8 @@ def main() -> None:
                 rl_block["pass_kernel_over_vendor_square"] = achieved / vg["square_8192_tflops"]
             rl_block["vendor_gemm_how"] = (f"torch.mm (hipBLASLt / rocBLAS) fp16 x fp16 -> fp16 (fp32 accumulate), {iters} launches each, HIP events, same run, same "
                                            f"pseudo-random data: [{rows_local} x {DIM}] . [{DIM} x {16 * NQ}] (one pass), . [{DIM} x {QUERIES_PER_STEP * NQ}] (a step), 8192^3")
+        elif rank == 0 and world == 1 and kind == 7:
+            rl_block["vendor_gemm_error"] = "skipped: --no-vendor-gemm"
     else:
         result["roofline"] = {"bound": "hbm", **hbm, "traffic": traffic}
     if kind in (5, 6, 7):  # for reference: the full-precision pass (eight queries) the approximate one replaces (and falls back to)
