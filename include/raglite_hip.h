@@ -203,8 +203,9 @@ int rl_index_arithmetic(rl_index* index, int* in_effect);
  *   RL_OPT_HI_MAXSIM            0 / 1 (1)          MaxSim batches rank on the HI image + exact re-scoring (else: full-precision passes)
  *   RL_OPT_HI_FEW               0 / 1 (1)          ... and ONE or TWO MaxSim queries (rl_maxsim_topk, batches of < 3) rank from the row-major HI plane
  *                                                  (2 B per element, HBM-bound) and re-score exactly (0: the streaming kernels over the fp32 rows)
- *   RL_OPT_TOPK_BLOCK           0 / 1 (1)          exact top-k of <= 262 144 scores per query (MaxSim chunk scores, the fused top-k's sample, rl_topk) in
- *                                                  ONE launch, one block per query (0: histogram / filter / final, three launches; same results)
+ *   RL_OPT_TOPK_BLOCK           0 / 1 / 2 (2)      exact top-k of <= 262 144 scores per query (MaxSim chunk scores, the fused top-k's sample, rl_topk) in
+ *                                                  ONE launch, one block per query (0: histogram / filter / final, three launches; same results);
+ *                                                  2: the block first cuts the scores to the ~k that reach the k-th largest of its 1024 thread maxima
  *   RL_OPT_HI_PRODUCTS          1 / 2 (1)          fp16 MFMA products per multiply in that approximate pass
  *   RL_OPT_PP_PASS              0 / 1 (1)          its sixteen-query kernel (maxsim_pp.hip; 0: the eight-query kernel)
  *   RL_OPT_FUSED_TOPK           0 / 1 (1)          B >= 96 row searches keep candidate lists instead of a score matrix

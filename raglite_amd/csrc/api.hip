@@ -200,7 +200,8 @@ struct Options {
         for (auto& x : v) x = 0;
         v[RL_OPT_HI_SEARCH] = v[RL_OPT_HI_MAXSIM] = v[RL_OPT_HI_PRODUCTS] = v[RL_OPT_PP_PASS] = v[RL_OPT_FUSED_TOPK] = v[RL_OPT_FUSED_HI] = 1;
         v[RL_OPT_FUSED_PP] = v[RL_OPT_GEMM_PASS] = v[RL_OPT_QUERY_PAIRS] = v[RL_OPT_PLANES_GEMM] = v[RL_OPT_KEEP_IMAGE] = v[RL_OPT_KEEP_HI] = 1;
-        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = v[RL_OPT_F16_EXACT] = v[RL_OPT_LAZY_IMAGES] = v[RL_OPT_FUSED_PP_SAMPLE] = v[RL_OPT_LIST_SELECT] = v[RL_OPT_HI_FEW] = v[RL_OPT_TOPK_BLOCK] = 1;
+        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = v[RL_OPT_F16_EXACT] = v[RL_OPT_LAZY_IMAGES] = v[RL_OPT_FUSED_PP_SAMPLE] = v[RL_OPT_LIST_SELECT] = v[RL_OPT_HI_FEW] = 1;
+        v[RL_OPT_TOPK_BLOCK] = 2;
         v[RL_OPT_IMAGE_HEADROOM_MB] = -1;
         v[RL_OPT_ARITHMETIC] = RL_ARITH_AUTO;
     }
@@ -212,8 +213,9 @@ bool option_value_ok(int key, int64_t value) {
     switch (key) {
         case RL_OPT_HI_SEARCH: case RL_OPT_HI_MAXSIM: case RL_OPT_PP_PASS: case RL_OPT_FUSED_TOPK: case RL_OPT_FUSED_HI: case RL_OPT_FUSED_PP:
         case RL_OPT_GEMM_PASS: case RL_OPT_QUERY_PAIRS: case RL_OPT_PLANES_GEMM: case RL_OPT_KEEP_IMAGE: case RL_OPT_KEEP_HI:
-        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED: case RL_OPT_F16_EXACT: case RL_OPT_LAZY_IMAGES: case RL_OPT_FUSED_PP_SAMPLE: case RL_OPT_LIST_SELECT: case RL_OPT_HI_FEW: case RL_OPT_TOPK_BLOCK:
+        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED: case RL_OPT_F16_EXACT: case RL_OPT_LAZY_IMAGES: case RL_OPT_FUSED_PP_SAMPLE: case RL_OPT_LIST_SELECT: case RL_OPT_HI_FEW:
             return value == 0 || value == 1;
+        case RL_OPT_TOPK_BLOCK: return value >= 0 && value <= 2;
         case RL_OPT_HI_PRODUCTS: return value == 1 || value == 2;
         case RL_OPT_FUSED_TOPK_CAP: return value >= 0 && value <= MERGE_CAP;
         case RL_OPT_FUSED_TOPK_STRIDE: return value == 0 || (value >= 2 && value <= (int64_t(1) << 20));
@@ -309,6 +311,7 @@ struct rl_index {
     // that finds the previous one fell back asks for the pre-split image, so that an index whose data keeps defeating the bound runs its
     // full-precision passes through the eight-query kernel instead of the streaming kernels (3-4 x faster) from the second batch on
     uint32_t* h_fell_back = nullptr;
+    uint32_t* d_fell_back = nullptr;  // the device's view of that word (written by guarded_select_kernel)
     // rl_time_kernel kind 8: what the candidate pass of the last fused-HI row search ran with (pointers into misc / fused / pp_work: valid
     // while those pools have not been re-reserved, which `pools` pins down)
     struct FusedReplay {
@@ -324,7 +327,7 @@ namespace {
 int use_scratch(rl_index* idx, hipStream_t s) {
     ++idx->scratch_epoch;  // (staged calls check that nothing else used the scratch between their stages)
     idx->filt = {};        // its pointers go into scratch this call may re-reserve: whoever filters next records itself again
-    idx->ws.block_route = idx->opt.on(RL_OPT_TOPK_BLOCK);
+    idx->ws.block_route = (int)idx->opt.v[RL_OPT_TOPK_BLOCK];
     idx->replay.valid = false;  // likewise: a later search overwrites the queries / thresholds the record points at (rl_time_kernel restores it for itself)
     if (idx->last_stream_set && idx->last_stream != s) RL_HIP(hipStreamSynchronize(idx->last_stream));
     idx->last_stream = s;
@@ -1442,7 +1445,7 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
     // ---- (4) guarded dense fallback -----------------------------------------------------------------------------------------------
     RL_TRY(launch_score_planes_pass(idx->planes.p, n, idx->dim, B, qs, sc, ld, idx->norm, idx->sumsq, mode, 1, flag, nullptr, idx->n_cu, s,
                                     img_scale, half));
-    RL_TRY(launch_topk(sc, B, n, ld, k, idx->ws, d_scores, d_rows, s, flag));
+    RL_TRY(launch_guarded_select(sc, B, n, ld, k, nullptr, nullptr, nullptr, 0, SCAN_RAW_DOT, 1.0f, d_scores, d_rows, flag, s));
     return RL_OK;
 }
 
@@ -1501,8 +1504,7 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
     const void* hi = idx->hi_image.p;
     const float sscale = idx->split_scale;
     // ---- (1) sample pass + its exact top-k ------------------------------------------------------------------------------------
-    RL_HIP(hipMemsetAsync(flag, 0, sizeof(uint32_t), s));
-    RL_TRY(launch_score_planes_queries(d_q, B, idx->dim, qs, mode, s));
+    RL_TRY(launch_score_planes_queries(d_q, B, idx->dim, qs, mode, s, flag));  // (also zeroes the flag)
     // (round 5: on the sixteen-group tile of maxsim_pp.hip, MODE 1 -- the eight-group kernel gives every workgroup ONE 256 x 256 tile and is
     // start-up bound there; RL_OPT_FUSED_PP_SAMPLE = 0 or shapes outside the tile: the eight-group kernel)
     int st_sample = RL_ERR_UNSUPPORTED;
@@ -1515,7 +1517,7 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
     RL_TRY(launch_topk(S_s, B, ld_s, ld_s, k, idx->ws, top_s, top_i, s));
     // ---- (2) thresholds lowered by the error band; candidate pass ---------------------------------------------------------------
     RL_TRY(launch_row_threshold(top_s, B, k, d_q, idx->dim, mode, hi_only ? q_unscale : nullptr, idx->max_lo_ratio, idx->max_lo_norm, idx->max_row_norm,
-                                thr, window, cnt, cnt2, flag, s));
+                                thr, window, cnt, cnt2, flag, s, thr1));  // (thr1: the first round's thresholds, kept for rl_time_kernel's replay)
     const CandArgs ca{thr, 1, c_s, c_i, cnt, flag, cap};
     idx->filt = {RL_FILTER_ROWS_FUSED_HI, B, cap, cnt, flag};
     // The candidate pass on the sixteen-group tile of maxsim_pp.hip (round 4: 128 rows x 512 queries per workgroup, every operand through
@@ -1538,7 +1540,6 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
         row_test = mode == SCAN_COSINE && !(idx->min_row_norm * 4.0f >= idx->max_row_norm);
         round1_tiles = (Tr >= 64 && idx->opt.on(RL_OPT_FUSED_TWO_ROUNDS)) ? (3 * Tr) / 16 : 0;  // (small corpora: one round)
         if (round1_tiles > 0) {
-            RL_HIP(hipMemcpyAsync(thr1, thr, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));  // (kept for rl_time_kernel's replay)
             st_pp = launch_pp_rows_pass(hi, n, idx->dim, B, qs, idx->norm, mode, &ca, idx->pp_work.p, log_cap, idx->n_cu, s, sscale, 0, round1_tiles, false,
                                         row_test);
             if (st_pp == RL_OK) {
@@ -1574,7 +1575,9 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
     // ---- (5) guarded dense fallback (full precision, over the pre-split image) ------------------------------------------------------
     RL_TRY(launch_score_planes_pass(idx->planes.p, n, idx->dim, B, qs, sc, ld, idx->norm, idx->sumsq, mode, 1, flag, nullptr, idx->n_cu, s,
                                     image_scale(idx), false));
-    RL_TRY(launch_topk(sc, B, n, ld, k, idx->ws, d_scores, d_rows, s, flag));
+    // (its selection in ONE guarded launch, a block per query: the three launches of the selection, each a grid of 64 x B workgroups that return
+    // at once behind the flag, were 36 us of every 1000-query batch)
+    RL_TRY(launch_guarded_select(sc, B, n, ld, k, nullptr, nullptr, nullptr, 0, SCAN_RAW_DOT, 1.0f, d_scores, d_rows, flag, s));
     return RL_OK;
 }
 
@@ -1996,7 +1999,9 @@ bool slim_batch_ok(const rl_index* idx, const float* d_q) {
     return !image_valid(idx) && !idx->E16 && idx->E && hi_image_valid(idx) && (d == 256 || d == 384 || d == 512 || d == 768 || d == 1024) &&
            !(reinterpret_cast<uintptr_t>(d_q) & 15) && !(reinterpret_cast<uintptr_t>(idx->E) & 15);
 }
-int gemm_prepare(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, int32_t n_queries, hipStream_t s, bool want_planes = false) {
+// zero_words: sixteen words the query-image kernel zeroes on its way (the batch's flag block: no memset launch)
+int gemm_prepare(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, int32_t n_queries, hipStream_t s, bool want_planes = false,
+                 uint32_t* zero_words = nullptr) {
     if (!idx->opt.on(RL_OPT_GEMM_PASS)) return RL_ERR_UNSUPPORTED;
     if (idx->has_empty_chunk || idx->n_chunks == 0 || nq < 1 || nq > 32 || n_queries < GEMM_PASS_MIN_QUERIES) return RL_ERR_UNSUPPORTED;
     // lazy images: the image the approximate pass multiplies; the pre-split image only where the batch cannot run on rows + HI image
@@ -2007,7 +2012,7 @@ int gemm_prepare(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, 
     if (want_planes || !hi_route || fell_back || (!image_valid(idx) && !slim_batch_ok(idx, d_q))) RL_TRY(demand_images(idx, IMG_PLANES, s));
     if (!(image_valid(idx) || slim_batch_ok(idx, d_q))) return RL_ERR_UNSUPPORTED;
     RL_TRY(idx->qplanes.reserve(query_planes_bytes(idx->dim, n_queries)));
-    return launch_query_planes(d_q, idx->dim, nq, q_stride, n_queries, idx->qplanes.p, s);
+    return launch_query_planes(d_q, idx->dim, nq, q_stride, n_queries, idx->qplanes.p, s, zero_words, zero_words ? 16 : 0);
 }
 int gemm_pass(rl_index* idx, int32_t nq, int32_t n_queries, int32_t first, int32_t n_q, float* d_out, int64_t out_stride, hipStream_t s) {
     return launch_maxsim_gemm(idx->planes.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, first, n_q, nq, idx->row_to_chunk,
@@ -2112,6 +2117,8 @@ struct HiBatch {
     float* ts; int32_t* ti; float* thr; uint32_t* cnt; uint32_t* flag; int32_t* ci; float* es;
     float* m; float* es_top;  // [n] the bound m_b of every query; [n x k] exact scores of the approximate top-k (second threshold)
     int32_t cap; bool one_product; float m_abs; const float* q_unscale;
+    const float* qsum = nullptr;  // [2 n] sum_i |q_i|, sum_i |q_lo,i| of every query where the query image carries them (launch_query_planes)
+    bool m_ready = true;          // hb.m holds the bounds (a threshold kernel ran); false: exact_threshold_kernel computes them from qsum
     bool exact_kth;           // second, tighter threshold from the exact scores of the approximate top-k (RL_OPT_EXACT_KTH_THRESHOLD)
 };
 // The scratch layout of a bound-filtered MaxSim batch of n queries (the same in every call that works on the batch)
@@ -2129,7 +2136,7 @@ void hi_batch_layout(rl_index* idx, int32_t n, int32_t k, HiBatch& hb) {
 }
 size_t hi_batch_words(int32_t n, int32_t k) { return (size_t)n * k * 3 + (size_t)n * 3 + 16 + (size_t)n * 2048 * 2; }
 int hi_batch_approx(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queries, int32_t n_gemm, int32_t k, float* sc, int64_t ld, HiBatch& hb,
-                    hipStream_t s) {
+                    hipStream_t s, bool flag_zeroed = false) {
     // ONE product per multiply -- q_hi.e_hi only, a plain fp16 GEMM -- with the bound widened by what the queries' hi halves drop,
     // (max|e| + max|e_lo|) sum_i |q_lo,i| (measured per query by the threshold kernel).  RL_OPT_HI_PRODUCTS = 2: two products.
     hb.one_product = idx->opt.v[RL_OPT_HI_PRODUCTS] == 1;
@@ -2141,8 +2148,10 @@ int hi_batch_approx(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queri
     // query's own 2^-22 split and twice the worst case of a 1024-term fp32 sum, 6e-5)
     hb.m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
     hb.q_unscale = reinterpret_cast<const float*>(idx->qplanes.as<char>() + (size_t)n_queries * idx->dim * 128);  // launch_query_planes' meta
-    RL_HIP(hipMemsetAsync(hb.flag, 0, 16 * sizeof(uint32_t), s));
-    RL_HIP(hipMemsetAsync(hb.ci, 0xff, (size_t)n_gemm * cap * sizeof(int32_t), s));  // unused slots: -1 = "no chunk"
+    hb.qsum = hb.q_unscale + 2 * (size_t)n_queries;                                                                 // ... and its sums
+    if (!flag_zeroed) RL_HIP(hipMemsetAsync(hb.flag, 0, 16 * sizeof(uint32_t), s));  // (else: the query-image kernel did, gemm_prepare)
+    // (the candidate lists' unused slots -- -1 = "no chunk" -- are filled where the lists are started: hi_batch_rescore)
+    (void)cap;
     // One product: SIXTEEN queries per pass through maxsim_pp.hip (dim >= 256; RL_OPT_PP_PASS = 0: the eight-query pass of
     // maxsim_gemm.hip instead -- A/B, and what two products still use).
     const bool pp = hb.one_product && idx->dim >= 256 && idx->opt.on(RL_OPT_PP_PASS);
@@ -2171,17 +2180,26 @@ int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_quer
     const bool rows16 = idx->E16 != nullptr;
     idx->filt = {RL_FILTER_MAXSIM_BATCH, n_gemm, hb.cap, hb.cnt, hb.flag};
     const bool packed = idx->opt.on(RL_OPT_PAIRS_PACKED);
+    const bool m_from_qsum = !hb.m_ready && hb.qsum != nullptr;
+    if (!hb.m_ready && !(hb.exact_kth && k <= hb.cap && hb.qsum)) return fail(RL_ERR_INVALID, "MaxSim batch: no bound for the candidate threshold");
     if (hb.exact_kth && k <= hb.cap) {
         // Second threshold (hi_filter.hip: exact_threshold_kernel): the approximate top-k is scored exactly FIRST; the k-th best of those
         // exact scores bounds the k-th best overall from below, so a candidate needs approx >= that - m instead of (k-th approx) - 2 m: about
         // half as many chunks beyond the top-k to re-score.  The approximate top-k becomes the head of the list; the collection appends only
         // what ranks below it, and only those entries are scored by the second launch.
         RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ti, k, n_gemm, hb.es_top, s, rows16, 0, 0, packed));
-        RL_TRY(launch_exact_threshold(hb.es_top, hb.ti, n_gemm, k, hb.m, hb.cap, hb.thr, hb.cnt, hb.ci, hb.es, hb.flag, s));
+        if (m_from_qsum)  // (also fills the lists' tails with -1)
+            RL_TRY(launch_exact_threshold(hb.es_top, hb.ti, n_gemm, k, hb.m, hb.cap, hb.thr, hb.cnt, hb.ci, hb.es, hb.flag, s, hb.qsum, hb.m_abs,
+                                          idx->max_row_norm + idx->max_lo_norm, hb.one_product));
+        else {
+            RL_HIP(hipMemsetAsync(hb.ci, 0xff, (size_t)n_gemm * hb.cap * sizeof(int32_t), s));  // unused slots: -1 = "no chunk"
+            RL_TRY(launch_exact_threshold(hb.es_top, hb.ti, n_gemm, k, hb.m, hb.cap, hb.thr, hb.cnt, hb.ci, hb.es, hb.flag, s));
+        }
         RL_TRY(launch_collect_above(sc, n_gemm, idx->n_chunks, ld, hb.thr, nullptr, hb.cap, hb.ci, nullptr, hb.cnt, hb.flag, s, hb.ts, hb.ti, k));
         if (hb.cap > k)
             RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap - k, n_gemm, hb.es, s, rows16, hb.cap, k, packed));
     } else {
+        RL_HIP(hipMemsetAsync(hb.ci, 0xff, (size_t)n_gemm * hb.cap * sizeof(int32_t), s));  // unused slots: -1 = "no chunk"
         RL_TRY(launch_collect_above(sc, n_gemm, idx->n_chunks, ld, hb.thr, nullptr, hb.cap, hb.ci, nullptr, hb.cnt, hb.flag, s));
         RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap, n_gemm, hb.es, s, rows16, 0, 0, packed));
     }
@@ -2206,14 +2224,26 @@ int hi_batch_fallback(rl_index* idx, const float* d_q, int32_t nq, int32_t n_que
     RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // (harmless on scores nobody reads)
     // (the exact top-k of the fallback's scores in ONE guarded launch, a block per query -- select.hip: guarded_select_kernel -- instead of the
     // selection's three: what usually returns at once is one launch shorter by two)
-    RL_TRY(launch_guarded_select(sc, n_gemm, idx->n_chunks, ld, k, nullptr, nullptr, nullptr, 0, SCAN_RAW_DOT, 1.0f, d_s, d_c, hb.flag, s));
+    uint32_t* host_word = nullptr;
     if (idx->opt.on(RL_OPT_LAZY_IMAGES) && !image_valid(idx) && !rows_only) {  // (lazy images: let the next batch know whether this one fell back)
         if (!idx->h_fell_back) {  // (no pinned word: no signal -- the fallback then stays on the streaming kernels, results unchanged)
-            if (hipHostMalloc(reinterpret_cast<void**>(&idx->h_fell_back), sizeof(uint32_t), hipHostMallocDefault) == hipSuccess) *idx->h_fell_back = 0u;
-            else { idx->h_fell_back = nullptr; (void)hipGetLastError(); }
+            if (hipHostMalloc(reinterpret_cast<void**>(&idx->h_fell_back), sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) {
+                *idx->h_fell_back = 0u;
+                if (hipHostGetDevicePointer(reinterpret_cast<void**>(&idx->d_fell_back), idx->h_fell_back, 0) != hipSuccess) {
+                    idx->d_fell_back = nullptr;
+                    (void)hipGetLastError();
+                }
+            } else { idx->h_fell_back = nullptr; (void)hipGetLastError(); }
         }
-        if (idx->h_fell_back) RL_HIP(hipMemcpyAsync(idx->h_fell_back, hb.flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        if (idx->h_fell_back) host_word = idx->d_fell_back;
+        // (no device view of the pinned word: a 4-byte copy behind the selection, as before round 6)
+        if (idx->h_fell_back && !host_word) {
+            RL_TRY(launch_guarded_select(sc, n_gemm, idx->n_chunks, ld, k, nullptr, nullptr, nullptr, 0, SCAN_RAW_DOT, 1.0f, d_s, d_c, hb.flag, s));
+            RL_HIP(hipMemcpyAsync(idx->h_fell_back, hb.flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            return RL_OK;
+        }
     }
+    RL_TRY(launch_guarded_select(sc, n_gemm, idx->n_chunks, ld, k, nullptr, nullptr, nullptr, 0, SCAN_RAW_DOT, 1.0f, d_s, d_c, hb.flag, s, host_word));
     return RL_OK;
 }
 
@@ -2258,7 +2288,6 @@ int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, 
     hb.m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
     hb.q_unscale = nullptr;
     RL_HIP(hipMemsetAsync(hb.flag, 0, 16 * sizeof(uint32_t), s));
-    RL_HIP(hipMemsetAsync(hb.ci, 0xff, (size_t)n * hb.cap * sizeof(int32_t), s));
     RL_TRY(mask_chunk_scores(idx, sc, n, ld, nullptr, s));  // tombstones never become candidates
     RL_TRY(launch_topk(sc, n, idx->n_chunks, ld, k, idx->ws, hb.ts, hb.ti, s));
     RL_TRY(launch_maxsim_threshold(hb.ts, n, k, d_q, nq, idx->dim, q_elems, 1.0f, hb.m_abs, hb.thr, hb.cnt, hb.flag, s, nullptr,
@@ -2310,12 +2339,21 @@ static int maxsim_topk_batch_any(rl_index* idx, const void* query_vecs, bool q16
     int32_t base = 0;
     bool hi_done = false;  // queries [0, base) were ranked by the half-bytes pipeline below (results already in d_s / d_c)
     {
-        const int st = gemm_prepare(idx, d_q, nq, (int64_t)q_elems, n_queries, s, k > 512);
+        const int32_t n_gemm = n_queries - base >= GEMM_PASS_MIN_QUERIES
+                                   ? (n_queries / GEMM_PASS_QUERIES) * GEMM_PASS_QUERIES +
+                                         ((n_queries % GEMM_PASS_QUERIES) >= GEMM_PASS_MIN_QUERIES ? n_queries % GEMM_PASS_QUERIES : 0)
+                                   : 0;
+        // (the flag block of the bound-filtered pipeline lies in a pool sized by n_gemm and k alone: reserved here so that the query-image
+        // kernel can zero it on its way -- one memset launch less per batch)
+        uint32_t* flag_words = nullptr;
+        if (n_gemm > 0 && k <= 512) {
+            RL_TRY(idx->hibuf.reserve(hi_batch_words(n_gemm, k) * 4));
+            HiBatch pre;
+            hi_batch_layout(idx, n_gemm, k, pre);
+            flag_words = pre.flag;
+        }
+        const int st = gemm_prepare(idx, d_q, nq, (int64_t)q_elems, n_queries, s, k > 512, flag_words);
         if (st == RL_OK) {
-            const int32_t n_gemm = n_queries - base >= GEMM_PASS_MIN_QUERIES
-                                       ? (n_queries / GEMM_PASS_QUERIES) * GEMM_PASS_QUERIES +
-                                             ((n_queries % GEMM_PASS_QUERIES) >= GEMM_PASS_MIN_QUERIES ? n_queries % GEMM_PASS_QUERIES : 0)
-                                       : 0;
             const bool hi_off = !idx->opt.on(RL_OPT_HI_MAXSIM);
             const bool two_products = idx->opt.v[RL_OPT_HI_PRODUCTS] == 2;  // (over an fp16-stored corpus two products ARE the full precision)
             const bool pp_route = idx->opt.v[RL_OPT_HI_PRODUCTS] == 1 && idx->dim >= 256 && idx->opt.on(RL_OPT_PP_PASS);
@@ -2334,7 +2372,7 @@ static int maxsim_topk_batch_any(rl_index* idx, const void* query_vecs, bool q16
                 // same argument (bit-identical on the benchmark shape, profiles/r02_u_probe.txt), the pass 1.01 -> 0.71 ms, 418 instead of
                 // 307 candidates per query, the 128-query step 17.1 -> 12.8 ms.  RL_OPT_HI_PRODUCTS = 2: two products.
                 HiBatch hb;
-                RL_TRY(hi_batch_approx(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, s));
+                RL_TRY(hi_batch_approx(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, s, flag_words != nullptr));
                 // (an fp32-STORED corpus whose every element is an fp16 value at the split scale -- what its HI halves drop was measured as
                 // exactly zero when the image was built -- is the same case: RAGLite's embeddings handed over as float32 arrays)
                 if (q16 && (idx->E16 || idx->max_lo_norm == 0.f) && hb.one_product && idx->opt.on(RL_OPT_F16_EXACT)) {
@@ -2344,8 +2382,11 @@ static int maxsim_topk_batch_any(rl_index* idx, const void* query_vecs, bool q16
                     RL_TRY(hi_batch_fallback(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, d_s, d_c, s));
                     idx->filt = {RL_FILTER_MAXSIM_F16_EXACT, n_gemm, hb.cap, hb.cnt, hb.flag};
                 } else {
-                    RL_TRY(launch_maxsim_threshold(hb.ts, n_gemm, k, d_q, nq, idx->dim, (int64_t)q_elems, 1.0f, hb.m_abs, hb.thr, hb.cnt, hb.flag, s,
-                                                   hb.one_product ? hb.q_unscale : nullptr, idx->max_row_norm + idx->max_lo_norm, hb.m));
+                    // (the second threshold needs the bound m_b only: exact_threshold_kernel takes it from the sums the query-image kernel left
+                    // -- no threshold kernel that reads the queries again: 10 us of every 128-query step)
+                    if (hb.exact_kth && k <= hb.cap && hb.qsum) hb.m_ready = false;
+                    else RL_TRY(launch_maxsim_threshold(hb.ts, n_gemm, k, d_q, nq, idx->dim, (int64_t)q_elems, 1.0f, hb.m_abs, hb.thr, hb.cnt, hb.flag, s,
+                                                        hb.one_product ? hb.q_unscale : nullptr, idx->max_row_norm + idx->max_lo_norm, hb.m));
                     RL_TRY(hi_batch_rescore(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, d_s, d_c, s));
                 }
                 base = n_gemm;
@@ -2616,7 +2657,7 @@ int rl_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32
     SelectWorkspace ws;  // one-off workspace: this entry point is for tests / external scorers
     {
         std::lock_guard<std::mutex> lock(g_default_opts_mu);
-        ws.block_route = g_default_opts.on(RL_OPT_TOPK_BLOCK);
+        ws.block_route = (int)g_default_opts.v[RL_OPT_TOPK_BLOCK];
     }
     int st = launch_topk(d_in, n_queries, n, ld, k, ws, d_os, d_oi, s);
     if (st == RL_OK) st = stage_out_end(out_scores, n_out, mem, s, t_os);

@@ -149,7 +149,7 @@ struct SelectWorkspace {      // device buffers sized for `capacity_queries`
     uint64_t* cand = nullptr; // [B][CAND_CAP]
     int32_t capacity_queries = 0;
     bool dirty = false;       // a launch sequence was cut short by an error: re-zero `hist` before the next use
-    bool block_route = true;  // RL_OPT_TOPK_BLOCK: selections of <= 256 k scores per query in ONE launch, one block per query (select.hip)
+    int block_route = 2;      // RL_OPT_TOPK_BLOCK: selections of <= 256 k scores per query in ONE launch, one block per query (select.hip); 2: with the thread-maximum prefilter
 };
 int select_workspace_reserve(SelectWorkspace& ws, int32_t n_queries, hipStream_t s);
 void select_workspace_free(SelectWorkspace& ws);
@@ -173,7 +173,7 @@ int launch_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, i
 // Transform + exact top-k of raw dots in ONE guarded launch, one block per query (slow: the fallback of the half-bytes row search)
 int launch_guarded_select(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t k, const float* row_norm, const float* row_sumsq,
                           const float* queries, int32_t dim, int mode, float pre_scale, float* out_scores, int32_t* out_ids,
-                          const uint32_t* run_if, hipStream_t s);
+                          const uint32_t* run_if, hipStream_t s, uint32_t* host_flag = nullptr);
 // launch_transform (scan.hip) + the selection's histogram pass in ONE launch: raw dots -> similarities in place, and their
 // 2048-bin key histogram into ws.hist (same statements as transform_kernel: same bits).  Follow with launch_topk(have_hist).
 // pre_scale: the raw dots are multiplied by it first (a power of two: exact; 1 = the plain transform); run_if as in launch_topk.
@@ -231,8 +231,9 @@ int launch_widen_f16(const uint16_t* src, float* dst, int64_t count, hipStream_t
 int launch_f16_exact_finish(const float* Q, int32_t nq, int32_t dim, int64_t q_stride, const float* q_unscale, const float* top_s,
                             const int32_t* top_i, int32_t n_queries, int32_t k, float* out_s, int32_t* out_i, uint32_t* cnt, uint32_t* flag,
                             hipStream_t s);
-int launch_exact_threshold(const float* exact, const int32_t* top_i, int32_t n_queries, int32_t k, const float* m, int32_t cap, float* thr,
-                           uint32_t* cnt, int32_t* ids, float* es, uint32_t* flag, hipStream_t s);
+int launch_exact_threshold(const float* exact, const int32_t* top_i, int32_t n_queries, int32_t k, float* m, int32_t cap, float* thr,
+                           uint32_t* cnt, int32_t* ids, float* es, uint32_t* flag, hipStream_t s, const float* qsum = nullptr, float m_abs = 0.f,
+                           float e_norm_max = 0.f, bool with_lo = false);
 // MaxSim flavour of the threshold: thr[b] = topk[b * k + k - 1] - 2 * m_rel * e_max * sum_i |q_i|; zeroes cnt[b]; sets *flag when
 // the k-th score is unusable.  One block per query.
 // q_unscale != nullptr (one-product pass: only the queries' fp16 hi halves were multiplied): q_unscale[2 * b] = 2^(ex - 14) of
@@ -253,7 +254,8 @@ int launch_max_row_norm16(const uint16_t* E, int64_t n_rows, int32_t dim, uint32
 int launch_diag_blocks(const float* src, int64_t ld, int32_t k2, int64_t count, float* dst, hipStream_t s);
 // Batched half-bytes search (experimental, api.hip: search_rows_fused_hi) -- see the kernels' comments in hi_filter.hip / select.hip
 int launch_row_threshold(const float* topk, int32_t nb, int32_t k, const float* Q, int32_t dim, int mode, const float* q_unscale, float lo_ratio,
-                         float lo_norm, float e_norm, float* thr, float* window, uint32_t* cnt, uint32_t* cnt2, uint32_t* flag, hipStream_t s);
+                         float lo_norm, float e_norm, float* thr, float* window, uint32_t* cnt, uint32_t* cnt2, uint32_t* flag, hipStream_t s,
+                         float* thr_copy = nullptr);
 int launch_row_dots(const float* E, int32_t dim, const float* Q, int32_t nb, const int32_t* rows, const uint32_t* cnt, int32_t cap, int mode,
                     const float* row_norm, const float* q_sumsq, float* out, hipStream_t s);
 int launch_list_prefix(const float* in_scores, const int32_t* in_ids, int32_t nq, int32_t k_in, int32_t k, const uint32_t* counts,
@@ -330,7 +332,8 @@ int launch_presplit_hi_rows(const float* E, int64_t first_row, int64_t n_rows, i
 size_t chunk_ends_words(int64_t rows);
 int launch_chunk_ends(const int32_t* row_to_chunk, int64_t n_rows, uint32_t* ends, hipStream_t s);
 size_t query_planes_bytes(int32_t dim, int32_t n_queries);
-int launch_query_planes(const float* Q, int32_t dim, int32_t nq, int64_t q_stride, int32_t n_queries, void* buf, hipStream_t s);
+int launch_query_planes(const float* Q, int32_t dim, int32_t nq, int64_t q_stride, int32_t n_queries, void* buf, hipStream_t s,
+                        uint32_t* zero_words = nullptr, int n_zero = 0);
 int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const void* qbuf, int32_t n_queries, int32_t first,
                        int32_t n_q, int32_t nq, const int32_t* row_to_chunk, const int64_t* chunk_offsets, const uint32_t* ends_bits,
                        float* out, int64_t out_stride, int n_cu, hipStream_t s, float split_scale, bool half = false,
@@ -349,7 +352,7 @@ int launch_score_planes(const void* planes, int64_t n_rows, int32_t dim, const f
                         const float* row_norm, const float* row_sumsq, float* scratch, int mode, int n_cu, hipStream_t s, float split_scale,
                         bool half = false);
 struct CandArgs { const float* tau; int32_t tau_stride; float* scores; int32_t* ids; uint32_t* cnt; uint32_t* overflow; int32_t cap; };
-int launch_score_planes_queries(const float* Q, int32_t nb, int32_t dim, float* scratch, int mode, hipStream_t s);
+int launch_score_planes_queries(const float* Q, int32_t nb, int32_t dim, float* scratch, int mode, hipStream_t s, uint32_t* zero_word = nullptr);
 size_t pp_rows_scratch_bytes(int64_t n_rows, int32_t nb, int n_cu, int32_t expected_per_query, int32_t* log_cap_out);
 // row tiles (of 128 rows) [tile_begin, tile_begin + tile_count) only (tile_count < 0: to the end); norms_ready: the block norm ranges in
 // `work` are those of an earlier launch of the same search

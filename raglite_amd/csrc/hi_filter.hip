@@ -203,10 +203,14 @@ __global__ __launch_bounds__(256) void maxsim_threshold_kernel(const float* __re
 // approx - m >= k-th approximate - m).  The approximate top-k itself passes (approx >= exact - m >= L - m): it becomes the head of the
 // candidate list -- ids[b][0 .. k), es[b][0 .. k), cnt[b] = k -- and collect_above_kernel appends only what ranks below it.
 // Fewer than k scorable chunks (an id < 0, a NaN): *flag, nothing collected (thr = +inf): the guarded full-precision path answers.
+// qsum != nullptr (a batch whose query image carries the sums, maxsim_gemm.hip: query_planes_kernel): m_b is computed HERE -- m_abs sum_i |q_i|
+// (+ e_norm_max sum_i |q_lo,i| for the one-product pass, the statement of maxsim_threshold_kernel) -- and left in m[b]; no threshold kernel
+// ran before.  The slots k .. cap - 1 of the list are set to -1 ("no chunk"): no memset launch in front of the collection.
 __global__ __launch_bounds__(256) void exact_threshold_kernel(const float* __restrict__ exact, const int32_t* __restrict__ top_i, int32_t k,
-                                                               const float* __restrict__ m, int32_t cap, float* __restrict__ thr,
+                                                               float* __restrict__ m, int32_t cap, float* __restrict__ thr,
                                                                uint32_t* __restrict__ cnt, int32_t* __restrict__ ids, float* __restrict__ es,
-                                                               uint32_t* __restrict__ flag) {
+                                                               uint32_t* __restrict__ flag, const float* __restrict__ qsum, float m_abs,
+                                                               float e_norm_max, int with_lo) {
     __shared__ float part[4];
     __shared__ int bad_sh;
     const int b = blockIdx.x;
@@ -222,13 +226,22 @@ __global__ __launch_bounds__(256) void exact_threshold_kernel(const float* __res
         ids[(int64_t)b * cap + j] = c;
         es[(int64_t)b * cap + j] = v;
     }
+    if (qsum)
+        for (int j = k + threadIdx.x; j < cap; j += 256) ids[(int64_t)b * cap + j] = -1;
     if (bad) bad_sh = 1;  // (benign race: every writer stores 1)
     mn = -wave_max(-mn);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mn;
     __syncthreads();
     if (threadIdx.x != 0) return;
     const float L = fminf(fminf(part[0], part[1]), fminf(part[2], part[3]));
-    const float mb = m[b];
+    float mb;
+    if (qsum) {
+        mb = m_abs * qsum[2 * b];
+        if (with_lo) mb += e_norm_max * qsum[2 * b + 1] * 1.00001f;
+        m[b] = mb;
+    } else {
+        mb = m[b];
+    }
     float t = L - mb * 1.00001f;
     t -= fabsf(t) * 0x1p-22f;  // (the subtraction's own rounding)
     const bool unusable = bad_sh != 0 || k > cap || !(t > -INFINITY) || !(mb >= 0.f);
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(256) void exact_threshold_kernel(const float* __res
 __global__ __launch_bounds__(256) void row_threshold_kernel(const float* __restrict__ topk, int32_t k, const float* __restrict__ Q, int dim, int mode,
                                                              const float* __restrict__ q_unscale, float lo_ratio, float lo_norm, float e_norm,
                                                              float* __restrict__ thr, float* __restrict__ window, uint32_t* __restrict__ cnt,
-                                                             uint32_t* __restrict__ cnt2, uint32_t* __restrict__ flag) {
+                                                             uint32_t* __restrict__ cnt2, uint32_t* __restrict__ flag, float* __restrict__ thr_copy) {
     __shared__ float part[4], part_lo[4];
     const int b = blockIdx.x;
     const float* q = Q + (int64_t)b * dim;
@@ -272,6 +285,7 @@ __global__ __launch_bounds__(256) void row_threshold_kernel(const float* __restr
     const float w = 2.0f * m * 1.00001f;
     const float t = topk[(int64_t)b * k + (k - 1)] - w;
     thr[b] = t;
+    if (thr_copy) thr_copy[b] = t;
     window[b] = w;
     cnt[b] = 0u;
     cnt2[b] = 0u;
@@ -551,19 +565,22 @@ int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, con
     return RL_OK;
 }
 
-int launch_exact_threshold(const float* exact, const int32_t* top_i, int32_t n_queries, int32_t k, const float* m, int32_t cap, float* thr,
-                           uint32_t* cnt, int32_t* ids, float* es, uint32_t* flag, hipStream_t s) {
+int launch_exact_threshold(const float* exact, const int32_t* top_i, int32_t n_queries, int32_t k, float* m, int32_t cap, float* thr,
+                           uint32_t* cnt, int32_t* ids, float* es, uint32_t* flag, hipStream_t s, const float* qsum, float m_abs, float e_norm_max,
+                           bool with_lo) {
     if (n_queries <= 0) return RL_OK;
-    hipLaunchKernelGGL(exact_threshold_kernel, dim3(n_queries), dim3(256), 0, s, exact, top_i, k, m, cap, thr, cnt, ids, es, flag);
+    hipLaunchKernelGGL(exact_threshold_kernel, dim3(n_queries), dim3(256), 0, s, exact, top_i, k, m, cap, thr, cnt, ids, es, flag, qsum, m_abs,
+                       e_norm_max, with_lo ? 1 : 0);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
 
 int launch_row_threshold(const float* topk, int32_t nb, int32_t k, const float* Q, int32_t dim, int mode, const float* q_unscale, float lo_ratio,
-                         float lo_norm, float e_norm, float* thr, float* window, uint32_t* cnt, uint32_t* cnt2, uint32_t* flag, hipStream_t s) {
+                         float lo_norm, float e_norm, float* thr, float* window, uint32_t* cnt, uint32_t* cnt2, uint32_t* flag, hipStream_t s,
+                         float* thr_copy) {
     if (nb <= 0) return RL_OK;
     hipLaunchKernelGGL(row_threshold_kernel, dim3(nb), dim3(256), 0, s, topk, k, Q, (int)dim, mode, q_unscale, lo_ratio, lo_norm, e_norm, thr, window,
-                       cnt, cnt2, flag);
+                       cnt, cnt2, flag, thr_copy);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

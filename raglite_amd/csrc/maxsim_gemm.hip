@@ -203,15 +203,22 @@ int launch_chunk_ends(const int32_t* row_to_chunk, int64_t n_rows, uint32_t* end
 //   frag[((query * nslab + s) * 4 + 2 * qb + part) * 64 + lane]   16 B = 8 halves, part 0 = hi, 1 = lo;
 //   lane (j = lane & 15, kq = lane >> 4) holds k = 32 s + 8 kq .. + 7 of query vector 16 qb + j (zeros past nq)
 //   meta[2 * query + {0, 1}] = {2^(ex - 14) (undoes the scale), any lo != 0}
-__global__ __launch_bounds__(256) void query_planes_kernel(const float* __restrict__ Q, int nq, int dim, int64_t q_stride,
-                                                            uint4* __restrict__ frag, float* __restrict__ meta) {
-    __shared__ float part[4];
+//   qsum[2 * query + {0, 1}] = {sum_i |q_i|, sum_i |q_lo,i|} with q_lo = q - fp16(q * scale) / scale: what the error bound of the one-product
+//   pass is made of (hi_filter.hip: maxsim_threshold_kernel's statements, a wave per query vector -- the same bits) -- the batch pipeline
+//   then needs no threshold kernel that reads the queries a third time
+//   zero_words[0 .. n_zero): zeroed by query 0's block (the batch's flag words: no memset launch)
+__global__ __launch_bounds__(1024) void query_planes_kernel(const float* __restrict__ Q, int nq, int dim, int64_t q_stride,
+                                                            uint4* __restrict__ frag, float* __restrict__ meta, float* __restrict__ qsum,
+                                                            uint32_t* __restrict__ zero_words, int n_zero) {
+    __shared__ float part[16];  // (1024 threads: with 256 the two walks over the query were 26 us of latency per 128-query step)
+    __shared__ float part_n[16], part_lo[16];
     __shared__ int any_lo_sh;
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_zero) zero_words[threadIdx.x] = 0u;
     const int64_t query = blockIdx.x;
     const float* const Qg = Q + query * q_stride;
     const int nslab = dim >> 5;
     float mx = 0.f;
-    for (int i = threadIdx.x * 4; i < nq * dim; i += 1024) {
+    for (int i = threadIdx.x * 4; i < nq * dim; i += 4096) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(Qg + i);
         mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
     }
@@ -220,14 +227,16 @@ __global__ __launch_bounds__(256) void query_planes_kernel(const float* __restri
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mx;
     if (threadIdx.x == 0) any_lo_sh = 0;
     __syncthreads();
-    mx = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+    mx = part[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, part[i]);
     int ex = 0;
     if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &ex);  // mx = f * 2^ex, f in [0.5, 1)
     ex = ex > -100 ? ex : -100;
     const float q_scale = ldexpf(1.f, 14 - ex);
     bool any_lo = false;
     uint4* const out = frag + query * nslab * 4 * 64;
-    for (int t = threadIdx.x; t < nslab * 2 * 64; t += 256) {
+    for (int t = threadIdx.x; t < nslab * 2 * 64; t += 1024) {
         const int lane = t & 63, qb = (t >> 6) & 1, s = t >> 7;
         const int qi = 16 * qb + (lane & 15), kq = lane >> 4;
         h16x8 hi8, lo8;
@@ -253,21 +262,55 @@ __global__ __launch_bounds__(256) void query_planes_kernel(const float* __restri
         out[(s * 4 + 2 * qb + 1) * 64 + lane] = b;
     }
     if (any_lo) any_lo_sh = 1;  // benign race: every writer stores 1
+    // sum_i |q_i| and sum_i |q_lo,i|: wave w takes the vectors w, w + 16 (maxsim_threshold_kernel: lane l sums the elements 4 (l + 64 j) .. + 3)
+    {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const float inv_scale = ldexpf(1.f, ex - 14);
+        float w_norms = 0.f, w_lo = 0.f;
+        const bool vec = (dim & 3) == 0;  // (dim % 32 == 0 here; Q and q_stride are 16-byte aligned: launch_query_planes)
+        for (int i = wv; i < nq; i += 16) {
+            float ss = 0.f, sl = 0.f;
+            auto add = [&](float v) {
+                ss = fmaf(v, v, ss);
+                const float x = v * q_scale;
+                const float lo = x - (float)(_Float16)x;
+                sl = fmaf(lo, lo, sl);
+            };
+            if (vec) {
+                const f32x4* row = reinterpret_cast<const f32x4*>(Qg + (int64_t)i * dim);
+                for (int c = lane; c < (dim >> 2); c += 64) {
+                    const f32x4 a = row[c];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) add(a[u]);
+                }
+            }
+            w_norms += sqrtf(wave_sum(ss));
+            w_lo += sqrtf(wave_sum(sl)) * inv_scale;
+        }
+        if (lane == 0) { part_n[wv] = w_norms; part_lo[wv] = w_lo; }
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         meta[2 * query + 0] = ldexpf(1.f, ex - 14);
         meta[2 * query + 1] = any_lo_sh ? 1.f : 0.f;
+        float sn = 0.f, sl = 0.f;
+        for (int i = 0; i < 16; ++i) { sn += part_n[i]; sl += part_lo[i]; }
+        qsum[2 * query + 0] = sn;
+        qsum[2 * query + 1] = sl;
     }
 }
 
-size_t query_planes_bytes(int32_t dim, int32_t n_queries) { return (size_t)n_queries * ((size_t)dim * 128 + 8) + 64; }
+size_t query_planes_bytes(int32_t dim, int32_t n_queries) { return (size_t)n_queries * ((size_t)dim * 128 + 16) + 64; }
 
-int launch_query_planes(const float* Q, int32_t dim, int32_t nq, int64_t q_stride, int32_t n_queries, void* buf, hipStream_t s) {
+int launch_query_planes(const float* Q, int32_t dim, int32_t nq, int64_t q_stride, int32_t n_queries, void* buf, hipStream_t s, uint32_t* zero_words,
+                        int n_zero) {
+    if (n_zero < 0 || n_zero > 1024 || (n_zero > 0 && !zero_words)) return RL_ERR_INVALID;
     if (nq < 1 || nq > 32 || n_queries < 1 || dim % 32 || dim < 32) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
     uint4* frag = static_cast<uint4*>(buf);
     float* meta = reinterpret_cast<float*>(static_cast<char*>(buf) + (size_t)n_queries * dim * 128);
-    hipLaunchKernelGGL(query_planes_kernel, dim3((unsigned)n_queries), dim3(256), 0, s, Q, (int)nq, (int)dim, q_stride, frag, meta);
+    float* qsum = meta + 2 * (size_t)n_queries;  // (query_planes_qsum)
+    hipLaunchKernelGGL(query_planes_kernel, dim3((unsigned)n_queries), dim3(1024), 0, s, Q, (int)nq, (int)dim, q_stride, frag, meta, qsum, zero_words, n_zero);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -982,22 +1025,26 @@ int launch_maxsim_gemm(const void* planes, int64_t n_rows, int32_t dim, const vo
 // ---- MODE 1: many independent queries (a6 batched, BASELINE cfg 5) -------------------------------------------------------
 // Query image: groups of 32 queries in the fragment layout of query_planes_kernel, but every query scaled by a power of two
 // of its OWN (a batch may span many orders of magnitude): unscale[q] = 2^(ex_q - 14), anylo[group].
-__global__ __launch_bounds__(256) void query_rows_planes_kernel(const float* __restrict__ Q, int B, int dim, uint4* __restrict__ frag,
-                                                                 float* __restrict__ unscale, float* __restrict__ anylo) {
+__global__ __launch_bounds__(1024) void query_rows_planes_kernel(const float* __restrict__ Q, int B, int dim, uint4* __restrict__ frag,
+                                                                  float* __restrict__ unscale, float* __restrict__ anylo, uint32_t* __restrict__ zero_word) {
     __shared__ float scale_sh[32];
     __shared__ int any_lo_sh;
     const int grp = blockIdx.x, nslab = dim >> 5;
-    const int v = threadIdx.x >> 3, sub = threadIdx.x & 7;  // 8 threads per query for the magnitude
+    if (zero_word && blockIdx.x == 0 && threadIdx.x == 0) *zero_word = 0u;  // (the search's overflow flag: no memset launch in front of the batch)
+    const int v = threadIdx.x >> 5, sub = threadIdx.x & 31;  // 32 threads per query for the magnitude (a group of 32 queries per block: B / 32 blocks
+                                                             // of 256 threads were 24 us of latency per 1000-query batch)
     const int q = grp * 32 + v;
     float mx = 0.f;
     if (q < B)
-        for (int c = 4 * sub; c < dim; c += 32) {
+        for (int c = 4 * sub; c < dim; c += 128) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(Q + (int64_t)q * dim + c);
             mx = fmaxf(mx, fmaxf(fmaxf(fabsf(x[0]), fabsf(x[1])), fmaxf(fabsf(x[2]), fabsf(x[3]))));
         }
     mx = fmaxf(mx, __shfl_xor(mx, 1));
     mx = fmaxf(mx, __shfl_xor(mx, 2));
     mx = fmaxf(mx, __shfl_xor(mx, 4));
+    mx = fmaxf(mx, __shfl_xor(mx, 8));
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
     int ex = 0;
     if (mx > 0.f && mx < INFINITY) (void)frexpf(mx, &ex);
     ex = ex > -100 ? ex : -100;
@@ -1009,7 +1056,7 @@ __global__ __launch_bounds__(256) void query_rows_planes_kernel(const float* __r
     __syncthreads();
     bool any_lo = false;
     uint4* const out = frag + (int64_t)grp * nslab * 4 * 64;
-    for (int t = threadIdx.x; t < nslab * 2 * 64; t += 256) {
+    for (int t = threadIdx.x; t < nslab * 2 * 64; t += 1024) {
         const int lane = t & 63, qb = (t >> 6) & 1, s = t >> 7;
         const int vi = 16 * qb + (lane & 15), kq = lane >> 4;
         const int qi = grp * 32 + vi;
@@ -1051,7 +1098,7 @@ int launch_query_sumsq(const float* Q, int32_t nb, int32_t dim, float* out, hipS
 
 // Query side of the row-score modes: fragments, per-query unscale, per-group lo flags, |q|^2 -> `scratch`
 // (score_planes_scratch_floats floats, 16-B aligned).
-int launch_score_planes_queries(const float* Q, int32_t nb, int32_t dim, float* scratch, int mode, hipStream_t s) {
+int launch_score_planes_queries(const float* Q, int32_t nb, int32_t dim, float* scratch, int mode, hipStream_t s, uint32_t* zero_word) {
     if (nb < 1 || dim % 32 || dim < 32) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(Q) & 15) || (reinterpret_cast<uintptr_t>(scratch) & 15)) return RL_ERR_UNSUPPORTED;
     const int32_t groups = (nb + 31) / 32;
@@ -1059,8 +1106,8 @@ int launch_score_planes_queries(const float* Q, int32_t nb, int32_t dim, float* 
     float* unscale = frag + (size_t)groups * 32 * dim;
     float* anylo = unscale + nb;
     float* qss = anylo + groups;
-    hipLaunchKernelGGL(query_rows_planes_kernel, dim3((unsigned)groups), dim3(256), 0, s, Q, (int)nb, (int)dim, reinterpret_cast<uint4*>(frag), unscale,
-                       anylo);
+    hipLaunchKernelGGL(query_rows_planes_kernel, dim3((unsigned)groups), dim3(1024), 0, s, Q, (int)nb, (int)dim, reinterpret_cast<uint4*>(frag), unscale,
+                       anylo, zero_word);
     RL_HIP(hipGetLastError());
     if (mode == SCAN_COSINE || mode == SCAN_L2) RL_TRY(launch_query_sumsq(Q, nb, dim, qss, s));
     return RL_OK;

@@ -508,16 +508,27 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const float* __restric
 // handful of keys on the threshold value, which are ranked by counting; (4) the k survivors are ordered and written.  No workspace, no
 // global atomics, the same (score desc, id asc) order on the same unique 64-bit keys: bit-identical results.  More keys in b* than the buffer
 // holds, or more than 1024 on one 22-bit prefix (massive ties): refine_in_bin over the global scores, the exact slow path of the final kernel.
+//
+// PREFILTER (round 6, option topk_block = 2, the default; k <= 512): most of that work is spent on scores that cannot matter -- a MaxSim query's
+// 125 k chunk scores crowd into two or three bins, whose LDS atomics serialise.  Every thread first takes the MAXIMUM key of the elements it
+// reads (thread t: 16-byte groups t, t + 1024, ...; no atomics); the k-th largest of the 1024 thread maxima -- 1024 DISTINCT elements, ordered by
+// one bitonic sort in LDS -- is a lower bound P of the k-th best key overall, and the keys >= P are the k thread maxima above it plus what else
+// their threads hold above P: about -1024 ln(1 - k / 1024) keys (105 at k = 100).  A second read collects them (one ballot per 16-byte group,
+// an append only where a lane has one), they are ranked, the best k written.  The keys are unique (score bits, ~index), so ties cost nothing.
+// Only data whose large keys all sit in few threads' groups can overflow the buffer (more than 8192 keys >= P): the histogram path
+// below then answers, as it does for k > 512.  Same keys, same order: bit-identical results (tests/test_gpu_topk_block.py).
 constexpr int BLOCK_BUF = 8192;          // keys of the threshold bin kept in LDS
 constexpr int64_t BLOCK_ROUTE_MAX_N = 262144;
+constexpr int PREFILTER_MAX_K = 512;
 struct BlockLds {
     uint64_t buf[BLOCK_BUF];                      // 64 KiB: the threshold bin; later the sort buffer of the results
     uint64_t fin[K_MAX];                          // 16 KiB
-    uint64_t tie[RANK_MAX];                       //  8 KiB: keys on the threshold sub-bin
+    uint64_t tie[RANK_MAX];                       //  8 KiB: keys on the threshold sub-bin (prefilter: the thread maxima)
     uint32_t h[HIST_COPIES * HIST_COPY_STRIDE];   // 33 KiB
     uint32_t scratch[20];
     uint32_t thr[2];
     uint32_t sh_cnt[4];
+    uint64_t pivot;
 };
 // position of this lane's element in a list that `pred` lanes of the wave append to (one LDS atomic per wave)
 __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
@@ -529,7 +540,7 @@ __device__ __forceinline__ uint32_t wave_append(uint32_t* counter, bool pred) {
     return base + __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 __global__ __launch_bounds__(1024) void topk_block_kernel(const float* __restrict__ scores, int64_t n, int64_t ld, int32_t k,
-                                                           float* __restrict__ out_scores, int32_t* __restrict__ out_ids) {
+                                                           float* __restrict__ out_scores, int32_t* __restrict__ out_ids, int prefilter) {
     __shared__ BlockLds L;
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int q = blockIdx.x;
@@ -540,6 +551,137 @@ __global__ __launch_bounds__(1024) void topk_block_kernel(const float* __restric
     if (kk == 0) { write_results(L.fin, 0, k, os, oi); return; }
     const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0;
     const int64_t n4 = vec ? n >> 2 : 0;
+    if (prefilter && kk <= (uint32_t)PREFILTER_MAX_K) {
+        const f4* const s4 = reinterpret_cast<const f4*>(s);
+        const f4 none = (f4){NAN, NAN, NAN, NAN};  // a group past the end: key bits 0, never a maximum
+        constexpr int REG_GROUPS = 12;             // up to 12 x 1024 16-byte groups (49 152 scores: the fused top-k's sample) stay in registers: ONE read
+        const bool resident = n4 > 0 && n4 <= (int64_t)REG_GROUPS * 1024 && (n & 3) == 0;  // (block-uniform)
+        f4 r[REG_GROUPS];
+        // (a) ONE of this thread's best elements (a float compare: the first of equal scores stays -- on massive ties the representatives are
+        // then the lowest indices, which is the selection's own order; -0 / +0 count as equal, NaN and -inf never win: ANY element per thread
+        // keeps the pivot a valid lower bound, a better one only makes it tighter)
+        float bv = -INFINITY;
+        uint32_t bi = 0u;
+        auto take = [&](float v, int64_t i) {
+            if (v > bv) { bv = v; bi = (uint32_t)i; }
+        };
+        if (resident) {
+#pragma unroll
+            for (int j = 0; j < REG_GROUPS; ++j) {
+                const int64_t i = (int64_t)threadIdx.x + 1024 * j;
+                r[j] = i < n4 ? s4[i] : none;
+            }
+#pragma unroll
+            for (int j = 0; j < REG_GROUPS; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) take(r[j][u], (((int64_t)threadIdx.x + 1024 * j) << 2) + u);
+        } else {
+            for (int64_t i = threadIdx.x; i < n4; i += 8192) {  // eight 16-byte loads in flight per lane: the block is alone on its CU, and a
+                f4 v[8];                                        // round trip to the cache the pass kernel left the scores in is ~1 us
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = i + 1024 * j < n4 ? s4[i + 1024 * j] : none;
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) take(v[j][u], ((i + 1024 * j) << 2) + u);
+            }
+            for (int64_t i = (n4 << 2) + threadIdx.x; i < n; i += 1024) take(s[i], i);
+        }
+        // (a thread without elements, or with NaN / -inf only, has no representative: key 0 sorts last)
+        uint64_t mine = bv > -INFINITY ? make_key64(bv, bi) : 0ull;
+        // k <= 128: the maxima of the 256 lane QUADS (~ -256 ln(1 - k / 256) keys reach their k-th largest: 127 at k = 100), ranked by counting by
+        // four waves; beyond: the 1024 thread maxima through a bitonic sort (55 barriers)
+        const bool quads = kk <= 128u;
+        if (quads) {
+#pragma unroll
+            for (int o = 1; o <= 2; o <<= 1) {
+                const uint32_t lo = __shfl_xor((uint32_t)mine, o, 64), hi = __shfl_xor((uint32_t)(mine >> 32), o, 64);
+                const uint64_t other = ((uint64_t)hi << 32) | lo;
+                mine = other > mine ? other : mine;
+            }
+            if ((threadIdx.x & 3) == 0) L.tie[threadIdx.x >> 2] = mine;
+        } else {
+            L.tie[threadIdx.x] = mine;
+        }
+        if (threadIdx.x == 0) { L.sh_cnt[0] = 0u; L.pivot = 0ull; }
+        __syncthreads();
+        if (quads) {
+            {   // all sixteen waves: lane quad t >> 2 ranks key t >> 2, each of its lanes against a quarter of the keys
+                const uint64_t m = L.tie[threadIdx.x >> 2];
+                uint32_t rank = 0;
+                for (int j = (threadIdx.x & 3); j < 256; j += 4) rank += L.tie[j] > m;
+                rank += __shfl_xor(rank, 1, 64);
+                rank += __shfl_xor(rank, 2, 64);
+                if ((threadIdx.x & 3) == 0 && rank == kk - 1u) L.pivot = m;  // (distinct keys; quads without one share key 0 and rank behind all others)
+            }
+            __syncthreads();
+        } else {
+            bitonic_sort_desc(L.tie, RANK_MAX);
+            if (threadIdx.x == 0) L.pivot = L.tie[kk - 1];
+            __syncthreads();
+        }
+        const uint64_t pivot = L.pivot;  // 0: fewer than kk maxima -- every key passes
+        const bool all = pivot == 0ull;
+        const float pf = key_score((uint32_t)(pivot >> 32));  // coarse test: a float compare (never misses a key >= pivot; the key decides)
+        // (b) the keys >= pivot
+        auto collect = [&](float v, int64_t i, bool coarse) {
+            const uint64_t key = make_key64(v, (uint32_t)i);
+            const bool hit = coarse && key >= pivot;
+            const uint32_t pos = wave_append(&L.sh_cnt[0], hit);
+            if (hit && pos < (uint32_t)BLOCK_BUF) L.buf[pos] = key;
+        };
+        auto group = [&](const f4 v, int64_t g, bool in) {  // (called by whole waves: the ballots are wave-wide)
+            bool c[4];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { c[u] = in && (all || v[u] >= pf); any |= c[u]; }
+            if (__builtin_amdgcn_ballot_w64(any) == 0ull) return;  // (wave-uniform)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) collect(v[u], (g << 2) + u, c[u]);
+        };
+        if (resident) {
+#pragma unroll
+            for (int j = 0; j < REG_GROUPS; ++j) group(r[j], (int64_t)threadIdx.x + 1024 * j, (int64_t)threadIdx.x + 1024 * j < n4);
+        } else {
+            for (int64_t i0 = 0; i0 < n4; i0 += 4096) {
+                const int64_t i = i0 + threadIdx.x;
+                f4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = i + 1024 * j < n4 ? s4[i + 1024 * j] : none;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) group(v[j], i + 1024 * j, i + 1024 * j < n4);
+            }
+            for (int64_t i0 = n4 << 2; i0 < n; i0 += 1024) {
+                const int64_t i = i0 + threadIdx.x;
+                const float v = i < n ? s[i] : 0.f;
+                collect(v, i, i < n && (all || v >= pf));
+            }
+        }
+        __syncthreads();
+        const uint32_t c_n = L.sh_cnt[0];  // >= kk (kk maxima >= pivot are among them; pivot 0: all n keys)
+        if (c_n <= (uint32_t)BLOCK_BUF) {
+            if (c_n <= 256u) {  // ranked by counting (distinct keys), a lane quad per key
+                const uint32_t a = threadIdx.x >> 2;
+                const uint64_t m = a < c_n ? L.buf[a] : 0ull;
+                uint32_t rank = 0;
+                for (uint32_t j = (threadIdx.x & 3); j < c_n; j += 4) rank += L.buf[j] > m;
+                rank += __shfl_xor(rank, 1, 64);
+                rank += __shfl_xor(rank, 2, 64);
+                if ((threadIdx.x & 3) == 0 && a < c_n && rank < kk) L.fin[rank] = m;
+                __syncthreads();
+                write_results(L.fin, (int)kk, k, os, oi);
+            } else {
+                int p2 = 512;
+                while (p2 < (int)c_n) p2 <<= 1;
+                for (int i = c_n + threadIdx.x; i < p2; i += 1024) L.buf[i] = 0ull;
+                __syncthreads();
+                bitonic_sort_desc(L.buf, p2);
+                write_results(L.buf, (int)kk, k, os, oi);
+            }
+            return;
+        }
+        __syncthreads();  // (overflow: the exact histogram path below, from scratch)
+    }
     // (1) histogram of the top 11 key bits
     hist_zero(L.h);
     __syncthreads();
@@ -659,9 +801,12 @@ __global__ __launch_bounds__(1024) void guarded_select_kernel(float* __restrict_
                                                                const float* __restrict__ row_norm, const float* __restrict__ row_sumsq,
                                                                const float* __restrict__ queries, int dim, int mode, float pre_scale,
                                                                float* __restrict__ out_scores, int32_t* __restrict__ out_ids,
-                                                               const uint32_t* __restrict__ run_if) {
+                                                               const uint32_t* __restrict__ run_if, uint32_t* __restrict__ host_flag) {
     __shared__ FinalLds L;
     __shared__ float part[4];
+    // host_flag: a word of pinned host memory that learns whether the guarded path ran (lazy images: the next batch then asks for the pre-split
+    // image) -- written by the kernel that reads the flag anyway instead of a 4-byte device-to-host copy behind it (5 us per batch)
+    if (host_flag && run_if && blockIdx.x == 0 && threadIdx.x == 0) *host_flag = *run_if;
     if (run_if && *run_if == 0u) return;
     const int q = blockIdx.x;
     float* const sb = scores + (int64_t)q * ld;
@@ -709,12 +854,12 @@ __global__ __launch_bounds__(1024) void guarded_select_kernel(float* __restrict_
 
 int launch_guarded_select(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t k, const float* row_norm, const float* row_sumsq,
                           const float* queries, int32_t dim, int mode, float pre_scale, float* out_scores, int32_t* out_ids,
-                          const uint32_t* run_if, hipStream_t s) {
+                          const uint32_t* run_if, hipStream_t s, uint32_t* host_flag) {
     if (nb <= 0 || k <= 0) return RL_OK;
     if (k > K_MAX) return fail(RL_ERR_UNSUPPORTED, "top-k: k must be <= 2048");
     if (n >= (int64_t)0x7fffffff) return fail(RL_ERR_UNSUPPORTED, "top-k: more than 2^31-2 elements per query");
     hipLaunchKernelGGL(guarded_select_kernel, dim3(nb), dim3(1024), 0, s, scores, n, ld, k, row_norm, row_sumsq, queries, (int)dim, mode, pre_scale,
-                       out_scores, out_ids, run_if);
+                       out_scores, out_ids, run_if, host_flag);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -774,7 +919,7 @@ int launch_topk(const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t 
     }
     // The block route (round 6): a query whose scores one block can read twice out of L2 is selected by ONE launch that touches no workspace
     if (!run_if && !have_hist && !emit && ws.block_route && n > 0 && n <= BLOCK_ROUTE_MAX_N) {
-        hipLaunchKernelGGL(topk_block_kernel, dim3(nq), dim3(1024), 0, s, scores, n, ld, k, out_scores, out_ids);
+        hipLaunchKernelGGL(topk_block_kernel, dim3(nq), dim3(1024), 0, s, scores, n, ld, k, out_scores, out_ids, ws.block_route >= 2 ? 1 : 0);
         RL_HIP(hipGetLastError());
         return RL_OK;
     }

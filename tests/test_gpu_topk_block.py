@@ -15,15 +15,20 @@ pytestmark = pytest.mark.gpu
 
 
 def _both(x, k):
-    raglite_amd.set_default_option("topk_block", 0)
-    try:
-        s0, i0 = raglite_amd.topk(x, k)
-    finally:
-        raglite_amd.set_default_option("topk_block", 1)
-    s1, i1 = raglite_amd.topk(x, k)
-    assert np.array_equal(i0, i1), "block route and three-launch route disagree on the ids"
-    assert np.array_equal(s0.view(np.uint32), s1.view(np.uint32))
-    return s1, i1
+    """Three routes, one result: 0 = histogram / filter / final, 1 = the block route, 2 = the block route with the thread-maximum prefilter."""
+    out = {}
+    for route in (0, 1, 2):
+        raglite_amd.set_default_option("topk_block", route)
+        try:
+            out[route] = raglite_amd.topk(x, k)
+        finally:
+            raglite_amd.set_default_option("topk_block", 2)
+    s0, i0 = out[0]
+    for route in (1, 2):
+        s1, i1 = out[route]
+        assert np.array_equal(i0, i1), f"block route {route} and three-launch route disagree on the ids"
+        assert np.array_equal(s0.view(np.uint32), s1.view(np.uint32)), route
+    return out[2]
 
 
 @pytest.mark.parametrize("n,k", [(1, 1), (3, 7), (63, 64), (4097, 100), (5000, 2048), (125_011, 100), (125_012, 512), (262_144, 1000), (262_143, 1)])
@@ -93,7 +98,7 @@ def test_device_tensors_unaligned_rows_and_the_pipelines_that_use_it():
     E = oracle.synth_matrix(40_000, n, dim, "small_int")
     Qb = np.stack([oracle.synth_matrix(40_100 + i, 32, dim, "small_int") for i in range(5)])
     idx = raglite_amd.DeviceIndex(E, off, metric="dot")
-    for opt in (1, 0):
+    for opt in (2, 1, 0):
         with idx.options(topk_block=opt):
             bs, bc = idx.maxsim_topk_batch(Qb, 100)
             ss, sc = idx.maxsim_topk(Qb[0], 100)
@@ -102,3 +107,35 @@ def test_device_tensors_unaligned_rows_and_the_pipelines_that_use_it():
             assert np.array_equal(bc[b], wc) and np.array_equal(bs[b], ws)
         assert np.array_equal(sc, bc[0]) and np.array_equal(ss, bs[0])
     idx.close()
+
+
+def test_prefilter_worst_cases_fall_back_to_the_histogram_path():
+    """The prefilter keeps the keys that reach the k-th largest of 1024 THREAD maxima (thread t reads the 16-byte groups t, t + 1024, ...).
+    Data whose large scores all sit in the groups of a few threads makes that pivot useless -- more keys pass than the LDS buffer holds --
+    and the block must notice and take the histogram path: same results as the other routes, bit for bit."""
+    rng = np.random.default_rng(8)
+    n = 200_000
+    x = rng.standard_normal(n).astype(np.float32)
+    g = np.arange(n) // 4  # 16-byte group of every element
+    few = (g % 1024) < 40  # the groups of forty threads
+    x[few] += 100.0        # ~7 800 large scores, all in forty threads' hands: the 100th thread maximum is an ordinary score
+    for k in (100, 512):
+        s, i = _both(x, k)
+        es, ei = oracle.topk_desc(x, k)
+        assert np.array_equal(i, ei) and np.array_equal(s, es)
+    # sorted data, both directions (ascending: every thread's maximum sits in its last group)
+    for y in (np.sort(x), np.sort(x)[::-1].copy()):
+        s, i = _both(y, 300)
+        es, ei = oracle.topk_desc(y, 300)
+        assert np.array_equal(i, ei) and np.array_equal(s, es)
+    # between 257 and 8192 survivors: the sorted path of the prefilter (k = 512 keeps ~700)
+    z = (480.0 + 34.0 * rng.standard_normal(125_000)).astype(np.float32)
+    s, i = _both(z, 512)
+    es, ei = oracle.topk_desc(z, 512)
+    assert np.array_equal(i, ei) and np.array_equal(s, es)
+    # NaN-heavy: threads whose elements are all NaN have no maximum; fewer than k real scores altogether
+    w = np.full(30_000, np.nan, dtype=np.float32)
+    w[rng.choice(30_000, size=60, replace=False)] = rng.standard_normal(60).astype(np.float32)
+    s, i = _both(w, 100)
+    es, ei = oracle.topk_desc(w, 100)
+    assert np.array_equal(i, ei) and np.array_equal(s.view(np.uint32)[:60], es.view(np.uint32)[:60]) and np.isnan(s[60:]).all()
