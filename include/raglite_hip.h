@@ -206,6 +206,8 @@ int rl_index_arithmetic(rl_index* index, int* in_effect);
  *   RL_OPT_TOPK_BLOCK           0 / 1 / 2 (2)      exact top-k of <= 262 144 scores per query (MaxSim chunk scores, the fused top-k's sample, rl_topk) in
  *                                                  ONE launch, one block per query (0: histogram / filter / final, three launches; same results);
  *                                                  2: the block first cuts the scores to the ~k that reach the k-th largest of its 1024 thread maxima
+ *   RL_OPT_HI_PIVOT             0 / 1 (1)          the B <= 16 row search takes its candidate threshold from the k-th largest of ~500 workgroup maxima of the
+ *                                                  approximate similarities (two launches, k <= 128) instead of ranking them exactly first (three); same results
  *   RL_OPT_HI_PRODUCTS          1 / 2 (1)          fp16 MFMA products per multiply in that approximate pass
  *   RL_OPT_PP_PASS              0 / 1 (1)          its sixteen-query kernel (maxsim_pp.hip; 0: the eight-query kernel)
  *   RL_OPT_FUSED_TOPK           0 / 1 (1)          B >= 96 row searches keep candidate lists instead of a score matrix
@@ -245,7 +247,7 @@ typedef enum {
     RL_OPT_PLANES_GEMM = 12, RL_OPT_KEEP_IMAGE = 13, RL_OPT_KEEP_HI = 14, RL_OPT_IMAGE_HEADROOM_MB = 15, RL_OPT_ARITHMETIC = 16,
     RL_OPT_EXACT_KTH_THRESHOLD = 17, RL_OPT_FUSED_TWO_ROUNDS = 18, RL_OPT_KEEP_HI_PLANE = 19, RL_OPT_PAIRS_PACKED = 20,
     RL_OPT_F16_EXACT = 21, RL_OPT_LAZY_IMAGES = 22, RL_OPT_FUSED_PP_SAMPLE = 23,
-    RL_OPT_LIST_SELECT = 24, RL_OPT_HI_FEW = 25, RL_OPT_TOPK_BLOCK = 26, RL_OPT_COUNT_ = 27
+    RL_OPT_LIST_SELECT = 24, RL_OPT_HI_FEW = 25, RL_OPT_TOPK_BLOCK = 26, RL_OPT_HI_PIVOT = 27, RL_OPT_COUNT_ = 28
 } rl_option;
 int rl_set_default_option(int key, int64_t value);
 int rl_get_default_option(int key, int64_t* value);

@@ -27,7 +27,7 @@ OPTIONS = {
     "hi_search": 1, "hi_maxsim": 2, "hi_products": 3, "pp_pass": 4, "fused_topk": 5, "fused_hi": 6, "fused_pp": 7, "fused_topk_cap": 8,
     "fused_topk_stride": 9, "gemm_pass": 10, "query_pairs": 11, "planes_gemm": 12, "keep_image": 13, "keep_hi": 14,
     "image_headroom_mb": 15, "arithmetic": 16, "exact_kth_threshold": 17, "fused_two_rounds": 18,
-    "keep_hi_plane": 19, "pairs_packed": 20, "f16_exact": 21, "lazy_images": 22, "fused_pp_sample": 23, "list_select": 24, "hi_few": 25, "topk_block": 26,
+    "keep_hi_plane": 19, "pairs_packed": 20, "f16_exact": 21, "lazy_images": 22, "fused_pp_sample": 23, "list_select": 24, "hi_few": 25, "topk_block": 26, "hi_pivot": 27,
 }
 
 c_void_p, c_int, c_i32, c_i64, c_u64, c_size_t = C.c_void_p, C.c_int, C.c_int32, C.c_int64, C.c_uint64, C.c_size_t

@@ -202,6 +202,7 @@ struct Options {
         v[RL_OPT_FUSED_PP] = v[RL_OPT_GEMM_PASS] = v[RL_OPT_QUERY_PAIRS] = v[RL_OPT_PLANES_GEMM] = v[RL_OPT_KEEP_IMAGE] = v[RL_OPT_KEEP_HI] = 1;
         v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = v[RL_OPT_F16_EXACT] = v[RL_OPT_LAZY_IMAGES] = v[RL_OPT_FUSED_PP_SAMPLE] = v[RL_OPT_LIST_SELECT] = v[RL_OPT_HI_FEW] = 1;
         v[RL_OPT_TOPK_BLOCK] = 2;
+        v[RL_OPT_HI_PIVOT] = 1;
         v[RL_OPT_IMAGE_HEADROOM_MB] = -1;
         v[RL_OPT_ARITHMETIC] = RL_ARITH_AUTO;
     }
@@ -213,7 +214,7 @@ bool option_value_ok(int key, int64_t value) {
     switch (key) {
         case RL_OPT_HI_SEARCH: case RL_OPT_HI_MAXSIM: case RL_OPT_PP_PASS: case RL_OPT_FUSED_TOPK: case RL_OPT_FUSED_HI: case RL_OPT_FUSED_PP:
         case RL_OPT_GEMM_PASS: case RL_OPT_QUERY_PAIRS: case RL_OPT_PLANES_GEMM: case RL_OPT_KEEP_IMAGE: case RL_OPT_KEEP_HI:
-        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED: case RL_OPT_F16_EXACT: case RL_OPT_LAZY_IMAGES: case RL_OPT_FUSED_PP_SAMPLE: case RL_OPT_LIST_SELECT: case RL_OPT_HI_FEW:
+        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED: case RL_OPT_F16_EXACT: case RL_OPT_LAZY_IMAGES: case RL_OPT_FUSED_PP_SAMPLE: case RL_OPT_LIST_SELECT: case RL_OPT_HI_FEW: case RL_OPT_HI_PIVOT:
             return value == 0 || value == 1;
         case RL_OPT_TOPK_BLOCK: return value >= 0 && value <= 2;
         case RL_OPT_HI_PRODUCTS: return value == 1 || value == 2;
@@ -1609,7 +1610,7 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     const int64_t nc = (int64_t)nb * cap, ldx = nc;
     // ---- scratch: approximate top-k scores (+ unused ids), thresholds, counters + flag, candidate rows, their norms, the
     // gathered rows, the exact score block and its diagonal -------------------------------------------------------------------------
-    const size_t words = (size_t)nb * k * 2 + 32 + 32 + (size_t)nc * 2 + (size_t)nc * dim + (size_t)nb * ldx + (size_t)nc;
+    const size_t words = (size_t)nb * k * 2 + 32 + 32 + (size_t)nc * 2 + (size_t)nc * dim + (size_t)nb * ldx + (size_t)nc + 2 + 2 * pivot_scratch_words(nb);
     RL_TRY(idx->hibuf.reserve(words * 4));
     float* ts = idx->hibuf.as<float>();                        // [nb x k]
     int32_t* ti = reinterpret_cast<int32_t*>(ts + (size_t)nb * k);
@@ -1622,6 +1623,7 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     float* G = gn + nc;                                        // [nb * cap x dim]
     float* xs = G + (size_t)nc * dim;                          // [nb x nb * cap]
     float* es = xs + (size_t)nb * ldx;                         // [nb x cap]
+    uint64_t* bmax = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(es + nc) + 7) & ~uintptr_t(7));  // [nb x 512] workgroup maxima (pivot route)
     float* sc = idx->scores.as<float>();
     // ---- (1) approximate pass over the HI plane ---------------------------------------------------------------------------------------------
     int st = launch_maxsim_stream16(idx->hiplane.as<uint16_t>(), n, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, sc, ld,
@@ -1632,6 +1634,7 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     // index (refresh_hi_image) -- plus 2^-12 |e| |q| for the query's own 2^-22 split and twice the worst case of a 1024-term fp32
     // sum (6e-5).  Without those maxima (no HI image on this index): the a-priori 2^-10 of the truncation, plus 2^-11.
     const bool measured = idx->max_row_norm_rows == idx->n_rows && idx->max_row_norm_scale == idx->hi_scale && idx->max_row_norm > 0.f;
+    bool gathered = false;
     float m_rel = 0x1p-10f + 0x1p-11f, e_bound = std::sqrt((float)dim) * idx->max_abs;
     if (measured) {
         if (mode == SCAN_COSINE) m_rel = idx->max_lo_ratio + 0x1p-12f;
@@ -1650,17 +1653,27 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
         // threshold kernel, no collecting pass over the scores.
         HiBound bound;
         bound.m_out = mb; bound.m_rel = m_rel; bound.e_norm_bound = e_bound;
-        RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f / idx->hi_scale, nullptr, cnt, 32, &bound));
-        HiEmit emit;
-        emit.m = mb; emit.cap = cap; emit.ids = ci; emit.norms = gn; emit.row_norm = mode == SCAN_COSINE ? idx->norm : nullptr;
-        emit.cnt = cnt; emit.flag = flag; emit.thr = thr;
-        RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s, nullptr, true, &emit));
+        // Round 6 (option hi_pivot): no approximate RANKING at all -- the candidates are re-scored and ranked exactly anyway, so any lower bound
+        // of the k-th best approximate similarity will do for the threshold: the k-th largest of ~500 workgroup maxima (hi_filter.hip:
+        // transform_bmax_kernel / pivot_collect_kernel), two launches instead of the selection's three (k <= 128, >= 3 k maxima)
+        int st_pv = RL_ERR_UNSUPPORTED;
+        if (idx->opt.on(RL_OPT_HI_PIVOT))
+            st_pv = launch_pivot_route(sc, nb, n, ld, k, idx->norm, idx->sumsq, d_q, dim, mode, 1.0f / idx->hi_scale, bmax, cnt, 32, bound, thr, cap, ci, gn,
+                                       cnt, flag, s, idx->E, G, &gathered);
+        if (st_pv != RL_OK && st_pv != RL_ERR_UNSUPPORTED) return st_pv;
+        if (st_pv == RL_ERR_UNSUPPORTED) {
+            RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f / idx->hi_scale, nullptr, cnt, 32, &bound));
+            HiEmit emit;
+            emit.m = mb; emit.cap = cap; emit.ids = ci; emit.norms = gn; emit.row_norm = mode == SCAN_COSINE ? idx->norm : nullptr;
+            emit.cnt = cnt; emit.flag = flag; emit.thr = thr;
+            RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s, nullptr, true, &emit));
+        }
     }
     idx->filt = {RL_FILTER_ROWS_HI, nb, cap, cnt, flag};
     // ---- (3) exact scores of the candidates, by the kernels of the full pass (slots past a list's length are neither gathered nor
     // ranked: the pass multiplies whatever their rows of G hold) -- and (4), the guarded full-precision pass over the corpus, as the
     // second grid row of the SAME launch: it returns at once unless a list overflowed / a bound was unusable ---------------------------------
-    RL_TRY(launch_gather_rows(idx->E, false, dim, n, ci, nc, G, s, cnt, cap));
+    if (!gathered) RL_TRY(launch_gather_rows(idx->E, false, dim, n, ci, nc, G, s, cnt, cap));  // (the pivot route's collection gathers on its way)
     StreamSecondJob full;
     full.D = idx->E; full.n_rows = n; full.out = sc; full.ld = ld; full.run_if = flag;
     st = launch_maxsim_stream_two(G, nc, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, xs, ldx, idx->n_cu, s, idx->split_scale, full);
@@ -2191,10 +2204,8 @@ int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_quer
         if (m_from_qsum)  // (also fills the lists' tails with -1)
             RL_TRY(launch_exact_threshold(hb.es_top, hb.ti, n_gemm, k, hb.m, hb.cap, hb.thr, hb.cnt, hb.ci, hb.es, hb.flag, s, hb.qsum, hb.m_abs,
                                           idx->max_row_norm + idx->max_lo_norm, hb.one_product));
-        else {
-            RL_HIP(hipMemsetAsync(hb.ci, 0xff, (size_t)n_gemm * hb.cap * sizeof(int32_t), s));  // unused slots: -1 = "no chunk"
+        else
             RL_TRY(launch_exact_threshold(hb.es_top, hb.ti, n_gemm, k, hb.m, hb.cap, hb.thr, hb.cnt, hb.ci, hb.es, hb.flag, s));
-        }
         RL_TRY(launch_collect_above(sc, n_gemm, idx->n_chunks, ld, hb.thr, nullptr, hb.cap, hb.ci, nullptr, hb.cnt, hb.flag, s, hb.ts, hb.ti, k));
         if (hb.cap > k)
             RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap - k, n_gemm, hb.es, s, rows16, hb.cap, k, packed));
@@ -2278,8 +2289,6 @@ int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, 
         st = launch_maxsim_stream_batch(idx->hiplane.p, true, idx->n_rows, idx->dim, d_q, nq, q_elems, n, idx->row_to_chunk, idx->offsets,
                                         idx->n_chunks, sc, ld, idx->n_cu, s, 0.f, nullptr);
     if (st != RL_OK) return st;
-    // the plane holds fp16(e * scale), scale a power of two: undone exactly
-    RL_TRY(launch_scale_f32(sc, sc, 1.0f / idx->split_scale, (int64_t)(n - 1) * ld + idx->n_chunks, s));
     HiBatch hb;
     hb.one_product = false;  // q_hi . e_hi + q_lo . e_hi: nothing of the query is dropped
     hb.exact_kth = idx->opt.on(RL_OPT_EXACT_KTH_THRESHOLD);
@@ -2287,7 +2296,9 @@ int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, 
     hi_batch_layout(idx, n, k, hb);
     hb.m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
     hb.q_unscale = nullptr;
-    RL_HIP(hipMemsetAsync(hb.flag, 0, 16 * sizeof(uint32_t), s));
+    // the plane holds fp16(e * scale), scale a power of two: undone exactly (the launch also zeroes the flag block: the two small memsets of
+    // this route were six fill launches, 28 us of a 0.44 ms query)
+    RL_TRY(launch_scale_f32(sc, sc, 1.0f / idx->split_scale, (int64_t)(n - 1) * ld + idx->n_chunks, s, hb.flag, 16));
     RL_TRY(mask_chunk_scores(idx, sc, n, ld, nullptr, s));  // tombstones never become candidates
     RL_TRY(launch_topk(sc, n, idx->n_chunks, ld, k, idx->ws, hb.ts, hb.ti, s));
     RL_TRY(launch_maxsim_threshold(hb.ts, n, k, d_q, nq, idx->dim, q_elems, 1.0f, hb.m_abs, hb.thr, hb.cnt, hb.flag, s, nullptr,

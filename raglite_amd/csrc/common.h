@@ -133,7 +133,8 @@ int launch_cast_f16(const float* src, uint16_t* dst, int64_t count, hipStream_t 
 // dst = fp16(src * scale) rounded to nearest even (the HI plane); count % 8 == 0, 16-byte aligned pointers
 int launch_cast_f16_scaled(const float* src, uint16_t* dst, int64_t count, float scale, hipStream_t s);
 int launch_fill_f32(float* dst, float value, int64_t count, hipStream_t s);
-int launch_scale_f32(const float* src, float* dst, float factor, int64_t count, hipStream_t s);  // hi_filter.hip: dst = src * factor
+int launch_scale_f32(const float* src, float* dst, float factor, int64_t count, hipStream_t s, uint32_t* zero_words = nullptr,
+                     int n_zero = 0);  // hi_filter.hip: dst = src * factor (and n_zero words set to zero on the way)
 // in-place metric transform of raw dots: scores[b*ld+i] (i<n), per-row norm / sumsq, per-query norm.
 // (pre_scale: the raw dots are multiplied by it first -- a power of two, exact; run_if as in launch_topk)
 int launch_transform(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm,
@@ -220,6 +221,11 @@ int launch_rank_cut(float* scores, int32_t n_queries, int64_t n, int64_t ld, int
 int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const float* queries, int32_t dim, int mode, float m_rel,
                             float e_norm_bound, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s);  // also zeroes cnt[0..nb) and *flag
 // top_s / top_i [nb x k] (optional): the approximate top-k in selection order -- only entries ranking BELOW its k-th one are collected
+size_t pivot_scratch_words(int32_t nb);
+int launch_pivot_route(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t k, const float* row_norm, const float* row_sumsq, const float* queries,
+                       int32_t dim, int mode, float pre_scale, uint64_t* bmax, uint32_t* zero_words, int n_zero, const HiBound& bound, float* thr,
+                       int32_t cap, int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* E = nullptr,
+                       float* gather_out = nullptr, bool* gathered = nullptr);
 int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld, const float* thr, const float* row_norm, int32_t cap,
                          int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* top_s = nullptr,
                          const int32_t* top_i = nullptr, int32_t k = 0);

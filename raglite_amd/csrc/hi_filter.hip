@@ -52,20 +52,13 @@ __global__ __launch_bounds__(256) void approx_threshold_kernel(const float* __re
 // top_s / top_i != nullptr (the second, tighter threshold of a MaxSim batch, api.hip: hi_batch_rescore): [nb x k] the approximate top-k
 // in selection order (score desc, id asc) -- its members are already in the list (positions 0 .. k - 1, cnt[b] starts at k) and are NOT
 // collected again: an entry is taken only if it ranks BELOW the k-th one, (key, id) < (key_k, id_k) in the selection's own order.
-__global__ __launch_bounds__(256) void collect_above_kernel(const float* __restrict__ scores, int64_t n, int64_t ld, const float* __restrict__ thr,
-                                                             const float* __restrict__ row_norm, int32_t cap, int32_t* __restrict__ ids,
-                                                             float* __restrict__ norms, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag,
-                                                             const float* __restrict__ top_s, const int32_t* __restrict__ top_i, int32_t k) {
+// (the body, shared with pivot_collect_kernel: every thread of the 256-thread block must call)
+__device__ __forceinline__ void collect_rows(const float* __restrict__ s, int64_t n, bool vec, float t, const float* __restrict__ row_norm, int32_t cap,
+                                             int32_t* __restrict__ ids, float* __restrict__ norms, uint32_t* __restrict__ cnt_b,
+                                             uint32_t* __restrict__ flag, bool below_top, uint32_t key_k, int64_t id_k, int32_t* l_ids, uint32_t* l_n,
+                                             uint32_t* l_base, const float* __restrict__ E = nullptr, int dim = 0, float* __restrict__ G = nullptr) {
     constexpr uint32_t LOCAL = 1024;
-    __shared__ int32_t l_ids[LOCAL];
-    __shared__ uint32_t l_n, l_base;
-    const int b = blockIdx.y;
-    const float t = thr[b];
-    const float* s = scores + (int64_t)b * ld;
-    const bool below_top = top_s != nullptr;
-    const uint32_t key_k = below_top ? score_key(top_s[(int64_t)b * k + (k - 1)]) : 0u;
-    const int64_t id_k = below_top ? (int64_t)top_i[(int64_t)b * k + (k - 1)] : -1;
-    if (threadIdx.x == 0) l_n = 0u;
+    if (threadIdx.x == 0) *l_n = 0u;
     __syncthreads();
     auto visit = [&](float v, int64_t i, bool in_range) {
         bool hit = in_range && v >= t;
@@ -77,7 +70,7 @@ __global__ __launch_bounds__(256) void collect_above_kernel(const float* __restr
         if (mask == 0ull) return;  // (wave-uniform)
         const int lane = threadIdx.x & 63;
         uint32_t base = 0;
-        if (lane == __builtin_ctzll(mask)) base = atomicAdd(&l_n, (uint32_t)__builtin_popcountll(mask));
+        if (lane == __builtin_ctzll(mask)) base = atomicAdd(l_n, (uint32_t)__builtin_popcountll(mask));
         base = __builtin_amdgcn_readlane(base, __builtin_ctzll(mask));
         if (hit) {
             const uint32_t p = base + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
@@ -85,7 +78,7 @@ __global__ __launch_bounds__(256) void collect_above_kernel(const float* __restr
         }
     };
     const int64_t stride = (int64_t)gridDim.x * 256;
-    if ((ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0) {
+    if (vec) {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4* s4 = reinterpret_cast<const f4*>(s);
         const int64_t n4 = n >> 2;
@@ -108,25 +101,185 @@ __global__ __launch_bounds__(256) void collect_above_kernel(const float* __restr
         }
     }
     __syncthreads();
-    const uint32_t found = l_n;
+    const uint32_t found = *l_n;
     if (found == 0u) return;  // (workgroup-uniform)
     const uint32_t mine = found < LOCAL ? found : LOCAL;
     if (threadIdx.x == 0) {
-        l_base = atomicAdd(cnt + b, mine);
+        *l_base = atomicAdd(cnt_b, mine);
         if (found > LOCAL) atomicOr(flag, 1u);
     }
     __syncthreads();
-    const uint32_t base = l_base;
+    const uint32_t base = *l_base;
     for (uint32_t j = threadIdx.x; j < mine; j += 256) {
         const uint32_t p = base + j;
         if (p < (uint32_t)cap) {
             const int32_t i = l_ids[j];
-            ids[(int64_t)b * cap + p] = i;
-            if (row_norm) norms[(int64_t)b * cap + p] = row_norm[i];
+            ids[p] = i;
+            if (row_norm) norms[p] = row_norm[i];
         } else {
             atomicOr(flag, 1u);
         }
     }
+    // E != nullptr: the rows themselves go to G[p] right away (dim % 4 == 0, 16-byte aligned: the launcher checks) -- the workgroup that found a
+    // row copies it, a handful of rows per workgroup and all workgroups at once: no gather launch behind the collection
+    if (E) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        for (uint32_t j = 0; j < mine && base + j < (uint32_t)cap; ++j) {  // (workgroup-uniform)
+            const f4* src = reinterpret_cast<const f4*>(E + (int64_t)l_ids[j] * dim);
+            f4* dst = reinterpret_cast<f4*>(G + (int64_t)(base + j) * dim);
+            for (int c = threadIdx.x; c < (dim >> 2); c += 256) dst[c] = src[c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void collect_above_kernel(const float* __restrict__ scores, int64_t n, int64_t ld, const float* __restrict__ thr,
+                                                             const float* __restrict__ row_norm, int32_t cap, int32_t* __restrict__ ids,
+                                                             float* __restrict__ norms, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag,
+                                                             const float* __restrict__ top_s, const int32_t* __restrict__ top_i, int32_t k) {
+    __shared__ int32_t l_ids[1024];
+    __shared__ uint32_t l_n, l_base;
+    const int b = blockIdx.y;
+    const bool below_top = top_s != nullptr;
+    const uint32_t key_k = below_top ? score_key(top_s[(int64_t)b * k + (k - 1)]) : 0u;
+    const int64_t id_k = below_top ? (int64_t)top_i[(int64_t)b * k + (k - 1)] : -1;
+    const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0;
+    collect_rows(scores + (int64_t)b * ld, n, vec, thr[b], row_norm, cap, ids + (int64_t)b * cap, norms ? norms + (int64_t)b * cap : nullptr, cnt + b, flag,
+                 below_top, key_k, id_k, l_ids, &l_n, &l_base);
+}
+
+// ---- the single-query row search without an approximate RANKING (round 6, api.hip: search_rows_hi, option hi_pivot) ---------------------------
+// What the half-bytes search needs from its approximate similarities is a candidate set, not their order: every row whose approximate
+// similarity reaches (k-th best approximate) - 2 m.  ANY lower bound P of the k-th best gives a superset {approx >= P - 2 m}, and the
+// candidates are re-scored and ranked exactly anyway.  P = the k-th largest of G >= 3 k workgroup MAXIMA (G distinct rows): about
+// -G ln(1 - k / G) rows reach it (128 of a million at k = 100, G = 489) -- as good as the exact k-th best for this purpose, and two launches
+// (transform + maxima; pivot + collection) instead of three (transform + histogram, filter, final: the radix selection of a million scores).
+//
+// (1) raw dots -> similarities in place (transform_score: the statements of transform_hist_kernel, same bits), the best key of every workgroup
+// -> bmax[b * G + blockIdx.x]; the bound m_b of the query (HiBound) and the zeroed counter block, as transform_hist_kernel leaves them.
+__global__ __launch_bounds__(256) void transform_bmax_kernel(float* __restrict__ scores, int64_t n, int64_t ld, const float* __restrict__ row_norm,
+                                                              const float* __restrict__ row_sumsq, const float* __restrict__ queries, int dim,
+                                                              int mode, float pre_scale, uint64_t* __restrict__ bmax, uint32_t* __restrict__ zero_words,
+                                                              int n_zero, HiBound hb) {
+    __shared__ float part[4];
+    __shared__ uint64_t wmax[4];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int b = blockIdx.y;
+    if (blockIdx.x == 0 && b == 0 && (int)threadIdx.x < n_zero) zero_words[threadIdx.x] = 0u;
+    float* const sb = scores + (int64_t)b * ld;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0;  // (row_norm / row_sumsq are hipMalloc'd)
+    const int64_t n4 = vec ? n >> 2 : 0;
+    const float* aux = mode == SCAN_COSINE ? row_norm : mode == SCAN_L2 ? row_sumsq : nullptr;
+    // the first trip's loads are issued before the query-norm reduction so that their latency hides behind it
+    const int64_t i_first = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    f4 d0 = (f4){0.f, 0.f, 0.f, 0.f}, a0 = d0;
+    if (i_first < n4) {
+        d0 = reinterpret_cast<const f4*>(sb)[i_first];
+        if (aux) a0 = reinterpret_cast<const f4*>(aux)[i_first];
+    }
+    float ss = 0.f;
+    for (int c = threadIdx.x; c < dim; c += 256) {
+        const float v = queries[(int64_t)b * dim + c];
+        ss = fmaf(v, v, ss);
+    }
+    ss = wave_sum(ss);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    const float qss = (part[0] + part[1]) + (part[2] + part[3]);
+    const float qn = sqrtf(qss);
+    if (hb.m_out && blockIdx.x == 0 && threadIdx.x == 0)
+        hb.m_out[b] = mode == SCAN_COSINE ? hb.m_rel : hb.m_rel * hb.e_norm_bound * qn + 0x1p-22f;
+    float bv = -INFINITY;  // ONE of this thread's best rows (the first of equal similarities; NaN / -inf never win)
+    uint32_t bi = 0u;
+    auto finish = [&](int64_t i, const f4 d, const f4 a) {
+        f4 o;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            o[u] = transform_score(d[u] * pre_scale, mode, a[u], a[u], qn, qss);
+            if (o[u] > bv) { bv = o[u]; bi = (uint32_t)((i << 2) + u); }
+        }
+        reinterpret_cast<f4*>(sb)[i] = o;
+    };
+    auto one = [&](int64_t i) {  // scalar tail / unaligned layout
+        const float o = transform_score(sb[i] * pre_scale, mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
+        if (o > bv) { bv = o; bi = (uint32_t)i; }
+        sb[i] = o;
+    };
+    if (vec) {
+        int64_t i = i_first;
+        while (i < n4) {
+            const int64_t nx = i + stride;
+            f4 d1 = (f4){0.f, 0.f, 0.f, 0.f}, a1 = d1;
+            if (nx < n4) {
+                d1 = reinterpret_cast<const f4*>(sb)[nx];
+                if (aux) a1 = reinterpret_cast<const f4*>(aux)[nx];
+            }
+            finish(i, d0, a0);
+            d0 = d1; a0 = a1;
+            i = nx;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < (n & 3)) one((n4 << 2) + threadIdx.x);
+    } else {
+        for (int64_t i = i_first; i < n; i += stride) one(i);
+    }
+    uint64_t mine = bv > -INFINITY ? make_key64(bv, bi) : 0ull;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)mine, o, 64), hi = __shfl_xor((uint32_t)(mine >> 32), o, 64);
+        const uint64_t other = ((uint64_t)hi << 32) | lo;
+        mine = other > mine ? other : mine;
+    }
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t m01 = wmax[0] > wmax[1] ? wmax[0] : wmax[1], m23 = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+        bmax[(int64_t)b * gridDim.x + blockIdx.x] = m01 > m23 ? m01 : m23;
+    }
+}
+
+// (2) every workgroup finds P = the k-th largest score among the query's G maxima -- ONE wave, the keys in registers (eight per lane), a radix
+// select over the 32 score bits by ballots: no barrier, ~1 us (a bitonic network over 512 keys in LDS cost 13 us of barriers in every workgroup)
+// -- sets thr[b] = P - 2 m_b and collects its share of the rows that reach it: ids / norms / cnt / flag as collect_above_kernel leaves them, and
+// (E != nullptr) the rows themselves into G.  Fewer than k usable maxima (NaN / -inf everywhere): *flag, nothing collected -- the guarded
+// full-precision pass answers.
+__global__ __launch_bounds__(256) void pivot_collect_kernel(const float* __restrict__ scores, int64_t n, int64_t ld, const uint64_t* __restrict__ bmax,
+                                                             int G, int32_t k, const float* __restrict__ m, float* __restrict__ thr,
+                                                             const float* __restrict__ row_norm, int32_t cap, int32_t* __restrict__ ids,
+                                                             float* __restrict__ norms, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag,
+                                                             const float* __restrict__ E, int dim, float* __restrict__ Gout) {
+    __shared__ int32_t l_ids[1024];
+    __shared__ uint32_t l_n, l_base, pivot_sh;
+    const int b = blockIdx.y;
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        uint32_t kv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kv[j] = lane + 64 * j < G ? (uint32_t)(bmax[(int64_t)b * G + lane + 64 * j] >> 32) : 0u;
+        uint32_t need = (uint32_t)k, prefix = 0u;
+        for (int bit = 31; bit >= 0; --bit) {  // the keys that agree with `prefix` above `bit` are alive; how many of them have the bit set?
+            const uint32_t want = (prefix >> bit) | 1u;
+            uint32_t c = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) c += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((kv[j] >> bit) == want));
+            if (c >= need) prefix |= 1u << bit;
+            else need -= c;
+        }
+        if (lane == 0) pivot_sh = prefix;  // the k-th largest score key, multiplicity counted (0: fewer than k maxima)
+    }
+    __syncthreads();
+    const uint32_t pivot = pivot_sh;
+    if (pivot == 0u) {  // (workgroup-uniform)
+        if (blockIdx.x == 0 && threadIdx.x == 0) { thr[b] = INFINITY; atomicOr(flag, 1u); }
+        return;
+    }
+    const float t = key_score(pivot) - 2.0f * m[b];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        thr[b] = t;
+        if (!(t > -INFINITY)) atomicOr(flag, 1u);
+    }
+    const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0;
+    collect_rows(scores + (int64_t)b * ld, n, vec, t, row_norm, cap, ids + (int64_t)b * cap, norms ? norms + (int64_t)b * cap : nullptr, cnt + b, flag,
+                 false, 0u, -1, l_ids, &l_n, &l_base, E, dim, Gout ? Gout + (int64_t)b * cap * dim : nullptr);
 }
 
 __global__ __launch_bounds__(256) void maxsim_threshold_kernel(const float* __restrict__ topk, int32_t k, const float* __restrict__ Q, int nq,
@@ -205,7 +358,7 @@ __global__ __launch_bounds__(256) void maxsim_threshold_kernel(const float* __re
 // Fewer than k scorable chunks (an id < 0, a NaN): *flag, nothing collected (thr = +inf): the guarded full-precision path answers.
 // qsum != nullptr (a batch whose query image carries the sums, maxsim_gemm.hip: query_planes_kernel): m_b is computed HERE -- m_abs sum_i |q_i|
 // (+ e_norm_max sum_i |q_lo,i| for the one-product pass, the statement of maxsim_threshold_kernel) -- and left in m[b]; no threshold kernel
-// ran before.  The slots k .. cap - 1 of the list are set to -1 ("no chunk"): no memset launch in front of the collection.
+// ran before.  Always: the slots k .. cap - 1 of the list are set to -1 ("no chunk"), so no memset launch precedes the collection.
 __global__ __launch_bounds__(256) void exact_threshold_kernel(const float* __restrict__ exact, const int32_t* __restrict__ top_i, int32_t k,
                                                                float* __restrict__ m, int32_t cap, float* __restrict__ thr,
                                                                uint32_t* __restrict__ cnt, int32_t* __restrict__ ids, float* __restrict__ es,
@@ -226,8 +379,7 @@ __global__ __launch_bounds__(256) void exact_threshold_kernel(const float* __res
         ids[(int64_t)b * cap + j] = c;
         es[(int64_t)b * cap + j] = v;
     }
-    if (qsum)
-        for (int j = k + threadIdx.x; j < cap; j += 256) ids[(int64_t)b * cap + j] = -1;
+    for (int j = k + threadIdx.x; j < cap; j += 256) ids[(int64_t)b * cap + j] = -1;  // (the list's unused slots: "no chunk" -- no memset launch)
     if (bad) bad_sh = 1;  // (benign race: every writer stores 1)
     mn = -wave_max(-mn);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mn;
@@ -459,6 +611,30 @@ int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const floa
     return RL_OK;
 }
 
+// The pivot route of the single-query row search: see transform_bmax_kernel.  bmax: pivot_scratch_words(nb) 8-byte words.  RL_ERR_UNSUPPORTED
+// where the route does not pay (fewer than 3 k workgroup maxima, k > 128).
+size_t pivot_scratch_words(int32_t nb) { return (size_t)nb * 512; }
+int launch_pivot_route(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t k, const float* row_norm, const float* row_sumsq, const float* queries,
+                       int32_t dim, int mode, float pre_scale, uint64_t* bmax, uint32_t* zero_words, int n_zero, const HiBound& bound, float* thr,
+                       int32_t cap, int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* E, float* gather_out,
+                       bool* gathered) {
+    if (gathered) *gathered = false;
+    if (n <= 0 || nb <= 0 || k < 1 || k > 128 || !bound.m_out) return RL_ERR_UNSUPPORTED;
+    if (n_zero < 0 || n_zero > 256 || (n_zero > 0 && !zero_words)) return RL_ERR_INVALID;
+    const int G = (int)std::min<int64_t>((n + 2047) / 2048, 512);
+    if (G < 3 * k) return RL_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(transform_bmax_kernel, dim3(G, nb), dim3(256), 0, s, scores, n, ld, row_norm, row_sumsq, queries, (int)dim, mode, pre_scale, bmax,
+                       zero_words, n_zero, bound);
+    const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((n + 4095) / 4096, 512));
+    // (the candidates' rows gathered by the collecting workgroups themselves where the layout allows 16-byte copies)
+    const bool fuse = E && gather_out && gathered && (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(E) | reinterpret_cast<uintptr_t>(gather_out)) & 15) == 0;
+    hipLaunchKernelGGL(pivot_collect_kernel, dim3(bx, nb), dim3(256), 0, s, scores, n, ld, bmax, G, k, bound.m_out, thr,
+                       mode == SCAN_COSINE ? row_norm : nullptr, cap, ids, norms, cnt, flag, fuse ? E : nullptr, (int)dim, fuse ? gather_out : nullptr);
+    if (fuse) *gathered = true;
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
 int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld, const float* thr, const float* row_norm, int32_t cap,
                          int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* top_s, const int32_t* top_i,
                          int32_t k) {
@@ -523,7 +699,9 @@ __global__ __launch_bounds__(256) void f16_exact_finish_kernel(const float* __re
     if (threadIdx.x == 0) cnt[b] = 0u;  // (rl_index_filter_stats: no candidate is re-scored on this route)
 }
 
-__global__ __launch_bounds__(256) void scale_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, float factor, int64_t count) {
+__global__ __launch_bounds__(256) void scale_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, float factor, int64_t count,
+                                                         uint32_t* __restrict__ zero_words, int n_zero) {
+    if (blockIdx.x == 0 && (int)threadIdx.x < n_zero) zero_words[threadIdx.x] = 0u;  // (a small hipMemsetAsync is THREE fill launches)
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) dst[i] = src[i] * factor;
 }
@@ -548,9 +726,10 @@ int launch_f16_exact_finish(const float* Q, int32_t nq, int32_t dim, int64_t q_s
     return RL_OK;
 }
 
-int launch_scale_f32(const float* src, float* dst, float factor, int64_t count, hipStream_t s) {
+int launch_scale_f32(const float* src, float* dst, float factor, int64_t count, hipStream_t s, uint32_t* zero_words, int n_zero) {
     if (count <= 0) return RL_OK;
-    hipLaunchKernelGGL(scale_f32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src, dst, factor, count);
+    if (n_zero < 0 || n_zero > 256 || (n_zero > 0 && !zero_words)) return RL_ERR_INVALID;
+    hipLaunchKernelGGL(scale_f32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, src, dst, factor, count, zero_words, n_zero);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -1266,6 +1266,25 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float* __restric
         buf[i] = key;
     }
     __syncthreads();
+    if (counts && total <= 256) {
+        // a candidate list of a bound-filtered search (one list, a few hundred DISTINCT ids at most): every record ranked by counting the larger
+        // ones, a lane quad per record -- three barriers instead of the 28-36 of the sorting network (9-11 us per launch in every pipeline that
+        // ends here; padding records -- key 0 -- are not ranked)
+        uint64_t* const fin = buf + 256;
+        const int kk = total < k ? total : k;
+        for (int i = threadIdx.x; i < kk; i += blockDim.x) fin[i] = 0ull;
+        __syncthreads();
+        const int a = threadIdx.x >> 2;
+        const uint64_t mine = a < total ? buf[a] : 0ull;
+        uint32_t rank = 0;
+        for (int j = (threadIdx.x & 3); j < total; j += 4) rank += buf[j] > mine;
+        rank += __shfl_xor(rank, 1, 64);
+        rank += __shfl_xor(rank, 2, 64);
+        if ((threadIdx.x & 3) == 0 && mine != 0ull && rank < (uint32_t)kk) fin[rank] = mine;
+        __syncthreads();
+        write_results(fin, kk, k, out_scores + (int64_t)q * k, out_ids + (int64_t)q * k);
+        return;
+    }
     bitonic_sort_desc(buf, p2);
     write_results(buf, total < k ? total : k, k, out_scores + (int64_t)q * k, out_ids + (int64_t)q * k);
 }
