@@ -2130,6 +2130,7 @@ struct HiBatch {
     float* ts; int32_t* ti; float* thr; uint32_t* cnt; uint32_t* flag; int32_t* ci; float* es;
     float* m; float* es_top;  // [n] the bound m_b of every query; [n x k] exact scores of the approximate top-k (second threshold)
     int32_t cap; bool one_product; float m_abs; const float* q_unscale;
+    uint64_t* bmax = nullptr;     // group maxima of the pivot route (one or two queries)
     const float* qsum = nullptr;  // [2 n] sum_i |q_i|, sum_i |q_lo,i| of every query where the query image carries them (launch_query_planes)
     bool m_ready = true;          // hb.m holds the bounds (a threshold kernel ran); false: exact_threshold_kernel computes them from qsum
     bool exact_kth;           // second, tighter threshold from the exact scores of the approximate top-k (RL_OPT_EXACT_KTH_THRESHOLD)
@@ -2146,8 +2147,11 @@ void hi_batch_layout(rl_index* idx, int32_t n, int32_t k, HiBatch& hb) {
     hb.es = reinterpret_cast<float*>(hb.ci + (size_t)n * hb.cap);          // [n x cap] their exact scores
     hb.m = hb.es + (size_t)n * hb.cap;                                     // [n]
     hb.es_top = hb.m + n;                                                  // [n x k]
+    hb.bmax = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(hb.es_top + (size_t)n * k) + 7) & ~uintptr_t(7));  // [min(n, 2) x 512] (few-queries pivot route)
 }
-size_t hi_batch_words(int32_t n, int32_t k) { return (size_t)n * k * 3 + (size_t)n * 3 + 16 + (size_t)n * 2048 * 2; }
+size_t hi_batch_words(int32_t n, int32_t k) {
+    return (size_t)n * k * 3 + (size_t)n * 3 + 16 + (size_t)n * 2048 * 2 + 2 + 2 * pivot_scratch_words(std::min<int32_t>(n, 2));
+}
 int hi_batch_approx(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queries, int32_t n_gemm, int32_t k, float* sc, int64_t ld, HiBatch& hb,
                     hipStream_t s, bool flag_zeroed = false) {
     // ONE product per multiply -- q_hi.e_hi only, a plain fp16 GEMM -- with the bound widened by what the queries' hi halves drop,
@@ -2296,6 +2300,25 @@ int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, 
     hi_batch_layout(idx, n, k, hb);
     hb.m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
     hb.q_unscale = nullptr;
+    // The pivot route (round 6, option hi_pivot; k <= 128, no tombstones): with the chip idle around one query, re-scoring ~2.5 x the candidates
+    // costs nothing, so the approximate scores need not be RANKED -- no top-k, no second threshold from its exact scores: the k-th largest of
+    // ~490 wave maxima bounds the k-th best from below, every chunk within 2 m of it is re-scored in ONE launch and ranked.  Four launches
+    // behind the pass (maxima + scale + bound, pivot + collection, exact scores, ranking) instead of nine.
+    if (idx->opt.on(RL_OPT_HI_PIVOT) && !idx->live_chunk_bits && k <= 128) {
+        HiBound bound;
+        bound.m_out = hb.m;
+        PivotMaxSim ms;
+        ms.nq = nq; ms.q_stride = q_elems; ms.m_abs = hb.m_abs; ms.fill_ids = hb.ci;
+        const int st_pv = launch_pivot_route(sc, n, idx->n_chunks, ld, k, nullptr, nullptr, d_q, idx->dim, SCAN_RAW_DOT, 1.0f / idx->split_scale, hb.bmax,
+                                             hb.cnt, n + 16, bound, hb.thr, hb.cap, hb.ci, nullptr, hb.cnt, hb.flag, s, nullptr, nullptr, nullptr, &ms);
+        if (st_pv == RL_OK) {
+            idx->filt = {RL_FILTER_MAXSIM_BATCH, n, hb.cap, hb.cnt, hb.flag};
+            RL_TRY(launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, q_elems, idx->offsets, hb.ci, hb.cap, n, hb.es, s, false, 0, 0, idx->opt.on(RL_OPT_PAIRS_PACKED)));
+            RL_TRY(launch_merge_topk(hb.es, hb.ci, 1, n, hb.cap, k, d_s, d_c, s, hb.cnt));
+            return hi_batch_fallback(idx, d_q, nq, n, n, k, sc, ld, hb, d_s, d_c, s, true);
+        }
+        if (st_pv != RL_ERR_UNSUPPORTED) return st_pv;
+    }
     // the plane holds fp16(e * scale), scale a power of two: undone exactly (the launch also zeroes the flag block: the two small memsets of
     // this route were six fill launches, 28 us of a 0.44 ms query)
     RL_TRY(launch_scale_f32(sc, sc, 1.0f / idx->split_scale, (int64_t)(n - 1) * ld + idx->n_chunks, s, hb.flag, 16));

@@ -221,11 +221,19 @@ int launch_rank_cut(float* scores, int32_t n_queries, int64_t n, int64_t ld, int
 int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const float* queries, int32_t dim, int mode, float m_rel,
                             float e_norm_bound, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s);  // also zeroes cnt[0..nb) and *flag
 // top_s / top_i [nb x k] (optional): the approximate top-k in selection order -- only entries ranking BELOW its k-th one are collected
+struct PivotMaxSim {                  // the MaxSim flavour of the pivot route (hi_filter.hip: transform_bmax_kernel)
+    int nq = 0;                       // query vectors per query (0: a row search)
+    int64_t q_stride = 0;             // floats between two queries
+    float m_abs = 0.f;                // m_b = m_abs * sum_i |q_i|
+    int32_t* fill_ids = nullptr;      // [nb x cap] candidate lists to pre-fill with -1
+    int64_t fill_n = 0;               // (set by the launcher)
+    int per_wave = 0;                 // (set by the launcher)
+};
 size_t pivot_scratch_words(int32_t nb);
 int launch_pivot_route(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t k, const float* row_norm, const float* row_sumsq, const float* queries,
                        int32_t dim, int mode, float pre_scale, uint64_t* bmax, uint32_t* zero_words, int n_zero, const HiBound& bound, float* thr,
                        int32_t cap, int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* E = nullptr,
-                       float* gather_out = nullptr, bool* gathered = nullptr);
+                       float* gather_out = nullptr, bool* gathered = nullptr, const PivotMaxSim* maxsim = nullptr);
 int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld, const float* thr, const float* row_norm, int32_t cap,
                          int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* top_s = nullptr,
                          const int32_t* top_i = nullptr, int32_t k = 0);

@@ -159,12 +159,18 @@ __global__ __launch_bounds__(256) void collect_above_kernel(const float* __restr
 __global__ __launch_bounds__(256) void transform_bmax_kernel(float* __restrict__ scores, int64_t n, int64_t ld, const float* __restrict__ row_norm,
                                                               const float* __restrict__ row_sumsq, const float* __restrict__ queries, int dim,
                                                               int mode, float pre_scale, uint64_t* __restrict__ bmax, uint32_t* __restrict__ zero_words,
-                                                              int n_zero, HiBound hb) {
+                                                              int n_zero, HiBound hb, PivotMaxSim ms) {
     __shared__ float part[4];
     __shared__ uint64_t wmax[4];
     typedef float f4 __attribute__((ext_vector_type(4)));
     const int b = blockIdx.y;
     if (blockIdx.x == 0 && b == 0 && (int)threadIdx.x < n_zero) zero_words[threadIdx.x] = 0u;
+    // MaxSim flavour (ms.nq > 0; the scores are chunk scores, mode = raw): the bound is m_abs * sum_i |q_i| over the query's nq vectors (the
+    // statement of maxsim_threshold_kernel: a wave per vector), computed by ONE workgroup per query AFTER its share of the scores (below);
+    // ms.fill_ids: the candidate lists start out as "no chunk" (-1) everywhere
+    if (ms.fill_ids)
+        for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 + threadIdx.x; i < ms.fill_n; i += (int64_t)gridDim.x * gridDim.y * 256)
+            ms.fill_ids[i] = -1;
     float* const sb = scores + (int64_t)b * ld;
     const int64_t stride = (int64_t)gridDim.x * 256;
     const bool vec = (ld & 3) == 0 && (reinterpret_cast<uintptr_t>(scores) & 15) == 0;  // (row_norm / row_sumsq are hipMalloc'd)
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256) void transform_bmax_kernel(float* __restrict__
         if (aux) a0 = reinterpret_cast<const f4*>(aux)[i_first];
     }
     float ss = 0.f;
-    for (int c = threadIdx.x; c < dim; c += 256) {
+    for (int c = threadIdx.x; c < dim && ms.nq == 0; c += 256) {
         const float v = queries[(int64_t)b * dim + c];
         ss = fmaf(v, v, ss);
     }
@@ -187,7 +193,7 @@ __global__ __launch_bounds__(256) void transform_bmax_kernel(float* __restrict__
     __syncthreads();
     const float qss = (part[0] + part[1]) + (part[2] + part[3]);
     const float qn = sqrtf(qss);
-    if (hb.m_out && blockIdx.x == 0 && threadIdx.x == 0)
+    if (hb.m_out && ms.nq == 0 && blockIdx.x == 0 && threadIdx.x == 0)
         hb.m_out[b] = mode == SCAN_COSINE ? hb.m_rel : hb.m_rel * hb.e_norm_bound * qn + 0x1p-22f;
     float bv = -INFINITY;  // ONE of this thread's best rows (the first of equal similarities; NaN / -inf never win)
     uint32_t bi = 0u;
@@ -229,11 +235,38 @@ __global__ __launch_bounds__(256) void transform_bmax_kernel(float* __restrict__
         const uint64_t other = ((uint64_t)hi << 32) | lo;
         mine = other > mine ? other : mine;
     }
-    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t m01 = wmax[0] > wmax[1] ? wmax[0] : wmax[1], m23 = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
-        bmax[(int64_t)b * gridDim.x + blockIdx.x] = m01 > m23 ? m01 : m23;
+    if (ms.per_wave) {  // few scores per query (MaxSim chunk scores): a maximum per WAVE -- 4 x gridDim.x groups
+        if ((threadIdx.x & 63) == 0) bmax[((int64_t)b * gridDim.x + blockIdx.x) * 4 + (threadIdx.x >> 6)] = mine;
+    } else {
+        if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = mine;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t m01 = wmax[0] > wmax[1] ? wmax[0] : wmax[1], m23 = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+            bmax[(int64_t)b * gridDim.x + blockIdx.x] = m01 > m23 ? m01 : m23;
+        }
+    }
+    if (ms.nq > 0 && hb.m_out && blockIdx.x == 0) {  // (workgroup-uniform)
+        const float* Qb = queries + (int64_t)b * ms.q_stride;
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        float w_norms = 0.f;
+        for (int i = wv; i < ms.nq; i += 4) {
+            float s2 = 0.f;
+            if ((dim & 3) == 0 && (ms.q_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(queries) & 15) == 0) {
+                const f4* row = reinterpret_cast<const f4*>(Qb + (int64_t)i * dim);
+                for (int c = lane; c < (dim >> 2); c += 64) {
+                    const f4 a = row[c];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) s2 = fmaf(a[u], a[u], s2);
+                }
+            } else {
+                for (int c = lane; c < dim; c += 64) { const float v = Qb[(int64_t)i * dim + c]; s2 = fmaf(v, v, s2); }
+            }
+            w_norms += sqrtf(wave_sum(s2));
+        }
+        __syncthreads();  // (part[] was read above by every thread)
+        if (lane == 0) part[wv] = w_norms;
+        __syncthreads();
+        if (threadIdx.x == 0) hb.m_out[b] = ms.m_abs * ((part[0] + part[1]) + (part[2] + part[3]));
     }
 }
 
@@ -611,24 +644,36 @@ int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const floa
     return RL_OK;
 }
 
-// The pivot route of the single-query row search: see transform_bmax_kernel.  bmax: pivot_scratch_words(nb) 8-byte words.  RL_ERR_UNSUPPORTED
-// where the route does not pay (fewer than 3 k workgroup maxima, k > 128).
+// The pivot route (see transform_bmax_kernel): candidates of a bound-filtered search without ranking the approximate scores.  bmax:
+// pivot_scratch_words(nb) 8-byte words.  RL_ERR_UNSUPPORTED where the route does not pay (fewer than 3 k group maxima, k > 128).
+// maxsim != nullptr: the scores are a MaxSim query's chunk scores (mode raw; `queries` = the queries' vectors, maxsim->q_stride floats apart):
+// bound m_b = m_abs * sum_i |q_i|, the lists pre-filled with -1 (maxsim_pairs_kernel walks every slot).
 size_t pivot_scratch_words(int32_t nb) { return (size_t)nb * 512; }
 int launch_pivot_route(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t k, const float* row_norm, const float* row_sumsq, const float* queries,
                        int32_t dim, int mode, float pre_scale, uint64_t* bmax, uint32_t* zero_words, int n_zero, const HiBound& bound, float* thr,
                        int32_t cap, int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* E, float* gather_out,
-                       bool* gathered) {
+                       bool* gathered, const PivotMaxSim* maxsim) {
     if (gathered) *gathered = false;
     if (n <= 0 || nb <= 0 || k < 1 || k > 128 || !bound.m_out) return RL_ERR_UNSUPPORTED;
     if (n_zero < 0 || n_zero > 256 || (n_zero > 0 && !zero_words)) return RL_ERR_INVALID;
-    const int G = (int)std::min<int64_t>((n + 2047) / 2048, 512);
-    if (G < 3 * k) return RL_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(transform_bmax_kernel, dim3(G, nb), dim3(256), 0, s, scores, n, ld, row_norm, row_sumsq, queries, (int)dim, mode, pre_scale, bmax,
-                       zero_words, n_zero, bound);
-    const int bx = (int)std::max<int64_t>(1, std::min<int64_t>((n + 4095) / 4096, 512));
+    PivotMaxSim ms = maxsim ? *maxsim : PivotMaxSim{};
+    if (maxsim && (ms.nq < 1 || mode != SCAN_RAW_DOT)) return RL_ERR_INVALID;
+    // groups: a maximum per workgroup of 2048 scores (up to 512 of them); a query with fewer scores than 3 k such groups gets one per WAVE
+    int bx = (int)std::min<int64_t>((n + 2047) / 2048, 512), G = bx;
+    ms.per_wave = 0;
+    if (G < 3 * k) {
+        bx = (int)std::min<int64_t>((n + 1023) / 1024, 128);
+        G = 4 * bx;
+        ms.per_wave = 1;
+        if (G < 3 * k) return RL_ERR_UNSUPPORTED;
+    }
+    if (ms.fill_ids) ms.fill_n = (int64_t)nb * cap;
+    hipLaunchKernelGGL(transform_bmax_kernel, dim3(bx, nb), dim3(256), 0, s, scores, n, ld, row_norm, row_sumsq, queries, (int)dim, mode, pre_scale, bmax,
+                       zero_words, n_zero, bound, ms);
+    const int cx = (int)std::max<int64_t>(1, std::min<int64_t>((n + 4095) / 4096, 512));
     // (the candidates' rows gathered by the collecting workgroups themselves where the layout allows 16-byte copies)
     const bool fuse = E && gather_out && gathered && (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(E) | reinterpret_cast<uintptr_t>(gather_out)) & 15) == 0;
-    hipLaunchKernelGGL(pivot_collect_kernel, dim3(bx, nb), dim3(256), 0, s, scores, n, ld, bmax, G, k, bound.m_out, thr,
+    hipLaunchKernelGGL(pivot_collect_kernel, dim3(cx, nb), dim3(256), 0, s, scores, n, ld, bmax, G, k, bound.m_out, thr,
                        mode == SCAN_COSINE ? row_norm : nullptr, cap, ids, norms, cnt, flag, fuse ? E : nullptr, (int)dim, fuse ? gather_out : nullptr);
     if (fuse) *gathered = true;
     RL_HIP(hipGetLastError());

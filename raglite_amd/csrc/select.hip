@@ -1266,21 +1266,22 @@ __global__ __launch_bounds__(1024) void merge_topk_kernel(const float* __restric
         buf[i] = key;
     }
     __syncthreads();
-    if (counts && total <= 256) {
+    if (counts && total <= 512) {
         // a candidate list of a bound-filtered search (one list, a few hundred DISTINCT ids at most): every record ranked by counting the larger
         // ones, a lane quad per record -- three barriers instead of the 28-36 of the sorting network (9-11 us per launch in every pipeline that
-        // ends here; padding records -- key 0 -- are not ranked)
-        uint64_t* const fin = buf + 256;
+        // ends here; padding records -- key 0 -- are not ranked; 257..512 records: a lane PAIR per record)
+        uint64_t* const fin = buf + 512;
         const int kk = total < k ? total : k;
         for (int i = threadIdx.x; i < kk; i += blockDim.x) fin[i] = 0ull;
         __syncthreads();
-        const int a = threadIdx.x >> 2;
+        const int per = total <= 256 ? 4 : 2;  // lanes per record
+        const int a = threadIdx.x / per, sub = threadIdx.x % per;
         const uint64_t mine = a < total ? buf[a] : 0ull;
         uint32_t rank = 0;
-        for (int j = (threadIdx.x & 3); j < total; j += 4) rank += buf[j] > mine;
+        for (int j = sub; j < total; j += per) rank += buf[j] > mine;
         rank += __shfl_xor(rank, 1, 64);
-        rank += __shfl_xor(rank, 2, 64);
-        if ((threadIdx.x & 3) == 0 && mine != 0ull && rank < (uint32_t)kk) fin[rank] = mine;
+        if (per == 4) rank += __shfl_xor(rank, 2, 64);
+        if (sub == 0 && mine != 0ull && rank < (uint32_t)kk) fin[rank] = mine;
         __syncthreads();
         write_results(fin, kk, k, out_scores + (int64_t)q * k, out_ids + (int64_t)q * k);
         return;

@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 echo "== $(date) start" | tee "$OUT/summary.txt"
-timeout 900 python -m pytest tests/test_gpu_hi_pivot.py tests/test_gpu_hi_few.py tests/test_gpu_hi_search.py -m gpu -q --timeout 600 > "$OUT/pytest_new.log" 2>&1; echo "pytest new exit $?" | tee -a "$OUT/summary.txt"
+timeout 900 python -m pytest tests/test_gpu_hi_pivot.py tests/test_gpu_hi_few.py tests/test_gpu_hi_search.py tests/test_gpu_hi_maxsim.py -m gpu -q --timeout 600 > "$OUT/pytest_new.log" 2>&1; echo "pytest new exit $?" | tee -a "$OUT/summary.txt"
 grep -a "passed\|failed\|^FAILED\|^ERROR\|^E  " "$OUT/pytest_new.log" | tail -30 | cut -c1-300 | tee -a "$OUT/summary.txt"
 for o in 1 0; do
   timeout 300 python scripts/bench_configs.py cfg2 hi_pivot=$o > "$OUT/cfg2_$o.json" 2> "$OUT/cfg2_$o.err"; python - "$OUT/cfg2_$o.json" <<'PY' | tee -a "$OUT/summary.txt"

@@ -23,6 +23,15 @@ pytestmark = pytest.mark.gpu
 N, DIM = 70_000, 1024  # >= 64 M elements: the index may keep a HI plane
 
 
+@pytest.fixture(autouse=True, params=[1, 0], ids=["pivot", "ranked"])
+def _both_candidate_routes(request):
+    """Every case under hi_pivot = 1 (round 6: the candidates from a pivot over group maxima, no approximate ranking; k <= 128 and >= 3 k groups)
+    and hi_pivot = 0 (top-k of the approximate scores + second threshold): one result."""
+    raglite_amd.set_default_option("hi_pivot", request.param)
+    yield
+    raglite_amd.set_default_option("hi_pivot", 1)
+
+
 def _route(idx):
     st = idx.filter_stats()
     return st["kind"], bool(st["fallback"])

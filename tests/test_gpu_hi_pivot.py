@@ -108,3 +108,67 @@ def test_pivot_route_where_it_does_not_apply_and_after_append():
     assert np.array_equal(R, R0) and _same(S, S0)
     idx.close()
     ref.close()
+
+
+# ---- the same idea for ONE or TWO MaxSim queries (api.hip: maxsim_few_hi_plane): chunk scores instead of row similarities, a maximum per wave ----
+@pytest.mark.parametrize("n_queries,nq,k", [(1, 32, 100), (2, 32, 128), (2, 5, 64), (1, 1, 7)])
+def test_few_maxsim_queries_pivot_route_integer_bit_exact(n_queries, nq, k):
+    """`sum_i max_j q_i . d_j` per chunk (`/root/reference/src/raglite/_search.py:143-149,394-396` generalised), 100 k chunks of 1-2 rows: the
+    route applies (>= 3 k wave maxima); scores and chunk ordinals bit-identical to the oracle and to the ranked route."""
+    from tests.util import ragged_offsets
+
+    rng = np.random.default_rng(40 + nq)
+    n, dim = 160_000, 512
+    off = ragged_offsets(rng, n, 1, 2)
+    E = oracle.synth_matrix(9850 + nq, n, dim, "small_int")
+    Qb = np.stack([oracle.synth_matrix(9860 + i + nq, nq, dim, "small_int") for i in range(n_queries)])
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    assert idx.n_chunks >= 3 * k * 256
+    S, Cc = idx.maxsim_topk_batch(Qb, k)
+    st = idx.filter_stats()
+    with idx.options(hi_pivot=0):
+        S1, C1 = idx.maxsim_topk_batch(Qb, k)
+        st1 = idx.filter_stats()
+    assert st["kind"] == st1["kind"] == "maxsim_batch_hi" and not st["fallback"] and not st1["fallback"]
+    assert np.array_equal(Cc, C1) and _same(S, S1)
+    assert st["candidates_per_query_mean"] >= st1["candidates_per_query_mean"] >= k
+    assert st["candidates_per_query_max"] < 2048
+    for i in range(n_queries):
+        ws, wc = oracle.maxsim_topk(E, off, Qb[i], k, np.float32)
+        assert np.array_equal(Cc[i], wc) and np.array_equal(S[i], ws)
+    s1, c1 = idx.maxsim_topk(Qb[0], k)  # the single-query entry point
+    assert np.array_equal(c1, Cc[0]) and _same(s1, S[0])
+    idx.close()
+
+
+def test_few_maxsim_queries_pivot_route_float_data_and_fallback():
+    from tests.util import ragged_offsets
+
+    rng = np.random.default_rng(50)
+    n, dim, k = 140_000, 512, 100  # (>= 64 M elements: the index keeps a HI plane)
+    off = np.arange(n + 1, dtype=np.int64)
+    E = oracle.synth_matrix(9870, n, dim)
+    Q = oracle.synth_matrix(9871, 8, dim)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    s, c = idx.maxsim_topk(Q, k)
+    st = idx.filter_stats()
+    assert st["kind"] == "maxsim_batch_hi" and not st["fallback"] and k <= st["candidates_per_query_max"] < 2048
+    with idx.options(hi_few=0):
+        fs, fc = idx.maxsim_topk(Q, k)
+    ref = oracle.maxsim_scores(E, off, Q, np.float64)
+    tol = 2e-6 * float(np.abs(ref).max())
+    assert_topk_close(s, c, ref, k, tol)
+    assert set(c.tolist()) == set(fc.tolist())
+    # 4 000 near-identical chunks at the top: the lists overflow, the guarded pass over the rows answers -- the bits of hi_few = 0
+    hot = rng.choice(n, 4000, replace=False)
+    E2 = E.copy()
+    E2[hot] = (3.0 * Q.sum(axis=0)[None, :] + 1e-4 * rng.standard_normal((4000, dim))).astype(np.float32)
+    idx2 = raglite_amd.DeviceIndex(E2, off, metric="dot")
+    s, c = idx2.maxsim_topk(Q, k)
+    st = idx2.filter_stats()
+    assert st["kind"] == "maxsim_batch_hi" and st["fallback"]
+    with idx2.options(hi_few=0):
+        fs, fc = idx2.maxsim_topk(Q, k)
+    assert np.array_equal(c, fc) and _same(s, fs)
+    idx.close()
+    idx2.close()
