@@ -60,12 +60,15 @@ __device__ __forceinline__ void collect_rows(const float* __restrict__ s, int64_
     constexpr uint32_t LOCAL = 1024;
     if (threadIdx.x == 0) *l_n = 0u;
     __syncthreads();
-    auto visit = [&](float v, int64_t i, bool in_range) {
+    auto test = [&](float v, int64_t i, bool in_range) {
         bool hit = in_range && v >= t;
         if (below_top) {
             const uint32_t kv = score_key(v);
             hit = hit && (kv < key_k || (kv == key_k && i > id_k));
         }
+        return hit;
+    };
+    auto append = [&](bool hit, int64_t i) {
         const uint64_t mask = __builtin_amdgcn_ballot_w64(hit);
         if (mask == 0ull) return;  // (wave-uniform)
         const int lane = threadIdx.x & 63;
@@ -77,18 +80,27 @@ __device__ __forceinline__ void collect_rows(const float* __restrict__ s, int64_
             if (p < LOCAL) l_ids[p] = (int32_t)i;
         }
     };
+    auto visit = [&](float v, int64_t i, bool in_range) { append(test(v, i, in_range), i); };
     const int64_t stride = (int64_t)gridDim.x * 256;
     if (vec) {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4* s4 = reinterpret_cast<const f4*>(s);
         const int64_t n4 = n >> 2;
-        // (whole waves walk the loop together -- the ballot needs every lane -- so the trip count is rounded up per block)
-        for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n4; i0 += stride) {
-            const int64_t i = i0 + threadIdx.x;
-            const bool in = i < n4;
-            const f4 v = in ? s4[i] : (f4){0.f, 0.f, 0.f, 0.f};
+        // (whole waves walk the loop together -- the ballots need every lane -- so the trip count is rounded up per block; two 16-byte loads
+        // in flight per lane, ONE ballot per group of four scores where nothing passes: the common case by four orders of magnitude)
+        for (int64_t i0 = (int64_t)blockIdx.x * 256; i0 < n4; i0 += 2 * stride) {
+            const int64_t ia = i0 + threadIdx.x, ib = ia + stride;
+            const bool in_a = ia < n4, in_b = ib < n4;
+            const f4 va = in_a ? s4[ia] : (f4){0.f, 0.f, 0.f, 0.f};
+            const f4 vb = in_b ? s4[ib] : (f4){0.f, 0.f, 0.f, 0.f};
+            bool ha[4], hb[4], any = false;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) visit(v[u], (i << 2) + u, in);
+            for (int u = 0; u < 4; ++u) { ha[u] = test(va[u], (ia << 2) + u, in_a); hb[u] = test(vb[u], (ib << 2) + u, in_b); any |= ha[u] | hb[u]; }
+            if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;  // (wave-uniform)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) append(ha[u], (ia << 2) + u);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) append(hb[u], (ib << 2) + u);
         }
         if (blockIdx.x == 0 && threadIdx.x < 64) {  // the n % 4 rows at the end: one wave
             const bool in = threadIdx.x < (n & 3);

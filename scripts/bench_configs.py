@@ -300,6 +300,14 @@ def cfg4():
     }
 
 
+def cfg4_end_to_end():
+    """cfg 4 from the TEXT: ~3.2 M token rows through the PyTorch-ROCm encoder (`_torch_embedder.py`, bge-m3's architecture, random weights)
+    and `rl_pool_norm` on the device -- `embed_strings` as the reference's indexing calls it (src/raglite/_embed.py:64-66,119,151-154)."""
+    import bench_embed
+
+    return bench_embed.run(66_000)
+
+
 def cfg5():
     """BASELINE cfg 5, the per-GPU part: a 1.25 M x 1024 shard of the 10 M-row corpus, 1000 queries, cosine exact
     top-100 (the all-gather merge of the 8 shards is tests/test_sharded_gloo.py / bench.py --gpus N)."""
