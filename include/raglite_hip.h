@@ -227,8 +227,9 @@ int rl_index_arithmetic(rl_index* index, int* in_effect);
  *   RL_OPT_KEEP_HI_PLANE        0 / 1 (1)          keep the row-major HI plane (2 B per element; what B <= 16 row searches rank on)
  *   RL_OPT_IMAGE_HEADROOM_MB    -1 | >= 0 (-1)     device memory the images must leave free (-1: max(2 GiB, 1/16 of the device))
  *   RL_OPT_ARITHMETIC           rl_arith (AUTO)    same as rl_index_set_arithmetic
- *   RL_OPT_PAIRS_PACKED         0 / 1 (1)          exact re-scoring of (query, chunk) pairs packs the candidates' rows into shared 16-row MFMA
- *                                                  tiles (0: every chunk its own tiles; same bits)
+ *   RL_OPT_PAIRS_PACKED         0 / 1 / 2 (2)      exact re-scoring of (query, chunk) pairs packs the candidates' rows into shared 16-row MFMA
+ *                                                  tiles (0: every chunk its own tiles; same bits); 2: sixteen waves per workgroup instead of eight
+ *                                                  (fp32 rows, dim % 128 == 0)
  *   RL_OPT_EXACT_KTH_THRESHOLD  0 / 1 (1)          MaxSim batches: second, tighter candidate threshold from the EXACT scores of the
  *                                                  approximate top-k (exact k-th - m instead of approximate k-th - 2 m)
  *   RL_OPT_F16_EXACT            0 / 1 (1)          rl_maxsim_topk_batch_f16 over an fp16-stored index returns the one-product pass's own top-k

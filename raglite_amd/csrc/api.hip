@@ -200,8 +200,8 @@ struct Options {
         for (auto& x : v) x = 0;
         v[RL_OPT_HI_SEARCH] = v[RL_OPT_HI_MAXSIM] = v[RL_OPT_HI_PRODUCTS] = v[RL_OPT_PP_PASS] = v[RL_OPT_FUSED_TOPK] = v[RL_OPT_FUSED_HI] = 1;
         v[RL_OPT_FUSED_PP] = v[RL_OPT_GEMM_PASS] = v[RL_OPT_QUERY_PAIRS] = v[RL_OPT_PLANES_GEMM] = v[RL_OPT_KEEP_IMAGE] = v[RL_OPT_KEEP_HI] = 1;
-        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_PAIRS_PACKED] = v[RL_OPT_F16_EXACT] = v[RL_OPT_LAZY_IMAGES] = v[RL_OPT_FUSED_PP_SAMPLE] = v[RL_OPT_LIST_SELECT] = v[RL_OPT_HI_FEW] = 1;
-        v[RL_OPT_TOPK_BLOCK] = 2;
+        v[RL_OPT_EXACT_KTH_THRESHOLD] = v[RL_OPT_FUSED_TWO_ROUNDS] = v[RL_OPT_KEEP_HI_PLANE] = v[RL_OPT_F16_EXACT] = v[RL_OPT_LAZY_IMAGES] = v[RL_OPT_FUSED_PP_SAMPLE] = v[RL_OPT_LIST_SELECT] = v[RL_OPT_HI_FEW] = 1;
+        v[RL_OPT_TOPK_BLOCK] = v[RL_OPT_PAIRS_PACKED] = 2;
         v[RL_OPT_HI_PIVOT] = 1;
         v[RL_OPT_IMAGE_HEADROOM_MB] = -1;
         v[RL_OPT_ARITHMETIC] = RL_ARITH_AUTO;
@@ -214,9 +214,9 @@ bool option_value_ok(int key, int64_t value) {
     switch (key) {
         case RL_OPT_HI_SEARCH: case RL_OPT_HI_MAXSIM: case RL_OPT_PP_PASS: case RL_OPT_FUSED_TOPK: case RL_OPT_FUSED_HI: case RL_OPT_FUSED_PP:
         case RL_OPT_GEMM_PASS: case RL_OPT_QUERY_PAIRS: case RL_OPT_PLANES_GEMM: case RL_OPT_KEEP_IMAGE: case RL_OPT_KEEP_HI:
-        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_PAIRS_PACKED: case RL_OPT_F16_EXACT: case RL_OPT_LAZY_IMAGES: case RL_OPT_FUSED_PP_SAMPLE: case RL_OPT_LIST_SELECT: case RL_OPT_HI_FEW: case RL_OPT_HI_PIVOT:
+        case RL_OPT_EXACT_KTH_THRESHOLD: case RL_OPT_FUSED_TWO_ROUNDS: case RL_OPT_KEEP_HI_PLANE: case RL_OPT_F16_EXACT: case RL_OPT_LAZY_IMAGES: case RL_OPT_FUSED_PP_SAMPLE: case RL_OPT_LIST_SELECT: case RL_OPT_HI_FEW: case RL_OPT_HI_PIVOT:
             return value == 0 || value == 1;
-        case RL_OPT_TOPK_BLOCK: return value >= 0 && value <= 2;
+        case RL_OPT_TOPK_BLOCK: case RL_OPT_PAIRS_PACKED: return value >= 0 && value <= 2;
         case RL_OPT_HI_PRODUCTS: return value == 1 || value == 2;
         case RL_OPT_FUSED_TOPK_CAP: return value >= 0 && value <= MERGE_CAP;
         case RL_OPT_FUSED_TOPK_STRIDE: return value == 0 || (value >= 2 && value <= (int64_t(1) << 20));
@@ -2196,7 +2196,7 @@ int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_quer
     const float* rows = idx->E16 ? reinterpret_cast<const float*>(idx->E16) : idx->E;
     const bool rows16 = idx->E16 != nullptr;
     idx->filt = {RL_FILTER_MAXSIM_BATCH, n_gemm, hb.cap, hb.cnt, hb.flag};
-    const bool packed = idx->opt.on(RL_OPT_PAIRS_PACKED);
+    const int packed = (int)idx->opt.v[RL_OPT_PAIRS_PACKED];
     const bool m_from_qsum = !hb.m_ready && hb.qsum != nullptr;
     if (!hb.m_ready && !(hb.exact_kth && k <= hb.cap && hb.qsum)) return fail(RL_ERR_INVALID, "MaxSim batch: no bound for the candidate threshold");
     if (hb.exact_kth && k <= hb.cap) {
@@ -2313,7 +2313,7 @@ int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, 
                                              hb.cnt, n + 16, bound, hb.thr, hb.cap, hb.ci, nullptr, hb.cnt, hb.flag, s, nullptr, nullptr, nullptr, &ms);
         if (st_pv == RL_OK) {
             idx->filt = {RL_FILTER_MAXSIM_BATCH, n, hb.cap, hb.cnt, hb.flag};
-            RL_TRY(launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, q_elems, idx->offsets, hb.ci, hb.cap, n, hb.es, s, false, 0, 0, idx->opt.on(RL_OPT_PAIRS_PACKED)));
+            RL_TRY(launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, q_elems, idx->offsets, hb.ci, hb.cap, n, hb.es, s, false, 0, 0, (int)idx->opt.v[RL_OPT_PAIRS_PACKED]));
             RL_TRY(launch_merge_topk(hb.es, hb.ci, 1, n, hb.cap, k, d_s, d_c, s, hb.cnt));
             return hi_batch_fallback(idx, d_q, nq, n, n, k, sc, ld, hb, d_s, d_c, s, true);
         }
@@ -2645,7 +2645,7 @@ int rl_maxsim_rerank(rl_index* idx, const float* query_vecs, int32_t n_queries, 
                       : launch_maxsim_cand(idx->E, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s, idx->split_scale);
     if (st == RL_ERR_UNSUPPORTED && !idx->E16)  // other dims: the fp32-MFMA pairs kernel (dim % 16 == 0, <= 1024, nq <= 32) ...
         st = launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, d_c, n_cand, n_queries, d_o, s, false, 0, 0,
-                                 idx->opt.on(RL_OPT_PAIRS_PACKED));
+                                 (int)idx->opt.v[RL_OPT_PAIRS_PACKED]);
     if (st == RL_ERR_UNSUPPORTED && !idx->E16)  // ... and the VALU backstop for everything else
         st = launch_maxsim_generic(idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, d_c, n_cand,
                                    n_queries, d_o, s);

@@ -401,7 +401,7 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
                         bool rows16 = false,  // rows16: D points at fp16 rows (an fp16-stored corpus)
                         int64_t item_stride = 0, int64_t first_item = 0,  // lists of `item_stride` (0: n_items_per_query) entries per query, of
                                                                           // which entries first_item .. first_item + n_items_per_query - 1 are scored
-                        bool packed = true);  // dim % 128 == 0: the row-packing kernel (same bits, about half the matrix work on short chunks)
+                        int packed = 1);  // 0: a chunk per tile; 1: rows packed into shared tiles; 2: ... by sixteen waves per workgroup  // dim % 128 == 0: the row-packing kernel (same bits, about half the matrix work on short chunks)
 int launch_maxsim_generic(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride_queries,
                           const int64_t* chunk_offsets, const int32_t* candidates, int64_t n_items,
                           int32_t n_queries, float* out, hipStream_t s);

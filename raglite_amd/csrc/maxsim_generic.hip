@@ -250,8 +250,10 @@ __global__ __launch_bounds__(512) void maxsim_pairs_kernel(const float* __restri
 // exact, the sum tree is the same: identical bits (tests/test_gpu_pairs_packed.py).  dim % KB == 0 only (the other shapes keep the kernel above).
 // DBG (experiment builds only, WRONG results): 1 = no MFMAs (the loads and the walk alone), 2 = the rows are loaded once per batch (the matrix
 // work and the walk alone), 4 = no query staging
-template <int KB, bool ROW16, int DBG = 0>
-__global__ __launch_bounds__(512) void maxsim_pairs_packed_kernel(const float* __restrict__ D, int dim, const float* __restrict__ Q, int nq,
+// NW: waves per workgroup (8; 16 -- option pairs_packed = 2, with KB = 128 so that a wave fits 128 VGPRs -- puts four waves on every SIMD
+// instead of two: the same bytes in flight per CU, twice the waves to fill the matrix pipe while others wait for their rows)
+template <int KB, bool ROW16, int DBG = 0, int NW = 8>
+__global__ __launch_bounds__(NW * 64) void maxsim_pairs_packed_kernel(const float* __restrict__ D, int dim, const float* __restrict__ Q, int nq,
                                                                    int64_t q_stride, const int64_t* __restrict__ offsets,
                                                                    const int32_t* __restrict__ candidates, int64_t n_items, int64_t item_stride,
                                                                    float* __restrict__ out) {
@@ -261,7 +263,7 @@ __global__ __launch_bounds__(512) void maxsim_pairs_packed_kernel(const float* _
     const int32_t* cb = candidates + (int64_t)blockIdx.y * item_stride;
     float* ob = out + (int64_t)blockIdx.y * item_stride;
     if constexpr ((DBG & 16) != 0) return;  // (timing: the launch alone)
-    for (int i = threadIdx.x * 4; i < 32 * dim && !(DBG & 4); i += 512 * 4) {
+    for (int i = threadIdx.x * 4; i < 32 * dim && !(DBG & 4); i += NW * 64 * 4) {
         const int n = i / dim, c = i - n * dim;
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (n < nq) v = *reinterpret_cast<const f32x4*>(Qb + (int64_t)n * dim + c);
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(512) void maxsim_pairs_packed_kernel(const float* _
     const int m = lane & 15, g = lane >> 4;
     const float* q0 = qs + m * pitch + 4 * g;
     const float* q1 = qs + (16 + m) * pitch + 4 * g;
-    const int64_t stride = (int64_t)gridDim.x * 8;
+    const int64_t stride = (int64_t)gridDim.x * NW;
     constexpr int NL = KB / 16;
     auto request = [&](f32x4 (&x)[NL], int32_t row, int t0) __attribute__((always_inline)) {
         if constexpr ((DBG & 2) != 0) row = m;  // (timing: always the same sixteen rows, cache-resident)
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(512) void maxsim_pairs_packed_kernel(const float* _
         }
     };
     f32x4 xc[NL], xn[NL];
-    for (int64_t base = (int64_t)blockIdx.x * 8 + w; base < n_items; base += 64 * stride) {
+    for (int64_t base = (int64_t)blockIdx.x * NW + w; base < n_items; base += 64 * stride) {
         const int64_t mine = base + (int64_t)lane * stride;
         int32_t vb = 0, ve = 0;  // (row numbers fit 31 bits: rl_index_create)
         if (mine < n_items) {
@@ -417,7 +419,8 @@ __global__ __launch_bounds__(512) void maxsim_pairs_packed_kernel(const float* _
 
 int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride, const int64_t* offsets,
                         const int32_t* candidates, int64_t n_items_per_query, int32_t n_queries, float* out, hipStream_t s, bool rows16,
-                        int64_t item_stride, int64_t first_item, bool packed) {
+                        int64_t item_stride, int64_t first_item, int packed_mode) {
+    bool packed = packed_mode != 0;
     if (n_items_per_query <= 0 || n_queries <= 0) return RL_OK;
     if (item_stride <= 0) item_stride = n_items_per_query;
     if (first_item < 0 || first_item + n_items_per_query > item_stride) return RL_ERR_INVALID;
@@ -434,6 +437,7 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
         RL_PACKED_ATTR(128, false);
         RL_PACKED_ATTR(256, true);
         RL_PACKED_ATTR(128, true);
+        RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_packed_kernel<128, false, 0, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
 #undef RL_PACKED_ATTR
         RL_PAIRS_ATTR(true, 256, false);
         RL_PAIRS_ATTR(true, 128, false);
@@ -448,7 +452,9 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
     // (the packing kernel wants MANY candidates per wave -- its padding is one partial tile per wave and batch: one workgroup per CU and round)
     const bool full = dim % 128 == 0;
     packed = packed && full;
-    int per_query = (int)std::max<int64_t>(1, std::min<int64_t>((n_items_per_query + 7) / 8, std::max<int64_t>(1, (packed ? 256 : 512) / n_queries)));
+    const bool wide = packed && packed_mode == 2 && !rows16;  // sixteen waves per workgroup (KB = 128)
+    const int nw = wide ? 16 : 8;
+    int per_query = (int)std::max<int64_t>(1, std::min<int64_t>((n_items_per_query + nw - 1) / nw, std::max<int64_t>(1, (packed ? 256 : 512) / n_queries)));
 #ifdef RAGLITE_EXPERIMENTS  // A/B of the split of a query's list over workgroups (scripts/gpu_calls/)
     if (const char* e = exp_env("RAGLITE_PAIRS_WG_BUDGET")) {
         const int budget = std::atoi(e);
@@ -496,7 +502,10 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
         return RL_OK;
     }
 #endif
-    if (packed && dim % 256 == 0) RL_PACKED(256);
+    if (wide)
+        hipLaunchKernelGGL((maxsim_pairs_packed_kernel<128, false, 0, 16>), dim3(per_query, n_queries), dim3(1024), lds, s, D, (int)dim, Q, (int)nq, q_stride,
+                           offsets, candidates, n_items_per_query, item_stride, out);
+    else if (packed && dim % 256 == 0) RL_PACKED(256);
     else if (packed && dim % 128 == 0) RL_PACKED(128);
     else if (dim % 256 == 0) RL_PAIRS(true, 256);
     else if (dim % 128 == 0) RL_PAIRS(true, 128);

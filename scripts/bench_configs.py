@@ -305,7 +305,7 @@ def cfg4_end_to_end():
     and `rl_pool_norm` on the device -- `embed_strings` as the reference's indexing calls it (src/raglite/_embed.py:64-66,119,151-154)."""
     import bench_embed
 
-    return bench_embed.run(66_000)
+    return bench_embed.run(100_000)
 
 
 def cfg5():

@@ -28,11 +28,16 @@ from raglite_amd._torch_embedder import TorchTokenEmbedder  # noqa: E402
 
 
 def sentences(n: int, seed: int = 0) -> list[str]:
+    """n sentences of 4-19 words drawn from a fixed vocabulary of 20 000 random words of 2-8 letters (the hashing tokenizer stand-in keeps one id
+    per distinct piece: unbounded random words would fill its 250 k-entry table at cfg 4's scale)."""
     rng = np.random.default_rng(seed)
-    out = []
-    for _ in range(n):
-        words = ["".join(chr(97 + int(c)) for c in rng.integers(0, 26, size=int(rng.integers(2, 9))))
-                 for _ in range(int(rng.integers(4, 20)))]
+    vocab = ["".join(chr(97 + int(c)) for c in rng.integers(0, 26, size=int(rng.integers(2, 9)))) for _ in range(20_000)]
+    lens = rng.integers(4, 20, size=n)
+    picks = rng.integers(0, len(vocab), size=int(lens.sum()))
+    out, at = [], 0
+    for ln in lens:
+        words = [vocab[i] for i in picks[at : at + ln]]
+        at += int(ln)
         out.append(" ".join(words).capitalize() + ". ")
     return out
 

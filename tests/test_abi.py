@@ -125,7 +125,7 @@ def test_default_options_without_gpu():
     defaults = {"hi_search": 1, "hi_maxsim": 1, "hi_products": 1, "pp_pass": 1, "fused_topk": 1, "fused_hi": 1, "fused_pp": 1,
                 "fused_topk_cap": 0, "fused_topk_stride": 0, "gemm_pass": 1, "query_pairs": 1, "planes_gemm": 1, "keep_image": 1,
                 "keep_hi": 1, "image_headroom_mb": -1, "arithmetic": 0, "exact_kth_threshold": 1, "fused_two_rounds": 1,
-                "keep_hi_plane": 1, "pairs_packed": 1, "f16_exact": 1, "lazy_images": 1, "fused_pp_sample": 1, "list_select": 1, "hi_few": 1, "topk_block": 2, "hi_pivot": 1}
+                "keep_hi_plane": 1, "pairs_packed": 2, "f16_exact": 1, "lazy_images": 1, "fused_pp_sample": 1, "list_select": 1, "hi_few": 1, "topk_block": 2, "hi_pivot": 1}
     assert set(defaults) == set(_abi.OPTIONS)
     for name, want in defaults.items():
         assert lib.rl_get_default_option(_abi.OPTIONS[name], C.byref(v)) == _abi.RL_OK and v.value == want, name

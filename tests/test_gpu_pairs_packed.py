@@ -44,10 +44,13 @@ def test_packed_equals_unpacked_bitwise(dim, layout, nq, n_queries, n_cand):
     cand = rng.integers(0, n_chunks, (n_queries, n_cand)).astype(np.int32)
     cand[rng.random(cand.shape) < 0.05] = -1  # the padding of a search result
     idx = raglite_amd.DeviceIndex(E, off, metric="dot")
-    packed = idx.maxsim_rerank(Q, cand)
+    packed = idx.maxsim_rerank(Q, cand)  # (the default, pairs_packed = 2: sixteen waves per workgroup, round 6)
     with idx.options(pairs_packed=0):
         plain = idx.maxsim_rerank(Q, cand)
+    with idx.options(pairs_packed=1):
+        eight = idx.maxsim_rerank(Q, cand)
     assert np.array_equal(packed.view(np.uint32), plain.view(np.uint32))
+    assert np.array_equal(eight.view(np.uint32), plain.view(np.uint32))
     empty = np.diff(off)[np.maximum(cand, 0)] == 0
     assert np.isneginf(packed[(cand < 0) | empty]).all() and np.isfinite(packed[(cand >= 0) & ~empty]).all()
     idx.close()
@@ -82,7 +85,8 @@ def test_batch_pipeline_same_bits_with_either_kernel(storage):
     s1, c1 = idx.maxsim_topk_batch(Qb, 100)
     st = idx.filter_stats()
     assert st["kind"] == "maxsim_batch_hi" and not st["fallback"]
-    with idx.options(pairs_packed=0):
-        s0, c0 = idx.maxsim_topk_batch(Qb, 100)
-    assert np.array_equal(c0, c1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32))
+    for mode in (0, 1):
+        with idx.options(pairs_packed=mode):
+            s0, c0 = idx.maxsim_topk_batch(Qb, 100)
+        assert np.array_equal(c0, c1) and np.array_equal(s0.view(np.uint32), s1.view(np.uint32)), mode
     idx.close()
