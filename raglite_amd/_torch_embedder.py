@@ -74,9 +74,11 @@ class HashTokenizer:
             for b in p.encode():
                 h = ((h ^ b) * 16777619) & 0xFFFFFFFF
             tid = self.reserved + h % (self.vocab_size - self.reserved)
-            while self._piece_of.get(tid, p) != p:  # keep decode a function under hash collisions
+            for _ in range(64):  # keep decode a function under hash collisions (linear probing, bounded: a table that is filling up --
+                if self._piece_of.get(tid, p) == p:  # more distinct pieces than ids -- lets pieces share an id instead of probing for ever)
+                    break
                 tid = self.reserved + (tid + 1 - self.reserved) % (self.vocab_size - self.reserved)
-            self._piece_of[tid] = p
+            self._piece_of.setdefault(tid, p)
             ids.append(tid)
         return ids
 
