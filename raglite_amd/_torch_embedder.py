@@ -20,6 +20,7 @@ it); without a model file the fallback is `HashTokenizer`, a deterministic hashi
 
 from __future__ import annotations
 
+import itertools
 from dataclasses import dataclass
 from typing import Any
 
@@ -51,6 +52,8 @@ class HashTokenizer:
     def __init__(self, vocab_size: int, reserved: int = 8) -> None:
         self.vocab_size, self.reserved = vocab_size, reserved
         self._piece_of: dict[int, str] = {}
+        self._id_of: dict[str, int] = {}
+        self._ids_of_run: dict[str, tuple[int, ...]] = {}
 
     @staticmethod
     def _pieces(text: str) -> list[str]:
@@ -67,9 +70,9 @@ class HashTokenizer:
                 i += 1
         return out
 
-    def encode(self, text: str) -> list[int]:
-        ids = []
-        for p in self._pieces(text):
+    def _id(self, p: str) -> int:
+        tid = self._id_of.get(p)
+        if tid is None:
             h = 2166136261
             for b in p.encode():
                 h = ((h ^ b) * 16777619) & 0xFFFFFFFF
@@ -79,7 +82,24 @@ class HashTokenizer:
                     break
                 tid = self.reserved + (tid + 1 - self.reserved) % (self.vocab_size - self.reserved)
             self._piece_of.setdefault(tid, p)
-            ids.append(tid)
+            self._id_of[p] = tid
+        return tid
+
+    def encode(self, text: str) -> list[int]:
+        """The ids of `_pieces(text)`, with the pieces of every alphanumeric run remembered per run (natural text repeats its words: a
+        SentencePiece model tokenises in C++, this stand-in should not be what an embedding benchmark measures)."""
+        ids: list[int] = []
+        for alnum, grp in itertools.groupby(text, key=str.isalnum):
+            run = "".join(grp)
+            if alnum:
+                got = self._ids_of_run.get(run)
+                if got is None:
+                    got = tuple(self._id(run[i : i + 4]) for i in range(0, len(run), 4))
+                    if len(self._ids_of_run) < 1_000_000:
+                        self._ids_of_run[run] = got
+                ids.extend(got)
+            else:
+                ids.extend(self._id(c) for c in run)
         return ids
 
     def decode(self, ids: list[int]) -> str:

@@ -2313,7 +2313,10 @@ int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, 
                                              hb.cnt, n + 16, bound, hb.thr, hb.cap, hb.ci, nullptr, hb.cnt, hb.flag, s, nullptr, nullptr, nullptr, &ms);
         if (st_pv == RL_OK) {
             idx->filt = {RL_FILTER_MAXSIM_BATCH, n, hb.cap, hb.cnt, hb.flag};
-            RL_TRY(launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, q_elems, idx->offsets, hb.ci, hb.cap, n, hb.es, s, false, 0, 0, (int)idx->opt.v[RL_OPT_PAIRS_PACKED]));
+            // (one candidate per wave here: the eight-wave kernel's 256-k blocks -- half as many dependent HBM round trips per tile -- suit it better
+            // than the sixteen-wave variant's 128-k blocks, which pay when a wave has many tiles to pipeline)
+            RL_TRY(launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, q_elems, idx->offsets, hb.ci, hb.cap, n, hb.es, s, false, 0, 0,
+                                       std::min<int>(1, (int)idx->opt.v[RL_OPT_PAIRS_PACKED])));
             RL_TRY(launch_merge_topk(hb.es, hb.ci, 1, n, hb.cap, k, d_s, d_c, s, hb.cnt));
             return hi_batch_fallback(idx, d_q, nq, n, n, k, sc, ld, hb, d_s, d_c, s, true);
         }

@@ -308,6 +308,47 @@ def cfg4_end_to_end():
     return bench_embed.run(100_000)
 
 
+def beyond_shape():
+    """What the fast paths do NOT cover: correct everywhere, slower outside the headline's shape.  The reference accepts any
+    litellm embedder (src/raglite/_embed.py:155-158: 1536- / 3072-wide models) and `l2` (_config.py:69); this block puts a number on those routes."""
+    out = {"workload": "routes outside the fast paths: dim 1536 MaxSim batch, l2 single-query search, k = 1000", "unit": "queries/s", "value": None}
+    # (1) MaxSim, 64 queries x 32 vectors over 300 k x 1536 (the HI routes need dim <= 1024)
+    n, d = 300_000, 1536
+    E = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=5)
+    off = np.arange(0, n + 1, 8, dtype=np.int64)
+    if off[-1] != n:
+        off = np.concatenate((off, [n]))
+    Q = torch.empty((64, 32, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=50)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    ms = timed(lambda: idx.maxsim_topk_batch(Q, 100), 5, 2)
+    out["maxsim_dim1536"] = {"rows": n, "dim": d, "queries_per_step": 64, "value": 64e3 / ms, "ms_per_step": float(ms), "route": idx.filter_stats()["kind"],
+                             "equivalent_rows_x_dim_per_s": 64e3 / ms * n * d}
+    idx.close()
+    del E, Q
+    torch.cuda.empty_cache()
+    # (2) one query, 1 M x 1024: l2 (full-precision scan) next to cosine (half-bytes route), and cosine at k = 1000 (> 512: the ranked full pass)
+    n, d = 1_000_000, 1024
+    E = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=2)
+    q = torch.empty((64, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(q, seed=20)
+    for name, metric, k in (("l2_top100", "l2", 100), ("cosine_top100", "cosine", 100), ("cosine_top1000", "cosine", 1000)):
+        idx = raglite_amd.DeviceIndex(E, metric=metric)
+        i = [0]
+
+        def one():
+            idx.search_rows(q[i[0] % 64], k)
+            i[0] += 1
+
+        ms = timed(one, 30)
+        out[name] = {"value": 1e3 / ms, "ms_per_query": float(ms), "route": idx.filter_stats()["kind"]}
+        idx.close()
+    out["value"] = out["maxsim_dim1536"]["value"]
+    return out
+
+
 def cfg5():
     """BASELINE cfg 5, the per-GPU part: a 1.25 M x 1024 shard of the 10 M-row corpus, 1000 queries, cosine exact
     top-100 (the all-gather merge of the 8 shards is tests/test_sharded_gloo.py / bench.py --gpus N)."""
