@@ -1696,7 +1696,13 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
 // The exact top-k of idx->scores [nb x ld] (+ for l2 batches the exact re-scoring of the hits): the tail of every row search.
 int select_from_scores(rl_index* idx, const float* d_qb, int32_t nb, int32_t k, float* o_s, int32_t* o_r, int64_t ld, bool hist_done, hipStream_t s) {
     const int64_t n = idx->n_rows;
-    RL_TRY(launch_topk(idx->scores.as<float>(), nb, n, ld, k, idx->ws, o_s, o_r, s, nullptr, hist_done));
+    // l2 similarities (1 - |e - q|) of a big corpus crowd into one bin of the radix selection (its one-block slow path: 2 ms per query at 1 M
+    // rows, three times the scan that produced the scores): the pivot route does not care how the scores are distributed (round 6)
+    int st_pv = RL_ERR_UNSUPPORTED;
+    if (!hist_done && idx->metric == RL_L2 && idx->opt.on(RL_OPT_HI_PIVOT))
+        st_pv = launch_topk_pivot(idx->scores.as<float>(), nb, n, ld, k, idx->ws, o_s, o_r, s);
+    if (st_pv != RL_OK && st_pv != RL_ERR_UNSUPPORTED) return st_pv;
+    if (st_pv == RL_ERR_UNSUPPORTED) RL_TRY(launch_topk(idx->scores.as<float>(), nb, n, ld, k, idx->ws, o_s, o_r, s, nullptr, hist_done));
     if (idx->metric == RL_L2 && (nb > 4)) {
         // The batched paths rank by |e|^2 + |q|^2 - 2 e.q; re-score the k hits of every query with the exact
         // sum (e - q)^2 and re-sort them (near-duplicates would otherwise report a cancelled distance).

@@ -148,6 +148,7 @@ struct SelectWorkspace {      // device buffers sized for `capacity_queries`
                               // has read it -- no memset launch in front of every top-k
     uint64_t* sel = nullptr;  // [B][K_MAX]
     uint64_t* cand = nullptr; // [B][CAND_CAP]
+    uint32_t* pv = nullptr;   // [3 B + 16] counters, flag block, bounds and thresholds of launch_topk_pivot
     int32_t capacity_queries = 0;
     bool dirty = false;       // a launch sequence was cut short by an error: re-zero `hist` before the next use
     int block_route = 2;      // RL_OPT_TOPK_BLOCK: selections of <= 256 k scores per query in ONE launch, one block per query (select.hip); 2: with the thread-maximum prefilter
@@ -228,12 +229,19 @@ struct PivotMaxSim {                  // the MaxSim flavour of the pivot route (
     int32_t* fill_ids = nullptr;      // [nb x cap] candidate lists to pre-fill with -1
     int64_t fill_n = 0;               // (set by the launcher)
     int per_wave = 0;                 // (set by the launcher)
+    int read_only = 0;                // the scores are not rewritten (an identity transform: launch_topk_pivot)
 };
 size_t pivot_scratch_words(int32_t nb);
 int launch_pivot_route(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t k, const float* row_norm, const float* row_sumsq, const float* queries,
                        int32_t dim, int mode, float pre_scale, uint64_t* bmax, uint32_t* zero_words, int n_zero, const HiBound& bound, float* thr,
                        int32_t cap, int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* E = nullptr,
-                       float* gather_out = nullptr, bool* gathered = nullptr, const PivotMaxSim* maxsim = nullptr);
+                       float* gather_out = nullptr, bool* gathered = nullptr, const PivotMaxSim* maxsim = nullptr, const float* aux_src = nullptr,
+                       int64_t aux_ld = 0);
+// Exact top-k of scores that CROWD (l2 similarities 1 - |e - q| of a big corpus share one exponent and a few mantissa bits: the radix selection's
+// threshold bin then holds the whole corpus and its one-block slow path takes 2 ms per query): the pivot route's group maxima do not care how the
+// scores are distributed.  k <= 128, >= 3 k groups, <= 240 queries; RL_ERR_UNSUPPORTED otherwise.  Same results as launch_topk.
+int launch_topk_pivot(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32_t k, SelectWorkspace& ws, float* out_scores,
+                      int32_t* out_ids, hipStream_t s);
 int launch_collect_above(const float* scores, int32_t nb, int64_t n, int64_t ld, const float* thr, const float* row_norm, int32_t cap,
                          int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* top_s = nullptr,
                          const int32_t* top_i = nullptr, int32_t k = 0);

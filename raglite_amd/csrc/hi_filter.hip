@@ -216,12 +216,12 @@ __global__ __launch_bounds__(256) void transform_bmax_kernel(float* __restrict__
             o[u] = transform_score(d[u] * pre_scale, mode, a[u], a[u], qn, qss);
             if (o[u] > bv) { bv = o[u]; bi = (uint32_t)((i << 2) + u); }
         }
-        reinterpret_cast<f4*>(sb)[i] = o;
+        if (!ms.read_only) reinterpret_cast<f4*>(sb)[i] = o;
     };
     auto one = [&](int64_t i) {  // scalar tail / unaligned layout
         const float o = transform_score(sb[i] * pre_scale, mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
         if (o > bv) { bv = o; bi = (uint32_t)i; }
-        sb[i] = o;
+        if (!ms.read_only) sb[i] = o;
     };
     if (vec) {
         int64_t i = i_first;
@@ -291,10 +291,11 @@ __global__ __launch_bounds__(256) void pivot_collect_kernel(const float* __restr
                                                              int G, int32_t k, const float* __restrict__ m, float* __restrict__ thr,
                                                              const float* __restrict__ row_norm, int32_t cap, int32_t* __restrict__ ids,
                                                              float* __restrict__ norms, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag,
-                                                             const float* __restrict__ E, int dim, float* __restrict__ Gout) {
+                                                             const float* __restrict__ E, int dim, float* __restrict__ Gout, int64_t aux_ld) {
     __shared__ int32_t l_ids[1024];
     __shared__ uint32_t l_n, l_base, pivot_sh;
     const int b = blockIdx.y;
+    if (row_norm) row_norm += (int64_t)b * aux_ld;  // (aux_ld != 0: the "norms" are a per-query array -- the scores themselves, launch_topk_pivot)
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
         uint32_t kv[8];
@@ -664,12 +665,12 @@ size_t pivot_scratch_words(int32_t nb) { return (size_t)nb * 512; }
 int launch_pivot_route(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t k, const float* row_norm, const float* row_sumsq, const float* queries,
                        int32_t dim, int mode, float pre_scale, uint64_t* bmax, uint32_t* zero_words, int n_zero, const HiBound& bound, float* thr,
                        int32_t cap, int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* E, float* gather_out,
-                       bool* gathered, const PivotMaxSim* maxsim) {
+                       bool* gathered, const PivotMaxSim* maxsim, const float* aux_src, int64_t aux_ld) {
     if (gathered) *gathered = false;
     if (n <= 0 || nb <= 0 || k < 1 || k > 128 || !bound.m_out) return RL_ERR_UNSUPPORTED;
     if (n_zero < 0 || n_zero > 256 || (n_zero > 0 && !zero_words)) return RL_ERR_INVALID;
     PivotMaxSim ms = maxsim ? *maxsim : PivotMaxSim{};
-    if (maxsim && (ms.nq < 1 || mode != SCAN_RAW_DOT)) return RL_ERR_INVALID;
+    if (maxsim && ms.nq > 0 && mode != SCAN_RAW_DOT) return RL_ERR_INVALID;
     // groups: a maximum per workgroup of 2048 scores (up to 512 of them); a query with fewer scores than 3 k such groups gets one per WAVE
     int bx = (int)std::min<int64_t>((n + 2047) / 2048, 512), G = bx;
     ms.per_wave = 0;
@@ -685,8 +686,10 @@ int launch_pivot_route(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t
     const int cx = (int)std::max<int64_t>(1, std::min<int64_t>((n + 4095) / 4096, 512));
     // (the candidates' rows gathered by the collecting workgroups themselves where the layout allows 16-byte copies)
     const bool fuse = E && gather_out && gathered && (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(E) | reinterpret_cast<uintptr_t>(gather_out)) & 15) == 0;
-    hipLaunchKernelGGL(pivot_collect_kernel, dim3(cx, nb), dim3(256), 0, s, scores, n, ld, bmax, G, k, bound.m_out, thr,
-                       mode == SCAN_COSINE ? row_norm : nullptr, cap, ids, norms, cnt, flag, fuse ? E : nullptr, (int)dim, fuse ? gather_out : nullptr);
+    // (aux_src: what goes into `norms` next to every collected id -- the rows' norms for a cosine search, or any other per-row / per-query array)
+    const float* aux = aux_src ? aux_src : (mode == SCAN_COSINE ? row_norm : nullptr);
+    hipLaunchKernelGGL(pivot_collect_kernel, dim3(cx, nb), dim3(256), 0, s, scores, n, ld, bmax, G, k, bound.m_out, thr, aux, cap, ids, norms, cnt, flag,
+                       fuse ? E : nullptr, (int)dim, fuse ? gather_out : nullptr, aux_src ? aux_ld : (int64_t)0);
     if (fuse) *gathered = true;
     RL_HIP(hipGetLastError());
     return RL_OK;

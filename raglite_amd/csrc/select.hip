@@ -870,6 +870,7 @@ int select_workspace_reserve(SelectWorkspace& ws, int32_t nq, hipStream_t s) {
         RL_HIP(hipMalloc(&ws.hist, (size_t)nq * HIST_STRIDE * sizeof(uint32_t)));
         RL_HIP(hipMalloc(&ws.sel, (size_t)nq * K_MAX * sizeof(uint64_t)));
         RL_HIP(hipMalloc(&ws.cand, (size_t)nq * CAND_CAP * sizeof(uint64_t)));
+        RL_HIP(hipMalloc(&ws.pv, ((size_t)nq * 3 + 16) * sizeof(uint32_t)));
         ws.capacity_queries = nq;
         ws.dirty = true;
     }
@@ -884,7 +885,38 @@ void select_workspace_free(SelectWorkspace& ws) {
     if (ws.hist) (void)hipFree(ws.hist);
     if (ws.sel) (void)hipFree(ws.sel);
     if (ws.cand) (void)hipFree(ws.cand);
+    if (ws.pv) (void)hipFree(ws.pv);
     ws = SelectWorkspace{};
+}
+
+int launch_topk_pivot(const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t k, SelectWorkspace& ws, float* out_scores, int32_t* out_ids,
+                      hipStream_t s) {
+    if (nq <= 0 || k <= 0) return RL_OK;
+    if (k > 128 || nq > 240 || n >= (int64_t)0x7fffffff || n < 3 * (int64_t)k * 1024 / 4) return RL_ERR_UNSUPPORTED;
+    const int block_route = ws.block_route;
+    RL_TRY(select_workspace_reserve(ws, nq, s));
+    ws.block_route = block_route;
+    // the selection's own buffers, idle on this route: group maxima in `sel` (512 of its 2048 words per query), the collected (id, score) lists in
+    // `cand` (4096 + 4096 four-byte words per query = its 4096 eight-byte ones)
+    constexpr int32_t cap = CAND_CAP;
+    uint64_t* bmax = ws.sel;
+    int32_t* ids = reinterpret_cast<int32_t*>(ws.cand);
+    float* vals = reinterpret_cast<float*>(ids + (size_t)nq * cap);
+    uint32_t* cnt = ws.pv;
+    uint32_t* flag = cnt + nq;
+    float* m = reinterpret_cast<float*>(flag + 16);
+    float* thr = m + nq;
+    HiBound bound;
+    bound.m_out = m;  // (no error band here: the kernel leaves 2^-22, the threshold is the pivot itself)
+    PivotMaxSim ms;
+    ms.read_only = 1;
+    const int st = launch_pivot_route(const_cast<float*>(scores), nq, n, ld, k, nullptr, nullptr, nullptr, 0, SCAN_RAW_DOT, 1.0f, bmax, cnt, nq + 16, bound, thr,
+                                      cap, ids, vals, cnt, flag, s, nullptr, nullptr, nullptr, &ms, scores, ld);
+    if (st != RL_OK) return st;
+    RL_TRY(launch_merge_topk(vals, ids, 1, nq, cap, k, out_scores, out_ids, s, cnt));
+    // more than 4096 scores reach the pivot (massive ties), or fewer than k groups have a usable maximum (NaN / -inf nearly everywhere): the
+    // radix selection answers, behind the flag
+    return launch_topk(scores, nq, n, ld, k, ws, out_scores, out_ids, s, flag);
 }
 
 static int hist_grid(int64_t n, int32_t nq) {

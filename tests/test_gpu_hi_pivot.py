@@ -172,3 +172,40 @@ def test_few_maxsim_queries_pivot_route_float_data_and_fallback():
     assert np.array_equal(c, fc) and _same(s, fs)
     idx.close()
     idx2.close()
+
+
+# ---- crowded scores: l2 (select.hip: launch_topk_pivot) ------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,dim,B,k", [(300_000, 64, 1, 100), (120_000, 128, 3, 10), (400_000, 32, 4, 128), (90_000, 64, 2, 1)])
+def test_l2_selection_over_crowded_scores_equals_the_radix_selection(n, dim, B, k):
+    """`ORDER BY dist LIMIT k` with the l2 metric (`/root/reference/src/raglite/_typing.py:123-134`, `_config.py:69`): the similarities
+    1 - |e - q| of a big corpus share their exponent and leading mantissa bits -- one bin of the radix selection holds them all and its exact slow
+    path takes milliseconds.  The pivot route (group maxima -> threshold -> a few hundred rows -> ranking) must return the same rows and score bits
+    (hi_pivot = 0: the radix selection), the oracle's ranking, and ties to the lowest row."""
+    E = oracle.synth_matrix(9900 + dim, n, dim)
+    Q = oracle.synth_matrix(9910 + B, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric="l2")
+    q = Q if B > 1 else Q[0]
+    S, R = idx.search_rows(q, k)
+    with idx.options(hi_pivot=0):
+        S0, R0 = idx.search_rows(q, k)
+    assert np.array_equal(R, R0) and _same(S, S0)
+    S, R = np.atleast_2d(S), np.atleast_2d(R)
+    for b in (0, B - 1):
+        sims = oracle.similarity(E, Q[b], "l2")
+        assert_topk_close(S[b], R[b], sims, k, 2e-6 * max(1.0, float(np.abs(sims).max())))
+    idx.close()
+    # integer data with thousands of exact ties around the k-th distance, and more than 4096 rows at the best distance (the list overflows:
+    # the radix selection answers behind the flag)
+    Ei = oracle.synth_matrix(9920, n, dim, "small_int")
+    Qi = oracle.synth_matrix(9921, 2, dim, "small_int")
+    Ei[1000:7000] = Qi[0]
+    idx = raglite_amd.DeviceIndex(Ei, metric="l2")
+    S, R = idx.search_rows(Qi, k)
+    with idx.options(hi_pivot=0):
+        S0, R0 = idx.search_rows(Qi, k)
+    assert np.array_equal(R, R0) and _same(S, S0)
+    assert R[0].tolist() == list(range(1000, 1000 + k))  # distance 0, ties to the lowest row
+    for b in range(2):
+        es, ei = oracle.topk_desc(sim_fp32_exact(Ei, Qi[b], "l2"), k)
+        assert np.array_equal(R[b], ei) and _same(S[b], es.astype(np.float32))
+    idx.close()
