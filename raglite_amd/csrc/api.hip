@@ -2189,7 +2189,13 @@ int hi_batch_approx(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queri
                                   nullptr, hb.one_product));
     }
     RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // tombstones never become candidates
-    RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, hb.ts, hb.ti, s));
+    // (a handful of queries over more chunks than the one-block selection takes: crowded MaxSim scores send the radix selection down its slow path
+    // -- the pivot route first, launch_topk_pivot; it declines what it does not cover)
+    int st_pv = RL_ERR_UNSUPPORTED;
+    if (n_gemm < 16 && idx->n_chunks > (int64_t)262144 && idx->opt.on(RL_OPT_HI_PIVOT))
+        st_pv = launch_topk_pivot(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, hb.ts, hb.ti, s);
+    if (st_pv != RL_OK && st_pv != RL_ERR_UNSUPPORTED) return st_pv;
+    if (st_pv == RL_ERR_UNSUPPORTED) RL_TRY(launch_topk(sc, n_gemm, idx->n_chunks, ld, k, idx->ws, hb.ts, hb.ti, s));
     return RL_OK;
 }
 // rows_only: the caller laid out no query fragments (the few-queries route over the HI plane) -- the guarded fallback then streams the rows even

@@ -949,8 +949,12 @@ int launch_topk(const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t 
     } else {
         RL_TRY(select_workspace_reserve(ws, nq, s));
     }
-    // The block route (round 6): a query whose scores one block can read twice out of L2 is selected by ONE launch that touches no workspace
-    if (!run_if && !have_hist && !emit && ws.block_route && n > 0 && n <= BLOCK_ROUTE_MAX_N) {
+    // The block route (round 6): a query whose scores one block can read twice out of L2 is selected by ONE launch that touches no workspace.
+    // With the prefilter also BATCHES over more scores per query (up to 8 M: MaxSim chunk scores of a corpus of more than 262 144 chunks crowd
+    // into one bin of the radix selection below -- its exact slow path, one block reading the scores three more times, was 1.1 ms of an 18.6 ms
+    // step over 300 k chunks; a block per query reading them twice is 0.08)
+    const bool big_batch = ws.block_route >= 2 && k <= PREFILTER_MAX_K && nq >= 16 && n <= (int64_t(8) << 20);
+    if (!run_if && !have_hist && !emit && ws.block_route && n > 0 && (n <= BLOCK_ROUTE_MAX_N || big_batch)) {
         hipLaunchKernelGGL(topk_block_kernel, dim3(nq), dim3(1024), 0, s, scores, n, ld, k, out_scores, out_ids, ws.block_route >= 2 ? 1 : 0);
         RL_HIP(hipGetLastError());
         return RL_OK;

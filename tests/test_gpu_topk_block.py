@@ -139,3 +139,25 @@ def test_prefilter_worst_cases_fall_back_to_the_histogram_path():
     s, i = _both(w, 100)
     es, ei = oracle.topk_desc(w, 100)
     assert np.array_equal(i, ei) and np.array_equal(s.view(np.uint32)[:60], es.view(np.uint32)[:60]) and np.isnan(s[60:]).all()
+
+
+def test_batches_over_more_scores_than_one_block_used_to_take():
+    """A batch (>= 16 queries) over more than 262 144 scores per query also takes the block route when the prefilter is on (MaxSim chunk scores
+    of a corpus of > 262 144 chunks crowd into one bin of the three-launch radix selection, whose exact slow path is one block reading the
+    scores three more times): crowded scores, ties, an unaligned leading dimension, the prefilter's overflow -- equal to the three-launch route
+    and the oracle bit for bit; fewer than 16 queries stay on the three-launch route and agree as well."""
+    rng = np.random.default_rng(9)
+    n = 700_003
+    X = (755.0 + 3.0 * rng.standard_normal((16, n))).astype(np.float32)   # every score in ONE 11-bit bin
+    X[3, rng.choice(n, size=5000, replace=False)] = 770.0                # massive ties on the threshold value
+    g = np.arange(n) // 4
+    X[5, (g % 1024) < 30] += 40.0                                        # the large scores in thirty threads' hands: prefilter overflow
+    for k in (1, 100, 512, 600):
+        S, I = _both(X, k)
+        for b in (0, 3, 5, 15):
+            es, ei = oracle.topk_desc(X[b], k)
+            assert np.array_equal(I[b], ei) and np.array_equal(S[b].view(np.uint32), es.view(np.uint32)), (k, b)
+    S, I = _both(X[:5], 100)
+    for b in (0, 3):
+        es, ei = oracle.topk_desc(X[b], 100)
+        assert np.array_equal(I[b], ei) and np.array_equal(S[b], es)
