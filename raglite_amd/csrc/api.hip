@@ -461,6 +461,13 @@ int refresh_planes(rl_index* idx, hipStream_t s) {
 
 // The HI plane follows the corpus like the image does: built for big fp32 corpora in split arithmetic whose dim the fp16
 // stream kernel takes; RAGLITE_NO_HI_PLANE=1 disables it (2 B per element of extra HBM).
+// The dims the half-bytes routes take: any multiple of 32 up to 1024; beyond -- the 1536- to 4096-wide embedders the reference also accepts
+// (src/raglite/_embed.py:155-158) -- multiples of 128 (round 6: the exact re-scoring kernels walk wider queries in 128-column windows).
+constexpr int32_t HI_MAX_DIM = 4096;
+bool hi_dim_ok(int32_t d) { return d % 32 == 0 && d >= 32 && (d <= 1024 || (d <= HI_MAX_DIM && d % 128 == 0)); }
+// The rounding term of every half-bytes bound: an fp32 sum of `dim` products is off by at most dim 2^-24 of sum |products| <= |q| |e|, once in
+// the approximate pass and once in the exact one, + the query's 2^-22 split: 2^-12 |q| |e| per started 1024 terms (twice what it takes).
+float sum_eps(int32_t d) { return 0x1p-12f * (float)((d + 1023) / 1024); }
 bool hi_valid(const rl_index* idx) {
     return idx->hi_scale > 0.f && idx->hi_scale == idx->split_scale && idx->hi_rows == idx->n_rows && idx->n_rows > 0;
 }
@@ -537,7 +544,7 @@ int refresh_hi_image(rl_index* idx, hipStream_t s) {
     const bool off = !idx->opt.on(RL_OPT_KEEP_HI);  // (shared with the row-major plane)
     // (round 4: independent of the pre-split image -- an index with RL_OPT_KEEP_IMAGE = 0 keeps rows + HI image, 1.5 x the corpus, and its
     // MaxSim batches fall back to the streaming kernels over the rows)
-    const bool want = !off && !idx->E16 && idx->E && idx->split_scale > 0.f && idx->dim % 32 == 0 && idx->dim >= 32 && idx->dim <= 1024 &&
+    const bool want = !off && !idx->E16 && idx->E && idx->split_scale > 0.f && hi_dim_ok(idx->dim) &&
                       (int64_t)idx->n_rows * idx->dim >= (int64_t(64) << 20) && (image_need(idx) & IMG_HI_IMAGE);
     if (!want) {
         idx->hi_image.release();
@@ -1518,7 +1525,7 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
     RL_TRY(launch_topk(S_s, B, ld_s, ld_s, k, idx->ws, top_s, top_i, s));
     // ---- (2) thresholds lowered by the error band; candidate pass ---------------------------------------------------------------
     RL_TRY(launch_row_threshold(top_s, B, k, d_q, idx->dim, mode, hi_only ? q_unscale : nullptr, idx->max_lo_ratio, idx->max_lo_norm, idx->max_row_norm,
-                                thr, window, cnt, cnt2, flag, s, thr1));  // (thr1: the first round's thresholds, kept for rl_time_kernel's replay)
+                                thr, window, cnt, cnt2, flag, s, thr1, sum_eps(idx->dim)));  // (thr1: the first round's thresholds, kept for rl_time_kernel's replay)
     const CandArgs ca{thr, 1, c_s, c_i, cnt, flag, cap};
     idx->filt = {RL_FILTER_ROWS_FUSED_HI, B, cap, cnt, flag};
     // The candidate pass on the sixteen-group tile of maxsim_pp.hip (round 4: 128 rows x 512 queries per workgroup, every operand through
@@ -1637,8 +1644,8 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     bool gathered = false;
     float m_rel = 0x1p-10f + 0x1p-11f, e_bound = std::sqrt((float)dim) * idx->max_abs;
     if (measured) {
-        if (mode == SCAN_COSINE) m_rel = idx->max_lo_ratio + 0x1p-12f;
-        else { m_rel = 1.0f; e_bound = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm; }
+        if (mode == SCAN_COSINE) m_rel = idx->max_lo_ratio + sum_eps(dim);
+        else { m_rel = 1.0f; e_bound = idx->max_lo_norm + sum_eps(idx->dim) * idx->max_row_norm; }
     }
     if (d_row_bits) {  // tombstones / metadata filter: masked rows rank -inf, so they reach neither the top-k nor the candidates
         RL_TRY(launch_transform(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, s, 1.0f / idx->hi_scale));
@@ -2169,7 +2176,7 @@ int hi_batch_approx(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queri
     const int32_t cap = hb.cap;
     // per pair |approx - exact| <= |q_i| |e_lo,j| (what the HI halves drop, measured: max_lo_norm) + 2^-12 |q_i| |e_j| (the
     // query's own 2^-22 split and twice the worst case of a 1024-term fp32 sum, 6e-5)
-    hb.m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
+    hb.m_abs = idx->max_lo_norm + sum_eps(idx->dim) * idx->max_row_norm;
     hb.q_unscale = reinterpret_cast<const float*>(idx->qplanes.as<char>() + (size_t)n_queries * idx->dim * 128);  // launch_query_planes' meta
     hb.qsum = hb.q_unscale + 2 * (size_t)n_queries;                                                                 // ... and its sums
     if (!flag_zeroed) RL_HIP(hipMemsetAsync(hb.flag, 0, 16 * sizeof(uint32_t), s));  // (else: the query-image kernel did, gemm_prepare)
@@ -2310,7 +2317,7 @@ int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, 
     hb.exact_kth = idx->opt.on(RL_OPT_EXACT_KTH_THRESHOLD);
     RL_TRY(idx->hibuf.reserve(hi_batch_words(n, k) * 4));
     hi_batch_layout(idx, n, k, hb);
-    hb.m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
+    hb.m_abs = idx->max_lo_norm + sum_eps(idx->dim) * idx->max_row_norm;
     hb.q_unscale = nullptr;
     // The pivot route (round 6, option hi_pivot; k <= 128, no tombstones): with the chip idle around one query, re-scoring ~2.5 x the candidates
     // costs nothing, so the approximate scores need not be RANKED -- no top-k, no second threshold from its exact scores: the k-th largest of
@@ -2610,7 +2617,7 @@ int rl_maxsim_approx_scores(rl_index* idx, const float* query_vecs, int32_t n_qu
                                       idx->ends.as<uint32_t>(), d_o + (int64_t)b * ld, ld, idx->n_cu, s, approx_scale(idx), true, nullptr, true));
     }
     if (d_b) {  // the bound of the one-product pass, by the kernel the pipeline computes its thresholds with (k = 1 over a dummy top list)
-        const float m_abs = idx->max_lo_norm + 0x1p-12f * idx->max_row_norm;
+        const float m_abs = idx->max_lo_norm + sum_eps(idx->dim) * idx->max_row_norm;
         const float* q_unscale = reinterpret_cast<const float*>(idx->qplanes.as<char>() + (size_t)n_queries * idx->dim * 128);
         RL_TRY(idx->hibuf.reserve((size_t)n_queries * 4 * sizeof(float) + 64));
         float* top = idx->hibuf.as<float>();                                     // [n] "k-th best" = 0

@@ -277,7 +277,7 @@ int launch_diag_blocks(const float* src, int64_t ld, int32_t k2, int64_t count, 
 // Batched half-bytes search (experimental, api.hip: search_rows_fused_hi) -- see the kernels' comments in hi_filter.hip / select.hip
 int launch_row_threshold(const float* topk, int32_t nb, int32_t k, const float* Q, int32_t dim, int mode, const float* q_unscale, float lo_ratio,
                          float lo_norm, float e_norm, float* thr, float* window, uint32_t* cnt, uint32_t* cnt2, uint32_t* flag, hipStream_t s,
-                         float* thr_copy = nullptr);
+                         float* thr_copy = nullptr, float sum_eps = 0x1p-12f);
 int launch_row_dots(const float* E, int32_t dim, const float* Q, int32_t nb, const int32_t* rows, const uint32_t* cnt, int32_t cap, int mode,
                     const float* row_norm, const float* q_sumsq, float* out, hipStream_t s);
 int launch_list_prefix(const float* in_scores, const int32_t* in_ids, int32_t nq, int32_t k_in, int32_t k, const uint32_t* counts,

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void exact_threshold_kernel(const float* __res
 __global__ __launch_bounds__(256) void row_threshold_kernel(const float* __restrict__ topk, int32_t k, const float* __restrict__ Q, int dim, int mode,
                                                              const float* __restrict__ q_unscale, float lo_ratio, float lo_norm, float e_norm,
                                                              float* __restrict__ thr, float* __restrict__ window, uint32_t* __restrict__ cnt,
-                                                             uint32_t* __restrict__ cnt2, uint32_t* __restrict__ flag, float* __restrict__ thr_copy) {
+                                                             uint32_t* __restrict__ cnt2, uint32_t* __restrict__ flag, float* __restrict__ thr_copy, float sum_eps) {
     __shared__ float part[4], part_lo[4];
     const int b = blockIdx.x;
     const float* q = Q + (int64_t)b * dim;
@@ -478,8 +478,8 @@ __global__ __launch_bounds__(256) void row_threshold_kernel(const float* __restr
     const float qn = sqrtf((part[0] + part[1]) + (part[2] + part[3]));
     const float ql = q_unscale ? sqrtf((part_lo[0] + part_lo[1]) + (part_lo[2] + part_lo[3])) * inv_scale * 1.00001f : 0.f;
     float m;
-    if (mode == SCAN_COSINE) m = lo_ratio + 0x1p-12f + (1.0f + lo_ratio) * (ql / qn) * 1.00001f;
-    else m = (lo_norm + 0x1p-12f * e_norm) * qn + (e_norm + lo_norm) * ql + 0x1p-22f;
+    if (mode == SCAN_COSINE) m = lo_ratio + sum_eps + (1.0f + lo_ratio) * (ql / qn) * 1.00001f;
+    else m = (lo_norm + sum_eps * e_norm) * qn + (e_norm + lo_norm) * ql + 0x1p-22f;
     const float w = 2.0f * m * 1.00001f;
     const float t = topk[(int64_t)b * k + (k - 1)] - w;
     thr[b] = t;
@@ -819,10 +819,10 @@ int launch_exact_threshold(const float* exact, const int32_t* top_i, int32_t n_q
 
 int launch_row_threshold(const float* topk, int32_t nb, int32_t k, const float* Q, int32_t dim, int mode, const float* q_unscale, float lo_ratio,
                          float lo_norm, float e_norm, float* thr, float* window, uint32_t* cnt, uint32_t* cnt2, uint32_t* flag, hipStream_t s,
-                         float* thr_copy) {
+                         float* thr_copy, float sum_eps) {
     if (nb <= 0) return RL_OK;
     hipLaunchKernelGGL(row_threshold_kernel, dim3(nb), dim3(256), 0, s, topk, k, Q, (int)dim, mode, q_unscale, lo_ratio, lo_norm, e_norm, thr, window,
-                       cnt, cnt2, flag, thr_copy);
+                       cnt, cnt2, flag, thr_copy, sum_eps);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

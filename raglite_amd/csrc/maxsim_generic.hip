@@ -21,6 +21,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int GEN_NQ_MAX = 1024;
+constexpr int PAIRS_MAX_DIM = 4096;  // maxsim_pairs_*: <= 1024 with the query in LDS, beyond through wave-private windows
 
 template <int NV, int VEC>
 __global__ __launch_bounds__(256) void maxsim_generic_kernel(const float* __restrict__ D, int dim,
@@ -417,6 +418,172 @@ __global__ __launch_bounds__(NW * 64) void maxsim_pairs_packed_kernel(const floa
     }
 }
 
+// maxsim_pairs_wide_kernel (round 6): the same scores for 1024 < dim <= 4096 (dim % 128 == 0) -- embedders wider than bge-m3 (the reference
+// takes any litellm embedder, src/raglite/_embed.py:155-158: 1536- and 3072-wide models).  A query's [32 x dim] fp32 matrix no longer fits a CU's
+// LDS, and a window of it SHARED by the workgroup would put a barrier between every wave's K blocks.  So the window is WAVE-PRIVATE: each of the
+// eight waves keeps 32 x 128 floats of the query (17 KiB at the pitch of the kernels above) and turns the loops inside out -- a GROUP of up to
+// eight packed tiles (the walk of maxsim_pairs_packed_kernel: the rows of the wave's candidates back to back) is multiplied window by window,
+// its 8 x 2 accumulator tiles staying in registers, so that a window is staged once per 128 rows x 128 k (16 KiB from L2 against 64 KiB of rows
+// from HBM); no workgroup barrier at all.  Per (row, query vector) the k steps accumulate in ascending order as in the kernels above, the
+// maximum is exact, the sum tree is the same: the bits of maxsim_pairs_kernel's arithmetic at any dim (tests/test_gpu_wide_dim.py).
+constexpr int PW_KW = 128, PW_T = 8, PW_PITCH = PW_KW + 8;
+__global__ __launch_bounds__(512) void maxsim_pairs_wide_kernel(const float* __restrict__ D, int dim, const float* __restrict__ Q, int nq,
+                                                                 int64_t q_stride, const int64_t* __restrict__ offsets,
+                                                                 const int32_t* __restrict__ candidates, int64_t n_items, int64_t item_stride,
+                                                                 float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float qs[];  // [8 waves][32][PW_PITCH]
+    const float* Qb = Q + (int64_t)blockIdx.y * q_stride;
+    const int32_t* cb = candidates + (int64_t)blockIdx.y * item_stride;
+    float* ob = out + (int64_t)blockIdx.y * item_stride;
+    const int lane = threadIdx.x & 63, w = wave_id();
+    const int m = lane & 15, g = lane >> 4;
+    float* const qw = qs + w * 32 * PW_PITCH;
+    const float* q0 = qw + m * PW_PITCH + 4 * g;
+    const float* q1 = qw + (16 + m) * PW_PITCH + 4 * g;
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    const int nwin = dim / PW_KW;
+    constexpr int NL = PW_KW / 16;
+    auto request = [&](f32x4 (&x)[NL], int32_t row, int t0) __attribute__((always_inline)) {
+        const float* a = D + (int64_t)row * dim + 4 * g + t0;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) x[j] = *reinterpret_cast<const f32x4*>(a + 16 * j);
+    };
+    f32x4 xc[NL], xn[NL];
+    for (int64_t base = (int64_t)blockIdx.x * 8 + w; base < n_items; base += 64 * stride) {
+        const int64_t mine = base + (int64_t)lane * stride;
+        int32_t vb = 0, ve = 0;  // (row numbers fit 31 bits: rl_index_create)
+        if (mine < n_items) {
+            const int64_t chunk = cb[mine];
+            if (chunk >= 0) { vb = (int32_t)offsets[chunk]; ve = (int32_t)offsets[chunk + 1]; }
+            if (ve <= vb) ob[mine] = -INFINITY;
+        }
+        const uint64_t todo = __builtin_amdgcn_ballot_w64(ve > vb);
+        if (todo == 0ull) continue;  // (wave-uniform)
+        uint32_t t_lo = ve > vb ? (uint32_t)(ve - vb) & 0xffffu : 0u, t_hi = ve > vb ? (uint32_t)(ve - vb) >> 16 : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { t_lo += __shfl_xor(t_lo, o); t_hi += __shfl_xor(t_hi, o); }
+        const int64_t R = ((int64_t)__builtin_amdgcn_readfirstlane(t_hi) << 16) + (int64_t)__builtin_amdgcn_readfirstlane(t_lo);
+        const int64_t n_tiles = (R + 15) >> 4;
+        // the walk of maxsim_pairs_packed_kernel (scalar): slot m of a tile is the next row of the current candidate
+        int cur = __builtin_ctzll(todo);
+        uint64_t rest = todo & (todo - 1ull);
+        int32_t cur_row = __builtin_amdgcn_readlane(vb, cur), cur_end = __builtin_amdgcn_readlane(ve, cur);
+        auto next_tile = [&](int32_t& row, int& cand) __attribute__((always_inline)) -> uint32_t {
+            uint32_t ends = 0u;
+            row = cur_row;
+            cand = cur;
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) {
+                if (cur >= 0) {  // (scalar)
+                    if (m == sl) { row = cur_row; cand = cur; }
+                    if (++cur_row == cur_end) {
+                        ends |= 1u << sl;
+                        if (rest != 0ull) {
+                            cur = __builtin_ctzll(rest);
+                            rest &= rest - 1ull;
+                            cur_row = __builtin_amdgcn_readlane(vb, cur);
+                            cur_end = __builtin_amdgcn_readlane(ve, cur);
+                        } else {
+                            cur = -1;
+                        }
+                    }
+                }
+            }
+            return ends;
+        };
+        float carry0 = -INFINITY, carry1 = -INFINITY;  // column maxima of the candidate left open by the previous tile
+        for (int64_t tile0 = 0; tile0 < n_tiles; tile0 += PW_T) {
+            const int gt = (int)(n_tiles - tile0 < PW_T ? n_tiles - tile0 : PW_T);  // tiles of this group (scalar)
+            int32_t row[PW_T];
+            int cand[PW_T];
+            uint32_t ends[PW_T];
+#pragma unroll
+            for (int t = 0; t < PW_T; ++t) {
+                row[t] = 0; cand[t] = 0; ends[t] = 0u;
+                if (t < gt) ends[t] = next_tile(row[t], cand[t]);
+            }
+            f32x4 acc[PW_T][2];
+#pragma unroll
+            for (int t = 0; t < PW_T; ++t) acc[t][0] = acc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            request(xc, row[0], 0);
+            for (int kw = 0; kw < nwin; ++kw) {
+                // this wave's window of the query: columns [128 kw, 128 kw + 128) of all 32 vectors (vectors past nq: zeros)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const int i = j * 64 + lane, n = i >> 5, c = (i & 31) * 4;
+                    f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (n < nq) v = *reinterpret_cast<const f32x4*>(Qb + (int64_t)n * dim + kw * PW_KW + c);
+                    *reinterpret_cast<f32x4*>(qw + n * PW_PITCH + c) = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < PW_T; ++t) {
+                    if (t < gt) {  // (scalar)
+                        const bool last_t = t + 1 >= gt;
+                        const int32_t n_row = (t + 1 < PW_T && !last_t) ? row[t + 1 < PW_T ? t + 1 : 0] : row[0];
+                        const int n_t0 = last_t ? (kw + 1 < nwin ? (kw + 1) * PW_KW : 0) : kw * PW_KW;
+                        request(xn, n_row, n_t0);  // (after the group's last block: its first block again, unused)
+                        f32x4 y0 = *reinterpret_cast<const f32x4*>(q0), y1 = *reinterpret_cast<const f32x4*>(q1);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int j = 0; j < NL; ++j) {
+                            const int tn = j + 1 < NL ? 16 * (j + 1) : 0;
+                            const f32x4 z0 = *reinterpret_cast<const f32x4*>(q0 + tn);
+                            const f32x4 z1 = *reinterpret_cast<const f32x4*>(q1 + tn);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j][u], y0[u], acc[t][0], 0, 0, 0);
+                                acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xc[j][u], y1[u], acc[t][1], 0, 0, 0);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                            y0 = z0;
+                            y1 = z1;
+                        }
+#pragma unroll
+                        for (int j = 0; j < NL; ++j) xc[j] = xn[j];
+                    }
+                }
+            }
+            // the group's tiles are complete: per tile the segment maxima and the sums of maxsim_pairs_packed_kernel, in tile order
+#pragma unroll
+            for (int t = 0; t < PW_T; ++t) {
+                if (t < gt) {
+                    const int64_t tile = tile0 + t;
+                    const int n_valid = R - 16 * tile < 16 ? (int)(R - 16 * tile) : 16;
+                    uint32_t em = ends[t];
+                    int s_lo = 0;
+                    while (s_lo < n_valid) {  // (scalar) one trip per candidate segment of the tile
+                        const bool closes = em != 0u;
+                        const int e = closes ? __builtin_ctz(em) : 15;
+                        float v0 = -INFINITY, v1 = -INFINITY;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (4 * g + i >= s_lo && 4 * g + i <= e) { v0 = fmaxf(v0, acc[t][0][i]); v1 = fmaxf(v1, acc[t][1][i]); }
+                        v0 = fmaxf(v0, __shfl_xor(v0, 16)); v0 = fmaxf(v0, __shfl_xor(v0, 32));
+                        v1 = fmaxf(v1, __shfl_xor(v1, 16)); v1 = fmaxf(v1, __shfl_xor(v1, 32));
+                        const float best0 = fmaxf(carry0, v0), best1 = fmaxf(carry1, v1);
+                        if (closes) {
+                            float s0 = best0, s1 = best1;
+#pragma unroll
+                            for (int o = 1; o < 16; o <<= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+                            const int c = __builtin_amdgcn_readlane(cand[t], e);  // (lane e = slot e of row group 0)
+                            if (lane == 0) ob[base + (int64_t)c * stride] = s0 + s1;
+                            carry0 = carry1 = -INFINITY;
+                            em &= em - 1u;
+                        } else {
+                            carry0 = best0;
+                            carry1 = best1;
+                        }
+                        s_lo = e + 1;
+                    }
+                }
+            }
+        }
+    }
+}
+
 int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride, const int64_t* offsets,
                         const int32_t* candidates, int64_t n_items_per_query, int32_t n_queries, float* out, hipStream_t s, bool rows16,
                         int64_t item_stride, int64_t first_item, int packed_mode) {
@@ -426,8 +593,22 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
     if (first_item < 0 || first_item + n_items_per_query > item_stride) return RL_ERR_INVALID;
     if (candidates) candidates += first_item;
     if (out) out += first_item;
-    if (nq < 1 || nq > 32 || dim % 16 || dim < 16 || dim > 1024 || !candidates) return RL_ERR_UNSUPPORTED;
+    if (nq < 1 || nq > 32 || dim % 16 || dim < 16 || dim > PAIRS_MAX_DIM || !candidates) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(D) & (rows16 ? 7 : 15)) || (reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
+    if (dim > 1024) {  // wider than a CU's LDS holds a query: wave-private query windows (maxsim_pairs_wide_kernel)
+        if (dim % PW_KW || rows16) return RL_ERR_UNSUPPORTED;
+        const size_t lds_w = (size_t)8 * 32 * PW_PITCH * sizeof(float);
+        static bool wide_attr = false;
+        if (!wide_attr) {
+            RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            wide_attr = true;
+        }
+        const int per_q = (int)std::max<int64_t>(1, std::min<int64_t>((n_items_per_query + 7) / 8, std::max<int64_t>(1, 256 / n_queries)));
+        hipLaunchKernelGGL(maxsim_pairs_wide_kernel, dim3(per_q, n_queries), dim3(512), lds_w, s, D, (int)dim, Q, (int)nq, q_stride, offsets, candidates,
+                           n_items_per_query, item_stride, out);
+        RL_HIP(hipGetLastError());
+        return RL_OK;
+    }
     const size_t lds = (size_t)32 * (dim + 8) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KiB of dynamic LDS needs the opt-in

@@ -1,0 +1,130 @@
+"""Embedders wider than bge-m3 (round 6): the reference takes any litellm embedder (`/root/reference/src/raglite/_embed.py:155-158`:
+1536-, 3072-wide models; 2048 / 2560 / 4096 exist), and the half-bytes routes used to stop at dim 1024 -- a wider index ran everything on its
+full-precision paths.  Now for dim % 128 == 0 up to 4096:
+
+* the exact re-scoring kernel (`maxsim_generic.hip: maxsim_pairs_wide_kernel`, wave-private 128-column windows of the query) -- the bits of
+  `maxsim_pairs_kernel`'s arithmetic: a 1024-wide problem padded with zero columns to 1152 gives the same bits as the 1024-wide kernel, integer
+  data equals the oracle, float data the float64 oracle within 2e-6 of the score scale;
+* the bound-filtered MaxSim batch (`rl_maxsim_topk_batch`: HI image + sixteen-query pass + exact re-scoring; score =
+  sum_i max_{j in chunk} Q[i].D[j], `_search.py:143-149` behind the reranker call :394-396) on 1536 / 2048 / 3072-wide indexes: route taken,
+  same chunks as the full-precision passes, the oracle's scores; the bound's rounding term grows with dim (api.hip: sum_eps);
+* the fused exact row top-k of a big batch (`_search.py:69-79` at B >= 96) over a 1536-wide index."""
+
+import numpy as np
+import pytest
+
+import raglite_amd
+from oracle import oracle
+from tests.util import assert_topk_close, ragged_offsets
+
+pytestmark = pytest.mark.gpu
+
+
+def _long_offsets(rng, n):
+    sizes = [1000]
+    while sum(sizes) < n:
+        sizes.append(int(rng.integers(1, 101)))
+    off = np.concatenate(([0], np.cumsum(sizes)))
+    off = off[off <= n]
+    return (off if off[-1] == n else np.concatenate((off, [n]))).astype(np.int64)
+
+
+@pytest.mark.parametrize("layout", ["ragged", "one_row", "long", "with_empty"])
+@pytest.mark.parametrize("nq,n_queries,n_cand", [(32, 5, 100), (17, 40, 37), (1, 3, 700), (32, 1, 1)])
+def test_wide_kernel_on_zero_padded_columns_is_the_1024_kernel_bit_for_bit(layout, nq, n_queries, n_cand):
+    rng = np.random.default_rng(nq + n_cand)
+    n, dim = 5_000, 1024
+    off = {"ragged": lambda: ragged_offsets(rng, n, 1, 15), "one_row": lambda: np.arange(n + 1, dtype=np.int64),
+           "long": lambda: _long_offsets(rng, n), "with_empty": lambda: ragged_offsets(rng, n, 1, 15, empty_every=7)}[layout]()
+    E = oracle.synth_matrix(21_000, n, dim)
+    Q = np.stack([oracle.synth_matrix(21_100 + i, nq, dim) for i in range(n_queries)])
+    cand = rng.integers(0, len(off) - 1, (n_queries, n_cand)).astype(np.int32)
+    cand[rng.random(cand.shape) < 0.05] = -1
+    narrow = raglite_amd.DeviceIndex(E, off, metric="dot")
+    want = narrow.maxsim_rerank(Q, cand)
+    narrow.close()
+    for pad in (128, 512):  # 1152 = 9 windows, 1536 = 12
+        Ep = np.concatenate((E, np.zeros((n, pad), np.float32)), axis=1)
+        Qp = np.concatenate((Q, np.zeros((n_queries, nq, pad), np.float32)), axis=2)
+        wide = raglite_amd.DeviceIndex(Ep, off, metric="dot")
+        got = wide.maxsim_rerank(Qp, cand)
+        wide.close()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), pad
+
+
+@pytest.mark.parametrize("dim", [1152, 1536, 2048, 3072, 4096])
+def test_wide_kernel_integer_data_is_the_oracle_and_float_data_close(dim):
+    rng = np.random.default_rng(dim)
+    n, nq = 3_000, 32
+    off = ragged_offsets(rng, n, 1, 15)
+    cand = rng.integers(0, len(off) - 1, (3, 200)).astype(np.int32)
+    for kind, exact in (("small_int", True), ("uniform", False)):
+        E = oracle.synth_matrix(21_500 + dim, n, dim, kind)
+        Q = np.stack([oracle.synth_matrix(21_600 + i, nq, dim, kind) for i in range(3)])
+        idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+        got = idx.maxsim_rerank(Q, cand)
+        idx.close()
+        for b in range(3):
+            ref = oracle.maxsim_scores(E, off, Q[b], np.float64)[cand[b]]
+            if exact:
+                assert np.array_equal(got[b].astype(np.float64), ref)
+            else:
+                np.testing.assert_allclose(got[b], ref, rtol=0, atol=2e-6 * float(np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("dim,n", [(1536, 48_000), (2048, 36_000), (3072, 24_000)])
+def test_maxsim_batch_over_a_wide_index_takes_the_bound_filtered_route(dim, n):
+    rng = np.random.default_rng(dim + 1)
+    off = ragged_offsets(rng, n, 1, 15)
+    k, n_queries = 100, 9
+    # integer data: bit-identical to the oracle, ties included
+    E = oracle.synth_matrix(22_000 + dim, n, dim, "small_int")
+    Qb = np.stack([oracle.synth_matrix(22_100 + i, 32, dim, "small_int") for i in range(n_queries)])
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    bs, bc = idx.maxsim_topk_batch(Qb, k)
+    st = idx.filter_stats()
+    assert st["kind"] == "maxsim_batch_hi" and not st["fallback"], st
+    for i in (0, 4, 8):
+        ws, wc = oracle.maxsim_topk(E, off, Qb[i], k, np.float32)
+        assert np.array_equal(bc[i], wc) and np.array_equal(bs[i], ws), i
+    idx.close()
+    # float data: the chunks of the full-precision passes, the float64 oracle's scores
+    E = oracle.synth_matrix(22_200 + dim, n, dim)
+    Qb = np.stack([oracle.synth_matrix(22_300 + i, 32, dim) for i in range(n_queries)])
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    bs, bc = idx.maxsim_topk_batch(Qb, k)
+    st = idx.filter_stats()
+    assert st["kind"] == "maxsim_batch_hi" and not st["fallback"], st
+    assert st["candidates_per_query_max"] < 2048
+    with idx.options(hi_maxsim=0):
+        fs, fc = idx.maxsim_topk_batch(Qb, k)
+    for i in range(n_queries):
+        ref = oracle.maxsim_scores(E, off, Qb[i], np.float64)
+        tol = 2e-6 * float(np.abs(ref).max())
+        assert_topk_close(bs[i], bc[i], ref, k, tol)
+        assert set(bc[i].tolist()) == set(fc[i].tolist())
+    # fp16 queries through the same route
+    bs16, bc16 = idx.maxsim_topk_batch(Qb.astype(np.float16), k)
+    for i in (0, 8):
+        ref = oracle.maxsim_scores(E, off, Qb[i].astype(np.float16).astype(np.float32), np.float64)
+        assert_topk_close(bs16[i], bc16[i], ref, k, 2e-6 * float(np.abs(ref).max()))
+    idx.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_fused_row_topk_of_a_big_batch_over_a_1536_wide_index(metric):
+    n, dim, B, k = 48_000, 1536, 128, 50
+    E = oracle.synth_matrix(23_000, n, dim)
+    Q = oracle.synth_matrix(23_100, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    s, r = idx.search_rows(Q, k)
+    st = idx.filter_stats()
+    assert st["kind"] == "rows_fused_hi" and not st["fallback"], st
+    for b in (0, 63, 127):
+        tol = 2e-6 * (1.0 if metric == "cosine" else max(1.0, float(np.linalg.norm(E, axis=1).max() * np.linalg.norm(Q[b]))))
+        assert_topk_close(s[b], r[b], oracle.similarity(E, Q[b], metric), k, tol)
+    with idx.options(fused_hi=0):  # (the fused top-k over the pre-split image: three products per multiply, what a wide index ran before)
+        s0, r0 = idx.search_rows(Q, k)
+    for b in (0, 127):
+        assert len(set(r[b].tolist()) ^ set(r0[b].tolist())) <= 2  # (the two routes' last bits differ: a swap at the k-th place is allowed)
+    idx.close()
