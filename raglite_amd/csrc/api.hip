@@ -588,7 +588,8 @@ int refresh_hi_plane(rl_index* idx, hipStream_t s) {
     RL_TRY(refresh_hi_image(idx, s));
     const bool off = !idx->opt.on(RL_OPT_KEEP_HI) || !idx->opt.on(RL_OPT_KEEP_HI_PLANE);
     const int32_t d = idx->dim;
-    const bool dim_ok = d == 128 || d == 256 || d == 384 || d == 512 || d == 768 || d == 1024;
+    // (the stream kernel's dims; wider embedders -- round 6 -- go through the packed scan, scan16.hip)
+    const bool dim_ok = d == 128 || d == 256 || d == 384 || d == 512 || d == 768 || d == 1024 || (d > 1024 && hi_dim_ok(d));
     const bool want = !off && !idx->E16 && idx->E && idx->split_scale > 0.f && dim_ok &&
                       (int64_t)idx->n_rows * d >= (int64_t(64) << 20) && (idx->metric == RL_COSINE || idx->metric == RL_DOT) &&
                       (image_need(idx) & IMG_HI_PLANE);
@@ -1613,6 +1614,12 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     const int mode = scan_mode(idx->metric);
     const int64_t n = idx->n_rows;
     if (!hi_valid(idx) || nb > 16 || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT) || n < 65536) return RL_ERR_UNSUPPORTED;
+    // WIDE index (dim > 1024, round 6): the stream kernels stop at 1024 (a wave keeps its slice of the queries in registers) -- the approximate
+    // pass is the packed VALU scan over the HI plane (scan16.hip: up to four queries per pass; the fp32 scan of such an index takes ONE), the
+    // candidates and the guarded full pass go through the fp32 scan.  Up to four queries: beyond, the passes over the plane cost what the
+    // full-precision scan does.
+    const bool wide = idx->dim > 1024;
+    if (wide && (nb > 4 || (reinterpret_cast<uintptr_t>(d_q) & 15))) return RL_ERR_UNSUPPORTED;
     const int32_t dim = idx->dim, cap = 1024;  // candidates per query (expected: k + a few dozen)
     const int64_t nc = (int64_t)nb * cap, ldx = nc;
     // ---- scratch: approximate top-k scores (+ unused ids), thresholds, counters + flag, candidate rows, their norms, the
@@ -1633,8 +1640,9 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     uint64_t* bmax = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(es + nc) + 7) & ~uintptr_t(7));  // [nb x 512] workgroup maxima (pivot route)
     float* sc = idx->scores.as<float>();
     // ---- (1) approximate pass over the HI plane ---------------------------------------------------------------------------------------------
-    int st = launch_maxsim_stream16(idx->hiplane.as<uint16_t>(), n, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, sc, ld,
-                                    idx->n_cu, s);
+    int st = wide ? launch_scan_rows16(idx->hiplane.as<uint16_t>(), n, dim, d_q, nb, nullptr, SCAN_RAW_DOT, sc, ld, s)
+                  : launch_maxsim_stream16(idx->hiplane.as<uint16_t>(), n, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, 1, sc, ld,
+                                           idx->n_cu, s);
     if (st != RL_OK) return st;
     // ---- (2) its exact top-k, and every row that could be in the exact top-k of the full-precision scores ----------------------------------
     // The bound: what the HI halves drop is known exactly per row -- max |e_lo| / |e| (cosine) and max |e_lo| (dot) are kept by the
@@ -1683,7 +1691,12 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     if (!gathered) RL_TRY(launch_gather_rows(idx->E, false, dim, n, ci, nc, G, s, cnt, cap));  // (the pivot route's collection gathers on its way)
     StreamSecondJob full;
     full.D = idx->E; full.n_rows = n; full.out = sc; full.ld = ld; full.run_if = flag;
-    st = launch_maxsim_stream_two(G, nc, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, xs, ldx, idx->n_cu, s, idx->split_scale, full);
+    if (wide) {  // raw dots of the gathered rows, then the guarded pass over the corpus: the fp32 scan, a query per pass
+        st = launch_scan_rows(G, nc, dim, d_q, nb, nullptr, SCAN_RAW_DOT, xs, ldx, s);
+        if (st == RL_OK) st = launch_scan_rows(idx->E, n, dim, d_q, nb, nullptr, SCAN_RAW_DOT, sc, ld, s, flag);
+    } else {
+        st = launch_maxsim_stream_two(G, nc, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, xs, ldx, idx->n_cu, s, idx->split_scale, full);
+    }
     if (st != RL_OK) return st;
     if (nb > 1) RL_TRY(launch_diag_blocks(xs, ldx, cap, nc, es, s));  // (one query: the block IS its diagonal)
     MergeTransform tr;  // (the metric transform of the re-scored candidates happens on the way into the ranking: transform_kernel's statements)
@@ -1747,7 +1760,7 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
         // lazy images: the routes below test what the index HAS; ask for what this batch's route reads first
         if (!d_row_bits && !cut && nb >= GEMM_MIN_QUERIES && k <= 512 && idx->opt.on(RL_OPT_FUSED_TOPK))
             RL_TRY(demand_images(idx, IMG_PLANES | (idx->opt.on(RL_OPT_FUSED_HI) ? IMG_HI_IMAGE : 0u), s));
-        if (!cut && nb <= 16 && k <= 512 && idx->opt.on(RL_OPT_HI_SEARCH)) RL_TRY(demand_images(idx, IMG_HI_PLANE, s));
+        if (!cut && nb <= (idx->dim > 1024 ? 4 : 16) && k <= 512 && idx->opt.on(RL_OPT_HI_SEARCH)) RL_TRY(demand_images(idx, IMG_HI_PLANE, s));
         if (!d_row_bits && !cut) {  // big batches over an index with a HI image: fused top-k at one MFMA product per multiply
             const int st = search_rows_fused_hi(idx, d_q + (int64_t)b0 * idx->dim, nb, k, d_scores + (int64_t)b0 * k, d_rows + (int64_t)b0 * k, ld, s);
             if (st == RL_OK) continue;
@@ -2017,6 +2030,8 @@ int pairs_pass(rl_index* idx, int32_t nq, int32_t n_queries, int32_t first, floa
 // n_q - 1 of them.  RL_ERR_UNSUPPORTED when the index has no image, has an empty chunk (the kernel finds a chunk by
 // counting chunk ends) or the shape is outside the kernel -- the caller then uses the streaming kernels.
 constexpr int32_t GEMM_PASS_QUERIES = 8, GEMM_PASS_MIN_QUERIES = 3;
+// (a WIDE index -- dim > 1024 -- has no streaming MaxSim kernel to fall back on but the VALU backstop: even ONE query goes through the pass)
+int32_t gemm_min_queries(const rl_index* idx) { return idx->dim > 1024 ? 1 : GEMM_PASS_MIN_QUERIES; }
 // An index WITHOUT the pre-split image (RL_OPT_KEEP_IMAGE = 0: rows + HI image, 1.5 x the corpus) still runs the bound-filtered batch: the
 // approximate pass reads the HI image, the exact re-scoring the rows, and the guarded full-precision fallback the rows through the streaming
 // kernels (one launch, grid row = query) -- which is what decides the shapes this holds for.
@@ -2029,7 +2044,7 @@ bool slim_batch_ok(const rl_index* idx, const float* d_q) {
 int gemm_prepare(rl_index* idx, const float* d_q, int32_t nq, int64_t q_stride, int32_t n_queries, hipStream_t s, bool want_planes = false,
                  uint32_t* zero_words = nullptr) {
     if (!idx->opt.on(RL_OPT_GEMM_PASS)) return RL_ERR_UNSUPPORTED;
-    if (idx->has_empty_chunk || idx->n_chunks == 0 || nq < 1 || nq > 32 || n_queries < GEMM_PASS_MIN_QUERIES) return RL_ERR_UNSUPPORTED;
+    if (idx->has_empty_chunk || idx->n_chunks == 0 || nq < 1 || nq > 32 || n_queries < gemm_min_queries(idx)) return RL_ERR_UNSUPPORTED;
     // lazy images: the image the approximate pass multiplies; the pre-split image only where the batch cannot run on rows + HI image
     // (options that route it through the eight-query kernel, shapes outside the slim batch, or the caller says so: k > 512, timing hooks)
     RL_TRY(demand_images(idx, approx_image_bit(idx), s));
@@ -2071,6 +2086,8 @@ int maxsim_scores_device(rl_index* idx, const float* d_q, int32_t nq, float* d_o
 
 int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, int32_t k, float* sc, int64_t ld, float* d_s, int32_t* d_c,
                         hipStream_t s);  // (defined behind the batch pipeline it shares its stages with)
+int maxsim_topk_batch_device(rl_index* idx, const float* d_q, bool q16, int32_t n_queries, int32_t nq, int32_t k, float* sc, int64_t ld, float* d_s,
+                             int32_t* d_c, hipStream_t s);
 }  // namespace
 
 int rl_maxsim_scores(rl_index* idx, const float* query_vecs, int32_t nq, float* out_scores, int mem, void* stream) {
@@ -2108,6 +2125,14 @@ int rl_maxsim_topk_filtered(rl_index* idx, const float* query_vecs, int32_t nq, 
     RL_TRY(stage_out_begin(out_scores, (size_t)k, mem, t_s, &d_s));
     RL_TRY(stage_out_begin(out_chunks, (size_t)k, mem, t_c, &d_c));
     RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));
+    if (!d_f && idx->dim > 1024) {  // a WIDE index: the batch's routes (the bound-filtered pipeline where the index keeps a HI image), batch of one
+        const int64_t ld1 = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
+        RL_TRY(idx->scores.reserve((size_t)ld1 * sizeof(float)));
+        RL_TRY(maxsim_topk_batch_device(idx, d_q, false, 1, nq, k, idx->scores.as<float>(), ld1, d_s, d_c, s));
+        RL_TRY(stage_out_end(out_scores, (size_t)k, mem, s, t_s));
+        RL_TRY(stage_out_end(out_chunks, (size_t)k, mem, s, t_c));
+        return finish(mem, s);
+    }
     if (!d_f) {  // one user query at a time, no metadata filter: the half-width route over the HI plane where the index has (or may build) one
         const int64_t ld1 = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
         RL_TRY(idx->scores.reserve((size_t)ld1 * sizeof(float)));
@@ -2295,6 +2320,7 @@ int hi_batch_fallback(rl_index* idx, const float* d_q, int32_t nq, int32_t n_que
 int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, int32_t k, float* sc, int64_t ld, float* d_s, int32_t* d_c,
                         hipStream_t s) {
     if (n < 1 || n > 2 || nq < 1 || nq > 32 || k > 512 || !idx->opt.on(RL_OPT_HI_MAXSIM) || !idx->opt.on(RL_OPT_HI_FEW)) return RL_ERR_UNSUPPORTED;
+    if (idx->dim > 1024) return RL_ERR_UNSUPPORTED;  // (the stream kernels' dims: a wide index takes the pass even for one query, gemm_min_queries)
     if (idx->E16 || !idx->E || !(idx->split_scale > 0.f) || idx->has_empty_chunk || idx->n_chunks == 0 || idx->n_rows == 0) return RL_ERR_UNSUPPORTED;
     RL_TRY(demand_images(idx, IMG_HI_PLANE, s));
     if (!hi_valid(idx) || idx->max_row_norm_rows != idx->n_rows || !(idx->max_row_norm > 0.f)) return RL_ERR_UNSUPPORTED;
@@ -2350,40 +2376,11 @@ int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, 
                                    idx->max_row_norm + idx->max_lo_norm, hb.m));
     return hi_batch_rescore(idx, d_q, nq, n, n, k, sc, ld, hb, d_s, d_c, s, true);
 }
-}  // namespace
-
-// query_vecs: [n_queries x nq x dim] fp32 -- or, q16, IEEE fp16 (rl_maxsim_topk_batch_f16): widened on the device (exact), and over an
-// fp16-stored index the one-product pass then IS the score (hi_filter.hip: f16_exact_finish_kernel)
-static int maxsim_topk_batch_any(rl_index* idx, const void* query_vecs, bool q16, int32_t n_queries, int32_t nq, int32_t k,
-                                 float* out_scores, int32_t* out_chunks, int mem, void* stream) {
-    if (!idx) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: null index");
-    if (n_queries < 0 || nq < 1) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: bad sizes");
-    if (k < 1) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: k must be >= 1");
-    if (k > K_MAX) return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_topk_batch: k must be <= 2048");
-    if (n_queries == 0) return RL_OK;
-    if (!query_vecs || !out_scores || !out_chunks) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: null argument");
-    hipStream_t s = as_stream(stream);
-    std::lock_guard<std::mutex> lock(idx->mu);
-    RL_TRY(use_scratch(idx, s));
-    DevBuf t_q, t_s, t_c;
-    const float* d_q; float* d_s; int32_t* d_c;
+// The device side of rl_maxsim_topk_batch: d_q [n_queries x nq x dim] -> d_s / d_c [n_queries x k]; sc: [n_queries x ld] scratch rows
+// (idx->scores); q16: the queries were widened from fp16 (exact).  Also what rl_maxsim_topk runs on a WIDE index, as a batch of one.
+int maxsim_topk_batch_device(rl_index* idx, const float* d_q, bool q16, int32_t n_queries, int32_t nq, int32_t k, float* sc, int64_t ld, float* d_s,
+                             int32_t* d_c, hipStream_t s) {
     const size_t q_elems = (size_t)nq * idx->dim;
-    if (q16) {
-        const uint16_t* d_q16;
-        RL_TRY(stage_in(static_cast<const uint16_t*>(query_vecs), (size_t)n_queries * q_elems, mem, s, t_q, &d_q16));
-        RL_TRY(idx->q32.reserve((size_t)n_queries * q_elems * sizeof(float)));
-        const int st_w = launch_widen_f16(d_q16, idx->q32.as<float>(), (int64_t)n_queries * (int64_t)q_elems, s);
-        if (st_w == RL_ERR_UNSUPPORTED) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch_f16: query_vecs_f16 must be 2-byte aligned");
-        RL_TRY(st_w);  // (a launch failure stays what it is)
-        d_q = idx->q32.as<float>();
-    } else {
-        RL_TRY(stage_in(static_cast<const float*>(query_vecs), (size_t)n_queries * q_elems, mem, s, t_q, &d_q));
-    }
-    RL_TRY(stage_out_begin(out_scores, (size_t)n_queries * k, mem, t_s, &d_s));
-    RL_TRY(stage_out_begin(out_chunks, (size_t)n_queries * k, mem, t_c, &d_c));
-    const int64_t ld = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
-    RL_TRY(idx->scores.reserve((size_t)n_queries * ld * sizeof(float)));
-    float* sc = idx->scores.as<float>();
     // One corpus pass per query, back to back on the caller's stream.  (Round-robin over side streams hides each
     // launch's tail behind the next one's ramp and measured +1.5 % at 1 M rows / +3.3 % on a 125 k-row shard, but
     // concurrent kernels stretch each other's durations 3x in a kernel trace, which would make the rocprofv3 summary
@@ -2395,9 +2392,9 @@ static int maxsim_topk_batch_any(rl_index* idx, const void* query_vecs, bool q16
     int32_t base = 0;
     bool hi_done = false;  // queries [0, base) were ranked by the half-bytes pipeline below (results already in d_s / d_c)
     {
-        const int32_t n_gemm = n_queries - base >= GEMM_PASS_MIN_QUERIES
+        const int32_t n_gemm = n_queries - base >= gemm_min_queries(idx)
                                    ? (n_queries / GEMM_PASS_QUERIES) * GEMM_PASS_QUERIES +
-                                         ((n_queries % GEMM_PASS_QUERIES) >= GEMM_PASS_MIN_QUERIES ? n_queries % GEMM_PASS_QUERIES : 0)
+                                         ((n_queries % GEMM_PASS_QUERIES) >= gemm_min_queries(idx) ? n_queries % GEMM_PASS_QUERIES : 0)
                                    : 0;
         // (the flag block of the bound-filtered pipeline lies in a pool sized by n_gemm and k alone: reserved here so that the query-image
         // kernel can zero it on its way -- one memset launch less per batch)
@@ -2448,7 +2445,7 @@ static int maxsim_topk_batch_any(rl_index* idx, const void* query_vecs, bool q16
                 base = n_gemm;
                 hi_done = true;
             } else if (!slim) {
-                while (n_queries - base >= GEMM_PASS_MIN_QUERIES) {
+                while (n_queries - base >= gemm_min_queries(idx)) {
                     const int32_t n_q = std::min<int32_t>(GEMM_PASS_QUERIES, n_queries - base);
                     RL_TRY(gemm_pass(idx, nq, n_queries, base, n_q, sc + (int64_t)base * ld, ld, s));
                     base += n_q;
@@ -2484,6 +2481,43 @@ static int maxsim_topk_batch_any(rl_index* idx, const void* query_vecs, bool q16
         }
     }
     if (idx->live_chunk_bits) RL_TRY(launch_fix_masked(d_s, d_c, (int64_t)n_queries * k, s));
+    return RL_OK;
+}
+}  // namespace
+
+// query_vecs: [n_queries x nq x dim] fp32 -- or, q16, IEEE fp16 (rl_maxsim_topk_batch_f16): widened on the device (exact), and over an
+// fp16-stored index the one-product pass then IS the score (hi_filter.hip: f16_exact_finish_kernel)
+static int maxsim_topk_batch_any(rl_index* idx, const void* query_vecs, bool q16, int32_t n_queries, int32_t nq, int32_t k,
+                                 float* out_scores, int32_t* out_chunks, int mem, void* stream) {
+    if (!idx) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: null index");
+    if (n_queries < 0 || nq < 1) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: bad sizes");
+    if (k < 1) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: k must be >= 1");
+    if (k > K_MAX) return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_topk_batch: k must be <= 2048");
+    if (n_queries == 0) return RL_OK;
+    if (!query_vecs || !out_scores || !out_chunks) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch: null argument");
+    hipStream_t s = as_stream(stream);
+    std::lock_guard<std::mutex> lock(idx->mu);
+    RL_TRY(use_scratch(idx, s));
+    DevBuf t_q, t_s, t_c;
+    const float* d_q; float* d_s; int32_t* d_c;
+    const size_t q_elems = (size_t)nq * idx->dim;
+    if (q16) {
+        const uint16_t* d_q16;
+        RL_TRY(stage_in(static_cast<const uint16_t*>(query_vecs), (size_t)n_queries * q_elems, mem, s, t_q, &d_q16));
+        RL_TRY(idx->q32.reserve((size_t)n_queries * q_elems * sizeof(float)));
+        const int st_w = launch_widen_f16(d_q16, idx->q32.as<float>(), (int64_t)n_queries * (int64_t)q_elems, s);
+        if (st_w == RL_ERR_UNSUPPORTED) return fail(RL_ERR_INVALID, "rl_maxsim_topk_batch_f16: query_vecs_f16 must be 2-byte aligned");
+        RL_TRY(st_w);  // (a launch failure stays what it is)
+        d_q = idx->q32.as<float>();
+    } else {
+        RL_TRY(stage_in(static_cast<const float*>(query_vecs), (size_t)n_queries * q_elems, mem, s, t_q, &d_q));
+    }
+    RL_TRY(stage_out_begin(out_scores, (size_t)n_queries * k, mem, t_s, &d_s));
+    RL_TRY(stage_out_begin(out_chunks, (size_t)n_queries * k, mem, t_c, &d_c));
+    const int64_t ld = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
+    RL_TRY(idx->scores.reserve((size_t)n_queries * ld * sizeof(float)));
+    float* sc = idx->scores.as<float>();
+    RL_TRY(maxsim_topk_batch_device(idx, d_q, q16, n_queries, nq, k, sc, ld, d_s, d_c, s));
     RL_TRY(stage_out_end(out_scores, (size_t)n_queries * k, mem, s, t_s));
     RL_TRY(stage_out_end(out_chunks, (size_t)n_queries * k, mem, s, t_c));
     return finish(mem, s);
@@ -2511,8 +2545,8 @@ int rl_maxsim_batch_begin(rl_index* idx, const float* query_vecs, int32_t n_quer
     idx->mb_B = 0;
     // the bound-filtered pipeline must cover the WHOLE batch (rl_maxsim_topk_batch takes other kernels for what it leaves over)
     const bool hi_off = !idx->opt.on(RL_OPT_HI_MAXSIM);
-    const bool whole = n_queries % GEMM_PASS_QUERIES == 0 || n_queries % GEMM_PASS_QUERIES >= GEMM_PASS_MIN_QUERIES;
-    if (hi_off || !whole || n_queries < GEMM_PASS_MIN_QUERIES || k > 512 || nq > 32)
+    const bool whole = n_queries % GEMM_PASS_QUERIES == 0 || n_queries % GEMM_PASS_QUERIES >= gemm_min_queries(idx);
+    if (hi_off || !whole || n_queries < gemm_min_queries(idx) || k > 512 || nq > 32)
         return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_batch_begin: needs >= 3 queries (n % 8 == 0 or n % 8 >= 3), nq <= 32 and k <= 512");
     DevBuf t_q, t_o;
     const float* d_q; float* d_o;

@@ -123,8 +123,8 @@ __device__ __forceinline__ float transform_score(float d, int mode, float row_no
 }
 // scores[b * ld + row] for b < nb (nb <= 4 per launch handled inside), rows < n.
 int launch_scan_rows(const float* E, int64_t n, int32_t dim, const float* queries, int32_t nb,
-                     const float* row_norm, int mode, float* scores, int64_t ld, hipStream_t s);
-// scan16.hip: the same over an fp16-stored corpus
+                     const float* row_norm, int mode, float* scores, int64_t ld, hipStream_t s, const uint32_t* run_if = nullptr);
+// scan16.hip: the same over an fp16-stored corpus (dim <= 1024) -- or over the HI plane of a WIDE fp32 index (dim <= 4096, nb <= 4: raw dots)
 int launch_scan_rows16(const uint16_t* E, int64_t n, int32_t dim, const float* queries, int32_t nb,
                        const float* row_norm, int mode, float* scores, int64_t ld, hipStream_t s);
 int launch_row_norms16(const uint16_t* E, int64_t n, int32_t dim, float* norm, float* sumsq, hipStream_t s);

@@ -55,7 +55,8 @@ template <int NV, int VEC, int BQ>
 __global__ __launch_bounds__(256) void scan_rows_kernel(const float* __restrict__ E, int64_t n, int dim,
                                                          const float* __restrict__ queries,
                                                          const float* __restrict__ row_norm, int mode,
-                                                         float* __restrict__ scores, int64_t ld) {
+                                                         float* __restrict__ scores, int64_t ld, const uint32_t* __restrict__ run_if) {
+    if (run_if && *run_if == 0u) return;  // (a guarded launch: the full-precision pass behind a half-bytes search of a wide index)
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
@@ -200,17 +201,17 @@ __global__ __launch_bounds__(256) void transform_kernel(float* __restrict__ scor
 
 template <int NV, int VEC, int BQ>
 static int scan_t(const float* E, int64_t n, int32_t dim, const float* q, const float* rn, int mode, float* sc,
-                  int64_t ld, hipStream_t s) {
+                  int64_t ld, hipStream_t s, const uint32_t* run_if) {
     const int blocks = persistent_grid(scan_rows_kernel<NV, VEC, BQ>, 256, (n + 7) / 8);
     hipLaunchKernelGGL((scan_rows_kernel<NV, VEC, BQ>), dim3(blocks), dim3(256), 0, s, E, n, (int)dim, q, rn, mode, sc,
-                       ld);
+                       ld, run_if);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
 
 template <int NV, int VEC>
 static int scan_nb(const float* E, int64_t n, int32_t dim, const float* q, int32_t nb, const float* rn, int mode,
-                   float* sc, int64_t ld, hipStream_t s) {
+                   float* sc, int64_t ld, hipStream_t s, const uint32_t* run_if) {
     // Queries are consumed 4 / 2 / 1 per corpus pass (registers permitting).
     constexpr bool wide = (NV * VEC <= 16);
     int32_t b = 0;
@@ -218,10 +219,10 @@ static int scan_nb(const float* E, int64_t n, int32_t dim, const float* q, int32
         const float* qb = q + (int64_t)b * dim;
         float* sb = sc + (int64_t)b * ld;
         if constexpr (wide) {
-            if (nb - b >= 4) { RL_TRY((scan_t<NV, VEC, 4>(E, n, dim, qb, rn, mode, sb, ld, s))); b += 4; continue; }
-            if (nb - b >= 2) { RL_TRY((scan_t<NV, VEC, 2>(E, n, dim, qb, rn, mode, sb, ld, s))); b += 2; continue; }
+            if (nb - b >= 4) { RL_TRY((scan_t<NV, VEC, 4>(E, n, dim, qb, rn, mode, sb, ld, s, run_if))); b += 4; continue; }
+            if (nb - b >= 2) { RL_TRY((scan_t<NV, VEC, 2>(E, n, dim, qb, rn, mode, sb, ld, s, run_if))); b += 2; continue; }
         }
-        RL_TRY((scan_t<NV, VEC, 1>(E, n, dim, qb, rn, mode, sb, ld, s)));
+        RL_TRY((scan_t<NV, VEC, 1>(E, n, dim, qb, rn, mode, sb, ld, s, run_if)));
         b += 1;
     }
     return RL_OK;
@@ -230,10 +231,10 @@ static int scan_nb(const float* E, int64_t n, int32_t dim, const float* q, int32
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int launch_scan_rows(const float* E, int64_t n, int32_t dim, const float* queries, int32_t nb, const float* row_norm,
-                     int mode, float* scores, int64_t ld, hipStream_t s) {
+                     int mode, float* scores, int64_t ld, hipStream_t s, const uint32_t* run_if) {
     if (n <= 0 || nb <= 0) return RL_OK;
     const bool vec4 = (dim % 4 == 0) && aligned16(E) && aligned16(queries);
-#define RL_SCAN(NV, VEC) return scan_nb<NV, VEC>(E, n, dim, queries, nb, row_norm, mode, scores, ld, s)
+#define RL_SCAN(NV, VEC) return scan_nb<NV, VEC>(E, n, dim, queries, nb, row_norm, mode, scores, ld, s, run_if)
     if (vec4) {
         const int nv = (dim + 255) / 256;
         if (nv <= 1) RL_SCAN(1, 4);

@@ -308,6 +308,72 @@ def cfg4_end_to_end():
     return bench_embed.run(100_000)
 
 
+def wide_dims():
+    """Embedders wider than bge-m3 (round 6; the reference takes any litellm embedder, src/raglite/_embed.py:155-158: 1536- and 3072-wide models):
+    the half-bytes routes at dim 1536 / 3072, each next to the full-precision route the same index ran before (the route's option off)."""
+    out = {"workload": "dim 1536 / 3072 indexes: MaxSim batch of 64 x 32 and one query over 300 k / 150 k rows, cosine top-100 of 1 and 1000 queries over 650 k x 1536",
+           "unit": "queries/s", "value": None}
+    for d, n in ((1536, 300_000), (3072, 150_000)):
+        E = torch.empty((n, d), dtype=torch.float32, device="cuda")
+        raglite_amd.synth_fill(E, seed=5)
+        off = np.arange(0, n + 1, 8, dtype=np.int64)
+        if off[-1] != n:
+            off = np.concatenate((off, [n]))
+        Q = torch.empty((64, 32, d), dtype=torch.float32, device="cuda")
+        raglite_amd.synth_fill(Q, seed=50)
+        idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+        ms = timed(lambda: idx.maxsim_topk_batch(Q, 100), 5, 2)
+        st = idx.filter_stats()
+        blk = {"rows": n, "dim": d, "queries_per_step": 64, "value": 64e3 / ms, "ms_per_step": float(ms), "route": st["kind"],
+               "candidates_per_query_mean": st.get("candidates_per_query_mean"), "fallback": st.get("fallback"),
+               "rows_x_dim_per_s": 64e3 / ms * n * d, "index_bytes_over_corpus": sum(idx.memory()[key] for key in ("rows", "presplit_image", "hi_image", "hi_plane")) / (4.0 * n * d)}
+        i = [0]
+
+        def one():
+            idx.maxsim_topk(Q[i[0] % 64], 100)
+            i[0] += 1
+
+        ms1 = timed(one, 20)
+        blk["one_query"] = {"value": 1e3 / ms1, "ms_per_query": float(ms1), "route": idx.filter_stats()["kind"]}
+        with idx.options(hi_maxsim=0):
+            ms0 = timed(lambda: idx.maxsim_topk_batch(Q, 100), 3, 1)
+            blk["full_precision_passes"] = {"value": 64e3 / ms0, "ms_per_step": float(ms0)}
+        out[f"maxsim_dim{d}"] = blk
+        idx.close()
+        del E, Q
+        torch.cuda.empty_cache()
+    n, d = 650_000, 1536
+    E = torch.empty((n, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(E, seed=2)
+    Q = torch.empty((1000, d), dtype=torch.float32, device="cuda")
+    raglite_amd.synth_fill(Q, seed=20)
+    idx = raglite_amd.DeviceIndex(E, metric="cosine")
+    i = [0]
+
+    def one_row():
+        idx.search_rows(Q[i[0] % 64], 100)
+        i[0] += 1
+
+    ms = timed(one_row, 30)
+    blk = {"rows": n, "dim": d, "value": 1e3 / ms, "ms_per_query": float(ms), "route": idx.filter_stats()["kind"],
+           "algorithmic_bytes_4B_per_element": 4.0 * n * d, "frac_vs_4B_per_element_whole_query": 4.0 * n * d / (ms * 1e-3) / 1e9 / HBM_PEAK,
+           "narrower_image": "HI plane: 2 B per element"}
+    with idx.options(hi_search=0):
+        ms0 = timed(one_row, 20)
+        blk["fp32_scan"] = {"value": 1e3 / ms0, "ms_per_query": float(ms0)}
+    out["cosine_top100_one_query_dim1536"] = blk
+    msb = timed(lambda: idx.search_rows(Q, 100), 5, 2)
+    blk = {"rows": n, "dim": d, "queries": 1000, "ms_per_batch": float(msb), "value": 1e6 / msb, "route": idx.filter_stats()["kind"],
+           "fp16_tflops_one_product": 2.0 * 1000 * n * d / (msb * 1e-3) / 1e12}
+    with idx.options(fused_hi=0):
+        msb0 = timed(lambda: idx.search_rows(Q, 100), 3, 1)
+        blk["three_products_over_the_presplit_image"] = {"ms_per_batch": float(msb0), "route": idx.filter_stats()["kind"]}
+    out["cosine_top100_1000_queries_dim1536"] = blk
+    idx.close()
+    out["value"] = out["maxsim_dim1536"]["value"]
+    return out
+
+
 def beyond_shape():
     """What the fast paths do NOT cover: correct everywhere, slower outside the headline's shape.  The reference accepts any
     litellm embedder (src/raglite/_embed.py:155-158: 1536- / 3072-wide models) and `l2` (_config.py:69); this block puts a number on those routes."""

@@ -128,3 +128,89 @@ def test_fused_row_topk_of_a_big_batch_over_a_1536_wide_index(metric):
     for b in (0, 127):
         assert len(set(r[b].tolist()) ^ set(r0[b].tolist())) <= 2  # (the two routes' last bits differ: a swap at the k-th place is allowed)
     idx.close()
+
+
+# ---- a few queries at a time over a wide index: the half-bytes row search through the packed scan (api.hip: search_rows_hi, `wide`) ------------
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+@pytest.mark.parametrize("n,dim,B,k", [(48_000, 1536, 1, 100), (70_000, 1536, 4, 512), (36_000, 2048, 3, 10), (24_000, 3072, 2, 100), (70_000, 4096, 1, 50)])
+def test_few_queries_row_search_over_a_wide_index(metric, n, dim, B, k):
+    E = oracle.synth_matrix(24_000 + dim, n, dim)
+    Q = oracle.synth_matrix(24_100 + B, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    S, R = idx.search_rows(Q if B > 1 else Q[0], k)
+    st = idx.filter_stats()
+    want_route = n >= 65_536  # (the route's own size gate)
+    assert (st["kind"] == "rows_hi") == want_route, st
+    assert not want_route or not st["fallback"]
+    with idx.options(hi_search=0):
+        S0, R0 = idx.search_rows(Q if B > 1 else Q[0], k)
+    S, R, S0, R0 = np.atleast_2d(S), np.atleast_2d(R), np.atleast_2d(S0), np.atleast_2d(R0)
+    for b in range(B):
+        sims = oracle.similarity(E, Q[b], metric)
+        assert_topk_close(S[b], R[b], sims, k, 2e-6 * max(1.0, float(np.abs(sims).max())))
+        if metric == "dot":  # (1 + e.q by the same scan: the same bits; a cosine's query norm is summed in another order by the two routes)
+            assert np.array_equal(R[b], R0[b]) and np.array_equal(S[b].view(np.uint32), S0[b].view(np.uint32))
+    idx.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot"])
+def test_wide_row_search_integer_data_filter_tombstones_and_the_guarded_full_pass(metric):
+    rng = np.random.default_rng(31)
+    n, dim, k = 70_000, 1536, 64
+    E = oracle.synth_matrix(25_000, n, dim, "small_int")
+    Q = oracle.synth_matrix(25_001, 3, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    S, R = idx.search_rows(Q, k)
+    assert idx.filter_stats()["kind"] == "rows_hi"
+    from tests.util import sim_fp32_exact
+    for b in range(3):
+        es, ei = oracle.topk_desc(sim_fp32_exact(E, Q[b], metric), k)
+        assert np.array_equal(R[b], ei) and np.array_equal(S[b].view(np.uint32), es.astype(np.float32).view(np.uint32))
+    ok = rng.random(n) < 0.4
+    S1, R1 = idx.search_rows(Q, k, chunk_filter=ok)
+    assert ok[R1].all()
+    for b in range(3):
+        sims = np.where(ok, sim_fp32_exact(E, Q[b], metric), -np.inf)
+        es, ei = oracle.topk_desc(sims, k)
+        assert np.array_equal(R1[b], ei)
+    idx.close()
+    # near-duplicates: more rows inside the band than a list holds -> the flag -> the guarded fp32 scan + selection answer
+    E = oracle.synth_matrix(25_100, n, dim)
+    q = oracle.synth_matrix(25_101, 1, dim)[0]
+    dup = rng.choice(n, 5000, replace=False)
+    E[dup] = (q[None, :] * 0.9 + 1e-4 * rng.standard_normal((5000, dim))).astype(np.float32)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    S, R = idx.search_rows(q, 100)
+    assert idx.filter_stats()["fallback"]
+    assert np.isin(R, dup).all()
+    sims = oracle.similarity(E, q, metric)
+    assert_topk_close(S, R, sims, 100, 2e-6 * max(1.0, float(np.abs(sims).max())))
+    idx.close()
+
+
+@pytest.mark.parametrize("dim,n", [(1536, 48_000), (3072, 24_000)])
+def test_one_maxsim_query_over_a_wide_index_goes_through_the_pass(dim, n):
+    """`rl_maxsim_topk` (one user query at a time: how the reference calls the reranker, `_search.py:394-396`) and batches of one or two on a wide
+    index: no streaming kernel covers dim > 1024, so even one query takes the bound-filtered pipeline (api.hip: gemm_min_queries)."""
+    rng = np.random.default_rng(dim + 7)
+    off = ragged_offsets(rng, n, 1, 15)
+    E = oracle.synth_matrix(26_000 + dim, n, dim)
+    Qb = np.stack([oracle.synth_matrix(26_100 + i, 32, dim) for i in range(2)])
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    s1, c1 = idx.maxsim_topk(Qb[0], 100)
+    st = idx.filter_stats()
+    assert st["kind"] == "maxsim_batch_hi" and not st["fallback"], st
+    ref = oracle.maxsim_scores(E, off, Qb[0], np.float64)
+    assert_topk_close(s1, c1, ref, 100, 2e-6 * float(np.abs(ref).max()))
+    s2, c2 = idx.maxsim_topk_batch(Qb, 100)
+    assert np.array_equal(c2[0], c1) and np.array_equal(s2[0].view(np.uint32), s1.view(np.uint32))
+    ref = oracle.maxsim_scores(E, off, Qb[1], np.float64)
+    assert_topk_close(s2[1], c2[1], ref, 100, 2e-6 * float(np.abs(ref).max()))
+    dead = np.unique(c1[:7])
+    idx.delete_chunks(dead)
+    s3, c3 = idx.maxsim_topk(Qb[0], 100)
+    assert not np.isin(c3, dead).any()
+    ok = rng.random(len(off) - 1) < 0.5  # (a metadata filter: the full-precision scores of every chunk, masked)
+    s4, c4 = idx.maxsim_topk(Qb[0], 50, chunk_filter=ok)
+    assert ok[c4].all() and not np.isin(c4, dead).any()
+    idx.close()
