@@ -2037,7 +2037,9 @@ int32_t gemm_min_queries(const rl_index* idx) { return idx->dim > 1024 ? 1 : GEM
 // kernels (one launch, grid row = query) -- which is what decides the shapes this holds for.
 bool slim_batch_ok(const rl_index* idx, const float* d_q) {
     const int32_t d = idx->dim;
-    return !image_valid(idx) && !idx->E16 && idx->E && hi_image_valid(idx) && (d == 256 || d == 384 || d == 512 || d == 768 || d == 1024) &&
+    // (the guarded fallback without the pre-split image: the streaming kernels' dims, or -- wide indexes -- the exact kernel over every chunk)
+    return !image_valid(idx) && !idx->E16 && idx->E && hi_image_valid(idx) &&
+           (d == 256 || d == 384 || d == 512 || d == 768 || d == 1024 || (d > 1024 && hi_dim_ok(d))) &&
            !(reinterpret_cast<uintptr_t>(d_q) & 15) && !(reinterpret_cast<uintptr_t>(idx->E) & 15);
 }
 // zero_words: sixteen words the query-image kernel zeroes on its way (the batch's flag block: no memset launch)
@@ -2275,6 +2277,8 @@ int hi_batch_fallback(rl_index* idx, const float* d_q, int32_t nq, int32_t n_que
     if (image_valid(idx) && !rows_only)
         RL_TRY(launch_maxsim_gemm(idx->planes.p, idx->n_rows, idx->dim, idx->qplanes.p, n_queries, 0, n_gemm, nq, idx->row_to_chunk, idx->offsets,
                                   idx->ends.as<uint32_t>(), sc, ld, idx->n_cu, s, image_scale(idx), idx->E16 != nullptr, hb.flag, false, true));
+    else if (idx->dim > 1024)  // (a wide index: no streaming kernel -- the exact re-scoring kernel over EVERY chunk, behind the flag)
+        RL_TRY(launch_maxsim_pairs_all_wide(idx->E, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, idx->n_chunks, n_gemm, sc, ld, s, hb.flag));
     else  // (grid row = query: with many queries a grid column of n_cu workgroups per query is 32 k workgroups that return at once behind the
           // flag -- 25 us of every step; n_cu / 8 columns keep the device as full when the passes do run and cost 3 us when they do not)
         RL_TRY(launch_maxsim_stream_batch(idx->E, false, idx->n_rows, idx->dim, d_q, nq, (int64_t)q_elems, n_gemm, idx->row_to_chunk, idx->offsets,

@@ -430,10 +430,13 @@ constexpr int PW_KW = 128, PW_T = 8, PW_PITCH = PW_KW + 8;
 __global__ __launch_bounds__(512) void maxsim_pairs_wide_kernel(const float* __restrict__ D, int dim, const float* __restrict__ Q, int nq,
                                                                  int64_t q_stride, const int64_t* __restrict__ offsets,
                                                                  const int32_t* __restrict__ candidates, int64_t n_items, int64_t item_stride,
-                                                                 float* __restrict__ out) {
+                                                                 float* __restrict__ out, const uint32_t* __restrict__ run_if) {
     extern __shared__ __attribute__((aligned(16))) float qs[];  // [8 waves][32][PW_PITCH]
+    // run_if: a guarded launch (the full-precision fallback of a MaxSim batch over a wide index that keeps no pre-split image: EVERY chunk
+    // is a candidate -- candidates == nullptr: item i is chunk i -- scored exactly; it returns at once unless the batch's flag is up)
+    if (run_if && __builtin_amdgcn_readfirstlane((int)*run_if) == 0) return;
     const float* Qb = Q + (int64_t)blockIdx.y * q_stride;
-    const int32_t* cb = candidates + (int64_t)blockIdx.y * item_stride;
+    const int32_t* cb = candidates ? candidates + (int64_t)blockIdx.y * item_stride : nullptr;
     float* ob = out + (int64_t)blockIdx.y * item_stride;
     const int lane = threadIdx.x & 63, w = wave_id();
     const int m = lane & 15, g = lane >> 4;
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(512) void maxsim_pairs_wide_kernel(const float* __r
         const int64_t mine = base + (int64_t)lane * stride;
         int32_t vb = 0, ve = 0;  // (row numbers fit 31 bits: rl_index_create)
         if (mine < n_items) {
-            const int64_t chunk = cb[mine];
+            const int64_t chunk = cb ? (int64_t)cb[mine] : mine;
             if (chunk >= 0) { vb = (int32_t)offsets[chunk]; ve = (int32_t)offsets[chunk + 1]; }
             if (ve <= vb) ob[mine] = -INFINITY;
         }
@@ -605,7 +608,7 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
         }
         const int per_q = (int)std::max<int64_t>(1, std::min<int64_t>((n_items_per_query + 7) / 8, std::max<int64_t>(1, 256 / n_queries)));
         hipLaunchKernelGGL(maxsim_pairs_wide_kernel, dim3(per_q, n_queries), dim3(512), lds_w, s, D, (int)dim, Q, (int)nq, q_stride, offsets, candidates,
-                           n_items_per_query, item_stride, out);
+                           n_items_per_query, item_stride, out, (const uint32_t*)nullptr);
         RL_HIP(hipGetLastError());
         return RL_OK;
     }
@@ -693,6 +696,26 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
     else RL_PAIRS(false, 128);
 #undef RL_PACKED
 #undef RL_PAIRS
+    RL_HIP(hipGetLastError());
+    return RL_OK;
+}
+
+// Exact MaxSim scores of EVERY chunk for a batch of queries over a wide index (1024 < dim <= 4096, dim % 128 == 0), behind a run-if flag:
+// out[q * out_stride + chunk].  The guarded full-precision fallback of the bound-filtered batch where the index keeps rows + HI image only.
+int launch_maxsim_pairs_all_wide(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride, const int64_t* offsets, int64_t n_chunks,
+                                 int32_t n_queries, float* out, int64_t out_stride, hipStream_t s, const uint32_t* run_if) {
+    if (n_chunks <= 0 || n_queries <= 0) return RL_OK;
+    if (nq < 1 || nq > 32 || dim <= 1024 || dim > PAIRS_MAX_DIM || dim % PW_KW) return RL_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
+    static bool attr = false;
+    if (!attr) {
+        RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const size_t lds_w = (size_t)8 * 32 * PW_PITCH * sizeof(float);
+    const int per_q = (int)std::max<int64_t>(1, std::min<int64_t>((n_chunks + 511) / 512, std::max<int64_t>(1, 1024 / n_queries)));
+    hipLaunchKernelGGL(maxsim_pairs_wide_kernel, dim3(per_q, n_queries), dim3(512), lds_w, s, D, (int)dim, Q, (int)nq, q_stride, offsets,
+                       (const int32_t*)nullptr, n_chunks, out_stride, out, run_if);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

@@ -214,3 +214,32 @@ def test_one_maxsim_query_over_a_wide_index_goes_through_the_pass(dim, n):
     s4, c4 = idx.maxsim_topk(Qb[0], 50, chunk_filter=ok)
     assert ok[c4].all() and not np.isin(c4, dead).any()
     idx.close()
+
+
+def test_wide_index_keeps_rows_and_hi_image_only_and_its_guarded_fallback_scores_every_chunk_exactly():
+    """A wide index runs the batch on rows + HI image (1.5 x the corpus) like a 1024-wide one; what stands behind the flag there is the exact
+    re-scoring kernel over EVERY chunk (no streaming kernel covers dim > 1024).  4 000 near-identical one-row chunks defeat the bound: the
+    first batch falls back through it, leaves word, and the second asks for the pre-split image (the eight-query full-precision pass)."""
+    rng = np.random.default_rng(16)
+    n, dim = 48_000, 1536
+    off = np.arange(n + 1, dtype=np.int64)
+    E = oracle.synth_matrix(27_000, n, dim)
+    Qb = np.stack([oracle.synth_matrix(27_100 + i, 8, dim) for i in range(4)])
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    s0, c0 = idx.maxsim_topk_batch(Qb, 100)
+    mem = idx.memory()
+    assert not idx.filter_stats()["fallback"] and mem["presplit_image"] == 0 and mem["hi_image"] > 0
+    idx.close()
+    hot = rng.choice(n, 4000, replace=False)
+    E[hot] = (3.0 * Qb[:, 0].sum(axis=0)[None, :] + 1e-4 * rng.standard_normal((4000, dim))).astype(np.float32)
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    s1, c1 = idx.maxsim_topk_batch(Qb, 100)
+    assert idx.filter_stats()["fallback"] and idx.memory()["presplit_image"] == 0
+    s2, c2 = idx.maxsim_topk_batch(Qb, 100)
+    assert idx.filter_stats()["fallback"] and idx.memory()["presplit_image"] > 0
+    for s_, c_ in ((s1, c1), (s2, c2)):
+        for i in range(len(Qb)):
+            ref = oracle.maxsim_scores(E, off, Qb[i], np.float64)
+            assert_topk_close(s_[i], c_[i], ref, 100, 2e-6 * float(np.abs(ref).max()))
+            assert np.isin(c_[i], hot).all()
+    idx.close()
