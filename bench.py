@@ -764,7 +764,7 @@ def main() -> None:
         import bench_configs
 
         result["configs"] = {}
-        for name in ("cfg1", "cfg2", "cfg3", "cfg3_pool2g", "cfg4", "cfg4_end_to_end", "cfg5", "cfg5_full_one_gpu", "beyond_shape"):
+        for name in ("cfg1", "cfg2", "cfg3", "cfg3_pool2g", "cfg4", "cfg4_end_to_end", "cfg5", "cfg5_full_one_gpu", "wide_dims", "beyond_shape"):
             try:
                 result["configs"][name] = bench_configs.run(name)
             except Exception as exc:  # noqa: BLE001 - a failing side config must not hide the headline
