@@ -125,11 +125,17 @@ int rl_index_info(const rl_index* index, int64_t* n_rows, int32_t* dim, int64_t*
  * RL_OPT_IMAGE_HEADROOM_MB overrides -- free for the scratch and the caller; without them the same calls run through the kernels over
  * the stored rows (same results: every image path is bit-identical to, or re-scored exactly against, the rows).
  * Index footprint: all three images make an fp32 index 3 x its corpus.  The headline path -- MaxSim batches -- needs only the HI image:
- * with RL_OPT_KEEP_IMAGE = 0 and RL_OPT_KEEP_HI_PLANE = 0 an fp32 index of dim 256 / 384 / 512 / 768 / 1024 holds rows + HI image
- * (1.5 x) and rl_maxsim_topk_batch / rl_maxsim_batch_begin run the same pipeline with the same results: approximate pass over the HI
- * image, exact re-scoring over the rows; only the guarded full-precision fallback (list overflow, unusable bound) changes kernel -- the
- * streaming kernels over the rows instead of the eight-query pass over the pre-split image.  Row searches on such an index take the
- * kernels over the rows (B <= 16: the full fp32 pass; B >= 96: score_gemm instead of the fused top-k). */
+ * with RL_OPT_KEEP_IMAGE = 0 and RL_OPT_KEEP_HI_PLANE = 0 an fp32 index of dim 256 / 384 / 512 / 768 / 1024 -- or a WIDE one, see below --
+ * holds rows + HI image (1.5 x) and rl_maxsim_topk_batch / rl_maxsim_batch_begin run the same pipeline with the same results: approximate
+ * pass over the HI image, exact re-scoring over the rows; only the guarded full-precision fallback (list overflow, unusable bound) changes
+ * kernel -- the streaming kernels over the rows (a wide index: the exact re-scoring kernel over every chunk) instead of the eight-query
+ * pass over the pre-split image.  Row searches on such an index take the kernels over the rows (B <= 16: the full fp32 pass; B >= 96:
+ * score_gemm instead of the fused top-k).
+ * WIDE indexes (round 6): the half-bytes routes -- HI image / HI plane, bound-filtered MaxSim batches, few-queries and fused row searches --
+ * take any dim % 32 == 0 up to 1024 and, beyond, dim % 128 == 0 up to 4096 (1536- / 3072-wide embedders, src/raglite/_embed.py:155-158);
+ * on a wide index even one MaxSim query goes through the sixteen-query pass and the few-queries row search takes up to 4 queries (16 at
+ * dim <= 1024).  Other widths, fp16-STORED wide indexes (rl_index_create_f16 keeps its six dims), l2 and k > 512 run on the
+ * full-precision routes: same results, 2-3 x slower. */
 int rl_index_memory(const rl_index* index, int64_t out[8]);
 
 /* Warm-up for lazy images (RL_OPT_LAZY_IMAGES, the default): build the images in `images` (RL_IMAGE_* bits) NOW, on `stream`, instead of

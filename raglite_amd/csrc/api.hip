@@ -2087,9 +2087,9 @@ int maxsim_scores_device(rl_index* idx, const float* d_q, int32_t nq, float* d_o
 }
 
 int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, int32_t k, float* sc, int64_t ld, float* d_s, int32_t* d_c,
-                        hipStream_t s);  // (defined behind the batch pipeline it shares its stages with)
+                        hipStream_t s, const uint32_t* d_filter = nullptr);  // (defined behind the batch pipeline it shares its stages with)
 int maxsim_topk_batch_device(rl_index* idx, const float* d_q, bool q16, int32_t n_queries, int32_t nq, int32_t k, float* sc, int64_t ld, float* d_s,
-                             int32_t* d_c, hipStream_t s);
+                             int32_t* d_c, hipStream_t s, const uint32_t* d_filter = nullptr);
 }  // namespace
 
 int rl_maxsim_scores(rl_index* idx, const float* query_vecs, int32_t nq, float* out_scores, int mem, void* stream) {
@@ -2127,20 +2127,21 @@ int rl_maxsim_topk_filtered(rl_index* idx, const float* query_vecs, int32_t nq, 
     RL_TRY(stage_out_begin(out_scores, (size_t)k, mem, t_s, &d_s));
     RL_TRY(stage_out_begin(out_chunks, (size_t)k, mem, t_c, &d_c));
     RL_TRY(idx->scores.reserve(std::max<size_t>((size_t)idx->n_chunks * sizeof(float), 16)));
-    if (!d_f && idx->dim > 1024) {  // a WIDE index: the batch's routes (the bound-filtered pipeline where the index keeps a HI image), batch of one
+    if (idx->dim > 1024) {  // a WIDE index: the batch's routes (the bound-filtered pipeline where the index keeps a HI image), batch of one
         const int64_t ld1 = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
         RL_TRY(idx->scores.reserve((size_t)ld1 * sizeof(float)));
-        RL_TRY(maxsim_topk_batch_device(idx, d_q, false, 1, nq, k, idx->scores.as<float>(), ld1, d_s, d_c, s));
+        RL_TRY(maxsim_topk_batch_device(idx, d_q, false, 1, nq, k, idx->scores.as<float>(), ld1, d_s, d_c, s, d_f));
         RL_TRY(stage_out_end(out_scores, (size_t)k, mem, s, t_s));
         RL_TRY(stage_out_end(out_chunks, (size_t)k, mem, s, t_c));
         return finish(mem, s);
     }
-    if (!d_f) {  // one user query at a time, no metadata filter: the half-width route over the HI plane where the index has (or may build) one
+    {   // one user query at a time: the half-width route over the HI plane where the index has (or may build) one -- with a metadata filter too
+        // (round 6: the filtered-out chunks rank -inf in the approximate scores, like tombstones)
         const int64_t ld1 = std::max<int64_t>((idx->n_chunks + 3) & ~int64_t(3), 4);
         RL_TRY(idx->scores.reserve((size_t)ld1 * sizeof(float)));
-        const int st = maxsim_few_hi_plane(idx, d_q, nq, 1, k, idx->scores.as<float>(), ld1, d_s, d_c, s);
+        const int st = maxsim_few_hi_plane(idx, d_q, nq, 1, k, idx->scores.as<float>(), ld1, d_s, d_c, s, d_f);
         if (st == RL_OK) {
-            if (idx->live_chunk_bits) RL_TRY(launch_fix_masked(d_s, d_c, k, s));
+            if (idx->live_chunk_bits || d_f) RL_TRY(launch_fix_masked(d_s, d_c, k, s));
             RL_TRY(stage_out_end(out_scores, (size_t)k, mem, s, t_s));
             RL_TRY(stage_out_end(out_chunks, (size_t)k, mem, s, t_c));
             return finish(mem, s);
@@ -2174,6 +2175,8 @@ struct HiBatch {
     const float* qsum = nullptr;  // [2 n] sum_i |q_i|, sum_i |q_lo,i| of every query where the query image carries them (launch_query_planes)
     bool m_ready = true;          // hb.m holds the bounds (a threshold kernel ran); false: exact_threshold_kernel computes them from qsum
     bool exact_kth;           // second, tighter threshold from the exact scores of the approximate top-k (RL_OPT_EXACT_KTH_THRESHOLD)
+    const uint32_t* filter = nullptr;  // chunk bitset of a metadata-filtered call: masked chunks rank -inf in the approximate scores, so they are
+                                       // neither in their top-k nor among the candidates (the bound's argument runs over the chunks that remain)
 };
 // The scratch layout of a bound-filtered MaxSim batch of n queries (the same in every call that works on the batch)
 void hi_batch_layout(rl_index* idx, int32_t n, int32_t k, HiBatch& hb) {
@@ -2222,7 +2225,7 @@ int hi_batch_approx(rl_index* idx, const float* d_q, int32_t nq, int32_t n_queri
                                   idx->offsets, idx->ends.as<uint32_t>(), sc + (int64_t)b * ld, ld, idx->n_cu, s, approx_scale(idx), true,
                                   nullptr, hb.one_product));
     }
-    RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // tombstones never become candidates
+    RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, hb.filter, s));  // tombstones (and filtered-out chunks) never become candidates
     // (a handful of queries over more chunks than the one-block selection takes: crowded MaxSim scores send the radix selection down its slow path
     // -- the pivot route first, launch_topk_pivot; it declines what it does not cover)
     int st_pv = RL_ERR_UNSUPPORTED;
@@ -2284,7 +2287,7 @@ int hi_batch_fallback(rl_index* idx, const float* d_q, int32_t nq, int32_t n_que
         RL_TRY(launch_maxsim_stream_batch(idx->E, false, idx->n_rows, idx->dim, d_q, nq, (int64_t)q_elems, n_gemm, idx->row_to_chunk, idx->offsets,
                                           idx->n_chunks, sc, ld, std::max(1, idx->n_cu / std::min<int32_t>(8, std::max<int32_t>(1, n_gemm / 4))), s,
                                           idx->split_scale, hb.flag));
-    RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, nullptr, s));  // (harmless on scores nobody reads)
+    RL_TRY(mask_chunk_scores(idx, sc, n_gemm, ld, hb.filter, s));  // (harmless on scores nobody reads)
     // (the exact top-k of the fallback's scores in ONE guarded launch, a block per query -- select.hip: guarded_select_kernel -- instead of the
     // selection's three: what usually returns at once is one launch shorter by two)
     uint32_t* host_word = nullptr;
@@ -2322,7 +2325,7 @@ int hi_batch_fallback(rl_index* idx, const float* d_q, int32_t nq, int32_t n_que
 // d_q: the n (1 or 2) queries, q_elems floats apart; sc: [n x ld] scratch rows; d_s / d_c: [n x k].  RL_ERR_UNSUPPORTED where the route
 // does not apply (the caller keeps the streaming kernels over the rows).
 int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, int32_t k, float* sc, int64_t ld, float* d_s, int32_t* d_c,
-                        hipStream_t s) {
+                        hipStream_t s, const uint32_t* d_filter) {
     if (n < 1 || n > 2 || nq < 1 || nq > 32 || k > 512 || !idx->opt.on(RL_OPT_HI_MAXSIM) || !idx->opt.on(RL_OPT_HI_FEW)) return RL_ERR_UNSUPPORTED;
     if (idx->dim > 1024) return RL_ERR_UNSUPPORTED;  // (the stream kernels' dims: a wide index takes the pass even for one query, gemm_min_queries)
     if (idx->E16 || !idx->E || !(idx->split_scale > 0.f) || idx->has_empty_chunk || idx->n_chunks == 0 || idx->n_rows == 0) return RL_ERR_UNSUPPORTED;
@@ -2349,11 +2352,12 @@ int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, 
     hi_batch_layout(idx, n, k, hb);
     hb.m_abs = idx->max_lo_norm + sum_eps(idx->dim) * idx->max_row_norm;
     hb.q_unscale = nullptr;
+    hb.filter = d_filter;
     // The pivot route (round 6, option hi_pivot; k <= 128, no tombstones): with the chip idle around one query, re-scoring ~2.5 x the candidates
     // costs nothing, so the approximate scores need not be RANKED -- no top-k, no second threshold from its exact scores: the k-th largest of
     // ~490 wave maxima bounds the k-th best from below, every chunk within 2 m of it is re-scored in ONE launch and ranked.  Four launches
     // behind the pass (maxima + scale + bound, pivot + collection, exact scores, ranking) instead of nine.
-    if (idx->opt.on(RL_OPT_HI_PIVOT) && !idx->live_chunk_bits && k <= 128) {
+    if (idx->opt.on(RL_OPT_HI_PIVOT) && !idx->live_chunk_bits && !d_filter && k <= 128) {
         HiBound bound;
         bound.m_out = hb.m;
         PivotMaxSim ms;
@@ -2374,7 +2378,7 @@ int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, 
     // the plane holds fp16(e * scale), scale a power of two: undone exactly (the launch also zeroes the flag block: the two small memsets of
     // this route were six fill launches, 28 us of a 0.44 ms query)
     RL_TRY(launch_scale_f32(sc, sc, 1.0f / idx->split_scale, (int64_t)(n - 1) * ld + idx->n_chunks, s, hb.flag, 16));
-    RL_TRY(mask_chunk_scores(idx, sc, n, ld, nullptr, s));  // tombstones never become candidates
+    RL_TRY(mask_chunk_scores(idx, sc, n, ld, d_filter, s));  // tombstones / filtered-out chunks never become candidates
     RL_TRY(launch_topk(sc, n, idx->n_chunks, ld, k, idx->ws, hb.ts, hb.ti, s));
     RL_TRY(launch_maxsim_threshold(hb.ts, n, k, d_q, nq, idx->dim, q_elems, 1.0f, hb.m_abs, hb.thr, hb.cnt, hb.flag, s, nullptr,
                                    idx->max_row_norm + idx->max_lo_norm, hb.m));
@@ -2383,7 +2387,7 @@ int maxsim_few_hi_plane(rl_index* idx, const float* d_q, int32_t nq, int32_t n, 
 // The device side of rl_maxsim_topk_batch: d_q [n_queries x nq x dim] -> d_s / d_c [n_queries x k]; sc: [n_queries x ld] scratch rows
 // (idx->scores); q16: the queries were widened from fp16 (exact).  Also what rl_maxsim_topk runs on a WIDE index, as a batch of one.
 int maxsim_topk_batch_device(rl_index* idx, const float* d_q, bool q16, int32_t n_queries, int32_t nq, int32_t k, float* sc, int64_t ld, float* d_s,
-                             int32_t* d_c, hipStream_t s) {
+                             int32_t* d_c, hipStream_t s, const uint32_t* d_filter) {
     const size_t q_elems = (size_t)nq * idx->dim;
     // One corpus pass per query, back to back on the caller's stream.  (Round-robin over side streams hides each
     // launch's tail behind the next one's ramp and measured +1.5 % at 1 M rows / +3.3 % on a 125 k-row shard, but
@@ -2429,6 +2433,7 @@ int maxsim_topk_batch_device(rl_index* idx, const float* d_q, bool q16, int32_t 
                 // same argument (bit-identical on the benchmark shape, profiles/r02_u_probe.txt), the pass 1.01 -> 0.71 ms, 418 instead of
                 // 307 candidates per query, the 128-query step 17.1 -> 12.8 ms.  RL_OPT_HI_PRODUCTS = 2: two products.
                 HiBatch hb;
+                hb.filter = d_filter;
                 RL_TRY(hi_batch_approx(idx, d_q, nq, n_queries, n_gemm, k, sc, ld, hb, s, flag_words != nullptr));
                 // (an fp32-STORED corpus whose every element is an fp16 value at the split scale -- what its HI halves drop was measured as
                 // exactly zero when the image was built -- is the same case: RAGLite's embeddings handed over as float32 arrays)
@@ -2463,7 +2468,7 @@ int maxsim_topk_batch_device(rl_index* idx, const float* d_q, bool q16, int32_t 
     int32_t few = 0;  // queries [base, base + few) were ranked by the few-queries route over the HI plane
     if (rest >= 1 && rest <= 2) {
         const int st = maxsim_few_hi_plane(idx, d_q + (size_t)base * q_elems, nq, rest, k, sc + (int64_t)base * ld, ld, d_s + (int64_t)base * k,
-                                           d_c + (int64_t)base * k, s);
+                                           d_c + (int64_t)base * k, s, d_filter);
         if (st == RL_OK) { few = rest; rest = 0; }
         else if (st != RL_ERR_UNSUPPORTED) return st;
     }
@@ -2479,12 +2484,12 @@ int maxsim_topk_batch_device(rl_index* idx, const float* d_q, bool q16, int32_t 
     {   // what the half-bytes pipelines did not rank: every query, or the one or two left over
         const int32_t first = few ? n_queries : (hi_done ? base : 0);
         if (n_queries > first) {
-            RL_TRY(mask_chunk_scores(idx, sc + (int64_t)first * ld, n_queries - first, ld, nullptr, s));  // tombstones (no-op without deletions)
+            RL_TRY(mask_chunk_scores(idx, sc + (int64_t)first * ld, n_queries - first, ld, d_filter, s));  // tombstones / the call's filter
             RL_TRY(launch_topk(sc + (int64_t)first * ld, n_queries - first, idx->n_chunks, ld, k, idx->ws, d_s + (int64_t)first * k,
                                d_c + (int64_t)first * k, s));
         }
     }
-    if (idx->live_chunk_bits) RL_TRY(launch_fix_masked(d_s, d_c, (int64_t)n_queries * k, s));
+    if (idx->live_chunk_bits || d_filter) RL_TRY(launch_fix_masked(d_s, d_c, (int64_t)n_queries * k, s));
     return RL_OK;
 }
 }  // namespace

@@ -146,15 +146,45 @@ def test_where_the_route_does_not_apply_the_rows_are_streamed_as_before():
     ws, wc = oracle.maxsim_topk(E, off, Q, 10, np.float32)
     assert np.array_equal(c, wc) and np.array_equal(s, ws)
     idx.close()
-    # a metadata filter keeps the masked full pass (filter-first semantics, `_search.py:105-119`)
+    # a metadata filter (filter-first semantics, `_search.py:105-119`) rides on the half-width route since round 6: filtered-out chunks rank
+    # -inf in the approximate scores, like tombstones; with the route off the masked full pass answers -- the same bits on integer data
     off = ragged_offsets(rng, N, 1, 15)
     E = oracle.synth_matrix(30_801, N, DIM, "small_int")
     idx = raglite_amd.DeviceIndex(E, off, metric="dot")
     mask = rng.random(len(off) - 1) < 0.5
     s, c = idx.maxsim_topk(Q, 10, chunk_filter=mask)
-    assert _route(idx)[0] == "none"
+    assert _route(idx)[0] == "maxsim_batch_hi" and not _route(idx)[1]
     ws, wc = oracle.maxsim_topk_filtered(E, off, Q, 10, mask, np.float32)
     assert np.array_equal(c, wc) and np.array_equal(s, ws)
+    with idx.options(hi_few=0):
+        s0, c0 = idx.maxsim_topk(Q, 10, chunk_filter=mask)
+    assert np.array_equal(c0, wc) and np.array_equal(s0, ws)
+    # ... together with tombstones; a filter that leaves fewer chunks than k (the bound is unusable: the guarded pass answers, padded)
+    dead = np.unique(wc[:4])
+    idx.delete_chunks(dead)
+    live = mask.copy()
+    live[dead] = False
+    s, c = idx.maxsim_topk(Q, 10, chunk_filter=mask)
+    ws, wc = oracle.maxsim_topk_filtered(E, off, Q, 10, live, np.float32)
+    assert np.array_equal(c, wc) and np.array_equal(s, ws)
+    tiny = np.zeros(len(off) - 1, bool)
+    tiny[rng.choice(len(off) - 1, 6, replace=False)] = True
+    tiny[dead] = False
+    s, c = idx.maxsim_topk(Q, 10, chunk_filter=tiny)
+    ws, wc = oracle.maxsim_topk_filtered(E, off, Q, 10, tiny, np.float32)
+    kk = int(tiny.sum())
+    assert np.array_equal(c[:kk], wc[:kk]) and np.array_equal(s[:kk], ws[:kk]) and (c[kk:] == -1).all() and np.isneginf(s[kk:]).all()
+    # float data: the float64 oracle's chunks among the eligible ones
+    Ef = oracle.synth_matrix(30_802, N, DIM)
+    Qf = oracle.synth_matrix(30_902, 32, DIM)
+    fidx = raglite_amd.DeviceIndex(Ef, off, metric="dot")
+    s, c = fidx.maxsim_topk(Qf, 100, chunk_filter=mask)
+    assert _route(fidx)[0] == "maxsim_batch_hi" and mask[c].all()
+    ref = oracle.maxsim_scores(Ef, off, Qf, np.float64)
+    ref[~mask] = -np.inf
+    from tests.util import assert_topk_close
+    assert_topk_close(s, c, ref, 100, 2e-6 * float(np.abs(ref[np.isfinite(ref)]).max()))
+    fidx.close()
     # fewer chunks than k: padding (-inf, -1) behind the real ones
     few = raglite_amd.DeviceIndex(E, np.array([0, N // 2, N], dtype=np.int64), metric="dot")
     s, c = few.maxsim_topk(Q, 5)

@@ -210,9 +210,15 @@ def test_one_maxsim_query_over_a_wide_index_goes_through_the_pass(dim, n):
     idx.delete_chunks(dead)
     s3, c3 = idx.maxsim_topk(Qb[0], 100)
     assert not np.isin(c3, dead).any()
-    ok = rng.random(len(off) - 1) < 0.5  # (a metadata filter: the full-precision scores of every chunk, masked)
+    ok = rng.random(len(off) - 1) < 0.5  # (a metadata filter rides on the same pipeline: filtered-out chunks rank -inf in the approximate scores)
     s4, c4 = idx.maxsim_topk(Qb[0], 50, chunk_filter=ok)
+    st = idx.filter_stats()
+    assert st["kind"] == "maxsim_batch_hi" and not st["fallback"], st
     assert ok[c4].all() and not np.isin(c4, dead).any()
+    ref = oracle.maxsim_scores(E, off, Qb[0], np.float64)
+    ref[~ok] = -np.inf
+    ref[dead] = -np.inf
+    assert_topk_close(s4, c4, ref, 50, 2e-6 * float(np.abs(ref[np.isfinite(ref)]).max()))
     idx.close()
 
 
