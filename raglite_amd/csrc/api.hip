@@ -591,7 +591,7 @@ int refresh_hi_plane(rl_index* idx, hipStream_t s) {
     // (the stream kernel's dims; wider embedders -- round 6 -- go through the packed scan, scan16.hip)
     const bool dim_ok = d == 128 || d == 256 || d == 384 || d == 512 || d == 768 || d == 1024 || (d > 1024 && hi_dim_ok(d));
     const bool want = !off && !idx->E16 && idx->E && idx->split_scale > 0.f && dim_ok &&
-                      (int64_t)idx->n_rows * d >= (int64_t(64) << 20) && (idx->metric == RL_COSINE || idx->metric == RL_DOT) &&
+                      (int64_t)idx->n_rows * d >= (int64_t(64) << 20) && (idx->metric == RL_COSINE || idx->metric == RL_DOT || idx->metric == RL_L2) &&
                       (image_need(idx) & IMG_HI_PLANE);
     if (!want) {
         idx->hiplane.release();
@@ -1613,7 +1613,13 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     if (!idx->opt.on(RL_OPT_HI_SEARCH)) return RL_ERR_UNSUPPORTED;
     const int mode = scan_mode(idx->metric);
     const int64_t n = idx->n_rows;
-    if (!hi_valid(idx) || nb > 16 || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT) || n < 65536) return RL_ERR_UNSUPPORTED;
+    if (!hi_valid(idx) || nb > 16 || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT && mode != SCAN_L2) || n < 65536) return RL_ERR_UNSUPPORTED;
+    // l2 (round 6): 1 - |e - q|.  The approximate similarity comes from |e|^2 + |q|^2 - 2 e_hi.q, its bound lives on the SQUARED distance
+    // (hi_filter.hip: l2_delta / lower_threshold), the candidates and the guarded full pass are scored by the scan that sums (e - q)^2 directly --
+    // the full-precision route's own kernel for up to four queries, so the same bits; candidates from the pivot route (k <= 128) or, with a
+    // row mask, from the ranked flow.  Needs the measured norms (an index whose HI plane was built with them) and |e|^2 per row.
+    const bool l2 = mode == SCAN_L2;
+    if (l2 && (nb > 4 || !idx->sumsq || (!d_row_bits && (!idx->opt.on(RL_OPT_HI_PIVOT) || !pivot_route_takes(n, k))))) return RL_ERR_UNSUPPORTED;
     // WIDE index (dim > 1024, round 6): the stream kernels stop at 1024 (a wave keeps its slice of the queries in registers) -- the approximate
     // pass is the packed VALU scan over the HI plane (scan16.hip: up to four queries per pass; the fp32 scan of such an index takes ONE), the
     // candidates and the guarded full pass go through the fp32 scan.  Up to four queries: beyond, the passes over the plane cost what the
@@ -1655,11 +1661,15 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
         if (mode == SCAN_COSINE) m_rel = idx->max_lo_ratio + sum_eps(dim);
         else { m_rel = 1.0f; e_bound = idx->max_lo_norm + sum_eps(idx->dim) * idx->max_row_norm; }
     }
+    if (l2) {
+        if (!measured) return RL_ERR_UNSUPPORTED;
+        m_rel = sum_eps(dim);  // (l2_delta's arguments: the rounding term, the dot's bound per |q|, max |e|)
+    }
     if (d_row_bits) {  // tombstones / metadata filter: masked rows rank -inf, so they reach neither the top-k nor the candidates
         RL_TRY(launch_transform(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, s, 1.0f / idx->hi_scale));
         RL_TRY(launch_mask_scores(sc, nb, n, ld, d_row_bits, s));
         RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s));
-        RL_TRY(launch_approx_threshold(ts, nb, k, d_q, dim, mode, m_rel, e_bound, thr, cnt, flag, s));
+        RL_TRY(launch_approx_threshold(ts, nb, k, d_q, dim, mode, m_rel, e_bound, thr, cnt, flag, s, idx->max_row_norm));
         RL_TRY(launch_collect_above(sc, nb, n, ld, thr, mode == SCAN_COSINE ? idx->norm : nullptr, cap, ci, gn, cnt, flag, s));
     } else {
         // Round 4 (cfg 2: thirteen launches of 4.6 - 9.9 us behind a 0.31 ms pass; now eight): the transform + histogram launch also zeroes
@@ -1667,7 +1677,7 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
         // than 2 m below the threshold bin, and its final kernel -- which knows the k-th best -- lists every row within 2 m of it: no
         // threshold kernel, no collecting pass over the scores.
         HiBound bound;
-        bound.m_out = mb; bound.m_rel = m_rel; bound.e_norm_bound = e_bound;
+        bound.m_out = mb; bound.m_rel = m_rel; bound.e_norm_bound = e_bound; bound.e_max = idx->max_row_norm;
         // Round 6 (option hi_pivot): no approximate RANKING at all -- the candidates are re-scored and ranked exactly anyway, so any lower bound
         // of the k-th best approximate similarity will do for the threshold: the k-th largest of ~500 workgroup maxima (hi_filter.hip:
         // transform_bmax_kernel / pivot_collect_kernel), two launches instead of the selection's three (k <= 128, >= 3 k maxima)
@@ -1676,6 +1686,7 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
             st_pv = launch_pivot_route(sc, nb, n, ld, k, idx->norm, idx->sumsq, d_q, dim, mode, 1.0f / idx->hi_scale, bmax, cnt, 32, bound, thr, cap, ci, gn,
                                        cnt, flag, s, idx->E, G, &gathered);
         if (st_pv != RL_OK && st_pv != RL_ERR_UNSUPPORTED) return st_pv;
+        if (st_pv == RL_ERR_UNSUPPORTED && l2) return RL_ERR_UNSUPPORTED;  // (too few group maxima for the pivot: the full-precision route)
         if (st_pv == RL_ERR_UNSUPPORTED) {
             RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f / idx->hi_scale, nullptr, cnt, 32, &bound));
             HiEmit emit;
@@ -1691,7 +1702,10 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     if (!gathered) RL_TRY(launch_gather_rows(idx->E, false, dim, n, ci, nc, G, s, cnt, cap));  // (the pivot route's collection gathers on its way)
     StreamSecondJob full;
     full.D = idx->E; full.n_rows = n; full.out = sc; full.ld = ld; full.run_if = flag;
-    if (wide) {  // raw dots of the gathered rows, then the guarded pass over the corpus: the fp32 scan, a query per pass
+    if (l2) {  // 1 - sqrt(sum (e - q)^2) of the gathered rows and, guarded, of the corpus: the scan of the full-precision route, same bits
+        st = launch_scan_rows(G, nc, dim, d_q, nb, nullptr, SCAN_L2, xs, ldx, s);
+        if (st == RL_OK) st = launch_scan_rows(idx->E, n, dim, d_q, nb, nullptr, SCAN_L2, sc, ld, s, flag);
+    } else if (wide) {  // raw dots of the gathered rows, then the guarded pass over the corpus: the fp32 scan, a query per pass
         st = launch_scan_rows(G, nc, dim, d_q, nb, nullptr, SCAN_RAW_DOT, xs, ldx, s);
         if (st == RL_OK) st = launch_scan_rows(idx->E, n, dim, d_q, nb, nullptr, SCAN_RAW_DOT, sc, ld, s, flag);
     } else {
@@ -1701,12 +1715,14 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     if (nb > 1) RL_TRY(launch_diag_blocks(xs, ldx, cap, nc, es, s));  // (one query: the block IS its diagonal)
     MergeTransform tr;  // (the metric transform of the re-scored candidates happens on the way into the ranking: transform_kernel's statements)
     tr.row_norm = gn; tr.queries = d_q; tr.dim = dim; tr.mode = mode;
-    RL_TRY(launch_merge_topk(nb > 1 ? es : xs, ci, 1, nb, cap, k, d_scores, d_rows, s, cnt, &tr));
+    RL_TRY(launch_merge_topk(nb > 1 ? es : xs, ci, 1, nb, cap, k, d_scores, d_rows, s, cnt, l2 ? nullptr : &tr));  // (l2: already similarities)
     // ---- (4b) ... and its selection -------------------------------------------------------------------------------------------------------
     if (d_row_bits) {  // (the mask needs no guard: applied to scores nobody reads it changes nothing)
-        RL_TRY(launch_transform(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, s, 1.0f, flag));
+        if (!l2) RL_TRY(launch_transform(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, s, 1.0f, flag));
         RL_TRY(launch_mask_scores(sc, nb, n, ld, d_row_bits, s));
         RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, d_scores, d_rows, s, flag));
+    } else if (l2) {
+        RL_TRY(launch_guarded_select(sc, nb, n, ld, k, nullptr, nullptr, nullptr, 0, SCAN_RAW_DOT, 1.0f, d_scores, d_rows, flag, s));
     } else {  // transform + exact top-k in ONE guarded launch (a block per query: slow, and run once in a blue moon)
         RL_TRY(launch_guarded_select(sc, nb, n, ld, k, idx->norm, idx->sumsq, d_q, dim, mode, 1.0f, d_scores, d_rows, flag, s));
     }
@@ -1760,7 +1776,8 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
         // lazy images: the routes below test what the index HAS; ask for what this batch's route reads first
         if (!d_row_bits && !cut && nb >= GEMM_MIN_QUERIES && k <= 512 && idx->opt.on(RL_OPT_FUSED_TOPK))
             RL_TRY(demand_images(idx, IMG_PLANES | (idx->opt.on(RL_OPT_FUSED_HI) ? IMG_HI_IMAGE : 0u), s));
-        if (!cut && nb <= (idx->dim > 1024 ? 4 : 16) && k <= 512 && idx->opt.on(RL_OPT_HI_SEARCH)) RL_TRY(demand_images(idx, IMG_HI_PLANE, s));
+        if (!cut && nb <= ((idx->dim > 1024 || idx->metric == RL_L2) ? 4 : 16) && k <= 512 && idx->opt.on(RL_OPT_HI_SEARCH))
+            RL_TRY(demand_images(idx, IMG_HI_PLANE, s));
         if (!d_row_bits && !cut) {  // big batches over an index with a HI image: fused top-k at one MFMA product per multiply
             const int st = search_rows_fused_hi(idx, d_q + (int64_t)b0 * idx->dim, nb, k, d_scores + (int64_t)b0 * k, d_rows + (int64_t)b0 * k, ld, s);
             if (st == RL_OK) continue;

@@ -184,6 +184,8 @@ int launch_guarded_select(float* scores, int32_t nb, int64_t n, int64_t ld, int3
 struct HiBound {
     float* m_out = nullptr;
     float m_rel = 0.f, e_norm_bound = 0.f;
+    float e_max = 0.f;  // l2 (round 6): max |e|; m_rel = the rounding term per |q| |e| (sum_eps), e_norm_bound = the dot bound per |q| -- m_out[b] is then
+                        // the bound of the SQUARED distance, hi_filter.hip: l2_delta
 };
 int launch_transform_hist(float* scores, int32_t nb, int64_t n, int64_t ld, const float* row_norm, const float* row_sumsq,
                           const float* queries, int32_t dim, int mode, SelectWorkspace& ws, hipStream_t s, float pre_scale = 1.0f,
@@ -220,7 +222,7 @@ int launch_rank_cut(float* scores, int32_t n_queries, int64_t n, int64_t ld, int
 
 // hi_filter.hip: helpers of the half-bytes single-query search (api.hip: search_rows_hi)
 int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const float* queries, int32_t dim, int mode, float m_rel,
-                            float e_norm_bound, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s);  // also zeroes cnt[0..nb) and *flag
+                            float e_norm_bound, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s, float e_max = 0.f);  // also zeroes cnt[0..nb) and *flag
 // top_s / top_i [nb x k] (optional): the approximate top-k in selection order -- only entries ranking BELOW its k-th one are collected
 struct PivotMaxSim {                  // the MaxSim flavour of the pivot route (hi_filter.hip: transform_bmax_kernel)
     int nq = 0;                       // query vectors per query (0: a row search)
@@ -232,6 +234,7 @@ struct PivotMaxSim {                  // the MaxSim flavour of the pivot route (
     int read_only = 0;                // the scores are not rewritten (an identity transform: launch_topk_pivot)
 };
 size_t pivot_scratch_words(int32_t nb);
+bool pivot_route_takes(int64_t n, int32_t k);
 int launch_pivot_route(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t k, const float* row_norm, const float* row_sumsq, const float* queries,
                        int32_t dim, int mode, float pre_scale, uint64_t* bmax, uint32_t* zero_words, int n_zero, const HiBound& bound, float* thr,
                        int32_t cap, int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* E = nullptr,

@@ -9,6 +9,26 @@
 namespace rl {
 namespace {
 
+// l2 (round 6).  The similarity is 1 - sqrt(D), D = |e - q|^2; the approximate one is made of D~ = |e|^2 + |q|^2 - 2 d~ (transform_score) with d~
+// the dot product over the hi halves.  |D~ - D| <= delta for every row, D the squared distance AS THE EXACT KERNEL COMPUTES IT:
+//   2 a |q|                      the dot's bound (a = max |e_lo| + eps max |e|: what the halves drop + the roundings of both dots),
+//   eps (|e|^2 + |q|^2) / 2 ...  the fp32 sums behind |e|^2, |q|^2 and the exact sum (e - q)^2 (each off by at most dim 2^-24 of itself),
+//   2^-22 (|e| + |q|)^2          the three fp32 operations of the transform
+// <= 2 a |q| + 2 eps (max |e| + |q|)^2 with eps = 2^-12 per started 1024 terms (api.hip: sum_eps).  A row of the exact top-k has
+// D <= D_k <= D~_k + delta (the k rows of the approximate top-k bound the exact k-th from above), so D~ <= D~_k + 2 delta: in similarities,
+// with ANY lower bound P of the k-th best approximate one, s~ >= 1 - sqrt((1 - P)^2 + 2 delta) -- the slack factors cover the roundings of
+// sqrt and 1 - x on both sides.
+__device__ __forceinline__ float l2_delta(float a, float eps, float e_max, float qn) {
+    const float t = e_max + qn;
+    return (2.0f * a * qn + 2.0f * eps * t * t) * 1.0001f;
+}
+// the candidate threshold under a lower bound P of the k-th best approximate similarity; m: the query's bound (l2: delta, in squared distance)
+__device__ __forceinline__ float lower_threshold(float P, float m, bool l2) {
+    if (!l2) return P - 2.0f * m;
+    const float r = fmaxf(1.0f - P, 0.f);
+    return 1.0f - sqrtf(fmaf(r, r, 2.0f * m)) * (1.0f + 0x1p-18f) - 0x1p-20f;
+}
+
 // One block per query.  topk[b * k + j] = the k best APPROXIMATE similarities, descending.  With |approx - exact| <= m for every
 // row, a row can be in the exact top-k only if its approximate score is >= (k-th best approximate) - 2 m =: thr[b]:
 //   cosine: m = m_rel (the scores are cosines);  dot: m = m_rel * e_norm_bound * |q|.
@@ -16,7 +36,7 @@ namespace {
 __global__ __launch_bounds__(256) void approx_threshold_kernel(const float* __restrict__ topk, int32_t nb, int32_t k,
                                                                 const float* __restrict__ queries, int dim, int mode, float m_rel,
                                                                 float e_norm_bound, float* __restrict__ thr, uint32_t* __restrict__ cnt,
-                                                                uint32_t* __restrict__ flag) {
+                                                                uint32_t* __restrict__ flag, float e_max) {
     // ONE block for all (<= 16) queries: it also zeroes the candidate counters and the flag of this call (no memset launch).
     __shared__ float part[4];
     bool bad = false;
@@ -33,8 +53,8 @@ __global__ __launch_bounds__(256) void approx_threshold_kernel(const float* __re
         if (threadIdx.x == 0) {
             const float qn = sqrtf((part[0] + part[1]) + (part[2] + part[3]));
             // (dot: the similarity is 1 + d, rounded to fp32 in both passes -- 2^-22 absolute covers that for scores up to 2)
-            const float m = mode == SCAN_COSINE ? m_rel : m_rel * e_norm_bound * qn + 0x1p-22f;
-            const float t = topk[(int64_t)b * k + (k - 1)] - 2.0f * m;
+            const float m = mode == SCAN_COSINE ? m_rel : mode == SCAN_L2 ? l2_delta(e_norm_bound, m_rel, e_max, qn) : m_rel * e_norm_bound * qn + 0x1p-22f;
+            const float t = lower_threshold(topk[(int64_t)b * k + (k - 1)], m, mode == SCAN_L2);
             thr[b] = t;
             cnt[b] = 0u;
             bad |= !(t > -INFINITY);  // NaN or -inf
@@ -206,7 +226,7 @@ __global__ __launch_bounds__(256) void transform_bmax_kernel(float* __restrict__
     const float qss = (part[0] + part[1]) + (part[2] + part[3]);
     const float qn = sqrtf(qss);
     if (hb.m_out && ms.nq == 0 && blockIdx.x == 0 && threadIdx.x == 0)
-        hb.m_out[b] = mode == SCAN_COSINE ? hb.m_rel : hb.m_rel * hb.e_norm_bound * qn + 0x1p-22f;
+        hb.m_out[b] = mode == SCAN_COSINE ? hb.m_rel : mode == SCAN_L2 ? l2_delta(hb.e_norm_bound, hb.m_rel, hb.e_max, qn) : hb.m_rel * hb.e_norm_bound * qn + 0x1p-22f;
     float bv = -INFINITY;  // ONE of this thread's best rows (the first of equal similarities; NaN / -inf never win)
     uint32_t bi = 0u;
     auto finish = [&](int64_t i, const f4 d, const f4 a) {
@@ -291,7 +311,7 @@ __global__ __launch_bounds__(256) void pivot_collect_kernel(const float* __restr
                                                              int G, int32_t k, const float* __restrict__ m, float* __restrict__ thr,
                                                              const float* __restrict__ row_norm, int32_t cap, int32_t* __restrict__ ids,
                                                              float* __restrict__ norms, uint32_t* __restrict__ cnt, uint32_t* __restrict__ flag,
-                                                             const float* __restrict__ E, int dim, float* __restrict__ Gout, int64_t aux_ld) {
+                                                             const float* __restrict__ E, int dim, float* __restrict__ Gout, int64_t aux_ld, int l2) {
     __shared__ int32_t l_ids[1024];
     __shared__ uint32_t l_n, l_base, pivot_sh;
     const int b = blockIdx.y;
@@ -318,7 +338,7 @@ __global__ __launch_bounds__(256) void pivot_collect_kernel(const float* __restr
         if (blockIdx.x == 0 && threadIdx.x == 0) { thr[b] = INFINITY; atomicOr(flag, 1u); }
         return;
     }
-    const float t = key_score(pivot) - 2.0f * m[b];
+    const float t = lower_threshold(key_score(pivot), m[b], l2 != 0);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         thr[b] = t;
         if (!(t > -INFINITY)) atomicOr(flag, 1u);
@@ -650,9 +670,9 @@ int launch_global_threshold(const float* lists, int32_t world, int32_t B, int32_
 }
 
 int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const float* queries, int32_t dim, int mode, float m_rel,
-                            float e_norm_bound, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s) {
+                            float e_norm_bound, float* thr, uint32_t* cnt, uint32_t* flag, hipStream_t s, float e_max) {
     hipLaunchKernelGGL(approx_threshold_kernel, dim3(1), dim3(256), 0, s, topk, nb, k, queries, (int)dim, mode, m_rel, e_norm_bound, thr, cnt,
-                       flag);
+                       flag, e_max);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
@@ -662,6 +682,12 @@ int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const floa
 // maxsim != nullptr: the scores are a MaxSim query's chunk scores (mode raw; `queries` = the queries' vectors, maxsim->q_stride floats apart):
 // bound m_b = m_abs * sum_i |q_i|, the lists pre-filled with -1 (maxsim_pairs_kernel walks every slot).
 size_t pivot_scratch_words(int32_t nb) { return (size_t)nb * 512; }
+// does launch_pivot_route take n scores per query at this k?  (its own test, for callers that have no other way to find candidates)
+bool pivot_route_takes(int64_t n, int32_t k) {
+    if (n <= 0 || k < 1 || k > 128) return false;
+    if (std::min<int64_t>((n + 2047) / 2048, 512) >= 3 * (int64_t)k) return true;
+    return 4 * std::min<int64_t>((n + 1023) / 1024, 128) >= 3 * (int64_t)k;
+}
 int launch_pivot_route(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t k, const float* row_norm, const float* row_sumsq, const float* queries,
                        int32_t dim, int mode, float pre_scale, uint64_t* bmax, uint32_t* zero_words, int n_zero, const HiBound& bound, float* thr,
                        int32_t cap, int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* E, float* gather_out,
@@ -689,7 +715,7 @@ int launch_pivot_route(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t
     // (aux_src: what goes into `norms` next to every collected id -- the rows' norms for a cosine search, or any other per-row / per-query array)
     const float* aux = aux_src ? aux_src : (mode == SCAN_COSINE ? row_norm : nullptr);
     hipLaunchKernelGGL(pivot_collect_kernel, dim3(cx, nb), dim3(256), 0, s, scores, n, ld, bmax, G, k, bound.m_out, thr, aux, cap, ids, norms, cnt, flag,
-                       fuse ? E : nullptr, (int)dim, fuse ? gather_out : nullptr, aux_src ? aux_ld : (int64_t)0);
+                       fuse ? E : nullptr, (int)dim, fuse ? gather_out : nullptr, aux_src ? aux_ld : (int64_t)0, mode == SCAN_L2 ? 1 : 0);
     if (fuse) *gathered = true;
     RL_HIP(hipGetLastError());
     return RL_OK;

@@ -202,3 +202,78 @@ def test_one_launch_fallback_selection_on_massive_ties(metric):
     ref_s, ref_r = oracle.search_rows(E, Q[0], k, metric, np.float64)
     assert np.array_equal(R[0], ref_r)
     idx.close()
+
+
+# ---- l2 on the half-bytes route (round 6): `vector_search_distance_metric = "l2"` (`/root/reference/src/raglite/_config.py:69`, `_typing.py:123-134`:
+# dist = |e - q|, sim = 1 - dist).  The approximate similarity comes from |e|^2 + |q|^2 - 2 e_hi.q, the bound lives on the squared distance, and the
+# candidates are scored by the scan that sums (e - q)^2 directly -- the full-precision route's own kernel for up to four queries: the same bits.
+@pytest.mark.parametrize("n,dim,B,k", [(80_000, 1024, 1, 100), (140_000, 512, 2, 10), (100_000, 1024, 4, 128), (530_000, 128, 3, 100), (70_000, 1536, 1, 50),
+                                        (80_000, 3072, 2, 100)])
+def test_l2_hi_search_equals_full_pass_bitwise(n, dim, B, k):  # (n >= ~770 k: the pivot needs 3 k group maxima of >= 1024 scores)
+    E = oracle.synth_matrix(9500 + dim, n, dim)
+    Q = oracle.synth_matrix(9600 + B, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric="l2")
+    S, R = idx.search_rows(Q if B > 1 else Q[0], k)
+    st = idx.filter_stats()
+    assert st["kind"] == "rows_hi" and not st["fallback"], st
+    with idx.options(hi_search=0):
+        S0, R0 = idx.search_rows(Q if B > 1 else Q[0], k)
+    assert np.array_equal(R, R0) and _same(S, S0)
+    S, R = np.atleast_2d(S), np.atleast_2d(R)
+    for b in (0, B - 1):
+        sims = oracle.similarity(E, Q[b], "l2")
+        assert_topk_close(S[b], R[b], sims, k, 4e-6 * max(1.0, float(np.abs(sims).max())))
+    idx.close()
+
+
+def test_l2_hi_search_integer_near_duplicates_filter_and_what_the_route_declines():
+    rng = np.random.default_rng(12)
+    n, dim, k = 80_000, 1024, 64
+    E = oracle.synth_matrix(9700, n, dim, "small_int")
+    Q = oracle.synth_matrix(9701, 3, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E, metric="l2")
+    S, R = idx.search_rows(Q, k)
+    assert idx.filter_stats()["kind"] == "rows_hi"
+    for b in range(3):
+        es, ei = oracle.topk_desc(sim_fp32_exact(E, Q[b], "l2"), k)
+        assert np.array_equal(R[b], ei) and _same(S[b], es.astype(np.float32))
+    # a metadata filter and tombstones: the ranked flow under a row mask
+    ok = rng.random(n) < 0.4
+    S1, R1 = idx.search_rows(Q, k, chunk_filter=ok)
+    assert idx.filter_stats()["kind"] == "rows_hi" and ok[R1].all()
+    with idx.options(hi_search=0):
+        S2, R2 = idx.search_rows(Q, k, chunk_filter=ok)
+    assert np.array_equal(R1, R2) and _same(S1, S2)
+    # k > 128 without a mask (or fewer than 3 k groups of 1024 rows), more than four queries: the full-precision route (same results, the route says so)
+    S3, R3 = idx.search_rows(Q[0], 300)
+    assert idx.filter_stats()["kind"] != "rows_hi"
+    es, ei = oracle.topk_desc(sim_fp32_exact(E, Q[0], "l2"), 300)
+    assert np.array_equal(R3, ei)
+    Q5 = oracle.synth_matrix(9702, 5, dim, "small_int")
+    S4, R4 = idx.search_rows(Q5, 10)
+    assert idx.filter_stats()["kind"] != "rows_hi"
+    idx.close()
+    # the reference's nearest neighbour IS often a near-duplicate: 5000 rows within 1e-4 of the query -- distances of ~3e-3 where |e|^2 + |q|^2 -
+    # 2 e.q has lost every digit; the band holds more rows than a list, the guarded scan answers with the full route's bits
+    E = oracle.synth_matrix(9800, n, dim)
+    q = oracle.synth_matrix(9801, 1, dim)[0]
+    dup = rng.choice(n, 5000, replace=False)
+    E[dup] = (q[None, :] + 1e-4 * rng.standard_normal((5000, dim))).astype(np.float32)
+    idx = raglite_amd.DeviceIndex(E, metric="l2")
+    S, R = idx.search_rows(q, 100)
+    assert idx.filter_stats()["kind"] == "rows_hi" and idx.filter_stats()["fallback"]
+    with idx.options(hi_search=0):
+        S0, R0 = idx.search_rows(q, 100)
+    assert np.array_equal(R, R0) and _same(S, S0) and np.isin(R, dup).all()
+    # ... and a few dozen near-duplicates only: the candidates hold them, no fallback, the same bits
+    E2 = oracle.synth_matrix(9802, n, dim)
+    few = rng.choice(n, 40, replace=False)
+    E2[few] = (q[None, :] + 1e-4 * rng.standard_normal((40, dim))).astype(np.float32)
+    idx2 = raglite_amd.DeviceIndex(E2, metric="l2")
+    S, R = idx2.search_rows(q, 100)
+    assert idx2.filter_stats()["kind"] == "rows_hi" and not idx2.filter_stats()["fallback"]
+    with idx2.options(hi_search=0):
+        S0, R0 = idx2.search_rows(q, 100)
+    assert np.array_equal(R, R0) and _same(S, S0) and np.isin(few, R).all()
+    idx.close()
+    idx2.close()
