@@ -753,6 +753,9 @@ int rl_pool_norm(const float* tokens, int64_t n_token_rows, int32_t dim, const i
 
 // Below this many queries the stream kernel's per-32-query corpus passes (HBM-bound) beat a 128-query GEMM tile.
 constexpr int32_t GEMM_MIN_QUERIES = 96;
+// (a WIDE index -- dim > 1024 -- has no 32-queries-per-pass streaming kernel between the few-queries routes and the GEMM-shaped ones: its scan takes ONE
+// query per pass, so the GEMM-shaped routes start right behind the few-queries search there)
+int32_t rows_gemm_min(const rl_index* idx) { return idx->dim > 1024 ? 5 : GEMM_MIN_QUERIES; }
 
 // ---- a5 ----------------------------------------------------------------------------------------------
 int rl_adapter_apply(const float* A, const float* queries, int32_t n_queries, int32_t dim, float* out_f32,
@@ -1331,8 +1334,8 @@ int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStrea
     };
     const int mode = scan_mode(idx->metric);
     float* sc = idx->scores.as<float>();
-    if (nb >= GEMM_MIN_QUERIES && idx->opt.on(RL_OPT_PLANES_GEMM)) RL_TRY(demand_images(idx, IMG_PLANES, s));
-    if (nb >= GEMM_MIN_QUERIES && image_valid(idx)) {
+    if (nb >= rows_gemm_min(idx) && idx->opt.on(RL_OPT_PLANES_GEMM)) RL_TRY(demand_images(idx, IMG_PLANES, s));
+    if (nb >= rows_gemm_min(idx) && image_valid(idx)) {
         // the row-score GEMM over the corpus image (maxsim_gemm.hip MODE 1; fp32 corpus: pre-split planes, fp16-stored corpus:
         // its one-plane image): no conversion in the loop
         if (idx->opt.on(RL_OPT_PLANES_GEMM)) {
@@ -1357,7 +1360,7 @@ int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStrea
         }
         return transform(sc, mode);
     }
-    if (nb >= GEMM_MIN_QUERIES) {  // MFMA-bound regime: one 128 x 128-tiled GEMM instead of a corpus pass per 32 queries
+    if (nb >= rows_gemm_min(idx)) {  // MFMA-bound regime: one 128 x 128-tiled GEMM instead of a corpus pass per 32 queries
         RL_TRY(idx->misc.reserve(score_gemm_scratch_floats(nb, idx->dim, idx->split_scale > 0.f) * sizeof(float)));
         const int st = launch_score_gemm(idx->E, idx->n_rows, idx->dim, d_q, nb, sc, ld, idx->norm, idx->sumsq,
                                          idx->misc.as<float>(), mode, idx->n_cu, s, idx->split_scale);
@@ -1409,7 +1412,7 @@ int search_rows_fused(rl_index* idx, const float* d_q, int32_t B, int32_t k, flo
     const bool off = !idx->opt.on(RL_OPT_FUSED_TOPK);
     const int cap_env = (int)idx->opt.v[RL_OPT_FUSED_TOPK_CAP];  // tests: force list overflows
     const int mode = scan_mode(idx->metric);
-    if (off || B < GEMM_MIN_QUERIES || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT)) return RL_ERR_UNSUPPORTED;
+    if (off || B < rows_gemm_min(idx) || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT)) return RL_ERR_UNSUPPORTED;
     if (!image_valid(idx)) return RL_ERR_UNSUPPORTED;
     const bool half = idx->E16 != nullptr;
     const float img_scale = image_scale(idx);
@@ -1478,7 +1481,7 @@ int search_rows_fused_hi(rl_index* idx, const float* d_q, int32_t B, int32_t k, 
     if (!idx->opt.on(RL_OPT_FUSED_HI) || !idx->opt.on(RL_OPT_FUSED_TOPK)) return RL_ERR_UNSUPPORTED;  // (the second asks for the dense path: no fused top-k at all)
     const bool hi_only = true;  // (two products -- q_hi.e_hi + q_lo.e_hi, no |q_lo| term in the band -- measured 4.88 ms against 3.51)
     const int mode = scan_mode(idx->metric);
-    if (B < GEMM_MIN_QUERIES || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT)) return RL_ERR_UNSUPPORTED;
+    if (B < rows_gemm_min(idx) || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT)) return RL_ERR_UNSUPPORTED;
     if (!hi_image_valid(idx) || !image_valid(idx) || !idx->E) return RL_ERR_UNSUPPORTED;
     if (mode == SCAN_COSINE && !idx->norm) return RL_ERR_UNSUPPORTED;
     const int64_t n = idx->n_rows, T = (n + 255) / 256;
@@ -1774,7 +1777,7 @@ int search_rows_device(rl_index* idx, const float* d_q, int32_t B, int32_t k, fl
         const int32_t nb = std::min<int32_t>(batch, B - b0);
         const bool cut = rank_limit > 0 && rank_limit < n;
         // lazy images: the routes below test what the index HAS; ask for what this batch's route reads first
-        if (!d_row_bits && !cut && nb >= GEMM_MIN_QUERIES && k <= 512 && idx->opt.on(RL_OPT_FUSED_TOPK))
+        if (!d_row_bits && !cut && nb >= rows_gemm_min(idx) && k <= 512 && idx->opt.on(RL_OPT_FUSED_TOPK))
             RL_TRY(demand_images(idx, IMG_PLANES | (idx->opt.on(RL_OPT_FUSED_HI) ? IMG_HI_IMAGE : 0u), s));
         if (!cut && nb <= ((idx->dim > 1024 || idx->metric == RL_L2) ? 4 : 16) && k <= 512 && idx->opt.on(RL_OPT_HI_SEARCH))
             RL_TRY(demand_images(idx, IMG_HI_PLANE, s));

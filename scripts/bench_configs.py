@@ -369,6 +369,9 @@ def wide_dims():
         msb0 = timed(lambda: idx.search_rows(Q, 100), 3, 1)
         blk["three_products_over_the_presplit_image"] = {"ms_per_batch": float(msb0), "route": idx.filter_stats()["kind"]}
     out["cosine_top100_1000_queries_dim1536"] = blk
+    ms16 = timed(lambda: idx.search_rows(Q[:16], 100), 10, 2)  # (between the few-queries search and the big batches: rows_gemm_min)
+    out["cosine_top100_16_queries_dim1536"] = {"rows": n, "dim": d, "queries": 16, "ms_per_batch": float(ms16), "value": 16e3 / ms16,
+                                                "route": idx.filter_stats()["kind"]}
     idx.close()
     out["value"] = out["maxsim_dim1536"]["value"]
     return out

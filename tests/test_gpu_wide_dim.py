@@ -249,3 +249,30 @@ def test_wide_index_keeps_rows_and_hi_image_only_and_its_guarded_fallback_scores
             assert_topk_close(s_[i], c_[i], ref, 100, 2e-6 * float(np.abs(ref).max()))
             assert np.isin(c_[i], hot).all()
     idx.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+@pytest.mark.parametrize("B", [5, 16, 50])
+def test_mid_size_batches_over_a_wide_index_take_the_gemm_shaped_routes(metric, B):
+    """Between the few-queries search (<= 4) and the big batches a 1024-wide index has the 32-queries-per-pass streaming kernel; a wide index had
+    only its scan, ONE query per pass (16 queries over 650 k x 1536: 14 ms).  There the GEMM-shaped routes -- the fused top-k over the HI image,
+    the dense GEMM for l2 / masks -- start at five queries (api.hip: rows_gemm_min)."""
+    n, dim, k = 48_000, 1536, 40
+    E = oracle.synth_matrix(28_000, n, dim)
+    Q = oracle.synth_matrix(28_100 + B, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    s, r = idx.search_rows(Q, k)
+    st = idx.filter_stats()
+    if metric != "l2":
+        assert st["kind"] == "rows_fused_hi" and not st["fallback"], st
+    for b in (0, B - 1):
+        sims = oracle.similarity(E, Q[b], metric)
+        scale = 1.0 if metric == "cosine" else max(1.0, float(np.linalg.norm(E, axis=1).max() * np.linalg.norm(Q[b])))
+        assert_topk_close(s[b], r[b], sims, k, 4e-6 * scale)
+    ok = np.random.default_rng(B).random(n) < 0.5  # a row mask: the dense route
+    s1, r1 = idx.search_rows(Q, k, chunk_filter=ok)
+    assert ok[r1].all()
+    sims = np.where(ok, oracle.similarity(E, Q[0], metric), -np.inf)
+    scale = 1.0 if metric == "cosine" else max(1.0, float(np.linalg.norm(E, axis=1).max() * np.linalg.norm(Q[0])))
+    assert_topk_close(s1[0], r1[0], sims, k, 4e-6 * scale)
+    idx.close()
