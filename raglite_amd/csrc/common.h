@@ -415,7 +415,7 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
                         int packed = 1);  // 0: a chunk per tile; 1: rows packed into shared tiles; 2: ... by sixteen waves per workgroup  // dim % 128 == 0: the row-packing kernel (same bits, about half the matrix work on short chunks)
 // 1024 < dim <= 4096 (dim % 128 == 0): launch_maxsim_pairs takes maxsim_pairs_wide_kernel; and the exact scores of EVERY chunk behind a run-if flag
 int launch_maxsim_pairs_all_wide(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride, const int64_t* offsets, int64_t n_chunks,
-                                 int32_t n_queries, float* out, int64_t out_stride, hipStream_t s, const uint32_t* run_if);
+                                 int32_t n_queries, float* out, int64_t out_stride, hipStream_t s, const uint32_t* run_if, bool rows16 = false);
 int launch_maxsim_generic(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride_queries,
                           const int64_t* chunk_offsets, const int32_t* candidates, int64_t n_items,
                           int32_t n_queries, float* out, hipStream_t s);

@@ -427,6 +427,8 @@ __global__ __launch_bounds__(NW * 64) void maxsim_pairs_packed_kernel(const floa
 // from HBM); no workgroup barrier at all.  Per (row, query vector) the k steps accumulate in ascending order as in the kernels above, the
 // maximum is exact, the sum tree is the same: the bits of maxsim_pairs_kernel's arithmetic at any dim (tests/test_gpu_wide_dim.py).
 constexpr int PW_KW = 128, PW_T = 8, PW_PITCH = PW_KW + 8;
+// ROW16: the rows are stored as fp16 (`D` points at halves; an fp16-stored wide index): 8 B per lane and k step, widened on the way in (exact)
+template <bool ROW16>
 __global__ __launch_bounds__(512) void maxsim_pairs_wide_kernel(const float* __restrict__ D, int dim, const float* __restrict__ Q, int nq,
                                                                  int64_t q_stride, const int64_t* __restrict__ offsets,
                                                                  const int32_t* __restrict__ candidates, int64_t n_items, int64_t item_stride,
@@ -447,9 +449,19 @@ __global__ __launch_bounds__(512) void maxsim_pairs_wide_kernel(const float* __r
     const int nwin = dim / PW_KW;
     constexpr int NL = PW_KW / 16;
     auto request = [&](f32x4 (&x)[NL], int32_t row, int t0) __attribute__((always_inline)) {
-        const float* a = D + (int64_t)row * dim + 4 * g + t0;
+        if constexpr (ROW16) {
+            typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+            const _Float16* a = reinterpret_cast<const _Float16*>(D) + (int64_t)row * dim + 4 * g + t0;
 #pragma unroll
-        for (int j = 0; j < NL; ++j) x[j] = *reinterpret_cast<const f32x4*>(a + 16 * j);
+            for (int j = 0; j < NL; ++j) {
+                const h16x4 h = *reinterpret_cast<const h16x4*>(a + 16 * j);
+                x[j] = (f32x4){(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+            }
+        } else {
+            const float* a = D + (int64_t)row * dim + 4 * g + t0;
+#pragma unroll
+            for (int j = 0; j < NL; ++j) x[j] = *reinterpret_cast<const f32x4*>(a + 16 * j);
+        }
     };
     f32x4 xc[NL], xn[NL];
     for (int64_t base = (int64_t)blockIdx.x * 8 + w; base < n_items; base += 64 * stride) {
@@ -599,16 +611,21 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
     if (nq < 1 || nq > 32 || dim % 16 || dim < 16 || dim > PAIRS_MAX_DIM || !candidates) return RL_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(D) & (rows16 ? 7 : 15)) || (reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
     if (dim > 1024) {  // wider than a CU's LDS holds a query: wave-private query windows (maxsim_pairs_wide_kernel)
-        if (dim % PW_KW || rows16) return RL_ERR_UNSUPPORTED;
+        if (dim % PW_KW) return RL_ERR_UNSUPPORTED;
         const size_t lds_w = (size_t)8 * 32 * PW_PITCH * sizeof(float);
         static bool wide_attr = false;
         if (!wide_attr) {
-            RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_wide_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_wide_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             wide_attr = true;
         }
         const int per_q = (int)std::max<int64_t>(1, std::min<int64_t>((n_items_per_query + 7) / 8, std::max<int64_t>(1, 256 / n_queries)));
-        hipLaunchKernelGGL(maxsim_pairs_wide_kernel, dim3(per_q, n_queries), dim3(512), lds_w, s, D, (int)dim, Q, (int)nq, q_stride, offsets, candidates,
-                           n_items_per_query, item_stride, out, (const uint32_t*)nullptr);
+        if (rows16)
+            hipLaunchKernelGGL(maxsim_pairs_wide_kernel<true>, dim3(per_q, n_queries), dim3(512), lds_w, s, D, (int)dim, Q, (int)nq, q_stride, offsets,
+                               candidates, n_items_per_query, item_stride, out, (const uint32_t*)nullptr);
+        else
+            hipLaunchKernelGGL(maxsim_pairs_wide_kernel<false>, dim3(per_q, n_queries), dim3(512), lds_w, s, D, (int)dim, Q, (int)nq, q_stride, offsets,
+                               candidates, n_items_per_query, item_stride, out, (const uint32_t*)nullptr);
         RL_HIP(hipGetLastError());
         return RL_OK;
     }
@@ -703,18 +720,23 @@ int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq,
 // Exact MaxSim scores of EVERY chunk for a batch of queries over a wide index (1024 < dim <= 4096, dim % 128 == 0), behind a run-if flag:
 // out[q * out_stride + chunk].  The guarded full-precision fallback of the bound-filtered batch where the index keeps rows + HI image only.
 int launch_maxsim_pairs_all_wide(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride, const int64_t* offsets, int64_t n_chunks,
-                                 int32_t n_queries, float* out, int64_t out_stride, hipStream_t s, const uint32_t* run_if) {
+                                 int32_t n_queries, float* out, int64_t out_stride, hipStream_t s, const uint32_t* run_if, bool rows16) {
     if (n_chunks <= 0 || n_queries <= 0) return RL_OK;
     if (nq < 1 || nq > 32 || dim <= 1024 || dim > PAIRS_MAX_DIM || dim % PW_KW) return RL_ERR_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(D) & 15) || (reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(D) & (rows16 ? 7 : 15)) || (reinterpret_cast<uintptr_t>(Q) & 15) || (q_stride & 3)) return RL_ERR_UNSUPPORTED;
     static bool attr = false;
     if (!attr) {
-        RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_wide_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(maxsim_pairs_wide_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     const size_t lds_w = (size_t)8 * 32 * PW_PITCH * sizeof(float);
     const int per_q = (int)std::max<int64_t>(1, std::min<int64_t>((n_chunks + 511) / 512, std::max<int64_t>(1, 1024 / n_queries)));
-    hipLaunchKernelGGL(maxsim_pairs_wide_kernel, dim3(per_q, n_queries), dim3(512), lds_w, s, D, (int)dim, Q, (int)nq, q_stride, offsets,
+    if (rows16)
+        hipLaunchKernelGGL(maxsim_pairs_wide_kernel<true>, dim3(per_q, n_queries), dim3(512), lds_w, s, D, (int)dim, Q, (int)nq, q_stride, offsets,
+                           (const int32_t*)nullptr, n_chunks, out_stride, out, run_if);
+    else
+    hipLaunchKernelGGL(maxsim_pairs_wide_kernel<false>, dim3(per_q, n_queries), dim3(512), lds_w, s, D, (int)dim, Q, (int)nq, q_stride, offsets,
                        (const int32_t*)nullptr, n_chunks, out_stride, out, run_if);
     RL_HIP(hipGetLastError());
     return RL_OK;

@@ -109,21 +109,28 @@ __global__ __launch_bounds__(256) void scan_rows16_kernel(const uint16_t* __rest
 // 1024 < dim <= 4096 (round 6), raw dots only: the approximate pass of a few-queries search over the HI plane of a wide fp32 index.  The two rows
 // in flight stay PACKED (16 B = 8 halves per register quad) until they are multiplied -- converted up front, as above, a 4096-wide row pair
 // alone would take 128 registers.  Same order of summation as above: lane l sums its elements v = 0 .. NV - 1, j = 0 .. 7, then the butterfly.
-template <int NV, int BQ>
+template <int NV, int BQ, bool L2>
 __global__ __launch_bounds__(256) void scan_rows16_wide_kernel(const uint16_t* __restrict__ E, int64_t n, int dim, const float* __restrict__ queries,
-                                                                float* __restrict__ scores, int64_t ld) {
+                                                                const float* __restrict__ row_norm, int mode, float* __restrict__ scores, int64_t ld) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int64_t n_waves = (int64_t)gridDim.x * 4;
     float q[BQ][NV][8];
+    float qn[BQ];
 #pragma unroll
-    for (int b = 0; b < BQ; ++b)
+    for (int b = 0; b < BQ; ++b) {
+        float ss = 0.f;
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) q[b][v][j] = 0.f;
             if ((v * 64 + lane) * 8 < dim) load8f(queries + (int64_t)b * dim + (v * 64 + lane) * 8, q[b][v]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss = fmaf(q[b][v][j], q[b][v][j], ss);
         }
+        qn[b] = sqrtf(wave_sum(ss));
+    }
+    constexpr bool l2 = L2;  // (mode == SCAN_L2; an fp16-STORED wide index scans its rows in every metric: the statements of scan_rows16_kernel)
     const h16x8 zero = (h16x8){0, 0, 0, 0, 0, 0, 0, 0};
     for (int64_t r = wave0; r < n; r += 2 * n_waves) {
         const int64_t r1 = r + n_waves;
@@ -145,17 +152,25 @@ __global__ __launch_bounds__(256) void scan_rows16_wide_kernel(const uint16_t* _
             for (int v = 0; v < NV; ++v)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    s0 = fmaf((float)t0[v][j], q[b][v][j], s0);
-                    s1 = fmaf((float)t1[v][j], q[b][v][j], s1);
+                    if constexpr (l2) {
+                        const float d0 = (float)t0[v][j] - q[b][v][j], d1 = (float)t1[v][j] - q[b][v][j];
+                        s0 = fmaf(d0, d0, s0);
+                        s1 = fmaf(d1, d1, s1);
+                    } else {
+                        s0 = fmaf((float)t0[v][j], q[b][v][j], s0);
+                        s1 = fmaf((float)t1[v][j], q[b][v][j], s1);
+                    }
                 }
             a0[b] = wave_sum(s0);
             a1[b] = wave_sum(s1);
         }
+        const float rn0 = (mode == SCAN_COSINE) ? row_norm[r] : 1.f;
+        const float rn1 = (mode == SCAN_COSINE && has1) ? row_norm[r1] : 1.f;
 #pragma unroll
         for (int b = 0; b < BQ; ++b) {
             if (lane == b) {
-                scores[(int64_t)b * ld + r] = a0[b];
-                if (has1) scores[(int64_t)b * ld + r1] = a1[b];
+                scores[(int64_t)b * ld + r] = finish16(a0[b], rn0, qn[b], mode);
+                if (has1) scores[(int64_t)b * ld + r1] = finish16(a1[b], rn1, qn[b], mode);
             }
         }
     }
@@ -211,48 +226,56 @@ int scan16_nb(const uint16_t* E, int64_t n, int32_t dim, const float* q, int32_t
     return RL_OK;
 }
 template <int NV, int BQ>
-int scan16_wide_t(const uint16_t* E, int64_t n, int32_t dim, const float* q, float* sc, int64_t ld, hipStream_t s) {
-    const int blocks = persistent_grid(scan_rows16_wide_kernel<NV, BQ>, 256, (n + 7) / 8);
-    hipLaunchKernelGGL((scan_rows16_wide_kernel<NV, BQ>), dim3(blocks), dim3(256), 0, s, E, n, (int)dim, q, sc, ld);
+int scan16_wide_t(const uint16_t* E, int64_t n, int32_t dim, const float* q, const float* rn, int mode, float* sc, int64_t ld, hipStream_t s) {
+    if (mode == SCAN_L2) {
+        const int blocks = persistent_grid(scan_rows16_wide_kernel<NV, BQ, true>, 256, (n + 7) / 8);
+        hipLaunchKernelGGL((scan_rows16_wide_kernel<NV, BQ, true>), dim3(blocks), dim3(256), 0, s, E, n, (int)dim, q, rn, mode, sc, ld);
+    } else {
+        const int blocks = persistent_grid(scan_rows16_wide_kernel<NV, BQ, false>, 256, (n + 7) / 8);
+        hipLaunchKernelGGL((scan_rows16_wide_kernel<NV, BQ, false>), dim3(blocks), dim3(256), 0, s, E, n, (int)dim, q, rn, mode, sc, ld);
+    }
     RL_HIP(hipGetLastError());
     return RL_OK;
 }
 template <int NV>
-int scan16_wide_nb(const uint16_t* E, int64_t n, int32_t dim, const float* q, int32_t nb, float* sc, int64_t ld, hipStream_t s) {
+int scan16_wide_nb(const uint16_t* E, int64_t n, int32_t dim, const float* q, int32_t nb, const float* rn, int mode, float* sc, int64_t ld, hipStream_t s) {
     constexpr int BQ_MAX = NV <= 4 ? 4 : 2;  // queries per corpus pass, registers permitting (a lane keeps NV x 8 elements of every query)
     int32_t b = 0;
     while (b < nb) {
         const float* qb = q + (int64_t)b * dim;
         float* sb = sc + (int64_t)b * ld;
         if constexpr (BQ_MAX >= 4) {
-            if (nb - b >= 4) { RL_TRY((scan16_wide_t<NV, 4>(E, n, dim, qb, sb, ld, s))); b += 4; continue; }
+            if (nb - b >= 4) { RL_TRY((scan16_wide_t<NV, 4>(E, n, dim, qb, rn, mode, sb, ld, s))); b += 4; continue; }
         }
-        if (nb - b >= 2) { RL_TRY((scan16_wide_t<NV, 2>(E, n, dim, qb, sb, ld, s))); b += 2; continue; }
-        RL_TRY((scan16_wide_t<NV, 1>(E, n, dim, qb, sb, ld, s)));
+        if (nb - b >= 2) { RL_TRY((scan16_wide_t<NV, 2>(E, n, dim, qb, rn, mode, sb, ld, s))); b += 2; continue; }
+        RL_TRY((scan16_wide_t<NV, 1>(E, n, dim, qb, rn, mode, sb, ld, s)));
         b += 1;
     }
     return RL_OK;
 }
 }  // namespace
 
-// dim % 8 == 0, 16-B aligned rows and queries (rl_index_create_f16 guarantees it); dim <= 1024 -- or, raw dots only (round 6), dim <= 4096:
-// the approximate pass of a few-queries search over the HI plane of a WIDE fp32 index (api.hip: search_rows_hi), half the bytes of the fp32
-// scan, which takes such an index one query per pass.
+// dim % 8 == 0, 16-B aligned rows and queries (rl_index_create_f16 guarantees it); dim <= 4096.  Beyond 1024 (round 6): the approximate pass of a
+// few-queries search over the HI plane of a WIDE fp32 index (api.hip: search_rows_hi; raw dots, half the bytes of the fp32 scan, which takes such
+// an index one query per pass) and the row scan of an fp16-STORED wide index (every metric).
 int launch_scan_rows16(const uint16_t* E, int64_t n, int32_t dim, const float* queries, int32_t nb,
                        const float* row_norm, int mode, float* scores, int64_t ld, hipStream_t s) {
     if (n <= 0 || nb <= 0) return RL_OK;
-    if (dim % 8 != 0 || dim > 4096 || (dim > 1024 && mode != SCAN_RAW_DOT)) return RL_ERR_UNSUPPORTED;
+    if (dim % 8 != 0 || dim > 4096 || (mode == SCAN_COSINE && !row_norm)) return RL_ERR_UNSUPPORTED;
     if (dim <= 512) return scan16_nb<1>(E, n, dim, queries, nb, row_norm, mode, scores, ld, s);
     if (dim <= 1024) return scan16_nb<2>(E, n, dim, queries, nb, row_norm, mode, scores, ld, s);
-    if (dim <= 2048) return scan16_wide_nb<4>(E, n, dim, queries, nb, scores, ld, s);
-    if (dim <= 3072) return scan16_wide_nb<6>(E, n, dim, queries, nb, scores, ld, s);
-    return scan16_wide_nb<8>(E, n, dim, queries, nb, scores, ld, s);
+    if (dim <= 2048) return scan16_wide_nb<4>(E, n, dim, queries, nb, row_norm, mode, scores, ld, s);
+    if (dim <= 3072) return scan16_wide_nb<6>(E, n, dim, queries, nb, row_norm, mode, scores, ld, s);
+    return scan16_wide_nb<8>(E, n, dim, queries, nb, row_norm, mode, scores, ld, s);
 }
 
 int launch_row_norms16(const uint16_t* E, int64_t n, int32_t dim, float* norm, float* sumsq, hipStream_t s) {
     if (n <= 0) return RL_OK;
-    if (dim % 8 != 0 || dim > 1024) return RL_ERR_UNSUPPORTED;
-    if (dim <= 512) {
+    if (dim % 8 != 0 || dim > 4096) return RL_ERR_UNSUPPORTED;
+    if (dim > 1024) {
+        const int blocks = persistent_grid(row_norms16_kernel<8>, 256, (n + 3) / 4);
+        hipLaunchKernelGGL((row_norms16_kernel<8>), dim3(blocks), dim3(256), 0, s, E, n, (int)dim, norm, sumsq);
+    } else if (dim <= 512) {
         const int blocks = persistent_grid(row_norms16_kernel<1>, 256, (n + 3) / 4);
         hipLaunchKernelGGL((row_norms16_kernel<1>), dim3(blocks), dim3(256), 0, s, E, n, (int)dim, norm, sumsq);
     } else {
