@@ -110,10 +110,11 @@ int rl_index_create(rl_index** out, const float* embeddings, int64_t n_rows, int
 /* fp16-STORED index.  The reference stores its embeddings as float16
  * (src/raglite/_embed.py:140, src/raglite/_database.py:279-283), so this storage is lossless for real
  * RAGLite data and halves the bytes of every HBM-bound pass.  embeddings_f16: [n_rows x dim] IEEE
- * binary16 bit patterns; dim must be one of 128, 256, 384, 512, 768, 1024.  Queries, scores and every
- * other argument stay fp32; arithmetic is fp32 (VALU) or fp16 x fp16 -> fp32 MFMA (exact products).
+ * binary16 bit patterns; dim must be one of 128, 256, 384, 512, 768, 1024 or (round 6: 1536- / 3072-wide embedders) a multiple of 128 up
+ * to 4096.  Queries, scores and every other argument stay fp32; arithmetic is fp32 (VALU) or fp16 x fp16 -> fp32 MFMA (exact products).
  * rl_index_append on such an index takes fp32 rows and rounds them to nearest-even fp16;
- * rl_maxsim_rerank needs dim == 128 and nq <= 32 on it (the cfg 3 shape). */
+ * rl_maxsim_rerank needs nq <= 32 and dim % 16 == 0 on it (dim 128: the cfg 3 kernel); beyond dim 1024 every MaxSim call takes up to 32
+ * query vectors. */
 int rl_index_create_f16(rl_index** out, const uint16_t* embeddings_f16, int64_t n_rows, int32_t dim,
                         const int64_t* chunk_offsets, int64_t n_chunks, int metric, int mem, void* stream);
 int rl_index_destroy(rl_index* index);
@@ -134,8 +135,7 @@ int rl_index_info(const rl_index* index, int64_t* n_rows, int32_t* dim, int64_t*
  * WIDE indexes (round 6): the half-bytes routes -- HI image / HI plane, bound-filtered MaxSim batches, few-queries and fused row searches --
  * take any dim % 32 == 0 up to 1024 and, beyond, dim % 128 == 0 up to 4096 (1536- / 3072-wide embedders, src/raglite/_embed.py:155-158);
  * on a wide index even one MaxSim query goes through the sixteen-query pass and the few-queries row search takes up to 4 queries (16 at
- * dim <= 1024).  Other widths, fp16-STORED wide indexes (rl_index_create_f16 keeps its six dims), l2 and k > 512 run on the
- * full-precision routes: same results, 2-3 x slower. */
+ * dim <= 1024).  Other widths and k > 512 run on the full-precision routes: same results, 2-3 x slower. */
 int rl_index_memory(const rl_index* index, int64_t out[8]);
 
 /* Warm-up for lazy images (RL_OPT_LAZY_IMAGES, the default): build the images in `images` (RL_IMAGE_* bits) NOW, on `stream`, instead of

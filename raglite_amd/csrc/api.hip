@@ -480,7 +480,7 @@ bool hi_image_valid(const rl_index* idx) {
 // bound has no e_lo term, and the candidates are re-scored over the stored rows).  Same size gate for both (>= 64 M elements).
 bool approx_image_valid(const rl_index* idx) {
     if (!idx->E16) return hi_image_valid(idx);
-    return image_valid(idx) && (int64_t)idx->n_rows * idx->dim >= (int64_t(64) << 20) && idx->dim <= 1024 && idx->max_row_norm_rows == idx->n_rows &&
+    return image_valid(idx) && (int64_t)idx->n_rows * idx->dim >= (int64_t(64) << 20) && hi_dim_ok(idx->dim) && idx->max_row_norm_rows == idx->n_rows &&
            idx->max_row_norm > 0.f;
 }
 const void* approx_image(const rl_index* idx) { return idx->E16 ? idx->planes.p : idx->hi_image.p; }
@@ -850,8 +850,9 @@ static int index_create_any(rl_index** out, const void* embeddings, bool f16, in
     if (n_rows >= (int64_t)0x7fffffff - 1) return fail(RL_ERR_UNSUPPORTED, "rl_index_create: more than 2^31-2 rows");
     if (scan_mode(metric) < 0) return fail(RL_ERR_INVALID, "rl_index_create: unknown metric");
     if (dim > 4096) return fail(RL_ERR_UNSUPPORTED, "rl_index_create: dim must be <= 4096");
-    if (f16 && dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024)
-        return fail(RL_ERR_UNSUPPORTED, "rl_index_create_f16: dim must be one of 128, 256, 384, 512, 768, 1024");
+    // (the stream kernels' dims; wider -- round 6 -- through the packed scan, the sixteen-query pass and the wide re-scoring kernel)
+    if (f16 && dim != 128 && dim != 256 && dim != 384 && dim != 512 && dim != 768 && dim != 1024 && !(dim > 1024 && hi_dim_ok(dim)))
+        return fail(RL_ERR_UNSUPPORTED, "rl_index_create_f16: dim must be one of 128, 256, 384, 512, 768, 1024, or a multiple of 128 up to 4096");
     if (f16 && mem == RL_MEM_DEVICE && (reinterpret_cast<uintptr_t>(embeddings) & 15))
         return fail(RL_ERR_INVALID, "rl_index_create_f16: device embeddings must be 16-byte aligned");
     std::vector<int64_t> host_offsets;
@@ -1350,7 +1351,9 @@ int score_rows(rl_index* idx, const float* d_q, int32_t nb, int64_t ld, hipStrea
         // half the bytes per row the LDS-DMA stream is the faster reader even for a single query.  Exception: l2 with up
         // to 4 queries keeps the scan, which sums (e - q)^2 directly; the stream path's |e|^2 + |q|^2 - 2 e.q loses a
         // near-duplicate's small distance to cancellation (the reference's nearest neighbour IS often a near-duplicate).
-        if (nb <= 4 && mode == SCAN_L2)
+        // A WIDE fp16-stored index (dim > 1024, round 6): the packed scan in every metric, up to four queries per pass -- no stream kernel
+        // covers it; batches of five and more took the GEMM over its image above (rows_gemm_min).
+        if ((nb <= 4 && mode == SCAN_L2) || idx->dim > 1024)
             return launch_scan_rows16(idx->E16, idx->n_rows, idx->dim, d_q, nb, idx->norm, mode, sc, ld, s);
         for (int32_t b0 = 0; b0 < nb; b0 += 32) {
             const int32_t nq = std::min<int32_t>(32, nb - b0);
@@ -2088,6 +2091,13 @@ int maxsim_scores_device(rl_index* idx, const float* d_q, int32_t nq, float* d_o
     if (idx->has_empty_chunk || idx->n_rows == 0)
         RL_TRY(launch_fill_f32(d_out, -std::numeric_limits<float>::infinity(), idx->n_chunks, s));
     if (idx->n_rows == 0) return RL_OK;
+    if (idx->E16 && idx->dim > 1024) {  // a wide fp16-stored index: the exact re-scoring kernel over every chunk (empty chunks: -inf)
+        if (nq > 32) return fail(RL_ERR_UNSUPPORTED, "MaxSim over an fp16-stored index wider than 1024 takes up to 32 query vectors");
+        st = launch_maxsim_pairs_all_wide(reinterpret_cast<const float*>(idx->E16), idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, idx->n_chunks, 1,
+                                          d_out, idx->n_chunks, s, nullptr, true);
+        if (st == RL_ERR_UNSUPPORTED) return fail(st, "MaxSim: query vectors must be 16-byte aligned on an fp16-stored index wider than 1024");
+        return st;
+    }
     // More than 32 query vectors: passes of 32, each adding its chunk scores to the previous ones (fixed pass order).
     for (int32_t v0 = 0; v0 < nq; v0 += 32) {
         const int32_t nv = std::min<int32_t>(32, nq - v0);
@@ -2705,8 +2715,8 @@ int rl_maxsim_rerank(rl_index* idx, const float* query_vecs, int32_t n_queries, 
     if (n_queries < 0 || n_cand < 0 || nq < 1) return fail(RL_ERR_INVALID, "rl_maxsim_rerank: bad sizes");
     if (n_queries == 0 || n_cand == 0) return RL_OK;
     if (!query_vecs || !candidates || !out_scores) return fail(RL_ERR_INVALID, "rl_maxsim_rerank: null argument");
-    if (idx->E16 && (idx->dim != 128 || nq > 32))
-        return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_rerank on an fp16-stored index needs dim == 128 and nq <= 32");
+    if (idx->E16 && (nq > 32 || idx->dim % 16))
+        return fail(RL_ERR_UNSUPPORTED, "rl_maxsim_rerank on an fp16-stored index needs nq <= 32 and dim % 16 == 0");
     if (mem == RL_MEM_HOST) {  // -1 = "no chunk" (the padding of rl_search_chunks results) is allowed and scores -inf
         for (int64_t i = 0; i < (int64_t)n_queries * n_cand; ++i)
             if (candidates[i] < -1 || candidates[i] >= idx->n_chunks)
@@ -2728,9 +2738,10 @@ int rl_maxsim_rerank(rl_index* idx, const float* query_vecs, int32_t n_queries, 
     }
     int st = idx->E16 ? launch_maxsim_cand16(idx->E16, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s)
                       : launch_maxsim_cand(idx->E, idx->dim, d_q, nq, idx->offsets, d_c, n_cand, n_queries, d_o, s, idx->split_scale);
-    if (st == RL_ERR_UNSUPPORTED && !idx->E16)  // other dims: the fp32-MFMA pairs kernel (dim % 16 == 0, <= 1024, nq <= 32) ...
-        st = launch_maxsim_pairs(idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, d_c, n_cand, n_queries, d_o, s, false, 0, 0,
-                                 (int)idx->opt.v[RL_OPT_PAIRS_PACKED]);
+    if (st == RL_ERR_UNSUPPORTED)  // other dims: the fp32-MFMA pairs kernels (dim % 16 == 0 up to 1024, % 128 up to 4096, nq <= 32; fp16 rows widened on the way in) ...
+        st = launch_maxsim_pairs(idx->E16 ? reinterpret_cast<const float*>(idx->E16) : idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, d_c,
+                                 n_cand, n_queries, d_o, s, idx->E16 != nullptr, 0, 0, (int)idx->opt.v[RL_OPT_PAIRS_PACKED]);
+    if (st == RL_ERR_UNSUPPORTED && idx->E16) return fail(st, "rl_maxsim_rerank: unsupported shape for an fp16-stored index");
     if (st == RL_ERR_UNSUPPORTED && !idx->E16)  // ... and the VALU backstop for everything else
         st = launch_maxsim_generic(idx->E, idx->dim, d_q, nq, (int64_t)nq * idx->dim, idx->offsets, d_c, n_cand,
                                    n_queries, d_o, s);

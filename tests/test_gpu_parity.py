@@ -777,8 +777,18 @@ def test_f16_storage_uniform_tolerance_and_lifecycle(metric):
     s3, r3 = idx.search_rows(extra[7], 5)
     assert r3[0] == n + 7
     assert_topk_close(s3, r3, np.where(alive, oracle.similarity(Ev2, extra[7], metric), -np.inf), 5, TOL)
-    with pytest.raises(Exception):  # the rerank fast path is dim 128 only on an fp16-stored index
-        idx.maxsim_rerank(np.zeros((1, 2, dim), np.float32), np.zeros((1, 2), np.int32))
+    # the rerank beyond dim 128 on an fp16-stored index (round 6): the pairs kernels over the stored halves
+    Qr = oracle.synth_matrix(92, 6, dim).reshape(1, 6, dim)
+    cand = np.array([[0, n_chunks - 1, 3]], np.int32)
+    Ev2c = np.concatenate([Ev, extra.astype(np.float16).astype(np.float32)])
+    off2 = np.concatenate((off, off[-1] + 1 + np.arange(33)))  # (appended rows: one chunk each)
+    got = idx.maxsim_rerank(Qr, cand)
+    want = oracle.maxsim_scores(Ev2c, off2, Qr[0], np.float64)[cand[0]]
+    live = np.concatenate([flt, np.ones(33, bool)])[cand[0]]
+    assert np.isneginf(got[0][~live]).all()
+    np.testing.assert_allclose(got[0][live], want[live], rtol=0, atol=2e-6 * max(1.0, float(np.abs(want).max())))
+    with pytest.raises(Exception):  # ... up to 32 query vectors
+        idx.maxsim_rerank(np.zeros((1, 33, dim), np.float32), np.zeros((1, 2), np.int32))
     idx.close()
     with pytest.raises(Exception):
         raglite_amd.DeviceIndex(np.zeros((4, 100), np.float16), storage="f16")  # dim outside the fast path

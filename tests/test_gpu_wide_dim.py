@@ -276,3 +276,96 @@ def test_mid_size_batches_over_a_wide_index_take_the_gemm_shaped_routes(metric, 
     scale = 1.0 if metric == "cosine" else max(1.0, float(np.linalg.norm(E, axis=1).max() * np.linalg.norm(Q[0])))
     assert_topk_close(s1[0], r1[0], sims, k, 4e-6 * scale)
     idx.close()
+
+
+# ---- fp16-STORED wide indexes (round 6): the reference's own storage precision (`_embed.py:140`, `_database.py:279-283`) at dim 1536 / 3072 ----------
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+@pytest.mark.parametrize("dim", [1536, 3072])
+def test_f16_stored_wide_index_row_searches_and_lifecycle(metric, dim):
+    rng = np.random.default_rng(dim)
+    n = 6_000
+    off = ragged_offsets(rng, n, 1, 9)
+    E16 = oracle.synth_matrix(29_000 + dim, n, dim).astype(np.float16)
+    Ev = E16.astype(np.float32)
+    idx = raglite_amd.DeviceIndex(E16, off, metric=metric, storage="f16")
+    for B in (1, 3, 4, 7, 20):  # the packed scan (<= 4 per pass), the GEMM-shaped routes from five up
+        Q = oracle.synth_matrix(29_100 + B, B, dim)
+        S, R = idx.search_rows(Q, 40)
+        for b in (0, B - 1):
+            sims = oracle.similarity(Ev, Q[b], metric)
+            scale = 1.0 if metric == "cosine" else max(1.0, float(np.linalg.norm(Ev, axis=1).max() * np.linalg.norm(Q[b])))
+            assert_topk_close(S[b], R[b], sims, 40, 4e-6 * scale)
+    n_chunks = len(off) - 1
+    r2c = np.repeat(np.arange(n_chunks), np.diff(off))
+    q = oracle.synth_matrix(29_200, 1, dim)[0]
+    flt = rng.random(n_chunks) < 0.4
+    s, r = idx.search_rows(q, 30, chunk_filter=flt)
+    assert flt[r2c[r]].all()
+    idx.delete_chunks(np.nonzero(~flt)[0])
+    s2, r2 = idx.search_rows(q, 30)
+    assert np.array_equal(r2, r) and np.array_equal(s2.view(np.uint32), s.view(np.uint32))
+    extra = oracle.synth_matrix(29_300, 17, dim)
+    idx.append(extra)
+    s3, r3 = idx.search_rows(extra[5].astype(np.float16).astype(np.float32), 3)
+    assert r3[0] == n + 5
+    cs, cc, cn = idx.search_chunks(q, 40, 5)
+    assert cn == 5 and flt[cc[cc < n_chunks]].all()
+    idx.close()
+    # integer data is exact in fp16: the oracle's rows and bits
+    Ei = oracle.synth_matrix(29_400 + dim, n, dim, "small_int")
+    Qi = oracle.synth_matrix(29_500, 3, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(Ei.astype(np.float16), off, metric=metric, storage="f16")
+    S, R = idx.search_rows(Qi, 25)
+    from tests.util import sim_fp32_exact
+    for b in range(3):
+        es, ei = oracle.topk_desc(sim_fp32_exact(Ei, Qi[b], metric), 25)
+        assert np.array_equal(R[b], ei) and np.array_equal(S[b].view(np.uint32), es.astype(np.float32).view(np.uint32))
+    idx.close()
+
+
+@pytest.mark.parametrize("dim,n", [(1536, 48_000), (3072, 24_000)])
+def test_f16_stored_wide_index_maxsim(dim, n):
+    rng = np.random.default_rng(dim + 3)
+    off = ragged_offsets(rng, n, 1, 15)
+    E16 = oracle.synth_matrix(29_600 + dim, n, dim).astype(np.float16)
+    Ev = E16.astype(np.float32)
+    Qb = np.stack([oracle.synth_matrix(29_700 + i, 32, dim) for i in range(9)])
+    idx = raglite_amd.DeviceIndex(E16, off, metric="dot", storage="f16")
+    assert idx.memory()["rows"] == n * dim * 2
+    k = 100
+    bs, bc = idx.maxsim_topk_batch(Qb, k)
+    st = idx.filter_stats()
+    assert st["kind"] == "maxsim_batch_hi" and not st["fallback"], st
+    for i in (0, 4, 8):
+        ref = oracle.maxsim_scores(Ev, off, Qb[i], np.float64)
+        assert_topk_close(bs[i], bc[i], ref, k, 2e-6 * float(np.abs(ref).max()))
+    # fp16 queries over fp16 rows: the pass IS the score
+    bs16, bc16 = idx.maxsim_topk_batch(Qb.astype(np.float16), k)
+    assert idx.filter_stats()["kind"] == "maxsim_batch_f16_exact"
+    ref = oracle.maxsim_scores(Ev, off, Qb[2].astype(np.float16).astype(np.float32), np.float64)
+    assert_topk_close(bs16[2], bc16[2], ref, k, 2e-6 * float(np.abs(ref).max()))
+    # one query; every chunk's score; the rerank of a candidate list
+    s1, c1 = idx.maxsim_topk(Qb[0], k)
+    assert np.array_equal(c1, bc[0])
+    all_scores = idx.maxsim_scores(Qb[1])
+    ref = oracle.maxsim_scores(Ev, off, Qb[1], np.float64)
+    np.testing.assert_allclose(all_scores, ref, rtol=0, atol=2e-6 * float(np.abs(ref).max()))
+    cand = rng.integers(0, len(off) - 1, (9, 60)).astype(np.int32)
+    cand[:, ::7] = -1
+    got = idx.maxsim_rerank(Qb, cand)
+    for i in (0, 8):
+        ref = oracle.maxsim_scores(Ev, off, Qb[i], np.float64)[np.maximum(cand[i], 0)]
+        ok = cand[i] >= 0
+        assert np.isneginf(got[i][~ok]).all()
+        np.testing.assert_allclose(got[i][ok], ref[ok], rtol=0, atol=2e-6 * float(np.abs(ref).max()))
+    idx.close()
+    # a small wide fp16 index (no image): the exact kernel over every chunk, with empty chunks
+    n2 = 3_000
+    off2 = ragged_offsets(rng, n2, 1, 15, empty_every=9)
+    Es = oracle.synth_matrix(29_800, n2, dim, "small_int")
+    Qs = oracle.synth_matrix(29_801, 17, dim, "small_int")
+    small = raglite_amd.DeviceIndex(Es.astype(np.float16), off2, metric="dot", storage="f16")
+    s, c = small.maxsim_topk(Qs, 20)
+    ws, wc = oracle.maxsim_topk(Es, off2, Qs, 20, np.float32)
+    assert np.array_equal(c, wc) and np.array_equal(s, ws)
+    small.close()
