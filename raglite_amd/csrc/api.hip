@@ -2286,9 +2286,9 @@ int hi_batch_rescore(rl_index* idx, const float* d_q, int32_t nq, int32_t n_quer
         RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ti, k, n_gemm, hb.es_top, s, rows16, 0, 0, packed));
         if (m_from_qsum)  // (also fills the lists' tails with -1)
             RL_TRY(launch_exact_threshold(hb.es_top, hb.ti, n_gemm, k, hb.m, hb.cap, hb.thr, hb.cnt, hb.ci, hb.es, hb.flag, s, hb.qsum, hb.m_abs,
-                                          idx->max_row_norm + idx->max_lo_norm, hb.one_product));
+                                          idx->max_row_norm + idx->max_lo_norm, hb.one_product, hb.ts));
         else
-            RL_TRY(launch_exact_threshold(hb.es_top, hb.ti, n_gemm, k, hb.m, hb.cap, hb.thr, hb.cnt, hb.ci, hb.es, hb.flag, s));
+            RL_TRY(launch_exact_threshold(hb.es_top, hb.ti, n_gemm, k, hb.m, hb.cap, hb.thr, hb.cnt, hb.ci, hb.es, hb.flag, s, nullptr, 0.f, 0.f, false, hb.ts));
         RL_TRY(launch_collect_above(sc, n_gemm, idx->n_chunks, ld, hb.thr, nullptr, hb.cap, hb.ci, nullptr, hb.cnt, hb.flag, s, hb.ts, hb.ti, k));
         if (hb.cap > k)
             RL_TRY(launch_maxsim_pairs(rows, idx->dim, d_q, nq, (int64_t)q_elems, idx->offsets, hb.ci, hb.cap - k, n_gemm, hb.es, s, rows16, hb.cap, k, packed));

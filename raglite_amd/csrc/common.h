@@ -258,7 +258,7 @@ int launch_f16_exact_finish(const float* Q, int32_t nq, int32_t dim, int64_t q_s
                             hipStream_t s);
 int launch_exact_threshold(const float* exact, const int32_t* top_i, int32_t n_queries, int32_t k, float* m, int32_t cap, float* thr,
                            uint32_t* cnt, int32_t* ids, float* es, uint32_t* flag, hipStream_t s, const float* qsum = nullptr, float m_abs = 0.f,
-                           float e_norm_max = 0.f, bool with_lo = false);
+                           float e_norm_max = 0.f, bool with_lo = false, const float* top_s = nullptr);  // top_s: the approximate top-k scores (-inf: masked)
 // MaxSim flavour of the threshold: thr[b] = topk[b * k + k - 1] - 2 * m_rel * e_max * sum_i |q_i|; zeroes cnt[b]; sets *flag when
 // the k-th score is unusable.  One block per query.
 // q_unscale != nullptr (one-product pass: only the queries' fp16 hi halves were multiplied): q_unscale[2 * b] = 2^(ex - 14) of

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void exact_threshold_kernel(const float* __res
                                                                float* __restrict__ m, int32_t cap, float* __restrict__ thr,
                                                                uint32_t* __restrict__ cnt, int32_t* __restrict__ ids, float* __restrict__ es,
                                                                uint32_t* __restrict__ flag, const float* __restrict__ qsum, float m_abs,
-                                                               float e_norm_max, int with_lo) {
+                                                               float e_norm_max, int with_lo, const float* __restrict__ top_s) {
     __shared__ float part[4];
     __shared__ int bad_sh;
     const int b = blockIdx.x;
@@ -441,6 +441,9 @@ __global__ __launch_bounds__(256) void exact_threshold_kernel(const float* __res
         const float v = exact[(int64_t)b * k + j];
         const int32_t c = top_i[(int64_t)b * k + j];
         bad |= c < 0 || !(v > -INFINITY);
+        // (a member of the approximate top-k whose approximate score is -inf is a MASKED chunk -- a tombstone, a metadata filter: fewer than k
+        // chunks are eligible, its exact score must not count; the guarded pass, which masks its scores, answers)
+        if (top_s) bad |= !(top_s[(int64_t)b * k + j] > -INFINITY);
         mn = fminf(mn, v);
         ids[(int64_t)b * cap + j] = c;
         es[(int64_t)b * cap + j] = v;
@@ -835,10 +838,10 @@ int launch_maxsim_threshold(const float* topk, int32_t n_queries, int32_t k, con
 
 int launch_exact_threshold(const float* exact, const int32_t* top_i, int32_t n_queries, int32_t k, float* m, int32_t cap, float* thr,
                            uint32_t* cnt, int32_t* ids, float* es, uint32_t* flag, hipStream_t s, const float* qsum, float m_abs, float e_norm_max,
-                           bool with_lo) {
+                           bool with_lo, const float* top_s) {
     if (n_queries <= 0) return RL_OK;
     hipLaunchKernelGGL(exact_threshold_kernel, dim3(n_queries), dim3(256), 0, s, exact, top_i, k, m, cap, thr, cnt, ids, es, flag, qsum, m_abs,
-                       e_norm_max, with_lo ? 1 : 0);
+                       e_norm_max, with_lo ? 1 : 0, top_s);
     RL_HIP(hipGetLastError());
     return RL_OK;
 }

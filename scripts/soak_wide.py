@@ -74,6 +74,9 @@ def maxsim64(E, off, Q):
 def check_topk(s, c, ref, k, tol, what):
     s, c = s.double(), c.long()
     kk = min(k, int((ref > float("-inf")).sum()))
+    assert (c[kk:] == -1).all() and torch.isinf(s[kk:]).all(), what  # slots that cannot be filled: (-inf, -1)
+    if kk == 0:
+        return
     assert (c[:kk] >= 0).all(), what
     got = ref[c[:kk]]
     assert (s[:kk] - got).abs().max() <= tol, (what, float((s[:kk] - got).abs().max()), tol)
@@ -114,14 +117,30 @@ def maxsim_case(rng, stats):
     d = int(rng.choice(DIMS))
     n = int((64 << 20) // d + rng.integers(1000, 30_000))
     integer = bool(rng.integers(0, 3) == 0)
+    f16 = bool(rng.integers(0, 3) == 0)  # fp16-STORED (the reference's storage precision)
     off = offsets(rng, n, int(rng.integers(0, 3)))  # (no empty chunks: the pass finds a chunk by counting chunk ends)
     nq, nqr, k = int(rng.integers(1, 33)), int(rng.choice([1, 2, 3, 8, 9, 17, 20])), int(rng.choice([1, 10, 100, 300]))
     E = fill((n, d), int(rng.integers(1, 1 << 30)), integer)
+    if f16:
+        E = E.half().float()
     Q = fill((nqr, nq, d), int(rng.integers(1, 1 << 30)), integer)
-    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot", storage="f16" if f16 else "f32")
     s, c = idx.maxsim_topk_batch(Q, k)
     st = idx.filter_stats()
-    stats["maxsim_" + st["kind"] + ("_fallback" if st.get("fallback") else "")] += 1
+    stats["maxsim_" + ("f16_" if f16 else "") + st["kind"] + ("_fallback" if st.get("fallback") else "")] += 1
+    if bool(rng.integers(0, 3) == 0):  # one query under a metadata filter (+ tombstones)
+        ok = rng.random(len(off) - 1) < float(rng.choice([0.5, 0.05, 0.0005]))
+        dead = rng.choice(len(off) - 1, 5, replace=False)
+        idx.delete_chunks(dead)
+        sf, cf = idx.maxsim_topk(Q[0], k, chunk_filter=torch.as_tensor(ok, device="cuda"))
+        ref = maxsim64(E, off, Q[0])
+        live = torch.as_tensor(ok, device="cuda").clone()
+        live[torch.as_tensor(dead, device="cuda")] = False
+        ref[~live] = float("-inf")
+        check_topk(sf, cf, ref, k, 1e-9 if integer else TOL * scale(E, Q[0]), ("maxsim filtered", d, n, nq, k, f16))
+        stats["maxsim_filtered"] += 1
+        idx.close()
+        return
     for b in sorted({0, nqr - 1}):
         ref = maxsim64(E, off, Q[b])
         tol = 1e-9 if integer else TOL * scale(E, Q[b])
@@ -139,25 +158,36 @@ def maxsim_case(rng, stats):
 def rows_case(rng, stats):
     d = int(rng.choice(DIMS))
     n = int(max(66_000, (64 << 20) // d) + rng.integers(0, 40_000))
-    metric = str(rng.choice(["cosine", "dot"]))
-    B = int(rng.choice([1, 2, 3, 4, 96, 200]))
+    metric = str(rng.choice(["cosine", "dot", "l2"]))
+    B = int(rng.choice([1, 2, 3, 4, 5, 16, 96, 200]))
     k = int(rng.choice([1, 10, 100, 512]))
+    f16 = bool(rng.integers(0, 3) == 0)
     E = fill((n, d), int(rng.integers(1, 1 << 30)), False)
     Q = fill((B, d), int(rng.integers(1, 1 << 30)), False)
     dup = bool(rng.integers(0, 5) == 0) and B <= 4
     if dup:
         rows = torch.as_tensor(rng.choice(n, 5000, replace=False), device="cuda")
-        E[rows] = Q[0][None, :] * 0.9 + 1e-4 * torch.randn((5000, d), device="cuda")
-    idx = raglite_amd.DeviceIndex(E, metric=metric)
-    s, r = idx.search_rows(Q, k)
+        E[rows] = Q[0][None, :] * (1.0 if metric == "l2" else 0.9) + 1e-4 * torch.randn((5000, d), device="cuda")
+    if f16:
+        E = E.half().float()
+    idx = raglite_amd.DeviceIndex(E, metric=metric, storage="f16" if f16 else "f32")
+    masked = bool(rng.integers(0, 4) == 0)
+    ok = torch.as_tensor(rng.random(n) < 0.4, device="cuda") if masked else None
+    s, r = idx.search_rows(Q, k, chunk_filter=ok) if masked else idx.search_rows(Q, k)
     st = idx.filter_stats()
-    stats["rows_" + st["kind"] + ("_fallback" if st.get("fallback") else "")] += 1
+    stats["rows_" + metric + ("_f16_" if f16 else "_") + st["kind"] + ("_fallback" if st.get("fallback") else "")] += 1
     En = E.double().norm(dim=1)
     for b in sorted({0, B - 1}):
-        dots = E.double() @ Q[b].double()
-        ref = dots / (En * Q[b].double().norm()) if metric == "cosine" else 1.0 + dots
-        tol = TOL * (1.0 if metric == "cosine" else max(1.0, float(En.max() * Q[b].double().norm())))
-        check_topk(s[b], r[b], ref, k, tol, ("rows", metric, d, n, B, k, dup))
+        if metric == "l2":
+            ref = 1.0 - (E.double() - Q[b].double()[None, :]).norm(dim=1)
+            tol = TOL * max(1.0, float(En.max() + Q[b].double().norm()))
+        else:
+            dots = E.double() @ Q[b].double()
+            ref = dots / (En * Q[b].double().norm()) if metric == "cosine" else 1.0 + dots
+            tol = TOL * (1.0 if metric == "cosine" else max(1.0, float(En.max() * Q[b].double().norm())))
+        if masked:
+            ref = torch.where(ok, ref, torch.tensor(float("-inf"), dtype=torch.float64, device="cuda"))
+        check_topk(s[b], r[b], ref, k, tol, ("rows", metric, d, n, B, k, dup, f16, masked))
     idx.close()
 
 

@@ -497,3 +497,28 @@ def test_streaming_fallback_of_a_big_batch_runs_on_a_narrower_grid_with_the_same
         order = np.lexsort((np.arange(len(ref)), -ref))[:100]
         assert np.array_equal(bc[i], order) and np.array_equal(bs[i].astype(np.float64), ref[order])
     idx.close()
+
+
+def test_fewer_live_chunks_than_k_never_returns_a_masked_chunk():
+    """Tombstones (or a metadata filter) that leave fewer than k eligible chunks: the approximate top-k then holds MASKED chunks at -inf, whose
+    exact scores are perfectly finite -- the second threshold must not count them (round 6, found by scripts/soak_wide.py: they came back as
+    results); the guarded full-precision pass, which masks its scores, answers, padded with (-inf, -1)."""
+    rng = np.random.default_rng(19)
+    off = ragged_offsets(rng, N, 1, 15)
+    n_chunks = len(off) - 1
+    E = oracle.synth_matrix(10_900, N, DIM)
+    Qb = np.stack([oracle.synth_matrix(10_950 + i, 32, DIM) for i in range(8)])
+    idx = raglite_amd.DeviceIndex(E, off, metric="dot")
+    keep = rng.choice(n_chunks, 37, replace=False)
+    dead = np.setdiff1d(np.arange(n_chunks), keep)
+    idx.delete_chunks(dead)
+    s, c = idx.maxsim_topk_batch(Qb, 100)
+    assert idx.filter_stats()["fallback"]
+    for i in (0, 7):
+        ref = oracle.maxsim_scores(E, off, Qb[i], np.float64)
+        assert np.isin(c[i][:37], keep).all() and len(set(c[i][:37].tolist())) == 37 and (c[i][37:] == -1).all() and np.isneginf(s[i][37:]).all()
+        np.testing.assert_allclose(s[i][:37], ref[c[i][:37]], rtol=0, atol=2e-6 * float(np.abs(ref[keep]).max()))
+        assert np.all(np.diff(s[i][:37]) <= 0)
+    s1, c1 = idx.maxsim_topk(Qb[0], 100)
+    assert np.isin(c1[:37], keep).all() and (c1[37:] == -1).all()
+    idx.close()

@@ -219,6 +219,12 @@ def test_one_maxsim_query_over_a_wide_index_goes_through_the_pass(dim, n):
     ref[~ok] = -np.inf
     ref[dead] = -np.inf
     assert_topk_close(s4, c4, ref, 50, 2e-6 * float(np.abs(ref[np.isfinite(ref)]).max()))
+    tiny = np.zeros(len(off) - 1, bool)  # fewer eligible chunks than k: never a masked chunk in the result (the guarded pass answers, padded)
+    tiny[rng.choice(len(off) - 1, 9, replace=False)] = True
+    tiny[dead] = False
+    s5, c5 = idx.maxsim_topk(Qb[0], 50, chunk_filter=tiny)
+    kk = int(tiny.sum())
+    assert tiny[c5[:kk]].all() and (c5[kk:] == -1).all() and np.isneginf(s5[kk:]).all() and idx.filter_stats()["fallback"]
     idx.close()
 
 
