@@ -406,7 +406,8 @@ size_t score_gemm_scratch_floats(int32_t nb, int32_t dim, bool split);
 int launch_maxsim_stream16(const uint16_t* D, int64_t n_rows, int32_t dim, const float* Q, int32_t nq,
                            const int32_t* row_to_chunk, const int64_t* chunk_offsets, int64_t n_chunks, int mode,
                            float* out, int64_t ld, int n_cu, hipStream_t s);
-// exact MaxSim of (query, candidate chunk) pairs, all queries in one launch: dim % 16 == 0, dim <= 1024, nq <= 32, fp32 MFMA
+// exact MaxSim of (query, candidate chunk) pairs, all queries in one launch: dim % 16 == 0 up to 1024, dim % 128 == 0 up to 4096 (wave-private query
+// windows, maxsim_pairs_wide_kernel), nq <= 32, fp32 MFMA
 int launch_maxsim_pairs(const float* D, int32_t dim, const float* Q, int32_t nq, int64_t q_stride, const int64_t* chunk_offsets,
                         const int32_t* candidates, int64_t n_items_per_query, int32_t n_queries, float* out, hipStream_t s,
                         bool rows16 = false,  // rows16: D points at fp16 rows (an fp16-stored corpus)

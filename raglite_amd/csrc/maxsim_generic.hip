@@ -2,6 +2,8 @@
 //
 //   maxsim_generic_kernel : any dim <= 4096, any nq <= 1024; one wave per (query, chunk) item; VALU dots
 //                           with a wave butterfly per (row, query vector).  Correctness backstop.
+//   maxsim_pairs_kernel, maxsim_pairs_packed_kernel, maxsim_pairs_wide_kernel : exact fp32-MFMA MaxSim of arbitrary (query, chunk) pairs --
+//                           the re-scoring step of the bound-filtered batch and the rerank beyond dim 128 (dim % 16 up to 1024; % 128 up to 4096).
 //   maxsim_cand_kernel    : the rerank shape (SURVEY.md cfg 3): dim == 128, nq <= 32, many independent
 //                           queries x candidate lists per launch.  v_mfma_f32_16x16x4_f32 with the query's
 //                           32 x 128 matrix resident in 64 VGPRs as B fragments; candidate rows are loaded
