@@ -375,3 +375,22 @@ def test_f16_stored_wide_index_maxsim(dim, n):
     ws, wc = oracle.maxsim_topk(Es, off2, Qs, 20, np.float32)
     assert np.array_equal(c, wc) and np.array_equal(s, ws)
     small.close()
+
+
+@pytest.mark.parametrize("storage", ["f32", "f16"])
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+def test_small_wide_index_every_batch_size(metric, storage):
+    """A wide index too small for any image (3 000 x 1536): 1 .. 130 queries through whatever route takes them (the scans, the dense GEMM from
+    five queries up) -- the oracle's rows, scores within tolerance; integer data exactly."""
+    n, dim, k = 3_000, 1536, 20
+    E = oracle.synth_matrix(31_000, n, dim, "small_int")
+    idx = raglite_amd.DeviceIndex(E.astype(np.float16) if storage == "f16" else E, metric=metric, storage=storage)
+    from tests.util import sim_fp32_exact
+    for B in (1, 4, 5, 16, 50, 130):
+        Q = oracle.synth_matrix(31_100 + B, B, dim, "small_int")
+        S, R = idx.search_rows(Q, k)
+        for b in (0, B - 1):
+            es, ei = oracle.topk_desc(sim_fp32_exact(E, Q[b], metric), k)
+            assert np.array_equal(R[b], ei), (B, b)
+            assert np.array_equal(S[b].view(np.uint32), es.astype(np.float32).view(np.uint32)), (B, b)
+    idx.close()
