@@ -1622,10 +1622,13 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     if (!hi_valid(idx) || nb > 16 || k > 512 || (mode != SCAN_COSINE && mode != SCAN_DOT && mode != SCAN_L2) || n < 65536) return RL_ERR_UNSUPPORTED;
     // l2 (round 6): 1 - |e - q|.  The approximate similarity comes from |e|^2 + |q|^2 - 2 e_hi.q, its bound lives on the SQUARED distance
     // (hi_filter.hip: l2_delta / lower_threshold), the candidates and the guarded full pass are scored by the scan that sums (e - q)^2 directly --
-    // the full-precision route's own kernel for up to four queries, so the same bits; candidates from the pivot route (k <= 128) or, with a
-    // row mask, from the ranked flow.  Needs the measured norms (an index whose HI plane was built with them) and |e|^2 per row.
+    // the full-precision route's own kernel for up to four queries, so the same bits; candidates from the pivot route, or -- under a row mask --
+    // the collecting flow behind a pivot selection.  Needs the measured norms (an index whose HI plane was built with them) and |e|^2 per row.
     const bool l2 = mode == SCAN_L2;
-    if (l2 && (nb > 4 || !idx->sumsq || (!d_row_bits && (!idx->opt.on(RL_OPT_HI_PIVOT) || !pivot_route_takes(n, k))))) return RL_ERR_UNSUPPORTED;
+    // (l2 similarities of a big corpus share their exponent and leading mantissa bits: the radix selection's threshold bin holds the whole corpus
+    // and the ranked flow's candidate lists overflow -- measured: every query fell back -- so l2 takes this route only where the pivot does the
+    // selecting: k <= 128 and >= 3 k group maxima; beyond, the full-precision route, whose own selection is the pivot's for l2)
+    if (l2 && (nb > 4 || !idx->sumsq || !idx->opt.on(RL_OPT_HI_PIVOT) || !pivot_route_takes(n, k))) return RL_ERR_UNSUPPORTED;
     // WIDE index (dim > 1024, round 6): the stream kernels stop at 1024 (a wave keeps its slice of the queries in registers) -- the approximate
     // pass is the packed VALU scan over the HI plane (scan16.hip: up to four queries per pass; the fp32 scan of such an index takes ONE), the
     // candidates and the guarded full pass go through the fp32 scan.  Up to four queries: beyond, the passes over the plane cost what the
@@ -1674,7 +1677,10 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     if (d_row_bits) {  // tombstones / metadata filter: masked rows rank -inf, so they reach neither the top-k nor the candidates
         RL_TRY(launch_transform(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, s, 1.0f / idx->hi_scale));
         RL_TRY(launch_mask_scores(sc, nb, n, ld, d_row_bits, s));
-        RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s));
+        int st_sel = RL_ERR_UNSUPPORTED;
+        if (l2) st_sel = launch_topk_pivot(sc, nb, n, ld, k, idx->ws, ts, ti, s);  // (crowded scores: see above)
+        if (st_sel != RL_OK && st_sel != RL_ERR_UNSUPPORTED) return st_sel;
+        if (st_sel == RL_ERR_UNSUPPORTED) RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s));
         RL_TRY(launch_approx_threshold(ts, nb, k, d_q, dim, mode, m_rel, e_bound, thr, cnt, flag, s, idx->max_row_norm));
         RL_TRY(launch_collect_above(sc, nb, n, ld, thr, mode == SCAN_COSINE ? idx->norm : nullptr, cap, ci, gn, cnt, flag, s));
     } else {
@@ -1692,12 +1698,11 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
             st_pv = launch_pivot_route(sc, nb, n, ld, k, idx->norm, idx->sumsq, d_q, dim, mode, 1.0f / idx->hi_scale, bmax, cnt, 32, bound, thr, cap, ci, gn,
                                        cnt, flag, s, idx->E, G, &gathered);
         if (st_pv != RL_OK && st_pv != RL_ERR_UNSUPPORTED) return st_pv;
-        if (st_pv == RL_ERR_UNSUPPORTED && l2) return RL_ERR_UNSUPPORTED;  // (too few group maxima for the pivot: the full-precision route)
         if (st_pv == RL_ERR_UNSUPPORTED) {
             RL_TRY(launch_transform_hist(sc, nb, n, ld, idx->norm, idx->sumsq, d_q, dim, mode, idx->ws, s, 1.0f / idx->hi_scale, nullptr, cnt, 32, &bound));
             HiEmit emit;
             emit.m = mb; emit.cap = cap; emit.ids = ci; emit.norms = gn; emit.row_norm = mode == SCAN_COSINE ? idx->norm : nullptr;
-            emit.cnt = cnt; emit.flag = flag; emit.thr = thr;
+            emit.cnt = cnt; emit.flag = flag; emit.thr = thr; emit.l2 = l2 ? 1 : 0;
             RL_TRY(launch_topk(sc, nb, n, ld, k, idx->ws, ts, ti, s, nullptr, true, &emit));
         }
     }

@@ -168,6 +168,7 @@ struct HiEmit {
     uint32_t* cnt = nullptr;          // [n_queries], zero on entry
     uint32_t* flag = nullptr;         // set on overflow / unusable threshold
     float* thr = nullptr;             // [n_queries] (optional) the thresholds, for diagnostics
+    int l2 = 0;                       // the scores are l2 similarities 1 - sqrt(D), m the bound of D: lower_threshold's other form
 };
 int launch_topk(const float* scores, int32_t n_queries, int64_t n, int64_t ld, int32_t k,
                 SelectWorkspace& ws, float* out_scores, int32_t* out_ids, hipStream_t s, const uint32_t* run_if = nullptr,
@@ -181,6 +182,18 @@ int launch_guarded_select(float* scores, int32_t nb, int64_t n, int64_t ld, int3
 // pre_scale: the raw dots are multiplied by it first (a power of two: exact; 1 = the plain transform); run_if as in launch_topk.
 // zero_words / n_zero (<= 256): words this launch also sets to zero (the candidate counters + flag of a B <= 16 row search: no memset launch).
 // bound: m_out[b] = the half-bytes search's error bound of query b -- cosine: m_rel; dot: m_rel * e_norm_bound * |q_b| + 2^-22
+// The half-bytes search's candidate threshold (hi_filter.hip has the derivation of the l2 form in front of approx_threshold_kernel)
+__device__ __forceinline__ float l2_delta(float a, float eps, float e_max, float qn) {
+    const float t = e_max + qn;
+    return (2.0f * a * qn + 2.0f * eps * t * t) * 1.0001f;
+}
+// the candidate threshold under a lower bound P of the k-th best approximate similarity; m: the query's bound (l2: delta, in squared distance)
+__device__ __forceinline__ float lower_threshold(float P, float m, bool l2) {
+    if (!l2) return P - 2.0f * m;
+    const float r = fmaxf(1.0f - P, 0.f);
+    return 1.0f - sqrtf(fmaf(r, r, 2.0f * m)) * (1.0f + 0x1p-18f) - 0x1p-20f;
+}
+
 struct HiBound {
     float* m_out = nullptr;
     float m_rel = 0.f, e_norm_bound = 0.f;

@@ -18,16 +18,7 @@ namespace {
 // D <= D_k <= D~_k + delta (the k rows of the approximate top-k bound the exact k-th from above), so D~ <= D~_k + 2 delta: in similarities,
 // with ANY lower bound P of the k-th best approximate one, s~ >= 1 - sqrt((1 - P)^2 + 2 delta) -- the slack factors cover the roundings of
 // sqrt and 1 - x on both sides.
-__device__ __forceinline__ float l2_delta(float a, float eps, float e_max, float qn) {
-    const float t = e_max + qn;
-    return (2.0f * a * qn + 2.0f * eps * t * t) * 1.0001f;
-}
-// the candidate threshold under a lower bound P of the k-th best approximate similarity; m: the query's bound (l2: delta, in squared distance)
-__device__ __forceinline__ float lower_threshold(float P, float m, bool l2) {
-    if (!l2) return P - 2.0f * m;
-    const float r = fmaxf(1.0f - P, 0.f);
-    return 1.0f - sqrtf(fmaf(r, r, 2.0f * m)) * (1.0f + 0x1p-18f) - 0x1p-20f;
-}
+// (l2_delta / lower_threshold: common.h -- the ranked flow of select.hip uses them too)
 
 // One block per query.  topk[b * k + j] = the k best APPROXIMATE similarities, descending.  With |approx - exact| <= m for every
 // row, a row can be in the exact top-k only if its approximate score is >= (k-th best approximate) - 2 m =: thr[b]:

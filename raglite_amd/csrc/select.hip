@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void transform_hist_kernel(float* __restrict__
     // the error bound of the half-bytes search for this query (the statements of approx_threshold_kernel: same bits), for the filter and
     // the final kernel of the selection that follows
     if (hb.m_out && blockIdx.x == 0 && threadIdx.x == 0)
-        hb.m_out[b] = mode == SCAN_COSINE ? hb.m_rel : hb.m_rel * hb.e_norm_bound * qn + 0x1p-22f;
+        hb.m_out[b] = mode == SCAN_COSINE ? hb.m_rel : mode == SCAN_L2 ? l2_delta(hb.e_norm_bound, hb.m_rel, hb.e_max, qn) : hb.m_rel * hb.e_norm_bound * qn + 0x1p-22f;
     auto one = [&](int64_t i) {  // scalar tail / unaligned layout
         const float o = transform_score(sb[i] * pre_scale, mode, mode == SCAN_COSINE ? row_norm[i] : 1.f, mode == SCAN_L2 ? row_sumsq[i] : 0.f, qn, qss);
         hist_add(h, o);
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void topk_filter_kernel(const float* __restric
                                                            int32_t k, uint32_t* __restrict__ ws_hist,
                                                            uint64_t* __restrict__ ws_sel,
                                                            uint64_t* __restrict__ ws_cand, const uint32_t* __restrict__ run_if,
-                                                           const float* __restrict__ below_m) {
+                                                           const float* __restrict__ below_m, int below_l2) {
     __shared__ uint32_t h[HIST_BINS];
     __shared__ uint32_t scratch[8];
     __shared__ uint32_t thr[2];
@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void topk_filter_kernel(const float* __restric
     // below_m != nullptr (the half-bytes row search, api.hip: search_rows_hi): scores less than 2 m below the threshold bin's lower edge
     // are candidates too -- the final kernel then finds every score within 2 m of the k-th best among sel + cand (the k-th best lies IN the
     // bin), and no separate pass over the scores has to collect them.  They rank below the whole bin: the selection itself is unchanged.
-    const float low = below_m ? key_score(bstar << 21) - 2.0002f * below_m[q] : INFINITY;
+    const float low = below_m ? lower_threshold(key_score(bstar << 21), 1.0001f * below_m[q], below_l2 != 0) : INFINITY;  // (the bin's edge bounds the k-th best from below)
     auto visit = [&](float v, int64_t i) {
         const uint32_t bin = score_key(v) >> 21;
         if (bin > bstar) {
@@ -411,7 +411,7 @@ __device__ __forceinline__ void topk_final_body(const float* __restrict__ scores
     };
     if (emit && threadIdx.x == 0) sh_cnt[0] = 0u;  // (ordered before the first emit_key by the barriers below)
     auto emit_threshold = [&](uint64_t kth_key) -> float {  // (every thread computes the same value)
-        const float t = key_score((uint32_t)(kth_key >> 32)) - 2.0f * em.m[q];
+        const float t = lower_threshold(key_score((uint32_t)(kth_key >> 32)), em.m[q], em.l2 != 0);
         if (threadIdx.x == 0) {
             if (em.thr) em.thr[q] = t;
             if (!(t > -INFINITY) || kk < (uint32_t)k) atomicOr(em.flag, 1u);  // NaN / -inf, or fewer than k rows
@@ -965,7 +965,7 @@ int launch_topk(const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t 
     if (n > 0) {
         const int bx = hist_grid(n, nq);
         if (!have_hist) hipLaunchKernelGGL(topk_hist_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, ws.hist, run_if);
-        hipLaunchKernelGGL(topk_filter_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, k, ws.hist, ws.sel, ws.cand, run_if, em.m);
+        hipLaunchKernelGGL(topk_filter_kernel, dim3(bx, nq), dim3(256), 0, s, scores, n, ld, k, ws.hist, ws.sel, ws.cand, run_if, em.m, em.l2);
     }
     hipLaunchKernelGGL(topk_final_kernel, dim3(nq), dim3(1024), 0, s, scores, n, ld, k, ws.hist, ws.sel, ws.cand, out_scores, out_ids, run_if, em);
     RL_HIP(hipGetLastError());
