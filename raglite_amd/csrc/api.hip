@@ -1627,8 +1627,8 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     const bool l2 = mode == SCAN_L2;
     // (l2 similarities of a big corpus share their exponent and leading mantissa bits: the radix selection's threshold bin holds the whole corpus
     // and the ranked flow's candidate lists overflow -- measured: every query fell back -- so l2 takes this route only where the pivot does the
-    // selecting: k <= 128 and >= 3 k group maxima; beyond, the full-precision route, whose own selection is the pivot's for l2)
-    if (l2 && (nb > 4 || !idx->sumsq || !idx->opt.on(RL_OPT_HI_PIVOT) || !pivot_route_takes(n, k))) return RL_ERR_UNSUPPORTED;
+    // selecting: k <= 512 (128 under a row mask) and >= 3 k group maxima; beyond, the full-precision route, whose own selection is the pivot's for l2)
+    if (l2 && (nb > 4 || !idx->sumsq || !idx->opt.on(RL_OPT_HI_PIVOT) || !pivot_route_takes(n, k) || (d_row_bits && k > 128))) return RL_ERR_UNSUPPORTED;
     // WIDE index (dim > 1024, round 6): the stream kernels stop at 1024 (a wave keeps its slice of the queries in registers) -- the approximate
     // pass is the packed VALU scan over the HI plane (scan16.hip: up to four queries per pass; the fp32 scan of such an index takes ONE), the
     // candidates and the guarded full pass go through the fp32 scan.  Up to four queries: beyond, the passes over the plane cost what the
@@ -1652,7 +1652,7 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     float* G = gn + nc;                                        // [nb * cap x dim]
     float* xs = G + (size_t)nc * dim;                          // [nb x nb * cap]
     float* es = xs + (size_t)nb * ldx;                         // [nb x cap]
-    uint64_t* bmax = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(es + nc) + 7) & ~uintptr_t(7));  // [nb x 512] workgroup maxima (pivot route)
+    uint64_t* bmax = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(es + nc) + 7) & ~uintptr_t(7));  // [nb x 2048] group maxima (pivot route)
     float* sc = idx->scores.as<float>();
     // ---- (1) approximate pass over the HI plane ---------------------------------------------------------------------------------------------
     int st = wide ? launch_scan_rows16(idx->hiplane.as<uint16_t>(), n, dim, d_q, nb, nullptr, SCAN_RAW_DOT, sc, ld, s)
@@ -1692,7 +1692,7 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
         bound.m_out = mb; bound.m_rel = m_rel; bound.e_norm_bound = e_bound; bound.e_max = idx->max_row_norm;
         // Round 6 (option hi_pivot): no approximate RANKING at all -- the candidates are re-scored and ranked exactly anyway, so any lower bound
         // of the k-th best approximate similarity will do for the threshold: the k-th largest of ~500 workgroup maxima (hi_filter.hip:
-        // transform_bmax_kernel / pivot_collect_kernel), two launches instead of the selection's three (k <= 128, >= 3 k maxima)
+        // transform_bmax_kernel / pivot_collect_kernel), two launches instead of the selection's three (k <= 512, >= 3 k maxima)
         int st_pv = RL_ERR_UNSUPPORTED;
         if (idx->opt.on(RL_OPT_HI_PIVOT))
             st_pv = launch_pivot_route(sc, nb, n, ld, k, idx->norm, idx->sumsq, d_q, dim, mode, 1.0f / idx->hi_scale, bmax, cnt, 32, bound, thr, cap, ci, gn,
@@ -2225,7 +2225,7 @@ void hi_batch_layout(rl_index* idx, int32_t n, int32_t k, HiBatch& hb) {
     hb.es = reinterpret_cast<float*>(hb.ci + (size_t)n * hb.cap);          // [n x cap] their exact scores
     hb.m = hb.es + (size_t)n * hb.cap;                                     // [n]
     hb.es_top = hb.m + n;                                                  // [n x k]
-    hb.bmax = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(hb.es_top + (size_t)n * k) + 7) & ~uintptr_t(7));  // [min(n, 2) x 512] (few-queries pivot route)
+    hb.bmax = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(hb.es_top + (size_t)n * k) + 7) & ~uintptr_t(7));  // [min(n, 2) x 2048] (few-queries pivot route)
 }
 size_t hi_batch_words(int32_t n, int32_t k) {
     return (size_t)n * k * 3 + (size_t)n * 3 + 16 + (size_t)n * 2048 * 2 + 2 + 2 * pivot_scratch_words(std::min<int32_t>(n, 2));

@@ -298,6 +298,9 @@ __global__ __launch_bounds__(256) void transform_bmax_kernel(float* __restrict__
 // -- sets thr[b] = P - 2 m_b and collects its share of the rows that reach it: ids / norms / cnt / flag as collect_above_kernel leaves them, and
 // (E != nullptr) the rows themselves into G.  Fewer than k usable maxima (NaN / -inf everywhere): *flag, nothing collected -- the guarded
 // full-precision pass answers.
+// KV: group maxima per lane of the selecting wave -- 8 (G <= 512: k <= 170) or 32 (G <= 2048, a maximum per wave of 512-score groups: k <= 512, the
+// num_hits of the reference's own callers -- 160 to 256, `_search.py:66-67` -- included)
+template <int KV>
 __global__ __launch_bounds__(256) void pivot_collect_kernel(const float* __restrict__ scores, int64_t n, int64_t ld, const uint64_t* __restrict__ bmax,
                                                              int G, int32_t k, const float* __restrict__ m, float* __restrict__ thr,
                                                              const float* __restrict__ row_norm, int32_t cap, int32_t* __restrict__ ids,
@@ -309,15 +312,15 @@ __global__ __launch_bounds__(256) void pivot_collect_kernel(const float* __restr
     if (row_norm) row_norm += (int64_t)b * aux_ld;  // (aux_ld != 0: the "norms" are a per-query array -- the scores themselves, launch_topk_pivot)
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
-        uint32_t kv[8];
+        uint32_t kv[KV];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) kv[j] = lane + 64 * j < G ? (uint32_t)(bmax[(int64_t)b * G + lane + 64 * j] >> 32) : 0u;
+        for (int j = 0; j < KV; ++j) kv[j] = lane + 64 * j < G ? (uint32_t)(bmax[(int64_t)b * G + lane + 64 * j] >> 32) : 0u;
         uint32_t need = (uint32_t)k, prefix = 0u;
         for (int bit = 31; bit >= 0; --bit) {  // the keys that agree with `prefix` above `bit` are alive; how many of them have the bit set?
             const uint32_t want = (prefix >> bit) | 1u;
             uint32_t c = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) c += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((kv[j] >> bit) == want));
+            for (int j = 0; j < KV; ++j) c += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64((kv[j] >> bit) == want));
             if (c >= need) prefix |= 1u << bit;
             else need -= c;
         }
@@ -672,34 +675,46 @@ int launch_approx_threshold(const float* topk, int32_t nb, int32_t k, const floa
 }
 
 // The pivot route (see transform_bmax_kernel): candidates of a bound-filtered search without ranking the approximate scores.  bmax:
-// pivot_scratch_words(nb) 8-byte words.  RL_ERR_UNSUPPORTED where the route does not pay (fewer than 3 k group maxima, k > 128).
+// pivot_scratch_words(nb) 8-byte words.  RL_ERR_UNSUPPORTED where the route does not pay (fewer than 3 k group maxima, k > 512).
 // maxsim != nullptr: the scores are a MaxSim query's chunk scores (mode raw; `queries` = the queries' vectors, maxsim->q_stride floats apart):
 // bound m_b = m_abs * sum_i |q_i|, the lists pre-filled with -1 (maxsim_pairs_kernel walks every slot).
-size_t pivot_scratch_words(int32_t nb) { return (size_t)nb * 512; }
+constexpr int PIVOT_MAX_K = 512, PIVOT_MAX_G = 2048;
+size_t pivot_scratch_words(int32_t nb) { return (size_t)nb * PIVOT_MAX_G; }
+// The groups whose maxima the pivot is taken from: a maximum per workgroup of 2048 scores (up to 512 of them); a query with fewer scores than 3 k such
+// groups gets one per WAVE (up to 4 x 128); k > 170 one per wave of up to 512 workgroups (G <= 2048).  false: fewer than 3 k groups -- no pivot.
+static bool pivot_groups(int64_t n, int32_t k, int* bx_out, int* G_out, int* per_wave_out) {
+    if (n <= 0 || k < 1 || k > PIVOT_MAX_K) return false;
+    int bx = (int)std::min<int64_t>((n + 2047) / 2048, 512), G = bx, per_wave = 0;
+    if (G < 3 * k) {
+        bx = (int)std::min<int64_t>((n + 1023) / 1024, 128);
+        G = 4 * bx;
+        per_wave = 1;
+    }
+    if (G < 3 * k) {
+        bx = (int)std::min<int64_t>((n + 1023) / 1024, 512);
+        G = 4 * bx;
+    }
+    if (G < 3 * k) return false;
+    *bx_out = bx; *G_out = G; *per_wave_out = per_wave;
+    return true;
+}
 // does launch_pivot_route take n scores per query at this k?  (its own test, for callers that have no other way to find candidates)
 bool pivot_route_takes(int64_t n, int32_t k) {
-    if (n <= 0 || k < 1 || k > 128) return false;
-    if (std::min<int64_t>((n + 2047) / 2048, 512) >= 3 * (int64_t)k) return true;
-    return 4 * std::min<int64_t>((n + 1023) / 1024, 128) >= 3 * (int64_t)k;
+    int bx, G, pw;
+    return pivot_groups(n, k, &bx, &G, &pw);
 }
 int launch_pivot_route(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t k, const float* row_norm, const float* row_sumsq, const float* queries,
                        int32_t dim, int mode, float pre_scale, uint64_t* bmax, uint32_t* zero_words, int n_zero, const HiBound& bound, float* thr,
                        int32_t cap, int32_t* ids, float* norms, uint32_t* cnt, uint32_t* flag, hipStream_t s, const float* E, float* gather_out,
                        bool* gathered, const PivotMaxSim* maxsim, const float* aux_src, int64_t aux_ld) {
     if (gathered) *gathered = false;
-    if (n <= 0 || nb <= 0 || k < 1 || k > 128 || !bound.m_out) return RL_ERR_UNSUPPORTED;
+    if (n <= 0 || nb <= 0 || k < 1 || k > PIVOT_MAX_K || !bound.m_out) return RL_ERR_UNSUPPORTED;
     if (n_zero < 0 || n_zero > 256 || (n_zero > 0 && !zero_words)) return RL_ERR_INVALID;
     PivotMaxSim ms = maxsim ? *maxsim : PivotMaxSim{};
     if (maxsim && ms.nq > 0 && mode != SCAN_RAW_DOT) return RL_ERR_INVALID;
-    // groups: a maximum per workgroup of 2048 scores (up to 512 of them); a query with fewer scores than 3 k such groups gets one per WAVE
-    int bx = (int)std::min<int64_t>((n + 2047) / 2048, 512), G = bx;
-    ms.per_wave = 0;
-    if (G < 3 * k) {
-        bx = (int)std::min<int64_t>((n + 1023) / 1024, 128);
-        G = 4 * bx;
-        ms.per_wave = 1;
-        if (G < 3 * k) return RL_ERR_UNSUPPORTED;
-    }
+    int bx = 0, G = 0, per_wave = 0;
+    if (!pivot_groups(n, k, &bx, &G, &per_wave)) return RL_ERR_UNSUPPORTED;
+    ms.per_wave = per_wave;
     if (ms.fill_ids) ms.fill_n = (int64_t)nb * cap;
     hipLaunchKernelGGL(transform_bmax_kernel, dim3(bx, nb), dim3(256), 0, s, scores, n, ld, row_norm, row_sumsq, queries, (int)dim, mode, pre_scale, bmax,
                        zero_words, n_zero, bound, ms);
@@ -708,8 +723,12 @@ int launch_pivot_route(float* scores, int32_t nb, int64_t n, int64_t ld, int32_t
     const bool fuse = E && gather_out && gathered && (dim & 3) == 0 && ((reinterpret_cast<uintptr_t>(E) | reinterpret_cast<uintptr_t>(gather_out)) & 15) == 0;
     // (aux_src: what goes into `norms` next to every collected id -- the rows' norms for a cosine search, or any other per-row / per-query array)
     const float* aux = aux_src ? aux_src : (mode == SCAN_COSINE ? row_norm : nullptr);
-    hipLaunchKernelGGL(pivot_collect_kernel, dim3(cx, nb), dim3(256), 0, s, scores, n, ld, bmax, G, k, bound.m_out, thr, aux, cap, ids, norms, cnt, flag,
-                       fuse ? E : nullptr, (int)dim, fuse ? gather_out : nullptr, aux_src ? aux_ld : (int64_t)0, mode == SCAN_L2 ? 1 : 0);
+    if (G <= 512)
+        hipLaunchKernelGGL(pivot_collect_kernel<8>, dim3(cx, nb), dim3(256), 0, s, scores, n, ld, bmax, G, k, bound.m_out, thr, aux, cap, ids, norms, cnt, flag,
+                           fuse ? E : nullptr, (int)dim, fuse ? gather_out : nullptr, aux_src ? aux_ld : (int64_t)0, mode == SCAN_L2 ? 1 : 0);
+    else
+        hipLaunchKernelGGL(pivot_collect_kernel<32>, dim3(cx, nb), dim3(256), 0, s, scores, n, ld, bmax, G, k, bound.m_out, thr, aux, cap, ids, norms, cnt, flag,
+                           fuse ? E : nullptr, (int)dim, fuse ? gather_out : nullptr, aux_src ? aux_ld : (int64_t)0, mode == SCAN_L2 ? 1 : 0);
     if (fuse) *gathered = true;
     RL_HIP(hipGetLastError());
     return RL_OK;

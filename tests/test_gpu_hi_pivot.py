@@ -4,7 +4,7 @@
 ranking pass are no longer RANKED -- the candidates are re-scored and ranked exactly anyway -- their threshold comes from the k-th largest of
 the workgroup maxima, a lower bound of the k-th best.  Contract: the same rows and the same score bits as the route that ranks first
 (`hi_pivot = 0`) and as the full-precision pass (`hi_search = 0`); a candidate list that is a superset of the ranked route's; the guarded
-fallback where the bound is defeated.  The route applies for k <= 128 and n >= 3 k x 2048 rows."""
+fallback where the bound is defeated.  The route applies for k <= 512 and >= 3 k groups of scores (2048 per workgroup, 512 or 256 per wave)."""
 
 import numpy as np
 import pytest
@@ -22,7 +22,9 @@ def _same(a, b):
 
 @pytest.mark.parametrize("metric", ["cosine", "dot"])
 @pytest.mark.parametrize("n,dim,B,k", [(70_000, 1024, 1, 10), (140_001, 512, 4, 20), (700_000, 128, 2, 100), (300_003, 256, 16, 48),
-                                        (266_240, 256, 1, 1), (800_000, 128, 3, 128)])
+                                        (266_240, 256, 1, 1), (800_000, 128, 3, 128),
+                                        # k beyond 170: a maximum per WAVE of up to 512 workgroups (G <= 2048) -- the reference's own num_hits are 160 - 256
+                                        (400_000, 256, 1, 160), (1_000_000, 128, 2, 256), (600_000, 128, 1, 512), (300_000, 256, 3, 200)])
 def test_pivot_route_equals_the_ranked_route_and_the_full_pass(metric, n, dim, B, k):
     E = oracle.synth_matrix(9800 + dim, n, dim)
     Q = oracle.synth_matrix(9810 + B, B, dim)
@@ -90,7 +92,7 @@ def test_pivot_route_defeated_bound_falls_back(metric):
 
 
 def test_pivot_route_where_it_does_not_apply_and_after_append():
-    """k > 128 or too few workgroup maxima: the ranked route, silently; rows appended later are searched through the same route."""
+    """Too few group maxima (k = 200 over 70 000 rows): the ranked route, silently; rows appended later are searched through the same route."""
     n, dim = 100_000, 256
     E = oracle.synth_matrix(9840, n, dim)
     q = oracle.synth_matrix(9841, 1, dim)[0]

@@ -208,7 +208,7 @@ def test_one_launch_fallback_selection_on_massive_ties(metric):
 # dist = |e - q|, sim = 1 - dist).  The approximate similarity comes from |e|^2 + |q|^2 - 2 e_hi.q, the bound lives on the squared distance, and the
 # candidates are scored by the scan that sums (e - q)^2 directly -- the full-precision route's own kernel for up to four queries: the same bits.
 @pytest.mark.parametrize("n,dim,B,k", [(80_000, 1024, 1, 100), (140_000, 512, 2, 10), (100_000, 1024, 4, 128), (530_000, 128, 3, 100), (70_000, 1536, 1, 50),
-                                        (80_000, 3072, 2, 100)])
+                                        (80_000, 3072, 2, 100), (400_000, 256, 2, 256), (800_000, 128, 1, 512)])
 def test_l2_hi_search_equals_full_pass_bitwise(n, dim, B, k):  # (where the pivot route applies: k <= 128, >= 3 k group maxima of >= 1024 rows)
     E = oracle.synth_matrix(9500 + dim, n, dim)
     Q = oracle.synth_matrix(9600 + B, B, dim)
@@ -244,8 +244,8 @@ def test_l2_hi_search_integer_near_duplicates_filter_and_what_the_route_declines
     with idx.options(hi_search=0):
         S2, R2 = idx.search_rows(Q, k, chunk_filter=ok)
     assert np.array_equal(R1, R2) and _same(S1, S2)
-    # k > 128 (l2 similarities crowd into one bin of the radix selection: only the pivot selects them fast), more than four queries: the
-    # full-precision route (same results, the route says so)
+    # too few group maxima for the pivot at this k (l2 similarities crowd into one bin of the radix selection: only the pivot selects them
+    # fast), more than four queries: the full-precision route (same results, the route says so)
     S3, R3 = idx.search_rows(Q[0], 300)
     assert idx.filter_stats()["kind"] != "rows_hi"
     es, ei = oracle.topk_desc(sim_fp32_exact(E, Q[0], "l2"), 300)
