@@ -1627,8 +1627,8 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     const bool l2 = mode == SCAN_L2;
     // (l2 similarities of a big corpus share their exponent and leading mantissa bits: the radix selection's threshold bin holds the whole corpus
     // and the ranked flow's candidate lists overflow -- measured: every query fell back -- so l2 takes this route only where the pivot does the
-    // selecting: k <= 512 (128 under a row mask) and >= 3 k group maxima; beyond, the full-precision route, whose own selection is the pivot's for l2)
-    if (l2 && (nb > 4 || !idx->sumsq || !idx->opt.on(RL_OPT_HI_PIVOT) || !pivot_route_takes(n, k) || (d_row_bits && k > 128))) return RL_ERR_UNSUPPORTED;
+    // selecting: k <= 512 and >= 3 k group maxima; beyond, the full-precision route, whose own selection is the pivot's for l2)
+    if (l2 && (nb > 4 || !idx->sumsq || !idx->opt.on(RL_OPT_HI_PIVOT) || !pivot_route_takes(n, k))) return RL_ERR_UNSUPPORTED;
     // WIDE index (dim > 1024, round 6): the stream kernels stop at 1024 (a wave keeps its slice of the queries in registers) -- the approximate
     // pass is the packed VALU scan over the HI plane (scan16.hip: up to four queries per pass; the fp32 scan of such an index takes ONE), the
     // candidates and the guarded full pass go through the fp32 scan.  Up to four queries: beyond, the passes over the plane cost what the

@@ -892,11 +892,11 @@ void select_workspace_free(SelectWorkspace& ws) {
 int launch_topk_pivot(const float* scores, int32_t nq, int64_t n, int64_t ld, int32_t k, SelectWorkspace& ws, float* out_scores, int32_t* out_ids,
                       hipStream_t s) {
     if (nq <= 0 || k <= 0) return RL_OK;
-    if (k > 128 || nq > 240 || n >= (int64_t)0x7fffffff || n < 3 * (int64_t)k * 1024 / 4) return RL_ERR_UNSUPPORTED;
+    if (k > 512 || nq > 240 || n >= (int64_t)0x7fffffff || !pivot_route_takes(n, k)) return RL_ERR_UNSUPPORTED;  // (k <= 512 since the pivot takes G <= 2048 groups)
     const int block_route = ws.block_route;
     RL_TRY(select_workspace_reserve(ws, nq, s));
     ws.block_route = block_route;
-    // the selection's own buffers, idle on this route: group maxima in `sel` (512 of its 2048 words per query), the collected (id, score) lists in
+    // the selection's own buffers, idle on this route: group maxima in `sel` (up to all 2048 of its words per query), the collected (id, score) lists in
     // `cand` (4096 + 4096 four-byte words per query = its 4096 eight-byte ones)
     constexpr int32_t cap = CAND_CAP;
     uint64_t* bmax = ws.sel;

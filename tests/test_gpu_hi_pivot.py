@@ -177,7 +177,8 @@ def test_few_maxsim_queries_pivot_route_float_data_and_fallback():
 
 
 # ---- crowded scores: l2 (select.hip: launch_topk_pivot) ------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n,dim,B,k", [(300_000, 64, 1, 100), (120_000, 128, 3, 10), (400_000, 32, 4, 128), (90_000, 64, 2, 1)])
+@pytest.mark.parametrize("n,dim,B,k", [(300_000, 64, 1, 100), (120_000, 128, 3, 10), (400_000, 32, 4, 128), (90_000, 64, 2, 1), (500_000, 32, 2, 256),
+                                        (450_000, 64, 1, 512)])
 def test_l2_selection_over_crowded_scores_equals_the_radix_selection(n, dim, B, k):
     """`ORDER BY dist LIMIT k` with the l2 metric (`/root/reference/src/raglite/_typing.py:123-134`, `_config.py:69`): the similarities
     1 - |e - q| of a big corpus share their exponent and leading mantissa bits -- one bin of the radix selection holds them all and its exact slow

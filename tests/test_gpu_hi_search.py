@@ -244,6 +244,10 @@ def test_l2_hi_search_integer_near_duplicates_filter_and_what_the_route_declines
     with idx.options(hi_search=0):
         S2, R2 = idx.search_rows(Q, k, chunk_filter=ok)
     assert np.array_equal(R1, R2) and _same(S1, S2)
+    S1b, R1b = idx.search_rows(Q[:2], 100, chunk_filter=ok)  # (k > 64 under a mask: still enough group maxima at 80 000 rows)
+    with idx.options(hi_search=0):
+        S2b, R2b = idx.search_rows(Q[:2], 100, chunk_filter=ok)
+    assert np.array_equal(R1b, R2b) and _same(S1b, S2b)
     # too few group maxima for the pivot at this k (l2 similarities crowd into one bin of the radix selection: only the pivot selects them
     # fast), more than four queries: the full-precision route (same results, the route says so)
     S3, R3 = idx.search_rows(Q[0], 300)
