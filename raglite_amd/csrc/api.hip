@@ -1639,7 +1639,7 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     const int64_t nc = (int64_t)nb * cap, ldx = nc;
     // ---- scratch: approximate top-k scores (+ unused ids), thresholds, counters + flag, candidate rows, their norms, the
     // gathered rows, the exact score block and its diagonal -------------------------------------------------------------------------
-    const size_t words = (size_t)nb * k * 2 + 32 + 32 + (size_t)nc * 2 + (size_t)nc * dim + (size_t)nb * ldx + (size_t)nc + 2 + 2 * pivot_scratch_words(nb);
+    const size_t words = (size_t)nb * k * 2 + 32 + 32 + (size_t)nc * 2 + 4 + (size_t)nc * dim + (size_t)nb * ldx + (size_t)nc + 2 + 2 * pivot_scratch_words(nb);
     RL_TRY(idx->hibuf.reserve(words * 4));
     float* ts = idx->hibuf.as<float>();                        // [nb x k]
     int32_t* ti = reinterpret_cast<int32_t*>(ts + (size_t)nb * k);
@@ -1649,7 +1649,10 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     uint32_t* flag = cnt + 16;
     int32_t* ci = reinterpret_cast<int32_t*>(cnt + 32);        // [nb x cap]
     float* gn = reinterpret_cast<float*>(ci + nc);             // [nb x cap]
-    float* G = gn + nc;                                        // [nb * cap x dim]
+    // (16-byte aligned whatever the parity of nb * k: the kernels that score the gathered rows take 16-byte loads -- misaligned, the stream kernel
+    // DECLINED after the approximate pass had run, every search with an odd nb * k paying for both routes, and the scan fell back to scalar loads,
+    // whose other order of summation costs the last bit of parity with the full pass; found by scripts/soak_pivot.py with l2 in, round 6)
+    float* G = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(gn + nc) + 15) & ~uintptr_t(15));  // [nb * cap x dim]
     float* xs = G + (size_t)nc * dim;                          // [nb x nb * cap]
     float* es = xs + (size_t)nb * ldx;                         // [nb x cap]
     uint64_t* bmax = reinterpret_cast<uint64_t*>((reinterpret_cast<uintptr_t>(es + nc) + 7) & ~uintptr_t(7));  // [nb x 2048] group maxima (pivot route)
@@ -1722,7 +1725,10 @@ int search_rows_hi(rl_index* idx, const float* d_q, int32_t nb, int32_t k, float
     } else {
         st = launch_maxsim_stream_two(G, nc, dim, d_q, nb, idx->row_to_chunk, idx->offsets, idx->n_chunks, xs, ldx, idx->n_cu, s, idx->split_scale, full);
     }
-    if (st != RL_OK) return st;
+    if (st != RL_OK) {  // (a late decline: the route did not answer -- whoever does records itself)
+        idx->filt = {};
+        return st;
+    }
     if (nb > 1) RL_TRY(launch_diag_blocks(xs, ldx, cap, nc, es, s));  // (one query: the block IS its diagonal)
     MergeTransform tr;  // (the metric transform of the re-scored candidates happens on the way into the ranking: transform_kernel's statements)
     tr.row_norm = gn; tr.queries = d_q; tr.dim = dim; tr.mode = mode;

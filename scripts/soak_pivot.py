@@ -6,7 +6,7 @@
   random n <= 262 144, k 1..2048, normal / crowded / tied / constant / sorted / NaN-sprinkled scores, batches of 1..40 rows;
 * the single-query row search (`ORDER BY dist LIMIT k`, `/root/reference/src/raglite/_search.py:69-79`) with candidates from a pivot over
   workgroup maxima (hi_pivot = 1) against the ranked route (hi_pivot = 0) and the full-precision pass (hi_search = 0): random n up to 1.5 M rows,
-  dims 128..1024, B 1..16, k 1..128, cosine / dot, uniform and integer data (ties), thousands of copies of one row (the lists overflow: the guarded
+  dims 128..1024, B 1..16, k 1..512, cosine / dot / l2 (B <= 4), uniform and integer data (ties), thousands of copies of one row (the lists overflow: the guarded
   pass answers), quantised rows (massive ties at the k-th score);
 * one or two MaxSim queries (`_search.py:143-149,394-396` generalised) through the pivot route against the ranked route (same bits) and the rows
   route (hi_few = 0: the same chunks; the same bits on integer data).
@@ -63,12 +63,12 @@ def topk_case(rng):
 
 
 def rows_case(rng):
-    metric = "cosine" if rng.random() < 0.5 else "dot"
+    metric = str(rng.choice(["cosine", "dot", "l2"]))
     dim = int(rng.choice([128, 256, 512, 1024]))
-    k = int(rng.choice([1, 5, 32, 100, 128]))
-    lo = max((64 << 20) // dim + 1, 3 * k * 2048)
+    k = int(rng.choice([1, 5, 32, 100, 128, 160, 256, 400, 512]))  # (beyond 170: a maximum per wave of up to 512 workgroups, G <= 2048)
+    lo = max((64 << 20) // dim + 1, 3 * k * 2048 if k <= 128 else 3 * k * 256)
     n = int(rng.integers(lo, max(lo + 1, min(1_500_000, (3 << 30) // (4 * dim)))))
-    B = int(rng.integers(1, 17))
+    B = int(rng.integers(1, 5 if metric == "l2" else 17))
     kind = "small_int" if rng.random() < 0.4 else "uniform"
     E = torch.empty((n, dim), dtype=torch.float32, device="cuda")
     raglite_amd.synth_fill(E, seed=int(rng.integers(1, 1 << 30)), kind=kind)

@@ -282,3 +282,24 @@ def test_l2_hi_search_integer_near_duplicates_filter_and_what_the_route_declines
     assert np.array_equal(R, R0) and _same(S, S0) and np.isin(few, R).all()
     idx.close()
     idx2.close()
+
+
+@pytest.mark.parametrize("metric", ["cosine", "dot", "l2"])
+@pytest.mark.parametrize("B,k", [(1, 5), (3, 1), (1, 101), (3, 33), (2, 7)])
+def test_odd_and_even_scratch_layouts_same_bits_and_the_route_answers(metric, B, k):
+    """The gather buffer of the half-bytes search sits behind 2 nb k words of other scratch: with nb k odd it used to be 8-byte misaligned -- the
+    stream kernel then declined AFTER the approximate pass (the full route answered: right results, both routes paid), and the l2 scan fell back
+    to scalar loads (another order of summation: the last bit of parity with the full pass).  Found by scripts/soak_pivot.py (round 6)."""
+    n, dim = 300_000, 256
+    E = oracle.synth_matrix(9990, n, dim)
+    Q = oracle.synth_matrix(9991, B, dim)
+    idx = raglite_amd.DeviceIndex(E, metric=metric)
+    q = Q if B > 1 else Q[0]
+    S, R = idx.search_rows(q, k)
+    st = idx.filter_stats()
+    assert st["kind"] == "rows_hi" and not st["fallback"], st
+    with idx.options(hi_search=0):
+        S0, R0 = idx.search_rows(q, k)
+        assert idx.filter_stats()["kind"] != "rows_hi"
+    assert np.array_equal(R, R0) and _same(S, S0)
+    idx.close()
